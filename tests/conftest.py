@@ -1,0 +1,37 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_files(pattern="rollout_*.npz"):
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, pattern)))
+
+
+def load_golden(path):
+    z = np.load(path, allow_pickle=False)
+    meta = eval(str(z["meta"]))  # repr of a plain dict written by make_golden.py
+    ins = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    outs = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    return meta, ins, outs
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

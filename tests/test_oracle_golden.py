@@ -1,0 +1,97 @@
+"""
+Pins the CPU oracle (oracle/) against the golden vectors produced by the unmodified
+reference (tests/golden/make_golden.py).  CPU only.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden
+from oracle import losses as olosses
+from oracle import rollout as orollout
+
+FILES = golden_files()
+
+
+def _tiny_model(meta, ins):
+    w, b = torch.from_numpy(ins["w"]), torch.from_numpy(ins["b"])
+    w.requires_grad_(True), b.requires_grad_(True)
+    if meta["layout"] == "grid":
+        fn = lambda x: torch.tanh(torch.nn.functional.conv2d(x, w, b, padding=1))
+    else:
+        fn = lambda x: torch.tanh(x @ w + b)
+    return fn, w, b
+
+
+def _run_oracle(meta, ins):
+    t = {k: torch.from_numpy(v) for k, v in ins.items()}
+    B = t["inputs"].shape[0]
+    fn, w, b = _tiny_model(meta, ins)
+    border, statics = t["border_mask"], t["statics"]
+    inputs, forcing, outputs = t["inputs"], t["forcing"], t["outputs"]
+    if meta["layout"] == "graph":
+        border, statics = border.flatten(0, 1), statics.flatten(0, 1)
+        inputs, forcing, outputs = inputs.flatten(2, 3), forcing.flatten(2, 3), outputs.flatten(2, 3)
+    statics_b = statics.unsqueeze(0).expand(B, *statics.shape)
+    pred = orollout.rollout(
+        fn, inputs, forcing, outputs, statics_b, border, 1.0 - border,
+        t["diff_std"], t["diff_mean"], meta["strategy"], meta["K"], bool(meta["nan"]), "train",
+        features_second=(meta["layout"] == "grid"),
+    )
+    return pred, outputs, border, t, w, b
+
+
+def test_fixtures_present():
+    assert len(FILES) >= 10
+
+
+@pytest.mark.parametrize("path", FILES, ids=lambda p: p.split("/")[-1][:-4])
+def test_rollout_matches_reference(path):
+    meta, ins, outs = load_golden(path)
+    pred, *_ = _run_oracle(meta, ins)
+    ref = outs["prediction"]
+    got = pred.detach().numpy()
+    assert got.shape == ref.shape
+    # same torch ops in the same order on the same machine: bit-exact, NaNs in the same places
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(ref), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("path", [f for f in FILES if "grid" in f], ids=lambda p: p.split("/")[-1][:-4])
+def test_losses_match_reference(path):
+    meta, ins, outs = load_golden(path)
+    pred, outputs, border, t, w, b = _run_oracle(meta, ins)
+    interior = 1.0 - border
+    mask, tgt = orollout.get_mask_on_nan(outputs, bool(meta["nan"]))
+    np.testing.assert_array_equal(mask.numpy().astype(np.float32), outs["mask"])  # index/mask op: bit exact
+    for tag, kind, fn in [("wmse", "mse", "w"), ("wl1", "l1", "w"), ("smse", "mse", "s"), ("sl1", "l1", "s")]:
+        if fn == "w":
+            wts = olosses.weighted_loss_weights(t["state_weight"], t["diff_std"], kind)
+            val = olosses.weighted_loss(pred, tgt, mask, wts, interior, kind)
+            vmap = olosses.weighted_loss(pred, tgt, mask, wts, interior, kind, reduce_spatial_dim=False)
+            np.testing.assert_allclose(vmap.detach().numpy(), outs[f"loss_{tag}_map"], rtol=2e-6, atol=1e-7)
+        else:
+            val = olosses.scaled_loss(pred, tgt, mask, t["std"], interior, kind)
+        np.testing.assert_allclose(val.detach().numpy(), outs[f"loss_{tag}"], rtol=2e-6, atol=1e-7)
+    # training step scalar + BPTT gradient wrt the tiny model's parameters
+    wts = olosses.weighted_loss_weights(t["state_weight"], t["diff_std"], "mse")
+    loss = olosses.training_loss(
+        pred, outputs, bool(meta["nan"]), [("WeightedLoss", 1.0, dict(weights=wts, interior_mask=interior, kind="mse"))]
+    )
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().numpy(), outs["train_loss"], rtol=2e-6)
+    np.testing.assert_allclose(w.grad.numpy(), outs["grad_w"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(b.grad.numpy(), outs["grad_b"], rtol=1e-4, atol=1e-7)
+
+
+def test_diff_ar_requires_single_inter_step():
+    # lightning.py:688-692
+    with pytest.raises(ValueError):
+        orollout.strategy_params("diff_ar", 2)
+
+
+def test_combined_scaled_member_raises_like_reference():
+    # losses.py:304-306: (B,T) += (B,T,F) is a RuntimeError in the reference as well
+    p = torch.zeros(2, 3, 4, 4, 5)
+    with pytest.raises(RuntimeError):
+        olosses.combined_loss(p, p, torch.ones_like(p), [("ScaledLoss", 1.0, dict(std=torch.ones(5), interior_mask=torch.ones(4, 4, 1)))])
