@@ -1,0 +1,181 @@
+/*
+ * py4cast_hip.h -- C ABI of libpy4cast_hip.so: the MI355X (gfx950) implementation of
+ * the py4cast autoregressive training hot path.
+ *
+ * The reference (meteofrance/py4cast) is 100 % Python and has no FFI; each entry point
+ * below replaces a span of reference Python (cited as file:line, relative to the
+ * reference repository) that today runs as a chain of PyTorch kernels.  The library is
+ * bound with ctypes (see INTEGRATION.md for the stub a py4cast maintainer would add).
+ *
+ * Conventions
+ *  - plain C, no C++/torch types.  Device buffers are raw pointers owned by the caller
+ *    (the PyTorch caching allocator in practice), work-spaces included: the library
+ *    allocates nothing persistent and frees nothing.
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never
+ *    synchronises the device, so calls are hipGraph-capturable.
+ *  - returns 0 on success, a negative P4C_ERR_* otherwise; p4c_last_error() returns a
+ *    thread-local message.  Nothing throws or aborts across the boundary.
+ *  - tensors are dense row-major; "N" is the number of grid points (H*W for grid models,
+ *    ngrid for graph models: the rollout arithmetic is identical for both, the reference
+ *    flattens the spatial dims of graph batches at lightning.py:526-535).
+ *  - strides are in ELEMENTS.
+ */
+#ifndef PY4CAST_HIP_H
+#define PY4CAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P4C_VERSION 100 /* 0.1.0 */
+
+typedef void* p4c_stream_t; /* hipStream_t */
+
+enum p4c_error {
+    P4C_OK = 0,
+    P4C_ERR_INVALID = -1, /* bad argument (shape, dtype, alignment, null pointer) */
+    P4C_ERR_LAUNCH = -2,  /* kernel launch failed */
+    P4C_ERR_RUNTIME = -3, /* HIP runtime call failed */
+    P4C_ERR_UNSUPPORTED = -4
+};
+
+enum p4c_dtype { P4C_F32 = 0, P4C_BF16 = 1 };
+
+/* loss kind = torch.nn class named in the yaml `losses[].params.loss` (losses.py:25-31) */
+enum p4c_loss_kind { P4C_LOSS_MSE = 0, P4C_LOSS_L1 = 1 };
+
+/* how the per-element mask of losses.py:144/195 is provided */
+enum p4c_mask_mode {
+    P4C_MASK_NONE = 0,    /* mask == 1 everywhere (lightning.py:797, mask_on_nan=False) */
+    P4C_MASK_FROM_NAN = 1,/* mask = !isnan(target), target = nan_to_num(target) (lightning.py:792-796) fused */
+    P4C_MASK_F32 = 2,     /* explicit float mask tensor, same shape as target */
+    P4C_MASK_U8 = 3       /* explicit bool/uint8 mask tensor */
+};
+
+int p4c_version(void);
+const char* p4c_last_error(void);
+/* number of compute units of the current device (persistent-grid sizing, bench reporting) */
+int p4c_num_cus(void);
+
+/* ------------------------------------------------------------------------------------
+ * K1  build_x  -- replaces AutoRegressiveLightning._next_x (lightning.py:711-767) and the
+ * layout handling around the model call (lightning.py:586-596).
+ *
+ *   x[b,n,:] = [ prev[b,0,n,:F], ..., prev[b,T_in-1,n,:F], statics[b,n,:Fs], forcing[b,n,:Ff],
+ *                (mask_on_nan ? !any_nan(inputs,forcing)[b,n] : -) , 0-padding up to c_pad ]
+ *   with NaN -> 0 in inputs/forcing when mask_on_nan (lightning.py:732-757, bit-exact).
+ *   downscaling_only drops the prev block (lightning.py:759-762).
+ * prev: (B,T_in,N,F) with element strides prev_bs/prev_ts (inner (N,F) dense);
+ * statics: (B,N,Fs) with batch stride statics_bs (0 = broadcast one (N,Fs) map);
+ * forcing: time-selected (B,N,Ff) with batch stride forcing_bs.
+ * x: (B,N,c_pad) dense, dtype x_dtype; channels >= C_in are written as zeros.
+ */
+int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, const float* statics, int64_t statics_bs,
+                const float* forcing, int64_t forcing_bs, void* x, int x_dtype, int c_pad, int B, int T_in,
+                int64_t N, int F, int Fs, int Ff, int mask_on_nan, int downscaling_only, p4c_stream_t stream);
+
+/* Backward of K1 wrt prev: dprev[b,t,n,f] = dx[b,n,t*F+f]  (dprev dense (B,T_in,N,F)). */
+int p4c_build_x_bwd(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N, int F,
+                    p4c_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2  ar_update -- replaces lightning.py:599-633 (clone, scaled / plain residual update,
+ * border forcing) in ONE pass, evaluated in the reference's operation order with FMA
+ * contraction disabled so that fp32 results are bit-identical to the torch op chain:
+ *
+ *   p   = nan_to_num?(prev) * keep_prev + y * std + mean        (scaled_ar, std != NULL)
+ *   p   = nan_to_num?(prev) * keep_prev + y                     (diff_ar / downscaling)
+ *   new = border_mask * nan_to_num?(border_state) + interior_mask * p   (border_mask != NULL)
+ *
+ * prev/border_state/new_state: (B,N,F) with batch strides; y: (B,N,y_cs) dense where only the
+ * first F channels of each row are used (y_cs >= F lets the model emit padded rows);
+ * std/mean: (F); masks: (N) floats.  prev may be NULL when keep_prev == 0.
+ */
+int p4c_ar_update_fwd(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                      const float* border_state, int64_t border_bs, const float* std, const float* mean,
+                      const float* border_mask, const float* interior_mask, float* new_state, int64_t new_bs,
+                      int B, int64_t N, int F, float keep_prev, int nan_to_num, p4c_stream_t stream);
+
+/* Backward of K2: dpred = dnew * interior_mask (or dnew when no border forcing);
+ *   dy = dpred * std (or dpred); dprev = dpred * keep_prev.  dy: (B,N,y_cs), channels >= F zeroed.
+ * dprev may be NULL. */
+int p4c_ar_update_bwd(const float* dnew, int64_t dnew_bs, const float* std, const float* interior_mask, void* dy,
+                      int dy_dtype, int y_cs, float* dprev, int64_t dprev_bs, int B, int64_t N, int F,
+                      float keep_prev, p4c_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  losses -- replaces WeightedLoss.forward (losses.py:130-169) and
+ * ScaledLoss.forward (losses.py:186-210).
+ *
+ * prediction/target: (B,T,N,F) with strides (bs, ts), inner (N,F) dense.
+ * mask per p4c_mask_mode.  weights: (F).  interior_mask: (N) floats.
+ * denominators: losses.py:156,167 -- num_interior - #(grid points masked for every b,t,f).
+ */
+
+/* count of grid points n with mask[b,t,n,f]==0 for all (b,t,f)  -> *count (device int32).
+ * For P4C_MASK_FROM_NAN `mask_or_target` is the raw target. */
+int p4c_mask_all_zero_count(const void* mask_or_target, int mask_mode, int64_t bs, int64_t ts, int B, int T,
+                            int64_t N, int F, int32_t* count, p4c_stream_t stream);
+
+/* workspace size (bytes) needed by the reducing loss kernels below */
+size_t p4c_loss_workspace_bytes(int B, int T, int64_t N, int F);
+
+/* WeightedLoss, reduce_spatial_dim=True -> out (B,T):
+ *   out[b,t] = sum_n interior[n] * sum_f w[f]*l(pred*m, tgt*m) / (num_interior - *masked_count)
+ * masked_count may be NULL (=0). */
+int p4c_weighted_loss_fwd(const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target, int64_t tgt_bs,
+                          int64_t tgt_ts, const void* mask, int mask_mode, const float* weights,
+                          const float* interior_mask, float num_interior, const int32_t* masked_count, int kind,
+                          float* out, void* workspace, int B, int T, int64_t N, int F, p4c_stream_t stream);
+
+/* WeightedLoss, reduce_spatial_dim=False -> out_map (B,T,N) (losses.py:150-154; used by plots.py:606). */
+int p4c_weighted_loss_map(const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target, int64_t tgt_bs,
+                          int64_t tgt_ts, const void* mask, int mask_mode, const float* weights, int kind,
+                          float* out_map, int B, int T, int64_t N, int F, p4c_stream_t stream);
+
+/* Backward of p4c_weighted_loss_fwd wrt prediction: gout (B,T) -> dpred (B,T,N,F) with strides. */
+int p4c_weighted_loss_bwd(const float* gout, const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target,
+                          int64_t tgt_bs, int64_t tgt_ts, const void* mask, int mask_mode, const float* weights,
+                          const float* interior_mask, float num_interior, const int32_t* masked_count, int kind,
+                          float* dpred, int64_t dpred_bs, int64_t dpred_ts, int B, int T, int64_t N, int F,
+                          p4c_stream_t stream);
+
+/* ScaledLoss -> out (B,T,F): mean over interior points per feature, sqrt if MSE, times std[f]. */
+int p4c_scaled_loss_fwd(const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target, int64_t tgt_bs,
+                        int64_t tgt_ts, const void* mask, int mask_mode, const float* std,
+                        const float* interior_mask, float num_interior, const int32_t* masked_count, int kind,
+                        float* out, void* workspace, int B, int T, int64_t N, int F, p4c_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2+K3 fused (training path): one AR step's state update AND its contribution to the
+ * training loss in a single pass over (B,N,F) -- the target of step i is also the border
+ * state of step i (lightning.py:567 / 816), so it is read once.
+ *   new_state as in p4c_ar_update_fwd (border_state == target);
+ *   loss_out[b] = sum_n interior[n] * sum_f w[f]*l(new*m, tgt*m) / denom     (one (b,t) column)
+ * loss_out: (B) with element stride loss_stride (so that it can alias out[:, t] of a (B,T) tensor).
+ */
+int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                           const float* target, int64_t tgt_bs, const float* std, const float* mean,
+                           const float* border_mask, const float* interior_mask, float* new_state, int64_t new_bs,
+                           const float* weights, float num_interior, const int32_t* masked_count, int kind,
+                           int mask_mode, float* loss_out, int64_t loss_stride, void* workspace, int B, int64_t N,
+                           int F, float keep_prev, p4c_stream_t stream);
+
+/* Backward of the fused step.  g_next: gradient wrt new_state arriving from the later AR step
+ * (may be NULL for the last step; g_next2 is an optional second addend with channel stride g2_cs,
+ * e.g. the first F channels of the model's dx); gloss: (B) with stride, the upstream gradient of
+ * loss_out.  Writes dy (B,N,y_cs) and dprev (B,N,F) (dprev may be NULL). */
+int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g_next2, int g2_dtype, int g2_cs,
+                           const float* gloss, int64_t gloss_stride, const float* new_state, int64_t new_bs,
+                           const float* target, int64_t tgt_bs, const float* std, const float* interior_mask,
+                           int force_border, const float* weights, float num_interior, const int32_t* masked_count,
+                           int kind, int mask_mode, void* dy, int dy_dtype, int y_cs, float* dprev, int64_t dprev_bs,
+                           int B, int64_t N, int F, float keep_prev, p4c_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PY4CAST_HIP_H */

@@ -1,0 +1,123 @@
+"""
+ctypes binding of ``libpy4cast_hip.so`` (C ABI: ``include/py4cast_hip.h``).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol is
+absent, import-time / call-time errors are raised.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C py4cast_amd/csrc``.
+"""
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpy4cast_hip.so")
+
+F32, BF16 = 0, 1
+LOSS_MSE, LOSS_L1 = 0, 1
+MASK_NONE, MASK_FROM_NAN, MASK_F32, MASK_U8 = 0, 1, 2, 3
+
+P = c_void_p
+I = c_int
+L = c_int64
+F = c_float
+
+# name -> argtypes (restype is int unless noted).  Mirrors include/py4cast_hip.h one to one.
+SIGNATURES = {
+    "p4c_build_x": [P, L, L, P, L, P, L, P, I, I, I, I, L, I, I, I, I, I, P],
+    "p4c_build_x_bwd": [P, I, I, P, I, I, L, I, P],
+    "p4c_ar_update_fwd": [P, L, P, I, I, P, L, P, P, P, P, P, L, I, L, I, F, I, P],
+    "p4c_ar_update_bwd": [P, L, P, P, P, I, I, P, L, I, L, I, F, P],
+    "p4c_mask_all_zero_count": [P, I, L, L, I, I, L, I, P, P],
+    "p4c_weighted_loss_fwd": [P, L, L, P, L, L, P, I, P, P, F, P, I, P, P, I, I, L, I, P],
+    "p4c_weighted_loss_map": [P, L, L, P, L, L, P, I, P, I, P, I, I, L, I, P],
+    "p4c_weighted_loss_bwd": [P, P, L, L, P, L, L, P, I, P, P, F, P, I, P, L, L, I, I, L, I, P],
+    "p4c_scaled_loss_fwd": [P, L, L, P, L, L, P, I, P, P, F, P, I, P, P, I, I, L, I, P],
+    "p4c_ar_update_loss_fwd": [P, L, P, I, I, P, L, P, P, P, P, P, L, P, F, P, I, I, P, L, P, I, L, I, F, P],
+    "p4c_ar_update_loss_bwd": [P, L, P, I, I, P, L, P, L, P, L, P, P, I, P, F, P, I, I, P, I, I, P, L, I, L, I, F, P],
+}
+OTHER = {
+    "p4c_version": ([], c_int),
+    "p4c_last_error": ([], c_char_p),
+    "p4c_num_cus": ([], c_int),
+    "p4c_loss_workspace_bytes": ([I, I, L, I], c_size_t),
+}
+
+_lib = None
+
+
+class P4CError(RuntimeError):
+    pass
+
+
+def _declare(lib, signatures, other):
+    for name, argtypes in signatures.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    for name, (argtypes, restype) in other.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+
+
+def all_symbols():
+    from . import _lib_model  # model-side signatures live next to their wrappers
+
+    names = list(SIGNATURES) + list(OTHER) + list(_lib_model.SIGNATURES) + list(_lib_model.OTHER)
+    return names
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the extension was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise P4CError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        _declare(handle, SIGNATURES, OTHER)
+        from . import _lib_model
+
+        _declare(handle, _lib_model.SIGNATURES, _lib_model.OTHER)
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().p4c_last_error()
+        raise P4CError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise P4CError(f"unsupported dtype {dt}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise P4CError(
+                "py4cast_amd kernels run on the GPU only (no CPU fallback); got a tensor on " + str(t.device)
+            )

@@ -1,0 +1,81 @@
+// Shared host/device helpers for the py4cast MI355X (gfx950) kernels.
+// Every exported entry point is declared in include/py4cast_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/py4cast_hip.h"
+
+namespace p4c {
+
+// ---------------------------------------------------------------- errors
+// Thread-local message; entry points return 0 or a negative code and never throw/abort.
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define P4C_CHECK_ARG(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) return ::p4c::fail(P4C_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define P4C_CHECK_LAUNCH(name)                                                               \
+    do {                                                                                     \
+        hipError_t e__ = hipGetLastError();                                                  \
+        if (e__ != hipSuccess)                                                               \
+            return ::p4c::fail(P4C_ERR_LAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+#define P4C_CHECK_HIP(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return ::p4c::fail(P4C_ERR_RUNTIME, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline hipStream_t as_stream(p4c_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Number of CUs of the current device (cached).  Used to size persistent grids.
+int num_cus();
+
+// ---------------------------------------------------------------- device helpers
+typedef __hip_bfloat16 bf16;
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<bf16>(bf16 v) { return __bfloat162float(v); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16 from_f32<bf16>(float v) { return __float2bfloat16(v); }
+
+// 64-lane wave all-reduce (sum) through DPP/shuffles.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over groups of `width` consecutive lanes (width = power of two <= 64).
+__device__ __forceinline__ float seg_sum(float v, int width) {
+    for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over lanes that share (lane % width): i.e. across the 64/width segments.
+__device__ __forceinline__ float cross_seg_sum(float v, int width) {
+    for (int off = 32; off >= width; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float nan_to_zero(float v) { return (v != v) ? 0.0f : v; }
+
+}  // namespace p4c

@@ -1,0 +1,586 @@
+// K3 losses: WeightedLoss / ScaledLoss (py4cast/losses.py:103-210) and the fused
+// "AR update + loss" training-path kernels (lightning.py:599-633 + 811-816 + losses.py:130-169).
+//
+// HBM-bound: every kernel streams (B,T,N,F) rows once.  Lanes of a wave are spread over the
+// features of one (or several) grid points, so per-feature weights live in registers, the
+// per-grid-point interior mask is one load per segment, and ScaledLoss's per-feature sums are
+// lane-local.  Reductions are two-stage and deterministic (block partials in a caller-provided
+// workspace + a tiny finalize kernel); no float atomics.
+//
+// Compiled with -ffp-contract=off (see rollout.hip).
+#include "common.hpp"
+
+namespace p4c {
+
+__host__ __device__ static inline int pow2_ge64(int v) {
+    int p = 1;
+    while (p < v && p < 64) p <<= 1;
+    return p;
+}
+
+constexpr int LOSS_MAX_ITERS = 4;     // F <= 256
+constexpr int LOSS_MAX_BLOCKS = 512;  // partial blocks per (b,t)
+
+struct MaskArg {
+    const void* ptr;
+    int mode;
+};
+
+// returns mask value m and rewrites tgt (nan_to_num) for P4C_MASK_FROM_NAN
+__device__ __forceinline__ float load_mask(const MaskArg& ma, int64_t idx, float& tgt) {
+    switch (ma.mode) {
+        case P4C_MASK_FROM_NAN: {
+            const bool isn = tgt != tgt;
+            if (isn) tgt = 0.0f;
+            return isn ? 0.0f : 1.0f;
+        }
+        case P4C_MASK_F32: return ((const float*)ma.ptr)[idx];
+        case P4C_MASK_U8: return ((const unsigned char*)ma.ptr)[idx] ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+
+__device__ __forceinline__ float loss_elem(float pred, float tgt, float m, int kind) {
+    const float pm = pred * m, tm = tgt * m;  // losses.py:144 / 195
+    const float d = pm - tm;
+    return kind == P4C_LOSS_MSE ? d * d : fabsf(d);
+}
+
+// d loss_elem / d pred
+__device__ __forceinline__ float loss_elem_grad(float pred, float tgt, float m, int kind) {
+    const float d = pred * m - tgt * m;
+    if (kind == P4C_LOSS_MSE) return 2.0f * d * m;
+    return (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f)) * m;  // torch L1Loss backward: sign(d)
+}
+
+// ------------------------------------------------------------------ mask union count
+__global__ void __launch_bounds__(256)
+    mask_all_zero_count_kernel(MaskArg ma, int64_t bs, int64_t ts, int B, int T, int64_t N, int F, int FP, int iters,
+                               int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const unsigned long long segmask = (FP == 64) ? ~0ull : (((1ull << FP) - 1ull) << (pp * FP));
+    int local = 0;
+    for (int64_t base = (int64_t)wave * PP; base < N; base += (int64_t)nwaves * PP) {
+        const int64_t n = base + pp;
+        const bool live = n < N;
+        bool any_set = false;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t)
+                for (int it = 0; it < iters; ++it) {
+                    const int f = c0 + it * FP;
+                    bool set = false;
+                    if (live && f < F) {
+                        const int64_t idx = (int64_t)b * bs + (int64_t)t * ts + n * F + f;
+                        float tg = (ma.mode == P4C_MASK_FROM_NAN) ? ((const float*)ma.ptr)[idx] : 0.0f;
+                        set = load_mask(ma, idx, tg) != 0.0f;
+                    }
+                    const unsigned long long bal = __ballot(set);
+                    any_set = any_set || ((bal & segmask) != 0ull);
+                }
+        if (live && c0 == 0 && !any_set) local += 1;
+    }
+    // integer atomics: order independent, exact
+    const int tot = (int)wave_sum((float)local);  // local <= a few thousand: exact in fp32
+    if (lane == 0 && tot) atomicAdd(count, tot);
+}
+
+// ------------------------------------------------------------------ weighted loss, reduced
+// grid: (nblk, B*T).  partial[bt*nblk + blk]
+__global__ void __launch_bounds__(256)
+    weighted_loss_partial_kernel(const float* __restrict__ pred, int64_t pred_bs, int64_t pred_ts,
+                                 const float* __restrict__ target, int64_t tgt_bs, int64_t tgt_ts, MaskArg ma,
+                                 int64_t mask_bs, int64_t mask_ts, const float* __restrict__ weights,
+                                 const float* __restrict__ interior, int kind, float* __restrict__ partial, int T,
+                                 int64_t N, int F, int FP, int iters) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bt = blockIdx.y, b = bt / T, t = bt - b * T;
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const float* p = pred + (int64_t)b * pred_bs + (int64_t)t * pred_ts;
+    const float* g = target + (int64_t)b * tgt_bs + (int64_t)t * tgt_ts;
+    const int64_t mbase = (int64_t)b * mask_bs + (int64_t)t * mask_ts;
+    float w[LOSS_MAX_ITERS];
+#pragma unroll
+    for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+        const int f = c0 + it * FP;
+        w[it] = (it < iters && f < F) ? weights[f] : 0.0f;
+    }
+    float acc = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        const float im = interior[n];
+        float s = 0.0f;
+#pragma unroll
+        for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+            const int f = c0 + it * FP;
+            if (it < iters && f < F) {
+                const int64_t e = n * F + f;
+                float tg = g[e];
+                const float m = load_mask(ma, mbase + e, tg);
+                s += loss_elem(p[e], tg, m, kind) * w[it];
+            }
+        }
+        acc += s * im;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)bt * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[bt*out_stride] = sum(partials) / (num_interior - masked)
+__global__ void weighted_loss_final_kernel(const float* __restrict__ partial, int nblk, float num_interior,
+                                           const int32_t* __restrict__ masked_count, float* __restrict__ out,
+                                           int64_t out_stride, int nbt) {
+    const int bt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bt >= nbt) return;
+    float s = 0.0f;
+    for (int i = 0; i < nblk; ++i) s += partial[(int64_t)bt * nblk + i];
+    const float denom = num_interior - (masked_count ? (float)(*masked_count) : 0.0f);
+    out[(int64_t)bt * out_stride] = s / denom;
+}
+
+// ------------------------------------------------------------------ weighted loss map (no spatial reduce)
+__global__ void __launch_bounds__(256)
+    weighted_loss_map_kernel(const float* __restrict__ pred, int64_t pred_bs, int64_t pred_ts,
+                             const float* __restrict__ target, int64_t tgt_bs, int64_t tgt_ts, MaskArg ma,
+                             int64_t mask_bs, int64_t mask_ts, const float* __restrict__ weights, int kind,
+                             float* __restrict__ out_map, int T, int64_t N, int F, int FP, int iters) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bt = blockIdx.y, b = bt / T, t = bt - b * T;
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const float* p = pred + (int64_t)b * pred_bs + (int64_t)t * pred_ts;
+    const float* g = target + (int64_t)b * tgt_bs + (int64_t)t * tgt_ts;
+    const int64_t mbase = (int64_t)b * mask_bs + (int64_t)t * mask_ts;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    // every lane of a wave runs the same number of iterations (shuffles need all lanes)
+    for (int64_t nb = ((int64_t)blockIdx.x * 4 + wv) * PP; nb < N; nb += stride) {
+        const int64_t n = nb + pp;
+        float s = 0.0f;
+        if (n < N) {
+            for (int it = 0; it < iters; ++it) {
+                const int f = c0 + it * FP;
+                if (f < F) {
+                    const int64_t e = n * F + f;
+                    float tg = g[e];
+                    const float m = load_mask(ma, mbase + e, tg);
+                    s += loss_elem(p[e], tg, m, kind) * weights[f];
+                }
+            }
+        }
+        s = seg_sum(s, FP);
+        if (n < N && c0 == 0) out_map[(int64_t)bt * N + n] = s;
+    }
+}
+
+// ------------------------------------------------------------------ weighted loss backward
+__global__ void __launch_bounds__(256)
+    weighted_loss_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pred, int64_t pred_bs,
+                             int64_t pred_ts, const float* __restrict__ target, int64_t tgt_bs, int64_t tgt_ts,
+                             MaskArg ma, int64_t mask_bs, int64_t mask_ts, const float* __restrict__ weights,
+                             const float* __restrict__ interior, float num_interior,
+                             const int32_t* __restrict__ masked_count, int kind, float* __restrict__ dpred,
+                             int64_t dpred_bs, int64_t dpred_ts, int T, int64_t N, int F, int FP, int iters) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bt = blockIdx.y, b = bt / T, t = bt - b * T;
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const float* p = pred + (int64_t)b * pred_bs + (int64_t)t * pred_ts;
+    const float* g = target + (int64_t)b * tgt_bs + (int64_t)t * tgt_ts;
+    float* dp = dpred + (int64_t)b * dpred_bs + (int64_t)t * dpred_ts;
+    const int64_t mbase = (int64_t)b * mask_bs + (int64_t)t * mask_ts;
+    const float denom = num_interior - (masked_count ? (float)(*masked_count) : 0.0f);
+    const float scale = gout[bt] / denom;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        const float sc = scale * interior[n];
+        for (int it = 0; it < iters; ++it) {
+            const int f = c0 + it * FP;
+            if (f < F) {
+                const int64_t e = n * F + f;
+                float tg = g[e];
+                const float m = load_mask(ma, mbase + e, tg);
+                dp[e] = sc * weights[f] * loss_elem_grad(p[e], tg, m, kind);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ scaled loss
+// partial[(bt*nblk + blk)*F + f]
+__global__ void __launch_bounds__(256)
+    scaled_loss_partial_kernel(const float* __restrict__ pred, int64_t pred_bs, int64_t pred_ts,
+                               const float* __restrict__ target, int64_t tgt_bs, int64_t tgt_ts, MaskArg ma,
+                               int64_t mask_bs, int64_t mask_ts, const float* __restrict__ interior, int kind,
+                               float* __restrict__ partial, int T, int64_t N, int F, int FP, int iters) {
+    __shared__ float red[4][64 * LOSS_MAX_ITERS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bt = blockIdx.y, b = bt / T, t = bt - b * T;
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const float* p = pred + (int64_t)b * pred_bs + (int64_t)t * pred_ts;
+    const float* g = target + (int64_t)b * tgt_bs + (int64_t)t * tgt_ts;
+    const int64_t mbase = (int64_t)b * mask_bs + (int64_t)t * mask_ts;
+    float acc[LOSS_MAX_ITERS];
+#pragma unroll
+    for (int it = 0; it < LOSS_MAX_ITERS; ++it) acc[it] = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        const float im = interior[n];
+#pragma unroll
+        for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+            const int f = c0 + it * FP;
+            if (it < iters && f < F) {
+                const int64_t e = n * F + f;
+                float tg = g[e];
+                const float m = load_mask(ma, mbase + e, tg);
+                acc[it] += loss_elem(p[e], tg, m, kind) * im;  // losses.py:200-201
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+        const float v = cross_seg_sum(acc[it], FP);
+        if (pp == 0) red[wv][it * 64 + c0] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < iters * FP; i += blockDim.x) {
+        const int it = i / FP, c = i - it * FP;
+        const int f = c + it * FP;
+        if (f < F) {
+            const int k = it * 64 + c;
+            partial[((int64_t)bt * gridDim.x + blockIdx.x) * F + f] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        }
+    }
+}
+
+__global__ void scaled_loss_final_kernel(const float* __restrict__ partial, int nblk, float num_interior,
+                                         const int32_t* __restrict__ masked_count, const float* __restrict__ std,
+                                         int kind, float* __restrict__ out, int nbt, int F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbt * F) return;
+    const int bt = i / F, f = i - bt * F;
+    float s = 0.0f;
+    for (int k = 0; k < nblk; ++k) s += partial[((int64_t)bt * nblk + k) * F + f];
+    const float denom = num_interior - (masked_count ? (float)(*masked_count) : 0.0f);
+    float v = s / denom;
+    if (kind == P4C_LOSS_MSE) v = sqrtf(v);  // losses.py:205-206
+    out[i] = v * std[f];                     // losses.py:208-210
+}
+
+// ------------------------------------------------------------------ fused AR update + loss (training path)
+// grid: (nblk, B).  One (b, t=i) column of the loss.
+template <typename TY>
+__global__ void __launch_bounds__(256)
+    ar_update_loss_fwd_kernel(const float* __restrict__ prev, int64_t prev_bs, const TY* __restrict__ y, int y_cs,
+                              const float* __restrict__ target, int64_t tgt_bs, const float* __restrict__ std,
+                              const float* __restrict__ mean, const float* __restrict__ border_mask,
+                              const float* __restrict__ interior_mask, float* __restrict__ new_state, int64_t new_bs,
+                              const float* __restrict__ weights, int kind, int mask_mode, float* __restrict__ partial,
+                              int64_t N, int F, float keep_prev, int FP, int iters) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const bool from_nan = mask_mode == P4C_MASK_FROM_NAN;
+    float w[LOSS_MAX_ITERS], sd[LOSS_MAX_ITERS], mn[LOSS_MAX_ITERS];
+#pragma unroll
+    for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+        const int f = c0 + it * FP;
+        const bool ok = it < iters && f < F;
+        w[it] = ok ? weights[f] : 0.0f;
+        sd[it] = (ok && std) ? std[f] : 1.0f;
+        mn[it] = (ok && mean) ? mean[f] : 0.0f;
+    }
+    float acc = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        const float im = interior_mask[n];
+        const float bm = border_mask ? border_mask[n] : 0.0f;
+        float s = 0.0f;
+#pragma unroll
+        for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+            const int f = c0 + it * FP;
+            if (it < iters && f < F) {
+                const int64_t e = n * F + f;
+                const float yv = to_f32<TY>(y[((int64_t)b * N + n) * y_cs + f]);
+                float pv = 0.0f;
+                if (prev) {
+                    pv = prev[(int64_t)b * prev_bs + e];
+                    if (from_nan) pv = nan_to_zero(pv);
+                }
+                float tg = target[(int64_t)b * tgt_bs + e];
+                float m = 1.0f;
+                if (from_nan) {
+                    m = (tg != tg) ? 0.0f : 1.0f;
+                    tg = nan_to_zero(tg);
+                }
+                float pr;
+                if (std) {
+                    pr = pv * keep_prev + yv * sd[it];
+                    pr = pr + mn[it];
+                } else {
+                    pr = pv * keep_prev + yv;
+                }
+                if (border_mask) pr = bm * tg + im * pr;
+                new_state[(int64_t)b * new_bs + e] = pr;
+                s += loss_elem(pr, tg, m, kind) * w[it];
+            }
+        }
+        acc += s * im;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <typename TY, typename TG>
+__global__ void __launch_bounds__(256)
+    ar_update_loss_bwd_kernel(const float* __restrict__ g_next, int64_t g_next_bs, const TG* __restrict__ g_next2,
+                              int g2_cs, const float* __restrict__ gloss, int64_t gloss_stride,
+                              const float* __restrict__ new_state, int64_t new_bs, const float* __restrict__ target,
+                              int64_t tgt_bs, const float* __restrict__ std, const float* __restrict__ interior_mask,
+                              int force_border, const float* __restrict__ weights, float num_interior,
+                              const int32_t* __restrict__ masked_count, int kind, int mask_mode, TY* __restrict__ dy,
+                              int y_cs, float* __restrict__ dprev, int64_t dprev_bs, int64_t N, int F, float keep_prev,
+                              int FP, int iters) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const bool from_nan = mask_mode == P4C_MASK_FROM_NAN;
+    const float denom = num_interior - (masked_count ? (float)(*masked_count) : 0.0f);
+    const float scale = gloss ? gloss[(int64_t)b * gloss_stride] / denom : 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        const float im = interior_mask[n];
+        const float sc = scale * im;
+        const float blend = force_border ? im : 1.0f;
+        for (int it = 0; it < iters; ++it) {
+            const int f = c0 + it * FP;
+            if (f >= y_cs) continue;
+            float gy = 0.0f;
+            if (f < F) {
+                const int64_t e = n * F + f;
+                float tg = target[(int64_t)b * tgt_bs + e];
+                float m = 1.0f;
+                if (from_nan) {
+                    m = (tg != tg) ? 0.0f : 1.0f;
+                    tg = nan_to_zero(tg);
+                }
+                float g = sc * weights[f] * loss_elem_grad(new_state[(int64_t)b * new_bs + e], tg, m, kind);
+                if (g_next) g += g_next[(int64_t)b * g_next_bs + e];
+                if (g_next2) g += to_f32<TG>(g_next2[((int64_t)b * N + n) * g2_cs + f]);
+                const float gp = g * blend;
+                gy = std ? gp * std[f] : gp;
+                if (dprev) dprev[(int64_t)b * dprev_bs + e] = gp * keep_prev;
+            }
+            dy[((int64_t)b * N + n) * y_cs + f] = from_f32<TY>(gy);
+        }
+    }
+}
+
+static inline int loss_blocks(int64_t N, int PP, int nbt) {
+    int64_t waves = (N + PP - 1) / PP;
+    int64_t blocks = (waves + 3) / 4;
+    // a few grid points per lane at least, bounded by the workspace contract and by ~8 blocks/CU overall
+    int64_t cap = ((int64_t)num_cus() * 8 + nbt - 1) / nbt;
+    if (cap < 1) cap = 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks > LOSS_MAX_BLOCKS) blocks = LOSS_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+static inline bool mask_strides(int mask_mode, const void* mask, int64_t tgt_bs, int64_t tgt_ts, int T, int64_t N, int F,
+                                int64_t& mbs, int64_t& mts) {
+    // explicit masks are dense (B,T,N,F); FROM_NAN reads the target itself
+    mts = N * F;
+    mbs = (int64_t)T * N * F;
+    if (mask_mode == P4C_MASK_F32 || mask_mode == P4C_MASK_U8) return mask != nullptr;
+    return true;
+}
+
+}  // namespace p4c
+
+using namespace p4c;
+
+extern "C" size_t p4c_loss_workspace_bytes(int B, int T, int64_t N, int F) {
+    (void)N;
+    return (size_t)B * (size_t)T * LOSS_MAX_BLOCKS * (size_t)(F > 1 ? F : 1) * sizeof(float);
+}
+
+extern "C" int p4c_mask_all_zero_count(const void* mask_or_target, int mask_mode, int64_t bs, int64_t ts, int B, int T,
+                                       int64_t N, int F, int32_t* count, p4c_stream_t stream) {
+    P4C_CHECK_ARG(count, "p4c_mask_all_zero_count: null count");
+    P4C_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), as_stream(stream)));
+    if (mask_mode == P4C_MASK_NONE) return P4C_OK;
+    P4C_CHECK_ARG(mask_or_target, "p4c_mask_all_zero_count: null mask");
+    P4C_CHECK_ARG(F <= 64 * LOSS_MAX_ITERS, "p4c_mask_all_zero_count: F too large");
+    const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
+    MaskArg ma{mask_or_target, mask_mode};
+    int64_t waves = (N + (64 / FP) - 1) / (64 / FP);
+    int blocks = (int)((waves + 3) / 4);
+    if (blocks > num_cus() * 8) blocks = num_cus() * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mask_all_zero_count_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), ma, bs, ts, B, T, N, F,
+                       FP, iters, count);
+    P4C_CHECK_LAUNCH("p4c_mask_all_zero_count");
+    return P4C_OK;
+}
+
+extern "C" int p4c_weighted_loss_fwd(const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target,
+                                     int64_t tgt_bs, int64_t tgt_ts, const void* mask, int mask_mode,
+                                     const float* weights, const float* interior_mask, float num_interior,
+                                     const int32_t* masked_count, int kind, float* out, void* workspace, int B, int T,
+                                     int64_t N, int F, p4c_stream_t stream) {
+    P4C_CHECK_ARG(pred && target && weights && interior_mask && out && workspace, "p4c_weighted_loss_fwd: null pointer");
+    P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS, "p4c_weighted_loss_fwd: F=%d unsupported", F);
+    P4C_CHECK_ARG(kind == P4C_LOSS_MSE || kind == P4C_LOSS_L1, "p4c_weighted_loss_fwd: bad loss kind");
+    int64_t mbs, mts;
+    P4C_CHECK_ARG(mask_strides(mask_mode, mask, tgt_bs, tgt_ts, T, N, F, mbs, mts), "p4c_weighted_loss_fwd: null mask");
+    const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
+    const int nblk = loss_blocks(N, 64 / FP, B * T);
+    MaskArg ma{mask, mask_mode};
+    hipLaunchKernelGGL(weighted_loss_partial_kernel, dim3(nblk, B * T), dim3(256), 0, as_stream(stream), pred, pred_bs,
+                       pred_ts, target, tgt_bs, tgt_ts, ma, mbs, mts, weights, interior_mask, kind, (float*)workspace, T,
+                       N, F, FP, iters);
+    P4C_CHECK_LAUNCH("p4c_weighted_loss_fwd(partial)");
+    hipLaunchKernelGGL(weighted_loss_final_kernel, dim3((B * T + 63) / 64), dim3(64), 0, as_stream(stream),
+                       (const float*)workspace, nblk, num_interior, masked_count, out, (int64_t)1, B * T);
+    P4C_CHECK_LAUNCH("p4c_weighted_loss_fwd(final)");
+    return P4C_OK;
+}
+
+extern "C" int p4c_weighted_loss_map(const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target,
+                                     int64_t tgt_bs, int64_t tgt_ts, const void* mask, int mask_mode,
+                                     const float* weights, int kind, float* out_map, int B, int T, int64_t N, int F,
+                                     p4c_stream_t stream) {
+    P4C_CHECK_ARG(pred && target && weights && out_map, "p4c_weighted_loss_map: null pointer");
+    P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS, "p4c_weighted_loss_map: F=%d unsupported", F);
+    int64_t mbs, mts;
+    P4C_CHECK_ARG(mask_strides(mask_mode, mask, tgt_bs, tgt_ts, T, N, F, mbs, mts), "p4c_weighted_loss_map: null mask");
+    const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
+    const int nblk = loss_blocks(N, 64 / FP, B * T);
+    MaskArg ma{mask, mask_mode};
+    hipLaunchKernelGGL(weighted_loss_map_kernel, dim3(nblk, B * T), dim3(256), 0, as_stream(stream), pred, pred_bs,
+                       pred_ts, target, tgt_bs, tgt_ts, ma, mbs, mts, weights, kind, out_map, T, N, F, FP, iters);
+    P4C_CHECK_LAUNCH("p4c_weighted_loss_map");
+    return P4C_OK;
+}
+
+extern "C" int p4c_weighted_loss_bwd(const float* gout, const float* pred, int64_t pred_bs, int64_t pred_ts,
+                                     const float* target, int64_t tgt_bs, int64_t tgt_ts, const void* mask,
+                                     int mask_mode, const float* weights, const float* interior_mask,
+                                     float num_interior, const int32_t* masked_count, int kind, float* dpred,
+                                     int64_t dpred_bs, int64_t dpred_ts, int B, int T, int64_t N, int F,
+                                     p4c_stream_t stream) {
+    P4C_CHECK_ARG(gout && pred && target && weights && interior_mask && dpred, "p4c_weighted_loss_bwd: null pointer");
+    P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS, "p4c_weighted_loss_bwd: F=%d unsupported", F);
+    int64_t mbs, mts;
+    P4C_CHECK_ARG(mask_strides(mask_mode, mask, tgt_bs, tgt_ts, T, N, F, mbs, mts), "p4c_weighted_loss_bwd: null mask");
+    const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
+    const int nblk = loss_blocks(N, 64 / FP, B * T);
+    MaskArg ma{mask, mask_mode};
+    hipLaunchKernelGGL(weighted_loss_bwd_kernel, dim3(nblk, B * T), dim3(256), 0, as_stream(stream), gout, pred, pred_bs,
+                       pred_ts, target, tgt_bs, tgt_ts, ma, mbs, mts, weights, interior_mask, num_interior, masked_count,
+                       kind, dpred, dpred_bs, dpred_ts, T, N, F, FP, iters);
+    P4C_CHECK_LAUNCH("p4c_weighted_loss_bwd");
+    return P4C_OK;
+}
+
+extern "C" int p4c_scaled_loss_fwd(const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target,
+                                   int64_t tgt_bs, int64_t tgt_ts, const void* mask, int mask_mode, const float* std,
+                                   const float* interior_mask, float num_interior, const int32_t* masked_count,
+                                   int kind, float* out, void* workspace, int B, int T, int64_t N, int F,
+                                   p4c_stream_t stream) {
+    P4C_CHECK_ARG(pred && target && std && interior_mask && out && workspace, "p4c_scaled_loss_fwd: null pointer");
+    P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS, "p4c_scaled_loss_fwd: F=%d unsupported", F);
+    int64_t mbs, mts;
+    P4C_CHECK_ARG(mask_strides(mask_mode, mask, tgt_bs, tgt_ts, T, N, F, mbs, mts), "p4c_scaled_loss_fwd: null mask");
+    const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
+    const int nblk = loss_blocks(N, 64 / FP, B * T);
+    MaskArg ma{mask, mask_mode};
+    hipLaunchKernelGGL(scaled_loss_partial_kernel, dim3(nblk, B * T), dim3(256), 0, as_stream(stream), pred, pred_bs,
+                       pred_ts, target, tgt_bs, tgt_ts, ma, mbs, mts, interior_mask, kind, (float*)workspace, T, N, F, FP,
+                       iters);
+    P4C_CHECK_LAUNCH("p4c_scaled_loss_fwd(partial)");
+    const int tot = B * T * F;
+    hipLaunchKernelGGL(scaled_loss_final_kernel, dim3((tot + 127) / 128), dim3(128), 0, as_stream(stream),
+                       (const float*)workspace, nblk, num_interior, masked_count, std, kind, out, B * T, F);
+    P4C_CHECK_LAUNCH("p4c_scaled_loss_fwd(final)");
+    return P4C_OK;
+}
+
+extern "C" int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                                      const float* target, int64_t tgt_bs, const float* std, const float* mean,
+                                      const float* border_mask, const float* interior_mask, float* new_state,
+                                      int64_t new_bs, const float* weights, float num_interior,
+                                      const int32_t* masked_count, int kind, int mask_mode, float* loss_out,
+                                      int64_t loss_stride, void* workspace, int B, int64_t N, int F, float keep_prev,
+                                      p4c_stream_t stream) {
+    P4C_CHECK_ARG(y && target && interior_mask && new_state && weights && loss_out && workspace,
+                  "p4c_ar_update_loss_fwd: null pointer");
+    P4C_CHECK_ARG(prev || keep_prev == 0.0f, "p4c_ar_update_loss_fwd: prev is null but keep_prev != 0");
+    P4C_CHECK_ARG((std == nullptr) == (mean == nullptr), "p4c_ar_update_loss_fwd: std and mean go together");
+    P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE || mask_mode == P4C_MASK_FROM_NAN,
+                  "p4c_ar_update_loss_fwd: only MASK_NONE / MASK_FROM_NAN are fused");
+    P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS && y_cs >= F, "p4c_ar_update_loss_fwd: bad F / y_cs");
+    const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
+    const int nblk = loss_blocks(N, 64 / FP, B);
+#define P4C_LAUNCH_FWD(TY)                                                                                              \
+    hipLaunchKernelGGL(ar_update_loss_fwd_kernel<TY>, dim3(nblk, B), dim3(256), 0, as_stream(stream), prev, prev_bs,      \
+                       (const TY*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs,    \
+                       weights, kind, mask_mode, (float*)workspace, N, F, keep_prev, FP, iters)
+    if (y_dtype == P4C_F32)
+        P4C_LAUNCH_FWD(float);
+    else if (y_dtype == P4C_BF16)
+        P4C_LAUNCH_FWD(bf16);
+    else
+        return fail(P4C_ERR_INVALID, "p4c_ar_update_loss_fwd: bad dtype %d", y_dtype);
+#undef P4C_LAUNCH_FWD
+    P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd");
+    hipLaunchKernelGGL(weighted_loss_final_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream),
+                       (const float*)workspace, nblk, num_interior, masked_count, loss_out, loss_stride, B);
+    P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(final)");
+    return P4C_OK;
+}
+
+extern "C" int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g_next2, int g2_dtype,
+                                      int g2_cs, const float* gloss, int64_t gloss_stride, const float* new_state,
+                                      int64_t new_bs, const float* target, int64_t tgt_bs, const float* std,
+                                      const float* interior_mask, int force_border, const float* weights,
+                                      float num_interior, const int32_t* masked_count, int kind, int mask_mode,
+                                      void* dy, int dy_dtype, int y_cs, float* dprev, int64_t dprev_bs, int B,
+                                      int64_t N, int F, float keep_prev, p4c_stream_t stream) {
+    P4C_CHECK_ARG(new_state && target && interior_mask && weights && dy, "p4c_ar_update_loss_bwd: null pointer");
+    P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE || mask_mode == P4C_MASK_FROM_NAN,
+                  "p4c_ar_update_loss_bwd: only MASK_NONE / MASK_FROM_NAN are fused");
+    P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS && y_cs >= F, "p4c_ar_update_loss_bwd: bad F / y_cs");
+    P4C_CHECK_ARG(dy_dtype == g2_dtype || !g_next2, "p4c_ar_update_loss_bwd: g_next2 dtype must equal dy dtype");
+    const int FP = pow2_ge64(y_cs), iters = (y_cs + FP - 1) / FP;
+    P4C_CHECK_ARG(iters <= LOSS_MAX_ITERS, "p4c_ar_update_loss_bwd: y_cs too large");
+    const int nblk = loss_blocks(N, 64 / FP, B);
+#define P4C_LAUNCH_BWD(TY)                                                                                              \
+    hipLaunchKernelGGL((ar_update_loss_bwd_kernel<TY, TY>), dim3(nblk, B), dim3(256), 0, as_stream(stream), g_next,       \
+                       g_next_bs, (const TY*)g_next2, g2_cs, gloss, gloss_stride, new_state, new_bs, target, tgt_bs,    \
+                       std, interior_mask, force_border, weights, num_interior, masked_count, kind, mask_mode, (TY*)dy, \
+                       y_cs, dprev, dprev_bs, N, F, keep_prev, FP, iters)
+    if (dy_dtype == P4C_F32)
+        P4C_LAUNCH_BWD(float);
+    else if (dy_dtype == P4C_BF16)
+        P4C_LAUNCH_BWD(bf16);
+    else
+        return fail(P4C_ERR_INVALID, "p4c_ar_update_loss_bwd: bad dtype %d", dy_dtype);
+#undef P4C_LAUNCH_BWD
+    P4C_CHECK_LAUNCH("p4c_ar_update_loss_bwd");
+    return P4C_OK;
+}

@@ -1,0 +1,306 @@
+// K1 build_x and K2 ar_update (+ backward): the non-model part of the AR rollout.
+// Reference: py4cast/lightning.py:495-676 (_common_step), 711-767 (_next_x).
+//
+// All kernels here are HBM-bound streaming passes over (B, N, features) rows.  The feature
+// dimension is the contiguous one in the reference's NamedTensor layout, so a wave walks
+// grid points with its lanes spread over the channels of one (or several) grid points:
+// loads/stores are contiguous per grid point and no index division happens per element.
+//
+// This translation unit is compiled with -ffp-contract=off: K2 evaluates the reference's
+// expression in the reference's order, one rounding per op, so fp32 results are bit-identical
+// to the torch op chain.
+#include "common.hpp"
+
+namespace p4c {
+
+// lanes are split into 64/FP segments of FP lanes; segment = one grid point, lane%FP = channel
+__host__ __device__ static inline int pow2_ge(int v) {
+    int p = 1;
+    while (p < v && p < 64) p <<= 1;
+    return p;
+}
+
+constexpr int K1_MAX_ITERS = 8;  // channels handled per lane: c_pad <= 64*K1_MAX_ITERS
+
+template <typename TX>
+__global__ void __launch_bounds__(256) build_x_kernel(const float* __restrict__ prev, int64_t prev_bs, int64_t prev_ts,
+                                                      const float* __restrict__ statics, int64_t statics_bs,
+                                                      const float* __restrict__ forcing, int64_t forcing_bs,
+                                                      TX* __restrict__ x, int c_pad, int B, int T_in, int64_t N,
+                                                      int F, int Fs, int Ff, int mask_on_nan, int n_prev_ch,
+                                                      int FP, int iters) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int PP = 64 / FP;
+    const int pp = lane / FP;
+    const int c0 = lane % FP;
+    const int o_stat = n_prev_ch, o_forc = n_prev_ch + Fs, o_mask = n_prev_ch + Fs + Ff;
+    const int c_in = o_mask + (mask_on_nan ? 1 : 0);
+    const int64_t total = (int64_t)B * N;
+    const unsigned long long segmask = (FP == 64) ? ~0ull : (((1ull << FP) - 1ull) << (pp * FP));
+
+    for (int64_t base = (int64_t)wave * PP; base < total; base += (int64_t)nwaves * PP) {
+        const int64_t pix = base + pp;
+        const bool live = pix < total;
+        const int b = live ? (int)(pix / N) : 0;
+        const int64_t n = live ? (pix - (int64_t)b * N) : 0;
+        float vals[K1_MAX_ITERS];
+        bool any_nan = false;
+#pragma unroll
+        for (int it = 0; it < K1_MAX_ITERS; ++it) {
+            if (it >= iters) break;
+            const int c = c0 + it * FP;
+            float v = 0.0f;
+            bool counts = false;  // channel takes part in the NaN union (inputs + forcing only)
+            if (live && c < c_pad) {
+                if (c < o_stat) {
+                    const int t = c / F, f = c - t * F;
+                    v = prev[(int64_t)b * prev_bs + (int64_t)t * prev_ts + n * F + f];
+                    counts = true;
+                } else if (c < o_forc) {
+                    v = statics[(int64_t)b * statics_bs + n * Fs + (c - o_stat)];
+                } else if (c < o_mask) {
+                    v = forcing[(int64_t)b * forcing_bs + n * Ff + (c - o_forc)];
+                    counts = true;
+                }
+            }
+            vals[it] = v;
+            if (mask_on_nan) {
+                const bool isn = counts && (v != v);
+                const unsigned long long bal = __ballot(isn);
+                any_nan = any_nan || ((bal & segmask) != 0ull);
+                if (counts && isn) vals[it] = 0.0f;  // nan_to_num on inputs and forcing (lightning.py:755-757)
+            }
+        }
+        if (!live) continue;
+        TX* xrow = x + pix * (int64_t)c_pad;
+#pragma unroll
+        for (int it = 0; it < K1_MAX_ITERS; ++it) {
+            if (it >= iters) break;
+            const int c = c0 + it * FP;
+            if (c < c_pad) {
+                float v = vals[it];
+                if (mask_on_nan && c == c_in - 1) v = any_nan ? 0.0f : 1.0f;  // ~combined_mask (lightning.py:750-752)
+                xrow[c] = from_f32<TX>(v);
+            }
+        }
+    }
+}
+
+template <typename TX>
+__global__ void __launch_bounds__(256) build_x_bwd_kernel(const TX* __restrict__ dx, int c_pad, float* __restrict__ dprev,
+                                                          int B, int T_in, int64_t N, int F, int FP, int iters) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const int nch = T_in * F;
+    const int64_t total = (int64_t)B * N;
+    for (int64_t base = (int64_t)wave * PP; base < total; base += (int64_t)nwaves * PP) {
+        const int64_t pix = base + pp;
+        if (pix >= total) continue;
+        const int b = (int)(pix / N);
+        const int64_t n = pix - (int64_t)b * N;
+        for (int it = 0; it < iters; ++it) {
+            const int c = c0 + it * FP;
+            if (c < nch) {
+                const int t = c / F, f = c - t * F;
+                dprev[(((int64_t)b * T_in + t) * N + n) * F + f] = to_f32<TX>(dx[pix * (int64_t)c_pad + c]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- K2
+template <typename TY>
+__global__ void __launch_bounds__(256)
+    ar_update_fwd_kernel(const float* __restrict__ prev, int64_t prev_bs, const TY* __restrict__ y, int y_cs,
+                         const float* __restrict__ border_state, int64_t border_bs, const float* __restrict__ std,
+                         const float* __restrict__ mean, const float* __restrict__ border_mask,
+                         const float* __restrict__ interior_mask, float* __restrict__ new_state, int64_t new_bs, int B,
+                         int64_t N, int F, float keep_prev, int nan_to_num, int FP, int iters) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const int64_t total = (int64_t)B * N;
+    for (int64_t base = (int64_t)wave * PP; base < total; base += (int64_t)nwaves * PP) {
+        const int64_t pix = base + pp;
+        if (pix >= total) continue;
+        const int b = (int)(pix / N);
+        const int64_t n = pix - (int64_t)b * N;
+        float bm = 0.f, im = 1.f;
+        if (border_mask) {
+            bm = border_mask[n];
+            im = interior_mask[n];
+        }
+        for (int it = 0; it < iters; ++it) {
+            const int f = c0 + it * FP;
+            if (f >= F) continue;
+            float yv = to_f32<TY>(y[pix * (int64_t)y_cs + f]);
+            float p;
+            float pv = 0.f;
+            if (prev) {
+                pv = prev[(int64_t)b * prev_bs + n * F + f];
+                if (nan_to_num) pv = nan_to_zero(pv);
+            }
+            // reference order (lightning.py:605-610 / 623): ((prev*(1-ds)) + (y*std)) + mean
+            if (std) {
+                p = pv * keep_prev + yv * std[f];
+                p = p + mean[f];
+            } else {
+                p = pv * keep_prev + yv;
+            }
+            if (border_mask) {  // lightning.py:628-631
+                float bs = border_state[(int64_t)b * border_bs + n * F + f];
+                if (nan_to_num) bs = nan_to_zero(bs);
+                p = bm * bs + im * p;
+            }
+            new_state[(int64_t)b * new_bs + n * F + f] = p;
+        }
+    }
+}
+
+template <typename TY>
+__global__ void __launch_bounds__(256)
+    ar_update_bwd_kernel(const float* __restrict__ dnew, int64_t dnew_bs, const float* __restrict__ std,
+                         const float* __restrict__ interior_mask, TY* __restrict__ dy, int y_cs,
+                         float* __restrict__ dprev, int64_t dprev_bs, int B, int64_t N, int F, float keep_prev, int FP,
+                         int iters) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const int64_t total = (int64_t)B * N;
+    for (int64_t base = (int64_t)wave * PP; base < total; base += (int64_t)nwaves * PP) {
+        const int64_t pix = base + pp;
+        if (pix >= total) continue;
+        const int b = (int)(pix / N);
+        const int64_t n = pix - (int64_t)b * N;
+        const float im = interior_mask ? interior_mask[n] : 1.0f;
+        for (int it = 0; it < iters; ++it) {
+            const int f = c0 + it * FP;
+            if (f >= y_cs) continue;
+            float gy = 0.f;
+            if (f < F) {
+                const float g = dnew[(int64_t)b * dnew_bs + n * F + f] * im;
+                gy = std ? g * std[f] : g;
+                if (dprev) dprev[(int64_t)b * dprev_bs + n * F + f] = g * keep_prev;
+            }
+            dy[pix * (int64_t)y_cs + f] = from_f32<TY>(gy);
+        }
+    }
+}
+
+static inline int stream_grid(int64_t total_pixels, int PP) {
+    // memory-bound: cap at ~8 blocks of 256 threads per CU and grid-stride the rest
+    int64_t waves = (total_pixels + PP - 1) / PP;
+    int64_t blocks = (waves + 3) / 4;
+    int64_t cap = (int64_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace p4c
+
+using namespace p4c;
+
+extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, const float* statics,
+                           int64_t statics_bs, const float* forcing, int64_t forcing_bs, void* x, int x_dtype,
+                           int c_pad, int B, int T_in, int64_t N, int F, int Fs, int Ff, int mask_on_nan,
+                           int downscaling_only, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && statics && forcing, "p4c_build_x: null pointer");
+    P4C_CHECK_ARG(B > 0 && N > 0 && F > 0 && Fs >= 0 && Ff >= 0 && T_in >= 0, "p4c_build_x: bad dims");
+    const int n_prev_ch = downscaling_only ? 0 : T_in * F;
+    P4C_CHECK_ARG(n_prev_ch == 0 || prev, "p4c_build_x: prev is null");
+    const int c_in = n_prev_ch + Fs + Ff + (mask_on_nan ? 1 : 0);
+    P4C_CHECK_ARG(c_pad >= c_in, "p4c_build_x: c_pad (%d) < C_in (%d)", c_pad, c_in);
+    const int FP = pow2_ge(c_pad);
+    const int iters = (c_pad + FP - 1) / FP;
+    P4C_CHECK_ARG(iters <= K1_MAX_ITERS, "p4c_build_x: c_pad %d too large (max %d)", c_pad, 64 * K1_MAX_ITERS);
+    const int grid = stream_grid((int64_t)B * N, 64 / FP);
+    if (x_dtype == P4C_F32)
+        hipLaunchKernelGGL(build_x_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
+                           statics, statics_bs, forcing, forcing_bs, (float*)x, c_pad, B, T_in, N, F, Fs, Ff,
+                           mask_on_nan, n_prev_ch, FP, iters);
+    else if (x_dtype == P4C_BF16)
+        hipLaunchKernelGGL(build_x_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
+                           statics, statics_bs, forcing, forcing_bs, (bf16*)x, c_pad, B, T_in, N, F, Fs, Ff,
+                           mask_on_nan, n_prev_ch, FP, iters);
+    else
+        return fail(P4C_ERR_INVALID, "p4c_build_x: bad dtype %d", x_dtype);
+    P4C_CHECK_LAUNCH("p4c_build_x");
+    return P4C_OK;
+}
+
+extern "C" int p4c_build_x_bwd(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N,
+                               int F, p4c_stream_t stream) {
+    P4C_CHECK_ARG(dx && dprev, "p4c_build_x_bwd: null pointer");
+    P4C_CHECK_ARG(c_pad >= T_in * F, "p4c_build_x_bwd: c_pad < T_in*F");
+    const int nch = T_in * F;
+    const int FP = pow2_ge(nch);
+    const int iters = (nch + FP - 1) / FP;
+    const int grid = stream_grid((int64_t)B * N, 64 / FP);
+    if (dx_dtype == P4C_F32)
+        hipLaunchKernelGGL(build_x_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dx,
+                           c_pad, dprev, B, T_in, N, F, FP, iters);
+    else if (dx_dtype == P4C_BF16)
+        hipLaunchKernelGGL(build_x_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)dx,
+                           c_pad, dprev, B, T_in, N, F, FP, iters);
+    else
+        return fail(P4C_ERR_INVALID, "p4c_build_x_bwd: bad dtype %d", dx_dtype);
+    P4C_CHECK_LAUNCH("p4c_build_x_bwd");
+    return P4C_OK;
+}
+
+extern "C" int p4c_ar_update_fwd(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                                 const float* border_state, int64_t border_bs, const float* std, const float* mean,
+                                 const float* border_mask, const float* interior_mask, float* new_state,
+                                 int64_t new_bs, int B, int64_t N, int F, float keep_prev, int nan_to_num,
+                                 p4c_stream_t stream) {
+    P4C_CHECK_ARG(y && new_state, "p4c_ar_update_fwd: null pointer");
+    P4C_CHECK_ARG(prev || keep_prev == 0.0f, "p4c_ar_update_fwd: prev is null but keep_prev != 0");
+    P4C_CHECK_ARG((std == nullptr) == (mean == nullptr), "p4c_ar_update_fwd: std and mean go together");
+    P4C_CHECK_ARG(!border_mask || (interior_mask && border_state), "p4c_ar_update_fwd: border forcing needs masks+state");
+    P4C_CHECK_ARG(y_cs >= F && B > 0 && N > 0 && F > 0, "p4c_ar_update_fwd: bad dims");
+    const int FP = pow2_ge(F);
+    const int iters = (F + FP - 1) / FP;
+    const int grid = stream_grid((int64_t)B * N, 64 / FP);
+    if (y_dtype == P4C_F32)
+        hipLaunchKernelGGL(ar_update_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), prev, prev_bs,
+                           (const float*)y, y_cs, border_state, border_bs, std, mean, border_mask, interior_mask,
+                           new_state, new_bs, B, N, F, keep_prev, nan_to_num, FP, iters);
+    else if (y_dtype == P4C_BF16)
+        hipLaunchKernelGGL(ar_update_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), prev, prev_bs,
+                           (const bf16*)y, y_cs, border_state, border_bs, std, mean, border_mask, interior_mask,
+                           new_state, new_bs, B, N, F, keep_prev, nan_to_num, FP, iters);
+    else
+        return fail(P4C_ERR_INVALID, "p4c_ar_update_fwd: bad dtype %d", y_dtype);
+    P4C_CHECK_LAUNCH("p4c_ar_update_fwd");
+    return P4C_OK;
+}
+
+extern "C" int p4c_ar_update_bwd(const float* dnew, int64_t dnew_bs, const float* std, const float* interior_mask,
+                                 void* dy, int dy_dtype, int y_cs, float* dprev, int64_t dprev_bs, int B, int64_t N,
+                                 int F, float keep_prev, p4c_stream_t stream) {
+    P4C_CHECK_ARG(dnew && dy, "p4c_ar_update_bwd: null pointer");
+    P4C_CHECK_ARG(y_cs >= F && B > 0 && N > 0 && F > 0, "p4c_ar_update_bwd: bad dims");
+    const int FP = pow2_ge(y_cs);
+    const int iters = (y_cs + FP - 1) / FP;
+    const int grid = stream_grid((int64_t)B * N, 64 / FP);
+    if (dy_dtype == P4C_F32)
+        hipLaunchKernelGGL(ar_update_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), dnew, dnew_bs, std,
+                           interior_mask, (float*)dy, y_cs, dprev, dprev_bs, B, N, F, keep_prev, FP, iters);
+    else if (dy_dtype == P4C_BF16)
+        hipLaunchKernelGGL(ar_update_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), dnew, dnew_bs, std,
+                           interior_mask, (bf16*)dy, y_cs, dprev, dprev_bs, B, N, F, keep_prev, FP, iters);
+    else
+        return fail(P4C_ERR_INVALID, "p4c_ar_update_bwd: bad dtype %d", dy_dtype);
+    P4C_CHECK_LAUNCH("p4c_ar_update_bwd");
+    return P4C_OK;
+}

@@ -1,0 +1,203 @@
+"""
+Loss plugins of the hot path, API-compatible with ``py4cast/losses.py`` of the reference
+(Py4CastLoss ABC :18-75, WeightedLoss :103-169, ScaledLoss :172-210, CombinedLoss :263-307)
+and computed by the HIP kernels of ``csrc/losses.hip`` through the C ABI.
+
+Same constructor/yaml schema (``losses: [{class, weight, params: {loss, reduction}}]``),
+same ``prepare(lm, interior_mask, dataset_info)`` / ``forward(prediction, target, mask)``
+contract, same output shapes ((B,T), (B,T,*S) with ``reduce_spatial_dim=False``, (B,T,F)),
+same error behaviour (unknown torch loss -> NameError; a ScaledLoss member inside a
+CombinedLoss raises on the shape mismatch, as the reference's in-place add does).
+
+Differences, on purpose:
+* graph-layout tensors (B,T,N,F): the reference raises IndexError (losses.py:156,197 use
+  ``dim=(0, 1, 4)``); here the value is defined as the grid-layout result of the same data.
+* per-feature weights are uploaded once in ``prepare`` (the reference rebuilds them through an
+  lru_cache keyed on (feature names, device), losses.py:77-84).
+* ``mask`` may be the marker object returned by ``FusedARLightning.get_mask_on_nan`` (no
+  mask tensor is materialised; the kernels derive it from the target's NaNs).
+"""
+
+from abc import ABC, abstractmethod
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .namedtensor import NamedTensor
+
+SUPPORTED_TORCH_LOSSES = ("MSELoss", "L1Loss")
+
+
+class NanMask:
+    """Marker: mask = ~isnan(raw_target) and target = nan_to_num(raw_target), fused in-kernel
+    (lightning.py:787-797).  ``raw_target`` is the un-masked target tensor."""
+
+    def __init__(self, raw_target: torch.Tensor):
+        self.raw_target = raw_target
+
+
+class OnesMask:
+    """Marker for ``torch.ones_like(target)`` (lightning.py:797) without allocating it."""
+
+
+def _mask_spec(mask, target: torch.Tensor) -> Tuple[ops.MaskSpec, torch.Tensor]:
+    if mask is None or isinstance(mask, OnesMask):
+        return ops.MaskSpec(L.MASK_NONE), target
+    if isinstance(mask, NanMask):
+        return ops.MaskSpec(L.MASK_FROM_NAN), mask.raw_target
+    return ops.MaskSpec.from_tensor(mask), target
+
+
+class Py4CastLoss(ABC):
+    """losses.py:18-75."""
+
+    def __init__(self, loss: str, *args, **kwargs) -> None:
+        if hasattr(torch.nn, loss):
+            self.loss = getattr(torch.nn, loss)(*args, **kwargs)  # kept for introspection / repr parity
+        elif loss in globals():
+            self.loss = globals()[loss](*args, **kwargs)
+        else:
+            raise NameError(f"Loss: {loss} is not defined")
+        self.loss_name = loss
+        reduction = kwargs.get("reduction", "mean")
+        if loss in SUPPORTED_TORCH_LOSSES and reduction != "none":
+            # the reference would broadcast a scalar through the weighted sums; py4cast's yaml
+            # always sets "none" (halfunet.yaml:3-8).  Refuse rather than silently differ.
+            raise ValueError(f'{type(self).__name__}: reduction must be "none" (got {reduction!r})')
+
+    @property
+    def kind(self) -> int:
+        return ops.loss_kind_code(self.loss_name)
+
+    @abstractmethod
+    def prepare(self, lm, interior_mask: torch.Tensor, dataset_info) -> None:
+        """Prepare the loss function using the dataset informations and the interior mask."""
+
+    @abstractmethod
+    def forward(self, prediction: NamedTensor, target: NamedTensor, mask) -> torch.Tensor:
+        """Compute the loss function."""
+
+    def register_loss_state_buffers(self, lm, interior_mask: torch.Tensor, loss_state_weight: dict,
+                                    squeeze_mask: bool = False) -> None:
+        """losses.py:52-72: registers interior_mask(_s) on the module and counts interior points."""
+        self.loss_state_weight = loss_state_weight
+        attr_name = "interior_mask_s" if squeeze_mask else "interior_mask"
+        if not hasattr(lm, attr_name):
+            lm.register_buffer(attr_name, interior_mask.squeeze(-1) if squeeze_mask else interior_mask, persistent=False)
+        self.num_interior = torch.sum(interior_mask).item()
+        self._weights_cache = {}
+
+    def __call__(self, *args, **kwds):
+        return self.forward(*args, **kwds)
+
+    def weights(self, feature_names: Tuple[str], device: torch.device) -> torch.Tensor:
+        """losses.py:77-84 (per (feature names, device) cache, built once)."""
+        key = (tuple(feature_names), str(device))
+        w = self._weights_cache.get(key)
+        if w is None:
+            w = torch.stack(
+                [torch.as_tensor(self.loss_state_weight[name], dtype=torch.float32) for name in feature_names]
+            ).to(device)
+            self._weights_cache[key] = w
+        return w
+
+    def _interior_flat(self, lm, device) -> torch.Tensor:
+        im = getattr(lm, "interior_mask")
+        flat = getattr(self, "_interior_flat_cache", None)
+        if flat is None or flat.device != device or flat.numel() != im.numel():
+            flat = im.detach().reshape(-1).to(device=device, dtype=torch.float32).contiguous()
+            self._interior_flat_cache = flat
+        return flat
+
+
+class WeightedLoss(Py4CastLoss):
+    """losses.py:103-169: per-feature weight state_weight/diff_std**p, masked spatial mean -> (B,T)."""
+
+    def prepare(self, lm, interior_mask: torch.Tensor, dataset_info) -> None:
+        exponent = 2.0 if self.loss_name == "MSELoss" else 1.0  # losses.py:119
+        loss_state_weight = {}
+        for name in dataset_info.state_weights:
+            loss_state_weight[name] = dataset_info.state_weights[name] / (
+                dataset_info.diff_stats[name]["std"] ** exponent
+            )
+        self.register_loss_state_buffers(lm, interior_mask, loss_state_weight, squeeze_mask=True)
+        self.lm = lm
+
+    def forward(self, prediction: NamedTensor, target: NamedTensor, mask, reduce_spatial_dim: bool = True,
+                masked_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+        spec, tgt = _mask_spec(mask, target.tensor)
+        weights = self.weights(tuple(prediction.feature_names), prediction.device)
+        if not reduce_spatial_dim:
+            return ops.weighted_loss_map(prediction.tensor, tgt, spec, weights, self.kind)
+        interior = self._interior_flat(self.lm, prediction.device)
+        return ops.weighted_loss(prediction.tensor, tgt, spec, weights, interior, self.num_interior, self.kind,
+                                 count=masked_count)
+
+
+class ScaledLoss(Py4CastLoss):
+    """losses.py:172-210: per-feature masked spatial mean, sqrt if MSE, times std -> (B,T,F)."""
+
+    def prepare(self, lm, interior_mask: torch.Tensor, dataset_info) -> None:
+        loss_state_weight = {}
+        for name in dataset_info.state_weights:
+            loss_state_weight[name] = dataset_info.stats[name]["std"]
+        self.register_loss_state_buffers(lm, interior_mask, loss_state_weight)
+        self.lm = lm
+
+    def forward(self, prediction: NamedTensor, target: NamedTensor, mask) -> torch.Tensor:
+        spec, tgt = _mask_spec(mask, target.tensor)
+        std = self.weights(tuple(prediction.feature_names), prediction.device)
+        interior = self._interior_flat(self.lm, prediction.device)
+        return ops.scaled_loss(prediction.tensor, tgt, spec, std, interior, self.num_interior, self.kind)
+
+
+class PerceptualLossPy4Cast(Py4CastLoss):
+    """losses.py:213-260 wraps mfai's PerceptualLoss (a VGG-style network): out of the hot-path scope."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        raise NotImplementedError(
+            "PerceptualLossPy4Cast needs mfai.pytorch.losses.perceptual.PerceptualLoss; it is outside the "
+            "MI355X hot-path scope (SURVEY.md section 2, row 2)."
+        )
+
+    def prepare(self, lm, interior_mask, dataset_info) -> None:  # pragma: no cover
+        pass
+
+    def forward(self, prediction, target, mask):  # pragma: no cover
+        pass
+
+
+class CombinedLoss(Py4CastLoss):
+    """losses.py:263-307: weighted sum of Py4CastLoss members built from yaml dicts."""
+
+    def __init__(self, losses_config: list):
+        self.losses = []
+        for loss_conf in losses_config:
+            LossClass = globals()[loss_conf["class"]]  # string class names, as in the reference (:271)
+            weight = loss_conf.get("weight", 1.0)
+            kwargs = loss_conf.get("params", {})
+            self.losses.append((LossClass(**kwargs), weight))
+
+    def prepare(self, lm, interior_mask: torch.Tensor, dataset_info):
+        for loss, _ in self.losses:
+            if hasattr(loss, "prepare"):
+                loss.prepare(lm, interior_mask, dataset_info)
+
+    def forward(self, prediction: NamedTensor, target: NamedTensor, mask, **kwargs) -> torch.Tensor:
+        loss_shape = (
+            prediction.tensor.shape[:2] if kwargs.get("reduce_spatial_dim", True) else prediction.tensor.shape[:-1]
+        )
+        total_loss = torch.zeros(loss_shape, device=prediction.tensor.device)
+        if len(self.losses) > 1 and "masked_count" not in kwargs and kwargs.get("reduce_spatial_dim", True):
+            # one union-mask pass shared by every member instead of one per member
+            spec, tgt = _mask_spec(mask, target.tensor)
+            if all(isinstance(l, WeightedLoss) for l, _ in self.losses):
+                kwargs = dict(kwargs, masked_count=ops.masked_count(spec, tgt))
+        for loss, weight in self.losses:
+            total_loss += weight * loss(prediction, target, mask, **kwargs)
+        return total_loss
+
+    def __repr__(self):
+        return "CombinedLoss(" + ", ".join(f"{w}*{type(l).__name__}({l.loss_name})" for l, w in self.losses) + ")"

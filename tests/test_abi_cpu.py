@@ -1,0 +1,93 @@
+"""CPU checks: the C-ABI library loads and exports every symbol include/py4cast_hip.h declares;
+host-side mirrors of the reference API (registry, NamedTensor, loss construction errors)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "py4cast_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(p4c_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from py4cast_amd import _lib
+
+    handle = _lib.lib()  # raises if not built
+    names = header_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/py4cast_hip.h but not exported"
+    # every declared symbol also has a ctypes signature (no untyped calls)
+    assert set(names) == set(_lib.all_symbols())
+    assert handle.p4c_version() == 100
+
+
+def test_no_cpu_fallback():
+    from py4cast_amd import _lib, ops
+
+    x = torch.zeros(1, 1, 4, 4, 2)
+    with pytest.raises(_lib.P4CError):
+        ops.build_x(x, torch.zeros(1, 4, 4, 1), torch.zeros(1, 4, 4, 1))
+
+
+def test_namedtensor_api():
+    from py4cast_amd.namedtensor import NamedTensor
+
+    t = NamedTensor(torch.arange(2 * 3 * 4 * 5 * 6.0).reshape(2, 3, 4, 5, 6), ["batch", "timestep", "lat", "lon", "features"], list("abcdef"))
+    assert t.spatial_dim_idx == [2, 3] and t.num_spatial_dims == 2
+    assert t.dim_size("timestep") == 3 and t.dim_index("lon") == 3
+    s = t.select_dim("timestep", 1)
+    assert s.names == ["batch", "lat", "lon", "features"] and s.tensor.shape == (2, 4, 5, 6)
+    assert t.index_select_tensor_dim("timestep", range(1, 3)).shape == (2, 2, 4, 5, 6)
+    t2 = t.clone()
+    t2.flatten_("ngrid", 2, 3)
+    assert t2.names == ["batch", "timestep", "ngrid", "features"] and t2.spatial_dim_idx == [2]
+    with pytest.raises(ValueError):
+        NamedTensor(torch.zeros(2, 3), ["a", "features"], ["x"])
+
+
+def test_registry_contract():
+    from py4cast_amd import models
+    from py4cast_amd.base import ModelABC
+
+    assert "HalfUNet" in models.registry  # the MI355X plugin was discovered through its module-name prefix
+    for name, kls in models.registry.items():
+        assert issubclass(kls, ModelABC) and kls.register
+    with pytest.raises(KeyError):
+        models.get_model_kls_and_settings("NoSuchModel", {})
+
+
+def test_loss_construction_errors():
+    from py4cast_amd.losses import CombinedLoss, WeightedLoss
+
+    with pytest.raises(NameError):  # losses.py:25-31
+        WeightedLoss("NoSuchLoss")
+    with pytest.raises(KeyError):  # losses.py:271 globals()[...]
+        CombinedLoss([{"class": "Nope", "params": {}}])
+    c = CombinedLoss([{"class": "WeightedLoss", "weight": 2.0, "params": {"loss": "L1Loss", "reduction": "none"}}])
+    assert c.losses[0][1] == 2.0
+
+
+def test_strategy_validation():
+    from helpers import make_dataset_info, register_test_models, synthetic_case
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    register_test_models()
+    case = synthetic_case(H=8, W=8, F=3)
+    info = make_dataset_info(case, Ff=5)
+    with pytest.raises(AttributeError):  # lightning.py:218-222
+        AutoRegressiveLightning({}, info, None, model_name="TinyConvModel", training_strategy="nope")
+    with pytest.raises(AttributeError):  # lightning.py:213-217
+        AutoRegressiveLightning({}, info, None, model_name="TinyConvModel", num_input_steps=2, num_inter_steps=2)
+    lm = AutoRegressiveLightning({}, info, None, model_name="TinyConvModel", training_strategy="diff_ar", num_inter_steps=2)
+    with pytest.raises(ValueError):  # lightning.py:688-692
+        lm._strategy_params()
+    assert lm.model.in_channels == 3 + 4 + 5  # lightning.py:256-261
+    assert lm.grid_static_features.shape == (2, 8, 8, 4) and lm.interior_mask.shape == (8, 8, 1)
+    assert hasattr(lm, "interior_mask_s")  # registered by WeightedLoss.prepare (losses.py:65-71)
