@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""
+bench.py -- AR-training samples/sec on the synthetic 512x512x60 grid, 3-step rollout
+(BASELINE.json metric; SURVEY.md section 8(d) workload).
+
+    python bench.py --gpus N --steps K --warmup W [--model HalfUNet] [--dtype bf16|f32]
+
+One "step" = one micro-batch of B samples per GPU through: 3 AR steps (build x -> model forward
+-> scaled residual update + border forcing -> weighted MSE) -> backward through the rollout
+(BPTT) -> gradient all-reduce (N>1, RCCL) -> AdamW step.  Inputs are synthetic, generated on
+the device and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+For N>1 launch with torch.distributed.run (one rank per GPU); samples are independent, each rank
+draws its own B samples (weak scaling) and the only collective is the gradient all-reduce.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # dense peaks, MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default=os.environ.get("P4C_BENCH_MODEL", "HalfUNet"))
+    ap.add_argument("--dtype", default=os.environ.get("P4C_BENCH_DTYPE", "f32"), choices=["f32", "bf16"])
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--grid", type=int, nargs=2, default=[512, 512])
+    ap.add_argument("--features", type=int, default=60)
+    ap.add_argument("--pred-steps", type=int, default=3)
+    ap.add_argument("--border", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def synthetic_case(seed, B, T, T_in, H, W, F, Ff, Fs, border, device):
+    """N(0,1) states clipped to [-3,3], U(0,1) date forcings, U(0,1366) TOA radiation."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g, device=device)
+    ru = lambda *s: torch.rand(*s, generator=g, device=device)
+    forcing = ru(B, T, H, W, Ff)
+    forcing[..., -1] *= 1366.0
+    ys, xs = torch.meshgrid(torch.linspace(0, 1, H, device=device), torch.linspace(0, 1, W, device=device), indexing="ij")
+    statics = torch.stack([xs, ys, ru(H, W), torch.zeros(H, W, device=device)], dim=-1)[..., :Fs]
+    bm = torch.zeros(H, W, 1, device=device)
+    if border > 0:
+        bm[:border], bm[-border:], bm[:, :border], bm[:, -border:] = 1, 1, 1, 1
+    statics[..., 3:4] = bm
+    levels = [250, 500, 700, 850]
+    sw = torch.tensor([1 + levels[i % 4] / 1000 if i < F - 4 else 2.0 for i in range(F)])
+    return dict(
+        inputs=rn(B, T_in, H, W, F).clamp(-3, 3),
+        forcing=forcing,
+        outputs=rn(B, T, H, W, F).clamp(-3, 3),
+        statics=statics,
+        border_mask=bm,
+        diff_std=(ru(F) + 0.5).cpu(),
+        diff_mean=(rn(F) * 0.01).cpu(),
+        std=(ru(F) + 0.5).cpu(),
+        state_weight=sw,
+    )
+
+
+def make_info(case, Ff):
+    from py4cast_amd.base import DatasetInfo, Statics, Stats
+    from py4cast_amd.namedtensor import NamedTensor
+
+    F = case["diff_std"].shape[0]
+    names = [f"f{i}" for i in range(F)]
+    gs = NamedTensor(case["statics"].cpu(), ["lat", "lon", "features"], ["x", "y", "geopotential", "border_mask"])
+    stats = Stats({n: {"std": case["std"][i], "mean": torch.tensor(0.0)} for i, n in enumerate(names)})
+    dstats = Stats({n: {"std": case["diff_std"][i], "mean": case["diff_mean"][i]} for i, n in enumerate(names)})
+    return DatasetInfo("synthetic", Statics(gs, tuple(gs.tensor.shape[:2])), stats, dstats,
+                       {n: float(case["state_weight"][i]) for i, n in enumerate(names)}, {"input_output": names}, F, Ff)
+
+
+def make_batch(case):
+    from py4cast_amd.base import ItemBatch
+    from py4cast_amd.namedtensor import NamedTensor
+
+    dims = ["batch", "timestep", "lat", "lon", "features"]
+    F, Ff = case["inputs"].shape[-1], case["forcing"].shape[-1]
+    return ItemBatch(
+        NamedTensor(case["inputs"], dims, [f"f{i}" for i in range(F)]),
+        NamedTensor(case["forcing"], dims, [f"g{i}" for i in range(Ff)]),
+        NamedTensor(case["outputs"], dims, [f"f{i}" for i in range(F)]),
+    )
+
+
+def cpu_baseline(args, seconds):
+    """
+    The CPU restatement (oracle/, kind "port") of the same step -- rollout + weighted MSE + backward +
+    AdamW with the oracle's torch-native model -- timed on the host cores on a bounded sample
+    (one sample, a 128x128 crop of the grid, scaled to samples/s of the full grid by pixel count).
+    """
+    from oracle import losses as olosses
+    from oracle import rollout as orollout
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 64)  # torch intra-op threading stops scaling (and oversubscribes small boxes) beyond this
+    torch.set_num_threads(cores)
+    H, W = min(args.grid[0], 128), min(args.grid[1], 128)
+    F, T = args.features, args.pred_steps
+    case = synthetic_case(99, 1, T, 1, H, W, F, 5, 4, args.border, torch.device("cpu"))
+    interior = 1.0 - case["border_mask"]
+    wts = olosses.weighted_loss_weights(case["state_weight"], case["diff_std"], "mse")
+    statics = case["statics"].unsqueeze(0)
+    if args.model == "Identity":
+        scaler = torch.rand(1, requires_grad=True)
+        params = [scaler]
+        model_fn = lambda x: x[..., :F] * scaler
+        features_second = False
+    else:
+        from oracle import halfunet as ohalf
+
+        net = ohalf.HalfUNetRef(F + 4 + 5, F)
+        params = list(net.parameters())
+        model_fn = net
+        features_second = True
+    opt = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.95))
+
+    def one():
+        pred = orollout.rollout(model_fn, case["inputs"], case["forcing"], case["outputs"], statics, case["border_mask"],
+                                interior, case["diff_std"], case["diff_mean"], "scaled_ar", 1, False, "train",
+                                features_second=features_second)
+        loss = olosses.training_loss(pred, case["outputs"], False, [("WeightedLoss", 1.0, dict(weights=wts, interior_mask=interior, kind="mse"))])
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+
+    one()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds and n < 50:
+        one()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    scale = (H * W) / float(args.grid[0] * args.grid[1])
+    return {
+        "value": scale / dt,
+        "unit": "samples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle (torch CPU) {args.model} step on 1 sample of a {H}x{W}x{F} crop, {n} iterations, "
+                  f"scaled by pixel count to the {args.grid[0]}x{args.grid[1]} grid",
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from py4cast_amd import _lib as L
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from py4cast_amd.trainer import FlatDDP
+
+    H, W = args.grid
+    B, F, T, Ff, Fs = args.batch, args.features, args.pred_steps, 5, 4
+    case = synthetic_case(1234 + rank, B, T, 1, H, W, F, Ff, Fs, args.border, device)
+    info = make_info(case, Ff)
+    settings = {}
+    if args.model not in ("Identity",):
+        settings = {"compute_dtype": args.dtype}
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    lm = AutoRegressiveLightning(
+        settings, info, None, num_input_steps=1, num_pred_steps_train=T, num_pred_steps_val_test=T, batch_size=B,
+        model_name=args.model,
+        losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+        training_strategy="scaled_ar", learning_rate=1e-3, min_learning_rate=3e-7, num_warmup_steps=1000,
+        betas=(0.9, 0.95),
+    ).to(device)
+    ddp = FlatDDP(lm.model, world)
+    opt = lm.configure_optimizers()["optimizer"]
+
+    def step(i):
+        loss = lm.training_step(make_batch(case), i)
+        loss.backward()
+        ddp.all_reduce_grads()
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timed = getattr(lm.model, "timed_entry_points", None) or (
+        "p4c_build_x", "p4c_ar_update_fwd", "p4c_weighted_loss_fwd", "p4c_weighted_loss_bwd", "p4c_ar_update_bwd")
+    L.enable_kernel_timing(timed)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = L.kernel_times()
+    L.enable_kernel_timing(None)
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        N = H * W
+        c_in = F + Fs + Ff
+        roof = None
+        if hasattr(lm.model, "roofline"):
+            roof = lm.model.roofline(ktimes, B=B, H=H, W=W)
+        if roof is None and ktimes:
+            # HBM-bound rollout kernels: algorithmic bytes per launch
+            alg = {
+                "p4c_build_x": 4.0 * B * N * (2 * c_in),
+                "p4c_ar_update_fwd": 4.0 * B * N * (4 * F + 2),
+                "p4c_weighted_loss_fwd": 4.0 * B * T * N * (2 * F),
+                "p4c_weighted_loss_bwd": 4.0 * B * T * N * (3 * F),
+                "p4c_ar_update_bwd": 4.0 * B * N * (3 * F),
+            }
+            name = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1])
+            gbs = alg[name] / (ktimes[name][1] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ktimes[name][1],
+                    "launches": ktimes[name][0]}
+        out = {
+            "metric": "AR-training samples/sec (512x512x60 grid, 3-step rollout)",
+            "value": world * B * args.steps / dt,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype if args.model != "Identity" else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.model} scaled_ar rollout T={T}, grid {H}x{W}x{F} (+{Ff} forcings, {Fs} statics), "
+                            f"WeightedLoss(MSE), AdamW, B={B}/GPU",
+                "global_batch": world * B,
+                "parallelism": f"dp{world}",
+                "border_size": args.border,
+            },
+            "loss": float(loss.detach()),
+            "roofline": roof,
+            "kernel_ms": {k: {"calls": v[0], "avg_ms": round(v[1], 4)} for k, v in ktimes.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,7 +95,35 @@ def check(rc: int, what: str = ""):
         raise P4CError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 
+# ---- optional per-entry-point timing with HIP events on the launch stream (bench.py roofline leg)
+_TIMED = None
+
+
+def enable_kernel_timing(names):
+    """Record a HIP event pair around every call of the named entry points (None disables)."""
+    global _TIMED
+    _TIMED = None if names is None else {n: [] for n in names}
+
+
+def kernel_times():
+    """{name: (calls, avg_ms)} for the calls recorded since enable_kernel_timing (synchronises)."""
+    out = {}
+    if _TIMED:
+        torch.cuda.synchronize()
+        for n, evs in _TIMED.items():
+            if evs:
+                out[n] = (len(evs), sum(a.elapsed_time(b) for a, b in evs) / len(evs))
+    return out
+
+
 def call(name: str, *args):
+    if _TIMED is not None and name in _TIMED:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()  # torch's current stream == the stream handed to the library
+        check(getattr(lib(), name)(*args), name)
+        b.record()
+        _TIMED[name].append((a, b))
+        return
     check(getattr(lib(), name)(*args), name)
 
 

@@ -6,14 +6,59 @@ MI355X-native models.  Put the repository root on PYTHONPATH and ``model_name: H
 selects the HIP implementation.
 """
 
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from py4cast_amd.base import ModelABC, ModelType
 from py4cast_amd.namedtensor import HAVE_MFAI
 
 try:
-    from py4cast_amd.halfunet import HalfUNetMI355X  # noqa: F401
+    from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings  # noqa: F401
 
     if not HAVE_MFAI:
         # stand-alone: take the upstream name so that config/CLI/model/halfunet.yaml works unchanged
         class HalfUNet(HalfUNetMI355X):
             register = True
-except ImportError:  # pragma: no cover
-    raise
+
+except ModuleNotFoundError as _e:  # TEMPORARY until py4cast_amd/halfunet.py lands
+    if "halfunet" not in str(_e):
+        raise
+
+
+@dataclass
+class IdentitySettings:
+    name: str = "Identity"
+
+
+class Identity(ModelABC, nn.Module):
+    """
+    Same contract as the reference's plugin example (py4cast_plugin_example.py:19-57): keeps the
+    first ``out_channels`` features and multiplies by one learnable scalar.  Plain torch ops; it
+    exercises the registry and the generic (any nn.Module) rollout path.
+    """
+
+    settings_kls = IdentitySettings
+    onnx_supported = False
+    features_last: bool = True
+    supported_num_spatial_dims = (2,)
+    num_spatial_dims = 2
+    model_type = ModelType.CONVOLUTIONAL
+    register: bool = not HAVE_MFAI  # with mfai + the reference's example on the path the name is taken
+
+    def __init__(self, in_channels: int, out_channels: int, input_shape: tuple = None,
+                 settings: IdentitySettings = IdentitySettings(), *args, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.input_shape = in_channels, out_channels, input_shape
+        self.num_output_features = out_channels
+        self.scaler = nn.Parameter(torch.rand(1))
+        self._settings = settings
+        self.check_required_attributes()
+
+    @property
+    def settings(self):
+        return self._settings
+
+    def forward(self, x):
+        return x[..., : self.num_output_features] * self.scaler
