@@ -175,6 +175,73 @@ int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g
                            int kind, int mask_mode, void* dy, int dy_dtype, int y_cs, float* dprev, int64_t dprev_bs,
                            int B, int64_t N, int F, float keep_prev, p4c_stream_t stream);
 
+/* ====================================================================================
+ * Model kernels -- the network arithmetic the reference obtains from mfai v5.0.1
+ * (py4cast/models.py:10-20; model forward at py4cast/lightning.py:591-596) and, underneath,
+ * from cuDNN/cuBLAS.  Activations are (B,H,W,C) with C contiguous ("features last"), C a
+ * multiple of 32, fp32 unless a dtype argument says otherwise.
+ * ==================================================================================== */
+
+/* Re-order a canonical torch conv weight w[CO][CI][ks][ks] into the MFMA operand stream used by
+ * p4c_conv_fwd: out[M_pad/64][ks*ks][K_pad/8][2][64][4] (zero padded).
+ * transpose_flip=0: forward (M = CO, K = CI).  transpose_flip=1: data gradient (M = CI, K = CO, taps
+ * flipped), so the same conv kernel evaluates dL/dinput.  out needs M_pad*K_pad*ks*ks floats. */
+int p4c_prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, float* out,
+                     p4c_stream_t stream);
+
+/* "same" convolution (ks = 1 or 3, stride 1, zero padding) on the fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32): out[b,y,x,m] = sum_{tap,k} act(in)[b,y+dy,x+dx,k] * W[m][k][tap] (+ bias[m])
+ * with act(v) = relu?(v*in_scale[b,k] + in_shift[b,k]) applied while the input tile is staged
+ * (in_scale/in_shift: (B,CI) or NULL).  stat_partial (or NULL): per-tile channel sums,
+ * [B*tiles][2][64] floats with tiles = ceil(H/4)*ceil(W/32) -- the BatchNorm/GroupNorm statistics of
+ * the output, produced in the epilogue.  in: (B,H,W,CI), CI in {32,64,96}; out: (B,H,W,out_cs),
+ * m_blocks*64 channels written. */
+int p4c_conv_fwd(const void* in, int dtype, int CI, const float* wprep, int ks, const float* in_scale,
+                 const float* in_shift, int in_relu, const float* bias, void* out, int out_cs, float* stat_partial,
+                 int B, int H, int W, int m_blocks, p4c_stream_t stream);
+
+/* Weight gradient of the same convolution: grad[CO][CI][ks][ks] += sum_px act(in)[px+tap][ci] * dout[px][co].
+ * dout: (B,H,W,64).  workspace: p4c_conv_wgrad_workspace_bytes(CI_pad, ks) bytes (per-workgroup partials,
+ * reduced deterministically). */
+size_t p4c_conv_wgrad_workspace_bytes(int CI_pad, int ks);
+int p4c_conv_wgrad(const void* in, int dtype, int CI_pad, int ks, const float* in_scale, const float* in_shift,
+                   int in_relu, const void* dout, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
+                   p4c_stream_t stream);
+
+/* HalfUNet (the network behind `model_name: HalfUNet`, config/CLI/model/halfunet.yaml): 5 encoder
+ * blocks [conv3x3 -> norm -> ReLU] x2 at 64 filters with 2x2 max-pool between, all levels bilinearly
+ * up-sampled and summed, one decoder block, 1x1 output conv.  One call enqueues the whole
+ * forward (or backward) on the stream. */
+typedef struct p4c_halfunet_desc {
+    int32_t B, H, W;      /* H, W multiples of 16 */
+    int32_t cin;          /* real input channels */
+    int32_t cin_pad;      /* x is (B,H,W,cin_pad), cin_pad in {32,64,96}; channels >= cin must be zero */
+    int32_t cout;         /* real output channels (<= 64); y is (B,H,W,64), channels >= cout are zero */
+    int32_t dx_channels;  /* leading input channels whose gradient is returned (<= 64, 0 = none) */
+    int32_t dtype;        /* P4C_F32 */
+    int32_t norm;         /* 0 = BatchNorm2d, 1 = GroupNorm */
+    int32_t groups;       /* GroupNorm groups (divides 64) */
+    int32_t has_bias;     /* conv bias (settings.bias); only 0 is implemented */
+    float eps;
+    float momentum;
+} p4c_halfunet_desc;
+
+/* number of floats of the flat parameter vector, laid out in this order (canonical torch layouts):
+ *   for block in enc1..enc5, decoder: conv1.weight (64,cin_b,3,3), norm1.weight (64), norm1.bias (64),
+ *                                     conv2.weight (64,64,3,3),   norm2.weight (64), norm2.bias (64)
+ *   outconv.weight (cout,64,1,1)
+ * (cin_b = cin for enc1, 64 otherwise).  running: [12 norms][2 (mean,var)][64] floats. */
+int64_t p4c_halfunet_param_count(const p4c_halfunet_desc* d);
+/* saved_bytes: activations kept from forward for backward (one per forward call still awaiting its
+ * backward); scratch_bytes: transient buffers shareable between calls on one stream. */
+int p4c_halfunet_workspace_bytes(const p4c_halfunet_desc* d, size_t* saved_bytes, size_t* scratch_bytes);
+int p4c_halfunet_forward(const p4c_halfunet_desc* d, const void* x, const float* params, float* running, void* y,
+                         void* saved, void* scratch, int training, p4c_stream_t stream);
+/* dy: (B,H,W,64) (channels >= cout ignored); dx: (B,H,W,64) or NULL (first dx_channels channels valid);
+ * grads: flat, same layout as params, ACCUMULATED into (+=). */
+int p4c_halfunet_backward(const p4c_halfunet_desc* d, const void* x, const float* params, const void* dy, void* dx,
+                          float* grads, void* saved, void* scratch, int training, p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,8 +1,33 @@
 """ctypes signatures of the model-side entry points of include/py4cast_hip.h (see _lib.py)."""
 
-from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+import ctypes
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
-SIGNATURES = {}
-OTHER = {}
+
+class HalfUNetDesc(ctypes.Structure):
+    """struct p4c_halfunet_desc"""
+
+    _fields_ = [
+        ("B", c_int32), ("H", c_int32), ("W", c_int32),
+        ("cin", c_int32), ("cin_pad", c_int32), ("cout", c_int32), ("dx_channels", c_int32),
+        ("dtype", c_int32), ("norm", c_int32), ("groups", c_int32), ("has_bias", c_int32),
+        ("eps", c_float), ("momentum", c_float),
+    ]
+
+
+DP = ctypes.POINTER(HalfUNetDesc)
+
+SIGNATURES = {
+    "p4c_prep_weights": [P, I, I, I, I, I, I, P, P],
+    "p4c_conv_fwd": [P, I, I, P, I, P, P, I, P, P, I, P, I, I, I, I, P],
+    "p4c_conv_wgrad": [P, I, I, I, P, P, I, P, I, I, P, P, I, I, I, P],
+    "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
+    "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],
+    "p4c_halfunet_backward": [DP, P, P, P, P, P, P, P, I, P],
+}
+OTHER = {
+    "p4c_conv_wgrad_workspace_bytes": ([I, I], c_size_t),
+    "p4c_halfunet_param_count": ([DP], c_int64),
+}

@@ -1,0 +1,408 @@
+// fp32 convolution kernels of the HalfUNet path on gfx950 matrix cores:
+//   conv_fwd_f32   : 3x3 / 1x1 "same" convolution, NHWC, implicit GEMM on v_mfma_f32_32x32x2_f32
+//                    (exact fp32 products, fp32 accumulate), with the previous layer's
+//                    normalisation + ReLU applied while the input tile is staged (the normalised
+//                    activation is never materialised) and the per-channel sum / sum-of-squares of
+//                    the output produced in the epilogue (BatchNorm / GroupNorm statistics).
+//                    The same kernel evaluates the data gradient (weights flipped + transposed by
+//                    prep_weights).
+//   conv_wgrad_f32 : weight gradient, persistent workgroups accumulate dW[tap][ci][co] in registers
+//                    over their share of pixel tiles (K = pixels), one partial per workgroup,
+//                    reduced by wgrad_reduce (deterministic, no float atomics).
+//
+// Layout: activations (B,H,W,C) with C contiguous (the reference's NamedTensor layout, features
+// last), C a multiple of 32.  GEMM orientation is "weights x pixels": A = W (M = output channel),
+// B = input pixels (N = pixel), so an accumulator lane owns one pixel and 4 consecutive output
+// channels per register quad -> 16-byte NHWC stores straight from registers.
+//
+// K ordering: an MFMA 32x32x2 step consumes 2 channels (one per lane half h).  Channels are taken
+// in groups of 8: sub-step s of group q uses channel 8q + 4h + s, so each lane reads its 4 channels
+// of a pixel as ONE 16-byte LDS read (ds_read_b128) and its 4 weights as one 16-byte global load.
+#include "common.hpp"
+
+namespace p4c {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TW = 32;  // tile width in pixels = one MFMA N-tile
+
+// ---------------------------------------------------------------------------------------------
+// prep_weights: canonical torch weight w[CO][CI][KS][KS] -> MFMA A-operand stream
+//   out[mb][tap][q][h][m_l(64)][s(4)],  k = 8q + 4h + s,  m = 64 mb + m_l
+//   transpose_flip = 0: out = w[m][k][tap]               (forward:  M = co, K = ci)
+//   transpose_flip = 1: out = w[k][m][ntaps-1-tap]       (data grad: M = ci, K = co, taps flipped)
+// zero-filled outside the real channel counts.
+__global__ void prep_weights_kernel(const float* __restrict__ w, int CO, int CI, int ntaps, int transpose_flip,
+                                    int M_pad, int K_pad, float* __restrict__ out) {
+    const int total = M_pad * K_pad * ntaps;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int t = i;
+        const int s = t & 3; t >>= 2;
+        const int m_l = t & 63; t >>= 6;
+        const int h = t & 1; t >>= 1;
+        const int q = t % (K_pad / 8); t /= (K_pad / 8);
+        const int tap = t % ntaps;
+        const int mb = t / ntaps;
+        const int k = 8 * q + 4 * h + s, m = 64 * mb + m_l;
+        float v = 0.0f;
+        if (!transpose_flip) {
+            if (m < CO && k < CI) v = w[((int64_t)m * CI + k) * ntaps + tap];
+        } else {
+            if (k < CO && m < CI) v = w[((int64_t)k * CI + m) * ntaps + (ntaps - 1 - tap)];
+        }
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage a (LH x LW) halo tile of the NHWC input into LDS, applying v = relu?(v*scale[c]+shift[c]).
+// Rows of CI floats are padded to CIS = CI+4 so that the per-pixel 16-byte reads of one
+// ds_read_b128 lane group fall on 16 distinct bank quads.
+template <int CI, int LH, int LW, int HALO>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ in, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, int relu, float* lds, int b, int y0, int x0,
+                                           int H, int W, int in_cs, int sc_cs) {
+    constexpr int CIS = CI + 4;
+    constexpr int C4 = CI / 4;
+    constexpr int TOTAL = LH * LW * C4;
+    for (int idx = threadIdx.x; idx < TOTAL; idx += 256) {
+        const int pix = idx / C4, c4 = idx - pix * C4;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            v = *reinterpret_cast<const f32x4*>(in + (((int64_t)b * H + gy) * W + gx) * in_cs + 4 * c4);
+            if (scale) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * sc_cs + 4 * c4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (int64_t)b * sc_cs + 4 * c4);
+                v = v * sc + sh;
+            }
+            if (relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+        }
+        *reinterpret_cast<f32x4*>(lds + pix * CIS + 4 * c4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_fwd_f32: grid (tiles_x, tiles_y*B, M_pad/64), 256 threads; tile = TH x 32 pixels x 64 outputs.
+// wave w owns rows [w*RW, (w+1)*RW) of the tile (RW = TH/4), i.e. RW pixel-tiles x 2 channel-tiles.
+template <int CI, int KS, int TH>
+__global__ void __launch_bounds__(256)
+    conv_fwd_f32_kernel(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ in_scale,
+                        const float* __restrict__ in_shift, int in_relu, const float* __restrict__ bias,
+                        float* __restrict__ out, int out_cs, float* __restrict__ stat_partial, int H, int W) {
+    constexpr int HALO = KS / 2;
+    constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+    constexpr int CIS = CI + 4;
+    constexpr int RW = TH / 4;
+    constexpr int NTAPS = KS * KS;
+    constexpr int NQ = CI / 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tiles_y = (H + TH - 1) / TH;
+    const int b = blockIdx.y / tiles_y, ty = blockIdx.y - b * tiles_y;
+    const int y0 = ty * TH, x0 = blockIdx.x * TW;
+    const int mb = blockIdx.z;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    stage_tile<CI, LH, LW, HALO>(in, in_scale, in_shift, in_relu, lds, b, y0, x0, H, W, CI, CI);
+    __syncthreads();
+
+    f32x16 acc[2][RW];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < RW; ++pt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][pt][i] = 0.f;
+
+    const float* wbase = wp + (int64_t)mb * NTAPS * CI * 64 + (h * 64 + r) * 4;
+#pragma unroll 1
+    for (int tap = 0; tap < NTAPS; ++tap) {
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const float* wt = wbase + (int64_t)tap * NQ * 512;
+        const float* lt = lds + ((wv * RW + ky) * LW + (r + kx)) * CIS + 4 * h;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 a[2], bb[RW];
+            a[0] = *reinterpret_cast<const f32x4*>(wt + q * 512);
+            a[1] = *reinterpret_cast<const f32x4*>(wt + q * 512 + 128);
+#pragma unroll
+            for (int pt = 0; pt < RW; ++pt) bb[pt] = *reinterpret_cast<const f32x4*>(lt + pt * LW * CIS + 8 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < RW; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][s], bb[pt][s], acc[ct][pt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: C[co][px]; lane = pixel r (+ half h), register i -> co = (i&3) + 8*(i>>2) + 4*h
+    const int gx = x0 + r;
+    float s1[2][16], s2[2][16];
+    if (stat_partial) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s1[ct][i] = s2[ct][i] = 0.f;
+    }
+#pragma unroll
+    for (int pt = 0; pt < RW; ++pt) {
+        const int gy = y0 + wv * RW + pt;
+        const bool valid = (gy < H) && (gx < W);
+        float* orow = out + (((int64_t)b * H + gy) * W + gx) * out_cs + mb * 64 + 4 * h;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
+                if (bias) v += *reinterpret_cast<const f32x4*>(bias + mb * 64 + ct * 32 + 8 * g + 4 * h);
+                if (valid) *reinterpret_cast<f32x4*>(orow + ct * 32 + 8 * g) = v;
+                if (stat_partial && valid) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s1[ct][4 * g + j] += v[j];
+                        s2[ct][4 * g + j] += v[j] * v[j];
+                    }
+                }
+            }
+        }
+    }
+    if (stat_partial) {
+        // reduce over the 32 pixels of each lane half, then over the 4 waves through LDS
+        __syncthreads();  // all waves are done reading the input tile; reuse LDS
+        float* red = lds;  // [wave][stat][64]
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float a1 = s1[ct][i], a2 = s2[ct][i];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {
+                    a1 += __shfl_xor(a1, off, 64);
+                    a2 += __shfl_xor(a2, off, 64);
+                }
+                if (r == 0) {
+                    const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    red[(wv * 2 + 0) * 64 + co] = a1;
+                    red[(wv * 2 + 1) * 64 + co] = a2;
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int t = threadIdx.x;
+            const float v = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+            const int64_t tile = ((int64_t)blockIdx.y) * gridDim.x + blockIdx.x;
+            stat_partial[tile * 128 + t] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_wgrad_f32: persistent; grid = G workgroups, each loops over pixel tiles (4 x 32).
+//   dW[tap][ci][co] += sum_px In[px + tap][ci] * dOut[px][co]
+// GEMM per tap: A[i=ci][k=px] (lane = ci, half h = pixel parity), B[k=px][j=co] (lane = co).
+// wave w owns (ci-tile, co-tile) units {w, w+4, ...}; 9 accumulator tiles per unit.
+template <int CI, int KS>
+__global__ void __launch_bounds__(256, 1)
+    conv_wgrad_f32_kernel(const float* __restrict__ in, const float* __restrict__ in_scale,
+                          const float* __restrict__ in_shift, int in_relu, const float* __restrict__ dout,
+                          float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip) {
+    constexpr int TH = 4;
+    constexpr int HALO = KS / 2;
+    constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+    constexpr int CIS = CI + 4;
+    constexpr int DS = 64 + 4;
+    constexpr int NTAPS = KS * KS;
+    constexpr int UNITS = (CI / 32) * 2;
+    constexpr int UPW = (UNITS + 3) / 4;  // units per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lin = lds;
+    float* ldo = lds + LH * LW * CIS;
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * B;
+
+    f32x16 acc[UPW][NTAPS];
+#pragma unroll
+    for (int u = 0; u < UPW; ++u)
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][t][i] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x;
+        const int rest = tile / tiles_x;
+        const int ty = rest % tiles_y, b = rest / tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();  // previous tile fully consumed
+        stage_tile<CI, LH, LW, HALO>(in + ci_off, in_scale ? in_scale + ci_off : nullptr, in_shift ? in_shift + ci_off : nullptr, in_relu,
+                                     lin, b, y0, x0, H, W, in_cs, in_cs);
+        for (int idx = threadIdx.x; idx < TH * TW * 16; idx += 256) {
+            const int pix = idx >> 4, c4 = idx & 15;
+            const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy < H && gx < W) v = *reinterpret_cast<const f32x4*>(dout + (((int64_t)b * H + gy) * W + gx) * 64 + 4 * c4);
+            *reinterpret_cast<f32x4*>(ldo + pix * DS + 4 * c4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) {
+            const int unit = wv + 4 * u;
+            if (unit < UNITS) {
+                const int cit = unit >> 1, cot = unit & 1;
+#pragma unroll 2
+                for (int kp = 0; kp < TH * TW / 2; ++kp) {
+                    const int p = 2 * kp + h;  // this lane half's pixel of the K-step
+                    const int row = p >> 5, col = p & 31;
+                    const float bv = ldo[p * DS + cot * 32 + r];
+                    const float* ain = lin + (row * LW + col) * CIS + cit * 32 + r;
+#pragma unroll
+                    for (int t = 0; t < NTAPS; ++t) {
+                        const int ky = t / KS, kx = t - ky * KS;
+                        const float av = ain[(ky * LW + kx) * CIS];
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // C[ci][co]: lane = co (r), register i -> ci = (i&3) + 8*(i>>2) + 4*h
+    float* pbase = partial + (int64_t)blockIdx.x * NTAPS * part_cip * 64;
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+        const int unit = wv + 4 * u;
+        if (unit < UNITS) {
+            const int cit = unit >> 1, cot = unit & 1;
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ci = ci_off + cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    pbase[((int64_t)t * part_cip + ci) * 64 + cot * 32 + r] = acc[u][t][i];
+                }
+        }
+    }
+}
+
+// grad[co][ci][tap] += sum_g partial[g][tap][ci_pad][co_pad64]   (canonical torch layout, real channels only)
+// threads follow the partial layout (co fastest) so the G partial reads are coalesced.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int G, int ntaps, int CI_pad, int CO, int CI,
+                                    float* __restrict__ grad) {
+    const int total = ntaps * CI_pad * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int co = i & 63;
+    const int ci = (i >> 6) % CI_pad;
+    const int tap = i / (64 * CI_pad);
+    if (co >= CO || ci >= CI) return;
+    const float* p = partial + i;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += p[(int64_t)g * total];
+    grad[((int64_t)co * CI + ci) * ntaps + tap] += s;
+}
+
+template <int CI, int KS, int TH>
+static int launch_conv_fwd(const float* in, const float* wp, const float* in_scale, const float* in_shift, int in_relu,
+                           const float* bias, float* out, int out_cs, float* stat_partial, int B, int H, int W,
+                           int m_blocks, hipStream_t stream) {
+    constexpr int HALO = KS / 2;
+    constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+    size_t smem = (size_t)LH * LW * (CI + 4) * sizeof(float);
+    if (smem < 4 * 2 * 64 * sizeof(float)) smem = 4 * 2 * 64 * sizeof(float);
+    auto kern = conv_fwd_f32_kernel<CI, KS, TH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    hipLaunchKernelGGL(kern, dim3(tiles_x, tiles_y * B, m_blocks), dim3(256), smem, stream, in, wp, in_scale, in_shift,
+                       in_relu, bias, out, out_cs, stat_partial, H, W);
+    P4C_CHECK_LAUNCH("conv_fwd_f32");
+    return P4C_OK;
+}
+
+template <int CI, int KS>
+static int launch_conv_wgrad(const float* in, const float* in_scale, const float* in_shift, int in_relu,
+                             const float* dout, float* partial, int G, int B, int H, int W, int in_cs, int ci_off,
+                             int part_cip, hipStream_t stream) {
+    constexpr int HALO = KS / 2;
+    constexpr int LH = 4 + 2 * HALO, LW = TW + 2 * HALO;
+    const size_t smem = ((size_t)LH * LW * (CI + 4) + (size_t)4 * TW * 68) * sizeof(float);
+    auto kern = conv_wgrad_f32_kernel<CI, KS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), smem, stream, in, in_scale, in_shift, in_relu, dout, partial, B, H, W,
+                       in_cs, ci_off, part_cip);
+    P4C_CHECK_LAUNCH("conv_wgrad_f32");
+    return P4C_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side dispatchers used by the C ABI and by the HalfUNet plan
+int conv_fwd_f32(const float* in, int CI, const float* wp, int ks, const float* in_scale, const float* in_shift,
+                 int in_relu, const float* bias, float* out, int out_cs, float* stat_partial, int B, int H, int W,
+                 int m_blocks, hipStream_t stream) {
+#define P4C_CASE(ci, k)                                                                                              \
+    if (CI == ci && ks == k)                                                                                         \
+        return launch_conv_fwd<ci, k, 4>(in, wp, in_scale, in_shift, in_relu, bias, out, out_cs, stat_partial, B, H, \
+                                         W, m_blocks, stream);
+    P4C_CASE(32, 3) P4C_CASE(64, 3) P4C_CASE(96, 3) P4C_CASE(32, 1) P4C_CASE(64, 1) P4C_CASE(96, 1)
+#undef P4C_CASE
+    return fail(P4C_ERR_UNSUPPORTED, "conv_fwd_f32: unsupported (CI=%d, ks=%d): CI must be 32/64/96, ks 1/3", CI, ks);
+}
+
+int conv_wgrad_f32(const float* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
+                   const float* dout, float* partial, int G, int B, int H, int W, hipStream_t stream) {
+    // input channels are processed in chunks of 64 (+32): the 9 accumulator tiles per (ci,co) unit of a
+    // 96-channel chunk would not fit the register file without spilling.
+    if (CI % 32 != 0 || CI <= 0 || CI > 256) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_f32: unsupported CI=%d", CI);
+    if (ks != 1 && ks != 3) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_f32: unsupported ks=%d", ks);
+    for (int off = 0; off < CI;) {
+        const int chunk = (CI - off >= 64) ? 64 : 32;
+        int rc;
+        if (chunk == 64 && ks == 3)
+            rc = launch_conv_wgrad<64, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
+        else if (chunk == 32 && ks == 3)
+            rc = launch_conv_wgrad<32, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
+        else if (chunk == 64)
+            rc = launch_conv_wgrad<64, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
+        else
+            rc = launch_conv_wgrad<32, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
+        if (rc != P4C_OK) return rc;
+        off += chunk;
+    }
+    return P4C_OK;
+}
+
+int prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, float* out,
+                 hipStream_t stream) {
+    const int total = M_pad * K_pad * ks * ks;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, CO, CI, ks * ks,
+                       transpose_flip, M_pad, K_pad, out);
+    P4C_CHECK_LAUNCH("prep_weights");
+    return P4C_OK;
+}
+
+int wgrad_reduce(const float* partial, int G, int ks, int CI_pad, int CO, int CI, float* grad, hipStream_t stream) {
+    const int total = 64 * CI_pad * ks * ks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, G, ks * ks, CI_pad,
+                       CO, CI, grad);
+    P4C_CHECK_LAUNCH("wgrad_reduce");
+    return P4C_OK;
+}
+
+}  // namespace p4c

@@ -1,0 +1,39 @@
+// Internal host-side launchers shared between translation units (not part of the C ABI).
+#pragma once
+#include "common.hpp"
+
+namespace p4c {
+
+// conv_f32.hip
+int prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, float* out,
+                 hipStream_t stream);
+int conv_fwd_f32(const float* in, int CI, const float* wp, int ks, const float* in_scale, const float* in_shift,
+                 int in_relu, const float* bias, float* out, int out_cs, float* stat_partial, int B, int H, int W,
+                 int m_blocks, hipStream_t stream);
+int conv_wgrad_f32(const float* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
+                   const float* dout, float* partial, int G, int B, int H, int W, hipStream_t stream);
+int wgrad_reduce(const float* partial, int G, int ks, int CI_pad, int CO, int CI, float* grad, hipStream_t stream);
+
+// norm_pool.hip
+int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw, int mode, int groups, const float* gamma,
+                  const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                  float* shift, float* mean, float* rstd, hipStream_t stream);
+int norm_eval(int B, const float* gamma, const float* beta, float eps, const float* running_mean,
+              const float* running_var, float* scale, float* shift, float* mean, float* rstd, hipStream_t stream);
+int norm_bwd_blocks(int64_t hw);
+int norm_bwd(const float* dA, const float* y, const float* scale, const float* shift, const float* mean,
+             const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
+             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, float* dY, hipStream_t stream);
+int pool_fwd(const float* y, const float* scale, const float* shift, int B, int H, int W, float* P, hipStream_t stream);
+int upsum_fwd(const float* const* y, const float* const* scale, const float* const* shift, int B, int H, int W, float* S,
+              hipStream_t stream);
+int up_bwd_x(const float* dS, int B, int H, int W, int s, float* T, hipStream_t stream);
+int enc_out_bwd(const float* T, int Hfull, int s, const float* dS, const float* dP, const float* y, const float* scale,
+                const float* shift, int B, int Hk, int Wk, float* dA, hipStream_t stream);
+
+// tiles of the conv kernels (for sizing the statistics partial buffers)
+constexpr int CONV_TH = 4;
+constexpr int CONV_TW = 32;
+static inline int conv_tiles_per_sample(int H, int W) { return ((H + CONV_TH - 1) / CONV_TH) * ((W + CONV_TW - 1) / CONV_TW); }
+
+}  // namespace p4c

@@ -1,0 +1,446 @@
+// Normalisation (BatchNorm2d / GroupNorm), 2x2 max-pool and bilinear up-sample-and-sum kernels of the
+// HalfUNet path, forward and backward.  All HBM-bound streaming passes over NHWC tensors with
+// C = 64 channels: a thread owns 4 consecutive channels (16-byte accesses), 16 threads per pixel.
+//
+// "Deferred normalisation": a conv writes its RAW output y plus per-tile channel sums; the
+// normalised activation a = relu(y*scale[b,c] + shift[b,c]) is applied by whoever reads y next
+// (next conv's tile staging, the pool, the up-sample-and-sum, the backward passes) and is never
+// written to HBM.  scale/shift/mean/rstd are (B,64) arrays for both norm types (BatchNorm repeats
+// the same row for every b), so consumers are norm-agnostic.
+#include "common.hpp"
+
+namespace p4c {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int C = 64;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// norm_finalize: conv epilogue partials [B*tiles_per_sample][2][64] -> scale/shift/mean/rstd (B,64)
+//   mode 0 (BatchNorm2d, training): statistics over (B,H,W) per channel, biased variance for the
+//          normalisation, running stats updated with the unbiased one (torch semantics).
+//   mode 1 (GroupNorm): statistics over (H,W,channels of the group) per sample.
+// grid: mode 0 -> 64 blocks (one per channel); mode 1 -> B*groups blocks.  256 threads.
+__global__ void __launch_bounds__(256)
+    norm_finalize_kernel(const float* __restrict__ partial, int tiles_per_sample, int B, int64_t hw, int mode, int groups,
+                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                         float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ scale,
+                         float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double red[2][256];
+    double s1 = 0.0, s2 = 0.0;
+    int c_lo, c_hi, b_lo, b_hi;
+    if (mode == 0) {
+        c_lo = blockIdx.x; c_hi = c_lo + 1; b_lo = 0; b_hi = B;
+    } else {
+        const int cpg = C / groups;
+        const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+        c_lo = g * cpg; c_hi = c_lo + cpg; b_lo = b; b_hi = b + 1;
+    }
+    const int nc = c_hi - c_lo;
+    const int64_t ntile = (int64_t)(b_hi - b_lo) * tiles_per_sample;
+    for (int64_t i = threadIdx.x; i < ntile * nc; i += 256) {
+        const int64_t t = i / nc;
+        const int c = c_lo + (int)(i - t * nc);
+        const int64_t tile = (int64_t)b_lo * tiles_per_sample + t;
+        s1 += (double)partial[tile * 128 + c];
+        s2 += (double)partial[tile * 128 + 64 + c];
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    const double n = (double)(b_hi - b_lo) * (double)hw * (double)nc;
+    const double mean = red[0][0] / n;
+    double var = red[1][0] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (mode == 0) {
+        const int c = c_lo;
+        if (threadIdx.x == 0 && running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+        const float sc = gamma[c] * rstd, sh = beta[c] - (float)mean * sc;
+        for (int b = threadIdx.x; b < B; b += 256) {
+            scale[b * C + c] = sc; shift[b * C + c] = sh; mean_out[b * C + c] = (float)mean; rstd_out[b * C + c] = rstd;
+        }
+    } else {
+        for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+            const float sc = gamma[c] * rstd;
+            scale[b_lo * C + c] = sc; shift[b_lo * C + c] = beta[c] - (float)mean * sc;
+            mean_out[b_lo * C + c] = (float)mean; rstd_out[b_lo * C + c] = rstd;
+        }
+    }
+}
+
+// BatchNorm2d in eval mode: scale/shift from the running statistics.
+__global__ void norm_eval_kernel(int B, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                 const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                 float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                 float* __restrict__ rstd_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int c = i & 63;
+    const float rstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float sc = gamma[c] * rstd;
+    scale[i] = sc; shift[i] = beta[c] - running_mean[c] * sc; mean_out[i] = running_mean[c]; rstd_out[i] = rstd;
+}
+
+// ------------------------------------------------------------------------------------------
+// norm backward, pass 1: per-(b,c) sums of g and g*xhat, g = dA * (y*scale+shift > 0),
+// xhat = (y-mean)*rstd.  grid (nblk, B); partial [b][blk][2][64].
+__global__ void __launch_bounds__(256)
+    norm_bwd_reduce_kernel(const float* __restrict__ dA, const float* __restrict__ y, const float* __restrict__ scale,
+                           const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                           int relu, int64_t hw, float* __restrict__ partial) {
+    __shared__ float red[2][16][64];
+    const int b = blockIdx.y;
+    const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;  // 16 pixels per block iteration
+    const f32x4 sc = ld4(scale + b * C + 4 * c4), sh = ld4(shift + b * C + 4 * c4);
+    const f32x4 mu = ld4(mean + b * C + 4 * c4), rs = ld4(rstd + b * C + 4 * c4);
+    f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    const float* yb = y + (int64_t)b * hw * C;
+    const float* gb = dA + (int64_t)b * hw * C;
+    for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < hw; p += (int64_t)gridDim.x * 16) {
+        const f32x4 yv = ld4(yb + p * C + 4 * c4);
+        f32x4 g = ld4(gb + p * C + 4 * c4);
+        if (relu) {
+            const f32x4 pre = yv * sc + sh;
+            g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f;
+            g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+        }
+        a1 += g;
+        a2 += g * ((yv - mu) * rs);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][pl][4 * c4 + j] = a1[j];
+        red[1][pl][4 * c4 + j] = a2[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[st][k][c];
+        partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = s;
+    }
+}
+
+// pass 1b: reduce partials; accumulate dgamma/dbeta; emit per-(b,c) k1,k2 so that
+//   dY = rstd * (gamma*g - k1 - xhat*k2)          (training statistics)
+//   dY = scale * g  (k1 = k2 = 0)                 (eval-mode BatchNorm: statistics are constants)
+// one block of 64*... threads: grid = 1, block = 256 (c = tid&63, slice = tid>>6).
+__global__ void __launch_bounds__(256)
+    norm_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int B, int64_t hw, int mode, int groups,
+                             int training, const float* __restrict__ gamma, float* __restrict__ dgamma,
+                             float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2) {
+    __shared__ float S[2][4][64];   // slices
+    __shared__ float SB[2][64];     // per-sample sums (loop over b)
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    float tot1 = 0.f, tot2 = 0.f;  // over batch (thread sl==0 keeps them)
+    for (int b = 0; b < B; ++b) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = sl; k < nblk; k += 4) {
+            s1 += partial[(((int64_t)b * nblk + k) * 2 + 0) * 64 + c];
+            s2 += partial[(((int64_t)b * nblk + k) * 2 + 1) * 64 + c];
+        }
+        S[0][sl][c] = s1; S[1][sl][c] = s2;
+        __syncthreads();
+        if (sl == 0) {
+            s1 = (S[0][0][c] + S[0][1][c]) + (S[0][2][c] + S[0][3][c]);
+            s2 = (S[1][0][c] + S[1][1][c]) + (S[1][2][c] + S[1][3][c]);
+            tot1 += s1; tot2 += s2;
+            SB[0][c] = s1; SB[1][c] = s2;
+        }
+        __syncthreads();
+        if (mode == 1 && sl == 0) {  // GroupNorm: per-sample group means of gamma-weighted sums
+            const int cpg = C / groups, g0 = (c / cpg) * cpg;
+            float m1 = 0.f, m2 = 0.f;
+            for (int j = 0; j < cpg; ++j) {
+                m1 += gamma[g0 + j] * SB[0][g0 + j];
+                m2 += gamma[g0 + j] * SB[1][g0 + j];
+            }
+            const float n = (float)hw * (float)cpg;
+            k1[b * C + c] = m1 / n; k2[b * C + c] = m2 / n;
+        }
+        __syncthreads();
+    }
+    if (sl == 0) {
+        dgamma[c] += tot2;
+        dbeta[c] += tot1;
+        if (mode == 0) {
+            const float n = (float)B * (float)hw;
+            const float a = training ? gamma[c] * tot1 / n : 0.f, bb = training ? gamma[c] * tot2 / n : 0.f;
+            for (int b = 0; b < B; ++b) { k1[b * C + c] = a; k2[b * C + c] = bb; }
+        }
+    }
+}
+
+// pass 2: dY = rstd*(gamma*g - k1 - xhat*k2), written over dA (in place allowed).
+__global__ void __launch_bounds__(256)
+    norm_bwd_apply_kernel(const float* __restrict__ dA, const float* __restrict__ y, const float* __restrict__ scale,
+                          const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                          const float* __restrict__ gamma, const float* __restrict__ k1, const float* __restrict__ k2,
+                          int relu, int64_t hw, int B, float* __restrict__ dY) {
+    const int64_t total = (int64_t)B * hw * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i & 15);
+        const int64_t pix = i >> 4;
+        const int b = (int)(pix / hw);
+        const f32x4 yv = ld4(y + pix * C + 4 * c4);
+        f32x4 g = ld4(dA + pix * C + 4 * c4);
+        const f32x4 mu = ld4(mean + b * C + 4 * c4), rs = ld4(rstd + b * C + 4 * c4);
+        if (relu) {
+            const f32x4 pre = yv * ld4(scale + b * C + 4 * c4) + ld4(shift + b * C + 4 * c4);
+            g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f;
+            g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+        }
+        const f32x4 xh = (yv - mu) * rs;
+        const f32x4 r = rs * (ld4(gamma + 4 * c4) * g - ld4(k1 + b * C + 4 * c4) - xh * ld4(k2 + b * C + 4 * c4));
+        st4(dY + pix * C + 4 * c4, r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pool_fwd: P[b,Y,X,:] = max over the 2x2 window of relu(y*scale+shift)      (H,W even)
+__global__ void __launch_bounds__(256)
+    pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int B,
+                    int H, int W, float* __restrict__ P) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i & 15);
+        int64_t pix = i >> 4;
+        const int X = (int)(pix % Wo); pix /= Wo;
+        const int Y = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        const f32x4 sc = ld4(scale + b * C + 4 * c4), sh = ld4(shift + b * C + 4 * c4);
+        const float* base = y + (((int64_t)b * H + 2 * Y) * W + 2 * X) * C + 4 * c4;
+        f32x4 m = relu4(ld4(base) * sc + sh);
+        f32x4 v = relu4(ld4(base + C) * sc + sh);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        v = relu4(ld4(base + (int64_t)W * C) * sc + sh);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        v = relu4(ld4(base + (int64_t)W * C + C) * sc + sh);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        st4(P + (i >> 4) * C + 4 * c4, m);
+    }
+}
+
+// bilinear source index, torch semantics (align_corners=False, scale_factor given): src = (dst+0.5)/s - 0.5, clamped >= 0
+__device__ __forceinline__ void bilin(int dst, int s, int n_in, int& i0, int& i1, float& l1) {
+    float src = ((float)dst + 0.5f) / (float)s - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+struct UpLevels {
+    const float* y[5];      // raw conv outputs of enc1..enc5 (level k at H/2^k)
+    const float* scale[5];  // (B,64)
+    const float* shift[5];
+};
+
+// upsum_fwd: S[b,y,x,:] = sum_k up_{2^k}( relu(y_k*scale_k+shift_k) )   (k = 0..4)
+__global__ void __launch_bounds__(256) upsum_fwd_kernel(UpLevels lv, int B, int H, int W, float* __restrict__ S) {
+    const int64_t total = (int64_t)B * H * W * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i & 15);
+        int64_t pix = i >> 4;
+        const int x = (int)(pix % W); pix /= W;
+        const int yy = (int)(pix % H);
+        const int b = (int)(pix / H);
+        f32x4 acc = relu4(ld4(lv.y[0] + (i >> 4) * C + 4 * c4) * ld4(lv.scale[0] + b * C + 4 * c4) + ld4(lv.shift[0] + b * C + 4 * c4));
+#pragma unroll
+        for (int k = 1; k < 5; ++k) {
+            const int s = 1 << k, Hk = H >> k, Wk = W >> k;
+            int y0, y1, x0, x1; float ly, lx;
+            bilin(yy, s, Hk, y0, y1, ly);
+            bilin(x, s, Wk, x0, x1, lx);
+            const f32x4 sc = ld4(lv.scale[k] + b * C + 4 * c4), sh = ld4(lv.shift[k] + b * C + 4 * c4);
+            const float* base = lv.y[k] + (int64_t)b * Hk * Wk * C + 4 * c4;
+            const f32x4 v00 = relu4(ld4(base + ((int64_t)y0 * Wk + x0) * C) * sc + sh);
+            const f32x4 v01 = relu4(ld4(base + ((int64_t)y0 * Wk + x1) * C) * sc + sh);
+            const f32x4 v10 = relu4(ld4(base + ((int64_t)y1 * Wk + x0) * C) * sc + sh);
+            const f32x4 v11 = relu4(ld4(base + ((int64_t)y1 * Wk + x1) * C) * sc + sh);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            acc += hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);  // torch: w00*.. grouping by rows
+        }
+        st4(S + (i >> 4) * C + 4 * c4, acc);
+    }
+}
+
+// up_bwd_x: T[b,y,X,:] = sum_x wx(x,X) dS[b,y,x,:]   for one level (scale s); T is (B,H,W/s,64)
+__global__ void __launch_bounds__(256) up_bwd_x_kernel(const float* __restrict__ dS, int B, int H, int W, int s, float* __restrict__ T) {
+    const int Wk = W / s;
+    const int64_t total = (int64_t)B * H * Wk * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i & 15);
+        int64_t pix = i >> 4;
+        const int X = (int)(pix % Wk);
+        const int64_t row = pix / Wk;  // b*H + y
+        f32x4 acc = {0, 0, 0, 0};
+        int xa = s * X - s / 2, xb = s * X + 3 * s / 2 - 1;
+        if (xa < 0) xa = 0;
+        if (xb > W - 1) xb = W - 1;
+        for (int x = xa; x <= xb; ++x) {
+            int x0, x1; float lx;
+            bilin(x, s, Wk, x0, x1, lx);
+            const float w = (x0 == X ? 1.f - lx : 0.f) + (x1 == X ? lx : 0.f);
+            if (w != 0.f) acc += w * ld4(dS + (row * W + x) * C + 4 * c4);
+        }
+        st4(T + (i >> 4) * C + 4 * c4, acc);
+    }
+}
+
+// enc_out_bwd: gradient wrt the (post-ReLU) output of encoder level k (at Hk x Wk):
+//   dA = [T given]   sum_y wy(y,Y) T[b,y,X,:]          (adjoint of the bilinear up-sample, y pass)
+//      + [dS given]  dS[b,Y,X,:]                        (level 1: identity)
+//      + [dP given]  dP[b,Y/2,X/2,:] if (Y,X) is the arg-max of its 2x2 window of relu(y*scale+shift)
+//                    (first maximum in row-major order, as torch's max_pool2d)
+__global__ void __launch_bounds__(256)
+    enc_out_bwd_kernel(const float* __restrict__ T, int Hfull, int s, const float* __restrict__ dS,
+                       const float* __restrict__ dP, const float* __restrict__ y, const float* __restrict__ scale,
+                       const float* __restrict__ shift, int B, int Hk, int Wk, float* __restrict__ dA) {
+    const int64_t total = (int64_t)B * Hk * Wk * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i & 15);
+        int64_t pix = i >> 4;
+        const int X = (int)(pix % Wk); pix /= Wk;
+        const int Y = (int)(pix % Hk);
+        const int b = (int)(pix / Hk);
+        f32x4 acc = {0, 0, 0, 0};
+        if (dS) acc = ld4(dS + (i >> 4) * C + 4 * c4);
+        if (T) {
+            int ya = s * Y - s / 2, yb = s * Y + 3 * s / 2 - 1;
+            if (ya < 0) ya = 0;
+            if (yb > Hfull - 1) yb = Hfull - 1;
+            for (int yy = ya; yy <= yb; ++yy) {
+                int y0, y1; float ly;
+                bilin(yy, s, Hk, y0, y1, ly);
+                const float w = (y0 == Y ? 1.f - ly : 0.f) + (y1 == Y ? ly : 0.f);
+                if (w != 0.f) acc += w * ld4(T + (((int64_t)b * Hfull + yy) * Wk + X) * C + 4 * c4);
+            }
+        }
+        if (dP) {
+            const f32x4 sc = ld4(scale + b * C + 4 * c4), sh = ld4(shift + b * C + 4 * c4);
+            const int Y0 = Y & ~1, X0 = X & ~1;
+            const float* base = y + (((int64_t)b * Hk + Y0) * Wk + X0) * C + 4 * c4;
+            f32x4 v[4];
+            v[0] = relu4(ld4(base) * sc + sh);
+            v[1] = relu4(ld4(base + C) * sc + sh);
+            v[2] = relu4(ld4(base + (int64_t)Wk * C) * sc + sh);
+            v[3] = relu4(ld4(base + (int64_t)Wk * C + C) * sc + sh);
+            const int me = (Y & 1) * 2 + (X & 1);
+            const f32x4 g = ld4(dP + (((int64_t)b * (Hk / 2) + Y / 2) * (Wk / 2) + X / 2) * C + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int arg = 0;
+                float m = v[0][j];
+#pragma unroll
+                for (int q = 1; q < 4; ++q)
+                    if (v[q][j] > m) { m = v[q][j]; arg = q; }
+                if (arg == me) acc[j] += g[j];
+            }
+        }
+        st4(dA + (i >> 4) * C + 4 * c4, acc);
+    }
+}
+
+static inline int ew_grid(int64_t total_threads) {
+    int64_t blocks = (total_threads + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// ---------------------------------------------------------------------------------------------- host wrappers
+int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw, int mode, int groups, const float* gamma,
+                  const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                  float* shift, float* mean, float* rstd, hipStream_t stream) {
+    const int grid = mode == 0 ? C : B * groups;
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(grid), dim3(256), 0, stream, partial, tiles_per_sample, B, hw, mode,
+                       groups, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd);
+    P4C_CHECK_LAUNCH("norm_finalize");
+    return P4C_OK;
+}
+
+int norm_eval(int B, const float* gamma, const float* beta, float eps, const float* running_mean,
+              const float* running_var, float* scale, float* shift, float* mean, float* rstd, hipStream_t stream) {
+    hipLaunchKernelGGL(norm_eval_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, B, gamma, beta, eps,
+                       running_mean, running_var, scale, shift, mean, rstd);
+    P4C_CHECK_LAUNCH("norm_eval");
+    return P4C_OK;
+}
+
+int norm_bwd_blocks(int64_t hw) {
+    int64_t nblk = (hw + 16 * 8 - 1) / (16 * 8);  // >= 8 pixels per thread row
+    if (nblk > 512) nblk = 512;
+    if (nblk < 1) nblk = 1;
+    return (int)nblk;
+}
+
+int norm_bwd(const float* dA, const float* y, const float* scale, const float* shift, const float* mean,
+             const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
+             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, float* dY, hipStream_t stream) {
+    const int nblk = norm_bwd_blocks(hw);
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 0, stream, dA, y, scale, shift, mean, rstd, relu,
+                       hw, partial);
+    P4C_CHECK_LAUNCH("norm_bwd_reduce");
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, nblk, B, hw, mode, groups,
+                       training, gamma, dgamma, dbeta, k1, k2);
+    P4C_CHECK_LAUNCH("norm_bwd_finalize");
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid((int64_t)B * hw * 16)), dim3(256), 0, stream, dA, y, scale,
+                       shift, mean, rstd, gamma, k1, k2, relu, hw, B, dY);
+    P4C_CHECK_LAUNCH("norm_bwd_apply");
+    return P4C_OK;
+}
+
+int pool_fwd(const float* y, const float* scale, const float* shift, int B, int H, int W, float* P, hipStream_t stream) {
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * 16)), dim3(256), 0, stream, y, scale,
+                       shift, B, H, W, P);
+    P4C_CHECK_LAUNCH("pool_fwd");
+    return P4C_OK;
+}
+
+int upsum_fwd(const float* const* y, const float* const* scale, const float* const* shift, int B, int H, int W, float* S,
+              hipStream_t stream) {
+    UpLevels lv;
+    for (int k = 0; k < 5; ++k) { lv.y[k] = y[k]; lv.scale[k] = scale[k]; lv.shift[k] = shift[k]; }
+    hipLaunchKernelGGL(upsum_fwd_kernel, dim3(ew_grid((int64_t)B * H * W * 16)), dim3(256), 0, stream, lv, B, H, W, S);
+    P4C_CHECK_LAUNCH("upsum_fwd");
+    return P4C_OK;
+}
+
+int up_bwd_x(const float* dS, int B, int H, int W, int s, float* T, hipStream_t stream) {
+    hipLaunchKernelGGL(up_bwd_x_kernel, dim3(ew_grid((int64_t)B * H * (W / s) * 16)), dim3(256), 0, stream, dS, B, H, W, s, T);
+    P4C_CHECK_LAUNCH("up_bwd_x");
+    return P4C_OK;
+}
+
+int enc_out_bwd(const float* T, int Hfull, int s, const float* dS, const float* dP, const float* y, const float* scale,
+                const float* shift, int B, int Hk, int Wk, float* dA, hipStream_t stream) {
+    hipLaunchKernelGGL(enc_out_bwd_kernel, dim3(ew_grid((int64_t)B * Hk * Wk * 16)), dim3(256), 0, stream, T, Hfull, s, dS,
+                       dP, y, scale, shift, B, Hk, Wk, dA);
+    P4C_CHECK_LAUNCH("enc_out_bwd");
+    return P4C_OK;
+}
+
+}  // namespace p4c

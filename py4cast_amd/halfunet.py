@@ -1,0 +1,268 @@
+"""
+HalfUNet on MI355X: host-side wrapper (a py4cast model plugin) around the HIP plan
+``p4c_halfunet_forward / p4c_halfunet_backward`` (csrc/halfunet.cpp).
+
+Plugin contract: py4cast/models.py:23-89 and doc/add_features_contribute.md:19-30 of the
+reference -- ``ModelABC`` + ``nn.Module``, positional ctor ``(in_channels, out_channels,
+input_shape, settings)``, class attributes below.  The architecture and the parameter / buffer
+names follow mfai's ``HalfUNet`` (``encoder1.enc1conv1.weight`` ...; restated in
+oracle/halfunet.py, parity unpinned because mfai is absent from the reference checkout), so
+state_dicts are interchangeable with a torch-native HalfUNet.
+
+``features_last = True``: the model consumes and produces (B,H,W,C) tensors, the layout of the
+reference's NamedTensors, so the rollout hands its tensors over without a permute
+(lightning.py:591-596 permutes only for ``features_second`` models).  mfai's own HalfUNet
+is NCHW; the registry contract allows either.
+"""
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from ._lib_model import HalfUNetDesc
+from .base import ModelABC, ModelType
+
+NF = 64
+BLOCKS = ("enc1", "enc2", "enc3", "enc4", "enc5", "decoder")
+BLOCK_ATTR = ("encoder1", "encoder2", "encoder3", "encoder4", "encoder5", "decoder")
+
+
+@dataclass
+class HalfUNetSettings:
+    """mfai's HalfUNetSettings fields (config/CLI/model/halfunet.yaml:19-26) + the MI355X knobs."""
+
+    num_filters: int = 64
+    dilation: int = 1
+    bias: bool = False
+    use_ghost: bool = False
+    last_activation: str = "Identity"
+    absolute_pos_embed: bool = False
+    autopad_enabled: bool = False
+    # MI355X-specific
+    norm: str = "batch"  # "batch" (mfai) or "group" (GroupNorm, BASELINE.json north star)
+    groups: int = 8
+    compute_dtype: str = "f32"  # "f32": exact fp32 MFMA path
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+class _Holder(nn.Module):
+    """Parameter/buffer container giving mfai's dotted names."""
+
+
+class _HalfUNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, training, *params):
+        L.require_cuda(x)
+        B, H, W, C = x.shape
+        assert C == model.cin_pad and x.dtype == torch.float32 and x.is_contiguous()
+        desc = model._desc(B, H, W)
+        flat = model._flat_params()
+        saved_bytes, scratch = model._workspaces(desc, x.device)
+        saved = torch.empty(saved_bytes // 4, dtype=torch.float32, device=x.device)
+        y = torch.empty(B, H, W, NF, dtype=torch.float32, device=x.device)
+        L.call("p4c_halfunet_forward", ctypes.byref(desc), L.ptr(x), L.ptr(flat), L.ptr(model._running), L.ptr(y),
+               L.ptr(saved), L.ptr(scratch), int(training), L.stream(x.device))
+        ctx.model, ctx.desc, ctx.training = model, desc, training
+        ctx.save_for_backward(x, saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, saved = ctx.saved_tensors
+        model, desc = ctx.model, ctx.desc
+        dy = dy.contiguous()
+        flat = model._flat_params()
+        _, scratch = model._workspaces(desc, x.device)
+        gflat = torch.zeros_like(flat)
+        dx = torch.empty_like(dy) if desc.dx_channels > 0 else None
+        L.call("p4c_halfunet_backward", ctypes.byref(desc), L.ptr(x), L.ptr(flat), L.ptr(dy), L.ptr(dx), L.ptr(gflat),
+               L.ptr(saved), L.ptr(scratch), int(ctx.training), L.stream(x.device))
+        dxp = None
+        if dx is not None:
+            dxp = torch.zeros_like(x)
+            dxp[..., : desc.dx_channels] = dx[..., : desc.dx_channels]
+        grads = tuple(gflat[o : o + n].view(s) for (o, n, s) in model._param_slices)
+        return (dxp, None, None) + grads
+
+
+class HalfUNetMI355X(ModelABC, nn.Module):
+    settings_kls = HalfUNetSettings
+    onnx_supported = False
+    supported_num_spatial_dims = (2,)
+    num_spatial_dims = 2
+    features_last = True
+    model_type = ModelType.CONVOLUTIONAL
+    register = True
+    is_native_hip = True  # common_step: precision is handled by the kernels, no torch.autocast
+
+    def __init__(self, in_channels: int, out_channels: int, input_shape: Optional[Tuple[int, int]] = None,
+                 settings: HalfUNetSettings = HalfUNetSettings(), *args, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.input_shape = in_channels, out_channels, input_shape
+        self._settings = settings
+        unsupported = []
+        if settings.num_filters != NF:
+            unsupported.append(f"num_filters={settings.num_filters} (kernels are built for 64)")
+        if settings.dilation != 1:
+            unsupported.append(f"dilation={settings.dilation}")
+        if settings.bias:
+            unsupported.append("bias=True")
+        if settings.use_ghost:
+            unsupported.append("use_ghost=True")
+        if settings.last_activation != "Identity":
+            unsupported.append(f"last_activation={settings.last_activation}")
+        if settings.absolute_pos_embed:
+            unsupported.append("absolute_pos_embed=True")
+        if settings.norm not in ("batch", "group"):
+            unsupported.append(f"norm={settings.norm}")
+        if settings.compute_dtype not in ("f32",):
+            unsupported.append(f"compute_dtype={settings.compute_dtype}")
+        if out_channels > NF:
+            unsupported.append(f"out_channels={out_channels} > 64")
+        if pad32(in_channels) > 96:
+            unsupported.append(f"in_channels={in_channels} > 96")
+        if unsupported:
+            raise NotImplementedError("HalfUNetMI355X: unsupported settings: " + ", ".join(unsupported))
+        self.cin_pad = pad32(in_channels)
+        self.dx_channels = min(in_channels, NF)  # gradient wrt the leading (previous-state) channels
+        self.compute_dtype = torch.float32
+        self.timed_entry_points = ("p4c_halfunet_forward", "p4c_halfunet_backward", "p4c_build_x",
+                                   "p4c_ar_update_loss_fwd", "p4c_ar_update_loss_bwd")
+
+        # parameters in the order of p4c_halfunet_param_count (include/py4cast_hip.h)
+        self._param_slices = []
+        off = 0
+        norm_bufs = []
+        for bi, (blk, attr) in enumerate(zip(BLOCKS, BLOCK_ATTR)):
+            holder = _Holder()
+            for j in (1, 2):
+                cin = in_channels if (bi == 0 and j == 1) else NF
+                conv, norm = _Holder(), _Holder()
+                w = torch.empty(NF, cin, 3, 3)
+                nn.init.kaiming_uniform_(w, a=5**0.5)  # nn.Conv2d default init
+                conv.weight = nn.Parameter(w)
+                norm.weight = nn.Parameter(torch.ones(NF))
+                norm.bias = nn.Parameter(torch.zeros(NF))
+                if settings.norm == "batch":
+                    norm.register_buffer("running_mean", torch.zeros(NF))
+                    norm.register_buffer("running_var", torch.ones(NF))
+                    norm.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+                norm_bufs.append(norm)
+                setattr(holder, f"{blk}conv{j}", conv)
+                setattr(holder, f"{blk}norm{j}", norm)
+                for p in (conv.weight, norm.weight, norm.bias):
+                    self._param_slices.append((off, p.numel(), tuple(p.shape)))
+                    off += p.numel()
+            setattr(self, attr, holder)
+        self.outconv = _Holder()
+        w = torch.empty(out_channels, NF, 1, 1)
+        nn.init.kaiming_uniform_(w, a=5**0.5)
+        self.outconv.weight = nn.Parameter(w)
+        self._param_slices.append((off, w.numel(), tuple(w.shape)))
+        off += w.numel()
+        self._nparams = off
+        self._norms = norm_bufs
+        self._flat = None
+        self._running = None
+        self._scratch = {}
+        self.check_required_attributes()
+
+    @property
+    def settings(self):
+        return self._settings
+
+    # ---------------------------------------------------------------- flat views
+    def _ordered_params(self):
+        out = []
+        for blk, attr in zip(BLOCKS, BLOCK_ATTR):
+            holder = getattr(self, attr)
+            for j in (1, 2):
+                conv, norm = getattr(holder, f"{blk}conv{j}"), getattr(holder, f"{blk}norm{j}")
+                out += [conv.weight, norm.weight, norm.bias]
+        out.append(self.outconv.weight)
+        return out
+
+    def _flat_params(self) -> torch.Tensor:
+        """One flat fp32 buffer holding every parameter (the named nn.Parameters are views of it)."""
+        params = self._ordered_params()
+        dev = params[0].device
+        ok = self._flat is not None and self._flat.device == dev
+        if ok:
+            base = self._flat.data_ptr()
+            for p, (o, n, _) in zip(params, self._param_slices):
+                if p.data_ptr() != base + 4 * o:
+                    ok = False
+                    break
+        if not ok:  # first use, or the module was moved / a state_dict replaced storages: re-flatten
+            flat = torch.empty(self._nparams, dtype=torch.float32, device=dev)
+            for p, (o, n, s) in zip(params, self._param_slices):
+                flat[o : o + n].copy_(p.data.reshape(-1))
+                p.data = flat[o : o + n].view(s)
+            self._flat = flat
+        return self._flat
+
+    def _running_stats(self, device) -> torch.Tensor:
+        """[12][2][64] flat running statistics, aliased by the named BatchNorm buffers."""
+        if self._settings.norm != "batch":
+            if self._running is None or self._running.device != device:
+                self._running = torch.zeros(12 * 128, device=device)
+            return self._running
+        ok = self._running is not None and self._running.device == device
+        if ok:
+            base = self._running.data_ptr()
+            for i, nb in enumerate(self._norms):
+                if nb.running_mean.data_ptr() != base + 4 * (i * 128) or nb.running_var.data_ptr() != base + 4 * (i * 128 + 64):
+                    ok = False
+                    break
+        if not ok:
+            r = torch.empty(12 * 128, dtype=torch.float32, device=device)
+            for i, nb in enumerate(self._norms):
+                r[i * 128 : i * 128 + 64].copy_(nb.running_mean)
+                r[i * 128 + 64 : i * 128 + 128].copy_(nb.running_var)
+                nb.running_mean = r[i * 128 : i * 128 + 64]
+                nb.running_var = r[i * 128 + 64 : i * 128 + 128]
+            self._running = r
+        return self._running
+
+    def _desc(self, B, H, W) -> HalfUNetDesc:
+        if H % 16 or W % 16:
+            raise L.P4CError(f"HalfUNetMI355X: grid {H}x{W} must be a multiple of 16 in both dimensions")
+        s = self._settings
+        return HalfUNetDesc(B, H, W, self.in_channels, self.cin_pad, self.out_channels, self.dx_channels, L.F32,
+                            0 if s.norm == "batch" else 1, s.groups, 0, 1e-5, 0.1)
+
+    def _workspaces(self, desc, device):
+        key = (desc.B, desc.H, desc.W, str(device))
+        hit = self._scratch.get(key)
+        if hit is None:
+            sb, cb = ctypes.c_size_t(), ctypes.c_size_t()
+            L.call("p4c_halfunet_workspace_bytes", ctypes.byref(desc), ctypes.byref(sb), ctypes.byref(cb))
+            hit = (sb.value, torch.empty(cb.value // 4, dtype=torch.float32, device=device))
+            self._scratch = {key: hit}  # one shape at a time
+        return hit
+
+    # ---------------------------------------------------------------- nn.Module API
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (B,H,W,in_channels) -> (B,H,W,out_channels)."""
+        L.require_cuda(x)
+        if x.shape[-1] == self.in_channels and self.cin_pad != self.in_channels:
+            x = torch.nn.functional.pad(x, (0, self.cin_pad - self.in_channels))
+        elif x.shape[-1] != self.cin_pad:
+            raise L.P4CError(f"HalfUNetMI355X: expected {self.in_channels} (or padded {self.cin_pad}) channels, got {x.shape[-1]}")
+        x = x.contiguous().float()
+        self._running = self._running_stats(x.device)
+        training = self.training
+        if training and self._settings.norm == "batch":
+            torch._foreach_add_([nb.num_batches_tracked for nb in self._norms], 1)
+        y = _HalfUNetFn.apply(x, self, training, *self._ordered_params())
+        return y[..., : self.out_channels]
+
+    def roofline(self, ktimes, B, H, W):
+        return None
