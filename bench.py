@@ -211,6 +211,7 @@ def main():
     timed = getattr(lm.model, "timed_entry_points", None) or (
         "p4c_build_x", "p4c_ar_update_fwd", "p4c_weighted_loss_fwd", "p4c_weighted_loss_bwd", "p4c_ar_update_bwd")
     L.enable_kernel_timing(timed)
+    L.lib().p4c_prof_enable(3, 4096)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -219,6 +220,8 @@ def main():
     dt = time.perf_counter() - t0
     ktimes = L.kernel_times()
     L.enable_kernel_timing(None)
+    roof_model = lm.model.roofline(ktimes, B=B, H=H, W=W) if (rank == 0 and hasattr(lm.model, "roofline")) else None
+    L.lib().p4c_prof_enable(0, 0)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -228,9 +231,9 @@ def main():
         N = H * W
         c_in = F + Fs + Ff
         roof = None
-        if hasattr(lm.model, "roofline"):
-            roof = lm.model.roofline(ktimes, B=B, H=H, W=W)
-        if roof is None and ktimes:
+        if roof_model is not None:
+            roof = roof_model
+        if roof is None and ktimes and not hasattr(lm.model, "roofline"):
             # HBM-bound rollout kernels: algorithmic bytes per launch
             alg = {
                 "p4c_build_x": 4.0 * B * N * (2 * c_in),

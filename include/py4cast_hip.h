@@ -60,6 +60,18 @@ const char* p4c_last_error(void);
 /* number of compute units of the current device (persistent-grid sizing, bench reporting) */
 int p4c_num_cus(void);
 
+/* Per-launch kernel timing for the bench harness (HIP events recorded on the launch stream, around
+ * every launch of the tagged kernels, including those issued inside p4c_halfunet_forward/backward).
+ * Disabled by default; p4c_prof_enable(0,0) disables and frees the events.  Not graph-capturable while on.
+ * `units` of a record = output pixels (B*H*W) of that launch. */
+enum p4c_prof_tag {
+    P4C_PROF_CONV3X3_C64 = 1, /* conv 3x3, 64 -> 64 channels (forward and data-gradient launches) */
+    P4C_PROF_WGRAD3X3_C64 = 2 /* weight gradient of the same */
+};
+int p4c_prof_enable(int tag_mask, int max_records);
+/* sums over the finished records of `tag` with units >= min_units; synchronises on their events */
+int p4c_prof_collect(int tag, int64_t min_units, double* total_ms, int* count, double* total_units);
+
 /* ------------------------------------------------------------------------------------
  * K1  build_x  -- replaces AutoRegressiveLightning._next_x (lightning.py:711-767) and the
  * layout handling around the model call (lightning.py:586-596).

@@ -88,7 +88,7 @@ def combined_loss(
     with kwargs the arguments of weighted_loss / scaled_loss besides (prediction,target,mask).
     """
     shape = prediction.shape[:2] if reduce_spatial_dim else prediction.shape[:-1]
-    total = torch.zeros(shape, dtype=prediction.dtype)
+    total = torch.zeros(shape, dtype=prediction.dtype, device=prediction.device)
     for name, weight, kw in members:
         if name == "WeightedLoss":
             total += weight * weighted_loss(prediction, target, mask, reduce_spatial_dim=reduce_spatial_dim, **kw)

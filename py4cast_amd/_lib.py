@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpy4cast_hip.so")
 
 F32, BF16 = 0, 1
+PROF_CONV3X3_C64, PROF_WGRAD3X3_C64 = 1, 2
 LOSS_MSE, LOSS_L1 = 0, 1
 MASK_NONE, MASK_FROM_NAN, MASK_F32, MASK_U8 = 0, 1, 2, 3
 
@@ -44,6 +45,8 @@ OTHER = {
     "p4c_last_error": ([], c_char_p),
     "p4c_num_cus": ([], c_int),
     "p4c_loss_workspace_bytes": ([I, I, L, I], c_size_t),
+    "p4c_prof_enable": ([I, I], c_int),
+    "p4c_prof_collect": ([I, L, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)], c_int),
 }
 
 _lib = None

@@ -40,6 +40,11 @@ static inline hipStream_t as_stream(p4c_stream_t s) { return reinterpret_cast<hi
 // Number of CUs of the current device (cached).  Used to size persistent grids.
 int num_cus();
 
+// Optional per-launch timing of selected kernels with HIP events recorded on the launch stream
+// (bench.py roofline leg; see p4c_prof_enable in include/py4cast_hip.h).  No-ops unless enabled.
+void prof_begin(int tag, int64_t units, hipStream_t stream);
+void prof_end(int tag, hipStream_t stream);
+
 // ---------------------------------------------------------------- device helpers
 typedef __hip_bfloat16 bf16;
 

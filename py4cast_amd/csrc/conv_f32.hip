@@ -326,8 +326,11 @@ static int launch_conv_fwd(const float* in, const float* wp, const float* in_sca
         attr_set = true;
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int tag = (CI == 64 && KS == 3 && m_blocks == 1) ? P4C_PROF_CONV3X3_C64 : 0;
+    if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
     hipLaunchKernelGGL(kern, dim3(tiles_x, tiles_y * B, m_blocks), dim3(256), smem, stream, in, wp, in_scale, in_shift,
                        in_relu, bias, out, out_cs, stat_partial, H, W);
+    if (tag) prof_end(tag, stream);
     P4C_CHECK_LAUNCH("conv_fwd_f32");
     return P4C_OK;
 }
@@ -345,8 +348,11 @@ static int launch_conv_wgrad(const float* in, const float* in_scale, const float
         P4C_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
+    const int tag = (CI == 64 && KS == 3 && in_cs == 64) ? P4C_PROF_WGRAD3X3_C64 : 0;
+    if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), smem, stream, in, in_scale, in_shift, in_relu, dout, partial, B, H, W,
                        in_cs, ci_off, part_cip);
+    if (tag) prof_end(tag, stream);
     P4C_CHECK_LAUNCH("conv_wgrad_f32");
     return P4C_OK;
 }

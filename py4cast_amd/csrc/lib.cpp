@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include <mutex>
+#include <vector>
 
 #include "common.hpp"
 
@@ -32,7 +33,60 @@ int num_cus() {
     return cus;
 }
 
+// ---- kernel timing (disabled by default)
+struct ProfRec { hipEvent_t a, b; int tag; int64_t units; bool open; };
+static std::vector<ProfRec> g_prof;
+static int g_prof_mask = 0;
+static size_t g_prof_cap = 0;
+static std::mutex g_prof_mu;
+
+void prof_begin(int tag, int64_t units, hipStream_t stream) {
+    if (!(g_prof_mask & tag)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.size() >= g_prof_cap) return;
+    ProfRec r{nullptr, nullptr, tag, units, true};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, stream);
+    g_prof.push_back(r);
+}
+
+void prof_end(int tag, hipStream_t stream) {
+    if (!(g_prof_mask & tag)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = g_prof.size(); i-- > 0;)
+        if (g_prof[i].tag == tag && g_prof[i].open) {
+            (void)hipEventRecord(g_prof[i].b, stream);
+            g_prof[i].open = false;
+            return;
+        }
+}
+
 }  // namespace p4c
+
+extern "C" int p4c_prof_enable(int tag_mask, int max_records) {
+    std::lock_guard<std::mutex> lk(p4c::g_prof_mu);
+    for (auto& r : p4c::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    p4c::g_prof.clear();
+    p4c::g_prof_mask = tag_mask;
+    p4c::g_prof_cap = max_records > 0 ? (size_t)max_records : 0;
+    return P4C_OK;
+}
+
+extern "C" int p4c_prof_collect(int tag, int64_t min_units, double* total_ms, int* count, double* total_units) {
+    std::lock_guard<std::mutex> lk(p4c::g_prof_mu);
+    double ms = 0.0, units = 0.0;
+    int n = 0;
+    for (auto& r : p4c::g_prof) {
+        if (r.tag != tag || r.open || r.units < min_units) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; units += (double)r.units; ++n; }
+    }
+    if (total_ms) *total_ms = ms;
+    if (count) *count = n;
+    if (total_units) *total_units = units;
+    return P4C_OK;
+}
 
 extern "C" int p4c_version(void) { return P4C_VERSION; }
 extern "C" const char* p4c_last_error(void) { return p4c::err_buf(); }

@@ -133,16 +133,19 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) partial[(int64_t)bt * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// out[bt*out_stride] = sum(partials) / (num_interior - masked)
-__global__ void weighted_loss_final_kernel(const float* __restrict__ partial, int nblk, float num_interior,
-                                           const int32_t* __restrict__ masked_count, float* __restrict__ out,
-                                           int64_t out_stride, int nbt) {
-    const int bt = blockIdx.x * blockDim.x + threadIdx.x;
+// out[bt*out_stride] = sum(partials) / (num_interior - masked); one wave per (b,t), fixed summation order
+__global__ void __launch_bounds__(64) weighted_loss_final_kernel(const float* __restrict__ partial, int nblk, float num_interior,
+                                                                 const int32_t* __restrict__ masked_count,
+                                                                 float* __restrict__ out, int64_t out_stride, int nbt) {
+    const int bt = blockIdx.x;
     if (bt >= nbt) return;
     float s = 0.0f;
-    for (int i = 0; i < nblk; ++i) s += partial[(int64_t)bt * nblk + i];
-    const float denom = num_interior - (masked_count ? (float)(*masked_count) : 0.0f);
-    out[(int64_t)bt * out_stride] = s / denom;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += partial[(int64_t)bt * nblk + i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        const float denom = num_interior - (masked_count ? (float)(*masked_count) : 0.0f);
+        out[(int64_t)bt * out_stride] = s / denom;
+    }
 }
 
 // ------------------------------------------------------------------ weighted loss map (no spatial reduce)
@@ -454,7 +457,7 @@ extern "C" int p4c_weighted_loss_fwd(const float* pred, int64_t pred_bs, int64_t
                        pred_ts, target, tgt_bs, tgt_ts, ma, mbs, mts, weights, interior_mask, kind, (float*)workspace, T,
                        N, F, FP, iters);
     P4C_CHECK_LAUNCH("p4c_weighted_loss_fwd(partial)");
-    hipLaunchKernelGGL(weighted_loss_final_kernel, dim3((B * T + 63) / 64), dim3(64), 0, as_stream(stream),
+    hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B * T), dim3(64), 0, as_stream(stream),
                        (const float*)workspace, nblk, num_interior, masked_count, out, (int64_t)1, B * T);
     P4C_CHECK_LAUNCH("p4c_weighted_loss_fwd(final)");
     return P4C_OK;
@@ -548,7 +551,7 @@ extern "C" int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const 
         return fail(P4C_ERR_INVALID, "p4c_ar_update_loss_fwd: bad dtype %d", y_dtype);
 #undef P4C_LAUNCH_FWD
     P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd");
-    hipLaunchKernelGGL(weighted_loss_final_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream),
+    hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B), dim3(64), 0, as_stream(stream),
                        (const float*)workspace, nblk, num_interior, masked_count, loss_out, loss_stride, B);
     P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(final)");
     return P4C_OK;

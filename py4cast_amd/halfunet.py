@@ -264,5 +264,151 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         y = _HalfUNetFn.apply(x, self, training, *self._ordered_params())
         return y[..., : self.out_channels]
 
+    # ---------------------------------------------------------------- native rollout (one autograd node)
+    def native_rollout(self, lm, batch, std, mean, border_flat, interior_flat, force_border):
+        """
+        Whole training/validation rollout of AutoRegressiveLightning._common_step (lightning.py:565-662) as ONE
+        autograd node: per AR step K1 (build x, padded layout) -> HalfUNet plan -> fused state update + border
+        forcing + weighted loss, and the matching reverse sweep (BPTT) enqueued back to back from Python with no
+        autograd bookkeeping in between.  Returns the (B,T,*S,F) prediction, with ``fused_loss`` (B,T) attached
+        when the configured loss is a single WeightedLoss.  Returns None when the configuration is not covered
+        (the caller then takes the generic per-op path).
+        """
+        from .losses import WeightedLoss
+
+        if batch.num_input_steps != 1 or batch.inputs.tensor.dim() != 5:
+            return None
+        members = getattr(lm.loss, "losses", [])
+        if len(members) != 1 or not isinstance(members[0][0], WeightedLoss):
+            return None
+        wl, wl_weight = members[0]
+        weights = wl.weights(tuple(batch.outputs.feature_names), batch.inputs.tensor.device)
+        mode = L.MASK_FROM_NAN if lm.mask_on_nan else L.MASK_NONE
+        self._running = self._running_stats(batch.inputs.tensor.device)
+        training = self.training
+        if training and self._settings.norm == "batch":
+            torch._foreach_add_([nb.num_batches_tracked for nb in self._norms], batch.num_pred_steps)
+        pred, loss = _NativeRolloutFn.apply(
+            self, lm, batch.inputs.tensor, batch.forcing.tensor, batch.outputs.tensor,
+            lm.grid_static_features[: batch.batch_size], std, mean, border_flat, interior_flat, bool(force_border),
+            weights, float(wl.num_interior), wl.kind, mode, training, torch.is_grad_enabled(), *self._ordered_params())
+        pred.fused_loss = loss * wl_weight
+        return pred
+
     def roofline(self, ktimes, B, H, W):
-        return None
+        """bench.py: achieved TFLOP/s of the dominant kernel (conv 3x3 64->64 at full resolution, forward and
+        data-gradient launches) from the per-launch HIP-event timings collected by p4c_prof_*."""
+        ms, n, units = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+        L.lib().p4c_prof_collect(L.PROF_CONV3X3_C64, B * H * W, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(units))
+        if n.value == 0:
+            return None
+        flops = 2.0 * 9 * 64 * 64 * units.value  # algorithmic: 2*taps*Cin*Cout per output pixel
+        tflops = flops / (ms.value * 1e-3) / 1e12
+        peak = 157.3  # fp32 matrix peak, MI355X_MICROARCH.md
+        wms, wn, wunits = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+        L.lib().p4c_prof_collect(L.PROF_WGRAD3X3_C64, B * H * W, ctypes.byref(wms), ctypes.byref(wn), ctypes.byref(wunits))
+        out = {"bound": "mfma", "kernel": "conv_fwd_f32_kernel<64,3,4> (3x3 conv 64->64, fwd + data-grad launches)",
+               "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
+               "avg_launch_ms": ms.value / n.value, "launches": n.value,
+               "flops_per_launch": flops / n.value}
+        if wn.value:
+            out["wgrad_kernel"] = {"avg_launch_ms": wms.value / wn.value, "launches": wn.value,
+                                   "achieved": 2.0 * 9 * 64 * 64 * wunits.value / (wms.value * 1e-3) / 1e12}
+        return out
+
+
+class _NativeRolloutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, lm, inputs, forcing, outputs, statics, std, mean, border_flat, interior_flat, force_border,
+                weights, num_interior, kind, mask_mode, training, keep_saved, *params):
+        L.require_cuda(inputs, forcing, outputs)
+        dev = inputs.device
+        B, T = outputs.shape[0], outputs.shape[1]
+        H, W, F = inputs.shape[2], inputs.shape[3], inputs.shape[4]
+        N = H * W
+        Fs, Ff = statics.shape[-1], forcing.shape[-1]
+        inputs, forcing, outputs = inputs.float().contiguous(), forcing.float().contiguous(), outputs.float().contiguous()
+        st = statics.float()
+        sbs = 0 if st.stride(0) == 0 else N * Fs
+        st = st[0].contiguous() if sbs == 0 else st.contiguous()
+        desc = model._desc(B, H, W)
+        flat = model._flat_params()
+        saved_bytes, scratch = model._workspaces(desc, dev)
+        cpad = model.cin_pad
+        mask_on_nan = int(mask_mode == L.MASK_FROM_NAN)
+        count = None
+        if mask_on_nan:
+            count = torch.empty(1, dtype=torch.int32, device=dev)
+            L.call("p4c_mask_all_zero_count", L.ptr(outputs), mask_mode, T * N * F, N * F, B, T, N, F, L.ptr(count), L.stream(dev))
+        # state buffer: slot 0 = input state, slot i+1 = new state of AR step i (= prediction[:, i])
+        states = torch.empty(B, T + 1, H, W, F, dtype=torch.float32, device=dev)
+        states[:, 0].copy_(inputs[:, 0])
+        sbs_state = (T + 1) * N * F
+        loss = torch.empty(B, T, dtype=torch.float32, device=dev)
+        ws = torch.empty(L.lib().p4c_loss_workspace_bytes(B, 1, N, 1) // 4, dtype=torch.float32, device=dev)
+        xs, saveds = [], []
+        y = torch.empty(B, H, W, NF, dtype=torch.float32, device=dev)
+        stream = L.stream(dev)
+        saved = None
+        for i in range(T):
+            x = torch.empty(B, H, W, cpad, dtype=torch.float32, device=dev)
+            L.call("p4c_build_x", L.ptr(states[:, i]), sbs_state, N * F, L.ptr(st), sbs, L.ptr(forcing[:, i]), T * N * Ff,
+                   L.ptr(x), L.F32, cpad, B, 1, N, F, Fs, Ff, mask_on_nan, 0, stream)
+            if saved is None or keep_saved:
+                saved = torch.empty(saved_bytes // 4, dtype=torch.float32, device=dev)
+            L.call("p4c_halfunet_forward", ctypes.byref(desc), L.ptr(x), L.ptr(flat), L.ptr(model._running), L.ptr(y),
+                   L.ptr(saved), L.ptr(scratch), int(training), stream)
+            L.call("p4c_ar_update_loss_fwd", L.ptr(states[:, i]), sbs_state, L.ptr(y), L.F32, NF, L.ptr(outputs[:, i]),
+                   T * N * F, L.ptr(std), L.ptr(mean), L.ptr(border_flat if force_border else None), L.ptr(interior_flat),
+                   L.ptr(states[:, i + 1]), sbs_state, L.ptr(weights), num_interior, L.ptr(count), kind, mask_mode,
+                   L.ptr(loss[:, i]), T, L.ptr(ws), B, N, F, 1.0, stream)
+            if keep_saved:
+                xs.append(x)
+                saveds.append(saved)
+        ctx.model, ctx.desc, ctx.training = model, desc, training
+        ctx.meta = (B, T, H, W, F, force_border, num_interior, kind, mask_mode)
+        ctx.tensors = (states, outputs, std, interior_flat, weights, count, xs, saveds)
+        ctx.set_materialize_grads(False)
+        pred = states[:, 1:]
+        return pred, loss
+
+    @staticmethod
+    def backward(ctx, g_pred, g_loss):
+        model, desc = ctx.model, ctx.desc
+        B, T, H, W, F, force_border, num_interior, kind, mask_mode = ctx.meta
+        states, outputs, std, interior_flat, weights, count, xs, saveds = ctx.tensors
+        dev = states.device
+        N = H * W
+        stream = L.stream(dev)
+        flat = model._flat_params()
+        _, scratch = model._workspaces(desc, dev)
+        gflat = torch.zeros_like(flat)
+        dy = torch.empty(B, H, W, NF, dtype=torch.float32, device=dev)
+        dx = torch.empty(B, H, W, NF, dtype=torch.float32, device=dev)
+        dprev = torch.empty(B, H, W, F, dtype=torch.float32, device=dev)
+        gl = g_loss.contiguous().float() if g_loss is not None else None
+        sbs_state = (T + 1) * N * F
+        desc0 = HalfUNetDesc.from_buffer_copy(desc)
+        desc0.dx_channels = 0  # the input state of step 0 is data: no gradient needed, skip that conv
+        have_next = False
+        for i in range(T - 1, -1, -1):
+            g_next = dprev if have_next else None
+            if g_pred is not None:  # somebody differentiates through the prediction itself: add its slice
+                if g_next is None:
+                    dprev.copy_(g_pred[:, i])
+                else:
+                    dprev.add_(g_pred[:, i])
+                g_next = dprev
+            L.call("p4c_ar_update_loss_bwd", L.ptr(g_next), N * F, L.ptr(dx if have_next else None), L.F32, NF,
+                   L.ptr(gl[:, i]) if gl is not None else None, T, L.ptr(states[:, i + 1]), sbs_state, L.ptr(outputs[:, i]),
+                   T * N * F, L.ptr(std), L.ptr(interior_flat), int(force_border), L.ptr(weights), num_interior,
+                   L.ptr(count), kind, mask_mode, L.ptr(dy), L.F32, NF, L.ptr(dprev) if i > 0 else None, N * F, B, N, F,
+                   1.0, stream)
+            d = desc if i > 0 else desc0
+            L.call("p4c_halfunet_backward", ctypes.byref(d), L.ptr(xs[i]), L.ptr(flat), L.ptr(dy),
+                   L.ptr(dx) if i > 0 else None, L.ptr(gflat), L.ptr(saveds[i]), L.ptr(scratch), int(ctx.training), stream)
+            have_next = True
+            xs[i] = None
+            saveds[i] = None  # release the step's activations as soon as its backward is enqueued
+        grads = tuple(gflat[o : o + n].view(s) for (o, n, s) in model._param_slices)
+        return (None,) * 17 + grads

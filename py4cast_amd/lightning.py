@@ -359,11 +359,13 @@ class AutoRegressiveLightning(_Base):
                 self.output_feature_names if inference else batch.outputs.feature_names, device
             )
 
-        native = getattr(self.model, "native_rollout", None)
+        native = getattr(self.model, "native_rollout", None) if getattr(self, "use_native_rollout", True) else None
         if native is not None and not ds and self.mask_ratio == 0 and num_inter_steps == 1 and not inference:
             prediction = native(self, batch, std, mean, border_flat, interior_flat, force_border)
-            pred_out = NamedTensor.new_like(prediction.type_as(batch.outputs.tensor), batch.outputs)
-            return pred_out, batch.outputs
+            if prediction is not None:
+                pred_out = NamedTensor.new_like(prediction.type_as(batch.outputs.tensor), batch.outputs)
+                pred_out.fused_loss = getattr(prediction, "fused_loss", None)
+                return pred_out, batch.outputs
 
         prev_states = batch.inputs
         prediction_list = []
