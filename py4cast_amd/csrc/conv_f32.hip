@@ -59,20 +59,49 @@ __global__ void prep_weights_kernel(const float* __restrict__ w, int CO, int CI,
 // Stage a (LH x LW) halo tile of the NHWC input into LDS, applying v = relu?(v*scale[c]+shift[c]).
 // Rows of CI floats are padded to CIS = CI+4 so that the per-pixel 16-byte reads of one
 // ds_read_b128 lane group fall on 16 distinct bank quads.
+// Split in two phases (T14, "issue early / write late"): tile_load() issues every global load of the
+// thread into registers without waiting; tile_store() transforms and writes them to LDS.  Callers put
+// independent work (the previous tile's MFMA phase) between the two.
+template <int CI, int LH, int LW>
+struct TileRegs {
+    static constexpr int C4 = CI / 4;
+    static constexpr int TOTAL = LH * LW * C4;
+    static constexpr int ITERS = (TOTAL + 255) / 256;
+    f32x4 v[ITERS];
+};
+
 template <int CI, int LH, int LW, int HALO>
-__device__ __forceinline__ void stage_tile(const float* __restrict__ in, const float* __restrict__ scale,
-                                           const float* __restrict__ shift, int relu, float* lds, int b, int y0, int x0,
-                                           int H, int W, int in_cs, int sc_cs) {
-    constexpr int CIS = CI + 4;
+__device__ __forceinline__ void tile_load(TileRegs<CI, LH, LW>& t, const float* __restrict__ in, int b, int y0, int x0, int H,
+                                          int W, int in_cs) {
     constexpr int C4 = CI / 4;
-    constexpr int TOTAL = LH * LW * C4;
-    for (int idx = threadIdx.x; idx < TOTAL; idx += 256) {
+#pragma unroll
+    for (int it = 0; it < TileRegs<CI, LH, LW>::ITERS; ++it) {
+        const int idx = threadIdx.x + it * 256;
         const int pix = idx / C4, c4 = idx - pix * C4;
         const int ly = pix / LW, lx = pix - ly * LW;
         const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        if (idx < TileRegs<CI, LH, LW>::TOTAL && gy >= 0 && gy < H && gx >= 0 && gx < W)
             v = *reinterpret_cast<const f32x4*>(in + (((int64_t)b * H + gy) * W + gx) * in_cs + 4 * c4);
+        t.v[it] = v;
+    }
+}
+
+template <int CI, int LH, int LW, int HALO>
+__device__ __forceinline__ void tile_store(const TileRegs<CI, LH, LW>& t, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, int relu, float* lds, int b, int y0, int x0,
+                                           int H, int W, int sc_cs) {
+    constexpr int CIS = CI + 4;
+    constexpr int C4 = CI / 4;
+#pragma unroll
+    for (int it = 0; it < TileRegs<CI, LH, LW>::ITERS; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        if (idx >= TileRegs<CI, LH, LW>::TOTAL) break;
+        const int pix = idx / C4, c4 = idx - pix * C4;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+        f32x4 v = t.v[it];
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {  // zero padding stays zero: it is applied AFTER norm+relu
             if (scale) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (int64_t)b * sc_cs + 4 * c4);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (int64_t)b * sc_cs + 4 * c4);
@@ -109,7 +138,11 @@ __global__ void __launch_bounds__(256)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    stage_tile<CI, LH, LW, HALO>(in, in_scale, in_shift, in_relu, lds, b, y0, x0, H, W, CI, CI);
+    {
+        TileRegs<CI, LH, LW> tr;
+        tile_load<CI, LH, LW, HALO>(tr, in, b, y0, x0, H, W, CI);
+        tile_store<CI, LH, LW, HALO>(tr, in_scale, in_shift, in_relu, lds, b, y0, x0, H, W, CI);
+    }
     __syncthreads();
 
     f32x16 acc[2][RW];
@@ -120,38 +153,41 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ct][pt][i] = 0.f;
 
+    // weight stream: [tap][q] groups are contiguous (512 floats each); the next group's two 16-byte loads are
+    // issued before the current group's 8*RW MFMAs so that the L2 latency hides under the matrix pipe
     const float* wbase = wp + (int64_t)mb * NTAPS * CI * 64 + (h * 64 + r) * 4;
+    constexpr int NJ = NTAPS * NQ;
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(wbase);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(wbase + 128);
 #pragma unroll 1
     for (int tap = 0; tap < NTAPS; ++tap) {
         const int ky = tap / KS, kx = tap - ky * KS;
-        const float* wt = wbase + (int64_t)tap * NQ * 512;
         const float* lt = lds + ((wv * RW + ky) * LW + (r + kx)) * CIS + 4 * h;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            f32x4 a[2], bb[RW];
-            a[0] = *reinterpret_cast<const f32x4*>(wt + q * 512);
-            a[1] = *reinterpret_cast<const f32x4*>(wt + q * 512 + 128);
+            int jn = tap * NQ + q + 1;
+            jn = jn < NJ ? jn : NJ - 1;
+            const f32x4 n0 = *reinterpret_cast<const f32x4*>(wbase + jn * 512);
+            const f32x4 n1 = *reinterpret_cast<const f32x4*>(wbase + jn * 512 + 128);
+            f32x4 bb[RW];
 #pragma unroll
             for (int pt = 0; pt < RW; ++pt) bb[pt] = *reinterpret_cast<const f32x4*>(lt + pt * LW * CIS + 8 * q);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int pt = 0; pt < RW; ++pt)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][s], bb[pt][s], acc[ct][pt], 0, 0, 0);
+                for (int pt = 0; pt < RW; ++pt) {
+                    acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bb[pt][s], acc[0][pt], 0, 0, 0);
+                    acc[1][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bb[pt][s], acc[1][pt], 0, 0, 0);
+                }
+            a0 = n0;
+            a1 = n1;
         }
     }
 
     // ---- epilogue: C[co][px]; lane = pixel r (+ half h), register i -> co = (i&3) + 8*(i>>2) + 4*h
     const int gx = x0 + r;
-    float s1[2][16], s2[2][16];
-    if (stat_partial) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s1[ct][i] = s2[ct][i] = 0.f;
-    }
+    if (stat_partial) __syncthreads();  // all waves are done reading the input tile: LDS is reused below
+    float* tw = lds + wv * (64 * 33);   // per-wave [co][33] transpose buffer
 #pragma unroll
     for (int pt = 0; pt < RW; ++pt) {
         const int gy = y0 + wv * RW + pt;
@@ -164,36 +200,32 @@ __global__ void __launch_bounds__(256)
                 f32x4 v = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
                 if (bias) v += *reinterpret_cast<const f32x4*>(bias + mb * 64 + ct * 32 + 8 * g + 4 * h);
                 if (valid) *reinterpret_cast<f32x4*>(orow + ct * 32 + 8 * g) = v;
-                if (stat_partial && valid) {
+                if (stat_partial) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        s1[ct][4 * g + j] += v[j];
-                        s2[ct][4 * g + j] += v[j] * v[j];
+                        const int co = ct * 32 + 8 * g + 4 * h + j;
+                        const float o = valid ? v[j] : 0.f;
+                        tw[co * 33 + r] = o;
                     }
                 }
             }
         }
     }
     if (stat_partial) {
-        // reduce over the 32 pixels of each lane half, then over the 4 waves through LDS
-        __syncthreads();  // all waves are done reading the input tile; reuse LDS
-        float* red = lds;  // [wave][stat][64]
+        static_assert(RW == 1, "statistics epilogue assumes one pixel-tile per wave");
+        // lane l now sums row co = l of its wave's [64][32] tile (stride 33: conflict-free), then 4 waves -> 1
+        __syncthreads();
+        float a1 = 0.f, a2 = 0.f;
+        const float* row = tw + lane * 33;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float a1 = s1[ct][i], a2 = s2[ct][i];
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {
-                    a1 += __shfl_xor(a1, off, 64);
-                    a2 += __shfl_xor(a2, off, 64);
-                }
-                if (r == 0) {
-                    const int co = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    red[(wv * 2 + 0) * 64 + co] = a1;
-                    red[(wv * 2 + 1) * 64 + co] = a2;
-                }
-            }
+        for (int k = 0; k < 32; ++k) {
+            const float o = row[k];
+            a1 += o;
+            a2 += o * o;
+        }
+        float* red = lds + 4 * 64 * 33;  // [wave][stat][64]
+        red[(wv * 2 + 0) * 64 + lane] = a1;
+        red[(wv * 2 + 1) * 64 + lane] = a2;
         __syncthreads();
         if (threadIdx.x < 128) {
             const int t = threadIdx.x;
@@ -208,7 +240,11 @@ __global__ void __launch_bounds__(256)
 // conv_wgrad_f32: persistent; grid = G workgroups, each loops over pixel tiles (4 x 32).
 //   dW[tap][ci][co] += sum_px In[px + tap][ci] * dOut[px][co]
 // GEMM per tap: A[i=ci][k=px] (lane = ci, half h = pixel parity), B[k=px][j=co] (lane = co).
-// wave w owns (ci-tile, co-tile) units {w, w+4, ...}; 9 accumulator tiles per unit.
+// A wave owns one (ci-tile, co-tile) unit = 9 accumulator tiles.  With fewer than 4 units (CI = 32) the
+// pixel range of a tile is split between wave pairs (KSPLIT) and each pair writes its own partial.
+// The next tile's global loads are issued before the current tile's MFMA phase and written to LDS after it
+// (register double buffering, T14): HBM latency hides under the matrix pipe although only one workgroup
+// fits a CU.
 template <int CI, int KS>
 __global__ void __launch_bounds__(256, 1)
     conv_wgrad_f32_kernel(const float* __restrict__ in, const float* __restrict__ in_scale,
@@ -220,95 +256,104 @@ __global__ void __launch_bounds__(256, 1)
     constexpr int CIS = CI + 4;
     constexpr int DS = 64 + 4;
     constexpr int NTAPS = KS * KS;
-    constexpr int UNITS = (CI / 32) * 2;
-    constexpr int UPW = (UNITS + 3) / 4;  // units per wave
+    constexpr int UNITS = (CI / 32) * 2;          // 2 or 4
+    constexpr int KSPLIT = 4 / UNITS;             // wave groups splitting the pixel range
+    constexpr int KSTEPS = TH * TW / 2 / KSPLIT;  // MFMA k-steps (pixel pairs) per wave and tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lin = lds;
     float* ldo = lds + LH * LW * CIS;
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
+    const int unit = wv % UNITS, ksl = wv / UNITS;
+    const int cit = unit >> 1, cot = unit & 1;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y * B;
+    const float* inb = in + ci_off;
+    const float* scb = in_scale ? in_scale + ci_off : nullptr;
+    const float* shb = in_shift ? in_shift + ci_off : nullptr;
 
-    f32x16 acc[UPW][NTAPS];
+    f32x16 acc[NTAPS];
 #pragma unroll
-    for (int u = 0; u < UPW; ++u)
+    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
-        for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[u][t][i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    TileRegs<CI, LH, LW> tr;
+    f32x4 dreg[TH * TW * 16 / 256];
+    auto load_tile = [&](int tile) {
         const int tx = tile % tiles_x;
         const int rest = tile / tiles_x;
         const int ty = rest % tiles_y, b = rest / tiles_y;
-        const int y0 = ty * TH, x0 = tx * TW;
-        __syncthreads();  // previous tile fully consumed
-        stage_tile<CI, LH, LW, HALO>(in + ci_off, in_scale ? in_scale + ci_off : nullptr, in_shift ? in_shift + ci_off : nullptr, in_relu,
-                                     lin, b, y0, x0, H, W, in_cs, in_cs);
-        for (int idx = threadIdx.x; idx < TH * TW * 16; idx += 256) {
+        tile_load<CI, LH, LW, HALO>(tr, inb, b, ty * TH, tx * TW, H, W, in_cs);
+#pragma unroll
+        for (int it = 0; it < TH * TW * 16 / 256; ++it) {
+            const int idx = threadIdx.x + it * 256;
             const int pix = idx >> 4, c4 = idx & 15;
-            const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+            const int gy = ty * TH + (pix >> 5), gx = tx * TW + (pix & 31);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gy < H && gx < W) v = *reinterpret_cast<const f32x4*>(dout + (((int64_t)b * H + gy) * W + gx) * 64 + 4 * c4);
-            *reinterpret_cast<f32x4*>(ldo + pix * DS + 4 * c4) = v;
+            dreg[it] = v;
         }
+    };
+    auto store_tile = [&](int tile) {
+        const int tx = tile % tiles_x;
+        const int rest = tile / tiles_x;
+        const int ty = rest % tiles_y, b = rest / tiles_y;
+        tile_store<CI, LH, LW, HALO>(tr, scb, shb, in_relu, lin, b, ty * TH, tx * TW, H, W, in_cs);
+#pragma unroll
+        for (int it = 0; it < TH * TW * 16 / 256; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            *reinterpret_cast<f32x4*>(ldo + (idx >> 4) * DS + 4 * (idx & 15)) = dreg[it];
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();  // previous tile fully consumed
+        store_tile(tile);
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < UPW; ++u) {
-            const int unit = wv + 4 * u;
-            if (unit < UNITS) {
-                const int cit = unit >> 1, cot = unit & 1;
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);  // in flight during the MFMA phase
 #pragma unroll 2
-                for (int kp = 0; kp < TH * TW / 2; ++kp) {
-                    const int p = 2 * kp + h;  // this lane half's pixel of the K-step
-                    const int row = p >> 5, col = p & 31;
-                    const float bv = ldo[p * DS + cot * 32 + r];
-                    const float* ain = lin + (row * LW + col) * CIS + cit * 32 + r;
+        for (int kp = 0; kp < KSTEPS; ++kp) {
+            const int p = 2 * (ksl * KSTEPS + kp) + h;  // this lane half's pixel of the K-step
+            const int row = p >> 5, col = p & 31;
+            const float bv = ldo[p * DS + cot * 32 + r];
+            const float* ain = lin + (row * LW + col) * CIS + cit * 32 + r;
 #pragma unroll
-                    for (int t = 0; t < NTAPS; ++t) {
-                        const int ky = t / KS, kx = t - ky * KS;
-                        const float av = ain[(ky * LW + kx) * CIS];
-                        acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u][t], 0, 0, 0);
-                    }
-                }
+            for (int t = 0; t < NTAPS; ++t) {
+                const int ky = t / KS, kx = t - ky * KS;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ain[(ky * LW + kx) * CIS], bv, acc[t], 0, 0, 0);
             }
         }
     }
-    // C[ci][co]: lane = co (r), register i -> ci = (i&3) + 8*(i>>2) + 4*h
-    float* pbase = partial + (int64_t)blockIdx.x * NTAPS * part_cip * 64;
+    // C[ci][co]: lane = co (r), register i -> ci = (i&3) + 8*(i>>2) + 4*h.  One partial per (workgroup, k-slice).
+    float* pbase = partial + ((int64_t)blockIdx.x * KSPLIT + ksl) * NTAPS * part_cip * 64;
 #pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-        const int unit = wv + 4 * u;
-        if (unit < UNITS) {
-            const int cit = unit >> 1, cot = unit & 1;
+    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int ci = ci_off + cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    pbase[((int64_t)t * part_cip + ci) * 64 + cot * 32 + r] = acc[u][t][i];
-                }
+        for (int i = 0; i < 16; ++i) {
+            const int ci = ci_off + cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            pbase[((int64_t)t * part_cip + ci) * 64 + cot * 32 + r] = acc[t][i];
         }
-    }
 }
 
-// grad[co][ci][tap] += sum_g partial[g][tap][ci_pad][co_pad64]   (canonical torch layout, real channels only)
-// threads follow the partial layout (co fastest) so the G partial reads are coalesced.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int G, int ntaps, int CI_pad, int CO, int CI,
-                                    float* __restrict__ grad) {
-    const int total = ntaps * CI_pad * 64;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int co = i & 63;
-    const int ci = (i >> 6) % CI_pad;
-    const int tap = i / (64 * CI_pad);
-    if (co >= CO || ci >= CI) return;
-    const float* p = partial + i;
+// grad[co][ci][tap] += sum_slots partial[slot][tap][ci_pad][64]  for ci in [ci_lo, ci_hi), real channels only.
+// One block per (tap, ci): 64 output channels x 4 slot slices, fixed summation order (deterministic).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int ntaps, int CI_pad,
+                                                           int ci_lo, int ci_hi, int CO, int CI, float* __restrict__ grad) {
+    __shared__ float red[4][64];
+    const int nci = ci_hi - ci_lo;
+    const int tap = blockIdx.x / nci, ci = ci_lo + (blockIdx.x - tap * nci);
+    const int co = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t stride = (int64_t)ntaps * CI_pad * 64;
+    const float* p = partial + ((int64_t)tap * CI_pad + ci) * 64 + co;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += p[(int64_t)g * total];
-    grad[((int64_t)co * CI + ci) * ntaps + tap] += s;
+    for (int g = sl; g < nslots; g += 4) s += p[g * stride];
+    red[sl][co] = s;
+    __syncthreads();
+    if (sl == 0 && co < CO && ci < CI) grad[((int64_t)co * CI + ci) * ntaps + tap] += (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
 }
 
 template <int CI, int KS, int TH>
@@ -318,7 +363,8 @@ static int launch_conv_fwd(const float* in, const float* wp, const float* in_sca
     constexpr int HALO = KS / 2;
     constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
     size_t smem = (size_t)LH * LW * (CI + 4) * sizeof(float);
-    if (smem < 4 * 2 * 64 * sizeof(float)) smem = 4 * 2 * 64 * sizeof(float);
+    const size_t stat_smem = (4 * 64 * 33 + 4 * 2 * 64) * sizeof(float);  // statistics epilogue scratch
+    if (smem < stat_smem) smem = stat_smem;
     auto kern = conv_fwd_f32_kernel<CI, KS, TH>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -371,8 +417,20 @@ int conv_fwd_f32(const float* in, int CI, const float* wp, int ks, const float* 
     return fail(P4C_ERR_UNSUPPORTED, "conv_fwd_f32: unsupported (CI=%d, ks=%d): CI must be 32/64/96, ks 1/3", CI, ks);
 }
 
+static int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo, int ci_hi, int CO, int CI, float* grad,
+                        hipStream_t stream) {
+    if (ci_hi > CI) ci_hi = CI;
+    if (ci_hi <= ci_lo) return P4C_OK;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ks * ks * (ci_hi - ci_lo)), dim3(256), 0, stream, partial, nslots, ks * ks,
+                       CI_pad, ci_lo, ci_hi, CO, CI, grad);
+    P4C_CHECK_LAUNCH("wgrad_reduce");
+    return P4C_OK;
+}
+
+// grad[CO][CIreal][ks][ks] += weight gradient.  partial: wgrad_partial_floats(CI, ks, G) floats of scratch.
 int conv_wgrad_f32(const float* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
-                   const float* dout, float* partial, int G, int B, int H, int W, hipStream_t stream) {
+                   const float* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
+                   hipStream_t stream) {
     // input channels are processed in chunks of 64 (+32): the 9 accumulator tiles per (ci,co) unit of a
     // 96-channel chunk would not fit the register file without spilling.
     if (CI % 32 != 0 || CI <= 0 || CI > 256) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_f32: unsupported CI=%d", CI);
@@ -389,6 +447,9 @@ int conv_wgrad_f32(const float* in, int CI, int ks, const float* in_scale, const
         else
             rc = launch_conv_wgrad<32, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         if (rc != P4C_OK) return rc;
+        const int nslots = G * (chunk == 64 ? 1 : 2);
+        rc = wgrad_reduce(partial, nslots, ks, CI, off, off + chunk, CO, CIreal, grad, stream);
+        if (rc != P4C_OK) return rc;
         off += chunk;
     }
     return P4C_OK;
@@ -400,14 +461,6 @@ int prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip, int
     hipLaunchKernelGGL(prep_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, CO, CI, ks * ks,
                        transpose_flip, M_pad, K_pad, out);
     P4C_CHECK_LAUNCH("prep_weights");
-    return P4C_OK;
-}
-
-int wgrad_reduce(const float* partial, int G, int ks, int CI_pad, int CO, int CI, float* grad, hipStream_t stream) {
-    const int total = 64 * CI_pad * ks * ks;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, G, ks * ks, CI_pad,
-                       CO, CI, grad);
-    P4C_CHECK_LAUNCH("wgrad_reduce");
     return P4C_OK;
 }
 

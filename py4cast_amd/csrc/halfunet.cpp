@@ -69,7 +69,7 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     off = 0;
     L.wprep = off; off += (int64_t)9 * 96 * 64;
     L.statp = off; off += (int64_t)d.B * conv_tiles_per_sample(d.H, d.W) * 128;
-    L.wgradp = off; off += (int64_t)L.G * 9 * 96 * 64;
+    L.wgradp = off; off += wgrad_partial_floats(96, 3, L.G);
     L.nbwdp = off; off += (int64_t)d.B * 512 * 128;
     L.k1 = off; off += (int64_t)d.B * NF;
     L.k2 = off; off += (int64_t)d.B * NF;
@@ -202,8 +202,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const Layout& L, int i, float* g,
     int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
     const int G = ntiles < L.G ? (int)ntiles : L.G;
     P4C_TRY(conv_wgrad_f32(in, cip, 3, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
-                           in_norm ? 1 : 0, g, scratch + L.wgradp, G, d.B, H, W, st));
-    P4C_TRY(wgrad_reduce(scratch + L.wgradp, G, 3, cip, NF, conv_cin(d, i), grads + L.w[i], st));
+                           in_norm ? 1 : 0, g, scratch + L.wgradp, G, d.B, H, W, NF, conv_cin(d, i), grads + L.w[i], st));
     if (din) {
         float* wp = scratch + L.wprep;
         P4C_TRY(prep_weights(params + L.w[i], NF, conv_cin(d, i), 3, 1, 64 * din_mblocks, NF, wp, st));
@@ -238,8 +237,8 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* xv
     {
         int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(d.H, d.W);
         const int G = ntiles < L.G ? (int)ntiles : L.G;
-        P4C_TRY(conv_wgrad_f32(saved + L.Y[11], NF, 1, nd2.scale, nd2.shift, 1, dy, scratch + L.wgradp, G, d.B, d.H, d.W, st));
-        P4C_TRY(wgrad_reduce(scratch + L.wgradp, G, 1, NF, d.cout, NF, grads + L.wout, st));
+        P4C_TRY(conv_wgrad_f32(saved + L.Y[11], NF, 1, nd2.scale, nd2.shift, 1, dy, scratch + L.wgradp, G, d.B, d.H, d.W,
+                               d.cout, NF, grads + L.wout, st));
         P4C_TRY(prep_weights(params + L.wout, d.cout, NF, 1, 1, 64, NF, wp, st));
         P4C_TRY(conv_fwd_f32(dy, NF, wp, 1, nullptr, nullptr, 0, nullptr, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
     }
@@ -297,7 +296,7 @@ extern "C" int p4c_conv_fwd(const void* in, int dtype, int CI, const float* wpre
 }
 
 extern "C" size_t p4c_conv_wgrad_workspace_bytes(int CI_pad, int ks) {
-    return (size_t)num_cus() * ks * ks * CI_pad * 64 * sizeof(float);
+    return (size_t)wgrad_partial_floats(CI_pad, ks, num_cus()) * sizeof(float);
 }
 
 extern "C" int p4c_conv_wgrad(const void* in, int dtype, int CI_pad, int ks, const float* in_scale,
@@ -308,7 +307,6 @@ extern "C" int p4c_conv_wgrad(const void* in, int dtype, int CI_pad, int ks, con
     if (dtype != P4C_F32) return fail(P4C_ERR_UNSUPPORTED, "p4c_conv_wgrad: only P4C_F32 is implemented");
     int64_t ntiles = (int64_t)B * conv_tiles_per_sample(H, W);
     const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
-    P4C_TRY(conv_wgrad_f32((const float*)in, CI_pad, ks, in_scale, in_shift, in_relu, (const float*)dout,
-                           (float*)workspace, G, B, H, W, as_stream(stream)));
-    return wgrad_reduce((const float*)workspace, G, ks, CI_pad, CO, CI, grad, as_stream(stream));
+    return conv_wgrad_f32((const float*)in, CI_pad, ks, in_scale, in_shift, in_relu, (const float*)dout,
+                          (float*)workspace, G, B, H, W, CO, CI, grad, as_stream(stream));
 }

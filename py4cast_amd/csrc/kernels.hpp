@@ -11,8 +11,10 @@ int conv_fwd_f32(const float* in, int CI, const float* wp, int ks, const float* 
                  int in_relu, const float* bias, float* out, int out_cs, float* stat_partial, int B, int H, int W,
                  int m_blocks, hipStream_t stream);
 int conv_wgrad_f32(const float* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
-                   const float* dout, float* partial, int G, int B, int H, int W, hipStream_t stream);
-int wgrad_reduce(const float* partial, int G, int ks, int CI_pad, int CO, int CI, float* grad, hipStream_t stream);
+                   const float* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
+                   hipStream_t stream);
+// floats of scratch needed by conv_wgrad_f32 (per-workgroup partials; 32-channel chunks use two slots per workgroup)
+static inline int64_t wgrad_partial_floats(int CI_pad, int ks, int G) { return (int64_t)2 * G * ks * ks * CI_pad * 64; }
 
 // norm_pool.hip
 int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw, int mode, int groups, const float* gamma,

@@ -143,39 +143,46 @@ __global__ void __launch_bounds__(256)
 // pass 1b: reduce partials; accumulate dgamma/dbeta; emit per-(b,c) k1,k2 so that
 //   dY = rstd * (gamma*g - k1 - xhat*k2)          (training statistics)
 //   dY = scale * g  (k1 = k2 = 0)                 (eval-mode BatchNorm: statistics are constants)
-// one block of 64*... threads: grid = 1, block = 256 (c = tid&63, slice = tid>>6).
+// One block per statistics group: BatchNorm -> one channel (64 blocks), GroupNorm -> the C/groups channels
+// of one group (`groups` blocks).  256 threads = channels of the group x slices over the partial blocks;
+// samples are walked in order, so every sum has a fixed order (deterministic).
 __global__ void __launch_bounds__(256)
     norm_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int B, int64_t hw, int mode, int groups,
                              int training, const float* __restrict__ gamma, float* __restrict__ dgamma,
                              float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2) {
-    __shared__ float S[2][4][64];   // slices
-    __shared__ float SB[2][64];     // per-sample sums (loop over b)
-    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    float tot1 = 0.f, tot2 = 0.f;  // over batch (thread sl==0 keeps them)
+    __shared__ float S[2][256];
+    const int cpg = mode == 0 ? 1 : C / groups;   // channels per block
+    const int c_lo = blockIdx.x * cpg;
+    const int cl = threadIdx.x % cpg, sl = threadIdx.x / cpg, nsl = 256 / cpg;
+    const int c = c_lo + cl;
+    float tot1 = 0.f, tot2 = 0.f;
     for (int b = 0; b < B; ++b) {
         float s1 = 0.f, s2 = 0.f;
-        for (int k = sl; k < nblk; k += 4) {
+        for (int k = sl; k < nblk; k += nsl) {
             s1 += partial[(((int64_t)b * nblk + k) * 2 + 0) * 64 + c];
             s2 += partial[(((int64_t)b * nblk + k) * 2 + 1) * 64 + c];
         }
-        S[0][sl][c] = s1; S[1][sl][c] = s2;
+        S[0][threadIdx.x] = s1;
+        S[1][threadIdx.x] = s2;
         __syncthreads();
-        if (sl == 0) {
-            s1 = (S[0][0][c] + S[0][1][c]) + (S[0][2][c] + S[0][3][c]);
-            s2 = (S[1][0][c] + S[1][1][c]) + (S[1][2][c] + S[1][3][c]);
-            tot1 += s1; tot2 += s2;
-            SB[0][c] = s1; SB[1][c] = s2;
+        for (int off = nsl >> 1; off > 0; off >>= 1) {  // tree over the slices of each channel
+            if (sl < off) {
+                S[0][threadIdx.x] += S[0][threadIdx.x + off * cpg];
+                S[1][threadIdx.x] += S[1][threadIdx.x + off * cpg];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (mode == 1 && sl == 0) {  // GroupNorm: per-sample group means of gamma-weighted sums
-            const int cpg = C / groups, g0 = (c / cpg) * cpg;
+        // S[.][cl] (sl == 0 rows) now hold the per-channel sums of sample b
+        if (sl == 0) { tot1 += S[0][cl]; tot2 += S[1][cl]; }
+        if (mode == 1 && sl == 0) {
             float m1 = 0.f, m2 = 0.f;
             for (int j = 0; j < cpg; ++j) {
-                m1 += gamma[g0 + j] * SB[0][g0 + j];
-                m2 += gamma[g0 + j] * SB[1][g0 + j];
+                m1 += gamma[c_lo + j] * S[0][j];
+                m2 += gamma[c_lo + j] * S[1][j];
             }
             const float n = (float)hw * (float)cpg;
-            k1[b * C + c] = m1 / n; k2[b * C + c] = m2 / n;
+            k1[b * C + c] = m1 / n;
+            k2[b * C + c] = m2 / n;
         }
         __syncthreads();
     }
@@ -404,7 +411,7 @@ int norm_bwd(const float* dA, const float* y, const float* scale, const float* s
     hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 0, stream, dA, y, scale, shift, mean, rstd, relu,
                        hw, partial);
     P4C_CHECK_LAUNCH("norm_bwd_reduce");
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, nblk, B, hw, mode, groups,
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(mode == 0 ? C : groups), dim3(256), 0, stream, partial, nblk, B, hw, mode, groups,
                        training, gamma, dgamma, dbeta, k1, k2);
     P4C_CHECK_LAUNCH("norm_bwd_finalize");
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid((int64_t)B * hw * 16)), dim3(256), 0, stream, dA, y, scale,

