@@ -14,17 +14,12 @@ from torch import nn
 from py4cast_amd.base import ModelABC, ModelType
 from py4cast_amd.namedtensor import HAVE_MFAI
 
-try:
-    from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings  # noqa: F401
+from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings  # noqa: F401,E402
 
-    if not HAVE_MFAI:
-        # stand-alone: take the upstream name so that config/CLI/model/halfunet.yaml works unchanged
-        class HalfUNet(HalfUNetMI355X):
-            register = True
-
-except ModuleNotFoundError as _e:  # TEMPORARY until py4cast_amd/halfunet.py lands
-    if "halfunet" not in str(_e):
-        raise
+if not HAVE_MFAI:
+    # stand-alone: take the upstream name so that config/CLI/model/halfunet.yaml works unchanged
+    class HalfUNet(HalfUNetMI355X):
+        register = True
 
 
 @dataclass

@@ -1,0 +1,47 @@
+"""world_size-2 gloo test of the flat-bucket gradient exchange used for data-parallel training (CPU)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from py4cast_amd.trainer import FlatDDP
+
+    torch.manual_seed(100 + rank)  # different initial weights on purpose: FlatDDP must broadcast rank 0's
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Tanh(), torch.nn.Linear(8, 2))
+    ddp = FlatDDP(net, world)
+    w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    torch.manual_seed(7 + rank)
+    x, y = torch.randn(5, 4), torch.randn(5, 2)
+    # two micro-batches accumulate locally, one all-reduce at the optimizer step (accumulate_grad_batches semantics)
+    for _ in range(2):
+        ((net(x) - y) ** 2).mean().backward()
+    local = ddp.flat_grad.clone()
+    ddp.all_reduce_grads()
+    ret[rank] = (w0, local, ddp.flat_grad.clone(), [p.grad.data_ptr() for p in net.parameters()], ddp.flat_grad.data_ptr())
+    dist.destroy_process_group()
+
+
+def test_flat_ddp_allreduce_mean_gloo():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    w_a, local_a, red_a, ptrs_a, base_a = ret[0]
+    w_b, local_b, red_b, _, _ = ret[1]
+    assert torch.equal(w_a, w_b)  # parameters broadcast from rank 0
+    assert not torch.allclose(local_a, local_b)
+    torch.testing.assert_close(red_a, (local_a + local_b) / 2)
+    torch.testing.assert_close(red_a, red_b)
+    assert ptrs_a[0] == base_a  # param.grad tensors are views into the single flat bucket
