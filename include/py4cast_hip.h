@@ -197,18 +197,20 @@ int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g
 /* Re-order a canonical torch conv weight w[CO][CI][ks][ks] into the MFMA operand stream used by
  * p4c_conv_fwd: out[M_pad/64][ks*ks][K_pad/8][2][64][4] (zero padded).
  * transpose_flip=0: forward (M = CO, K = CI).  transpose_flip=1: data gradient (M = CI, K = CO, taps
- * flipped), so the same conv kernel evaluates dL/dinput.  out needs M_pad*K_pad*ks*ks floats. */
-int p4c_prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, float* out,
-                     p4c_stream_t stream);
+ * flipped), so the same conv kernel evaluates dL/dinput.  out needs M_pad*K_pad*ks*ks elements (fp32 for
+ * compute = P4C_F32; bf16 in the [..][K_pad/16][2][64][8] order for compute = P4C_BF16). */
+int p4c_prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, void* out,
+                     int compute, p4c_stream_t stream);
 
 /* "same" convolution (ks = 1 or 3, stride 1, zero padding) on the fp32 matrix cores
- * (v_mfma_f32_32x32x2_f32): out[b,y,x,m] = sum_{tap,k} act(in)[b,y+dy,x+dx,k] * W[m][k][tap] (+ bias[m])
+ * (compute = P4C_F32: v_mfma_f32_32x32x2_f32, exact; P4C_BF16: v_mfma_f32_32x32x16_bf16 on operands rounded
+ * to bf16 while staged; tensors are fp32 in both cases): out[b,y,x,m] = sum_{tap,k} act(in)[b,y+dy,x+dx,k] * W[m][k][tap] (+ bias[m])
  * with act(v) = relu?(v*in_scale[b,k] + in_shift[b,k]) applied while the input tile is staged
  * (in_scale/in_shift: (B,CI) or NULL).  stat_partial (or NULL): per-tile channel sums,
- * [B*tiles][2][64] floats with tiles = ceil(H/4)*ceil(W/32) -- the BatchNorm/GroupNorm statistics of
+ * [B*tiles][2][64] floats with tiles = p4c_conv_stat_tiles(compute, CI, H, W) -- the BatchNorm/GroupNorm statistics of
  * the output, produced in the epilogue.  in: (B,H,W,CI), CI in {32,64,96}; out: (B,H,W,out_cs),
  * m_blocks*64 channels written. */
-int p4c_conv_fwd(const void* in, int dtype, int CI, const float* wprep, int ks, const float* in_scale,
+int p4c_conv_fwd(const void* in, int compute, int CI, const void* wprep, int ks, const float* in_scale,
                  const float* in_shift, int in_relu, const float* bias, void* out, int out_cs, float* stat_partial,
                  int B, int H, int W, int m_blocks, p4c_stream_t stream);
 
@@ -216,7 +218,9 @@ int p4c_conv_fwd(const void* in, int dtype, int CI, const float* wprep, int ks, 
  * dout: (B,H,W,64).  workspace: p4c_conv_wgrad_workspace_bytes(CI_pad, ks) bytes (per-workgroup partials,
  * reduced deterministically). */
 size_t p4c_conv_wgrad_workspace_bytes(int CI_pad, int ks);
-int p4c_conv_wgrad(const void* in, int dtype, int CI_pad, int ks, const float* in_scale, const float* in_shift,
+/* number of pixel tiles per sample of p4c_conv_fwd (rows of its stat_partial output) */
+int p4c_conv_stat_tiles(int compute, int CI, int H, int W);
+int p4c_conv_wgrad(const void* in, int compute, int CI_pad, int ks, const float* in_scale, const float* in_shift,
                    int in_relu, const void* dout, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                    p4c_stream_t stream);
 
@@ -236,6 +240,8 @@ typedef struct p4c_halfunet_desc {
     int32_t has_bias;     /* conv bias (settings.bias); only 0 is implemented */
     float eps;
     float momentum;
+    int32_t compute;      /* matrix-core input type of the convolutions: P4C_F32 (exact fp32 MFMA) or P4C_BF16
+                             (operands rounded to bf16 in LDS, fp32 accumulate; activations stay fp32 in HBM) */
 } p4c_halfunet_desc;
 
 /* number of floats of the flat parameter vector, laid out in this order (canonical torch layouts):

@@ -13,14 +13,14 @@ class HalfUNetDesc(ctypes.Structure):
         ("B", c_int32), ("H", c_int32), ("W", c_int32),
         ("cin", c_int32), ("cin_pad", c_int32), ("cout", c_int32), ("dx_channels", c_int32),
         ("dtype", c_int32), ("norm", c_int32), ("groups", c_int32), ("has_bias", c_int32),
-        ("eps", c_float), ("momentum", c_float),
+        ("eps", c_float), ("momentum", c_float), ("compute", c_int32),
     ]
 
 
 DP = ctypes.POINTER(HalfUNetDesc)
 
 SIGNATURES = {
-    "p4c_prep_weights": [P, I, I, I, I, I, I, P, P],
+    "p4c_prep_weights": [P, I, I, I, I, I, I, P, I, P],
     "p4c_conv_fwd": [P, I, I, P, I, P, P, I, P, P, I, P, I, I, I, I, P],
     "p4c_conv_wgrad": [P, I, I, I, P, P, I, P, I, I, P, P, I, I, I, P],
     "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
@@ -29,5 +29,6 @@ SIGNATURES = {
 }
 OTHER = {
     "p4c_conv_wgrad_workspace_bytes": ([I, I], c_size_t),
+    "p4c_conv_stat_tiles": ([I, I, I, I], c_int),
     "p4c_halfunet_param_count": ([DP], c_int64),
 }

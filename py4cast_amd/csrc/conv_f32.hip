@@ -417,7 +417,7 @@ int conv_fwd_f32(const float* in, int CI, const float* wp, int ks, const float* 
     return fail(P4C_ERR_UNSUPPORTED, "conv_fwd_f32: unsupported (CI=%d, ks=%d): CI must be 32/64/96, ks 1/3", CI, ks);
 }
 
-static int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo, int ci_hi, int CO, int CI, float* grad,
+int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo, int ci_hi, int CO, int CI, float* grad,
                         hipStream_t stream) {
     if (ci_hi > CI) ci_hi = CI;
     if (ci_hi <= ci_lo) return P4C_OK;

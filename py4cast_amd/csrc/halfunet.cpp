@@ -27,6 +27,28 @@ inline int conv_level(int i) { return i < 10 ? i / 2 : 0; }
 inline int conv_cin(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin : NF; }
 inline int conv_cin_pad(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin_pad : NF; }
 
+inline int stat_tiles(int compute, int CI, int H, int W) {
+    const int th = compute == P4C_BF16 ? conv_bf16_tile_h(CI) : CONV_TH;
+    return ((H + th - 1) / th) * ((W + CONV_TW - 1) / CONV_TW);
+}
+
+// dtype-dispatching wrappers: one call site per use, both matrix-core flavours
+inline int prep_w(int compute, const float* w, int CO, int CI, int ks, int tf, int M_pad, int K_pad, float* out, hipStream_t st) {
+    return compute == P4C_BF16 ? prep_weights_bf16(w, CO, CI, ks, tf, M_pad, K_pad, out, st)
+                               : prep_weights(w, CO, CI, ks, tf, M_pad, K_pad, out, st);
+}
+inline int conv_fwd(int compute, const float* in, int CI, const float* wp, int ks, const float* sc, const float* sh, int relu,
+                    float* out, int out_cs, float* statp, int B, int H, int W, int mblocks, hipStream_t st) {
+    return compute == P4C_BF16 ? conv_fwd_bf16(in, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st)
+                               : conv_fwd_f32(in, CI, wp, ks, sc, sh, relu, nullptr, out, out_cs, statp, B, H, W, mblocks, st);
+}
+inline int conv_wgrad(int compute, const float* in, int CI, int ks, const float* sc, const float* sh, int relu,
+                      const float* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
+                      hipStream_t st) {
+    return compute == P4C_BF16 ? conv_wgrad_bf16(in, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st)
+                               : conv_wgrad_f32(in, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st);
+}
+
 int check_desc(const p4c_halfunet_desc* d) {
     P4C_CHECK_ARG(d, "halfunet: null descriptor");
     P4C_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0, "halfunet: bad shape");
@@ -37,7 +59,8 @@ int check_desc(const p4c_halfunet_desc* d) {
     P4C_CHECK_ARG(d->cout > 0 && d->cout <= 64, "halfunet: cout must be in 1..64 (got %d)", d->cout);
     P4C_CHECK_ARG(d->dx_channels >= 0 && d->dx_channels <= 64 && d->dx_channels <= d->cin, "halfunet: bad dx_channels");
     P4C_CHECK_ARG(d->norm == 0 || (d->norm == 1 && d->groups > 0 && 64 % d->groups == 0), "halfunet: bad norm/groups");
-    if (d->dtype != P4C_F32) return fail(P4C_ERR_UNSUPPORTED, "halfunet: only P4C_F32 is implemented");
+    if (d->dtype != P4C_F32) return fail(P4C_ERR_UNSUPPORTED, "halfunet: activation storage must be P4C_F32");
+    P4C_CHECK_ARG(d->compute == P4C_F32 || d->compute == P4C_BF16, "halfunet: compute must be P4C_F32 or P4C_BF16");
     if (d->has_bias) return fail(P4C_ERR_UNSUPPORTED, "halfunet: conv bias (settings.bias=True) is not implemented");
     return P4C_OK;
 }
@@ -97,17 +120,16 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const Layout& L, int i, const flo
                    const float* params, float* running, float* saved, float* scratch, int training, hipStream_t st) {
     const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
     float* wp = scratch + L.wprep;
-    P4C_TRY(prep_weights(params + L.w[i], NF, conv_cin(d, i), 3, 0, 64, conv_cin_pad(d, i), wp, st));
+    P4C_TRY(prep_w(d.compute, params + L.w[i], NF, conv_cin(d, i), 3, 0, 64, conv_cin_pad(d, i), wp, st));
     const bool batch_stats = (d.norm == 1) || training;
     float* statp = batch_stats ? scratch + L.statp : nullptr;
-    P4C_TRY(conv_fwd_f32(in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
-                         in_norm ? in_norm->shift : nullptr, in_norm ? 1 : 0, nullptr, saved + L.Y[i], NF, statp, d.B, H, W,
-                         1, st));
+    P4C_TRY(conv_fwd(d.compute, in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
+                     in_norm ? in_norm->shift : nullptr, in_norm ? 1 : 0, saved + L.Y[i], NF, statp, d.B, H, W, 1, st));
     Norm nm = norm_at(saved, L, i, d.B);
     float* rm = running ? running + (int64_t)i * 128 : nullptr;
     float* rv = running ? rm + 64 : nullptr;
     if (batch_stats) {
-        P4C_TRY(norm_finalize(statp, conv_tiles_per_sample(H, W), d.B, (int64_t)H * W, d.norm, d.groups,
+        P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, conv_cin_pad(d, i), H, W), d.B, (int64_t)H * W, d.norm, d.groups,
                               params + L.gamma[i], params + L.beta[i], d.eps, d.momentum, d.norm == 0 ? rm : nullptr,
                               d.norm == 0 ? rv : nullptr, nm.scale, nm.shift, nm.mean, nm.rstd, st));
     } else {
@@ -178,9 +200,8 @@ extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* xv,
     Norm nd2 = norm_at(saved, L, 11, d.B);
     // 1x1 output conv on relu(norm(Y_dec2)); last activation = Identity
     float* wp = scratch + L.wprep;
-    P4C_TRY(prep_weights(params + L.wout, d.cout, NF, 1, 0, 64, NF, wp, st));
-    P4C_TRY(conv_fwd_f32(saved + L.Y[11], NF, wp, 1, nd2.scale, nd2.shift, 1, nullptr, (float*)yv, NF, nullptr, d.B, d.H, d.W,
-                         1, st));
+    P4C_TRY(prep_w(d.compute, params + L.wout, d.cout, NF, 1, 0, 64, NF, wp, st));
+    P4C_TRY(conv_fwd(d.compute, saved + L.Y[11], NF, wp, 1, nd2.scale, nd2.shift, 1, (float*)yv, NF, nullptr, d.B, d.H, d.W, 1, st));
     return P4C_OK;
 }
 
@@ -201,13 +222,12 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const Layout& L, int i, float* g,
     const int cip = conv_cin_pad(d, i);
     int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
     const int G = ntiles < L.G ? (int)ntiles : L.G;
-    P4C_TRY(conv_wgrad_f32(in, cip, 3, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
-                           in_norm ? 1 : 0, g, scratch + L.wgradp, G, d.B, H, W, NF, conv_cin(d, i), grads + L.w[i], st));
+    P4C_TRY(conv_wgrad(d.compute, in, cip, 3, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
+                       in_norm ? 1 : 0, g, scratch + L.wgradp, G, d.B, H, W, NF, conv_cin(d, i), grads + L.w[i], st));
     if (din) {
         float* wp = scratch + L.wprep;
-        P4C_TRY(prep_weights(params + L.w[i], NF, conv_cin(d, i), 3, 1, 64 * din_mblocks, NF, wp, st));
-        P4C_TRY(conv_fwd_f32(g, NF, wp, 3, nullptr, nullptr, 0, nullptr, din, 64 * din_mblocks, nullptr, d.B, H, W,
-                             din_mblocks, st));
+        P4C_TRY(prep_w(d.compute, params + L.w[i], NF, conv_cin(d, i), 3, 1, 64 * din_mblocks, NF, wp, st));
+        P4C_TRY(conv_fwd(d.compute, g, NF, wp, 3, nullptr, nullptr, 0, din, 64 * din_mblocks, nullptr, d.B, H, W, din_mblocks, st));
     }
     return P4C_OK;
 }
@@ -237,10 +257,10 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* xv
     {
         int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(d.H, d.W);
         const int G = ntiles < L.G ? (int)ntiles : L.G;
-        P4C_TRY(conv_wgrad_f32(saved + L.Y[11], NF, 1, nd2.scale, nd2.shift, 1, dy, scratch + L.wgradp, G, d.B, d.H, d.W,
-                               d.cout, NF, grads + L.wout, st));
-        P4C_TRY(prep_weights(params + L.wout, d.cout, NF, 1, 1, 64, NF, wp, st));
-        P4C_TRY(conv_fwd_f32(dy, NF, wp, 1, nullptr, nullptr, 0, nullptr, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
+        P4C_TRY(conv_wgrad(d.compute, saved + L.Y[11], NF, 1, nd2.scale, nd2.shift, 1, dy, scratch + L.wgradp, G, d.B, d.H, d.W,
+                           d.cout, NF, grads + L.wout, st));
+        P4C_TRY(prep_w(d.compute, params + L.wout, d.cout, NF, 1, 1, 64, NF, wp, st));
+        P4C_TRY(conv_fwd(d.compute, dy, NF, wp, 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
     }
     // ---- decoder
     Norm nd1 = norm_at(saved, L, 10, d.B);
@@ -277,21 +297,29 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* xv
 
 // ------------------------------------------------------------------------------ single-op entry points (tests, reuse)
 extern "C" int p4c_prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad,
-                                float* out, p4c_stream_t stream) {
+                                void* out, int compute, p4c_stream_t stream) {
     P4C_CHECK_ARG(w && out, "p4c_prep_weights: null pointer");
     P4C_CHECK_ARG((ks == 1 || ks == 3) && M_pad % 64 == 0 && K_pad % 32 == 0, "p4c_prep_weights: bad ks / padding");
-    return prep_weights(w, CO, CI, ks, transpose_flip, M_pad, K_pad, out, as_stream(stream));
+    P4C_CHECK_ARG(compute == P4C_F32 || compute == P4C_BF16, "p4c_prep_weights: bad compute type");
+    return prep_w(compute, w, CO, CI, ks, transpose_flip, M_pad, K_pad, (float*)out, as_stream(stream));
 }
 
-extern "C" int p4c_conv_fwd(const void* in, int dtype, int CI, const float* wprep, int ks, const float* in_scale,
+extern "C" int p4c_conv_stat_tiles(int compute, int CI, int H, int W) { return stat_tiles(compute, CI, H, W); }
+
+extern "C" int p4c_conv_fwd(const void* in, int compute, int CI, const void* wprep, int ks, const float* in_scale,
                             const float* in_shift, int in_relu, const float* bias, void* out, int out_cs,
                             float* stat_partial, int B, int H, int W, int m_blocks, p4c_stream_t stream) {
     P4C_CHECK_ARG(in && wprep && out, "p4c_conv_fwd: null pointer");
     P4C_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "p4c_conv_fwd: scale and shift go together");
     P4C_CHECK_ARG(m_blocks >= 1 && out_cs >= 64 * m_blocks && out_cs % 4 == 0, "p4c_conv_fwd: bad out_cs / m_blocks");
     P4C_CHECK_ARG(!stat_partial || m_blocks == 1, "p4c_conv_fwd: statistics need m_blocks == 1");
-    if (dtype != P4C_F32) return fail(P4C_ERR_UNSUPPORTED, "p4c_conv_fwd: only P4C_F32 is implemented");
-    return conv_fwd_f32((const float*)in, CI, wprep, ks, in_scale, in_shift, in_relu, bias, (float*)out, out_cs,
+    if (compute == P4C_BF16) {
+        if (bias) return fail(P4C_ERR_UNSUPPORTED, "p4c_conv_fwd: bias is not implemented for P4C_BF16");
+        return conv_fwd_bf16((const float*)in, CI, wprep, ks, in_scale, in_shift, in_relu, (float*)out, out_cs, stat_partial,
+                             B, H, W, m_blocks, as_stream(stream));
+    }
+    if (compute != P4C_F32) return fail(P4C_ERR_INVALID, "p4c_conv_fwd: bad compute type %d", compute);
+    return conv_fwd_f32((const float*)in, CI, (const float*)wprep, ks, in_scale, in_shift, in_relu, bias, (float*)out, out_cs,
                         stat_partial, B, H, W, m_blocks, as_stream(stream));
 }
 
@@ -299,14 +327,14 @@ extern "C" size_t p4c_conv_wgrad_workspace_bytes(int CI_pad, int ks) {
     return (size_t)wgrad_partial_floats(CI_pad, ks, num_cus()) * sizeof(float);
 }
 
-extern "C" int p4c_conv_wgrad(const void* in, int dtype, int CI_pad, int ks, const float* in_scale,
+extern "C" int p4c_conv_wgrad(const void* in, int compute, int CI_pad, int ks, const float* in_scale,
                               const float* in_shift, int in_relu, const void* dout, int CO, int CI, float* grad,
                               void* workspace, int B, int H, int W, p4c_stream_t stream) {
     P4C_CHECK_ARG(in && dout && grad && workspace, "p4c_conv_wgrad: null pointer");
     P4C_CHECK_ARG(CO <= 64 && CI <= CI_pad, "p4c_conv_wgrad: CO must be <= 64 and CI <= CI_pad");
-    if (dtype != P4C_F32) return fail(P4C_ERR_UNSUPPORTED, "p4c_conv_wgrad: only P4C_F32 is implemented");
+    P4C_CHECK_ARG(compute == P4C_F32 || compute == P4C_BF16, "p4c_conv_wgrad: bad compute type");
     int64_t ntiles = (int64_t)B * conv_tiles_per_sample(H, W);
     const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
-    return conv_wgrad_f32((const float*)in, CI_pad, ks, in_scale, in_shift, in_relu, (const float*)dout,
-                          (float*)workspace, G, B, H, W, CO, CI, grad, as_stream(stream));
+    return conv_wgrad(compute, (const float*)in, CI_pad, ks, in_scale, in_shift, in_relu, (const float*)dout,
+                      (float*)workspace, G, B, H, W, CO, CI, grad, as_stream(stream));
 }

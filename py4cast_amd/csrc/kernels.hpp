@@ -16,6 +16,20 @@ int conv_wgrad_f32(const float* in, int CI, int ks, const float* in_scale, const
 // floats of scratch needed by conv_wgrad_f32 (per-workgroup partials; 32-channel chunks use two slots per workgroup)
 static inline int64_t wgrad_partial_floats(int CI_pad, int ks, int G) { return (int64_t)2 * G * ks * ks * CI_pad * 64; }
 
+int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo, int ci_hi, int CO, int CI, float* grad,
+                 hipStream_t stream);
+
+// conv_bf16.hip (bf16 matrix cores, fp32 storage)
+int prep_weights_bf16(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, void* out,
+                      hipStream_t stream);
+int conv_bf16_tile_h(int CI);
+int conv_fwd_bf16(const float* in, int CI, const void* wp, int ks, const float* in_scale, const float* in_shift,
+                  int in_relu, float* out, int out_cs, float* stat_partial, int B, int H, int W, int m_blocks,
+                  hipStream_t stream);
+int conv_wgrad_bf16(const float* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
+                    const float* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
+                    hipStream_t stream);
+
 // norm_pool.hip
 int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw, int mode, int groups, const float* gamma,
                   const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,

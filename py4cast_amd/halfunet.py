@@ -45,7 +45,7 @@ class HalfUNetSettings:
     # MI355X-specific
     norm: str = "batch"  # "batch" (mfai) or "group" (GroupNorm, BASELINE.json north star)
     groups: int = 8
-    compute_dtype: str = "f32"  # "f32": exact fp32 MFMA path
+    compute_dtype: str = "f32"  # matrix-core input type: "f32" (exact fp32 MFMA) or "bf16" (autocast-like)
 
 
 def pad32(c: int) -> int:
@@ -122,7 +122,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             unsupported.append("absolute_pos_embed=True")
         if settings.norm not in ("batch", "group"):
             unsupported.append(f"norm={settings.norm}")
-        if settings.compute_dtype not in ("f32",):
+        if settings.compute_dtype not in ("f32", "bf16"):
             unsupported.append(f"compute_dtype={settings.compute_dtype}")
         if out_channels > NF:
             unsupported.append(f"out_channels={out_channels} > 64")
@@ -132,7 +132,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             raise NotImplementedError("HalfUNetMI355X: unsupported settings: " + ", ".join(unsupported))
         self.cin_pad = pad32(in_channels)
         self.dx_channels = min(in_channels, NF)  # gradient wrt the leading (previous-state) channels
-        self.compute_dtype = torch.float32
+        self.compute_dtype = torch.float32 if settings.compute_dtype == "f32" else torch.bfloat16
         self.timed_entry_points = ("p4c_halfunet_forward", "p4c_halfunet_backward", "p4c_build_x",
                                    "p4c_ar_update_loss_fwd", "p4c_ar_update_loss_bwd")
 
@@ -236,7 +236,8 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             raise L.P4CError(f"HalfUNetMI355X: grid {H}x{W} must be a multiple of 16 in both dimensions")
         s = self._settings
         return HalfUNetDesc(B, H, W, self.in_channels, self.cin_pad, self.out_channels, self.dx_channels, L.F32,
-                            0 if s.norm == "batch" else 1, s.groups, 0, 1e-5, 0.1)
+                            0 if s.norm == "batch" else 1, s.groups, 0, 1e-5, 0.1,
+                            L.F32 if s.compute_dtype == "f32" else L.BF16)
 
     def _workspaces(self, desc, device):
         key = (desc.B, desc.H, desc.W, str(device))
@@ -304,9 +305,17 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             return None
         flops = 2.0 * 9 * 64 * 64 * units.value  # algorithmic: 2*taps*Cin*Cout per output pixel
         tflops = flops / (ms.value * 1e-3) / 1e12
-        peak = 157.3  # fp32 matrix peak, MI355X_MICROARCH.md
+        bf = self._settings.compute_dtype == "bf16"
+        peak = 2500.0 if bf else 157.3  # dense MFMA peaks, MI355X_MICROARCH.md
         wms, wn, wunits = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
         L.lib().p4c_prof_collect(L.PROF_WGRAD3X3_C64, B * H * W, ctypes.byref(wms), ctypes.byref(wn), ctypes.byref(wunits))
+        if bf:
+            # at the bf16 MFMA rate the kernel is HBM-bound: algorithmic bytes = read 64 ch + write 64 ch fp32 per pixel
+            gbs = 2.0 * 64 * 4 * units.value / (ms.value * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "conv_fwd_bf16_kernel<64,3,8> (3x3 conv 64->64, fwd + data-grad launches)",
+                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+                    "avg_launch_ms": ms.value / n.value, "launches": n.value, "mfma_tflops": tflops,
+                    "wgrad_avg_launch_ms": (wms.value / wn.value) if wn.value else None}
         out = {"bound": "mfma", "kernel": "conv_fwd_f32_kernel<64,3,4> (3x3 conv 64->64, fwd + data-grad launches)",
                "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
                "avg_launch_ms": ms.value / n.value, "launches": n.value,

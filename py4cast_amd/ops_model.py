@@ -8,38 +8,45 @@ import torch
 from . import _lib as L
 
 
-def prep_weights(w: torch.Tensor, transpose_flip: bool, M_pad: int, K_pad: int) -> torch.Tensor:
+def _compute(compute) -> int:
+    return {"f32": L.F32, "bf16": L.BF16, L.F32: L.F32, L.BF16: L.BF16}[compute]
+
+
+def prep_weights(w: torch.Tensor, transpose_flip: bool, M_pad: int, K_pad: int, compute="f32") -> torch.Tensor:
     """w: canonical (CO,CI,ks,ks) fp32 -> MFMA operand stream (see include/py4cast_hip.h)."""
     CO, CI, ks, _ = w.shape
-    out = torch.empty(M_pad * K_pad * ks * ks, dtype=torch.float32, device=w.device)
-    L.call("p4c_prep_weights", L.ptr(w.contiguous()), CO, CI, ks, int(transpose_flip), M_pad, K_pad, L.ptr(out), L.stream(w.device))
+    dt = torch.float32 if _compute(compute) == L.F32 else torch.bfloat16
+    out = torch.empty(M_pad * K_pad * ks * ks, dtype=dt, device=w.device)
+    L.call("p4c_prep_weights", L.ptr(w.contiguous()), CO, CI, ks, int(transpose_flip), M_pad, K_pad, L.ptr(out),
+           _compute(compute), L.stream(w.device))
     return out
 
 
-def conv_tiles(B, H, W):
-    return B * ((H + 3) // 4) * ((W + 31) // 32)
+def conv_tiles(B, H, W, CI=64, compute="f32"):
+    return B * L.lib().p4c_conv_stat_tiles(_compute(compute), CI, H, W)
 
 
 def conv_fwd(x: torch.Tensor, wprep: torch.Tensor, ks: int, m_blocks: int = 1, in_scale: Optional[torch.Tensor] = None,
              in_shift: Optional[torch.Tensor] = None, in_relu: bool = False, bias: Optional[torch.Tensor] = None,
-             want_stats: bool = False):
+             want_stats: bool = False, compute="f32"):
     """x: (B,H,W,CI) fp32 NHWC, CI in {32,64,96} -> (B,H,W,64*m_blocks) [+ per-tile channel sums]."""
     L.require_cuda(x)
     B, H, W, CI = x.shape
     out = torch.empty(B, H, W, 64 * m_blocks, dtype=torch.float32, device=x.device)
-    stats = torch.empty(conv_tiles(B, H, W), 2, 64, dtype=torch.float32, device=x.device) if want_stats else None
-    L.call("p4c_conv_fwd", L.ptr(x.contiguous()), L.F32, CI, L.ptr(wprep), ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
+    stats = torch.empty(conv_tiles(B, H, W, CI, compute), 2, 64, dtype=torch.float32, device=x.device) if want_stats else None
+    L.call("p4c_conv_fwd", L.ptr(x.contiguous()), _compute(compute), CI, L.ptr(wprep), ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
            L.ptr(bias), L.ptr(out), 64 * m_blocks, L.ptr(stats), B, H, W, m_blocks, L.stream(x.device))
     return (out, stats) if want_stats else out
 
 
 def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, ks: int, CO: int, CI: int, grad: torch.Tensor,
-               in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None, in_relu: bool = False):
+               in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None, in_relu: bool = False,
+               compute="f32"):
     """grad (CO,CI,ks,ks) += sum_px act(x)[px+tap][ci] * dout[px][co];  x (B,H,W,CI_pad), dout (B,H,W,64)."""
     L.require_cuda(x, dout, grad)
     B, H, W, CIp = x.shape
     nbytes = L.lib().p4c_conv_wgrad_workspace_bytes(CIp, ks)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    L.call("p4c_conv_wgrad", L.ptr(x.contiguous()), L.F32, CIp, ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
+    L.call("p4c_conv_wgrad", L.ptr(x.contiguous()), _compute(compute), CIp, ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
            L.ptr(dout.contiguous()), CO, CI, L.ptr(grad), L.ptr(ws), B, H, W, L.stream(x.device))
     return grad

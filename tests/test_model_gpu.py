@@ -246,3 +246,103 @@ def test_native_rollout_equals_generic_path(gpu_device, strategy, nan, border):
     assert abs(res[True][1] - res[False][1]) / abs(res[False][1]) < 1e-5
     for n in res[True][2]:
         assert rel_err(res[True][2][n], res[False][2][n]) < 5e-2, n  # chaotic BPTT (see test above); typical 1e-4
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# bf16 matrix-core flavour: operands are rounded to bf16 (RNE) in LDS, products accumulate in fp32.  The reference
+# below applies the same rounding to inputs and weights and convolves in float64, so the only difference left is
+# the fp32 accumulation order: the comparison is as strict as the fp32 one and checks every index mapping.
+def _bf(t):
+    return t.bfloat16().double()
+
+
+@pytest.mark.parametrize("CI,CIreal,ks,H,W", [(64, 64, 3, 16, 32), (96, 69, 3, 20, 40), (32, 10, 3, 8, 8), (64, 64, 1, 12, 36),
+                                                (64, 60, 3, 4, 4), (96, 96, 1, 8, 64), (64, 64, 3, 40, 72)])
+def test_conv_fwd_bf16_matches_rounded_reference(gpu_device, CI, CIreal, ks, H, W):
+    from py4cast_amd import ops_model as om
+
+    g = torch.Generator().manual_seed(CI + ks + H)
+    B, CO = 2, 64
+    x = torch.randn(B, H, W, CI, generator=g)
+    x[..., CIreal:] = 0
+    w = torch.randn(CO, CIreal, ks, ks, generator=g) * 0.1
+    scale = torch.rand(B, CI, generator=g) + 0.5
+    shift = torch.randn(B, CI, generator=g) * 0.3
+    for transform in (False, True):
+        xin = torch.relu(x * scale[:, None, None, :] + shift[:, None, None, :]) if transform else x
+        ref = Fn.conv2d(_bf(xin[..., :CIreal]).permute(0, 3, 1, 2), _bf(w), padding=ks // 2).permute(0, 2, 3, 1)
+        wp = om.prep_weights(w.to(gpu_device), False, 64, CI, compute="bf16")
+        out, stats = om.conv_fwd(x.to(gpu_device), wp, ks, in_scale=scale.to(gpu_device) if transform else None,
+                                 in_shift=shift.to(gpu_device) if transform else None, in_relu=transform, want_stats=True,
+                                 compute="bf16")
+        # with the fused input transform an fp32 last-bit difference (FMA contraction) can land on a bf16 rounding
+        # boundary and move that operand by one bf16 ulp: ~1e-4 on the output; index mistakes give O(1)
+        assert rel_err(out, ref) < (5e-4 if transform else 2e-5)
+        s = stats.sum(0).cpu().double()
+        np.testing.assert_allclose(s[0].numpy(), ref.sum((0, 1, 2)).numpy(), rtol=2e-3, atol=5e-2)
+        np.testing.assert_allclose(s[1].numpy(), (ref**2).sum((0, 1, 2)).numpy(), rtol=2e-3, atol=5e-2)
+
+
+@pytest.mark.parametrize("CIreal,ks,H,W", [(64, 3, 16, 32), (60, 3, 12, 20), (64, 1, 8, 40)])
+def test_conv_data_grad_bf16(gpu_device, CIreal, ks, H, W):
+    from py4cast_amd import ops_model as om
+
+    g = torch.Generator().manual_seed(7)
+    B, CO = 2, 64
+    x = torch.zeros(B, CIreal, H, W, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(CO, CIreal, ks, ks, generator=g) * 0.1
+    dout = torch.randn(B, H, W, CO, generator=g)
+    Fn.conv2d(x, _bf(w), padding=ks // 2).backward(_bf(dout).permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1)
+    wp = om.prep_weights(w.to(gpu_device), True, 64, 64, compute="bf16")
+    got = om.conv_fwd(dout.to(gpu_device), wp, ks, compute="bf16")
+    assert rel_err(got[..., :CIreal], ref) < 2e-5
+    assert float(got[..., CIreal:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("CI,CIreal,CO,ks,H,W", [(64, 64, 64, 3, 16, 32), (96, 69, 64, 3, 24, 40), (32, 10, 64, 3, 8, 8),
+                                                   (64, 64, 60, 1, 12, 36), (64, 64, 64, 3, 40, 72)])
+def test_conv_weight_grad_bf16(gpu_device, CI, CIreal, CO, ks, H, W):
+    from py4cast_amd import ops_model as om
+
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    x = torch.randn(B, H, W, CI, generator=g)
+    x[..., CIreal:] = 0
+    scale = torch.rand(B, CI, generator=g) + 0.5
+    shift = torch.randn(B, CI, generator=g) * 0.3
+    dout = torch.randn(B, H, W, 64, generator=g)
+    dout[..., CO:] = 0
+    w = torch.zeros(CO, CIreal, ks, ks, dtype=torch.float64, requires_grad=True)
+    xin = torch.relu(x * scale[:, None, None, :] + shift[:, None, None, :])
+    Fn.conv2d(_bf(xin[..., :CIreal]).permute(0, 3, 1, 2), w, padding=ks // 2).backward(_bf(dout[..., :CO]).permute(0, 3, 1, 2))
+    grad = torch.ones(CO, CIreal, ks, ks, device=gpu_device)
+    om.conv_wgrad(x.to(gpu_device), dout.to(gpu_device), ks, CO, CIreal, grad, scale.to(gpu_device), shift.to(gpu_device), True,
+                  compute="bf16")
+    assert rel_err(grad - 1.0, w.grad) < 5e-4  # fused input transform: see test_conv_fwd_bf16_matches_rounded_reference
+
+
+def test_halfunet_bf16_close_to_fp32_oracle(gpu_device):
+    """End to end with bf16 matrix cores: bf16 operand rounding (2^-9 relative per product) through 13 conv layers."""
+    from oracle.halfunet import HalfUNetRef
+    from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings
+
+    torch.manual_seed(0)
+    cin, cout, H, W = 69, 60, 64, 64
+    ref = HalfUNetRef(cin, cout).double()
+    model = HalfUNetMI355X(cin, cout, (H, W), HalfUNetSettings(compute_dtype="bf16"))
+    model.load_state_dict(HalfUNetRef(cin, cout).state_dict() if False else {k: v.float() for k, v in ref.state_dict().items()})
+    model = model.to(gpu_device).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, H, W, cin, generator=g)
+    gy = torch.randn(2, H, W, cout, generator=g)
+    ref.train()
+    yr = ref(x.double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    (yr * gy.double()).sum().backward()
+    yg = model(x.to(gpu_device))
+    (yg * gy.to(gpu_device)).sum().backward()
+    assert rel_err(yg, yr) < 8e-2
+    pr = dict(ref.named_parameters())
+    for name, p in model.named_parameters():  # direction of the gradient (bf16 noise through 13 ReLU/BN layers is large)
+        a, b = p.grad.detach().cpu().double().flatten(), pr[name].grad.flatten()
+        assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.9, name
