@@ -97,6 +97,15 @@ __device__ __forceinline__ void btile_store(const BTile<CI, LH, LW>& t, const fl
                                             const float* __restrict__ shift, int relu, char* lds, int b, int y0, int x0,
                                             int H, int W, int sc_cs) {
     constexpr int C8 = CI / 8;
+    constexpr bool FIXED = (256 % C8) == 0;  // the thread's channel octet is the same in every iteration
+    f32x4 sc_lo = {1, 1, 1, 1}, sc_hi = {1, 1, 1, 1}, sh_lo = {0, 0, 0, 0}, sh_hi = {0, 0, 0, 0};
+    if (FIXED && scale) {
+        const int c8 = threadIdx.x % C8;
+        const float* sc = scale + (int64_t)b * sc_cs + 8 * c8;
+        const float* sh = shift + (int64_t)b * sc_cs + 8 * c8;
+        sc_lo = *reinterpret_cast<const f32x4*>(sc); sc_hi = *reinterpret_cast<const f32x4*>(sc + 4);
+        sh_lo = *reinterpret_cast<const f32x4*>(sh); sh_hi = *reinterpret_cast<const f32x4*>(sh + 4);
+    }
 #pragma unroll
     for (int it = 0; it < BTile<CI, LH, LW>::ITERS; ++it) {
         const int idx = threadIdx.x + it * 256;
@@ -107,10 +116,14 @@ __device__ __forceinline__ void btile_store(const BTile<CI, LH, LW>& t, const fl
         f32x4 lo = t.lo[it], hi = t.hi[it];
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
             if (scale) {
-                const float* sc = scale + (int64_t)b * sc_cs + 8 * c8;
-                const float* sh = shift + (int64_t)b * sc_cs + 8 * c8;
-                lo = lo * *reinterpret_cast<const f32x4*>(sc) + *reinterpret_cast<const f32x4*>(sh);
-                hi = hi * *reinterpret_cast<const f32x4*>(sc + 4) + *reinterpret_cast<const f32x4*>(sh + 4);
+                if (!FIXED) {
+                    const float* sc = scale + (int64_t)b * sc_cs + 8 * c8;
+                    const float* sh = shift + (int64_t)b * sc_cs + 8 * c8;
+                    sc_lo = *reinterpret_cast<const f32x4*>(sc); sc_hi = *reinterpret_cast<const f32x4*>(sc + 4);
+                    sh_lo = *reinterpret_cast<const f32x4*>(sh); sh_hi = *reinterpret_cast<const f32x4*>(sh + 4);
+                }
+                lo = lo * sc_lo + sh_lo;
+                hi = hi * sc_hi + sh_hi;
             }
             if (relu) {
                 lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
@@ -156,28 +169,34 @@ __global__ void __launch_bounds__(256, 1)
     }
 
     BTile<CI, LH, LW> tr;
-    int tile = blockIdx.x;
-    auto coords = [&](int t, int& b, int& y0, int& x0) {
-        const int tx = t % tiles_x;
-        const int rest = t / tiles_x;
-        b = rest / tiles_y;
-        y0 = (rest - b * tiles_y) * TH;
+    // each workgroup walks a contiguous run of tiles ordered down a 32-pixel-wide strip (ty fastest): the two halo
+    // rows shared with the previous tile were fetched by this same CU a moment ago (L2 hits, not HBM re-reads)
+    const int t_begin = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
+    const int t_end = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    int tile = t_begin;
+    auto coords = [&](int t, int& b, int& y0, int& x0, int& canon) {
+        const int ty = t % tiles_y;
+        const int rest = t / tiles_y;
+        const int tx = rest % tiles_x;
+        b = rest / tiles_x;
+        y0 = ty * TH;
         x0 = tx * BTW;
+        canon = (b * tiles_y + ty) * tiles_x + tx;
     };
-    if (tile < ntiles) {
-        int b, y0, x0;
-        coords(tile, b, y0, x0);
+    if (tile < t_end) {
+        int b, y0, x0, cn;
+        coords(tile, b, y0, x0, cn);
         btile_load<CI, LH, LW, HALO>(tr, in, b, y0, x0, H, W, CI);
     }
-    for (; tile < ntiles; tile += gridDim.x) {
-        int b, y0, x0;
-        coords(tile, b, y0, x0);
+    for (; tile < t_end; ++tile) {
+        int b, y0, x0, canon;
+        coords(tile, b, y0, x0, canon);
         __syncthreads();  // previous tile (and its statistics scratch) fully consumed; weights landed
         btile_store<CI, LH, LW, HALO, ROWB>(tr, in_scale, in_shift, in_relu, lt, b, y0, x0, H, W, CI);
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) {  // next tile's loads fly during this tile's MFMAs
-            int nb, ny, nx;
-            coords(tile + gridDim.x, nb, ny, nx);
+        if (tile + 1 < t_end) {  // next tile's loads fly during this tile's MFMAs
+            int nb, ny, nx, ncn;
+            coords(tile + 1, nb, ny, nx, ncn);
             btile_load<CI, LH, LW, HALO>(tr, in, nb, ny, nx, H, W, CI);
         }
 
@@ -247,7 +266,7 @@ __global__ void __launch_bounds__(256, 1)
             __syncthreads();
             if (threadIdx.x < 128) {
                 const int t = threadIdx.x;
-                stat_partial[(int64_t)tile * 128 + t] = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+                stat_partial[(int64_t)canon * 128 + t] = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
             }
         }
     }
@@ -301,29 +320,31 @@ __global__ void __launch_bounds__(256, 1)
     BTile<CI, LH, LW> tr;
     BTile<64, TH, BTW> td;
     auto coords = [&](int t, int& b, int& y0, int& x0) {
-        const int tx = t % tiles_x;
-        const int rest = t / tiles_x;
-        b = rest / tiles_y;
-        y0 = (rest - b * tiles_y) * TH;
-        x0 = tx * BTW;
+        const int ty = t % tiles_y;
+        const int rest = t / tiles_y;
+        b = rest / tiles_x;
+        y0 = ty * TH;
+        x0 = (rest - b * tiles_x) * BTW;
     };
-    int tile = blockIdx.x;
-    if (tile < ntiles) {
+    const int t_begin = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
+    const int t_end = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    int tile = t_begin;
+    if (tile < t_end) {
         int b, y0, x0;
         coords(tile, b, y0, x0);
         btile_load<CI, LH, LW, HALO>(tr, inb, b, y0, x0, H, W, in_cs);
         btile_load<64, TH, BTW, 0>(td, dout, b, y0, x0, H, W, 64);
     }
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < t_end; ++tile) {
         int b, y0, x0;
         coords(tile, b, y0, x0);
         __syncthreads();
         btile_store<CI, LH, LW, HALO, ROWA>(tr, scb, shb, in_relu, lin, b, y0, x0, H, W, in_cs);
         btile_store<64, TH, BTW, 0, ROWD>(td, nullptr, nullptr, 0, ldo, b, y0, x0, H, W, 64);
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) {
+        if (tile + 1 < t_end) {
             int nb, ny, nx;
-            coords(tile + gridDim.x, nb, ny, nx);
+            coords(tile + 1, nb, ny, nx);
             btile_load<CI, LH, LW, HALO>(tr, inb, nb, ny, nx, H, W, in_cs);
             btile_load<64, TH, BTW, 0>(td, dout, nb, ny, nx, H, W, 64);
         }

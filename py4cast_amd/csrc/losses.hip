@@ -277,6 +277,132 @@ __global__ void scaled_loss_final_kernel(const float* __restrict__ partial, int 
     out[i] = v * std[f];                     // losses.py:208-210
 }
 
+// ------------------------------------------------------------------ fused AR update + loss, 16-byte vectorised
+// Same arithmetic (and operation order) as the scalar kernels below, for F % 4 == 0, F <= 64 and fp32 y/dy rows
+// whose stride is a multiple of 4: a lane owns 4 consecutive features of a grid point, so every access is a
+// 16-byte load/store and a wave covers 64/FP4 grid points per iteration.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+    ar_update_loss_fwd_v4_kernel(const float* __restrict__ prev, int64_t prev_bs, const float* __restrict__ y, int y_cs,
+                                 const float* __restrict__ target, int64_t tgt_bs, const float* __restrict__ std,
+                                 const float* __restrict__ mean, const float* __restrict__ border_mask,
+                                 const float* __restrict__ interior_mask, float* __restrict__ new_state, int64_t new_bs,
+                                 const float* __restrict__ weights, int kind, int mask_mode, float* __restrict__ partial,
+                                 int64_t N, int F, float keep_prev, int FP4) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int PP = 64 / FP4;
+    const int pp = lane / FP4, q = lane % FP4;
+    const bool act = 4 * q < F;
+    const bool from_nan = mask_mode == P4C_MASK_FROM_NAN;
+    v4f w = {0, 0, 0, 0}, sd = {1, 1, 1, 1}, mn = {0, 0, 0, 0};
+    if (act) {
+        w = *reinterpret_cast<const v4f*>(weights + 4 * q);
+        if (std) {
+            sd = *reinterpret_cast<const v4f*>(std + 4 * q);
+            mn = *reinterpret_cast<const v4f*>(mean + 4 * q);
+        }
+    }
+    float acc = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        if (!act) continue;
+        const float im = interior_mask[n];
+        const float bm = border_mask ? border_mask[n] : 0.0f;
+        const int64_t e = n * F + 4 * q;
+        const v4f yv = *reinterpret_cast<const v4f*>(y + ((int64_t)b * N + n) * y_cs + 4 * q);
+        v4f pv = {0, 0, 0, 0};
+        if (prev) pv = *reinterpret_cast<const v4f*>(prev + (int64_t)b * prev_bs + e);
+        v4f tg = *reinterpret_cast<const v4f*>(target + (int64_t)b * tgt_bs + e);
+        v4f o;
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float p0 = pv[j], t0 = tg[j], m = 1.0f;
+            if (from_nan) {
+                p0 = nan_to_zero(p0);
+                m = (t0 != t0) ? 0.0f : 1.0f;
+                t0 = nan_to_zero(t0);
+            }
+            float pr;
+            if (std) {
+                pr = p0 * keep_prev + yv[j] * sd[j];
+                pr = pr + mn[j];
+            } else {
+                pr = p0 * keep_prev + yv[j];
+            }
+            if (border_mask) pr = bm * t0 + im * pr;
+            o[j] = pr;
+            s += loss_elem(pr, t0, m, kind) * w[j];
+        }
+        *reinterpret_cast<v4f*>(new_state + (int64_t)b * new_bs + e) = o;
+        acc += s * im;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256)
+    ar_update_loss_bwd_v4_kernel(const float* __restrict__ g_next, int64_t g_next_bs, const float* __restrict__ g_next2,
+                                 int g2_cs, const float* __restrict__ gloss, int64_t gloss_stride,
+                                 const float* __restrict__ new_state, int64_t new_bs, const float* __restrict__ target,
+                                 int64_t tgt_bs, const float* __restrict__ std, const float* __restrict__ interior_mask,
+                                 int force_border, const float* __restrict__ weights, float num_interior,
+                                 const int32_t* __restrict__ masked_count, int kind, int mask_mode, float* __restrict__ dy,
+                                 int y_cs, float* dprev, int64_t dprev_bs, int64_t N, int F, float keep_prev, int FP4) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int PP = 64 / FP4;
+    const int pp = lane / FP4, q = lane % FP4;
+    const bool act = 4 * q < F, wr = 4 * q < y_cs;
+    const bool from_nan = mask_mode == P4C_MASK_FROM_NAN;
+    const float denom = num_interior - (masked_count ? (float)(*masked_count) : 0.0f);
+    const float scale = gloss ? gloss[(int64_t)b * gloss_stride] / denom : 0.0f;
+    v4f w = {0, 0, 0, 0}, sd = {1, 1, 1, 1};
+    if (act) {
+        w = *reinterpret_cast<const v4f*>(weights + 4 * q);
+        if (std) sd = *reinterpret_cast<const v4f*>(std + 4 * q);
+    }
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        if (!wr) continue;
+        v4f gy = {0, 0, 0, 0};
+        if (act) {
+            const float im = interior_mask[n];
+            const float sc = scale * im;
+            const float blend = force_border ? im : 1.0f;
+            const int64_t e = n * F + 4 * q;
+            const v4f ns = *reinterpret_cast<const v4f*>(new_state + (int64_t)b * new_bs + e);
+            const v4f tg = *reinterpret_cast<const v4f*>(target + (int64_t)b * tgt_bs + e);
+            v4f g1 = {0, 0, 0, 0}, g2 = {0, 0, 0, 0};
+            if (g_next) g1 = *reinterpret_cast<const v4f*>(g_next + (int64_t)b * g_next_bs + e);
+            if (g_next2) g2 = *reinterpret_cast<const v4f*>(g_next2 + ((int64_t)b * N + n) * g2_cs + 4 * q);
+            v4f gp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t0 = tg[j], m = 1.0f;
+                if (from_nan) {
+                    m = (t0 != t0) ? 0.0f : 1.0f;
+                    t0 = nan_to_zero(t0);
+                }
+                float g = sc * w[j] * loss_elem_grad(ns[j], t0, m, kind);
+                if (g_next) g += g1[j];
+                if (g_next2) g += g2[j];
+                gp[j] = g * blend;
+                gy[j] = std ? gp[j] * sd[j] : gp[j];
+            }
+            if (dprev) *reinterpret_cast<v4f*>(dprev + (int64_t)b * dprev_bs + e) = gp * keep_prev;
+        }
+        *reinterpret_cast<v4f*>(dy + ((int64_t)b * N + n) * y_cs + 4 * q) = gy;
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // ------------------------------------------------------------------ fused AR update + loss (training path)
 // grid: (nblk, B).  One (b, t=i) column of the loss.
 template <typename TY>
@@ -537,6 +663,20 @@ extern "C" int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const 
     P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE || mask_mode == P4C_MASK_FROM_NAN,
                   "p4c_ar_update_loss_fwd: only MASK_NONE / MASK_FROM_NAN are fused");
     P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS && y_cs >= F, "p4c_ar_update_loss_fwd: bad F / y_cs");
+    if (y_dtype == P4C_F32 && F % 4 == 0 && F <= 64 && y_cs % 4 == 0 && prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 &&
+        aligned16(prev) && aligned16(y) && aligned16(target) && aligned16(new_state) && aligned16(weights) && aligned16(std) &&
+        aligned16(mean)) {
+        const int FP4 = pow2_ge64(F / 4);
+        const int nblk4 = loss_blocks(N, 64 / FP4, B);
+        hipLaunchKernelGGL(ar_update_loss_fwd_v4_kernel, dim3(nblk4, B), dim3(256), 0, as_stream(stream), prev, prev_bs,
+                           (const float*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs,
+                           weights, kind, mask_mode, (float*)workspace, N, F, keep_prev, FP4);
+        P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(v4)");
+        hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const float*)workspace,
+                           nblk4, num_interior, masked_count, loss_out, loss_stride, B);
+        P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(final)");
+        return P4C_OK;
+    }
     const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
     const int nblk = loss_blocks(N, 64 / FP, B);
 #define P4C_LAUNCH_FWD(TY)                                                                                              \
@@ -569,6 +709,21 @@ extern "C" int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, co
                   "p4c_ar_update_loss_bwd: only MASK_NONE / MASK_FROM_NAN are fused");
     P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS && y_cs >= F, "p4c_ar_update_loss_bwd: bad F / y_cs");
     P4C_CHECK_ARG(dy_dtype == g2_dtype || !g_next2, "p4c_ar_update_loss_bwd: g_next2 dtype must equal dy dtype");
+    if (dy_dtype == P4C_F32 && F % 4 == 0 && y_cs % 4 == 0 && y_cs <= 256 && g_next_bs % 4 == 0 && new_bs % 4 == 0 &&
+        tgt_bs % 4 == 0 && dprev_bs % 4 == 0 && g2_cs % 4 == 0 && aligned16(g_next) && aligned16(g_next2) &&
+        aligned16(new_state) && aligned16(target) && aligned16(dy) && aligned16(dprev) && aligned16(weights) &&
+        aligned16(std)) {
+        const int FP4 = pow2_ge64(y_cs / 4);
+        if (y_cs / 4 <= 64) {
+            const int nblk4 = loss_blocks(N, 64 / FP4, B);
+            hipLaunchKernelGGL(ar_update_loss_bwd_v4_kernel, dim3(nblk4, B), dim3(256), 0, as_stream(stream), g_next,
+                               g_next_bs, (const float*)g_next2, g2_cs, gloss, gloss_stride, new_state, new_bs, target,
+                               tgt_bs, std, interior_mask, force_border, weights, num_interior, masked_count, kind,
+                               mask_mode, (float*)dy, y_cs, dprev, dprev_bs, N, F, keep_prev, FP4);
+            P4C_CHECK_LAUNCH("p4c_ar_update_loss_bwd(v4)");
+            return P4C_OK;
+        }
+    }
     const int FP = pow2_ge64(y_cs), iters = (y_cs + FP - 1) / FP;
     P4C_CHECK_ARG(iters <= LOSS_MAX_ITERS, "p4c_ar_update_loss_bwd: y_cs too large");
     const int nblk = loss_blocks(N, 64 / FP, B);

@@ -88,6 +88,65 @@ __global__ void __launch_bounds__(256) build_x_kernel(const float* __restrict__ 
     }
 }
 
+// 16-byte vectorised build_x (fp32 output, no NaN masking, c_pad % 4 == 0): a lane produces one float4 of the
+// output row; quads lying wholly inside the previous-state or statics block are one 16-byte load, the rest
+// (forcing rows are 5 floats = unaligned) are gathered element by element.  Stores are always 16 bytes.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+    build_x_v4_kernel(const float* __restrict__ prev, int64_t prev_bs, int64_t prev_ts, const float* __restrict__ statics,
+                      int64_t statics_bs, const float* __restrict__ forcing, int64_t forcing_bs, float* __restrict__ x,
+                      int c_pad, int B, int T_in, int64_t N, int F, int Fs, int Ff, int n_prev_ch, int FP4, int vec_prev,
+                      int vec_stat) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int PP = 64 / FP4;
+    const int pp = lane / FP4, q = lane % FP4;
+    const int c0 = 4 * q;
+    const int o_stat = n_prev_ch, o_forc = n_prev_ch + Fs, c_in = n_prev_ch + Fs + Ff;
+    const int64_t total = (int64_t)B * N;
+    if (c0 >= c_pad) return;
+    // classify the quad once (it is the same for every grid point)
+    int kind = 3;  // 0: vector prev, 1: vector statics, 2: all zero padding, 3: per-element gather
+    int t_idx = 0, f_idx = 0;
+    if (c0 + 3 < o_stat && vec_prev) {
+        t_idx = c0 / F;
+        f_idx = c0 - t_idx * F;
+        if (f_idx + 3 < F) kind = 0;
+    } else if (c0 >= o_stat && c0 + 3 < o_forc && vec_stat) {
+        kind = 1;
+    } else if (c0 >= c_in) {
+        kind = 2;
+    }
+    for (int64_t pix = (int64_t)wave * PP + pp; pix < total; pix += (int64_t)nwaves * PP) {
+        const int b = (int)(pix / N);
+        const int64_t n = pix - (int64_t)b * N;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (kind == 0) {
+            v = *reinterpret_cast<const v4f*>(prev + (int64_t)b * prev_bs + (int64_t)t_idx * prev_ts + n * F + f_idx);
+        } else if (kind == 1) {
+            v = *reinterpret_cast<const v4f*>(statics + (int64_t)b * statics_bs + n * Fs + (c0 - o_stat));
+        } else if (kind == 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                float e = 0.f;
+                if (c < o_stat) {
+                    const int t = c / F, f = c - t * F;
+                    e = prev[(int64_t)b * prev_bs + (int64_t)t * prev_ts + n * F + f];
+                } else if (c < o_forc) {
+                    e = statics[(int64_t)b * statics_bs + n * Fs + (c - o_stat)];
+                } else if (c < c_in) {
+                    e = forcing[(int64_t)b * forcing_bs + n * Ff + (c - o_forc)];
+                }
+                v[j] = e;
+            }
+        }
+        *reinterpret_cast<v4f*>(x + pix * (int64_t)c_pad + c0) = v;
+    }
+}
+
 template <typename TX>
 __global__ void __launch_bounds__(256) build_x_bwd_kernel(const TX* __restrict__ dx, int c_pad, float* __restrict__ dprev,
                                                           int B, int T_in, int64_t N, int F, int FP, int iters) {
@@ -223,6 +282,19 @@ extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, 
     const int FP = pow2_ge(c_pad);
     const int iters = (c_pad + FP - 1) / FP;
     P4C_CHECK_ARG(iters <= K1_MAX_ITERS, "p4c_build_x: c_pad %d too large (max %d)", c_pad, 64 * K1_MAX_ITERS);
+    if (x_dtype == P4C_F32 && !mask_on_nan && c_pad % 4 == 0 && c_pad <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const int FP4 = pow2_ge(c_pad / 4);
+        const int vec_prev = n_prev_ch > 0 && F % 4 == 0 && prev_bs % 4 == 0 && prev_ts % 4 == 0 &&
+                             (reinterpret_cast<uintptr_t>(prev) & 15) == 0;
+        const int vec_stat = Fs % 4 == 0 && n_prev_ch % 4 == 0 && statics_bs % 4 == 0 &&
+                             (reinterpret_cast<uintptr_t>(statics) & 15) == 0;
+        const int grid4 = stream_grid((int64_t)B * N, 64 / FP4);
+        hipLaunchKernelGGL(build_x_v4_kernel, dim3(grid4), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts, statics,
+                           statics_bs, forcing, forcing_bs, (float*)x, c_pad, B, T_in, N, F, Fs, Ff, n_prev_ch, FP4, vec_prev,
+                           vec_stat);
+        P4C_CHECK_LAUNCH("p4c_build_x(v4)");
+        return P4C_OK;
+    }
     const int grid = stream_grid((int64_t)B * N, 64 / FP);
     if (x_dtype == P4C_F32)
         hipLaunchKernelGGL(build_x_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
