@@ -15,6 +15,8 @@
 //                     offsets and no transposed copy is staged.
 //
 // At 16x the fp32 MFMA rate these kernels are HBM-bound: 2 * 4 B * 64 ch per pixel (read + write).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace p4c {
@@ -26,6 +28,20 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BTW = 32;  // tile width in pixels
+
+#ifdef P4C_STAMPS  // diagnostic build only: per-iteration s_memtime stamps of one compute and one loader wave
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ __forceinline__ void stamp(int slot) {
+    if (g_stamps && blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        g_stamps[slot] = t;
+    }
+}
+#define P4C_STAMP(slot) stamp(slot)
+#else
+#define P4C_STAMP(slot)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // prep_weights_bf16: canonical w[CO][CI][ks][ks] fp32 -> bf16 MFMA A-operand stream
@@ -61,61 +77,94 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Register image of a (LH x LW) halo tile of an fp32 NHWC tensor, 8 channels (32 B) per slot.
-template <int CI, int LH, int LW>
+// 8 channels of one pixel in registers, as loaded from an fp32 (32 B) or bf16 (16 B) NHWC tensor.
+template <typename T>
+struct Slot8;
+template <>
+struct Slot8<float> {
+    f32x4 lo, hi;
+    __device__ __forceinline__ void zero() { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; }
+    __device__ __forceinline__ void load(const float* p) {
+        lo = *reinterpret_cast<const f32x4*>(p);
+        hi = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    __device__ __forceinline__ void get(f32x4& a, f32x4& b) const { a = lo; b = hi; }
+    __device__ __forceinline__ bf16x8 raw() const { return pack8(lo, hi); }
+};
+template <>
+struct Slot8<__bf16> {
+    bf16x8 v;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+    }
+    __device__ __forceinline__ void load(const __bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void get(f32x4& a, f32x4& b) const {
+        a = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        b = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    }
+    __device__ __forceinline__ bf16x8 raw() const { return v; }
+};
+
+// Register image of a (LH x LW) halo tile of an NHWC tensor, 8 channels per slot.
+template <typename T, int CI, int LH, int LW>
 struct BTile {
     static constexpr int C8 = CI / 8;
     static constexpr int TOTAL = LH * LW * C8;
     static constexpr int ITERS = (TOTAL + 255) / 256;
-    f32x4 lo[ITERS], hi[ITERS];
+    Slot8<T> s[ITERS];
 };
 
-template <int CI, int LH, int LW, int HALO>
-__device__ __forceinline__ void btile_load(BTile<CI, LH, LW>& t, const float* __restrict__ in, int b, int y0, int x0, int H,
-                                           int W, int in_cs) {
+template <typename T, int CI, int LH, int LW, int HALO>
+__device__ __forceinline__ void btile_load(BTile<T, CI, LH, LW>& t, const T* __restrict__ in, int b, int y0, int x0, int H,
+                                           int W, int in_cs, int tid = threadIdx.x) {
     constexpr int C8 = CI / 8;
 #pragma unroll
-    for (int it = 0; it < BTile<CI, LH, LW>::ITERS; ++it) {
-        const int idx = threadIdx.x + it * 256;
+    for (int it = 0; it < BTile<T, CI, LH, LW>::ITERS; ++it) {
+        const int idx = tid + it * 256;
         const int pix = idx / C8, c8 = idx - pix * C8;
         const int ly = pix / LW, lx = pix - ly * LW;
         const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-        if (idx < BTile<CI, LH, LW>::TOTAL && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float* p = in + (((int64_t)b * H + gy) * W + gx) * in_cs + 8 * c8;
-            lo = *reinterpret_cast<const f32x4*>(p);
-            hi = *reinterpret_cast<const f32x4*>(p + 4);
-        }
-        t.lo[it] = lo;
-        t.hi[it] = hi;
+        t.s[it].zero();
+        if (idx < BTile<T, CI, LH, LW>::TOTAL && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            t.s[it].load(in + (((int64_t)b * H + gy) * W + gx) * in_cs + 8 * c8);
     }
 }
 
-// transform (norm + relu of the producer layer), round to bf16, write [pixel][channel] rows of ROWB bytes
-template <int CI, int LH, int LW, int HALO, int ROWB>
-__device__ __forceinline__ void btile_store(const BTile<CI, LH, LW>& t, const float* __restrict__ scale,
-                                            const float* __restrict__ shift, int relu, char* lds, int b, int y0, int x0,
-                                            int H, int W, int sc_cs) {
+// transform (norm + relu of the producer layer), round to bf16, write [pixel][channel] rows of ROWB bytes.
+// MODE 0: plain copy, 1: ReLU, 2: scale/shift (+ReLU if `relu`).  Branch-free per slot (out-of-image slots are
+// selected to zero AFTER the transform: zero padding applies to the normalised activation), so the unrolled
+// iterations stay one straight-line stream.
+template <typename T, int CI, int LH, int LW, int HALO, int ROWB, int MODE>
+__device__ __forceinline__ void btile_store_mode(const BTile<T, CI, LH, LW>& t, const float* __restrict__ scale,
+                                                 const float* __restrict__ shift, int relu, char* lds, int b, int y0,
+                                                 int x0, int H, int W, int sc_cs, int tid) {
     constexpr int C8 = CI / 8;
     constexpr bool FIXED = (256 % C8) == 0;  // the thread's channel octet is the same in every iteration
     f32x4 sc_lo = {1, 1, 1, 1}, sc_hi = {1, 1, 1, 1}, sh_lo = {0, 0, 0, 0}, sh_hi = {0, 0, 0, 0};
-    if (FIXED && scale) {
-        const int c8 = threadIdx.x % C8;
+    if (MODE == 2 && FIXED) {
+        const int c8 = tid % C8;
         const float* sc = scale + (int64_t)b * sc_cs + 8 * c8;
         const float* sh = shift + (int64_t)b * sc_cs + 8 * c8;
         sc_lo = *reinterpret_cast<const f32x4*>(sc); sc_hi = *reinterpret_cast<const f32x4*>(sc + 4);
         sh_lo = *reinterpret_cast<const f32x4*>(sh); sh_hi = *reinterpret_cast<const f32x4*>(sh + 4);
     }
+    const float lo_clamp = (MODE == 1 || relu) ? 0.f : -3.402823466e38f;
 #pragma unroll
-    for (int it = 0; it < BTile<CI, LH, LW>::ITERS; ++it) {
-        const int idx = threadIdx.x + it * 256;
-        if (idx >= BTile<CI, LH, LW>::TOTAL) break;
+    for (int it = 0; it < BTile<T, CI, LH, LW>::ITERS; ++it) {
+        const int idx = tid + it * 256;
+        if (idx >= BTile<T, CI, LH, LW>::TOTAL) break;
         const int pix = idx / C8, c8 = idx - pix * C8;
-        const int ly = pix / LW, lx = pix - ly * LW;
-        const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
-        f32x4 lo = t.lo[it], hi = t.hi[it];
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            if (scale) {
+        bf16x8 o;
+        if (MODE == 0) {
+            o = t.s[it].raw();
+        } else {
+            const int ly = pix / LW, lx = pix - ly * LW;
+            const int gy = y0 + ly - HALO, gx = x0 + lx - HALO;
+            const bool inb = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            f32x4 lo, hi;
+            t.s[it].get(lo, hi);
+            if (MODE == 2) {
                 if (!FIXED) {
                     const float* sc = scale + (int64_t)b * sc_cs + 8 * c8;
                     const float* sh = shift + (int64_t)b * sc_cs + 8 * c8;
@@ -125,35 +174,64 @@ __device__ __forceinline__ void btile_store(const BTile<CI, LH, LW>& t, const fl
                 lo = lo * sc_lo + sh_lo;
                 hi = hi * sc_hi + sh_hi;
             }
-            if (relu) {
-                lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
-                hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
-            }
+            lo.x = fmaxf(lo.x, lo_clamp); lo.y = fmaxf(lo.y, lo_clamp); lo.z = fmaxf(lo.z, lo_clamp); lo.w = fmaxf(lo.w, lo_clamp);
+            hi.x = fmaxf(hi.x, lo_clamp); hi.y = fmaxf(hi.y, lo_clamp); hi.z = fmaxf(hi.z, lo_clamp); hi.w = fmaxf(hi.w, lo_clamp);
+            const float keep = inb ? 1.f : 0.f;
+            o = pack8(lo * keep, hi * keep);
         }
-        *reinterpret_cast<bf16x8*>(lds + pix * ROWB + 16 * c8) = pack8(lo, hi);
+        *reinterpret_cast<bf16x8*>(lds + pix * ROWB + 16 * c8) = o;
     }
+}
+
+template <typename T, int CI, int LH, int LW, int HALO, int ROWB>
+__device__ __forceinline__ void btile_store(const BTile<T, CI, LH, LW>& t, const float* __restrict__ scale,
+                                            const float* __restrict__ shift, int relu, char* lds, int b, int y0, int x0,
+                                            int H, int W, int sc_cs, int tid = threadIdx.x) {
+    if (scale)
+        btile_store_mode<T, CI, LH, LW, HALO, ROWB, 2>(t, scale, shift, relu, lds, b, y0, x0, H, W, sc_cs, tid);
+    else if (relu)
+        btile_store_mode<T, CI, LH, LW, HALO, ROWB, 1>(t, scale, shift, relu, lds, b, y0, x0, H, W, sc_cs, tid);
+    else
+        btile_store_mode<T, CI, LH, LW, HALO, ROWB, 0>(t, scale, shift, relu, lds, b, y0, x0, H, W, sc_cs, tid);
+}
+
+// 4 consecutive output channels of one pixel
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(__bf16* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4*>(p) = o;
 }
 
 // ---------------------------------------------------------------------------------------------
 // conv_fwd_bf16: persistent, grid = G workgroups x M_pad/64 (blockIdx.y), 256 threads.
-// Tile TH x 32 pixels x 64 output channels; wave w owns rows [w*RW, (w+1)*RW), RW = TH/4.
-// LDS: weights [tap][kstep][h][64][8] bf16, then the halo tile with rows padded by one 16-byte slot
-// (row stride = odd number of slots -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots).
-template <int CI, int KS, int TH>
+// Tile 4 x 32 pixels x 64 output channels; wave w owns tile row w (one 32-pixel MFMA N-tile, two channel tiles).
+// LDS: weights [tap][kstep][h][64][8] bf16 for the whole launch, NBUF halo-tile buffers with rows padded by one
+// 16-byte slot (row stride = odd number of slots -> the 16 lanes of a ds_read_b128 group hit 16 distinct
+// slots), and a small statistics scratch.
+// NBUF = 2 (CI <= 64): software pipeline over tiles, ONE barrier per tile --
+//     MFMA(tile i from buf[i&1]) ; write registers(tile i+1) -> buf[~i&1] ; issue global loads(tile i+2) ;
+//     epilogue(tile i: stores + statistics) ; barrier
+//   so global-load latency spans a whole iteration and LDS writes overlap other waves' MFMAs.
+// NBUF = 1 (CI = 96, LDS-limited): load -> barrier -> MFMA with the next tile's loads in flight.
+template <typename T, int CI, int KS, int NBUF>
 __global__ void __launch_bounds__(256, 1)
-    conv_fwd_bf16_kernel(const float* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ in_scale,
-                         const float* __restrict__ in_shift, int in_relu, float* __restrict__ out, int out_cs,
+    conv_fwd_bf16_kernel(const T* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ in_scale,
+                         const float* __restrict__ in_shift, int in_relu, T* __restrict__ out, int out_cs,
                          float* __restrict__ stat_partial, int B, int H, int W) {
+    constexpr int TH = 4;
     constexpr int HALO = KS / 2;
     constexpr int LH = TH + 2 * HALO, LW = BTW + 2 * HALO;
     constexpr int ROWB = CI * 2 + 16;
-    constexpr int RW = TH / 4;
     constexpr int NTAPS = KS * KS;
     constexpr int NKS = CI / 16;
     constexpr int WBYTES = NTAPS * CI * 64 * 2;
+    constexpr int TILEB = (LH * LW * ROWB + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lw = smem;
     char* lt = smem + WBYTES;
+    // statistics scratch [4 waves][32][33] + 2 x [4][2][64]; with one tile buffer (LDS-limited) it aliases the tile
+    float* sscr = reinterpret_cast<float*>(NBUF == 2 ? smem + WBYTES + NBUF * TILEB : lt);
 
     const int mb = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -161,19 +239,16 @@ __global__ void __launch_bounds__(256, 1)
     const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y * B;
 
-    // weights -> LDS once per workgroup (linear copy, 16 B per thread and step)
-    {
+    {   // weights -> LDS once per workgroup (linear copy, 16 B per thread and step)
         const char* src = reinterpret_cast<const char*>(wp) + (int64_t)mb * WBYTES;
         for (int i = threadIdx.x * 16; i < WBYTES; i += 256 * 16)
             *reinterpret_cast<f32x4*>(lw + i) = *reinterpret_cast<const f32x4*>(src + i);
     }
 
-    BTile<CI, LH, LW> tr;
-    // each workgroup walks a contiguous run of tiles ordered down a 32-pixel-wide strip (ty fastest): the two halo
-    // rows shared with the previous tile were fetched by this same CU a moment ago (L2 hits, not HBM re-reads)
+    // each workgroup walks a contiguous run of tiles ordered down a 32-pixel-wide strip (ty fastest): the halo rows
+    // shared with the previous tile were fetched by this same CU a moment ago (L2 hits, not HBM re-reads)
     const int t_begin = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
     const int t_end = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
-    int tile = t_begin;
     auto coords = [&](int t, int& b, int& y0, int& x0, int& canon) {
         const int ty = t % tiles_y;
         const int rest = t / tiles_y;
@@ -183,92 +258,342 @@ __global__ void __launch_bounds__(256, 1)
         x0 = tx * BTW;
         canon = (b * tiles_y + ty) * tiles_x + tx;
     };
-    if (tile < t_end) {
+    BTile<T, CI, LH, LW> tr;
+    auto load = [&](int t) {
         int b, y0, x0, cn;
-        coords(tile, b, y0, x0, cn);
-        btile_load<CI, LH, LW, HALO>(tr, in, b, y0, x0, H, W, CI);
+        coords(t, b, y0, x0, cn);
+        btile_load<T, CI, LH, LW, HALO>(tr, in, b, y0, x0, H, W, CI);
+    };
+    auto store = [&](int t, char* buf) {
+        int b, y0, x0, cn;
+        coords(t, b, y0, x0, cn);
+        btile_store<T, CI, LH, LW, HALO, ROWB>(tr, in_scale, in_shift, in_relu, buf, b, y0, x0, H, W, CI);
+    };
+
+    if (t_begin >= t_end) return;
+    if (NBUF == 2) {
+        load(t_begin);
+        store(t_begin, lt);
+        if (t_begin + 1 < t_end) load(t_begin + 1);
+    } else {
+        load(t_begin);
     }
-    for (; tile < t_end; ++tile) {
+    __syncthreads();
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
         int b, y0, x0, canon;
         coords(tile, b, y0, x0, canon);
-        __syncthreads();  // previous tile (and its statistics scratch) fully consumed; weights landed
-        btile_store<CI, LH, LW, HALO, ROWB>(tr, in_scale, in_shift, in_relu, lt, b, y0, x0, H, W, CI);
-        __syncthreads();
-        if (tile + 1 < t_end) {  // next tile's loads fly during this tile's MFMAs
-            int nb, ny, nx, ncn;
-            coords(tile + 1, nb, ny, nx, ncn);
-            btile_load<CI, LH, LW, HALO>(tr, in, nb, ny, nx, H, W, CI);
+        char* cur = lt;
+        if (NBUF == 2) {
+            cur = lt + ((tile - t_begin) & 1) * TILEB;
+        } else {
+            store(tile, lt);
+            __syncthreads();
+            if (tile + 1 < t_end) load(tile + 1);
         }
 
-        f32x16 acc[2][RW];
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < RW; ++pt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[ct][pt][i] = 0.f;
-
+        for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
         const char* wl = lw + (h * 64 + r) * 16;
 #pragma unroll 1
         for (int tap = 0; tap < NTAPS; ++tap) {
             const int ky = tap / KS, kx = tap - ky * KS;
-            const char* pl = lt + ((wv * RW + ky) * LW + (r + kx)) * ROWB + 16 * h;
+            const char* pl = cur + ((wv + ky) * LW + (r + kx)) * ROWB + 16 * h;
             const char* wt = wl + tap * NKS * 2048;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wt + ks * 2048);
                 const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wt + ks * 2048 + 512);
-#pragma unroll
-                for (int pt = 0; pt < RW; ++pt) {
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(pl + pt * LW * ROWB + 32 * ks);
-                    acc[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[0][pt], 0, 0, 0);
-                    acc[1][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[1][pt], 0, 0, 0);
-                }
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(pl + 32 * ks);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
             }
         }
 
+        if (NBUF == 2) {
+            // the other buffer was last read by MFMA(tile-1), which every wave finished before the previous barrier
+            if (tile + 1 < t_end) store(tile + 1, lt + (((tile - t_begin) & 1) ^ 1) * TILEB);
+            if (tile + 2 < t_end) load(tile + 2);
+        }
+
         // ---- epilogue: C[co][px]; lane = pixel r (+ half h), register i -> co = (i&3) + 8*(i>>2) + 4*h
-        const int gx = x0 + r;
-        if (stat_partial) __syncthreads();  // tile reads done: its LDS is reused for the statistics transpose
-        float* tw = reinterpret_cast<float*>(lt) + wv * (64 * 33);
+        if (NBUF == 1 && stat_partial) __syncthreads();  // every wave is done reading the tile the scratch aliases
+        const int gx = x0 + r, gy = y0 + wv;
+        const bool valid = (gy < H) && (gx < W);
+        T* orow = out + (((int64_t)b * H + gy) * W + gx) * out_cs + mb * 64 + 4 * h;
+        float* tw = sscr + wv * (32 * 33);
         float a1s = 0.f, a2s = 0.f;
 #pragma unroll
-        for (int pt = 0; pt < RW; ++pt) {
-            const int gy = y0 + wv * RW + pt;
-            const bool valid = (gy < H) && (gx < W);
-            float* orow = out + (((int64_t)b * H + gy) * W + gx) * out_cs + mb * 64 + 4 * h;
+        for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& a = ct == 0 ? acc0 : acc1;
+                const f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                if (valid) store4(orow + ct * 32 + 8 * g, v);
+                if (stat_partial) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = {acc[ct][pt][4 * g], acc[ct][pt][4 * g + 1], acc[ct][pt][4 * g + 2], acc[ct][pt][4 * g + 3]};
-                    if (valid) *reinterpret_cast<f32x4*>(orow + ct * 32 + 8 * g) = v;
-                    if (stat_partial) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) tw[(ct * 32 + 8 * g + 4 * h + j) * 33 + r] = valid ? v[j] : 0.f;
-                    }
+                    for (int j = 0; j < 4; ++j) tw[(8 * g + 4 * h + j) * 33 + r] = valid ? v[j] : 0.f;
                 }
+            }
             if (stat_partial) {
-                // the wave wrote its own [64][32] block; lane l sums row co = l (stride 33: conflict-free)
-                const float* row = tw + lane * 33;
+                // the wave wrote its own [32 co][32 px] block; lane l < 32 sums row l (stride 33: conflict-free)
+                const float* row = tw + r * 33;
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 32; ++k) {
                     const float o = row[k];
-                    a1s += o;
-                    a2s += o * o;
+                    s1 += o;
+                    s2 += o * o;
                 }
+                if ((lane >> 5) == ct) { a1s = s1; a2s = s2; }  // lanes 0-31 keep ct=0, lanes 32-63 keep ct=1: co = lane
             }
         }
         if (stat_partial) {
-            float* red = reinterpret_cast<float*>(lt) + 4 * 64 * 33;  // [wave][stat][64]
+            float* red = sscr + 4 * 32 * 33 + ((tile - t_begin) & 1) * 512;  // [parity][wave][stat][64]
             red[(wv * 2 + 0) * 64 + lane] = a1s;
             red[(wv * 2 + 1) * 64 + lane] = a2s;
-            __syncthreads();
-            if (threadIdx.x < 128) {
-                const int t = threadIdx.x;
-                stat_partial[(int64_t)canon * 128 + t] = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
-            }
         }
+        __syncthreads();
+        if (stat_partial && threadIdx.x < 128) {
+            const float* red = sscr + 4 * 32 * 33 + ((tile - t_begin) & 1) * 512;
+            const int t = threadIdx.x;
+            stat_partial[(int64_t)canon * 128 + t] = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+        }
+    }
+}
+
+// workgroup barrier that orders LDS traffic only: global loads (the loader's prefetch) and stores (the epilogue)
+// stay in flight across it.  __syncthreads() would drain vmcnt(0) and expose a full memory latency per tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Per-wave flush of the running channel statistics: lane (r,h) holds, for register i of channel tile ct, the sum
+// over ITS pixels of channel co = ct*32 + (i&3) + 8*(i>>2) + 4*h.  The 32 pixel-lanes are summed through a
+// [32 co][33] LDS transpose (conflict-free) and lane l writes channel l of slot `dst` ([2][64] floats).
+__device__ __forceinline__ void flush_stats(float (&s1)[2][16], float (&s2)[2][16], float* tw, float* dst, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float keep = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tw[((i & 3) + 8 * (i >> 2) + 4 * h) * 33 + r] = st == 0 ? s1[ct][i] : s2[ct][i];
+            const float* row = tw + r * 33;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s += row[k];
+            if (h == ct) keep = s;  // lanes 0-31 -> channels 0-31, lanes 32-63 -> channels 32-63
+        }
+        dst[st * 64 + lane] = keep;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s1[ct][i] = s2[ct][i] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_fwd_bf16_ws: the tile pipeline with ROLE-SPLIT waves (512 threads): waves 0-3 only run the matrix phase +
+// epilogue, waves 4-7 only stage tiles (global -> registers -> normalise/ReLU/round -> LDS).  With one 4-wave
+// workgroup per CU every staging instruction would sit in the MFMA waves' issue stream; with the split the two
+// waves of each SIMD run a matrix-heavy and a memory-heavy stream side by side.  One LDS-only barrier per tile.
+//   iteration i:  compute waves: MFMA(buf[i&1]) ; epilogue(i)
+//                 loader waves : write regs(tile i+1) -> buf[~i&1] ; issue loads(tile i+2)
+// Channel statistics are accumulated in registers over all tiles of a sample and flushed once per
+// (sample, wave): stat_partial[b][G*4][2][64], zero-filled by the launcher.
+template <typename T, int CI, int KS>
+__global__ void __launch_bounds__(512, 2)
+    conv_fwd_bf16_ws_kernel(const T* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ in_scale,
+                            const float* __restrict__ in_shift, int in_relu, T* __restrict__ out, int out_cs,
+                            float* __restrict__ stat_partial, int B, int H, int W) {
+    constexpr int TH = 4;
+    constexpr int HALO = KS / 2;
+    constexpr int LH = TH + 2 * HALO, LW = BTW + 2 * HALO;
+    constexpr int ROWB = CI * 2 + 16;
+    constexpr int NTAPS = KS * KS;
+    constexpr int NKS = CI / 16;
+    constexpr int WBYTES = NTAPS * CI * 64 * 2;
+    constexpr int TILEB = (LH * LW * ROWB + 15) / 16 * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lw = smem;
+    char* lt = smem + WBYTES;
+    float* sscr = reinterpret_cast<float*>(smem + WBYTES + 2 * TILEB);  // [4 waves][32][33] statistics transpose
+
+    const int mb = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool loader = wv >= 4;
+    const int ltid = threadIdx.x - 256;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * B;
+
+    const int t_begin = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
+    const int t_end = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    auto coords = [&](int t, int& b, int& y0, int& x0) {
+        const int ty = t % tiles_y;
+        const int rest = t / tiles_y;
+        const int tx = rest % tiles_x;
+        b = rest / tiles_x;
+        y0 = ty * TH;
+        x0 = tx * BTW;
+    };
+    if (t_begin >= t_end) return;
+
+    const char* wsrc = reinterpret_cast<const char*>(wp) + (int64_t)mb * WBYTES;
+    constexpr int WIT = (WBYTES + 512 * 16 - 1) / (512 * 16);
+    // weights -> LDS once per workgroup: all loads of a thread are issued before its stores
+    auto copy_weights = [&]() {
+        f32x4 wr[WIT];
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = (threadIdx.x + it * 512) * 16;
+            if (i < WBYTES) wr[it] = *reinterpret_cast<const f32x4*>(wsrc + i);
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = (threadIdx.x + it * 512) * 16;
+            if (i < WBYTES) *reinterpret_cast<f32x4*>(lw + i) = wr[it];
+        }
+    };
+
+    // The two roles run SEPARATE loops (same number of barriers) so that their register sets do not add up.
+    if (loader) {
+        // two register images (A, B) alternate: while tile i+1 is transformed and written to LDS from one of them,
+        // the loads of tiles i+2 and i+3 are already in flight in the other / re-issued into the freed one, so
+        // about two tiles of global loads are outstanding per CU at any time (memory-level parallelism).
+        BTile<T, CI, LH, LW> ta, tb;
+        auto load = [&](BTile<T, CI, LH, LW>& tr, int t) {
+            if (t >= t_end) return;
+            int b, y0, x0;
+            coords(t, b, y0, x0);
+            btile_load<T, CI, LH, LW, HALO>(tr, in, b, y0, x0, H, W, CI, ltid);
+        };
+        auto store = [&](const BTile<T, CI, LH, LW>& tr, int t, char* buf) {
+            if (t >= t_end) return;
+            int b, y0, x0;
+            coords(t, b, y0, x0);
+            btile_store<T, CI, LH, LW, HALO, ROWB>(tr, in_scale, in_shift, in_relu, buf, b, y0, x0, H, W, CI, ltid);
+        };
+        load(ta, t_begin);      // first tiles' loads fly while the weights are copied
+        load(tb, t_begin + 1);
+        copy_weights();
+        store(ta, t_begin, lt);
+        load(ta, t_begin + 2);
+        lds_barrier();
+        // iteration `tile`: stage tile+1 into the buffer the compute waves are NOT reading
+        for (int tile = t_begin; tile < t_end; tile += 2) {
+            P4C_STAMP(1000 + 4 * (tile - t_begin) + 0);
+            store(tb, tile + 1, lt + TILEB);   // (tile - t_begin) even -> compute reads buffer 0
+            P4C_STAMP(1000 + 4 * (tile - t_begin) + 1);
+            load(tb, tile + 3);
+            P4C_STAMP(1000 + 4 * (tile - t_begin) + 2);
+            lds_barrier();
+            P4C_STAMP(1000 + 4 * (tile - t_begin) + 3);
+            if (tile + 1 >= t_end) break;
+            P4C_STAMP(1000 + 4 * (tile + 1 - t_begin) + 0);
+            store(ta, tile + 2, lt);           // compute reads buffer 1
+            P4C_STAMP(1000 + 4 * (tile + 1 - t_begin) + 1);
+            load(ta, tile + 4);
+            P4C_STAMP(1000 + 4 * (tile + 1 - t_begin) + 2);
+            lds_barrier();
+            P4C_STAMP(1000 + 4 * (tile + 1 - t_begin) + 3);
+        }
+        return;
+    }
+
+    copy_weights();
+    lds_barrier();
+    float s1[2][16], s2[2][16];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s1[ct][i] = s2[ct][i] = 0.f;
+    int cur_b = -1;
+    float* tw = sscr + wv * (32 * 33);
+    const int nslot = gridDim.x * 4;
+    const char* wl = lw + (h * 64 + r) * 16;
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int par = (tile - t_begin) & 1;
+        int b, y0, x0;
+        coords(tile, b, y0, x0);
+        if (stat_partial && b != cur_b) {
+            if (cur_b >= 0) flush_stats(s1, s2, tw, stat_partial + ((int64_t)cur_b * nslot + blockIdx.x * 4 + wv) * 128, lane);
+            cur_b = b;
+        }
+        P4C_STAMP(4 * (tile - t_begin) + 0);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+        const char* pl = lt + par * TILEB + (wv * LW + r) * ROWB + 16 * h;
+        // fully unrolled tap stream with operand double buffering at TAP granularity: the 3*NKS ds_read_b128 of tap
+        // t+1 are issued before the 2*NKS MFMAs of tap t (>= 256 cycles of matrix work cover the LDS read latency;
+        // a one-step look-ahead of 64 cycles does not: measured 65 cycles per MFMA instead of 32)
+        bf16x8 fa0[2][NKS], fa1[2][NKS], fb[2][NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            fa0[0][ks] = *reinterpret_cast<const bf16x8*>(wl + ks * 2048);
+            fa1[0][ks] = *reinterpret_cast<const bf16x8*>(wl + ks * 2048 + 512);
+            fb[0][ks] = *reinterpret_cast<const bf16x8*>(pl + 32 * ks);
+        }
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int cb = tap & 1, nb = cb ^ 1;
+            if (tap + 1 < NTAPS) {
+                const int ky = (tap + 1) / KS, kx = (tap + 1) % KS;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    fa0[nb][ks] = *reinterpret_cast<const bf16x8*>(wl + ((tap + 1) * NKS + ks) * 2048);
+                    fa1[nb][ks] = *reinterpret_cast<const bf16x8*>(wl + ((tap + 1) * NKS + ks) * 2048 + 512);
+                    fb[nb][ks] = *reinterpret_cast<const bf16x8*>(pl + (ky * LW + kx) * ROWB + 32 * ks);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this tap's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[cb][ks], fb[cb][ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[cb][ks], fb[cb][ks], acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        P4C_STAMP(4 * (tile - t_begin) + 1);
+        // ---- epilogue: C[co][px]; lane = pixel r (+ half h), register i -> co = (i&3) + 8*(i>>2) + 4*h
+        const int gx = x0 + r, gy = y0 + wv;
+        const bool valid = (gy < H) && (gx < W);
+        const float vkeep = valid ? 1.f : 0.f;
+        T* orow = out + (((int64_t)b * H + gy) * W + gx) * out_cs + mb * 64 + 4 * h;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& a = ct == 0 ? acc0 : acc1;
+                const f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                if (valid) store4(orow + ct * 32 + 8 * g, v);
+                if (stat_partial) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float o = v[j] * vkeep;
+                        s1[ct][4 * g + j] += o;
+                        s2[ct][4 * g + j] += o * o;
+                    }
+                }
+            }
+        P4C_STAMP(4 * (tile - t_begin) + 2);
+        lds_barrier();
+        P4C_STAMP(4 * (tile - t_begin) + 3);
+    }
+    if (stat_partial) {
+        flush_stats(s1, s2, tw, stat_partial + ((int64_t)cur_b * nslot + blockIdx.x * 4 + wv) * 128, lane);
+        // samples this workgroup never touched: its slots must read as zero (no memset pass needed)
+        int bf, y0, x0;
+        coords(t_begin, bf, y0, x0);
+        for (int b = 0; b < B; ++b)
+            if (b < bf || b > cur_b) {
+                float* dst = stat_partial + ((int64_t)b * nslot + blockIdx.x * 4 + wv) * 128;
+                dst[lane] = 0.f;
+                dst[64 + lane] = 0.f;
+            }
     }
 }
 
@@ -278,10 +603,10 @@ __global__ void __launch_bounds__(256, 1)
 // MFMA per tap and 16-pixel K step: A[i=ci][k=px], B[k=px][j=co]; both operands are transposing LDS reads
 // (ds_read_b64_tr_b16: 4 pixel rows x 16 channels per 16-lane group) of the [pixel][channel] bf16 images.
 // Row strides of 64 B (mod 256) make the 4 rows x 2 groups of a half-wave cover all 64 banks once.
-template <int CI, int KS>
+template <typename T, int CI, int KS>
 __global__ void __launch_bounds__(256, 1)
-    conv_wgrad_bf16_kernel(const float* __restrict__ in, const float* __restrict__ in_scale,
-                           const float* __restrict__ in_shift, int in_relu, const float* __restrict__ dout,
+    conv_wgrad_bf16_kernel(const T* __restrict__ in, const float* __restrict__ in_scale,
+                           const float* __restrict__ in_shift, int in_relu, const T* __restrict__ dout,
                            float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip) {
     constexpr int TH = 8;
     constexpr int HALO = KS / 2;
@@ -302,7 +627,7 @@ __global__ void __launch_bounds__(256, 1)
     const int cit = unit >> 1, cot = unit & 1;
     const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y * B;
-    const float* inb = in + ci_off;
+    const T* inb = in + ci_off;
     const float* scb = in_scale ? in_scale + ci_off : nullptr;
     const float* shb = in_shift ? in_shift + ci_off : nullptr;
 
@@ -317,8 +642,8 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    BTile<CI, LH, LW> tr;
-    BTile<64, TH, BTW> td;
+    BTile<T, CI, LH, LW> tr;
+    BTile<T, 64, TH, BTW> td;
     auto coords = [&](int t, int& b, int& y0, int& x0) {
         const int ty = t % tiles_y;
         const int rest = t / tiles_y;
@@ -332,37 +657,31 @@ __global__ void __launch_bounds__(256, 1)
     if (tile < t_end) {
         int b, y0, x0;
         coords(tile, b, y0, x0);
-        btile_load<CI, LH, LW, HALO>(tr, inb, b, y0, x0, H, W, in_cs);
-        btile_load<64, TH, BTW, 0>(td, dout, b, y0, x0, H, W, 64);
+        btile_load<T, CI, LH, LW, HALO>(tr, inb, b, y0, x0, H, W, in_cs);
+        btile_load<T, 64, TH, BTW, 0>(td, dout, b, y0, x0, H, W, 64);
     }
     for (; tile < t_end; ++tile) {
         int b, y0, x0;
         coords(tile, b, y0, x0);
         __syncthreads();
-        btile_store<CI, LH, LW, HALO, ROWA>(tr, scb, shb, in_relu, lin, b, y0, x0, H, W, in_cs);
-        btile_store<64, TH, BTW, 0, ROWD>(td, nullptr, nullptr, 0, ldo, b, y0, x0, H, W, 64);
+        btile_store<T, CI, LH, LW, HALO, ROWA>(tr, scb, shb, in_relu, lin, b, y0, x0, H, W, in_cs);
+        btile_store<T, 64, TH, BTW, 0, ROWD>(td, nullptr, nullptr, 0, ldo, b, y0, x0, H, W, 64);
         __syncthreads();
         if (tile + 1 < t_end) {
             int nb, ny, nx;
             coords(tile + 1, nb, ny, nx);
-            btile_load<CI, LH, LW, HALO>(tr, inb, nb, ny, nx, H, W, in_cs);
-            btile_load<64, TH, BTW, 0>(td, dout, nb, ny, nx, H, W, 64);
+            btile_load<T, CI, LH, LW, HALO>(tr, inb, nb, ny, nx, H, W, in_cs);
+            btile_load<T, 64, TH, BTW, 0>(td, dout, nb, ny, nx, H, W, 64);
         }
 #pragma unroll 1
         for (int kk = 0; kk < KSTEPS; ++kk) {
             const int kstep = ksl * KSTEPS + kk;        // 16 pixels: row kstep>>1, columns (kstep&1)*16 ..
             const int row = kstep >> 1, col0 = (kstep & 1) * 16;
             const int px = col0 + 8 * h + tq;           // this lane's pixel for the first 4-row block (+4 for the second)
-            // B operand: dOut[px][co]
             const char* bp = ldo + (row * BTW + px) * ROWD + b_col;
-            const s16x4 b_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
-            const s16x4 b_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 4 * ROWD));
-            bf16x8 bv;
-            {
-                union { s16x4 s[2]; bf16x8 v; } u;
-                u.s[0] = b_lo; u.s[1] = b_hi;
-                bv = u.v;
-            }
+            union { s16x4 s[2]; bf16x8 v; } ub;
+            ub.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+            ub.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 4 * ROWD));
             const char* ap0 = lin + (row * LW + px) * ROWA + a_col;
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
@@ -371,7 +690,7 @@ __global__ void __launch_bounds__(256, 1)
                 union { s16x4 s[2]; bf16x8 v; } u;
                 u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap));
                 u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap + 4 * ROWA));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, bv, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ub.v, acc[t], 0, 0, 0);
             }
         }
     }
@@ -387,20 +706,24 @@ __global__ void __launch_bounds__(256, 1)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int CI, int KS, int TH>
-static int launch_conv_fwd_bf16(const float* in, const __bf16* wp, const float* in_scale, const float* in_shift, int in_relu,
-                                float* out, int out_cs, float* stat_partial, int B, int H, int W, int m_blocks,
+template <typename T, int CI, int KS, int NBUF>
+static int launch_conv_fwd_bf16(const T* in, const __bf16* wp, const float* in_scale, const float* in_shift, int in_relu,
+                                T* out, int out_cs, float* stat_partial, int B, int H, int W, int m_blocks,
                                 hipStream_t stream) {
+    constexpr int TH = 4;
     constexpr int HALO = KS / 2;
     constexpr int LH = TH + 2 * HALO, LW = BTW + 2 * HALO;
-    size_t tile_b = (size_t)LH * LW * (CI * 2 + 16);
-    const size_t stat_b = (4 * 64 * 33 + 4 * 2 * 64) * sizeof(float);
-    if (tile_b < stat_b) tile_b = stat_b;
-    const size_t smem = (size_t)KS * KS * CI * 64 * 2 + tile_b;
-    auto kern = conv_fwd_bf16_kernel<CI, KS, TH>;
+    constexpr int TILEB = (LH * LW * (CI * 2 + 16) + 15) / 16 * 16;
+    const size_t scratch = (4 * 32 * 33 + 2 * 4 * 2 * 64) * sizeof(float);
+    const size_t smem = (size_t)KS * KS * CI * 64 * 2 + (NBUF == 2 ? (size_t)2 * TILEB + scratch : (TILEB > scratch ? TILEB : scratch));
     static bool attr_set = false;
     if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (NBUF == 2)
+            P4C_CHECK_HIP(hipFuncSetAttribute((const void*)conv_fwd_bf16_ws_kernel<T, CI, KS>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        else
+            P4C_CHECK_HIP(hipFuncSetAttribute((const void*)conv_fwd_bf16_kernel<T, CI, KS, NBUF>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + TH - 1) / TH;
@@ -409,22 +732,26 @@ static int launch_conv_fwd_bf16(const float* in, const __bf16* wp, const float* 
     if (ntiles < G) G = (int)ntiles;
     const int tag = (CI == 64 && KS == 3 && m_blocks == 1) ? P4C_PROF_CONV3X3_C64 : 0;
     if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
-    hipLaunchKernelGGL(kern, dim3(G, m_blocks), dim3(256), smem, stream, in, wp, in_scale, in_shift, in_relu, out, out_cs,
-                       stat_partial, B, H, W);
+    if (NBUF == 2)
+        hipLaunchKernelGGL((conv_fwd_bf16_ws_kernel<T, CI, KS>), dim3(G, m_blocks), dim3(512), smem, stream, in, wp, in_scale,
+                           in_shift, in_relu, out, out_cs, stat_partial, B, H, W);
+    else
+        hipLaunchKernelGGL((conv_fwd_bf16_kernel<T, CI, KS, NBUF>), dim3(G, m_blocks), dim3(256), smem, stream, in, wp,
+                           in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W);
     if (tag) prof_end(tag, stream);
     P4C_CHECK_LAUNCH("conv_fwd_bf16");
     return P4C_OK;
 }
 
-template <int CI, int KS>
-static int launch_conv_wgrad_bf16(const float* in, const float* in_scale, const float* in_shift, int in_relu,
-                                  const float* dout, float* partial, int G, int B, int H, int W, int in_cs, int ci_off,
-                                  int part_cip, hipStream_t stream) {
+template <typename T, int CI, int KS>
+static int launch_conv_wgrad_bf16(const T* in, const float* in_scale, const float* in_shift, int in_relu, const T* dout,
+                                  float* partial, int G, int B, int H, int W, int in_cs, int ci_off, int part_cip,
+                                  hipStream_t stream) {
     constexpr int HALO = KS / 2;
     constexpr int LH = 8 + 2 * HALO, LW = BTW + 2 * HALO;
     constexpr int ROWA = (CI * 2) % 256 == 64 ? CI * 2 : CI * 2 + 64;
     const size_t smem = (size_t)LH * LW * ROWA + (size_t)8 * BTW * 192;
-    auto kern = conv_wgrad_bf16_kernel<CI, KS>;
+    auto kern = conv_wgrad_bf16_kernel<T, CI, KS>;
     static bool attr_set = false;
     if (!attr_set) {
         P4C_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -439,28 +766,46 @@ static int launch_conv_wgrad_bf16(const float* in, const float* in_scale, const 
     return P4C_OK;
 }
 
-// tiles of the bf16 forward kernel (statistics partial buffers are indexed by tile)
-int conv_bf16_tile_h(int CI) { return CI <= 64 ? 8 : 4; }
+// rows per sample of the statistics partial buffer written by conv_fwd_bf16
+int conv_bf16_stat_slots(int CI, int B, int H, int W) {
+    const int tiles = ((H + 3) / 4) * ((W + BTW - 1) / BTW);
+    if (CI > 64) return tiles;  // per-tile partials (single-buffer kernel)
+    int64_t ntiles = (int64_t)tiles * B;
+    const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
+    return G * 4;               // per (workgroup, compute wave) partials
+}
 
-int conv_fwd_bf16(const float* in, int CI, const void* wp, int ks, const float* in_scale, const float* in_shift,
-                  int in_relu, float* out, int out_cs, float* stat_partial, int B, int H, int W, int m_blocks,
-                  hipStream_t stream) {
+template <typename T>
+static int conv_fwd_bf16_t(const T* in, int CI, const void* wp, int ks, const float* in_scale, const float* in_shift,
+                           int in_relu, T* out, int out_cs, float* stat_partial, int B, int H, int W, int m_blocks,
+                           hipStream_t stream) {
     const __bf16* w = (const __bf16*)wp;
-#define P4C_CASE(ci, k, th)                                                                                          \
+#define P4C_CASE(ci, k, nb)                                                                                          \
     if (CI == ci && ks == k)                                                                                         \
-        return launch_conv_fwd_bf16<ci, k, th>(in, w, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, \
-                                               m_blocks, stream);
-    P4C_CASE(32, 3, 8) P4C_CASE(64, 3, 8) P4C_CASE(96, 3, 4) P4C_CASE(32, 1, 8) P4C_CASE(64, 1, 8) P4C_CASE(96, 1, 4)
+        return launch_conv_fwd_bf16<T, ci, k, nb>(in, w, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, \
+                                                  W, m_blocks, stream);
+    P4C_CASE(32, 3, 2) P4C_CASE(64, 3, 2) P4C_CASE(96, 3, 1) P4C_CASE(32, 1, 2) P4C_CASE(64, 1, 2) P4C_CASE(96, 1, 1)
 #undef P4C_CASE
     return fail(P4C_ERR_UNSUPPORTED, "conv_fwd_bf16: unsupported (CI=%d, ks=%d)", CI, ks);
+}
+
+int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
+                  const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
+                  int m_blocks, hipStream_t stream) {
+    if (storage == P4C_BF16)
+        return conv_fwd_bf16_t<__bf16>((const __bf16*)in, CI, wp, ks, in_scale, in_shift, in_relu, (__bf16*)out, out_cs,
+                                       stat_partial, B, H, W, m_blocks, stream);
+    return conv_fwd_bf16_t<float>((const float*)in, CI, wp, ks, in_scale, in_shift, in_relu, (float*)out, out_cs, stat_partial,
+                                  B, H, W, m_blocks, stream);
 }
 
 int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo, int ci_hi, int CO, int CI, float* grad,
                  hipStream_t stream);
 
-int conv_wgrad_bf16(const float* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
-                    const float* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
-                    hipStream_t stream) {
+template <typename T>
+static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
+                             const T* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
+                             hipStream_t stream) {
     if (CI % 32 != 0 || CI <= 0 || CI > 256) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16: unsupported CI=%d", CI);
     if (ks != 1 && ks != 3) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16: unsupported ks=%d", ks);
     const int tiles = ((H + 7) / 8) * ((W + BTW - 1) / BTW) * B;
@@ -469,13 +814,13 @@ int conv_wgrad_bf16(const float* in, int CI, int ks, const float* in_scale, cons
         const int chunk = (CI - off >= 64) ? 64 : 32;
         int rc;
         if (chunk == 64 && ks == 3)
-            rc = launch_conv_wgrad_bf16<64, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
+            rc = launch_conv_wgrad_bf16<T, 64, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         else if (chunk == 32 && ks == 3)
-            rc = launch_conv_wgrad_bf16<32, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
+            rc = launch_conv_wgrad_bf16<T, 32, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         else if (chunk == 64)
-            rc = launch_conv_wgrad_bf16<64, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
+            rc = launch_conv_wgrad_bf16<T, 64, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         else
-            rc = launch_conv_wgrad_bf16<32, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
+            rc = launch_conv_wgrad_bf16<T, 32, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         if (rc != P4C_OK) return rc;
         rc = wgrad_reduce(partial, G * (chunk == 64 ? 1 : 2), ks, CI, off, off + chunk, CO, CIreal, grad, stream);
         if (rc != P4C_OK) return rc;
@@ -483,6 +828,24 @@ int conv_wgrad_bf16(const float* in, int CI, int ks, const float* in_scale, cons
     }
     return P4C_OK;
 }
+
+int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
+                    const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
+                    hipStream_t stream) {
+    if (storage == P4C_BF16)
+        return conv_wgrad_bf16_t<__bf16>((const __bf16*)in, CI, ks, in_scale, in_shift, in_relu, (const __bf16*)dout, partial, G,
+                                         B, H, W, CO, CIreal, grad, stream);
+    return conv_wgrad_bf16_t<float>((const float*)in, CI, ks, in_scale, in_shift, in_relu, (const float*)dout, partial, G, B, H,
+                                    W, CO, CIreal, grad, stream);
+}
+
+#ifdef P4C_STAMPS
+}  // namespace p4c
+extern "C" int p4c_debug_set_stamps(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(p4c::g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+namespace p4c {
+#endif
 
 int prep_weights_bf16(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, void* out,
                       hipStream_t stream) {

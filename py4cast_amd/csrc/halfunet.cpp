@@ -27,9 +27,9 @@ inline int conv_level(int i) { return i < 10 ? i / 2 : 0; }
 inline int conv_cin(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin : NF; }
 inline int conv_cin_pad(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin_pad : NF; }
 
-inline int stat_tiles(int compute, int CI, int H, int W) {
-    const int th = compute == P4C_BF16 ? conv_bf16_tile_h(CI) : CONV_TH;
-    return ((H + th - 1) / th) * ((W + CONV_TW - 1) / CONV_TW);
+inline int stat_tiles(int compute, int CI, int B, int H, int W) {
+    if (compute == P4C_BF16) return conv_bf16_stat_slots(CI, B, H, W);
+    return ((H + CONV_TH - 1) / CONV_TH) * ((W + CONV_TW - 1) / CONV_TW);
 }
 
 // dtype-dispatching wrappers: one call site per use, both matrix-core flavours
@@ -39,13 +39,13 @@ inline int prep_w(int compute, const float* w, int CO, int CI, int ks, int tf, i
 }
 inline int conv_fwd(int compute, const float* in, int CI, const float* wp, int ks, const float* sc, const float* sh, int relu,
                     float* out, int out_cs, float* statp, int B, int H, int W, int mblocks, hipStream_t st) {
-    return compute == P4C_BF16 ? conv_fwd_bf16(in, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st)
+    return compute == P4C_BF16 ? conv_fwd_bf16(in, P4C_F32, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st)
                                : conv_fwd_f32(in, CI, wp, ks, sc, sh, relu, nullptr, out, out_cs, statp, B, H, W, mblocks, st);
 }
 inline int conv_wgrad(int compute, const float* in, int CI, int ks, const float* sc, const float* sh, int relu,
                       const float* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                       hipStream_t st) {
-    return compute == P4C_BF16 ? conv_wgrad_bf16(in, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st)
+    return compute == P4C_BF16 ? conv_wgrad_bf16(in, P4C_F32, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st)
                                : conv_wgrad_f32(in, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st);
 }
 
@@ -91,7 +91,7 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     L.G = num_cus();
     off = 0;
     L.wprep = off; off += (int64_t)9 * 96 * 64;
-    L.statp = off; off += (int64_t)d.B * conv_tiles_per_sample(d.H, d.W) * 128;
+    L.statp = off; off += (int64_t)d.B * (conv_tiles_per_sample(d.H, d.W) > 4 * num_cus() ? conv_tiles_per_sample(d.H, d.W) : 4 * num_cus()) * 128;
     L.wgradp = off; off += wgrad_partial_floats(96, 3, L.G);
     L.nbwdp = off; off += (int64_t)d.B * 512 * 128;
     L.k1 = off; off += (int64_t)d.B * NF;
@@ -129,7 +129,7 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const Layout& L, int i, const flo
     float* rm = running ? running + (int64_t)i * 128 : nullptr;
     float* rv = running ? rm + 64 : nullptr;
     if (batch_stats) {
-        P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, conv_cin_pad(d, i), H, W), d.B, (int64_t)H * W, d.norm, d.groups,
+        P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, conv_cin_pad(d, i), d.B, H, W), d.B, (int64_t)H * W, d.norm, d.groups,
                               params + L.gamma[i], params + L.beta[i], d.eps, d.momentum, d.norm == 0 ? rm : nullptr,
                               d.norm == 0 ? rv : nullptr, nm.scale, nm.shift, nm.mean, nm.rstd, st));
     } else {
@@ -304,7 +304,7 @@ extern "C" int p4c_prep_weights(const float* w, int CO, int CI, int ks, int tran
     return prep_w(compute, w, CO, CI, ks, transpose_flip, M_pad, K_pad, (float*)out, as_stream(stream));
 }
 
-extern "C" int p4c_conv_stat_tiles(int compute, int CI, int H, int W) { return stat_tiles(compute, CI, H, W); }
+extern "C" int p4c_conv_stat_tiles(int compute, int CI, int B, int H, int W) { return stat_tiles(compute, CI, B, H, W); }
 
 extern "C" int p4c_conv_fwd(const void* in, int compute, int CI, const void* wprep, int ks, const float* in_scale,
                             const float* in_shift, int in_relu, const float* bias, void* out, int out_cs,
@@ -315,8 +315,8 @@ extern "C" int p4c_conv_fwd(const void* in, int compute, int CI, const void* wpr
     P4C_CHECK_ARG(!stat_partial || m_blocks == 1, "p4c_conv_fwd: statistics need m_blocks == 1");
     if (compute == P4C_BF16) {
         if (bias) return fail(P4C_ERR_UNSUPPORTED, "p4c_conv_fwd: bias is not implemented for P4C_BF16");
-        return conv_fwd_bf16((const float*)in, CI, wprep, ks, in_scale, in_shift, in_relu, (float*)out, out_cs, stat_partial,
-                             B, H, W, m_blocks, as_stream(stream));
+        return conv_fwd_bf16(in, P4C_F32, CI, wprep, ks, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W,
+                             m_blocks, as_stream(stream));
     }
     if (compute != P4C_F32) return fail(P4C_ERR_INVALID, "p4c_conv_fwd: bad compute type %d", compute);
     return conv_fwd_f32((const float*)in, CI, (const float*)wprep, ks, in_scale, in_shift, in_relu, bias, (float*)out, out_cs,

@@ -22,12 +22,13 @@ int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo
 // conv_bf16.hip (bf16 matrix cores, fp32 storage)
 int prep_weights_bf16(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, void* out,
                       hipStream_t stream);
-int conv_bf16_tile_h(int CI);
-int conv_fwd_bf16(const float* in, int CI, const void* wp, int ks, const float* in_scale, const float* in_shift,
-                  int in_relu, float* out, int out_cs, float* stat_partial, int B, int H, int W, int m_blocks,
-                  hipStream_t stream);
-int conv_wgrad_bf16(const float* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
-                    const float* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
+int conv_bf16_stat_slots(int CI, int B, int H, int W);
+// `storage` = element type of in/out/dout in HBM (P4C_F32 or P4C_BF16)
+int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
+                  const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
+                  int m_blocks, hipStream_t stream);
+int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
+                    const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                     hipStream_t stream);
 
 // norm_pool.hip

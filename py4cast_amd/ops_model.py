@@ -23,7 +23,7 @@ def prep_weights(w: torch.Tensor, transpose_flip: bool, M_pad: int, K_pad: int, 
 
 
 def conv_tiles(B, H, W, CI=64, compute="f32"):
-    return B * L.lib().p4c_conv_stat_tiles(_compute(compute), CI, H, W)
+    return B * L.lib().p4c_conv_stat_tiles(_compute(compute), CI, B, H, W)
 
 
 def conv_fwd(x: torch.Tensor, wprep: torch.Tensor, ks: int, m_blocks: int = 1, in_scale: Optional[torch.Tensor] = None,
