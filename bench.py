@@ -36,7 +36,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default=os.environ.get("P4C_BENCH_MODEL", "HalfUNet"))
-    ap.add_argument("--dtype", default=os.environ.get("P4C_BENCH_DTYPE", "f32"), choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default=os.environ.get("P4C_BENCH_DTYPE", "f32"), choices=["f32", "bf16"],
+                    help="matrix-core input type of the model convolutions")
+    ap.add_argument("--act-dtype", default=os.environ.get("P4C_BENCH_ACT_DTYPE"), choices=["f32", "bf16"],
+                    help="HBM storage of activations (default: same as --dtype)")
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--grid", type=int, nargs=2, default=[512, 512])
     ap.add_argument("--features", type=int, default=60)
@@ -181,7 +184,7 @@ def main():
     info = make_info(case, Ff)
     settings = {}
     if args.model not in ("Identity",):
-        settings = {"compute_dtype": args.dtype}
+        settings = {"compute_dtype": args.dtype, "activation_dtype": args.act_dtype or args.dtype}
     torch.manual_seed(1234)  # identical initial weights on every rank
     lm = AutoRegressiveLightning(
         settings, info, None, num_input_steps=1, num_pred_steps_train=T, num_pred_steps_val_test=T, batch_size=B,

@@ -204,13 +204,14 @@ int p4c_prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip,
 
 /* "same" convolution (ks = 1 or 3, stride 1, zero padding) on the fp32 matrix cores
  * (compute = P4C_F32: v_mfma_f32_32x32x2_f32, exact; P4C_BF16: v_mfma_f32_32x32x16_bf16 on operands rounded
- * to bf16 while staged; tensors are fp32 in both cases): out[b,y,x,m] = sum_{tap,k} act(in)[b,y+dy,x+dx,k] * W[m][k][tap] (+ bias[m])
+ * to bf16 while staged).  `storage` is the element type of in/out (and dout) in HBM: P4C_F32, or P4C_BF16 with
+ * compute = P4C_BF16.  out[b,y,x,m] = sum_{tap,k} act(in)[b,y+dy,x+dx,k] * W[m][k][tap] (+ bias[m])
  * with act(v) = relu?(v*in_scale[b,k] + in_shift[b,k]) applied while the input tile is staged
  * (in_scale/in_shift: (B,CI) or NULL).  stat_partial (or NULL): per-tile channel sums,
  * [B*tiles][2][64] floats with tiles = p4c_conv_stat_tiles(compute, CI, B, H, W) -- the BatchNorm/GroupNorm statistics of
  * the output, produced in the epilogue.  in: (B,H,W,CI), CI in {32,64,96}; out: (B,H,W,out_cs),
  * m_blocks*64 channels written. */
-int p4c_conv_fwd(const void* in, int compute, int CI, const void* wprep, int ks, const float* in_scale,
+int p4c_conv_fwd(const void* in, int compute, int storage, int CI, const void* wprep, int ks, const float* in_scale,
                  const float* in_shift, int in_relu, const float* bias, void* out, int out_cs, float* stat_partial,
                  int B, int H, int W, int m_blocks, p4c_stream_t stream);
 
@@ -221,7 +222,7 @@ size_t p4c_conv_wgrad_workspace_bytes(int CI_pad, int ks);
 /* rows per sample of p4c_conv_fwd's stat_partial output (pixel tiles, or (workgroup, wave) slots of the
  * persistent bf16 kernel) */
 int p4c_conv_stat_tiles(int compute, int CI, int B, int H, int W);
-int p4c_conv_wgrad(const void* in, int compute, int CI_pad, int ks, const float* in_scale, const float* in_shift,
+int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_pad, int ks, const float* in_scale, const float* in_shift,
                    int in_relu, const void* dout, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                    p4c_stream_t stream);
 
@@ -235,7 +236,7 @@ typedef struct p4c_halfunet_desc {
     int32_t cin_pad;      /* x is (B,H,W,cin_pad), cin_pad in {32,64,96}; channels >= cin must be zero */
     int32_t cout;         /* real output channels (<= 64); y is (B,H,W,64), channels >= cout are zero */
     int32_t dx_channels;  /* leading input channels whose gradient is returned (<= 64, 0 = none) */
-    int32_t dtype;        /* P4C_F32 */
+    int32_t dtype;        /* storage of x, y, dy, dx and of the saved activations: P4C_F32, or P4C_BF16 (needs compute = P4C_BF16) */
     int32_t norm;         /* 0 = BatchNorm2d, 1 = GroupNorm */
     int32_t groups;       /* GroupNorm groups (divides 64) */
     int32_t has_bias;     /* conv bias (settings.bias); only 0 is implemented */

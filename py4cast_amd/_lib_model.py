@@ -21,8 +21,8 @@ DP = ctypes.POINTER(HalfUNetDesc)
 
 SIGNATURES = {
     "p4c_prep_weights": [P, I, I, I, I, I, I, P, I, P],
-    "p4c_conv_fwd": [P, I, I, P, I, P, P, I, P, P, I, P, I, I, I, I, P],
-    "p4c_conv_wgrad": [P, I, I, I, P, P, I, P, I, I, P, P, I, I, I, P],
+    "p4c_conv_fwd": [P, I, I, I, P, I, P, P, I, P, P, I, P, I, I, I, I, P],
+    "p4c_conv_wgrad": [P, I, I, I, I, P, P, I, P, I, I, P, P, I, I, I, P],
     "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],
     "p4c_halfunet_backward": [DP, P, P, P, P, P, P, P, I, P],

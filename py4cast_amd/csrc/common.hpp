@@ -83,4 +83,19 @@ __device__ __forceinline__ float cross_seg_sum(float v, int width) {
 
 __device__ __forceinline__ float nan_to_zero(float v) { return (v != v) ? 0.0f : v; }
 
+// 4 consecutive elements as fp32, from/to fp32 (16 B) or bf16 (8 B) storage
+typedef float p4c_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 p4c_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ p4c_f32x4 load4f(const float* p) { return *reinterpret_cast<const p4c_f32x4*>(p); }
+__device__ __forceinline__ p4c_f32x4 load4f(const bf16* p) {
+    const p4c_bf16x4 v = *reinterpret_cast<const p4c_bf16x4*>(p);
+    return p4c_f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void store4f(float* p, p4c_f32x4 v) { *reinterpret_cast<p4c_f32x4*>(p) = v; }
+__device__ __forceinline__ void store4f(bf16* p, p4c_f32x4 v) {
+    p4c_bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<p4c_bf16x4*>(p) = o;
+}
+
 }  // namespace p4c

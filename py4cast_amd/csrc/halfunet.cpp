@@ -1,6 +1,12 @@
 // HalfUNet forward / backward plan: enqueues every kernel of one network call on the caller's
 // stream (no host synchronisation, no allocation: all buffers are carved from the two
 // caller-provided workspaces).  Architecture: see include/py4cast_hip.h and oracle/halfunet.py.
+//
+// Two knobs of the descriptor select the kernel flavours:
+//   compute = P4C_F32  : exact fp32 matrix cores (conv_f32.hip); activations fp32
+//   compute = P4C_BF16 : bf16 matrix cores (conv_bf16.hip); activations / activation gradients stored
+//                        fp32 (dtype = P4C_F32) or bf16 (dtype = P4C_BF16).  Parameters, statistics,
+//                        normalisation coefficients and weight gradients are always fp32.
 #include "kernels.hpp"
 
 namespace p4c {
@@ -11,42 +17,46 @@ constexpr int NLEV = 5;      // encoder levels
 constexpr int NCONV = 12;    // 3x3 convs: enc k conv j -> 2(k-1)+j-1 ; decoder -> 10, 11
 
 struct Layout {
-    // sizes in floats
+    int esz;                  // bytes per activation element
     int64_t n[NLEV];          // B*Hk*Wk per level
     int Hk[NLEV], Wk[NLEV];
-    // parameter offsets
+    // parameter offsets (floats)
     int64_t w[NCONV], gamma[NCONV], beta[NCONV], wout, nparams;
-    // saved workspace offsets (floats)
-    int64_t Y[NCONV], P[NLEV], S, norm[NCONV], saved_total;  // norm[i]: scale,shift,mean,rstd (4*B*64)
-    // scratch offsets (floats)
-    int64_t wprep, statp, wgradp, nbwdp, k1, k2, G0, G1, G2, TB, scratch_total;
+    // saved workspace: activations (element offsets) then normalisation arrays (float offsets from norm_base bytes)
+    int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
+    // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
+    int64_t wprep, statp, wgradp, nbwdp, k1, k2, f_floats, g_base, G0, G1, G2, TB, scratch_bytes;
     int G;  // persistent workgroups of the weight-gradient kernel
 };
 
 inline int conv_level(int i) { return i < 10 ? i / 2 : 0; }
 inline int conv_cin(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin : NF; }
 inline int conv_cin_pad(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin_pad : NF; }
+inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 inline int stat_tiles(int compute, int CI, int B, int H, int W) {
     if (compute == P4C_BF16) return conv_bf16_stat_slots(CI, B, H, W);
     return ((H + CONV_TH - 1) / CONV_TH) * ((W + CONV_TW - 1) / CONV_TW);
 }
 
-// dtype-dispatching wrappers: one call site per use, both matrix-core flavours
-inline int prep_w(int compute, const float* w, int CO, int CI, int ks, int tf, int M_pad, int K_pad, float* out, hipStream_t st) {
+// dtype-dispatching wrappers: one call site per use, all kernel flavours
+inline int prep_w(int compute, const float* w, int CO, int CI, int ks, int tf, int M_pad, int K_pad, void* out, hipStream_t st) {
     return compute == P4C_BF16 ? prep_weights_bf16(w, CO, CI, ks, tf, M_pad, K_pad, out, st)
-                               : prep_weights(w, CO, CI, ks, tf, M_pad, K_pad, out, st);
+                               : prep_weights(w, CO, CI, ks, tf, M_pad, K_pad, (float*)out, st);
 }
-inline int conv_fwd(int compute, const float* in, int CI, const float* wp, int ks, const float* sc, const float* sh, int relu,
-                    float* out, int out_cs, float* statp, int B, int H, int W, int mblocks, hipStream_t st) {
-    return compute == P4C_BF16 ? conv_fwd_bf16(in, P4C_F32, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st)
-                               : conv_fwd_f32(in, CI, wp, ks, sc, sh, relu, nullptr, out, out_cs, statp, B, H, W, mblocks, st);
+inline int conv_fwd(int compute, int storage, const void* in, int CI, const void* wp, int ks, const float* sc, const float* sh,
+                    int relu, void* out, int out_cs, float* statp, int B, int H, int W, int mblocks, hipStream_t st) {
+    return compute == P4C_BF16
+               ? conv_fwd_bf16(in, storage, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st)
+               : conv_fwd_f32((const float*)in, CI, (const float*)wp, ks, sc, sh, relu, nullptr, (float*)out, out_cs, statp, B, H, W,
+                              mblocks, st);
 }
-inline int conv_wgrad(int compute, const float* in, int CI, int ks, const float* sc, const float* sh, int relu,
-                      const float* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
+inline int conv_wgrad(int compute, int storage, const void* in, int CI, int ks, const float* sc, const float* sh, int relu,
+                      const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                       hipStream_t st) {
-    return compute == P4C_BF16 ? conv_wgrad_bf16(in, P4C_F32, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st)
-                               : conv_wgrad_f32(in, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st);
+    return compute == P4C_BF16
+               ? conv_wgrad_bf16(in, storage, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st)
+               : conv_wgrad_f32((const float*)in, CI, ks, sc, sh, relu, (const float*)dout, partial, G, B, H, W, CO, CIreal, grad, st);
 }
 
 int check_desc(const p4c_halfunet_desc* d) {
@@ -59,13 +69,16 @@ int check_desc(const p4c_halfunet_desc* d) {
     P4C_CHECK_ARG(d->cout > 0 && d->cout <= 64, "halfunet: cout must be in 1..64 (got %d)", d->cout);
     P4C_CHECK_ARG(d->dx_channels >= 0 && d->dx_channels <= 64 && d->dx_channels <= d->cin, "halfunet: bad dx_channels");
     P4C_CHECK_ARG(d->norm == 0 || (d->norm == 1 && d->groups > 0 && 64 % d->groups == 0), "halfunet: bad norm/groups");
-    if (d->dtype != P4C_F32) return fail(P4C_ERR_UNSUPPORTED, "halfunet: activation storage must be P4C_F32");
     P4C_CHECK_ARG(d->compute == P4C_F32 || d->compute == P4C_BF16, "halfunet: compute must be P4C_F32 or P4C_BF16");
+    P4C_CHECK_ARG(d->dtype == P4C_F32 || d->dtype == P4C_BF16, "halfunet: dtype must be P4C_F32 or P4C_BF16");
+    if (d->dtype == P4C_BF16 && d->compute != P4C_BF16)
+        return fail(P4C_ERR_UNSUPPORTED, "halfunet: bf16 activation storage needs compute = P4C_BF16");
     if (d->has_bias) return fail(P4C_ERR_UNSUPPORTED, "halfunet: conv bias (settings.bias=True) is not implemented");
     return P4C_OK;
 }
 
 void make_layout(const p4c_halfunet_desc& d, Layout& L) {
+    L.esz = d.dtype == P4C_BF16 ? 2 : 4;
     for (int k = 0; k < NLEV; ++k) {
         L.Hk[k] = d.H >> k;
         L.Wk[k] = d.W >> k;
@@ -85,22 +98,29 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     L.P[0] = -1;
     for (int k = 1; k < NLEV; ++k) { L.P[k] = off; off += L.n[k] * NF; }
     L.S = off; off += L.n[0] * NF;
+    L.act_elems = off;
+    L.norm_base = align256(off * L.esz);
+    off = 0;
     for (int i = 0; i < NCONV; ++i) { L.norm[i] = off; off += 4 * (int64_t)d.B * NF; }
-    L.saved_total = off;
+    L.saved_bytes = L.norm_base + off * (int64_t)sizeof(float);
 
     L.G = num_cus();
     off = 0;
     L.wprep = off; off += (int64_t)9 * 96 * 64;
-    L.statp = off; off += (int64_t)d.B * (conv_tiles_per_sample(d.H, d.W) > 4 * num_cus() ? conv_tiles_per_sample(d.H, d.W) : 4 * num_cus()) * 128;
+    const int64_t tps = conv_tiles_per_sample(d.H, d.W);
+    L.statp = off; off += (int64_t)d.B * (tps > 4 * (int64_t)L.G ? tps : 4 * (int64_t)L.G) * 128;
     L.wgradp = off; off += wgrad_partial_floats(96, 3, L.G);
     L.nbwdp = off; off += (int64_t)d.B * 512 * 128;
     L.k1 = off; off += (int64_t)d.B * NF;
     L.k2 = off; off += (int64_t)d.B * NF;
+    L.f_floats = off;
+    L.g_base = align256(off * (int64_t)sizeof(float));
+    off = 0;
     L.G0 = off; off += L.n[0] * NF;
     L.G1 = off; off += L.n[0] * NF;
     L.G2 = off; off += L.n[0] * NF;
     L.TB = off; off += L.n[0] * NF / 2;
-    L.scratch_total = off;
+    L.scratch_bytes = L.g_base + off * L.esz;
 }
 
 #define P4C_TRY(expr)              \
@@ -109,33 +129,69 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
         if (rc__ != P4C_OK) return rc__; \
     } while (0)
 
+// workspace views
+struct WS {
+    const Layout& L;
+    char* saved;
+    char* scratch;
+    void* act(int64_t elem_off) const { return saved + elem_off * L.esz; }          // saved activation
+    float* nrm(int64_t float_off) const { return reinterpret_cast<float*>(saved + L.norm_base) + float_off; }
+    float* f(int64_t float_off) const { return reinterpret_cast<float*>(scratch) + float_off; }  // fp32 scratch
+    void* g(int64_t elem_off) const { return scratch + L.g_base + elem_off * L.esz; }             // gradient buffers
+};
+
 struct Norm { float *scale, *shift, *mean, *rstd; };
-inline Norm norm_at(float* saved, const Layout& L, int i, int B) {
-    float* p = saved + L.norm[i];
+inline Norm norm_at(const WS& ws, int i, int B) {
+    float* p = ws.nrm(ws.L.norm[i]);
     return {p, p + (int64_t)B * NF, p + 2 * (int64_t)B * NF, p + 3 * (int64_t)B * NF};
 }
 
 // conv3x3 forward + statistics + normalisation parameters of its output
-int conv_block_fwd(const p4c_halfunet_desc& d, const Layout& L, int i, const float* in, const Norm* in_norm,
-                   const float* params, float* running, float* saved, float* scratch, int training, hipStream_t st) {
+int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* in, const Norm* in_norm, const float* params,
+                   float* running, int training, hipStream_t st) {
+    const Layout& L = ws.L;
     const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
-    float* wp = scratch + L.wprep;
+    void* wp = ws.f(L.wprep);
     P4C_TRY(prep_w(d.compute, params + L.w[i], NF, conv_cin(d, i), 3, 0, 64, conv_cin_pad(d, i), wp, st));
     const bool batch_stats = (d.norm == 1) || training;
-    float* statp = batch_stats ? scratch + L.statp : nullptr;
-    P4C_TRY(conv_fwd(d.compute, in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
-                     in_norm ? in_norm->shift : nullptr, in_norm ? 1 : 0, saved + L.Y[i], NF, statp, d.B, H, W, 1, st));
-    Norm nm = norm_at(saved, L, i, d.B);
+    float* statp = batch_stats ? ws.f(L.statp) : nullptr;
+    P4C_TRY(conv_fwd(d.compute, d.dtype, in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
+                     in_norm ? in_norm->shift : nullptr, in_norm ? 1 : 0, ws.act(L.Y[i]), NF, statp, d.B, H, W, 1, st));
+    Norm nm = norm_at(ws, i, d.B);
     float* rm = running ? running + (int64_t)i * 128 : nullptr;
     float* rv = running ? rm + 64 : nullptr;
     if (batch_stats) {
-        P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, conv_cin_pad(d, i), d.B, H, W), d.B, (int64_t)H * W, d.norm, d.groups,
-                              params + L.gamma[i], params + L.beta[i], d.eps, d.momentum, d.norm == 0 ? rm : nullptr,
-                              d.norm == 0 ? rv : nullptr, nm.scale, nm.shift, nm.mean, nm.rstd, st));
+        P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, conv_cin_pad(d, i), d.B, H, W), d.B, (int64_t)H * W, d.norm,
+                              d.groups, params + L.gamma[i], params + L.beta[i], d.eps, d.momentum,
+                              d.norm == 0 ? rm : nullptr, d.norm == 0 ? rv : nullptr, nm.scale, nm.shift, nm.mean, nm.rstd, st));
     } else {
         P4C_CHECK_ARG(running, "halfunet: eval-mode BatchNorm needs the running statistics");
         P4C_TRY(norm_eval(d.B, params + L.gamma[i], params + L.beta[i], d.eps, rm, rv, nm.scale, nm.shift, nm.mean,
                           nm.rstd, st));
+    }
+    return P4C_OK;
+}
+
+// backward through [conv i -> norm -> relu] given dA (grad wrt the post-ReLU activation) in `g`:
+//   g := dY (in place); grads of gamma/beta/weight accumulated; if `din` != null: din = dL/d(conv input)
+int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, const void* in, const Norm* in_norm, void* din,
+                   const float* params, float* grads, int training, hipStream_t st) {
+    const Layout& L = ws.L;
+    const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
+    Norm nm = norm_at(ws, i, d.B);
+    const int stats_training = (d.norm == 1) || training;
+    P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
+                     (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1), ws.f(L.k2),
+                     grads + L.gamma[i], grads + L.beta[i], g, st));
+    const int cip = conv_cin_pad(d, i);
+    int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
+    const int G = ntiles < L.G ? (int)ntiles : L.G;
+    P4C_TRY(conv_wgrad(d.compute, d.dtype, in, cip, 3, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
+                       in_norm ? 1 : 0, g, ws.f(L.wgradp), G, d.B, H, W, NF, conv_cin(d, i), grads + L.w[i], st));
+    if (din) {
+        void* wp = ws.f(L.wprep);
+        P4C_TRY(prep_w(d.compute, params + L.w[i], NF, conv_cin(d, i), 3, 1, 64, NF, wp, st));
+        P4C_TRY(conv_fwd(d.compute, d.dtype, g, NF, wp, 3, nullptr, nullptr, 0, din, 64, nullptr, d.B, H, W, 1, st));
     }
     return P4C_OK;
 }
@@ -156,140 +212,105 @@ extern "C" int p4c_halfunet_workspace_bytes(const p4c_halfunet_desc* d, size_t* 
     P4C_TRY(check_desc(d));
     Layout L;
     make_layout(*d, L);
-    if (saved_bytes) *saved_bytes = (size_t)L.saved_total * sizeof(float);
-    if (scratch_bytes) *scratch_bytes = (size_t)L.scratch_total * sizeof(float);
+    if (saved_bytes) *saved_bytes = (size_t)L.saved_bytes;
+    if (scratch_bytes) *scratch_bytes = (size_t)L.scratch_bytes;
     return P4C_OK;
 }
 
-extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* xv, const float* params, float* running,
-                                    void* yv, void* savedv, void* scratchv, int training, p4c_stream_t stream) {
+extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* x, const float* params, float* running,
+                                    void* y, void* savedv, void* scratchv, int training, p4c_stream_t stream) {
     P4C_TRY(check_desc(dp));
-    P4C_CHECK_ARG(xv && params && yv && savedv && scratchv, "p4c_halfunet_forward: null pointer");
+    P4C_CHECK_ARG(x && params && y && savedv && scratchv, "p4c_halfunet_forward: null pointer");
     const p4c_halfunet_desc& d = *dp;
     Layout L;
     make_layout(d, L);
     hipStream_t st = as_stream(stream);
-    const float* x = (const float*)xv;
-    float* saved = (float*)savedv;
-    float* scratch = (float*)scratchv;
+    const WS ws{L, (char*)savedv, (char*)scratchv};
 
     // encoder
     for (int k = 0; k < NLEV; ++k) {
-        const float* in = k == 0 ? x : saved + L.P[k];
-        P4C_TRY(conv_block_fwd(d, L, 2 * k, in, nullptr, params, running, saved, scratch, training, st));
-        Norm n1 = norm_at(saved, L, 2 * k, d.B);
-        P4C_TRY(conv_block_fwd(d, L, 2 * k + 1, saved + L.Y[2 * k], &n1, params, running, saved, scratch, training, st));
+        const void* in = k == 0 ? x : ws.act(L.P[k]);
+        P4C_TRY(conv_block_fwd(d, ws, 2 * k, in, nullptr, params, running, training, st));
+        Norm n1 = norm_at(ws, 2 * k, d.B);
+        P4C_TRY(conv_block_fwd(d, ws, 2 * k + 1, ws.act(L.Y[2 * k]), &n1, params, running, training, st));
         if (k + 1 < NLEV) {
-            Norm n2 = norm_at(saved, L, 2 * k + 1, d.B);
-            P4C_TRY(pool_fwd(saved + L.Y[2 * k + 1], n2.scale, n2.shift, d.B, L.Hk[k], L.Wk[k], saved + L.P[k + 1], st));
+            Norm n2 = norm_at(ws, 2 * k + 1, d.B);
+            P4C_TRY(pool_fwd(d.dtype, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, L.Hk[k], L.Wk[k], ws.act(L.P[k + 1]), st));
         }
     }
     // up-sample every level to full resolution and sum
     {
-        const float *ys[NLEV], *sc[NLEV], *sh[NLEV];
+        const void* ys[NLEV];
+        const float *sc[NLEV], *sh[NLEV];
         for (int k = 0; k < NLEV; ++k) {
-            Norm n2 = norm_at(saved, L, 2 * k + 1, d.B);
-            ys[k] = saved + L.Y[2 * k + 1]; sc[k] = n2.scale; sh[k] = n2.shift;
+            Norm n2 = norm_at(ws, 2 * k + 1, d.B);
+            ys[k] = ws.act(L.Y[2 * k + 1]); sc[k] = n2.scale; sh[k] = n2.shift;
         }
-        P4C_TRY(upsum_fwd(ys, sc, sh, d.B, d.H, d.W, saved + L.S, st));
+        P4C_TRY(upsum_fwd(d.dtype, ys, sc, sh, d.B, d.H, d.W, ws.act(L.S), st));
     }
     // decoder
-    P4C_TRY(conv_block_fwd(d, L, 10, saved + L.S, nullptr, params, running, saved, scratch, training, st));
-    Norm nd1 = norm_at(saved, L, 10, d.B);
-    P4C_TRY(conv_block_fwd(d, L, 11, saved + L.Y[10], &nd1, params, running, saved, scratch, training, st));
-    Norm nd2 = norm_at(saved, L, 11, d.B);
+    P4C_TRY(conv_block_fwd(d, ws, 10, ws.act(L.S), nullptr, params, running, training, st));
+    Norm nd1 = norm_at(ws, 10, d.B);
+    P4C_TRY(conv_block_fwd(d, ws, 11, ws.act(L.Y[10]), &nd1, params, running, training, st));
+    Norm nd2 = norm_at(ws, 11, d.B);
     // 1x1 output conv on relu(norm(Y_dec2)); last activation = Identity
-    float* wp = scratch + L.wprep;
+    void* wp = ws.f(L.wprep);
     P4C_TRY(prep_w(d.compute, params + L.wout, d.cout, NF, 1, 0, 64, NF, wp, st));
-    P4C_TRY(conv_fwd(d.compute, saved + L.Y[11], NF, wp, 1, nd2.scale, nd2.shift, 1, (float*)yv, NF, nullptr, d.B, d.H, d.W, 1, st));
+    P4C_TRY(conv_fwd(d.compute, d.dtype, ws.act(L.Y[11]), NF, wp, 1, nd2.scale, nd2.shift, 1, y, NF, nullptr, d.B, d.H, d.W, 1, st));
     return P4C_OK;
 }
 
-namespace p4c {
-namespace {
-
-// backward through [conv i -> norm -> relu] given dA (grad wrt the post-ReLU activation) in `g`:
-//   g := dY (in place); grads of gamma/beta/weight accumulated; if `din` != null: din = dL/d(conv input)
-int conv_block_bwd(const p4c_halfunet_desc& d, const Layout& L, int i, float* g, const float* in, const Norm* in_norm,
-                   float* din, int din_mblocks, const float* params, float* grads, float* saved, float* scratch,
-                   int training, hipStream_t st) {
-    const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
-    Norm nm = norm_at(saved, L, i, d.B);
-    const int stats_training = (d.norm == 1) || training;
-    P4C_TRY(norm_bwd(g, saved + L.Y[i], nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B, (int64_t)H * W,
-                     d.norm, d.groups, stats_training, scratch + L.nbwdp, scratch + L.k1, scratch + L.k2,
-                     grads + L.gamma[i], grads + L.beta[i], g, st));
-    const int cip = conv_cin_pad(d, i);
-    int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
-    const int G = ntiles < L.G ? (int)ntiles : L.G;
-    P4C_TRY(conv_wgrad(d.compute, in, cip, 3, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
-                       in_norm ? 1 : 0, g, scratch + L.wgradp, G, d.B, H, W, NF, conv_cin(d, i), grads + L.w[i], st));
-    if (din) {
-        float* wp = scratch + L.wprep;
-        P4C_TRY(prep_w(d.compute, params + L.w[i], NF, conv_cin(d, i), 3, 1, 64 * din_mblocks, NF, wp, st));
-        P4C_TRY(conv_fwd(d.compute, g, NF, wp, 3, nullptr, nullptr, 0, din, 64 * din_mblocks, nullptr, d.B, H, W, din_mblocks, st));
-    }
-    return P4C_OK;
-}
-
-}  // namespace
-}  // namespace p4c
-
-extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* xv, const float* params, const void* dyv,
-                                     void* dxv, float* grads, void* savedv, void* scratchv, int training,
+extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x, const float* params, const void* dy,
+                                     void* dx, float* grads, void* savedv, void* scratchv, int training,
                                      p4c_stream_t stream) {
     P4C_TRY(check_desc(dp));
-    P4C_CHECK_ARG(xv && params && dyv && grads && savedv && scratchv, "p4c_halfunet_backward: null pointer");
+    P4C_CHECK_ARG(x && params && dy && grads && savedv && scratchv, "p4c_halfunet_backward: null pointer");
     const p4c_halfunet_desc& d = *dp;
-    P4C_CHECK_ARG(dxv || d.dx_channels == 0, "p4c_halfunet_backward: dx is null but dx_channels > 0");
+    P4C_CHECK_ARG(dx || d.dx_channels == 0, "p4c_halfunet_backward: dx is null but dx_channels > 0");
     Layout L;
     make_layout(d, L);
     hipStream_t st = as_stream(stream);
-    const float* x = (const float*)xv;
-    const float* dy = (const float*)dyv;
-    float* saved = (float*)savedv;
-    float* scratch = (float*)scratchv;
-    float *G0 = scratch + L.G0, *G1 = scratch + L.G1, *G2 = scratch + L.G2, *TB = scratch + L.TB;
-    float* wp = scratch + L.wprep;
+    const WS ws{L, (char*)savedv, (char*)scratchv};
+    void *G0 = ws.g(L.G0), *G1 = ws.g(L.G1), *G2 = ws.g(L.G2), *TB = ws.g(L.TB);
+    void* wp = ws.f(L.wprep);
 
     // ---- output 1x1 conv
-    Norm nd2 = norm_at(saved, L, 11, d.B);
+    Norm nd2 = norm_at(ws, 11, d.B);
     {
         int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(d.H, d.W);
         const int G = ntiles < L.G ? (int)ntiles : L.G;
-        P4C_TRY(conv_wgrad(d.compute, saved + L.Y[11], NF, 1, nd2.scale, nd2.shift, 1, dy, scratch + L.wgradp, G, d.B, d.H, d.W,
-                           d.cout, NF, grads + L.wout, st));
+        P4C_TRY(conv_wgrad(d.compute, d.dtype, ws.act(L.Y[11]), NF, 1, nd2.scale, nd2.shift, 1, dy, ws.f(L.wgradp), G, d.B, d.H,
+                           d.W, d.cout, NF, grads + L.wout, st));
         P4C_TRY(prep_w(d.compute, params + L.wout, d.cout, NF, 1, 1, 64, NF, wp, st));
-        P4C_TRY(conv_fwd(d.compute, dy, NF, wp, 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
+        P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wp, 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
     }
     // ---- decoder
-    Norm nd1 = norm_at(saved, L, 10, d.B);
-    P4C_TRY(conv_block_bwd(d, L, 11, G0, saved + L.Y[10], &nd1, G1, 1, params, grads, saved, scratch, training, st));
-    P4C_TRY(conv_block_bwd(d, L, 10, G1, saved + L.S, nullptr, G0, 1, params, grads, saved, scratch, training, st));
+    Norm nd1 = norm_at(ws, 10, d.B);
+    P4C_TRY(conv_block_bwd(d, ws, 11, G0, ws.act(L.Y[10]), &nd1, G1, params, grads, training, st));
+    P4C_TRY(conv_block_bwd(d, ws, 10, G1, ws.act(L.S), nullptr, G0, params, grads, training, st));
     // G0 = dS, kept until the last level
 
     // ---- encoder levels, deepest first
-    float *a = G1, *b = G2;  // a: holds dP_{k+1} on entry (k < 4)
+    void *a = G1, *b = G2;  // a: holds dP_{k+1} on entry (k < 4)
     for (int k = NLEV - 1; k >= 0; --k) {
         const int Hk = L.Hk[k], Wk = L.Wk[k];
-        Norm n2 = norm_at(saved, L, 2 * k + 1, d.B);
-        Norm n1 = norm_at(saved, L, 2 * k, d.B);
-        const float* dP = (k + 1 < NLEV) ? a : nullptr;
+        Norm n2 = norm_at(ws, 2 * k + 1, d.B);
+        Norm n1 = norm_at(ws, 2 * k, d.B);
+        const void* dP = (k + 1 < NLEV) ? a : nullptr;
         if (k > 0) {
-            P4C_TRY(up_bwd_x(G0, d.B, d.H, d.W, 1 << k, TB, st));
-            P4C_TRY(enc_out_bwd(TB, d.H, 1 << k, nullptr, dP, saved + L.Y[2 * k + 1], n2.scale, n2.shift, d.B, Hk, Wk, b, st));
+            P4C_TRY(up_bwd_x(d.dtype, G0, d.B, d.H, d.W, 1 << k, TB, st));
+            P4C_TRY(enc_out_bwd(d.dtype, TB, d.H, 1 << k, nullptr, dP, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st));
         } else {
-            P4C_TRY(enc_out_bwd(nullptr, d.H, 1, G0, dP, saved + L.Y[1], n2.scale, n2.shift, d.B, Hk, Wk, b, st));
+            P4C_TRY(enc_out_bwd(d.dtype, nullptr, d.H, 1, G0, dP, ws.act(L.Y[1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st));
         }
         // conv2 of the block: input = relu(norm1(Y_k1))
-        P4C_TRY(conv_block_bwd(d, L, 2 * k + 1, b, saved + L.Y[2 * k], &n1, a, 1, params, grads, saved, scratch, training, st));
+        P4C_TRY(conv_block_bwd(d, ws, 2 * k + 1, b, ws.act(L.Y[2 * k]), &n1, a, params, grads, training, st));
         // conv1 of the block: input = P_k (k>0) or x
         if (k > 0) {
-            P4C_TRY(conv_block_bwd(d, L, 2 * k, a, saved + L.P[k], nullptr, b, 1, params, grads, saved, scratch, training, st));
-            float* t = a; a = b; b = t;  // dP_k now in a
+            P4C_TRY(conv_block_bwd(d, ws, 2 * k, a, ws.act(L.P[k]), nullptr, b, params, grads, training, st));
+            void* t = a; a = b; b = t;  // dP_k now in a
         } else {
-            float* dx = d.dx_channels > 0 ? (float*)dxv : nullptr;
-            P4C_TRY(conv_block_bwd(d, L, 0, a, x, nullptr, dx, 1, params, grads, saved, scratch, training, st));
+            P4C_TRY(conv_block_bwd(d, ws, 0, a, x, nullptr, d.dx_channels > 0 ? dx : nullptr, params, grads, training, st));
         }
     }
     return P4C_OK;
@@ -301,24 +322,24 @@ extern "C" int p4c_prep_weights(const float* w, int CO, int CI, int ks, int tran
     P4C_CHECK_ARG(w && out, "p4c_prep_weights: null pointer");
     P4C_CHECK_ARG((ks == 1 || ks == 3) && M_pad % 64 == 0 && K_pad % 32 == 0, "p4c_prep_weights: bad ks / padding");
     P4C_CHECK_ARG(compute == P4C_F32 || compute == P4C_BF16, "p4c_prep_weights: bad compute type");
-    return prep_w(compute, w, CO, CI, ks, transpose_flip, M_pad, K_pad, (float*)out, as_stream(stream));
+    return prep_w(compute, w, CO, CI, ks, transpose_flip, M_pad, K_pad, out, as_stream(stream));
 }
 
 extern "C" int p4c_conv_stat_tiles(int compute, int CI, int B, int H, int W) { return stat_tiles(compute, CI, B, H, W); }
 
-extern "C" int p4c_conv_fwd(const void* in, int compute, int CI, const void* wprep, int ks, const float* in_scale,
-                            const float* in_shift, int in_relu, const float* bias, void* out, int out_cs,
-                            float* stat_partial, int B, int H, int W, int m_blocks, p4c_stream_t stream) {
+extern "C" int p4c_conv_fwd(const void* in, int compute, int storage, int CI, const void* wprep, int ks,
+                            const float* in_scale, const float* in_shift, int in_relu, const float* bias, void* out,
+                            int out_cs, float* stat_partial, int B, int H, int W, int m_blocks, p4c_stream_t stream) {
     P4C_CHECK_ARG(in && wprep && out, "p4c_conv_fwd: null pointer");
     P4C_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "p4c_conv_fwd: scale and shift go together");
     P4C_CHECK_ARG(m_blocks >= 1 && out_cs >= 64 * m_blocks && out_cs % 4 == 0, "p4c_conv_fwd: bad out_cs / m_blocks");
     P4C_CHECK_ARG(!stat_partial || m_blocks == 1, "p4c_conv_fwd: statistics need m_blocks == 1");
-    if (compute == P4C_BF16) {
-        if (bias) return fail(P4C_ERR_UNSUPPORTED, "p4c_conv_fwd: bias is not implemented for P4C_BF16");
-        return conv_fwd_bf16(in, P4C_F32, CI, wprep, ks, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W,
+    P4C_CHECK_ARG(compute == P4C_F32 || compute == P4C_BF16, "p4c_conv_fwd: bad compute type %d", compute);
+    P4C_CHECK_ARG(storage == P4C_F32 || (storage == P4C_BF16 && compute == P4C_BF16), "p4c_conv_fwd: bad storage type");
+    if (compute == P4C_BF16 && bias) return fail(P4C_ERR_UNSUPPORTED, "p4c_conv_fwd: bias is not implemented for P4C_BF16");
+    if (compute == P4C_BF16)
+        return conv_fwd_bf16(in, storage, CI, wprep, ks, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W,
                              m_blocks, as_stream(stream));
-    }
-    if (compute != P4C_F32) return fail(P4C_ERR_INVALID, "p4c_conv_fwd: bad compute type %d", compute);
     return conv_fwd_f32((const float*)in, CI, (const float*)wprep, ks, in_scale, in_shift, in_relu, bias, (float*)out, out_cs,
                         stat_partial, B, H, W, m_blocks, as_stream(stream));
 }
@@ -327,14 +348,15 @@ extern "C" size_t p4c_conv_wgrad_workspace_bytes(int CI_pad, int ks) {
     return (size_t)wgrad_partial_floats(CI_pad, ks, num_cus()) * sizeof(float);
 }
 
-extern "C" int p4c_conv_wgrad(const void* in, int compute, int CI_pad, int ks, const float* in_scale,
+extern "C" int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_pad, int ks, const float* in_scale,
                               const float* in_shift, int in_relu, const void* dout, int CO, int CI, float* grad,
                               void* workspace, int B, int H, int W, p4c_stream_t stream) {
     P4C_CHECK_ARG(in && dout && grad && workspace, "p4c_conv_wgrad: null pointer");
     P4C_CHECK_ARG(CO <= 64 && CI <= CI_pad, "p4c_conv_wgrad: CO must be <= 64 and CI <= CI_pad");
     P4C_CHECK_ARG(compute == P4C_F32 || compute == P4C_BF16, "p4c_conv_wgrad: bad compute type");
+    P4C_CHECK_ARG(storage == P4C_F32 || (storage == P4C_BF16 && compute == P4C_BF16), "p4c_conv_wgrad: bad storage type");
     int64_t ntiles = (int64_t)B * conv_tiles_per_sample(H, W);
     const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
-    return conv_wgrad(compute, (const float*)in, CI_pad, ks, in_scale, in_shift, in_relu, (const float*)dout,
-                      (float*)workspace, G, B, H, W, CO, CI, grad, as_stream(stream));
+    return conv_wgrad(compute, storage, in, CI_pad, ks, in_scale, in_shift, in_relu, dout, (float*)workspace, G, B, H, W, CO,
+                      CI, grad, as_stream(stream));
 }

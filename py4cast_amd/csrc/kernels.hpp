@@ -38,15 +38,17 @@ int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw,
 int norm_eval(int B, const float* gamma, const float* beta, float eps, const float* running_mean,
               const float* running_var, float* scale, float* shift, float* mean, float* rstd, hipStream_t stream);
 int norm_bwd_blocks(int64_t hw);
-int norm_bwd(const float* dA, const float* y, const float* scale, const float* shift, const float* mean,
+// `storage` = element type of activations / activation gradients in HBM (P4C_F32 or P4C_BF16)
+int norm_bwd(int storage, const void* dA, const void* y, const float* scale, const float* shift, const float* mean,
              const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
-             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, float* dY, hipStream_t stream);
-int pool_fwd(const float* y, const float* scale, const float* shift, int B, int H, int W, float* P, hipStream_t stream);
-int upsum_fwd(const float* const* y, const float* const* scale, const float* const* shift, int B, int H, int W, float* S,
-              hipStream_t stream);
-int up_bwd_x(const float* dS, int B, int H, int W, int s, float* T, hipStream_t stream);
-int enc_out_bwd(const float* T, int Hfull, int s, const float* dS, const float* dP, const float* y, const float* scale,
-                const float* shift, int B, int Hk, int Wk, float* dA, hipStream_t stream);
+             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream);
+int pool_fwd(int storage, const void* y, const float* scale, const float* shift, int B, int H, int W, void* P,
+             hipStream_t stream);
+int upsum_fwd(int storage, const void* const* y, const float* const* scale, const float* const* shift, int B, int H, int W,
+              void* S, hipStream_t stream);
+int up_bwd_x(int storage, const void* dS, int B, int H, int W, int s, void* Tx, hipStream_t stream);
+int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, const void* dP, const void* y,
+                const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream);
 
 // tiles of the conv kernels (for sizing the statistics partial buffers)
 constexpr int CONV_TH = 4;

@@ -283,8 +283,9 @@ __global__ void scaled_loss_final_kernel(const float* __restrict__ partial, int 
 // 16-byte load/store and a wave covers 64/FP4 grid points per iteration.
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+template <typename TY>
 __global__ void __launch_bounds__(256)
-    ar_update_loss_fwd_v4_kernel(const float* __restrict__ prev, int64_t prev_bs, const float* __restrict__ y, int y_cs,
+    ar_update_loss_fwd_v4_kernel(const float* __restrict__ prev, int64_t prev_bs, const TY* __restrict__ y, int y_cs,
                                  const float* __restrict__ target, int64_t tgt_bs, const float* __restrict__ std,
                                  const float* __restrict__ mean, const float* __restrict__ border_mask,
                                  const float* __restrict__ interior_mask, float* __restrict__ new_state, int64_t new_bs,
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(256)
         const float im = interior_mask[n];
         const float bm = border_mask ? border_mask[n] : 0.0f;
         const int64_t e = n * F + 4 * q;
-        const v4f yv = *reinterpret_cast<const v4f*>(y + ((int64_t)b * N + n) * y_cs + 4 * q);
+        const v4f yv = load4f(y + ((int64_t)b * N + n) * y_cs + 4 * q);
         v4f pv = {0, 0, 0, 0};
         if (prev) pv = *reinterpret_cast<const v4f*>(prev + (int64_t)b * prev_bs + e);
         v4f tg = *reinterpret_cast<const v4f*>(target + (int64_t)b * tgt_bs + e);
@@ -346,13 +347,14 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+template <typename TY>
 __global__ void __launch_bounds__(256)
-    ar_update_loss_bwd_v4_kernel(const float* __restrict__ g_next, int64_t g_next_bs, const float* __restrict__ g_next2,
+    ar_update_loss_bwd_v4_kernel(const float* __restrict__ g_next, int64_t g_next_bs, const TY* __restrict__ g_next2,
                                  int g2_cs, const float* __restrict__ gloss, int64_t gloss_stride,
                                  const float* __restrict__ new_state, int64_t new_bs, const float* __restrict__ target,
                                  int64_t tgt_bs, const float* __restrict__ std, const float* __restrict__ interior_mask,
                                  int force_border, const float* __restrict__ weights, float num_interior,
-                                 const int32_t* __restrict__ masked_count, int kind, int mask_mode, float* __restrict__ dy,
+                                 const int32_t* __restrict__ masked_count, int kind, int mask_mode, TY* __restrict__ dy,
                                  int y_cs, float* dprev, int64_t dprev_bs, int64_t N, int F, float keep_prev, int FP4) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(256)
             const v4f tg = *reinterpret_cast<const v4f*>(target + (int64_t)b * tgt_bs + e);
             v4f g1 = {0, 0, 0, 0}, g2 = {0, 0, 0, 0};
             if (g_next) g1 = *reinterpret_cast<const v4f*>(g_next + (int64_t)b * g_next_bs + e);
-            if (g_next2) g2 = *reinterpret_cast<const v4f*>(g_next2 + ((int64_t)b * N + n) * g2_cs + 4 * q);
+            if (g_next2) g2 = load4f(g_next2 + ((int64_t)b * N + n) * g2_cs + 4 * q);
             v4f gp;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(256)
             }
             if (dprev) *reinterpret_cast<v4f*>(dprev + (int64_t)b * dprev_bs + e) = gp * keep_prev;
         }
-        *reinterpret_cast<v4f*>(dy + ((int64_t)b * N + n) * y_cs + 4 * q) = gy;
+        store4f(dy + ((int64_t)b * N + n) * y_cs + 4 * q, gy);
     }
 }
 
@@ -663,14 +665,19 @@ extern "C" int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const 
     P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE || mask_mode == P4C_MASK_FROM_NAN,
                   "p4c_ar_update_loss_fwd: only MASK_NONE / MASK_FROM_NAN are fused");
     P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS && y_cs >= F, "p4c_ar_update_loss_fwd: bad F / y_cs");
-    if (y_dtype == P4C_F32 && F % 4 == 0 && F <= 64 && y_cs % 4 == 0 && prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 &&
+    if ((y_dtype == P4C_F32 || y_dtype == P4C_BF16) && F % 4 == 0 && F <= 64 && y_cs % 4 == 0 && prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 &&
         aligned16(prev) && aligned16(y) && aligned16(target) && aligned16(new_state) && aligned16(weights) && aligned16(std) &&
         aligned16(mean)) {
         const int FP4 = pow2_ge64(F / 4);
         const int nblk4 = loss_blocks(N, 64 / FP4, B);
-        hipLaunchKernelGGL(ar_update_loss_fwd_v4_kernel, dim3(nblk4, B), dim3(256), 0, as_stream(stream), prev, prev_bs,
-                           (const float*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs,
-                           weights, kind, mask_mode, (float*)workspace, N, F, keep_prev, FP4);
+        if (y_dtype == P4C_F32)
+            hipLaunchKernelGGL(ar_update_loss_fwd_v4_kernel<float>, dim3(nblk4, B), dim3(256), 0, as_stream(stream), prev, prev_bs,
+                               (const float*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs,
+                               weights, kind, mask_mode, (float*)workspace, N, F, keep_prev, FP4);
+        else
+            hipLaunchKernelGGL(ar_update_loss_fwd_v4_kernel<bf16>, dim3(nblk4, B), dim3(256), 0, as_stream(stream), prev, prev_bs,
+                               (const bf16*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs,
+                               weights, kind, mask_mode, (float*)workspace, N, F, keep_prev, FP4);
         P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(v4)");
         hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const float*)workspace,
                            nblk4, num_interior, masked_count, loss_out, loss_stride, B);
@@ -709,17 +716,23 @@ extern "C" int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, co
                   "p4c_ar_update_loss_bwd: only MASK_NONE / MASK_FROM_NAN are fused");
     P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS && y_cs >= F, "p4c_ar_update_loss_bwd: bad F / y_cs");
     P4C_CHECK_ARG(dy_dtype == g2_dtype || !g_next2, "p4c_ar_update_loss_bwd: g_next2 dtype must equal dy dtype");
-    if (dy_dtype == P4C_F32 && F % 4 == 0 && y_cs % 4 == 0 && y_cs <= 256 && g_next_bs % 4 == 0 && new_bs % 4 == 0 &&
+    if ((dy_dtype == P4C_F32 || dy_dtype == P4C_BF16) && F % 4 == 0 && y_cs % 4 == 0 && y_cs <= 256 && g_next_bs % 4 == 0 && new_bs % 4 == 0 &&
         tgt_bs % 4 == 0 && dprev_bs % 4 == 0 && g2_cs % 4 == 0 && aligned16(g_next) && aligned16(g_next2) &&
         aligned16(new_state) && aligned16(target) && aligned16(dy) && aligned16(dprev) && aligned16(weights) &&
         aligned16(std)) {
         const int FP4 = pow2_ge64(y_cs / 4);
         if (y_cs / 4 <= 64) {
             const int nblk4 = loss_blocks(N, 64 / FP4, B);
-            hipLaunchKernelGGL(ar_update_loss_bwd_v4_kernel, dim3(nblk4, B), dim3(256), 0, as_stream(stream), g_next,
-                               g_next_bs, (const float*)g_next2, g2_cs, gloss, gloss_stride, new_state, new_bs, target,
-                               tgt_bs, std, interior_mask, force_border, weights, num_interior, masked_count, kind,
-                               mask_mode, (float*)dy, y_cs, dprev, dprev_bs, N, F, keep_prev, FP4);
+            if (dy_dtype == P4C_F32)
+                hipLaunchKernelGGL(ar_update_loss_bwd_v4_kernel<float>, dim3(nblk4, B), dim3(256), 0, as_stream(stream), g_next,
+                                   g_next_bs, (const float*)g_next2, g2_cs, gloss, gloss_stride, new_state, new_bs, target,
+                                   tgt_bs, std, interior_mask, force_border, weights, num_interior, masked_count, kind,
+                                   mask_mode, (float*)dy, y_cs, dprev, dprev_bs, N, F, keep_prev, FP4);
+            else
+                hipLaunchKernelGGL(ar_update_loss_bwd_v4_kernel<bf16>, dim3(nblk4, B), dim3(256), 0, as_stream(stream), g_next,
+                                   g_next_bs, (const bf16*)g_next2, g2_cs, gloss, gloss_stride, new_state, new_bs, target,
+                                   tgt_bs, std, interior_mask, force_border, weights, num_interior, masked_count, kind,
+                                   mask_mode, (bf16*)dy, y_cs, dprev, dprev_bs, N, F, keep_prev, FP4);
             P4C_CHECK_LAUNCH("p4c_ar_update_loss_bwd(v4)");
             return P4C_OK;
         }

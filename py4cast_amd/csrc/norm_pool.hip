@@ -14,8 +14,19 @@ namespace p4c {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int C = 64;
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// 4 consecutive channels of one pixel, activations stored as fp32 (16 B) or bf16 (8 B); arithmetic is fp32
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4(__bf16* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     return v;
@@ -102,8 +113,9 @@ __global__ void norm_eval_kernel(int B, const float* __restrict__ gamma, const f
 // ------------------------------------------------------------------------------------------
 // norm backward, pass 1: per-(b,c) sums of g and g*xhat, g = dA * (y*scale+shift > 0),
 // xhat = (y-mean)*rstd.  grid (nblk, B); partial [b][blk][2][64].
+template <typename T>
 __global__ void __launch_bounds__(256)
-    norm_bwd_reduce_kernel(const float* __restrict__ dA, const float* __restrict__ y, const float* __restrict__ scale,
+    norm_bwd_reduce_kernel(const T* __restrict__ dA, const T* __restrict__ y, const float* __restrict__ scale,
                            const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
                            int relu, int64_t hw, float* __restrict__ partial) {
     __shared__ float red[2][16][64];
@@ -112,8 +124,8 @@ __global__ void __launch_bounds__(256)
     const f32x4 sc = ld4(scale + b * C + 4 * c4), sh = ld4(shift + b * C + 4 * c4);
     const f32x4 mu = ld4(mean + b * C + 4 * c4), rs = ld4(rstd + b * C + 4 * c4);
     f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-    const float* yb = y + (int64_t)b * hw * C;
-    const float* gb = dA + (int64_t)b * hw * C;
+    const T* yb = y + (int64_t)b * hw * C;
+    const T* gb = dA + (int64_t)b * hw * C;
     for (int64_t p = (int64_t)blockIdx.x * 16 + pl; p < hw; p += (int64_t)gridDim.x * 16) {
         const f32x4 yv = ld4(yb + p * C + 4 * c4);
         f32x4 g = ld4(gb + p * C + 4 * c4);
@@ -198,11 +210,12 @@ __global__ void __launch_bounds__(256)
 }
 
 // pass 2: dY = rstd*(gamma*g - k1 - xhat*k2), written over dA (in place allowed).
+template <typename T>
 __global__ void __launch_bounds__(256)
-    norm_bwd_apply_kernel(const float* __restrict__ dA, const float* __restrict__ y, const float* __restrict__ scale,
+    norm_bwd_apply_kernel(const T* __restrict__ dA, const T* __restrict__ y, const float* __restrict__ scale,
                           const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
                           const float* __restrict__ gamma, const float* __restrict__ k1, const float* __restrict__ k2,
-                          int relu, int64_t hw, int B, float* __restrict__ dY) {
+                          int relu, int64_t hw, int B, T* __restrict__ dY) {
     const int64_t total = (int64_t)B * hw * 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c4 = (int)(i & 15);
@@ -224,9 +237,10 @@ __global__ void __launch_bounds__(256)
 
 // ------------------------------------------------------------------------------------------
 // pool_fwd: P[b,Y,X,:] = max over the 2x2 window of relu(y*scale+shift)      (H,W even)
+template <typename T>
 __global__ void __launch_bounds__(256)
-    pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int B,
-                    int H, int W, float* __restrict__ P) {
+    pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int B,
+                    int H, int W, T* __restrict__ P) {
     const int Ho = H / 2, Wo = W / 2;
     const int64_t total = (int64_t)B * Ho * Wo * 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -236,7 +250,7 @@ __global__ void __launch_bounds__(256)
         const int Y = (int)(pix % Ho);
         const int b = (int)(pix / Ho);
         const f32x4 sc = ld4(scale + b * C + 4 * c4), sh = ld4(shift + b * C + 4 * c4);
-        const float* base = y + (((int64_t)b * H + 2 * Y) * W + 2 * X) * C + 4 * c4;
+        const T* base = y + (((int64_t)b * H + 2 * Y) * W + 2 * X) * C + 4 * c4;
         f32x4 m = relu4(ld4(base) * sc + sh);
         f32x4 v = relu4(ld4(base + C) * sc + sh);
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
@@ -258,14 +272,16 @@ __device__ __forceinline__ void bilin(int dst, int s, int n_in, int& i0, int& i1
     l1 = src - (float)i0;
 }
 
+template <typename T>
 struct UpLevels {
-    const float* y[5];      // raw conv outputs of enc1..enc5 (level k at H/2^k)
+    const T* y[5];          // raw conv outputs of enc1..enc5 (level k at H/2^k)
     const float* scale[5];  // (B,64)
     const float* shift[5];
 };
 
 // upsum_fwd: S[b,y,x,:] = sum_k up_{2^k}( relu(y_k*scale_k+shift_k) )   (k = 0..4)
-__global__ void __launch_bounds__(256) upsum_fwd_kernel(UpLevels lv, int B, int H, int W, float* __restrict__ S) {
+template <typename T>
+__global__ void __launch_bounds__(256) upsum_fwd_kernel(UpLevels<T> lv, int B, int H, int W, T* __restrict__ S) {
     const int64_t total = (int64_t)B * H * W * 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c4 = (int)(i & 15);
@@ -281,7 +297,7 @@ __global__ void __launch_bounds__(256) upsum_fwd_kernel(UpLevels lv, int B, int 
             bilin(yy, s, Hk, y0, y1, ly);
             bilin(x, s, Wk, x0, x1, lx);
             const f32x4 sc = ld4(lv.scale[k] + b * C + 4 * c4), sh = ld4(lv.shift[k] + b * C + 4 * c4);
-            const float* base = lv.y[k] + (int64_t)b * Hk * Wk * C + 4 * c4;
+            const T* base = lv.y[k] + (int64_t)b * Hk * Wk * C + 4 * c4;
             const f32x4 v00 = relu4(ld4(base + ((int64_t)y0 * Wk + x0) * C) * sc + sh);
             const f32x4 v01 = relu4(ld4(base + ((int64_t)y0 * Wk + x1) * C) * sc + sh);
             const f32x4 v10 = relu4(ld4(base + ((int64_t)y1 * Wk + x0) * C) * sc + sh);
@@ -294,7 +310,8 @@ __global__ void __launch_bounds__(256) upsum_fwd_kernel(UpLevels lv, int B, int 
 }
 
 // up_bwd_x: T[b,y,X,:] = sum_x wx(x,X) dS[b,y,x,:]   for one level (scale s); T is (B,H,W/s,64)
-__global__ void __launch_bounds__(256) up_bwd_x_kernel(const float* __restrict__ dS, int B, int H, int W, int s, float* __restrict__ T) {
+template <typename T>
+__global__ void __launch_bounds__(256) up_bwd_x_kernel(const T* __restrict__ dS, int B, int H, int W, int s, T* __restrict__ Tx) {
     const int Wk = W / s;
     const int64_t total = (int64_t)B * H * Wk * 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -312,7 +329,7 @@ __global__ void __launch_bounds__(256) up_bwd_x_kernel(const float* __restrict__
             const float w = (x0 == X ? 1.f - lx : 0.f) + (x1 == X ? lx : 0.f);
             if (w != 0.f) acc += w * ld4(dS + (row * W + x) * C + 4 * c4);
         }
-        st4(T + (i >> 4) * C + 4 * c4, acc);
+        st4(Tx + (i >> 4) * C + 4 * c4, acc);
     }
 }
 
@@ -321,10 +338,11 @@ __global__ void __launch_bounds__(256) up_bwd_x_kernel(const float* __restrict__
 //      + [dS given]  dS[b,Y,X,:]                        (level 1: identity)
 //      + [dP given]  dP[b,Y/2,X/2,:] if (Y,X) is the arg-max of its 2x2 window of relu(y*scale+shift)
 //                    (first maximum in row-major order, as torch's max_pool2d)
+template <typename T>
 __global__ void __launch_bounds__(256)
-    enc_out_bwd_kernel(const float* __restrict__ T, int Hfull, int s, const float* __restrict__ dS,
-                       const float* __restrict__ dP, const float* __restrict__ y, const float* __restrict__ scale,
-                       const float* __restrict__ shift, int B, int Hk, int Wk, float* __restrict__ dA) {
+    enc_out_bwd_kernel(const T* __restrict__ Tx, int Hfull, int s, const T* __restrict__ dS,
+                       const T* __restrict__ dP, const T* __restrict__ y, const float* __restrict__ scale,
+                       const float* __restrict__ shift, int B, int Hk, int Wk, T* __restrict__ dA) {
     const int64_t total = (int64_t)B * Hk * Wk * 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c4 = (int)(i & 15);
@@ -334,7 +352,7 @@ __global__ void __launch_bounds__(256)
         const int b = (int)(pix / Hk);
         f32x4 acc = {0, 0, 0, 0};
         if (dS) acc = ld4(dS + (i >> 4) * C + 4 * c4);
-        if (T) {
+        if (Tx) {
             int ya = s * Y - s / 2, yb = s * Y + 3 * s / 2 - 1;
             if (ya < 0) ya = 0;
             if (yb > Hfull - 1) yb = Hfull - 1;
@@ -342,13 +360,13 @@ __global__ void __launch_bounds__(256)
                 int y0, y1; float ly;
                 bilin(yy, s, Hk, y0, y1, ly);
                 const float w = (y0 == Y ? 1.f - ly : 0.f) + (y1 == Y ? ly : 0.f);
-                if (w != 0.f) acc += w * ld4(T + (((int64_t)b * Hfull + yy) * Wk + X) * C + 4 * c4);
+                if (w != 0.f) acc += w * ld4(Tx + (((int64_t)b * Hfull + yy) * Wk + X) * C + 4 * c4);
             }
         }
         if (dP) {
             const f32x4 sc = ld4(scale + b * C + 4 * c4), sh = ld4(shift + b * C + 4 * c4);
             const int Y0 = Y & ~1, X0 = X & ~1;
-            const float* base = y + (((int64_t)b * Hk + Y0) * Wk + X0) * C + 4 * c4;
+            const T* base = y + (((int64_t)b * Hk + Y0) * Wk + X0) * C + 4 * c4;
             f32x4 v[4];
             v[0] = relu4(ld4(base) * sc + sh);
             v[1] = relu4(ld4(base + C) * sc + sh);
@@ -404,50 +422,91 @@ int norm_bwd_blocks(int64_t hw) {
     return (int)nblk;
 }
 
-int norm_bwd(const float* dA, const float* y, const float* scale, const float* shift, const float* mean,
-             const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
-             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, float* dY, hipStream_t stream) {
+// `storage` = element type of the activation / gradient tensors in HBM (P4C_F32 or P4C_BF16); statistics,
+// scale/shift and partial sums are always fp32.
+template <typename T>
+static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* shift, const float* mean,
+                      const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups,
+                      int training, float* partial, float* k1, float* k2, float* dgamma, float* dbeta, T* dY,
+                      hipStream_t stream) {
     const int nblk = norm_bwd_blocks(hw);
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(nblk, B), dim3(256), 0, stream, dA, y, scale, shift, mean, rstd, relu,
-                       hw, partial);
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk, B), dim3(256), 0, stream, dA, y, scale, shift, mean, rstd,
+                       relu, hw, partial);
     P4C_CHECK_LAUNCH("norm_bwd_reduce");
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(mode == 0 ? C : groups), dim3(256), 0, stream, partial, nblk, B, hw, mode, groups,
-                       training, gamma, dgamma, dbeta, k1, k2);
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(mode == 0 ? C : groups), dim3(256), 0, stream, partial, nblk, B, hw,
+                       mode, groups, training, gamma, dgamma, dbeta, k1, k2);
     P4C_CHECK_LAUNCH("norm_bwd_finalize");
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(ew_grid((int64_t)B * hw * 16)), dim3(256), 0, stream, dA, y, scale,
+    hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(ew_grid((int64_t)B * hw * 16)), dim3(256), 0, stream, dA, y, scale,
                        shift, mean, rstd, gamma, k1, k2, relu, hw, B, dY);
     P4C_CHECK_LAUNCH("norm_bwd_apply");
     return P4C_OK;
 }
 
-int pool_fwd(const float* y, const float* scale, const float* shift, int B, int H, int W, float* P, hipStream_t stream) {
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * 16)), dim3(256), 0, stream, y, scale,
-                       shift, B, H, W, P);
+int norm_bwd(int storage, const void* dA, const void* y, const float* scale, const float* shift, const float* mean,
+             const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
+             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream) {
+    if (storage == P4C_BF16)
+        return norm_bwd_t<__bf16>((const __bf16*)dA, (const __bf16*)y, scale, shift, mean, rstd, gamma, relu, B, hw, mode,
+                                  groups, training, partial, k1, k2, dgamma, dbeta, (__bf16*)dY, stream);
+    return norm_bwd_t<float>((const float*)dA, (const float*)y, scale, shift, mean, rstd, gamma, relu, B, hw, mode, groups,
+                             training, partial, k1, k2, dgamma, dbeta, (float*)dY, stream);
+}
+
+template <typename T>
+static int pool_fwd_t(const T* y, const float* scale, const float* shift, int B, int H, int W, T* P, hipStream_t stream) {
+    hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * 16)), dim3(256), 0, stream, y,
+                       scale, shift, B, H, W, P);
     P4C_CHECK_LAUNCH("pool_fwd");
     return P4C_OK;
 }
+int pool_fwd(int storage, const void* y, const float* scale, const float* shift, int B, int H, int W, void* P,
+             hipStream_t stream) {
+    return storage == P4C_BF16 ? pool_fwd_t<__bf16>((const __bf16*)y, scale, shift, B, H, W, (__bf16*)P, stream)
+                               : pool_fwd_t<float>((const float*)y, scale, shift, B, H, W, (float*)P, stream);
+}
 
-int upsum_fwd(const float* const* y, const float* const* scale, const float* const* shift, int B, int H, int W, float* S,
-              hipStream_t stream) {
-    UpLevels lv;
-    for (int k = 0; k < 5; ++k) { lv.y[k] = y[k]; lv.scale[k] = scale[k]; lv.shift[k] = shift[k]; }
-    hipLaunchKernelGGL(upsum_fwd_kernel, dim3(ew_grid((int64_t)B * H * W * 16)), dim3(256), 0, stream, lv, B, H, W, S);
+template <typename T>
+static int upsum_fwd_t(const void* const* y, const float* const* scale, const float* const* shift, int B, int H, int W,
+                       T* S, hipStream_t stream) {
+    UpLevels<T> lv;
+    for (int k = 0; k < 5; ++k) { lv.y[k] = (const T*)y[k]; lv.scale[k] = scale[k]; lv.shift[k] = shift[k]; }
+    hipLaunchKernelGGL(upsum_fwd_kernel<T>, dim3(ew_grid((int64_t)B * H * W * 16)), dim3(256), 0, stream, lv, B, H, W, S);
     P4C_CHECK_LAUNCH("upsum_fwd");
     return P4C_OK;
 }
+int upsum_fwd(int storage, const void* const* y, const float* const* scale, const float* const* shift, int B, int H, int W,
+              void* S, hipStream_t stream) {
+    return storage == P4C_BF16 ? upsum_fwd_t<__bf16>(y, scale, shift, B, H, W, (__bf16*)S, stream)
+                               : upsum_fwd_t<float>(y, scale, shift, B, H, W, (float*)S, stream);
+}
 
-int up_bwd_x(const float* dS, int B, int H, int W, int s, float* T, hipStream_t stream) {
-    hipLaunchKernelGGL(up_bwd_x_kernel, dim3(ew_grid((int64_t)B * H * (W / s) * 16)), dim3(256), 0, stream, dS, B, H, W, s, T);
+template <typename T>
+static int up_bwd_x_t(const T* dS, int B, int H, int W, int s, T* Tx, hipStream_t stream) {
+    hipLaunchKernelGGL(up_bwd_x_kernel<T>, dim3(ew_grid((int64_t)B * H * (W / s) * 16)), dim3(256), 0, stream, dS, B, H, W,
+                       s, Tx);
     P4C_CHECK_LAUNCH("up_bwd_x");
     return P4C_OK;
 }
+int up_bwd_x(int storage, const void* dS, int B, int H, int W, int s, void* Tx, hipStream_t stream) {
+    return storage == P4C_BF16 ? up_bwd_x_t<__bf16>((const __bf16*)dS, B, H, W, s, (__bf16*)Tx, stream)
+                               : up_bwd_x_t<float>((const float*)dS, B, H, W, s, (float*)Tx, stream);
+}
 
-int enc_out_bwd(const float* T, int Hfull, int s, const float* dS, const float* dP, const float* y, const float* scale,
-                const float* shift, int B, int Hk, int Wk, float* dA, hipStream_t stream) {
-    hipLaunchKernelGGL(enc_out_bwd_kernel, dim3(ew_grid((int64_t)B * Hk * Wk * 16)), dim3(256), 0, stream, T, Hfull, s, dS,
-                       dP, y, scale, shift, B, Hk, Wk, dA);
+template <typename T>
+static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP, const T* y, const float* scale,
+                         const float* shift, int B, int Hk, int Wk, T* dA, hipStream_t stream) {
+    hipLaunchKernelGGL(enc_out_bwd_kernel<T>, dim3(ew_grid((int64_t)B * Hk * Wk * 16)), dim3(256), 0, stream, Tx, Hfull, s,
+                       dS, dP, y, scale, shift, B, Hk, Wk, dA);
     P4C_CHECK_LAUNCH("enc_out_bwd");
     return P4C_OK;
+}
+int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, const void* dP, const void* y,
+                const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream) {
+    if (storage == P4C_BF16)
+        return enc_out_bwd_t<__bf16>((const __bf16*)Tx, Hfull, s, (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale,
+                                     shift, B, Hk, Wk, (__bf16*)dA, stream);
+    return enc_out_bwd_t<float>((const float*)Tx, Hfull, s, (const float*)dS, (const float*)dP, (const float*)y, scale, shift,
+                                B, Hk, Wk, (float*)dA, stream);
 }
 
 }  // namespace p4c

@@ -93,9 +93,10 @@ __global__ void __launch_bounds__(256) build_x_kernel(const float* __restrict__ 
 // (forcing rows are 5 floats = unaligned) are gathered element by element.  Stores are always 16 bytes.
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+template <typename TX>
 __global__ void __launch_bounds__(256)
     build_x_v4_kernel(const float* __restrict__ prev, int64_t prev_bs, int64_t prev_ts, const float* __restrict__ statics,
-                      int64_t statics_bs, const float* __restrict__ forcing, int64_t forcing_bs, float* __restrict__ x,
+                      int64_t statics_bs, const float* __restrict__ forcing, int64_t forcing_bs, TX* __restrict__ x,
                       int c_pad, int B, int T_in, int64_t N, int F, int Fs, int Ff, int n_prev_ch, int FP4, int vec_prev,
                       int vec_stat) {
     const int lane = threadIdx.x & 63;
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(256)
                 v[j] = e;
             }
         }
-        *reinterpret_cast<v4f*>(x + pix * (int64_t)c_pad + c0) = v;
+        store4f(x + pix * (int64_t)c_pad + c0, v);
     }
 }
 
@@ -282,16 +283,22 @@ extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, 
     const int FP = pow2_ge(c_pad);
     const int iters = (c_pad + FP - 1) / FP;
     P4C_CHECK_ARG(iters <= K1_MAX_ITERS, "p4c_build_x: c_pad %d too large (max %d)", c_pad, 64 * K1_MAX_ITERS);
-    if (x_dtype == P4C_F32 && !mask_on_nan && c_pad % 4 == 0 && c_pad <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    if (!mask_on_nan && c_pad % 4 == 0 && c_pad <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+        (x_dtype == P4C_F32 || x_dtype == P4C_BF16)) {
         const int FP4 = pow2_ge(c_pad / 4);
         const int vec_prev = n_prev_ch > 0 && F % 4 == 0 && prev_bs % 4 == 0 && prev_ts % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(prev) & 15) == 0;
         const int vec_stat = Fs % 4 == 0 && n_prev_ch % 4 == 0 && statics_bs % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(statics) & 15) == 0;
         const int grid4 = stream_grid((int64_t)B * N, 64 / FP4);
-        hipLaunchKernelGGL(build_x_v4_kernel, dim3(grid4), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts, statics,
-                           statics_bs, forcing, forcing_bs, (float*)x, c_pad, B, T_in, N, F, Fs, Ff, n_prev_ch, FP4, vec_prev,
-                           vec_stat);
+        if (x_dtype == P4C_F32)
+            hipLaunchKernelGGL(build_x_v4_kernel<float>, dim3(grid4), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
+                               statics, statics_bs, forcing, forcing_bs, (float*)x, c_pad, B, T_in, N, F, Fs, Ff, n_prev_ch, FP4,
+                               vec_prev, vec_stat);
+        else
+            hipLaunchKernelGGL(build_x_v4_kernel<bf16>, dim3(grid4), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
+                               statics, statics_bs, forcing, forcing_bs, (bf16*)x, c_pad, B, T_in, N, F, Fs, Ff, n_prev_ch, FP4,
+                               vec_prev, vec_stat);
         P4C_CHECK_LAUNCH("p4c_build_x(v4)");
         return P4C_OK;
     }

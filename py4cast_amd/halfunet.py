@@ -46,6 +46,7 @@ class HalfUNetSettings:
     norm: str = "batch"  # "batch" (mfai) or "group" (GroupNorm, BASELINE.json north star)
     groups: int = 8
     compute_dtype: str = "f32"  # matrix-core input type: "f32" (exact fp32 MFMA) or "bf16" (autocast-like)
+    activation_dtype: Optional[str] = None  # HBM storage of activations / their gradients: "f32" | "bf16"; None = compute_dtype
 
 
 def pad32(c: int) -> int:
@@ -61,12 +62,12 @@ class _HalfUNetFn(torch.autograd.Function):
     def forward(ctx, x, model, training, *params):
         L.require_cuda(x)
         B, H, W, C = x.shape
-        assert C == model.cin_pad and x.dtype == torch.float32 and x.is_contiguous()
+        assert C == model.cin_pad and x.dtype == model.act_dtype and x.is_contiguous()
         desc = model._desc(B, H, W)
         flat = model._flat_params()
         saved_bytes, scratch = model._workspaces(desc, x.device)
-        saved = torch.empty(saved_bytes // 4, dtype=torch.float32, device=x.device)
-        y = torch.empty(B, H, W, NF, dtype=torch.float32, device=x.device)
+        saved = torch.empty(saved_bytes, dtype=torch.uint8, device=x.device)
+        y = torch.empty(B, H, W, NF, dtype=model.act_dtype, device=x.device)
         L.call("p4c_halfunet_forward", ctypes.byref(desc), L.ptr(x), L.ptr(flat), L.ptr(model._running), L.ptr(y),
                L.ptr(saved), L.ptr(scratch), int(training), L.stream(x.device))
         ctx.model, ctx.desc, ctx.training = model, desc, training
@@ -77,7 +78,7 @@ class _HalfUNetFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, saved = ctx.saved_tensors
         model, desc = ctx.model, ctx.desc
-        dy = dy.contiguous()
+        dy = dy.contiguous().to(model.act_dtype)
         flat = model._flat_params()
         _, scratch = model._workspaces(desc, x.device)
         gflat = torch.zeros_like(flat)
@@ -124,6 +125,9 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             unsupported.append(f"norm={settings.norm}")
         if settings.compute_dtype not in ("f32", "bf16"):
             unsupported.append(f"compute_dtype={settings.compute_dtype}")
+        act = settings.activation_dtype or settings.compute_dtype
+        if act not in ("f32", "bf16") or (act == "bf16" and settings.compute_dtype != "bf16"):
+            unsupported.append(f"activation_dtype={settings.activation_dtype} with compute_dtype={settings.compute_dtype}")
         if out_channels > NF:
             unsupported.append(f"out_channels={out_channels} > 64")
         if pad32(in_channels) > 96:
@@ -133,6 +137,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         self.cin_pad = pad32(in_channels)
         self.dx_channels = min(in_channels, NF)  # gradient wrt the leading (previous-state) channels
         self.compute_dtype = torch.float32 if settings.compute_dtype == "f32" else torch.bfloat16
+        self.act_dtype = torch.float32 if act == "f32" else torch.bfloat16  # dtype of x / y / dy / dx handed to the plan
         self.timed_entry_points = ("p4c_halfunet_forward", "p4c_halfunet_backward", "p4c_build_x",
                                    "p4c_ar_update_loss_fwd", "p4c_ar_update_loss_bwd")
 
@@ -235,7 +240,8 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         if H % 16 or W % 16:
             raise L.P4CError(f"HalfUNetMI355X: grid {H}x{W} must be a multiple of 16 in both dimensions")
         s = self._settings
-        return HalfUNetDesc(B, H, W, self.in_channels, self.cin_pad, self.out_channels, self.dx_channels, L.F32,
+        return HalfUNetDesc(B, H, W, self.in_channels, self.cin_pad, self.out_channels, self.dx_channels,
+                            L.dtype_code(self.act_dtype),
                             0 if s.norm == "batch" else 1, s.groups, 0, 1e-5, 0.1,
                             L.F32 if s.compute_dtype == "f32" else L.BF16)
 
@@ -245,7 +251,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         if hit is None:
             sb, cb = ctypes.c_size_t(), ctypes.c_size_t()
             L.call("p4c_halfunet_workspace_bytes", ctypes.byref(desc), ctypes.byref(sb), ctypes.byref(cb))
-            hit = (sb.value, torch.empty(cb.value // 4, dtype=torch.float32, device=device))
+            hit = (sb.value, torch.empty(cb.value, dtype=torch.uint8, device=device))
             self._scratch = {key: hit}  # one shape at a time
         return hit
 
@@ -257,13 +263,15 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             x = torch.nn.functional.pad(x, (0, self.cin_pad - self.in_channels))
         elif x.shape[-1] != self.cin_pad:
             raise L.P4CError(f"HalfUNetMI355X: expected {self.in_channels} (or padded {self.cin_pad}) channels, got {x.shape[-1]}")
-        x = x.contiguous().float()
+        out_dtype = x.dtype
+        x = x.contiguous().to(self.act_dtype)
         self._running = self._running_stats(x.device)
         training = self.training
         if training and self._settings.norm == "batch":
             torch._foreach_add_([nb.num_batches_tracked for nb in self._norms], 1)
         y = _HalfUNetFn.apply(x, self, training, *self._ordered_params())
-        return y[..., : self.out_channels]
+        y = y[..., : self.out_channels]
+        return y if y.dtype == out_dtype or not out_dtype.is_floating_point else y.to(out_dtype)
 
     # ---------------------------------------------------------------- native rollout (one autograd node)
     def native_rollout(self, lm, batch, std, mean, border_flat, interior_flat, force_border):
@@ -310,9 +318,10 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         wms, wn, wunits = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
         L.lib().p4c_prof_collect(L.PROF_WGRAD3X3_C64, B * H * W, ctypes.byref(wms), ctypes.byref(wn), ctypes.byref(wunits))
         if bf:
-            # at the bf16 MFMA rate the kernel is HBM-bound: algorithmic bytes = read 64 ch + write 64 ch fp32 per pixel
-            gbs = 2.0 * 64 * 4 * units.value / (ms.value * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": "conv_fwd_bf16_kernel<64,3,8> (3x3 conv 64->64, fwd + data-grad launches)",
+            # at the bf16 MFMA rate the kernel is HBM-bound: algorithmic bytes = read 64 ch + write 64 ch per pixel
+            esz = 2 if self.act_dtype == torch.bfloat16 else 4
+            gbs = 2.0 * 64 * esz * units.value / (ms.value * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "conv_fwd_bf16_ws_kernel<%s,64,3> (3x3 conv 64->64, fwd + data-grad launches)" % ("bf16" if esz == 2 else "f32"),
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
                     "avg_launch_ms": ms.value / n.value, "launches": n.value, "mfma_tflops": tflops,
                     "wgrad_avg_launch_ms": (wms.value / wn.value) if wn.value else None}
@@ -356,18 +365,19 @@ class _NativeRolloutFn(torch.autograd.Function):
         loss = torch.empty(B, T, dtype=torch.float32, device=dev)
         ws = torch.empty(L.lib().p4c_loss_workspace_bytes(B, 1, N, 1) // 4, dtype=torch.float32, device=dev)
         xs, saveds = [], []
-        y = torch.empty(B, H, W, NF, dtype=torch.float32, device=dev)
+        adt, acode = model.act_dtype, L.dtype_code(model.act_dtype)
+        y = torch.empty(B, H, W, NF, dtype=adt, device=dev)
         stream = L.stream(dev)
         saved = None
         for i in range(T):
-            x = torch.empty(B, H, W, cpad, dtype=torch.float32, device=dev)
+            x = torch.empty(B, H, W, cpad, dtype=adt, device=dev)
             L.call("p4c_build_x", L.ptr(states[:, i]), sbs_state, N * F, L.ptr(st), sbs, L.ptr(forcing[:, i]), T * N * Ff,
-                   L.ptr(x), L.F32, cpad, B, 1, N, F, Fs, Ff, mask_on_nan, 0, stream)
+                   L.ptr(x), acode, cpad, B, 1, N, F, Fs, Ff, mask_on_nan, 0, stream)
             if saved is None or keep_saved:
-                saved = torch.empty(saved_bytes // 4, dtype=torch.float32, device=dev)
+                saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
             L.call("p4c_halfunet_forward", ctypes.byref(desc), L.ptr(x), L.ptr(flat), L.ptr(model._running), L.ptr(y),
                    L.ptr(saved), L.ptr(scratch), int(training), stream)
-            L.call("p4c_ar_update_loss_fwd", L.ptr(states[:, i]), sbs_state, L.ptr(y), L.F32, NF, L.ptr(outputs[:, i]),
+            L.call("p4c_ar_update_loss_fwd", L.ptr(states[:, i]), sbs_state, L.ptr(y), acode, NF, L.ptr(outputs[:, i]),
                    T * N * F, L.ptr(std), L.ptr(mean), L.ptr(border_flat if force_border else None), L.ptr(interior_flat),
                    L.ptr(states[:, i + 1]), sbs_state, L.ptr(weights), num_interior, L.ptr(count), kind, mask_mode,
                    L.ptr(loss[:, i]), T, L.ptr(ws), B, N, F, 1.0, stream)
@@ -392,8 +402,9 @@ class _NativeRolloutFn(torch.autograd.Function):
         flat = model._flat_params()
         _, scratch = model._workspaces(desc, dev)
         gflat = torch.zeros_like(flat)
-        dy = torch.empty(B, H, W, NF, dtype=torch.float32, device=dev)
-        dx = torch.empty(B, H, W, NF, dtype=torch.float32, device=dev)
+        adt, acode = model.act_dtype, L.dtype_code(model.act_dtype)
+        dy = torch.empty(B, H, W, NF, dtype=adt, device=dev)
+        dx = torch.empty(B, H, W, NF, dtype=adt, device=dev)
         dprev = torch.empty(B, H, W, F, dtype=torch.float32, device=dev)
         gl = g_loss.contiguous().float() if g_loss is not None else None
         sbs_state = (T + 1) * N * F
@@ -408,10 +419,10 @@ class _NativeRolloutFn(torch.autograd.Function):
                 else:
                     dprev.add_(g_pred[:, i])
                 g_next = dprev
-            L.call("p4c_ar_update_loss_bwd", L.ptr(g_next), N * F, L.ptr(dx if have_next else None), L.F32, NF,
+            L.call("p4c_ar_update_loss_bwd", L.ptr(g_next), N * F, L.ptr(dx if have_next else None), acode, NF,
                    L.ptr(gl[:, i]) if gl is not None else None, T, L.ptr(states[:, i + 1]), sbs_state, L.ptr(outputs[:, i]),
                    T * N * F, L.ptr(std), L.ptr(interior_flat), int(force_border), L.ptr(weights), num_interior,
-                   L.ptr(count), kind, mask_mode, L.ptr(dy), L.F32, NF, L.ptr(dprev) if i > 0 else None, N * F, B, N, F,
+                   L.ptr(count), kind, mask_mode, L.ptr(dy), acode, NF, L.ptr(dprev) if i > 0 else None, N * F, B, N, F,
                    1.0, stream)
             d = desc if i > 0 else desc0
             L.call("p4c_halfunet_backward", ctypes.byref(d), L.ptr(xs[i]), L.ptr(flat), L.ptr(dy),

@@ -29,12 +29,13 @@ def conv_tiles(B, H, W, CI=64, compute="f32"):
 def conv_fwd(x: torch.Tensor, wprep: torch.Tensor, ks: int, m_blocks: int = 1, in_scale: Optional[torch.Tensor] = None,
              in_shift: Optional[torch.Tensor] = None, in_relu: bool = False, bias: Optional[torch.Tensor] = None,
              want_stats: bool = False, compute="f32"):
-    """x: (B,H,W,CI) fp32 NHWC, CI in {32,64,96} -> (B,H,W,64*m_blocks) [+ per-tile channel sums]."""
+    """x: (B,H,W,CI) fp32 (or bf16 with compute="bf16") NHWC, CI in {32,64,96} -> (B,H,W,64*m_blocks) of x's dtype
+    [+ per-tile channel sums]."""
     L.require_cuda(x)
     B, H, W, CI = x.shape
-    out = torch.empty(B, H, W, 64 * m_blocks, dtype=torch.float32, device=x.device)
+    out = torch.empty(B, H, W, 64 * m_blocks, dtype=x.dtype, device=x.device)
     stats = torch.empty(conv_tiles(B, H, W, CI, compute), 2, 64, dtype=torch.float32, device=x.device) if want_stats else None
-    L.call("p4c_conv_fwd", L.ptr(x.contiguous()), _compute(compute), CI, L.ptr(wprep), ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
+    L.call("p4c_conv_fwd", L.ptr(x.contiguous()), _compute(compute), L.dtype_code(x.dtype), CI, L.ptr(wprep), ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
            L.ptr(bias), L.ptr(out), 64 * m_blocks, L.ptr(stats), B, H, W, m_blocks, L.stream(x.device))
     return (out, stats) if want_stats else out
 
@@ -47,6 +48,6 @@ def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, ks: int, CO: int, CI: int, g
     B, H, W, CIp = x.shape
     nbytes = L.lib().p4c_conv_wgrad_workspace_bytes(CIp, ks)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    L.call("p4c_conv_wgrad", L.ptr(x.contiguous()), _compute(compute), CIp, ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
+    L.call("p4c_conv_wgrad", L.ptr(x.contiguous()), _compute(compute), L.dtype_code(x.dtype), CIp, ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
            L.ptr(dout.contiguous()), CO, CI, L.ptr(grad), L.ptr(ws), B, H, W, L.stream(x.device))
     return grad

@@ -330,8 +330,8 @@ def test_halfunet_bf16_close_to_fp32_oracle(gpu_device):
     torch.manual_seed(0)
     cin, cout, H, W = 69, 60, 64, 64
     ref = HalfUNetRef(cin, cout).double()
-    model = HalfUNetMI355X(cin, cout, (H, W), HalfUNetSettings(compute_dtype="bf16"))
-    model.load_state_dict(HalfUNetRef(cin, cout).state_dict() if False else {k: v.float() for k, v in ref.state_dict().items()})
+    model = HalfUNetMI355X(cin, cout, (H, W), HalfUNetSettings(compute_dtype="bf16", activation_dtype="f32"))
+    model.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
     model = model.to(gpu_device).train()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, H, W, cin, generator=g)
@@ -346,3 +346,63 @@ def test_halfunet_bf16_close_to_fp32_oracle(gpu_device):
     for name, p in model.named_parameters():  # direction of the gradient (bf16 noise through 13 ReLU/BN layers is large)
         a, b = p.grad.detach().cpu().double().flatten(), pr[name].grad.flatten()
         assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.9, name
+
+
+@pytest.mark.parametrize("CI,CIreal,ks,H,W", [(64, 64, 3, 16, 32), (96, 69, 3, 20, 40), (32, 10, 3, 8, 8), (64, 64, 1, 12, 36), (64, 64, 3, 40, 72)])
+def test_conv_bf16_storage(gpu_device, CI, CIreal, ks, H, W):
+    """bf16 activation storage: inputs, outputs and gradients-of-activations live in HBM as bf16 (fp32 accumulate);
+    outputs are rounded once to bf16 (2^-9 relative)."""
+    from py4cast_amd import ops_model as om
+
+    g = torch.Generator().manual_seed(CI + ks + H)
+    B, CO = 2, 64
+    x = torch.randn(B, H, W, CI, generator=g).bfloat16()
+    x[..., CIreal:] = 0
+    w = torch.randn(CO, CIreal, ks, ks, generator=g) * 0.1
+    scale = torch.rand(B, CI, generator=g) + 0.5
+    shift = torch.randn(B, CI, generator=g) * 0.3
+    dout = torch.randn(B, H, W, 64, generator=g).bfloat16()
+    for transform in (False, True):
+        xin = torch.relu(x.float() * scale[:, None, None, :] + shift[:, None, None, :]) if transform else x.float()
+        wd = torch.zeros(CO, CIreal, ks, ks, dtype=torch.float64, requires_grad=True)
+        ref = Fn.conv2d(_bf(xin[..., :CIreal]).permute(0, 3, 1, 2), _bf(w) + wd, padding=ks // 2)
+        ref.backward(dout.double().permute(0, 3, 1, 2))
+        ref = ref.detach().permute(0, 2, 3, 1)
+        wp = om.prep_weights(w.to(gpu_device), False, 64, CI, compute="bf16")
+        out, stats = om.conv_fwd(x.to(gpu_device), wp, ks, in_scale=scale.to(gpu_device) if transform else None,
+                                 in_shift=shift.to(gpu_device) if transform else None, in_relu=transform, want_stats=True,
+                                 compute="bf16")
+        assert out.dtype == torch.bfloat16
+        assert rel_err(out.float(), ref) < 8e-3
+        s = stats.sum(0).cpu().double()  # statistics come from the fp32 accumulators
+        np.testing.assert_allclose(s[0].numpy(), ref.sum((0, 1, 2)).numpy(), rtol=2e-3, atol=5e-2)
+        grad = torch.zeros(CO, CIreal, ks, ks, device=gpu_device)
+        om.conv_wgrad(x.to(gpu_device), dout.to(gpu_device), ks, CO, CIreal, grad, scale.to(gpu_device) if transform else None,
+                      shift.to(gpu_device) if transform else None, transform, compute="bf16")
+        assert rel_err(grad, wd.grad) < 5e-4
+
+
+def test_halfunet_bf16_storage_runs_and_tracks_fp32(gpu_device):
+    from oracle.halfunet import HalfUNetRef
+    from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings
+
+    torch.manual_seed(0)
+    cin, cout, H, W = 69, 60, 64, 64
+    ref = HalfUNetRef(cin, cout).double()
+    model = HalfUNetMI355X(cin, cout, (H, W), HalfUNetSettings(compute_dtype="bf16", activation_dtype="bf16"))
+    model.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    model = model.to(gpu_device).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, H, W, cin, generator=g)
+    gy = torch.randn(2, H, W, cout, generator=g)
+    ref.train()
+    yr = ref(x.double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    (yr * gy.double()).sum().backward()
+    yg = model(x.to(gpu_device))
+    assert yg.dtype == torch.float32  # the module hands back the caller's dtype
+    (yg * gy.to(gpu_device)).sum().backward()
+    assert rel_err(yg, yr) < 0.1
+    pr = dict(ref.named_parameters())
+    for name, p in model.named_parameters():
+        a, b = p.grad.detach().cpu().double().flatten(), pr[name].grad.flatten()
+        assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.85, name
