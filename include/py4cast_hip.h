@@ -243,7 +243,10 @@ typedef struct p4c_halfunet_desc {
     float eps;
     float momentum;
     int32_t compute;      /* matrix-core input type of the convolutions: P4C_F32 (exact fp32 MFMA) or P4C_BF16
-                             (operands rounded to bf16 in LDS, fp32 accumulate; activations stay fp32 in HBM) */
+                             (operands rounded to bf16, fp32 accumulate) */
+    int32_t weights_prepared; /* 1: p4c_halfunet_prepare_weights() ran on this scratch workspace since the parameters
+                                 last changed (e.g. once per rollout); forward/backward then skip their own
+                                 re-layout of the weights.  0: each call prepares what it needs (one extra launch). */
 } p4c_halfunet_desc;
 
 /* number of floats of the flat parameter vector, laid out in this order (canonical torch layouts):
@@ -255,6 +258,9 @@ int64_t p4c_halfunet_param_count(const p4c_halfunet_desc* d);
 /* saved_bytes: activations kept from forward for backward (one per forward call still awaiting its
  * backward); scratch_bytes: transient buffers shareable between calls on one stream. */
 int p4c_halfunet_workspace_bytes(const p4c_halfunet_desc* d, size_t* saved_bytes, size_t* scratch_bytes);
+/* re-lays (and for P4C_BF16 rounds) every convolution weight, forward and data-gradient orientation, into the
+ * scratch workspace: one launch.  Valid until the parameters change or the scratch workspace is reused elsewhere. */
+int p4c_halfunet_prepare_weights(const p4c_halfunet_desc* d, const float* params, void* scratch, p4c_stream_t stream);
 int p4c_halfunet_forward(const p4c_halfunet_desc* d, const void* x, const float* params, float* running, void* y,
                          void* saved, void* scratch, int training, p4c_stream_t stream);
 /* dy: (B,H,W,64) (channels >= cout ignored); dx: (B,H,W,64) or NULL (first dx_channels channels valid);

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpy4cast_hip.so")
+LIB_PATH = os.environ.get("P4C_LIB_PATH") or os.path.join(_HERE, "libpy4cast_hip.so")  # override: diagnostic builds
 
 F32, BF16 = 0, 1
 PROF_CONV3X3_C64, PROF_WGRAD3X3_C64 = 1, 2

@@ -14,6 +14,7 @@ class HalfUNetDesc(ctypes.Structure):
         ("cin", c_int32), ("cin_pad", c_int32), ("cout", c_int32), ("dx_channels", c_int32),
         ("dtype", c_int32), ("norm", c_int32), ("groups", c_int32), ("has_bias", c_int32),
         ("eps", c_float), ("momentum", c_float), ("compute", c_int32),
+        ("weights_prepared", c_int32),
     ]
 
 
@@ -24,6 +25,7 @@ SIGNATURES = {
     "p4c_conv_fwd": [P, I, I, I, P, I, P, P, I, P, P, I, P, I, I, I, I, P],
     "p4c_conv_wgrad": [P, I, I, I, I, P, P, I, P, I, I, P, P, I, I, I, P],
     "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
+    "p4c_halfunet_prepare_weights": [DP, P, P, P],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],
     "p4c_halfunet_backward": [DP, P, P, P, P, P, P, P, I, P],
 }

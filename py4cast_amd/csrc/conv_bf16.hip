@@ -17,7 +17,7 @@
 // At 16x the fp32 MFMA rate these kernels are HBM-bound: 2 * 4 B * 64 ch per pixel (read + write).
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "kernels.hpp"
 
 namespace p4c {
 
@@ -28,6 +28,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BTW = 32;  // tile width in pixels
+
+#ifndef P4C_EXP
+#define P4C_EXP 0  // diagnostic builds only (scratch/exp_build.sh): bit mask of pipeline stages to leave out
+#endif
 
 #ifdef P4C_STAMPS  // diagnostic build only: per-iteration s_memtime stamps of one compute and one loader wave
 __device__ unsigned long long* g_stamps = nullptr;
@@ -465,12 +469,14 @@ __global__ void __launch_bounds__(512, 2)
         BTile<T, CI, LH, LW> ta, tb;
         auto load = [&](BTile<T, CI, LH, LW>& tr, int t) {
             if (t >= t_end) return;
+            if (P4C_EXP & 2) { if (t > t_begin + 1) return; }
             int b, y0, x0;
             coords(t, b, y0, x0);
             btile_load<T, CI, LH, LW, HALO>(tr, in, b, y0, x0, H, W, CI, ltid);
         };
         auto store = [&](const BTile<T, CI, LH, LW>& tr, int t, char* buf) {
             if (t >= t_end) return;
+            if (P4C_EXP & 1) { if (t > t_begin + 1) return; }
             int b, y0, x0;
             coords(t, b, y0, x0);
             btile_store<T, CI, LH, LW, HALO, ROWB>(tr, in_scale, in_shift, in_relu, buf, b, y0, x0, H, W, CI, ltid);
@@ -527,6 +533,7 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
         const char* pl = lt + par * TILEB + (wv * LW + r) * ROWB + 16 * h;
+        if (!(P4C_EXP & 16)) {
         // fully unrolled tap stream with operand double buffering at TAP granularity: the 3*NKS ds_read_b128 of tap
         // t+1 are issued before the 2*NKS MFMAs of tap t (>= 256 cycles of matrix work cover the LDS read latency;
         // a one-step look-ahead of 64 cycles does not: measured 65 cycles per MFMA instead of 32)
@@ -557,6 +564,7 @@ __global__ void __launch_bounds__(512, 2)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        } else { acc0[0] = pl[0]; acc1[3] = pl[16]; }
         P4C_STAMP(4 * (tile - t_begin) + 1);
         // ---- epilogue: C[co][px]; lane = pixel r (+ half h), register i -> co = (i&3) + 8*(i>>2) + 4*h
         const int gx = x0 + r, gy = y0 + wv;
@@ -569,8 +577,8 @@ __global__ void __launch_bounds__(512, 2)
             for (int g = 0; g < 4; ++g) {
                 const f32x16& a = ct == 0 ? acc0 : acc1;
                 const f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-                if (valid) store4(orow + ct * 32 + 8 * g, v);
-                if (stat_partial) {
+                if (valid && (!(P4C_EXP & 4) || v.x == 123.456f)) store4(orow + ct * 32 + 8 * g, v);
+                if (stat_partial && !(P4C_EXP & 8)) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float o = v[j] * vkeep;
@@ -853,6 +861,48 @@ int prep_weights_bf16(const float* w, int CO, int CI, int ks, int transpose_flip
     hipLaunchKernelGGL(prep_weights_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, CO, CI, ks * ks,
                        transpose_flip, M_pad, K_pad, (__bf16*)out);
     P4C_CHECK_LAUNCH("prep_weights_bf16");
+    return P4C_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prep_weights_batch: every weight tensor of a network re-laid in ONE launch (blockIdx.y = job); the job table
+// travels in the kernel arguments.  bf16 = 0 writes the fp32 stream of conv_f32.hip (k = 8q + 4h + s).
+__global__ void __launch_bounds__(256) prep_weights_batch_kernel(PrepBatch pb) {
+    const PrepJob& jb = pb.job[blockIdx.y];
+    const int total = jb.M_pad * jb.K_pad * jb.ntaps;
+    const int kv = pb.bf16 ? 8 : 4;           // k values per lane slot
+    const int ksteps = jb.K_pad / (2 * kv);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int t = i;
+        const int j = t % kv; t /= kv;
+        const int m_l = t & 63; t >>= 6;
+        const int h = t & 1; t >>= 1;
+        const int ks = t % ksteps; t /= ksteps;
+        const int tap = t % jb.ntaps;
+        const int mb = t / jb.ntaps;
+        const int k = 2 * kv * ks + kv * h + j, m = 64 * mb + m_l;
+        float v = 0.0f;
+        if (!jb.transpose_flip) {
+            if (m < jb.CO && k < jb.CI) v = jb.w[((int64_t)m * jb.CI + k) * jb.ntaps + tap];
+        } else {
+            if (k < jb.CO && m < jb.CI) v = jb.w[((int64_t)k * jb.CI + m) * jb.ntaps + (jb.ntaps - 1 - tap)];
+        }
+        if (pb.bf16) reinterpret_cast<__bf16*>(jb.out)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(jb.out)[i] = v;
+    }
+}
+
+int prep_weights_batch(const PrepBatch& pb, hipStream_t stream) {
+    if (pb.n <= 0) return P4C_OK;
+    int maxtotal = 0;
+    for (int i = 0; i < pb.n; ++i) {
+        const int t = pb.job[i].M_pad * pb.job[i].K_pad * pb.job[i].ntaps;
+        if (t > maxtotal) maxtotal = t;
+    }
+    int bx = (maxtotal + 256 * 4 - 1) / (256 * 4);
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(prep_weights_batch_kernel, dim3(bx, pb.n), dim3(256), 0, stream, pb);
+    P4C_CHECK_LAUNCH("prep_weights_batch");
     return P4C_OK;
 }
 

@@ -340,20 +340,29 @@ __global__ void __launch_bounds__(256, 1)
 }
 
 // grad[co][ci][tap] += sum_slots partial[slot][tap][ci_pad][64]  for ci in [ci_lo, ci_hi), real channels only.
-// One block per (tap, ci): 64 output channels x 4 slot slices, fixed summation order (deterministic).
+// One block per (tap, ci): 16 lanes x 4 output channels (16-byte loads) x 16 slot slices, all of a thread's loads
+// independent; fixed summation order (deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int ntaps, int CI_pad,
                                                            int ci_lo, int ci_hi, int CO, int CI, float* __restrict__ grad) {
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     const int nci = ci_hi - ci_lo;
     const int tap = blockIdx.x / nci, ci = ci_lo + (blockIdx.x - tap * nci);
-    const int co = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int64_t stride = (int64_t)ntaps * CI_pad * 64;
-    const float* p = partial + ((int64_t)tap * CI_pad + ci) * 64 + co;
-    float s = 0.f;
-    for (int g = sl; g < nslots; g += 4) s += p[g * stride];
-    red[sl][co] = s;
+    const float* p = partial + ((int64_t)tap * CI_pad + ci) * 64 + 4 * q;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int g = sl; g < nslots; g += 16) s += *reinterpret_cast<const f32x4*>(p + g * stride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[sl][4 * q + j] = s[j];
     __syncthreads();
-    if (sl == 0 && co < CO && ci < CI) grad[((int64_t)co * CI + ci) * ntaps + tap] += (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+    if (threadIdx.x < 64) {
+        const int co = threadIdx.x;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][co];
+        if (co < CO && ci < CI) grad[((int64_t)co * CI + ci) * ntaps + tap] += t;
+    }
 }
 
 template <int CI, int KS, int TH>

@@ -15,6 +15,10 @@ namespace {
 constexpr int NF = 64;       // num_filters
 constexpr int NLEV = 5;      // encoder levels
 constexpr int NCONV = 12;    // 3x3 convs: enc k conv j -> 2(k-1)+j-1 ; decoder -> 10, 11
+// prepared-weight cache in the scratch workspace: slot i = conv i forward, NCONV + i = conv i data gradient,
+// 2*NCONV / 2*NCONV + 1 = 1x1 output conv forward / data gradient
+constexpr int NWSLOT = 2 * NCONV + 2;
+constexpr int64_t WSLOT_FLOATS = 9 * 96 * 64;
 
 struct Layout {
     int esz;                  // bytes per activation element
@@ -106,7 +110,7 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
 
     L.G = num_cus();
     off = 0;
-    L.wprep = off; off += (int64_t)9 * 96 * 64;
+    L.wprep = off; off += (int64_t)NWSLOT * WSLOT_FLOATS;
     const int64_t tps = conv_tiles_per_sample(d.H, d.W);
     L.statp = off; off += (int64_t)d.B * (tps > 4 * (int64_t)L.G ? tps : 4 * (int64_t)L.G) * 128;
     L.wgradp = off; off += wgrad_partial_floats(96, 3, L.G);
@@ -119,7 +123,7 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     L.G0 = off; off += L.n[0] * NF;
     L.G1 = off; off += L.n[0] * NF;
     L.G2 = off; off += L.n[0] * NF;
-    L.TB = off; off += L.n[0] * NF / 2;
+    L.TB = off; off += L.n[0] * NF;  // x-pass outputs of the four up-sampling adjoints: n0*NF*(1/2+1/4+1/8+1/16)
     L.scratch_bytes = L.g_base + off * L.esz;
 }
 
@@ -146,13 +150,30 @@ inline Norm norm_at(const WS& ws, int i, int B) {
     return {p, p + (int64_t)B * NF, p + 2 * (int64_t)B * NF, p + 3 * (int64_t)B * NF};
 }
 
+inline void* wslot(const WS& ws, int slot) { return ws.f(ws.L.wprep + (int64_t)slot * WSLOT_FLOATS); }
+
+// (re)prepares the weight operand streams: which = 1 forward orientation, 2 data-gradient orientation, 3 both
+int prepare_weights(const p4c_halfunet_desc& d, const WS& ws, const float* params, int which, hipStream_t st) {
+    const Layout& L = ws.L;
+    PrepBatch pb;
+    pb.n = 0;
+    pb.bf16 = d.compute == P4C_BF16;
+    for (int i = 0; i < NCONV; ++i) {
+        if (which & 1) pb.job[pb.n++] = {params + L.w[i], wslot(ws, i), NF, conv_cin(d, i), 9, 0, 64, conv_cin_pad(d, i)};
+        // data gradient: M = input channel (the first 64 at most: dx_channels <= 64), K = output channel, taps flipped
+        if (which & 2) pb.job[pb.n++] = {params + L.w[i], wslot(ws, NCONV + i), NF, conv_cin(d, i), 9, 1, 64, NF};
+    }
+    if (which & 1) pb.job[pb.n++] = {params + L.wout, wslot(ws, 2 * NCONV), d.cout, NF, 1, 0, 64, NF};
+    if (which & 2) pb.job[pb.n++] = {params + L.wout, wslot(ws, 2 * NCONV + 1), d.cout, NF, 1, 1, 64, NF};
+    return prep_weights_batch(pb, st);
+}
+
 // conv3x3 forward + statistics + normalisation parameters of its output
 int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* in, const Norm* in_norm, const float* params,
                    float* running, int training, hipStream_t st) {
     const Layout& L = ws.L;
     const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
-    void* wp = ws.f(L.wprep);
-    P4C_TRY(prep_w(d.compute, params + L.w[i], NF, conv_cin(d, i), 3, 0, 64, conv_cin_pad(d, i), wp, st));
+    void* wp = wslot(ws, i);
     const bool batch_stats = (d.norm == 1) || training;
     float* statp = batch_stats ? ws.f(L.statp) : nullptr;
     P4C_TRY(conv_fwd(d.compute, d.dtype, in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
@@ -189,9 +210,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
     P4C_TRY(conv_wgrad(d.compute, d.dtype, in, cip, 3, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
                        in_norm ? 1 : 0, g, ws.f(L.wgradp), G, d.B, H, W, NF, conv_cin(d, i), grads + L.w[i], st));
     if (din) {
-        void* wp = ws.f(L.wprep);
-        P4C_TRY(prep_w(d.compute, params + L.w[i], NF, conv_cin(d, i), 3, 1, 64, NF, wp, st));
-        P4C_TRY(conv_fwd(d.compute, d.dtype, g, NF, wp, 3, nullptr, nullptr, 0, din, 64, nullptr, d.B, H, W, 1, st));
+        P4C_TRY(conv_fwd(d.compute, d.dtype, g, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, nullptr, d.B, H, W, 1, st));
     }
     return P4C_OK;
 }
@@ -217,6 +236,16 @@ extern "C" int p4c_halfunet_workspace_bytes(const p4c_halfunet_desc* d, size_t* 
     return P4C_OK;
 }
 
+extern "C" int p4c_halfunet_prepare_weights(const p4c_halfunet_desc* dp, const float* params, void* scratchv,
+                                            p4c_stream_t stream) {
+    P4C_TRY(check_desc(dp));
+    P4C_CHECK_ARG(params && scratchv, "p4c_halfunet_prepare_weights: null pointer");
+    Layout L;
+    make_layout(*dp, L);
+    const WS ws{L, nullptr, (char*)scratchv};
+    return prepare_weights(*dp, ws, params, 3, as_stream(stream));
+}
+
 extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* x, const float* params, float* running,
                                     void* y, void* savedv, void* scratchv, int training, p4c_stream_t stream) {
     P4C_TRY(check_desc(dp));
@@ -226,6 +255,7 @@ extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* x, 
     make_layout(d, L);
     hipStream_t st = as_stream(stream);
     const WS ws{L, (char*)savedv, (char*)scratchv};
+    if (!d.weights_prepared) P4C_TRY(prepare_weights(d, ws, params, 1, st));
 
     // encoder
     for (int k = 0; k < NLEV; ++k) {
@@ -254,9 +284,7 @@ extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* x, 
     P4C_TRY(conv_block_fwd(d, ws, 11, ws.act(L.Y[10]), &nd1, params, running, training, st));
     Norm nd2 = norm_at(ws, 11, d.B);
     // 1x1 output conv on relu(norm(Y_dec2)); last activation = Identity
-    void* wp = ws.f(L.wprep);
-    P4C_TRY(prep_w(d.compute, params + L.wout, d.cout, NF, 1, 0, 64, NF, wp, st));
-    P4C_TRY(conv_fwd(d.compute, d.dtype, ws.act(L.Y[11]), NF, wp, 1, nd2.scale, nd2.shift, 1, y, NF, nullptr, d.B, d.H, d.W, 1, st));
+    P4C_TRY(conv_fwd(d.compute, d.dtype, ws.act(L.Y[11]), NF, wslot(ws, 2 * NCONV), 1, nd2.scale, nd2.shift, 1, y, NF, nullptr, d.B, d.H, d.W, 1, st));
     return P4C_OK;
 }
 
@@ -272,7 +300,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     hipStream_t st = as_stream(stream);
     const WS ws{L, (char*)savedv, (char*)scratchv};
     void *G0 = ws.g(L.G0), *G1 = ws.g(L.G1), *G2 = ws.g(L.G2), *TB = ws.g(L.TB);
-    void* wp = ws.f(L.wprep);
+    if (!d.weights_prepared) P4C_TRY(prepare_weights(d, ws, params, 2, st));
 
     // ---- output 1x1 conv
     Norm nd2 = norm_at(ws, 11, d.B);
@@ -281,8 +309,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         const int G = ntiles < L.G ? (int)ntiles : L.G;
         P4C_TRY(conv_wgrad(d.compute, d.dtype, ws.act(L.Y[11]), NF, 1, nd2.scale, nd2.shift, 1, dy, ws.f(L.wgradp), G, d.B, d.H,
                            d.W, d.cout, NF, grads + L.wout, st));
-        P4C_TRY(prep_w(d.compute, params + L.wout, d.cout, NF, 1, 1, 64, NF, wp, st));
-        P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wp, 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
+        P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
     }
     // ---- decoder
     Norm nd1 = norm_at(ws, 10, d.B);
@@ -291,6 +318,13 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     // G0 = dS, kept until the last level
 
     // ---- encoder levels, deepest first
+    // x pass of all four up-sampling adjoints from one read of dS
+    void* tx[4];
+    {
+        int64_t off = 0;
+        for (int k = 1; k < NLEV; ++k) { tx[k - 1] = (char*)TB + off * L.esz; off += L.n[0] * NF >> k; }
+        P4C_TRY(up_bwd_x4(d.dtype, G0, d.B, d.H, d.W, tx, st));
+    }
     void *a = G1, *b = G2;  // a: holds dP_{k+1} on entry (k < 4)
     for (int k = NLEV - 1; k >= 0; --k) {
         const int Hk = L.Hk[k], Wk = L.Wk[k];
@@ -298,8 +332,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         Norm n1 = norm_at(ws, 2 * k, d.B);
         const void* dP = (k + 1 < NLEV) ? a : nullptr;
         if (k > 0) {
-            P4C_TRY(up_bwd_x(d.dtype, G0, d.B, d.H, d.W, 1 << k, TB, st));
-            P4C_TRY(enc_out_bwd(d.dtype, TB, d.H, 1 << k, nullptr, dP, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st));
+            P4C_TRY(enc_out_bwd(d.dtype, tx[k - 1], d.H, 1 << k, nullptr, dP, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st));
         } else {
             P4C_TRY(enc_out_bwd(d.dtype, nullptr, d.H, 1, G0, dP, ws.act(L.Y[1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st));
         }

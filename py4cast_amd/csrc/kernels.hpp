@@ -22,6 +22,18 @@ int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo
 // conv_bf16.hip (bf16 matrix cores, fp32 storage)
 int prep_weights_bf16(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, void* out,
                       hipStream_t stream);
+// all weight tensors of a network in one launch (job table passed by value in the kernel arguments)
+struct PrepJob {
+    const float* w;   // canonical torch weight [CO][CI][ks][ks]
+    void* out;        // prepared operand stream
+    int CO, CI, ntaps, transpose_flip, M_pad, K_pad;
+};
+struct PrepBatch {
+    PrepJob job[32];
+    int n;
+    int bf16;         // 1: bf16 stream (conv_bf16.hip), 0: fp32 stream (conv_f32.hip)
+};
+int prep_weights_batch(const PrepBatch& pb, hipStream_t stream);
 int conv_bf16_stat_slots(int CI, int B, int H, int W);
 // `storage` = element type of in/out/dout in HBM (P4C_F32 or P4C_BF16)
 int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
@@ -46,7 +58,8 @@ int pool_fwd(int storage, const void* y, const float* scale, const float* shift,
              hipStream_t stream);
 int upsum_fwd(int storage, const void* const* y, const float* const* scale, const float* const* shift, int B, int H, int W,
               void* S, hipStream_t stream);
-int up_bwd_x(int storage, const void* dS, int B, int H, int W, int s, void* Tx, hipStream_t stream);
+// tx[k-1]: (B,H,W>>k,64) for k = 1..4
+int up_bwd_x4(int storage, const void* dS, int B, int H, int W, void* const* tx, hipStream_t stream);
 int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, const void* dP, const void* y,
                 const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream);
 

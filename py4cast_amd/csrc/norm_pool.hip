@@ -279,58 +279,135 @@ struct UpLevels {
     const float* shift[5];
 };
 
-// upsum_fwd: S[b,y,x,:] = sum_k up_{2^k}( relu(y_k*scale_k+shift_k) )   (k = 0..4)
-template <typename T>
-__global__ void __launch_bounds__(256) upsum_fwd_kernel(UpLevels<T> lv, int B, int H, int W, T* __restrict__ S) {
-    const int64_t total = (int64_t)B * H * W * 16;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c4 = (int)(i & 15);
-        int64_t pix = i >> 4;
-        const int x = (int)(pix % W); pix /= W;
-        const int yy = (int)(pix % H);
-        const int b = (int)(pix / H);
-        f32x4 acc = relu4(ld4(lv.y[0] + (i >> 4) * C + 4 * c4) * ld4(lv.scale[0] + b * C + 4 * c4) + ld4(lv.shift[0] + b * C + 4 * c4));
+// One level of the up-sample-and-sum for a run of 16 output pixels x 4 channels held by one thread.
+// The 16 outputs of a level-K run (scale s = 2^K) interpolate between 16/s + 2 source columns: those are
+// normalised (+ReLU) and blended along y ONCE, then each output is one x-blend with compile-time weights.
+// Source columns are clamped to the image, which reproduces torch's border rule (src < 0 -> 0, i1 <= n-1)
+// because both blended values then coincide.
+template <typename T, int K>
+__device__ __forceinline__ void up_level_run(const T* __restrict__ yk, const float* __restrict__ scale,
+                                             const float* __restrict__ shift, int b, int yy, int x0, int H, int W, int c4,
+                                             f32x4 (&acc)[16]) {
+    constexpr int s = 1 << K;
+    constexpr int NC = 16 / s + 2;
+    const int Hk = H >> K, Wk = W >> K;
+    int y0, y1;
+    float ly;
+    bilin(yy, s, Hk, y0, y1, ly);
+    const float hy = 1.f - ly;
+    const f32x4 sc = ld4(scale + b * C + 4 * c4), sh = ld4(shift + b * C + 4 * c4);
+    const T* r0 = yk + ((int64_t)b * Hk + y0) * Wk * C + 4 * c4;
+    const T* r1 = yk + ((int64_t)b * Hk + y1) * Wk * C + 4 * c4;
+    const int cbase = x0 / s - 1;
+    f32x4 v[NC];
 #pragma unroll
-        for (int k = 1; k < 5; ++k) {
-            const int s = 1 << k, Hk = H >> k, Wk = W >> k;
-            int y0, y1, x0, x1; float ly, lx;
-            bilin(yy, s, Hk, y0, y1, ly);
-            bilin(x, s, Wk, x0, x1, lx);
-            const f32x4 sc = ld4(lv.scale[k] + b * C + 4 * c4), sh = ld4(lv.shift[k] + b * C + 4 * c4);
-            const T* base = lv.y[k] + (int64_t)b * Hk * Wk * C + 4 * c4;
-            const f32x4 v00 = relu4(ld4(base + ((int64_t)y0 * Wk + x0) * C) * sc + sh);
-            const f32x4 v01 = relu4(ld4(base + ((int64_t)y0 * Wk + x1) * C) * sc + sh);
-            const f32x4 v10 = relu4(ld4(base + ((int64_t)y1 * Wk + x0) * C) * sc + sh);
-            const f32x4 v11 = relu4(ld4(base + ((int64_t)y1 * Wk + x1) * C) * sc + sh);
-            const float hy = 1.f - ly, hx = 1.f - lx;
-            acc += hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);  // torch: w00*.. grouping by rows
-        }
-        st4(S + (i >> 4) * C + 4 * c4, acc);
+    for (int j = 0; j < NC; ++j) {
+        int col = cbase + j;
+        col = col < 0 ? 0 : (col > Wk - 1 ? Wk - 1 : col);
+        const f32x4 a = relu4(ld4(r0 + (int64_t)col * C) * sc + sh);
+        const f32x4 q = relu4(ld4(r1 + (int64_t)col * C) * sc + sh);
+        v[j] = hy * a + ly * q;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float t = ((float)i + 0.5f) / (float)s - 0.5f;  // constant-folded after unrolling
+        const float fl = t < 0.f ? -1.f : (float)(int)t;
+        const int j0 = (int)fl + 1;
+        const float lx = t - fl;
+        acc[i] += (1.f - lx) * v[j0] + lx * v[j0 + 1];
     }
 }
 
-// up_bwd_x: T[b,y,X,:] = sum_x wx(x,X) dS[b,y,x,:]   for one level (scale s); T is (B,H,W/s,64)
+// upsum_fwd: S[b,y,x,:] = sum_k up_{2^k}( relu(y_k*scale_k+shift_k) )   (k = 0..4), bilinear, align_corners=False.
+// Thread = 4 channels x 16 consecutive pixels of a row (W % 16 == 0).
 template <typename T>
-__global__ void __launch_bounds__(256) up_bwd_x_kernel(const T* __restrict__ dS, int B, int H, int W, int s, T* __restrict__ Tx) {
-    const int Wk = W / s;
-    const int64_t total = (int64_t)B * H * Wk * 16;
+__global__ void __launch_bounds__(256) upsum_fwd_kernel(UpLevels<T> lv, int B, int H, int W, T* __restrict__ S) {
+    const int segs = W / 16;
+    const int64_t total = (int64_t)B * H * segs * 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c4 = (int)(i & 15);
-        int64_t pix = i >> 4;
-        const int X = (int)(pix % Wk);
-        const int64_t row = pix / Wk;  // b*H + y
-        f32x4 acc = {0, 0, 0, 0};
-        int xa = s * X - s / 2, xb = s * X + 3 * s / 2 - 1;
-        if (xa < 0) xa = 0;
-        if (xb > W - 1) xb = W - 1;
-        for (int x = xa; x <= xb; ++x) {
-            int x0, x1; float lx;
-            bilin(x, s, Wk, x0, x1, lx);
-            const float w = (x0 == X ? 1.f - lx : 0.f) + (x1 == X ? lx : 0.f);
-            if (w != 0.f) acc += w * ld4(dS + (row * W + x) * C + 4 * c4);
+        int64_t seg = i >> 4;
+        const int x0 = (int)(seg % segs) * 16; seg /= segs;
+        const int yy = (int)(seg % H);
+        const int b = (int)(seg / H);
+        const int64_t pix0 = ((int64_t)b * H + yy) * W + x0;
+        f32x4 acc[16];
+        {
+            const f32x4 sc = ld4(lv.scale[0] + b * C + 4 * c4), sh = ld4(lv.shift[0] + b * C + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = relu4(ld4(lv.y[0] + (pix0 + j) * C + 4 * c4) * sc + sh);
         }
-        st4(Tx + (i >> 4) * C + 4 * c4, acc);
+        up_level_run<T, 1>(lv.y[1], lv.scale[1], lv.shift[1], b, yy, x0, H, W, c4, acc);
+        up_level_run<T, 2>(lv.y[2], lv.scale[2], lv.shift[2], b, yy, x0, H, W, c4, acc);
+        up_level_run<T, 3>(lv.y[3], lv.scale[3], lv.shift[3], b, yy, x0, H, W, c4, acc);
+        up_level_run<T, 4>(lv.y[4], lv.scale[4], lv.shift[4], b, yy, x0, H, W, c4, acc);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st4(S + (pix0 + j) * C + 4 * c4, acc[j]);
     }
+}
+
+// up_bwd_x4: x pass of the adjoint of the four bilinear up-samplings, all levels from ONE read of dS:
+//   Tx_k[b,y,X,:] = sum_x wx_k(x,X) dS[b,y,x,:]   (k = 1..4, s = 2^k), Tx_k is (B,H,W/s,64).
+// wx_k(x,X) = max(0, 1 - |src - X|), src = (x+0.5)/s - 0.5, except at the clamped borders (src < 0 -> all weight
+// on X = 0; src > Wk-1 -> all weight on X = Wk-1).  One workgroup = one row x 64 pixels (+8 halo each side) staged
+// in LDS as fp32; the 2s taps of an output are split over thread groups so every thread does 8 taps per level.
+template <typename T>
+struct UpBwdOut {
+    T* tx[4];
+};
+
+template <typename T, int K>
+__device__ __forceinline__ void up_bwd_level(const f32x4 (*tile)[16], int64_t row, int x0, int W, int c4, int g, T* __restrict__ out) {
+    constexpr int s = 1 << K;
+    constexpr int NOUT = 64 / s;                    // outputs of this level in the strip
+    constexpr int PARTS = NOUT >= 16 ? 1 : 16 / NOUT;  // thread groups sharing one output
+    constexpr int PER = NOUT >= 16 ? NOUT / 16 : 1;    // outputs per thread group
+    constexpr int TAPS = 2 * s / PARTS;
+    const int Wk = W >> K;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int Xl = PARTS == 1 ? g * PER + q : g / PARTS;
+        const int part = PARTS == 1 ? 0 : g % PARTS;
+        const int X = x0 / s + Xl;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < TAPS; ++jj) {
+            const int j = part * TAPS + jj;
+            float w = 1.f - fabsf(((float)j + 0.5f) / (float)s - 1.f);
+            if ((X == 0 && j < s) || (X == Wk - 1 && j >= s)) w = 1.f;
+            acc += w * tile[s * Xl - s / 2 + j + 8][c4];
+        }
+        if (PARTS >= 2) {
+            acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16);
+            acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+        }
+        if (PARTS >= 4) {
+            acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32);
+            acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+        }
+        if (part == 0 && X < Wk) st4(out + (row * Wk + X) * C + 4 * c4, acc);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) up_bwd_x4_kernel(const T* __restrict__ dS, int H, int W, UpBwdOut<T> o) {
+    __shared__ f32x4 tile[80][16];
+    const int strips = (W + 63) / 64;
+    const int64_t row = blockIdx.x / strips;  // b*H + y
+    const int x0 = (int)(blockIdx.x % strips) * 64;
+    const int c4 = threadIdx.x & 15, g = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = g; p < 80; p += 16) {
+        const int x = x0 - 8 + p;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (x >= 0 && x < W) v = ld4(dS + (row * W + x) * C + 4 * c4);
+        tile[p][c4] = v;
+    }
+    __syncthreads();
+    up_bwd_level<T, 1>(tile, row, x0, W, c4, g, o.tx[0]);
+    up_bwd_level<T, 2>(tile, row, x0, W, c4, g, o.tx[1]);
+    up_bwd_level<T, 3>(tile, row, x0, W, c4, g, o.tx[2]);
+    up_bwd_level<T, 4>(tile, row, x0, W, c4, g, o.tx[3]);
 }
 
 // enc_out_bwd: gradient wrt the (post-ReLU) output of encoder level k (at Hk x Wk):
@@ -470,7 +547,7 @@ static int upsum_fwd_t(const void* const* y, const float* const* scale, const fl
                        T* S, hipStream_t stream) {
     UpLevels<T> lv;
     for (int k = 0; k < 5; ++k) { lv.y[k] = (const T*)y[k]; lv.scale[k] = scale[k]; lv.shift[k] = shift[k]; }
-    hipLaunchKernelGGL(upsum_fwd_kernel<T>, dim3(ew_grid((int64_t)B * H * W * 16)), dim3(256), 0, stream, lv, B, H, W, S);
+    hipLaunchKernelGGL(upsum_fwd_kernel<T>, dim3(ew_grid((int64_t)B * H * (W / 16) * 16)), dim3(256), 0, stream, lv, B, H, W, S);
     P4C_CHECK_LAUNCH("upsum_fwd");
     return P4C_OK;
 }
@@ -481,15 +558,16 @@ int upsum_fwd(int storage, const void* const* y, const float* const* scale, cons
 }
 
 template <typename T>
-static int up_bwd_x_t(const T* dS, int B, int H, int W, int s, T* Tx, hipStream_t stream) {
-    hipLaunchKernelGGL(up_bwd_x_kernel<T>, dim3(ew_grid((int64_t)B * H * (W / s) * 16)), dim3(256), 0, stream, dS, B, H, W,
-                       s, Tx);
-    P4C_CHECK_LAUNCH("up_bwd_x");
+static int up_bwd_x4_t(const T* dS, int B, int H, int W, void* const* tx, hipStream_t stream) {
+    UpBwdOut<T> o;
+    for (int k = 0; k < 4; ++k) o.tx[k] = (T*)tx[k];
+    hipLaunchKernelGGL(up_bwd_x4_kernel<T>, dim3(B * H * ((W + 63) / 64)), dim3(256), 0, stream, dS, H, W, o);
+    P4C_CHECK_LAUNCH("up_bwd_x4");
     return P4C_OK;
 }
-int up_bwd_x(int storage, const void* dS, int B, int H, int W, int s, void* Tx, hipStream_t stream) {
-    return storage == P4C_BF16 ? up_bwd_x_t<__bf16>((const __bf16*)dS, B, H, W, s, (__bf16*)Tx, stream)
-                               : up_bwd_x_t<float>((const float*)dS, B, H, W, s, (float*)Tx, stream);
+int up_bwd_x4(int storage, const void* dS, int B, int H, int W, void* const* tx, hipStream_t stream) {
+    return storage == P4C_BF16 ? up_bwd_x4_t<__bf16>((const __bf16*)dS, B, H, W, tx, stream)
+                               : up_bwd_x4_t<float>((const float*)dS, B, H, W, tx, stream);
 }
 
 template <typename T>

@@ -120,31 +120,44 @@ __global__ void __launch_bounds__(256)
     } else if (c0 >= c_in) {
         kind = 2;
     }
-    for (int64_t pix = (int64_t)wave * PP + pp; pix < total; pix += (int64_t)nwaves * PP) {
-        const int b = (int)(pix / N);
-        const int64_t n = pix - (int64_t)b * N;
-        v4f v = {0.f, 0.f, 0.f, 0.f};
-        if (kind == 0) {
-            v = *reinterpret_cast<const v4f*>(prev + (int64_t)b * prev_bs + (int64_t)t_idx * prev_ts + n * F + f_idx);
-        } else if (kind == 1) {
-            v = *reinterpret_cast<const v4f*>(statics + (int64_t)b * statics_bs + n * Fs + (c0 - o_stat));
-        } else if (kind == 3) {
+    // 4 grid points per thread and trip: the 4 loads are independent and all issued before the first store
+    // (memory-level parallelism; one load in flight per lane left this pass latency-bound)
+    constexpr int UNR = 4;
+    for (int64_t base = (int64_t)wave * PP + pp; base < total; base += (int64_t)nwaves * PP * UNR) {
+        v4f v[UNR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = c0 + j;
-                float e = 0.f;
-                if (c < o_stat) {
-                    const int t = c / F, f = c - t * F;
-                    e = prev[(int64_t)b * prev_bs + (int64_t)t * prev_ts + n * F + f];
-                } else if (c < o_forc) {
-                    e = statics[(int64_t)b * statics_bs + n * Fs + (c - o_stat)];
-                } else if (c < c_in) {
-                    e = forcing[(int64_t)b * forcing_bs + n * Ff + (c - o_forc)];
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t pix = base + (int64_t)u * nwaves * PP;
+            v[u] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (pix >= total) continue;
+            const int b = (int)(pix / N);
+            const int64_t n = pix - (int64_t)b * N;
+            if (kind == 0) {
+                v[u] = *reinterpret_cast<const v4f*>(prev + (int64_t)b * prev_bs + (int64_t)t_idx * prev_ts + n * F + f_idx);
+            } else if (kind == 1) {
+                v[u] = *reinterpret_cast<const v4f*>(statics + (int64_t)b * statics_bs + n * Fs + (c0 - o_stat));
+            } else if (kind == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;
+                    float e = 0.f;
+                    if (c < o_stat) {
+                        const int t = c / F, f = c - t * F;
+                        e = prev[(int64_t)b * prev_bs + (int64_t)t * prev_ts + n * F + f];
+                    } else if (c < o_forc) {
+                        e = statics[(int64_t)b * statics_bs + n * Fs + (c - o_stat)];
+                    } else if (c < c_in) {
+                        e = forcing[(int64_t)b * forcing_bs + n * Ff + (c - o_forc)];
+                    }
+                    v[u][j] = e;
                 }
-                v[j] = e;
             }
         }
-        store4f(x + pix * (int64_t)c_pad + c0, v);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t pix = base + (int64_t)u * nwaves * PP;
+            if (pix < total) store4f(x + pix * (int64_t)c_pad + c0, v[u]);
+        }
     }
 }
 

@@ -243,7 +243,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         return HalfUNetDesc(B, H, W, self.in_channels, self.cin_pad, self.out_channels, self.dx_channels,
                             L.dtype_code(self.act_dtype),
                             0 if s.norm == "batch" else 1, s.groups, 0, 1e-5, 0.1,
-                            L.F32 if s.compute_dtype == "f32" else L.BF16)
+                            L.F32 if s.compute_dtype == "f32" else L.BF16, 0)
 
     def _workspaces(self, desc, device):
         key = (desc.B, desc.H, desc.W, str(device))
@@ -369,6 +369,9 @@ class _NativeRolloutFn(torch.autograd.Function):
         y = torch.empty(B, H, W, NF, dtype=adt, device=dev)
         stream = L.stream(dev)
         saved = None
+        # the parameters are fixed for the whole rollout: re-lay / round the weights once, not once per AR step
+        L.call("p4c_halfunet_prepare_weights", ctypes.byref(desc), L.ptr(flat), L.ptr(scratch), stream)
+        desc.weights_prepared = 1
         for i in range(T):
             x = torch.empty(B, H, W, cpad, dtype=adt, device=dev)
             L.call("p4c_build_x", L.ptr(states[:, i]), sbs_state, N * F, L.ptr(st), sbs, L.ptr(forcing[:, i]), T * N * Ff,
@@ -408,6 +411,8 @@ class _NativeRolloutFn(torch.autograd.Function):
         dprev = torch.empty(B, H, W, F, dtype=torch.float32, device=dev)
         gl = g_loss.contiguous().float() if g_loss is not None else None
         sbs_state = (T + 1) * N * F
+        # the scratch workspace may have served another call since forward: prepare again (one launch per sweep)
+        L.call("p4c_halfunet_prepare_weights", ctypes.byref(desc), L.ptr(flat), L.ptr(scratch), stream)
         desc0 = HalfUNetDesc.from_buffer_copy(desc)
         desc0.dx_channels = 0  # the input state of step 0 is data: no gradient needed, skip that conv
         have_next = False
