@@ -17,6 +17,8 @@
 // At 16x the fp32 MFMA rate these kernels are HBM-bound: 2 * 4 B * 64 ch per pixel (read + write).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace p4c {
@@ -606,6 +608,398 @@ __global__ void __launch_bounds__(512, 2)
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv3x3_bf16_ring: 3x3 conv, 64 -> 64 channels, bf16 activations in HBM (the hot kernel of the bf16 plan).
+// Same role split as conv_fwd_bf16_ws (waves 0-3 matrix phase, waves 4-7 memory side) with three changes that the
+// stage-removal measurements asked for (scratch/conv_exp.py: epilogue alone 27 us, loader+transform alone 50 us,
+// matrix phase alone 21 us per 512x512x2 launch):
+//   * the compute waves no longer store to HBM (8 scattered 8-byte stores per lane) nor keep statistics: they
+//     round their accumulators to bf16 into an LDS staging tile; the LOADER waves drain it with 16-byte,
+//     fully coalesced stores (8 lanes = one pixel's 128 bytes) and accumulate the channel statistics from the
+//     same registers (8 fixed channels per lane), i.e. of exactly the rounded values a consumer will normalise;
+//   * input rows live in a 12-row LDS RING per 32-pixel strip: walking down a strip, a tile re-uses the two
+//     halo rows the previous tile already staged (loaded AND normalised), so 4 rows instead of 6 are fetched
+//     and transformed per tile;
+//   * rows are 128 bytes (no padding) with the 16-byte slot index XOR-swizzled by the pixel column, which keeps
+//     both the B-operand reads and the loader writes bank-conflict free and fits ring + staging + weights in LDS.
+// LDS: weights 72 KB | ring 12 x 34 x 128 B = 51 KB | staging 2 x 16 KB.
+namespace ring {
+constexpr int TH = 4, LW = BTW + 2, R = 12, ROWB = 128, RROW = LW * ROWB;
+constexpr int WBYTES = 9 * 64 * 64 * 2, RINGB = R * RROW, STGB = TH * BTW * 128;
+constexpr int MAXB = 8;                       // samples whose normalisation rows fit the LDS left over
+constexpr int SMEM = WBYTES + RINGB + 2 * STGB + MAXB * 128 * 4;
+constexpr int NIMG = 7;                       // register slots per lane of a staged tile (6 rows fresh, 4 otherwise)
+constexpr int ROWSLOTS = LW * 8;              // 16-byte slots per halo row
+}  // namespace ring
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int ring_swz(int col) { return (col >> 1) & 7; }
+
+// relu(v*scale+shift) on the 2 bf16 channels packed in one word (fp32 arithmetic, one rounding), or parts of it.
+// MODE 0: copy, 1: ReLU, 2: scale/shift + ReLU, 3: scale/shift.
+template <int MODE>
+__device__ __forceinline__ unsigned int xform2(unsigned int w, f32x2 sc, f32x2 sh) {
+    if (MODE >= 2) {
+        f32x2 v = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+        v = v * sc + sh;
+        w = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+    }
+    if (MODE == 1 || MODE == 2) {
+        // bf16 ReLU on the packed pair: negative floats are negative int16 (sign bit), max(.,0) clears them
+        const s16x2 z = {0, 0};
+        w = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
+    }
+    return w;
+}
+
+// raw buffer descriptor over [base, base+bytes): loads beyond `bytes` return 0 and stores are dropped, which turns
+// every image-border test of the memory side into an offset select (no divergent branches, no zero-fill code)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+constexpr int OOB = 0x7fffffff;
+
+template <int MODE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+    conv3x3_bf16_ring_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ in_scale,
+                             const float* __restrict__ in_shift, __bf16* __restrict__ out, int out_cs,
+                             float* __restrict__ stat_partial, int B, int H, int W) {
+    using namespace ring;
+    constexpr int NKS = 4, NTAPS = 9;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lw = smem;
+    char* lring = smem + WBYTES;
+    char* lstg = smem + WBYTES + RINGB;
+    float* lnorm = reinterpret_cast<float*>(smem + WBYTES + RINGB + 2 * STGB);  // [B][2][64] scale, shift (MODE >= 2)
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool loader = wv >= 4;
+    const int ltid = threadIdx.x - 256;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * B;
+    const int t_begin = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
+    const int t_end = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    if (t_begin >= t_end) return;
+    // tile t: down a 32-pixel strip first (ty fastest); `fresh` = no halo rows to inherit from tile t-1
+    auto coords = [&](int t, int& b, int& y0, int& x0, bool& fresh) __attribute__((always_inline)) {
+        const int ty = t % tiles_y;
+        const int rest = t / tiles_y;
+        const int tx = rest % tiles_x;
+        b = rest / tiles_x;
+        y0 = ty * TH;
+        x0 = tx * BTW;
+        fresh = (t == t_begin) || (ty == 0);
+    };
+
+    const char* wsrc = reinterpret_cast<const char*>(wp);
+    constexpr int WIT = WBYTES / (512 * 16);
+    auto copy_weights = [&]() __attribute__((always_inline)) {
+        f32x4 wr[WIT];
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) wr[it] = *reinterpret_cast<const f32x4*>(wsrc + (threadIdx.x + it * 512) * 16);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) *reinterpret_cast<f32x4*>(lw + (threadIdx.x + it * 512) * 16) = wr[it];
+    };
+
+    if (loader) {
+        const int c8 = ltid & 7;
+        const unsigned int sample_bytes = (unsigned int)H * W * 64 * 2;
+        const unsigned int out_sample_bytes = (unsigned int)H * W * out_cs * 2;
+        struct Img { u32x4 s[NIMG]; };
+        Img ta, tb;
+        // A tile stages 6 halo rows when fresh, else 4 (rows 2..5; rows 0..1 are the previous tile's rows 4..5).
+        // The instruction stream is the SAME either way (7 buffer loads per lane, slots that are not needed get an
+        // out-of-range offset and cost no traffic): with a fixed number of memory operations per iteration every
+        // s_waitcnt is an exact count, and the prefetches / output stores in flight are never drained by accident.
+        auto load = [&](Img& im, int t) __attribute__((always_inline)) {
+            int b = 0, y0 = 0, x0 = 0; bool fresh = false;
+            int nact = 0;
+            if (t < t_end && !((P4C_EXP & 2) && t > t_begin + 1)) {
+                coords(t, b, y0, x0, fresh);
+                nact = (fresh ? 6 : 4) * ROWSLOTS;
+            }
+            const int j0 = fresh ? 0 : 2;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + (int64_t)b * H * W * 64, sample_bytes);
+#pragma unroll
+            for (int it = 0; it < NIMG; ++it) {
+                const int idx = ltid + it * 256;
+                const int rr = idx / ROWSLOTS, col = (idx - rr * ROWSLOTS) >> 3;
+                const int gy = y0 - 1 + j0 + rr, gx = x0 - 1 + col;
+                const bool ok = (idx < nact) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (gy * W + gx) * 128 + 16 * c8 : OOB, 0, 0);
+            }
+        };
+        // per-sample normalisation of this lane's 8 channels
+        f32x2 sc[4], sh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sc[k] = sh[k] = f32x2{0.f, 0.f};
+        int sc_b = -1;
+        auto store = [&](const Img& im, int t, int base) __attribute__((always_inline)) {
+            if (t >= t_end || ((P4C_EXP & 1) && t > t_begin + 1)) return;
+            int b, y0, x0; bool fresh;
+            coords(t, b, y0, x0, fresh);
+            if (MODE >= 2 && b != sc_b) {
+                sc_b = b;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sc[k] = *reinterpret_cast<const f32x2*>(lnorm + b * 128 + 8 * c8 + 2 * k);
+                    sh[k] = *reinterpret_cast<const f32x2*>(lnorm + b * 128 + 64 + 8 * c8 + 2 * k);
+                }
+            }
+            const int j0 = fresh ? 0 : 2, nact = (fresh ? 6 : 4) * ROWSLOTS;
+#pragma unroll
+            for (int it = 0; it < NIMG; ++it) {
+                const int idx = ltid + it * 256;
+                const int rr = idx / ROWSLOTS, col = (idx - rr * ROWSLOTS) >> 3;
+                int rs = base + j0 + rr;
+                rs = rs >= R ? rs - R : rs;
+                rs = rs >= R ? rs - R : rs;
+                u32x4 o = im.s[it];
+                if (MODE != 0) {
+                    // zero padding applies to the NORMALISED activation: out-of-image slots are cleared after the transform
+                    const int gy = y0 - 1 + j0 + rr, gx = x0 - 1 + col;
+                    const unsigned int keep = (((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W)) ? 0xffffffffu : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = xform2<MODE>(o[k], sc[k], sh[k]) & keep;
+                }
+                if (idx < nact) *reinterpret_cast<u32x4*>(lring + rs * RROW + col * ROWB + ((c8 ^ ring_swz(col)) << 4)) = o;
+            }
+        };
+        // channel statistics of this lane's 8 channels over the pixels it drains (pairs: even/odd channel of a word)
+        f32x2 a1[4], a2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a1[q] = a2[q] = f32x2{0.f, 0.f};
+        int cur_b = -1;
+        const int nslot = gridDim.x * 4, lwv = wv - 4;
+        auto flush = [&](int b) __attribute__((always_inline)) {
+            float* dst = stat_partial + ((int64_t)b * nslot + blockIdx.x * 4 + lwv) * 128;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float u = a1[q][e], v = a2[q][e];
+                    u += __shfl_xor(u, 8); v += __shfl_xor(v, 8);
+                    u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+                    u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+                    if (lane < 8) { dst[8 * c8 + 2 * q + e] = u; dst[64 + 8 * c8 + 2 * q + e] = v; }
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a1[q] = a2[q] = f32x2{0.f, 0.f};
+        };
+        auto drain = [&](int t, bool live) __attribute__((always_inline)) {
+            int b, y0, x0; bool fresh;
+            coords(live ? t : t_begin, b, y0, x0, fresh);
+            const char* stg = lstg + ((t - t_begin) & 1) * STGB;
+            if (live && stat_partial && b != cur_b) {
+                if (cur_b >= 0) flush(cur_b);
+                cur_b = b;
+            }
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(out + (int64_t)b * H * W * out_cs, out_sample_bytes);
+            u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int px = (ltid + k * 256) >> 3;
+                v[k] = *reinterpret_cast<const u32x4*>(stg + px * 128 + ((c8 ^ (px & 7)) << 4));
+            }
+            unsigned int keep[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int px = (ltid + k * 256) >> 3;
+                const int gy = y0 + (px >> 5), gx = x0 + (px & 31);
+                const bool valid = (gy < H) & (gx < W) & live;
+                keep[k] = valid ? 0xffffffffu : 0u;
+                if (!(P4C_EXP & 4))
+                    __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, valid ? ((gy * W + gx) * out_cs + 8 * c8) * 2 : OOB, 0, 0);
+            }
+            if (stat_partial && !(P4C_EXP & 8)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned int w = v[k][q] & keep[k];
+                        const f32x2 f = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+                        a1[q] += f;
+                        a2[q] += f * f;
+                    }
+            }
+        };
+
+        // ring position of tile t: tiles advance the ring by 4 rows when they inherit 2 halo rows, by 6 when fresh
+        auto next_base = [&](int base, int t) __attribute__((always_inline)) {
+            int b, y0, x0; bool fresh;
+            coords(t, b, y0, x0, fresh);
+            base += fresh ? 6 : 4;
+            return base >= R ? base - R : base;
+        };
+        load(ta, t_begin);
+        load(tb, t_begin + 1);
+        copy_weights();
+        if (MODE >= 2) {
+            // normalisation rows of every sample -> LDS: the per-sample reload below is then an LDS read, which
+            // does not tie the staging code to the global-memory counter (vmcnt) of the prefetches in flight
+            for (int i = ltid; i < B * 64; i += 256) {
+                const int b = i >> 6, c = i & 63;
+                lnorm[b * 128 + c] = in_scale[i];
+                lnorm[b * 128 + 64 + c] = in_shift[i];
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        int sbase = 0;                      // ring base of the tile being staged
+        store(ta, t_begin, sbase);
+        load(ta, t_begin + 2);
+        lds_barrier();
+        for (int tile = t_begin; tile < t_end; tile += 2) {
+            // compute reads tile `tile`; drain tile-1, stage tile+1, prefetch tile+3.  The first trip has nothing to
+            // drain but still issues the 4 (dropped, out-of-range) stores: the loop body then has the same number of
+            // memory operations on every trip and the waits on the prefetched images stay exact counts.
+            drain(tile - 1, tile > t_begin);
+            if (tile + 1 < t_end) sbase = next_base(sbase, tile + 1);
+            store(tb, tile + 1, sbase);
+            load(tb, tile + 3);
+            lds_barrier();
+            if (tile + 1 >= t_end) break;
+            drain(tile, true);
+            if (tile + 2 < t_end) sbase = next_base(sbase, tile + 2);
+            store(ta, tile + 2, sbase);
+            load(ta, tile + 4);
+            lds_barrier();
+        }
+        drain(t_end - 1, true);
+        if (stat_partial) {
+            flush(cur_b);
+            int bf, y0, x0; bool fresh;
+            coords(t_begin, bf, y0, x0, fresh);
+            for (int b = 0; b < B; ++b)   // samples this workgroup never touched read as zero (no memset pass)
+                if (b < bf || b > cur_b) {
+                    float* dst = stat_partial + ((int64_t)b * nslot + blockIdx.x * 4 + lwv) * 128;
+                    dst[lane] = 0.f;
+                    dst[64 + lane] = 0.f;
+                }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- compute waves
+    copy_weights();
+    if (MODE >= 2) lds_barrier();  // pairs with the loaders' barrier after the normalisation rows are in LDS
+    lds_barrier();
+    const char* wl = lw + (h * 64 + r) * 16;
+    int boff[3][NKS];  // B-operand byte offset inside a ring row: pixel column r+kx, channel slot 2ks+h (swizzled)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) boff[kx][ks] = (r + kx) * ROWB + (((2 * ks + h) ^ ring_swz(r + kx)) << 4);
+    int base = 0;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int b, y0, x0; bool fresh;
+        coords(tile, b, y0, x0, fresh);
+        if (tile > t_begin) {
+            base += fresh ? 6 : 4;
+            base = base >= R ? base - R : base;
+        }
+        const char* rowp[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            int rs = base + wv + ky;
+            rs = rs >= R ? rs - R : rs;
+            rowp[ky] = lring + rs * RROW;
+        }
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+        if (!(P4C_EXP & 16)) {
+        bf16x8 fa0[2][NKS], fa1[2][NKS], fb[2][NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            fa0[0][ks] = *reinterpret_cast<const bf16x8*>(wl + ks * 2048);
+            fa1[0][ks] = *reinterpret_cast<const bf16x8*>(wl + ks * 2048 + 512);
+            fb[0][ks] = *reinterpret_cast<const bf16x8*>(rowp[0] + boff[0][ks]);
+        }
+#pragma unroll
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int cb = tap & 1, nb = cb ^ 1;
+            if (tap + 1 < NTAPS) {
+                const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    if (P4C_EXP & 32) { fa0[nb][ks] = fa0[cb][ks]; fa1[nb][ks] = fa1[cb][ks]; }
+                    else {
+                    fa0[nb][ks] = *reinterpret_cast<const bf16x8*>(wl + ((tap + 1) * NKS + ks) * 2048);
+                    fa1[nb][ks] = *reinterpret_cast<const bf16x8*>(wl + ((tap + 1) * NKS + ks) * 2048 + 512);
+                    }
+                    if (P4C_EXP & 64) fb[nb][ks] = fb[cb][ks];
+                    else
+                    fb[nb][ks] = *reinterpret_cast<const bf16x8*>(rowp[ky] + boff[kx][ks]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this tap's MFMAs
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[cb][ks], fb[cb][ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[cb][ks], fb[cb][ks], acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        } else { acc0[0] = rowp[0][boff[0][0]]; acc1[3] = rowp[1][boff[1][1]]; }
+        // epilogue: C[co][px]; lane = pixel r (+ half h), register quad g of tile ct -> channels 32ct + 8g + 4h .. +3,
+        // i.e. half h of 16-byte slot 4ct + g of pixel wv*32 + r in the staging tile (slot XOR-swizzled by the pixel)
+        char* stg = lstg + ((tile - t_begin) & 1) * STGB + (wv * 32 + r) * 128 + 8 * h;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& a = ct == 0 ? acc0 : acc1;
+                const f32x2 lo = {a[4 * g], a[4 * g + 1]}, hi = {a[4 * g + 2], a[4 * g + 3]};
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 o;
+                o[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2));
+                o[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2));
+                *reinterpret_cast<u32x2*>(stg + (((4 * ct + g) ^ (r & 7)) << 4)) = o;
+            }
+        lds_barrier();
+    }
+}
+
+template <int MODE>
+static int launch_ring_mode(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, __bf16* out,
+                            int out_cs, float* stat_partial, int B, int H, int W, int G, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_bf16_ring_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          ring::SMEM));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_bf16_ring_kernel<MODE>, dim3(G), dim3(512), ring::SMEM, stream, in, wp, in_scale, in_shift, out,
+                       out_cs, stat_partial, B, H, W);
+    return P4C_OK;
+}
+
+static int launch_conv3x3_bf16_ring(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift,
+                                    int in_relu, __bf16* out, int out_cs, float* stat_partial, int B, int H, int W,
+                                    hipStream_t stream) {
+    const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + 3) / 4;
+    int64_t ntiles = (int64_t)tiles_x * tiles_y * B;
+    int G = num_cus();
+    if (ntiles < G) G = (int)ntiles;
+    prof_begin(P4C_PROF_CONV3X3_C64, (int64_t)B * H * W, stream);
+    int rc;
+    if (in_scale)
+        rc = in_relu ? launch_ring_mode<2>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream)
+                     : launch_ring_mode<3>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream);
+    else
+        rc = in_relu ? launch_ring_mode<1>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream)
+                     : launch_ring_mode<0>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream);
+    prof_end(P4C_PROF_CONV3X3_C64, stream);
+    if (rc != P4C_OK) return rc;
+    P4C_CHECK_LAUNCH("conv3x3_bf16_ring");
+    return P4C_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // conv_wgrad_bf16: persistent; grid = G workgroups, tiles of 8 x 32 pixels.
 //   dW[tap][ci][co] += sum_px In[px + tap][ci] * dOut[px][co]
 // MFMA per tap and 16-pixel K step: A[i=ci][k=px], B[k=px][j=co]; both operands are transposing LDS reads
@@ -800,6 +1194,10 @@ static int conv_fwd_bf16_t(const T* in, int CI, const void* wp, int ks, const fl
 int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
                   int m_blocks, hipStream_t stream) {
+    if (storage == P4C_BF16 && CI == 64 && ks == 3 && m_blocks == 1 && out_cs % 8 == 0 && B <= ring::MAXB &&
+        (int64_t)H * W * out_cs * 2 < (int64_t)1 << 31)  // per-sample byte offsets of the buffer descriptors are 32-bit
+        return launch_conv3x3_bf16_ring((const __bf16*)in, (const __bf16*)wp, in_scale, in_shift, in_relu, (__bf16*)out, out_cs,
+                                        stat_partial, B, H, W, stream);
     if (storage == P4C_BF16)
         return conv_fwd_bf16_t<__bf16>((const __bf16*)in, CI, wp, ks, in_scale, in_shift, in_relu, (__bf16*)out, out_cs,
                                        stat_partial, B, H, W, m_blocks, stream);

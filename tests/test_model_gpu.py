@@ -374,8 +374,16 @@ def test_conv_bf16_storage(gpu_device, CI, CIreal, ks, H, W):
                                  compute="bf16")
         assert out.dtype == torch.bfloat16
         assert rel_err(out.float(), ref) < 8e-3
-        s = stats.sum(0).cpu().double()  # statistics come from the fp32 accumulators
-        np.testing.assert_allclose(s[0].numpy(), ref.sum((0, 1, 2)).numpy(), rtol=2e-3, atol=5e-2)
+        s = stats.sum(0).cpu().double()
+        # statistics describe what a consumer will normalise: either the fp32 accumulators (generic kernels) or the
+        # bf16-rounded outputs actually stored (3x3 64->64 ring kernel); both are within rounding noise of the reference
+        o64 = out.cpu().double()
+        own1, own2 = o64.sum((0, 1, 2)).numpy(), (o64 * o64).sum((0, 1, 2)).numpy()
+        ref1 = ref.sum((0, 1, 2)).numpy()
+        noise = 4 * float(ref.abs().max()) * 2.0**-9 * (B * H * W) ** 0.5
+        assert (np.abs(s[0].numpy() - own1) < 1e-3 * np.abs(own1).max() + 1e-3).all() or np.allclose(s[0].numpy(), ref1, rtol=2e-3, atol=5e-2)
+        np.testing.assert_allclose(s[0].numpy(), ref1, rtol=2e-3, atol=noise)
+        np.testing.assert_allclose(s[1].numpy(), own2, rtol=1e-2)
         grad = torch.zeros(CO, CIreal, ks, ks, device=gpu_device)
         om.conv_wgrad(x.to(gpu_device), dout.to(gpu_device), ks, CO, CIreal, grad, scale.to(gpu_device) if transform else None,
                       shift.to(gpu_device) if transform else None, transform, compute="bf16")
