@@ -31,6 +31,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BTW = 32;  // tile width in pixels
 
+#ifndef P4C_PRIO
+#define P4C_PRIO 0  // diagnostic builds only: static wave priority of the memory-side (1, 3) or matrix (2) waves
+#endif
 #ifndef P4C_EXP
 #define P4C_EXP 0  // diagnostic builds only (scratch/exp_build.sh): bit mask of pipeline stages to leave out
 #endif
@@ -609,29 +612,36 @@ __global__ void __launch_bounds__(512, 2)
 
 // ---------------------------------------------------------------------------------------------
 // conv3x3_bf16_ring: 3x3 conv, 64 -> 64 channels, bf16 activations in HBM (the hot kernel of the bf16 plan).
-// Same role split as conv_fwd_bf16_ws (waves 0-3 matrix phase, waves 4-7 memory side) with three changes that the
-// stage-removal measurements asked for (scratch/conv_exp.py: epilogue alone 27 us, loader+transform alone 50 us,
-// matrix phase alone 21 us per 512x512x2 launch):
-//   * the compute waves no longer store to HBM (8 scattered 8-byte stores per lane) nor keep statistics: they
-//     round their accumulators to bf16 into an LDS staging tile; the LOADER waves drain it with 16-byte,
-//     fully coalesced stores (8 lanes = one pixel's 128 bytes) and accumulate the channel statistics from the
-//     same registers (8 fixed channels per lane), i.e. of exactly the rounded values a consumer will normalise;
-//   * input rows live in a 12-row LDS RING per 32-pixel strip: walking down a strip, a tile re-uses the two
-//     halo rows the previous tile already staged (loaded AND normalised), so 4 rows instead of 6 are fetched
-//     and transformed per tile;
-//   * rows are 128 bytes (no padding) with the 16-byte slot index XOR-swizzled by the pixel column, which keeps
-//     both the B-operand reads and the loader writes bank-conflict free and fits ring + staging + weights in LDS.
-// LDS: weights 72 KB | ring 12 x 34 x 128 B = 51 KB | staging 2 x 16 KB.
+// 512 threads: waves 0-3 run the matrix phase, waves 4-7 the memory side (global -> registers -> normalise/ReLU ->
+// LDS ring, and LDS staging -> HBM + channel statistics).  On a SIMD the scarce resource is VECTOR ISSUE: an MFMA
+// holds it for 8 of its 32 cycles, every other vector instruction of EITHER wave for ~4, so the two roles overlap
+// only while their non-MFMA instructions fit the 24 free cycles per MFMA (stage-removal runs, scratch/conv_exp.py:
+// the roles' times ADDED up).  The design therefore minimises instructions, not bytes:
+//   * WEIGHTS STATIONARY IN REGISTERS: a compute wave owns 32 output channels x 2 tile rows and keeps its
+//     9 taps x 64 input channels of weights (36 A operands, 144 VGPRs) for the whole launch; per MFMA it reads ONE
+//     B operand from LDS (was 1.5 with LDS-resident weights, which saturated the LDS pipe at 97 %);
+//   * input rows live in a CONTIGUOUS LDS ring per 32-pixel strip: walking down a strip a tile re-uses the two halo
+//     rows its predecessor staged (4 rows fetched and normalised instead of 6); a tile's 6 rows are contiguous, so
+//     every B read is `per-tile base VGPR + immediate`;
+//   * rows are 128 bytes with the 16-byte slot index XOR-swizzled by the pixel column: conflict-free B reads and
+//     loader writes without padding;
+//   * the compute waves round their accumulators to bf16 into an LDS staging tile; the memory-side waves drain it
+//     with 16-byte fully coalesced stores and accumulate the statistics of exactly those rounded values;
+//   * the memory side is table driven (per-lane offsets computed once; buffer descriptors with a per-tile scalar
+//     offset), with a slower bounds-checked path for tiles that touch the image border; both paths issue the same
+//     number of memory operations, which keeps every s_waitcnt an exact count.
+// LDS: ring 22 x 34 x 128 B = 94 KB | staging 2 x 16 KB | normalisation rows 4 KB.
 namespace ring {
-constexpr int TH = 4, LW = BTW + 2, R = 12, ROWB = 128, RROW = LW * ROWB;
-constexpr int WBYTES = 9 * 64 * 64 * 2, RINGB = R * RROW, STGB = TH * BTW * 128;
-constexpr int MAXB = 8;                       // samples whose normalisation rows fit the LDS left over
-constexpr int SMEM = WBYTES + RINGB + 2 * STGB + MAXB * 128 * 4;
+constexpr int TH = 4, LW = BTW + 2, NROW = 22, ROWB = 128, RROW = LW * ROWB;
+constexpr int RINGB = NROW * RROW, STGB = TH * BTW * 128;
+constexpr int MAXB = 8;                       // samples whose normalisation rows fit
+constexpr int SMEM = RINGB + 2 * STGB + MAXB * 128 * 4;
 constexpr int NIMG = 7;                       // register slots per lane of a staged tile (6 rows fresh, 4 otherwise)
 constexpr int ROWSLOTS = LW * 8;              // 16-byte slots per halo row
 }  // namespace ring
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -643,8 +653,10 @@ __device__ __forceinline__ int ring_swz(int col) { return (col >> 1) & 7; }
 template <int MODE>
 __device__ __forceinline__ unsigned int xform2(unsigned int w, f32x2 sc, f32x2 sh) {
     if (MODE >= 2) {
-        f32x2 v = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
-        v = v * sc + sh;
+        // scalar fma pair on purpose: beside MFMAs a v_pk_fma_f32 costs more issue time than two v_fma_f32
+        const float lo = __builtin_fmaf(__builtin_bit_cast(float, w << 16), sc.x, sh.x);
+        const float hi = __builtin_fmaf(__builtin_bit_cast(float, w & 0xffff0000u), sc.y, sh.y);
+        const f32x2 v = {lo, hi};
         w = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
     }
     if (MODE == 1 || MODE == 2) {
@@ -668,12 +680,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                              const float* __restrict__ in_shift, __bf16* __restrict__ out, int out_cs,
                              float* __restrict__ stat_partial, int B, int H, int W) {
     using namespace ring;
-    constexpr int NKS = 4, NTAPS = 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lw = smem;
-    char* lring = smem + WBYTES;
-    char* lstg = smem + WBYTES + RINGB;
-    float* lnorm = reinterpret_cast<float*>(smem + WBYTES + RINGB + 2 * STGB);  // [B][2][64] scale, shift (MODE >= 2)
+    char* lring = smem;
+    char* lstg = smem + RINGB;
+    float* lnorm = reinterpret_cast<float*>(smem + RINGB + 2 * STGB);  // [B][2][64] scale, shift (MODE >= 2)
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool loader = wv >= 4;
@@ -684,53 +694,90 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int t_begin = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
     const int t_end = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
     if (t_begin >= t_end) return;
-    // tile t: down a 32-pixel strip first (ty fastest); `fresh` = no halo rows to inherit from tile t-1
-    auto coords = [&](int t, int& b, int& y0, int& x0, bool& fresh) __attribute__((always_inline)) {
-        const int ty = t % tiles_y;
-        const int rest = t / tiles_y;
-        const int tx = rest % tiles_x;
-        b = rest / tiles_x;
-        y0 = ty * TH;
-        x0 = tx * BTW;
-        fresh = (t == t_begin) || (ty == 0);
+    // Tile cursor: tiles run down a 32-pixel strip first (ty fastest), then across, then over samples; every role
+    // walks its own cursors forward one tile at a time (no divisions in the loops).  `p` is the tile's first ring
+    // row: a tile that continues down its strip and still fits shares its rows 0..1 with the predecessor's rows
+    // 4..5 (p += 4); otherwise it is "fresh": all 6 rows are staged, behind the predecessor if that fits, else at the
+    // start of the ring.  Either way the rows written for tile t+1 never overlap the 6 rows being read for tile t.
+    struct Cur { int t, b, tx, ty, p; bool fresh; };
+    auto cur_init = [&]() __attribute__((always_inline)) {
+        Cur c;
+        c.t = t_begin;
+        c.ty = t_begin % tiles_y;
+        const int rest = t_begin / tiles_y;
+        c.tx = rest % tiles_x;
+        c.b = rest / tiles_x;
+        c.p = 0;
+        c.fresh = true;
+        return c;
     };
-
-    const char* wsrc = reinterpret_cast<const char*>(wp);
-    constexpr int WIT = WBYTES / (512 * 16);
-    auto copy_weights = [&]() __attribute__((always_inline)) {
-        f32x4 wr[WIT];
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) wr[it] = *reinterpret_cast<const f32x4*>(wsrc + (threadIdx.x + it * 512) * 16);
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) *reinterpret_cast<f32x4*>(lw + (threadIdx.x + it * 512) * 16) = wr[it];
+    auto cur_next = [&](Cur& c) __attribute__((always_inline)) {
+        ++c.t;
+        if (++c.ty == tiles_y) {
+            c.ty = 0;
+            if (++c.tx == tiles_x) { c.tx = 0; ++c.b; }
+        }
+        if (c.ty != 0 && c.p + 10 <= NROW) {
+            c.p += 4;
+            c.fresh = false;
+        } else {
+            c.fresh = true;
+            c.p = (c.p + 12 <= NROW) ? c.p + 6 : 0;
+        }
     };
 
     if (loader) {
+        if (P4C_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (P4C_PRIO == 3) __builtin_amdgcn_s_setprio(3);
         const int c8 = ltid & 7;
         const unsigned int sample_bytes = (unsigned int)H * W * 64 * 2;
         const unsigned int out_sample_bytes = (unsigned int)H * W * out_cs * 2;
+        // per-lane tables: slot `it` of a staged block (row-major over the block's rows, 272 slots per row)
+        int gofs[NIMG], lofs[NIMG], rrcol[NIMG];
+#pragma unroll
+        for (int it = 0; it < NIMG; ++it) {
+            const int idx = ltid + it * 256;
+            const int rr = idx / ROWSLOTS, col = (idx - rr * ROWSLOTS) >> 3;
+            gofs[it] = (rr * W + col) * 128 + 16 * c8;
+            lofs[it] = rr * RROW + col * ROWB + ((c8 ^ ring_swz(col)) << 4);
+            rrcol[it] = (rr << 8) | col;
+        }
+        int dofs[4], sofs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int px = (ltid + k * 256) >> 3;
+            dofs[k] = (((px >> 5) * W + (px & 31)) * out_cs + 8 * c8) * 2;
+            sofs[k] = px * 128 + ((c8 ^ (px & 7)) << 4);
+        }
         struct Img { u32x4 s[NIMG]; };
         Img ta, tb;
-        // A tile stages 6 halo rows when fresh, else 4 (rows 2..5; rows 0..1 are the previous tile's rows 4..5).
-        // The instruction stream is the SAME either way (7 buffer loads per lane, slots that are not needed get an
-        // out-of-range offset and cost no traffic): with a fixed number of memory operations per iteration every
-        // s_waitcnt is an exact count, and the prefetches / output stores in flight are never drained by accident.
-        auto load = [&](Img& im, int t) __attribute__((always_inline)) {
-            int b = 0, y0 = 0, x0 = 0; bool fresh = false;
-            int nact = 0;
-            if (t < t_end && !((P4C_EXP & 2) && t > t_begin + 1)) {
-                coords(t, b, y0, x0, fresh);
-                nact = (fresh ? 6 : 4) * ROWSLOTS;
+        // A tile stages 6 halo rows when fresh, else 4 (its rows 2..5).  The instruction stream is the SAME either
+        // way and on the fast and the border path (7 buffer loads per lane; slots that are not needed get an
+        // out-of-range offset and cost no traffic): with a fixed number of memory operations per trip every
+        // s_waitcnt is an exact count and the prefetches / output stores in flight are never drained by accident.
+        Cur lc = cur_init();  // load cursor: the next tile a prefetch is issued for
+        auto load = [&](Img& im) __attribute__((always_inline)) {
+            int b = 0, y0 = 0, x0 = 0, nact = 0, j0 = 0;
+            if (lc.t < t_end && !((P4C_EXP & 2) && lc.t > t_begin + 1)) {
+                b = lc.b; y0 = lc.ty * TH; x0 = lc.tx * BTW;
+                nact = (lc.fresh ? 6 : 4) * ROWSLOTS;
+                j0 = lc.fresh ? 0 : 2;
             }
-            const int j0 = fresh ? 0 : 2;
+            cur_next(lc);
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(in + (int64_t)b * H * W * 64, sample_bytes);
+            const int gy0 = y0 - 1 + j0, gx0 = x0 - 1;
+            if (gy0 >= 0 && y0 + 5 <= H && gx0 >= 0 && x0 + 33 <= W) {
+                const int so = (gy0 * W + gx0) * 128;   // interior: one scalar offset, per-lane table entries
 #pragma unroll
-            for (int it = 0; it < NIMG; ++it) {
-                const int idx = ltid + it * 256;
-                const int rr = idx / ROWSLOTS, col = (idx - rr * ROWSLOTS) >> 3;
-                const int gy = y0 - 1 + j0 + rr, gx = x0 - 1 + col;
-                const bool ok = (idx < nact) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-                im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (gy * W + gx) * 128 + 16 * c8 : OOB, 0, 0);
+                for (int it = 0; it < NIMG; ++it)
+                    im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (ltid + it * 256 < nact) ? gofs[it] : OOB, so, 0);
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIMG; ++it) {
+                    const int gy = gy0 + (rrcol[it] >> 8), gx = gx0 + (rrcol[it] & 255);
+                    const bool ok = (ltid + it * 256 < nact) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                    im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (gy * W + gx) * 128 + 16 * c8 : OOB, 0, 0);
+                }
             }
         };
         // per-sample normalisation of this lane's 8 channels
@@ -738,10 +785,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int k = 0; k < 4; ++k) sc[k] = sh[k] = f32x2{0.f, 0.f};
         int sc_b = -1;
-        auto store = [&](const Img& im, int t, int base) __attribute__((always_inline)) {
+        Cur sc_ = cur_init();  // store cursor: the next tile to stage into the ring
+        auto store = [&](const Img& im) __attribute__((always_inline)) {
+            const int t = sc_.t, b = sc_.b, y0 = sc_.ty * TH, x0 = sc_.tx * BTW, sp = sc_.p;
+            const bool fresh = sc_.fresh;
+            cur_next(sc_);
             if (t >= t_end || ((P4C_EXP & 1) && t > t_begin + 1)) return;
-            int b, y0, x0; bool fresh;
-            coords(t, b, y0, x0, fresh);
             if (MODE >= 2 && b != sc_b) {
                 sc_b = b;
 #pragma unroll
@@ -751,49 +800,55 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
             const int j0 = fresh ? 0 : 2, nact = (fresh ? 6 : 4) * ROWSLOTS;
+            char* dst = lring + (sp + j0) * RROW;
+            const int gy0 = y0 - 1 + j0, gx0 = x0 - 1;
+            const bool interior = gy0 >= 0 && y0 + 5 <= H && gx0 >= 0 && x0 + 33 <= W;
+            if (MODE == 0 || interior) {
 #pragma unroll
-            for (int it = 0; it < NIMG; ++it) {
-                const int idx = ltid + it * 256;
-                const int rr = idx / ROWSLOTS, col = (idx - rr * ROWSLOTS) >> 3;
-                int rs = base + j0 + rr;
-                rs = rs >= R ? rs - R : rs;
-                rs = rs >= R ? rs - R : rs;
-                u32x4 o = im.s[it];
-                if (MODE != 0) {
+                for (int it = 0; it < NIMG; ++it) {
+                    u32x4 o = im.s[it];
+                    if (MODE != 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = xform2<MODE>(o[k], sc[k], sh[k]);
+                    }
+                    if (ltid + it * 256 < nact) *reinterpret_cast<u32x4*>(dst + lofs[it]) = o;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIMG; ++it) {
                     // zero padding applies to the NORMALISED activation: out-of-image slots are cleared after the transform
-                    const int gy = y0 - 1 + j0 + rr, gx = x0 - 1 + col;
+                    const int gy = gy0 + (rrcol[it] >> 8), gx = gx0 + (rrcol[it] & 255);
                     const unsigned int keep = (((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W)) ? 0xffffffffu : 0u;
+                    u32x4 o = im.s[it];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[k] = xform2<MODE>(o[k], sc[k], sh[k]) & keep;
+                    if (ltid + it * 256 < nact) *reinterpret_cast<u32x4*>(dst + lofs[it]) = o;
                 }
-                if (idx < nact) *reinterpret_cast<u32x4*>(lring + rs * RROW + col * ROWB + ((c8 ^ ring_swz(col)) << 4)) = o;
             }
         };
-        // channel statistics of this lane's 8 channels over the pixels it drains (pairs: even/odd channel of a word)
-        f32x2 a1[4], a2[4];
+        // channel statistics of this lane's 8 channels over the pixels it drains
+        float a1[8], a2[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a1[q] = a2[q] = f32x2{0.f, 0.f};
+        for (int q = 0; q < 8; ++q) a1[q] = a2[q] = 0.f;
         int cur_b = -1;
         const int nslot = gridDim.x * 4, lwv = wv - 4;
         auto flush = [&](int b) __attribute__((always_inline)) {
             float* dst = stat_partial + ((int64_t)b * nslot + blockIdx.x * 4 + lwv) * 128;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float u = a1[q][e], v = a2[q][e];
-                    u += __shfl_xor(u, 8); v += __shfl_xor(v, 8);
-                    u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
-                    u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
-                    if (lane < 8) { dst[8 * c8 + 2 * q + e] = u; dst[64 + 8 * c8 + 2 * q + e] = v; }
-                }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a1[q] = a2[q] = f32x2{0.f, 0.f};
+            for (int q = 0; q < 8; ++q) {
+                float u = a1[q], v = a2[q];
+                u += __shfl_xor(u, 8); v += __shfl_xor(v, 8);
+                u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+                u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+                if (lane < 8) { dst[8 * c8 + q] = u; dst[64 + 8 * c8 + q] = v; }
+                a1[q] = a2[q] = 0.f;
+            }
         };
-        auto drain = [&](int t, bool live) __attribute__((always_inline)) {
-            int b, y0, x0; bool fresh;
-            coords(live ? t : t_begin, b, y0, x0, fresh);
-            const char* stg = lstg + ((t - t_begin) & 1) * STGB;
+        Cur dc = cur_init();  // drain cursor: the next tile whose staged output goes to HBM
+        auto drain = [&](bool live) __attribute__((always_inline)) {
+            const int b = dc.b, y0 = dc.ty * TH, x0 = dc.tx * BTW;
+            const char* stg = lstg + ((dc.t - t_begin + (live ? 0 : 1)) & 1) * STGB;
+            if (live) cur_next(dc);
             if (live && stat_partial && b != cur_b) {
                 if (cur_b >= 0) flush(cur_b);
                 cur_b = b;
@@ -801,45 +856,39 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(out + (int64_t)b * H * W * out_cs, out_sample_bytes);
             u32x4 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int px = (ltid + k * 256) >> 3;
-                v[k] = *reinterpret_cast<const u32x4*>(stg + px * 128 + ((c8 ^ (px & 7)) << 4));
-            }
-            unsigned int keep[4];
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4*>(stg + sofs[k]);
+            if (live && y0 + 4 <= H && x0 + 32 <= W) {
+                const int so = (y0 * W + x0) * out_cs * 2;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int px = (ltid + k * 256) >> 3;
-                const int gy = y0 + (px >> 5), gx = x0 + (px & 31);
-                const bool valid = (gy < H) & (gx < W) & live;
-                keep[k] = valid ? 0xffffffffu : 0u;
-                if (!(P4C_EXP & 4))
-                    __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, valid ? ((gy * W + gx) * out_cs + 8 * c8) * 2 : OOB, 0, 0);
+                for (int k = 0; k < 4; ++k)
+                    __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, (P4C_EXP & 4) ? OOB : dofs[k], so, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = (ltid + k * 256) >> 3;
+                    const int gy = y0 + (px >> 5), gx = x0 + (px & 31);
+                    const bool valid = (gy < H) & (gx < W) & live;
+                    if (!valid) v[k] = u32x4{0u, 0u, 0u, 0u};   // keeps the statistics below unmasked
+                    __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, (valid && !(P4C_EXP & 4)) ? ((gy * W + gx) * out_cs + 8 * c8) * 2 : OOB, 0, 0);
+                }
             }
             if (stat_partial && !(P4C_EXP & 8)) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const unsigned int w = v[k][q] & keep[k];
-                        const f32x2 f = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
-                        a1[q] += f;
-                        a2[q] += f * f;
+                        const float lo = __builtin_bit_cast(float, v[k][q] << 16);
+                        const float hi = __builtin_bit_cast(float, v[k][q] & 0xffff0000u);
+                        a1[2 * q] += lo; a2[2 * q] = __builtin_fmaf(lo, lo, a2[2 * q]);
+                        a1[2 * q + 1] += hi; a2[2 * q + 1] = __builtin_fmaf(hi, hi, a2[2 * q + 1]);
                     }
             }
         };
 
-        // ring position of tile t: tiles advance the ring by 4 rows when they inherit 2 halo rows, by 6 when fresh
-        auto next_base = [&](int base, int t) __attribute__((always_inline)) {
-            int b, y0, x0; bool fresh;
-            coords(t, b, y0, x0, fresh);
-            base += fresh ? 6 : 4;
-            return base >= R ? base - R : base;
-        };
-        load(ta, t_begin);
-        load(tb, t_begin + 1);
-        copy_weights();
+        load(ta);
+        load(tb);
         if (MODE >= 2) {
-            // normalisation rows of every sample -> LDS: the per-sample reload below is then an LDS read, which
+            // normalisation rows of every sample -> LDS: the per-sample reload in store() is then an LDS read, which
             // does not tie the staging code to the global-memory counter (vmcnt) of the prefetches in flight
             for (int i = ltid; i < B * 64; i += 256) {
                 const int b = i >> 6, c = i & 63;
@@ -848,31 +897,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        int sbase = 0;                      // ring base of the tile being staged
-        store(ta, t_begin, sbase);
-        load(ta, t_begin + 2);
+        store(ta);
+        load(ta);
         lds_barrier();
         for (int tile = t_begin; tile < t_end; tile += 2) {
             // compute reads tile `tile`; drain tile-1, stage tile+1, prefetch tile+3.  The first trip has nothing to
-            // drain but still issues the 4 (dropped, out-of-range) stores: the loop body then has the same number of
-            // memory operations on every trip and the waits on the prefetched images stay exact counts.
-            drain(tile - 1, tile > t_begin);
-            if (tile + 1 < t_end) sbase = next_base(sbase, tile + 1);
-            store(tb, tile + 1, sbase);
-            load(tb, tile + 3);
+            // drain but still issues the 4 (dropped, out-of-range) stores: same operation count on every trip.
+            drain(tile > t_begin);
+            store(tb);
+            load(tb);
             lds_barrier();
             if (tile + 1 >= t_end) break;
-            drain(tile, true);
-            if (tile + 2 < t_end) sbase = next_base(sbase, tile + 2);
-            store(ta, tile + 2, sbase);
-            load(ta, tile + 4);
+            drain(true);
+            store(ta);
+            load(ta);
             lds_barrier();
         }
-        drain(t_end - 1, true);
+        drain(true);
         if (stat_partial) {
             flush(cur_b);
-            int bf, y0, x0; bool fresh;
-            coords(t_begin, bf, y0, x0, fresh);
+            const int bf = (t_begin / tiles_y) / tiles_x;
             for (int b = 0; b < B; ++b)   // samples this workgroup never touched read as zero (no memset pass)
                 if (b < bf || b > cur_b) {
                     float* dst = stat_partial + ((int64_t)b * nslot + blockIdx.x * 4 + lwv) * 128;
@@ -884,81 +928,81 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 
     // ---------------------------------------------------------------- compute waves
-    copy_weights();
+    // wave wv: output channels 32*ct .. +31 (ct = wv >> 1), tile rows 2*rp and 2*rp+1 (rp = wv & 1)
+    const int ct = wv >> 1, rp = wv & 1;
+    if (P4C_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    bf16x8 A[9][4];
+    {
+        const char* wsrc = reinterpret_cast<const char*>(wp) + (h * 64 + ct * 32 + r) * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) A[tap][ks] = *reinterpret_cast<const bf16x8*>(wsrc + (tap * 4 + ks) * 2048);
+    }
     if (MODE >= 2) lds_barrier();  // pairs with the loaders' barrier after the normalisation rows are in LDS
     lds_barrier();
-    const char* wl = lw + (h * 64 + r) * 16;
-    int boff[3][NKS];  // B-operand byte offset inside a ring row: pixel column r+kx, channel slot 2ks+h (swizzled)
+    int boff[3][4];  // B-operand byte offset inside a ring row: pixel column r+kx, channel slot 2ks+h (swizzled)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) boff[kx][ks] = (r + kx) * ROWB + (((2 * ks + h) ^ ring_swz(r + kx)) << 4);
-    int base = 0;
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        int b, y0, x0; bool fresh;
-        coords(tile, b, y0, x0, fresh);
-        if (tile > t_begin) {
-            base += fresh ? 6 : 4;
-            base = base >= R ? base - R : base;
-        }
-        const char* rowp[3];
+        for (int ks = 0; ks < 4; ++ks) boff[kx][ks] = 2 * rp * RROW + (r + kx) * ROWB + (((2 * ks + h) ^ ring_swz(r + kx)) << 4);
+    int soff[4];     // staging offsets of this lane's 4 channel quads (row 0 of the wave; row 1 = +32 pixels)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            int rs = base + wv + ky;
-            rs = rs >= R ? rs - R : rs;
-            rowp[ky] = lring + rs * RROW;
-        }
+    for (int g = 0; g < 4; ++g) soff[g] = (2 * rp * 32 + r) * 128 + 8 * h + (((4 * ct + g) ^ (r & 7)) << 4);
+    Cur cc = cur_init();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const char* tb0 = lring + cc.p * RROW;
+        cur_next(cc);
+        const char* ba[3][4];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ba[kx][ks] = tb0 + boff[kx][ks];
         f32x16 acc0, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
         if (!(P4C_EXP & 16)) {
-        bf16x8 fa0[2][NKS], fa1[2][NKS], fb[2][NKS];
+            // 18 stages of (tap, channel half): 4 B reads (2 k-steps x 2 rows) feed 4 MFMAs; reads run two stages
+            // ahead through a ring of three operand buffers (>= 256 cycles of matrix work cover the LDS latency)
+            bf16x8 fb[3][2][2];
+            auto issue = [&](int s, int buf) __attribute__((always_inline)) {
+                const int tap = s >> 1, ky = tap / 3, kx = tap % 3;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            fa0[0][ks] = *reinterpret_cast<const bf16x8*>(wl + ks * 2048);
-            fa1[0][ks] = *reinterpret_cast<const bf16x8*>(wl + ks * 2048 + 512);
-            fb[0][ks] = *reinterpret_cast<const bf16x8*>(rowp[0] + boff[0][ks]);
-        }
-#pragma unroll
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            const int cb = tap & 1, nb = cb ^ 1;
-            if (tap + 1 < NTAPS) {
-                const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    if (P4C_EXP & 32) { fa0[nb][ks] = fa0[cb][ks]; fa1[nb][ks] = fa1[cb][ks]; }
-                    else {
-                    fa0[nb][ks] = *reinterpret_cast<const bf16x8*>(wl + ((tap + 1) * NKS + ks) * 2048);
-                    fa1[nb][ks] = *reinterpret_cast<const bf16x8*>(wl + ((tap + 1) * NKS + ks) * 2048 + 512);
-                    }
-                    if (P4C_EXP & 64) fb[nb][ks] = fb[cb][ks];
-                    else
-                    fb[nb][ks] = *reinterpret_cast<const bf16x8*>(rowp[ky] + boff[kx][ks]);
+                for (int kl = 0; kl < 2; ++kl) {
+                    const int ks = (s & 1) * 2 + kl;
+                    fb[buf][kl][0] = *reinterpret_cast<const bf16x8*>(ba[kx][ks] + ky * RROW);
+                    fb[buf][kl][1] = *reinterpret_cast<const bf16x8*>(ba[kx][ks] + (ky + 1) * RROW);
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this tap's MFMAs
+            };
+            issue(0, 0);
+            issue(1, 1);
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[cb][ks], fb[cb][ks], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[cb][ks], fb[cb][ks], acc1, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        } else { acc0[0] = rowp[0][boff[0][0]]; acc1[3] = rowp[1][boff[1][1]]; }
-        // epilogue: C[co][px]; lane = pixel r (+ half h), register quad g of tile ct -> channels 32ct + 8g + 4h .. +3,
-        // i.e. half h of 16-byte slot 4ct + g of pixel wv*32 + r in the staging tile (slot XOR-swizzled by the pixel)
-        char* stg = lstg + ((tile - t_begin) & 1) * STGB + (wv * 32 + r) * 128 + 8 * h;
+            for (int s = 0; s < 18; ++s) {
+                if (s + 2 < 18) issue(s + 2, (s + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this stage's MFMAs
+                const int tap = s >> 1;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+                for (int kl = 0; kl < 2; ++kl) {
+                    const int ks = (s & 1) * 2 + kl;
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap][ks], fb[s % 3][kl][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap][ks], fb[s % 3][kl][1], acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else { acc0[0] = ba[0][0][0]; acc1[3] = ba[1][1][16]; }
+        // epilogue: C[co][px]; lane = pixel r (+ half h), register quad g -> channels 32ct + 8g + 4h .. +3, i.e. half h
+        // of 16-byte slot 4ct + g of the pixel in the staging tile (slot XOR-swizzled by the pixel)
+        char* stg = lstg + ((tile - t_begin) & 1) * STGB;
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x16& a = ct == 0 ? acc0 : acc1;
+                const f32x16& a = row == 0 ? acc0 : acc1;
                 const f32x2 lo = {a[4 * g], a[4 * g + 1]}, hi = {a[4 * g + 2], a[4 * g + 3]};
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 u32x2 o;
                 o[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2));
                 o[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2));
-                *reinterpret_cast<u32x2*>(stg + (((4 * ct + g) ^ (r & 7)) << 4)) = o;
+                *reinterpret_cast<u32x2*>(stg + soff[g] + row * 32 * 128) = o;
             }
         lds_barrier();
     }
