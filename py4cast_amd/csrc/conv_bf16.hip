@@ -48,7 +48,12 @@ __device__ __forceinline__ void stamp(int slot) {
     }
 }
 #define P4C_STAMP(slot) stamp(slot)
+__device__ __forceinline__ void stamp_rt(int slot) {   // constant 100 MHz counter: in-kernel clock = d(memtime)/d(realtime)*100 MHz
+    if (g_stamps && blockIdx.x == 7 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_stamps[slot] = __builtin_amdgcn_s_memrealtime();
+}
+#define P4C_STAMP_RT(slot) stamp_rt(slot)
 #else
+#define P4C_STAMP_RT(slot)
 #define P4C_STAMP(slot)
 #endif
 
@@ -1088,8 +1093,6 @@ __global__ void __launch_bounds__(256, 1)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    BTile<T, CI, LH, LW> tr;
-    BTile<T, 64, TH, BTW> td;
     auto coords = [&](int t, int& b, int& y0, int& x0) {
         const int ty = t % tiles_y;
         const int rest = t / tiles_y;
@@ -1099,47 +1102,177 @@ __global__ void __launch_bounds__(256, 1)
     };
     const int t_begin = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
     const int t_end = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
-    int tile = t_begin;
-    if (tile < t_end) {
-        int b, y0, x0;
-        coords(tile, b, y0, x0);
-        btile_load<T, CI, LH, LW, HALO>(tr, inb, b, y0, x0, H, W, in_cs);
-        btile_load<T, 64, TH, BTW, 0>(td, dout, b, y0, x0, H, W, 64);
-    }
-    for (; tile < t_end; ++tile) {
-        int b, y0, x0;
-        coords(tile, b, y0, x0);
-        __syncthreads();
-        btile_store<T, CI, LH, LW, HALO, ROWA>(tr, scb, shb, in_relu, lin, b, y0, x0, H, W, in_cs);
-        btile_store<T, 64, TH, BTW, 0, ROWD>(td, nullptr, nullptr, 0, ldo, b, y0, x0, H, W, 64);
-        __syncthreads();
-        if (tile + 1 < t_end) {
-            int nb, ny, nx;
-            coords(tile + 1, nb, ny, nx);
-            btile_load<T, CI, LH, LW, HALO>(tr, inb, nb, ny, nx, H, W, in_cs);
-            btile_load<T, 64, TH, BTW, 0>(td, dout, nb, ny, nx, H, W, 64);
+
+    // ---- staging of the two tiles (input with halo, output gradient): global -> registers -> (normalise) -> LDS.
+    // bf16 storage: table driven.  Each lane's slots are the same for every tile, so their global / LDS offsets are
+    // computed once; per tile an interior tile needs one scalar offset per tensor and no bounds tests (buffer
+    // descriptors return 0 beyond the sample, border tiles take a bounds-checked path with the same number of loads).
+    constexpr bool TAB = std::is_same<T, __bf16>::value;
+    constexpr int C8 = CI / 8;
+    constexpr int TOT_IN = LH * LW * C8, NI = (TOT_IN + 255) / 256, ND = TH * BTW * 8 / 256;
+    BTile<T, TAB ? 8 : CI, TAB ? 1 : LH, TAB ? 1 : LW> tr;   // generic (fp32 storage) path only
+    BTile<T, TAB ? 8 : 64, TAB ? 1 : TH, TAB ? 1 : BTW> td;
+    u32x4 ri[TAB ? NI : 1], rd[TAB ? ND : 1];
+    int gi[TAB ? NI : 1], li[TAB ? NI : 1], pi[TAB ? NI : 1], gd[TAB ? ND : 1], ld[TAB ? ND : 1];
+    const int c8i = threadIdx.x % C8, c8d = threadIdx.x & 7;
+    if (TAB) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int idx = threadIdx.x + it * 256, pix = idx / C8;
+            const int ly = pix / LW, lx = pix - ly * LW;
+            gi[it] = ((ly * W + lx) * in_cs + 8 * c8i) * 2;
+            li[it] = pix * ROWA + 16 * c8i;
+            pi[it] = (ly << 8) | lx;
         }
-#pragma unroll 1
-        for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+        for (int it = 0; it < ND; ++it) {
+            const int pix = (threadIdx.x + it * 256) >> 3;
+            gd[it] = (((pix >> 5) * W + (pix & 31)) * 64 + 8 * c8d) * 2;
+            ld[it] = pix * ROWD + 16 * c8d;
+        }
+    }
+    f32x2 nsc[4], nsh[4];   // normalisation of this lane's 8 channels for the tile in flight (fetched with the tile)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nsc[k] = nsh[k] = f32x2{0.f, 0.f};
+    auto stage_load = [&](int t) __attribute__((always_inline)) {
+        int b, y0, x0;
+        coords(t, b, y0, x0);
+        if constexpr (TAB) {
+            if (scb) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    nsc[k] = *reinterpret_cast<const f32x2*>(scb + (int64_t)b * in_cs + 8 * c8i + 2 * k);
+                    nsh[k] = *reinterpret_cast<const f32x2*>(shb + (int64_t)b * in_cs + 8 * c8i + 2 * k);
+                }
+            }
+            const __amdgpu_buffer_rsrc_t rsi = make_rsrc(inb + (int64_t)b * H * W * in_cs, (unsigned)(((int64_t)H * W * in_cs - ci_off) * 2));
+            const __amdgpu_buffer_rsrc_t rsd = make_rsrc(dout + (int64_t)b * H * W * 64, (unsigned)((int64_t)H * W * 64 * 2));
+            const int gy0 = y0 - HALO, gx0 = x0 - HALO;
+            if (gy0 >= 0 && y0 + TH + HALO <= H && gx0 >= 0 && x0 + BTW + HALO <= W) {
+                const int so = (gy0 * W + gx0) * in_cs * 2, sd = (y0 * W + x0) * 64 * 2;
+#pragma unroll
+                for (int it = 0; it < NI; ++it)
+                    ri[it] = __builtin_amdgcn_raw_buffer_load_b128(rsi, (threadIdx.x + it * 256 < TOT_IN) ? gi[it] : OOB, so, 0);
+#pragma unroll
+                for (int it = 0; it < ND; ++it) rd[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, gd[it], sd, 0);
+            } else {
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int gy = gy0 + (pi[it] >> 8), gx = gx0 + (pi[it] & 255);
+                    const bool ok = (threadIdx.x + it * 256 < TOT_IN) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                    ri[it] = __builtin_amdgcn_raw_buffer_load_b128(rsi, ok ? ((gy * W + gx) * in_cs + 8 * c8i) * 2 : OOB, 0, 0);
+                }
+#pragma unroll
+                for (int it = 0; it < ND; ++it) {
+                    const int pix = (threadIdx.x + it * 256) >> 3;
+                    const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+                    rd[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, ((gy < H) & (gx < W)) ? ((gy * W + gx) * 64 + 8 * c8d) * 2 : OOB, 0, 0);
+                }
+            }
+        } else {
+            btile_load<T, CI, LH, LW, HALO>(tr, inb, b, y0, x0, H, W, in_cs);
+            btile_load<T, 64, TH, BTW, 0>(td, dout, b, y0, x0, H, W, 64);
+        }
+    };
+    auto stage_store = [&](int t) __attribute__((always_inline)) {
+        int b, y0, x0;
+        coords(t, b, y0, x0);
+        if constexpr (TAB) {
+            const int mode = scb ? (in_relu ? 2 : 3) : (in_relu ? 1 : 0);
+            f32x2 sc[4], sh[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sc[k] = nsc[k]; sh[k] = nsh[k]; }
+            const int gy0 = y0 - HALO, gx0 = x0 - HALO;
+            const bool interior = gy0 >= 0 && y0 + TH + HALO <= H && gx0 >= 0 && x0 + BTW + HALO <= W;
+            auto put = [&](auto mode_tag) __attribute__((always_inline)) {
+                constexpr int M = decltype(mode_tag)::value;
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    u32x4 o = ri[it];
+                    if (M != 0) {
+                        unsigned int keep = 0xffffffffu;
+                        if (!interior) {   // zero padding applies to the NORMALISED activation
+                            const int gy = gy0 + (pi[it] >> 8), gx = gx0 + (pi[it] & 255);
+                            keep = (((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W)) ? 0xffffffffu : 0u;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = xform2<M>(o[k], sc[k], sh[k]) & keep;
+                    }
+                    if (threadIdx.x + it * 256 < TOT_IN) *reinterpret_cast<u32x4*>(lin + li[it]) = o;
+                }
+            };
+            if (mode == 0) put(std::integral_constant<int, 0>());
+            else if (mode == 1) put(std::integral_constant<int, 1>());
+            else if (mode == 2) put(std::integral_constant<int, 2>());
+            else put(std::integral_constant<int, 3>());
+#pragma unroll
+            for (int it = 0; it < ND; ++it) *reinterpret_cast<u32x4*>(ldo + ld[it]) = rd[it];
+        } else {
+            btile_store<T, CI, LH, LW, HALO, ROWA>(tr, scb, shb, in_relu, lin, b, y0, x0, H, W, in_cs);
+            btile_store<T, 64, TH, BTW, 0, ROWD>(td, nullptr, nullptr, 0, ldo, b, y0, x0, H, W, 64);
+        }
+    };
+
+    int tile = t_begin;
+    if (tile < t_end) stage_load(tile);
+    P4C_STAMP(3000); P4C_STAMP_RT(3001);
+    for (; tile < t_end; ++tile) {
+        P4C_STAMP(2000 + 4 * (tile - t_begin) + 0);
+        __syncthreads();
+        if (!(P4C_EXP & 1) || tile == t_begin) stage_store(tile);
+        __syncthreads();
+        if (tile + 1 < t_end && !(P4C_EXP & 2)) stage_load(tile + 1);
+        // K loop over 16-pixel steps, software pipelined: the 2 + 2*NTAPS transposing LDS reads of step kk+1 are issued
+        // before the NTAPS MFMAs of step kk (two operand sets alternate), so the matrix pipe never waits on LDS latency
+        struct Ops { s16x4 b[2]; s16x4 a[NTAPS][2]; };
+        auto fetch = [&](Ops& o, int kk) __attribute__((always_inline)) {
             const int kstep = ksl * KSTEPS + kk;        // 16 pixels: row kstep>>1, columns (kstep&1)*16 ..
             const int row = kstep >> 1, col0 = (kstep & 1) * 16;
             const int px = col0 + 8 * h + tq;           // this lane's pixel for the first 4-row block (+4 for the second)
             const char* bp = ldo + (row * BTW + px) * ROWD + b_col;
-            union { s16x4 s[2]; bf16x8 v; } ub;
-            ub.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
-            ub.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 4 * ROWD));
+            if (!(P4C_EXP & 64) || kk < 2) {
+            o.b[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+            o.b[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 4 * ROWD));
+            }
             const char* ap0 = lin + (row * LW + px) * ROWA + a_col;
+            if (!(P4C_EXP & 32) || kk < 2)
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
                 const int ky = t / KS, kx = t - ky * KS;
                 const char* ap = ap0 + (ky * LW + kx) * ROWA;
+                o.a[t][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap));
+                o.a[t][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap + 4 * ROWA));
+            }
+        };
+        auto mma = [&](const Ops& o) __attribute__((always_inline)) {
+            union { s16x4 s[2]; bf16x8 v; } ub;
+            ub.s[0] = o.b[0]; ub.s[1] = o.b[1];
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
                 union { s16x4 s[2]; bf16x8 v; } u;
-                u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap));
-                u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap + 4 * ROWA));
+                u.s[0] = o.a[t][0]; u.s[1] = o.a[t][1];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ub.v, acc[t], 0, 0, 0);
             }
+        };
+        P4C_STAMP(2000 + 4 * (tile - t_begin) + 1);
+        static_assert(KSTEPS % 2 == 0, "the pipelined K loop handles steps in pairs");
+        constexpr int KLOOP = (P4C_EXP & 16) ? 2 : KSTEPS;
+        Ops o0, o1;
+        fetch(o0, 0);
+#pragma unroll 1
+        for (int kk = 0; kk < KLOOP; kk += 2) {
+            fetch(o1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(o0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < KLOOP) fetch(o0, kk + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(o1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        P4C_STAMP(2000 + 4 * (tile - t_begin) + 2);
     }
+    P4C_STAMP(3002); P4C_STAMP_RT(3003);
     // C[ci][co]: lane = co (r), register i -> ci = (i&3) + 8*(i>>2) + 4*h.  One partial per (workgroup, k-slice).
     float* pbase = partial + ((int64_t)blockIdx.x * KSPLIT + ksl) * NTAPS * part_cip * 64;
 #pragma unroll

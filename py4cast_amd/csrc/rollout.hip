@@ -102,11 +102,12 @@ __global__ void __launch_bounds__(256)
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int b = blockIdx.y;  // one sample per grid row: no 64-bit division per grid point
     const int PP = 64 / FP4;
     const int pp = lane / FP4, q = lane % FP4;
     const int c0 = 4 * q;
     const int o_stat = n_prev_ch, o_forc = n_prev_ch + Fs, c_in = n_prev_ch + Fs + Ff;
-    const int64_t total = (int64_t)B * N;
+    const int64_t total = N;
     if (c0 >= c_pad) return;
     // classify the quad once (it is the same for every grid point)
     int kind = 3;  // 0: vector prev, 1: vector statics, 2: all zero padding, 3: per-element gather
@@ -127,11 +128,9 @@ __global__ void __launch_bounds__(256)
         v4f v[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int64_t pix = base + (int64_t)u * nwaves * PP;
+            const int64_t n = base + (int64_t)u * nwaves * PP;
             v[u] = v4f{0.f, 0.f, 0.f, 0.f};
-            if (pix >= total) continue;
-            const int b = (int)(pix / N);
-            const int64_t n = pix - (int64_t)b * N;
+            if (n >= total) continue;
             if (kind == 0) {
                 v[u] = *reinterpret_cast<const v4f*>(prev + (int64_t)b * prev_bs + (int64_t)t_idx * prev_ts + n * F + f_idx);
             } else if (kind == 1) {
@@ -155,8 +154,8 @@ __global__ void __launch_bounds__(256)
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int64_t pix = base + (int64_t)u * nwaves * PP;
-            if (pix < total) store4f(x + pix * (int64_t)c_pad + c0, v[u]);
+            const int64_t n = base + (int64_t)u * nwaves * PP;
+            if (n < total) store4f(x + ((int64_t)b * N + n) * (int64_t)c_pad + c0, v[u]);
         }
     }
 }
@@ -303,13 +302,13 @@ extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, 
                              (reinterpret_cast<uintptr_t>(prev) & 15) == 0;
         const int vec_stat = Fs % 4 == 0 && n_prev_ch % 4 == 0 && statics_bs % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(statics) & 15) == 0;
-        const int grid4 = stream_grid((int64_t)B * N, 64 / FP4);
+        const int grid4 = stream_grid(N, 64 / FP4);
         if (x_dtype == P4C_F32)
-            hipLaunchKernelGGL(build_x_v4_kernel<float>, dim3(grid4), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
+            hipLaunchKernelGGL(build_x_v4_kernel<float>, dim3(grid4, B), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
                                statics, statics_bs, forcing, forcing_bs, (float*)x, c_pad, B, T_in, N, F, Fs, Ff, n_prev_ch, FP4,
                                vec_prev, vec_stat);
         else
-            hipLaunchKernelGGL(build_x_v4_kernel<bf16>, dim3(grid4), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
+            hipLaunchKernelGGL(build_x_v4_kernel<bf16>, dim3(grid4, B), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
                                statics, statics_bs, forcing, forcing_bs, (bf16*)x, c_pad, B, T_in, N, F, Fs, Ff, n_prev_ch, FP4,
                                vec_prev, vec_stat);
         P4C_CHECK_LAUNCH("p4c_build_x(v4)");

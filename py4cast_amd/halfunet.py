@@ -213,6 +213,25 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             self._flat = flat
         return self._flat
 
+    def _flat_grad_target(self):
+        """The flat fp32 buffer every ``param.grad`` is a view of, in parameter order (the layout FlatDDP sets up), or
+        None.  When it exists the backward plan accumulates straight into it (the C entry point is ``+=`` anyway) and
+        autograd is handed no per-parameter gradients: that saves one zero-fill and 37 tiny ``grad +=`` launches."""
+        params = self._ordered_params()
+        g0 = params[0].grad
+        if g0 is None or g0.dtype != torch.float32 or not g0.is_contiguous():
+            return None
+        base = g0.data_ptr() - 4 * self._param_slices[0][0]
+        for p, (o, n, _) in zip(params, self._param_slices):
+            g = p.grad
+            if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + 4 * o:
+                return None
+        store = g0.untyped_storage()
+        first = (base - store.data_ptr()) // 4
+        if base < store.data_ptr() or (first + self._nparams) * 4 > store.nbytes():
+            return None
+        return torch.empty(0, dtype=torch.float32, device=g0.device).set_(store, first, (self._nparams,))
+
     def _running_stats(self, device) -> torch.Tensor:
         """[12][2][64] flat running statistics, aliased by the named BatchNorm buffers."""
         if self._settings.norm != "batch":
@@ -404,7 +423,8 @@ class _NativeRolloutFn(torch.autograd.Function):
         stream = L.stream(dev)
         flat = model._flat_params()
         _, scratch = model._workspaces(desc, dev)
-        gflat = torch.zeros_like(flat)
+        target = model._flat_grad_target()
+        gflat = target if target is not None else torch.zeros_like(flat)
         adt, acode = model.act_dtype, L.dtype_code(model.act_dtype)
         dy = torch.empty(B, H, W, NF, dtype=adt, device=dev)
         dx = torch.empty(B, H, W, NF, dtype=adt, device=dev)
@@ -435,5 +455,7 @@ class _NativeRolloutFn(torch.autograd.Function):
             have_next = True
             xs[i] = None
             saveds[i] = None  # release the step's activations as soon as its backward is enqueued
+        if target is not None:  # already accumulated into param.grad
+            return (None,) * (17 + len(model._param_slices))
         grads = tuple(gflat[o : o + n].view(s) for (o, n, s) in model._param_slices)
         return (None,) * 17 + grads

@@ -248,6 +248,36 @@ def test_native_rollout_equals_generic_path(gpu_device, strategy, nan, border):
         assert rel_err(res[True][2][n], res[False][2][n]) < 5e-2, n  # chaotic BPTT (see test above); typical 1e-4
 
 
+def test_native_rollout_accumulates_into_flat_grad_buffer(gpu_device):
+    """With FlatDDP's layout (every param.grad a view of one flat buffer) the backward plan accumulates straight into
+    that buffer: gradients equal the per-parameter path, and a second backward ADDS to them."""
+    from helpers import make_batch, make_dataset_info, synthetic_case
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from py4cast_amd.trainer import FlatDDP
+
+    case = synthetic_case(seed=4, B=2, T=2, H=32, W=32, F=12, Ff=5, Fs=4, border=0, nan=False)
+    info = make_dataset_info(case, 5)
+    torch.manual_seed(0)
+    lm = AutoRegressiveLightning(
+        {}, info, None, num_pred_steps_train=2, batch_size=2, model_name="HalfUNet",
+        losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+        training_strategy="scaled_ar",
+    ).to(gpu_device)
+    lm.train()
+    lm.use_native_rollout = True
+    for p in lm.parameters():
+        p.grad = None
+    lm.training_step(make_batch(case, gpu_device), 0).backward()
+    ref = {n: p.grad.detach().clone() for n, p in lm.model.named_parameters()}
+    ddp = FlatDDP(lm, world_size=1)
+    assert lm.model._flat_grad_target() is not None
+    for k in (1, 2):
+        lm.training_step(make_batch(case, gpu_device), 0).backward()
+        for n, p in lm.model.named_parameters():
+            assert rel_err(p.grad, k * ref[n]) < 5e-2, (k, n)  # BatchNorm running stats move between calls; typical 1e-4
+    assert float(ddp.flat_grad.abs().sum()) > 0
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # bf16 matrix-core flavour: operands are rounded to bf16 (RNE) in LDS, products accumulate in fp32.  The reference
 # below applies the same rounding to inputs and weights and convolves in float64, so the only difference left is
