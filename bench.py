@@ -201,7 +201,7 @@ def main():
         loss.backward()
         ddp.all_reduce_grads()
         opt.step()
-        opt.zero_grad(set_to_none=False)
+        ddp.zero_grad()
         return loss
 
     def barrier():

@@ -340,8 +340,17 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             # at the bf16 MFMA rate the kernel is HBM-bound: algorithmic bytes = read 64 ch + write 64 ch per pixel
             esz = 2 if self.act_dtype == torch.bfloat16 else 4
             gbs = 2.0 * 64 * esz * units.value / (ms.value * 1e-3) / 1e9
-            return {"bound": "hbm", "kernel": "conv_fwd_bf16_ws_kernel<%s,64,3> (3x3 conv 64->64, fwd + data-grad launches)" % ("bf16" if esz == 2 else "f32"),
-                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+            kname = "conv3x3_bf16_ring_kernel" if esz == 2 else "conv_fwd_bf16_ws_kernel<f32,64,3>"
+            traffic = None
+            if esz == 2 and (B, H, W) == (2, 512, 512):
+                # HBM bytes per launch of this very launch shape, from the committed rocprofv3 PMC passes
+                import json, os
+                f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
+                if os.path.exists(f):
+                    traffic = json.load(open(f)).get("conv3x3_bf16_ring_kernel", {}).get("hbm_bytes_per_launch")
+            return {"bound": "hbm", "kernel": kname + " (3x3 conv 64->64, fwd + data-grad launches at full resolution)",
+                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": 2.0 * 64 * esz * B * H * W,
                     "avg_launch_ms": ms.value / n.value, "launches": n.value, "mfma_tflops": tflops,
                     "wgrad_avg_launch_ms": (wms.value / wn.value) if wn.value else None}
         out = {"bound": "mfma", "kernel": "conv_fwd_f32_kernel<64,3,4> (3x3 conv 64->64, fwd + data-grad launches)",

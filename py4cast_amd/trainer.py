@@ -47,6 +47,16 @@ class FlatDDP:
         for p in self.params:
             dist.broadcast(p.data, src)
 
+    def zero_grad(self):
+        """One fill over the flat buffer instead of one per parameter (``optimizer.zero_grad(set_to_none=False)``)."""
+        base = self.flat_grad.untyped_storage().data_ptr()
+        if self._views_ok and all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params):
+            self.flat_grad.zero_()
+        else:
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.zero_()
+
     def all_reduce_grads(self):
         if self.world_size <= 1:
             return
@@ -126,7 +136,7 @@ class Trainer:
         ddp = FlatDDP(module)
         if hasattr(module, "on_train_start"):
             module.on_train_start()
-        opt.zero_grad(set_to_none=False)
+        ddp.zero_grad()
         done = False
         for epoch in range(self.max_epochs):
             module.train()
@@ -140,7 +150,7 @@ class Trainer:
                     opt.step()
                     if sched is not None:
                         sched.step()
-                    opt.zero_grad(set_to_none=False)
+                    ddp.zero_grad()
                     self.global_step += 1
                     if 0 < self.max_steps <= self.global_step:
                         done = True
