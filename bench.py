@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default=os.environ.get("P4C_BENCH_MODEL", "HalfUNet"))
-    ap.add_argument("--dtype", default=os.environ.get("P4C_BENCH_DTYPE", "f32"), choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default=os.environ.get("P4C_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"],
                     help="matrix-core input type of the model convolutions")
     ap.add_argument("--act-dtype", default=os.environ.get("P4C_BENCH_ACT_DTYPE"), choices=["f32", "bf16"],
                     help="HBM storage of activations (default: same as --dtype)")
