@@ -890,6 +890,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         };
 
+        P4C_STAMP_RT(3100);
         load(ta);
         load(tb);
         if (MODE >= 2) {
@@ -904,7 +905,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         store(ta);
         load(ta);
+        P4C_STAMP_RT(3101);
         lds_barrier();
+        P4C_STAMP_RT(3102);
         for (int tile = t_begin; tile < t_end; tile += 2) {
             // compute reads tile `tile`; drain tile-1, stage tile+1, prefetch tile+3.  The first trip has nothing to
             // drain but still issues the 4 (dropped, out-of-range) stores: same operation count on every trip.
@@ -918,7 +921,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             load(ta);
             lds_barrier();
         }
+        P4C_STAMP_RT(3103);
         drain(true);
+        P4C_STAMP_RT(3104);
         if (stat_partial) {
             flush(cur_b);
             const int bf = (t_begin / tiles_y) / tiles_x;
@@ -936,6 +941,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // wave wv: output channels 32*ct .. +31 (ct = wv >> 1), tile rows 2*rp and 2*rp+1 (rp = wv & 1)
     const int ct = wv >> 1, rp = wv & 1;
     if (P4C_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    P4C_STAMP_RT(3110);
     bf16x8 A[9][4];
     {
         const char* wsrc = reinterpret_cast<const char*>(wp) + (h * 64 + ct * 32 + r) * 16;
@@ -955,7 +961,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int g = 0; g < 4; ++g) soff[g] = (2 * rp * 32 + r) * 128 + 8 * h + (((4 * ct + g) ^ (r & 7)) << 4);
     Cur cc = cur_init();
+    P4C_STAMP_RT(3111);
     for (int tile = t_begin; tile < t_end; ++tile) {
+        P4C_STAMP_RT(3120 + 2 * (tile - t_begin));
         const char* tb0 = lring + cc.p * RROW;
         cur_next(cc);
         const char* ba[3][4];
@@ -1009,8 +1017,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 o[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2));
                 *reinterpret_cast<u32x2*>(stg + soff[g] + row * 32 * 128) = o;
             }
+        P4C_STAMP_RT(3121 + 2 * (tile - t_begin));
         lds_barrier();
     }
+    P4C_STAMP_RT(3112);
 }
 
 template <int MODE>

@@ -62,16 +62,22 @@ __global__ void __launch_bounds__(256)
         s1 += (double)partial[tile * 128 + c];
         s2 += (double)partial[tile * 128 + 64 + c];
     }
-    red[0][threadIdx.x] = s1;
-    red[1][threadIdx.x] = s2;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + off];
-            red[1][threadIdx.x] += red[1][threadIdx.x + off];
-        }
-        __syncthreads();
+    // wave-level butterfly (no LDS round trips), then one 4-way combine through LDS: the result lands in red[.][0]
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
     }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s1;
+        red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        red[0][0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        red[1][0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+    __syncthreads();
     const double n = (double)(b_hi - b_lo) * (double)hw * (double)nc;
     const double mean = red[0][0] / n;
     double var = red[1][0] / n - mean * mean;
@@ -168,6 +174,32 @@ __global__ void __launch_bounds__(256)
     const int cl = threadIdx.x % cpg, sl = threadIdx.x / cpg, nsl = 256 / cpg;
     const int c = c_lo + cl;
     float tot1 = 0.f, tot2 = 0.f;
+    if (mode == 0) {
+        // BatchNorm: only the totals over the batch are needed -> one pass, wave butterflies, one LDS combine
+        float s1 = 0.f, s2 = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int k = threadIdx.x; k < nblk; k += 256) {
+                s1 += partial[(((int64_t)b * nblk + k) * 2 + 0) * 64 + c];
+                s2 += partial[(((int64_t)b * nblk + k) * 2 + 1) * 64 + c];
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+        }
+        if ((threadIdx.x & 63) == 0) { S[0][threadIdx.x >> 6] = s1; S[1][threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            tot1 = (S[0][0] + S[0][1]) + (S[0][2] + S[0][3]);
+            tot2 = (S[1][0] + S[1][1]) + (S[1][2] + S[1][3]);
+            dgamma[c] += tot2;
+            dbeta[c] += tot1;
+            const float n = (float)B * (float)hw;
+            const float a = training ? gamma[c] * tot1 / n : 0.f, bb = training ? gamma[c] * tot2 / n : 0.f;
+            for (int b = 0; b < B; ++b) { k1[b * C + c] = a; k2[b * C + c] = bb; }
+        }
+        return;
+    }
     for (int b = 0; b < B; ++b) {
         float s1 = 0.f, s2 = 0.f;
         for (int k = sl; k < nblk; k += nsl) {
