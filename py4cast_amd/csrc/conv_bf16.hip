@@ -989,18 +989,25 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             };
             issue(0, 0);
             issue(1, 1);
+            // one B read (for stage s+2) in each MFMA gap of stage s: the micro-benchmark (scratch/micro/mfma_rate.hip)
+            // runs 36 cycles per MFMA in this shape against 48 when the 4 reads and the 4 MFMAs of a stage go in bursts
+            auto issue1 = [&](int s, int buf, int j) __attribute__((always_inline)) {
+                const int tap = s >> 1, ky = tap / 3, kx = tap % 3;
+                const int kl = j >> 1, ks = (s & 1) * 2 + kl;
+                fb[buf][kl][j & 1] = *reinterpret_cast<const bf16x8*>(ba[kx][ks] + (ky + (j & 1)) * RROW);
+            };
 #pragma unroll
             for (int s = 0; s < 18; ++s) {
-                if (s + 2 < 18) issue(s + 2, (s + 2) % 3);
-                __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this stage's MFMAs
                 const int tap = s >> 1;
 #pragma unroll
-                for (int kl = 0; kl < 2; ++kl) {
-                    const int ks = (s & 1) * 2 + kl;
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap][ks], fb[s % 3][kl][0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap][ks], fb[s % 3][kl][1], acc1, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    if (s + 2 < 18) issue1(s + 2, (s + 2) % 3, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int kl = j >> 1, ks = (s & 1) * 2 + kl;
+                    if ((j & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap][ks], fb[s % 3][kl][0], acc0, 0, 0, 0);
+                    else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap][ks], fb[s % 3][kl][1], acc1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         } else { acc0[0] = ba[0][0][0]; acc1[3] = ba[1][1][16]; }
         // epilogue: C[co][px]; lane = pixel r (+ half h), register quad g -> channels 32ct + 8g + 4h .. +3, i.e. half h
