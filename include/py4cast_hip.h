@@ -161,6 +161,23 @@ int p4c_scaled_loss_fwd(const float* pred, int64_t pred_bs, int64_t pred_ts, con
                         const float* interior_mask, float num_interior, const int32_t* masked_count, int kind,
                         float* out, void* workspace, int B, int T, int64_t N, int F, p4c_stream_t stream);
 
+/* Anomaly-correlation sums of MetricACC.update (metrics.py:387-433), the validation metric next to the losses:
+ * out (3,B,T,F) = spatial means of (p-c)(t-c)m, ((p-c)m)^2, ((t-c)m)^2 with c = climate_means[f].
+ * workspace: 3 * p4c_loss_workspace_bytes(B,T,N,F). */
+int p4c_acc_sums(const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target, int64_t tgt_bs, int64_t tgt_ts,
+                 const void* mask, int mask_mode, const float* climate_means, float* out, void* workspace, int B, int T,
+                 int64_t N, int F, p4c_stream_t stream);
+
+/* Rows next to the path.
+ * p4c_unnormalize: out[r,f] = x[r,f]*std[f] + mean[f] as two rounded steps (predict path, lightning.py:1162-1169);
+ *   out may alias x.
+ * p4c_pack_standardize: planes raw[f*plane_stride + r] -> rows out[r*F + f] = (raw - mean[f]) / std[f]
+ *   (Sample.load standardisation datasets/base.py:448-452 + NamedTensor.concat + collate_fn :173-195 in one pass). */
+int p4c_unnormalize(const float* x, const float* std, const float* mean, float* out, int64_t rows, int F,
+                    p4c_stream_t stream);
+int p4c_pack_standardize(const float* raw, int64_t plane_stride, const float* mean, const float* std, float* out,
+                         int64_t rows, int F, p4c_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K2+K3 fused (training path): one AR step's state update AND its contribution to the
  * training loss in a single pass over (B,N,F) -- the target of step i is also the border

@@ -37,6 +37,9 @@ SIGNATURES = {
     "p4c_weighted_loss_map": [P, L, L, P, L, L, P, I, P, I, P, I, I, L, I, P],
     "p4c_weighted_loss_bwd": [P, P, L, L, P, L, L, P, I, P, P, F, P, I, P, L, L, I, I, L, I, P],
     "p4c_scaled_loss_fwd": [P, L, L, P, L, L, P, I, P, P, F, P, I, P, P, I, I, L, I, P],
+    "p4c_acc_sums": [P, L, L, P, L, L, P, I, P, P, P, I, I, L, I, P],
+    "p4c_unnormalize": [P, P, P, P, L, I, P],
+    "p4c_pack_standardize": [P, L, P, P, P, L, I, P],
     "p4c_ar_update_loss_fwd": [P, L, P, I, I, P, L, P, P, P, P, P, L, P, F, P, I, I, P, L, P, I, L, I, F, P],
     "p4c_ar_update_loss_bwd": [P, L, P, I, I, P, L, P, L, P, L, P, P, I, P, F, P, I, I, P, I, I, P, L, I, L, I, F, P],
 }

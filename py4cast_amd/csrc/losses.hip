@@ -277,6 +277,122 @@ __global__ void scaled_loss_final_kernel(const float* __restrict__ partial, int 
     out[i] = v * std[f];                     // losses.py:208-210
 }
 
+// ------------------------------------------------------------------ anomaly-correlation sums (validation metric)
+// MetricACC.update (py4cast/metrics.py:387-433): per (b,t,f), over the spatial points,
+//   num = mean((p-c)*(t-c)*m),  pp = mean(((p-c)*m)^2),  tt = mean(((t-c)*m)^2)      c = climate mean of feature f
+// partial[((k*nbt + bt)*nblk + blk)*F + f], k = 0 (num), 1 (pp), 2 (tt); same two-stage fixed-order reduction as the
+// losses, one pass over prediction and target.
+__global__ void __launch_bounds__(256)
+    acc_partial_kernel(const float* __restrict__ pred, int64_t pred_bs, int64_t pred_ts, const float* __restrict__ target,
+                       int64_t tgt_bs, int64_t tgt_ts, MaskArg ma, int64_t mask_bs, int64_t mask_ts,
+                       const float* __restrict__ clim, float* __restrict__ partial, int T, int64_t N, int F, int FP,
+                       int iters) {
+    __shared__ float red[3][4][64 * LOSS_MAX_ITERS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bt = blockIdx.y, b = bt / T, t = bt - b * T;
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const float* p = pred + (int64_t)b * pred_bs + (int64_t)t * pred_ts;
+    const float* g = target + (int64_t)b * tgt_bs + (int64_t)t * tgt_ts;
+    const int64_t mbase = (int64_t)b * mask_bs + (int64_t)t * mask_ts;
+    float a0[LOSS_MAX_ITERS], a1[LOSS_MAX_ITERS], a2[LOSS_MAX_ITERS];
+#pragma unroll
+    for (int it = 0; it < LOSS_MAX_ITERS; ++it) a0[it] = a1[it] = a2[it] = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+#pragma unroll
+        for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+            const int f = c0 + it * FP;
+            if (it < iters && f < F) {
+                const int64_t e = n * F + f;
+                float tg = g[e];
+                const float m = load_mask(ma, mbase + e, tg);
+                const float c = clim[f];
+                const float dp = p[e] - c, dt = tg - c;
+                a0[it] += dp * dt * m;             // metrics.py:414-418
+                const float pm = dp * m, tm = dt * m;
+                a1[it] += pm * pm;                 // metrics.py:419-421
+                a2[it] += tm * tm;                 // metrics.py:421-423
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+        const float v0 = cross_seg_sum(a0[it], FP), v1 = cross_seg_sum(a1[it], FP), v2 = cross_seg_sum(a2[it], FP);
+        if (pp == 0) { red[0][wv][it * 64 + c0] = v0; red[1][wv][it * 64 + c0] = v1; red[2][wv][it * 64 + c0] = v2; }
+    }
+    __syncthreads();
+    const int nbt = gridDim.y;
+    for (int i = threadIdx.x; i < 3 * iters * FP; i += blockDim.x) {
+        const int k = i / (iters * FP), j = i - k * iters * FP;
+        const int it = j / FP, c = j - it * FP;
+        const int f = c + it * FP;
+        if (f < F) {
+            const int q = it * 64 + c;
+            partial[(((int64_t)k * nbt + bt) * gridDim.x + blockIdx.x) * F + f] =
+                (red[k][0][q] + red[k][1][q]) + (red[k][2][q] + red[k][3][q]);
+        }
+    }
+}
+
+// 16-byte vectorised form (F % 4 == 0, F <= 64, no explicit mask tensor): a lane owns 4 features of a grid point
+__global__ void __launch_bounds__(256)
+    acc_partial_v4_kernel(const float* __restrict__ pred, int64_t pred_bs, int64_t pred_ts, const float* __restrict__ target,
+                          int64_t tgt_bs, int64_t tgt_ts, int from_nan, const float* __restrict__ clim,
+                          float* __restrict__ partial, int T, int64_t N, int F, int FP4) {
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    __shared__ float red[3][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int bt = blockIdx.y, b = bt / T, t = bt - b * T;
+    const int PP = 64 / FP4;
+    const int pp = lane / FP4, q = lane % FP4;
+    const bool act = 4 * q < F;
+    const float* p = pred + (int64_t)b * pred_bs + (int64_t)t * pred_ts;
+    const float* g = target + (int64_t)b * tgt_bs + (int64_t)t * tgt_ts;
+    v4f_ c = {0, 0, 0, 0};
+    if (act) c = *reinterpret_cast<const v4f_*>(clim + 4 * q);
+    v4f_ a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0;
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        if (!act) continue;
+        const v4f_ pv = *reinterpret_cast<const v4f_*>(p + n * F + 4 * q);
+        v4f_ tv = *reinterpret_cast<const v4f_*>(g + n * F + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float tg = tv[j], m = 1.0f;
+            if (from_nan) { m = (tg != tg) ? 0.0f : 1.0f; tg = (tg != tg) ? 0.0f : tg; }
+            const float dp = pv[j] - c[j], dt = tg - c[j];
+            a0[j] += dp * dt * m;
+            const float pm = dp * m, tm = dt * m;
+            a1[j] += pm * pm;
+            a2[j] += tm * tm;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v0 = cross_seg_sum(a0[j], FP4), v1 = cross_seg_sum(a1[j], FP4), v2 = cross_seg_sum(a2[j], FP4);
+        if (pp == 0 && act) { red[0][wv][4 * q + j] = v0; red[1][wv][4 * q + j] = v1; red[2][wv][4 * q + j] = v2; }
+    }
+    __syncthreads();
+    const int nbt = gridDim.y;
+    for (int i = threadIdx.x; i < 3 * F; i += blockDim.x) {
+        const int k = i / F, f = i - k * F;
+        partial[(((int64_t)k * nbt + bt) * gridDim.x + blockIdx.x) * F + f] =
+            (red[k][0][f] + red[k][1][f]) + (red[k][2][f] + red[k][3][f]);
+    }
+}
+
+__global__ void acc_final_kernel(const float* __restrict__ partial, int nblk, float n_points, float* __restrict__ out,
+                                 int nbt, int F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * nbt * F) return;
+    const int k = i / (nbt * F), j = i - k * nbt * F;
+    const int bt = j / F, f = j - bt * F;
+    float s = 0.0f;
+    for (int q = 0; q < nblk; ++q) s += partial[(((int64_t)k * nbt + bt) * nblk + q) * F + f];
+    out[i] = s / n_points;   // torch .mean(dim=spatial)
+}
+
 // ------------------------------------------------------------------ fused AR update + loss, 16-byte vectorised
 // Same arithmetic (and operation order) as the scalar kernels below, for F % 4 == 0, F <= 64 and fp32 y/dy rows
 // whose stride is a multiple of 4: a lane owns 4 consecutive features of a grid point, so every access is a
@@ -648,6 +764,36 @@ extern "C" int p4c_scaled_loss_fwd(const float* pred, int64_t pred_bs, int64_t p
     hipLaunchKernelGGL(scaled_loss_final_kernel, dim3((tot + 127) / 128), dim3(128), 0, as_stream(stream),
                        (const float*)workspace, nblk, num_interior, masked_count, std, kind, out, B * T, F);
     P4C_CHECK_LAUNCH("p4c_scaled_loss_fwd(final)");
+    return P4C_OK;
+}
+
+extern "C" int p4c_acc_sums(const float* pred, int64_t pred_bs, int64_t pred_ts, const float* target, int64_t tgt_bs,
+                            int64_t tgt_ts, const void* mask, int mask_mode, const float* climate_means, float* out,
+                            void* workspace, int B, int T, int64_t N, int F, p4c_stream_t stream) {
+    P4C_CHECK_ARG(pred && target && climate_means && out && workspace, "p4c_acc_sums: null pointer");
+    P4C_CHECK_ARG(B > 0 && T > 0 && N > 0 && F > 0 && F <= 64 * LOSS_MAX_ITERS, "p4c_acc_sums: bad dims");
+    P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE || mask_mode == P4C_MASK_FROM_NAN || mask, "p4c_acc_sums: mask pointer needed");
+    int nblk;
+    if ((mask_mode == P4C_MASK_NONE || mask_mode == P4C_MASK_FROM_NAN) && F % 4 == 0 && F <= 64 && pred_bs % 4 == 0 &&
+        pred_ts % 4 == 0 && tgt_bs % 4 == 0 && tgt_ts % 4 == 0 && aligned16(pred) && aligned16(target) && aligned16(climate_means)) {
+        const int FP4 = pow2_ge64(F / 4);
+        nblk = loss_blocks(N, 64 / FP4, B * T);
+        hipLaunchKernelGGL(acc_partial_v4_kernel, dim3(nblk, B * T), dim3(256), 0, as_stream(stream), pred, pred_bs, pred_ts,
+                           target, tgt_bs, tgt_ts, mask_mode == P4C_MASK_FROM_NAN ? 1 : 0, climate_means, (float*)workspace, T, N,
+                           F, FP4);
+    } else {
+        const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
+        nblk = loss_blocks(N, 64 / FP, B * T);
+        const int64_t mbs = (int64_t)T * N * F, mts = N * F;
+        MaskArg ma{mask, mask_mode};
+        hipLaunchKernelGGL(acc_partial_kernel, dim3(nblk, B * T), dim3(256), 0, as_stream(stream), pred, pred_bs, pred_ts,
+                           target, tgt_bs, tgt_ts, ma, mbs, mts, climate_means, (float*)workspace, T, N, F, FP, iters);
+    }
+    P4C_CHECK_LAUNCH("p4c_acc_sums(partial)");
+    const int tot = 3 * B * T * F;
+    hipLaunchKernelGGL(acc_final_kernel, dim3((tot + 127) / 128), dim3(128), 0, as_stream(stream), (const float*)workspace,
+                       nblk, (float)N, out, B * T, F);
+    P4C_CHECK_LAUNCH("p4c_acc_sums(final)");
     return P4C_OK;
 }
 

@@ -329,6 +329,88 @@ extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, 
     return P4C_OK;
 }
 
+// ---------------------------------------------------------------------------- rows next to the path
+// un-normalise a prediction per feature: out = x*std[f] + mean[f], evaluated as the reference's two in-place passes
+// (`*= std` then `+= mean`, lightning.py:1162-1169): two roundings, no FMA (this file is built with -ffp-contract=off).
+__global__ void __launch_bounds__(256) unnormalize_kernel(const float* __restrict__ x, const float* __restrict__ std,
+                                                          const float* __restrict__ mean, float* __restrict__ out,
+                                                          int64_t total, int F) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int f = (int)(i % F);
+        const float v = x[i] * std[f];
+        out[i] = v + mean[f];
+    }
+}
+
+// standardise + pack: per-parameter planes raw[f][r] (what a loader reading one .npy per parameter produces, r over
+// batch x timestep x grid) -> features-last rows out[r][f] = (raw[f][r] - mean[f]) / std[f]
+// (datasets/base.py:448-452 followed by NamedTensor.concat + collate_fn :173-195).  A block transposes 256 rows x all
+// features through LDS: every plane read is a contiguous 1 KB run and the block's output (256*F floats) is one
+// contiguous run written in order.
+constexpr int PACK_ROWS = 256;
+__global__ void __launch_bounds__(256) pack_standardize_kernel(const float* __restrict__ raw, int64_t plane_stride,
+                                                               const float* __restrict__ mean, const float* __restrict__ std,
+                                                               float* __restrict__ out, int64_t R, int F) {
+    extern __shared__ float tile[];  // [F][PACK_ROWS + 1]
+    const int64_t r0 = (int64_t)blockIdx.x * PACK_ROWS;
+    const int64_t r = r0 + threadIdx.x;
+    // 8 planes per trip: the 8 loads of a thread are independent and in flight together
+    for (int f0 = 0; f0 < F; f0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (f0 + k < F && r < R) ? raw[(int64_t)(f0 + k) * plane_stride + r] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (f0 + k < F) {
+                const float d = v[k] - mean[f0 + k];
+                tile[(f0 + k) * (PACK_ROWS + 1) + threadIdx.x] = (r < R) ? d / std[f0 + k] : 0.f;
+            }
+    }
+    __syncthreads();
+    const int64_t rows_here = (R - r0 < PACK_ROWS) ? (R - r0) : PACK_ROWS;
+    const int64_t total = rows_here * F;
+    float* dst = out + r0 * F;
+    int row = threadIdx.x / F, f = threadIdx.x - row * F;
+    const int drow = 256 / F, df = 256 - drow * F;
+    for (int64_t j = threadIdx.x; j < total; j += 256) {
+        dst[j] = tile[f * (PACK_ROWS + 1) + row];
+        row += drow;
+        f += df;
+        if (f >= F) { f -= F; ++row; }
+    }
+}
+
+extern "C" int p4c_unnormalize(const float* x, const float* std, const float* mean, float* out, int64_t rows, int F,
+                               p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && std && mean && out, "p4c_unnormalize: null pointer");
+    P4C_CHECK_ARG(rows > 0 && F > 0, "p4c_unnormalize: bad dims");
+    const int64_t total = rows * F;
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(unnormalize_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, std, mean, out, total, F);
+    P4C_CHECK_LAUNCH("p4c_unnormalize");
+    return P4C_OK;
+}
+
+extern "C" int p4c_pack_standardize(const float* raw, int64_t plane_stride, const float* mean, const float* std, float* out,
+                                    int64_t rows, int F, p4c_stream_t stream) {
+    P4C_CHECK_ARG(raw && mean && std && out, "p4c_pack_standardize: null pointer");
+    P4C_CHECK_ARG(rows > 0 && F > 0 && plane_stride >= rows, "p4c_pack_standardize: bad dims");
+    P4C_CHECK_ARG((rows + PACK_ROWS - 1) / PACK_ROWS < ((int64_t)1 << 31), "p4c_pack_standardize: too many rows");
+    P4C_CHECK_ARG(F <= 144, "p4c_pack_standardize: at most 144 features per call (LDS tile)");
+    const size_t smem = (size_t)F * (PACK_ROWS + 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)pack_standardize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * (PACK_ROWS + 1) * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pack_standardize_kernel, dim3((unsigned)((rows + PACK_ROWS - 1) / PACK_ROWS)), dim3(256), smem,
+                       as_stream(stream), raw, plane_stride, mean, std, out, rows, F);
+    P4C_CHECK_LAUNCH("p4c_pack_standardize");
+    return P4C_OK;
+}
+
 extern "C" int p4c_build_x_bwd(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N,
                                int F, p4c_stream_t stream) {
     P4C_CHECK_ARG(dx && dprev, "p4c_build_x_bwd: null pointer");

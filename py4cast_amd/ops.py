@@ -310,3 +310,40 @@ def ar_step_loss(prev, y, target, std, mean, border_mask, interior_mask, weights
                  mask_mode, keep_prev, force_border):
     return _ARStepLoss.apply(prev, y, target, std, mean, border_mask, interior_mask, weights, num_interior,
                              count, kind, mask_mode, keep_prev, force_border)
+
+
+# ------------------------------------------------------------------------------------------------ rows next to the path
+def unnormalize(x: torch.Tensor, std: torch.Tensor, mean: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """out = x*std + mean per feature (last dim), as the reference's two in-place passes (lightning.py:1162-1169)."""
+    L.require_cuda(x)
+    x = x.contiguous().float()
+    F = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    L.call("p4c_unnormalize", L.ptr(x), L.ptr(std.to(x).contiguous()), L.ptr(mean.to(x).contiguous()), L.ptr(out),
+           x.numel() // F, F, L.stream(x.device))
+    return out
+
+
+def acc_sums(pred: torch.Tensor, target: torch.Tensor, spec: "MaskSpec", climate_means: torch.Tensor) -> torch.Tensor:
+    """Spatial means of (p-c)(t-c)m, ((p-c)m)^2, ((t-c)m)^2 -> (3,B,T,F) (MetricACC.update, metrics.py:414-423)."""
+    L.require_cuda(pred, target)
+    p, g = pred.contiguous().float(), target.contiguous().float()
+    B, T, F = p.shape[0], p.shape[1], p.shape[-1]
+    N = p.numel() // (B * T * F)
+    out = torch.empty(3, B, T, F, dtype=torch.float32, device=p.device)
+    ws = torch.empty(3 * L.lib().p4c_loss_workspace_bytes(B, T, N, F) // 4, dtype=torch.float32, device=p.device)
+    L.call("p4c_acc_sums", L.ptr(p), T * N * F, N * F, L.ptr(g), T * N * F, N * F, L.ptr(spec.tensor), spec.mode,
+           L.ptr(climate_means.to(p).contiguous()), L.ptr(out), L.ptr(ws), B, T, N, F, L.stream(p.device))
+    return out
+
+
+def pack_standardize(raw: torch.Tensor, mean: torch.Tensor, std: torch.Tensor) -> torch.Tensor:
+    """raw (F, *lead) parameter planes -> (*lead, F) standardised features-last tensor (base.py:448-452 + concat)."""
+    L.require_cuda(raw)
+    raw = raw.contiguous().float()
+    F = raw.shape[0]
+    rows = raw.numel() // F
+    out = torch.empty(*raw.shape[1:], F, dtype=torch.float32, device=raw.device)
+    L.call("p4c_pack_standardize", L.ptr(raw), rows, L.ptr(mean.to(raw).contiguous()), L.ptr(std.to(raw).contiguous()),
+           L.ptr(out), rows, F, L.stream(raw.device))
+    return out

@@ -1,0 +1,103 @@
+"""GPU parity of the rows next to the hot path: kernels vs the oracle and the reference's golden vectors."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_unnormalize_bit_exact_vs_reference(gpu_device):
+    from py4cast_amd import ops
+
+    z = np.load(os.path.join(GOLD, "next_unnormalize.npz"))
+    x = torch.from_numpy(z["x"]).to(gpu_device)
+    out = ops.unnormalize(x, torch.from_numpy(z["std"]).to(gpu_device), torch.from_numpy(z["mean"]).to(gpu_device))
+    assert np.array_equal(out.cpu().numpy(), z["out"])  # two rounded steps, no FMA
+    # in place, benchmark-sized feature count, odd row count
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(3, 2, 33, 17, 60, generator=g)
+    std, mean = torch.rand(60, generator=g) + 0.5, torch.randn(60, generator=g)
+    ref = y.clone(); ref *= std; ref += mean
+    yd = y.to(gpu_device)
+    r = ops.unnormalize(yd, std.to(gpu_device), mean.to(gpu_device), out=yd)
+    assert r.data_ptr() == yd.data_ptr() and torch.equal(yd.cpu(), ref)
+
+
+def test_pack_standardize_bit_exact_vs_reference(gpu_device):
+    from py4cast_amd import ops
+    from py4cast_amd.datapipe import load_batch
+    from py4cast_amd.namedtensor import NamedTensor
+
+    z = np.load(os.path.join(GOLD, "next_pack.npz"))
+    raw = torch.from_numpy(z["raw"]).to(gpu_device)
+    full = ops.pack_standardize(raw, torch.from_numpy(z["mean"]).to(gpu_device), torch.from_numpy(z["std"]).to(gpu_device))
+    assert np.array_equal(full[:, :1].cpu().numpy(), z["inputs"]) and np.array_equal(full[:, 1:].cpu().numpy(), z["outputs"])
+
+    class Stats:
+        def to_list(self, stat, names, dtype=torch.float32):
+            return torch.from_numpy(z[stat]).type(dtype)
+
+    names = [f"p{i}" for i in range(raw.shape[0])]
+    forcing = NamedTensor(torch.zeros(2, 3, 6, 5, 1, device=gpu_device), ["batch", "timestep", "lat", "lon", "features"], ["x"])
+    batch = load_batch(raw, names, forcing, Stats(), num_input_steps=1)
+    assert batch.num_input_steps == 1 and batch.num_pred_steps == 3 and batch.batch_size == 2
+    assert np.array_equal(batch.outputs.tensor.cpu().numpy(), z["outputs"])
+    # ragged sizes: rows not a multiple of 64, features not a multiple of 32
+    g = torch.Generator().manual_seed(2)
+    r2 = torch.randn(37, 2, 1, 9, 11, generator=g) * 7 + 3
+    m2, s2 = torch.randn(37, generator=g), torch.rand(37, generator=g) + 0.3
+    ref = torch.stack([(r2[f] - m2[f]) / s2[f] for f in range(37)], dim=-1)
+    out = ops.pack_standardize(r2.to(gpu_device), m2.to(gpu_device), s2.to(gpu_device))
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_metric_acc_matches_reference(gpu_device):
+    from py4cast_amd.metrics import MetricACC
+    from py4cast_amd.namedtensor import NamedTensor
+
+    z = np.load(os.path.join(GOLD, "next_acc.npz"))
+    F = z["clim"].shape[0]
+    names = [f"f{i}" for i in range(F)]
+
+    class Stats:
+        def to_list(self, stat, ns, dtype=torch.float32):
+            return torch.from_numpy(z["clim"]).type(dtype)
+
+    class Info:
+        shortnames = {"input_output": names[:3], "output": names[3:]}
+        stats = Stats()
+
+    with pytest.warns(UserWarning):
+        m = MetricACC(Info())
+    dims = ["batch", "timestep", "lat", "lon", "features"]
+    for step in range(2):
+        p = NamedTensor(torch.from_numpy(z[f"pred{step}"]).to(gpu_device), dims, names)
+        t = NamedTensor(torch.from_numpy(z[f"target{step}"]).to(gpu_device), dims, names)
+        m.update(p, t, torch.from_numpy(z[f"mask{step}"]).to(gpu_device))
+        np.testing.assert_allclose(m.sum_acc.cpu().numpy(), z[f"sum_acc{step}"], rtol=2e-5, atol=2e-6)
+    res = m.compute(prefix="val")
+    keys = sorted(res)
+    assert keys == list(z["compute_keys"])
+    np.testing.assert_allclose(np.array([float(res[k]) for k in keys], dtype=np.float32), z["compute_vals"], rtol=2e-5, atol=2e-6)
+    assert m.step_count == 0  # compute() resets, as the reference
+
+
+def test_acc_sums_full_size_properties(gpu_device):
+    """At the benchmark size: ACC(x, x) = 1 for every (t, f); shifting both by the climate mean leaves it unchanged."""
+    from py4cast_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, T, H, W, F = 1, 1, 512, 512, 60
+    x = torch.randn(B, T, H, W, F, generator=g).to(gpu_device)
+    clim = torch.randn(F, generator=g).to(gpu_device)
+    s = ops.acc_sums(x, x, ops.MaskSpec(0), clim)
+    acc = s[0] / torch.sqrt(s[1] * s[2])
+    assert torch.allclose(acc, torch.ones_like(acc), atol=1e-5)
+    y = torch.randn(B, T, H, W, F, generator=g).to(gpu_device)
+    a1 = ops.acc_sums(x + clim, y + clim, ops.MaskSpec(0), clim)
+    a0 = ops.acc_sums(x, y, ops.MaskSpec(0), torch.zeros_like(clim))
+    assert torch.allclose(a1, a0, rtol=1e-4, atol=1e-6)

@@ -95,3 +95,44 @@ def test_combined_scaled_member_raises_like_reference():
     p = torch.zeros(2, 3, 4, 4, 5)
     with pytest.raises(RuntimeError):
         olosses.combined_loss(p, p, torch.ones_like(p), [("ScaledLoss", 1.0, dict(std=torch.ones(5), interior_mask=torch.ones(4, 4, 1)))])
+
+
+# ------------------------------------------------------------------------------------------ rows next to the path (8f)
+def _load_next(name):
+    import os
+
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name), allow_pickle=False)
+
+
+def test_oracle_acc_matches_reference():
+    from oracle.next_rows import acc_compute, acc_update
+
+    z = _load_next("next_acc.npz")
+    clim = torch.from_numpy(z["clim"])
+    total = None
+    for step in range(2):
+        inc = acc_update(torch.from_numpy(z[f"pred{step}"]), torch.from_numpy(z[f"target{step}"]),
+                         torch.from_numpy(z[f"mask{step}"]), clim)
+        total = inc if total is None else total + inc
+        np.testing.assert_allclose(total.numpy(), z[f"sum_acc{step}"], rtol=1e-6, atol=1e-7)
+    names = [f"f{i}" for i in range(clim.numel())]
+    res = acc_compute(total, 2.0, names, "val")
+    keys = sorted(res)
+    assert keys == list(z["compute_keys"])
+    np.testing.assert_allclose(np.array([float(res[k]) for k in keys], dtype=np.float32), z["compute_vals"], rtol=1e-6)
+
+
+def test_oracle_unnormalize_matches_reference_bit_exact():
+    from oracle.next_rows import unnormalize
+
+    z = _load_next("next_unnormalize.npz")
+    out = unnormalize(torch.from_numpy(z["x"]), torch.from_numpy(z["std"]), torch.from_numpy(z["mean"]))
+    assert np.array_equal(out.numpy(), z["out"])
+
+
+def test_oracle_standardize_pack_matches_reference_bit_exact():
+    from oracle.next_rows import standardize_pack
+
+    z = _load_next("next_pack.npz")
+    full = standardize_pack(z["raw"], z["mean"], z["std"])
+    assert np.array_equal(full[:, :1], z["inputs"]) and np.array_equal(full[:, 1:], z["outputs"])
