@@ -7,6 +7,10 @@
 //   compute = P4C_BF16 : bf16 matrix cores (conv_bf16.hip); activations / activation gradients stored
 //                        fp32 (dtype = P4C_F32) or bf16 (dtype = P4C_BF16).  Parameters, statistics,
 //                        normalisation coefficients and weight gradients are always fp32.
+#include <stdlib.h>
+
+#include <vector>
+
 #include "kernels.hpp"
 
 namespace p4c {
@@ -29,7 +33,7 @@ struct Layout {
     // saved workspace: activations (element offsets) then normalisation arrays (float offsets from norm_base bytes)
     int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
     // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
-    int64_t wprep, statp, wgradp, nbwdp, k1, k2, f_floats, g_base, G0, G1, G2, TB, scratch_bytes;
+    int64_t wprep, statp, wgradp, nbwdp, k1, k2, f_floats, g_base, G0, G1, G2, TB, DY[NCONV], scratch_bytes;
     int G;  // persistent workgroups of the weight-gradient kernel
 };
 
@@ -124,6 +128,9 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     L.G1 = off; off += L.n[0] * NF;
     L.G2 = off; off += L.n[0] * NF;
     L.TB = off; off += L.n[0] * NF;  // x-pass outputs of the four up-sampling adjoints: n0*NF*(1/2+1/4+1/8+1/16)
+    // dY (gradient wrt the raw conv output) of every conv block in its own buffer: the weight-gradient kernels read them
+    // from a side stream while the main stream already overwrites the rotating buffers G0..G2
+    for (int i = 0; i < NCONV; ++i) { L.DY[i] = off; off += L.n[conv_level(i)] * NF; }
     L.scratch_bytes = L.g_base + off * L.esz;
 }
 
@@ -193,24 +200,67 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     return P4C_OK;
 }
 
+// Side stream for the weight gradients.  Nothing on the backward chain waits for a weight gradient, and half of that
+// chain is latency-bound work on the coarse levels that occupies a few CUs: the weight-gradient kernels (+ their
+// reductions) are enqueued on a second stream, ordered after the dY they read by an event, and joined back into the
+// caller's stream at the end of the call.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> events;
+    size_t next = 0;
+    bool enabled = true;
+    int init() {
+        if (stream) return P4C_OK;
+        const char* e = getenv("P4C_SIDE_STREAM");
+        enabled = !(e && e[0] == '0');
+        if (!enabled) return P4C_OK;
+        P4C_CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return P4C_OK;
+    }
+    int event(hipEvent_t* ev) {
+        if (next == events.size()) {
+            hipEvent_t e;
+            P4C_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            events.push_back(e);
+        }
+        *ev = events[next++];
+        return P4C_OK;
+    }
+    // make `to` wait for everything enqueued on `from` so far
+    int order(hipStream_t from, hipStream_t to) {
+        hipEvent_t ev;
+        P4C_TRY(event(&ev));
+        P4C_CHECK_HIP(hipEventRecord(ev, from));
+        P4C_CHECK_HIP(hipStreamWaitEvent(to, ev, 0));
+        return P4C_OK;
+    }
+};
+thread_local SideStream g_side;
+
 // backward through [conv i -> norm -> relu] given dA (grad wrt the post-ReLU activation) in `g`:
-//   g := dY (in place); grads of gamma/beta/weight accumulated; if `din` != null: din = dL/d(conv input)
+//   dY -> its own buffer; grads of gamma/beta/weight accumulated; if `din` != null: din = dL/d(conv input)
 int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, const void* in, const Norm* in_norm, void* din,
                    const float* params, float* grads, int training, hipStream_t st) {
     const Layout& L = ws.L;
     const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
     Norm nm = norm_at(ws, i, d.B);
     const int stats_training = (d.norm == 1) || training;
+    void* dY = ws.g(L.DY[i]);
     P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
                      (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1), ws.f(L.k2),
-                     grads + L.gamma[i], grads + L.beta[i], g, st));
+                     grads + L.gamma[i], grads + L.beta[i], dY, st));
     const int cip = conv_cin_pad(d, i);
     int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
     const int G = ntiles < L.G ? (int)ntiles : L.G;
+    hipStream_t wst = st;
+    if (g_side.enabled) {
+        P4C_TRY(g_side.order(st, g_side.stream));   // the weight gradient starts once dY is complete
+        wst = g_side.stream;
+    }
     P4C_TRY(conv_wgrad(d.compute, d.dtype, in, cip, 3, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
-                       in_norm ? 1 : 0, g, ws.f(L.wgradp), G, d.B, H, W, NF, conv_cin(d, i), grads + L.w[i], st));
+                       in_norm ? 1 : 0, dY, ws.f(L.wgradp), G, d.B, H, W, NF, conv_cin(d, i), grads + L.w[i], wst));
     if (din) {
-        P4C_TRY(conv_fwd(d.compute, d.dtype, g, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, nullptr, d.B, H, W, 1, st));
+        P4C_TRY(conv_fwd(d.compute, d.dtype, dY, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, nullptr, d.B, H, W, 1, st));
     }
     return P4C_OK;
 }
@@ -301,14 +351,21 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     const WS ws{L, (char*)savedv, (char*)scratchv};
     void *G0 = ws.g(L.G0), *G1 = ws.g(L.G1), *G2 = ws.g(L.G2), *TB = ws.g(L.TB);
     if (!d.weights_prepared) P4C_TRY(prepare_weights(d, ws, params, 2, st));
+    P4C_TRY(g_side.init());
+    g_side.next = 0;
 
     // ---- output 1x1 conv
     Norm nd2 = norm_at(ws, 11, d.B);
     {
         int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(d.H, d.W);
         const int G = ntiles < L.G ? (int)ntiles : L.G;
+        hipStream_t wst = st;
+        if (g_side.enabled) {
+            P4C_TRY(g_side.order(st, g_side.stream));   // after everything the caller enqueued before this call (dy, ...)
+            wst = g_side.stream;
+        }
         P4C_TRY(conv_wgrad(d.compute, d.dtype, ws.act(L.Y[11]), NF, 1, nd2.scale, nd2.shift, 1, dy, ws.f(L.wgradp), G, d.B, d.H,
-                           d.W, d.cout, NF, grads + L.wout, st));
+                           d.W, d.cout, NF, grads + L.wout, wst));
         P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
     }
     // ---- decoder
@@ -346,6 +403,8 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
             P4C_TRY(conv_block_bwd(d, ws, 0, a, x, nullptr, d.dx_channels > 0 ? dx : nullptr, params, grads, training, st));
         }
     }
+    // join: the caller's stream continues only after every weight gradient of this call has been accumulated
+    if (g_side.enabled) P4C_TRY(g_side.order(g_side.stream, st));
     return P4C_OK;
 }
 
