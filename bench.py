@@ -214,7 +214,7 @@ def main():
     timed = getattr(lm.model, "timed_entry_points", None) or (
         "p4c_build_x", "p4c_ar_update_fwd", "p4c_weighted_loss_fwd", "p4c_weighted_loss_bwd", "p4c_ar_update_bwd")
     L.enable_kernel_timing(timed)
-    L.lib().p4c_prof_enable(3, 4096)
+    L.lib().p4c_prof_enable(7, 4096)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):

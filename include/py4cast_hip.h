@@ -65,8 +65,9 @@ int p4c_num_cus(void);
  * Disabled by default; p4c_prof_enable(0,0) disables and frees the events.  Not graph-capturable while on.
  * `units` of a record = output pixels (B*H*W) of that launch. */
 enum p4c_prof_tag {
-    P4C_PROF_CONV3X3_C64 = 1, /* conv 3x3, 64 -> 64 channels (forward and data-gradient launches) */
-    P4C_PROF_WGRAD3X3_C64 = 2 /* weight gradient of the same */
+    P4C_PROF_CONV3X3_C64 = 1,     /* conv 3x3, 64 -> 64 channels: launches of the forward plan (nothing else runs beside them) */
+    P4C_PROF_WGRAD3X3_C64 = 2,    /* weight gradient of the same (side stream of the backward plan: overlaps other kernels) */
+    P4C_PROF_CONV3X3_C64_BWD = 4  /* the same conv kernel evaluating data gradients in the backward plan (overlapped likewise) */
 };
 int p4c_prof_enable(int tag_mask, int max_records);
 /* sums over the finished records of `tag` with units >= min_units; synchronises on their events */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("P4C_LIB_PATH") or os.path.join(_HERE, "libpy4cast_hip.so")  # override: diagnostic builds
 
 F32, BF16 = 0, 1
-PROF_CONV3X3_C64, PROF_WGRAD3X3_C64 = 1, 2
+PROF_CONV3X3_C64, PROF_WGRAD3X3_C64, PROF_CONV3X3_C64_BWD = 1, 2, 4
 LOSS_MSE, LOSS_L1 = 0, 1
 MASK_NONE, MASK_FROM_NAN, MASK_F32, MASK_U8 = 0, 1, 2, 3
 

@@ -44,6 +44,8 @@ int num_cus();
 // (bench.py roofline leg; see p4c_prof_enable in include/py4cast_hip.h).  No-ops unless enabled.
 void prof_begin(int tag, int64_t units, hipStream_t stream);
 void prof_end(int tag, hipStream_t stream);
+// launches issued by the backward plan are recorded under the *_BWD tag (they overlap the side-stream weight gradients)
+void prof_set_backward(bool on);
 
 // ---------------------------------------------------------------- device helpers
 typedef __hip_bfloat16 bf16;

@@ -353,6 +353,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     if (!d.weights_prepared) P4C_TRY(prepare_weights(d, ws, params, 2, st));
     P4C_TRY(g_side.init());
     g_side.next = 0;
+    struct BwdPhase { BwdPhase() { prof_set_backward(true); } ~BwdPhase() { prof_set_backward(false); } } bwd_phase;
 
     // ---- output 1x1 conv
     Norm nd2 = norm_at(ws, 11, d.B);

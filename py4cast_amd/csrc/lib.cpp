@@ -40,7 +40,12 @@ static int g_prof_mask = 0;
 static size_t g_prof_cap = 0;
 static std::mutex g_prof_mu;
 
+static thread_local bool g_prof_bwd = false;
+void prof_set_backward(bool on) { g_prof_bwd = on; }
+static inline int phase_tag(int tag) { return (tag == P4C_PROF_CONV3X3_C64 && g_prof_bwd) ? P4C_PROF_CONV3X3_C64_BWD : tag; }
+
 void prof_begin(int tag, int64_t units, hipStream_t stream) {
+    tag = phase_tag(tag);
     if (!(g_prof_mask & tag)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof.size() >= g_prof_cap) return;
@@ -51,6 +56,7 @@ void prof_begin(int tag, int64_t units, hipStream_t stream) {
 }
 
 void prof_end(int tag, hipStream_t stream) {
+    tag = phase_tag(tag);
     if (!(g_prof_mask & tag)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (size_t i = g_prof.size(); i-- > 0;)

@@ -378,6 +378,35 @@ def test_halfunet_bf16_close_to_fp32_oracle(gpu_device):
         assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.9, name
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 202, 72), (9, 24, 40), (2, 512, 64)])
+def test_ring_conv_workgroups_walking_strips_and_samples(gpu_device, B, H, W):
+    """3x3 64->64 bf16 conv where a persistent workgroup owns SEVERAL tiles: rows inherited through the LDS ring while
+    walking down a strip, fresh starts at strip / sample changes, partial last tiles (H % 4, W % 32 != 0), statistics
+    flushed per sample; B = 9 exceeds the ring kernel's per-launch sample limit and takes the generic kernel."""
+    from py4cast_amd import ops_model as om
+
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, 64, generator=g).bfloat16()
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.1
+    scale = torch.rand(B, 64, generator=g) + 0.5
+    shift = torch.randn(B, 64, generator=g) * 0.3
+    wp = om.prep_weights(w.to(gpu_device), False, 64, 64, compute="bf16")
+    for transform in (False, True):
+        xin = torch.relu(x.float() * scale[:, None, None, :] + shift[:, None, None, :]) if transform else x.float()
+        ref = Fn.conv2d(_bf(xin).permute(0, 3, 1, 2), _bf(w), padding=1).permute(0, 2, 3, 1)
+        out, stats = om.conv_fwd(x.to(gpu_device), wp, 3, in_scale=scale.to(gpu_device) if transform else None,
+                                 in_shift=shift.to(gpu_device) if transform else None, in_relu=transform, want_stats=True,
+                                 compute="bf16")
+        assert rel_err(out.float(), ref) < 8e-3
+        # per-pixel check catches a misplaced ring row (a whole row of wrong values) that a norm could average away
+        err = (out.float().cpu().double() - ref).abs().amax(dim=-1)
+        assert float(err.max()) < 0.25, (float(err.max()), torch.nonzero(err > 0.25)[:4])
+        o64 = out.cpu().double()
+        s = stats.cpu().double().reshape(B, -1, 2, 64).sum(1)   # per-sample statistics
+        np.testing.assert_allclose(s[:, 0].numpy(), o64.sum((1, 2)).numpy(), rtol=2e-3, atol=0.5)
+        np.testing.assert_allclose(s[:, 1].numpy(), (o64 * o64).sum((1, 2)).numpy(), rtol=1e-2)
+
+
 @pytest.mark.parametrize("CI,CIreal,ks,H,W", [(64, 64, 3, 16, 32), (96, 69, 3, 20, 40), (32, 10, 3, 8, 8), (64, 64, 1, 12, 36), (64, 64, 3, 40, 72)])
 def test_conv_bf16_storage(gpu_device, CI, CIreal, ks, H, W):
     """bf16 activation storage: inputs, outputs and gradients-of-activations live in HBM as bf16 (fp32 accumulate);
