@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(256) build_x_kernel(const float* __restrict__ 
 // output row; quads lying wholly inside the previous-state or statics block are one 16-byte load, the rest
 // (forcing rows are 5 floats = unaligned) are gathered element by element.  Stores are always 16 bytes.
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte access (forcing rows)
 
 template <typename TX>
 __global__ void __launch_bounds__(256)
@@ -109,17 +110,26 @@ __global__ void __launch_bounds__(256)
     const int o_stat = n_prev_ch, o_forc = n_prev_ch + Fs, c_in = n_prev_ch + Fs + Ff;
     const int64_t total = N;
     if (c0 >= c_pad) return;
-    // classify the quad once (it is the same for every grid point)
-    int kind = 3;  // 0: vector prev, 1: vector statics, 2: all zero padding, 3: per-element gather
-    int t_idx = 0, f_idx = 0;
-    if (c0 + 3 < o_stat && vec_prev) {
-        t_idx = c0 / F;
-        f_idx = c0 - t_idx * F;
-        if (f_idx + 3 < F) kind = 0;
-    } else if (c0 >= o_stat && c0 + 3 < o_forc && vec_stat) {
-        kind = 1;
-    } else if (c0 >= c_in) {
+    // classify the quad once (it is the same for every grid point): every lane ends up with ONE source row pointer and
+    // row stride, so the whole wave runs the same load instruction (no per-source branches in the loop):
+    //   kind 0: 4 values from one source tensor (state / statics / forcing; forcing rows are 4-byte aligned only, which
+    //           a global dwordx4 load accepts);  kind 1: the last 1..3 values of the forcing row (scalar loads);
+    //   kind 2: zero padding;  kind 3: a quad straddling two sources (generic per-element gather)
+    int kind = 3, nvalid = 0;
+    const float* src = nullptr;
+    int64_t rstride = 0;
+    if (c0 >= c_in) {
         kind = 2;
+    } else if (c0 + 3 < o_stat) {
+        const int t_idx = c0 / F, f_idx = c0 - t_idx * F;
+        if (vec_prev && f_idx + 3 < F) { kind = 0; src = prev + (int64_t)b * prev_bs + (int64_t)t_idx * prev_ts + f_idx; rstride = F; }
+    } else if (c0 >= o_stat && c0 + 3 < o_forc) {
+        if (vec_stat) { kind = 0; src = statics + (int64_t)b * statics_bs + (c0 - o_stat); rstride = Fs; }
+    } else if (c0 >= o_forc) {
+        src = forcing + (int64_t)b * forcing_bs + (c0 - o_forc);
+        rstride = Ff;
+        nvalid = c_in - c0 < 4 ? c_in - c0 : 4;
+        kind = nvalid == 4 ? 0 : 1;
     }
     // 4 grid points per thread and trip: the 4 loads are independent and all issued before the first store
     // (memory-level parallelism; one load in flight per lane left this pass latency-bound)
@@ -132,9 +142,12 @@ __global__ void __launch_bounds__(256)
             v[u] = v4f{0.f, 0.f, 0.f, 0.f};
             if (n >= total) continue;
             if (kind == 0) {
-                v[u] = *reinterpret_cast<const v4f*>(prev + (int64_t)b * prev_bs + (int64_t)t_idx * prev_ts + n * F + f_idx);
+                v[u] = *reinterpret_cast<const v4f_a4*>(src + n * rstride);
             } else if (kind == 1) {
-                v[u] = *reinterpret_cast<const v4f*>(statics + (int64_t)b * statics_bs + n * Fs + (c0 - o_stat));
+                const float* p = src + n * rstride;
+                v[u][0] = p[0];
+                if (nvalid > 1) v[u][1] = p[1];
+                if (nvalid > 2) v[u][2] = p[2];
             } else if (kind == 3) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
