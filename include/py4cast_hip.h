@@ -194,6 +194,19 @@ int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const void* y, in
                            int mask_mode, float* loss_out, int64_t loss_stride, void* workspace, int B, int64_t N,
                            int F, float keep_prev, p4c_stream_t stream);
 
+/* The same step, additionally emitting the NEXT AR step's network input x_next (B,N,c_pad) in the dtype / padded
+ * layout of p4c_build_x with T_in = 1: [new state (F) | statics (Fs) | forcing of the next step (Ff) | zeros], so the
+ * state just computed is not read back by a separate p4c_build_x ("feed next step", lightning.py:636-656 + 711-767).
+ * x_next has the dtype of y.  Needs the 16-byte path (F % 4 == 0, F <= 64, Fs % 4 == 0, aligned rows) and
+ * mask_mode == P4C_MASK_NONE; returns P4C_ERR_UNSUPPORTED otherwise (call p4c_build_x then). */
+int p4c_ar_update_loss_fwd_next(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                                const float* target, int64_t tgt_bs, const float* std, const float* mean,
+                                const float* border_mask, const float* interior_mask, float* new_state, int64_t new_bs,
+                                const float* weights, float num_interior, const int32_t* masked_count, int kind,
+                                int mask_mode, float* loss_out, int64_t loss_stride, void* workspace, int B, int64_t N,
+                                int F, float keep_prev, void* x_next, int c_pad, const float* statics, int64_t statics_bs,
+                                int Fs, const float* forcing_next, int64_t forcing_bs, int Ff, p4c_stream_t stream);
+
 /* Backward of the fused step.  g_next: gradient wrt new_state arriving from the later AR step
  * (may be NULL for the last step; g_next2 is an optional second addend with channel stride g2_cs,
  * e.g. the first F channels of the model's dx); gloss: (B) with stride, the upstream gradient of

@@ -41,6 +41,8 @@ SIGNATURES = {
     "p4c_unnormalize": [P, P, P, P, L, I, P],
     "p4c_pack_standardize": [P, L, P, P, P, L, I, P],
     "p4c_ar_update_loss_fwd": [P, L, P, I, I, P, L, P, P, P, P, P, L, P, F, P, I, I, P, L, P, I, L, I, F, P],
+    "p4c_ar_update_loss_fwd_next": [P, L, P, I, I, P, L, P, P, P, P, P, L, P, F, P, I, I, P, L, P, I, L, I, F,
+                                    P, I, P, L, I, P, L, I, P],
     "p4c_ar_update_loss_bwd": [P, L, P, I, I, P, L, P, L, P, L, P, P, I, P, F, P, I, I, P, I, I, P, L, I, L, I, F, P],
 }
 OTHER = {

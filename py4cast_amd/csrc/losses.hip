@@ -399,14 +399,28 @@ __global__ void acc_final_kernel(const float* __restrict__ partial, int nblk, fl
 // 16-byte load/store and a wave covers 64/FP4 grid points per iteration.
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <typename TY>
+// optional extra output of the fused step: the NEXT AR step's network input in the padded layout of p4c_build_x
+// (new state | statics | next step's forcing | zero padding), so that the state just computed is not read again
+struct NextX {
+    void* x;
+    int c_pad;
+    const float* statics;
+    int64_t statics_bs;
+    int Fs;
+    const float* forcing;
+    int64_t forcing_bs;
+    int Ff;
+};
+typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <typename TY, bool NEXT>
 __global__ void __launch_bounds__(256)
     ar_update_loss_fwd_v4_kernel(const float* __restrict__ prev, int64_t prev_bs, const TY* __restrict__ y, int y_cs,
                                  const float* __restrict__ target, int64_t tgt_bs, const float* __restrict__ std,
                                  const float* __restrict__ mean, const float* __restrict__ border_mask,
                                  const float* __restrict__ interior_mask, float* __restrict__ new_state, int64_t new_bs,
                                  const float* __restrict__ weights, int kind, int mask_mode, float* __restrict__ partial,
-                                 int64_t N, int F, float keep_prev, int FP4) {
+                                 int64_t N, int F, float keep_prev, int FP4, NextX nx) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -423,8 +437,39 @@ __global__ void __launch_bounds__(256)
         }
     }
     float acc = 0.0f;
+    // tail quad of the next-step input owned by this lane: channels F + 4q .. +3 (statics, forcing, zero padding)
+    int tkind = 4;  // 0: 16 bytes from one source, 1: last 1..3 forcing values, 2: zeros, 4: none
+    int tvalid = 0;
+    const float* tsrc = nullptr;
+    int64_t tstride = 0;
+    TY* xn = nullptr;
+    if (NEXT) {
+        xn = reinterpret_cast<TY*>(nx.x) + (int64_t)b * N * nx.c_pad;
+        const int c0 = F + 4 * q, o_forc = F + nx.Fs, c_in = F + nx.Fs + nx.Ff;
+        if (c0 < nx.c_pad) {
+            if (c0 >= c_in) tkind = 2;
+            else if (c0 + 3 < o_forc) { tkind = 0; tsrc = nx.statics + (int64_t)b * nx.statics_bs + (c0 - F); tstride = nx.Fs; }
+            else {
+                tsrc = nx.forcing + (int64_t)b * nx.forcing_bs + (c0 - o_forc);
+                tstride = nx.Ff;
+                tvalid = c_in - c0 < 4 ? c_in - c0 : 4;
+                tkind = tvalid == 4 ? 0 : 1;
+            }
+        }
+    }
     const int64_t stride = (int64_t)gridDim.x * 4 * PP;
     for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
+        if (NEXT && tkind != 4) {
+            v4f tq = {0, 0, 0, 0};
+            if (tkind == 0) tq = *reinterpret_cast<const v4f_a4*>(tsrc + n * tstride);
+            else if (tkind == 1) {
+                const float* pf = tsrc + n * tstride;
+                tq[0] = pf[0];
+                if (tvalid > 1) tq[1] = pf[1];
+                if (tvalid > 2) tq[2] = pf[2];
+            }
+            store4f(xn + n * nx.c_pad + F + 4 * q, tq);
+        }
         if (!act) continue;
         const float im = interior_mask[n];
         const float bm = border_mask ? border_mask[n] : 0.0f;
@@ -455,6 +500,7 @@ __global__ void __launch_bounds__(256)
             s += loss_elem(pr, t0, m, kind) * w[j];
         }
         *reinterpret_cast<v4f*>(new_state + (int64_t)b * new_bs + e) = o;
+        if (NEXT) store4f(xn + n * nx.c_pad + 4 * q, o);
         acc += s * im;
     }
     acc = wave_sum(acc);
@@ -797,13 +843,13 @@ extern "C" int p4c_acc_sums(const float* pred, int64_t pred_bs, int64_t pred_ts,
     return P4C_OK;
 }
 
-extern "C" int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
-                                      const float* target, int64_t tgt_bs, const float* std, const float* mean,
-                                      const float* border_mask, const float* interior_mask, float* new_state,
-                                      int64_t new_bs, const float* weights, float num_interior,
-                                      const int32_t* masked_count, int kind, int mask_mode, float* loss_out,
-                                      int64_t loss_stride, void* workspace, int B, int64_t N, int F, float keep_prev,
-                                      p4c_stream_t stream) {
+static int ar_update_loss_fwd_impl(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                                   const float* target, int64_t tgt_bs, const float* std, const float* mean,
+                                   const float* border_mask, const float* interior_mask, float* new_state,
+                                   int64_t new_bs, const float* weights, float num_interior,
+                                   const int32_t* masked_count, int kind, int mask_mode, float* loss_out,
+                                   int64_t loss_stride, void* workspace, int B, int64_t N, int F, float keep_prev,
+                                   const NextX* next, p4c_stream_t stream) {
     P4C_CHECK_ARG(y && target && interior_mask && new_state && weights && loss_out && workspace,
                   "p4c_ar_update_loss_fwd: null pointer");
     P4C_CHECK_ARG(prev || keep_prev == 0.0f, "p4c_ar_update_loss_fwd: prev is null but keep_prev != 0");
@@ -816,20 +862,25 @@ extern "C" int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const 
         aligned16(mean)) {
         const int FP4 = pow2_ge64(F / 4);
         const int nblk4 = loss_blocks(N, 64 / FP4, B);
-        if (y_dtype == P4C_F32)
-            hipLaunchKernelGGL(ar_update_loss_fwd_v4_kernel<float>, dim3(nblk4, B), dim3(256), 0, as_stream(stream), prev, prev_bs,
-                               (const float*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs,
-                               weights, kind, mask_mode, (float*)workspace, N, F, keep_prev, FP4);
-        else
-            hipLaunchKernelGGL(ar_update_loss_fwd_v4_kernel<bf16>, dim3(nblk4, B), dim3(256), 0, as_stream(stream), prev, prev_bs,
-                               (const bf16*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs,
-                               weights, kind, mask_mode, (float*)workspace, N, F, keep_prev, FP4);
+        NextX nx{};
+        if (next) nx = *next;
+#define P4C_LAUNCH_V4(TY, NEXTF)                                                                                              \
+    hipLaunchKernelGGL((ar_update_loss_fwd_v4_kernel<TY, NEXTF>), dim3(nblk4, B), dim3(256), 0, as_stream(stream), prev, prev_bs, \
+                       (const TY*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs, weights,  \
+                       kind, mask_mode, (float*)workspace, N, F, keep_prev, FP4, nx)
+        if (y_dtype == P4C_F32) {
+            if (next) P4C_LAUNCH_V4(float, true); else P4C_LAUNCH_V4(float, false);
+        } else {
+            if (next) P4C_LAUNCH_V4(bf16, true); else P4C_LAUNCH_V4(bf16, false);
+        }
+#undef P4C_LAUNCH_V4
         P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(v4)");
         hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const float*)workspace,
                            nblk4, num_interior, masked_count, loss_out, loss_stride, B);
         P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(final)");
         return P4C_OK;
     }
+    if (next) return fail(P4C_ERR_UNSUPPORTED, "p4c_ar_update_loss_fwd_next: needs the 16-byte path (F %% 4 == 0, F <= 64, aligned rows)");
     const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
     const int nblk = loss_blocks(N, 64 / FP, B);
 #define P4C_LAUNCH_FWD(TY)                                                                                              \
@@ -848,6 +899,37 @@ extern "C" int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const 
                        (const float*)workspace, nblk, num_interior, masked_count, loss_out, loss_stride, B);
     P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(final)");
     return P4C_OK;
+}
+
+extern "C" int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                                      const float* target, int64_t tgt_bs, const float* std, const float* mean,
+                                      const float* border_mask, const float* interior_mask, float* new_state,
+                                      int64_t new_bs, const float* weights, float num_interior,
+                                      const int32_t* masked_count, int kind, int mask_mode, float* loss_out,
+                                      int64_t loss_stride, void* workspace, int B, int64_t N, int F, float keep_prev,
+                                      p4c_stream_t stream) {
+    return ar_update_loss_fwd_impl(prev, prev_bs, y, y_dtype, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask,
+                                   new_state, new_bs, weights, num_interior, masked_count, kind, mask_mode, loss_out,
+                                   loss_stride, workspace, B, N, F, keep_prev, nullptr, stream);
+}
+
+extern "C" int p4c_ar_update_loss_fwd_next(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                                           const float* target, int64_t tgt_bs, const float* std, const float* mean,
+                                           const float* border_mask, const float* interior_mask, float* new_state,
+                                           int64_t new_bs, const float* weights, float num_interior,
+                                           const int32_t* masked_count, int kind, int mask_mode, float* loss_out,
+                                           int64_t loss_stride, void* workspace, int B, int64_t N, int F, float keep_prev,
+                                           void* x_next, int c_pad, const float* statics, int64_t statics_bs, int Fs,
+                                           const float* forcing_next, int64_t forcing_bs, int Ff, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x_next && statics && forcing_next, "p4c_ar_update_loss_fwd_next: null pointer");
+    P4C_CHECK_ARG(c_pad % 4 == 0 && c_pad >= F + Fs + Ff && Fs % 4 == 0 && Fs >= 0 && Ff >= 0,
+                  "p4c_ar_update_loss_fwd_next: c_pad / Fs must be multiples of 4 and c_pad >= F + Fs + Ff");
+    P4C_CHECK_ARG(c_pad / 4 - F / 4 <= pow2_ge64(F / 4), "p4c_ar_update_loss_fwd_next: too many tail channels for one pass");
+    P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE, "p4c_ar_update_loss_fwd_next: the NaN-mask input channel is built by p4c_build_x");
+    NextX nx{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff};
+    return ar_update_loss_fwd_impl(prev, prev_bs, y, y_dtype, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask,
+                                   new_state, new_bs, weights, num_interior, masked_count, kind, mask_mode, loss_out,
+                                   loss_stride, workspace, B, N, F, keep_prev, &nx, stream);
 }
 
 extern "C" int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g_next2, int g2_dtype,

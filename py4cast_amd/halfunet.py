@@ -139,7 +139,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         self.compute_dtype = torch.float32 if settings.compute_dtype == "f32" else torch.bfloat16
         self.act_dtype = torch.float32 if act == "f32" else torch.bfloat16  # dtype of x / y / dy / dx handed to the plan
         self.timed_entry_points = ("p4c_halfunet_forward", "p4c_halfunet_backward", "p4c_build_x",
-                                   "p4c_ar_update_loss_fwd", "p4c_ar_update_loss_bwd")
+                                   "p4c_ar_update_loss_fwd", "p4c_ar_update_loss_fwd_next", "p4c_ar_update_loss_bwd")
 
         # parameters in the order of p4c_halfunet_param_count (include/py4cast_hip.h)
         self._param_slices = []
@@ -407,18 +407,36 @@ class _NativeRolloutFn(torch.autograd.Function):
         # the parameters are fixed for the whole rollout: re-lay / round the weights once, not once per AR step
         L.call("p4c_halfunet_prepare_weights", ctypes.byref(desc), L.ptr(flat), L.ptr(scratch), stream)
         desc.weights_prepared = 1
+        # "feed next step" fused: the update kernel of step i also writes step i+1's network input (new state | statics |
+        # next forcing | padding), so only step 0 runs p4c_build_x.  (The NaN-mask input channel needs p4c_build_x.)
+        lanes = 1
+        while lanes < F // 4:
+            lanes *= 2  # lanes per grid point of the 16-byte update kernel; each also owns one tail quad of x_next
+        fuse_next = ((not mask_on_nan) and F % 4 == 0 and F <= 64 and Fs % 4 == 0 and cpad % 4 == 0
+                     and cpad // 4 - F // 4 <= lanes)
+        x_next = None
         for i in range(T):
-            x = torch.empty(B, H, W, cpad, dtype=adt, device=dev)
-            L.call("p4c_build_x", L.ptr(states[:, i]), sbs_state, N * F, L.ptr(st), sbs, L.ptr(forcing[:, i]), T * N * Ff,
-                   L.ptr(x), acode, cpad, B, 1, N, F, Fs, Ff, mask_on_nan, 0, stream)
+            if x_next is not None:
+                x = x_next
+            else:
+                x = torch.empty(B, H, W, cpad, dtype=adt, device=dev)
+                L.call("p4c_build_x", L.ptr(states[:, i]), sbs_state, N * F, L.ptr(st), sbs, L.ptr(forcing[:, i]), T * N * Ff,
+                       L.ptr(x), acode, cpad, B, 1, N, F, Fs, Ff, mask_on_nan, 0, stream)
             if saved is None or keep_saved:
                 saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
             L.call("p4c_halfunet_forward", ctypes.byref(desc), L.ptr(x), L.ptr(flat), L.ptr(model._running), L.ptr(y),
                    L.ptr(saved), L.ptr(scratch), int(training), stream)
-            L.call("p4c_ar_update_loss_fwd", L.ptr(states[:, i]), sbs_state, L.ptr(y), acode, NF, L.ptr(outputs[:, i]),
-                   T * N * F, L.ptr(std), L.ptr(mean), L.ptr(border_flat if force_border else None), L.ptr(interior_flat),
-                   L.ptr(states[:, i + 1]), sbs_state, L.ptr(weights), num_interior, L.ptr(count), kind, mask_mode,
-                   L.ptr(loss[:, i]), T, L.ptr(ws), B, N, F, 1.0, stream)
+            step_args = (L.ptr(states[:, i]), sbs_state, L.ptr(y), acode, NF, L.ptr(outputs[:, i]),
+                         T * N * F, L.ptr(std), L.ptr(mean), L.ptr(border_flat if force_border else None), L.ptr(interior_flat),
+                         L.ptr(states[:, i + 1]), sbs_state, L.ptr(weights), num_interior, L.ptr(count), kind, mask_mode,
+                         L.ptr(loss[:, i]), T, L.ptr(ws), B, N, F, 1.0)
+            x_next = None
+            if fuse_next and i + 1 < T:
+                x_next = torch.empty(B, H, W, cpad, dtype=adt, device=dev)
+                L.call("p4c_ar_update_loss_fwd_next", *step_args, L.ptr(x_next), cpad, L.ptr(st), sbs, Fs,
+                       L.ptr(forcing[:, i + 1]), T * N * Ff, Ff, stream)
+            else:
+                L.call("p4c_ar_update_loss_fwd", *step_args, stream)
             if keep_saved:
                 xs.append(x)
                 saveds.append(saved)

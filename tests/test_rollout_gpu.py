@@ -231,3 +231,51 @@ def test_common_step_matches_reference_golden(gpu_device, path):
     np.testing.assert_allclose(loss.item(), outs["train_loss"], rtol=1e-4)
     np.testing.assert_allclose(lm.model.w.grad.cpu().numpy(), outs["grad_w"], rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(lm.model.b.grad.cpu().numpy(), outs["grad_b"], rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("F,Ff,Fs,cpad,border", [(60, 5, 4, 96, 0), (12, 7, 4, 24, 2), (20, 4, 8, 32, 0)])
+def test_fused_step_emits_next_input_bit_exact(gpu_device, dtype, F, Ff, Fs, cpad, border):
+    """p4c_ar_update_loss_fwd_next: same new state and loss as p4c_ar_update_loss_fwd, and its x_next is bit-identical to
+    p4c_build_x applied to that new state ("feed next step", lightning.py:636-656 + 711-767)."""
+    import ctypes
+
+    from py4cast_amd import _lib as L
+    from py4cast_amd import ops
+
+    g = torch.Generator().manual_seed(F * 7 + Ff)
+    B, H, W, T = 2, 24, 20, 2
+    N = H * W
+    dev = gpu_device
+    prev = torch.randn(B, H, W, F, generator=g).to(dev)
+    y = (torch.randn(B, H, W, 64, generator=g)).to(dev).to(dtype)
+    target = torch.randn(B, H, W, F, generator=g).to(dev)
+    statics = torch.rand(B, H, W, Fs, generator=g).to(dev)
+    forcing_next = (torch.rand(B, H, W, Ff, generator=g) * 100).to(dev)
+    std, mean = (torch.rand(F, generator=g) + 0.5).to(dev), (torch.randn(F, generator=g) * 0.01).to(dev)
+    weights = (torch.rand(F, generator=g) + 0.5).to(dev)
+    bm = torch.zeros(H, W)
+    if border:
+        bm[:border] = 1; bm[-border:] = 1; bm[:, :border] = 1; bm[:, -border:] = 1
+    border_flat, interior_flat = bm.reshape(-1).to(dev), (1 - bm).reshape(-1).to(dev)
+    num_interior = float(interior_flat.sum())
+    acode = L.dtype_code(dtype)
+    ws = torch.empty(L.lib().p4c_loss_workspace_bytes(B, 1, N, 1) // 4, dtype=torch.float32, device=dev)
+    stream = L.stream(dev)
+    outs = {}
+    for fused in (False, True):
+        new = torch.empty(B, H, W, F, device=dev)
+        loss = torch.empty(B, device=dev)
+        args = (L.ptr(prev), N * F, L.ptr(y), acode, 64, L.ptr(target), N * F, L.ptr(std), L.ptr(mean),
+                L.ptr(border_flat if border else None), L.ptr(interior_flat), L.ptr(new), N * F, L.ptr(weights), num_interior,
+                None, L.LOSS_MSE, L.MASK_NONE, L.ptr(loss), 1, L.ptr(ws), B, N, F, 1.0)
+        xn = None
+        if fused:
+            xn = torch.full((B, H, W, cpad), float("nan"), device=dev).to(dtype)
+            L.call("p4c_ar_update_loss_fwd_next", *args, L.ptr(xn), cpad, L.ptr(statics), N * Fs, Fs, L.ptr(forcing_next), N * Ff, Ff, stream)
+        else:
+            L.call("p4c_ar_update_loss_fwd", *args, stream)
+        outs[fused] = (new, loss, xn)
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    ref_x = ops.build_x(outs[False][0][:, None], statics, forcing_next, c_pad=cpad, dtype=dtype)
+    assert torch.equal(outs[True][2], ref_x)
