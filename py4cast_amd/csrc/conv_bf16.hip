@@ -35,7 +35,7 @@ constexpr int BTW = 32;  // tile width in pixels
 #define P4C_PRIO 0  // diagnostic builds only: static wave priority of the memory-side (1, 3) or matrix (2) waves
 #endif
 #ifndef P4C_EXP
-#define P4C_EXP 0  // diagnostic builds only (scratch/exp_build.sh): bit mask of pipeline stages to leave out
+#define P4C_EXP 0  // diagnostic builds only (tools/diagnostics/exp_build.sh): bit mask of pipeline stages to leave out
 #endif
 
 #ifdef P4C_STAMPS  // diagnostic build only: per-iteration s_memtime stamps of one compute and one loader wave
@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(512, 2)
 // 512 threads: waves 0-3 run the matrix phase, waves 4-7 the memory side (global -> registers -> normalise/ReLU ->
 // LDS ring, and LDS staging -> HBM + channel statistics).  On a SIMD the scarce resource is VECTOR ISSUE: an MFMA
 // holds it for 8 of its 32 cycles, every other vector instruction of EITHER wave for ~4, so the two roles overlap
-// only while their non-MFMA instructions fit the 24 free cycles per MFMA (stage-removal runs, scratch/conv_exp.py:
+// only while their non-MFMA instructions fit the 24 free cycles per MFMA (stage-removal runs, tools/diagnostics/conv_exp.py:
 // the roles' times ADDED up).  The design therefore minimises instructions, not bytes:
 //   * WEIGHTS STATIONARY IN REGISTERS: a compute wave owns 32 output channels x 2 tile rows and keeps its
 //     9 taps x 64 input channels of weights (36 A operands, 144 VGPRs) for the whole launch; per MFMA it reads ONE
@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             };
             issue(0, 0);
             issue(1, 1);
-            // one B read (for stage s+2) in each MFMA gap of stage s: the micro-benchmark (scratch/micro/mfma_rate.hip)
+            // one B read (for stage s+2) in each MFMA gap of stage s: the micro-benchmark (tools/diagnostics/mfma_rate.hip)
             // runs 36 cycles per MFMA in this shape against 48 when the 4 reads and the 4 MFMAs of a stage go in bursts
             auto issue1 = [&](int s, int buf, int j) __attribute__((always_inline)) {
                 const int tap = s >> 1, ky = tap / 3, kx = tap % 3;
