@@ -239,7 +239,7 @@ int p4c_prep_weights(const float* w, int CO, int CI, int ks, int transpose_flip,
  * compute = P4C_BF16.  out[b,y,x,m] = sum_{tap,k} act(in)[b,y+dy,x+dx,k] * W[m][k][tap] (+ bias[m])
  * with act(v) = relu?(v*in_scale[b,k] + in_shift[b,k]) applied while the input tile is staged
  * (in_scale/in_shift: (B,CI) or NULL).  stat_partial (or NULL): per-tile channel sums,
- * [B*tiles][2][64] floats with tiles = p4c_conv_stat_tiles(compute, CI, B, H, W) -- the BatchNorm/GroupNorm statistics of
+ * [B*tiles][2][64] floats with tiles = p4c_conv_stat_tiles(compute, storage, CI, B, H, W) -- the BatchNorm/GroupNorm statistics of
  * the output, produced in the epilogue.  in: (B,H,W,CI), CI in {32,64,96}; out: (B,H,W,out_cs),
  * m_blocks*64 channels written. */
 int p4c_conv_fwd(const void* in, int compute, int storage, int CI, const void* wprep, int ks, const float* in_scale,
@@ -252,7 +252,7 @@ int p4c_conv_fwd(const void* in, int compute, int storage, int CI, const void* w
 size_t p4c_conv_wgrad_workspace_bytes(int CI_pad, int ks);
 /* rows per sample of p4c_conv_fwd's stat_partial output (pixel tiles, or (workgroup, wave) slots of the
  * persistent bf16 kernel) */
-int p4c_conv_stat_tiles(int compute, int CI, int B, int H, int W);
+int p4c_conv_stat_tiles(int compute, int storage, int CI, int B, int H, int W);
 int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_pad, int ks, const float* in_scale, const float* in_shift,
                    int in_relu, const void* dout, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                    p4c_stream_t stream);

@@ -31,6 +31,6 @@ SIGNATURES = {
 }
 OTHER = {
     "p4c_conv_wgrad_workspace_bytes": ([I, I], c_size_t),
-    "p4c_conv_stat_tiles": ([I, I, I, I, I], c_int),
+    "p4c_conv_stat_tiles": ([I, I, I, I, I, I], c_int),
     "p4c_halfunet_param_count": ([DP], c_int64),
 }

@@ -293,6 +293,25 @@ __global__ void __launch_bounds__(256, 1)
         load(t_begin);
     }
     __syncthreads();
+    // staged epilogue (bf16 storage, one tile buffer): running statistics of this lane's 8 channels
+    constexpr bool STAGED = NBUF == 1 && std::is_same<T, __bf16>::value;
+    float st1[8], st2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st1[q] = st2[q] = 0.f;
+    int st_b = -1;
+    auto st_flush = [&](int bb) __attribute__((always_inline)) {
+        float* dst = stat_partial + ((int64_t)bb * gridDim.x * 4 + blockIdx.x * 4 + wv) * 128;
+        const int c8 = threadIdx.x & 7;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float u = st1[q], v = st2[q];
+            u += __shfl_xor(u, 8); v += __shfl_xor(v, 8);
+            u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+            u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+            if (lane < 8) { dst[8 * c8 + q] = u; dst[64 + 8 * c8 + q] = v; }
+            st1[q] = st2[q] = 0.f;
+        }
+    };
 
     for (int tile = t_begin; tile < t_end; ++tile) {
         int b, y0, x0, canon;
@@ -332,6 +351,55 @@ __global__ void __launch_bounds__(256, 1)
         }
 
         // ---- epilogue: C[co][px]; lane = pixel r (+ half h), register i -> co = (i&3) + 8*(i>>2) + 4*h
+        if constexpr (STAGED) {
+            // bf16 storage, single tile buffer: the accumulators are rounded into an LDS staging tile (it aliases the
+            // input tile, which every wave has finished reading), then ALL threads store it with 16-byte fully
+            // coalesced stores and accumulate the statistics of those rounded values in registers (8 fixed channels per
+            // lane, flushed per sample).  Replaces 8 scattered 8-byte stores + two LDS transposes per lane and tile.
+            __syncthreads();
+            char* stg = lt + (wv * 32 + r) * 128 + 8 * h;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& a = ct == 0 ? acc0 : acc1;
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+                    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ lo = {a[4 * g], a[4 * g + 1]}, hi = {a[4 * g + 2], a[4 * g + 3]};
+                    u32x2_ o;
+                    o[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2_));
+                    o[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2_));
+                    *reinterpret_cast<u32x2_*>(stg + (((4 * ct + g) ^ (r & 7)) << 4)) = o;
+                }
+            __syncthreads();
+            if (stat_partial && b != st_b) {
+                if (st_b >= 0) st_flush(st_b);
+                st_b = b;
+            }
+            const int c8 = threadIdx.x & 7;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int px = (threadIdx.x + k * 256) >> 3;
+                typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+                u32x4_ v = *reinterpret_cast<const u32x4_*>(lt + px * 128 + ((c8 ^ (px & 7)) << 4));
+                const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+                const bool ok = (oy < H) & (ox < W);
+                if (ok) *reinterpret_cast<u32x4_*>(out + (((int64_t)b * H + oy) * W + ox) * out_cs + mb * 64 + 8 * c8) = v;
+                if (stat_partial) {
+                    const unsigned int keep = ok ? 0xffffffffu : 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned int w = v[q] & keep;
+                        const float lo = __builtin_bit_cast(float, w << 16), hi = __builtin_bit_cast(float, w & 0xffff0000u);
+                        st1[2 * q] += lo; st2[2 * q] = __builtin_fmaf(lo, lo, st2[2 * q]);
+                        st1[2 * q + 1] += hi; st2[2 * q + 1] = __builtin_fmaf(hi, hi, st2[2 * q + 1]);
+                    }
+                }
+            }
+            __syncthreads();   // the staging tile is overwritten by the next tile's input
+            continue;
+        }
         if (NBUF == 1 && stat_partial) __syncthreads();  // every wave is done reading the tile the scratch aliases
         const int gx = x0 + r, gy = y0 + wv;
         const bool valid = (gy < H) && (gx < W);
@@ -373,6 +441,19 @@ __global__ void __launch_bounds__(256, 1)
             const float* red = sscr + 4 * 32 * 33 + ((tile - t_begin) & 1) * 512;
             const int t = threadIdx.x;
             stat_partial[(int64_t)canon * 128 + t] = (red[t] + red[128 + t]) + (red[256 + t] + red[384 + t]);
+        }
+    }
+    if constexpr (STAGED) {
+        if (stat_partial) {
+            st_flush(st_b);
+            int bf, y0, x0, cn;
+            coords(t_begin, bf, y0, x0, cn);
+            for (int bb = 0; bb < B; ++bb)   // samples this workgroup never touched read as zero (no memset pass)
+                if (bb < bf || bb > st_b) {
+                    float* dst = stat_partial + ((int64_t)bb * gridDim.x * 4 + blockIdx.x * 4 + wv) * 128;
+                    dst[lane] = 0.f;
+                    dst[64 + lane] = 0.f;
+                }
         }
     }
 }
@@ -433,6 +514,11 @@ __global__ void __launch_bounds__(512, 2)
     char* lw = smem;
     char* lt = smem + WBYTES;
     float* sscr = reinterpret_cast<float*>(smem + WBYTES + 2 * TILEB);  // [4 waves][32][33] statistics transpose
+    // 1x1 convs on bf16 storage without statistics (the output conv and its data gradient): the outputs go through two
+    // LDS staging tiles and the loader waves write them with 16-byte coalesced stores (see conv3x3_bf16_ring_kernel)
+    constexpr bool CAN_STAGE = KS == 1 && std::is_same<T, __bf16>::value;
+    const bool staged = CAN_STAGE && stat_partial == nullptr && (out_cs & 7) == 0;
+    char* lstg = smem + WBYTES + 2 * TILEB + 4 * 32 * 33 * (int)sizeof(float);
 
     const int mb = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -491,6 +577,22 @@ __global__ void __launch_bounds__(512, 2)
             coords(t, b, y0, x0);
             btile_store<T, CI, LH, LW, HALO, ROWB>(tr, in_scale, in_shift, in_relu, buf, b, y0, x0, H, W, CI, ltid);
         };
+        auto drain = [&](int t) __attribute__((always_inline)) {   // staged outputs of tile t -> HBM
+            if (!staged || t < t_begin) return;
+            int b, y0, x0;
+            coords(t, b, y0, x0);
+            const char* stg = lstg + ((t - t_begin) & 1) * (TH * BTW * 128);
+            const int c8 = ltid & 7;
+            typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int px = (ltid + k * 256) >> 3;
+                const u32x4_ v = *reinterpret_cast<const u32x4_*>(stg + px * 128 + ((c8 ^ (px & 7)) << 4));
+                const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
+                if ((oy < H) & (ox < W))
+                    *reinterpret_cast<u32x4_*>(reinterpret_cast<__bf16*>(out) + (((int64_t)b * H + oy) * W + ox) * out_cs + mb * 64 + 8 * c8) = v;
+            }
+        };
         load(ta, t_begin);      // first tiles' loads fly while the weights are copied
         load(tb, t_begin + 1);
         copy_weights();
@@ -500,6 +602,7 @@ __global__ void __launch_bounds__(512, 2)
         // iteration `tile`: stage tile+1 into the buffer the compute waves are NOT reading
         for (int tile = t_begin; tile < t_end; tile += 2) {
             P4C_STAMP(1000 + 4 * (tile - t_begin) + 0);
+            drain(tile - 1);
             store(tb, tile + 1, lt + TILEB);   // (tile - t_begin) even -> compute reads buffer 0
             P4C_STAMP(1000 + 4 * (tile - t_begin) + 1);
             load(tb, tile + 3);
@@ -508,6 +611,7 @@ __global__ void __launch_bounds__(512, 2)
             P4C_STAMP(1000 + 4 * (tile - t_begin) + 3);
             if (tile + 1 >= t_end) break;
             P4C_STAMP(1000 + 4 * (tile + 1 - t_begin) + 0);
+            drain(tile);
             store(ta, tile + 2, lt);           // compute reads buffer 1
             P4C_STAMP(1000 + 4 * (tile + 1 - t_begin) + 1);
             load(ta, tile + 4);
@@ -515,6 +619,7 @@ __global__ void __launch_bounds__(512, 2)
             lds_barrier();
             P4C_STAMP(1000 + 4 * (tile + 1 - t_begin) + 3);
         }
+        drain(t_end - 1);
         return;
     }
 
@@ -581,6 +686,23 @@ __global__ void __launch_bounds__(512, 2)
         const bool valid = (gy < H) && (gx < W);
         const float vkeep = valid ? 1.f : 0.f;
         T* orow = out + (((int64_t)b * H + gy) * W + gx) * out_cs + mb * 64 + 4 * h;
+        if (CAN_STAGE && staged) {
+            char* stg = lstg + par * (TH * BTW * 128) + (wv * 32 + r) * 128 + 8 * h;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& a = ct == 0 ? acc0 : acc1;
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+                    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ lo = {a[4 * g], a[4 * g + 1]}, hi = {a[4 * g + 2], a[4 * g + 3]};
+                    u32x2_ o;
+                    o[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2_));
+                    o[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2_));
+                    *reinterpret_cast<u32x2_*>(stg + (((4 * ct + g) ^ (r & 7)) << 4)) = o;
+                }
+        } else
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -1311,7 +1433,7 @@ static int launch_conv_fwd_bf16(const T* in, const __bf16* wp, const float* in_s
     constexpr int LH = TH + 2 * HALO, LW = BTW + 2 * HALO;
     constexpr int TILEB = (LH * LW * (CI * 2 + 16) + 15) / 16 * 16;
     const size_t scratch = (4 * 32 * 33 + 2 * 4 * 2 * 64) * sizeof(float);
-    const size_t smem = (size_t)KS * KS * CI * 64 * 2 + (NBUF == 2 ? (size_t)2 * TILEB + scratch : (TILEB > scratch ? TILEB : scratch));
+    const size_t smem = (size_t)KS * KS * CI * 64 * 2 + (NBUF == 2 ? (size_t)2 * TILEB + scratch + (KS == 1 ? 2 * 4 * 32 * 128 : 0) : (TILEB > scratch ? TILEB : scratch));
     static bool attr_set = false;
     if (!attr_set) {
         if (NBUF == 2)
@@ -1363,9 +1485,9 @@ static int launch_conv_wgrad_bf16(const T* in, const float* in_scale, const floa
 }
 
 // rows per sample of the statistics partial buffer written by conv_fwd_bf16
-int conv_bf16_stat_slots(int CI, int B, int H, int W) {
+int conv_bf16_stat_slots(int CI, int storage, int B, int H, int W) {
     const int tiles = ((H + 3) / 4) * ((W + BTW - 1) / BTW);
-    if (CI > 64) return tiles;  // per-tile partials (single-buffer kernel)
+    if (CI > 64 && storage != P4C_BF16) return tiles;  // per-tile partials (single-buffer kernel, fp32 storage)
     int64_t ntiles = (int64_t)tiles * B;
     const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
     return G * 4;               // per (workgroup, compute wave) partials

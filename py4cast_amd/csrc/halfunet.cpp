@@ -42,8 +42,8 @@ inline int conv_cin(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin :
 inline int conv_cin_pad(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin_pad : NF; }
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
-inline int stat_tiles(int compute, int CI, int B, int H, int W) {
-    if (compute == P4C_BF16) return conv_bf16_stat_slots(CI, B, H, W);
+inline int stat_tiles(int compute, int storage, int CI, int B, int H, int W) {
+    if (compute == P4C_BF16) return conv_bf16_stat_slots(CI, storage, B, H, W);
     return ((H + CONV_TH - 1) / CONV_TH) * ((W + CONV_TW - 1) / CONV_TW);
 }
 
@@ -189,7 +189,7 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     float* rm = running ? running + (int64_t)i * 128 : nullptr;
     float* rv = running ? rm + 64 : nullptr;
     if (batch_stats) {
-        P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, conv_cin_pad(d, i), d.B, H, W), d.B, (int64_t)H * W, d.norm,
+        P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, d.dtype, conv_cin_pad(d, i), d.B, H, W), d.B, (int64_t)H * W, d.norm,
                               d.groups, params + L.gamma[i], params + L.beta[i], d.eps, d.momentum,
                               d.norm == 0 ? rm : nullptr, d.norm == 0 ? rv : nullptr, nm.scale, nm.shift, nm.mean, nm.rstd, st));
     } else {
@@ -418,7 +418,9 @@ extern "C" int p4c_prep_weights(const float* w, int CO, int CI, int ks, int tran
     return prep_w(compute, w, CO, CI, ks, transpose_flip, M_pad, K_pad, out, as_stream(stream));
 }
 
-extern "C" int p4c_conv_stat_tiles(int compute, int CI, int B, int H, int W) { return stat_tiles(compute, CI, B, H, W); }
+extern "C" int p4c_conv_stat_tiles(int compute, int storage, int CI, int B, int H, int W) {
+    return stat_tiles(compute, storage, CI, B, H, W);
+}
 
 extern "C" int p4c_conv_fwd(const void* in, int compute, int storage, int CI, const void* wprep, int ks,
                             const float* in_scale, const float* in_shift, int in_relu, const float* bias, void* out,

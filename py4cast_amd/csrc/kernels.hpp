@@ -34,7 +34,7 @@ struct PrepBatch {
     int bf16;         // 1: bf16 stream (conv_bf16.hip), 0: fp32 stream (conv_f32.hip)
 };
 int prep_weights_batch(const PrepBatch& pb, hipStream_t stream);
-int conv_bf16_stat_slots(int CI, int B, int H, int W);
+int conv_bf16_stat_slots(int CI, int storage, int B, int H, int W);
 // `storage` = element type of in/out/dout in HBM (P4C_F32 or P4C_BF16)
 int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
