@@ -62,7 +62,7 @@ int p4c_num_cus(void);
 
 /* Per-launch kernel timing for the bench harness (HIP events recorded on the launch stream, around
  * every launch of the tagged kernels, including those issued inside p4c_halfunet_forward/backward).
- * Disabled by default; p4c_prof_enable(0,0) disables and frees the events.  Not graph-capturable while on.
+ * Disabled by default; p4c_prof_enable(mask, n) creates its 2n events up front (none in the timed region), (0,0) disables.  Not graph-capturable while on.
  * `units` of a record = output pixels (B*H*W) of that launch. */
 enum p4c_prof_tag {
     P4C_PROF_CONV3X3_C64 = 1,     /* conv 3x3, 64 -> 64 channels: launches of the forward plan (nothing else runs beside them) */
@@ -70,6 +70,8 @@ enum p4c_prof_tag {
     P4C_PROF_CONV3X3_C64_BWD = 4  /* the same conv kernel evaluating data gradients in the backward plan (overlapped likewise) */
 };
 int p4c_prof_enable(int tag_mask, int max_records);
+/* only launches covering at least min_units units (output pixels) are recorded (reset to 0 by p4c_prof_enable) */
+int p4c_prof_filter(int64_t min_units);
 /* sums over the finished records of `tag` with units >= min_units; synchronises on their events */
 int p4c_prof_collect(int tag, int64_t min_units, double* total_ms, int* count, double* total_units);
 

@@ -320,27 +320,45 @@ __global__ void __launch_bounds__(256, 1)
         if (NBUF == 2) {
             cur = lt + ((tile - t_begin) & 1) * TILEB;
         } else {
-            store(tile, lt);
+            if (!(P4C_EXP & 1) || tile == t_begin) store(tile, lt);
             __syncthreads();
-            if (tile + 1 < t_end) load(tile + 1);
+            if (tile + 1 < t_end && !(P4C_EXP & 2)) load(tile + 1);
         }
 
         f32x16 acc0, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
         const char* wl = lw + (h * 64 + r) * 16;
-#pragma unroll 1
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const char* pl = cur + ((wv + ky) * LW + (r + kx)) * ROWB + 16 * h;
-            const char* wt = wl + tap * NKS * 2048;
+        {
+            // tap stream with operand double buffering at tap granularity: the 3*NKS LDS reads of tap t+1 are issued
+            // before the 2*NKS MFMAs of tap t (see conv_fwd_bf16_ws_kernel)
+            const char* pl0 = cur + (wv * LW + r) * ROWB + 16 * h;
+            bf16x8 fa0[2][NKS], fa1[2][NKS], fb[2][NKS];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wt + ks * 2048);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wt + ks * 2048 + 512);
-                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(pl + 32 * ks);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc1, 0, 0, 0);
+                fa0[0][ks] = *reinterpret_cast<const bf16x8*>(wl + ks * 2048);
+                fa1[0][ks] = *reinterpret_cast<const bf16x8*>(wl + ks * 2048 + 512);
+                fb[0][ks] = *reinterpret_cast<const bf16x8*>(pl0 + 32 * ks);
+            }
+#pragma unroll
+            for (int tap = 0; tap < ((P4C_EXP & 16) ? 1 : NTAPS); ++tap) {
+                const int cb = tap & 1, nb = cb ^ 1;
+                if (tap + 1 < NTAPS) {
+                    const int ky = (tap + 1) / KS, kx = (tap + 1) % KS;
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        fa0[nb][ks] = *reinterpret_cast<const bf16x8*>(wl + ((tap + 1) * NKS + ks) * 2048);
+                        fa1[nb][ks] = *reinterpret_cast<const bf16x8*>(wl + ((tap + 1) * NKS + ks) * 2048 + 512);
+                        fb[nb][ks] = *reinterpret_cast<const bf16x8*>(pl0 + (ky * LW + kx) * ROWB + 32 * ks);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[cb][ks], fb[cb][ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[cb][ks], fb[cb][ks], acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -385,8 +403,8 @@ __global__ void __launch_bounds__(256, 1)
                 u32x4_ v = *reinterpret_cast<const u32x4_*>(lt + px * 128 + ((c8 ^ (px & 7)) << 4));
                 const int oy = y0 + (px >> 5), ox = x0 + (px & 31);
                 const bool ok = (oy < H) & (ox < W);
-                if (ok) *reinterpret_cast<u32x4_*>(out + (((int64_t)b * H + oy) * W + ox) * out_cs + mb * 64 + 8 * c8) = v;
-                if (stat_partial) {
+                if (ok && !(P4C_EXP & 4)) *reinterpret_cast<u32x4_*>(out + (((int64_t)b * H + oy) * W + ox) * out_cs + mb * 64 + 8 * c8) = v;
+                if (stat_partial && !(P4C_EXP & 8)) {
                     const unsigned int keep = ok ? 0xffffffffu : 0u;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {

@@ -35,8 +35,11 @@ int num_cus() {
 
 // ---- kernel timing (disabled by default)
 struct ProfRec { hipEvent_t a, b; int tag; int64_t units; bool open; };
-static std::vector<ProfRec> g_prof;
+static std::vector<ProfRec> g_prof;          // records in use
+static std::vector<hipEvent_t> g_prof_pool;  // events created once by p4c_prof_enable (none are created in the timed region)
+static size_t g_prof_pool_next = 0;
 static int g_prof_mask = 0;
+static int64_t g_prof_min_units = 0;
 static size_t g_prof_cap = 0;
 static std::mutex g_prof_mu;
 
@@ -46,11 +49,11 @@ static inline int phase_tag(int tag) { return (tag == P4C_PROF_CONV3X3_C64 && g_
 
 void prof_begin(int tag, int64_t units, hipStream_t stream) {
     tag = phase_tag(tag);
-    if (!(g_prof_mask & tag)) return;
+    if (!(g_prof_mask & tag) || units < g_prof_min_units) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_prof.size() >= g_prof_cap) return;
-    ProfRec r{nullptr, nullptr, tag, units, true};
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    if (g_prof.size() >= g_prof_cap || g_prof_pool_next + 2 > g_prof_pool.size()) return;
+    ProfRec r{g_prof_pool[g_prof_pool_next], g_prof_pool[g_prof_pool_next + 1], tag, units, true};
+    g_prof_pool_next += 2;
     (void)hipEventRecord(r.a, stream);
     g_prof.push_back(r);
 }
@@ -71,10 +74,22 @@ void prof_end(int tag, hipStream_t stream) {
 
 extern "C" int p4c_prof_enable(int tag_mask, int max_records) {
     std::lock_guard<std::mutex> lk(p4c::g_prof_mu);
-    for (auto& r : p4c::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     p4c::g_prof.clear();
+    p4c::g_prof_pool_next = 0;
     p4c::g_prof_mask = tag_mask;
-    p4c::g_prof_cap = max_records > 0 ? (size_t)max_records : 0;
+    p4c::g_prof_min_units = 0;
+    p4c::g_prof_cap = (tag_mask && max_records > 0) ? (size_t)max_records : 0;
+    while (p4c::g_prof_pool.size() < 2 * p4c::g_prof_cap) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return p4c::fail(P4C_ERR_RUNTIME, "p4c_prof_enable: hipEventCreate failed");
+        p4c::g_prof_pool.push_back(e);
+    }
+    return P4C_OK;
+}
+
+extern "C" int p4c_prof_filter(int64_t min_units) {
+    std::lock_guard<std::mutex> lk(p4c::g_prof_mu);
+    p4c::g_prof_min_units = min_units;
     return P4C_OK;
 }
 
