@@ -171,6 +171,13 @@ int p4c_acc_sums(const float* pred, int64_t pred_bs, int64_t pred_ts, const floa
                  const void* mask, int mask_mode, const float* climate_means, float* out, void* workspace, int B, int T,
                  int64_t N, int F, p4c_stream_t stream);
 
+/* NaN-aware moments for the dataset statistics (compute_dataset_stats.py:11-127): out (5,B,F) = per (sample, feature)
+ * sum, sum of squares, count of non-NaN values, min, max over `rows` rows of F features (sample b starts at
+ * x + b*batch_stride).  With x_next != NULL the value is x_next[i] - x[i] (time-step differences: pass the views
+ * in_out[:, 1:] and in_out[:, :-1]).  workspace: 5 * p4c_loss_workspace_bytes(B, 1, rows, F). */
+int p4c_nan_moments(const float* x, const float* x_next, int64_t batch_stride, float* out, void* workspace, int B,
+                    int64_t rows, int F, p4c_stream_t stream);
+
 /* Rows next to the path.
  * p4c_unnormalize: out[r,f] = x[r,f]*std[f] + mean[f] as two rounded steps (predict path, lightning.py:1162-1169);
  *   out may alias x.

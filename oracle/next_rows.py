@@ -38,3 +38,17 @@ def standardize_pack(raw: np.ndarray, mean: np.ndarray, std: np.ndarray) -> np.n
     raw: (F, B, T, H, W) planes -> (B, T, H, W, F)."""
     planes = [(raw[f] - np.asarray(mean[f])) / np.asarray(std[f]) for f in range(raw.shape[0])]
     return np.stack(planes, axis=-1).astype(np.float32)
+
+
+def nan_moments(x: torch.Tensor, x_next: torch.Tensor = None) -> torch.Tensor:
+    """The per-(sample, feature) reductions compute_dataset_stats.py is built from (:45-52, :105-108):
+    (5,B,F) = nansum, nansum of squares, non-NaN count, min / max with NaN ignored, over all dims between batch and
+    features, of x or of x_next - x."""
+    v = (x_next - x if x_next is not None else x).double()
+    B, F = v.shape[0], v.shape[-1]
+    v = v.reshape(B, -1, F)
+    ok = ~torch.isnan(v)
+    z = torch.where(ok, v, torch.zeros_like(v))
+    mn = torch.min(torch.nan_to_num(v, nan=float("inf")), dim=1).values
+    mx = torch.max(torch.nan_to_num(v, nan=float("-inf")), dim=1).values
+    return torch.stack([z.sum(1), (z * z).sum(1), ok.sum(1).double(), mn, mx]).float()

@@ -393,6 +393,86 @@ __global__ void acc_final_kernel(const float* __restrict__ partial, int nblk, fl
     out[i] = s / n_points;   // torch .mean(dim=spatial)
 }
 
+// ------------------------------------------------------------------ NaN-aware moments (dataset statistics)
+// compute_mean_std_min_max / compute_time_step_stats (py4cast/datasets/compute_dataset_stats.py:11-127) need, per
+// (sample, feature) over all grid points and time steps: the sum and the sum of squares of the non-NaN values, their
+// count, and min / max with NaN ignored.  value = x[idx] (or x_next[idx] - x[idx] for the time-step differences).
+// partial[((k*B + b)*nblk + blk)*F + f], k = 0 sum, 1 sum of squares, 2 count, 3 min, 4 max
+__global__ void __launch_bounds__(256)
+    nan_moments_partial_kernel(const float* __restrict__ x, const float* __restrict__ x_next, int64_t bs, int64_t R,
+                               float* __restrict__ partial, int F, int FP, int iters) {
+    __shared__ float red[5][4][64 * LOSS_MAX_ITERS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int PP = 64 / FP;
+    const int pp = lane / FP, c0 = lane % FP;
+    const float* p = x + (int64_t)b * bs;
+    const float* q = x_next ? x_next + (int64_t)b * bs : nullptr;
+    float a0[LOSS_MAX_ITERS], a1[LOSS_MAX_ITERS], a2[LOSS_MAX_ITERS], mn[LOSS_MAX_ITERS], mx[LOSS_MAX_ITERS];
+#pragma unroll
+    for (int it = 0; it < LOSS_MAX_ITERS; ++it) { a0[it] = a1[it] = a2[it] = 0.0f; mn[it] = INFINITY; mx[it] = -INFINITY; }
+    const int64_t stride = (int64_t)gridDim.x * 4 * PP;
+    for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < R; n += stride) {
+#pragma unroll
+        for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+            const int f = c0 + it * FP;
+            if (it < iters && f < F) {
+                const int64_t e = n * F + f;
+                const float v = q ? q[e] - p[e] : p[e];
+                if (v == v) {
+                    a0[it] += v;
+                    a1[it] += v * v;
+                    a2[it] += 1.0f;
+                    mn[it] = fminf(mn[it], v);
+                    mx[it] = fmaxf(mx[it], v);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < LOSS_MAX_ITERS; ++it) {
+        const float v0 = cross_seg_sum(a0[it], FP), v1 = cross_seg_sum(a1[it], FP), v2 = cross_seg_sum(a2[it], FP);
+        float lo = mn[it], hi = mx[it];
+        for (int off = FP; off < 64; off <<= 1) {   // lanes with the same feature are FP apart
+            lo = fminf(lo, __shfl_xor(lo, off));
+            hi = fmaxf(hi, __shfl_xor(hi, off));
+        }
+        if (pp == 0) {
+            red[0][wv][it * 64 + c0] = v0; red[1][wv][it * 64 + c0] = v1; red[2][wv][it * 64 + c0] = v2;
+            red[3][wv][it * 64 + c0] = lo; red[4][wv][it * 64 + c0] = hi;
+        }
+    }
+    __syncthreads();
+    const int B = gridDim.y;
+    for (int i = threadIdx.x; i < 5 * iters * FP; i += blockDim.x) {
+        const int k = i / (iters * FP), j = i - k * iters * FP;
+        const int it = j / FP, c = j - it * FP;
+        const int f = c + it * FP;
+        if (f < F) {
+            const int z = it * 64 + c;
+            float v;
+            if (k < 3) v = (red[k][0][z] + red[k][1][z]) + (red[k][2][z] + red[k][3][z]);
+            else if (k == 3) v = fminf(fminf(red[3][0][z], red[3][1][z]), fminf(red[3][2][z], red[3][3][z]));
+            else v = fmaxf(fmaxf(red[4][0][z], red[4][1][z]), fmaxf(red[4][2][z], red[4][3][z]));
+            partial[(((int64_t)k * B + b) * gridDim.x + blockIdx.x) * F + f] = v;
+        }
+    }
+}
+
+__global__ void nan_moments_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out, int B, int F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 5 * B * F) return;
+    const int k = i / (B * F), j = i - k * B * F;
+    const int b = j / F, f = j - b * F;
+    const float* src = partial + (((int64_t)k * B + b) * nblk) * F + f;
+    float s = k == 3 ? INFINITY : (k == 4 ? -INFINITY : 0.0f);
+    for (int q = 0; q < nblk; ++q) {
+        const float v = src[(int64_t)q * F];
+        s = k < 3 ? s + v : (k == 3 ? fminf(s, v) : fmaxf(s, v));
+    }
+    out[i] = s;
+}
+
 // ------------------------------------------------------------------ fused AR update + loss, 16-byte vectorised
 // Same arithmetic (and operation order) as the scalar kernels below, for F % 4 == 0, F <= 64 and fp32 y/dy rows
 // whose stride is a multiple of 4: a lane owns 4 consecutive features of a grid point, so every access is a
@@ -840,6 +920,22 @@ extern "C" int p4c_acc_sums(const float* pred, int64_t pred_bs, int64_t pred_ts,
     hipLaunchKernelGGL(acc_final_kernel, dim3((tot + 127) / 128), dim3(128), 0, as_stream(stream), (const float*)workspace,
                        nblk, (float)N, out, B * T, F);
     P4C_CHECK_LAUNCH("p4c_acc_sums(final)");
+    return P4C_OK;
+}
+
+extern "C" int p4c_nan_moments(const float* x, const float* x_next, int64_t batch_stride, float* out, void* workspace,
+                               int B, int64_t rows, int F, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && out && workspace, "p4c_nan_moments: null pointer");
+    P4C_CHECK_ARG(B > 0 && rows > 0 && F > 0 && F <= 64 * LOSS_MAX_ITERS, "p4c_nan_moments: bad dims");
+    const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
+    const int nblk = loss_blocks(rows, 64 / FP, B);
+    hipLaunchKernelGGL(nan_moments_partial_kernel, dim3(nblk, B), dim3(256), 0, as_stream(stream), x, x_next, batch_stride, rows,
+                       (float*)workspace, F, FP, iters);
+    P4C_CHECK_LAUNCH("p4c_nan_moments(partial)");
+    const int tot = 5 * B * F;
+    hipLaunchKernelGGL(nan_moments_final_kernel, dim3((tot + 127) / 128), dim3(128), 0, as_stream(stream), (const float*)workspace,
+                       nblk, out, B, F);
+    P4C_CHECK_LAUNCH("p4c_nan_moments(final)");
     return P4C_OK;
 }
 

@@ -163,8 +163,70 @@ def gen_pack():
                         inputs=batch.inputs.tensor.numpy(), outputs=batch.outputs.tensor.numpy())
 
 
+
+
+def gen_stats():
+    """compute_mean_std_min_max / compute_time_step_stats of the unmodified compute_dataset_stats.py on a fake dataset."""
+    for k in [k for k in sys.modules if k.startswith("py4cast")]:
+        sys.modules.pop(k, None)
+    mg.stub("py4cast")
+    sys.modules["py4cast"].__path__ = [os.path.join(mg.REF, "py4cast")]
+    mg.stub("py4cast.datasets", __path__=[os.path.join(mg.REF, "py4cast", "datasets")])
+    mg.stub("py4cast.datasets.base", DatasetABC=object)
+    saved = {}
+    mg.stub("py4cast.utils", torch_save=lambda obj, path: saved.__setitem__(str(path), obj))
+    cds = importlib.import_module("py4cast.datasets.compute_dataset_stats")  # unmodified reference file
+
+    g = torch.Generator().manual_seed(21)
+    B, T, H, W = 2, 3, 6, 5
+    names = {"inputs": ["a", "b", "c"], "outputs": ["a", "b", "c"], "forcing": ["f0", "f1"]}
+    dims = ["batch", "timestep", "lat", "lon", "features"]
+
+    def batch(nan):
+        out = {}
+        for kind, steps in (("inputs", 1), ("outputs", T), ("forcing", T)):
+            t = torch.randn(B, steps, H, W, len(names[kind]), generator=g) * 3 + 1
+            if nan and kind != "forcing":
+                t[torch.rand(t.shape, generator=g) < 0.05] = float("nan")
+            out[kind] = NT(t, dims, names[kind])
+        return types.SimpleNamespace(**out)
+
+    batches = [batch(False), batch(True), batch(True)]
+
+    class DS:
+        cache_dir = __import__("pathlib").Path("/nonexistent")
+
+        def __init__(self, standardize):
+            self.settings = types.SimpleNamespace(standardize=standardize)
+
+        def torch_dataloader(self):
+            return list(batches)
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = {}
+        for kind in ("inputs", "outputs", "forcing"):
+            st = cds.compute_mean_std_min_max(DS(False), kind)
+            for n, d in st.items():
+                for k, v in d.items():
+                    out[f"{kind}__{n}__{k}"] = np.float32(v)
+        cds.compute_time_step_stats(DS(True))
+    diff = saved["/nonexistent/diff_stats.pt"]
+    for n, d in diff.items():
+        for k, v in d.items():
+            out[f"diff__{n}__{k}"] = np.float32(v)
+    for i, b in enumerate(batches):
+        for kind in ("inputs", "outputs", "forcing"):
+            out[f"batch{i}__{kind}"] = getattr(b, kind).tensor.numpy()
+    np.savez_compressed(os.path.join(HERE, "next_stats.npz"), **out)
+
+
+
+
 if __name__ == "__main__":
     gen_acc()
     gen_unnormalize()
     gen_pack()
+    gen_stats()
     print("written:", sorted(f for f in os.listdir(HERE) if f.startswith("next_")))

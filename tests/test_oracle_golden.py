@@ -136,3 +136,46 @@ def test_oracle_standardize_pack_matches_reference_bit_exact():
     z = _load_next("next_pack.npz")
     full = standardize_pack(z["raw"], z["mean"], z["std"])
     assert np.array_equal(full[:, :1], z["inputs"]) and np.array_equal(full[:, 1:], z["outputs"])
+
+
+def _stats_from_moments(z, moments_fn):
+    """the reference's loops (compute_dataset_stats.py:11-127) on top of per-batch NaN-aware moments"""
+    names = {"inputs": ["a", "b", "c"], "outputs": ["a", "b", "c"], "forcing": ["f0", "f1"]}
+    res = {}
+    for kind in ("inputs", "outputs", "forcing"):
+        F = len(names[kind])
+        first = torch.from_numpy(z[f"batch0__{kind}"])
+        m0 = moments_fn(first.reshape(1, -1, F))
+        best_min, best_max = m0[3, 0], m0[4, 0]
+        s1 = torch.zeros(F); s2 = torch.zeros(F); counter = 0
+        for i in range(3):
+            t = torch.from_numpy(z[f"batch{i}__{kind}"])
+            m = moments_fn(t)
+            counter += t.shape[0]
+            s1 += torch.nansum(m[0] / m[2], dim=0); s2 += torch.nansum(m[1] / m[2], dim=0)
+            best_min = torch.minimum(best_min, m[3, 0]); best_max = torch.maximum(best_max, m[4, 0])
+        mean = s1 / counter
+        std = torch.sqrt(s2 / counter - mean**2)
+        for j, n in enumerate(names[kind]):
+            res[f"{kind}__{n}"] = dict(mean=mean[j], std=std[j], min=best_min[j], max=best_max[j])
+    s1 = torch.zeros(3); s2 = torch.zeros(3); counter = 0
+    for i in range(3):
+        io = torch.cat([torch.from_numpy(z[f"batch{i}__inputs"]), torch.from_numpy(z[f"batch{i}__outputs"])], dim=1)
+        m = moments_fn(io[:, :-1], io[:, 1:])
+        counter += io.shape[0]
+        s1 += torch.nansum(m[0] / m[2], dim=0); s2 += torch.nansum(m[1] / m[2], dim=0)
+    dm = s1 / counter
+    ds = torch.sqrt(s2 / counter - dm**2)
+    for j, n in enumerate(names["inputs"]):
+        res[f"diff__{n}"] = dict(mean=dm[j], std=ds[j])
+    return res
+
+
+def test_oracle_dataset_stats_match_reference():
+    from oracle.next_rows import nan_moments
+
+    z = _load_next("next_stats.npz")
+    res = _stats_from_moments(z, nan_moments)
+    for key, d in res.items():
+        for stat, v in d.items():
+            np.testing.assert_allclose(float(v), float(z[f"{key}__{stat}"]), rtol=2e-5, atol=2e-6, err_msg=f"{key} {stat}")

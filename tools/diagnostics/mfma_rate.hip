@@ -52,6 +52,12 @@ __global__ void __launch_bounds__(256, 1) k(const bf16x8* in, float* out, unsign
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    } else if (MODE == 4) {   // fp32 matrix cores: v_mfma_f32_32x32x2_f32, 8 accumulators
+        const float af = __builtin_bit_cast(float, ((const unsigned*)&a)[0]), bf_ = __builtin_bit_cast(float, ((const unsigned*)&b)[1]);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf_, acc[t], 0, 0, 0);
+        }
     } else if (MODE == 3) {   // pure MFMA, 2 accumulators alternating
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -91,6 +97,7 @@ int main() {
         run<3>("pure MFMA, 2 accumulators", 8, z);
         run<1>("1 ds_read_b128 per MFMA, interleaved", 8, z);
         run<2>("4 reads then 4 MFMAs (bursts)", 24, z);
+        run<4>("fp32 v_mfma_f32_32x32x2_f32, 8 accumulators", 8, z);
     }
     return 0;
 }
