@@ -178,6 +178,11 @@ int p4c_acc_sums(const float* pred, int64_t pred_bs, int64_t pred_ts, const floa
 int p4c_nan_moments(const float* x, const float* x_next, int64_t batch_stride, float* out, void* workspace, int B,
                     int64_t rows, int F, p4c_stream_t stream);
 
+/* One AdamW step (torch.optim.AdamW semantics, decoupled weight decay, no amsgrad) over flat fp32 buffers of n elements;
+ * `step` is the 1-based step count used for the bias corrections (configure_optimizers, lightning.py:442-467). */
+int p4c_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, int64_t step, p4c_stream_t stream);
+
 /* Rows next to the path.
  * p4c_unnormalize: out[r,f] = x[r,f]*std[f] + mean[f] as two rounded steps (predict path, lightning.py:1162-1169);
  *   out may alias x.

@@ -9,6 +9,8 @@
 // This translation unit is compiled with -ffp-contract=off: K2 evaluates the reference's
 // expression in the reference's order, one rounding per op, so fp32 results are bit-identical
 // to the torch op chain.
+#include <math.h>
+
 #include "common.hpp"
 
 namespace p4c {
@@ -391,6 +393,39 @@ __global__ void __launch_bounds__(256) pack_standardize_kernel(const float* __re
         f += df;
         if (f >= F) { f -= F; ++row; }
     }
+}
+
+// AdamW over one flat fp32 parameter / gradient buffer (configure_optimizers, lightning.py:442-467 -> torch.optim.AdamW):
+// the update order of torch's implementation (decoupled weight decay, lerp of the first moment, mul + addcmul of the
+// second, bias corrections folded into step_size and the denominator), one launch instead of ~20 multi-tensor passes.
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float decay, float w1, float beta2,
+                                                    float w2, float bc2_sqrt, float eps, float step_size) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float grad = g[i];
+        float param = p[i] * decay;                       // param.mul_(1 - lr * weight_decay)
+        const float mi = m[i] + w1 * (grad - m[i]);       // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * beta2 + w2 * grad * grad; // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        param = param - step_size * (mi / denom);         // param.addcdiv_(exp_avg, denom, value=-step_size)
+        p[i] = param; m[i] = mi; v[i] = vi;
+    }
+}
+
+extern "C" int p4c_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                              double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                              p4c_stream_t stream) {
+    P4C_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "p4c_adamw_step: null pointer");
+    P4C_CHECK_ARG(n > 0 && step >= 1, "p4c_adamw_step: n and step must be positive");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), params, grads, exp_avg, exp_avg_sq, n,
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)sqrt(bc2), (float)eps, (float)(lr / bc1));
+    P4C_CHECK_LAUNCH("p4c_adamw_step");
+    return P4C_OK;
 }
 
 extern "C" int p4c_unnormalize(const float* x, const float* std, const float* mean, float* out, int64_t rows, int F,

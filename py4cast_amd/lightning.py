@@ -35,6 +35,7 @@ from .losses import CombinedLoss, NanMask, OnesMask, ScaledLoss, WeightedLoss
 from .models import build_model_from_settings, get_model_kls_and_settings
 from .models import registry as model_registry
 from .namedtensor import NamedTensor
+from .optim import FlatAdamW
 
 try:  # pragma: no cover - lightning absent in the build image
     from lightning import LightningModule as _Base  # type: ignore
@@ -253,7 +254,8 @@ class AutoRegressiveLightning(_Base):
 
     def configure_optimizers(self):
         """AdamW + cosine-with-min-lr warmup schedule stepped per optimizer step (lightning.py:442-467)."""
-        optimizer = torch.optim.AdamW(self.parameters(), lr=self.hparams.learning_rate, betas=self.hparams.betas)
+        # a torch.optim.AdamW whose step is one kernel when parameters and gradients are flat (HalfUNetMI355X + FlatDDP)
+        optimizer = FlatAdamW(self.parameters(), lr=self.hparams.learning_rate, betas=self.hparams.betas)
         total = getattr(self.trainer, "estimated_stepping_batches", 1000) if self.trainer is not None else 1000
         scheduler = torch.optim.lr_scheduler.LambdaLR(
             optimizer,

@@ -473,3 +473,48 @@ def test_halfunet_bf16_storage_runs_and_tracks_fp32(gpu_device):
     for name, p in model.named_parameters():
         a, b = p.grad.detach().cpu().double().flatten(), pr[name].grad.flatten()
         assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.85, name
+
+
+def test_flat_adamw_matches_torch_adamw(gpu_device):
+    """FlatAdamW (one kernel over the flat parameter / gradient buffers) against torch.optim.AdamW step by step, with
+    the LR changing between steps; state_dict keeps torch's per-parameter layout; scattered parameters fall back."""
+    from py4cast_amd.optim import FlatAdamW
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 9, 3, 3), (64,), (64,), (7, 64, 1, 1)]
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat_p, flat_g = torch.randn(n, generator=g).to(gpu_device), torch.zeros(n, device=gpu_device)
+    ps, rs, off = [], [], 0
+    for s in shapes:
+        k = int(np.prod(s))
+        p = torch.nn.Parameter(flat_p[off : off + k].view(s))
+        p.grad = flat_g[off : off + k].view(s)
+        ps.append(p)
+        rs.append(torch.nn.Parameter(p.detach().clone()))
+        off += k
+    opt = FlatAdamW(ps, lr=1e-3, betas=(0.9, 0.95))
+    ref = torch.optim.AdamW(rs, lr=1e-3, betas=(0.9, 0.95))
+    for step in range(5):
+        gr = torch.randn(n, generator=g).to(gpu_device) * (10.0 ** (step - 2))
+        flat_g.copy_(gr)
+        off = 0
+        for r in rs:
+            r.grad = gr[off : off + r.numel()].view_as(r).clone()
+            off += r.numel()
+        for o in (opt, ref):
+            o.param_groups[0]["lr"] = 1e-3 / (step + 1)
+            o.step()
+        assert opt._flat_state is not None  # the flat path was taken
+        for p, r in zip(ps, rs):
+            assert rel_err(p.detach(), r.detach()) < 2e-6, step
+    sd = opt.state_dict()["state"]
+    assert set(sd[0].keys()) >= {"step", "exp_avg", "exp_avg_sq"} and float(sd[0]["step"]) == 5
+    for i, r in enumerate(rs):
+        assert rel_err(sd[i]["exp_avg_sq"], ref.state[r]["exp_avg_sq"]) < 2e-6
+    # not flat -> parent implementation
+    q = [torch.nn.Parameter(torch.randn(5, device=gpu_device)), torch.nn.Parameter(torch.randn(7, device=gpu_device))]
+    for t in q:
+        t.grad = torch.randn_like(t)
+    o2 = FlatAdamW(q, lr=1e-2)
+    o2.step()
+    assert o2._flat_state is None and float(o2.state[q[0]]["step"]) == 1
