@@ -12,10 +12,10 @@ def run(device: torch.device) -> None:
     from oracle import rollout as orollout
     from oracle.halfunet import HalfUNetRef
 
-    from . import _lib as L
-    from .base import DatasetInfo, ItemBatch, Statics, Stats
-    from .lightning import AutoRegressiveLightning
-    from .namedtensor import NamedTensor
+    from py4cast_amd import _lib as L
+    from py4cast_amd.base import DatasetInfo, ItemBatch, Statics, Stats
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from py4cast_amd.namedtensor import NamedTensor
 
     L.lib()  # fails loudly if the extension is missing
     B, T, H, W, F, Ff, Fs = 2, 2, 32, 32, 6, 5, 4

@@ -91,3 +91,18 @@ def test_strategy_validation():
     assert lm.model.in_channels == 3 + 4 + 5  # lightning.py:256-261
     assert lm.grid_static_features.shape == (2, 8, 8, 4) and lm.interior_mask.shape == (8, 8, 1)
     assert hasattr(lm, "interior_mask_s")  # registered by WeightedLoss.prepare (losses.py:65-71)
+
+
+def test_product_package_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure and the reference never travels: no file of the product package (nor the plugin,
+    nor bin/) may import / open either."""
+    import glob
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "py4cast_amd", "*.py")) + glob.glob(os.path.join(root, "py4cast_amd", "csrc", "*")) + \
+        [os.path.join(root, "py4cast_plugin_mi355x.py")] + glob.glob(os.path.join(root, "bin", "*.py"))
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle)|/root/reference", re.M)
+    bad = [f for f in files if os.path.isfile(f) and not f.endswith((".o", ".so")) and pat.search(open(f, errors="ignore").read())]
+    assert not bad, bad
