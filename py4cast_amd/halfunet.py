@@ -358,6 +358,9 @@ class HalfUNetMI355X(ModelABC, nn.Module):
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
                     "algorithmic_bytes_per_launch": 2.0 * 64 * esz * B * H * W,
                     "avg_launch_ms": ms.value / n.value, "launches": n.value, "mfma_tflops": tflops,
+                    # context: on random operands the matrix pipe sustains 22.7 ns per v_mfma_f32_32x32x16_bf16 per SIMD
+                    # (power-limited clock, profiles/r01_mfma_rate_microbench.txt) = 1478 TFLOP/s, not the 2500 dense peak
+                    "mfma_sustained_tflops_measured": 1478.0, "mfma_frac_of_sustained": tflops / 1478.0,
                     "wgrad_avg_launch_ms": (wms.value / wn.value) if wn.value else None}
         out = {"bound": "mfma", "kernel": "conv_fwd_f32_kernel<64,3,4> (3x3 conv 64->64, forward-plan launches at full resolution)",
                "datagrad_avg_launch_ms_overlapped": dgrad_ms,
