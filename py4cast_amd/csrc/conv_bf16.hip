@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(512, 2)
 namespace ring {
 constexpr int TH = 4, LW = BTW + 2, NROW = 22, ROWB = 128, RROW = LW * ROWB;
 constexpr int RINGB = NROW * RROW, STGB = TH * BTW * 128;
-constexpr int MAXB = 8;                       // samples whose normalisation rows fit
+constexpr int MAXB = 32;                      // samples whose normalisation rows fit (512 B each)
 constexpr int SMEM = RINGB + 2 * STGB + MAXB * 128 * 4;
 constexpr int NIMG = 7;                       // register slots per lane of a staged tile (6 rows fresh, 4 otherwise)
 constexpr int ROWSLOTS = LW * 8;              // 16-byte slots per halo row
