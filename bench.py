@@ -35,6 +35,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--accumulate", type=int, default=1,
+                    help="accumulate_grad_batches (trainer.yaml:58): micro-batches per gradient all-reduce + optimizer step; "
+                         "a bench step is one micro-batch")
     ap.add_argument("--kernel-times", action="store_true",
                     help="also record HIP events around every C entry point and every tagged conv / weight-gradient launch "
                          "(kernel_ms, data-gradient and weight-gradient launch times); costs ~0.5 ms per step of event markers")
@@ -202,12 +205,16 @@ def main():
     ddp = FlatDDP(lm.model, world)
     opt = lm.configure_optimizers()["optimizer"]
 
+    micro = [0]
+
     def step(i):
         loss = lm.training_step(make_batch(case), i)
-        loss.backward()
-        ddp.all_reduce_grads()
-        opt.step()
-        ddp.zero_grad()
+        (loss / args.accumulate if args.accumulate > 1 else loss).backward()
+        micro[0] += 1
+        if micro[0] % args.accumulate == 0:   # non-stepping micro-batches neither sync nor step (trainer.yaml:58)
+            ddp.all_reduce_grads()
+            opt.step()
+            ddp.zero_grad()
         return loss
 
     def barrier():
@@ -286,6 +293,7 @@ def main():
                 "parallelism": f"dp{world}",
                 "border_size": args.border,
                 "setup_steps": args.setup_steps,
+                "accumulate_grad_batches": args.accumulate,
             },
             "loss": float(loss.detach()),
             "roofline": roof,

@@ -373,6 +373,19 @@ class AutoRegressiveLightning(_Base):
         prediction_list = []
         T = batch.num_pred_steps
         keep_prev = 0.0 if ds else 1.0
+        # Any nn.Module model: when the configured loss is a single WeightedLoss, every AR step's state update, border
+        # forcing and loss column are ONE kernel (p4c_ar_update_loss_fwd) writing straight into the (B,T,...) prediction
+        # buffer -- no separate loss passes over the stacked prediction, no torch.stack copy (lightning.py:599-660,816).
+        members = getattr(self.loss, "losses", [])
+        fuse = (not inference and not ds and num_inter_steps == 1 and len(members) == 1
+                and isinstance(members[0][0], WeightedLoss) and getattr(self, "use_fused_step", True))
+        if fuse:
+            wl, wl_weight = members[0]
+            f_weights = wl.weights(tuple(batch.outputs.feature_names), device)
+            f_mode = L.MASK_FROM_NAN if self.mask_on_nan else L.MASK_NONE
+            f_count = ops.masked_count(ops.MaskSpec(f_mode), batch.outputs.tensor) if self.mask_on_nan else None
+            f_states = torch.empty(batch.outputs.tensor.shape, dtype=torch.float32, device=device)
+            f_losses = []
         for i in range(T):
             border_state = None if inference else batch.outputs.select_tensor_dim("timestep", i)
             for k in range(num_inter_steps):
@@ -393,11 +406,17 @@ class AutoRegressiveLightning(_Base):
                 else:
                     keep = keep_prev
                 do_force = (not inference) and force_border
-                new_state = ops.ar_update(
-                    last_prev, y, border_state if do_force else None, std, mean,
-                    border_flat if do_force else None, interior_flat if do_force else None,
-                    keep_prev=keep, nan_to_num=self.mask_on_nan,
-                )
+                if fuse:
+                    new_state, loss_i = ops.ar_step_loss(
+                        last_prev, y, border_state, std, mean, border_flat, interior_flat, f_weights, wl.num_interior,
+                        f_count, wl.kind, f_mode, keep, do_force, out=f_states.select(1, i))
+                    f_losses.append(loss_i)
+                else:
+                    new_state = ops.ar_update(
+                        last_prev, y, border_state if do_force else None, std, mean,
+                        border_flat if do_force else None, interior_flat if do_force else None,
+                        keep_prev=keep, nan_to_num=self.mask_on_nan,
+                    )
                 if i < T - 1 or k < num_inter_steps - 1:  # lightning.py:636-656
                     t_dim = batch.inputs.dim_index("timestep")
                     if prev_states.dim_size("timestep") == 1:
@@ -409,6 +428,10 @@ class AutoRegressiveLightning(_Base):
                     prev_states = NamedTensor.new_like(new_prev, prev_states)
             prediction_list.append(new_state)
 
+        if fuse:
+            pred_out = NamedTensor.new_like(f_states.type_as(batch.outputs.tensor), batch.outputs)
+            pred_out.fused_loss = torch.stack(f_losses, dim=1) * wl_weight
+            return pred_out, batch.outputs
         prediction = torch.stack(prediction_list, dim=1)
         if inference:
             pred_out = NamedTensor(prediction.type(self.output_dtype), self.output_dim_names, self.output_feature_names)

@@ -263,7 +263,7 @@ class _ARStepLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prev, y, target, std, mean, border_mask, interior_mask, weights, num_interior, count,
-                kind, mask_mode, keep_prev, force_border):
+                kind, mask_mode, keep_prev, force_border, out=None):
         L.require_cuda(y, target)
         B, F = target.shape[0], target.shape[-1]
         y_c = y.contiguous()
@@ -273,8 +273,12 @@ class _ARStepLoss(torch.autograd.Function):
         if prev is not None:
             pv, (pbs,) = _rows(prev, 1)
         tg, (tbs,) = _rows(target, 1)
-        new_state = torch.empty(target.shape, dtype=torch.float32, device=y.device)
-        ns, nbs = new_state, N * F
+        if out is not None:   # caller-provided slot of the (B,T,*S,F) prediction buffer: no stack/copy afterwards
+            assert out.shape == target.shape and out.dtype == torch.float32 and out[0].is_contiguous()
+            new_state, nbs = out, out.stride(0)
+        else:
+            new_state, nbs = torch.empty(target.shape, dtype=torch.float32, device=y.device), N * F
+        ns = new_state
         loss = torch.empty(B, dtype=torch.float32, device=y.device)
         ws = _workspace(B, 1, N, 1, y.device)
         L.call(
@@ -303,13 +307,13 @@ class _ARStepLoss(torch.autograd.Function):
             L.ptr(tg), tbs, L.ptr(std), L.ptr(interior), int(force), L.ptr(weights), num_interior, L.ptr(count), kind,
             mask_mode, L.ptr(dy), L.dtype_code(ydt), y_cs, L.ptr(dprev), N * F, B, N, F, keep, L.stream(tg.device),
         )
-        return (dprev, dy) + (None,) * 12
+        return (dprev, dy) + (None,) * 13
 
 
 def ar_step_loss(prev, y, target, std, mean, border_mask, interior_mask, weights, num_interior, count, kind,
-                 mask_mode, keep_prev, force_border):
+                 mask_mode, keep_prev, force_border, out=None):
     return _ARStepLoss.apply(prev, y, target, std, mean, border_mask, interior_mask, weights, num_interior,
-                             count, kind, mask_mode, keep_prev, force_border)
+                             count, kind, mask_mode, keep_prev, force_border, out)
 
 
 # ------------------------------------------------------------------------------------------------ rows next to the path

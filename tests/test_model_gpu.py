@@ -231,21 +231,24 @@ def test_native_rollout_equals_generic_path(gpu_device, strategy, nan, border):
     ).to(gpu_device)
     lm.train()
     res = {}
-    for native in (True, False):
-        lm.use_native_rollout = native
+    # three routes to the same numbers: the one-node native rollout, the generic per-op path with the fused update+loss
+    # step (any nn.Module model), and the generic path with separate update and loss passes (the reference's structure)
+    for mode, native, fused in (("native", True, True), ("generic_fused", False, True), ("generic", False, False)):
+        lm.use_native_rollout, lm.use_fused_step = native, fused
         for p in lm.parameters():
             p.grad = None
         pred, _ = lm.common_step(make_batch(case, gpu_device), 0, "train")
-        assert (getattr(pred, "fused_loss", None) is not None) == native
+        assert (getattr(pred, "fused_loss", None) is not None) == (native or fused)
         loss = lm.training_step(make_batch(case, gpu_device), 0)
         loss.backward()
-        res[native] = (pred.tensor.detach().cpu(), loss.item(), {n: p.grad.detach().cpu().clone() for n, p in lm.model.named_parameters()})
-    a, b = res[True][0], res[False][0]
-    assert torch.equal(torch.isnan(a), torch.isnan(b))
-    assert rel_err(torch.nan_to_num(a), torch.nan_to_num(b)) < 2e-5  # BatchNorm batch statistics differ in the last bits per call
-    assert abs(res[True][1] - res[False][1]) / abs(res[False][1]) < 1e-5
-    for n in res[True][2]:
-        assert rel_err(res[True][2][n], res[False][2][n]) < 5e-2, n  # chaotic BPTT (see test above); typical 1e-4
+        res[mode] = (pred.tensor.detach().cpu(), loss.item(), {n: p.grad.detach().cpu().clone() for n, p in lm.model.named_parameters()})
+    for mode in ("native", "generic_fused"):
+        a, b = res[mode][0], res["generic"][0]
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert rel_err(torch.nan_to_num(a), torch.nan_to_num(b)) < 2e-5  # BatchNorm batch statistics differ in the last bits per call
+        assert abs(res[mode][1] - res["generic"][1]) / abs(res["generic"][1]) < 1e-5
+        for n in res[mode][2]:
+            assert rel_err(res[mode][2][n], res["generic"][2][n]) < 5e-2, (mode, n)  # chaotic BPTT (see test above); typical 1e-4
 
 
 def test_native_rollout_accumulates_into_flat_grad_buffer(gpu_device):
