@@ -493,7 +493,9 @@ class AutoRegressiveLightning(_Base):
         with torch.no_grad():
             prediction, target = self.common_step(batch, batch_idx, phase="val_test")
             mask, target_masked = self.get_mask_on_nan(target)
-            time_step_loss = torch.mean(self.loss(prediction, target_masked, mask), dim=0)  # lightning.py:895
+            fused = getattr(prediction, "fused_loss", None)   # (B,T) loss already produced by the rollout's fused steps
+            loss_bt = fused if fused is not None else self.loss(prediction, target_masked, mask)
+            time_step_loss = torch.mean(loss_bt, dim=0)  # lightning.py:895
             mean_loss = torch.mean(time_step_loss)
         return prediction, target_masked, mask, time_step_loss, mean_loss
 

@@ -231,6 +231,11 @@ def test_common_step_matches_reference_golden(gpu_device, path):
     np.testing.assert_allclose(loss.item(), outs["train_loss"], rtol=1e-4)
     np.testing.assert_allclose(lm.model.w.grad.cpu().numpy(), outs["grad_w"], rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(lm.model.b.grad.cpu().numpy(), outs["grad_b"], rtol=2e-3, atol=2e-5)
+    # validation_step (lightning.py:888-917): mean over batch and steps of the same loss, with and without the fused step
+    for fused in (True, False):
+        lm.use_fused_step = fused
+        val = lm.validation_step(make_batch(case, gpu_device), 0)
+        np.testing.assert_allclose(float(val), float(np.mean(outs["loss_wmse"])), rtol=2e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
