@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) build_x_kernel(const float* __restrict__ 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte access (forcing rows)
 
-template <typename TX>
+template <typename TX, bool ODD = false>
 __global__ void __launch_bounds__(256)
     build_x_v4_kernel(const float* __restrict__ prev, int64_t prev_bs, int64_t prev_ts, const float* __restrict__ statics,
                       int64_t statics_bs, const float* __restrict__ forcing, int64_t forcing_bs, TX* __restrict__ x,
@@ -170,7 +170,16 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int64_t n = base + (int64_t)u * nwaves * PP;
-            if (n < total) store4f(x + ((int64_t)b * N + n) * (int64_t)c_pad + c0, v[u]);
+            if (n < total) {
+                TX* xr = x + ((int64_t)b * N + n) * (int64_t)c_pad + c0;
+                if constexpr (ODD) {   // fp32 rows of c_pad % 4 != 0 channels: 4-byte aligned 16-byte stores + a scalar tail
+                    if (c0 + 3 < c_pad) *reinterpret_cast<v4f_a4*>(xr) = v[u];
+                    else
+                        for (int j = 0; j < c_pad - c0; ++j) xr[j] = v[u][j];
+                } else {
+                    store4f(xr, v[u]);
+                }
+            }
         }
     }
 }
@@ -310,15 +319,20 @@ extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, 
     const int FP = pow2_ge(c_pad);
     const int iters = (c_pad + FP - 1) / FP;
     P4C_CHECK_ARG(iters <= K1_MAX_ITERS, "p4c_build_x: c_pad %d too large (max %d)", c_pad, 64 * K1_MAX_ITERS);
-    if (!mask_on_nan && c_pad % 4 == 0 && c_pad <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-        (x_dtype == P4C_F32 || x_dtype == P4C_BF16)) {
-        const int FP4 = pow2_ge(c_pad / 4);
+    const bool odd = c_pad % 4 != 0;   // the exact C_in of a generic model (e.g. 69): fp32 rows, unaligned vector stores
+    if (!mask_on_nan && c_pad <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+        ((x_dtype == P4C_F32) || (x_dtype == P4C_BF16 && !odd))) {
+        const int FP4 = pow2_ge((c_pad + 3) / 4);
         const int vec_prev = n_prev_ch > 0 && F % 4 == 0 && prev_bs % 4 == 0 && prev_ts % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(prev) & 15) == 0;
         const int vec_stat = Fs % 4 == 0 && n_prev_ch % 4 == 0 && statics_bs % 4 == 0 &&
                              (reinterpret_cast<uintptr_t>(statics) & 15) == 0;
         const int grid4 = stream_grid(N, 64 / FP4);
-        if (x_dtype == P4C_F32)
+        if (x_dtype == P4C_F32 && odd)
+            hipLaunchKernelGGL((build_x_v4_kernel<float, true>), dim3(grid4, B), dim3(256), 0, as_stream(stream), prev, prev_bs,
+                               prev_ts, statics, statics_bs, forcing, forcing_bs, (float*)x, c_pad, B, T_in, N, F, Fs, Ff,
+                               n_prev_ch, FP4, vec_prev, vec_stat);
+        else if (x_dtype == P4C_F32)
             hipLaunchKernelGGL(build_x_v4_kernel<float>, dim3(grid4, B), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
                                statics, statics_bs, forcing, forcing_bs, (float*)x, c_pad, B, T_in, N, F, Fs, Ff, n_prev_ch, FP4,
                                vec_prev, vec_stat);
