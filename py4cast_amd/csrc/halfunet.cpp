@@ -112,7 +112,10 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     for (int i = 0; i < NCONV; ++i) { L.norm[i] = off; off += 4 * (int64_t)d.B * NF; }
     L.saved_bytes = L.norm_base + off * (int64_t)sizeof(float);
 
-    L.G = num_cus();
+    // The weight-gradient kernels run beside the main stream's kernels: 3/4 of the CUs measured best (fewer per-workgroup
+    // partials to write and reduce, and CUs left to the kernels they overlap); P4C_WGRAD_G overrides for experiments.
+    L.G = d.compute == P4C_BF16 ? num_cus() * 3 / 4 : num_cus();   // (fp32 matrix cores: the kernel is MFMA-bound, all CUs)
+    if (const char* e = getenv("P4C_WGRAD_G")) { const int g = atoi(e); if (g > 0 && g <= num_cus()) L.G = g; }
     off = 0;
     L.wprep = off; off += (int64_t)NWSLOT * WSLOT_FLOATS;
     const int64_t tps = conv_tiles_per_sample(d.H, d.W);
