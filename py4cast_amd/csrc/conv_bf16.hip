@@ -1442,6 +1442,274 @@ __global__ void __launch_bounds__(256, 1)
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv3x3_wgrad_bf16_ws: weight gradient of the 3x3 conv, 64 input channels (one 64-channel chunk) x 64 output
+// channels, bf16 storage -- the role-split form of conv_wgrad_bf16_kernel.  In the single-role kernel the staging of a
+// tile (wait, 19 LDS writes, barrier, 19 buffer loads per lane: ~4.7k cycles) is serial with its 8k-cycle matrix phase.
+// Here waves 4-7 stage tile t+1 into the other LDS buffer (and prefetch tiles t+2, t+3 into registers) while waves 0-3
+// run the K loop of tile t; one LDS-only barrier per tile.  Tiles are 4 x 32 pixels so that two (input + halo, output
+// gradient) images fit: 2 x (6x34 + 4x32) pixels x 192 B = 125 KB.
+namespace wgws {
+constexpr int TH = 4, LH = TH + 2, LW = BTW + 2, ROWA = 192, ROWD = 192;
+constexpr int INB = LH * LW * ROWA, DOB = TH * BTW * ROWD, BUFB = INB + DOB;
+constexpr int MAXB = 32;
+constexpr int SMEM = 2 * BUFB + MAXB * 128 * 4;
+constexpr int NI = (LH * LW * 8 + 255) / 256, ND = TH * BTW * 8 / 256;   // 7 + 4 slots of 16 B per lane and tile
+constexpr int TOT_IN = LH * LW * 8;
+}  // namespace wgws
+
+template <int MODE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+    conv3x3_wgrad_bf16_ws_kernel(const __bf16* __restrict__ in, const float* __restrict__ in_scale,
+                                 const float* __restrict__ in_shift, const __bf16* __restrict__ dout,
+                                 float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip) {
+    using namespace wgws;
+    constexpr int NTAPS = 9, KSTEPS = TH * BTW / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lnorm = reinterpret_cast<float*>(smem + 2 * BUFB);
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool loader = wv >= 4;
+    const int ltid = threadIdx.x - 256;
+    const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * B;
+    const int t_begin = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
+    const int t_end = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    const __bf16* inb = in + ci_off;
+
+    if (loader) {
+        if (t_begin >= t_end) return;
+        const int c8 = ltid & 7;
+        struct Cur { int t, b, tx, ty; };
+        auto cur_init = [&]() __attribute__((always_inline)) {
+            Cur c;
+            c.t = t_begin;
+            c.ty = t_begin % tiles_y;
+            const int rest = t_begin / tiles_y;
+            c.tx = rest % tiles_x;
+            c.b = rest / tiles_x;
+            return c;
+        };
+        auto cur_next = [&](Cur& c) __attribute__((always_inline)) {
+            ++c.t;
+            if (++c.ty == tiles_y) {
+                c.ty = 0;
+                if (++c.tx == tiles_x) { c.tx = 0; ++c.b; }
+            }
+        };
+        // per-lane tables (slot -> offsets), same for every tile
+        int gi[NI], li[NI], pi[NI], gd[ND], ld[ND];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int pix = (ltid + it * 256) >> 3;
+            const int ly = pix / LW, lx = pix - ly * LW;
+            gi[it] = ((ly * W + lx) * in_cs + 8 * c8) * 2;
+            li[it] = pix * ROWA + 16 * c8;
+            pi[it] = (ly << 8) | lx;
+        }
+#pragma unroll
+        for (int it = 0; it < ND; ++it) {
+            const int pix = (ltid + it * 256) >> 3;
+            gd[it] = (((pix >> 5) * W + (pix & 31)) * 64 + 8 * c8) * 2;
+            ld[it] = INB + pix * ROWD + 16 * c8;
+        }
+        struct Img { u32x4 a[NI]; u32x4 d[ND]; };
+        Img ta, tb;
+        Cur lc = cur_init(), sc_ = cur_init();
+        // same number of memory operations on every path (see conv3x3_bf16_ring_kernel): exact s_waitcnt counts
+        auto load = [&](Img& im) __attribute__((always_inline)) {
+            const bool live = lc.t < t_end;
+            const int b = live ? lc.b : 0, y0 = live ? lc.ty * TH : 0, x0 = live ? lc.tx * BTW : 0;
+            cur_next(lc);
+            const __amdgpu_buffer_rsrc_t rsi = make_rsrc(inb + (int64_t)b * H * W * in_cs, (unsigned)(((int64_t)H * W * in_cs - ci_off) * 2));
+            const __amdgpu_buffer_rsrc_t rsd = make_rsrc(dout + (int64_t)b * H * W * 64, (unsigned)((int64_t)H * W * 64 * 2));
+            const int gy0 = y0 - 1, gx0 = x0 - 1;
+            if (live && gy0 >= 0 && y0 + TH + 1 <= H && gx0 >= 0 && x0 + BTW + 1 <= W) {
+                const int so = (gy0 * W + gx0) * in_cs * 2, sd = (y0 * W + x0) * 64 * 2;
+#pragma unroll
+                for (int it = 0; it < NI; ++it)
+                    im.a[it] = __builtin_amdgcn_raw_buffer_load_b128(rsi, (ltid + it * 256 < TOT_IN) ? gi[it] : OOB, so, 0);
+#pragma unroll
+                for (int it = 0; it < ND; ++it) im.d[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, gd[it], sd, 0);
+            } else {
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int gy = gy0 + (pi[it] >> 8), gx = gx0 + (pi[it] & 255);
+                    const bool ok = live & (ltid + it * 256 < TOT_IN) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                    im.a[it] = __builtin_amdgcn_raw_buffer_load_b128(rsi, ok ? ((gy * W + gx) * in_cs + 8 * c8) * 2 : OOB, 0, 0);
+                }
+#pragma unroll
+                for (int it = 0; it < ND; ++it) {
+                    const int pix = (ltid + it * 256) >> 3;
+                    const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+                    im.d[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, (live & (gy < H) & (gx < W)) ? ((gy * W + gx) * 64 + 8 * c8) * 2 : OOB, 0, 0);
+                }
+            }
+        };
+        f32x2 sc[4], sh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sc[k] = sh[k] = f32x2{0.f, 0.f};
+        int sc_b = -1;
+        auto store = [&](const Img& im, char* buf) __attribute__((always_inline)) {
+            const int t = sc_.t, b = sc_.b, y0 = sc_.ty * TH, x0 = sc_.tx * BTW;
+            cur_next(sc_);
+            if (t >= t_end) return;
+            if (MODE >= 2 && b != sc_b) {
+                sc_b = b;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sc[k] = *reinterpret_cast<const f32x2*>(lnorm + b * 128 + 8 * c8 + 2 * k);
+                    sh[k] = *reinterpret_cast<const f32x2*>(lnorm + b * 128 + 64 + 8 * c8 + 2 * k);
+                }
+            }
+            const int gy0 = y0 - 1, gx0 = x0 - 1;
+            const bool interior = gy0 >= 0 && y0 + TH + 1 <= H && gx0 >= 0 && x0 + BTW + 1 <= W;
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                u32x4 o = im.a[it];
+                if (MODE != 0) {
+                    unsigned int keep = 0xffffffffu;
+                    if (!interior) {   // zero padding applies to the NORMALISED activation
+                        const int gy = gy0 + (pi[it] >> 8), gx = gx0 + (pi[it] & 255);
+                        keep = (((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W)) ? 0xffffffffu : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = xform2<MODE>(o[k], sc[k], sh[k]) & keep;
+                }
+                if (ltid + it * 256 < TOT_IN) *reinterpret_cast<u32x4*>(buf + li[it]) = o;
+            }
+#pragma unroll
+            for (int it = 0; it < ND; ++it) *reinterpret_cast<u32x4*>(buf + ld[it]) = im.d[it];
+        };
+
+        load(ta);
+        load(tb);
+        if (MODE >= 2) {
+            for (int i = ltid; i < B * 64; i += 256) {
+                const int b = i >> 6, c = i & 63;
+                lnorm[b * 128 + c] = in_scale[(int64_t)b * in_cs + ci_off + c];
+                lnorm[b * 128 + 64 + c] = in_shift[(int64_t)b * in_cs + ci_off + c];
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        store(ta, smem);
+        load(ta);
+        lds_barrier();
+        for (int tile = t_begin; tile < t_end; tile += 2) {
+            store(tb, smem + BUFB);     // compute reads buffer 0
+            load(tb);
+            lds_barrier();
+            if (tile + 1 >= t_end) break;
+            store(ta, smem);            // compute reads buffer 1
+            load(ta);
+            lds_barrier();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- compute waves: one (32 ci x 32 co) unit each
+    const int h = lane >> 5, r = lane & 31;
+    const int cit = wv >> 1, cot = wv & 1;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    const int a_col = (cit * 32 + tg * 16 + tp * 4) * 2, b_col = (cot * 32 + tg * 16 + tp * 4) * 2;
+    f32x16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    if (t_begin < t_end) {
+        if (MODE >= 2) lds_barrier();
+        lds_barrier();
+        struct Ops { s16x4 b[2]; s16x4 a[NTAPS][2]; };
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const char* lin = smem + ((tile - t_begin) & 1) * BUFB;
+            const char* ldo = lin + INB;
+            auto fetch = [&](Ops& o, int kstep) __attribute__((always_inline)) {
+                const int row = kstep >> 1, col0 = (kstep & 1) * 16;
+                const int px = col0 + 8 * h + tq;
+                const char* bp = ldo + (row * BTW + px) * ROWD + b_col;
+                o.b[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+                o.b[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 4 * ROWD));
+                const char* ap0 = lin + (row * LW + px) * ROWA + a_col;
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    const int ky = t / 3, kx = t - ky * 3;
+                    const char* ap = ap0 + (ky * LW + kx) * ROWA;
+                    o.a[t][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap));
+                    o.a[t][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap + 4 * ROWA));
+                }
+            };
+            auto mma = [&](const Ops& o) __attribute__((always_inline)) {
+                union { s16x4 s[2]; bf16x8 v; } ub;
+                ub.s[0] = o.b[0]; ub.s[1] = o.b[1];
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    union { s16x4 s[2]; bf16x8 v; } u;
+                    u.s[0] = o.a[t][0]; u.s[1] = o.a[t][1];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ub.v, acc[t], 0, 0, 0);
+                }
+            };
+            Ops o0, o1;
+            fetch(o0, 0);
+#pragma unroll 1
+            for (int kk = 0; kk < KSTEPS; kk += 2) {
+                fetch(o1, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(o0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < KSTEPS) fetch(o0, kk + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(o1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_barrier();
+        }
+    }
+    // C[ci][co]: lane = co (r), register i -> ci = (i&3) + 8*(i>>2) + 4*h.  One partial per workgroup.
+    float* pbase = partial + (int64_t)blockIdx.x * NTAPS * part_cip * 64;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ci = ci_off + cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            pbase[((int64_t)t * part_cip + ci) * 64 + cot * 32 + r] = acc[t][i];
+        }
+}
+
+template <int MODE>
+static int launch_wgrad_ws_mode(const __bf16* in, const float* in_scale, const float* in_shift, const __bf16* dout, float* partial,
+                                int G, int B, int H, int W, int in_cs, int ci_off, int part_cip, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_ws_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          wgws::SMEM));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_bf16_ws_kernel<MODE>, dim3(G), dim3(512), wgws::SMEM, stream, in, in_scale, in_shift, dout,
+                       partial, B, H, W, in_cs, ci_off, part_cip);
+    return P4C_OK;
+}
+
+static int launch_conv3x3_wgrad_bf16_ws(const __bf16* in, const float* in_scale, const float* in_shift, int in_relu,
+                                        const __bf16* dout, float* partial, int G, int B, int H, int W, int in_cs, int ci_off,
+                                        int part_cip, hipStream_t stream) {
+    const int tiles = ((H + 3) / 4) * ((W + BTW - 1) / BTW) * B;
+    if (tiles < G) G = tiles;
+    const int tag = (in_cs == 64) ? P4C_PROF_WGRAD3X3_C64 : 0;
+    if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
+    int rc;
+    if (in_scale)
+        rc = in_relu ? launch_wgrad_ws_mode<2>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream)
+                     : launch_wgrad_ws_mode<3>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream);
+    else
+        rc = in_relu ? launch_wgrad_ws_mode<1>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream)
+                     : launch_wgrad_ws_mode<0>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream);
+    if (tag) prof_end(tag, stream);
+    if (rc != P4C_OK) return rc;
+    P4C_CHECK_LAUNCH("conv3x3_wgrad_bf16_ws");
+    return P4C_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <typename T, int CI, int KS, int NBUF>
 static int launch_conv_fwd_bf16(const T* in, const __bf16* wp, const float* in_scale, const float* in_shift, int in_relu,
                                 T* out, int out_cs, float* stat_partial, int B, int H, int W, int m_blocks,
@@ -1553,7 +1821,10 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
     for (int off = 0; off < CI;) {
         const int chunk = (CI - off >= 64) ? 64 : 32;
         int rc;
-        if (chunk == 64 && ks == 3)
+        if (chunk == 64 && ks == 3 && std::is_same<T, __bf16>::value && B <= wgws::MAXB && getenv("P4C_NO_WGWS") == nullptr)
+            rc = launch_conv3x3_wgrad_bf16_ws((const __bf16*)in, in_scale, in_shift, in_relu, (const __bf16*)dout, partial, G, B, H, W,
+                                              CI, off, CI, stream);
+        else if (chunk == 64 && ks == 3)
             rc = launch_conv_wgrad_bf16<T, 64, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         else if (chunk == 32 && ks == 3)
             rc = launch_conv_wgrad_bf16<T, 32, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
