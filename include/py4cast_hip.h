@@ -313,6 +313,56 @@ int p4c_halfunet_forward(const p4c_halfunet_desc* d, const void* x, const float*
 int p4c_halfunet_backward(const p4c_halfunet_desc* d, const void* x, const float* params, const void* dy, void* dx,
                           float* grads, void* saved, void* scratch, int training, p4c_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------
+ * Mesh-GNN path (model_name GraphLam / HiLam / HiLamParallel: config/CLI/model/graphlam.yaml:19-26, hilam.yaml,
+ * hilamparallel.yaml; graph batches are (B, ngrid, features), py4cast/lightning.py:526-535).  An InteractionNet layer
+ * is  m_e = MLP_e([e, x_s[src(e)], x_r[dst(e)]]),  agg_n = sum_{e: dst(e)=n} m_e  (mesh_aggr: sum),
+ * x_r += MLP_n([x_r, agg]).  These entry points are its edge gather / scatter passes; rows are C contiguous
+ * features, C * sizeof(dtype) a multiple of 16 bytes, indices int32.
+ * ------------------------------------------------------------------------------------ */
+enum p4c_activation { P4C_ACT_NONE = 0, P4C_ACT_RELU = 1, P4C_ACT_SILU = 2 };
+
+/* out[e] = act(base[e] + a[ia[e]] + b[ib[e]])  for e < E: the first Linear of MLP_e distributed over the concat
+ * (base = e W_e + bias, a = x_s W_s, b = x_r W_r are projected once per edge / node), replacing
+ * index_select + cat + activation.  base, (a, ia), (b, ib) are each optional (NULL).  All rows have C features. */
+int p4c_edge_gather_add_fwd(const void* base, const void* a, const int32_t* ia, const void* b, const int32_t* ib,
+                            void* out, int64_t E, int C, int dtype, int act, p4c_stream_t stream);
+/* dpre[e] = dh[e] * act'(base[e] + a[ia[e]] + b[ib[e]]) (the pre-activation is recomputed, never stored).  dpre is the
+ * gradient of base; the gradients of a and b are p4c_segment_sum(dpre) over the CSR of ia and ib. */
+int p4c_edge_gather_add_bwd(const void* dh, const void* base, const void* a, const int32_t* ia, const void* b,
+                            const int32_t* ib, void* dpre, int64_t E, int C, int dtype, int act, p4c_stream_t stream);
+/* out[n] = (init ? init[n] : 0) + sum_{j in [offsets[n], offsets[n+1])} msg[perm ? perm[j] : j]   for n < N:
+ * receiver-sorted CSR (offsets: N+1 entries; perm: E edge ids grouped by receiver, NULL if msg is already grouped),
+ * replacing index_add_ -- no atomics, fixed summation order (bitwise reproducible).  Also the adjoint of a row
+ * gather.  msg: (E,C) of `dtype`; init/out: (N,C) of `out_dtype` (= dtype, or P4C_F32 for bf16 messages). */
+int p4c_segment_sum(const void* msg, const int32_t* offsets, const int32_t* perm, const void* init, void* out,
+                    int64_t N, int64_t E, int C, int dtype, int out_dtype, p4c_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------
+ * Swin path (model_name SwinUNetR: config/CLI/model/swinunetr.yaml:19-30 -- depths [2,2,2,2], num_heads [3,6,12,24],
+ * feature_size 24 => head_dim 8; grid batches (B, lat, lon, features), py4cast/lightning.py:591-596).
+ * Windowed multi-head self-attention of one Swin block on the token grid, shift / window partition / head split and
+ * their inverses folded into the addressing:
+ *   out[b,y,x,head,:] = sum_k softmax_k(q.k * scale + bias[head][q][k] + shift_mask[q][k]) v_k
+ * over the ws x ws window of the grid rolled by (-shift, -shift) that contains (y, x); shift_mask = -100 between tokens
+ * of different wrap-around regions (Swin's attn_mask), 0 otherwise.
+ *   qkv   : (B, Hp, Wp, 3, heads, head_dim)   -- the qkv Linear's output, `dtype` storage; Hp, Wp multiples of ws
+ *   bias_t: (heads, N, N) fp32 indexed [head][key][query], N = ws*ws (the relative-position bias, TRANSPOSED); NULL = none
+ *   out   : (B, Hp, Wp, heads*head_dim)
+ * head_dim in {8,16,32}, ws in 3..8.  Products on the bf16 matrix cores (operands rounded to bf16), softmax in fp32.
+ * ------------------------------------------------------------------------------------ */
+int p4c_window_attn_fwd(const void* qkv, const float* bias_t, void* out, int B, int Hp, int Wp, int heads, int head_dim,
+                        int ws, int shift, float scale, int dtype, p4c_stream_t stream);
+/* dqkv: gradient of qkv (same layout; fully written).  dbias_t (or NULL): gradient of bias_t, (heads,N,N) [key][query],
+ * summed over batch and windows in a fixed order; needs `workspace` of p4c_window_attn_bwd_workspace_bytes() bytes.
+ * The attention matrix is recomputed from qkv, nothing is saved by the forward. */
+size_t p4c_window_attn_bwd_workspace_bytes(int B, int Hp, int Wp, int heads, int ws);
+int p4c_window_attn_bwd(const void* qkv, const float* bias_t, const void* dout, void* dqkv, float* dbias_t, void* workspace,
+                        int B, int Hp, int Wp, int heads, int head_dim, int ws, int shift, float scale, int dtype,
+                        p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,9 +28,15 @@ SIGNATURES = {
     "p4c_halfunet_prepare_weights": [DP, P, P, P],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],
     "p4c_halfunet_backward": [DP, P, P, P, P, P, P, P, I, P],
+    "p4c_edge_gather_add_fwd": [P, P, P, P, P, P, L, I, I, I, P],
+    "p4c_edge_gather_add_bwd": [P, P, P, P, P, P, P, L, I, I, I, P],
+    "p4c_segment_sum": [P, P, P, P, P, L, L, I, I, I, P],
+    "p4c_window_attn_fwd": [P, P, P, I, I, I, I, I, I, I, F, I, P],
+    "p4c_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
 }
 OTHER = {
     "p4c_conv_wgrad_workspace_bytes": ([I, I], c_size_t),
     "p4c_conv_stat_tiles": ([I, I, I, I, I, I], c_int),
     "p4c_halfunet_param_count": ([DP], c_int64),
+    "p4c_window_attn_bwd_workspace_bytes": ([I, I, I, I, I], c_size_t),
 }

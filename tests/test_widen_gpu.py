@@ -1,0 +1,213 @@
+"""GPU parity of the widened model kernels against their oracles (oracle/graph.py, oracle/window_attention.py):
+mesh-GNN edge gather / segment sum (fp32: exact up to summation order; bf16: one rounding) and the fused Swin window
+attention (bf16 matrix cores: compared with a float64 oracle fed the SAME bf16-rounded operands)."""
+
+import pytest
+import torch
+
+from oracle import graph as og
+from oracle import window_attention as owa
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+# ----------------------------------------------------------------------------------------- graph
+def _edges(E, Ns, Nr, seed, skew=False):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, Ns, (E,), generator=g)
+    if skew:  # a few very popular receivers, some with no edge at all
+        dst = (torch.rand(E, generator=g) ** 4 * (Nr - 3)).long()
+    else:
+        dst = torch.randint(0, Nr, (E,), generator=g)
+    return src, dst
+
+
+@pytest.mark.parametrize("C", [64, 16, 96, 264])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [None, "relu", "silu"])
+def test_edge_gather_add_forward(gpu_device, C, dtype, act):
+    from py4cast_amd import ops_graph as G
+
+    if dtype == torch.bfloat16 and C % 8:
+        pytest.skip("row not a multiple of 16 bytes")
+    E, Ns, Nr = 1000 + 7, 301, 77
+    src, dst = _edges(E, Ns, Nr, 3)
+    torch.manual_seed(4)
+    base, a, b = (torch.randn(n, C).to(dtype) for n in (E, Ns, Nr))
+    es = G.EdgeSet(src, dst, Ns, Nr).to(gpu_device)
+    got = G.edge_gather_add(base.to(gpu_device), a.to(gpu_device), b.to(gpu_device), es, act).cpu()
+    ref = og.edge_gather_add(base.double(), a.double(), src, b.double(), dst, act)
+    tol = 1e-6 if dtype == torch.float32 else 6e-3
+    assert _rel(got, ref) < tol
+    # optional operands
+    got2 = G.edge_gather_add(None, a.to(gpu_device), None, es, act).cpu()
+    assert _rel(got2, og.edge_gather_add(None, a.double(), src, None, dst, act)) < tol
+
+
+@pytest.mark.parametrize("skew", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("E,N,C", [(5000, 300, 64), (20000, 37, 64), (300, 1000, 32), (4097, 511, 128)])
+def test_segment_sum(gpu_device, E, N, C, dtype, skew):
+    from py4cast_amd import ops_graph as G
+
+    src, dst = _edges(E, 50, N, 5, skew)
+    torch.manual_seed(6)
+    msg = torch.randn(E, C).to(dtype)
+    es = G.EdgeSet(src, dst, 50, N).to(gpu_device)
+    got = G.aggregate_sum(msg.to(gpu_device), es)
+    ref = og.aggregate_sum(msg.double(), dst, N)
+    assert _rel(got.cpu(), ref) < (1e-6 if dtype == torch.float32 else 6e-3)
+    # bitwise reproducible (fixed summation order, no atomics)
+    again = G.aggregate_sum(msg.to(gpu_device), es)
+    assert torch.equal(got, again)
+    # empty receivers are exact zeros
+    empty = torch.bincount(dst, minlength=N) == 0
+    if empty.any():
+        assert float(got.cpu()[empty].abs().max()) == 0.0
+
+
+def test_segment_sum_bf16_to_f32_and_empty(gpu_device):
+    from py4cast_amd import ops_graph as G
+
+    src, dst = _edges(3000, 50, 100, 7)
+    msg = torch.randn(3000, 64).bfloat16()
+    es = G.EdgeSet(src, dst, 50, 100).to(gpu_device)
+    got = G._segment_sum_raw(msg.to(gpu_device), *es.by_dst, 100, out_dtype=torch.float32)
+    assert got.dtype == torch.float32
+    assert _rel(got.cpu(), og.aggregate_sum(msg.double(), dst, 100)) < 1e-6
+    none = G.EdgeSet(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 5, 9).to(gpu_device)
+    z = G.aggregate_sum(torch.zeros(0, 64, device=gpu_device), none)
+    assert z.shape == (9, 64) and float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("act", [None, "silu", "relu"])
+def test_interaction_edge_pass_gradients(gpu_device, act):
+    """gather-add -> (x2) -> aggregate: gradients of every input against torch autograd on the oracle (float64)."""
+    from py4cast_amd import ops_graph as G
+
+    E, Ns, Nr, C = 4000, 200, 150, 64
+    src, dst = _edges(E, Ns, Nr, 8, skew=True)
+    torch.manual_seed(9)
+    base, a, b = (torch.randn(n, C) for n in (E, Ns, Nr))
+    wgt = torch.randn(Nr, C)
+    es = G.EdgeSet(src, dst, Ns, Nr).to(gpu_device)
+    leaves = [t.clone().to(gpu_device).requires_grad_(True) for t in (base, a, b)]
+    h = G.edge_gather_add(*leaves, es, act)
+    agg = G.aggregate_sum(h * 2.0, es)
+    (agg * wgt.to(gpu_device)).sum().backward()
+    ref_leaves = [t.double().requires_grad_(True) for t in (base, a, b)]
+    hr = og.edge_gather_add(ref_leaves[0], ref_leaves[1], src, ref_leaves[2], dst, act)
+    (og.aggregate_sum(hr * 2.0, dst, Nr) * wgt.double()).sum().backward()
+    assert _rel(agg.detach().cpu(), og.aggregate_sum(hr.detach() * 2.0, dst, Nr)) < 1e-5
+    for got, ref in zip(leaves, ref_leaves):
+        assert _rel(got.grad.cpu(), ref.grad) < 1e-5
+
+
+def test_graph_ops_reject_cpu_tensors():
+    from py4cast_amd import _lib as L
+    from py4cast_amd import ops_graph as G
+
+    es = G.EdgeSet(torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long), 2, 2)
+    with pytest.raises(L.P4CError):
+        G.edge_gather_add(torch.zeros(4, 64), None, None, es)
+
+
+# ----------------------------------------------------------------------------------------- window attention
+CASES = [
+    # B, Hp, Wp, heads, d, ws, shift
+    (2, 14, 21, 3, 8, 7, 0),
+    (2, 14, 21, 3, 8, 7, 3),
+    (1, 16, 24, 2, 16, 8, 4),
+    (1, 16, 8, 1, 32, 8, 0),
+    (2, 8, 12, 4, 8, 4, 2),
+    (1, 35, 35, 6, 8, 7, 3),
+    (1, 7, 7, 3, 8, 7, 0),
+]
+
+
+def _attn_inputs(B, Hp, Wp, heads, d, ws, seed, dtype):
+    torch.manual_seed(seed)
+    qkv = (torch.randn(B, Hp, Wp, 3 * heads * d) * 1.5).to(dtype)
+    table = torch.randn((2 * ws - 1) ** 2, heads) * 0.5
+    bias = table[owa.relative_position_index(ws).view(-1)].view(ws * ws, ws * ws, heads).permute(2, 0, 1).contiguous()
+    return qkv, bias
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", CASES)
+def test_window_attention_forward(gpu_device, case, dtype):
+    from py4cast_amd.ops_attention import window_attention
+
+    B, Hp, Wp, heads, d, ws, shift = case
+    qkv, bias = _attn_inputs(B, Hp, Wp, heads, d, ws, 11, dtype)
+    got = window_attention(qkv.to(gpu_device), bias.to(gpu_device), heads, ws, shift).float().cpu()
+    ref = owa.window_attention(qkv.bfloat16().double(), bias.double(), heads, ws, shift)  # the operands the MFMAs see
+    # P is rounded to bf16 before P @ V (2^-9 relative per element), bf16 outputs add one more rounding
+    assert _rel(got, ref) < (4e-3 if dtype == torch.float32 else 6e-3)
+    no_bias = window_attention(qkv.to(gpu_device), None, heads, ws, shift).float().cpu()
+    assert _rel(no_bias, owa.window_attention(qkv.bfloat16().double(), None, heads, ws, shift)) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", CASES)
+def test_window_attention_backward(gpu_device, case, dtype):
+    from py4cast_amd.ops_attention import window_attention
+
+    B, Hp, Wp, heads, d, ws, shift = case
+    qkv, bias = _attn_inputs(B, Hp, Wp, heads, d, ws, 12, dtype)
+    torch.manual_seed(13)
+    dout = torch.randn(B, Hp, Wp, heads * d).to(dtype)
+    q_g = qkv.to(gpu_device).requires_grad_(True)
+    b_g = bias.to(gpu_device).requires_grad_(True)
+    out = window_attention(q_g, b_g, heads, ws, shift)
+    out.backward(dout.to(gpu_device))
+    q_r = qkv.bfloat16().double().requires_grad_(True)
+    b_r = bias.double().requires_grad_(True)
+    owa.window_attention(q_r, b_r, heads, ws, shift).backward(dout.bfloat16().double())
+    # bf16-rounded P / dS operands: ~1e-2 on individual gradients
+    assert _rel(q_g.grad.float().cpu(), q_r.grad) < 1.5e-2
+    assert _rel(b_g.grad.float().cpu(), b_r.grad) < 1.5e-2
+    # each of dq, dk, dv on its own (a wrong block would hide in the norm of the others)
+    C = heads * d
+    for part in range(3):
+        sl = slice(part * C, (part + 1) * C)
+        assert _rel(q_g.grad.float().cpu()[..., sl], q_r.grad[..., sl]) < 2e-2
+    # deterministic bias gradient (fixed reduction order)
+    q2 = qkv.to(gpu_device).requires_grad_(True)
+    b2 = bias.to(gpu_device).requires_grad_(True)
+    window_attention(q2, b2, heads, ws, shift).backward(dout.to(gpu_device))
+    assert torch.equal(b2.grad, b_g.grad) and torch.equal(q2.grad, q_g.grad)
+
+
+def test_window_attention_masks_are_exact(gpu_device):
+    """Index / mask semantics: with v = one-hot of the token's wrap-around region and huge logits inside a region the output
+    must reproduce the region structure exactly (no leakage across the shift mask beyond exp(-100))."""
+    from py4cast_amd.ops_attention import window_attention
+
+    B, Hp, Wp, heads, d, ws, shift = 1, 14, 14, 1, 8, 7, 3
+    qkv = torch.zeros(B, Hp, Wp, 3 * d)
+    rolled_region = torch.zeros(Hp, Wp, dtype=torch.long)
+    for i, hs in enumerate((slice(0, -ws), slice(-ws, -shift), slice(-shift, None))):
+        for j, wsl in enumerate((slice(0, -ws), slice(-ws, -shift), slice(-shift, None))):
+            rolled_region[hs, wsl] = (i % 2) * 2 + (j % 2)   # 4 ids are enough inside one window
+    region = torch.roll(rolled_region, shifts=(shift, shift), dims=(0, 1))  # back to unshifted coordinates
+    qkv[0, :, :, 2 * d:2 * d + 4] = torch.nn.functional.one_hot(region, 4).float()
+    out = window_attention(qkv.to(gpu_device), None, heads, ws, shift).cpu()
+    # q = k = 0 => uniform attention over the unmasked tokens => output is exactly the own region's one-hot
+    assert torch.allclose(out[0, :, :, :4], torch.nn.functional.one_hot(region, 4).float(), atol=1e-6)
+
+
+def test_window_attention_rejects_bad_shapes(gpu_device):
+    from py4cast_amd import _lib as L
+    from py4cast_amd.ops_attention import window_attention
+
+    with pytest.raises(L.P4CError):
+        window_attention(torch.zeros(1, 10, 14, 24, device=gpu_device), None, 1, 7, 0)   # 10 not a multiple of 7
+    with pytest.raises(L.P4CError):
+        window_attention(torch.zeros(1, 7, 7, 3 * 12, device=gpu_device), None, 1, 7, 0)  # head_dim 12
+    with pytest.raises(L.P4CError):
+        window_attention(torch.zeros(1, 7, 7, 24), None, 1, 7, 0)                          # CPU tensor

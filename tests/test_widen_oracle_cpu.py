@@ -1,0 +1,89 @@
+"""CPU checks of the oracles of the widened model kernels (mesh-GNN edge passes, Swin window attention): each restatement is
+compared with an independent formulation of the same published operation (parity with mfai itself is unpinned: the package is
+absent from the reference checkout, see oracle/__init__.py)."""
+
+import math
+
+import pytest
+import torch
+
+from oracle import graph as og
+from oracle import window_attention as owa
+
+
+def test_edge_first_layer_distributes_over_concat():
+    torch.manual_seed(0)
+    E, Ns, Nr, C = 200, 30, 17, 16
+    e, xs, xr = torch.randn(E, C, dtype=torch.float64), torch.randn(Ns, C, dtype=torch.float64), torch.randn(Nr, C, dtype=torch.float64)
+    src, dst = torch.randint(0, Ns, (E,)), torch.randint(0, Nr, (E,))
+    w, bias = torch.randn(C, 3 * C, dtype=torch.float64), torch.randn(C, dtype=torch.float64)
+    ref = og.edge_mlp_first_layer_concat(e, xs, xr, src, dst, w, bias, "silu")
+    got = og.edge_gather_add(e @ w[:, :C].T + bias, xs @ w[:, C:2 * C].T, src, xr @ w[:, 2 * C:].T, dst, "silu")
+    assert torch.allclose(got, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_aggregate_sum_matches_loop():
+    torch.manual_seed(1)
+    E, N, C = 64, 9, 4
+    msg, dst = torch.randn(E, C, dtype=torch.float64), torch.randint(0, N, (E,))
+    ref = torch.zeros(N, C, dtype=torch.float64)
+    for i in range(E):
+        ref[dst[i]] += msg[i]
+    assert torch.allclose(og.aggregate_sum(msg, dst, N), ref, rtol=1e-12, atol=1e-12)
+
+
+def _attention_per_pixel(qkv, bias, heads, ws, shift, scale):
+    """Brute force: for every pixel find its window in the rolled grid, attend over that window token by token."""
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    d = C // heads
+    out = torch.zeros(B, H, W, C, dtype=qkv.dtype)
+
+    def region(v, size):  # wrap-around region of a ROLLED coordinate
+        return 0 if v < size - ws else (1 if v < size - shift else 2)
+
+    for b in range(B):
+        for yr in range(H):          # rolled coordinates
+            for xr in range(W):
+                y, x = (yr + shift) % H, (xr + shift) % W
+                wy0, wx0 = yr // ws * ws, xr // ws * ws
+                qi = (yr - wy0) * ws + (xr - wx0)
+                for hd in range(heads):
+                    q = qkv[b, y, x, hd * d:(hd + 1) * d]
+                    logits, vals = [], []
+                    for ky in range(ws):
+                        for kx in range(ws):
+                            kyr, kxr = wy0 + ky, wx0 + kx
+                            yy, xx = (kyr + shift) % H, (kxr + shift) % W
+                            k = qkv[b, yy, xx, C + hd * d:C + (hd + 1) * d]
+                            s = float(q @ k) * scale
+                            if bias is not None:
+                                s += float(bias[hd, qi, ky * ws + kx])
+                            if shift > 0 and (region(yr, H), region(xr, W)) != (region(kyr, H), region(kxr, W)):
+                                s += -100.0
+                            logits.append(s)
+                            vals.append(qkv[b, yy, xx, 2 * C + hd * d:2 * C + (hd + 1) * d])
+                    p = torch.softmax(torch.tensor(logits, dtype=qkv.dtype), 0)
+                    out[b, y, x, hd * d:(hd + 1) * d] = (p[:, None] * torch.stack(vals)).sum(0)
+    return out
+
+
+@pytest.mark.parametrize("ws,shift", [(4, 0), (4, 2), (3, 1)])
+def test_window_attention_oracle_matches_per_pixel(ws, shift):
+    torch.manual_seed(2)
+    B, H, W, heads, d = 1, 2 * ws, 3 * ws, 2, 4
+    qkv = torch.randn(B, H, W, 3 * heads * d, dtype=torch.float64)
+    bias = torch.randn(heads, ws * ws, ws * ws, dtype=torch.float64)
+    ref = _attention_per_pixel(qkv, bias, heads, ws, shift, d ** -0.5)
+    got = owa.window_attention(qkv, bias, heads, ws, shift)
+    assert torch.allclose(got, ref, rtol=1e-10, atol=1e-10)
+
+
+def test_relative_position_index_is_toeplitz():
+    ws = 4
+    idx = owa.relative_position_index(ws)
+    assert idx.shape == (16, 16) and idx.min() == 0 and idx.max() == (2 * ws - 1) ** 2 - 1
+    for a in range(16):
+        for b in range(16):
+            dy, dx = a // ws - b // ws, a % ws - b % ws
+            assert idx[a, b] == (dy + ws - 1) * (2 * ws - 1) + dx + ws - 1
