@@ -1,0 +1,184 @@
+"""
+GraphLAM on the MI355X edge kernels -- the model behind ``model_name: GraphLam``
+(config/CLI/model/graphlam.yaml:19-26: hidden_dims 64, hidden_layers 1, processor_layers 4, mesh_aggr sum, tmp_dir).
+The reference takes the class from mfai v5.0.1 (py4cast/models.py:10-20), which follows neural-lam's encode-process-decode
+GNN: grid/mesh/edge embedders (MLP = Linear-SiLU-Linear-LayerNorm), InteractionNet grid->mesh, ``processor_layers``
+InteractionNets on the mesh, InteractionNet mesh->grid, output MLP.  PARITY UNPINNED against mfai (absent here); the
+arithmetic is checked against oracle/graphlam.py, which runs the same parameters through index_select / cat / index_add_.
+
+What runs where
+* every Linear / LayerNorm: torch (hipBLASLt GEMMs -- plain library GEMMs, 2 GFLOP each on 262k grid nodes);
+* every edge pass: the HIP kernels of csrc/graph.hip through py4cast_amd.ops_graph -- the first Linear of an edge MLP is
+  distributed over ``cat[e, x_s[src], x_r[dst]]`` (three small GEMMs on E / N_s / N_r rows instead of one on an E x 3C gather),
+  gather + add + SiLU is one kernel, aggregation is a CSR segment sum (no atomics, reproducible).
+The batch dimension is folded into the node dimension (edge lists replicated with node offsets, cached per batch size).
+Graph models receive (B, ngrid, C_in) and return (B, ngrid, F) (py4cast/lightning.py:526-535).
+"""
+
+import os
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops_graph as G
+from .base import ModelABC, ModelType
+from .graph_build import MeshGraph, build_mesh_graph, graph_path
+
+try:  # the reference's settings classes are dataclass_json dataclasses (py4cast_plugin_example.py:12-17)
+    from dataclasses_json import dataclass_json
+except Exception:  # pragma: no cover
+    def dataclass_json(cls):
+        return cls
+
+
+@dataclass_json
+@dataclass(slots=True)
+class GraphLamSettings:
+    tmp_dir: str = "/tmp"  # nosec B108 -- same default as the reference yaml
+    hidden_dims: int = 64
+    hidden_layers: int = 1
+    processor_layers: int = 4
+    mesh_aggr: str = "sum"
+    use_checkpointing: bool = False
+    offload_to_cpu: bool = False
+    mesh_levels: int = 0            # 0 = every level that fits (neural-lam's multiscale mesh)
+    activation_dtype: str = "f32"   # "bf16": node / edge representations stored as bf16
+
+
+def make_mlp(blueprint, layer_norm=True) -> nn.Sequential:
+    layers = []
+    for i, (a, b) in enumerate(zip(blueprint[:-1], blueprint[1:])):
+        layers.append(nn.Linear(a, b))
+        if i != len(blueprint) - 2:
+            layers.append(nn.SiLU())
+    if layer_norm:
+        layers.append(nn.LayerNorm(blueprint[-1]))
+    return nn.Sequential(*layers)
+
+
+def _run(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """An MLP on rows of x's dtype (parameters are fp32 masters)."""
+    if x.dtype == torch.float32:
+        return mlp(x)
+    for m in mlp:
+        if isinstance(m, nn.Linear):
+            x = F.linear(x, m.weight.to(x.dtype), m.bias.to(x.dtype))
+        elif isinstance(m, nn.LayerNorm):
+            x = F.layer_norm(x.float(), m.normalized_shape, m.weight, m.bias, m.eps).to(x.dtype)
+        else:
+            x = m(x)
+    return x
+
+
+class InteractionNet(nn.Module):
+    """neural-lam's InteractionNet; parameter layout identical to the concat formulation (edge_mlp.0.weight is (C, 3C))."""
+
+    def __init__(self, hidden: int, hidden_layers: int = 1, update_edges: bool = True):
+        super().__init__()
+        self.hidden, self.update_edges = hidden, update_edges
+        self.edge_mlp = make_mlp([3 * hidden] + [hidden] * (hidden_layers + 1))
+        self.aggr_mlp = make_mlp([2 * hidden] + [hidden] * (hidden_layers + 1))
+
+    def forward(self, send_rep, rec_rep, edge_rep, edges: G.EdgeSet):
+        C = self.hidden
+        lin0 = self.edge_mlp[0]
+        w = lin0.weight.to(edge_rep.dtype)
+        base = F.linear(edge_rep, w[:, :C], lin0.bias.to(edge_rep.dtype))     # E x C
+        a = F.linear(send_rep, w[:, C:2 * C])                                  # N_s x C
+        b = F.linear(rec_rep, w[:, 2 * C:])                                    # N_r x C
+        h = G.edge_gather_add(base, a, b, edges, "silu")                       # first Linear + SiLU of the edge MLP
+        msg = _run(self.edge_mlp[2:], h)
+        agg = G.aggregate_sum(msg, edges)
+        rec_rep = rec_rep + _run(self.aggr_mlp, torch.cat([rec_rep, agg], dim=-1))
+        if self.update_edges:
+            return rec_rep, edge_rep + msg
+        return rec_rep
+
+
+class GraphLamMI355X(ModelABC, nn.Module):
+    settings_kls = GraphLamSettings
+    onnx_supported: bool = False
+    supported_num_spatial_dims = (1,)
+    num_spatial_dims: int = 1
+    features_last: bool = True
+    model_type = ModelType.GRAPH
+    register: bool = True
+
+    def __init__(self, in_channels: int, out_channels: int, input_shape: Tuple[int, ...] = None,
+                 settings: GraphLamSettings = GraphLamSettings(), *args, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.input_shape = in_channels, out_channels, input_shape
+        self._settings = settings
+        if settings.mesh_aggr != "sum":
+            raise NotImplementedError("mesh_aggr: only 'sum' is implemented (the reference yaml's value)")
+        path = graph_path(settings.tmp_dir, input_shape, settings.mesh_levels)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: run {type(self).__name__}.rank_zero_setup(settings, meshgrid) first "
+                                    "(py4cast does, lightning.py:141-144)")
+        graph = MeshGraph.load(path)
+        self.n_grid, self.n_mesh = graph.n_grid, graph.n_mesh
+        for k in ("g2m", "m2m", "m2g"):
+            self.register_buffer(f"{k}_index", getattr(graph, k), persistent=False)
+            self.register_buffer(f"{k}_features", getattr(graph, f"{k}_feat"), persistent=False)
+        self.register_buffer("mesh_static_features", graph.mesh_pos, persistent=False)
+        self._edge_cache: Dict[tuple, Dict[str, G.EdgeSet]] = {}
+
+        h, L_ = settings.hidden_dims, settings.hidden_layers
+        bp = [h] * (L_ + 1)
+        self.grid_embedder = make_mlp([in_channels] + bp)
+        self.g2m_embedder = make_mlp([3] + bp)
+        self.m2g_embedder = make_mlp([3] + bp)
+        self.mesh_embedder = make_mlp([2] + bp)
+        self.m2m_embedder = make_mlp([3] + bp)
+        self.g2m_gnn = InteractionNet(h, L_, update_edges=False)
+        self.encoding_grid_mlp = make_mlp([h] + bp)
+        self.processor = nn.ModuleList([InteractionNet(h, L_, update_edges=True) for _ in range(settings.processor_layers)])
+        self.m2g_gnn = InteractionNet(h, L_, update_edges=False)
+        self.output_map = make_mlp(bp + [out_channels], layer_norm=False)
+        self.check_required_attributes()
+
+    @property
+    def settings(self) -> GraphLamSettings:
+        return self._settings
+
+    @classmethod
+    def rank_zero_setup(cls, settings: GraphLamSettings, meshgrid: torch.Tensor):
+        """Builds the mesh graph once and stores it under settings.tmp_dir (lightning.py:141-144)."""
+        shape = tuple(meshgrid.shape[1:])
+        path = graph_path(settings.tmp_dir, shape, settings.mesh_levels)
+        if not os.path.exists(path):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            build_mesh_graph(meshgrid, settings.mesh_levels).save(path)
+
+    def _edges(self, B: int, device) -> Dict[str, G.EdgeSet]:
+        key = (B, str(device))
+        if key not in self._edge_cache:
+            sets = {}
+            sizes = {"g2m": (self.n_grid, self.n_mesh), "m2m": (self.n_mesh, self.n_mesh), "m2g": (self.n_mesh, self.n_grid)}
+            for k, (ns, nr) in sizes.items():
+                idx = getattr(self, f"{k}_index")
+                src = torch.cat([idx[0] + b * ns for b in range(B)])
+                dst = torch.cat([idx[1] + b * nr for b in range(B)])
+                sets[k] = G.EdgeSet(src, dst, B * ns, B * nr).to(device)
+            self._edge_cache[key] = sets
+        return self._edge_cache[key]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, N, _ = x.shape
+        dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
+        es = self._edges(B, x.device)
+        rep = lambda t: t.unsqueeze(0).expand(B, *t.shape).reshape(B * t.shape[0], t.shape[1])  # noqa: E731
+        grid = _run(self.grid_embedder, x.reshape(B * N, -1).to(dt))
+        g2m_e = rep(_run(self.g2m_embedder, self.g2m_features.to(dt)))
+        m2g_e = rep(_run(self.m2g_embedder, self.m2g_features.to(dt)))
+        m2m_e = rep(_run(self.m2m_embedder, self.m2m_features.to(dt)))
+        mesh = rep(_run(self.mesh_embedder, self.mesh_static_features.to(dt)))
+        mesh = self.g2m_gnn(grid, mesh, g2m_e, es["g2m"])
+        grid = grid + _run(self.encoding_grid_mlp, grid)
+        for layer in self.processor:
+            mesh, m2m_e = layer(mesh, mesh, m2m_e, es["m2m"])
+        grid = self.m2g_gnn(mesh, grid, m2g_e, es["m2g"])
+        return _run(self.output_map, grid).to(x.dtype).reshape(B, N, self.out_channels)

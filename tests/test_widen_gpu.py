@@ -211,3 +211,96 @@ def test_window_attention_rejects_bad_shapes(gpu_device):
         window_attention(torch.zeros(1, 7, 7, 3 * 12, device=gpu_device), None, 1, 7, 0)  # head_dim 12
     with pytest.raises(L.P4CError):
         window_attention(torch.zeros(1, 7, 7, 24), None, 1, 7, 0)                          # CPU tensor
+
+
+# ----------------------------------------------------------------------------------------- GraphLAM on the edge kernels
+def _graphlam_pair(tmp_path, H, W, cin, cout, dtype="f32"):
+    from oracle.graphlam import GraphLam as OracleGraphLam
+    from py4cast_amd.graphlam import GraphLamMI355X, GraphLamSettings
+
+    ys, xs = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    st = GraphLamSettings(tmp_dir=str(tmp_path), activation_dtype=dtype)
+    GraphLamMI355X.rank_zero_setup(st, torch.stack([xs, ys]))
+    torch.manual_seed(21)
+    model = GraphLamMI355X(cin, cout, (H, W), st)
+    graph = {k: getattr(model, f"{k}_index") for k in ("g2m", "m2m", "m2g")}
+    graph.update({f"{k}_feat": getattr(model, f"{k}_features") for k in ("g2m", "m2m", "m2g")})
+    graph["mesh_pos"] = model.mesh_static_features
+    oracle = OracleGraphLam(cin, cout, graph).double()
+    oracle.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+    return model, oracle
+
+
+def test_graphlam_matches_oracle(gpu_device, tmp_path):
+    H, W, cin, cout = 36, 45, 13, 5
+    model, oracle = _graphlam_pair(tmp_path, H, W, cin, cout)
+    model = model.to(gpu_device)
+    torch.manual_seed(22)
+    x = torch.randn(2, H * W, cin)
+    gy = torch.randn(2, H * W, cout)
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = model(xg)
+    y.backward(gy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    yr = oracle(xr)
+    yr.backward(gy.double())
+    assert y.shape == (2, H * W, cout)
+    assert _rel(y.detach().cpu(), yr.detach()) < 1e-4          # north-star bar: <= 1e-4 relative in fp32
+    assert _rel(xg.grad.cpu(), xr.grad) < 1e-3
+    ref_grads = dict(oracle.named_parameters())
+    for name, p in model.named_parameters():
+        assert _rel(p.grad.cpu(), ref_grads[name].grad) < 2e-3, name
+
+
+def test_graphlam_bf16_tracks_fp32(gpu_device, tmp_path):
+    H, W, cin, cout = 36, 45, 13, 5
+    model, oracle = _graphlam_pair(tmp_path, H, W, cin, cout, dtype="bf16")
+    model = model.to(gpu_device)
+    x = torch.randn(2, H * W, cin)
+    y = model(x.to(gpu_device))
+    assert y.dtype == torch.float32
+    assert _rel(y.detach().cpu(), oracle(x.double()).detach()) < 3e-2
+
+
+def test_graphlam_rollout_through_lightning(gpu_device, tmp_path):
+    """config 4's shape in small: GraphLam from the registry, graph layout (B, ngrid, F), 3-step diff_ar rollout with the
+    fused update+loss step, loss and gradients against the oracle GNN driven through the oracle rollout."""
+    from oracle import losses as olosses
+    from oracle import rollout as orollout
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from tests.helpers import make_batch, make_dataset_info, synthetic_case
+
+    H, W, F, Ff = 27, 27, 6, 5
+    case = synthetic_case(seed=31, B=2, T=3, H=H, W=W, F=F, Ff=Ff, border=2)
+    info = make_dataset_info(case, Ff)
+    torch.manual_seed(32)
+    lm = AutoRegressiveLightning(
+        {"tmp_dir": str(tmp_path)}, info, None, num_input_steps=1, num_pred_steps_train=3, batch_size=2, model_name="GraphLam",
+        losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+        training_strategy="diff_ar",
+    ).to(gpu_device)
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    assert torch.isfinite(loss)
+    # the same parameters through the torch-native GNN and the oracle's rollout / loss
+    from oracle.graphlam import GraphLam as OracleGraphLam
+
+    m = lm.model
+    graph = {k: getattr(m, f"{k}_index").cpu() for k in ("g2m", "m2m", "m2g")}
+    graph.update({f"{k}_feat": getattr(m, f"{k}_features").cpu() for k in ("g2m", "m2m", "m2g")})
+    graph["mesh_pos"] = m.mesh_static_features.cpu()
+    oracle = OracleGraphLam(m.in_channels, m.out_channels, graph).double()
+    oracle.load_state_dict({k: v.detach().cpu().double() for k, v in m.state_dict().items()})
+    c = {k: (v.double() if v.is_floating_point() else v) for k, v in case.items()}
+    flat = lambda t: t.flatten(2, 3)  # noqa: E731
+    statics_b = c["statics"].flatten(0, 1).unsqueeze(0).expand(2, -1, -1)
+    border, interior = c["border_mask"].flatten(0, 1), 1.0 - c["border_mask"].flatten(0, 1)
+    pred = orollout.rollout(oracle, flat(c["inputs"]), flat(c["forcing"]), flat(c["outputs"]), statics_b, border, interior,
+                            None, None, training_strategy="diff_ar")
+    w = olosses.weighted_loss_weights(c["state_weight"], c["diff_std"], "mse")
+    ref = olosses.weighted_loss(pred, flat(c["outputs"]), torch.ones_like(pred), w, interior, "mse").mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-4
+    ref_grads = dict(oracle.named_parameters())
+    worst = max(_rel(p.grad.cpu(), ref_grads[n].grad) for n, p in m.named_parameters())
+    assert worst < 5e-3, worst
