@@ -363,6 +363,29 @@ int p4c_window_attn_bwd(const void* qkv, const float* bias_t, const void* dout, 
                         int B, int Hp, int Wp, int heads, int head_dim, int ws, int shift, float scale, int dtype,
                         p4c_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------
+ * Row-wise passes of the GNN's MLPs (every MLP of GraphLam / HiLam is Linear - SiLU - Linear - LayerNorm on rows of
+ * hidden_dims = 64 features, config/CLI/model/graphlam.yaml:21-22): streams of R rows (0.5 M grid nodes, 1-2 M edges per
+ * sample) of C contiguous features, C * sizeof(dtype) a multiple of 16 bytes and at most 1 KiB.
+ * ------------------------------------------------------------------------------------ */
+/* out[r] = LayerNorm(x[r]) * gamma + beta (+ res[r])   -- torch.nn.LayerNorm(C) semantics (biased variance, eps inside the
+ * square root), statistics in fp32; res may be NULL. */
+int p4c_row_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, float eps, void* out,
+                          int64_t R, int C, int dtype, p4c_stream_t stream);
+/* dx, dgamma (C), dbeta (C; must be dgamma + C: one (2,C) buffer) from dy and the forward INPUT x (row statistics are
+ * recomputed, nothing is saved by the forward); the gradient of res is dy itself.  Parameter gradients are reduced in a
+ * fixed order (no atomics); workspace: p4c_row_layernorm_bwd_workspace_bytes(R, C, dtype) bytes. */
+size_t p4c_row_layernorm_bwd_workspace_bytes(int64_t R, int C, int dtype);
+int p4c_row_layernorm_bwd(const void* dy, const void* x, const float* gamma, float eps, void* dx, float* dgamma, float* dbeta,
+                          void* workspace, int64_t R, int C, int dtype, p4c_stream_t stream);
+/* Weight and bias gradient of y = x W^T + b over R >> O rows:  dw_db[0 .. O*K) = dW[o][k] = sum_r dy[r][o] x[r][k],
+ * dw_db[O*K .. O*K+O) = db[o] = sum_r dy[r][o]  (fp32, overwritten).  O = 64, K a multiple of 16 up to 128, bf16 rows
+ * (bf16 matrix cores, fp32 accumulation, fixed reduction order).  workspace: p4c_row_linear_wgrad_workspace_bytes(R, K). */
+size_t p4c_row_linear_wgrad_workspace_bytes(int64_t R, int K);
+int p4c_row_linear_wgrad(const void* dy, const void* x, float* dw_db, void* workspace, int64_t R, int O, int K, int dtype,
+                         p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

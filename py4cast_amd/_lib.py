@@ -123,17 +123,28 @@ def kernel_times():
         torch.cuda.synchronize()
         for n, evs in _TIMED.items():
             if evs:
-                out[n] = (len(evs), sum(a.elapsed_time(b) for a, b in evs) / len(evs))
+                out[n] = (len(evs), sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs))
     return out
 
 
-def call(name: str, *args):
+def kernel_bytes():
+    """{name: algorithmic HBM bytes summed over the recorded calls} for the entry points whose wrappers state them."""
+    out = {}
+    if _TIMED:
+        for n, evs in _TIMED.items():
+            if evs and all(nb is not None for _, _, nb in evs):
+                out[n] = float(sum(nb for _, _, nb in evs))
+    return out
+
+
+def call(name: str, *args, alg_bytes=None):
+    """alg_bytes: the call's algorithmic HBM bytes (roofline bookkeeping of bench.py; ignored unless timing is enabled)."""
     if _TIMED is not None and name in _TIMED:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()  # torch's current stream == the stream handed to the library
         check(getattr(lib(), name)(*args), name)
         b.record()
-        _TIMED[name].append((a, b))
+        _TIMED[name].append((a, b, alg_bytes))
         return
     check(getattr(lib(), name)(*args), name)
 

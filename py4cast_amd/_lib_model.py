@@ -31,6 +31,9 @@ SIGNATURES = {
     "p4c_edge_gather_add_fwd": [P, P, P, P, P, P, L, I, I, I, P],
     "p4c_edge_gather_add_bwd": [P, P, P, P, P, P, P, L, I, I, I, P],
     "p4c_segment_sum": [P, P, P, P, P, L, L, I, I, I, P],
+    "p4c_row_layernorm_fwd": [P, P, P, P, F, P, L, I, I, P],
+    "p4c_row_layernorm_bwd": [P, P, P, F, P, P, P, P, L, I, I, P],
+    "p4c_row_linear_wgrad": [P, P, P, P, L, I, I, I, P],
     "p4c_window_attn_fwd": [P, P, P, I, I, I, I, I, I, I, F, I, P],
     "p4c_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
 }
@@ -39,4 +42,6 @@ OTHER = {
     "p4c_conv_stat_tiles": ([I, I, I, I, I, I], c_int),
     "p4c_halfunet_param_count": ([DP], c_int64),
     "p4c_window_attn_bwd_workspace_bytes": ([I, I, I, I, I], c_size_t),
+    "p4c_row_layernorm_bwd_workspace_bytes": ([L, I, I], c_size_t),
+    "p4c_row_linear_wgrad_workspace_bytes": ([L, I], c_size_t),
 }

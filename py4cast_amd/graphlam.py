@@ -17,13 +17,14 @@ Graph models receive (B, ngrid, C_in) and return (B, ngrid, F) (py4cast/lightnin
 
 import os
 from dataclasses import dataclass
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import ops_graph as G
+from . import ops_rows as R
 from .base import ModelABC, ModelType
 from .graph_build import MeshGraph, build_mesh_graph, graph_path
 
@@ -59,18 +60,33 @@ def make_mlp(blueprint, layer_norm=True) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
-def _run(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    """An MLP on rows of x's dtype (parameters are fp32 masters)."""
-    if x.dtype == torch.float32:
-        return mlp(x)
+def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """A Linear on rows of x's dtype (fp32 master parameters).  bf16 rows go through ops_rows.row_linear (native weight
+    gradient), with the input / output features zero-padded to the kernel's shapes (K multiple of 16, 64 outputs)."""
+    w, b = m.weight, m.bias
+    if x.dtype != torch.bfloat16:
+        return F.linear(x, w, b)
+    O, K = w.shape
+    kp, op = (-K) % 16, (64 - O) if O < 64 else 0
+    if kp:
+        x, w = F.pad(x, (0, kp)), F.pad(w, (0, kp))
+    if op:
+        w, b = F.pad(w, (0, 0, 0, op)), F.pad(b, (0, op))
+    y = R.row_linear(x, w, b)
+    return y[:, :O] if op else y
+
+
+def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """An MLP on rows of x's dtype; ``res`` is added to the result (fused into the LayerNorm kernel when the MLP ends in one)."""
     for m in mlp:
         if isinstance(m, nn.Linear):
-            x = F.linear(x, m.weight.to(x.dtype), m.bias.to(x.dtype))
+            x = _linear(m, x)
         elif isinstance(m, nn.LayerNorm):
-            x = F.layer_norm(x.float(), m.normalized_shape, m.weight, m.bias, m.eps).to(x.dtype)
+            x = R.row_layer_norm(x.contiguous(), m.weight, m.bias, m.eps, res)
+            res = None
         else:
             x = m(x)
-    return x
+    return x if res is None else x + res
 
 
 class InteractionNet(nn.Module):
@@ -85,14 +101,18 @@ class InteractionNet(nn.Module):
     def forward(self, send_rep, rec_rep, edge_rep, edges: G.EdgeSet):
         C = self.hidden
         lin0 = self.edge_mlp[0]
-        w = lin0.weight.to(edge_rep.dtype)
-        base = F.linear(edge_rep, w[:, :C], lin0.bias.to(edge_rep.dtype))     # E x C
-        a = F.linear(send_rep, w[:, C:2 * C])                                  # N_s x C
-        b = F.linear(rec_rep, w[:, 2 * C:])                                    # N_r x C
-        h = G.edge_gather_add(base, a, b, edges, "silu")                       # first Linear + SiLU of the edge MLP
+        if edge_rep.dtype == torch.bfloat16:
+            base = R.row_linear(edge_rep, lin0.weight[:, :C], lin0.bias)          # E x C
+            a = R.row_linear(send_rep, lin0.weight[:, C:2 * C])                   # N_s x C
+            b = R.row_linear(rec_rep, lin0.weight[:, 2 * C:])                     # N_r x C
+        else:
+            base = F.linear(edge_rep, lin0.weight[:, :C], lin0.bias)
+            a = F.linear(send_rep, lin0.weight[:, C:2 * C])
+            b = F.linear(rec_rep, lin0.weight[:, 2 * C:])
+        h = G.edge_gather_add(base, a, b, edges, "silu")                           # first Linear + SiLU of the edge MLP
         msg = _run(self.edge_mlp[2:], h)
         agg = G.aggregate_sum(msg, edges)
-        rec_rep = rec_rep + _run(self.aggr_mlp, torch.cat([rec_rep, agg], dim=-1))
+        rec_rep = _run(self.aggr_mlp, torch.cat([rec_rep, agg], dim=-1), res=rec_rep)
         if self.update_edges:
             return rec_rep, edge_rep + msg
         return rec_rep
@@ -138,6 +158,9 @@ class GraphLamMI355X(ModelABC, nn.Module):
         self.processor = nn.ModuleList([InteractionNet(h, L_, update_edges=True) for _ in range(settings.processor_layers)])
         self.m2g_gnn = InteractionNet(h, L_, update_edges=False)
         self.output_map = make_mlp(bp + [out_channels], layer_norm=False)
+        self.timed_entry_points = ("p4c_edge_gather_add_fwd", "p4c_edge_gather_add_bwd", "p4c_segment_sum",
+                                   "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd", "p4c_row_linear_wgrad")
+        self.roofline_from_entry_points = True   # bench.py: time every call of the entry points above
         self.check_required_attributes()
 
     @property
@@ -177,8 +200,27 @@ class GraphLamMI355X(ModelABC, nn.Module):
         m2m_e = rep(_run(self.m2m_embedder, self.m2m_features.to(dt)))
         mesh = rep(_run(self.mesh_embedder, self.mesh_static_features.to(dt)))
         mesh = self.g2m_gnn(grid, mesh, g2m_e, es["g2m"])
-        grid = grid + _run(self.encoding_grid_mlp, grid)
+        grid = _run(self.encoding_grid_mlp, grid, res=grid)
         for layer in self.processor:
             mesh, m2m_e = layer(mesh, mesh, m2m_e, es["m2m"])
         grid = self.m2g_gnn(mesh, grid, m2g_e, es["m2g"])
         return _run(self.output_map, grid).to(x.dtype).reshape(B, N, self.out_channels)
+
+    # ------------------------------------------------------------------ bench.py hook
+    def roofline(self, ktimes, B, H, W):
+        """Achieved HBM rate of the native entry point that takes the most time: algorithmic bytes of its calls (stated by the
+        wrappers in ops_graph / ops_rows next to each call) over their HIP-event durations."""
+        from . import _lib as L
+
+        nbytes = L.kernel_bytes()
+        names = [k for k in ktimes if k in nbytes]
+        if not names:
+            return None
+        name = max(names, key=lambda k: ktimes[k][0] * ktimes[k][1])
+        calls, avg_ms = ktimes[name]
+        gbs = nbytes[name] / (calls * avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": f"{name} (all launches)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                "frac": gbs / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": nbytes[name] / calls,
+                "avg_launch_ms": avg_ms, "launches": calls,
+                "all": {k: {"calls": ktimes[k][0], "avg_ms": round(ktimes[k][1], 4),
+                            "GBps": round(nbytes[k] / (ktimes[k][0] * ktimes[k][1] * 1e-3) / 1e9, 1)} for k in names}}

@@ -51,7 +51,8 @@ def _segment_sum_raw(msg: torch.Tensor, offsets: torch.Tensor, perm: Optional[to
     out_dtype = msg.dtype if out_dtype is None else out_dtype
     out = torch.empty(n, C, dtype=out_dtype, device=msg.device)
     L.call("p4c_segment_sum", L.ptr(msg), L.ptr(offsets), L.ptr(perm), None, L.ptr(out), n, E, C, L.dtype_code(msg.dtype),
-           L.dtype_code(out_dtype), L.stream(msg.device))
+           L.dtype_code(out_dtype), L.stream(msg.device),
+           alg_bytes=E * C * msg.element_size() + n * C * out.element_size() + 4 * E * (perm is not None) + 4 * n)
     return out
 
 
@@ -61,7 +62,12 @@ def _gather_raw(base, a, ia, b, ib, dh, act: int, E: int, C: int, like: torch.Te
     args = [L.ptr(base), L.ptr(a), L.ptr(ia), L.ptr(b), L.ptr(ib), L.ptr(out), E, C, L.dtype_code(like.dtype), act, L.stream(like.device)]
     if dh is not None:
         args = [L.ptr(dh)] + args
-    L.call(name, *args)
+    row = C * like.element_size()
+    nbytes = E * row * (1 + (base is not None) + (dh is not None))          # out, base, dh: one row per edge
+    for t in (a, b):                                                          # gathered operands: every distinct row once
+        if t is not None:
+            nbytes += min(E, t.shape[0]) * row + 4 * E
+    L.call(name, *args, alg_bytes=nbytes)
     return out
 
 

@@ -1,0 +1,93 @@
+"""Autograd wrappers of the row-wise MLP passes (include/py4cast_hip.h: p4c_row_layernorm_fwd/bwd, p4c_row_linear_wgrad).
+
+The GNN models' MLPs (Linear - SiLU - Linear - LayerNorm on 64-feature rows, config/CLI/model/graphlam.yaml:21-22) run over
+0.5 M grid nodes and 1-2 M edges per sample.  The forward / input-gradient GEMMs stay with the library (tall-skinny but
+efficient); LayerNorm (+ residual) and the weight gradients (64 x K outputs, reduction over millions of rows) are the HIP
+kernels of csrc/rows.hip.  No CPU fallback.
+"""
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+
+class _LayerNormRes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps: float):
+        L.require_cuda(x)
+        x = x.contiguous()
+        R, C = x.shape
+        if res is not None:
+            res = res.contiguous()
+            if res.dtype != x.dtype or res.shape != x.shape:
+                raise L.P4CError("row_layer_norm: residual must match x in shape and dtype")
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        out = torch.empty_like(x)
+        L.call("p4c_row_layernorm_fwd", L.ptr(x), L.ptr(res), L.ptr(g), L.ptr(b), float(eps), L.ptr(out), R, C,
+               L.dtype_code(x.dtype), L.stream(x.device), alg_bytes=R * C * x.element_size() * (2 + (res is not None)))
+        ctx.save_for_backward(x, g)
+        ctx.eps, ctx.has_res, ctx.pdtype = float(eps), res is not None, gamma.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        R, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        nbytes = L.lib().p4c_row_layernorm_bwd_workspace_bytes(R, C, L.dtype_code(x.dtype))
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+        L.call("p4c_row_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(g), ctx.eps, L.ptr(dx), L.ptr(dgb), L.ptr(dgb[1]), L.ptr(ws), R, C,
+               L.dtype_code(x.dtype), L.stream(x.device), alg_bytes=3 * R * C * x.element_size())
+        return dx, (dy if ctx.has_res else None), dgb[0].to(ctx.pdtype), dgb[1].to(ctx.pdtype), None
+
+
+def row_layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                   res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``LayerNorm(x) * gamma + beta (+ res)`` on rows: x (R, C)."""
+    return _LayerNormRes.apply(x, res, gamma, beta, eps)
+
+
+def _native_wgrad_ok(x: torch.Tensor, O: int, K: int) -> bool:
+    return x.dtype == torch.bfloat16 and O == 64 and K % 16 == 0 and 16 <= K <= 128 and x.shape[0] >= 4096
+
+
+class _RowLinear(torch.autograd.Function):
+    """y = x W^T + b with W, b fp32 masters and bf16 rows: library GEMMs for y and dx, p4c_row_linear_wgrad for dW, db."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        wq = w.to(x.dtype)
+        ctx.save_for_backward(x, wq)
+        ctx.has_bias, ctx.pdtype = b is not None, w.dtype
+        return F.linear(x, wq, None if b is None else b.to(x.dtype))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, K = x.shape
+        O = wq.shape[0]
+        dx = dy @ wq if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            buf = torch.empty(O * K + O, dtype=torch.float32, device=x.device)
+            nbytes = L.lib().p4c_row_linear_wgrad_workspace_bytes(R, K)
+            ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+            L.call("p4c_row_linear_wgrad", L.ptr(dy), L.ptr(x.contiguous()), L.ptr(buf), L.ptr(ws), R, O, K, L.dtype_code(x.dtype),
+                   L.stream(x.device), alg_bytes=R * (O + K) * x.element_size())
+            dw = buf[: O * K].view(O, K).to(ctx.pdtype)
+            db = buf[O * K:].to(ctx.pdtype) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def row_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x @ w.T + b`` for rows x (R, K).  bf16 rows with 64 outputs and K a multiple of 16 (<= 128) take the native weight-gradient
+    kernel; everything else (fp32 parity flavour, odd shapes, few rows) is the library's Linear."""
+    if x.is_cuda and _native_wgrad_ok(x, w.shape[0], w.shape[1]):
+        return _RowLinear.apply(x, w, b)
+    return F.linear(x, w.to(x.dtype), None if b is None else b.to(x.dtype))

@@ -304,3 +304,61 @@ def test_graphlam_rollout_through_lightning(gpu_device, tmp_path):
     ref_grads = dict(oracle.named_parameters())
     worst = max(_rel(p.grad.cpu(), ref_grads[n].grad) for n, p in m.named_parameters())
     assert worst < 5e-3, worst
+
+
+# ----------------------------------------------------------------------------------------- row-wise MLP passes
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C", [(1000, 64), (4099, 64), (777, 128), (513, 96), (3, 64)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_row_layer_norm(gpu_device, R, C, dtype, with_res):
+    from py4cast_amd.ops_rows import row_layer_norm
+
+    torch.manual_seed(41)
+    x = (torch.randn(R, C) * 2 + 0.5).to(dtype)
+    res = torch.randn(R, C).to(dtype) if with_res else None
+    gamma, beta, dy = torch.rand(C) + 0.5, torch.randn(C), torch.randn(R, C).to(dtype)
+    xg = x.to(gpu_device).requires_grad_(True)
+    rg = res.to(gpu_device).requires_grad_(True) if with_res else None
+    gg, bg = gamma.to(gpu_device).requires_grad_(True), beta.to(gpu_device).requires_grad_(True)
+    y = row_layer_norm(xg, gg, bg, 1e-5, rg)
+    y.backward(dy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
+    if with_res:
+        yr = yr + rr
+    yr.backward(dy.double())
+    tol = 2e-6 if dtype == torch.float32 else 5e-3
+    assert _rel(y.detach().cpu(), yr.detach()) < tol
+    assert _rel(xg.grad.cpu(), xr.grad) < (1e-5 if dtype == torch.float32 else 8e-3)
+    assert _rel(gg.grad.cpu(), gr.grad) < 1e-5 and _rel(bg.grad.cpu(), br.grad) < 1e-5
+    if with_res:
+        assert torch.equal(rg.grad.cpu(), dy)
+
+
+@pytest.mark.parametrize("R,K", [(5000, 64), (70001, 64), (4096, 16), (9000, 80), (8191, 128), (6000, 48)])
+def test_row_linear_weight_gradient(gpu_device, R, K):
+    from py4cast_amd.ops_rows import row_linear
+
+    torch.manual_seed(42)
+    x, dy = torch.randn(R, K).bfloat16(), torch.randn(R, 64).bfloat16()
+    w, b = torch.randn(64, K) * 0.1, torch.randn(64) * 0.1
+    xg = x.to(gpu_device).requires_grad_(True)
+    wg, bg = w.to(gpu_device).requires_grad_(True), b.to(gpu_device).requires_grad_(True)
+    y = row_linear(xg, wg, bg)
+    y.backward(dy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    wr, br = w.bfloat16().double().requires_grad_(True), b.bfloat16().double().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(dy.double())
+    assert _rel(y.detach().float().cpu(), yr.detach()) < 5e-3
+    assert _rel(xg.grad.float().cpu(), xr.grad) < 5e-3
+    # the operands are exactly the bf16 rows, products accumulate in fp32: 1e-5-level agreement with float64
+    assert _rel(wg.grad.cpu(), wr.grad) < 2e-5
+    assert _rel(bg.grad.cpu(), br.grad) < 2e-5
+    # bitwise reproducible
+    x2 = x.to(gpu_device).requires_grad_(True)
+    w2, b2 = w.to(gpu_device).requires_grad_(True), b.to(gpu_device).requires_grad_(True)
+    row_linear(x2, w2, b2).backward(dy.to(gpu_device))
+    assert torch.equal(w2.grad, wg.grad) and torch.equal(b2.grad, bg.grad)
