@@ -152,6 +152,13 @@ def cpu_baseline(args, seconds):
         interior, statics = 1.0 - case["border_mask"], case["statics"].unsqueeze(0)
         model_fn = net
         features_second = False
+    elif args.model.startswith("Swin"):
+        from oracle.swinunetr import SwinUNetR as OracleSwin
+
+        net = OracleSwin(F + 4 + 5, F)
+        params = list(net.parameters())
+        model_fn = net
+        features_second = False
     else:
         from oracle import halfunet as ohalf
 

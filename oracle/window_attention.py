@@ -57,7 +57,7 @@ def window_attention(qkv, bias, heads, ws, shift=0, scale=None):
     if bias is not None:
         attn = attn + bias.unsqueeze(0)
     if shift > 0:
-        m = shift_mask(H, W, ws, shift, attn.dtype)  # (nW, N, N)
+        m = shift_mask(H, W, ws, shift, attn.dtype).to(attn.device)  # (nW, N, N)
         nW = m.shape[0]
         attn = attn.view(Bn // nW, nW, heads, N, N) + m.unsqueeze(1).unsqueeze(0)
         attn = attn.view(Bn, heads, N, N)

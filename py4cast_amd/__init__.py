@@ -7,3 +7,12 @@ PyTorch-ROCm; PyTorch provides device memory, streams and torch.distributed only
 """
 
 __version__ = "0.1.0"
+
+import os as _os
+
+# Library convolutions (only the UNETR decoder of SwinUNetR uses them): MIOpen's default find mode benchmarks every
+# applicable solver on first use of a shape, and on this stack (ROCm 7.2 / MIOpen 3.5, gfx950) one of the candidates it tries for
+# the decoder's backward convolutions takes the process down with a GPU memory access fault (reproduced with plain torch modules
+# and an empty MIOpen cache; scratch notes in DESIGN.md section 8).  FAST mode (immediate-mode heuristics, no benchmarking pass)
+# avoids it.  Respect an explicit user choice.
+_os.environ.setdefault("MIOPEN_FIND_MODE", "2")

@@ -1,0 +1,219 @@
+"""
+SwinUNETR with the fused MI355X window attention -- the model behind ``model_name: SwinUNetR``
+(config/CLI/model/swinunetr.yaml:19-30: depths [2,2,2,2], num_heads [3,6,12,24], feature_size 24, norm_name instance,
+downsample merging, use_v2 False).  The reference takes the class from mfai v5.0.1 (py4cast/models.py:10-20), which wraps MONAI's
+2-D SwinUNETR (Hatamizadeh et al. 2022): patch-2 embedding, four Swin stages (window 7, alternating shift 0 / 3, relative position
+bias, patch merging at the end of each stage) and a UNETR convolutional decoder (residual conv blocks with instance norm, transposed
+conv up-sampling, skip connections).  PARITY UNPINNED against mfai (absent here); the arithmetic is checked against
+oracle/swinunetr.py (the same parameters through roll / window_partition / softmax / window_reverse).
+
+What runs where
+* window attention of every Swin block: ONE HIP kernel each way (csrc/attention.hip through py4cast_amd.ops_attention) on the
+  (B, Hp, Wp, 3C) output of the qkv Linear -- shift, window partition, head split, bias, mask, softmax, PV and all inverses;
+* LayerNorms of the Swin blocks: csrc/rows.hip (row LayerNorm) when the row fits its limits;
+* Linear layers: library GEMMs; the UNETR decoder's 3x3 / transposed convolutions and instance norms: torch (MIOpen) -- the
+  decoder is NOT yet on native kernels.
+Input / output are features-last (B, H, W, C); H and W must be multiples of 32.
+"""
+
+from dataclasses import dataclass, field
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops_rows as R
+from .base import ModelABC, ModelType
+from .ops_attention import window_attention
+
+try:
+    from dataclasses_json import dataclass_json
+except Exception:  # pragma: no cover
+    def dataclass_json(cls):
+        return cls
+
+
+@dataclass_json
+@dataclass(slots=True)
+class SwinUNetRSettings:
+    depths: Tuple[int, ...] = (2, 2, 2, 2)
+    num_heads: Tuple[int, ...] = (3, 6, 12, 24)
+    feature_size: int = 24
+    norm_name: str = "instance"
+    drop_rate: float = 0.0
+    attn_drop_rate: float = 0.0
+    dropout_path_rate: float = 0.0
+    normalize: bool = True
+    use_checkpoint: bool = False
+    downsample: str = "merging"
+    use_v2: bool = False
+    window_size: int = 7
+    activation_dtype: str = "f32"   # "bf16": token tensors of the Swin stages stored as bf16
+
+
+def relative_position_index(ws: int) -> torch.Tensor:
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def _layer_norm(m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    C = x.shape[-1]
+    if x.is_cuda and (C * x.element_size()) % 16 == 0 and C * x.element_size() <= 1024:
+        return R.row_layer_norm(x.reshape(-1, C), m.weight, m.bias, m.eps).view(x.shape)
+    return F.layer_norm(x.float(), m.normalized_shape, m.weight, m.bias, m.eps).to(x.dtype)
+
+
+def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    return F.linear(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
+
+
+class SwinBlock(nn.Module):
+    def __init__(self, dim: int, heads: int, ws: int, shift: int, mlp_ratio: float = 4.0):
+        super().__init__()
+        self.dim, self.heads, self.ws, self.shift = dim, heads, ws, shift
+        self.norm1 = nn.LayerNorm(dim)
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 2, heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        self.register_buffer("relative_position_index", relative_position_index(ws), persistent=False)
+        self.norm2 = nn.LayerNorm(dim)
+        self.fc1 = nn.Linear(dim, int(dim * mlp_ratio))
+        self.fc2 = nn.Linear(int(dim * mlp_ratio), dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, H, W, C = x.shape
+        ws = self.ws
+        shift = self.shift if min(H, W) > ws else 0
+        h = _layer_norm(self.norm1, x)
+        pb, pr = (-H) % ws, (-W) % ws
+        if pb or pr:
+            h = F.pad(h, (0, 0, 0, pr, 0, pb))
+        N = ws * ws
+        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(N, N, self.heads).permute(2, 0, 1)
+        a = window_attention(_linear(self.qkv, h), bias, self.heads, ws, shift)
+        a = _linear(self.proj, a)
+        if pb or pr:
+            a = a[:, :H, :W, :]
+        x = x + a
+        return x + _linear(self.fc2, F.gelu(_linear(self.fc1, _layer_norm(self.norm2, x))))
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.norm = nn.LayerNorm(4 * dim)
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], dim=-1)
+        return _linear(self.reduction, _layer_norm(self.norm, x))
+
+
+class ResBlock(nn.Module):
+    """MONAI's UnetResBlock: conv3x3 - IN - LeakyReLU - conv3x3 - IN, (+ 1x1 conv - IN on the skip when channels differ), LeakyReLU."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1, bias=False)
+        self.norm1 = nn.InstanceNorm2d(cout, affine=True)
+        self.norm2 = nn.InstanceNorm2d(cout, affine=True)
+        self.down = cin != cout
+        if self.down:
+            self.conv3 = nn.Conv2d(cin, cout, 1, bias=False)
+            self.norm3 = nn.InstanceNorm2d(cout, affine=True)
+
+    def forward(self, x):
+        out = F.leaky_relu(self.norm1(self.conv1(x)), 0.01)
+        out = self.norm2(self.conv2(out))
+        res = self.norm3(self.conv3(x)) if self.down else x
+        return F.leaky_relu(out + res, 0.01)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.transp_conv = nn.ConvTranspose2d(cin, cout, 2, stride=2, bias=False)
+        self.conv_block = ResBlock(2 * cout, cout)
+
+    def forward(self, x, skip):
+        return self.conv_block(torch.cat([self.transp_conv(x), skip], dim=1))
+
+
+class SwinUNetRMI355X(ModelABC, nn.Module):
+    settings_kls = SwinUNetRSettings
+    onnx_supported: bool = False
+    supported_num_spatial_dims = (2,)
+    num_spatial_dims: int = 2
+    features_last: bool = True
+    model_type = ModelType.VISION_TRANSFORMER
+    register: bool = True
+
+    def __init__(self, in_channels: int, out_channels: int, input_shape: Tuple[int, ...] = None,
+                 settings: SwinUNetRSettings = SwinUNetRSettings(), *args, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.input_shape = in_channels, out_channels, input_shape
+        self._settings = settings
+        if settings.use_v2 or settings.downsample != "merging" or settings.norm_name != "instance":
+            raise NotImplementedError("SwinUNetR: only use_v2=False, downsample='merging', norm_name='instance' (the reference yaml)")
+        if input_shape is not None and (input_shape[0] % 32 or input_shape[1] % 32):
+            raise ValueError(f"SwinUNetR: grid {tuple(input_shape)} must be a multiple of 32 (patch 2 x four 2x merges)")
+        fs, ws = settings.feature_size, settings.window_size
+        self.patch_embed = nn.Conv2d(in_channels, fs, 2, stride=2)
+        self.stages = nn.ModuleList()
+        self.merges = nn.ModuleList()
+        for i, (depth, heads) in enumerate(zip(settings.depths, settings.num_heads)):
+            dim = fs * 2 ** i
+            self.stages.append(nn.ModuleList([SwinBlock(dim, heads, ws, 0 if j % 2 == 0 else ws // 2) for j in range(depth)]))
+            self.merges.append(PatchMerging(dim))
+        self.encoder1 = ResBlock(in_channels, fs)
+        self.encoder2 = ResBlock(fs, fs)
+        self.encoder3 = ResBlock(2 * fs, 2 * fs)
+        self.encoder4 = ResBlock(4 * fs, 4 * fs)
+        self.encoder10 = ResBlock(16 * fs, 16 * fs)
+        self.decoder5 = UpBlock(16 * fs, 8 * fs)
+        self.decoder4 = UpBlock(8 * fs, 4 * fs)
+        self.decoder3 = UpBlock(4 * fs, 2 * fs)
+        self.decoder2 = UpBlock(2 * fs, fs)
+        self.decoder1 = UpBlock(fs, fs)
+        self.out = nn.Conv2d(fs, out_channels, 1)
+        self.check_required_attributes()
+
+    @property
+    def settings(self) -> SwinUNetRSettings:
+        return self._settings
+
+    def _hidden(self, t: torch.Tensor) -> torch.Tensor:
+        """A Swin hidden state handed to the decoder: layer-normalised over channels without affine (MONAI's proj_out), NCHW fp32."""
+        t = t.float()
+        if self._settings.normalize:
+            t = F.layer_norm(t, (t.shape[-1],))
+        return t.permute(0, 3, 1, 2).contiguous()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        xin = x.permute(0, 3, 1, 2).contiguous()                   # the conv decoder is channels-second
+        dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
+        t = self.patch_embed(xin).permute(0, 2, 3, 1).contiguous().to(dt)
+        hidden = [self._hidden(t)]
+        for blocks, merge in zip(self.stages, self.merges):
+            for blk in blocks:
+                t = blk(t)
+            t = merge(t)
+            hidden.append(self._hidden(t))
+        enc0 = self.encoder1(xin)
+        enc1 = self.encoder2(hidden[0])
+        enc2 = self.encoder3(hidden[1])
+        enc3 = self.encoder4(hidden[2])
+        dec4 = self.encoder10(hidden[4])
+        dec3 = self.decoder5(dec4, hidden[3])
+        dec2 = self.decoder4(dec3, enc3)
+        dec1 = self.decoder3(dec2, enc2)
+        dec0 = self.decoder2(dec1, enc1)
+        out = self.decoder1(dec0, enc0)
+        return self.out(out).permute(0, 2, 3, 1).contiguous()

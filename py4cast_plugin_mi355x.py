@@ -3,7 +3,8 @@ py4cast plugin module (discovered through its ``py4cast_plugin_`` name prefix, e
 reference's ``py4cast_plugin_example.py``; see py4cast/models.py:23-46): registers the
 MI355X-native models.  Put the repository root on PYTHONPATH and ``model_name: HalfUNet`` (or
 ``HalfUNetMI355X`` next to a real mfai install, which already owns the name ``HalfUNet``)
-selects the HIP implementation; likewise ``GraphLam`` / ``GraphLamMI355X`` (mesh GNN on the edge kernels).
+selects the HIP implementation; likewise ``GraphLam`` / ``GraphLamMI355X`` (mesh GNN on the edge kernels) and
+``SwinUNetR`` / ``SwinUNetRMI355X`` (fused window attention).
 """
 
 from dataclasses import dataclass
@@ -17,6 +18,7 @@ from py4cast_amd.namedtensor import HAVE_MFAI
 from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings  # noqa: F401,E402
 
 from py4cast_amd.graphlam import GraphLamMI355X, GraphLamSettings  # noqa: F401,E402
+from py4cast_amd.swinunetr import SwinUNetRMI355X, SwinUNetRSettings  # noqa: F401,E402
 
 if not HAVE_MFAI:
     # stand-alone: take the upstream names so that config/CLI/model/halfunet.yaml / graphlam.yaml work unchanged
@@ -24,6 +26,9 @@ if not HAVE_MFAI:
         register = True
 
     class GraphLam(GraphLamMI355X):
+        register = True
+
+    class SwinUNetR(SwinUNetRMI355X):
         register = True
 
 

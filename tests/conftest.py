@@ -2,6 +2,8 @@ import glob
 import os
 import sys
 
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")  # see py4cast_amd/__init__.py (must be set before the first library conv)
+
 import numpy as np
 import pytest
 

@@ -362,3 +362,62 @@ def test_row_linear_weight_gradient(gpu_device, R, K):
     w2, b2 = w.to(gpu_device).requires_grad_(True), b.to(gpu_device).requires_grad_(True)
     row_linear(x2, w2, b2).backward(dy.to(gpu_device))
     assert torch.equal(w2.grad, wg.grad) and torch.equal(b2.grad, bg.grad)
+
+
+# ----------------------------------------------------------------------------------------- SwinUNETR on the fused attention
+def _swin_pair(cin, cout, shape, dtype="f32", ws=7):
+    from oracle.swinunetr import SwinUNetR as OracleSwin
+    from py4cast_amd.swinunetr import SwinUNetRMI355X, SwinUNetRSettings
+
+    torch.manual_seed(51)
+    model = SwinUNetRMI355X(cin, cout, shape, SwinUNetRSettings(activation_dtype=dtype, window_size=ws))
+    with torch.no_grad():   # non-trivial relative position biases
+        for name, p in model.named_parameters():
+            if name.endswith("relative_position_bias_table"):
+                p.normal_(0, 0.5)
+    oracle = OracleSwin(cin, cout, window_size=ws).double()
+    oracle.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+    return model, oracle
+
+
+@pytest.mark.parametrize("ws", [7, 8])
+def test_swinunetr_matches_oracle(gpu_device, ws):
+    H, W, cin, cout = 64, 96, 9, 4
+    model, oracle = _swin_pair(cin, cout, (H, W), ws=ws)
+    model = model.to(gpu_device)
+    torch.manual_seed(52)
+    x, gy = torch.randn(2, H, W, cin), torch.randn(2, H, W, cout)
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = model(xg)
+    y.backward(gy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    yr = oracle(xr)
+    yr.backward(gy.double())
+    assert y.shape == (2, H, W, cout)
+    # attention products run on bf16 matrix cores (operands and P rounded to bf16): 1e-2-level agreement of the network output
+    assert _rel(y.detach().cpu(), yr.detach()) < 2e-2
+    assert _rel(xg.grad.cpu(), xr.grad) < 6e-2
+    ref = dict(oracle.named_parameters())
+    cos = []
+    for name, p in model.named_parameters():
+        a, b = p.grad.double().cpu().flatten(), ref[name].grad.flatten()
+        cos.append(float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)))
+    assert min(cos) > 0.98, min(cos)
+
+
+def test_swinunetr_rollout_through_lightning(gpu_device):
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from tests.helpers import make_batch, make_dataset_info, synthetic_case
+
+    H, W, F, Ff = 64, 64, 6, 5
+    case = synthetic_case(seed=53, B=2, T=2, H=H, W=W, F=F, Ff=Ff)
+    info = make_dataset_info(case, Ff)
+    lm = AutoRegressiveLightning(
+        {"activation_dtype": "bf16"}, info, None, num_input_steps=1, num_pred_steps_train=2, batch_size=2, model_name="SwinUNetR",
+        losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+        training_strategy="scaled_ar",
+    ).to(gpu_device)
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lm.model.parameters())
