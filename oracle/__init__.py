@@ -16,4 +16,9 @@ Parity status
   which is absent from ``/root/reference`` and not installable here.  The oracle
   restates the published Half-UNet architecture as used by mfai from plain
   ``torch.nn.functional`` ops; the HIP kernels are compared against that.
+* ``oracle.graph`` / ``oracle.graphlam`` (mesh GNN: index_select + cat + index_add_) and
+  ``oracle.window_attention`` / ``oracle.swinunetr`` (Swin: roll, window_partition, softmax
+  attention with relative position bias and shift mask): PARITY UNPINNED for the same reason
+  (GraphLam and SwinUNetR are mfai classes); each restatement is cross-checked on CPU against an
+  independent formulation of the published operation (tests/test_widen_oracle_cpu.py).
 """

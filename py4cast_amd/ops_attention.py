@@ -26,7 +26,7 @@ class _WindowAttention(torch.autograd.Function):
         bias_t = None if bias is None else bias.detach().to(torch.float32).transpose(1, 2).contiguous()  # [head][key][query]
         out = torch.empty(B, Hp, Wp, C, dtype=qkv.dtype, device=qkv.device)
         L.call("p4c_window_attn_fwd", L.ptr(qkv), L.ptr(bias_t), L.ptr(out), B, Hp, Wp, heads, d, ws, shift, float(scale),
-               L.dtype_code(qkv.dtype), L.stream(qkv.device))
+               L.dtype_code(qkv.dtype), L.stream(qkv.device), alg_bytes=B * Hp * Wp * 4 * C * qkv.element_size())
         ctx.save_for_backward(qkv, bias_t)
         ctx.cfg = (heads, d, ws, shift, float(scale), None if bias is None else bias.dtype)
         return out
@@ -45,7 +45,8 @@ class _WindowAttention(torch.autograd.Function):
             nbytes = L.lib().p4c_window_attn_bwd_workspace_bytes(B, Hp, Wp, heads, ws)
             wsp = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
         L.call("p4c_window_attn_bwd", L.ptr(qkv), L.ptr(bias_t), L.ptr(dout), L.ptr(dqkv), L.ptr(dbias_t), L.ptr(wsp), B, Hp, Wp,
-               heads, d, ws, shift, scale, L.dtype_code(qkv.dtype), L.stream(qkv.device))
+               heads, d, ws, shift, scale, L.dtype_code(qkv.dtype), L.stream(qkv.device),
+               alg_bytes=B * Hp * Wp * 7 * heads * d * qkv.element_size())
         dbias = dbias_t.transpose(1, 2).to(bias_dtype) if want_dbias else None
         return dqkv, dbias, None, None, None, None
 

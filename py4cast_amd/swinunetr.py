@@ -183,6 +183,8 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         self.decoder2 = UpBlock(2 * fs, fs)
         self.decoder1 = UpBlock(fs, fs)
         self.out = nn.Conv2d(fs, out_channels, 1)
+        self.timed_entry_points = ("p4c_window_attn_fwd", "p4c_window_attn_bwd", "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd")
+        self.roofline_from_entry_points = True   # bench.py: time every call of the entry points above
         self.check_required_attributes()
 
     @property
@@ -217,3 +219,22 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         dec0 = self.decoder2(dec1, enc1)
         out = self.decoder1(dec0, enc0)
         return self.out(out).permute(0, 2, 3, 1).contiguous()
+
+    # ------------------------------------------------------------------ bench.py hook
+    def roofline(self, ktimes, B, H, W):
+        """Achieved HBM rate of the native entry point that takes the most time (algorithmic bytes stated by the wrappers:
+        window attention forward = read qkv + write out, backward = read qkv and dout + write dqkv)."""
+        from . import _lib as L
+
+        nbytes = L.kernel_bytes()
+        names = [k for k in ktimes if k in nbytes]
+        if not names:
+            return None
+        name = max(names, key=lambda k: ktimes[k][0] * ktimes[k][1])
+        calls, avg_ms = ktimes[name]
+        gbs = nbytes[name] / (calls * avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": f"{name} (all launches)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                "frac": gbs / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": nbytes[name] / calls,
+                "avg_launch_ms": avg_ms, "launches": calls,
+                "all": {k: {"calls": ktimes[k][0], "avg_ms": round(ktimes[k][1], 4),
+                            "GBps": round(nbytes[k] / (ktimes[k][0] * ktimes[k][1] * 1e-3) / 1e9, 1)} for k in names}}
