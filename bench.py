@@ -215,7 +215,7 @@ def main():
     case = synthetic_case(1234 + rank, B, T, 1, H, W, F, Ff, Fs, args.border, device)
     info = make_info(case, Ff)
     settings = {}
-    if args.model.startswith("GraphLam"):
+    if args.model.startswith(("GraphLam", "HiLAM", "HiLam")):
         settings = {"activation_dtype": args.act_dtype or args.dtype, "tmp_dir": os.environ.get("TMPDIR", "/tmp")}
     elif args.model.startswith("Swin"):
         settings = {"activation_dtype": args.act_dtype or args.dtype}

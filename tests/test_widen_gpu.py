@@ -421,3 +421,58 @@ def test_swinunetr_rollout_through_lightning(gpu_device):
     loss.backward()
     assert torch.isfinite(loss)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lm.model.parameters())
+
+
+# ----------------------------------------------------------------------------------------- HiLAM (hierarchical mesh GNN)
+def test_hilam_matches_oracle(gpu_device, tmp_path):
+    from oracle.hilam import HiLam as OracleHiLam
+    from py4cast_amd.hilam import HiLamMI355X, HiLamSettings
+
+    H, W, cin, cout = 36, 45, 11, 4
+    ys, xs = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    st = HiLamSettings(tmp_dir=str(tmp_path), processor_layers=2)
+    HiLamMI355X.rank_zero_setup(st, torch.stack([xs, ys]))
+    torch.manual_seed(61)
+    m = HiLamMI355X(cin, cout, (H, W), st)
+    Lv = m.num_levels
+    assert Lv == 2 and m.n_mesh == [81, 9]
+    graph = {"g2m": m.g2m_index, "m2g": m.m2g_index, "g2m_feat": m.g2m_features, "m2g_feat": m.m2g_features,
+             "mesh_pos": [getattr(m, f"mesh_pos_{l}") for l in range(Lv)],
+             "same": [getattr(m, f"same_index_{l}") for l in range(Lv)],
+             "same_feat": [getattr(m, f"same_features_{l}") for l in range(Lv)]}
+    for k in ("up", "down"):
+        graph[k] = [getattr(m, f"{k}_index_{l}") for l in range(Lv - 1)]
+        graph[f"{k}_feat"] = [getattr(m, f"{k}_features_{l}") for l in range(Lv - 1)]
+    oracle = OracleHiLam(cin, cout, graph, processor_layers=2).double()
+    oracle.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    m = m.to(gpu_device)
+    x, gy = torch.randn(2, H * W, cin), torch.randn(2, H * W, cout)
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = m(xg)
+    y.backward(gy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    yr = oracle(xr)
+    yr.backward(gy.double())
+    assert _rel(y.detach().cpu(), yr.detach()) < 1e-4
+    assert _rel(xg.grad.cpu(), xr.grad) < 1e-3
+    ref = dict(oracle.named_parameters())
+    for name, p in m.named_parameters():
+        assert _rel(p.grad.cpu(), ref[name].grad) < 3e-3, name
+
+
+def test_hilam_registered_and_trains_bf16(gpu_device, tmp_path):
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from tests.helpers import make_batch, make_dataset_info, synthetic_case
+
+    case = synthetic_case(seed=62, B=2, T=2, H=27, W=27, F=5, Ff=5)
+    info = make_dataset_info(case, 5)
+    lm = AutoRegressiveLightning(
+        {"tmp_dir": str(tmp_path), "activation_dtype": "bf16", "processor_layers": 1}, info, None, num_input_steps=1,
+        num_pred_steps_train=2, batch_size=2, model_name="HiLAM",
+        losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+        training_strategy="diff_ar",
+    ).to(gpu_device)
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lm.model.parameters())
