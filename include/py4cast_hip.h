@@ -386,6 +386,47 @@ size_t p4c_row_linear_wgrad_workspace_bytes(int64_t R, int K);
 int p4c_row_linear_wgrad(const void* dy, const void* x, float* dw_db, void* workspace, int64_t R, int O, int K, int dtype,
                          p4c_stream_t stream);
 
+
+/* Fused row MLP of the GNN models (make_mlp: Linear - SiLU - Linear - LayerNorm, hidden = out = 64 features):
+ *   pre  = x W1^T + b1 (+ gather_a[index_a[r]] + gather_b[index_b[r]])      -- the gathered addends are the sender / receiver
+ *                                                                              parts of a distributed edge-MLP first layer
+ *   y    = LayerNorm(SiLU(pre) W2^T + b2) * gamma + beta                     (LayerNorm skipped when gamma is NULL)
+ *   out[r] = y,  out_res[r] = y + res[r]                                     (each optional)
+ * one pass over the rows each way: a row is read once and written once; nothing but x is kept for the backward (the forward is
+ * recomputed).  bf16 rows, fp32 parameters; bf16 matrix cores with fp32 accumulation, SiLU / LayerNorm in fp32. */
+typedef struct p4c_row_mlp_desc {
+    int64_t rows;
+    const void* x;           /* (rows, k) bf16, k a multiple of 16 up to 80 (features beyond k_real zero-padded) */
+    int32_t k, k_real;
+    const float* w1;         /* [64][k_real] with row stride ldw1 (a column slice of a wider weight is fine) */
+    int32_t ldw1;
+    const float* b1;         /* [64] or NULL */
+    const float* w2;         /* [o_real][64] contiguous */
+    const float* b2;         /* [o_real] or NULL */
+    int32_t o_real;          /* <= 64; output features beyond are written as zeros (no LayerNorm in that case) */
+    const float* gamma;      /* [64] or NULL */
+    const float* beta;
+    float eps;
+    const void* gather_a;    /* (n_a, 64) bf16 or NULL */
+    const int32_t* index_a;  /* (rows) */
+    const void* gather_b;
+    const int32_t* index_b;
+    const void* res;         /* (rows, 64) bf16 or NULL */
+    void* out;               /* (rows, 64) bf16 or NULL */
+    void* out_res;           /* (rows, 64) bf16 or NULL (needs res) */
+    /* backward only */
+    const void* dy;          /* gradient of out, or NULL */
+    const void* dy_res;      /* gradient of out_res, or NULL (the gradient of res is dy_res itself) */
+    void* dx;                /* (rows, k) bf16 or NULL */
+    void* dpre;              /* (rows, 64) bf16 or NULL: gradient of the pre-activation = gradient of the gathered rows before
+                                their p4c_segment_sum over index_a / index_b */
+} p4c_row_mlp_desc;
+int p4c_row_mlp_fwd(const p4c_row_mlp_desc* d, p4c_stream_t stream);
+/* grads (fp32, overwritten): dW1 [64][k] | dW2 [64][64] | db1 [64] | db2 [64] | dgamma [64] | dbeta [64], reduced in a fixed
+ * order.  workspace: p4c_row_mlp_bwd_workspace_bytes(rows, k) bytes. */
+size_t p4c_row_mlp_bwd_workspace_bytes(int64_t rows, int k);
+int p4c_row_mlp_bwd(const p4c_row_mlp_desc* d, float* grads, void* workspace, p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

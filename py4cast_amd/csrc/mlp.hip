@@ -1,0 +1,625 @@
+// Fused row MLP of the mesh-GNN models:  y = LayerNorm(W2 SiLU(W1 x + b1 [+ a[ia] + b[ib]]) + b2) [+ res]   on R rows, hidden = out = 64.
+// Every MLP of GraphLam / HiLAM is this shape (make_mlp: Linear - SiLU - Linear - LayerNorm, hidden_layers 1, hidden_dims 64:
+// config/CLI/model/graphlam.yaml:21-22; the networks come from mfai, py4cast/models.py:10-20); on edges the first Linear is
+// distributed over cat[e, x_s[src], x_r[dst]] (see graph.hip), which is the optional gathered addend here.  The library path runs it
+// as 2 GEMMs + SiLU + LayerNorm + add (and 6 more passes backward), each a full stream of 0.5-2 M rows through HBM; here a row is
+// read once and written once per direction:
+//   * orientation "weights x rows": A = W (M = output feature), B = x^T (N = row): a lane loads 16 bytes of ITS row straight from
+//     HBM as the B operand (no LDS staging of activations); the accumulator has the features of a row on the registers of one lane
+//     pair, so SiLU, LayerNorm statistics (per-lane sums + one exchange between lane halves) and the residual are register math;
+//   * the first product's accumulator, rounded to bf16, IS the B operand of the second (cdna_hip_programming.md "An accumulator tile
+//     as the next MFMA's operand"); weights are re-laid once per workgroup into LDS operand images (the second layer's in the permuted
+//     k order that idiom needs);
+//   * backward recomputes the forward from x (nothing saved but x), chains dz -> dh -> dpre -> dx through the same idiom with the
+//     transposed weight images, and forms dW1, dW2, db1, db2 from [row][feature] LDS images of (x, h, dz, dpre) with transposed reads
+//     (ds_read_b64_tr_b16) -- the reduction index of a weight gradient is the row; 64 x K + 64 x 64 accumulators stay in registers
+//     over a persistent wave's rows; all parameter gradients are reduced in a fixed order (no atomics).
+#include "kernels.hpp"
+
+namespace p4c {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int HID = 64;
+constexpr int PROW = HID * 2 + 16;   // LDS row stride of a [row][64 features] bf16 image (padded: transposed reads spread over banks)
+
+struct MlpArgs {
+    const bf16* x;          // (R, K) rows, K = 16 * KS (zero-padded features)
+    const float* w1;        // first Linear weight [64][>= Kreal], row stride ldw1 (may be a column slice of a wider matrix)
+    int ldw1, Kreal;
+    const float* b1;        // [64] or NULL
+    const float* w2;        // [Oreal][64] contiguous
+    const float* b2;        // [Oreal] or NULL
+    int Oreal;              // real output features (<= 64; rows beyond are zero)
+    const float* gamma;     // LayerNorm weight / bias [64]; NULL = no LayerNorm
+    const float* beta;
+    float eps;
+    const bf16* ga;         // gathered addends to the pre-activation: ga[ia[r]] + gb[ib[r]] (rows of 64) or NULL
+    const int32_t* ia;
+    const bf16* gb;
+    const int32_t* ib;
+    const bf16* res;        // residual rows (R, 64) or NULL
+    bf16* out;              // y (R, 64) or NULL
+    bf16* out_res;          // y + res (R, 64) or NULL
+    // backward
+    const bf16* dy;         // gradient of out or NULL
+    const bf16* dy_res;     // gradient of out_res or NULL
+    bf16* dx;               // (R, K) or NULL
+    bf16* dpre;             // gradient of the pre-activation (R, 64): the gradient of ga / gb rows before their segment sums; or NULL
+    float* partial;         // per-workgroup parameter-gradient partials
+    int64_t R;
+};
+
+__device__ __forceinline__ int rowmap(int i) { return (i & 3) + 8 * (i >> 2); }
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)0.f;
+    return r;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+__device__ __forceinline__ bf16x8 acc_op(const float* x, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)x[8 * s + j];
+    return r;
+}
+__device__ __forceinline__ f32x4 load4(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
+    bf16x4 o;
+    o[0] = (__bf16)a; o[1] = (__bf16)b; o[2] = (__bf16)c; o[3] = (__bf16)d;
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ void lds_order() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+// natural-order transposed operand of k-step ks (rows 16 ks .. +15) from a [row][feature] image with row stride `rs` bytes:
+// lane (feature 32 tile + (lane & 31), h) receives rows 16 ks + 8 h + j, j = 0..7
+__device__ __forceinline__ bf16x8 read_tr_nat(const char* img, int rs, int ks, int tile, int lane) {
+    const int i = lane & 15, tg = (lane >> 4) & 1, h = lane >> 5;
+    const char* p = img + (16 * ks + 8 * h + (i >> 2)) * rs + (32 * tile + tg * 16 + (i & 3) * 4) * 2;
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * rs));
+    return u.v;
+}
+
+__device__ __forceinline__ float silu_sig(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-x * LOG2E)); }
+
+// ---- LDS weight operand images: image[(tile * S + s) * 64 + lane] = 8 bf16 (16 B)
+// natural k order:  element j = M[row 32 tile + (lane & 31)][col 16 s + 8 h + j]
+// permuted k order: element j = M[row 32 tile + (lane & 31)][col 16 s + 8 (j >> 2) + 4 h + (j & 3)]   (matches acc_op)
+// M(row, col) = transposed ? W[col][row] : W[row][col], zero outside (rows_real, cols_real)
+__device__ __forceinline__ void build_image(bf16* img, int tiles, int S, const float* W, int ld, int rows_real, int cols_real,
+                                            bool transposed, bool permuted) {
+    const int total = tiles * S * 64 * 8;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, ts = idx >> 9;
+        const int s = ts % S, tile = ts / S;
+        const int h = lane >> 5;
+        const int row = 32 * tile + (lane & 31);
+        const int col = permuted ? 16 * s + 8 * (j >> 2) + 4 * h + (j & 3) : 16 * s + 8 * h + j;
+        float v = 0.f;
+        if (row < rows_real && col < cols_real) v = transposed ? W[(int64_t)col * ld + row] : W[(int64_t)row * ld + col];
+        img[idx] = (bf16)v;
+    }
+}
+__device__ __forceinline__ bf16x8 wop(const bf16* img, int S, int tile, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(img + ((tile * S + s) * 64 + lane) * 8);
+}
+
+// constants: [b1 | b2 | gamma | beta] x 64 floats
+__device__ __forceinline__ void build_consts(float* lc, const MlpArgs& a) {
+    for (int i = threadIdx.x; i < 4 * HID; i += blockDim.x) {
+        const int which = i >> 6, c = i & 63;
+        float v = 0.f;
+        if (which == 0 && a.b1) v = a.b1[c];
+        if (which == 1 && a.b2 && c < a.Oreal) v = a.b2[c];
+        if (which == 2) v = a.gamma ? a.gamma[c] : 1.f;
+        if (which == 3 && a.beta) v = a.beta[c];
+        lc[i] = v;
+    }
+}
+
+// the forward of one 32-row tile up to z (pre-LayerNorm output).  Row of this lane: row0 + (lane & 31).
+template <int KS>
+struct Tile {
+    bf16x8 xop[KS];
+    float pre[32];   // [m * 16 + i]: hidden feature 32 m + rowmap(i) + 4 h
+    float z[32];     // output feature, same indexing
+};
+
+template <int KS>
+__device__ __forceinline__ void tile_forward(Tile<KS>& t, const MlpArgs& a, const bf16* w1img, const bf16* w2img, const float* lc,
+                                             int64_t row, bool live, int lane, float* hval /*32 or null*/) {
+    const int h = lane >> 5;
+    constexpr int K = 16 * KS;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        t.xop[s] = live ? *reinterpret_cast<const bf16x8*>(a.x + row * K + 16 * s + 8 * h) : zero8();
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        acc[m] = zero16();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1img, KS, m, s, lane), t.xop[s], acc[m], 0, 0, 0);
+    }
+    int ja = 0, jb = 0;
+    if (a.ga && live) ja = a.ia[row];
+    if (a.gb && live) jb = a.ib[row];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * m + 8 * g + 4 * h;
+            f32x4 v = *reinterpret_cast<const f32x4*>(lc + c0);
+            if (a.ga && live) v += load4(a.ga + (int64_t)ja * HID + c0);
+            if (a.gb && live) v += load4(a.gb + (int64_t)jb * HID + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t.pre[m * 16 + 4 * g + e] = acc[m][4 * g + e] + v[e];
+        }
+    float hv[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        hv[i] = t.pre[i] * silu_sig(t.pre[i]);
+        if (hval) hval[i] = hv[i];
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        acc[m] = zero16();
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w2img, 4, m, sp, lane), acc_op(hv + 16 * (sp >> 1), sp & 1), acc[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lc + 64 + 32 * m + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t.z[m * 16 + 4 * g + e] = acc[m][4 * g + e] + v[e];
+        }
+}
+
+// LayerNorm statistics of the lane's row (the 64 features live on this lane and its partner in the other half)
+__device__ __forceinline__ void row_stats(const float* z, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += z[i];
+    s += __shfl_xor(s, 32, 64);
+    mean = s * (1.f / 64.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) q += (z[i] - mean) * (z[i] - mean);
+    q += __shfl_xor(q, 32, 64);
+    rstd = rsqrtf(q * (1.f / 64.f) + eps);
+}
+
+constexpr int fwd_lds_bytes(int KS) { return 4 * HID * 4 + (2 * KS + 8) * 1024; }
+
+template <int KS>
+__global__ void __launch_bounds__(256, 2) row_mlp_fwd_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lc = reinterpret_cast<float*>(smem);
+    bf16* w1img = reinterpret_cast<bf16*>(smem + 4 * HID * 4);
+    bf16* w2img = w1img + 2 * KS * 512;
+    build_consts(lc, a);
+    build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false);
+    build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t ntiles = (a.R + 31) / 32;
+    for (int64_t tIdx = wave; tIdx < ntiles; tIdx += nwaves) {
+        asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads (weights, constants) inside the loop: hoisted, they spill
+        const int64_t row = tIdx * 32 + r;
+        const bool live = row < a.R;
+        Tile<KS> t;
+        tile_forward<KS>(t, a, w1img, w2img, lc, row, live, lane, nullptr);
+        float mean = 0.f, rstd = 1.f;
+        if (a.gamma) row_stats(t.z, a.eps, mean, rstd);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g + 4 * h;
+                float y[4];
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0), bt = *reinterpret_cast<const f32x4*>(lc + 192 + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float zz = t.z[m * 16 + 4 * g + e];
+                    y[e] = a.gamma ? (zz - mean) * rstd * gm[e] + bt[e] : zz;
+                }
+                if (live) {
+                    if (a.out) store4(a.out + row * HID + c0, y[0], y[1], y[2], y[3]);
+                    if (a.out_res) {
+                        const f32x4 rv = load4(a.res + row * HID + c0);
+                        store4(a.out_res + row * HID + c0, y[0] + rv[0], y[1] + rv[1], y[2] + rv[2], y[3] + rv[3]);
+                    }
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+template <int KS> constexpr int nkt() { return (16 * KS + 31) / 32; }
+template <int KS> constexpr int xrow_bytes() { return 16 * KS * 2 + 16; }
+template <int KS> constexpr int wave_img_bytes() { return 32 * (xrow_bytes<KS>() + 3 * PROW); }
+template <int KS> constexpr int bwd_weights_bytes() { return (2 * KS + 8 + 8 + 4 * nkt<KS>()) * 1024; }
+template <int KS> constexpr int bwd_lds_bytes() { return 4 * HID * 4 + bwd_weights_bytes<KS>() + 4 * wave_img_bytes<KS>(); }
+// floats of one workgroup's partial: dW1 [64][K] | dW2 [64][64] | db1 | db2 | dgamma | dbeta
+template <int KS> constexpr int partial_floats() { return HID * 16 * KS + HID * HID + 4 * HID; }
+
+template <int KS>
+__global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
+    constexpr int K = 16 * KS, NKT = nkt<KS>(), XROW = xrow_bytes<KS>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lc = reinterpret_cast<float*>(smem);
+    bf16* w1img = reinterpret_cast<bf16*>(smem + 4 * HID * 4);
+    bf16* w2img = w1img + 2 * KS * 512;
+    bf16* w2timg = w2img + 8 * 512;        // A[m = hidden][k = output], permuted k
+    bf16* w1timg = w2timg + 8 * 512;       // A[m = input feature][k = hidden], permuted k
+    char* wbase = smem + 4 * HID * 4 + bwd_weights_bytes<KS>() + (threadIdx.x >> 6) * wave_img_bytes<KS>();
+    char* imgX = wbase;
+    char* imgH = imgX + 32 * XROW;
+    char* imgDZ = imgH + 32 * PROW;
+    char* imgDP = imgDZ + 32 * PROW;
+    build_consts(lc, a);
+    build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false);
+    build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true);
+    build_image(w2timg, 2, 4, a.w2, HID, HID, a.Oreal, true, true);
+    build_image(w1timg, NKT, 4, a.w1, a.ldw1, a.Kreal, HID, true, true);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    const int64_t ntiles = (a.R + 31) / 32;
+
+    f32x16 dw1[2][NKT], dw2[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < NKT; ++n) dw1[m][n] = zero16();
+        dw2[m][0] = zero16();
+        dw2[m][1] = zero16();
+    }
+    float dgam[32], dbet[32], db1[8], db2[8];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) dgam[i] = dbet[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) db1[i] = db2[i] = 0.f;
+
+    for (int64_t tIdx = wave; tIdx < ntiles; tIdx += nwaves) {
+        asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads (weights, constants) inside the loop: hoisted, they spill
+        const int64_t row = tIdx * 32 + r;
+        const bool live = row < a.R;
+        Tile<KS> t;
+        float hv[32];
+        tile_forward<KS>(t, a, w1img, w2img, lc, row, live, lane, hv);
+        // images of x and h (B operands of the weight gradients)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(imgX + r * XROW + (16 * s + 8 * h) * 2) = t.xop[s];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store4(reinterpret_cast<bf16*>(imgH + r * PROW + (32 * m + 8 * g + 4 * h) * 2), hv[m * 16 + 4 * g], hv[m * 16 + 4 * g + 1],
+                       hv[m * 16 + 4 * g + 2], hv[m * 16 + 4 * g + 3]);
+        // upstream gradient d (of y), LayerNorm backward -> dz
+        float mean = 0.f, rstd = 1.f;
+        if (a.gamma) row_stats(t.z, a.eps, mean, rstd);
+        float dz[32];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g + 4 * h;
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (live) {
+                    if (a.dy) d += load4(a.dy + row * HID + c0);
+                    if (a.dy_res) d += load4(a.dy_res + row * HID + c0);
+                }
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = m * 16 + 4 * g + e;
+                    if (a.gamma) {
+                        const float xh = (t.z[i] - mean) * rstd;
+                        dgam[i] += d[e] * xh;
+                        dbet[i] += d[e];
+                        const float gq = d[e] * gm[e];
+                        m1 += gq;
+                        m2 += gq * xh;
+                        dz[i] = gq;
+                        t.z[i] = xh;
+                    } else {
+                        dz[i] = d[e];
+                    }
+                }
+            }
+        if (a.gamma) {
+            m1 += __shfl_xor(m1, 32, 64);
+            m2 += __shfl_xor(m2, 32, 64);
+            m1 *= (1.f / 64.f);
+            m2 *= (1.f / 64.f);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) dz[i] = rstd * (dz[i] - m1 - t.z[i] * m2);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store4(reinterpret_cast<bf16*>(imgDZ + r * PROW + (32 * m + 8 * g + 4 * h) * 2), dz[m * 16 + 4 * g], dz[m * 16 + 4 * g + 1],
+                       dz[m * 16 + 4 * g + 2], dz[m * 16 + 4 * g + 3]);
+        // dh = W2^T dz, dpre = dh * silu'(pre)
+        float dp[32];
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = zero16();
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w2timg, 4, m, sp, lane), acc_op(dz + 16 * (sp >> 1), sp & 1), acc[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float x = t.pre[i], sg = silu_sig(x);
+                dp[i] = acc[i >> 4][i & 15] * (sg * (1.f + x * (1.f - sg)));
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = 32 * m + 8 * g + 4 * h, i = m * 16 + 4 * g;
+                store4(reinterpret_cast<bf16*>(imgDP + r * PROW + c0 * 2), dp[i], dp[i + 1], dp[i + 2], dp[i + 3]);
+                if (a.dpre && live) store4(a.dpre + row * HID + c0, dp[i], dp[i + 1], dp[i + 2], dp[i + 3]);
+            }
+        // dx = W1^T dpre
+        if (a.dx) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                f32x16 acc = zero16();
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1timg, 4, kt, sp, lane), acc_op(dp + 16 * (sp >> 1), sp & 1), acc, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 32 * kt + 8 * g + 4 * h;
+                    if (live && c0 < K) store4(a.dx + row * K + c0, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                }
+            }
+        }
+        lds_order();
+        // weight gradients: reduction over the tile's 32 rows (2 k-steps), operands by transposed reads of the images
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 adz[2], adp[2], bh[2], bx[NKT];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                adz[m] = read_tr_nat(imgDZ, PROW, ks, m, lane);
+                adp[m] = read_tr_nat(imgDP, PROW, ks, m, lane);
+                bh[m] = read_tr_nat(imgH, PROW, ks, m, lane);
+            }
+#pragma unroll
+            for (int n = 0; n < NKT; ++n) {
+                // K = 16 (mod 32): the upper half-tile re-reads the lower one (valid memory), its columns are discarded at the end
+                const bool upper_missing = (32 * n + 16 >= K) && (((lane >> 4) & 1) == 1);
+                bx[n] = read_tr_nat(imgX - (upper_missing ? 32 : 0), XROW, ks, n, lane);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) dw2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adz[m], bh[n], dw2[m][n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NKT; ++n) dw1[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adp[m], bx[n], dw1[m][n], 0, 0, 0);
+            }
+        }
+        // bias gradients: column sums of the dz / dpre images (lane = 16-byte feature chunk lane & 7 of rows (lane >> 3) + 8 it)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = (lane >> 3) + 8 * it, c = lane & 7;
+            const bf16x8 vz = *reinterpret_cast<const bf16x8*>(imgDZ + rr * PROW + c * 16);
+            const bf16x8 vp = *reinterpret_cast<const bf16x8*>(imgDP + rr * PROW + c * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                db2[j] += (float)vz[j];
+                db1[j] += (float)vp[j];
+            }
+        }
+        lds_order();
+    }
+
+    // ---- per-workgroup partial (the four waves add in wave order through LDS: fixed order), then one global partial per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem + 4 * HID * 4 + bwd_weights_bytes<KS>());
+    constexpr int OFF_W2 = HID * K, OFF_B1 = OFF_W2 + HID * HID, OFF_B2 = OFF_B1 + HID, OFF_G = OFF_B2 + HID, OFF_BT = OFF_G + HID;
+    // cross-lane sums that are per wave: dgamma / dbeta over the 32 rows-lanes of a half, db1 / db2 over the 8 row groups
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        for (int o = 1; o < 32; o <<= 1) {
+            dgam[i] += __shfl_xor(dgam[i], o, 64);
+            dbet[i] += __shfl_xor(dbet[i], o, 64);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        for (int o = 8; o < 64; o <<= 1) {
+            db1[j] += __shfl_xor(db1[j], o, 64);
+            db2[j] += __shfl_xor(db2[j], o, 64);
+        }
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wv == turn) {
+            const bool first = turn == 0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int o = 32 * m + rowmap(i) + 4 * h;
+#pragma unroll
+                    for (int n = 0; n < NKT; ++n) {
+                        const int k = 32 * n + r;
+                        if (k < K) red[o * K + k] = (first ? 0.f : red[o * K + k]) + dw1[m][n][i];
+                    }
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int k = 32 * n + r;
+                        red[OFF_W2 + o * HID + k] = (first ? 0.f : red[OFF_W2 + o * HID + k]) + dw2[m][n][i];
+                    }
+                    if (r == 0) {
+                        red[OFF_G + o] = (first ? 0.f : red[OFF_G + o]) + dgam[m * 16 + i];
+                        red[OFF_BT + o] = (first ? 0.f : red[OFF_BT + o]) + dbet[m * 16 + i];
+                    }
+                }
+            if (lane < 8)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    red[OFF_B1 + lane * 8 + j] = (first ? 0.f : red[OFF_B1 + lane * 8 + j]) + db1[j];
+                    red[OFF_B2 + lane * 8 + j] = (first ? 0.f : red[OFF_B2 + lane * 8 + j]) + db2[j];
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = a.partial + (int64_t)blockIdx.x * partial_floats<KS>();
+    for (int i = threadIdx.x; i < partial_floats<KS>(); i += blockDim.x) dst[i] = red[i];
+}
+
+// out[j] = sum_s partial[s][j] in a fixed order (same scheme as rows.hip)
+__global__ void __launch_bounds__(256) mlp_param_reduce_kernel(const float* __restrict__ partial, int slots, int n, float* __restrict__ out) {
+    __shared__ float red[8][33];
+    const int jj = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jj;
+    float s0 = 0.f, s1 = 0.f;
+    if (j < n) {
+        int s = sg;
+        for (; s + 8 < slots; s += 16) {
+            s0 += partial[(int64_t)s * n + j];
+            s1 += partial[(int64_t)(s + 8) * n + j];
+        }
+        for (; s < slots; s += 8) s0 += partial[(int64_t)s * n + j];
+    }
+    red[sg][jj] = s0 + s1;
+    __syncthreads();
+    if (sg == 0 && j < n) {
+        float t = red[0][jj];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][jj];
+        out[j] = t;
+    }
+}
+
+int mlp_grid(int64_t R, int per_cu) {
+    const int64_t tiles = (R + 31) / 32;
+    int64_t blocks = (tiles + 3) / 4;
+    const int64_t cap = (int64_t)num_cus() * per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int check_args(const char* name, const MlpArgs& a, int K) {
+    P4C_CHECK_ARG(a.R > 0, "%s: R must be positive", name);
+    P4C_CHECK_ARG(K % 16 == 0 && K >= 16 && K <= 80, "%s: K = %d input features (multiples of 16 up to 80; pad)", name, K);
+    P4C_CHECK_ARG(a.x && a.w1 && a.w2, "%s: NULL pointer", name);
+    P4C_CHECK_ARG(a.Kreal > 0 && a.Kreal <= K && a.ldw1 >= a.Kreal, "%s: bad first-layer weight shape", name);
+    P4C_CHECK_ARG(a.Oreal > 0 && a.Oreal <= HID, "%s: bad output feature count %d", name, a.Oreal);
+    P4C_CHECK_ARG((a.ga == nullptr) == (a.ia == nullptr) && (a.gb == nullptr) == (a.ib == nullptr), "%s: ga/ia, gb/ib go together", name);
+    P4C_CHECK_ARG((a.gamma == nullptr) == (a.beta == nullptr), "%s: gamma and beta go together", name);
+    return P4C_OK;
+}
+
+template <int KS>
+int launch_fwd(const MlpArgs& a, hipStream_t s) {
+    constexpr int smem = fwd_lds_bytes(KS);
+    hipLaunchKernelGGL(row_mlp_fwd_kernel<KS>, dim3(mlp_grid(a.R, 4)), dim3(256), smem, s, a);
+    P4C_CHECK_LAUNCH("row_mlp_fwd");
+    return P4C_OK;
+}
+template <int KS>
+int launch_bwd(const MlpArgs& a, float* grads, hipStream_t s) {
+    constexpr int smem = bwd_lds_bytes<KS>();
+    static_assert(4 * wave_img_bytes<KS>() >= partial_floats<KS>() * 4, "reduction buffer must fit the waves' images");
+    static bool attr_set = false;
+    if (!attr_set) {
+        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)row_mlp_bwd_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int G = mlp_grid(a.R, 1);
+    hipLaunchKernelGGL(row_mlp_bwd_kernel<KS>, dim3(G), dim3(256), smem, s, a);
+    P4C_CHECK_LAUNCH("row_mlp_bwd");
+    const int n = partial_floats<KS>();
+    hipLaunchKernelGGL(mlp_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, grads);
+    P4C_CHECK_LAUNCH("mlp_param_reduce");
+    return P4C_OK;
+}
+
+}  // namespace
+}  // namespace p4c
+
+using namespace p4c;
+
+static MlpArgs to_args(const p4c_row_mlp_desc* d) {
+    MlpArgs a{};
+    a.x = (const bf16*)d->x; a.w1 = d->w1; a.ldw1 = d->ldw1; a.Kreal = d->k_real; a.b1 = d->b1;
+    a.w2 = d->w2; a.b2 = d->b2; a.Oreal = d->o_real; a.gamma = d->gamma; a.beta = d->beta; a.eps = d->eps;
+    a.ga = (const bf16*)d->gather_a; a.ia = d->index_a; a.gb = (const bf16*)d->gather_b; a.ib = d->index_b;
+    a.res = (const bf16*)d->res; a.out = (bf16*)d->out; a.out_res = (bf16*)d->out_res;
+    a.dy = (const bf16*)d->dy; a.dy_res = (const bf16*)d->dy_res; a.dx = (bf16*)d->dx; a.dpre = (bf16*)d->dpre;
+    a.partial = nullptr; a.R = d->rows;
+    return a;
+}
+
+extern "C" int p4c_row_mlp_fwd(const p4c_row_mlp_desc* d, p4c_stream_t stream) {
+    P4C_CHECK_ARG(d != nullptr, "p4c_row_mlp_fwd: NULL descriptor");
+    MlpArgs a = to_args(d);
+    int rc = check_args("p4c_row_mlp_fwd", a, d->k);
+    if (rc != P4C_OK) return rc;
+    P4C_CHECK_ARG(a.out || a.out_res, "p4c_row_mlp_fwd: no output");
+    P4C_CHECK_ARG(!a.out_res || a.res, "p4c_row_mlp_fwd: out_res needs res");
+    hipStream_t s = as_stream(stream);
+    switch (d->k / 16) {
+        case 1: return launch_fwd<1>(a, s);
+        case 2: return launch_fwd<2>(a, s);
+        case 3: return launch_fwd<3>(a, s);
+        case 4: return launch_fwd<4>(a, s);
+        default: return launch_fwd<5>(a, s);
+    }
+}
+
+extern "C" size_t p4c_row_mlp_bwd_workspace_bytes(int64_t rows, int k) {
+    if (rows <= 0 || k <= 0) return 0;
+    return (size_t)mlp_grid(rows, 1) * (HID * (size_t)k + HID * HID + 4 * HID) * sizeof(float);
+}
+
+extern "C" int p4c_row_mlp_bwd(const p4c_row_mlp_desc* d, float* grads, void* workspace, p4c_stream_t stream) {
+    P4C_CHECK_ARG(d != nullptr && grads != nullptr && workspace != nullptr, "p4c_row_mlp_bwd: NULL pointer");
+    MlpArgs a = to_args(d);
+    int rc = check_args("p4c_row_mlp_bwd", a, d->k);
+    if (rc != P4C_OK) return rc;
+    P4C_CHECK_ARG(a.dy || a.dy_res, "p4c_row_mlp_bwd: no upstream gradient");
+    a.partial = reinterpret_cast<float*>(workspace);
+    hipStream_t s = as_stream(stream);
+    switch (d->k / 16) {
+        case 1: return launch_bwd<1>(a, grads, s);
+        case 2: return launch_bwd<2>(a, grads, s);
+        case 3: return launch_bwd<3>(a, grads, s);
+        case 4: return launch_bwd<4>(a, grads, s);
+        default: return launch_bwd<5>(a, grads, s);
+    }
+}

@@ -1,0 +1,110 @@
+"""Autograd wrapper of the fused row MLP (include/py4cast_hip.h: p4c_row_mlp_fwd / p4c_row_mlp_bwd).
+
+``y = LayerNorm(SiLU(x W1^T + b1 [+ ga[ia] + gb[ib]]) W2^T + b2) [+ res]`` -- the shape of every MLP of GraphLam / HiLAM
+(config/CLI/model/graphlam.yaml:21-22) -- as ONE kernel each way over bf16 rows; on edges the gathered addends are the sender /
+receiver parts of the distributed first layer (py4cast_amd.ops_graph).  No CPU fallback.
+"""
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from ._lib_model import RowMlpDesc
+from .ops_graph import EdgeSet, _segment_sum_raw
+
+MAX_K = 80
+
+
+def supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and w1.shape[0] == 64 and w2.shape[1] == 64 and w2.shape[0] <= 64
+            and w1.shape[1] <= MAX_K)
+
+
+def _desc(x, K, w1, b1, w2, b2, gamma, beta, eps, ga, ia, gb, ib, res, out, out_res, dy=None, dy_res=None, dx=None, dpre=None):
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    return RowMlpDesc(rows=x.shape[0], x=p(x), k=K, k_real=w1.shape[1], w1=p(w1), ldw1=w1.stride(0), b1=p(b1), w2=p(w2), b2=p(b2),
+                      o_real=w2.shape[0], gamma=p(gamma), beta=p(beta), eps=eps, gather_a=p(ga), index_a=p(ia), gather_b=p(gb),
+                      index_b=p(ib), res=p(res), out=p(out), out_res=p(out_res), dy=p(dy), dy_res=p(dy_res), dx=p(dx), dpre=p(dpre))
+
+
+class _RowMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges: Optional[EdgeSet], eps: float, want_out: bool):
+        R, K = x.shape
+        x = x.contiguous()
+        for t in (w1, w2):
+            if t.dtype != torch.float32 or t.stride(1) != 1:
+                raise L.P4CError("row_mlp: weights must be fp32 with unit column stride")
+        w2c = w2.contiguous()
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+        b1c, b2c, gc, bc = f32(b1), f32(b2), f32(gamma), f32(beta)
+        gac = None if ga is None else ga.contiguous()
+        gbc = None if gb is None else gb.contiguous()
+        resc = None if res is None else res.contiguous()
+        out = torch.empty(R, 64, dtype=x.dtype, device=x.device) if want_out else None
+        out_res = torch.empty(R, 64, dtype=x.dtype, device=x.device) if res is not None else None
+        ia = edges.src if ga is not None else None
+        ib = edges.dst if gb is not None else None
+        d = _desc(x, K, w1.detach(), b1c, w2c.detach(), b2c, gc, bc, eps, gac, ia, gbc, ib, resc, out, out_res)
+        rows_io = 1 + (out is not None) + 2 * (out_res is not None)
+        gathered = sum(min(R, t.shape[0]) for t in (gac, gbc) if t is not None)
+        L.call("p4c_row_mlp_fwd", ctypes.byref(d), L.stream(x.device),
+               alg_bytes=R * K * 2 + (rows_io - 1) * R * 128 + gathered * 128 + 4 * R * ((ga is not None) + (gb is not None)))
+        ctx.save_for_backward(x, w1, w2c, b1c, b2c, gc, bc, gac, gbc)
+        ctx.edges, ctx.eps = edges, eps
+        ctx.flags = (b1 is not None, b2 is not None, gamma is not None, res is not None)
+        ctx.pdtype = w1.dtype
+        if out is None:
+            ctx.mark_non_differentiable()
+        return out, out_res
+
+    @staticmethod
+    def backward(ctx, dout, dout_res):
+        x, w1, w2, b1, b2, gamma, beta, ga, gb = ctx.saved_tensors
+        has_b1, has_b2, has_ln, has_res = ctx.flags
+        edges = ctx.edges
+        R, K = x.shape
+        dy = None if dout is None else dout.contiguous()
+        dyr = None if dout_res is None else dout_res.contiguous()
+        if dy is None and dyr is None:
+            return (None,) * 13
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        gathered = ga is not None or gb is not None
+        dpre = torch.empty(R, 64, dtype=x.dtype, device=x.device) if gathered else None
+        grads = torch.empty(64 * K + 64 * 64 + 4 * 64, dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(L.lib().p4c_row_mlp_bwd_workspace_bytes(R, K) // 4, 1), dtype=torch.float32, device=x.device)
+        ia = edges.src if ga is not None else None
+        ib = edges.dst if gb is not None else None
+        d = _desc(x, K, w1.detach(), b1, w2, b2, gamma, beta, ctx.eps, ga, ia, gb, ib, None, None, None, dy, dyr, dx, dpre)
+        rows_io = 1 + (dy is not None) + (dyr is not None) + need_dx * K / 64 + gathered
+        n_gath = sum(min(R, t.shape[0]) for t in (ga, gb) if t is not None)
+        L.call("p4c_row_mlp_bwd", ctypes.byref(d), L.ptr(grads), L.ptr(ws), L.stream(x.device),
+               alg_bytes=R * K * 2 + (rows_io - 1) * R * 128 + n_gath * 128 + 4 * R * ((ga is not None) + (gb is not None)))
+        kr, o = w1.shape[1], w2.shape[0]
+        dw1 = grads[: 64 * K].view(64, K)[:, :kr]
+        dw2 = grads[64 * K: 64 * K + 4096].view(64, 64)[:o]
+        base = 64 * K + 4096
+        db1 = grads[base: base + 64] if has_b1 else None
+        db2 = grads[base + 64: base + 64 + o] if has_b2 else None
+        dgam = grads[base + 128: base + 192] if has_ln else None
+        dbet = grads[base + 192: base + 256] if has_ln else None
+        dga = _segment_sum_raw(dpre, *edges.by_src, edges.n_src) if (ga is not None and ctx.needs_input_grad[7]) else None
+        dgb = _segment_sum_raw(dpre, *edges.by_dst, edges.n_dst) if (gb is not None and ctx.needs_input_grad[8]) else None
+        dres = dyr if has_res else None
+        return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None
+
+
+def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=None, beta=None, eps: float = 1e-5,
+            ga: Optional[torch.Tensor] = None, gb: Optional[torch.Tensor] = None, edges: Optional[EdgeSet] = None,
+            res: Optional[torch.Tensor] = None, want_out: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Returns (y, y + res); x (R, K) bf16 with K <= 80 (padded to a multiple of 16 here), w1 (64, K), w2 (O <= 64, 64).
+    ga / gb: (n_src, 64) / (n_dst, 64) rows added to the pre-activation through edges.src / edges.dst."""
+    L.require_cuda(x)
+    kp = (-x.shape[1]) % 16
+    if kp:
+        x = F.pad(x, (0, kp))
+    return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out)

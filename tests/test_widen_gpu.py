@@ -476,3 +476,72 @@ def test_hilam_registered_and_trains_bf16(gpu_device, tmp_path):
     loss.backward()
     assert torch.isfinite(loss)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lm.model.parameters())
+
+
+# ----------------------------------------------------------------------------------------- fused row MLP
+def _mlp_ref(x, w1, b1, w2, b2, gamma, beta, ga, ia, gb, ib, res):
+    pre = torch.nn.functional.linear(x, w1, b1)
+    if ga is not None:
+        pre = pre + ga[ia.long()]
+    if gb is not None:
+        pre = pre + gb[ib.long()]
+    z = torch.nn.functional.linear(torch.nn.functional.silu(pre), w2, b2)
+    y = torch.nn.functional.layer_norm(z, (64,), gamma, beta, 1e-5) if gamma is not None else z
+    return y, (y + res if res is not None else None)
+
+
+@pytest.mark.parametrize("K,O,ln,gather,with_res,R", [
+    (64, 64, True, False, False, 5000), (64, 64, True, True, True, 7001), (69, 64, True, False, True, 3000),
+    (3, 64, True, False, False, 4097), (64, 60, False, False, False, 2500), (40, 64, True, True, False, 33), (16, 64, True, False, True, 1)])
+def test_row_mlp_fused(gpu_device, K, O, ln, gather, with_res, R):
+    from py4cast_amd import ops_graph as G
+    from py4cast_amd.ops_mlp import row_mlp
+
+    torch.manual_seed(71)
+    bf = torch.bfloat16
+    x = torch.randn(R, K).to(bf)
+    wbig = torch.randn(64, K + 7) * (1.0 / K ** 0.5)      # the first-layer weight is a column slice of a wider matrix
+    b1, w2, b2 = torch.randn(64) * 0.1, torch.randn(O, 64) * 0.2, torch.randn(O) * 0.1
+    gamma, beta = (torch.rand(64) + 0.5, torch.randn(64) * 0.1) if ln else (None, None)
+    res = torch.randn(R, 64).to(bf) if with_res else None
+    Ns, Nr = 57, 91
+    src, dst = torch.randint(0, Ns, (R,)), torch.randint(0, Nr, (R,))
+    ga, gb = (torch.randn(Ns, 64).to(bf), torch.randn(Nr, 64).to(bf)) if gather else (None, None)
+    es = G.EdgeSet(src, dst, Ns, Nr).to(gpu_device) if gather else None
+    dy, dyr = torch.randn(R, 64).to(bf), torch.randn(R, 64).to(bf)
+    if O < 64:
+        dy[:, O:] = 0
+
+    dev = lambda t, g=True: None if t is None else t.to(gpu_device).requires_grad_(g)  # noqa: E731
+    xg, wg, b1g, w2g, b2g, gg, bg, gag, gbg, rg = (dev(t) for t in (x, wbig, b1, w2, b2, gamma, beta, ga, gb, res))
+    out, out_res = row_mlp(xg, wg[:, 3:3 + K], b1g, w2g, b2g, gg, bg, 1e-5, gag, gbg, es, rg)
+    loss = (out.float() * dy.to(gpu_device).float()).sum()
+    if with_res:
+        loss = loss + (out_res.float() * dyr.to(gpu_device).float()).sum()
+    loss.backward()
+
+    # float64 reference on the same bf16-rounded rows and weights (the operands the matrix cores see)
+    rd = lambda t: None if t is None else t.double().requires_grad_(True)  # noqa: E731
+    q = lambda t: None if t is None else t.to(bf).double()  # noqa: E731
+    xr, gar, gbr, rr = rd(x), rd(ga), rd(gb), rd(res)
+    wr, w2r = q(wbig).requires_grad_(True), q(w2).requires_grad_(True)
+    b1r, b2r, gr, br = rd(b1), rd(b2), rd(gamma), rd(beta)
+    w2full = torch.cat([w2r, torch.zeros(64 - O, 64, dtype=torch.float64)]) if O < 64 else w2r
+    b2full = torch.cat([b2r, torch.zeros(64 - O, dtype=torch.float64)]) if O < 64 else b2r
+    yr, yrr = _mlp_ref(xr, wr[:, 3:3 + K], b1r, w2full, b2full, gr, br, gar, src, gbr, dst, rr)
+    lr = (yr * dy.double()).sum() + ((yrr * dyr.double()).sum() if with_res else 0.0)
+    lr.backward()
+
+    assert _rel(out.detach().float().cpu(), yr.detach()) < 1.5e-2     # h and y are rounded to bf16
+    if with_res:
+        assert _rel(out_res.detach().float().cpu(), yrr.detach()) < 1.5e-2
+        assert torch.equal(rg.grad.cpu(), dyr)
+    tol = 3e-2
+    assert _rel(xg.grad.float().cpu(), xr.grad) < tol
+    assert _rel(wg.grad.cpu(), wr.grad) < tol
+    assert _rel(w2g.grad.cpu(), w2r.grad) < tol
+    assert _rel(b1g.grad.cpu(), b1r.grad) < tol and _rel(b2g.grad.cpu(), b2r.grad) < tol
+    if ln:
+        assert _rel(gg.grad.cpu(), gr.grad) < tol and _rel(bg.grad.cpu(), br.grad) < tol
+    if gather:
+        assert _rel(gag.grad.float().cpu(), gar.grad) < tol and _rel(gbg.grad.float().cpu(), gbr.grad) < tol
