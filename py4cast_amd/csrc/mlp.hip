@@ -260,13 +260,27 @@ __global__ void __launch_bounds__(256, 2) row_mlp_fwd_kernel(MlpArgs a) {
 // ---------------------------------------------------------------------------------------------- backward
 template <int KS> constexpr int nkt() { return (16 * KS + 31) / 32; }
 template <int KS> constexpr int xrow_bytes() { return 16 * KS * 2 + 16; }
-template <int KS> constexpr int wave_img_bytes() { return 32 * (xrow_bytes<KS>() + 3 * PROW); }
+// per-wave LDS images of one 32-row tile: x | h | dz | dpre | d*xhat | d
+template <int KS> constexpr int wave_img_bytes() { return 32 * (xrow_bytes<KS>() + 5 * PROW); }
 template <int KS> constexpr int bwd_weights_bytes() { return (2 * KS + 8 + 8 + 4 * nkt<KS>()) * 1024; }
 template <int KS> constexpr int bwd_lds_bytes() { return 4 * HID * 4 + bwd_weights_bytes<KS>() + 4 * wave_img_bytes<KS>(); }
 // floats of one workgroup's partial: dW1 [64][K] | dW2 [64][64] | db1 | db2 | dgamma | dbeta
 template <int KS> constexpr int partial_floats() { return HID * 16 * KS + HID * HID + 4 * HID; }
 
+// what a lane reads from HBM for one tile: 16-byte pieces of its row of x, 8-byte pieces of the upstream gradients
 template <int KS>
+struct TileIn {
+    bf16x8 x[KS];
+    bf16x4 dy[8], dyr[8];
+};
+struct TileGather {
+    bf16x4 a[8], b[8];
+};
+
+// One wave = one 32-row tile per iteration; the NEXT tile's rows, gradients and gathered rows are in flight while the current one
+// is computed (one wave per SIMD here: 64 x (K + 64) gradient accumulators + the working set need the whole register file, so
+// memory latency is hidden by this software prefetch, not by occupancy).
+template <int KS, bool GATHER>
 __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
     constexpr int K = 16 * KS, NKT = nkt<KS>(), XROW = xrow_bytes<KS>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -280,6 +294,8 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
     char* imgH = imgX + 32 * XROW;
     char* imgDZ = imgH + 32 * PROW;
     char* imgDP = imgDZ + 32 * PROW;
+    char* imgDG = imgDP + 32 * PROW;
+    char* imgDD = imgDG + 32 * PROW;
     build_consts(lc, a);
     build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false);
     build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true);
@@ -289,6 +305,7 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     const int64_t ntiles = (a.R + 31) / 32;
+    const bool has_dy = a.dy != nullptr, has_dyr = a.dy_res != nullptr, has_ln = a.gamma != nullptr;
 
     f32x16 dw1[2][NKT], dw2[2][2];
 #pragma unroll
@@ -298,77 +315,167 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
         dw2[m][0] = zero16();
         dw2[m][1] = zero16();
     }
-    float dgam[32], dbet[32], db1[8], db2[8];
+    float db1[8], db2[8], dgam[8], dbet[8];   // column sums of the dpre / dz / d*xhat / d images: features 8 (lane & 7) + j
 #pragma unroll
-    for (int i = 0; i < 32; ++i) dgam[i] = dbet[i] = 0.f;
+    for (int i = 0; i < 8; ++i) db1[i] = db2[i] = dgam[i] = dbet[i] = 0.f;
+
+    const bf16x4 z4 = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    auto load_in = [&](TileIn<KS>& in, int64_t tile) __attribute__((always_inline)) {
+        const int64_t row = tile * 32 + r;
+        const bool live = tile < ntiles && row < a.R;
+        const int64_t rc = live ? row : 0;          // clamped address, result discarded: every path issues the same loads
 #pragma unroll
-    for (int i = 0; i < 8; ++i) db1[i] = db2[i] = 0.f;
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.x + rc * K + 16 * s + 8 * h);
+            in.x[s] = live ? v : zero8();
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+            in.dy[q] = in.dyr[q] = z4;
+            if (has_dy) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>(a.dy + rc * HID + c0);
+                in.dy[q] = live ? v : z4;
+            }
+            if (has_dyr) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>(a.dy_res + rc * HID + c0);
+                in.dyr[q] = live ? v : z4;
+            }
+        }
+    };
+    auto load_idx = [&](int64_t tile, int& ja, int& jb) __attribute__((always_inline)) {
+        const int64_t row = tile * 32 + r;
+        const bool live = tile < ntiles && row < a.R;
+        ja = jb = 0;
+        if (GATHER) {
+            if (a.ga) ja = a.ia[live ? row : 0];
+            if (a.gb) jb = a.ib[live ? row : 0];
+        }
+    };
+    auto load_gather = [&](TileGather& g, int ja, int jb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+            g.a[q] = g.b[q] = z4;
+            if (a.ga) g.a[q] = *reinterpret_cast<const bf16x4*>(a.ga + (int64_t)ja * HID + c0);
+            if (a.gb) g.b[q] = *reinterpret_cast<const bf16x4*>(a.gb + (int64_t)jb * HID + c0);
+        }
+    };
+
+    TileIn<KS> cur, nxt;
+    TileGather gcur, gnxt;
+    int ja_n = 0, jb_n = 0;
+    {
+        int ja, jb;
+        load_idx(wave, ja, jb);
+        if (GATHER) load_gather(gcur, ja, jb);
+        load_in(cur, wave);
+        load_idx(wave + nwaves, ja_n, jb_n);
+    }
 
     for (int64_t tIdx = wave; tIdx < ntiles; tIdx += nwaves) {
         asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads (weights, constants) inside the loop: hoisted, they spill
         const int64_t row = tIdx * 32 + r;
         const bool live = row < a.R;
-        Tile<KS> t;
-        float hv[32];
-        tile_forward<KS>(t, a, w1img, w2img, lc, row, live, lane, hv);
-        // images of x and h (B operands of the weight gradients)
+        // ---- next tile's loads first: they stay in flight during this tile's compute
+        if (GATHER) load_gather(gnxt, ja_n, jb_n);
+        load_in(nxt, tIdx + nwaves);
+        load_idx(tIdx + 2 * nwaves, ja_n, jb_n);
+
+        // ---- forward recompute: pre = W1 x + b1 (+ gathers), h = silu(pre), z = W2 h + b2
+        float pre[32], dz[32];
+        {
+            f32x16 acc[2];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(imgX + r * XROW + (16 * s + 8 * h) * 2) = t.xop[s];
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = zero16();
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+                for (int s = 0; s < KS; ++s) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1img, KS, m, s, lane), cur.x[s], acc[m], 0, 0, 0);
+            }
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                store4(reinterpret_cast<bf16*>(imgH + r * PROW + (32 * m + 8 * g + 4 * h) * 2), hv[m * 16 + 4 * g], hv[m * 16 + 4 * g + 1],
-                       hv[m * 16 + 4 * g + 2], hv[m * 16 + 4 * g + 3]);
-        // upstream gradient d (of y), LayerNorm backward -> dz
-        float mean = 0.f, rstd = 1.f;
-        if (a.gamma) row_stats(t.z, a.eps, mean, rstd);
-        float dz[32];
-        float m1 = 0.f, m2 = 0.f;
+            for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(imgX + r * XROW + (16 * s + 8 * h) * 2) = cur.x[s];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int q = 0; q < 8; ++q) {
+                const int m = q >> 2, g = q & 3, c0 = 32 * m + 8 * g + 4 * h;
+                f32x4 v = *reinterpret_cast<const f32x4*>(lc + c0);
+                if (GATHER) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = 32 * m + 8 * g + 4 * h;
-                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (live) {
-                    if (a.dy) d += load4(a.dy + row * HID + c0);
-                    if (a.dy_res) d += load4(a.dy_res + row * HID + c0);
+                    for (int e = 0; e < 4; ++e) v[e] += (float)gcur.a[q][e] + (float)gcur.b[q][e];
                 }
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = m * 16 + 4 * g + e;
-                    if (a.gamma) {
-                        const float xh = (t.z[i] - mean) * rstd;
-                        dgam[i] += d[e] * xh;
-                        dbet[i] += d[e];
+                for (int e = 0; e < 4; ++e) pre[m * 16 + 4 * g + e] = acc[m][4 * g + e] + v[e];
+            }
+        }
+        float zz[32];
+        {
+            float hv[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) hv[i] = pre[i] * silu_sig(pre[i]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                store4(reinterpret_cast<bf16*>(imgH + r * PROW + (32 * (q >> 2) + 8 * (q & 3) + 4 * h) * 2), hv[4 * q], hv[4 * q + 1],
+                       hv[4 * q + 2], hv[4 * q + 3]);
+            f32x16 acc[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = zero16();
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w2img, 4, m, sp, lane), acc_op(hv + 16 * (sp >> 1), sp & 1), acc[m], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(lc + 64 + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zz[4 * q + e] = acc[q >> 2][4 * (q & 3) + e] + v[e];
+            }
+        }
+        // ---- upstream gradient d (of y), LayerNorm backward -> dz; d*xhat and d go to images (their column sums are dgamma, dbeta)
+        {
+            float mean = 0.f, rstd = 1.f;
+            if (has_ln) row_stats(zz, a.eps, mean, rstd);
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = (float)cur.dy[q][e] + (float)cur.dyr[q][e];
+                if (has_ln) {
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0);
+                    float dg[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * q + e;
+                        const float xh = (zz[i] - mean) * rstd;
+                        dg[e] = d[e] * xh;
                         const float gq = d[e] * gm[e];
                         m1 += gq;
                         m2 += gq * xh;
                         dz[i] = gq;
-                        t.z[i] = xh;
-                    } else {
-                        dz[i] = d[e];
+                        zz[i] = xh;
                     }
+                    store4(reinterpret_cast<bf16*>(imgDG + r * PROW + c0 * 2), dg[0], dg[1], dg[2], dg[3]);
+                    store4(reinterpret_cast<bf16*>(imgDD + r * PROW + c0 * 2), d[0], d[1], d[2], d[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dz[4 * q + e] = d[e];
                 }
             }
-        if (a.gamma) {
-            m1 += __shfl_xor(m1, 32, 64);
-            m2 += __shfl_xor(m2, 32, 64);
-            m1 *= (1.f / 64.f);
-            m2 *= (1.f / 64.f);
+            if (has_ln) {
+                m1 += __shfl_xor(m1, 32, 64);
+                m2 += __shfl_xor(m2, 32, 64);
+                m1 *= (1.f / 64.f);
+                m2 *= (1.f / 64.f);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) dz[i] = rstd * (dz[i] - m1 - t.z[i] * m2);
+                for (int i = 0; i < 32; ++i) dz[i] = rstd * (dz[i] - m1 - zz[i] * m2);
+            }
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                store4(reinterpret_cast<bf16*>(imgDZ + r * PROW + (32 * m + 8 * g + 4 * h) * 2), dz[m * 16 + 4 * g], dz[m * 16 + 4 * g + 1],
-                       dz[m * 16 + 4 * g + 2], dz[m * 16 + 4 * g + 3]);
-        // dh = W2^T dz, dpre = dh * silu'(pre)
-        float dp[32];
+        for (int q = 0; q < 8; ++q)
+            store4(reinterpret_cast<bf16*>(imgDZ + r * PROW + (32 * (q >> 2) + 8 * (q & 3) + 4 * h) * 2), dz[4 * q], dz[4 * q + 1], dz[4 * q + 2],
+                   dz[4 * q + 3]);
+        // ---- dh = W2^T dz, dpre = dh * silu'(pre)
         {
             f32x16 acc[2];
 #pragma unroll
@@ -380,26 +487,24 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                const float x = t.pre[i], sg = silu_sig(x);
-                dp[i] = acc[i >> 4][i & 15] * (sg * (1.f + x * (1.f - sg)));
+                const float x = pre[i], sg = silu_sig(x);
+                pre[i] = acc[i >> 4][i & 15] * (sg * (1.f + x * (1.f - sg)));   // dpre
             }
         }
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = 32 * m + 8 * g + 4 * h, i = m * 16 + 4 * g;
-                store4(reinterpret_cast<bf16*>(imgDP + r * PROW + c0 * 2), dp[i], dp[i + 1], dp[i + 2], dp[i + 3]);
-                if (a.dpre && live) store4(a.dpre + row * HID + c0, dp[i], dp[i + 1], dp[i + 2], dp[i + 3]);
-            }
-        // dx = W1^T dpre
+        for (int q = 0; q < 8; ++q) {
+            const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h, i = 4 * q;
+            store4(reinterpret_cast<bf16*>(imgDP + r * PROW + c0 * 2), pre[i], pre[i + 1], pre[i + 2], pre[i + 3]);
+            if (a.dpre && live) store4(a.dpre + row * HID + c0, pre[i], pre[i + 1], pre[i + 2], pre[i + 3]);
+        }
+        // ---- dx = W1^T dpre
         if (a.dx) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 f32x16 acc = zero16();
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1timg, 4, kt, sp, lane), acc_op(dp + 16 * (sp >> 1), sp & 1), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1timg, 4, kt, sp, lane), acc_op(pre + 16 * (sp >> 1), sp & 1), acc, 0, 0, 0);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c0 = 32 * kt + 8 * g + 4 * h;
@@ -408,7 +513,7 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             }
         }
         lds_order();
-        // weight gradients: reduction over the tile's 32 rows (2 k-steps), operands by transposed reads of the images
+        // ---- weight gradients: reduction over the tile's 32 rows (2 k-steps), operands by transposed reads of the images
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 adz[2], adp[2], bh[2], bx[NKT];
@@ -432,37 +537,43 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
                 for (int n = 0; n < NKT; ++n) dw1[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adp[m], bx[n], dw1[m][n], 0, 0, 0);
             }
         }
-        // bias gradients: column sums of the dz / dpre images (lane = 16-byte feature chunk lane & 7 of rows (lane >> 3) + 8 it)
+        // ---- bias / LayerNorm-parameter gradients: column sums of the images (lane = 16-byte chunk lane & 7 of rows (lane >> 3) + 8 it)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int rr = (lane >> 3) + 8 * it, c = lane & 7;
-            const bf16x8 vz = *reinterpret_cast<const bf16x8*>(imgDZ + rr * PROW + c * 16);
-            const bf16x8 vp = *reinterpret_cast<const bf16x8*>(imgDP + rr * PROW + c * 16);
+            const int off = ((lane >> 3) + 8 * it) * PROW + (lane & 7) * 16;
+            const bf16x8 vz = *reinterpret_cast<const bf16x8*>(imgDZ + off);
+            const bf16x8 vp = *reinterpret_cast<const bf16x8*>(imgDP + off);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 db2[j] += (float)vz[j];
                 db1[j] += (float)vp[j];
             }
+            if (has_ln) {
+                const bf16x8 vg = *reinterpret_cast<const bf16x8*>(imgDG + off);
+                const bf16x8 vd = *reinterpret_cast<const bf16x8*>(imgDD + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dgam[j] += (float)vg[j];
+                    dbet[j] += (float)vd[j];
+                }
+            }
         }
         lds_order();
+        cur = nxt;
+        if (GATHER) gcur = gnxt;
     }
 
     // ---- per-workgroup partial (the four waves add in wave order through LDS: fixed order), then one global partial per workgroup
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem + 4 * HID * 4 + bwd_weights_bytes<KS>());
     constexpr int OFF_W2 = HID * K, OFF_B1 = OFF_W2 + HID * HID, OFF_B2 = OFF_B1 + HID, OFF_G = OFF_B2 + HID, OFF_BT = OFF_G + HID;
-    // cross-lane sums that are per wave: dgamma / dbeta over the 32 rows-lanes of a half, db1 / db2 over the 8 row groups
-#pragma unroll
-    for (int i = 0; i < 32; ++i)
-        for (int o = 1; o < 32; o <<= 1) {
-            dgam[i] += __shfl_xor(dgam[i], o, 64);
-            dbet[i] += __shfl_xor(dbet[i], o, 64);
-        }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         for (int o = 8; o < 64; o <<= 1) {
             db1[j] += __shfl_xor(db1[j], o, 64);
             db2[j] += __shfl_xor(db2[j], o, 64);
+            dgam[j] += __shfl_xor(dgam[j], o, 64);
+            dbet[j] += __shfl_xor(dbet[j], o, 64);
         }
     for (int turn = 0; turn < 4; ++turn) {
         if (wv == turn) {
@@ -482,16 +593,15 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
                         const int k = 32 * n + r;
                         red[OFF_W2 + o * HID + k] = (first ? 0.f : red[OFF_W2 + o * HID + k]) + dw2[m][n][i];
                     }
-                    if (r == 0) {
-                        red[OFF_G + o] = (first ? 0.f : red[OFF_G + o]) + dgam[m * 16 + i];
-                        red[OFF_BT + o] = (first ? 0.f : red[OFF_BT + o]) + dbet[m * 16 + i];
-                    }
                 }
             if (lane < 8)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    red[OFF_B1 + lane * 8 + j] = (first ? 0.f : red[OFF_B1 + lane * 8 + j]) + db1[j];
-                    red[OFF_B2 + lane * 8 + j] = (first ? 0.f : red[OFF_B2 + lane * 8 + j]) + db2[j];
+                    const int c = lane * 8 + j;
+                    red[OFF_B1 + c] = (first ? 0.f : red[OFF_B1 + c]) + db1[j];
+                    red[OFF_B2 + c] = (first ? 0.f : red[OFF_B2 + c]) + db2[j];
+                    red[OFF_G + c] = (first ? 0.f : red[OFF_G + c]) + dgam[j];
+                    red[OFF_BT + c] = (first ? 0.f : red[OFF_BT + c]) + dbet[j];
                 }
         }
         __syncthreads();
@@ -557,11 +667,15 @@ int launch_bwd(const MlpArgs& a, float* grads, hipStream_t s) {
     static_assert(4 * wave_img_bytes<KS>() >= partial_floats<KS>() * 4, "reduction buffer must fit the waves' images");
     static bool attr_set = false;
     if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)row_mlp_bwd_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)row_mlp_bwd_kernel<KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)row_mlp_bwd_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const int G = mlp_grid(a.R, 1);
-    hipLaunchKernelGGL(row_mlp_bwd_kernel<KS>, dim3(G), dim3(256), smem, s, a);
+    if (a.ga || a.gb)
+        hipLaunchKernelGGL((row_mlp_bwd_kernel<KS, true>), dim3(G), dim3(256), smem, s, a);
+    else
+        hipLaunchKernelGGL((row_mlp_bwd_kernel<KS, false>), dim3(G), dim3(256), smem, s, a);
     P4C_CHECK_LAUNCH("row_mlp_bwd");
     const int n = partial_floats<KS>();
     hipLaunchKernelGGL(mlp_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, grads);

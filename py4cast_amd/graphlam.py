@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops_graph as G
+from . import ops_mlp as M
 from . import ops_rows as R
 from .base import ModelABC, ModelType
 from .graph_build import MeshGraph, build_mesh_graph, graph_path
@@ -76,8 +77,26 @@ def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     return y[:, :O] if op else y
 
 
+def _fusable(mlp: nn.Sequential, x: torch.Tensor) -> bool:
+    """Linear - SiLU - Linear [- LayerNorm] with 64 hidden features on bf16 rows: the fused row-MLP kernel's shape."""
+    n = len(mlp)
+    if n not in (3, 4) or not (isinstance(mlp[0], nn.Linear) and isinstance(mlp[1], nn.SiLU) and isinstance(mlp[2], nn.Linear)):
+        return False
+    if n == 4 and not (isinstance(mlp[3], nn.LayerNorm) and mlp[3].normalized_shape == (64,)):
+        return False
+    return M.supported(x, mlp[0].weight, mlp[2].weight) and x.shape[0] >= 1024
+
+
 def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """An MLP on rows of x's dtype; ``res`` is added to the result (fused into the LayerNorm kernel when the MLP ends in one)."""
+    """An MLP on rows of x's dtype; ``res`` is added to the result.  bf16 rows of the standard shape take ONE fused kernel each way
+    (ops_mlp.row_mlp); other shapes run layer by layer (library GEMMs + the row LayerNorm / weight-gradient kernels)."""
+    if _fusable(mlp, x):
+        ln = mlp[3] if len(mlp) == 4 else None
+        out, out_res = M.row_mlp(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
+                                 None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                 1e-5 if ln is None else ln.eps, res=res, want_out=res is None)
+        y = out if res is None else out_res
+        return y if mlp[2].out_features == 64 else y[:, : mlp[2].out_features]
     for m in mlp:
         if isinstance(m, nn.Linear):
             x = _linear(m, x)
@@ -100,23 +119,31 @@ class InteractionNet(nn.Module):
 
     def forward(self, send_rep, rec_rep, edge_rep, edges: G.EdgeSet):
         C = self.hidden
-        lin0 = self.edge_mlp[0]
-        if edge_rep.dtype == torch.bfloat16:
-            base = R.row_linear(edge_rep, lin0.weight[:, :C], lin0.bias)          # E x C
-            a = R.row_linear(send_rep, lin0.weight[:, C:2 * C])                   # N_s x C
-            b = R.row_linear(rec_rep, lin0.weight[:, 2 * C:])                     # N_r x C
+        lin0, lin1, ln = self.edge_mlp[0], self.edge_mlp[2], self.edge_mlp[3]
+        if edge_rep.dtype == torch.bfloat16 and C == 64 and edge_rep.shape[0] >= 1024:
+            # sender / receiver parts of the first Linear once per NODE (small library GEMMs), everything per EDGE in one kernel:
+            # e W_e + a[src] + b[dst] + bias -> SiLU -> Linear -> LayerNorm -> msg (and edge_rep + msg)
+            a = R.row_linear(send_rep, lin0.weight[:, C:2 * C])
+            b = R.row_linear(rec_rep, lin0.weight[:, 2 * C:])
+            msg, new_edge = M.row_mlp(edge_rep, lin0.weight[:, :C], lin0.bias, lin1.weight, lin1.bias, ln.weight, ln.bias, ln.eps,
+                                      ga=a, gb=b, edges=edges, res=edge_rep if self.update_edges else None)
         else:
-            base = F.linear(edge_rep, lin0.weight[:, :C], lin0.bias)
-            a = F.linear(send_rep, lin0.weight[:, C:2 * C])
-            b = F.linear(rec_rep, lin0.weight[:, 2 * C:])
-        h = G.edge_gather_add(base, a, b, edges, "silu")                           # first Linear + SiLU of the edge MLP
-        msg = _run(self.edge_mlp[2:], h)
+            if edge_rep.dtype == torch.bfloat16:
+                base = R.row_linear(edge_rep, lin0.weight[:, :C], lin0.bias)          # E x C
+                a = R.row_linear(send_rep, lin0.weight[:, C:2 * C])                   # N_s x C
+                b = R.row_linear(rec_rep, lin0.weight[:, 2 * C:])                     # N_r x C
+            else:
+                base = F.linear(edge_rep, lin0.weight[:, :C], lin0.bias)
+                a = F.linear(send_rep, lin0.weight[:, C:2 * C])
+                b = F.linear(rec_rep, lin0.weight[:, 2 * C:])
+            h = G.edge_gather_add(base, a, b, edges, "silu")                           # first Linear + SiLU of the edge MLP
+            msg = _run(self.edge_mlp[2:], h)
+            new_edge = edge_rep + msg if self.update_edges else None
         agg = G.aggregate_sum(msg, edges)
         rec_rep = _run(self.aggr_mlp, torch.cat([rec_rep, agg], dim=-1), res=rec_rep)
         if self.update_edges:
-            return rec_rep, edge_rep + msg
+            return rec_rep, new_edge
         return rec_rep
-
 
 class GraphLamMI355X(ModelABC, nn.Module):
     settings_kls = GraphLamSettings
@@ -159,7 +186,8 @@ class GraphLamMI355X(ModelABC, nn.Module):
         self.m2g_gnn = InteractionNet(h, L_, update_edges=False)
         self.output_map = make_mlp(bp + [out_channels], layer_norm=False)
         self.timed_entry_points = ("p4c_edge_gather_add_fwd", "p4c_edge_gather_add_bwd", "p4c_segment_sum",
-                                   "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd", "p4c_row_linear_wgrad")
+                                   "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd", "p4c_row_linear_wgrad",
+                                   "p4c_row_mlp_fwd", "p4c_row_mlp_bwd")
         self.roofline_from_entry_points = True   # bench.py: time every call of the entry points above
         self.check_required_attributes()
 
