@@ -214,7 +214,7 @@ __device__ __forceinline__ void row_stats(const float* z, float eps, float& mean
 constexpr int fwd_lds_bytes(int KS) { return 4 * HID * 4 + (2 * KS + 8) * 1024; }
 
 template <int KS>
-__global__ void __launch_bounds__(256, 2) row_mlp_fwd_kernel(MlpArgs a) {
+__global__ void __launch_bounds__(256, 4) row_mlp_fwd_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lc = reinterpret_cast<float*>(smem);
     bf16* w1img = reinterpret_cast<bf16*>(smem + 4 * HID * 4);
@@ -657,7 +657,7 @@ int check_args(const char* name, const MlpArgs& a, int K) {
 template <int KS>
 int launch_fwd(const MlpArgs& a, hipStream_t s) {
     constexpr int smem = fwd_lds_bytes(KS);
-    hipLaunchKernelGGL(row_mlp_fwd_kernel<KS>, dim3(mlp_grid(a.R, 4)), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(row_mlp_fwd_kernel<KS>, dim3(mlp_grid(a.R, 8)), dim3(256), smem, s, a);
     P4C_CHECK_LAUNCH("row_mlp_fwd");
     return P4C_OK;
 }

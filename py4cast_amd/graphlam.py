@@ -172,6 +172,7 @@ class GraphLamMI355X(ModelABC, nn.Module):
             self.register_buffer(f"{k}_features", getattr(graph, f"{k}_feat"), persistent=False)
         self.register_buffer("mesh_static_features", graph.mesh_pos, persistent=False)
         self._edge_cache: Dict[tuple, Dict[str, G.EdgeSet]] = {}
+        self._static_cache = None
 
         h, L_ = settings.hidden_dims, settings.hidden_layers
         bp = [h] * (L_ + 1)
@@ -217,16 +218,33 @@ class GraphLamMI355X(ModelABC, nn.Module):
             self._edge_cache[key] = sets
         return self._edge_cache[key]
 
+    def _static_embeddings(self, B: int, dt: torch.dtype):
+        """Embeddings of the graph's static edge / mesh-node features.  They depend on the parameters only, so the AR steps of one
+        rollout (the model is called once per step, py4cast/lightning.py:591-596) share them: computed once per parameter version
+        (and autograd mode), their autograd graph is walked once by the rollout's backward, which sums the steps' gradients."""
+        embedders = (self.g2m_embedder, self.m2g_embedder, self.m2m_embedder, self.mesh_embedder)
+        key = (B, dt, torch.is_grad_enabled(), tuple(p._version for e in embedders for p in e.parameters()),
+               tuple(p.data_ptr() for e in embedders for p in e.parameters()))
+        if self._static_cache is None or self._static_cache[0] != key:
+            rep = lambda t: t.unsqueeze(0).expand(B, *t.shape).reshape(B * t.shape[0], t.shape[1])  # noqa: E731
+            feats = (self.g2m_features, self.m2g_features, self.m2m_features, self.mesh_static_features)
+            embs = tuple(rep(_run(e, f.to(dt))) for e, f in zip(embedders, feats))
+            self._static_cache = (key, embs)
+            for t in embs:          # a backward pass consumes their graph: the next forward must rebuild it (gradient accumulation)
+                if t.requires_grad:
+                    t.register_hook(self._drop_static_cache)
+        return self._static_cache[1]
+
+    def _drop_static_cache(self, grad):
+        self._static_cache = None
+        return None
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, N, _ = x.shape
         dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
         es = self._edges(B, x.device)
-        rep = lambda t: t.unsqueeze(0).expand(B, *t.shape).reshape(B * t.shape[0], t.shape[1])  # noqa: E731
         grid = _run(self.grid_embedder, x.reshape(B * N, -1).to(dt))
-        g2m_e = rep(_run(self.g2m_embedder, self.g2m_features.to(dt)))
-        m2g_e = rep(_run(self.m2g_embedder, self.m2g_features.to(dt)))
-        m2m_e = rep(_run(self.m2m_embedder, self.m2m_features.to(dt)))
-        mesh = rep(_run(self.mesh_embedder, self.mesh_static_features.to(dt)))
+        g2m_e, m2g_e, m2m_e, mesh = self._static_embeddings(B, dt)
         mesh = self.g2m_gnn(grid, mesh, g2m_e, es["g2m"])
         grid = _run(self.encoding_grid_mlp, grid, res=grid)
         for layer in self.processor:

@@ -545,3 +545,29 @@ def test_row_mlp_fused(gpu_device, K, O, ln, gather, with_res, R):
         assert _rel(gg.grad.cpu(), gr.grad) < tol and _rel(bg.grad.cpu(), br.grad) < tol
     if gather:
         assert _rel(gag.grad.float().cpu(), gar.grad) < tol and _rel(gbg.grad.float().cpu(), gbr.grad) < tol
+
+
+def test_graphlam_static_embedding_cache(gpu_device, tmp_path):
+    """The static-feature embeddings are shared by the AR steps of a rollout: several forwards + ONE backward must give the same
+    gradients as without sharing, and a second forward/backward round (gradient accumulation, same parameters) must work."""
+    model, _ = _graphlam_pair(tmp_path, 27, 27, 7, 3, dtype="bf16")
+    model = model.to(gpu_device)
+    torch.manual_seed(81)
+    xs = [torch.randn(2, 27 * 27, 7, device=gpu_device) for _ in range(3)]
+
+    def run(share):
+        model.zero_grad()
+        total = 0
+        for x in xs:
+            if not share:
+                model._static_cache = None
+            total = total + model(x).square().mean()
+        total.backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    shared, separate = run(True), run(False)
+    for a, b in zip(shared, separate):
+        assert _rel(a, b) < 2e-2        # bf16 rounding of the summed vs separately propagated gradients
+    again = run(True)                   # the first backward consumed the cached graph: must have been rebuilt
+    for a, b in zip(again, shared):
+        assert torch.equal(a, b)
