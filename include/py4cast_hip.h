@@ -408,7 +408,7 @@ typedef struct p4c_row_mlp_desc {
     const float* beta;
     float eps;
     const void* gather_a;    /* (n_a, 64) bf16 or NULL */
-    const int32_t* index_a;  /* (rows) */
+    const int32_t* index_a;  /* (rows), or NULL with gather_a set: row-aligned addend gather_a[r] */
     const void* gather_b;
     const int32_t* index_b;
     const void* res;         /* (rows, 64) bf16 or NULL */

@@ -161,8 +161,8 @@ __device__ __forceinline__ void tile_forward(Tile<KS>& t, const MlpArgs& a, cons
         for (int s = 0; s < KS; ++s) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1img, KS, m, s, lane), t.xop[s], acc[m], 0, 0, 0);
     }
     int ja = 0, jb = 0;
-    if (a.ga && live) ja = a.ia[row];
-    if (a.gb && live) jb = a.ib[row];
+    if (a.ga && live) ja = a.ia ? a.ia[row] : (int)row;   // no index list: the addend is row-aligned
+    if (a.gb && live) jb = a.ib ? a.ib[row] : (int)row;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -348,8 +348,8 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
         const bool live = tile < ntiles && row < a.R;
         ja = jb = 0;
         if (GATHER) {
-            if (a.ga) ja = a.ia[live ? row : 0];
-            if (a.gb) jb = a.ib[live ? row : 0];
+            if (a.ga) ja = a.ia ? a.ia[live ? row : 0] : (int)(live ? row : 0);
+            if (a.gb) jb = a.ib ? a.ib[live ? row : 0] : (int)(live ? row : 0);
         }
     };
     auto load_gather = [&](TileGather& g, int ja, int jb) __attribute__((always_inline)) {
@@ -649,7 +649,8 @@ int check_args(const char* name, const MlpArgs& a, int K) {
     P4C_CHECK_ARG(a.x && a.w1 && a.w2, "%s: NULL pointer", name);
     P4C_CHECK_ARG(a.Kreal > 0 && a.Kreal <= K && a.ldw1 >= a.Kreal, "%s: bad first-layer weight shape", name);
     P4C_CHECK_ARG(a.Oreal > 0 && a.Oreal <= HID, "%s: bad output feature count %d", name, a.Oreal);
-    P4C_CHECK_ARG((a.ga == nullptr) == (a.ia == nullptr) && (a.gb == nullptr) == (a.ib == nullptr), "%s: ga/ia, gb/ib go together", name);
+    P4C_CHECK_ARG((a.ga != nullptr || a.ia == nullptr) && (a.gb != nullptr || a.ib == nullptr), "%s: an index list needs its rows", name);
+    P4C_CHECK_ARG(a.R < (int64_t)1 << 31, "%s: too many rows", name);
     P4C_CHECK_ARG((a.gamma == nullptr) == (a.beta == nullptr), "%s: gamma and beta go together", name);
     return P4C_OK;
 }

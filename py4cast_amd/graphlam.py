@@ -140,7 +140,14 @@ class InteractionNet(nn.Module):
             msg = _run(self.edge_mlp[2:], h)
             new_edge = edge_rep + msg if self.update_edges else None
         agg = G.aggregate_sum(msg, edges)
-        rec_rep = _run(self.aggr_mlp, torch.cat([rec_rep, agg], dim=-1), res=rec_rep)
+        al0, al1, aln = self.aggr_mlp[0], self.aggr_mlp[2], self.aggr_mlp[3]
+        if rec_rep.dtype == torch.bfloat16 and C == 64 and rec_rep.shape[0] >= 1024:
+            # Linear over cat[x_r, agg] = x_r W[:, :C]^T (small library GEMM, row-aligned addend) + agg W[:, C:]^T (fused kernel's x)
+            part = R.row_linear(rec_rep, al0.weight[:, :C])
+            _, rec_rep = M.row_mlp(agg, al0.weight[:, C:], al0.bias, al1.weight, al1.bias, aln.weight, aln.bias, aln.eps,
+                                   ga=part, res=rec_rep, want_out=False)
+        else:
+            rec_rep = _run(self.aggr_mlp, torch.cat([rec_rep, agg], dim=-1), res=rec_rep)
         if self.update_edges:
             return rec_rep, new_edge
         return rec_rep

@@ -46,8 +46,10 @@ class _RowMLP(torch.autograd.Function):
         resc = None if res is None else res.contiguous()
         out = torch.empty(R, 64, dtype=x.dtype, device=x.device) if want_out else None
         out_res = torch.empty(R, 64, dtype=x.dtype, device=x.device) if res is not None else None
-        ia = edges.src if ga is not None else None
-        ib = edges.dst if gb is not None else None
+        ia = edges.src if (ga is not None and edges is not None) else None   # no edge set: ga is a row-aligned addend
+        ib = edges.dst if (gb is not None and edges is not None) else None
+        if edges is None and any(t is not None and t.shape[0] != R for t in (gac, gbc)):
+            raise L.P4CError("row_mlp: without an edge set the addends must have one row per row of x")
         d = _desc(x, K, w1.detach(), b1c, w2c.detach(), b2c, gc, bc, eps, gac, ia, gbc, ib, resc, out, out_res)
         rows_io = 1 + (out is not None) + 2 * (out_res is not None)
         gathered = sum(min(R, t.shape[0]) for t in (gac, gbc) if t is not None)
@@ -77,8 +79,8 @@ class _RowMLP(torch.autograd.Function):
         dpre = torch.empty(R, 64, dtype=x.dtype, device=x.device) if gathered else None
         grads = torch.empty(64 * K + 64 * 64 + 4 * 64, dtype=torch.float32, device=x.device)
         ws = torch.empty(max(L.lib().p4c_row_mlp_bwd_workspace_bytes(R, K) // 4, 1), dtype=torch.float32, device=x.device)
-        ia = edges.src if ga is not None else None
-        ib = edges.dst if gb is not None else None
+        ia = edges.src if (ga is not None and edges is not None) else None
+        ib = edges.dst if (gb is not None and edges is not None) else None
         d = _desc(x, K, w1.detach(), b1, w2, b2, gamma, beta, ctx.eps, ga, ia, gb, ib, None, None, None, dy, dyr, dx, dpre)
         rows_io = 1 + (dy is not None) + (dyr is not None) + need_dx * K / 64 + gathered
         n_gath = sum(min(R, t.shape[0]) for t in (ga, gb) if t is not None)
@@ -92,8 +94,12 @@ class _RowMLP(torch.autograd.Function):
         db2 = grads[base + 64: base + 64 + o] if has_b2 else None
         dgam = grads[base + 128: base + 192] if has_ln else None
         dbet = grads[base + 192: base + 256] if has_ln else None
-        dga = _segment_sum_raw(dpre, *edges.by_src, edges.n_src) if (ga is not None and ctx.needs_input_grad[7]) else None
-        dgb = _segment_sum_raw(dpre, *edges.by_dst, edges.n_dst) if (gb is not None and ctx.needs_input_grad[8]) else None
+        if edges is None:   # row-aligned addends: their gradient is the pre-activation gradient itself
+            dga = dpre if (ga is not None and ctx.needs_input_grad[7]) else None
+            dgb = dpre if (gb is not None and ctx.needs_input_grad[8]) else None
+        else:
+            dga = _segment_sum_raw(dpre, *edges.by_src, edges.n_src) if (ga is not None and ctx.needs_input_grad[7]) else None
+            dgb = _segment_sum_raw(dpre, *edges.by_dst, edges.n_dst) if (gb is not None and ctx.needs_input_grad[8]) else None
         dres = dyr if has_res else None
         return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None
 
@@ -102,7 +108,8 @@ def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=N
             ga: Optional[torch.Tensor] = None, gb: Optional[torch.Tensor] = None, edges: Optional[EdgeSet] = None,
             res: Optional[torch.Tensor] = None, want_out: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
     """Returns (y, y + res); x (R, K) bf16 with K <= 80 (padded to a multiple of 16 here), w1 (64, K), w2 (O <= 64, 64).
-    ga / gb: (n_src, 64) / (n_dst, 64) rows added to the pre-activation through edges.src / edges.dst."""
+    ga / gb: (n_src, 64) / (n_dst, 64) rows added to the pre-activation through edges.src / edges.dst; with ``edges=None`` they
+    are row-aligned addends (R, 64) -- e.g. the other half of a Linear over a concatenation of two 64-feature sources."""
     L.require_cuda(x)
     kp = (-x.shape[1]) % 16
     if kp:

@@ -571,3 +571,33 @@ def test_graphlam_static_embedding_cache(gpu_device, tmp_path):
     again = run(True)                   # the first backward consumed the cached graph: must have been rebuilt
     for a, b in zip(again, shared):
         assert torch.equal(a, b)
+
+
+def test_row_mlp_row_aligned_addend(gpu_device):
+    """Linear over cat[a, b] = a W_a^T (addend, one row per row) + b W_b^T (the fused kernel's input): node-update MLP of an
+    InteractionNet without materialising the concatenation."""
+    from py4cast_amd.ops_mlp import row_mlp
+
+    torch.manual_seed(91)
+    bf = torch.bfloat16
+    R = 3001
+    x, add, res = torch.randn(R, 64).to(bf), torch.randn(R, 64).to(bf), torch.randn(R, 64).to(bf)
+    w1, b1, w2, b2 = torch.randn(64, 64) * 0.12, torch.randn(64) * 0.1, torch.randn(64, 64) * 0.2, torch.randn(64) * 0.1
+    gamma, beta = torch.rand(64) + 0.5, torch.randn(64) * 0.1
+    dyr = torch.randn(R, 64).to(bf)
+    dev = lambda t: t.to(gpu_device).requires_grad_(True)  # noqa: E731
+    xg, ag, rg, w1g, b1g, w2g, b2g, gg, bg = (dev(t) for t in (x, add, res, w1, b1, w2, b2, gamma, beta))
+    out, out_res = row_mlp(xg, w1g, b1g, w2g, b2g, gg, bg, 1e-5, ga=ag, res=rg, want_out=False)
+    assert out is None
+    (out_res.float() * dyr.to(gpu_device).float()).sum().backward()
+    rd = lambda t: t.double().requires_grad_(True)  # noqa: E731
+    xr, ar, rr = rd(x), rd(add), rd(res)
+    w1r, w2r = w1.to(bf).double().requires_grad_(True), w2.to(bf).double().requires_grad_(True)
+    pre = torch.nn.functional.linear(xr, w1r, b1.double()) + ar
+    y = torch.nn.functional.layer_norm(torch.nn.functional.linear(torch.nn.functional.silu(pre), w2r, b2.double()), (64,),
+                                       gamma.double(), beta.double(), 1e-5) + rr
+    (y * dyr.double()).sum().backward()
+    assert _rel(out_res.detach().float().cpu(), y.detach()) < 1.5e-2
+    for got, ref in ((xg, xr), (ag, ar), (w1g, w1r), (w2g, w2r)):
+        assert _rel(got.grad.float().cpu(), ref.grad) < 3e-2
+    assert torch.equal(rg.grad.cpu(), dyr)
