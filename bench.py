@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--features", type=int, default=60)
     ap.add_argument("--pred-steps", type=int, default=3)
     ap.add_argument("--border", type=int, default=0)
+    ap.add_argument("--hip-graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the micro-batch (rollout + loss + backward) from a HIP graph; auto: only for models that ask for it "
+                         "(launch-bound small-kernel models); the roofline object is then measured in eager steps before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
@@ -233,10 +236,15 @@ def main():
     opt = lm.configure_optimizers()["optimizer"]
 
     micro = [0]
+    use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and getattr(lm.model, "prefers_hip_graph", False))
+    graphed = [None]
 
     def step(i):
-        loss = lm.training_step(make_batch(case), i)
-        (loss / args.accumulate if args.accumulate > 1 else loss).backward()
+        if graphed[0] is not None:
+            loss = graphed[0](make_batch(case))
+        else:
+            loss = lm.training_step(make_batch(case), i)
+            (loss / args.accumulate if args.accumulate > 1 else loss).backward()
         micro[0] += 1
         if micro[0] % args.accumulate == 0:   # non-stepping micro-batches neither sync nor step (trainer.yaml:58)
             ddp.all_reduce_grads()
@@ -266,14 +274,32 @@ def main():
         L.lib().p4c_prof_enable(1, args.steps * T * 4 + 16)
         L.lib().p4c_prof_filter(B * H * W)
     barrier()
+    roof_model = None
+    if use_graph:
+        # kernel timings for the roofline object come from two eager steps (a replayed graph has no per-call host hooks);
+        # then the micro-batch is captured and the warm-up + timed steps replay it
+        from py4cast_amd.trainer import GraphedTrainingStep
+
+        for i in range(2):
+            step(args.warmup + i)
+        ktimes = L.kernel_times()
+        roof_model = lm.model.roofline(ktimes, B=B, H=H, W=W) if (rank == 0 and hasattr(lm.model, "roofline")) else None
+        L.enable_kernel_timing(None)
+        ddp.zero_grad()
+        graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
+        ddp.zero_grad()
+        for i in range(args.warmup):
+            step(i)
+        barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    ktimes = L.kernel_times()
-    roof_model = lm.model.roofline(ktimes, B=B, H=H, W=W) if (rank == 0 and hasattr(lm.model, "roofline")) else None
-    L.enable_kernel_timing(None)
+    if not use_graph:
+        ktimes = L.kernel_times()
+        roof_model = lm.model.roofline(ktimes, B=B, H=H, W=W) if (rank == 0 and hasattr(lm.model, "roofline")) else None
+        L.enable_kernel_timing(None)
     L.lib().p4c_prof_enable(0, 0)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -321,6 +347,7 @@ def main():
                 "border_size": args.border,
                 "setup_steps": args.setup_steps,
                 "accumulate_grad_batches": args.accumulate,
+                "hip_graph": bool(use_graph),
             },
             "loss": float(loss.detach()),
             "roofline": roof,

@@ -84,7 +84,7 @@ def _fusable(mlp: nn.Sequential, x: torch.Tensor) -> bool:
         return False
     if n == 4 and not (isinstance(mlp[3], nn.LayerNorm) and mlp[3].normalized_shape == (64,)):
         return False
-    return M.supported(x, mlp[0].weight, mlp[2].weight) and x.shape[0] >= 1024
+    return M.supported(x, mlp[0].weight, mlp[2].weight) and x.shape[0] >= 1
 
 
 def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -108,6 +108,28 @@ def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None
     return x if res is None else x + res
 
 
+def cached_static_embeddings(model: nn.Module, embedders, feats, B: int, dt: torch.dtype):
+    """Embeddings of the graph's static edge / mesh-node features, batch-expanded.  They depend on the parameters only, so the AR
+    steps of one rollout (the model is called once per step, py4cast/lightning.py:591-596) share them: computed once per parameter
+    version (and autograd mode); their autograd graph is walked once by the rollout's backward, which sums the steps' gradients,
+    and is rebuilt by the next forward (gradient accumulation over micro-batches with unchanged parameters)."""
+    key = (B, dt, torch.is_grad_enabled(), tuple(p._version for e in embedders for p in e.parameters()),
+           tuple(p.data_ptr() for e in embedders for p in e.parameters()))
+    cache = getattr(model, "_static_cache", None)
+    if cache is None or cache[0] != key:
+        rep = lambda t: t.unsqueeze(0).expand(B, *t.shape).reshape(B * t.shape[0], t.shape[1])  # noqa: E731
+        embs = tuple(rep(_run(e, f.to(dt))) for e, f in zip(embedders, feats))
+        model._static_cache = (key, embs)
+
+        def drop(grad):
+            model._static_cache = None
+
+        for t in embs:
+            if t.requires_grad:
+                t.register_hook(drop)
+    return model._static_cache[1]
+
+
 class InteractionNet(nn.Module):
     """neural-lam's InteractionNet; parameter layout identical to the concat formulation (edge_mlp.0.weight is (C, 3C))."""
 
@@ -120,7 +142,7 @@ class InteractionNet(nn.Module):
     def forward(self, send_rep, rec_rep, edge_rep, edges: G.EdgeSet):
         C = self.hidden
         lin0, lin1, ln = self.edge_mlp[0], self.edge_mlp[2], self.edge_mlp[3]
-        if edge_rep.dtype == torch.bfloat16 and C == 64 and edge_rep.shape[0] >= 1024:
+        if edge_rep.dtype == torch.bfloat16 and C == 64 and edge_rep.shape[0] >= 1:
             # sender / receiver parts of the first Linear once per NODE (small library GEMMs), everything per EDGE in one kernel:
             # e W_e + a[src] + b[dst] + bias -> SiLU -> Linear -> LayerNorm -> msg (and edge_rep + msg)
             a = R.row_linear(send_rep, lin0.weight[:, C:2 * C])
@@ -141,7 +163,7 @@ class InteractionNet(nn.Module):
             new_edge = edge_rep + msg if self.update_edges else None
         agg = G.aggregate_sum(msg, edges)
         al0, al1, aln = self.aggr_mlp[0], self.aggr_mlp[2], self.aggr_mlp[3]
-        if rec_rep.dtype == torch.bfloat16 and C == 64 and rec_rep.shape[0] >= 1024:
+        if rec_rep.dtype == torch.bfloat16 and C == 64 and rec_rep.shape[0] >= 1:
             # Linear over cat[x_r, agg] = x_r W[:, :C]^T (small library GEMM, row-aligned addend) + agg W[:, C:]^T (fused kernel's x)
             part = R.row_linear(rec_rep, al0.weight[:, :C])
             _, rec_rep = M.row_mlp(agg, al0.weight[:, C:], al0.bias, al1.weight, al1.bias, aln.weight, aln.bias, aln.eps,
@@ -197,6 +219,7 @@ class GraphLamMI355X(ModelABC, nn.Module):
                                    "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd", "p4c_row_linear_wgrad",
                                    "p4c_row_mlp_fwd", "p4c_row_mlp_bwd")
         self.roofline_from_entry_points = True   # bench.py: time every call of the entry points above
+        self.prefers_hip_graph = True            # ~10^3 launches per training step: replay them from a HIP graph (trainer.GraphedTrainingStep)
         self.check_required_attributes()
 
     @property
@@ -226,25 +249,9 @@ class GraphLamMI355X(ModelABC, nn.Module):
         return self._edge_cache[key]
 
     def _static_embeddings(self, B: int, dt: torch.dtype):
-        """Embeddings of the graph's static edge / mesh-node features.  They depend on the parameters only, so the AR steps of one
-        rollout (the model is called once per step, py4cast/lightning.py:591-596) share them: computed once per parameter version
-        (and autograd mode), their autograd graph is walked once by the rollout's backward, which sums the steps' gradients."""
         embedders = (self.g2m_embedder, self.m2g_embedder, self.m2m_embedder, self.mesh_embedder)
-        key = (B, dt, torch.is_grad_enabled(), tuple(p._version for e in embedders for p in e.parameters()),
-               tuple(p.data_ptr() for e in embedders for p in e.parameters()))
-        if self._static_cache is None or self._static_cache[0] != key:
-            rep = lambda t: t.unsqueeze(0).expand(B, *t.shape).reshape(B * t.shape[0], t.shape[1])  # noqa: E731
-            feats = (self.g2m_features, self.m2g_features, self.m2m_features, self.mesh_static_features)
-            embs = tuple(rep(_run(e, f.to(dt))) for e, f in zip(embedders, feats))
-            self._static_cache = (key, embs)
-            for t in embs:          # a backward pass consumes their graph: the next forward must rebuild it (gradient accumulation)
-                if t.requires_grad:
-                    t.register_hook(self._drop_static_cache)
-        return self._static_cache[1]
-
-    def _drop_static_cache(self, grad):
-        self._static_cache = None
-        return None
+        feats = (self.g2m_features, self.m2g_features, self.m2m_features, self.mesh_static_features)
+        return cached_static_embeddings(self, embedders, feats, B, dt)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, N, _ = x.shape

@@ -17,7 +17,7 @@ from torch import nn
 from . import ops_graph as G
 from .base import ModelABC, ModelType
 from .graph_build import HiMeshGraph, build_hierarchical_graph, hi_graph_path
-from .graphlam import InteractionNet, _run, make_mlp
+from .graphlam import GraphLamMI355X, InteractionNet, _run, cached_static_embeddings, make_mlp
 
 try:
     from dataclasses_json import dataclass_json
@@ -75,6 +75,7 @@ class HiLamMI355X(ModelABC, nn.Module):
                 reg(f"{k}_index_{l}", getattr(g, k)[l])
                 reg(f"{k}_features_{l}", getattr(g, f"{k}_feat")[l])
         self._edge_cache: Dict[tuple, Dict[str, G.EdgeSet]] = {}
+        self._static_cache = None
 
         h, hl, P = settings.hidden_dims, settings.hidden_layers, settings.processor_layers
         bp = [h] * (hl + 1)
@@ -95,11 +96,17 @@ class HiLamMI355X(ModelABC, nn.Module):
         self.mesh_up_same_gnns = nn.ModuleList([gnns(Lv) for _ in range(P)])
         self.m2g_gnn = InteractionNet(h, hl, update_edges=False)
         self.output_map = make_mlp(bp + [out_channels], layer_norm=False)
+        self.timed_entry_points = ("p4c_edge_gather_add_fwd", "p4c_edge_gather_add_bwd", "p4c_segment_sum", "p4c_row_layernorm_fwd",
+                                   "p4c_row_layernorm_bwd", "p4c_row_linear_wgrad", "p4c_row_mlp_fwd", "p4c_row_mlp_bwd")
+        self.roofline_from_entry_points = True
+        self.prefers_hip_graph = True   # ~10^4 launches per training step: host-bound when launched eagerly (trainer.GraphedTrainingStep)
         self.check_required_attributes()
 
     @property
     def settings(self) -> HiLamSettings:
         return self._settings
+
+    roofline = GraphLamMI355X.roofline   # bench.py hook: same entry points, same bookkeeping
 
     @classmethod
     def rank_zero_setup(cls, settings: HiLamSettings, meshgrid: torch.Tensor):
@@ -131,14 +138,17 @@ class HiLamMI355X(ModelABC, nn.Module):
         B, N, _ = x.shape
         dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
         es, Lv = self._edges(B, x.device), self.num_levels
-        rep = lambda t: t.unsqueeze(0).expand(B, *t.shape).reshape(B * t.shape[0], t.shape[1])  # noqa: E731
-        emb = lambda mlp, name: rep(_run(mlp, getattr(self, name).to(dt)))  # noqa: E731
         grid = _run(self.grid_embedder, x.reshape(B * N, -1).to(dt))
-        g2m_e, m2g_e = emb(self.g2m_embedder, "g2m_features"), emb(self.m2g_embedder, "m2g_features")
-        levels: List[torch.Tensor] = [emb(self.mesh_embedders[l], f"mesh_pos_{l}") for l in range(Lv)]
-        same_e = [emb(self.mesh_same_embedders[l], f"same_features_{l}") for l in range(Lv)]
-        up_e = [emb(self.mesh_up_embedders[l], f"up_features_{l}") for l in range(Lv - 1)]
-        down_e = [emb(self.mesh_down_embedders[l], f"down_features_{l}") for l in range(Lv - 1)]
+        embedders = [self.g2m_embedder, self.m2g_embedder] + list(self.mesh_embedders) + list(self.mesh_same_embedders) \
+            + list(self.mesh_up_embedders) + list(self.mesh_down_embedders)
+        names = ["g2m_features", "m2g_features"] + [f"mesh_pos_{l}" for l in range(Lv)] + [f"same_features_{l}" for l in range(Lv)] \
+            + [f"up_features_{l}" for l in range(Lv - 1)] + [f"down_features_{l}" for l in range(Lv - 1)]
+        embs = list(cached_static_embeddings(self, embedders, [getattr(self, n) for n in names], B, dt))
+        g2m_e, m2g_e = embs[0], embs[1]
+        levels: List[torch.Tensor] = embs[2:2 + Lv]
+        same_e = embs[2 + Lv:2 + 2 * Lv]
+        up_e = embs[2 + 2 * Lv:2 + 2 * Lv + (Lv - 1)]
+        down_e = embs[2 + 2 * Lv + (Lv - 1):]
 
         levels[0] = self.g2m_gnn(grid, levels[0], g2m_e, es["g2m"])
         grid = _run(self.encoding_grid_mlp, grid, res=grid)

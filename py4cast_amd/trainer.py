@@ -90,6 +90,65 @@ class FlatDDP:
             off += n
 
 
+class GraphedTrainingStep:
+    """One micro-batch -- ``training_step`` (rollout + loss) and its ``backward`` -- captured in a HIP graph and replayed.
+
+    The eager step of a small-kernel model is bound by the host, not the GPU: a hierarchical GNN issues ~10^4 launches per step
+    from Python (HiLAM at 512x512: 164 ms eager per step for ~30 ms of kernels).  Every entry point of the C ABI only enqueues on
+    the caller's stream and takes its work-spaces from the caller, so a whole step is capturable; replaying it costs one launch.
+    Inputs live in static tensors (a replay copies the new batch in), gradients accumulate into the parameters' existing ``.grad``
+    buffers (FlatDDP's flat bucket), so ``all_reduce_grads`` / ``optimizer.step`` / ``zero_grad`` run outside the graph as usual.
+    Shapes must not change between steps; a module whose step synchronises with the host cannot be captured (the constructor
+    raises, nothing is left half-captured)."""
+
+    def __init__(self, module, sample_batch, loss_scale: float = 1.0, warmup: int = 3):
+        from .base import ItemBatch
+        from .namedtensor import NamedTensor
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedTrainingStep needs a GPU")
+        self.module = module
+        self._static = {}
+        for name in ("inputs", "forcing", "outputs"):
+            nt = getattr(sample_batch, name)
+            self._static[name] = (nt.tensor.clone(), list(nt.names), list(nt.feature_names))
+
+        def fresh():   # graph models flatten the batch's NamedTensors in place (lightning.py:526-535): new wrappers every call
+            return ItemBatch(*[NamedTensor(t, list(n), list(f)) for t, n, f in (self._static[k] for k in ("inputs", "forcing", "outputs"))])
+
+        def run(idx):
+            loss = module.training_step(fresh(), idx)
+            (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+            return loss.detach()
+
+        # NOTE for callers: no tensor of an earlier EAGER step of this module may still be referenced here (typically its loss):
+        # it keeps that step's AccumulateGrad nodes alive, they are bound to the stream they were created on (the default stream),
+        # and autograd would make that stream wait on the capturing one -- which breaks the capture (observed: a crash in the HIP
+        # runtime).  Keep `loss.detach()` / `float(loss)` instead, as `AutoRegressiveLightning.training_step_losses` does.
+        import gc
+
+        gc.collect()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup):      # lazy initialisation (edge sets, kernel attributes, allocator pools) happens here
+                run(i)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = run(warmup)
+        self.warmup_backwards = warmup + 1   # gradient contributions already accumulated by construction: zero_grad() after
+
+    def __call__(self, batch):
+        for name in ("inputs", "forcing", "outputs"):
+            src = getattr(batch, name).tensor
+            dst = self._static[name][0]
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        self.graph.replay()
+        return self.loss
+
+
 class _Logger:
     log_dir = None
 
@@ -100,13 +159,14 @@ class Trainer:
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, accumulate_grad_batches: int = 1,
                  precision: str = "32-true", limit_train_batches: Optional[int] = None,
                  limit_val_batches: Optional[int] = None, device: Optional[torch.device] = None,
-                 fast_dev_run: bool = False):
+                 fast_dev_run: bool = False, hip_graph: Optional[bool] = None):
         self.max_epochs, self.max_steps = (1, 1) if fast_dev_run else (max_epochs, max_steps)
         self.accumulate_grad_batches = accumulate_grad_batches
         self.precision = {"32": "32-true", 32: "32-true", "bf16": "bf16-true"}.get(precision, precision)
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
         self.device = device or (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
         self.logger = _Logger()
+        self.hip_graph = hip_graph   # None: follow the model's `prefers_hip_graph`; True / False: force
         self.global_step = 0
         self.estimated_stepping_batches = 1000
         self.callback_metrics = {}
@@ -138,13 +198,26 @@ class Trainer:
             module.on_train_start()
         ddp.zero_grad()
         done = False
+        use_graph = self.device.type == "cuda" and (self.hip_graph if self.hip_graph is not None
+                                                    else getattr(getattr(module, "model", None), "prefers_hip_graph", False))
+        graphed = None
         for epoch in range(self.max_epochs):
             module.train()
             for i, batch in enumerate(train_dataloader):
                 if self.limit_train_batches and i >= self.limit_train_batches:
                     break
-                loss = module.training_step(self._to_device(batch, self.device), i)
-                (loss / self.accumulate_grad_batches).backward()
+                batch = self._to_device(batch, self.device)
+                loss = None   # see GraphedTrainingStep: nothing of an earlier eager step may be alive at capture time
+                if graphed is None and use_graph and i > 0:
+                    # the first micro-batch ran eagerly (names / dtypes recorded, lazy initialisation done); capture from the second
+                    saved = ddp.flat_grad.clone()
+                    graphed = GraphedTrainingStep(module, batch, loss_scale=1.0 / self.accumulate_grad_batches)
+                    ddp.flat_grad.copy_(saved)   # the capture's warm-up backward passes are not part of the training run
+                if graphed is not None:
+                    loss = graphed(batch)
+                else:
+                    loss = module.training_step(batch, i)
+                    (loss / self.accumulate_grad_batches).backward()
                 if (i + 1) % self.accumulate_grad_batches == 0:  # non-stepping micro-batches do not sync
                     ddp.all_reduce_grads()
                     opt.step()
