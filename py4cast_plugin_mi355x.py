@@ -20,6 +20,7 @@ from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings  # noqa: F401,
 from py4cast_amd.graphlam import GraphLamMI355X, GraphLamSettings  # noqa: F401,E402
 from py4cast_amd.swinunetr import SwinUNetRMI355X, SwinUNetRSettings  # noqa: F401,E402
 from py4cast_amd.hilam import HiLamMI355X, HiLamSettings  # noqa: F401,E402
+from py4cast_amd.hilamparallel import HiLamParallelMI355X, HiLamParallelSettings  # noqa: F401,E402
 
 if not HAVE_MFAI:
     # stand-alone: take the upstream names so that config/CLI/model/halfunet.yaml / graphlam.yaml work unchanged
@@ -33,6 +34,9 @@ if not HAVE_MFAI:
         register = True
 
     class HiLAM(HiLamMI355X):
+        register = True
+
+    class HiLAMParallel(HiLamParallelMI355X):
         register = True
 
 

@@ -696,3 +696,42 @@ def test_widened_models_validate_and_predict(gpu_device, tmp_path, model_name, s
         pred = lm.predict_step(ItemBatch(b.inputs, b.forcing, None), 1)   # names / dtype were recorded by the steps above
     pt = pred.tensor
     assert torch.isfinite(pt).all() and pt.shape[:2] == (2, 2) and pt.shape[-1] == 5
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 4e-2)])
+def test_hilamparallel_matches_oracle(gpu_device, tmp_path, dtype, tol):
+    from oracle.hilam import HiLamParallel as OracleHiLamParallel
+    from py4cast_amd.hilamparallel import HiLamParallelMI355X, HiLamParallelSettings
+
+    H, W, cin, cout = 36, 45, 11, 4
+    ys, xs = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    st = HiLamParallelSettings(tmp_dir=str(tmp_path), processor_layers=2, activation_dtype=dtype)
+    HiLamParallelMI355X.rank_zero_setup(st, torch.stack([xs, ys]))
+    torch.manual_seed(141)
+    m = HiLamParallelMI355X(cin, cout, (H, W), st)
+    Lv = m.num_levels
+    graph = {"g2m": m.g2m_index, "m2g": m.m2g_index, "g2m_feat": m.g2m_features, "m2g_feat": m.m2g_features,
+             "mesh_pos": [getattr(m, f"mesh_pos_{l}") for l in range(Lv)],
+             "same": [getattr(m, f"same_index_{l}") for l in range(Lv)],
+             "same_feat": [getattr(m, f"same_features_{l}") for l in range(Lv)]}
+    for k in ("up", "down"):
+        graph[k] = [getattr(m, f"{k}_index_{l}") for l in range(Lv - 1)]
+        graph[f"{k}_feat"] = [getattr(m, f"{k}_features_{l}") for l in range(Lv - 1)]
+    oracle = OracleHiLamParallel(cin, cout, graph, processor_layers=2).double()
+    oracle.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    m = m.to(gpu_device)
+    x, gy = torch.randn(2, H * W, cin), torch.randn(2, H * W, cout)
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = m(xg)
+    y.backward(gy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    yr = oracle(xr)
+    yr.backward(gy.double())
+    assert _rel(y.detach().cpu(), yr.detach()) < tol
+    if dtype == "f32":
+        assert _rel(xg.grad.cpu(), xr.grad) < 1e-3
+        ref = dict(oracle.named_parameters())
+        for name, p in m.named_parameters():
+            assert _rel(p.grad.cpu(), ref[name].grad) < 3e-3, name
+    else:
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
