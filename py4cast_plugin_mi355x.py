@@ -27,7 +27,10 @@ if not HAVE_MFAI:
     class HalfUNet(HalfUNetMI355X):
         register = True
 
-    class GraphLam(GraphLamMI355X):
+    class GraphLAM(GraphLamMI355X):     # mfai's class name = the reference's registry key (tests/test_models.py:145-165)
+        register = True
+
+    class GraphLam(GraphLamMI355X):     # the spelling config/CLI/model/graphlam.yaml:2 uses
         register = True
 
     class SwinUNetR(SwinUNetRMI355X):

@@ -57,6 +57,8 @@ def test_registry_contract():
     from py4cast_amd.base import ModelABC
 
     assert "HalfUNet" in models.registry  # the MI355X plugin was discovered through its module-name prefix
+    # the reference's registry keys this build provides natively (tests/test_models.py:145-165 of the reference)
+    assert {"HalfUNet", "SwinUNetR", "GraphLAM", "HiLAM", "HiLAMParallel", "Identity"} <= set(models.registry)
     for name, kls in models.registry.items():
         assert issubclass(kls, ModelABC) and kls.register
     with pytest.raises(KeyError):
