@@ -89,11 +89,13 @@ str_to_dtype = {  # py4cast/utils.py:104-109
 def rank_zero_init(model_kls, model_settings, statics):
     """lightning.py:141-144 (rank_zero_only when lightning is present)."""
     if hasattr(model_kls, "rank_zero_setup"):
-        rank = 0
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            rank = torch.distributed.get_rank()
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        rank = torch.distributed.get_rank() if distributed else 0
         if rank == 0:
             model_kls.rank_zero_setup(model_settings, statics.meshgrid)
+        if distributed:
+            # the other ranks construct the model right after this call and read what rank 0 wrote (e.g. the mesh graph file)
+            torch.distributed.barrier()
 
 
 def cosine_with_min_lr_lambda(num_warmup_steps: int, num_training_steps: int, min_lr_rate: float, num_cycles: float = 0.5):
