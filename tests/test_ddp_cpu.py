@@ -45,3 +45,31 @@ def test_flat_ddp_allreduce_mean_gloo():
     torch.testing.assert_close(red_a, (local_a + local_b) / 2)
     torch.testing.assert_close(red_a, red_b)
     assert ptrs_a[0] == base_a  # param.grad tensors are views into the single flat bucket
+
+
+def _graph_worker(rank, world, port, tmp_dir, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import make_dataset_info, synthetic_case
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    case = synthetic_case(seed=5, B=2, T=2, H=27, W=27, F=5, Ff=5)
+    # every rank constructs the module; only rank 0 builds the mesh graph (rank_zero_setup), the others must find its file
+    lm = AutoRegressiveLightning({"tmp_dir": tmp_dir, "processor_layers": 1}, make_dataset_info(case, 5), None, batch_size=2,
+                                 model_name="GraphLAM", training_strategy="diff_ar")
+    ret[rank] = (lm.model.n_mesh, int(lm.model.g2m_index.shape[1]), sum(p.numel() for p in lm.model.parameters()))
+    dist.destroy_process_group()
+
+
+def test_rank_zero_setup_is_visible_to_all_ranks_gloo(tmp_path):
+    """Graph models: rank 0 writes the mesh graph, a barrier makes it visible before the other ranks' constructors read it
+    (py4cast/lightning.py:141-144 leaves that ordering to Lightning)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 30500 + (os.getpid() % 1000)
+    mp.spawn(_graph_worker, args=(world, port, str(tmp_path), ret), nprocs=world, join=True)
+    assert ret[0] == ret[1] and ret[0][0] == 81
