@@ -414,6 +414,8 @@ typedef struct p4c_row_mlp_desc {
     const void* res;         /* (rows, 64) bf16 or NULL */
     void* out;               /* (rows, 64) bf16 or NULL */
     void* out_res;           /* (rows, 64) bf16 or NULL (needs res) */
+    const void* prepared;    /* parameters re-laid by p4c_row_mlp_prepare (valid while they are unchanged), or NULL: every launch
+                                then re-lays them itself */
     /* backward only */
     const void* dy;          /* gradient of out, or NULL */
     const void* dy_res;      /* gradient of out_res, or NULL (the gradient of res is dy_res itself) */
@@ -421,6 +423,10 @@ typedef struct p4c_row_mlp_desc {
     void* dpre;              /* (rows, 64) bf16 or NULL: gradient of the pre-activation = gradient of the gathered rows before
                                 their p4c_segment_sum over index_a / index_b */
 } p4c_row_mlp_desc;
+/* Re-lays w1, b1, w2, b2, gamma, beta (as described by d) into the operand images both kernels use: `prepared` needs
+ * p4c_row_mlp_prepared_bytes(k) bytes and stays valid until a parameter changes. */
+size_t p4c_row_mlp_prepared_bytes(int k);
+int p4c_row_mlp_prepare(const p4c_row_mlp_desc* d, void* prepared, p4c_stream_t stream);
 int p4c_row_mlp_fwd(const p4c_row_mlp_desc* d, p4c_stream_t stream);
 /* grads (fp32, overwritten): dW1 [64][k] | dW2 [64][64] | db1 [64] | db2 [64] | dgamma [64] | dbeta [64], reduced in a fixed
  * order.  workspace: p4c_row_mlp_bwd_workspace_bytes(rows, k) bytes. */

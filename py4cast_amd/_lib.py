@@ -59,6 +59,10 @@ OTHER = {
 
 _lib = None
 
+# bumped whenever a kernel updates parameters through raw pointers (FlatAdamW): caches of re-laid parameters key on it as well
+# as on tensor._version
+PARAM_EPOCH = [0]
+
 
 class P4CError(RuntimeError):
     pass

@@ -28,7 +28,7 @@ class RowMlpDesc(ctypes.Structure):
         ("rows", c_int64), ("x", c_void_p), ("k", c_int32), ("k_real", c_int32), ("w1", c_void_p), ("ldw1", c_int32),
         ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("o_real", c_int32), ("gamma", c_void_p), ("beta", c_void_p),
         ("eps", c_float), ("gather_a", c_void_p), ("index_a", c_void_p), ("gather_b", c_void_p), ("index_b", c_void_p),
-        ("res", c_void_p), ("out", c_void_p), ("out_res", c_void_p), ("dy", c_void_p), ("dy_res", c_void_p), ("dx", c_void_p),
+        ("res", c_void_p), ("out", c_void_p), ("out_res", c_void_p), ("prepared", c_void_p), ("dy", c_void_p), ("dy_res", c_void_p), ("dx", c_void_p),
         ("dpre", c_void_p),
     ]
 
@@ -50,6 +50,7 @@ SIGNATURES = {
     "p4c_row_layernorm_bwd": [P, P, P, F, P, P, P, P, L, I, I, P],
     "p4c_row_linear_wgrad": [P, P, P, P, L, I, I, I, P],
     "p4c_row_mlp_fwd": [MP, P],
+    "p4c_row_mlp_prepare": [MP, P, P],
     "p4c_row_mlp_bwd": [MP, P, P, P],
     "p4c_window_attn_fwd": [P, P, P, I, I, I, I, I, I, I, F, I, P],
     "p4c_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
@@ -62,4 +63,5 @@ OTHER = {
     "p4c_row_layernorm_bwd_workspace_bytes": ([L, I, I], c_size_t),
     "p4c_row_linear_wgrad_workspace_bytes": ([L, I], c_size_t),
     "p4c_row_mlp_bwd_workspace_bytes": ([L, I], c_size_t),
+    "p4c_row_mlp_prepared_bytes": ([I], c_size_t),
 }

@@ -53,6 +53,7 @@ struct MlpArgs {
     bf16* dx;               // (R, K) or NULL
     bf16* dpre;             // gradient of the pre-activation (R, 64): the gradient of ga / gb rows before their segment sums; or NULL
     float* partial;         // per-workgroup parameter-gradient partials
+    const void* prepared;   // constants + weight operand images as laid out in LDS (p4c_row_mlp_prepare), or NULL
     int64_t R;
 };
 
@@ -107,9 +108,9 @@ __device__ __forceinline__ float silu_sig(float x) { return __builtin_amdgcn_rcp
 // permuted k order: element j = M[row 32 tile + (lane & 31)][col 16 s + 8 (j >> 2) + 4 h + (j & 3)]   (matches acc_op)
 // M(row, col) = transposed ? W[col][row] : W[row][col], zero outside (rows_real, cols_real)
 __device__ __forceinline__ void build_image(bf16* img, int tiles, int S, const float* W, int ld, int rows_real, int cols_real,
-                                            bool transposed, bool permuted) {
+                                            bool transposed, bool permuted, int tid, int nthreads) {
     const int total = tiles * S * 64 * 8;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    for (int idx = tid; idx < total; idx += nthreads) {
         const int j = idx & 7, lane = (idx >> 3) & 63, ts = idx >> 9;
         const int s = ts % S, tile = ts / S;
         const int h = lane >> 5;
@@ -125,8 +126,8 @@ __device__ __forceinline__ bf16x8 wop(const bf16* img, int S, int tile, int s, i
 }
 
 // constants: [b1 | b2 | gamma | beta] x 64 floats
-__device__ __forceinline__ void build_consts(float* lc, const MlpArgs& a) {
-    for (int i = threadIdx.x; i < 4 * HID; i += blockDim.x) {
+__device__ __forceinline__ void build_consts(float* lc, const MlpArgs& a, int tid, int nthreads) {
+    for (int i = tid; i < 4 * HID; i += nthreads) {
         const int which = i >> 6, c = i & 63;
         float v = 0.f;
         if (which == 0 && a.b1) v = a.b1[c];
@@ -135,6 +136,49 @@ __device__ __forceinline__ void build_consts(float* lc, const MlpArgs& a) {
         if (which == 3 && a.beta) v = a.beta[c];
         lc[i] = v;
     }
+}
+
+
+// constants + weight images into LDS: a 16-byte-per-thread copy of the prepared blob, or built from the raw fp32 parameters
+template <int KS, bool BWD>
+__device__ __forceinline__ void stage_parameters(char* smem, const MlpArgs& a) {
+    constexpr int NKT = (16 * KS + 31) / 32;
+    constexpr int bytes = 4 * HID * 4 + (BWD ? (2 * KS + 8 + 8 + 4 * NKT) : (2 * KS + 8)) * 1024;
+    if (a.prepared) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.prepared);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < bytes / 16; i += blockDim.x) dst[i] = src[i];
+        return;
+    }
+    float* lc = reinterpret_cast<float*>(smem);
+    bf16* w1img = reinterpret_cast<bf16*>(smem + 4 * HID * 4);
+    bf16* w2img = w1img + 2 * KS * 512;
+    build_consts(lc, a, threadIdx.x, blockDim.x);
+    build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false, threadIdx.x, blockDim.x);
+    build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true, threadIdx.x, blockDim.x);
+    if (BWD) {
+        bf16* w2timg = w2img + 8 * 512;
+        bf16* w1timg = w2timg + 8 * 512;
+        build_image(w2timg, 2, 4, a.w2, HID, HID, a.Oreal, true, true, threadIdx.x, blockDim.x);
+        build_image(w1timg, NKT, 4, a.w1, a.ldw1, a.Kreal, HID, true, true, threadIdx.x, blockDim.x);
+    }
+}
+
+// the same images written to global memory once per parameter version (every launch of the fused kernels then copies them)
+template <int KS>
+__global__ void __launch_bounds__(256) row_mlp_prepare_kernel(MlpArgs a, char* blob) {
+    constexpr int NKT = (16 * KS + 31) / 32;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+    float* lc = reinterpret_cast<float*>(blob);
+    bf16* w1img = reinterpret_cast<bf16*>(blob + 4 * HID * 4);
+    bf16* w2img = w1img + 2 * KS * 512;
+    bf16* w2timg = w2img + 8 * 512;
+    bf16* w1timg = w2timg + 8 * 512;
+    build_consts(lc, a, tid, n);
+    build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false, tid, n);
+    build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true, tid, n);
+    build_image(w2timg, 2, 4, a.w2, HID, HID, a.Oreal, true, true, tid, n);
+    build_image(w1timg, NKT, 4, a.w1, a.ldw1, a.Kreal, HID, true, true, tid, n);
 }
 
 // the forward of one 32-row tile up to z (pre-LayerNorm output).  Row of this lane: row0 + (lane & 31).
@@ -150,9 +194,27 @@ __device__ __forceinline__ void tile_forward(Tile<KS>& t, const MlpArgs& a, cons
                                              int64_t row, bool live, int lane, float* hval /*32 or null*/) {
     const int h = lane >> 5;
     constexpr int K = 16 * KS;
+    const int64_t rc = live ? row : 0;   // clamped address: every lane issues the same loads, dead rows are zeroed afterwards
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-        t.xop[s] = live ? *reinterpret_cast<const bf16x8*>(a.x + row * K + 16 * s + 8 * h) : zero8();
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.x + rc * K + 16 * s + 8 * h);
+        t.xop[s] = live ? v : zero8();
+    }
+    // gathered addends: one (wave-uniform) branch per source around all eight 8-byte pieces of the row
+    const bf16x4 z4 = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    bf16x4 pa[8], pb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pa[q] = pb[q] = z4;
+    if (a.ga) {
+        const int64_t ja = a.ia ? (int64_t)a.ia[rc] : rc;   // no index list: the addend is row-aligned
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pa[q] = *reinterpret_cast<const bf16x4*>(a.ga + ja * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+    }
+    if (a.gb) {
+        const int64_t jb = a.ib ? (int64_t)a.ib[rc] : rc;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pb[q] = *reinterpret_cast<const bf16x4*>(a.gb + jb * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+    }
     f32x16 acc[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -160,20 +222,13 @@ __device__ __forceinline__ void tile_forward(Tile<KS>& t, const MlpArgs& a, cons
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1img, KS, m, s, lane), t.xop[s], acc[m], 0, 0, 0);
     }
-    int ja = 0, jb = 0;
-    if (a.ga && live) ja = a.ia ? a.ia[row] : (int)row;   // no index list: the addend is row-aligned
-    if (a.gb && live) jb = a.ib ? a.ib[row] : (int)row;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int q = 0; q < 8; ++q) {
+        const int m = q >> 2, g = q & 3;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lc + 32 * m + 8 * g + 4 * h);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = 32 * m + 8 * g + 4 * h;
-            f32x4 v = *reinterpret_cast<const f32x4*>(lc + c0);
-            if (a.ga && live) v += load4(a.ga + (int64_t)ja * HID + c0);
-            if (a.gb && live) v += load4(a.gb + (int64_t)jb * HID + c0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t.pre[m * 16 + 4 * g + e] = acc[m][4 * g + e] + v[e];
-        }
+        for (int e = 0; e < 4; ++e) t.pre[m * 16 + 4 * g + e] = acc[m][4 * g + e] + (v[e] + ((float)pa[q][e] + (float)pb[q][e]));
+    }
     float hv[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
@@ -219,9 +274,7 @@ __global__ void __launch_bounds__(256, 4) row_mlp_fwd_kernel(MlpArgs a) {
     float* lc = reinterpret_cast<float*>(smem);
     bf16* w1img = reinterpret_cast<bf16*>(smem + 4 * HID * 4);
     bf16* w2img = w1img + 2 * KS * 512;
-    build_consts(lc, a);
-    build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false);
-    build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true);
+    stage_parameters<KS, false>(smem, a);
     __syncthreads();
     const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
@@ -234,26 +287,33 @@ __global__ void __launch_bounds__(256, 4) row_mlp_fwd_kernel(MlpArgs a) {
         tile_forward<KS>(t, a, w1img, w2img, lc, row, live, lane, nullptr);
         float mean = 0.f, rstd = 1.f;
         if (a.gamma) row_stats(t.z, a.eps, mean, rstd);
+        float y[32];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 8; ++q) {
+            const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0), bt = *reinterpret_cast<const f32x4*>(lc + 192 + c0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = 32 * m + 8 * g + 4 * h;
-                float y[4];
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0), bt = *reinterpret_cast<const f32x4*>(lc + 192 + c0);
+            for (int e = 0; e < 4; ++e) y[4 * q + e] = a.gamma ? (t.z[4 * q + e] - mean) * rstd * gm[e] + bt[e] : t.z[4 * q + e];
+        }
+        const int64_t rc = live ? row : 0;
+        bf16x4 rv[8];
+        if (a.out_res) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float zz = t.z[m * 16 + 4 * g + e];
-                    y[e] = a.gamma ? (zz - mean) * rstd * gm[e] + bt[e] : zz;
-                }
-                if (live) {
-                    if (a.out) store4(a.out + row * HID + c0, y[0], y[1], y[2], y[3]);
-                    if (a.out_res) {
-                        const f32x4 rv = load4(a.res + row * HID + c0);
-                        store4(a.out_res + row * HID + c0, y[0] + rv[0], y[1] + rv[1], y[2] + rv[2], y[3] + rv[3]);
-                    }
-                }
+            for (int q = 0; q < 8; ++q) rv[q] = *reinterpret_cast<const bf16x4*>(a.res + rc * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+        }
+        if (live) {
+            if (a.out) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    store4(a.out + row * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h, y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
             }
+            if (a.out_res) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    store4(a.out_res + row * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h, y[4 * q] + (float)rv[q][0], y[4 * q + 1] + (float)rv[q][1],
+                           y[4 * q + 2] + (float)rv[q][2], y[4 * q + 3] + (float)rv[q][3]);
+            }
+        }
     }
 }
 
@@ -296,11 +356,7 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
     char* imgDP = imgDZ + 32 * PROW;
     char* imgDG = imgDP + 32 * PROW;
     char* imgDD = imgDG + 32 * PROW;
-    build_consts(lc, a);
-    build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false);
-    build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true);
-    build_image(w2timg, 2, 4, a.w2, HID, HID, a.Oreal, true, true);
-    build_image(w1timg, NKT, 4, a.w1, a.ldw1, a.Kreal, HID, true, true);
+    stage_parameters<KS, true>(smem, a);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
@@ -495,21 +551,32 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
         for (int q = 0; q < 8; ++q) {
             const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h, i = 4 * q;
             store4(reinterpret_cast<bf16*>(imgDP + r * PROW + c0 * 2), pre[i], pre[i + 1], pre[i + 2], pre[i + 3]);
-            if (a.dpre && live) store4(a.dpre + row * HID + c0, pre[i], pre[i + 1], pre[i + 2], pre[i + 3]);
+        }
+        if (a.dpre && live) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h, i = 4 * q;
+                store4(a.dpre + row * HID + c0, pre[i], pre[i + 1], pre[i + 2], pre[i + 3]);
+            }
         }
         // ---- dx = W1^T dpre
         if (a.dx) {
+            f32x16 acc[NKT];
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                f32x16 acc = zero16();
+                acc[kt] = zero16();
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1timg, 4, kt, sp, lane), acc_op(pre + 16 * (sp >> 1), sp & 1), acc, 0, 0, 0);
+                    acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1timg, 4, kt, sp, lane), acc_op(pre + 16 * (sp >> 1), sp & 1), acc[kt], 0, 0, 0);
+            }
+            if (live) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = 32 * kt + 8 * g + 4 * h;
-                    if (live && c0 < K) store4(a.dx + row * K + c0, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-                }
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c0 = 32 * kt + 8 * g + 4 * h;
+                        if (c0 < K) store4(a.dx + row * K + c0, acc[kt][4 * g], acc[kt][4 * g + 1], acc[kt][4 * g + 2], acc[kt][4 * g + 3]);
+                    }
             }
         }
         lds_order();
@@ -696,7 +763,7 @@ static MlpArgs to_args(const p4c_row_mlp_desc* d) {
     a.ga = (const bf16*)d->gather_a; a.ia = d->index_a; a.gb = (const bf16*)d->gather_b; a.ib = d->index_b;
     a.res = (const bf16*)d->res; a.out = (bf16*)d->out; a.out_res = (bf16*)d->out_res;
     a.dy = (const bf16*)d->dy; a.dy_res = (const bf16*)d->dy_res; a.dx = (bf16*)d->dx; a.dpre = (bf16*)d->dpre;
-    a.partial = nullptr; a.R = d->rows;
+    a.partial = nullptr; a.R = d->rows; a.prepared = d->prepared;
     return a;
 }
 
@@ -737,4 +804,30 @@ extern "C" int p4c_row_mlp_bwd(const p4c_row_mlp_desc* d, float* grads, void* wo
         case 4: return launch_bwd<4>(a, grads, s);
         default: return launch_bwd<5>(a, grads, s);
     }
+}
+
+extern "C" size_t p4c_row_mlp_prepared_bytes(int k) {
+    if (k <= 0 || k % 16) return 0;
+    const int KS = k / 16, NKT = (k + 31) / 32;
+    return (size_t)4 * HID * 4 + (size_t)(2 * KS + 8 + 8 + 4 * NKT) * 1024;
+}
+
+extern "C" int p4c_row_mlp_prepare(const p4c_row_mlp_desc* d, void* prepared, p4c_stream_t stream) {
+    P4C_CHECK_ARG(d != nullptr && prepared != nullptr, "p4c_row_mlp_prepare: NULL pointer");
+    MlpArgs a = to_args(d);
+    a.prepared = nullptr;
+    P4C_CHECK_ARG(d->k % 16 == 0 && d->k >= 16 && d->k <= 80, "p4c_row_mlp_prepare: K = %d input features (multiples of 16 up to 80)", d->k);
+    P4C_CHECK_ARG(a.w1 && a.w2 && a.Kreal > 0 && a.Kreal <= d->k && a.ldw1 >= a.Kreal && a.Oreal > 0 && a.Oreal <= HID,
+                  "p4c_row_mlp_prepare: bad weight shapes");
+    hipStream_t s = as_stream(stream);
+    char* blob = reinterpret_cast<char*>(prepared);
+    switch (d->k / 16) {
+        case 1: hipLaunchKernelGGL(row_mlp_prepare_kernel<1>, dim3(32), dim3(256), 0, s, a, blob); break;
+        case 2: hipLaunchKernelGGL(row_mlp_prepare_kernel<2>, dim3(32), dim3(256), 0, s, a, blob); break;
+        case 3: hipLaunchKernelGGL(row_mlp_prepare_kernel<3>, dim3(32), dim3(256), 0, s, a, blob); break;
+        case 4: hipLaunchKernelGGL(row_mlp_prepare_kernel<4>, dim3(32), dim3(256), 0, s, a, blob); break;
+        default: hipLaunchKernelGGL(row_mlp_prepare_kernel<5>, dim3(32), dim3(256), 0, s, a, blob); break;
+    }
+    P4C_CHECK_LAUNCH("row_mlp_prepare");
+    return P4C_OK;
 }

@@ -95,4 +95,5 @@ class FlatAdamW(torch.optim.AdamW):
                float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]), step, L.stream(flat_p.device))
         for p in params:
             self.state[p]["step"] += 1
+        L.PARAM_EPOCH[0] += 1   # the kernel wrote the parameters behind autograd's back (tensor._version did not move)
         return loss

@@ -735,3 +735,24 @@ def test_hilamparallel_matches_oracle(gpu_device, tmp_path, dtype, tol):
             assert _rel(p.grad.cpu(), ref[name].grad) < 3e-3, name
     else:
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_row_mlp_prepared_parameters_follow_updates(gpu_device):
+    """The cache of re-laid parameters must notice in-place updates (optimizer steps) and raw-pointer updates (FlatAdamW)."""
+    from py4cast_amd import _lib as L
+    from py4cast_amd.ops_mlp import row_mlp
+
+    torch.manual_seed(151)
+    x = torch.randn(2000, 64, device=gpu_device).bfloat16()
+    w1 = (torch.randn(64, 64, device=gpu_device) * 0.1).requires_grad_(True)
+    w2 = (torch.randn(64, 64, device=gpu_device) * 0.1).requires_grad_(True)
+    y0 = row_mlp(x, w1, None, w2, None)[0].float()
+    assert torch.equal(row_mlp(x, w1, None, w2, None)[0].float(), y0)         # cache hit: same result
+    with torch.no_grad():
+        w2.mul_(2.0)                                                          # in-place: tensor._version moves
+    y1 = row_mlp(x, w1, None, w2, None)[0].float()
+    assert _rel(y1, 2 * y0) < 2e-2
+    w2.data.copy_(w2.data * 0.5)                                              # .data write: the version does NOT move ...
+    L.PARAM_EPOCH[0] += 1                                                     # ... which is what FlatAdamW signals this way
+    y2 = row_mlp(x, w1, None, w2, None)[0].float()
+    assert _rel(y2, y0) < 2e-2
