@@ -624,7 +624,7 @@ def test_graphed_training_step_equals_eager(gpu_device, tmp_path):
     ddp.zero_grad()
     loss_e = lm.training_step(make_batch(other, gpu_device), 0)
     loss_e.backward()
-    loss_e = float(loss_e)          # keep the number, not the tensor: its autograd graph must be gone before a capture
+    loss_e = float(loss_e.detach())  # keep the number, not the tensor: its autograd graph must be gone before a capture
     eager = ddp.flat_grad.clone()
     ddp.zero_grad()
     step = GraphedTrainingStep(lm, make_batch(case, gpu_device))     # captured on one batch ...
