@@ -432,6 +432,19 @@ int p4c_row_mlp_fwd(const p4c_row_mlp_desc* d, p4c_stream_t stream);
  * order.  workspace: p4c_row_mlp_bwd_workspace_bytes(rows, k) bytes. */
 size_t p4c_row_mlp_bwd_workspace_bytes(int64_t rows, int k);
 int p4c_row_mlp_bwd(const p4c_row_mlp_desc* d, float* grads, void* workspace, p4c_stream_t stream);
+/* The same backward with the parameter gradients ADDED (+=) straight into the parameters' gradient buffers instead of returned:
+ * replaces six `param.grad += g` launches per call (an MLP is applied once per AR step: torch's AccumulateGrad adds them one by
+ * one).  dw1: [64][k_real] with row stride ld_dw1 (a column slice of a wider gradient is fine); dw2: [o_real][64]; NULL = dropped. */
+typedef struct p4c_row_mlp_grad_sinks {
+    float* dw1;
+    int32_t ld_dw1;
+    float* db1;
+    float* dw2;
+    float* db2;
+    float* dgamma;
+    float* dbeta;
+} p4c_row_mlp_grad_sinks;
+int p4c_row_mlp_bwd_accumulate(const p4c_row_mlp_desc* d, const p4c_row_mlp_grad_sinks* sinks, void* workspace, p4c_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,16 @@ class RowMlpDesc(ctypes.Structure):
 
 MP = ctypes.POINTER(RowMlpDesc)
 
+
+class RowMlpGradSinks(ctypes.Structure):
+    """struct p4c_row_mlp_grad_sinks"""
+
+    _fields_ = [("dw1", c_void_p), ("ld_dw1", c_int32), ("db1", c_void_p), ("dw2", c_void_p), ("db2", c_void_p),
+                ("dgamma", c_void_p), ("dbeta", c_void_p)]
+
+
+SP = ctypes.POINTER(RowMlpGradSinks)
+
 SIGNATURES = {
     "p4c_prep_weights": [P, I, I, I, I, I, I, P, I, P],
     "p4c_conv_fwd": [P, I, I, I, P, I, P, P, I, P, P, I, P, I, I, I, I, P],
@@ -52,6 +62,7 @@ SIGNATURES = {
     "p4c_row_mlp_fwd": [MP, P],
     "p4c_row_mlp_prepare": [MP, P, P],
     "p4c_row_mlp_bwd": [MP, P, P, P],
+    "p4c_row_mlp_bwd_accumulate": [MP, SP, P, P],
     "p4c_window_attn_fwd": [P, P, P, I, I, I, I, I, I, I, F, I, P],
     "p4c_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
 }

@@ -701,6 +701,48 @@ __global__ void __launch_bounds__(256) mlp_param_reduce_kernel(const float* __re
     }
 }
 
+// the same sums ADDED into the parameters' gradient buffers (the roles of the n = 64 K + 4096 + 256 entries are fixed by the layout)
+struct GradSinks {
+    float* dw1; int ld_dw1, k_real;
+    float* dw2; int o_real;
+    float* db1; float* db2; float* dgamma; float* dbeta;
+};
+__global__ void __launch_bounds__(256) mlp_param_reduce_acc_kernel(const float* __restrict__ partial, int slots, int n, int K, GradSinks g) {
+    __shared__ float red[8][33];
+    const int jj = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jj;
+    float s0 = 0.f, s1 = 0.f;
+    if (j < n) {
+        int s = sg;
+        for (; s + 8 < slots; s += 16) {
+            s0 += partial[(int64_t)s * n + j];
+            s1 += partial[(int64_t)(s + 8) * n + j];
+        }
+        for (; s < slots; s += 8) s0 += partial[(int64_t)s * n + j];
+    }
+    red[sg][jj] = s0 + s1;
+    __syncthreads();
+    if (sg == 0 && j < n) {
+        float t = red[0][jj];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][jj];
+        const int w2_0 = HID * K, b1_0 = w2_0 + HID * HID;
+        if (j < w2_0) {
+            const int o = j / K, k = j - o * K;
+            if (g.dw1 && k < g.k_real) g.dw1[(int64_t)o * g.ld_dw1 + k] += t;
+        } else if (j < b1_0) {
+            const int o = (j - w2_0) >> 6;
+            if (g.dw2 && o < g.o_real) g.dw2[j - w2_0] += t;
+        } else {
+            const int which = (j - b1_0) >> 6, c = (j - b1_0) & 63;
+            if (which == 0 && g.db1) g.db1[c] += t;
+            if (which == 1 && g.db2 && c < g.o_real) g.db2[c] += t;
+            if (which == 2 && g.dgamma) g.dgamma[c] += t;
+            if (which == 3 && g.dbeta) g.dbeta[c] += t;
+        }
+    }
+}
+
 int mlp_grid(int64_t R, int per_cu) {
     const int64_t tiles = (R + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
@@ -730,7 +772,7 @@ int launch_fwd(const MlpArgs& a, hipStream_t s) {
     return P4C_OK;
 }
 template <int KS>
-int launch_bwd(const MlpArgs& a, float* grads, hipStream_t s) {
+int launch_bwd(const MlpArgs& a, float* grads, const GradSinks* sinks, hipStream_t s) {
     constexpr int smem = bwd_lds_bytes<KS>();
     static_assert(4 * wave_img_bytes<KS>() >= partial_floats<KS>() * 4, "reduction buffer must fit the waves' images");
     static bool attr_set = false;
@@ -746,7 +788,10 @@ int launch_bwd(const MlpArgs& a, float* grads, hipStream_t s) {
         hipLaunchKernelGGL((row_mlp_bwd_kernel<KS, false>), dim3(G), dim3(256), smem, s, a);
     P4C_CHECK_LAUNCH("row_mlp_bwd");
     const int n = partial_floats<KS>();
-    hipLaunchKernelGGL(mlp_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, grads);
+    if (sinks)
+        hipLaunchKernelGGL(mlp_param_reduce_acc_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, 16 * KS, *sinks);
+    else
+        hipLaunchKernelGGL(mlp_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, grads);
     P4C_CHECK_LAUNCH("mlp_param_reduce");
     return P4C_OK;
 }
@@ -789,21 +834,34 @@ extern "C" size_t p4c_row_mlp_bwd_workspace_bytes(int64_t rows, int k) {
     return (size_t)mlp_grid(rows, 1) * (HID * (size_t)k + HID * HID + 4 * HID) * sizeof(float);
 }
 
-extern "C" int p4c_row_mlp_bwd(const p4c_row_mlp_desc* d, float* grads, void* workspace, p4c_stream_t stream) {
-    P4C_CHECK_ARG(d != nullptr && grads != nullptr && workspace != nullptr, "p4c_row_mlp_bwd: NULL pointer");
+static int row_mlp_bwd_common(const char* name, const p4c_row_mlp_desc* d, float* grads, const GradSinks* sinks, void* workspace,
+                              p4c_stream_t stream) {
     MlpArgs a = to_args(d);
-    int rc = check_args("p4c_row_mlp_bwd", a, d->k);
+    int rc = check_args(name, a, d->k);
     if (rc != P4C_OK) return rc;
-    P4C_CHECK_ARG(a.dy || a.dy_res, "p4c_row_mlp_bwd: no upstream gradient");
+    P4C_CHECK_ARG(a.dy || a.dy_res, "%s: no upstream gradient", name);
     a.partial = reinterpret_cast<float*>(workspace);
     hipStream_t s = as_stream(stream);
     switch (d->k / 16) {
-        case 1: return launch_bwd<1>(a, grads, s);
-        case 2: return launch_bwd<2>(a, grads, s);
-        case 3: return launch_bwd<3>(a, grads, s);
-        case 4: return launch_bwd<4>(a, grads, s);
-        default: return launch_bwd<5>(a, grads, s);
+        case 1: return launch_bwd<1>(a, grads, sinks, s);
+        case 2: return launch_bwd<2>(a, grads, sinks, s);
+        case 3: return launch_bwd<3>(a, grads, sinks, s);
+        case 4: return launch_bwd<4>(a, grads, sinks, s);
+        default: return launch_bwd<5>(a, grads, sinks, s);
     }
+}
+
+extern "C" int p4c_row_mlp_bwd(const p4c_row_mlp_desc* d, float* grads, void* workspace, p4c_stream_t stream) {
+    P4C_CHECK_ARG(d != nullptr && grads != nullptr && workspace != nullptr, "p4c_row_mlp_bwd: NULL pointer");
+    return row_mlp_bwd_common("p4c_row_mlp_bwd", d, grads, nullptr, workspace, stream);
+}
+
+extern "C" int p4c_row_mlp_bwd_accumulate(const p4c_row_mlp_desc* d, const p4c_row_mlp_grad_sinks* sinks, void* workspace,
+                                          p4c_stream_t stream) {
+    P4C_CHECK_ARG(d != nullptr && sinks != nullptr && workspace != nullptr, "p4c_row_mlp_bwd_accumulate: NULL pointer");
+    P4C_CHECK_ARG(sinks->dw1 == nullptr || sinks->ld_dw1 >= d->k_real, "p4c_row_mlp_bwd_accumulate: bad dw1 row stride");
+    GradSinks g{sinks->dw1, sinks->ld_dw1, d->k_real, sinks->dw2, d->o_real, sinks->db1, sinks->db2, sinks->dgamma, sinks->dbeta};
+    return row_mlp_bwd_common("p4c_row_mlp_bwd_accumulate", d, nullptr, &g, workspace, stream);
 }
 
 extern "C" size_t p4c_row_mlp_prepared_bytes(int k) {

@@ -50,6 +50,13 @@ class GraphLamSettings:
     activation_dtype: str = "f32"   # "bf16": node / edge representations stored as bf16
 
 
+# The fused MLP kernels add their parameter gradients straight into the parameters' existing .grad buffers (one reduction launch)
+# instead of returning them for autograd's AccumulateGrad (six small `+=` launches per MLP application, ~10^3-10^4 per step).
+# Only when every parameter already HAS a gradient buffer (FlatDDP / Trainer allocate them; otherwise the ordinary path runs);
+# set to False for code that needs torch.autograd.grad() with respect to these parameters.
+GRADS_IN_PLACE = True
+
+
 def make_mlp(blueprint, layer_norm=True) -> nn.Sequential:
     layers = []
     for i, (a, b) in enumerate(zip(blueprint[:-1], blueprint[1:])):
@@ -94,7 +101,7 @@ def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None
         ln = mlp[3] if len(mlp) == 4 else None
         out, out_res = M.row_mlp(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
                                  None if ln is None else ln.weight, None if ln is None else ln.bias,
-                                 1e-5 if ln is None else ln.eps, res=res, want_out=res is None)
+                                 1e-5 if ln is None else ln.eps, res=res, want_out=res is None, grads_in_place=GRADS_IN_PLACE)
         y = out if res is None else out_res
         return y if mlp[2].out_features == 64 else y[:, : mlp[2].out_features]
     for m in mlp:
@@ -148,7 +155,8 @@ class InteractionNet(nn.Module):
             a = R.row_linear(send_rep, lin0.weight[:, C:2 * C])
             b = R.row_linear(rec_rep, lin0.weight[:, 2 * C:])
             msg, new_edge = M.row_mlp(edge_rep, lin0.weight[:, :C], lin0.bias, lin1.weight, lin1.bias, ln.weight, ln.bias, ln.eps,
-                                      ga=a, gb=b, edges=edges, res=edge_rep if self.update_edges else None)
+                                      ga=a, gb=b, edges=edges, res=edge_rep if self.update_edges else None,
+                                      grads_in_place=GRADS_IN_PLACE)
         else:
             if edge_rep.dtype == torch.bfloat16:
                 base = R.row_linear(edge_rep, lin0.weight[:, :C], lin0.bias)          # E x C
@@ -167,7 +175,7 @@ class InteractionNet(nn.Module):
             # Linear over cat[x_r, agg] = x_r W[:, :C]^T (small library GEMM, row-aligned addend) + agg W[:, C:]^T (fused kernel's x)
             part = R.row_linear(rec_rep, al0.weight[:, :C])
             _, rec_rep = M.row_mlp(agg, al0.weight[:, C:], al0.bias, al1.weight, al1.bias, aln.weight, aln.bias, aln.eps,
-                                   ga=part, res=rec_rep, want_out=False)
+                                   ga=part, res=rec_rep, want_out=False, grads_in_place=GRADS_IN_PLACE)
         else:
             rec_rep = _run(self.aggr_mlp, torch.cat([rec_rep, agg], dim=-1), res=rec_rep)
         if self.update_edges:

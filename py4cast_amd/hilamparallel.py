@@ -22,6 +22,7 @@ from torch import nn
 from . import ops_graph as G
 from . import ops_mlp as M
 from . import ops_rows as R
+from . import graphlam as _gl
 from .graphlam import _run, cached_static_embeddings, make_mlp
 from .hilam import HiLamMI355X, HiLamSettings
 
@@ -56,7 +57,7 @@ def _edge_messages(mlp: nn.Sequential, send, rec, edge_rep, edges: G.EdgeSet):
         a = R.row_linear(send, lin0.weight[:, C:2 * C])
         b = R.row_linear(rec, lin0.weight[:, 2 * C:])
         return M.row_mlp(edge_rep, lin0.weight[:, :C], lin0.bias, lin1.weight, lin1.bias, ln.weight, ln.bias, ln.eps,
-                         ga=a, gb=b, edges=edges, res=edge_rep)
+                         ga=a, gb=b, edges=edges, res=edge_rep, grads_in_place=_gl.GRADS_IN_PLACE)
     base = F.linear(edge_rep, lin0.weight[:, :C], lin0.bias)
     h = G.edge_gather_add(base, F.linear(send, lin0.weight[:, C:2 * C]), F.linear(rec, lin0.weight[:, 2 * C:]), edges, "silu")
     msg = _run(mlp[2:], h)
@@ -69,7 +70,7 @@ def _node_update(mlp: nn.Sequential, rec, agg):
     if rec.dtype == torch.bfloat16 and C == 64:
         part = R.row_linear(rec, al0.weight[:, :C])
         return M.row_mlp(agg, al0.weight[:, C:], al0.bias, al1.weight, al1.bias, aln.weight, aln.bias, aln.eps, ga=part, res=rec,
-                         want_out=False)[1]
+                         want_out=False, grads_in_place=_gl.GRADS_IN_PLACE)[1]
     return _run(mlp, torch.cat([rec, agg], dim=-1), res=rec)
 
 

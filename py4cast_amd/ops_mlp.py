@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from ._lib_model import RowMlpDesc
+from ._lib_model import RowMlpDesc, RowMlpGradSinks
 from .ops_graph import EdgeSet, _segment_sum_raw
 
 MAX_K = 80
@@ -52,7 +52,7 @@ def _prepared(d: RowMlpDesc, K: int, tensors, device) -> torch.Tensor:
 
 class _RowMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges: Optional[EdgeSet], eps: float, want_out: bool):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges: Optional[EdgeSet], eps: float, want_out: bool, sinks=None):
         R, K = x.shape
         x = x.contiguous()
         for t in (w1, w2):
@@ -78,7 +78,7 @@ class _RowMLP(torch.autograd.Function):
         L.call("p4c_row_mlp_fwd", ctypes.byref(d), L.stream(x.device),
                alg_bytes=R * K * 2 + (rows_io - 1) * R * 128 + gathered * 128 + 4 * R * ((ga is not None) + (gb is not None)))
         ctx.save_for_backward(x, w1, w2c, b1c, b2c, gc, bc, gac, gbc)
-        ctx.edges, ctx.eps = edges, eps
+        ctx.edges, ctx.eps, ctx.sinks = edges, eps, sinks
         ctx.flags = (b1 is not None, b2 is not None, gamma is not None, res is not None)
         ctx.pdtype = w1.dtype
         if out is None:
@@ -94,12 +94,12 @@ class _RowMLP(torch.autograd.Function):
         dy = None if dout is None else dout.contiguous()
         dyr = None if dout_res is None else dout_res.contiguous()
         if dy is None and dyr is None:
-            return (None,) * 13
+            return (None,) * 14
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         gathered = ga is not None or gb is not None
         dpre = torch.empty(R, 64, dtype=x.dtype, device=x.device) if gathered else None
-        grads = torch.empty(64 * K + 64 * 64 + 4 * 64, dtype=torch.float32, device=x.device)
+        grads = None if ctx.sinks is not None else torch.empty(64 * K + 64 * 64 + 4 * 64, dtype=torch.float32, device=x.device)
         ws = torch.empty(max(L.lib().p4c_row_mlp_bwd_workspace_bytes(R, K) // 4, 1), dtype=torch.float32, device=x.device)
         ia = edges.src if (ga is not None and edges is not None) else None
         ib = edges.dst if (gb is not None and edges is not None) else None
@@ -108,16 +108,25 @@ class _RowMLP(torch.autograd.Function):
         d.prepared = blob.data_ptr()
         rows_io = 1 + (dy is not None) + (dyr is not None) + need_dx * K / 64 + gathered
         n_gath = sum(min(R, t.shape[0]) for t in (ga, gb) if t is not None)
-        L.call("p4c_row_mlp_bwd", ctypes.byref(d), L.ptr(grads), L.ptr(ws), L.stream(x.device),
-               alg_bytes=R * K * 2 + (rows_io - 1) * R * 128 + n_gath * 128 + 4 * R * ((ga is not None) + (gb is not None)))
-        kr, o = w1.shape[1], w2.shape[0]
-        dw1 = grads[: 64 * K].view(64, K)[:, :kr]
-        dw2 = grads[64 * K: 64 * K + 4096].view(64, 64)[:o]
-        base = 64 * K + 4096
-        db1 = grads[base: base + 64] if has_b1 else None
-        db2 = grads[base + 64: base + 64 + o] if has_b2 else None
-        dgam = grads[base + 128: base + 192] if has_ln else None
-        dbet = grads[base + 192: base + 256] if has_ln else None
+        nbytes = R * K * 2 + (rows_io - 1) * R * 128 + n_gath * 128 + 4 * R * ((ga is not None) + (gb is not None))
+        if ctx.sinks is not None:
+            # parameter gradients go straight into the parameters' .grad buffers (+=): nothing is returned for them
+            sw1, sb1, sw2, sb2, sg, sb = ctx.sinks
+            p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+            gs = RowMlpGradSinks(dw1=p(sw1), ld_dw1=0 if sw1 is None else sw1.stride(0), db1=p(sb1), dw2=p(sw2), db2=p(sb2),
+                                 dgamma=p(sg), dbeta=p(sb))
+            L.call("p4c_row_mlp_bwd_accumulate", ctypes.byref(d), ctypes.byref(gs), L.ptr(ws), L.stream(x.device), alg_bytes=nbytes)
+            dw1 = dw2 = db1 = db2 = dgam = dbet = None
+        else:
+            L.call("p4c_row_mlp_bwd", ctypes.byref(d), L.ptr(grads), L.ptr(ws), L.stream(x.device), alg_bytes=nbytes)
+            kr, o = w1.shape[1], w2.shape[0]
+            dw1 = grads[: 64 * K].view(64, K)[:, :kr]
+            dw2 = grads[64 * K: 64 * K + 4096].view(64, 64)[:o]
+            base = 64 * K + 4096
+            db1 = grads[base: base + 64] if has_b1 else None
+            db2 = grads[base + 64: base + 64 + o] if has_b2 else None
+            dgam = grads[base + 128: base + 192] if has_ln else None
+            dbet = grads[base + 192: base + 256] if has_ln else None
         if edges is None:   # row-aligned addends: their gradient is the pre-activation gradient itself
             dga = dpre if (ga is not None and ctx.needs_input_grad[7]) else None
             dgb = dpre if (gb is not None and ctx.needs_input_grad[8]) else None
@@ -125,12 +134,13 @@ class _RowMLP(torch.autograd.Function):
             dga = _segment_sum_raw(dpre, *edges.by_src, edges.n_src) if (ga is not None and ctx.needs_input_grad[7]) else None
             dgb = _segment_sum_raw(dpre, *edges.by_dst, edges.n_dst) if (gb is not None and ctx.needs_input_grad[8]) else None
         dres = dyr if has_res else None
-        return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None
+        return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None, None
 
 
 def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=None, beta=None, eps: float = 1e-5,
             ga: Optional[torch.Tensor] = None, gb: Optional[torch.Tensor] = None, edges: Optional[EdgeSet] = None,
-            res: Optional[torch.Tensor] = None, want_out: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+            res: Optional[torch.Tensor] = None, want_out: bool = True,
+            grads_in_place: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
     """Returns (y, y + res); x (R, K) bf16 with K <= 80 (padded to a multiple of 16 here), w1 (64, K), w2 (O <= 64, 64).
     ga / gb: (n_src, 64) / (n_dst, 64) rows added to the pre-activation through edges.src / edges.dst; with ``edges=None`` they
     are row-aligned addends (R, 64) -- e.g. the other half of a Linear over a concatenation of two 64-feature sources."""
@@ -138,4 +148,34 @@ def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=N
     kp = (-x.shape[1]) % 16
     if kp:
         x = F.pad(x, (0, kp))
-    return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out)
+    sinks = grad_sinks(w1, b1, w2, b2, gamma, beta) if grads_in_place else None
+    if sinks is not None:   # autograd must not also accumulate what the kernel adds itself
+        w1, b1, w2, b2, gamma, beta = (None if t is None else t.detach() for t in (w1, b1, w2, b2, gamma, beta))
+    return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out, sinks)
+
+
+def _grad_view(t: Optional[torch.Tensor]):
+    """The region of a leaf parameter's .grad that corresponds to t (t = the parameter itself or a basic slice of it)."""
+    if t is None:
+        return None
+    base = t._base if t._base is not None else t
+    g = base.grad
+    if (not base.is_leaf or g is None or g.dtype != torch.float32 or g.shape != base.shape or g.stride() != base.stride()
+            or t.dtype != torch.float32):
+        return False
+    return g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset() + g.storage_offset())
+
+
+def grad_sinks(w1, b1, w2, b2, gamma, beta):
+    """Destinations for p4c_row_mlp_bwd_accumulate, or None when any parameter has no gradient buffer yet (e.g. before the first
+    backward, or after zero_grad(set_to_none=True)) -- the caller then takes the ordinary autograd path."""
+    if not torch.is_grad_enabled():
+        return None
+    views = [_grad_view(t) for t in (w1, b1, w2, b2, gamma, beta)]
+    if any(v is False for v in views):
+        return None
+    if any(t is not None and not t.requires_grad for t in (w1, b1, w2, b2, gamma, beta)):
+        return None
+    if views[0].stride(1) != 1 or not views[2].is_contiguous():
+        return None
+    return tuple(views)

@@ -756,3 +756,44 @@ def test_row_mlp_prepared_parameters_follow_updates(gpu_device):
     L.PARAM_EPOCH[0] += 1                                                     # ... which is what FlatAdamW signals this way
     y2 = row_mlp(x, w1, None, w2, None)[0].float()
     assert _rel(y2, y0) < 2e-2
+
+
+def test_row_mlp_gradients_in_place(gpu_device):
+    """grads_in_place: the kernel adds parameter gradients into existing .grad buffers (incl. a column slice of a wider weight);
+    same result as the autograd path; falls back when a buffer is missing."""
+    from py4cast_amd.ops_mlp import row_mlp
+
+    torch.manual_seed(161)
+    R = 3000
+    x = torch.randn(R, 64, device=gpu_device).bfloat16().requires_grad_(True)
+    res = torch.randn(R, 64, device=gpu_device).bfloat16()
+
+    def params():
+        torch.manual_seed(162)
+        wide = (torch.randn(64, 192, device=gpu_device) * 0.1).requires_grad_(True)
+        others = [(torch.randn(64, device=gpu_device) * 0.1).requires_grad_(True), (torch.randn(64, 64, device=gpu_device) * 0.1).requires_grad_(True),
+                  (torch.randn(64, device=gpu_device) * 0.1).requires_grad_(True), (torch.rand(64, device=gpu_device) + 0.5).requires_grad_(True),
+                  (torch.randn(64, device=gpu_device) * 0.1).requires_grad_(True)]
+        return wide, others
+
+    def run(in_place, prefill):
+        wide, (b1, w2, b2, g, b) = params()
+        if prefill is not None:
+            for t in (wide, b1, w2, b2, g, b):
+                t.grad = torch.full_like(t, prefill)
+        x.grad = None
+        for _ in range(2):     # two applications accumulate, as two AR steps do
+            _, y = row_mlp(x, wide[:, 64:128], b1, w2, b2, g, b, 1e-5, res=res, want_out=False, grads_in_place=in_place)
+            y.float().square().mean().backward()
+        return [t.grad.clone() for t in (wide, b1, w2, b2, g, b)], x.grad.clone()
+
+    ref, xref = run(False, 0.25)
+    got, xgot = run(True, 0.25)
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 1e-6
+    assert torch.equal(xgot, xref)
+    assert float((got[0][:, :64] - 0.25).abs().max()) == 0.0      # the rest of the wide gradient is untouched
+    fallback, _ = run(True, None)                                   # no .grad buffers yet: ordinary autograd path
+    plain, _ = run(False, None)
+    for a, b in zip(fallback, plain):
+        assert torch.equal(a, b)
