@@ -386,15 +386,18 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             in.x[s] = live ? v : zero8();
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
-            in.dy[q] = in.dyr[q] = z4;
-            if (has_dy) {
-                const bf16x4 v = *reinterpret_cast<const bf16x4*>(a.dy + rc * HID + c0);
+        for (int q = 0; q < 8; ++q) in.dy[q] = in.dyr[q] = z4;
+        if (has_dy) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>(a.dy + rc * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
                 in.dy[q] = live ? v : z4;
             }
-            if (has_dyr) {
-                const bf16x4 v = *reinterpret_cast<const bf16x4*>(a.dy_res + rc * HID + c0);
+        }
+        if (has_dyr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bf16x4 v = *reinterpret_cast<const bf16x4*>(a.dy_res + rc * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
                 in.dyr[q] = live ? v : z4;
             }
         }
@@ -410,11 +413,14 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
     };
     auto load_gather = [&](TileGather& g, int ja, int jb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
-            g.a[q] = g.b[q] = z4;
-            if (a.ga) g.a[q] = *reinterpret_cast<const bf16x4*>(a.ga + (int64_t)ja * HID + c0);
-            if (a.gb) g.b[q] = *reinterpret_cast<const bf16x4*>(a.gb + (int64_t)jb * HID + c0);
+        for (int q = 0; q < 8; ++q) g.a[q] = g.b[q] = z4;
+        if (a.ga) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g.a[q] = *reinterpret_cast<const bf16x4*>(a.ga + (int64_t)ja * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+        }
+        if (a.gb) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g.b[q] = *reinterpret_cast<const bf16x4*>(a.gb + (int64_t)jb * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
         }
     };
 
@@ -626,7 +632,7 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             }
         }
         lds_order();
-        cur = nxt;
+        cur = nxt;     // (a two-tile unrolled loop with swapped buffers avoids these copies but spills: 169 registers)
         if (GATHER) gcur = gnxt;
     }
 
