@@ -97,7 +97,7 @@ class HiLamMI355X(ModelABC, nn.Module):
         self.m2g_gnn = InteractionNet(h, hl, update_edges=False)
         self.output_map = make_mlp(bp + [out_channels], layer_norm=False)
         self.timed_entry_points = ("p4c_edge_gather_add_fwd", "p4c_edge_gather_add_bwd", "p4c_segment_sum", "p4c_row_layernorm_fwd",
-                                   "p4c_row_layernorm_bwd", "p4c_row_linear_wgrad", "p4c_row_mlp_fwd", "p4c_row_mlp_bwd")
+                                   "p4c_row_layernorm_bwd", "p4c_row_linear_wgrad", "p4c_row_mlp_fwd", "p4c_row_mlp_bwd", "p4c_row_mlp_bwd_accumulate")
         self.roofline_from_entry_points = True
         self.prefers_hip_graph = True   # ~10^4 launches per training step: host-bound when launched eagerly (trainer.GraphedTrainingStep)
         self.check_required_attributes()
