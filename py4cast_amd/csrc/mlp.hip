@@ -181,77 +181,6 @@ __global__ void __launch_bounds__(256) row_mlp_prepare_kernel(MlpArgs a, char* b
     build_image(w1timg, NKT, 4, a.w1, a.ldw1, a.Kreal, HID, true, true, tid, n);
 }
 
-// the forward of one 32-row tile up to z (pre-LayerNorm output).  Row of this lane: row0 + (lane & 31).
-template <int KS>
-struct Tile {
-    bf16x8 xop[KS];
-    float pre[32];   // [m * 16 + i]: hidden feature 32 m + rowmap(i) + 4 h
-    float z[32];     // output feature, same indexing
-};
-
-template <int KS>
-__device__ __forceinline__ void tile_forward(Tile<KS>& t, const MlpArgs& a, const bf16* w1img, const bf16* w2img, const float* lc,
-                                             int64_t row, bool live, int lane, float* hval /*32 or null*/) {
-    const int h = lane >> 5;
-    constexpr int K = 16 * KS;
-    const int64_t rc = live ? row : 0;   // clamped address: every lane issues the same loads, dead rows are zeroed afterwards
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.x + rc * K + 16 * s + 8 * h);
-        t.xop[s] = live ? v : zero8();
-    }
-    // gathered addends: one (wave-uniform) branch per source around all eight 8-byte pieces of the row
-    const bf16x4 z4 = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-    bf16x4 pa[8], pb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) pa[q] = pb[q] = z4;
-    if (a.ga) {
-        const int64_t ja = a.ia ? (int64_t)a.ia[rc] : rc;   // no index list: the addend is row-aligned
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pa[q] = *reinterpret_cast<const bf16x4*>(a.ga + ja * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
-    }
-    if (a.gb) {
-        const int64_t jb = a.ib ? (int64_t)a.ib[rc] : rc;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pb[q] = *reinterpret_cast<const bf16x4*>(a.gb + jb * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
-    }
-    f32x16 acc[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        acc[m] = zero16();
-#pragma unroll
-        for (int s = 0; s < KS; ++s) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1img, KS, m, s, lane), t.xop[s], acc[m], 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int m = q >> 2, g = q & 3;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(lc + 32 * m + 8 * g + 4 * h);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t.pre[m * 16 + 4 * g + e] = acc[m][4 * g + e] + (v[e] + ((float)pa[q][e] + (float)pb[q][e]));
-    }
-    float hv[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        hv[i] = t.pre[i] * silu_sig(t.pre[i]);
-        if (hval) hval[i] = hv[i];
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        acc[m] = zero16();
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp)
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w2img, 4, m, sp, lane), acc_op(hv + 16 * (sp >> 1), sp & 1), acc[m], 0, 0, 0);
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(lc + 64 + 32 * m + 8 * g + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t.z[m * 16 + 4 * g + e] = acc[m][4 * g + e] + v[e];
-        }
-}
-
 // LayerNorm statistics of the lane's row (the 64 features live on this lane and its partner in the other half)
 __device__ __forceinline__ void row_stats(const float* z, float eps, float& mean, float& rstd) {
     float s = 0.f;
@@ -266,53 +195,157 @@ __device__ __forceinline__ void row_stats(const float* z, float eps, float& mean
     rstd = rsqrtf(q * (1.f / 64.f) + eps);
 }
 
-constexpr int fwd_lds_bytes(int KS) { return 4 * HID * 4 + (2 * KS + 8) * 1024; }
+// ---------------------------------------------------------------------------------------------- forward
+// Rows enter and leave through a per-wave LDS staging tile: HBM sees 16 bytes per lane with 8 lanes per 128-byte row (whole cache
+// lines per instruction), the MFMA / accumulator layout (a lane = one row, 8-byte pieces of it) is taken from LDS.  Reading the
+// pieces straight from HBM touches every line of a row in 8 separate instructions and runs at a quarter of this rate (L1 bound).
+constexpr int SROW = HID * 2 + 16;   // staged row stride
+template <int KS> constexpr int stage_bytes() { return 32 * ((16 * KS * 2 + 16) > SROW ? (16 * KS * 2 + 16) : SROW); }
+template <int KS> constexpr int fwd_lds_bytes() { return 4 * HID * 4 + (2 * KS + 8) * 1024 + 4 * stage_bytes<KS>(); }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KS>
-__global__ void __launch_bounds__(256, 4) row_mlp_fwd_kernel(MlpArgs a) {
+__global__ void __launch_bounds__(256, 2) row_mlp_fwd_kernel(MlpArgs a) {
+    constexpr int K = 16 * KS, XV = K / 8, XROW = K * 2 + 16, X_IT = (32 * XV + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lc = reinterpret_cast<float*>(smem);
     bf16* w1img = reinterpret_cast<bf16*>(smem + 4 * HID * 4);
     bf16* w2img = w1img + 2 * KS * 512;
+    char* stg = smem + 4 * HID * 4 + (2 * KS + 8) * 1024 + (threadIdx.x >> 6) * stage_bytes<KS>();
     stage_parameters<KS, false>(smem, a);
     __syncthreads();
     const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
+    const int rsub = lane >> 3, chunk = lane & 7;            // row layout: rows 8 it + rsub, 16-byte chunk
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
     const int64_t ntiles = (a.R + 31) / 32;
+    const bool has_ga = a.ga != nullptr, has_gb = a.gb != nullptr, has_res = a.out_res != nullptr, has_ln = a.gamma != nullptr;
+
     for (int64_t tIdx = wave; tIdx < ntiles; tIdx += nwaves) {
         asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads (weights, constants) inside the loop: hoisted, they spill
-        const int64_t row = tIdx * 32 + r;
-        const bool live = row < a.R;
-        Tile<KS> t;
-        tile_forward<KS>(t, a, w1img, w2img, lc, row, live, lane, nullptr);
-        float mean = 0.f, rstd = 1.f;
-        if (a.gamma) row_stats(t.z, a.eps, mean, rstd);
+        const int64_t row0 = tIdx * 32;
+        const int64_t last = a.R - 1;
+        // ---- all HBM loads of the tile, row layout (addresses of rows past the end are clamped: their results are never stored)
+        u32x4 vx[X_IT], va[4], vb[4], vr[4];
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int v = lane + 64 * it, rr = v / XV, c = v - rr * XV;
+            int64_t gr = row0 + (rr < 32 ? rr : 31);
+            gr = gr < last ? gr : last;
+            vx[it] = reinterpret_cast<const u32x4*>(a.x)[gr * XV + c];
+        }
+        int64_t rl = row0 + r;
+        rl = rl < last ? rl : last;
+        if (has_ga) {
+            const int ia = a.ia ? a.ia[rl] : (int)rl;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) va[it] = reinterpret_cast<const u32x4*>(a.ga)[(int64_t)__shfl(ia, 8 * it + rsub, 64) * 8 + chunk];
+        }
+        if (has_gb) {
+            const int ib = a.ib ? a.ib[rl] : (int)rl;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) vb[it] = reinterpret_cast<const u32x4*>(a.gb)[(int64_t)__shfl(ib, 8 * it + rsub, 64) * 8 + chunk];
+        }
+        if (has_res) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int64_t gr = row0 + 8 * it + rsub;
+                gr = gr < last ? gr : last;
+                vr[it] = reinterpret_cast<const u32x4*>(a.res)[gr * 8 + chunk];
+            }
+        }
+        // ---- x through the staging tile -> B operands -> pre = W1 x
+        bf16x8 xop[KS];
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int v = lane + 64 * it, rr = v / XV, c = v - rr * XV;
+            if (rr < 32) *reinterpret_cast<u32x4*>(stg + rr * XROW + c * 16) = vx[it];
+        }
+        lds_order();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xop[s] = *reinterpret_cast<const bf16x8*>(stg + r * XROW + (16 * s + 8 * h) * 2);
+        lds_order();
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            acc[m] = zero16();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1img, KS, m, s, lane), xop[s], acc[m], 0, 0, 0);
+        }
+        float pre[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lc + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pre[4 * q + e] = acc[q >> 2][4 * (q & 3) + e] + v[e];
+        }
+        // ---- gathered addends through the staging tile (one source after the other)
+        auto add_staged = [&](const u32x4 (&v)[4], float* dstv) __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(stg + (8 * it + rsub) * SROW + chunk * 16) = v[it];
+            lds_order();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bf16x4 pc = *reinterpret_cast<const bf16x4*>(stg + r * SROW + (32 * (q >> 2) + 8 * (q & 3) + 4 * h) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dstv[4 * q + e] += (float)pc[e];
+            }
+            lds_order();
+        };
+        if (has_ga) add_staged(va, pre);
+        if (has_gb) add_staged(vb, pre);
+        // ---- h = silu(pre) -> z = W2 h + b2 -> LayerNorm
+        float hv[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) hv[i] = pre[i] * silu_sig(pre[i]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            acc[m] = zero16();
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp)
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w2img, 4, m, sp, lane), acc_op(hv + 16 * (sp >> 1), sp & 1), acc[m], 0, 0, 0);
+        }
         float y[32];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0), bt = *reinterpret_cast<const f32x4*>(lc + 192 + c0);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lc + 64 + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[4 * q + e] = a.gamma ? (t.z[4 * q + e] - mean) * rstd * gm[e] + bt[e] : t.z[4 * q + e];
+            for (int e = 0; e < 4; ++e) y[4 * q + e] = acc[q >> 2][4 * (q & 3) + e] + v[e];
         }
-        const int64_t rc = live ? row : 0;
-        bf16x4 rv[8];
-        if (a.out_res) {
+        if (has_ln) {
+            float mean, rstd;
+            row_stats(y, a.eps, mean, rstd);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rv[q] = *reinterpret_cast<const bf16x4*>(a.res + rc * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+            for (int q = 0; q < 8; ++q) {
+                const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0), bt = *reinterpret_cast<const f32x4*>(lc + 192 + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[4 * q + e] = (y[4 * q + e] - mean) * rstd * gm[e] + bt[e];
+            }
         }
-        if (live) {
-            if (a.out) {
+        // ---- outputs through the staging tile: accumulator-layout pieces in, whole rows out
+        auto store_staged = [&](bf16* dst) __attribute__((always_inline)) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    store4(a.out + row * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h, y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-            }
-            if (a.out_res) {
+            for (int q = 0; q < 8; ++q)
+                store4(reinterpret_cast<bf16*>(stg + r * SROW + (32 * (q >> 2) + 8 * (q & 3) + 4 * h) * 2), y[4 * q], y[4 * q + 1], y[4 * q + 2],
+                       y[4 * q + 3]);
+            lds_order();
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    store4(a.out_res + row * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h, y[4 * q] + (float)rv[q][0], y[4 * q + 1] + (float)rv[q][1],
-                           y[4 * q + 2] + (float)rv[q][2], y[4 * q + 3] + (float)rv[q][3]);
+            for (int it = 0; it < 4; ++it) {
+                const int rr = 8 * it + rsub;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stg + rr * SROW + chunk * 16);
+                if (row0 + rr < a.R) reinterpret_cast<u32x4*>(dst)[(row0 + rr) * 8 + chunk] = v;
             }
+            lds_order();
+        };
+        if (a.out) store_staged(a.out);
+        if (has_res) {
+            float zero[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) zero[i] = 0.f;
+            (void)zero;
+            add_staged(vr, y);
+            store_staged(a.out_res);
         }
     }
 }
@@ -772,8 +805,8 @@ int check_args(const char* name, const MlpArgs& a, int K) {
 
 template <int KS>
 int launch_fwd(const MlpArgs& a, hipStream_t s) {
-    constexpr int smem = fwd_lds_bytes(KS);
-    hipLaunchKernelGGL(row_mlp_fwd_kernel<KS>, dim3(mlp_grid(a.R, 8)), dim3(256), smem, s, a);
+    constexpr int smem = fwd_lds_bytes<KS>();
+    hipLaunchKernelGGL(row_mlp_fwd_kernel<KS>, dim3(mlp_grid(a.R, 4)), dim3(256), smem, s, a);
     P4C_CHECK_LAUNCH("row_mlp_fwd");
     return P4C_OK;
 }

@@ -12,6 +12,7 @@ from py4cast_amd import _lib as L  # noqa: E402
 from py4cast_amd import ops_graph as G  # noqa: E402
 from py4cast_amd import ops_rows as R  # noqa: E402
 from py4cast_amd.ops_attention import window_attention  # noqa: E402
+from py4cast_amd.ops_mlp import row_mlp  # noqa: E402
 
 once = "--once" in sys.argv
 dev = torch.device("cuda:0")
@@ -55,8 +56,31 @@ def attn_bwd():
     return lambda: torch.autograd.grad(out, (q, bb), dout, retain_graph=True)
 
 
+def mlp_pair():
+    """fused edge MLP of the mesh->grid InteractionNet: forward, and forward + backward (the difference is the backward)"""
+    w1 = (torch.randn(64, 192, device=dev) * 0.1).requires_grad_(True)
+    b1, b2 = [(torch.randn(64, device=dev) * 0.1).requires_grad_(True) for _ in range(2)]
+    w2 = (torch.randn(64, 64, device=dev) * 0.1).requires_grad_(True)
+    g, bt = (torch.rand(64, device=dev) + 0.5).requires_grad_(True), torch.zeros(64, device=dev, requires_grad=True)
+    e = base.clone().requires_grad_(True)
+    aa, bb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+
+    def fwd():
+        return row_mlp(e, w1[:, :64], b1, w2, b2, g, bt, 1e-5, ga=aa, gb=bb, edges=es, res=e)
+
+    def fwd_bwd():
+        msg, new_e = fwd()
+        torch.autograd.grad((msg, new_e), (e, aa, bb, w1, w2), (base2, base2))
+
+    return fwd, fwd_bwd
+
+
+mlp_fwd, mlp_fwd_bwd = mlp_pair()
 row = C * 2
 cases = {
+    "row_mlp_fwd (m2g edge MLP: gathers, LN, msg + residual out)": (mlp_fwd, E2 * row * 4 + (B * n_mesh + B * n_grid) * row + 8 * E2),
+    "row_mlp fwd + bwd (+ 2 segment sums of dpre)": (mlp_fwd_bwd, E2 * row * 4 + E2 * row * 5 + 2 * (B * n_mesh + B * n_grid) * row + 16 * E2
+                                                     + 2 * E2 * row),
     "edge_gather_add_fwd (m2g, silu)": (lambda: G._gather_raw(base, a, es.src, b, es.dst, None, 2, E2, C, base),
                                         2 * E2 * row + (B * n_mesh + B * n_grid) * row + 8 * E2),
     "edge_gather_add_bwd (m2g, silu)": (lambda: G._gather_raw(base, a, es.src, b, es.dst, base2, 2, E2, C, base),
