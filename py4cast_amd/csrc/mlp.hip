@@ -591,11 +591,13 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h, i = 4 * q;
             store4(reinterpret_cast<bf16*>(imgDP + r * PROW + c0 * 2), pre[i], pre[i + 1], pre[i + 2], pre[i + 3]);
         }
-        if (a.dpre && live) {
+        if (a.dpre) {   // whole rows from the image just written (16 bytes per lane: full cache lines per store instruction)
+            lds_order();
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h, i = 4 * q;
-                store4(a.dpre + row * HID + c0, pre[i], pre[i + 1], pre[i + 2], pre[i + 3]);
+            for (int it = 0; it < 4; ++it) {
+                const int rr = 8 * it + (lane >> 3);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(imgDP + rr * PROW + (lane & 7) * 16);
+                if (tIdx * 32 + rr < a.R) reinterpret_cast<u32x4*>(a.dpre)[(tIdx * 32 + rr) * 8 + (lane & 7)] = v;
             }
         }
         // ---- dx = W1^T dpre
