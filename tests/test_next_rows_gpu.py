@@ -149,3 +149,43 @@ def test_dataset_stats_match_reference(gpu_device):
     got, exp = ds.nan_moments(x.to(gpu_device)).cpu(), ref(x)
     assert torch.equal(got[2], exp[2]) and torch.equal(got[3], exp[3]) and torch.equal(got[4], exp[4])
     np.testing.assert_allclose(got[:2].numpy(), exp[:2].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_titan_npy_layout_to_device_batch_bit_exact(gpu_device, tmp_path):
+    """8f-4: planes written in Titan's layout (one .npy per date and parameter) -> pinned buffer -> one transfer -> one
+    standardise + pack kernel, against the reference's np.load / (arr - mean) / std / stack / concat (datasets/base.py:431-527)."""
+    import datetime as dt
+
+    from py4cast_amd import diskio
+    from py4cast_amd.base import Stats
+    from py4cast_amd.namedtensor import NamedTensor
+
+    rng = np.random.default_rng(3)
+    H, W, B, T, T_in = 12, 20, 2, 4, 1
+    params = [("aro_t2m", 2, "heightAboveGround"), ("aro_z", 500, "isobaricInhPa"), ("aro_u", 850, "isobaricInhPa")]
+    dates = [[dt.datetime(2023, 1, 1 + b, 3 * t) for t in range(T)] for b in range(B)]
+    names, planes = [], {}
+    for (n, lv, lt) in params:
+        names.append(f"{n}_{lv}{'m' if lt == 'heightAboveGround' else 'hpa'}")
+        for b in range(B):
+            for t in range(T):
+                p = diskio.titan_plane_path(tmp_path, n, lv, lt, dates[b][t])
+                p.parent.mkdir(parents=True, exist_ok=True)
+                arr = (rng.standard_normal((H, W)) * 50 + 270).astype(np.float32)
+                np.save(p, arr)
+                planes[(names[-1], b, t)] = arr
+    stats_dict = {nm: {"mean": torch.tensor(float(260 + 5 * i)), "std": torch.tensor(float(3 + i))} for i, nm in enumerate(names)}
+    diskio.save_stats(stats_dict, tmp_path / "parameters_stats.pt")
+    stats = diskio.load_stats(tmp_path / "parameters_stats.pt")
+    forcing = NamedTensor(torch.zeros(B, T - T_in, H, W, 1, device=gpu_device), ["batch", "timestep", "lat", "lon", "features"], ["x"])
+    batch = diskio.load_titan_batch(tmp_path, params, dates, stats, T_in, forcing, device=gpu_device)
+    # the reference's arithmetic, parameter by parameter (numpy float32 planes, float32 0-d statistics)
+    per_param = []
+    for nm in names:
+        arr = np.stack([np.stack([planes[(nm, b, t)] for t in range(T)]) for b in range(B)])          # (B,T,H,W)
+        mean, std = np.asarray(stats[nm]["mean"]), np.asarray(stats[nm]["std"])
+        per_param.append(torch.from_numpy((arr - mean) / std))
+    ref = torch.stack(per_param, dim=-1).float()
+    assert batch.inputs.tensor.shape == (B, T_in, H, W, 3) and batch.outputs.tensor.shape == (B, T - T_in, H, W, 3)
+    assert torch.equal(batch.inputs.tensor.cpu(), ref[:, :T_in]) and torch.equal(batch.outputs.tensor.cpu(), ref[:, T_in:])
+    assert batch.inputs.feature_names == names
