@@ -7,6 +7,10 @@
 // (next conv's tile staging, the pool, the up-sample-and-sum, the backward passes) and is never
 // written to HBM.  scale/shift/mean/rstd are (B,64) arrays for both norm types (BatchNorm repeats
 // the same row for every b), so consumers are norm-agnostic.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace p4c {
@@ -154,6 +158,74 @@ __global__ void __launch_bounds__(256)
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[st][k][c];
+        partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = s;
+    }
+}
+
+// The same pass for bf16 storage with 16-byte loads (8 channels per thread, 8 threads per pixel, 32 pixels per block iteration)
+// and four iterations of both tensors in flight per thread: the 8-byte-per-lane form above streams the full-resolution maps at
+// 3.6 TB/s (37 us per launch, rocprofv3), this one is what the row kernels of rows.hip reach (>5 TB/s).  Same partial layout.
+typedef unsigned int norm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void unpack8(const norm_u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__global__ void __launch_bounds__(256)
+    norm_bwd_reduce_bf16x8_kernel(const __bf16* __restrict__ dA, const __bf16* __restrict__ y, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                  int relu, int64_t hw, float* __restrict__ partial) {
+    __shared__ float red[2][32][65];
+    const int b = blockIdx.y;
+    const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;   // 32 pixels per block iteration
+    float sc[8], sh[8], mu[8], rs[8], a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[b * C + 8 * c8 + j]; sh[j] = shift[b * C + 8 * c8 + j];
+        mu[j] = mean[b * C + 8 * c8 + j]; rs[j] = rstd[b * C + 8 * c8 + j];
+        a1[j] = a2[j] = 0.f;
+    }
+    const norm_u32x4* yb = reinterpret_cast<const norm_u32x4*>(y + (int64_t)b * hw * C);
+    const norm_u32x4* gb = reinterpret_cast<const norm_u32x4*>(dA + (int64_t)b * hw * C);
+    const int64_t stride = (int64_t)gridDim.x * 32;
+    for (int64_t p0 = (int64_t)blockIdx.x * 32 + pl; p0 < hw; p0 += 4 * stride) {
+        norm_u32x4 vy[4], vg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + u * stride;
+            vy[u] = vg[u] = norm_u32x4{0u, 0u, 0u, 0u};
+            if (p < hw) {
+                vy[u] = yb[p * 8 + c8];
+                vg[u] = gb[p * 8 + c8];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float fy[8], fg[8];
+            unpack8(vy[u], fy);
+            unpack8(vg[u], fg);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float g = fg[j];
+                if (relu) g = (fy[j] * sc[j] + sh[j]) > 0.f ? g : 0.f;
+                a1[j] += g;
+                a2[j] += g * ((fy[j] - mu[j]) * rs[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[0][pl][8 * c8 + j] = a1[j];
+        red[1][pl][8 * c8 + j] = a2[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += red[st][k][c];
         partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = s;
     }
 }
@@ -539,8 +611,12 @@ static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* 
                       int training, float* partial, float* k1, float* k2, float* dgamma, float* dbeta, T* dY,
                       hipStream_t stream) {
     const int nblk = norm_bwd_blocks(hw);
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk, B), dim3(256), 0, stream, dA, y, scale, shift, mean, rstd,
-                       relu, hw, partial);
+    if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_REDUCE_V1") == nullptr)
+        hipLaunchKernelGGL(norm_bwd_reduce_bf16x8_kernel, dim3(nblk, B), dim3(256), 0, stream, (const __bf16*)dA, (const __bf16*)y, scale,
+                           shift, mean, rstd, relu, hw, partial);
+    else
+        hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk, B), dim3(256), 0, stream, dA, y, scale, shift, mean, rstd,
+                           relu, hw, partial);
     P4C_CHECK_LAUNCH("norm_bwd_reduce");
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(mode == 0 ? C : groups), dim3(256), 0, stream, partial, nblk, B, hw,
                        mode, groups, training, gamma, dgamma, dbeta, k1, k2);
