@@ -139,7 +139,7 @@ def cpu_baseline(args, seconds):
         params = [scaler]
         model_fn = lambda x: x[..., :F] * scaler
         features_second = False
-    elif args.model.startswith("GraphLam"):
+    elif args.model.lower().startswith("graphlam"):
         from oracle.graphlam import GraphLam as OracleGraphLam
         from py4cast_amd.graph_build import build_mesh_graph   # host-side graph construction (data for the oracle)
 
@@ -155,7 +155,7 @@ def cpu_baseline(args, seconds):
         interior, statics = 1.0 - case["border_mask"], case["statics"].unsqueeze(0)
         model_fn = net
         features_second = False
-    elif args.model.startswith(("HiLAM", "HiLam")):
+    elif args.model.lower().startswith("hilam"):
         from oracle.hilam import HiLam as OracleHiLam, HiLamParallel as OracleHiLamParallel
         from py4cast_amd.graph_build import build_hierarchical_graph   # host-side graph construction (data for the oracle)
 
@@ -172,7 +172,7 @@ def cpu_baseline(args, seconds):
         interior, statics = 1.0 - case["border_mask"], case["statics"].unsqueeze(0)
         model_fn = net
         features_second = False
-    elif args.model.startswith("Swin"):
+    elif args.model.lower().startswith("swin"):
         from oracle.swinunetr import SwinUNetR as OracleSwin
 
         net = OracleSwin(F + 4 + 5, F)
@@ -235,9 +235,9 @@ def main():
     case = synthetic_case(1234 + rank, B, T, 1, H, W, F, Ff, Fs, args.border, device)
     info = make_info(case, Ff)
     settings = {}
-    if args.model.startswith(("GraphLam", "HiLAM", "HiLam")):
+    if args.model.lower().startswith(("graphlam", "hilam")):
         settings = {"activation_dtype": args.act_dtype or args.dtype, "tmp_dir": os.environ.get("TMPDIR", "/tmp")}
-    elif args.model.startswith("Swin"):
+    elif args.model.lower().startswith("swin"):
         settings = {"activation_dtype": args.act_dtype or args.dtype}
     elif args.model not in ("Identity",):
         settings = {"compute_dtype": args.dtype, "activation_dtype": args.act_dtype or args.dtype}
