@@ -447,11 +447,17 @@ class AutoRegressiveLightning(_Base):
         num_blocks = int((1 - self.mask_ratio) * height * width)
         block_size_h = height // int(height**0.5)
         block_size_w = width // int(width**0.5)
-        mask = torch.ones(height, width, dtype=torch.bool)
-        for i in torch.randperm(height * width)[:num_blocks].tolist():
-            row, col = i // width, i % width
-            mask[row * block_size_h : (row + 1) * block_size_h, col * block_size_w : (col + 1) * block_size_w] = False
-        return x * mask.to(x.device)[None, :, :, None]
+        # The reference clears, for every drawn index i, the block [row*bh, (row+1)*bh) x [col*bw, (col+1)*bw) with row = i // W,
+        # col = i % W, in a Python loop over up to H*W indices.  Equivalently: pixel (y, x) is cleared iff index
+        # (y // bh) * W + (x // bw) was drawn -- one scatter and one gather on the device (same torch CPU generator draw, so the
+        # same mask bit for bit: tests/test_abi_cpu.py::test_mask_tensor_matches_reference_loop).
+        drawn = torch.randperm(height * width)[:num_blocks]
+        selected = torch.zeros(height * width, dtype=torch.bool, device=x.device)
+        selected[drawn.to(x.device)] = True
+        by = torch.arange(height, device=x.device) // block_size_h
+        bx = torch.arange(width, device=x.device) // block_size_w
+        mask = ~selected[by[:, None] * width + bx[None, :]]
+        return x * mask[None, :, :, None]
 
     def get_mask_on_nan(self, target: NamedTensor):
         """

@@ -108,3 +108,22 @@ def test_product_package_never_touches_the_oracle_or_the_reference():
     pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle)|/root/reference", re.M)
     bad = [f for f in files if os.path.isfile(f) and not f.endswith((".o", ".so")) and pat.search(open(f, errors="ignore").read())]
     assert not bad, bad
+
+
+def test_mask_tensor_matches_reference_loop():
+    """lightning.py:769-785: the vectorised block masking draws the same permutation from the CPU generator and clears exactly the
+    pixels the reference's Python loop clears (bit-exact index op)."""
+    from oracle import rollout as orollout
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    class Holder:
+        mask_ratio = 0.6
+
+    for (H, W) in ((16, 16), (20, 37), (9, 64)):
+        x = torch.randn(2, H, W, 3)
+        torch.manual_seed(5)
+        got = AutoRegressiveLightning.mask_tensor(Holder(), x)
+        torch.manual_seed(5)
+        idx = torch.randperm(H * W)[: int((1 - Holder.mask_ratio) * H * W)]
+        ref = orollout.mask_tensor(x, Holder.mask_ratio, idx)
+        assert torch.equal(got, ref), (H, W)
