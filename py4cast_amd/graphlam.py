@@ -73,6 +73,7 @@ def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     gradient), with the input / output features zero-padded to the kernel's shapes (K multiple of 16, 64 outputs)."""
     w, b = m.weight, m.bias
     if x.dtype != torch.bfloat16:
+        R.L.require_cuda(x)   # fp32 parity flavour: the GPU library's GEMM (there is no CPU path)
         return F.linear(x, w, b)
     O, K = w.shape
     kp, op = (-K) % 16, (64 - O) if O < 64 else 0

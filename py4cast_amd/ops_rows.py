@@ -88,6 +88,7 @@ class _RowLinear(torch.autograd.Function):
 def row_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x @ w.T + b`` for rows x (R, K).  bf16 rows with 64 outputs and K a multiple of 16 (<= 128) take the native weight-gradient
     kernel; everything else (fp32 parity flavour, odd shapes, few rows) is the library's Linear."""
-    if x.is_cuda and _native_wgrad_ok(x, w.shape[0], w.shape[1]):
+    L.require_cuda(x)   # no CPU path: the library GEMM below is the GPU library's
+    if _native_wgrad_ok(x, w.shape[0], w.shape[1]):
         return _RowLinear.apply(x, w, b)
     return F.linear(x, w.to(x.dtype), None if b is None else b.to(x.dtype))

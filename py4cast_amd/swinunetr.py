@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib as L
 from . import ops_rows as R
 from .base import ModelABC, ModelType
 from .ops_attention import window_attention
@@ -63,7 +64,8 @@ def relative_position_index(ws: int) -> torch.Tensor:
 
 def _layer_norm(m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     C = x.shape[-1]
-    if x.is_cuda and (C * x.element_size()) % 16 == 0 and C * x.element_size() <= 1024:
+    L.require_cuda(x)   # the model has no CPU path (rows beyond the kernel's limits use the GPU library's LayerNorm)
+    if (C * x.element_size()) % 16 == 0 and C * x.element_size() <= 1024:
         return R.row_layer_norm(x.reshape(-1, C), m.weight, m.bias, m.eps).view(x.shape)
     return F.layer_norm(x.float(), m.normalized_shape, m.weight, m.bias, m.eps).to(x.dtype)
 

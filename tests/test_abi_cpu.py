@@ -34,6 +34,20 @@ def test_no_cpu_fallback():
     x = torch.zeros(1, 1, 4, 4, 2)
     with pytest.raises(_lib.P4CError):
         ops.build_x(x, torch.zeros(1, 4, 4, 1), torch.zeros(1, 4, 4, 1))
+    # the widened model ops: no CPU path either (a CPU tensor raises before any arithmetic)
+    from py4cast_amd import ops_graph, ops_mlp, ops_rows
+    from py4cast_amd.ops_attention import window_attention
+
+    es = ops_graph.EdgeSet(torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long), 2, 2)
+    rows = torch.zeros(4, 64)
+    for call in (lambda: ops_graph.edge_gather_add(rows, None, None, es),
+                 lambda: ops_graph.aggregate_sum(rows, es),
+                 lambda: ops_rows.row_layer_norm(rows, torch.ones(64), torch.zeros(64)),
+                 lambda: ops_rows.row_linear(rows, torch.zeros(64, 64)),
+                 lambda: ops_mlp.row_mlp(rows.bfloat16(), torch.zeros(64, 64), None, torch.zeros(64, 64), None),
+                 lambda: window_attention(torch.zeros(1, 7, 7, 24), None, 1, 7)):
+        with pytest.raises(_lib.P4CError):
+            call()
 
 
 def test_namedtensor_api():
