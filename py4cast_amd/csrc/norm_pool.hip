@@ -514,6 +514,66 @@ __global__ void __launch_bounds__(256) up_bwd_x4_kernel(const T* __restrict__ dS
     up_bwd_level<T, 4>(tile, row, x0, W, c4, g, o.tx[3]);
 }
 
+// norm backward pass 2 for bf16 storage: 16-byte accesses (8 channels per thread), the seven per-channel constants of the sample in
+// registers (grid.y = sample), four pixel rows in flight.
+__device__ __forceinline__ norm_u32x4 pack8(const float* f) {
+    norm_u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned int lo = __float_as_uint(f[2 * i]), hi = __float_as_uint(f[2 * i + 1]);
+        lo = ((lo & 0x7fffffffu) > 0x7f800000u) ? ((lo >> 16) | 0x40u) : ((lo + 0x7fffu + ((lo >> 16) & 1u)) >> 16);
+        hi = ((hi & 0x7fffffffu) > 0x7f800000u) ? ((hi >> 16) | 0x40u) : ((hi + 0x7fffu + ((hi >> 16) & 1u)) >> 16);
+        v[i] = lo | (hi << 16);
+    }
+    return v;
+}
+__global__ void __launch_bounds__(256)
+    norm_bwd_apply_bf16x8_kernel(const __bf16* __restrict__ dA, const __bf16* __restrict__ y, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 const float* __restrict__ gamma, const float* __restrict__ k1, const float* __restrict__ k2, int relu,
+                                 int64_t hw, __bf16* __restrict__ dY) {
+    const int b = blockIdx.y;
+    const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float sc[8], sh[8], mu[8], rs[8], ga[8], a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = b * C + 8 * c8 + j;
+        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
+        ga[j] = gamma[8 * c8 + j]; a1[j] = k1[c]; a2[j] = k2[c];
+    }
+    const norm_u32x4* yb = reinterpret_cast<const norm_u32x4*>(y + (int64_t)b * hw * C);
+    const norm_u32x4* gb = reinterpret_cast<const norm_u32x4*>(dA + (int64_t)b * hw * C);
+    norm_u32x4* ob = reinterpret_cast<norm_u32x4*>(dY + (int64_t)b * hw * C);
+    const int64_t stride = (int64_t)gridDim.x * 32;
+    for (int64_t p0 = (int64_t)blockIdx.x * 32 + pl; p0 < hw; p0 += 4 * stride) {
+        norm_u32x4 vy[4], vg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + u * stride;
+            vy[u] = vg[u] = norm_u32x4{0u, 0u, 0u, 0u};
+            if (p < hw) {
+                vy[u] = yb[p * 8 + c8];
+                vg[u] = gb[p * 8 + c8];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t p = p0 + u * stride;
+            float fy[8], fg[8], r[8];
+            unpack8(vy[u], fy);
+            unpack8(vg[u], fg);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float g = fg[j];
+                if (relu) g = (fy[j] * sc[j] + sh[j]) > 0.f ? g : 0.f;
+                const float xh = (fy[j] - mu[j]) * rs[j];
+                r[j] = rs[j] * (ga[j] * g - a1[j] - xh * a2[j]);
+            }
+            if (p < hw) ob[p * 8 + c8] = pack8(r);
+        }
+    }
+}
+
 // enc_out_bwd: gradient wrt the (post-ReLU) output of encoder level k (at Hk x Wk):
 //   dA = [T given]   sum_y wy(y,Y) T[b,y,X,:]          (adjoint of the bilinear up-sample, y pass)
 //      + [dS given]  dS[b,Y,X,:]                        (level 1: identity)
@@ -621,8 +681,17 @@ static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* 
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(mode == 0 ? C : groups), dim3(256), 0, stream, partial, nblk, B, hw,
                        mode, groups, training, gamma, dgamma, dbeta, k1, k2);
     P4C_CHECK_LAUNCH("norm_bwd_finalize");
-    hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(ew_grid((int64_t)B * hw * 16)), dim3(256), 0, stream, dA, y, scale,
-                       shift, mean, rstd, gamma, k1, k2, relu, hw, B, dY);
+    if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_APPLY_V1") == nullptr) {
+        int64_t blocks = (hw + 127) / 128;                       // >= 4 pixel rows of 32 per workgroup
+        const int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(norm_bwd_apply_bf16x8_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const __bf16*)dA,
+                           (const __bf16*)y, scale, shift, mean, rstd, gamma, k1, k2, relu, hw, (__bf16*)dY);
+    } else {
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<T>, dim3(ew_grid((int64_t)B * hw * 16)), dim3(256), 0, stream, dA, y, scale,
+                           shift, mean, rstd, gamma, k1, k2, relu, hw, B, dY);
+    }
     P4C_CHECK_LAUNCH("norm_bwd_apply");
     return P4C_OK;
 }
