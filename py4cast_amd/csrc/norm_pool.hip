@@ -629,6 +629,74 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// enc_out_bwd for bf16 storage: 16-byte accesses (8 channels per thread, 32 pixels per block iteration), grid.y = sample; the same
+// operations in the same order per element as the generic kernel above (bit-identical results).
+__global__ void __launch_bounds__(256)
+    enc_out_bwd_bf16x8_kernel(const __bf16* __restrict__ Tx, int Hfull, int s, const __bf16* __restrict__ dS,
+                              const __bf16* __restrict__ dP, const __bf16* __restrict__ y, const float* __restrict__ scale,
+                              const float* __restrict__ shift, int Hk, int Wk, __bf16* __restrict__ dA) {
+    const int b = blockIdx.y;
+    const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = dP ? scale[b * C + 8 * c8 + j] : 0.f;
+        sh[j] = dP ? shift[b * C + 8 * c8 + j] : 0.f;
+    }
+    const int hw = Hk * Wk;
+    const norm_u32x4* dSb = dS ? reinterpret_cast<const norm_u32x4*>(dS + (int64_t)b * hw * C) : nullptr;
+    const norm_u32x4* Txb = Tx ? reinterpret_cast<const norm_u32x4*>(Tx + (int64_t)b * Hfull * Wk * C) : nullptr;
+    const norm_u32x4* yb = reinterpret_cast<const norm_u32x4*>(y + (int64_t)b * hw * C);
+    const norm_u32x4* dPb = dP ? reinterpret_cast<const norm_u32x4*>(dP + (int64_t)b * (Hk / 2) * (Wk / 2) * C) : nullptr;
+    norm_u32x4* ob = reinterpret_cast<norm_u32x4*>(dA + (int64_t)b * hw * C);
+    for (int p = blockIdx.x * 32 + pl; p < hw; p += gridDim.x * 32) {
+        const int Y = p / Wk, X = p - Y * Wk;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (dSb) unpack8(dSb[(int64_t)p * 8 + c8], acc);
+        if (Txb) {
+            int ya = s * Y - s / 2, ye = s * Y + 3 * s / 2 - 1;
+            if (ya < 0) ya = 0;
+            if (ye > Hfull - 1) ye = Hfull - 1;
+            for (int yy = ya; yy <= ye; ++yy) {
+                int y0, y1; float ly;
+                bilin(yy, s, Hk, y0, y1, ly);
+                const float w = (y0 == Y ? 1.f - ly : 0.f) + (y1 == Y ? ly : 0.f);
+                if (w != 0.f) {
+                    float t[8];
+                    unpack8(Txb[((int64_t)yy * Wk + X) * 8 + c8], t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += w * t[j];
+                }
+            }
+        }
+        if (dPb) {
+            const int Y0 = Y & ~1, X0 = X & ~1;
+            const int64_t base = ((int64_t)Y0 * Wk + X0) * 8 + c8;
+            float v[4][8], g[8];
+            unpack8(yb[base], v[0]);
+            unpack8(yb[base + 8], v[1]);
+            unpack8(yb[base + (int64_t)Wk * 8], v[2]);
+            unpack8(yb[base + (int64_t)Wk * 8 + 8], v[3]);
+            unpack8(dPb[((int64_t)(Y / 2) * (Wk / 2) + X / 2) * 8 + c8], g);
+            const int me = (Y & 1) * 2 + (X & 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int arg = 0;
+                float m = fmaxf(v[0][j] * sc[j] + sh[j], 0.f);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const float vq = fmaxf(v[q][j] * sc[j] + sh[j], 0.f);
+                    if (vq > m) { m = vq; arg = q; }
+                }
+                if (arg == me) acc[j] += g[j];
+            }
+        }
+        ob[(int64_t)p * 8 + c8] = pack8(acc);
+    }
+}
+
 static inline int ew_grid(int64_t total_threads) {
     int64_t blocks = (total_threads + 255) / 256;
     const int64_t cap = (int64_t)num_cus() * 8;
@@ -750,8 +818,17 @@ int up_bwd_x4(int storage, const void* dS, int B, int H, int W, void* const* tx,
 template <typename T>
 static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP, const T* y, const float* scale,
                          const float* shift, int B, int Hk, int Wk, T* dA, hipStream_t stream) {
-    hipLaunchKernelGGL(enc_out_bwd_kernel<T>, dim3(ew_grid((int64_t)B * Hk * Wk * 16)), dim3(256), 0, stream, Tx, Hfull, s,
-                       dS, dP, y, scale, shift, B, Hk, Wk, dA);
+    if (std::is_same<T, __bf16>::value && getenv("P4C_ENC_OUT_V1") == nullptr) {
+        int64_t blocks = ((int64_t)Hk * Wk + 31) / 32;
+        const int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(enc_out_bwd_bf16x8_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const __bf16*)Tx, Hfull, s,
+                           (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale, shift, Hk, Wk, (__bf16*)dA);
+    } else {
+        hipLaunchKernelGGL(enc_out_bwd_kernel<T>, dim3(ew_grid((int64_t)B * Hk * Wk * 16)), dim3(256), 0, stream, Tx, Hfull, s,
+                           dS, dP, y, scale, shift, B, Hk, Wk, dA);
+    }
     P4C_CHECK_LAUNCH("enc_out_bwd");
     return P4C_OK;
 }
