@@ -50,6 +50,14 @@ __global__ void __launch_bounds__(256)
     __shared__ double red[2][256];
     double s1 = 0.0, s2 = 0.0;
     int c_lo, c_hi, b_lo, b_hi;
+    // BatchNorm: the channel's parameters are requested before the partial sums are (one memory round trip less on the critical
+    // path of a kernel that is nothing but dependent round trips)
+    float pf_gamma = 0.f, pf_beta = 0.f, pf_rm = 0.f, pf_rv = 0.f;
+    if (mode == 0) {
+        pf_gamma = gamma[blockIdx.x];
+        pf_beta = beta[blockIdx.x];
+        if (running_mean) { pf_rm = running_mean[blockIdx.x]; pf_rv = running_var[blockIdx.x]; }
+    }
     if (mode == 0) {
         c_lo = blockIdx.x; c_hi = c_lo + 1; b_lo = 0; b_hi = B;
     } else {
@@ -90,11 +98,11 @@ __global__ void __launch_bounds__(256)
     if (mode == 0) {
         const int c = c_lo;
         if (threadIdx.x == 0 && running_mean) {
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_mean[c] = (1.f - momentum) * pf_rm + momentum * (float)mean;
             const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            running_var[c] = (1.f - momentum) * pf_rv + momentum * (float)unbiased;
         }
-        const float sc = gamma[c] * rstd, sh = beta[c] - (float)mean * sc;
+        const float sc = pf_gamma * rstd, sh = pf_beta - (float)mean * sc;
         for (int b = threadIdx.x; b < B; b += 256) {
             scale[b * C + c] = sc; shift[b * C + c] = sh; mean_out[b * C + c] = (float)mean; rstd_out[b * C + c] = rstd;
         }
@@ -248,6 +256,7 @@ __global__ void __launch_bounds__(256)
     float tot1 = 0.f, tot2 = 0.f;
     if (mode == 0) {
         // BatchNorm: only the totals over the batch are needed -> one pass, wave butterflies, one LDS combine
+        const float pf_gamma = gamma[c], pf_dg = dgamma[c], pf_db = dbeta[c];   // requested before the partials (see norm_finalize)
         float s1 = 0.f, s2 = 0.f;
         for (int b = 0; b < B; ++b)
             for (int k = threadIdx.x; k < nblk; k += 256) {
@@ -264,10 +273,10 @@ __global__ void __launch_bounds__(256)
         if (threadIdx.x == 0) {
             tot1 = (S[0][0] + S[0][1]) + (S[0][2] + S[0][3]);
             tot2 = (S[1][0] + S[1][1]) + (S[1][2] + S[1][3]);
-            dgamma[c] += tot2;
-            dbeta[c] += tot1;
+            dgamma[c] = pf_dg + tot2;
+            dbeta[c] = pf_db + tot1;
             const float n = (float)B * (float)hw;
-            const float a = training ? gamma[c] * tot1 / n : 0.f, bb = training ? gamma[c] * tot2 / n : 0.f;
+            const float a = training ? pf_gamma * tot1 / n : 0.f, bb = training ? pf_gamma * tot2 / n : 0.f;
             for (int b = 0; b < B; ++b) { k1[b * C + c] = a; k2[b * C + c] = bb; }
         }
         return;
