@@ -360,14 +360,39 @@ template <int KS> constexpr int bwd_lds_bytes() { return 4 * HID * 4 + bwd_weigh
 // floats of one workgroup's partial: dW1 [64][K] | dW2 [64][64] | db1 | db2 | dgamma | dbeta
 template <int KS> constexpr int partial_floats() { return HID * 16 * KS + HID * HID + 4 * HID; }
 
+// A lane of the accumulator layout owns features 8q + 4h .. +3 (q = 0..7) of its row: eight 8-byte pieces, interleaved with those
+// of its partner lane (same row, other half h).  Loaded as such, a wave instruction touches 32 rows x 16 bytes; instead each lane
+// loads the four 16-byte chunks 16i + 8h .. +7 (32 contiguous bytes per row and instruction, half the memory instructions) and
+// the partners trade the halves that belong to the other one: v_permlane32_swap exchanges lanes 32..63 of its first operand with
+// lanes 0..31 of its second, which is exactly that trade.
+typedef unsigned int mlp_u32x2 __attribute__((ext_vector_type(2)));
+struct RowChunks { u32x4 c[4]; };
+__device__ __forceinline__ void load_row_chunks(const bf16* __restrict__ rowp, int h, bool live, RowChunks& out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(rowp + 16 * i + 8 * h);
+        out.c[i] = live ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+}
+// the trade, done where the values are consumed (next to the load it would wait for the memory and undo the prefetch)
+__device__ __forceinline__ void trade_pieces(const RowChunks& in, bf16x4 (&out)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const mlp_u32x2 s0 = __builtin_amdgcn_permlane32_swap(in.c[i][0], in.c[i][2], false, false);
+        const mlp_u32x2 s1 = __builtin_amdgcn_permlane32_swap(in.c[i][1], in.c[i][3], false, false);
+        out[2 * i] = __builtin_bit_cast(bf16x4, mlp_u32x2{s0.x, s1.x});       // features 16 i + 4 h ..
+        out[2 * i + 1] = __builtin_bit_cast(bf16x4, mlp_u32x2{s0.y, s1.y});   // features 16 i + 8 + 4 h ..
+    }
+}
+
 // what a lane reads from HBM for one tile: 16-byte pieces of its row of x, 8-byte pieces of the upstream gradients
 template <int KS>
 struct TileIn {
     bf16x8 x[KS];
-    bf16x4 dy[8], dyr[8];
+    RowChunks dy, dyr;
 };
 struct TileGather {
-    bf16x4 a[8], b[8];
+    RowChunks a, b;
 };
 
 // One wave = one 32-row tile per iteration; the NEXT tile's rows, gradients and gathered rows are in flight while the current one
@@ -408,7 +433,6 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) db1[i] = db2[i] = dgam[i] = dbet[i] = 0.f;
 
-    const bf16x4 z4 = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
     auto load_in = [&](TileIn<KS>& in, int64_t tile) __attribute__((always_inline)) {
         const int64_t row = tile * 32 + r;
         const bool live = tile < ntiles && row < a.R;
@@ -419,21 +443,9 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             in.x[s] = live ? v : zero8();
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) in.dy[q] = in.dyr[q] = z4;
-        if (has_dy) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const bf16x4 v = *reinterpret_cast<const bf16x4*>(a.dy + rc * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
-                in.dy[q] = live ? v : z4;
-            }
-        }
-        if (has_dyr) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const bf16x4 v = *reinterpret_cast<const bf16x4*>(a.dy_res + rc * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
-                in.dyr[q] = live ? v : z4;
-            }
-        }
+        for (int i = 0; i < 4; ++i) in.dy.c[i] = in.dyr.c[i] = u32x4{0u, 0u, 0u, 0u};
+        if (has_dy) load_row_chunks(a.dy + rc * HID, h, live, in.dy);
+        if (has_dyr) load_row_chunks(a.dy_res + rc * HID, h, live, in.dyr);
     };
     auto load_idx = [&](int64_t tile, int& ja, int& jb) __attribute__((always_inline)) {
         const int64_t row = tile * 32 + r;
@@ -446,15 +458,9 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
     };
     auto load_gather = [&](TileGather& g, int ja, int jb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) g.a[q] = g.b[q] = z4;
-        if (a.ga) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) g.a[q] = *reinterpret_cast<const bf16x4*>(a.ga + (int64_t)ja * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
-        }
-        if (a.gb) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) g.b[q] = *reinterpret_cast<const bf16x4*>(a.gb + (int64_t)jb * HID + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
-        }
+        for (int i = 0; i < 4; ++i) g.a.c[i] = g.b.c[i] = u32x4{0u, 0u, 0u, 0u};
+        if (a.ga) load_row_chunks(a.ga + (int64_t)ja * HID, h, true, g.a);
+        if (a.gb) load_row_chunks(a.gb + (int64_t)jb * HID, h, true, g.b);
     };
 
     TileIn<KS> cur, nxt;
@@ -489,13 +495,18 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             }
 #pragma unroll
             for (int s = 0; s < KS; ++s) *reinterpret_cast<bf16x8*>(imgX + r * XROW + (16 * s + 8 * h) * 2) = cur.x[s];
+            bf16x4 pa[8], pb[8];
+            if (GATHER) {
+                trade_pieces(gcur.a, pa);
+                trade_pieces(gcur.b, pb);
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int m = q >> 2, g = q & 3, c0 = 32 * m + 8 * g + 4 * h;
                 f32x4 v = *reinterpret_cast<const f32x4*>(lc + c0);
                 if (GATHER) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)gcur.a[q][e] + (float)gcur.b[q][e];
+                    for (int e = 0; e < 4; ++e) v[e] += (float)pa[q][e] + (float)pb[q][e];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pre[m * 16 + 4 * g + e] = acc[m][4 * g + e] + v[e];
@@ -505,7 +516,13 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
         {
             float hv[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) hv[i] = pre[i] * silu_sig(pre[i]);
+            for (int i = 0; i < 32; ++i) {
+                // silu'(x) = s + h (1 - s) with s = sigmoid(x), h = x s: taken here, where s exists, so that the exp / rcp pair
+                // (quarter-rate instructions, the largest single vector cost of a tile) runs once per element, not twice
+                const float sg = silu_sig(pre[i]);
+                hv[i] = pre[i] * sg;
+                pre[i] = __builtin_fmaf(hv[i], 1.f - sg, sg);
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 store4(reinterpret_cast<bf16*>(imgH + r * PROW + (32 * (q >> 2) + 8 * (q & 3) + 4 * h) * 2), hv[4 * q], hv[4 * q + 1],
@@ -530,12 +547,15 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             float mean = 0.f, rstd = 1.f;
             if (has_ln) row_stats(zz, a.eps, mean, rstd);
             float m1 = 0.f, m2 = 0.f;
+            bf16x4 pdy[8], pdyr[8];
+            trade_pieces(cur.dy, pdy);
+            trade_pieces(cur.dyr, pdyr);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int c0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * h;
                 float d[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = (float)cur.dy[q][e] + (float)cur.dyr[q][e];
+                for (int e = 0; e < 4; ++e) d[e] = (float)pdy[q][e] + (float)pdyr[q][e];
                 if (has_ln) {
                     const f32x4 gm = *reinterpret_cast<const f32x4*>(lc + 128 + c0);
                     float dg[4];
@@ -581,10 +601,7 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w2timg, 4, m, sp, lane), acc_op(dz + 16 * (sp >> 1), sp & 1), acc[m], 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const float x = pre[i], sg = silu_sig(x);
-                pre[i] = acc[i >> 4][i & 15] * (sg * (1.f + x * (1.f - sg)));   // dpre
-            }
+            for (int i = 0; i < 32; ++i) pre[i] *= acc[i >> 4][i & 15];   // dpre = dh * silu'(pre)
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -610,14 +627,20 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
                 for (int sp = 0; sp < 4; ++sp)
                     acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1timg, 4, kt, sp, lane), acc_op(pre + 16 * (sp >> 1), sp & 1), acc[kt], 0, 0, 0);
             }
-            if (live) {
+            // the reverse trade of load_row_chunks: 16-byte stores of the chunk 16 i + 8 h .. +7
 #pragma unroll
-                for (int kt = 0; kt < NKT; ++kt)
+            for (int i = 0; i < KS; ++i) {
+                const int kt = i >> 1, g0 = 2 * (i & 1);
+                bf16x4 pa, pb;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int c0 = 32 * kt + 8 * g + 4 * h;
-                        if (c0 < K) store4(a.dx + row * K + c0, acc[kt][4 * g], acc[kt][4 * g + 1], acc[kt][4 * g + 2], acc[kt][4 * g + 3]);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    pa[e] = (__bf16)acc[kt][4 * g0 + e];
+                    pb[e] = (__bf16)acc[kt][4 * g0 + 4 + e];
+                }
+                const mlp_u32x2 ua = __builtin_bit_cast(mlp_u32x2, pa), ub = __builtin_bit_cast(mlp_u32x2, pb);
+                const mlp_u32x2 s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+                const mlp_u32x2 s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+                if (live) *reinterpret_cast<u32x4*>(a.dx + row * K + 16 * i + 8 * h) = u32x4{s0.x, s1.x, s0.y, s1.y};
             }
         }
         lds_order();
