@@ -351,6 +351,9 @@ __global__ void __launch_bounds__(256, 2) row_mlp_fwd_kernel(MlpArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------- backward
+#ifndef P4C_MLP_EXP
+#define P4C_MLP_EXP 0   // diagnostic builds: bit 0 no weight-gradient phase, 1 no column sums, 2 no HBM stores, 4 no HBM loads after the first tile
+#endif
 template <int KS> constexpr int nkt() { return (16 * KS + 31) / 32; }
 template <int KS> constexpr int xrow_bytes() { return 16 * KS * 2 + 16; }
 // per-wave LDS images of one 32-row tile: x | h | dz | dpre | d*xhat | d
@@ -474,14 +477,17 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
         load_idx(wave + nwaves, ja_n, jb_n);
     }
 
+    if (P4C_MLP_EXP & 16) { nxt = cur; gnxt = gcur; }
     for (int64_t tIdx = wave; tIdx < ntiles; tIdx += nwaves) {
         asm volatile("" ::: "memory");   // keep the loop-invariant LDS reads (weights, constants) inside the loop: hoisted, they spill
         const int64_t row = tIdx * 32 + r;
         const bool live = row < a.R;
         // ---- next tile's loads first: they stay in flight during this tile's compute
-        if (GATHER) load_gather(gnxt, ja_n, jb_n);
-        load_in(nxt, tIdx + nwaves);
-        load_idx(tIdx + 2 * nwaves, ja_n, jb_n);
+        if (!(P4C_MLP_EXP & 16)) {
+            if (GATHER) load_gather(gnxt, ja_n, jb_n);
+            load_in(nxt, tIdx + nwaves);
+            load_idx(tIdx + 2 * nwaves, ja_n, jb_n);
+        }
 
         // ---- forward recompute: pre = W1 x + b1 (+ gathers), h = silu(pre), z = W2 h + b2
         float pre[32], dz[32];
@@ -614,7 +620,7 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             for (int it = 0; it < 4; ++it) {
                 const int rr = 8 * it + (lane >> 3);
                 const u32x4 v = *reinterpret_cast<const u32x4*>(imgDP + rr * PROW + (lane & 7) * 16);
-                if (tIdx * 32 + rr < a.R) reinterpret_cast<u32x4*>(a.dpre)[(tIdx * 32 + rr) * 8 + (lane & 7)] = v;
+                if (tIdx * 32 + rr < a.R && !(P4C_MLP_EXP & 4)) reinterpret_cast<u32x4*>(a.dpre)[(tIdx * 32 + rr) * 8 + (lane & 7)] = v;
             }
         }
         // ---- dx = W1^T dpre
@@ -640,13 +646,13 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
                 const mlp_u32x2 ua = __builtin_bit_cast(mlp_u32x2, pa), ub = __builtin_bit_cast(mlp_u32x2, pb);
                 const mlp_u32x2 s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
                 const mlp_u32x2 s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
-                if (live) *reinterpret_cast<u32x4*>(a.dx + row * K + 16 * i + 8 * h) = u32x4{s0.x, s1.x, s0.y, s1.y};
+                if (live && !(P4C_MLP_EXP & 4)) *reinterpret_cast<u32x4*>(a.dx + row * K + 16 * i + 8 * h) = u32x4{s0.x, s1.x, s0.y, s1.y};
             }
         }
         lds_order();
         // ---- weight gradients: reduction over the tile's 32 rows (2 k-steps), operands by transposed reads of the images
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < ((P4C_MLP_EXP & 1) ? 0 : 2); ++ks) {
             bf16x8 adz[2], adp[2], bh[2], bx[NKT];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -670,7 +676,7 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
         }
         // ---- bias / LayerNorm-parameter gradients: column sums of the images (lane = 16-byte chunk lane & 7 of rows (lane >> 3) + 8 it)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < ((P4C_MLP_EXP & 2) ? 0 : 4); ++it) {
             const int off = ((lane >> 3) + 8 * it) * PROW + (lane & 7) * 16;
             const bf16x8 vz = *reinterpret_cast<const bf16x8*>(imgDZ + off);
             const bf16x8 vp = *reinterpret_cast<const bf16x8*>(imgDP + off);
