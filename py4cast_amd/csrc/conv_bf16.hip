@@ -1463,7 +1463,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                                  const float* __restrict__ in_shift, const __bf16* __restrict__ dout,
                                  float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip) {
     using namespace wgws;
-    constexpr int NTAPS = 9, KSTEPS = TH * BTW / 16;
+    constexpr int NTAPS = 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lnorm = reinterpret_cast<float*>(smem + 2 * BUFB);
 
@@ -1619,47 +1619,53 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (t_begin < t_end) {
         if (MODE >= 2) lds_barrier();
         lds_barrier();
-        struct Ops { s16x4 b[2]; s16x4 a[NTAPS][2]; };
+        // The K loop walks INPUT rows, not output rows: input row j of the tile feeds the taps ky of the gradient rows j - ky, so
+        // its three column-shifted operands are read once (6 transposed reads) and used by up to nine MFMAs, and the four
+        // gradient-row operands of a half tile stay in registers: 88 LDS reads per tile for 72 MFMAs instead of 160 (the reads, not
+        // the matrix pipe, bounded this phase: 58 cycles per MFMA at 2.2 reads each).
+        struct AOps { s16x4 a[3][2]; };
         for (int tile = t_begin; tile < t_end; ++tile) {
             const char* lin = smem + ((tile - t_begin) & 1) * BUFB;
             const char* ldo = lin + INB;
-            auto fetch = [&](Ops& o, int kstep) __attribute__((always_inline)) {
-                const int row = kstep >> 1, col0 = (kstep & 1) * 16;
-                const int px = col0 + 8 * h + tq;
-                const char* bp = ldo + (row * BTW + px) * ROWD + b_col;
-                o.b[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
-                o.b[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 4 * ROWD));
-                const char* ap0 = lin + (row * LW + px) * ROWA + a_col;
+            auto fetch_a = [&](AOps& o, int j, int col0) __attribute__((always_inline)) {
+                const char* ap0 = lin + (j * LW + col0 + 8 * h + tq) * ROWA + a_col;
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t) {
-                    const int ky = t / 3, kx = t - ky * 3;
-                    const char* ap = ap0 + (ky * LW + kx) * ROWA;
-                    o.a[t][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap));
-                    o.a[t][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap + 4 * ROWA));
+                for (int kx = 0; kx < 3; ++kx) {
+                    o.a[kx][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap0 + kx * ROWA));
+                    o.a[kx][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap0 + (kx + 4) * ROWA));
                 }
             };
-            auto mma = [&](const Ops& o) __attribute__((always_inline)) {
-                union { s16x4 s[2]; bf16x8 v; } ub;
-                ub.s[0] = o.b[0]; ub.s[1] = o.b[1];
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t) {
-                    union { s16x4 s[2]; bf16x8 v; } u;
-                    u.s[0] = o.a[t][0]; u.s[1] = o.a[t][1];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ub.v, acc[t], 0, 0, 0);
+            for (int half = 0; half < 2; ++half) {
+                const int col0 = half * 16;
+                s16x4 bo[TH][2];
+#pragma unroll
+                for (int rr = 0; rr < TH; ++rr) {
+                    const char* bp = ldo + (rr * BTW + col0 + 8 * h + tq) * ROWD + b_col;
+                    bo[rr][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp));
+                    bo[rr][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(bp + 4 * ROWD));
                 }
-            };
-            Ops o0, o1;
-            fetch(o0, 0);
-#pragma unroll 1
-            for (int kk = 0; kk < KSTEPS; kk += 2) {
-                fetch(o1, kk + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(o0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk + 2 < KSTEPS) fetch(o0, kk + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(o1);
-                __builtin_amdgcn_sched_barrier(0);
+                AOps ao[2];
+                fetch_a(ao[0], 0, col0);
+#pragma unroll
+                for (int j = 0; j < LH; ++j) {
+                    if (j + 1 < LH) fetch_a(ao[(j + 1) & 1], j + 1, col0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int rr = j - ky;
+                        if (rr < 0 || rr >= TH) continue;
+                        union { s16x4 s[2]; bf16x8 v; } ub;
+                        ub.s[0] = bo[rr][0]; ub.s[1] = bo[rr][1];
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            union { s16x4 s[2]; bf16x8 v; } u;
+                            u.s[0] = ao[j & 1].a[kx][0]; u.s[1] = ao[j & 1].a[kx][1];
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ub.v, acc[ky * 3 + kx], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             lds_barrier();
         }
