@@ -1115,37 +1115,34 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
         if (!(P4C_EXP & 16)) {
-            // 18 stages of (tap, channel half): 4 B reads (2 k-steps x 2 rows) feed 4 MFMAs; reads run two stages
-            // ahead through a ring of three operand buffers (>= 256 cycles of matrix work cover the LDS latency)
-            bf16x8 fb[3][2][2];
-            auto issue = [&](int s, int buf) __attribute__((always_inline)) {
-                const int tap = s >> 1, ky = tap / 3, kx = tap % 3;
-#pragma unroll
-                for (int kl = 0; kl < 2; ++kl) {
-                    const int ks = (s & 1) * 2 + kl;
-                    fb[buf][kl][0] = *reinterpret_cast<const bf16x8*>(ba[kx][ks] + ky * RROW);
-                    fb[buf][kl][1] = *reinterpret_cast<const bf16x8*>(ba[kx][ks] + (ky + 1) * RROW);
-                }
-            };
-            issue(0, 0);
-            issue(1, 1);
-            // one B read (for stage s+2) in each MFMA gap of stage s: the micro-benchmark (tools/diagnostics/mfma_rate.hip)
-            // runs 36 cycles per MFMA in this shape against 48 when the 4 reads and the 4 MFMAs of a stage go in bursts
-            auto issue1 = [&](int s, int buf, int j) __attribute__((always_inline)) {
-                const int tap = s >> 1, ky = tap / 3, kx = tap % 3;
-                const int kl = j >> 1, ks = (s & 1) * 2 + kl;
-                fb[buf][kl][j & 1] = *reinterpret_cast<const bf16x8*>(ba[kx][ks] + (ky + (j & 1)) * RROW);
+            // The wave's two output rows use the four input rows j = 0..3 of the ring: row j is tap row ky = j of output row 0
+            // and tap row ky = j - 1 of output row 1, so each of the 48 operands (j, kx, 16-channel slice) is read ONCE and feeds
+            // one MFMA (j = 0, 3) or two (j = 1, 2): 48 B reads for 72 MFMAs instead of 72.  Order: the single-use rows first,
+            // alternating j = 0 / 3 (accumulators alternate), then j = 1 and j = 2.  Reads run LEAD operands ahead of their MFMAs
+            // through a ring of LEAD + 1 buffers, one read per MFMA gap at most (bursts of reads beside MFMAs cost 48 instead of
+            // 36 cycles per MFMA, tools/diagnostics/mfma_rate.hip).
+            constexpr int LEAD = 8, NBUF_B = LEAD + 1;
+            bf16x8 fb[NBUF_B];
+            auto issue = [&](int q) __attribute__((always_inline)) {
+                const int i = q < 24 ? (q >> 1) : (q < 36 ? q - 24 : q - 36);
+                const int j = q < 24 ? ((q & 1) ? 3 : 0) : (q < 36 ? 1 : 2);
+                fb[q % NBUF_B] = *reinterpret_cast<const bf16x8*>(ba[i >> 2][i & 3] + j * RROW);
             };
 #pragma unroll
-            for (int s = 0; s < 18; ++s) {
-                const int tap = s >> 1;
+            for (int q = 0; q < LEAD; ++q) issue(q);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (s + 2 < 18) issue1(s + 2, (s + 2) % 3, j);
+            for (int q = 0; q < 48; ++q) {
+                const int i = q < 24 ? (q >> 1) : (q < 36 ? q - 24 : q - 36);
+                const int j = q < 24 ? ((q & 1) ? 3 : 0) : (q < 36 ? 1 : 2);
+                const int kx = i >> 2, ks = i & 3;
+                if (q + LEAD < 48) issue(q + LEAD);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j <= 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j * 3 + kx][ks], fb[q % NBUF_B], acc0, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int kl = j >> 1, ks = (s & 1) * 2 + kl;
-                    if ((j & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap][ks], fb[s % 3][kl][0], acc0, 0, 0, 0);
-                    else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[tap][ks], fb[s % 3][kl][1], acc1, 0, 0, 0);
+                }
+                if (j >= 1) {
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(j - 1) * 3 + kx][ks], fb[q % NBUF_B], acc1, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
