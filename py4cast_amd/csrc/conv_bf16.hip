@@ -1121,7 +1121,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             // alternating j = 0 / 3 (accumulators alternate), then j = 1 and j = 2.  Reads run LEAD operands ahead of their MFMAs
             // through a ring of LEAD + 1 buffers, one read per MFMA gap at most (bursts of reads beside MFMAs cost 48 instead of
             // 36 cycles per MFMA, tools/diagnostics/mfma_rate.hip).
-            constexpr int LEAD = 8, NBUF_B = LEAD + 1;
+#ifndef P4C_RING_LEAD
+#define P4C_RING_LEAD 8
+#endif
+            constexpr int LEAD = P4C_RING_LEAD, NBUF_B = LEAD + 1;
             bf16x8 fb[NBUF_B];
             auto issue = [&](int q) __attribute__((always_inline)) {
                 const int i = q < 24 ? (q >> 1) : (q < 36 ? q - 24 : q - 36);
