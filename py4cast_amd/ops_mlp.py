@@ -154,16 +154,7 @@ def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=N
     return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out, sinks)
 
 
-def _grad_view(t: Optional[torch.Tensor]):
-    """The region of a leaf parameter's .grad that corresponds to t (t = the parameter itself or a basic slice of it)."""
-    if t is None:
-        return None
-    base = t._base if t._base is not None else t
-    g = base.grad
-    if (not base.is_leaf or g is None or g.dtype != torch.float32 or g.shape != base.shape or g.stride() != base.stride()
-            or t.dtype != torch.float32):
-        return False
-    return g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset() + g.storage_offset())
+from .ops_rows import grad_view as _grad_view  # noqa: E402  (one definition, shared with ops_rows.row_linear)
 
 
 def grad_sinks(w1, b1, w2, b2, gamma, beta):

@@ -85,10 +85,62 @@ class _RowLinear(torch.autograd.Function):
         return dx, dw, db
 
 
-def row_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+def grad_view(t: Optional[torch.Tensor]):
+    """The region of a leaf parameter's .grad that corresponds to t (t = the parameter itself or a basic slice of it): None for
+    t = None, False when there is no such buffer (no .grad yet, another dtype or layout)."""
+    if t is None:
+        return None
+    base = t._base if t._base is not None else t
+    g = base.grad
+    if (not base.is_leaf or g is None or g.dtype != torch.float32 or g.shape != base.shape or g.stride() != base.stride()
+            or t.dtype != torch.float32):
+        return False
+    return g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset() + g.storage_offset())
+
+
+class _RowLinearSink(torch.autograd.Function):
+    """``x @ W^T`` on bf16 rows whose weight gradient the backward ADDS into ``gw`` -- the view of the parameter's ``.grad`` that
+    corresponds to W -- instead of handing it to autograd.  W is typically a column block of a wider Linear (the sender / receiver
+    parts of an edge MLP's first layer): through autograd each backward cost a zero-filled full-size gradient, a copy into its
+    slice, a cast and an accumulation (four launches beside the product itself; ~1 700 of them per HiLAM step)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gw):
+        # w (the live parameter view) is an input so that the node is recorded even when x needs no gradient; its gradient slot
+        # returns None: autograd must not also accumulate what the backward adds itself
+        wq = w.detach().to(x.dtype)
+        ctx.save_for_backward(x, wq)
+        ctx.gw = gw
+        return F.linear(x, wq)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, K = x.shape
+        O = wq.shape[0]
+        dx = dy @ wq if ctx.needs_input_grad[0] else None
+        if _native_wgrad_ok(x, O, K):
+            buf = torch.empty(O * K + O, dtype=torch.float32, device=x.device)
+            nbytes = L.lib().p4c_row_linear_wgrad_workspace_bytes(R, K)
+            ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+            L.call("p4c_row_linear_wgrad", L.ptr(dy), L.ptr(x.contiguous()), L.ptr(buf), L.ptr(ws), R, O, K, L.dtype_code(x.dtype),
+                   L.stream(x.device), alg_bytes=R * (O + K) * x.element_size())
+            ctx.gw.add_(buf[: O * K].view(O, K))
+        else:
+            ctx.gw.add_(dy.t() @ x)   # library GEMM in the rows' dtype (what autograd's Linear backward computes), promoted add
+        return dx, None, None
+
+
+def row_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, grads_in_place: bool = False) -> torch.Tensor:
     """``x @ w.T + b`` for rows x (R, K).  bf16 rows with 64 outputs and K a multiple of 16 (<= 128) take the native weight-gradient
-    kernel; everything else (fp32 parity flavour, odd shapes, few rows) is the library's Linear."""
+    kernel; everything else (fp32 parity flavour, odd shapes, few rows) is the library's Linear.  ``grads_in_place`` (bias-free
+    bf16 case): the weight gradient is accumulated straight into the parameter's ``.grad`` when that buffer exists."""
     L.require_cuda(x)   # no CPU path: the library GEMM below is the GPU library's
+    if grads_in_place and b is None and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and w.requires_grad:
+        gw = grad_view(w)
+        if gw is not None and gw is not False:
+            return _RowLinearSink.apply(x, w, gw)
     if _native_wgrad_ok(x, w.shape[0], w.shape[1]):
         return _RowLinear.apply(x, w, b)
     return F.linear(x, w.to(x.dtype), None if b is None else b.to(x.dtype))

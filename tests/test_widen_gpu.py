@@ -799,6 +799,44 @@ def test_row_mlp_gradients_in_place(gpu_device):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("R", [300, 9000])
+def test_row_linear_gradient_in_place(gpu_device, R):
+    """row_linear(grads_in_place=True) on a column block of a wider weight: the block's gradient is added into the parameter's .grad
+    by the backward (library GEMM for few rows, the tall-skinny kernel from 4096 rows), the other columns stay untouched, dx and
+    the accumulated gradient equal the autograd path's; without a .grad buffer it IS the autograd path."""
+    from py4cast_amd.ops_rows import row_linear
+
+    torch.manual_seed(171)
+    x = torch.randn(R, 64, device=gpu_device).bfloat16().requires_grad_(True)
+
+    def run(in_place, prefill):
+        torch.manual_seed(172)
+        wide = (torch.randn(64, 192, device=gpu_device) * 0.1).requires_grad_(True)
+        if prefill is not None:
+            wide.grad = torch.full_like(wide, prefill)
+        x.grad = None
+        for _ in range(2):
+            y = row_linear(x, wide[:, 64:128], grads_in_place=in_place)
+            y.float().square().mean().backward()
+        return wide.grad.clone(), x.grad.clone()
+
+    ref, xref = run(False, 0.25)
+    got, xgot = run(True, 0.25)
+    assert _rel(got, ref) < 1e-6
+    assert torch.equal(xgot, xref)
+    assert float((got[:, :64] - 0.25).abs().max()) == 0.0 and float((got[:, 128:] - 0.25).abs().max()) == 0.0
+    fallback, _ = run(True, None)
+    plain, _ = run(False, None)
+    assert torch.equal(fallback, plain)
+    # rows that need no gradient themselves: the node must still be recorded (the parameter is an input of it)
+    wide = (torch.randn(64, 192, device=gpu_device) * 0.1).requires_grad_(True)
+    wide.grad = torch.zeros_like(wide)
+    y = row_linear(x.detach(), wide[:, :64], grads_in_place=True)
+    assert y.requires_grad
+    y.float().sum().backward()
+    assert float(wide.grad[:, :64].abs().sum()) > 0 and float(wide.grad[:, 64:].abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize("model_name,settings", [("GraphLAM", {"activation_dtype": "bf16", "processor_layers": 2}),
                                                   ("HiLAMParallel", {"activation_dtype": "bf16", "processor_layers": 1}),
                                                   ("SwinUNetR", {"activation_dtype": "bf16"})])
