@@ -62,6 +62,20 @@ _lib = None
 # bumped whenever a kernel updates parameters through raw pointers (FlatAdamW): caches of re-laid parameters key on it as well
 # as on tensor._version
 PARAM_EPOCH = [0]
+# Values derived from the parameters (re-laid weight images, bf16 copies of weight blocks) are cached per parameter version in
+# eager mode.  Inside a HIP-graph capture they must be produced by kernels of THAT graph (a replay has to see the current
+# parameters), but once per capture is enough: the capturing code (trainer.GraphedTrainingStep) opens a scope, the ops keep what
+# they derived in it -- which also keeps those tensors allocated, hence intact, until the capture ends.
+CAPTURE_SCOPE = [None]
+
+
+def capture_cache():
+    """The dict of the capture in progress, or None (not capturing, or a capture nobody opened a scope for: derive every time)."""
+    import torch
+
+    if CAPTURE_SCOPE[0] is not None and torch.cuda.is_current_stream_capturing():
+        return CAPTURE_SCOPE[0]
+    return None
 
 
 class P4CError(RuntimeError):

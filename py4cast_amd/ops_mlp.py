@@ -35,18 +35,21 @@ _PREPARED = {}   # (parameter addresses, shapes) -> (parameter versions, blob)
 
 def _prepared(d: RowMlpDesc, K: int, tensors, device) -> torch.Tensor:
     """The parameters re-laid into the kernels' operand images (p4c_row_mlp_prepare): once per parameter version in eager mode;
-    under HIP-graph capture always re-issued, so that a replay re-lays the CURRENT parameters."""
+    under HIP-graph capture re-issued (once per capture when the capturing code opened a scope, _lib.CAPTURE_SCOPE), so that a
+    replay re-lays the CURRENT parameters."""
     capturing = torch.cuda.is_current_stream_capturing()
     key = (K, d.k_real, d.ldw1, d.o_real, d.eps) + tuple(None if t is None else t.data_ptr() for t in tensors)
     ver = (L.PARAM_EPOCH[0],) + tuple(None if t is None else t._version for t in tensors)
-    if not capturing:
-        hit = _PREPARED.get(key)
+    scope = L.capture_cache()   # capture with an open scope: once per capture (the AR steps and the backward share the images)
+    cache = _PREPARED if not capturing else scope
+    if cache is not None:
+        hit = cache.get(("mlp",) + key)
         if hit is not None and hit[0] == ver:
             return hit[1]
     blob = torch.empty(L.lib().p4c_row_mlp_prepared_bytes(K), dtype=torch.uint8, device=device)
     L.call("p4c_row_mlp_prepare", ctypes.byref(d), L.ptr(blob), L.stream(device))
-    if not capturing:
-        _PREPARED[key] = (ver, blob)
+    if cache is not None:
+        cache[("mlp",) + key] = (ver, blob)
     return blob
 
 

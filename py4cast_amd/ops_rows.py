@@ -98,6 +98,26 @@ def grad_view(t: Optional[torch.Tensor]):
     return g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset() + g.storage_offset())
 
 
+_WCAST = {}   # eager mode: (address, shape, strides, dtype) -> (parameter version, copy in the rows' dtype)
+
+
+def weight_as(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """``w.detach().to(dtype)`` (contiguous), once per parameter version in eager mode and once per HIP-graph capture: the three AR
+    steps of a rollout use the same weight blocks, and a cast is a launch."""
+    key = ("wcast", w.data_ptr(), tuple(w.shape), tuple(w.stride()), dtype)
+    ver = (L.PARAM_EPOCH[0], w._version)
+    capturing = torch.cuda.is_current_stream_capturing()
+    cache = _WCAST if not capturing else L.capture_cache()
+    if cache is not None:
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+    wq = w.detach().to(dtype).contiguous()
+    if cache is not None:
+        cache[key] = (ver, wq)
+    return wq
+
+
 class _RowLinearSink(torch.autograd.Function):
     """``x @ W^T`` on bf16 rows whose weight gradient the backward ADDS into ``gw`` -- the view of the parameter's ``.grad`` that
     corresponds to W -- instead of handing it to autograd.  W is typically a column block of a wider Linear (the sender / receiver
@@ -108,7 +128,7 @@ class _RowLinearSink(torch.autograd.Function):
     def forward(ctx, x, w, gw):
         # w (the live parameter view) is an input so that the node is recorded even when x needs no gradient; its gradient slot
         # returns None: autograd must not also accumulate what the backward adds itself
-        wq = w.detach().to(x.dtype)
+        wq = weight_as(w, x.dtype)
         ctx.save_for_backward(x, wq)
         ctx.gw = gw
         return F.linear(x, wq)

@@ -135,9 +135,15 @@ class GraphedTrainingStep:
             for i in range(warmup):      # lazy initialisation (edge sets, kernel attributes, allocator pools) happens here
                 run(i)
         torch.cuda.current_stream().wait_stream(side)
+        from . import _lib as L
+
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = run(warmup)
+        L.CAPTURE_SCOPE[0] = {}
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = run(warmup)
+        finally:
+            L.CAPTURE_SCOPE[0] = None
         self.warmup_backwards = warmup + 1   # gradient contributions already accumulated by construction: zero_grad() after
 
     def __call__(self, batch):
