@@ -101,6 +101,14 @@ __device__ __forceinline__ bf16x8 read_tr_nat(const char* img, int rs, int ks, i
     return u.v;
 }
 
+// sum over the 8 lanes that share (lane & 7), in every lane
+__device__ __forceinline__ float lane8_sum(float v) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 __device__ __forceinline__ float silu_sig(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-x * LOG2E)); }
 
 // ---- LDS weight operand images: image[(tile * S + s) * 64 + lane] = 8 bf16 (16 B)
@@ -704,16 +712,20 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem + 4 * HID * 4 + bwd_weights_bytes<KS>());
     constexpr int OFF_W2 = HID * K, OFF_B1 = OFF_W2 + HID * HID, OFF_B2 = OFF_B1 + HID, OFF_G = OFF_B2 + HID, OFF_BT = OFF_G + HID;
+    // a wave that had no tile holds zeros: it neither reduces nor adds (wave 0 of a workgroup always has one and initialises the
+    // buffer); most backward launches of a hierarchical GNN are one or two tiles, where this epilogue IS the kernel's time
+    const bool contributed = wave < ntiles;
+    if (contributed) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        for (int o = 8; o < 64; o <<= 1) {
-            db1[j] += __shfl_xor(db1[j], o, 64);
-            db2[j] += __shfl_xor(db2[j], o, 64);
-            dgam[j] += __shfl_xor(dgam[j], o, 64);
-            dbet[j] += __shfl_xor(dbet[j], o, 64);
+        for (int j = 0; j < 8; ++j) {
+            db1[j] = lane8_sum(db1[j]);
+            db2[j] = lane8_sum(db2[j]);
+            dgam[j] = lane8_sum(dgam[j]);
+            dbet[j] = lane8_sum(dbet[j]);
         }
+    }
     for (int turn = 0; turn < 4; ++turn) {
-        if (wv == turn) {
+        if (wv == turn && contributed) {
             const bool first = turn == 0;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
