@@ -710,11 +710,14 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
 
     // ---- per-workgroup partial (the four waves add in wave order through LDS: fixed order), then one global partial per workgroup
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem + 4 * HID * 4 + bwd_weights_bytes<KS>());
+    // every wave that had a tile stores its sums to its OWN slot (weights and images are dead: the whole LDS allocation is free),
+    // then all threads add the slots in wave order -- fixed order, no read-modify-write turns (four serial turns of LDS round
+    // trips were 15 us of a launch that is otherwise ~18: most backward launches of a hierarchical GNN are a few tiles)
+    constexpr int PF = partial_floats<KS>();
+    static_assert(4 * PF * 4 <= bwd_lds_bytes<KS>(), "a reduction slot per wave must fit the kernel's LDS");
+    float* red = reinterpret_cast<float*>(smem) + wv * PF;
     constexpr int OFF_W2 = HID * K, OFF_B1 = OFF_W2 + HID * HID, OFF_B2 = OFF_B1 + HID, OFF_G = OFF_B2 + HID, OFF_BT = OFF_G + HID;
-    // a wave that had no tile holds zeros: it neither reduces nor adds (wave 0 of a workgroup always has one and initialises the
-    // buffer); most backward launches of a hierarchical GNN are one or two tiles, where this epilogue IS the kernel's time
-    const bool contributed = wave < ntiles;
+    const bool contributed = wave < ntiles;   // wave 0 of a workgroup always has a tile
     if (contributed) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -723,40 +726,39 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
             dgam[j] = lane8_sum(dgam[j]);
             dbet[j] = lane8_sum(dbet[j]);
         }
-    }
-    for (int turn = 0; turn < 4; ++turn) {
-        if (wv == turn && contributed) {
-            const bool first = turn == 0;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int o = 32 * m + rowmap(i) + 4 * h;
+            for (int i = 0; i < 16; ++i) {
+                const int o = 32 * m + rowmap(i) + 4 * h;
 #pragma unroll
-                    for (int n = 0; n < NKT; ++n) {
-                        const int k = 32 * n + r;
-                        if (k < K) red[o * K + k] = (first ? 0.f : red[o * K + k]) + dw1[m][n][i];
-                    }
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const int k = 32 * n + r;
-                        red[OFF_W2 + o * HID + k] = (first ? 0.f : red[OFF_W2 + o * HID + k]) + dw2[m][n][i];
-                    }
+                for (int n = 0; n < NKT; ++n) {
+                    const int k = 32 * n + r;
+                    if (k < K) red[o * K + k] = dw1[m][n][i];
                 }
-            if (lane < 8)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = lane * 8 + j;
-                    red[OFF_B1 + c] = (first ? 0.f : red[OFF_B1 + c]) + db1[j];
-                    red[OFF_B2 + c] = (first ? 0.f : red[OFF_B2 + c]) + db2[j];
-                    red[OFF_G + c] = (first ? 0.f : red[OFF_G + c]) + dgam[j];
-                    red[OFF_BT + c] = (first ? 0.f : red[OFF_BT + c]) + dbet[j];
-                }
-        }
-        __syncthreads();
+                for (int n = 0; n < 2; ++n) red[OFF_W2 + o * HID + 32 * n + r] = dw2[m][n][i];
+            }
+        if (lane < 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = lane * 8 + j;
+                red[OFF_B1 + c] = db1[j];
+                red[OFF_B2 + c] = db2[j];
+                red[OFF_G + c] = dgam[j];
+                red[OFF_BT + c] = dbet[j];
+            }
     }
-    float* dst = a.partial + (int64_t)blockIdx.x * partial_floats<KS>();
-    for (int i = threadIdx.x; i < partial_floats<KS>(); i += blockDim.x) dst[i] = red[i];
+    __syncthreads();
+    const int64_t left = ntiles - (int64_t)blockIdx.x * 4;
+    const int nact = left >= 4 ? 4 : (int)left;
+    const float* slot = reinterpret_cast<const float*>(smem);
+    float* dst = a.partial + (int64_t)blockIdx.x * PF;
+    for (int i = threadIdx.x; i < PF; i += blockDim.x) {
+        float t = slot[i];
+        for (int w = 1; w < nact; ++w) t += slot[w * PF + i];
+        dst[i] = t;
+    }
 }
 
 // out[j] = sum_s partial[s][j] in a fixed order (same scheme as rows.hip)
