@@ -140,16 +140,61 @@ class _RowLinearSink(torch.autograd.Function):
         R, K = x.shape
         O = wq.shape[0]
         dx = dy @ wq if ctx.needs_input_grad[0] else None
-        if _native_wgrad_ok(x, O, K):
-            buf = torch.empty(O * K + O, dtype=torch.float32, device=x.device)
-            nbytes = L.lib().p4c_row_linear_wgrad_workspace_bytes(R, K)
-            ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
-            L.call("p4c_row_linear_wgrad", L.ptr(dy), L.ptr(x.contiguous()), L.ptr(buf), L.ptr(ws), R, O, K, L.dtype_code(x.dtype),
-                   L.stream(x.device), alg_bytes=R * (O + K) * x.element_size())
-            ctx.gw.add_(buf[: O * K].view(O, K))
-        else:
-            ctx.gw.add_(dy.t() @ x)   # library GEMM in the rows' dtype (what autograd's Linear backward computes), promoted add
+        _sink_weight_grad(x, dy, ctx.gw)
         return dx, None, None
+
+
+def _sink_weight_grad(x, dy, gw):
+    """gw += dy^T x: the tall-skinny kernel from 4096 rows, else the library GEMM in the rows' dtype with a promoted add."""
+    R, K = x.shape
+    O = dy.shape[1]
+    if _native_wgrad_ok(x, O, K):
+        buf = torch.empty(O * K + O, dtype=torch.float32, device=x.device)
+        nbytes = L.lib().p4c_row_linear_wgrad_workspace_bytes(R, K)
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+        L.call("p4c_row_linear_wgrad", L.ptr(dy), L.ptr(x.contiguous()), L.ptr(buf), L.ptr(ws), R, O, K, L.dtype_code(x.dtype),
+               L.stream(x.device), alg_bytes=R * (O + K) * x.element_size())
+        gw.add_(buf[: O * K].view(O, K))
+    else:
+        gw.add_(dy.t() @ x)
+
+
+class _RowLinearMulti(torch.autograd.Function):
+    """Several bias-free projections of the SAME rows (x W_1^T, ..., x W_n^T) as one autograd node: the backward accumulates
+    dx = sum_i dy_i W_i inside the GEMMs (addmm, beta = 1) instead of leaving n - 1 elementwise additions to autograd, and adds
+    every weight gradient into its ``.grad`` view (see _RowLinearSink)."""
+
+    @staticmethod
+    def forward(ctx, x, n, *args):
+        ws, gws = args[:n], args[n:]
+        wqs = [weight_as(w, x.dtype) for w in ws]
+        ctx.save_for_backward(x, *wqs)
+        ctx.gws, ctx.n = gws, n
+        return tuple(F.linear(x, wq) for wq in wqs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, *wqs = ctx.saved_tensors
+        dx = None
+        for dy, wq, gw in zip(dys, wqs, ctx.gws):
+            if dy is None:
+                continue
+            dy = dy.contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = dy @ wq if dx is None else dx.addmm_(dy, wq)
+            _sink_weight_grad(x, dy, gw)
+        return (dx, None) + (None,) * (2 * ctx.n)
+
+
+def row_linear_multi(x: torch.Tensor, weights, grads_in_place: bool = False):
+    """``[x @ w.T for w in weights]`` for bf16 rows; with ``grads_in_place`` and gradient buffers for all weights, one autograd
+    node (_RowLinearMulti); otherwise one ``row_linear`` each."""
+    L.require_cuda(x)
+    if grads_in_place and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and all(w.requires_grad for w in weights):
+        gws = [grad_view(w) for w in weights]
+        if all(g is not None and g is not False for g in gws):
+            return _RowLinearMulti.apply(x, len(weights), *weights, *gws)
+    return tuple(row_linear(x, w, grads_in_place=grads_in_place) for w in weights)
 
 
 def row_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, grads_in_place: bool = False) -> torch.Tensor:

@@ -837,6 +837,34 @@ def test_row_linear_gradient_in_place(gpu_device, R):
     assert float(wide.grad[:, :64].abs().sum()) > 0 and float(wide.grad[:, 64:].abs().sum()) == 0.0
 
 
+def test_row_linear_multi_equals_separate_projections(gpu_device):
+    """Several projections of one node tensor as one autograd node: outputs, the input gradient (accumulated inside the GEMMs) and
+    the weight gradients (added into the .grad views) equal those of separate row_linear calls."""
+    from py4cast_amd.ops_rows import row_linear, row_linear_multi
+
+    torch.manual_seed(181)
+    x = torch.randn(1500, 64, device=gpu_device).bfloat16().requires_grad_(True)
+    cot = [torch.randn(1500, 64, device=gpu_device).bfloat16() for _ in range(3)]
+
+    def run(multi):
+        torch.manual_seed(182)
+        wide = (torch.randn(64, 192, device=gpu_device) * 0.1).requires_grad_(True)
+        other = (torch.randn(64, 128, device=gpu_device) * 0.1).requires_grad_(True)
+        wide.grad, other.grad, x.grad = torch.zeros_like(wide), torch.zeros_like(other), None
+        ws = [wide[:, 64:128], wide[:, 128:], other[:, :64]]
+        ys = row_linear_multi(x, ws, grads_in_place=True) if multi else [row_linear(x, w, grads_in_place=True) for w in ws]
+        sum((y.float() * c.float()).sum() for y, c in zip(ys, cot)).backward()
+        return [y.detach().clone() for y in ys], x.grad.clone(), wide.grad.clone(), other.grad.clone()
+
+    ys_m, dx_m, gw_m, go_m = run(True)
+    ys_s, dx_s, gw_s, go_s = run(False)
+    for a, b in zip(ys_m, ys_s):
+        assert torch.equal(a, b)
+    assert _rel(dx_m, dx_s) < 1e-2          # bf16 sums in a different association
+    assert torch.equal(gw_m, gw_s) and torch.equal(go_m, go_s)
+    assert float(gw_m[:, :64].abs().max()) == 0.0 and float(go_m[:, 64:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("model_name,settings", [("GraphLAM", {"activation_dtype": "bf16", "processor_layers": 2}),
                                                   ("HiLAMParallel", {"activation_dtype": "bf16", "processor_layers": 1}),
                                                   ("SwinUNetR", {"activation_dtype": "bf16"})])
