@@ -338,6 +338,12 @@ int p4c_edge_gather_add_bwd(const void* dh, const void* base, const void* a, con
  * gather.  msg: (E,C) of `dtype`; init/out: (N,C) of `out_dtype` (= dtype, or P4C_F32 for bf16 messages). */
 int p4c_segment_sum(const void* msg, const int32_t* offsets, const int32_t* perm, const void* init, void* out,
                     int64_t N, int64_t E, int C, int dtype, int out_dtype, p4c_stream_t stream);
+/* Two segment sums over the same E rows in ONE launch -- out_a over (offsets_a, perm_a), out_b over (offsets_b, perm_b); both
+ * (N*,C) of `dtype`, no init: the two adjoints of an edge MLP's gathers (gradient rows summed by sender and by receiver, as
+ * autograd's two index_add_ calls do).  Each side is computed exactly as its own p4c_segment_sum launch would (same order). */
+int p4c_segment_sum_pair(const void* msg, const int32_t* offsets_a, const int32_t* perm_a, void* out_a, int64_t Na,
+                         const int32_t* offsets_b, const int32_t* perm_b, void* out_b, int64_t Nb, int64_t E, int C, int dtype,
+                         p4c_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------

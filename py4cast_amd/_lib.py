@@ -69,6 +69,22 @@ PARAM_EPOCH = [0]
 CAPTURE_SCOPE = [None]
 
 
+def _base(t):
+    return t._base if t._base is not None else t
+
+
+def owner_refs(tensors):
+    """Weak references to the tensors that own the storage of `tensors` (parameters, for slices of parameters).  A cache keyed by
+    addresses and version counters alone can hit a DIFFERENT parameter that the allocator placed at a freed one's address."""
+    import weakref
+
+    return tuple(None if t is None else weakref.ref(_base(t)) for t in tensors)
+
+
+def owners_alive(refs, tensors) -> bool:
+    return all((r is None and t is None) or (r is not None and t is not None and r() is _base(t)) for r, t in zip(refs, tensors))
+
+
 def capture_cache():
     """The dict of the capture in progress, or None (not capturing, or a capture nobody opened a scope for: derive every time)."""
     import torch

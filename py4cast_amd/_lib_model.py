@@ -56,6 +56,7 @@ SIGNATURES = {
     "p4c_edge_gather_add_fwd": [P, P, P, P, P, P, L, I, I, I, P],
     "p4c_edge_gather_add_bwd": [P, P, P, P, P, P, P, L, I, I, I, P],
     "p4c_segment_sum": [P, P, P, P, P, L, L, I, I, I, P],
+    "p4c_segment_sum_pair": [P, P, P, P, L, P, P, P, L, L, I, I, P],
     "p4c_row_layernorm_fwd": [P, P, P, P, F, P, L, I, I, P],
     "p4c_row_layernorm_bwd": [P, P, P, F, P, P, P, P, L, I, I, P],
     "p4c_row_linear_wgrad": [P, P, P, P, L, I, I, I, P],

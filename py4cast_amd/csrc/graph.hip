@@ -128,9 +128,9 @@ __global__ void __launch_bounds__(256)
 // `split` = 2^split_log2 lane groups (of lpr lanes) share one segment: group g takes list positions g, g+split, ... four rows in
 // flight each, partial sums combined by a butterfly over the groups -- the order depends only on (split, lpr): reproducible.
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256)
-    segment_sum_kernel(const T* __restrict__ msg, const int32_t* __restrict__ off, const int32_t* __restrict__ perm,
-                       const TO* __restrict__ init, TO* __restrict__ out, int64_t N, int chunks, int lpr_log2, int split_log2) {
+__device__ __forceinline__ void segment_sum_body(const T* __restrict__ msg, const int32_t* __restrict__ off,
+                                                 const int32_t* __restrict__ perm, const TO* __restrict__ init, TO* __restrict__ out,
+                                                 int64_t N, int chunks, int lpr_log2, int split_log2, int block, int nblocks) {
     constexpr int NV = Row16<T>::N;
     const int lane = threadIdx.x & 63;
     const int lpr = 1 << lpr_log2, split = 1 << split_log2;
@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256)
     const int g = grp & (split - 1);                // position among the groups of its segment
     const int seg_in_wave = grp >> split_log2;
     const int spw = (64 >> lpr_log2) >> split_log2; // segments per wave pass
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave = (int64_t)block * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)nblocks * (blockDim.x >> 6);
     const int64_t row_v = chunks;                   // row length in 16-byte vectors
     for (int64_t n0 = wave * spw; n0 < N; n0 += nwaves * spw) {
         const int64_t n = n0 + seg_in_wave;
@@ -195,6 +195,31 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256)
+    segment_sum_kernel(const T* __restrict__ msg, const int32_t* __restrict__ off, const int32_t* __restrict__ perm,
+                       const TO* __restrict__ init, TO* __restrict__ out, int64_t N, int chunks, int lpr_log2, int split_log2) {
+    segment_sum_body<T, TO>(msg, off, perm, init, out, N, chunks, lpr_log2, split_log2, blockIdx.x, gridDim.x);
+}
+
+// Two segment sums over the SAME rows in one launch (the two adjoints of an edge MLP's gathers: the gradient rows summed by sender
+// and by receiver): blocks [0, blocks_a) take the first CSR structure, the rest the second.  Each half computes exactly what its
+// own launch would (same block count, same order).
+struct SegSide {
+    const int32_t* off;
+    const int32_t* perm;
+    void* out;
+    int64_t N;
+    int split_log2, blocks;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) segment_sum_pair_kernel(const T* __restrict__ msg, SegSide a, SegSide b, int chunks, int lpr_log2) {
+    if ((int)blockIdx.x < a.blocks)
+        segment_sum_body<T, T>(msg, a.off, a.perm, nullptr, (T*)a.out, a.N, chunks, lpr_log2, a.split_log2, blockIdx.x, a.blocks);
+    else
+        segment_sum_body<T, T>(msg, b.off, b.perm, nullptr, (T*)b.out, b.N, chunks, lpr_log2, b.split_log2, blockIdx.x - a.blocks, b.blocks);
+}
+
 static inline int ceil_log2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -247,6 +272,24 @@ int gather_add_common(const char* name, const void* base, const void* a, const i
                             : dispatch_gather_add<bf16>(act, base, a, ia, b, ib, dh, out, E, chunks, stream);
 }
 
+// launch shape of a segment sum: lane groups per segment from the mean list length (one group moves 4 rows at a time)
+int64_t segment_sum_shape(int64_t N, int64_t E, int chunks, int* lpr_log2_out, int* split_log2_out) {
+    int lpr_log2 = ceil_log2(chunks);
+    if (lpr_log2 > 6) lpr_log2 = 6;
+    const int groups_log2 = 6 - lpr_log2;
+    const int64_t mean_len = (E + N - 1) / N;
+    int split_log2 = 0;
+    while (split_log2 < groups_log2 && (int64_t)(4 << split_log2) < mean_len) ++split_log2;
+    const int spw = (64 >> lpr_log2) >> split_log2;
+    int64_t waves = (N + spw - 1) / spw;
+    int64_t blocks = (waves + 3) / 4;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    *lpr_log2_out = lpr_log2;
+    *split_log2_out = split_log2;
+    return blocks;
+}
+
 }  // namespace
 }  // namespace p4c
 
@@ -275,18 +318,8 @@ extern "C" int p4c_segment_sum(const void* msg, const int32_t* offsets, const in
     P4C_CHECK_ARG((C * esz) % 16 == 0, "p4c_segment_sum: a row (C=%d x %d B) must be a multiple of 16 bytes", C, esz);
     if (N == 0) return P4C_OK;
     const int chunks = C * esz / 16;
-    int lpr_log2 = ceil_log2(chunks);
-    if (lpr_log2 > 6) lpr_log2 = 6;
-    const int groups_log2 = 6 - lpr_log2;
-    // lane groups per segment from the mean list length: one group moves 4 rows at a time
-    const int64_t mean_len = (E + N - 1) / N;
-    int split_log2 = 0;
-    while (split_log2 < groups_log2 && (int64_t)(4 << split_log2) < mean_len) ++split_log2;
-    const int spw = (64 >> lpr_log2) >> split_log2;
-    int64_t waves = (N + spw - 1) / spw;
-    int64_t blocks = (waves + 3) / 4;
-    const int64_t cap = (int64_t)num_cus() * 16;
-    if (blocks > cap) blocks = cap;
+    int lpr_log2, split_log2;
+    const int64_t blocks = segment_sum_shape(N, E, chunks, &lpr_log2, &split_log2);
     hipStream_t s = as_stream(stream);
     if (dtype == P4C_F32)
         hipLaunchKernelGGL((segment_sum_kernel<float, float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)msg, offsets,
@@ -298,5 +331,29 @@ extern "C" int p4c_segment_sum(const void* msg, const int32_t* offsets, const in
         hipLaunchKernelGGL((segment_sum_kernel<bf16, float>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16*)msg, offsets, perm,
                            (const float*)init, (float*)out, N, chunks, lpr_log2, split_log2);
     P4C_CHECK_LAUNCH("segment_sum");
+    return P4C_OK;
+}
+
+extern "C" int p4c_segment_sum_pair(const void* msg, const int32_t* offsets_a, const int32_t* perm_a, void* out_a, int64_t Na,
+                                    const int32_t* offsets_b, const int32_t* perm_b, void* out_b, int64_t Nb, int64_t E, int C, int dtype,
+                                    p4c_stream_t stream) {
+    P4C_CHECK_ARG(msg && offsets_a && offsets_b && out_a && out_b, "p4c_segment_sum_pair: NULL pointer");
+    P4C_CHECK_ARG(Na > 0 && Nb > 0 && E > 0 && C > 0, "p4c_segment_sum_pair: bad sizes (use p4c_segment_sum for empty sides)");
+    P4C_CHECK_ARG(dtype == P4C_F32 || dtype == P4C_BF16, "p4c_segment_sum_pair: dtype must be P4C_F32 or P4C_BF16");
+    const int esz = dtype == P4C_F32 ? 4 : 2;
+    P4C_CHECK_ARG((C * esz) % 16 == 0, "p4c_segment_sum_pair: a row (C=%d x %d B) must be a multiple of 16 bytes", C, esz);
+    const int chunks = C * esz / 16;
+    int lpr_log2, lpr_b;
+    SegSide a{offsets_a, perm_a, out_a, Na, 0, 0}, b{offsets_b, perm_b, out_b, Nb, 0, 0};
+    a.blocks = (int)segment_sum_shape(Na, E, chunks, &lpr_log2, &a.split_log2);
+    b.blocks = (int)segment_sum_shape(Nb, E, chunks, &lpr_b, &b.split_log2);
+    hipStream_t s = as_stream(stream);
+    if (dtype == P4C_F32)
+        hipLaunchKernelGGL((segment_sum_pair_kernel<float>), dim3((unsigned)(a.blocks + b.blocks)), dim3(256), 0, s, (const float*)msg, a, b,
+                           chunks, lpr_log2);
+    else
+        hipLaunchKernelGGL((segment_sum_pair_kernel<bf16>), dim3((unsigned)(a.blocks + b.blocks)), dim3(256), 0, s, (const bf16*)msg, a, b,
+                           chunks, lpr_log2);
+    P4C_CHECK_LAUNCH("segment_sum_pair");
     return P4C_OK;
 }

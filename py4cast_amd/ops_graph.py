@@ -56,6 +56,21 @@ def _segment_sum_raw(msg: torch.Tensor, offsets: torch.Tensor, perm: Optional[to
     return out
 
 
+def _segment_sum_pair_raw(msg: torch.Tensor, by_a, na: int, by_b, nb: int):
+    """The sums of the same rows over two CSR structures (by_a = (offsets, perm), by_b likewise) in one launch."""
+    L.require_cuda(msg)
+    msg = msg.contiguous()
+    E, C = msg.shape
+    if E == 0 or na == 0 or nb == 0:
+        return _segment_sum_raw(msg, *by_a, na), _segment_sum_raw(msg, *by_b, nb)
+    out_a = torch.empty(na, C, dtype=msg.dtype, device=msg.device)
+    out_b = torch.empty(nb, C, dtype=msg.dtype, device=msg.device)
+    L.call("p4c_segment_sum_pair", L.ptr(msg), L.ptr(by_a[0]), L.ptr(by_a[1]), L.ptr(out_a), na, L.ptr(by_b[0]), L.ptr(by_b[1]),
+           L.ptr(out_b), nb, E, C, L.dtype_code(msg.dtype), L.stream(msg.device),
+           alg_bytes=2 * E * C * msg.element_size() + (na + nb) * C * msg.element_size() + 8 * E + 4 * (na + nb))
+    return out_a, out_b
+
+
 def _gather_raw(base, a, ia, b, ib, dh, act: int, E: int, C: int, like: torch.Tensor):
     out = torch.empty(E, C, dtype=like.dtype, device=like.device)
     name = "p4c_edge_gather_add_bwd" if dh is not None else "p4c_edge_gather_add_fwd"

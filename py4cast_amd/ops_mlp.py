@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from ._lib_model import RowMlpDesc, RowMlpGradSinks
-from .ops_graph import EdgeSet, _segment_sum_raw
+from .ops_graph import EdgeSet, _segment_sum_pair_raw, _segment_sum_raw
 
 MAX_K = 80
 
@@ -33,23 +33,24 @@ def _desc(x, K, w1, b1, w2, b2, gamma, beta, eps, ga, ia, gb, ib, res, out, out_
 _PREPARED = {}   # (parameter addresses, shapes) -> (parameter versions, blob)
 
 
-def _prepared(d: RowMlpDesc, K: int, tensors, device) -> torch.Tensor:
+def _prepared(d: RowMlpDesc, K: int, tensors, device, owners=None) -> torch.Tensor:
     """The parameters re-laid into the kernels' operand images (p4c_row_mlp_prepare): once per parameter version in eager mode;
     under HIP-graph capture re-issued (once per capture when the capturing code opened a scope, _lib.CAPTURE_SCOPE), so that a
     replay re-lays the CURRENT parameters."""
     capturing = torch.cuda.is_current_stream_capturing()
+    owners = tensors if owners is None else owners   # the caller's parameter objects (`tensors` may be temporaries over their storage)
     key = (K, d.k_real, d.ldw1, d.o_real, d.eps) + tuple(None if t is None else t.data_ptr() for t in tensors)
     ver = (L.PARAM_EPOCH[0],) + tuple(None if t is None else t._version for t in tensors)
     scope = L.capture_cache()   # capture with an open scope: once per capture (the AR steps and the backward share the images)
     cache = _PREPARED if not capturing else scope
     if cache is not None:
         hit = cache.get(("mlp",) + key)
-        if hit is not None and hit[0] == ver:
+        if hit is not None and hit[0] == ver and L.owners_alive(hit[2], owners):
             return hit[1]
     blob = torch.empty(L.lib().p4c_row_mlp_prepared_bytes(K), dtype=torch.uint8, device=device)
     L.call("p4c_row_mlp_prepare", ctypes.byref(d), L.ptr(blob), L.stream(device))
     if cache is not None:
-        cache[("mlp",) + key] = (ver, blob)
+        cache[("mlp",) + key] = (ver, blob, L.owner_refs(owners))
     return blob
 
 
@@ -74,14 +75,14 @@ class _RowMLP(torch.autograd.Function):
         if edges is None and any(t is not None and t.shape[0] != R for t in (gac, gbc)):
             raise L.P4CError("row_mlp: without an edge set the addends must have one row per row of x")
         d = _desc(x, K, w1.detach(), b1c, w2c.detach(), b2c, gc, bc, eps, gac, ia, gbc, ib, resc, out, out_res)
-        blob = _prepared(d, K, (w1, b1c, w2c, b2c, gc, bc), x.device)
+        blob = _prepared(d, K, (w1, b1c, w2c, b2c, gc, bc), x.device, owners=(w1, b1, w2, b2, gamma, beta))
         d.prepared = blob.data_ptr()
         rows_io = 1 + (out is not None) + 2 * (out_res is not None)
         gathered = sum(min(R, t.shape[0]) for t in (gac, gbc) if t is not None)
         L.call("p4c_row_mlp_fwd", ctypes.byref(d), L.stream(x.device),
                alg_bytes=R * K * 2 + (rows_io - 1) * R * 128 + gathered * 128 + 4 * R * ((ga is not None) + (gb is not None)))
         ctx.save_for_backward(x, w1, w2c, b1c, b2c, gc, bc, gac, gbc)
-        ctx.edges, ctx.eps, ctx.sinks = edges, eps, sinks
+        ctx.edges, ctx.eps, ctx.sinks, ctx.prepared_blob = edges, eps, sinks, blob
         ctx.flags = (b1 is not None, b2 is not None, gamma is not None, res is not None)
         ctx.pdtype = w1.dtype
         if out is None:
@@ -107,7 +108,7 @@ class _RowMLP(torch.autograd.Function):
         ia = edges.src if (ga is not None and edges is not None) else None
         ib = edges.dst if (gb is not None and edges is not None) else None
         d = _desc(x, K, w1.detach(), b1, w2, b2, gamma, beta, ctx.eps, ga, ia, gb, ib, None, None, None, dy, dyr, dx, dpre)
-        blob = _prepared(d, K, (w1, b1, w2, b2, gamma, beta), x.device)
+        blob = ctx.prepared_blob   # the images the forward used (the parameters cannot have changed in between: autograd checks)
         d.prepared = blob.data_ptr()
         rows_io = 1 + (dy is not None) + (dyr is not None) + need_dx * K / 64 + gathered
         n_gath = sum(min(R, t.shape[0]) for t in (ga, gb) if t is not None)
@@ -134,8 +135,12 @@ class _RowMLP(torch.autograd.Function):
             dga = dpre if (ga is not None and ctx.needs_input_grad[7]) else None
             dgb = dpre if (gb is not None and ctx.needs_input_grad[8]) else None
         else:
-            dga = _segment_sum_raw(dpre, *edges.by_src, edges.n_src) if (ga is not None and ctx.needs_input_grad[7]) else None
-            dgb = _segment_sum_raw(dpre, *edges.by_dst, edges.n_dst) if (gb is not None and ctx.needs_input_grad[8]) else None
+            want_a, want_b = ga is not None and ctx.needs_input_grad[7], gb is not None and ctx.needs_input_grad[8]
+            if want_a and want_b:   # both adjoints of the gathers read the same dpre rows: one launch
+                dga, dgb = _segment_sum_pair_raw(dpre, edges.by_src, edges.n_src, edges.by_dst, edges.n_dst)
+            else:
+                dga = _segment_sum_raw(dpre, *edges.by_src, edges.n_src) if want_a else None
+                dgb = _segment_sum_raw(dpre, *edges.by_dst, edges.n_dst) if want_b else None
         dres = dyr if has_res else None
         return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None, None
 

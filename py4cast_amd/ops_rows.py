@@ -110,11 +110,11 @@ def weight_as(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     cache = _WCAST if not capturing else L.capture_cache()
     if cache is not None:
         hit = cache.get(key)
-        if hit is not None and hit[0] == ver:
+        if hit is not None and hit[0] == ver and L.owners_alive(hit[2], (w,)):
             return hit[1]
     wq = w.detach().to(dtype).contiguous()
     if cache is not None:
-        cache[key] = (ver, wq)
+        cache[key] = (ver, wq, L.owner_refs((w,)))
     return wq
 
 

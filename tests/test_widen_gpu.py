@@ -70,6 +70,23 @@ def test_segment_sum(gpu_device, E, N, C, dtype, skew):
         assert float(got.cpu()[empty].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_segment_sum_pair_equals_two_launches(gpu_device, dtype):
+    """p4c_segment_sum_pair: the sums of the same rows by sender and by receiver in one launch, bit-identical to two launches."""
+    from py4cast_amd import ops_graph as G
+
+    torch.manual_seed(191)
+    E, ns, nr = 7001, 333, 2050
+    src, dst = torch.randint(0, ns, (E,), device=gpu_device), torch.randint(0, nr, (E,), device=gpu_device)
+    edges = G.EdgeSet(src, dst, ns, nr)
+    msg = torch.randn(E, 64, device=gpu_device).to(dtype)
+    a, b = G._segment_sum_pair_raw(msg, edges.by_src, ns, edges.by_dst, nr)
+    assert torch.equal(a, G._segment_sum_raw(msg, *edges.by_src, ns))
+    assert torch.equal(b, G._segment_sum_raw(msg, *edges.by_dst, nr))
+    ref = torch.zeros(nr, 64, dtype=torch.float64, device=gpu_device).index_add_(0, dst, msg.double())
+    assert _rel(b, ref) < (1e-6 if dtype == torch.float32 else 2e-2)
+
+
 def test_segment_sum_bf16_to_f32_and_empty(gpu_device):
     from py4cast_amd import ops_graph as G
 
