@@ -882,6 +882,31 @@ def test_row_linear_multi_equals_separate_projections(gpu_device):
     assert float(gw_m[:, :64].abs().max()) == 0.0 and float(go_m[:, 64:].abs().max()) == 0.0
 
 
+def test_parameter_caches_do_not_outlive_their_parameters(gpu_device):
+    """The per-parameter-version caches (bf16 weight blocks, re-laid MLP images) are keyed by addresses and version counters; a NEW
+    parameter that the allocator places at a freed one's address (same version counter, no optimizer step in between) must not hit
+    the old entry: entries hold weak references to the owning tensors."""
+    from py4cast_amd.ops_mlp import row_mlp
+    from py4cast_amd.ops_rows import row_linear
+
+    x = torch.randn(300, 64, device=gpu_device).bfloat16()
+    addresses = set()
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        w = (torch.randn(64, 192, device=gpu_device) * 0.1).requires_grad_(True)
+        w.grad = torch.zeros_like(w)
+        addresses.add(w.data_ptr())
+        y = row_linear(x, w[:, :64], grads_in_place=True)
+        assert torch.equal(y, torch.nn.functional.linear(x, w[:, :64].detach().bfloat16()))
+        b1, w2, b2 = torch.zeros(64, device=gpu_device), (torch.randn(64, 64, device=gpu_device) * 0.1), torch.zeros(64, device=gpu_device)
+        out, _ = row_mlp(x, w[:, 64:128].detach(), b1, w2, b2)
+        ref = torch.nn.functional.linear(torch.nn.functional.silu(torch.nn.functional.linear(x.float(), w[:, 64:128].detach().bfloat16().float())).bfloat16().float(),
+                                         w2.bfloat16().float())
+        assert _rel(out, ref) < 2e-2
+        del w, y, out, b1, w2, b2
+    assert len(addresses) < 3   # the scenario did occur: the allocator re-used an address
+
+
 @pytest.mark.parametrize("model_name,settings", [("GraphLAM", {"activation_dtype": "bf16", "processor_layers": 2}),
                                                   ("HiLAMParallel", {"activation_dtype": "bf16", "processor_layers": 1}),
                                                   ("SwinUNetR", {"activation_dtype": "bf16"})])
