@@ -56,7 +56,8 @@ def _prepared(d: RowMlpDesc, K: int, tensors, device, owners=None) -> torch.Tens
 
 class _RowMLP(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges: Optional[EdgeSet], eps: float, want_out: bool, sinks=None):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges: Optional[EdgeSet], eps: float, want_out: bool, sinks=None,
+                owners=None):
         R, K = x.shape
         x = x.contiguous()
         for t in (w1, w2):
@@ -75,7 +76,7 @@ class _RowMLP(torch.autograd.Function):
         if edges is None and any(t is not None and t.shape[0] != R for t in (gac, gbc)):
             raise L.P4CError("row_mlp: without an edge set the addends must have one row per row of x")
         d = _desc(x, K, w1.detach(), b1c, w2c.detach(), b2c, gc, bc, eps, gac, ia, gbc, ib, resc, out, out_res)
-        blob = _prepared(d, K, (w1, b1c, w2c, b2c, gc, bc), x.device, owners=(w1, b1, w2, b2, gamma, beta))
+        blob = _prepared(d, K, (w1, b1c, w2c, b2c, gc, bc), x.device, owners=owners if owners is not None else (w1, b1, w2, b2, gamma, beta))
         d.prepared = blob.data_ptr()
         rows_io = 1 + (out is not None) + 2 * (out_res is not None)
         gathered = sum(min(R, t.shape[0]) for t in (gac, gbc) if t is not None)
@@ -142,7 +143,7 @@ class _RowMLP(torch.autograd.Function):
                 dga = _segment_sum_raw(dpre, *edges.by_src, edges.n_src) if want_a else None
                 dgb = _segment_sum_raw(dpre, *edges.by_dst, edges.n_dst) if want_b else None
         dres = dyr if has_res else None
-        return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None, None
+        return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None, None, None
 
 
 def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=None, beta=None, eps: float = 1e-5,
@@ -157,9 +158,10 @@ def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=N
     if kp:
         x = F.pad(x, (0, kp))
     sinks = grad_sinks(w1, b1, w2, b2, gamma, beta) if grads_in_place else None
+    owners = (w1, b1, w2, b2, gamma, beta)   # the caller's parameter objects: what the weight-image cache checks for identity
     if sinks is not None:   # autograd must not also accumulate what the kernel adds itself
         w1, b1, w2, b2, gamma, beta = (None if t is None else t.detach() for t in (w1, b1, w2, b2, gamma, beta))
-    return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out, sinks)
+    return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out, sinks, owners)
 
 
 from .ops_rows import grad_view as _grad_view  # noqa: E402  (one definition, shared with ops_rows.row_linear)
