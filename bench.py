@@ -289,6 +289,36 @@ def main():
     for i in range(args.setup_steps):   # lazy one-time initialisation, not part of the W + K contract
         step(-1 - i)
     barrier()
+    probe = None
+    if args.hip_graph == "auto" and not use_graph and hasattr(lm.model, "native_rollout"):
+        # Launch-mode probe (also outside the W + K contract).  The native HalfUNet step is ~300 launches: issued eagerly they cost
+        # the host ~3.4 ms, less than the GPU needs, and eager launching is then ~7 % FASTER than replaying the captured step -- but
+        # on a slow or busy host the step becomes host-bound, and the replay (one launch) is the faster way.  Measure both, keep one.
+        def per_step(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(n):
+                step(-100 - i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+
+        t_eager, t_graph = per_step(3), None
+        try:
+            from py4cast_amd.trainer import GraphedTrainingStep
+
+            ddp.zero_grad()
+            graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
+            ddp.zero_grad()
+            per_step(1)
+            t_graph = per_step(3)
+        except Exception as exc:  # noqa: BLE001  (a step that cannot be captured simply stays eager)
+            print(f"bench: HIP-graph probe failed ({type(exc).__name__}: {exc}); eager launching", file=sys.stderr)
+        graphed[0] = None
+        ddp.zero_grad()
+        use_graph = t_graph is not None and t_graph < 0.97 * t_eager
+        probe = {"eager_ms_per_step": 1e3 * t_eager, "graph_ms_per_step": None if t_graph is None else 1e3 * t_graph,
+                 "chosen": "graph" if use_graph else "eager"}
+        barrier()
     for i in range(args.warmup):
         step(i)
     timed = getattr(lm.model, "timed_entry_points", None) or (
@@ -316,6 +346,7 @@ def main():
         ktimes = L.kernel_times()
         roof_model = lm.model.roofline(ktimes, B=B, H=H, W=W) if (rank == 0 and hasattr(lm.model, "roofline")) else None
         L.enable_kernel_timing(None)
+        L.lib().p4c_prof_enable(0, 0)   # no event markers inside a capture
         ddp.zero_grad()
         graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
         ddp.zero_grad()
@@ -379,6 +410,7 @@ def main():
                 "setup_steps": args.setup_steps,
                 "accumulate_grad_batches": args.accumulate,
                 "hip_graph": bool(use_graph),
+                "launch_mode_probe": probe,
             },
             "loss": float(loss.detach()),
             "roofline": roof,
