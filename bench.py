@@ -302,17 +302,19 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
 
-        t_eager, t_graph = per_step(3), None
+        t_eager, captured = per_step(3), True
         try:
             from py4cast_amd.trainer import GraphedTrainingStep
 
             ddp.zero_grad()
             graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
-            ddp.zero_grad()
-            per_step(1)
-            t_graph = per_step(3)
         except Exception as exc:  # noqa: BLE001  (a step that cannot be captured simply stays eager)
             print(f"bench: HIP-graph probe failed ({type(exc).__name__}: {exc}); eager launching", file=sys.stderr)
+            graphed[0], captured = None, False
+        ddp.zero_grad()
+        per_step(1)                # (run on every rank whether or not its capture worked: the ranks' collective counts stay equal)
+        t_second = per_step(3)
+        t_graph = t_second if captured else None
         graphed[0] = None
         ddp.zero_grad()
         use_graph = t_graph is not None and t_graph < 0.97 * t_eager
