@@ -290,10 +290,12 @@ def main():
         step(-1 - i)
     barrier()
     probe = None
-    if args.hip_graph == "auto" and not use_graph and hasattr(lm.model, "native_rollout"):
+    if args.hip_graph == "auto" and not use_graph and hasattr(lm.model, "native_rollout") and world == 1:
         # Launch-mode probe (also outside the W + K contract).  The native HalfUNet step is ~300 launches: issued eagerly they cost
         # the host ~3.4 ms, less than the GPU needs, and eager launching is then ~7 % FASTER than replaying the captured step -- but
         # on a slow or busy host the step becomes host-bound, and the replay (one launch) is the faster way.  Measure both, keep one.
+        # (Single-process runs only: with several ranks the eager mode is kept -- a capture next to RCCL's watchdog threads is a
+        # risk the measurement does not need; `--hip-graph on` still forces the replay there.)
         def per_step(n):
             torch.cuda.synchronize()
             t = time.perf_counter()
