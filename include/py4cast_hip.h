@@ -96,6 +96,18 @@ int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, const float
 int p4c_build_x_bwd(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N, int F,
                     p4c_stream_t stream);
 
+/* K1 with the masked-auto-encoder block mask of mask_tensor (lightning.py:769-785, applied at :580-581) fused in:
+ * x[b, (yy,xx), c] *= 0 for every grid point whose block index (yy / block_h) * W + (xx / block_w) is set in
+ * block_selected (H*W bytes, 1 = drawn by the caller's randperm; the draw itself stays with torch's CPU generator,
+ * as in the reference).  The product with 0.0 is literal (x * False in torch: signed zeros, NaN stays NaN).
+ * Grid layout only (N == H*W).  The backward is the same mask applied to dx. */
+int p4c_build_x_masked(const float* prev, int64_t prev_bs, int64_t prev_ts, const float* statics, int64_t statics_bs,
+                       const float* forcing, int64_t forcing_bs, void* x, int x_dtype, int c_pad, int B, int T_in,
+                       int64_t N, int F, int Fs, int Ff, int mask_on_nan, int downscaling_only,
+                       const uint8_t* block_selected, int H, int W, int block_h, int block_w, p4c_stream_t stream);
+int p4c_build_x_bwd_masked(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N, int F,
+                           const uint8_t* block_selected, int H, int W, int block_h, int block_w, p4c_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K2  ar_update -- replaces lightning.py:599-633 (clone, scaled / plain residual update,
  * border forcing) in ONE pass, evaluated in the reference's operation order with FMA

@@ -15,6 +15,32 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 
 
+def common_features_idx(output_feature_names: Sequence[str], forcing_feature_names: Sequence[str]) -> List[int]:
+    """lightning.py:548-557 (downscaling_only): forcing indices whose name matches an output name after the first
+    underscore-separated token."""
+    idx = []
+    for out_name in output_feature_names:
+        for i, forcing_name in enumerate(forcing_feature_names):
+            if out_name.split("_")[1:] == forcing_name.split("_")[1:]:
+                idx.append(i)
+    return idx
+
+
+def cosine_with_min_lr(step: int, num_warmup_steps: int, num_training_steps: int, min_lr_rate: float,
+                       num_cycles: float = 0.5) -> float:
+    """The LR multiplier of transformers' get_cosine_with_min_lr_schedule_with_warmup (third-party, pinned
+    transformers==4.45.2 in the reference's requirements; used at lightning.py:453-458 with min_lr=min_learning_rate, i.e.
+    min_lr_rate = min_lr / lr).  Published algorithm: linear warm-up, then a cosine from 1 to min_lr_rate."""
+    import math
+
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    factor = 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress))
+    factor = factor * (1 - min_lr_rate) + min_lr_rate
+    return max(0, factor)
+
+
 def strategy_params(training_strategy: str, num_inter_steps: int) -> Tuple[bool, bool, int]:
     """lightning.py:678-694 (_strategy_params)."""
     force_border = training_strategy == "scaled_ar"
@@ -69,6 +95,7 @@ def rollout(
     features_second: bool = False,
     num_pred_steps: Optional[int] = None,
     common_features_idx: Optional[Sequence[int]] = None,
+    mask_ratio: float = 0,
 ) -> torch.Tensor:
     """
     lightning.py:495-676 (_common_step).  ``model_fn`` maps x -> y in the layout the model
@@ -89,6 +116,9 @@ def rollout(
                 border_state = torch.nan_to_num(border_state, nan=0)
         for k in range(K):
             x = next_x(prev_states, statics, forcing.select(1, i), T_in, mask_on_nan, ds)
+            if mask_ratio != 0:  # :580-581, one draw from the global CPU generator per model call (:775)
+                n_blocks = int((1 - mask_ratio) * x.shape[1] * x.shape[2])
+                x = mask_tensor(x, mask_ratio, torch.randperm(x.shape[1] * x.shape[2])[:n_blocks])
             if features_second:
                 y = model_fn(x.movedim(-1, 1)).movedim(1, -1)
             else:

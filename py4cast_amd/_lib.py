@@ -30,6 +30,8 @@ F = c_float
 SIGNATURES = {
     "p4c_build_x": [P, L, L, P, L, P, L, P, I, I, I, I, L, I, I, I, I, I, P],
     "p4c_build_x_bwd": [P, I, I, P, I, I, L, I, P],
+    "p4c_build_x_masked": [P, L, L, P, L, P, L, P, I, I, I, I, L, I, I, I, I, I, P, I, I, I, I, P],
+    "p4c_build_x_bwd_masked": [P, I, I, P, I, I, L, I, P, I, I, I, I, P],
     "p4c_ar_update_fwd": [P, L, P, I, I, P, L, P, P, P, P, P, L, I, L, I, F, I, P],
     "p4c_ar_update_bwd": [P, L, P, P, P, I, I, P, L, I, L, I, F, P],
     "p4c_mask_all_zero_count": [P, I, L, L, I, I, L, I, P, P],

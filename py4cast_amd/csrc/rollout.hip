@@ -24,13 +24,24 @@ __host__ __device__ static inline int pow2_ge(int v) {
 
 constexpr int K1_MAX_ITERS = 8;  // channels handled per lane: c_pad <= 64*K1_MAX_ITERS
 
+// mask_tensor (lightning.py:769-785) as addressing: grid point (yy, xx) lies in a cleared block iff flat index
+// (yy / block_h) * W + (xx / block_w) was drawn -- `selected` is that H*W byte table (1 = drawn).
+struct BlockMask {
+    const uint8_t* selected;
+    int W, block_h, block_w;
+    __device__ bool hit(int64_t n) const {
+        const int yy = (int)(n / W), xx = (int)(n - (int64_t)yy * W);
+        return selected[(int64_t)(yy / block_h) * W + (xx / block_w)] != 0;
+    }
+};
+
 template <typename TX>
 __global__ void __launch_bounds__(256) build_x_kernel(const float* __restrict__ prev, int64_t prev_bs, int64_t prev_ts,
                                                       const float* __restrict__ statics, int64_t statics_bs,
                                                       const float* __restrict__ forcing, int64_t forcing_bs,
                                                       TX* __restrict__ x, int c_pad, int B, int T_in, int64_t N,
                                                       int F, int Fs, int Ff, int mask_on_nan, int n_prev_ch,
-                                                      int FP, int iters) {
+                                                      int FP, int iters, BlockMask bm) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -84,6 +95,9 @@ __global__ void __launch_bounds__(256) build_x_kernel(const float* __restrict__ 
             if (c < c_pad) {
                 float v = vals[it];
                 if (mask_on_nan && c == c_in - 1) v = any_nan ? 0.0f : 1.0f;  // ~combined_mask (lightning.py:750-752)
+                // masked-auto-encoder blocks (lightning.py:769-785: `x * mask`, mask False on the drawn blocks): the product
+                // with 0.0 is taken literally (sign of zero, NaN propagation), bit for bit what torch's x * False gives
+                if (bm.selected && c < c_in && bm.hit(n)) v = v * 0.0f;
                 xrow[c] = from_f32<TX>(v);
             }
         }
@@ -186,7 +200,8 @@ __global__ void __launch_bounds__(256)
 
 template <typename TX>
 __global__ void __launch_bounds__(256) build_x_bwd_kernel(const TX* __restrict__ dx, int c_pad, float* __restrict__ dprev,
-                                                          int B, int T_in, int64_t N, int F, int FP, int iters) {
+                                                          int B, int T_in, int64_t N, int F, int FP, int iters,
+                                                          BlockMask bm) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -203,7 +218,9 @@ __global__ void __launch_bounds__(256) build_x_bwd_kernel(const TX* __restrict__
             const int c = c0 + it * FP;
             if (c < nch) {
                 const int t = c / F, f = c - t * F;
-                dprev[(((int64_t)b * T_in + t) * N + n) * F + f] = to_f32<TX>(dx[pix * (int64_t)c_pad + c]);
+                float g = to_f32<TX>(dx[pix * (int64_t)c_pad + c]);
+                if (bm.selected && bm.hit(n)) g = g * 0.0f;   // adjoint of x * mask
+                dprev[(((int64_t)b * T_in + t) * N + n) * F + f] = g;
             }
         }
     }
@@ -306,10 +323,10 @@ static inline int stream_grid(int64_t total_pixels, int PP) {
 
 using namespace p4c;
 
-extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, const float* statics,
-                           int64_t statics_bs, const float* forcing, int64_t forcing_bs, void* x, int x_dtype,
-                           int c_pad, int B, int T_in, int64_t N, int F, int Fs, int Ff, int mask_on_nan,
-                           int downscaling_only, p4c_stream_t stream) {
+static int build_x_impl(const float* prev, int64_t prev_bs, int64_t prev_ts, const float* statics,
+                        int64_t statics_bs, const float* forcing, int64_t forcing_bs, void* x, int x_dtype,
+                        int c_pad, int B, int T_in, int64_t N, int F, int Fs, int Ff, int mask_on_nan,
+                        int downscaling_only, BlockMask bm, p4c_stream_t stream) {
     P4C_CHECK_ARG(x && statics && forcing, "p4c_build_x: null pointer");
     P4C_CHECK_ARG(B > 0 && N > 0 && F > 0 && Fs >= 0 && Ff >= 0 && T_in >= 0, "p4c_build_x: bad dims");
     const int n_prev_ch = downscaling_only ? 0 : T_in * F;
@@ -320,7 +337,7 @@ extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, 
     const int iters = (c_pad + FP - 1) / FP;
     P4C_CHECK_ARG(iters <= K1_MAX_ITERS, "p4c_build_x: c_pad %d too large (max %d)", c_pad, 64 * K1_MAX_ITERS);
     const bool odd = c_pad % 4 != 0;   // the exact C_in of a generic model (e.g. 69): fp32 rows, unaligned vector stores
-    if (!mask_on_nan && c_pad <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+    if (!mask_on_nan && !bm.selected && c_pad <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
         ((x_dtype == P4C_F32) || (x_dtype == P4C_BF16 && !odd))) {
         const int FP4 = pow2_ge((c_pad + 3) / 4);
         const int vec_prev = n_prev_ch > 0 && F % 4 == 0 && prev_bs % 4 == 0 && prev_ts % 4 == 0 &&
@@ -347,15 +364,40 @@ extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, 
     if (x_dtype == P4C_F32)
         hipLaunchKernelGGL(build_x_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
                            statics, statics_bs, forcing, forcing_bs, (float*)x, c_pad, B, T_in, N, F, Fs, Ff,
-                           mask_on_nan, n_prev_ch, FP, iters);
+                           mask_on_nan, n_prev_ch, FP, iters, bm);
     else if (x_dtype == P4C_BF16)
         hipLaunchKernelGGL(build_x_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), prev, prev_bs, prev_ts,
                            statics, statics_bs, forcing, forcing_bs, (bf16*)x, c_pad, B, T_in, N, F, Fs, Ff,
-                           mask_on_nan, n_prev_ch, FP, iters);
+                           mask_on_nan, n_prev_ch, FP, iters, bm);
     else
         return fail(P4C_ERR_INVALID, "p4c_build_x: bad dtype %d", x_dtype);
     P4C_CHECK_LAUNCH("p4c_build_x");
     return P4C_OK;
+}
+
+extern "C" int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, const float* statics,
+                           int64_t statics_bs, const float* forcing, int64_t forcing_bs, void* x, int x_dtype,
+                           int c_pad, int B, int T_in, int64_t N, int F, int Fs, int Ff, int mask_on_nan,
+                           int downscaling_only, p4c_stream_t stream) {
+    return build_x_impl(prev, prev_bs, prev_ts, statics, statics_bs, forcing, forcing_bs, x, x_dtype, c_pad, B, T_in, N, F, Fs,
+                        Ff, mask_on_nan, downscaling_only, BlockMask{nullptr, 1, 1, 1}, stream);
+}
+
+static int check_block_mask(const uint8_t* selected, int H, int W, int block_h, int block_w, int64_t N, const char* who) {
+    P4C_CHECK_ARG(selected, "%s: block table is null", who);
+    P4C_CHECK_ARG(H > 0 && W > 0 && (int64_t)H * W == N, "%s: H*W (%d*%d) != N (%lld)", who, H, W, (long long)N);
+    P4C_CHECK_ARG(block_h > 0 && block_w > 0, "%s: block size must be positive", who);
+    return P4C_OK;
+}
+
+extern "C" int p4c_build_x_masked(const float* prev, int64_t prev_bs, int64_t prev_ts, const float* statics,
+                                  int64_t statics_bs, const float* forcing, int64_t forcing_bs, void* x, int x_dtype,
+                                  int c_pad, int B, int T_in, int64_t N, int F, int Fs, int Ff, int mask_on_nan,
+                                  int downscaling_only, const uint8_t* block_selected, int H, int W, int block_h,
+                                  int block_w, p4c_stream_t stream) {
+    if (int rc = check_block_mask(block_selected, H, W, block_h, block_w, N, "p4c_build_x_masked")) return rc;
+    return build_x_impl(prev, prev_bs, prev_ts, statics, statics_bs, forcing, forcing_bs, x, x_dtype, c_pad, B, T_in, N, F, Fs,
+                        Ff, mask_on_nan, downscaling_only, BlockMask{block_selected, W, block_h, block_w}, stream);
 }
 
 // ---------------------------------------------------------------------------- rows next to the path
@@ -473,8 +515,8 @@ extern "C" int p4c_pack_standardize(const float* raw, int64_t plane_stride, cons
     return P4C_OK;
 }
 
-extern "C" int p4c_build_x_bwd(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N,
-                               int F, p4c_stream_t stream) {
+static int build_x_bwd_impl(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N,
+                            int F, BlockMask bm, p4c_stream_t stream) {
     P4C_CHECK_ARG(dx && dprev, "p4c_build_x_bwd: null pointer");
     P4C_CHECK_ARG(c_pad >= T_in * F, "p4c_build_x_bwd: c_pad < T_in*F");
     const int nch = T_in * F;
@@ -483,14 +525,26 @@ extern "C" int p4c_build_x_bwd(const void* dx, int dx_dtype, int c_pad, float* d
     const int grid = stream_grid((int64_t)B * N, 64 / FP);
     if (dx_dtype == P4C_F32)
         hipLaunchKernelGGL(build_x_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dx,
-                           c_pad, dprev, B, T_in, N, F, FP, iters);
+                           c_pad, dprev, B, T_in, N, F, FP, iters, bm);
     else if (dx_dtype == P4C_BF16)
         hipLaunchKernelGGL(build_x_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)dx,
-                           c_pad, dprev, B, T_in, N, F, FP, iters);
+                           c_pad, dprev, B, T_in, N, F, FP, iters, bm);
     else
         return fail(P4C_ERR_INVALID, "p4c_build_x_bwd: bad dtype %d", dx_dtype);
     P4C_CHECK_LAUNCH("p4c_build_x_bwd");
     return P4C_OK;
+}
+
+extern "C" int p4c_build_x_bwd(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N,
+                               int F, p4c_stream_t stream) {
+    return build_x_bwd_impl(dx, dx_dtype, c_pad, dprev, B, T_in, N, F, BlockMask{nullptr, 1, 1, 1}, stream);
+}
+
+extern "C" int p4c_build_x_bwd_masked(const void* dx, int dx_dtype, int c_pad, float* dprev, int B, int T_in, int64_t N,
+                                      int F, const uint8_t* block_selected, int H, int W, int block_h, int block_w,
+                                      p4c_stream_t stream) {
+    if (int rc = check_block_mask(block_selected, H, W, block_h, block_w, N, "p4c_build_x_bwd_masked")) return rc;
+    return build_x_bwd_impl(dx, dx_dtype, c_pad, dprev, B, T_in, N, F, BlockMask{block_selected, W, block_h, block_w}, stream);
 }
 
 extern "C" int p4c_ar_update_fwd(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,

@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib as L
 from . import ops_graph as G
 from . import ops_mlp as M
 from . import ops_rows as R
@@ -121,13 +122,28 @@ def cached_static_embeddings(model: nn.Module, embedders, feats, B: int, dt: tor
     steps of one rollout (the model is called once per step, py4cast/lightning.py:591-596) share them: computed once per parameter
     version (and autograd mode); their autograd graph is walked once by the rollout's backward, which sums the steps' gradients,
     and is rebuilt by the next forward (gradient accumulation over micro-batches with unchanged parameters)."""
-    key = (B, dt, torch.is_grad_enabled(), tuple(p._version for e in embedders for p in e.parameters()),
-           tuple(p.data_ptr() for e in embedders for p in e.parameters()))
-    cache = getattr(model, "_static_cache", None)
-    if cache is None or cache[0] != key:
+    params = [p for e in embedders for p in e.parameters()]
+    key = (B, dt, torch.is_grad_enabled(), L.PARAM_EPOCH[0], tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+
+    def compute():
         rep = lambda t: t.unsqueeze(0).expand(B, *t.shape).reshape(B * t.shape[0], t.shape[1])  # noqa: E731
-        embs = tuple(rep(_run(e, f.to(dt))) for e, f in zip(embedders, feats))
-        model._static_cache = (key, embs)
+        return tuple(rep(_run(e, f.to(dt))) for e, f in zip(embedders, feats))
+
+    if torch.cuda.is_current_stream_capturing():
+        # a HIP graph must derive the embeddings with ITS OWN kernels (a replay has to see the current parameters, and a tensor of
+        # an eager warm-up step would be read after the allocator has recycled it): once per capture when the capturing code
+        # opened a scope, else once per call; the module-level cache is neither read nor written here
+        scope = L.capture_cache()
+        if scope is None:
+            return compute()
+        skey = ("static_emb", id(model)) + key
+        if skey not in scope:
+            scope[skey] = compute()
+        return scope[skey]
+    cache = getattr(model, "_static_cache", None)
+    if cache is None or cache[0] != key or not L.owners_alive(cache[2], params):
+        embs = compute()
+        model._static_cache = (key, embs, L.owner_refs(params))
 
         def drop(grad):
             model._static_cache = None

@@ -329,13 +329,15 @@ class AutoRegressiveLightning(_Base):
                         common.append(i)
             self.common_features_idx = common
 
-    def _next_x(self, batch: ItemBatch, prev_states: NamedTensor, step_idx: int, c_pad=None, dtype=torch.float32):
-        """lightning.py:711-767 as one kernel (K1).  Returns (B,*S,C_in[+pad])."""
+    def _next_x(self, batch: ItemBatch, prev_states: NamedTensor, step_idx: int, c_pad=None, dtype=torch.float32,
+                blocks=None):
+        """lightning.py:711-767 as one kernel (K1).  Returns (B,*S,C_in[+pad]).  ``blocks``: the block mask of
+        ``mask_tensor`` (:580-581), applied by the same kernel."""
         forcing_i = batch.forcing.select_tensor_dim("timestep", step_idx)
         ds = self.training_strategy == "downscaling_only"
         return ops.build_x(
             prev_states.tensor, self.grid_static_features[: batch.batch_size], forcing_i, self.mask_on_nan, ds,
-            c_pad=c_pad, dtype=dtype,
+            c_pad=c_pad, dtype=dtype, blocks=blocks,
         )
 
     def _common_step(self, batch: ItemBatch, batch_idx: int, phase: str) -> Tuple[NamedTensor, NamedTensor]:
@@ -391,11 +393,16 @@ class AutoRegressiveLightning(_Base):
         for i in range(T):
             border_state = None if inference else batch.outputs.select_tensor_dim("timestep", i)
             for k in range(num_inter_steps):
-                x = self._next_x(batch, prev_states, i)
+                # maskedautoencoder strategy (lightning.py:580-581): the draw is the reference's (torch CPU generator, one per
+                # model call), the product x * mask happens inside build_x (and its adjoint inside build_x's backward)
+                blocks = None
+                if self.mask_ratio != 0 and batch.forcing.tensor.dim() == 5:
+                    blocks = ops.BlockMask.draw(batch.forcing.tensor.shape[2], batch.forcing.tensor.shape[3], self.mask_ratio, device)
+                x = self._next_x(batch, prev_states, i, blocks=blocks)
                 if self.channels_last:
                     x = x.to(memory_format=torch.channels_last)
-                if self.mask_ratio != 0:
-                    x = self.mask_tensor(x)
+                if self.mask_ratio != 0 and blocks is None:
+                    x = self.mask_tensor(x)   # graph layout: the reference's unpacking raises ValueError (3-d x), so does this
                 if self.model.features_second:  # lightning.py:591-596
                     y = features_second_to_last(self.model(features_last_to_second(x)))
                 else:
@@ -442,22 +449,14 @@ class AutoRegressiveLightning(_Base):
         return pred_out, batch.outputs
 
     def mask_tensor(self, x):
-        """lightning.py:769-785 (MAE-style block masking; index op, torch CPU generator)."""
+        """lightning.py:769-785 (MAE-style block masking) for callers outside the rollout; the rollout itself applies the same
+        mask inside ``build_x``.  The reference clears, for every drawn index i, the block [row*bh, (row+1)*bh) x
+        [col*bw, (col+1)*bw) with row = i // W, col = i % W, in a Python loop over up to H*W indices.  Equivalently: pixel
+        (y, x) is cleared iff index (y // bh) * W + (x // bw) was drawn (same torch CPU generator draw, so the same mask bit
+        for bit: tests/test_abi_cpu.py::test_mask_tensor_matches_reference_loop, tests/test_round2_gpu.py)."""
         _, height, width, _ = x.shape
-        num_blocks = int((1 - self.mask_ratio) * height * width)
-        block_size_h = height // int(height**0.5)
-        block_size_w = width // int(width**0.5)
-        # The reference clears, for every drawn index i, the block [row*bh, (row+1)*bh) x [col*bw, (col+1)*bw) with row = i // W,
-        # col = i % W, in a Python loop over up to H*W indices.  Equivalently: pixel (y, x) is cleared iff index
-        # (y // bh) * W + (x // bw) was drawn -- one scatter and one gather on the device (same torch CPU generator draw, so the
-        # same mask bit for bit: tests/test_abi_cpu.py::test_mask_tensor_matches_reference_loop).
-        drawn = torch.randperm(height * width)[:num_blocks]
-        selected = torch.zeros(height * width, dtype=torch.bool, device=x.device)
-        selected[drawn.to(x.device)] = True
-        by = torch.arange(height, device=x.device) // block_size_h
-        bx = torch.arange(width, device=x.device) // block_size_w
-        mask = ~selected[by[:, None] * width + bx[None, :]]
-        return x * mask[None, :, :, None]
+        blocks = ops.BlockMask.draw(height, width, self.mask_ratio, x.device)
+        return x * blocks.dense(height, width)[None, :, :, None]
 
     def get_mask_on_nan(self, target: NamedTensor):
         """

@@ -53,7 +53,7 @@ def pad_channels(c: int, multiple: int = 16) -> int:
 # ------------------------------------------------------------------------------ K1
 class _BuildX(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, prev_states, statics, forcing_i, mask_on_nan, downscaling_only, c_pad, out_dtype):
+    def forward(ctx, prev_states, statics, forcing_i, mask_on_nan, downscaling_only, c_pad, out_dtype, blocks=None):
         L.require_cuda(prev_states, statics, forcing_i)
         B, T_in = prev_states.shape[0], prev_states.shape[1]
         F, Fs, Ff = prev_states.shape[-1], statics.shape[-1], forcing_i.shape[-1]
@@ -64,27 +64,64 @@ class _BuildX(torch.autograd.Function):
         c_in = (0 if downscaling_only else T_in * F) + Fs + Ff + int(mask_on_nan)
         c_pad = c_in if c_pad is None else c_pad
         x = torch.empty(forcing_i.shape[:-1] + (c_pad,), dtype=out_dtype, device=forcing_i.device)
-        L.call(
-            "p4c_build_x", L.ptr(prev), pbs, pts, L.ptr(st), sbs, L.ptr(fo), fbs, L.ptr(x), L.dtype_code(out_dtype),
-            c_pad, B, T_in, N, F, Fs, Ff, int(mask_on_nan), int(downscaling_only), L.stream(x.device),
-        )
-        ctx.meta = (B, T_in, N, F, c_pad, bool(downscaling_only), prev_states.shape)
+        args = (L.ptr(prev), pbs, pts, L.ptr(st), sbs, L.ptr(fo), fbs, L.ptr(x), L.dtype_code(out_dtype),
+                c_pad, B, T_in, N, F, Fs, Ff, int(mask_on_nan), int(downscaling_only))
+        if blocks is None:
+            L.call("p4c_build_x", *args, L.stream(x.device))
+        else:
+            if forcing_i.dim() != 4:
+                raise L.P4CError("build_x: the block mask needs the grid layout (B, H, W, features)")
+            L.call("p4c_build_x_masked", *args, L.ptr(blocks.selected), forcing_i.shape[1], forcing_i.shape[2], blocks.block_h,
+                   blocks.block_w, L.stream(x.device))
+        ctx.meta = (B, T_in, N, F, c_pad, bool(downscaling_only), prev_states.shape, blocks, tuple(forcing_i.shape[1:3]))
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        B, T_in, N, F, c_pad, ds, shape = ctx.meta
+        B, T_in, N, F, c_pad, ds, shape, blocks, hw = ctx.meta
         if ds:
-            return (torch.zeros(shape, dtype=torch.float32, device=dx.device),) + (None,) * 6
+            return (torch.zeros(shape, dtype=torch.float32, device=dx.device),) + (None,) * 7
         dx = dx.contiguous()
         dprev = torch.empty(shape, dtype=torch.float32, device=dx.device)
-        L.call("p4c_build_x_bwd", L.ptr(dx), L.dtype_code(dx.dtype), c_pad, L.ptr(dprev), B, T_in, N, F, L.stream(dx.device))
-        return (dprev,) + (None,) * 6
+        if blocks is None:
+            L.call("p4c_build_x_bwd", L.ptr(dx), L.dtype_code(dx.dtype), c_pad, L.ptr(dprev), B, T_in, N, F, L.stream(dx.device))
+        else:
+            L.call("p4c_build_x_bwd_masked", L.ptr(dx), L.dtype_code(dx.dtype), c_pad, L.ptr(dprev), B, T_in, N, F,
+                   L.ptr(blocks.selected), hw[0], hw[1], blocks.block_h, blocks.block_w, L.stream(dx.device))
+        return (dprev,) + (None,) * 7
 
 
-def build_x(prev_states, statics, forcing_i, mask_on_nan=False, downscaling_only=False, c_pad=None, dtype=torch.float32):
-    """lightning.py:711-767.  prev_states (B,T_in,*S,F); statics (B,*S,Fs); forcing_i (B,*S,Ff) -> (B,*S,c_pad)."""
-    return _BuildX.apply(prev_states, statics, forcing_i, mask_on_nan, downscaling_only, c_pad, dtype)
+class BlockMask:
+    """The draw of ``mask_tensor`` (lightning.py:769-785) as a table: ``selected`` (H*W,) uint8 on the device, 1 where the flat
+    index was drawn; grid point (y, x) is cleared iff ``selected[(y // block_h) * W + x // block_w]``."""
+
+    def __init__(self, selected: torch.Tensor, block_h: int, block_w: int):
+        self.selected, self.block_h, self.block_w = selected, int(block_h), int(block_w)
+
+    @staticmethod
+    def draw(height: int, width: int, mask_ratio: float, device) -> "BlockMask":
+        """Same arithmetic and the same torch CPU generator draw as the reference, so the same mask bit for bit."""
+        num_blocks = int((1 - mask_ratio) * height * width)
+        block_h = height // int(height**0.5)
+        block_w = width // int(width**0.5)
+        drawn = torch.randperm(height * width)[:num_blocks]
+        selected = torch.zeros(height * width, dtype=torch.uint8)
+        selected[drawn] = 1
+        return BlockMask(selected.to(device), block_h, block_w)
+
+    def dense(self, height: int, width: int) -> torch.Tensor:
+        """(H, W) bool, True = kept (the reference's ``mask[0, :, :, 0]``); for observers and tests."""
+        dev = self.selected.device
+        by = torch.arange(height, device=dev) // self.block_h
+        bx = torch.arange(width, device=dev) // self.block_w
+        return self.selected[by[:, None] * width + bx[None, :]] == 0
+
+
+def build_x(prev_states, statics, forcing_i, mask_on_nan=False, downscaling_only=False, c_pad=None, dtype=torch.float32,
+            blocks: Optional[BlockMask] = None):
+    """lightning.py:711-767.  prev_states (B,T_in,*S,F); statics (B,*S,Fs); forcing_i (B,*S,Ff) -> (B,*S,c_pad).
+    ``blocks``: the masked-auto-encoder block mask (lightning.py:580-581, 769-785) applied in the same pass."""
+    return _BuildX.apply(prev_states, statics, forcing_i, mask_on_nan, downscaling_only, c_pad, dtype, blocks)
 
 
 # ------------------------------------------------------------------------------ K2

@@ -159,8 +159,11 @@ def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=N
         x = F.pad(x, (0, kp))
     sinks = grad_sinks(w1, b1, w2, b2, gamma, beta) if grads_in_place else None
     owners = (w1, b1, w2, b2, gamma, beta)   # the caller's parameter objects: what the weight-image cache checks for identity
-    if sinks is not None:   # autograd must not also accumulate what the kernel adds itself
-        w1, b1, w2, b2, gamma, beta = (None if t is None else t.detach() for t in (w1, b1, w2, b2, gamma, beta))
+    if sinks is not None:
+        # autograd must not also accumulate what the kernel adds itself: five of the six parameters enter detached.  w1 stays
+        # LIVE so that the node is recorded even when neither x nor the addends / residual need a gradient (first AR step of an
+        # embedder: all inputs are data) -- its slot returns None in the backward, as _RowLinearSink does for its weight
+        b1, w2, b2, gamma, beta = (None if t is None else t.detach() for t in (b1, w2, b2, gamma, beta))
     return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out, sinks, owners)
 
 

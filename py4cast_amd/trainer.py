@@ -49,18 +49,28 @@ class FlatDDP:
 
     def zero_grad(self):
         """One fill over the flat buffer instead of one per parameter (``optimizer.zero_grad(set_to_none=False)``)."""
-        base = self.flat_grad.untyped_storage().data_ptr()
-        if self._views_ok and all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params):
+        if self._views_ok and self._grads_are_views():
             self.flat_grad.zero_()
         else:
             for p in self.params:
                 if p.grad is not None:
                     p.grad.zero_()
 
+    def _grads_are_views(self) -> bool:
+        """Every ``p.grad`` still IS its slice of the flat bucket (same address, so same storage at the expected offset): a grad
+        re-created by autograd after ``zero_grad(set_to_none=True)`` -- wherever the allocator put it -- fails this."""
+        base, off = self.flat_grad.data_ptr(), 0
+        for p in self.params:
+            g = p.grad
+            if g is None or g.dtype != torch.float32 or g.data_ptr() != base + 4 * off or not g.is_contiguous():
+                return False
+            off += p.numel()
+        return True
+
     def all_reduce_grads(self):
         if self.world_size <= 1:
             return
-        if not self._views_ok or any(p.grad is None or p.grad.data_ptr() < self.flat_grad.data_ptr() for p in self.params):
+        if not self._views_ok or not self._grads_are_views():
             self._regather()
         dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
         self.flat_grad.div_(self.world_size)
@@ -146,6 +156,11 @@ class GraphedTrainingStep:
             L.CAPTURE_SCOPE[0] = None
         self.warmup_backwards = warmup + 1   # gradient contributions already accumulated by construction: zero_grad() after
 
+    def accepts(self, batch) -> bool:
+        """The captured graph serves batches of the captured shapes only."""
+        return all(getattr(batch, n).tensor.numel() == self._static[n][0].numel()
+                   and getattr(batch, n).tensor.shape[0] == self._static[n][0].shape[0] for n in ("inputs", "forcing", "outputs"))
+
     def __call__(self, batch):
         for name in ("inputs", "forcing", "outputs"):
             src = getattr(batch, name).tensor
@@ -176,6 +191,7 @@ class Trainer:
         self.global_step = 0
         self.estimated_stepping_batches = 1000
         self.callback_metrics = {}
+        self.train_step_losses = []   # detached per-micro-batch training losses of the last fit (device tensors: no sync here)
 
     @staticmethod
     def _to_device(batch, device):
@@ -200,6 +216,7 @@ class Trainer:
         conf = module.configure_optimizers()
         opt, sched = conf["optimizer"], conf.get("lr_scheduler", {}).get("scheduler")
         ddp = FlatDDP(module)
+        self.train_step_losses = []
         if hasattr(module, "on_train_start"):
             module.on_train_start()
         ddp.zero_grad()
@@ -209,22 +226,39 @@ class Trainer:
         graphed = None
         for epoch in range(self.max_epochs):
             module.train()
-            for i, batch in enumerate(train_dataloader):
+            pending = 0   # micro-batches accumulated since the last optimizer step
+            it = iter(train_dataloader)
+            nxt = next(it, None)
+            i = -1
+            while nxt is not None:
+                batch, nxt = nxt, next(it, None)
+                i += 1
                 if self.limit_train_batches and i >= self.limit_train_batches:
                     break
+                last_of_epoch = nxt is None or bool(self.limit_train_batches and i + 1 >= self.limit_train_batches)
                 batch = self._to_device(batch, self.device)
                 loss = None   # see GraphedTrainingStep: nothing of an earlier eager step may be alive at capture time
                 if graphed is None and use_graph and i > 0:
-                    # the first micro-batch ran eagerly (names / dtypes recorded, lazy initialisation done); capture from the second
+                    # the first micro-batch ran eagerly (names / dtypes recorded, lazy initialisation done); capture from the second.
+                    # The capture's warm-up passes are not part of the training run: gradients and module buffers (BatchNorm
+                    # running statistics, num_batches_tracked) are restored afterwards
                     saved = ddp.flat_grad.clone()
+                    buffers = [(b, b.detach().clone()) for b in module.buffers()]
                     graphed = GraphedTrainingStep(module, batch, loss_scale=1.0 / self.accumulate_grad_batches)
-                    ddp.flat_grad.copy_(saved)   # the capture's warm-up backward passes are not part of the training run
-                if graphed is not None:
+                    ddp.flat_grad.copy_(saved)
+                    for b, keep in buffers:
+                        b.copy_(keep)
+                if graphed is not None and graphed.accepts(batch):
                     loss = graphed(batch)
-                else:
+                else:   # eager; also a batch whose shape differs from the captured one (a short last batch)
                     loss = module.training_step(batch, i)
                     (loss / self.accumulate_grad_batches).backward()
-                if (i + 1) % self.accumulate_grad_batches == 0:  # non-stepping micro-batches do not sync
+                self.train_step_losses.append(loss.detach())
+                pending += 1
+                # Lightning steps every accumulate_grad_batches micro-batches AND on the last batch of an epoch: leftovers do not
+                # leak into the next epoch.  Non-stepping micro-batches do not sync
+                if pending == self.accumulate_grad_batches or last_of_epoch:
+                    pending = 0
                     ddp.all_reduce_grads()
                     opt.step()
                     if sched is not None:

@@ -1,0 +1,361 @@
+"""
+Round-2 GPU parity tests: reference behaviours the first fixture set left out (downscaling_only, multi-member CombinedLoss,
+mask_ratio != 0, the autocast branch of common_step), BASELINE configuration 1 through Trainer.fit, and the benchmark workload
+itself (2 x 512 x 512 x 60, T = 3) in both flavours.  Everything goes through the C ABI (py4cast_amd -> ctypes -> libpy4cast_hip.so).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from helpers import (GRID_DIMS, TinyConvModel, make_batch, make_dataset_info, register_test_models, synthetic_case)
+
+pytestmark = pytest.mark.gpu
+
+MSE = [{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+    return z, eval(str(z["meta"]))
+
+
+def _case(z, prefix="in_"):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+def _named_batch(case, device, feat, fnames):
+    from py4cast_amd.base import ItemBatch
+    from py4cast_amd.namedtensor import NamedTensor
+
+    return ItemBatch(NamedTensor(case["inputs"].clone().to(device), GRID_DIMS, list(feat)),
+                     NamedTensor(case["forcing"].clone().to(device), GRID_DIMS, list(fnames)),
+                     NamedTensor(case["outputs"].clone().to(device), GRID_DIMS, list(feat)))
+
+
+def _tiny_module(case, device, strategy, losses=MSE, feat=None, **kw):
+    from py4cast_amd.base import Stats
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    register_test_models()
+    Ff = case["forcing"].shape[-1]
+    info = make_dataset_info(case, Ff)
+    if feat is not None:   # named features (downscaling_only pairs names): re-key the per-feature dictionaries
+        F = len(feat)
+        info.stats = Stats({n: {"std": case["std"][i], "mean": torch.tensor(0.0)} for i, n in enumerate(feat)})
+        info.diff_stats = Stats({n: {"std": case["diff_std"][i], "mean": case["diff_mean"][i]} for i, n in enumerate(feat)})
+        info.state_weights = {n: float(case["state_weight"][i]) for i, n in enumerate(feat)}
+        info.shortnames = {"input_output": list(feat)}
+        assert F == info.weather_dim
+    lm = AutoRegressiveLightning({}, info, None, num_input_steps=1, num_pred_steps_train=3, batch_size=2, model_name="TinyConvModel",
+                                 losses=losses, training_strategy=strategy, **kw)
+    with torch.no_grad():
+        lm.model.w.copy_(case["w"])
+        lm.model.b.copy_(case["b"])
+    return lm.to(device), info
+
+
+# ------------------------------------------------------------------------------------------------ downscaling_only (a3)
+def test_downscaling_only_matches_reference_golden(gpu_device):
+    """lightning.py:541-558 (name pairing), :611-621 (coarse forcing + y), :725-766 (x without the previous states)."""
+    z, meta = load("r2_downscaling_only.npz")
+    case = _case(z)
+    lm, info = _tiny_module(case, gpu_device, "downscaling_only", feat=meta["feat"])
+    batch = _named_batch(case, gpu_device, meta["feat"], meta["fnames"])
+    pred, tgt = lm._common_step(batch, 0, "train")
+    assert lm.common_features_idx == list(z["out_common_features_idx"])
+    np.testing.assert_allclose(pred.tensor.detach().cpu().numpy(), z["out_prediction"], rtol=1e-4, atol=2e-5)
+    loss = lm.training_step(_named_batch(case, gpu_device, meta["feat"], meta["fnames"]), 0)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z["out_train_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(lm.model.w.grad.cpu().numpy(), z["out_grad_w"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(lm.model.b.grad.cpu().numpy(), z["out_grad_b"], rtol=2e-3, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ CombinedLoss (a9)
+@pytest.mark.parametrize("tag,nan", [("nonan", False), ("nan", True)])
+def test_two_member_combined_loss_matches_reference_golden(gpu_device, tag, nan):
+    """losses.py:268-307: 0.7 * WeightedLoss(MSE) + 0.3 * WeightedLoss(L1), values, spatial map, training loss and BPTT gradients."""
+    z, meta = load("r2_combined_loss.npz")
+    case = _case(z, f"in_{tag}_")
+    lm, info = _tiny_module(case, gpu_device, "scaled_ar", losses=meta["losses"], mask_on_nan=nan)
+    assert len(lm.loss.losses) == 2
+    pred, tgt = lm._common_step(make_batch(case, gpu_device), 0, "train")
+    assert getattr(pred, "fused_loss", None) is None   # two members: the generic per-op path, losses evaluated by CombinedLoss
+    mask, tgt_m = lm.get_mask_on_nan(tgt)
+    val = lm.loss(pred, tgt_m, mask=mask)
+    vmap = lm.loss(pred, tgt_m, mask=mask, reduce_spatial_dim=False)
+    np.testing.assert_allclose(val.detach().cpu().numpy(), z[f"out_{tag}_loss"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(vmap.detach().cpu().numpy(), z[f"out_{tag}_loss_map"], rtol=2e-3, atol=2e-4)
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z[f"out_{tag}_train_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(lm.model.w.grad.cpu().numpy(), z[f"out_{tag}_grad_w"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(lm.model.b.grad.cpu().numpy(), z[f"out_{tag}_grad_b"], rtol=2e-3, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ mask_tensor (a7)
+def test_mask_tensor_on_gpu_bit_exact_vs_reference(gpu_device):
+    """lightning.py:769-785 on the device: same CPU-generator draw, same bits (-0.0 and NaN included) as the reference's loop."""
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    z, _ = load("r2_mask_ratio.npz")
+    for idx in range(3):
+        H, W, ratio, seed = z[f"mt{idx}_meta"]
+
+        class Holder:
+            mask_ratio = float(ratio)
+
+        torch.manual_seed(int(seed))
+        got = AutoRegressiveLightning.mask_tensor(Holder(), torch.from_numpy(z[f"mt{idx}_x"]).to(gpu_device))
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), z[f"mt{idx}_out"].view(np.uint32)), idx
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nan", [False, True])
+def test_build_x_with_fused_block_mask(gpu_device, dtype, nan):
+    """p4c_build_x_masked == p4c_build_x followed by the reference's `x * mask` (bit for bit), and its backward is the adjoint."""
+    from oracle import rollout as orollout
+    from py4cast_amd import ops
+
+    H, W, T_in, F, Ff, Fs = 20, 37, 2, 5, 7, 4
+    case = synthetic_case(seed=31, H=H, W=W, T_in=T_in, F=F, Ff=Ff, Fs=Fs, nan=nan)
+    B = case["inputs"].shape[0]
+    statics = case["statics"].unsqueeze(0).expand(B, *case["statics"].shape)
+    torch.manual_seed(17)
+    draw = torch.randperm(H * W)[: int((1 - 0.4) * H * W)]
+    ref = orollout.mask_tensor(orollout.next_x(case["inputs"], statics, case["forcing"][:, 1], T_in, mask_on_nan=nan).float(), 0.4, draw)
+    torch.manual_seed(17)
+    blocks = ops.BlockMask.draw(H, W, 0.4, gpu_device)
+    prev = case["inputs"].to(gpu_device).requires_grad_(True)
+    got = ops.build_x(prev, statics.to(gpu_device), case["forcing"][:, 1].to(gpu_device), nan, dtype=dtype, blocks=blocks)
+    want = ref.to(dtype).float()
+    assert np.array_equal(got.float().detach().cpu().numpy().view(np.uint32), want.numpy().view(np.uint32))
+    g = torch.randn(got.shape, generator=torch.Generator().manual_seed(3)).to(gpu_device).to(dtype)
+    got.backward(g)
+    keep = blocks.dense(H, W)[None, :, :, None]
+    gref = torch.stack([g[..., :F], g[..., F:2 * F]], dim=1).float() * keep[:, None]
+    assert torch.equal(prev.grad, gref)
+
+
+def test_mask_ratio_rollout_matches_reference_golden(gpu_device):
+    """A 3-step scaled_ar rollout with mask_ratio = 0.5: one draw per model call in call order, applied inside build_x."""
+    z, meta = load("r2_mask_ratio.npz")
+    case = _case(z)
+    lm, info = _tiny_module(case, gpu_device, "scaled_ar", mask_ratio=meta["mask_ratio"])
+    torch.manual_seed(meta["seed"])
+    pred, _ = lm._common_step(make_batch(case, gpu_device), 0, "train")
+    np.testing.assert_allclose(pred.tensor.detach().cpu().numpy(), z["out_prediction"], rtol=1e-4, atol=2e-5)
+    torch.manual_seed(meta["seed"])
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z["out_train_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(lm.model.w.grad.cpu().numpy(), z["out_grad_w"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(lm.model.b.grad.cpu().numpy(), z["out_grad_b"], rtol=2e-3, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ autocast branch (a2)
+def test_common_step_precision_follows_the_trainer(gpu_device):
+    """lightning.py:479-493: common_step wraps the rollout in torch.autocast(dtype = trainer.precision) for torch models; native HIP
+    models carry their precision themselves.  A torch model under `bf16-true` must see bf16 matmul inputs (its conv output is
+    bf16), under `32-true` fp32; the state update and the loss stay fp32 either way."""
+    from py4cast_amd.trainer import Trainer
+
+    z, meta = load("r2_combined_loss.npz")
+    case = _case(z, "in_nonan_")
+    lm, info = _tiny_module(case, gpu_device, "scaled_ar")
+    seen = []
+    lm.model.register_forward_hook(lambda m, i, o: seen.append(o.dtype))
+    ref = {}
+    for precision, want in (("32-true", torch.float32), ("bf16-true", torch.bfloat16), ("bf16", torch.bfloat16), (32, torch.float32)):
+        lm.trainer = Trainer(precision=precision, device=gpu_device)
+        assert lm.dtype == want
+        seen.clear()
+        pred, tgt = lm.common_step(make_batch(case, gpu_device), 0, "train")
+        assert seen and all(d == want for d in seen), (precision, seen)
+        assert pred.tensor.dtype == torch.float32   # .type_as(batch.outputs.tensor), lightning.py:672-675
+        ref[want] = pred.tensor.detach().clone()
+    # the bf16 rollout is the fp32 one up to bf16 rounding of the model output (2^-9 relative per step)
+    assert 1e-5 < rel_err(ref[torch.bfloat16], ref[torch.float32]) < 2e-2
+    # the same thing computed with plain torch under autocast (the reference's literal structure) agrees to rounding
+    from oracle import rollout as orollout
+
+    c = {k: v.to(gpu_device) for k, v in case.items()}
+    B = c["inputs"].shape[0]
+    with torch.no_grad(), torch.amp.autocast("cuda", dtype=torch.bfloat16):
+        want = orollout.rollout(lm.model, c["inputs"], c["forcing"], c["outputs"], c["statics"].unsqueeze(0).expand(B, *c["statics"].shape),
+                                c["border_mask"], 1.0 - c["border_mask"], c["diff_std"], c["diff_mean"], "scaled_ar", 1, False, "train",
+                                features_second=True)
+    assert rel_err(ref[torch.bfloat16], want) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configuration 1
+def test_config1_dummy_dataset_halfunet_through_trainer_fit(gpu_device):
+    """BASELINE.json configs[0] as the reference ships it (config/CLI/dataset/dummy.yaml + model/halfunet.yaml + trainer.yaml):
+    64x64 grid, ONE weather feature (dummy_parameter_500, diff std 1.42, weight 1), 5 forcings, 4 statics, diff_ar, 1 AR step,
+    B = 2, fp32, AdamW(1e-3, betas 0.9/0.95) + cosine schedule with 1000 warm-up steps, through Trainer.fit -- against the same
+    loop on the CPU oracle (rollout + loss restatements pinned to the reference; HalfUNet restatement unpinned)."""
+    from oracle import losses as olosses
+    from oracle import rollout as orollout
+    from oracle.halfunet import HalfUNetRef
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from py4cast_amd.trainer import Trainer
+
+    H = W = 64
+    F, Ff, Fs, B, n_batches, accumulate = 1, 5, 4, 2, 4, 2
+    cases = []
+    for i in range(n_batches):
+        c = synthetic_case(seed=400 + i, B=B, T=1, H=H, W=W, F=F, Ff=Ff, Fs=Fs, border=0)
+        c["diff_std"], c["diff_mean"] = torch.tensor([1.42]), torch.tensor([0.0])
+        c["std"], c["state_weight"] = torch.tensor([1.0]), torch.tensor([1.0])
+        c["statics"] = cases[0]["statics"] if cases else c["statics"]
+        cases.append(c)
+    info = make_dataset_info(cases[0], Ff)
+    settings = dict(num_filters=64, dilation=1, bias=False, use_ghost=False, last_activation="Identity", absolute_pos_embed=False,
+                    autopad_enabled=True)   # config/CLI/model/halfunet.yaml:19-26
+    torch.manual_seed(0)
+    lm = AutoRegressiveLightning(settings, info, None, dataset_name="dummy", num_input_steps=1, num_pred_steps_train=1,
+                                 num_pred_steps_val_test=1, batch_size=B, model_name="HalfUNet", losses=MSE, training_strategy="diff_ar",
+                                 learning_rate=1e-3, min_learning_rate=3e-7, num_warmup_steps=1000, betas=(0.9, 0.95))
+    ref = HalfUNetRef(F + Fs + Ff, F)
+    ref.load_state_dict(lm.model.state_dict())
+    init = {k: v.detach().clone() for k, v in lm.model.state_dict().items()}
+    trainer = Trainer(max_epochs=1, accumulate_grad_batches=accumulate, precision=32, device=gpu_device)
+    trainer.fit(lm, [make_batch(c, torch.device("cpu")) for c in cases])
+    assert trainer.global_step == n_batches // accumulate
+    got_losses = [float(l) for l in trainer.train_step_losses]
+
+    # the same loop on the oracle
+    total = max(1, n_batches // accumulate)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, betas=(0.9, 0.95))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: orollout.cosine_with_min_lr(s, 1000, total, 3e-7 / 1e-3))
+    ref.train()
+    ref_losses = []
+    for i, c in enumerate(cases):
+        statics = c["statics"].unsqueeze(0).expand(B, *c["statics"].shape)
+        interior = 1.0 - c["border_mask"]
+        pred = orollout.rollout(ref, c["inputs"], c["forcing"], c["outputs"], statics, c["border_mask"], interior, c["diff_std"],
+                                c["diff_mean"], "diff_ar", 1, False, "train", features_second=True)
+        wts = olosses.weighted_loss_weights(c["state_weight"], c["diff_std"], "mse")
+        loss = olosses.training_loss(pred, c["outputs"], False, [("WeightedLoss", 1.0, dict(weights=wts, interior_mask=interior, kind="mse"))])
+        (loss / accumulate).backward()
+        ref_losses.append(float(loss))
+        if (i + 1) % accumulate == 0:
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+    np.testing.assert_allclose(got_losses, ref_losses, rtol=2e-4)
+    # with 1000 warm-up steps the first update has lr = 0 (the schedule's multiplier at step 0) and the second lr = 1e-6: an AdamW
+    # step moves every element by ~lr.  Both loops must have moved the parameters, and by the same amount to a few percent of lr
+    sd = ref.state_dict()
+    moved, apart = [], []
+    for name, p in lm.model.named_parameters():
+        moved.append((p.detach().cpu().double() - init[name].double()).abs().mean())
+        apart.append((p.detach().cpu().double() - sd[name].double()).abs().mean())
+    assert float(torch.stack(moved).mean()) > 3e-7, moved
+    assert float(torch.stack(apart).mean()) < 1e-7, apart
+    for name, b in lm.model.named_buffers():   # BatchNorm running statistics after 4 training forwards
+        if b.dtype.is_floating_point:
+            assert rel_err(b, sd[name]) < 1e-4, name
+        else:
+            assert int(b) == int(sd[name]), name
+
+
+# ------------------------------------------------------------------------------------------------ the benchmark workload itself
+@pytest.fixture(scope="module")
+def bench_case(gpu_device):
+    import bench
+
+    torch.cuda.empty_cache()
+    return bench.synthetic_case(1234, 2, 3, 1, 512, 512, 60, 5, 4, 10, gpu_device)   # border 10: access.py:173 default
+
+
+def _bench_module(case, dt, device):
+    import bench
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    info = bench.make_info(case, 5)
+    torch.manual_seed(1234)
+    lm = AutoRegressiveLightning({"compute_dtype": dt, "activation_dtype": dt}, info, None, num_pred_steps_train=3, batch_size=2,
+                                 model_name="HalfUNet", losses=MSE, training_strategy="scaled_ar").to(device)
+    return lm.train()
+
+
+def test_bench_workload_native_rollout_both_flavours(gpu_device, bench_case):
+    """bench.py's workload at its size (B = 2, 512 x 512 x 60, T = 3, HalfUNet, scaled_ar, WeightedLoss MSE): 512-wide strips, 16
+    tiles per CU walking the LDS ring across samples, the full plan.  fp32 and bf16 flavours agree on the loss, borders are the
+    forced targets bit for bit, the native one-node rollout equals the generic fused path, gradients of the two flavours align."""
+    import bench
+
+    res = {}
+    for dt in ("f32", "bf16"):
+        lm = _bench_module(bench_case, dt, gpu_device)
+        pred, tgt = lm.common_step(bench.make_batch(bench_case), 0, "train")
+        p = pred.tensor
+        assert p.shape == (2, 3, 512, 512, 60) and bool(torch.isfinite(p).all())
+        bm = bench_case["border_mask"][..., 0] > 0
+        assert torch.equal(p[:, :, bm], bench_case["outputs"][:, :, bm])       # forced border = the target, bit for bit
+        for q in lm.parameters():
+            q.grad = None
+        loss = lm.training_step(bench.make_batch(bench_case), 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = torch.cat([q.grad.flatten() for q in lm.model.parameters()]).double()
+        assert bool(torch.isfinite(grads).all())
+        # same weights, generic per-op path with the fused update+loss step (any-nn.Module route): same kernels, same numbers
+        lm.use_native_rollout = False
+        lm.eval()   # (no running-statistics side effects; batch statistics are what both routes normalise with in train mode)
+        lm.train()
+        pred2, _ = lm.common_step(bench.make_batch(bench_case), 0, "train")
+        assert rel_err(pred2.tensor, p) < (2e-5 if dt == "f32" else 2e-2)
+        res[dt] = (float(loss), grads.cpu(), p[:, 0].detach().float().cpu())
+        del lm, pred, pred2, p
+        torch.cuda.empty_cache()
+    l32, l16 = res["f32"][0], res["bf16"][0]
+    assert abs(l32 - l16) / l32 < 2e-4, (l32, l16)                              # 272.128 vs 272.159
+    assert rel_err(res["bf16"][2], res["f32"][2]) < 2e-2                         # first AR step's prediction
+    cos = float(torch.dot(res["f32"][1], res["bf16"][1]) / (res["f32"][1].norm() * res["bf16"][1].norm()))
+    assert cos > 0.8, cos
+
+
+@pytest.mark.parametrize("transform", [False, True])
+def test_full_resolution_conv_and_wgrad_vs_float64(gpu_device, transform):
+    """One 64->64 3x3 layer at the benchmark resolution (2 x 512 x 512): forward (ring kernel) and weight gradient against float64
+    on the SAME bf16-rounded operands (matmul per tap on the device in float64)."""
+    from py4cast_amd import ops_model as om
+
+    g = torch.Generator(device=gpu_device).manual_seed(5)
+    B, H, W, C = 2, 512, 512, 64
+    x = torch.randn(B, H, W, C, generator=g, device=gpu_device).bfloat16()
+    dy = torch.randn(B, H, W, C, generator=g, device=gpu_device).bfloat16()
+    w = (torch.randn(C, C, 3, 3, generator=g, device=gpu_device) * 0.05)
+    scale = torch.rand(B, C, generator=g, device=gpu_device) + 0.5 if transform else None
+    shift = torch.randn(B, C, generator=g, device=gpu_device) * 0.3 if transform else None
+    xin = x.float()
+    if transform:
+        xin = torch.relu(xin * scale[:, None, None, :] + shift[:, None, None, :])
+    xin = xin.bfloat16().double()
+    wq = w.bfloat16().double()
+    xp = torch.nn.functional.pad(xin, (0, 0, 1, 1, 1, 1))
+    ref = torch.zeros(B, H, W, C, dtype=torch.float64, device=gpu_device)
+    gw = torch.zeros(C, C, 3, 3, dtype=torch.float64, device=gpu_device)
+    dyd = dy.double().reshape(-1, C)
+    for ky in range(3):
+        for kx in range(3):
+            xs = xp[:, ky:ky + H, kx:kx + W, :].reshape(-1, C)
+            ref += (xs @ wq[:, :, ky, kx].t()).view(B, H, W, C)
+            gw[:, :, ky, kx] = dyd.t() @ xs
+    wp = om.prep_weights(w, False, 64, 64, compute="bf16")
+    got = om.conv_fwd(x, wp, 3, in_scale=scale, in_shift=shift, in_relu=transform, compute="bf16")
+    assert got.dtype == torch.bfloat16
+    assert rel_err(got.float(), ref) < 4e-3          # bf16 output rounding (2^-9) dominates
+    grad = torch.zeros(C, C, 3, 3, device=gpu_device)
+    om.conv_wgrad(x, dy, 3, C, C, grad, scale, shift, transform, compute="bf16")
+    assert rel_err(grad, gw) < 5e-4

@@ -941,3 +941,59 @@ def test_widened_models_learn(gpu_device, tmp_path, model_name, settings):
     with torch.no_grad():
         after = float(lm.training_step(make_batch(case, gpu_device), 1))
     assert after < 0.85 * before, (before, after)
+
+
+def test_row_mlp_gradients_in_place_with_data_inputs(gpu_device):
+    """Regression (round-1 advisor finding): with grads_in_place and .grad buffers present, an MLP whose inputs are all DATA (x,
+    addends and residual need no gradient -- every embedder on AR step 0) must still record an autograd node and accumulate
+    its parameter gradients; they equal the ordinary autograd path's."""
+    from py4cast_amd.ops_mlp import row_mlp
+
+    R = 2500
+    torch.manual_seed(171)
+    x = torch.randn(R, 64, device=gpu_device).bfloat16()           # requires_grad = False
+    assert not x.requires_grad
+
+    def params():
+        torch.manual_seed(172)
+        mk = lambda *s, scale=0.1: (torch.randn(*s, device=gpu_device) * scale).requires_grad_(True)  # noqa: E731
+        return [mk(64, 64), mk(64), mk(64, 64), mk(64), (torch.rand(64, device=gpu_device) + 0.5).requires_grad_(True), mk(64)]
+
+    def run(in_place):
+        ps = params()
+        for t in ps:
+            t.grad = torch.full_like(t, 0.5)
+        y, _ = row_mlp(x, *ps, 1e-5, grads_in_place=in_place)
+        assert y.requires_grad and y.grad_fn is not None, in_place
+        y.float().square().mean().backward()
+        return [t.grad.clone() for t in ps]
+
+    ref, got = run(False), run(True)
+    for a, b in zip(got, ref):
+        assert float((b - 0.5).abs().max()) > 0          # the reference path did produce a gradient
+        assert _rel(a, b) < 1e-6
+
+
+def test_graphlam_bf16_gradients_with_flat_ddp_buffers_match_oracle(gpu_device, tmp_path):
+    """Model-level check of the same finding: bf16 GraphLam with FlatDDP's gradient buffers present (the configuration of
+    Trainer.fit / bench.py, GRADS_IN_PLACE on), ONE AR step from data inputs -- every parameter, the embedders included, gets the
+    oracle's gradient (bf16 tolerance), none is left at zero."""
+    from py4cast_amd.trainer import FlatDDP
+
+    H, W, cin, cout = 36, 45, 13, 5
+    model, oracle = _graphlam_pair(tmp_path, H, W, cin, cout, dtype="bf16")
+    model = model.to(gpu_device)
+    ddp = FlatDDP(model, world_size=1)
+    assert all(p.grad is not None for p in model.parameters())
+    torch.manual_seed(23)
+    x = torch.randn(2, H * W, cin)
+    gy = torch.randn(2, H * W, cout)
+    y = model(x.to(gpu_device))                  # x is data: requires_grad False
+    y.backward(gy.to(gpu_device))
+    yr = oracle(x.double())
+    yr.backward(gy.double())
+    ref_grads = dict(oracle.named_parameters())
+    for name, p in model.named_parameters():
+        assert float(p.grad.abs().sum()) > 0, f"{name}: no gradient arrived"
+        assert _rel(p.grad.cpu(), ref_grads[name].grad) < 8e-2, name
+    assert float(ddp.flat_grad.abs().sum()) > 0
