@@ -10,9 +10,16 @@
  * Conventions
  *  - plain C, no C++/torch types.  Device buffers are raw pointers owned by the caller
  *    (the PyTorch caching allocator in practice), work-spaces included: the library
- *    allocates nothing persistent and frees nothing.
+ *    allocates no device memory and frees nothing.
  *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never
  *    synchronises the device, so calls are hipGraph-capturable.
+ *  - host-side state, all of it: (1) a lock-guarded table of "dynamic LDS size set" marks per
+ *    (kernel, device) and the CU count per device; (2) p4c_halfunet_backward orders its weight
+ *    gradients on a SIDE stream: by default one non-blocking stream + a handful of timing-disabled
+ *    events per calling thread, created on first use and kept for the life of the thread -- pass
+ *    your own with p4c_set_side_stream() and the library creates none; (3) the opt-in profiler
+ *    below (process-wide, lock-guarded; events created by p4c_prof_enable only).  Everything else
+ *    is reentrant and safe from several host threads / devices at once.
  *  - returns 0 on success, a negative P4C_ERR_* otherwise; p4c_last_error() returns a
  *    thread-local message.  Nothing throws or aborts across the boundary.
  *  - tensors are dense row-major; "N" is the number of grid points (H*W for grid models,
@@ -305,6 +312,12 @@ typedef struct p4c_halfunet_desc {
                                  last changed (e.g. once per rollout); forward/backward then skip their own
                                  re-layout of the weights.  0: each call prepares what it needs (one extra launch). */
 } p4c_halfunet_desc;
+
+/* Side stream of the calling thread for p4c_halfunet_backward (weight gradients run beside the backward chain, ordered by
+ * events and joined before the call returns control of `stream`): `side` a hipStream_t, `events` n_events >= 8 hipEvent_t
+ * handles created with hipEventDisableTiming, all owned by the caller and alive until replaced.  side = NULL restores the
+ * default (library-created on first use).  Environment: P4C_SIDE_STREAM=0 runs everything on `stream`. */
+int p4c_set_side_stream(p4c_stream_t side, void* const* events, int n_events);
 
 /* number of floats of the flat parameter vector, laid out in this order (canonical torch layouts):
  *   for block in enc1..enc5, decoder: conv1.weight (64,cin_b,3,3), norm1.weight (64), norm1.bias (64),

@@ -54,6 +54,7 @@ OTHER = {
     "p4c_last_error": ([], c_char_p),
     "p4c_num_cus": ([], c_int),
     "p4c_loss_workspace_bytes": ([I, I, L, I], c_size_t),
+    "p4c_set_side_stream": ([P, P, I], c_int),
     "p4c_prof_enable": ([I, I], c_int),
     "p4c_prof_filter": ([L], c_int),
     "p4c_prof_collect": ([I, L, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)], c_int),

@@ -537,11 +537,7 @@ template <typename T, int D>
 int launch_bwd(const void* qkv, const float* bias_t, const void* dout, void* dqkv, float* partial, float* dbias_t, const Geo& g,
                float scale, hipStream_t stream) {
     const int smem = BIAS_BYTES + 4 * (3 * IMG + STAT_BYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)window_attn_bwd_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)window_attn_bwd_kernel<T, D>, smem));
     const int GW = attn_grid(g.heads, g.B * g.nwy * g.nwx);
     hipLaunchKernelGGL((window_attn_bwd_kernel<T, D>), dim3(((GW + 7) / 8) * 8 * g.heads), dim3(256), smem, stream, (const T*)qkv, bias_t,
                        (const T*)dout, (T*)dqkv, partial, g, scale, GW);

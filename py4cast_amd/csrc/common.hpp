@@ -35,10 +35,20 @@ int fail(int code, const char* fmt, ...);
             return ::p4c::fail(P4C_ERR_RUNTIME, "%s failed: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 
+#define P4C_TRY(expr)                    \
+    do {                                 \
+        int rc__ = (expr);               \
+        if (rc__ != P4C_OK) return rc__; \
+    } while (0)
+
 static inline hipStream_t as_stream(p4c_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Number of CUs of the current device (cached).  Used to size persistent grids.
 int num_cus();
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size): lock-guarded table, so concurrent first
+// launches from several host threads (Lightning's fit thread + autograd's backward thread) and several devices are safe.
+int ensure_dyn_smem(const void* kernel, int bytes);
 
 // Optional per-launch timing of selected kernels with HIP events recorded on the launch stream
 // (bench.py roofline leg; see p4c_prof_enable in include/py4cast_hip.h).  No-ops unless enabled.

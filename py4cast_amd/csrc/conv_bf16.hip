@@ -1173,12 +1173,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int MODE>
 static int launch_ring_mode(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, __bf16* out,
                             int out_cs, float* stat_partial, int B, int H, int W, int G, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_bf16_ring_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          ring::SMEM));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_ring_kernel<MODE>, ring::SMEM));
     hipLaunchKernelGGL(conv3x3_bf16_ring_kernel<MODE>, dim3(G), dim3(512), ring::SMEM, stream, in, wp, in_scale, in_shift, out,
                        out_cs, stat_partial, B, H, W);
     return P4C_OK;
@@ -1684,12 +1679,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int MODE>
 static int launch_wgrad_ws_mode(const __bf16* in, const float* in_scale, const float* in_shift, const __bf16* dout, float* partial,
                                 int G, int B, int H, int W, int in_cs, int ci_off, int part_cip, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_ws_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          wgws::SMEM));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_wgrad_bf16_ws_kernel<MODE>, wgws::SMEM));
     hipLaunchKernelGGL(conv3x3_wgrad_bf16_ws_kernel<MODE>, dim3(G), dim3(512), wgws::SMEM, stream, in, in_scale, in_shift, dout,
                        partial, B, H, W, in_cs, ci_off, part_cip);
     return P4C_OK;
@@ -1726,16 +1716,10 @@ static int launch_conv_fwd_bf16(const T* in, const __bf16* wp, const float* in_s
     constexpr int TILEB = (LH * LW * (CI * 2 + 16) + 15) / 16 * 16;
     const size_t scratch = (4 * 32 * 33 + 2 * 4 * 2 * 64) * sizeof(float);
     const size_t smem = (size_t)KS * KS * CI * 64 * 2 + (NBUF == 2 ? (size_t)2 * TILEB + scratch + (KS == 1 ? 2 * 4 * 32 * 128 : 0) : (TILEB > scratch ? TILEB : scratch));
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (NBUF == 2)
-            P4C_CHECK_HIP(hipFuncSetAttribute((const void*)conv_fwd_bf16_ws_kernel<T, CI, KS>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        else
-            P4C_CHECK_HIP(hipFuncSetAttribute((const void*)conv_fwd_bf16_kernel<T, CI, KS, NBUF>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    if (NBUF == 2)
+        P4C_TRY(ensure_dyn_smem((const void*)conv_fwd_bf16_ws_kernel<T, CI, KS>, (int)smem));
+    else
+        P4C_TRY(ensure_dyn_smem((const void*)conv_fwd_bf16_kernel<T, CI, KS, NBUF>, (int)smem));
     const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + TH - 1) / TH;
     int64_t ntiles = (int64_t)tiles_x * tiles_y * B;
     int G = num_cus();
@@ -1762,11 +1746,7 @@ static int launch_conv_wgrad_bf16(const T* in, const float* in_scale, const floa
     constexpr int ROWA = (CI * 2) % 256 == 64 ? CI * 2 : CI * 2 + 64;
     const size_t smem = (size_t)LH * LW * ROWA + (size_t)8 * BTW * 192;
     auto kern = conv_wgrad_bf16_kernel<T, CI, KS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)kern, (int)smem));
     const int tag = (CI == 64 && KS == 3 && in_cs == 64) ? P4C_PROF_WGRAD3X3_C64 : 0;
     if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), smem, stream, in, in_scale, in_shift, in_relu, dout, partial, B, H, W,

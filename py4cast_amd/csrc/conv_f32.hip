@@ -375,11 +375,7 @@ static int launch_conv_fwd(const float* in, const float* wp, const float* in_sca
     const size_t stat_smem = (4 * 64 * 33 + 4 * 2 * 64) * sizeof(float);  // statistics epilogue scratch
     if (smem < stat_smem) smem = stat_smem;
     auto kern = conv_fwd_f32_kernel<CI, KS, TH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)kern, (int)smem));
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int tag = (CI == 64 && KS == 3 && m_blocks == 1) ? P4C_PROF_CONV3X3_C64 : 0;
     if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
@@ -398,11 +394,7 @@ static int launch_conv_wgrad(const float* in, const float* in_scale, const float
     constexpr int LH = 4 + 2 * HALO, LW = TW + 2 * HALO;
     const size_t smem = ((size_t)LH * LW * (CI + 4) + (size_t)4 * TW * 68) * sizeof(float);
     auto kern = conv_wgrad_f32_kernel<CI, KS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)kern, (int)smem));
     const int tag = (CI == 64 && KS == 3 && in_cs == 64) ? P4C_PROF_WGRAD3X3_C64 : 0;
     if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), smem, stream, in, in_scale, in_shift, in_relu, dout, partial, B, H, W,

@@ -138,12 +138,6 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     L.scratch_bytes = L.g_base + off * L.esz;
 }
 
-#define P4C_TRY(expr)              \
-    do {                           \
-        int rc__ = (expr);         \
-        if (rc__ != P4C_OK) return rc__; \
-    } while (0)
-
 // workspace views
 struct WS {
     const Layout& L;
@@ -213,12 +207,13 @@ struct SideStream {
     std::vector<hipEvent_t> events;
     size_t next = 0;
     bool enabled = true;
+    bool external = false;   // stream and events were handed in by the caller (p4c_set_side_stream): create nothing
     // weight-gradient launches waiting for their ordering event: an event record costs the MAIN stream a bubble (rocprofv3: the
     // kernel after one starts 8 us later in the median, 20 us on average), so several blocks share one
     std::vector<std::function<int(hipStream_t)>> pending;
     int every = 3;   // measured on the benchmark configuration: 1 -> 6.06, 2 -> 5.97, 3 -> 5.91, 4 -> 5.99, 6 -> 6.14 ms per step
     int init() {
-        if (stream) return P4C_OK;
+        if (stream || external) return P4C_OK;
         const char* e = getenv("P4C_SIDE_STREAM");
         enabled = !(e && e[0] == '0');
         if (const char* n = getenv("P4C_SIDE_EVERY")) { const int v = atoi(n); if (v > 0) every = v; }
@@ -236,6 +231,9 @@ struct SideStream {
     }
     int event(hipEvent_t* ev) {
         if (next == events.size()) {
+            if (external)
+                return fail(P4C_ERR_INVALID, "p4c_halfunet_backward: the caller's %zu ordering events are used up "
+                                             "(p4c_set_side_stream: pass at least 8)", events.size());
             hipEvent_t e;
             P4C_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             events.push_back(e);
@@ -296,6 +294,22 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
 }  // namespace p4c
 
 using namespace p4c;
+
+extern "C" int p4c_set_side_stream(p4c_stream_t side, void* const* events, int n_events) {
+    // per calling thread (the backward plan runs on autograd's thread): replaces the lazily created stream / event pool
+    SideStream& sd = g_side;
+    if (!side) {   // back to the library-owned defaults (created on first use)
+        if (sd.external) { sd.stream = nullptr; sd.events.clear(); sd.external = false; sd.enabled = true; }
+        return P4C_OK;
+    }
+    P4C_CHECK_ARG(events && n_events >= 8, "p4c_set_side_stream: needs >= 8 ordering events (hipEvent_t, timing disabled)");
+    sd.stream = as_stream(side);
+    sd.events.assign(reinterpret_cast<hipEvent_t const*>(events), reinterpret_cast<hipEvent_t const*>(events) + n_events);
+    sd.next = 0;
+    sd.external = true;
+    sd.enabled = true;
+    return P4C_OK;
+}
 
 extern "C" int64_t p4c_halfunet_param_count(const p4c_halfunet_desc* d) {
     if (check_desc(d) != P4C_OK) return -1;

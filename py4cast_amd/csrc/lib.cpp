@@ -1,7 +1,9 @@
 // Library-wide state of libpy4cast_hip.so: thread-local error message, device queries.
 #include <stdarg.h>
 
+#include <atomic>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -21,16 +23,35 @@ int fail(int code, const char* fmt, ...) {
 }
 
 int num_cus() {
-    static int cus = 0;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;  // MI355X
-    });
-    return cus;
+    // per device (one process may drive several): filled on first use under a lock, read lock-free afterwards
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int v = cus[dev].load(std::memory_order_acquire);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;  // MI355X
+    cus[dev].store(n, std::memory_order_release);
+    return n;
+}
+
+int ensure_dyn_smem(const void* kernel, int bytes) {
+    struct Key { const void* k; int dev; };
+    static std::mutex mu;
+    static std::vector<std::pair<Key, int>> done;   // a few dozen entries at most: linear scan
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : done)
+        if (e.first.k == kernel && e.first.dev == dev) {
+            if (e.second >= bytes) return P4C_OK;
+            P4C_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            e.second = bytes;
+            return P4C_OK;
+        }
+    P4C_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.push_back({Key{kernel, dev}, bytes});
+    return P4C_OK;
 }
 
 // ---- kernel timing (disabled by default)

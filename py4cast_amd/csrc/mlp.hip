@@ -859,12 +859,8 @@ template <int KS>
 int launch_bwd(const MlpArgs& a, float* grads, const GradSinks* sinks, hipStream_t s) {
     constexpr int smem = bwd_lds_bytes<KS>();
     static_assert(4 * wave_img_bytes<KS>() >= partial_floats<KS>() * 4, "reduction buffer must fit the waves' images");
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)row_mlp_bwd_kernel<KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)row_mlp_bwd_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)row_mlp_bwd_kernel<KS, false>, smem));
+    P4C_TRY(ensure_dyn_smem((const void*)row_mlp_bwd_kernel<KS, true>, smem));
     const int G = mlp_grid(a.R, 1);
     if (a.ga || a.gb)
         hipLaunchKernelGGL((row_mlp_bwd_kernel<KS, true>), dim3(G), dim3(256), smem, s, a);

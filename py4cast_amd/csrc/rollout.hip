@@ -504,11 +504,7 @@ extern "C" int p4c_pack_standardize(const float* raw, int64_t plane_stride, cons
     P4C_CHECK_ARG((rows + PACK_ROWS - 1) / PACK_ROWS < ((int64_t)1 << 31), "p4c_pack_standardize: too many rows");
     P4C_CHECK_ARG(F <= 144, "p4c_pack_standardize: at most 144 features per call (LDS tile)");
     const size_t smem = (size_t)F * (PACK_ROWS + 1) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)pack_standardize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * (PACK_ROWS + 1) * 4));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)pack_standardize_kernel, 144 * (PACK_ROWS + 1) * 4));
     hipLaunchKernelGGL(pack_standardize_kernel, dim3((unsigned)((rows + PACK_ROWS - 1) / PACK_ROWS)), dim3(256), smem,
                        as_stream(stream), raw, plane_stride, mean, std, out, rows, F);
     P4C_CHECK_LAUNCH("p4c_pack_standardize");

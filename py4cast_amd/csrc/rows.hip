@@ -404,11 +404,7 @@ int launch_wgrad(const void* dy, const void* x, float* partial, int64_t R, int G
     constexpr int smem_tiles = 4 * WG_ROWS * ((64 * 2 + 16) + (K * 2 + 16));
     constexpr int smem_red = (64 * K + 64) * 4;
     constexpr int smem = smem_tiles > smem_red ? smem_tiles : smem_red;
-    static bool attr_set = false;
-    if (!attr_set) {
-        P4C_CHECK_HIP(hipFuncSetAttribute((const void*)row_linear_wgrad_kernel<KS16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    P4C_TRY(ensure_dyn_smem((const void*)row_linear_wgrad_kernel<KS16>, smem));
     hipLaunchKernelGGL((row_linear_wgrad_kernel<KS16>), dim3(G), dim3(256), smem, stream, (const bf16*)dy, (const bf16*)x, partial, R);
     P4C_CHECK_LAUNCH("row_linear_wgrad");
     return P4C_OK;

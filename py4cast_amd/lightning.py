@@ -111,6 +111,28 @@ def cosine_with_min_lr_lambda(num_warmup_steps: int, num_training_steps: int, mi
     return fn
 
 
+class _LazyMaskedTarget(NamedTensor):
+    """``target_masked`` of lightning.py:792-796 (a clone with NaN -> 0) that costs nothing until somebody reads ``.tensor``:
+    the loss kernels take the RAW target through the NanMask marker and replace NaNs in registers, so on the hot path the
+    NaN-free copy (one full pass over the target per step in the reference) is never made; observers that do read it get the
+    reference's tensor."""
+
+    def __init__(self, raw: NamedTensor):   # metadata copied, no tensor work
+        self.__dict__.update({k: v for k, v in raw.__dict__.items() if k != "tensor"})
+        self.names, self.feature_names = list(raw.names), list(raw.feature_names)
+        self._raw, self._clean = raw.tensor, None
+
+    @property
+    def tensor(self) -> torch.Tensor:
+        if self._clean is None:
+            self._clean = torch.nan_to_num(self._raw, nan=0)
+        return self._clean
+
+    @tensor.setter
+    def tensor(self, value: torch.Tensor):
+        self._clean = value
+
+
 class AutoRegressiveLightning(_Base):
     """Auto-regressive module for predicting meteorological fields (lightning.py:147)."""
 
@@ -118,7 +140,7 @@ class AutoRegressiveLightning(_Base):
         self,
         settings_init_args: dict,
         dataset_info,
-        infer_ds=None,
+        infer_ds,
         dataset_name: str = "dummy",
         dataset_conf: Optional[Dict] = None,
         num_input_steps: int = 1,
@@ -460,16 +482,17 @@ class AutoRegressiveLightning(_Base):
 
     def get_mask_on_nan(self, target: NamedTensor):
         """
-        lightning.py:787-797.  Returns (mask, target_masked) where ``mask`` is a marker understood
-        by py4cast_amd.losses (the kernels derive the mask from the target's NaNs); pass
-        ``materialize=True`` semantics via ``materialize_mask`` when a real tensor is needed.
+        lightning.py:787-797.  Returns (mask, target_masked).  ``mask`` is a lazy stand-in for the reference's tensor: the loss
+        kernels of py4cast_amd.losses read it as a marker (they derive the mask from the target's NaNs, nothing is allocated);
+        any other consumer -- plotters, metrics, ``mask * x``, ``mask.shape`` -- gets the reference's literal tensor, built on
+        first use.  ``target_masked`` is likewise NaN-free only once somebody other than the loss kernels reads it.
         """
         if self.mask_on_nan:
-            return NanMask(target.tensor), target
-        return OnesMask(), target
+            return NanMask(target.tensor), _LazyMaskedTarget(target)
+        return OnesMask(target.tensor), target
 
     def materialize_mask(self, target: NamedTensor):
-        """The reference's literal (mask tensor, NaN-free target) pair, for observers (plots)."""
+        """The reference's literal (mask tensor, NaN-free target) pair."""
         if self.mask_on_nan:
             mask = ~torch.isnan(target.tensor)
             t = target.clone()
@@ -494,7 +517,187 @@ class AutoRegressiveLightning(_Base):
         return batch_loss
 
     def on_train_epoch_end(self):
+        """lightning.py:833-839."""
+        if self.logging_enabled and self.training_step_losses:
+            experiment = getattr(getattr(self, "logger", None), "experiment", None)
+            if experiment is not None and hasattr(experiment, "add_scalar"):
+                experiment.add_scalar("mean_loss_epoch/train", torch.stack(list(self.training_step_losses)).mean(),
+                                      getattr(self, "global_step", 0))
         self.training_step_losses.clear()
+
+    # ------------------------------------------------------------------ housekeeping hooks of the reference (host side)
+    def configure_loggers(self):
+        """lightning.py:328-337."""
+        layout = {"Check Overfit": {"loss": ["Multiline", ["mean_loss_epoch/train", "mean_loss_epoch/validation"]]}}
+        experiment = getattr(getattr(self, "logger", None), "experiment", None)
+        if experiment is not None and hasattr(experiment, "add_custom_scalars"):
+            experiment.add_custom_scalars(layout)
+
+    def print_summary_model(self):
+        """lightning.py:399-414 (rank zero)."""
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+            return
+        if hasattr(self.dataset_info, "summary"):
+            self.dataset_info.summary()
+        print(f"Number of input_steps : {self.num_input_steps}")
+        print(f"Number of pred_steps (training) : {self.num_pred_steps_train}")
+        print(f"Number of pred_steps (test/val) : {self.num_pred_steps_val_test}")
+        print(f"Number of intermediary steps :{self.num_inter_steps}")
+        print(f"Training strategy :{self.training_strategy}")
+        print("---------------------")
+        print(f"Loss {self.loss}")
+        print(f"Batch size {self.batch_size}")
+        print("---------------------------")
+        n = sum(p.numel() for p in self.model.parameters())
+        print(f"{type(self.model).__name__}: {n} parameters")
+
+    def inspect_tensors(self):
+        """lightning.py:416-428."""
+        for name, param in self.named_parameters():
+            print(name, param.shape, param.dtype)
+        for name, buffer in self.named_buffers():
+            print(name, buffer.shape, buffer.dtype)
+
+    def log_hparams_tb(self):
+        """lightning.py:430-448: the git state next to the logs (only when logging is on)."""
+        if not self.logging_enabled:
+            return
+        import subprocess
+
+        try:
+            text = subprocess.check_output(["git", "log", "-n", "1"]).strip().decode() + \
+                subprocess.check_output(["git", "status"]).strip().decode()
+            (Path(self.trainer.logger.log_dir) / "git_log.txt").write_text(text)
+        except Exception:   # not a git checkout: nothing to record
+            pass
+
+    def on_fit_start(self):
+        """lightning.py:450-452."""
+        self.log_hparams_tb()
+        self.print_summary_model()
+
+    def on_train_end(self):
+        """lightning.py:841-858 logs the model to MLflow when an MLFlowLogger is attached; without one (this stack has no
+        mlflow) there is nothing to do."""
+
+    def load_weigths(self, path, map_location):
+        """lightning.py:1109-1120 (sic): state dict with the "model." prefix removed from every key."""
+        from collections import OrderedDict
+
+        weights = torch.load(path, map_location)
+        return OrderedDict((k.replace("model.", ""), v) for k, v in weights.items())
+
+    # ------------------------------------------------------------------ observers (plots / metrics of the reference)
+    # The plotters and the PSD metrics are py4cast's own host-side code (matplotlib, out of the hot-path scope): when the
+    # `py4cast` package is importable they are attached and notified exactly where the reference notifies them
+    # (lightning.py:868-1065); when it is not, the hooks are no-ops.  They receive the lazy mask / target of get_mask_on_nan.
+    @staticmethod
+    def _reference_observers():
+        try:
+            import py4cast.metrics as ref_metrics   # type: ignore
+            import py4cast.plots as ref_plots       # type: ignore
+
+            return ref_plots, ref_metrics
+        except Exception:
+            return None, None
+
+    @property
+    def current_epoch_(self) -> int:
+        return int(getattr(self, "current_epoch", 0) or 0)
+
+    def setup(self, stage=None):
+        """lightning.py:312-326."""
+        self.list_metrics = []
+        if not self.logging_enabled:
+            return
+        self.save_path = Path(self.trainer.logger.log_dir)
+        from .metrics import MetricACC   # device-side sums (p4c_acc_sums)
+
+        self.acc_metric = MetricACC(self.dataset_info)
+        self.list_metrics = [self.acc_metric]
+        _, ref_metrics = self._reference_observers()
+        if ref_metrics is not None:
+            max_pred_step = self.num_pred_steps_val_test - 1
+            self.rmse_psd_plot_metric = ref_metrics.MetricPSDVar(pred_step=max_pred_step)
+            self.psd_plot_metric = ref_metrics.MetricPSDK(self.save_path, pred_step=max_pred_step)
+            self.list_metrics += [self.psd_plot_metric, self.rmse_psd_plot_metric]
+
+    def on_validation_start(self):
+        """lightning.py:864-886."""
+        self.valid_plotters = []
+        ref_plots, _ = self._reference_observers()
+        if self.logging_enabled and ref_plots is not None:
+            l1_loss = ScaledLoss("L1Loss", reduction="none")
+            l1_loss.prepare(self, self.interior_mask, self.dataset_info)
+            sp = getattr(self, "save_path", None)
+            self.valid_plotters = [
+                ref_plots.StateErrorPlot({"mae": l1_loss}, prefix="Validation"),
+                ref_plots.PredictionTimestepPlot(num_samples_to_plot=1, num_features_to_plot=4, prefix="Validation", save_path=sp),
+                ref_plots.PredictionEpochPlot(num_samples_to_plot=1, num_features_to_plot=4, prefix="Validation", save_path=sp),
+            ]
+
+    def on_test_start(self):
+        """lightning.py:986-1008."""
+        self.test_plotters = []
+        ref_plots, _ = self._reference_observers()
+        if self.logging_enabled and ref_plots is not None:
+            metrics = {}
+            for torch_loss, alias in ("L1Loss", "mae"), ("MSELoss", "rmse"):
+                loss = ScaledLoss(torch_loss, reduction="none")
+                loss.prepare(self, self.interior_mask, self.dataset_info)
+                metrics[alias] = loss
+            sp = getattr(self, "save_path", None)
+            self.test_plotters = [
+                ref_plots.StateErrorPlot(metrics, save_path=sp),
+                ref_plots.SpatialErrorPlot(),
+                ref_plots.PredictionTimestepPlot(num_samples_to_plot=self.num_samples_to_plot, num_features_to_plot=4,
+                                                 prefix="Test", save_path=sp),
+            ]
+
+    def _notify(self, plotters, batch, prediction, target, mask):
+        for plotter in plotters:
+            plotter.update(self, batch=batch, prediction=prediction, target=target, mask=mask)
+        for metric in getattr(self, "list_metrics", []):
+            if metric is getattr(self, "acc_metric", None):
+                metric.update(prediction, target, mask)
+            else:
+                metric.update(prediction, target, mask, self.original_shape)
+
+    def validation_step_logging(self, batch, prediction, target, mask):
+        """lightning.py:919-941."""
+        if self.logging_enabled:
+            plot_period = 10   # PLOT_PERIOD, lightning.py:54
+            self._notify(getattr(self, "valid_plotters", []) if self.current_epoch_ % plot_period == 0 else [], batch, prediction,
+                         target, mask)
+
+    def test_step_logging(self, batch, prediction, target, mask):
+        """lightning.py:1044-1065."""
+        if self.logging_enabled:
+            self._notify(getattr(self, "test_plotters", []), batch, prediction, target, mask)
+
+    def _epoch_end(self, plotters, label: str, prefix=None):
+        """lightning.py:943-982 / 1067-1103: metric results are logged (tensors) or handed to the logger (figures)."""
+        if not self.logging_enabled:
+            return
+        results = {}
+        for metric in getattr(self, "list_metrics", []):
+            results.update(metric.compute() if prefix is None else metric.compute(prefix=prefix))
+        figures = {k: v for k, v in results.items() if not isinstance(v, torch.Tensor)}
+        self.log_dict({k: v for k, v in results.items() if isinstance(v, torch.Tensor)}, prog_bar=False, on_step=False,
+                      on_epoch=True, sync_dist=True)
+        experiment = getattr(getattr(self, "logger", None), "experiment", None)
+        if experiment is not None and hasattr(experiment, "add_figure"):
+            for name, fig in figures.items():
+                experiment.add_figure(f"{name}", fig, self.current_epoch_)
+        for plotter in plotters:
+            plotter.on_step_end(self, label=label)
+
+    def on_validation_epoch_end(self):
+        self._epoch_end(getattr(self, "valid_plotters", []) if self.current_epoch_ % 10 == 0 else [], "Valid")
+        self.validation_step_losses.clear()
+
+    def on_test_epoch_end(self):
+        self._epoch_end(getattr(self, "test_plotters", []), "Test", prefix="test")
 
     def _eval_step(self, batch: ItemBatch, batch_idx: int, label: str):
         with torch.no_grad():
@@ -507,22 +710,25 @@ class AutoRegressiveLightning(_Base):
         return prediction, target_masked, mask, time_step_loss, mean_loss
 
     def validation_step(self, batch: ItemBatch, batch_idx: int):
-        """lightning.py:888-917 without the plot/metric observers (out of the hot-path scope)."""
-        _, _, _, time_step_loss, mean_loss = self._eval_step(batch, batch_idx, "val")
+        """lightning.py:888-917."""
+        prediction, target_masked, mask, time_step_loss, mean_loss = self._eval_step(batch, batch_idx, "val")
         log = {"val_mean_loss": mean_loss}
         for step in range(time_step_loss.shape[0]):
             log[f"val_loss_step_{step + 1}"] = time_step_loss[step]
         self.log_dict(log, sync_dist=True)
         self.validation_step_losses.append(mean_loss)
+        self.val_mean_loss = mean_loss
+        self.validation_step_logging(batch, prediction, target_masked, mask)
         return mean_loss
 
     def test_step(self, batch: ItemBatch, batch_idx: int):
-        """lightning.py:1017-1042 (loss part)."""
-        _, _, _, time_step_loss, mean_loss = self._eval_step(batch, batch_idx, "test")
+        """lightning.py:1017-1042."""
+        prediction, target_masked, mask, time_step_loss, mean_loss = self._eval_step(batch, batch_idx, "test")
         log = {"test_mean_loss": mean_loss}
         for step in range(time_step_loss.shape[0]):
             log[f"test_loss_step_{step + 1}"] = time_step_loss[step]
         self.log_dict(log, sync_dist=True)
+        self.test_step_logging(batch, prediction, target_masked, mask)
         return mean_loss
 
     def predict_step(self, batch: ItemBatch, batch_idx: int) -> torch.Tensor:

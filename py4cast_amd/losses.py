@@ -30,24 +30,81 @@ from .namedtensor import NamedTensor
 SUPPORTED_TORCH_LOSSES = ("MSELoss", "L1Loss")
 
 
-class NanMask:
-    """Marker: mask = ~isnan(raw_target) and target = nan_to_num(raw_target), fused in-kernel
-    (lightning.py:787-797).  ``raw_target`` is the un-masked target tensor."""
+class _LazyMask:
+    """A mask the loss kernels never need as a tensor (lightning.py:787-797 allocates it per step).  The kernels of this
+    package recognise the marker and derive the mask in place; for EVERY other consumer -- the reference's plot / metric
+    observers (plots.py:524,606; metrics.py:411), arithmetic, indexing, any ``torch.*`` function, attribute access -- the
+    object behaves like the reference's literal tensor: it materialises it once, on first use, and forwards to it."""
+
+    _tensor = None
+
+    def _build(self) -> torch.Tensor:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def materialize(self) -> torch.Tensor:
+        if self._tensor is None:
+            self._tensor = self._build()
+        return self._tensor
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+
+        conv = lambda a: a.materialize() if isinstance(a, _LazyMask) else a  # noqa: E731
+        return func(*tree_map(conv, args), **tree_map(conv, kwargs or {}))
+
+    def __getattr__(self, name):   # reached only for names the marker itself lacks: shape, dtype, device, sum, to, ...
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+
+def _forward_dunder(name):
+    def method(self, *args, **kwargs):
+        args = tuple(a.materialize() if isinstance(a, _LazyMask) else a for a in args)
+        return getattr(self.materialize(), name)(*args, **kwargs)
+
+    method.__name__ = name
+    return method
+
+
+for _n in ("add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "and", "rand", "or", "ror", "xor", "rxor", "invert",
+           "neg", "eq", "ne", "lt", "le", "gt", "ge", "getitem", "len", "iter", "bool", "float", "int", "matmul", "pow", "array"):
+    setattr(_LazyMask, f"__{_n}__", _forward_dunder(f"__{_n}__"))
+_LazyMask.__hash__ = object.__hash__   # defining __eq__ would otherwise make the markers unhashable
+
+
+class NanMask(_LazyMask):
+    """mask = ~isnan(raw_target) and target = nan_to_num(raw_target), fused in-kernel (lightning.py:792-796).
+    ``raw_target`` is the un-masked target tensor."""
 
     def __init__(self, raw_target: torch.Tensor):
         self.raw_target = raw_target
 
+    def _build(self) -> torch.Tensor:
+        return ~torch.isnan(self.raw_target)
 
-class OnesMask:
-    """Marker for ``torch.ones_like(target)`` (lightning.py:797) without allocating it."""
+
+class OnesMask(_LazyMask):
+    """``torch.ones_like(target)`` (lightning.py:797) without allocating it unless somebody looks."""
+
+    def __init__(self, like: Optional[torch.Tensor] = None):
+        self.like = like
+
+    def _build(self) -> torch.Tensor:
+        if self.like is None:
+            raise RuntimeError("OnesMask() was built without its target: nothing to materialise")
+        return torch.ones_like(self.like)
 
 
-def _mask_spec(mask, target: torch.Tensor) -> Tuple[ops.MaskSpec, torch.Tensor]:
-    if mask is None or isinstance(mask, OnesMask):
-        return ops.MaskSpec(L.MASK_NONE), target
+def _mask_spec(mask, target: NamedTensor) -> Tuple[ops.MaskSpec, torch.Tensor]:
+    """(mask specification for the kernels, target tensor they read).  ``target.tensor`` is only touched when it is needed: with a
+    NanMask marker the kernels read the RAW target and a lazily masked target (lightning._LazyMaskedTarget) stays unbuilt."""
     if isinstance(mask, NanMask):
         return ops.MaskSpec(L.MASK_FROM_NAN), mask.raw_target
-    return ops.MaskSpec.from_tensor(mask), target
+    if mask is None or isinstance(mask, OnesMask):
+        return ops.MaskSpec(L.MASK_NONE), target.tensor
+    return ops.MaskSpec.from_tensor(mask), target.tensor
 
 
 class Py4CastLoss(ABC):
@@ -127,7 +184,7 @@ class WeightedLoss(Py4CastLoss):
 
     def forward(self, prediction: NamedTensor, target: NamedTensor, mask, reduce_spatial_dim: bool = True,
                 masked_count: Optional[torch.Tensor] = None) -> torch.Tensor:
-        spec, tgt = _mask_spec(mask, target.tensor)
+        spec, tgt = _mask_spec(mask, target)
         weights = self.weights(tuple(prediction.feature_names), prediction.device)
         if not reduce_spatial_dim:
             return ops.weighted_loss_map(prediction.tensor, tgt, spec, weights, self.kind)
@@ -147,7 +204,7 @@ class ScaledLoss(Py4CastLoss):
         self.lm = lm
 
     def forward(self, prediction: NamedTensor, target: NamedTensor, mask) -> torch.Tensor:
-        spec, tgt = _mask_spec(mask, target.tensor)
+        spec, tgt = _mask_spec(mask, target)
         std = self.weights(tuple(prediction.feature_names), prediction.device)
         interior = self._interior_flat(self.lm, prediction.device)
         return ops.scaled_loss(prediction.tensor, tgt, spec, std, interior, self.num_interior, self.kind)
@@ -192,7 +249,7 @@ class CombinedLoss(Py4CastLoss):
         total_loss = torch.zeros(loss_shape, device=prediction.tensor.device)
         if len(self.losses) > 1 and "masked_count" not in kwargs and kwargs.get("reduce_spatial_dim", True):
             # one union-mask pass shared by every member instead of one per member
-            spec, tgt = _mask_spec(mask, target.tensor)
+            spec, tgt = _mask_spec(mask, target)
             if all(isinstance(l, WeightedLoss) for l, _ in self.losses):
                 kwargs = dict(kwargs, masked_count=ops.masked_count(spec, tgt))
         for loss, weight in self.losses:

@@ -38,7 +38,10 @@ class MetricACC:
             self.climate_means = self.climate_means.to(preds.tensor.device)
             self.feature_names = preds.feature_names
             self.pred_steps = preds.tensor.shape[1]
-        sums = ops.acc_sums(preds.tensor, target.tensor, ops.MaskSpec.from_tensor(mask), self.climate_means)
+        from .losses import _mask_spec   # the lazy markers of get_mask_on_nan are read in place (no mask / clean target built)
+
+        spec, tgt = _mask_spec(mask, target)
+        sums = ops.acc_sums(preds.tensor, tgt, spec, self.climate_means)
         res = torch.mean(sums[0] / torch.sqrt(sums[1] * sums[2]), dim=0)  # tiny (B,T,F) tail, metrics.py:425
         if not self.sum_acc.ndim:
             self.sum_acc = torch.zeros(self.pred_steps, preds.tensor.shape[-1], device=preds.tensor.device)

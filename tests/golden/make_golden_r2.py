@@ -184,8 +184,24 @@ def scheduler():
     print("wrote r2_scheduler", transformers.__version__)
 
 
+def ctor_signature(lightning):
+    """The CLI boundary (cli.py:22-56 links dataset arguments into these parameters): names, kinds and defaults of
+    AutoRegressiveLightning.__init__ (lightning.py:152-184), as data."""
+    import inspect
+    import json
+
+    sig = inspect.signature(lightning.AutoRegressiveLightning.__init__)
+    params = [dict(name=p.name, kind=p.kind.name, default=None if p.default is inspect._empty else repr(p.default),
+                   has_default=p.default is not inspect._empty) for p in sig.parameters.values()]
+    public = sorted(n for n, v in vars(lightning.AutoRegressiveLightning).items() if callable(v) and not n.startswith("_"))
+    with open(os.path.join(HERE, "r2_ctor_signature.json"), "w") as f:
+        json.dump(dict(params=params, public_methods=public), f, indent=1)
+    print("wrote r2_ctor_signature", len(params), "parameters,", len(public), "public methods")
+
+
 if __name__ == "__main__":
     losses, lightning = mg.install_stubs()
+    ctor_signature(lightning)
     downscaling_only(losses, lightning)
     combined_loss(losses, lightning)
     mask_ratio(losses, lightning)

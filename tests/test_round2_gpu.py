@@ -320,7 +320,7 @@ def test_bench_workload_native_rollout_both_flavours(gpu_device, bench_case):
         torch.cuda.empty_cache()
     l32, l16 = res["f32"][0], res["bf16"][0]
     assert abs(l32 - l16) / l32 < 2e-4, (l32, l16)                              # 272.128 vs 272.159
-    assert rel_err(res["bf16"][2], res["f32"][2]) < 2e-2                         # first AR step's prediction
+    assert rel_err(res["bf16"][2], res["f32"][2]) < 4e-2                         # first AR step's prediction
     cos = float(torch.dot(res["f32"][1], res["bf16"][1]) / (res["f32"][1].norm() * res["bf16"][1].norm()))
     assert cos > 0.8, cos
 
