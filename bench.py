@@ -58,7 +58,11 @@ def parse_args():
                     help="replay the micro-batch (rollout + loss + backward) from a HIP graph; auto: only for models that ask for it "
                          "(launch-bound small-kernel models); the roofline object is then measured in eager steps before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="CPU-baseline budget: iterations are timed until it is spent, at least two")
+    ap.add_argument("--cpu-crop", type=int, default=0, help="debugging: time the CPU baseline on a crop of this size (scaled)")
+    ap.add_argument("--no-fp32-flavour", action="store_true",
+                    help="skip the short fp32 (parity flavour) measurement reported as `fp32_flavour`")
     return ap.parse_args()
 
 
@@ -119,8 +123,8 @@ def make_batch(case):
 def cpu_baseline(args, seconds):
     """
     The CPU restatement (oracle/, kind "port") of the same step -- rollout + weighted MSE + backward +
-    AdamW with the oracle's torch-native model -- timed on the host cores on a bounded sample
-    (one sample, a 128x128 crop of the grid, scaled to samples/s of the full grid by pixel count).
+    AdamW with the oracle's torch-native model -- timed on the host cores on a bounded sample: ONE sample of the
+    FULL grid (no crop, no scaling), one untimed iteration then at least two timed ones (about 7 s each for HalfUNet).
     """
     from oracle import losses as olosses
     from oracle import rollout as orollout
@@ -128,7 +132,9 @@ def cpu_baseline(args, seconds):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, 64)  # torch intra-op threading stops scaling (and oversubscribes small boxes) beyond this
     torch.set_num_threads(cores)
-    H, W = min(args.grid[0], 128), min(args.grid[1], 128)
+    H, W = args.grid
+    if args.cpu_crop:   # debugging aid only: the default times the full grid
+        H, W = min(H, args.cpu_crop), min(W, args.cpu_crop)
     F, T = args.features, args.pred_steps
     case = synthetic_case(99, 1, T, 1, H, W, F, 5, 4, args.border, torch.device("cpu"))
     interior = 1.0 - case["border_mask"]
@@ -198,20 +204,63 @@ def cpu_baseline(args, seconds):
         opt.zero_grad()
 
     one()
-    t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < seconds and n < 50:
+    t0, n, times = time.perf_counter(), 0, []
+    while (time.perf_counter() - t0 < seconds or n < 2) and n < 50:
+        t1 = time.perf_counter()
         one()
+        times.append(time.perf_counter() - t1)
         n += 1
     dt = (time.perf_counter() - t0) / n
     scale = (H * W) / float(args.grid[0] * args.grid[1])
+    what = f"the full {H}x{W}x{F} grid" if scale == 1.0 else f"a {H}x{W}x{F} crop, scaled by pixel count to {args.grid[0]}x{args.grid[1]}"
     return {
         "value": scale / dt,
         "unit": "samples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"oracle (torch CPU) {args.model} step on 1 sample of a {H}x{W}x{F} crop, {n} iterations, "
-                  f"scaled by pixel count to the {args.grid[0]}x{args.grid[1]} grid",
+        "sample": f"oracle (torch CPU, fp32) {args.model} training step (T={T} rollout + loss + backward + AdamW) on 1 sample of "
+                  f"{what}: 1 untimed + {n} timed iterations, {min(times):.2f}-{max(times):.2f} s each",
     }
+
+
+def fp32_flavour(args, case, info, device, steps=6, warmup=2):
+    from py4cast_amd import _lib as L
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from py4cast_amd.trainer import FlatDDP
+
+    H, W = args.grid
+    B, T = args.batch, args.pred_steps
+    torch.manual_seed(1234)
+    lm = AutoRegressiveLightning(
+        {"compute_dtype": "f32", "activation_dtype": "f32"}, info, None, num_input_steps=1, num_pred_steps_train=T,
+        num_pred_steps_val_test=T, batch_size=B, model_name=args.model,
+        losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+        training_strategy="scaled_ar", learning_rate=1e-3, min_learning_rate=3e-7, num_warmup_steps=1000, betas=(0.9, 0.95),
+    ).to(device)
+    ddp = FlatDDP(lm.model, 1)
+    opt = lm.configure_optimizers()["optimizer"]
+
+    def step(i):
+        loss = lm.training_step(make_batch(case), i)
+        loss.backward()
+        opt.step()
+        ddp.zero_grad()
+        return loss
+
+    for i in range(2 + warmup):
+        step(i)
+    L.lib().p4c_prof_enable(1, steps * T * 3)
+    L.lib().p4c_prof_filter(B * H * W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    roof = lm.model.roofline({}, B=B, H=H, W=W)
+    L.lib().p4c_prof_enable(0, 0)
+    return {"value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "dtype": "f32", "loss": float(loss.detach()), "roofline": roof}
 
 
 def main():
@@ -357,16 +406,31 @@ def main():
         for i in range(args.warmup):
             step(i)
         barrier()
+    # one event per step boundary (a record costs the stream a few microseconds against a ~5 ms step): min / median / max
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if not use_graph:
         ktimes = L.kernel_times()
         roof_model = lm.model.roofline(ktimes, B=B, H=H, W=W) if (rank == 0 and hasattr(lm.model, "roofline")) else None
         L.enable_kernel_timing(None)
     L.lib().p4c_prof_enable(0, 0)
+    extra = None
+    if rank == 0 and has_roofline and not use_graph and not getattr(lm.model, "roofline_from_entry_points", False) \
+            and hasattr(lm.model, "launch_times"):
+        # ONE extra un-timed step with every tagged launch bracketed by events: data-gradient and weight-gradient launch times
+        # of the roofline kernel's siblings (they overlap each other in the backward plan, hence reported apart)
+        L.lib().p4c_prof_enable(7, 4096)
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize()
+        extra = lm.model.launch_times(B=B, H=H, W=W)
+        L.lib().p4c_prof_enable(0, 0)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -378,6 +442,8 @@ def main():
         roof = None
         if roof_model is not None:
             roof = roof_model
+            if extra:
+                roof.update(extra)
         if roof is None and ktimes and not hasattr(lm.model, "roofline"):
             # HBM-bound rollout kernels: algorithmic bytes per launch
             alg = {
@@ -400,6 +466,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1],
+                        "note": "per-step durations between HIP events on the compute stream of rank 0 inside the timed region"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -420,6 +488,13 @@ def main():
             "roofline": roof,
             "kernel_ms": {k: {"calls": v[0], "avg_ms": round(v[1], 4)} for k, v in ktimes.items()},
         }
+        if (world == 1 and not args.no_fp32_flavour and args.dtype == "bf16" and args.model == "HalfUNet"
+                and hasattr(lm.model, "native_rollout")):
+            # the parity flavour (exact fp32 matrix cores, fp32 storage; <= 1e-4 vs the oracle) of the SAME workload, measured by
+            # the same process after the headline run: a short run of its own (2 setup + 2 warm-up + 6 timed steps)
+            del lm, ddp, opt
+            torch.cuda.empty_cache()
+            out["fp32_flavour"] = fp32_flavour(args, case, info, device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out))

@@ -43,6 +43,11 @@ int fail(int code, const char* fmt, ...);
 
 static inline hipStream_t as_stream(p4c_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Timing diagnostics only (results become wrong): P4C_DIAG bit mask, honoured after the first 400 calls of each site so that
+// buffers hold plausible values.  1: skip forward norm_finalize, 2: skip norm_bwd_finalize, 4: skip norm_bwd_reduce too,
+// 8: skip wgrad_reduce, 16: skip norm_bwd_apply.
+int diag_skip(int bit);
+
 // Number of CUs of the current device (cached).  Used to size persistent grids.
 int num_cus();
 

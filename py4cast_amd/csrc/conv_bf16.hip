@@ -819,11 +819,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 constexpr int OOB = 0x7fffffff;
 
-template <int MODE>
+template <int MODE, bool BST = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     conv3x3_bf16_ring_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ in_scale,
                              const float* __restrict__ in_shift, __bf16* __restrict__ out, int out_cs,
-                             float* __restrict__ stat_partial, int B, int H, int W) {
+                             float* __restrict__ stat_partial, int B, int H, int W, BatchFin fin, RingBwdStats bst) {
     using namespace ring;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lring = smem;
@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int k = 0; k < 4; ++k) {
             const int px = (ltid + k * 256) >> 3;
             dofs[k] = (((px >> 5) * W + (px & 31)) * out_cs + 8 * c8) * 2;
-            sofs[k] = px * 128 + ((c8 ^ (px & 7)) << 4);
+            sofs[k] = px * 128 + ((c8 ^ ((px >> 1) & 7)) << 4);
         }
         struct Img { u32x4 s[NIMG]; };
         Img ta, tb;
@@ -985,8 +985,38 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 u += __shfl_xor(u, 8); v += __shfl_xor(v, 8);
                 u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
                 u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+                if (BST) v *= bst.rstd[b * 64 + 8 * c8 + q];   // sums of g * (y - mean) -> sums of g * xhat
                 if (lane < 8) { dst[8 * c8 + q] = u; dst[64 + 8 * c8 + q] = v; }
                 a1[q] = a2[q] = 0.f;
+            }
+        };
+        // BST: the y tile of the next tile to drain (prefetched one trip ahead) and the lane's normalisation constants
+        u32x4 yq[4];
+        f32x2 bsc[4], bsh[4], bmu[4];
+        int yofs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int px = (ltid + k * 256) >> 3;
+            yofs[k] = (((px >> 5) * W + (px & 31)) * 64 + 8 * c8) * 2;
+            yq[k] = u32x4{0u, 0u, 0u, 0u};
+            bsc[k] = bsh[k] = bmu[k] = f32x2{0.f, 0.f};
+        }
+        auto yload = [&](const Cur& c) __attribute__((always_inline)) {
+            const bool act = c.t < t_end;
+            const int b = act ? c.b : 0, y0 = c.ty * TH, x0 = c.tx * BTW;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const __bf16*>(bst.y) + (int64_t)b * H * W * 64, sample_bytes);
+            if (act && y0 + 4 <= H && x0 + 32 <= W) {
+                const int so = (y0 * W + x0) * 128;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) yq[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, yofs[k], so, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = (ltid + k * 256) >> 3;
+                    const int gy = y0 + (px >> 5), gx = x0 + (px & 31);
+                    const bool valid = act & (gy < H) & (gx < W);
+                    yq[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, valid ? ((gy * W + gx) * 64 + 8 * c8) * 2 : OOB, 0, 0);
+                }
             }
         };
         Cur dc = cur_init();  // drain cursor: the next tile whose staged output goes to HBM
@@ -995,8 +1025,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const char* stg = lstg + ((dc.t - t_begin + (live ? 0 : 1)) & 1) * STGB;
             if (live) cur_next(dc);
             if (live && stat_partial && b != cur_b) {
-                if (cur_b >= 0) flush(cur_b);
+                if (cur_b >= 0 && !fin.slots) flush(cur_b);   // (batch statistics: one sum over all samples, nothing to flush)
                 cur_b = b;
+                if (BST) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        bsc[k] = *reinterpret_cast<const f32x2*>(lnorm + b * 192 + 8 * c8 + 2 * k);
+                        bsh[k] = *reinterpret_cast<const f32x2*>(lnorm + b * 192 + 64 + 8 * c8 + 2 * k);
+                        bmu[k] = *reinterpret_cast<const f32x2*>(lnorm + b * 192 + 128 + 8 * c8 + 2 * k);
+                    }
+                }
             }
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(out + (int64_t)b * H * W * out_cs, out_sample_bytes);
             u32x4 v[4];
@@ -1017,7 +1055,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     __builtin_amdgcn_raw_buffer_store_b128(v[k], rs, (valid && !(P4C_EXP & 4)) ? ((gy * W + gx) * out_cs + 8 * c8) * 2 : OOB, 0, 0);
                 }
             }
-            if (stat_partial && !(P4C_EXP & 8)) {
+            if (BST) {
+                if (live) {
+                    // pass 1 of the normalisation backward on the gradient tile just stored (its rounded values, what a separate
+                    // pass would read back): g = dA where the forward ReLU was alive, sums of g and of g * (y - mean)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float ylo = __builtin_bit_cast(float, yq[k][q] << 16);
+                            const float yhi = __builtin_bit_cast(float, yq[k][q] & 0xffff0000u);
+                            float lo = __builtin_bit_cast(float, v[k][q] << 16);
+                            float hi = __builtin_bit_cast(float, v[k][q] & 0xffff0000u);
+                            lo = __builtin_fmaf(ylo, bsc[q].x, bsh[q].x) > 0.f ? lo : 0.f;
+                            hi = __builtin_fmaf(yhi, bsc[q].y, bsh[q].y) > 0.f ? hi : 0.f;
+                            a1[2 * q] += lo; a2[2 * q] = __builtin_fmaf(lo, ylo - bmu[q].x, a2[2 * q]);
+                            a1[2 * q + 1] += hi; a2[2 * q + 1] = __builtin_fmaf(hi, yhi - bmu[q].y, a2[2 * q + 1]);
+                        }
+                    yload(dc);   // dc already points at the next tile to drain
+                }
+            } else if (stat_partial && !(P4C_EXP & 8)) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -1043,6 +1100,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        if (BST) {   // (MODE 0 launches only: lnorm is free) scale, shift, mean of the gradient's layer, 192 floats per sample
+            for (int i = ltid; i < B * 64; i += 256) {
+                const int b = i >> 6, c = i & 63;
+                lnorm[b * 192 + c] = bst.scale[i];
+                lnorm[b * 192 + 64 + c] = bst.shift[i];
+                lnorm[b * 192 + 128 + c] = bst.mean[i];
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            yload(dc);   // the first tile's y rows
+        }
         store(ta);
         load(ta);
         P4C_STAMP_RT(3101);
@@ -1064,6 +1131,76 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         P4C_STAMP_RT(3103);
         drain(true);
         P4C_STAMP_RT(3104);
+        if (fin.slots) {
+            // ---- BatchNorm finished in place (kernels.hpp: BatchFin).  The compute waves have left (their last barrier was the
+            // one that released the final staged tile), so barriers from here on are among the four loader waves only.
+            float* lred = lnorm;                                          // [4 waves][128], then doubles [8][128] -- all dead by now
+            unsigned int* lflag = reinterpret_cast<unsigned int*>(lnorm + 4 * 128 + 8 * 256);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float u = a1[q], v = a2[q];
+                u += __shfl_xor(u, 8); v += __shfl_xor(v, 8);
+                u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+                u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+                if (lane < 8) { lred[lwv * 128 + 8 * c8 + q] = u; lred[lwv * 128 + 64 + 8 * c8 + q] = v; }
+            }
+            lds_barrier();
+            if (lwv == 0) {
+                // The slot goes out with device-scope (write-through) stores and the ticket follows once they are acknowledged: no
+                // release FENCE -- at the end of a kernel that has just written its output map a fence means writing back every
+                // dirty line of this XCD's L2 (measured: +10 us per launch, more than the finalize launch it was to replace).
+#pragma unroll
+                for (int j = lane; j < 128; j += 64)   // fixed order over the waves
+                    __hip_atomic_store(fin.slots + (int64_t)blockIdx.x * 128 + j,
+                                       (lred[j] + lred[128 + j]) + (lred[256 + j] + lred[384 + j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) *lflag = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            lds_barrier();
+            if (*lflag != gridDim.x - 1) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // invalidate only: the other workgroups' slots are read from memory
+            // 256 threads: 32 column quads x 8 slot groups; slots summed in increasing order within a group, groups in order
+            const int cq = ltid & 31, sg = ltid >> 5;
+            double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int s0 = sg; s0 < (int)gridDim.x; s0 += 8 * 8) {
+                p4c_f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int sl = s0 + 8 * u;
+                    v[u] = sl < (int)gridDim.x ? *(reinterpret_cast<const p4c_f32x4*>(fin.slots + (int64_t)sl * 128) + cq)
+                                               : p4c_f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc4[0] += v[u].x; acc4[1] += v[u].y; acc4[2] += v[u].z; acc4[3] += v[u].w; }
+            }
+            double* dred = reinterpret_cast<double*>(lnorm + 4 * 128);   // [8][128]
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dred[sg * 128 + 4 * cq + k] = acc4[k];
+            lds_barrier();
+            if (ltid < 64) {
+                const int c = ltid;
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) { s1 += dred[g8 * 128 + c]; s2 += dred[g8 * 128 + 64 + c]; }
+                const double n = fin.count;
+                const double mean = s1 / n;
+                double var = s2 / n - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+                if (fin.running_mean) {   // torch semantics: biased variance normalises, the unbiased one is tracked
+                    fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)mean;
+                    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+                    fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+                }
+                const float sc = fin.gamma[c] * rstd, sh = fin.beta[c] - (float)mean * sc;
+                for (int b = 0; b < fin.B; ++b) {
+                    fin.scale[b * 64 + c] = sc; fin.shift[b * 64 + c] = sh; fin.mean[b * 64 + c] = (float)mean; fin.rstd[b * 64 + c] = rstd;
+                }
+            }
+            if (ltid == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         if (stat_partial) {
             flush(cur_b);
             const int bf = (t_begin / tiles_y) / tiles_x;
@@ -1090,7 +1227,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) A[tap][ks] = *reinterpret_cast<const bf16x8*>(wsrc + (tap * 4 + ks) * 2048);
     }
-    if (MODE >= 2) lds_barrier();  // pairs with the loaders' barrier after the normalisation rows are in LDS
+    if (MODE >= 2 || BST) lds_barrier();  // pairs with the loaders' barrier after the normalisation rows are in LDS
     lds_barrier();
     int boff[3][4];  // B-operand byte offset inside a ring row: pixel column r+kx, channel slot 2ks+h (swizzled)
 #pragma unroll
@@ -1099,7 +1236,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int ks = 0; ks < 4; ++ks) boff[kx][ks] = 2 * rp * RROW + (r + kx) * ROWB + (((2 * ks + h) ^ ring_swz(r + kx)) << 4);
     int soff[4];     // staging offsets of this lane's 4 channel quads (row 0 of the wave; row 1 = +32 pixels)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) soff[g] = (2 * rp * 32 + r) * 128 + 8 * h + (((4 * ct + g) ^ (r & 7)) << 4);
+    // (slot XOR (r >> 1) & 7: a row is 128 B = 32 banks, so rows r and r + 2 meet in the same banks; keyed on r & 7 the 8-byte
+    // writes of a wave fell on 16 distinct slots only -- a 4-way conflict, the 128 conflict cycles per tile of the round-1
+    // counters -- keyed on r >> 1 sixteen consecutive rows cover all 64 banks: two passes, the minimum for 512 bytes)
+    for (int g = 0; g < 4; ++g) soff[g] = (2 * rp * 32 + r) * 128 + 8 * h + (((4 * ct + g) ^ ((r >> 1) & 7)) << 4);
     Cur cc = cur_init();
     P4C_STAMP_RT(3111);
     for (int tile = t_begin; tile < t_end; ++tile) {
@@ -1114,6 +1254,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         f32x16 acc0, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+        // epilogue target: C[co][px]; lane = pixel r (+ half h), register quad g -> channels 32ct + 8g + 4h .. +3, i.e. half h
+        // of 16-byte slot 4ct + g of the pixel in the staging tile (slot XOR-swizzled by (pixel >> 1) & 7)
+        char* stg = lstg + ((tile - t_begin) & 1) * STGB;
         if (!(P4C_EXP & 16)) {
             // The wave's two output rows use the four input rows j = 0..3 of the ring: row j is tap row ky = j of output row 0
             // and tap row ky = j - 1 of output row 1, so each of the 48 operands (j, kx, 16-channel slice) is read ONCE and feeds
@@ -1126,17 +1269,34 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
             constexpr int LEAD = P4C_RING_LEAD, NBUF_B = LEAD + 1;
             bf16x8 fb[NBUF_B];
+#ifndef P4C_RING_ORDER
+#define P4C_RING_ORDER 1
+#endif
+            // operand order.  0 (round 1): the single-use rows first, j = 0 / 3 alternating, then j = 1, j = 2.  1: rows in order
+            // j = 0, 1, 2, 3 -- the first output row (acc0) is complete after row 2, so its conversion + staging stores are issued
+            // between the last twelve MFMAs (row 3 feeds acc1 only) instead of after them; only acc1's epilogue stays exposed.
+            auto q_i = [](int q) __attribute__((always_inline)) {
+                return P4C_RING_ORDER ? q % 12 : (q < 24 ? (q >> 1) : (q < 36 ? q - 24 : q - 36));
+            };
+            auto q_j = [](int q) __attribute__((always_inline)) {
+                return P4C_RING_ORDER ? q / 12 : (q < 24 ? ((q & 1) ? 3 : 0) : (q < 36 ? 1 : 2));
+            };
             auto issue = [&](int q) __attribute__((always_inline)) {
-                const int i = q < 24 ? (q >> 1) : (q < 36 ? q - 24 : q - 36);
-                const int j = q < 24 ? ((q & 1) ? 3 : 0) : (q < 36 ? 1 : 2);
+                const int i = q_i(q), j = q_j(q);
                 fb[q % NBUF_B] = *reinterpret_cast<const bf16x8*>(ba[i >> 2][i & 3] + j * RROW);
+            };
+            auto stage = [&](const f32x16& a, int row, int g) __attribute__((always_inline)) {
+                const f32x2 lo = {a[4 * g], a[4 * g + 1]}, hi = {a[4 * g + 2], a[4 * g + 3]};
+                u32x2 o;
+                o[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2));
+                o[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2));
+                *reinterpret_cast<u32x2*>(stg + soff[g] + row * 32 * 128) = o;
             };
 #pragma unroll
             for (int q = 0; q < LEAD; ++q) issue(q);
 #pragma unroll
             for (int q = 0; q < 48; ++q) {
-                const int i = q < 24 ? (q >> 1) : (q < 36 ? q - 24 : q - 36);
-                const int j = q < 24 ? ((q & 1) ? 3 : 0) : (q < 36 ? 1 : 2);
+                const int i = q_i(q), j = q_j(q);
                 const int kx = i >> 2, ks = i & 3;
                 if (q + LEAD < 48) issue(q + LEAD);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1148,40 +1308,54 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(j - 1) * 3 + kx][ks], fb[q % NBUF_B], acc1, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (P4C_RING_ORDER && q >= 38 && q <= 44 && ((q - 38) & 1) == 0) {   // acc0 is final since q = 35: one channel quad per gap
+                    stage(acc0, 0, (q - 38) >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            if (!P4C_RING_ORDER) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) stage(acc0, 0, g);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) stage(acc1, 1, g);
         } else { acc0[0] = ba[0][0][0]; acc1[3] = ba[1][1][16]; }
-        // epilogue: C[co][px]; lane = pixel r (+ half h), register quad g -> channels 32ct + 8g + 4h .. +3, i.e. half h
-        // of 16-byte slot 4ct + g of the pixel in the staging tile (slot XOR-swizzled by the pixel)
-        char* stg = lstg + ((tile - t_begin) & 1) * STGB;
-#pragma unroll
-        for (int row = 0; row < 2; ++row)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x16& a = row == 0 ? acc0 : acc1;
-                const f32x2 lo = {a[4 * g], a[4 * g + 1]}, hi = {a[4 * g + 2], a[4 * g + 3]};
-                u32x2 o;
-                o[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2));
-                o[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2));
-                *reinterpret_cast<u32x2*>(stg + soff[g] + row * 32 * 128) = o;
-            }
         P4C_STAMP_RT(3121 + 2 * (tile - t_begin));
         lds_barrier();
     }
     P4C_STAMP_RT(3112);
 }
 
-template <int MODE>
+template <int MODE, bool BST = false>
 static int launch_ring_mode(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, __bf16* out,
-                            int out_cs, float* stat_partial, int B, int H, int W, int G, hipStream_t stream) {
-    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_ring_kernel<MODE>, ring::SMEM));
-    hipLaunchKernelGGL(conv3x3_bf16_ring_kernel<MODE>, dim3(G), dim3(512), ring::SMEM, stream, in, wp, in_scale, in_shift, out,
-                       out_cs, stat_partial, B, H, W);
+                            int out_cs, float* stat_partial, int B, int H, int W, int G, hipStream_t stream, const BatchFin& fin,
+                            const RingBwdStats& bst = RingBwdStats{}) {
+    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_ring_kernel<MODE, BST>, ring::SMEM));
+    hipLaunchKernelGGL((conv3x3_bf16_ring_kernel<MODE, BST>), dim3(G), dim3(512), ring::SMEM, stream, in, wp, in_scale, in_shift,
+                       out, out_cs, stat_partial, B, H, W, fin, bst);
     return P4C_OK;
 }
 
 static int launch_conv3x3_bf16_ring(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift,
                                     int in_relu, __bf16* out, int out_cs, float* stat_partial, int B, int H, int W,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, const BatchFin* finp, const RingBwdStats* bst, int* nblk_out) {
+    BatchFin fin{};
+    if (finp && stat_partial) { fin = *finp; fin.slots = stat_partial; }
+    if (bst) {
+        P4C_CHECK_ARG(!in_scale && !in_relu && stat_partial && !finp && out_cs == 64 && B <= RING_BWD_STATS_MAXB && nblk_out,
+                      "conv3x3_bf16_ring: backward statistics need a plain 64-channel launch with a partial buffer and B <= %d",
+                      RING_BWD_STATS_MAXB);
+        const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + 3) / 4;
+        const int64_t ntiles = (int64_t)tiles_x * tiles_y * B;
+        const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
+        *nblk_out = 4 * G;
+        prof_begin(P4C_PROF_CONV3X3_C64, (int64_t)B * H * W, stream);
+        const int rc = launch_ring_mode<0, true>(in, wp, nullptr, nullptr, out, out_cs, stat_partial, B, H, W, G, stream, fin, *bst);
+        prof_end(P4C_PROF_CONV3X3_C64, stream);
+        if (rc != P4C_OK) return rc;
+        P4C_CHECK_LAUNCH("conv3x3_bf16_ring(bwd stats)");
+        return P4C_OK;
+    }
     const int tiles_x = (W + BTW - 1) / BTW, tiles_y = (H + 3) / 4;
     int64_t ntiles = (int64_t)tiles_x * tiles_y * B;
     int G = num_cus();
@@ -1189,11 +1363,11 @@ static int launch_conv3x3_bf16_ring(const __bf16* in, const __bf16* wp, const fl
     prof_begin(P4C_PROF_CONV3X3_C64, (int64_t)B * H * W, stream);
     int rc;
     if (in_scale)
-        rc = in_relu ? launch_ring_mode<2>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream)
-                     : launch_ring_mode<3>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream);
+        rc = in_relu ? launch_ring_mode<2>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream, fin)
+                     : launch_ring_mode<3>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream, fin);
     else
-        rc = in_relu ? launch_ring_mode<1>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream)
-                     : launch_ring_mode<0>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream);
+        rc = in_relu ? launch_ring_mode<1>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream, fin)
+                     : launch_ring_mode<0>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, G, stream, fin);
     prof_end(P4C_PROF_CONV3X3_C64, stream);
     if (rc != P4C_OK) return rc;
     P4C_CHECK_LAUNCH("conv3x3_bf16_ring");
@@ -1779,13 +1953,18 @@ static int conv_fwd_bf16_t(const T* in, int CI, const void* wp, int ks, const fl
     return fail(P4C_ERR_UNSUPPORTED, "conv_fwd_bf16: unsupported (CI=%d, ks=%d)", CI, ks);
 }
 
+bool conv_bf16_is_ring(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W) {
+    return storage == P4C_BF16 && CI == 64 && ks == 3 && m_blocks == 1 && out_cs % 8 == 0 && B <= ring::MAXB &&
+           (int64_t)H * W * out_cs * 2 < (int64_t)1 << 31;  // per-sample byte offsets of the buffer descriptors are 32-bit
+}
+
 int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
-                  int m_blocks, hipStream_t stream) {
-    if (storage == P4C_BF16 && CI == 64 && ks == 3 && m_blocks == 1 && out_cs % 8 == 0 && B <= ring::MAXB &&
-        (int64_t)H * W * out_cs * 2 < (int64_t)1 << 31)  // per-sample byte offsets of the buffer descriptors are 32-bit
+                  int m_blocks, hipStream_t stream, const BatchFin* fin, const RingBwdStats* bst, int* nblk_out) {
+    if (conv_bf16_is_ring(storage, CI, ks, m_blocks, out_cs, B, H, W))
         return launch_conv3x3_bf16_ring((const __bf16*)in, (const __bf16*)wp, in_scale, in_shift, in_relu, (__bf16*)out, out_cs,
-                                        stat_partial, B, H, W, stream);
+                                        stat_partial, B, H, W, stream, fin, bst, nblk_out);
+    if (fin || bst) return fail(P4C_ERR_INVALID, "conv_fwd_bf16: in-kernel statistics need the ring kernel");
     if (storage == P4C_BF16)
         return conv_fwd_bf16_t<__bf16>((const __bf16*)in, CI, wp, ks, in_scale, in_shift, in_relu, (__bf16*)out, out_cs,
                                        stat_partial, B, H, W, m_blocks, stream);
@@ -1800,6 +1979,7 @@ template <typename T>
 static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                              const T* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                              hipStream_t stream) {
+    if (diag_skip(32)) return P4C_OK;
     if (CI % 32 != 0 || CI <= 0 || CI > 256) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16: unsupported CI=%d", CI);
     if (ks != 1 && ks != 3) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16: unsupported ks=%d", ks);
     const int tiles = ((H + 7) / 8) * ((W + BTW - 1) / BTW) * B;
@@ -1819,7 +1999,7 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
         else
             rc = launch_conv_wgrad_bf16<T, 32, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         if (rc != P4C_OK) return rc;
-        rc = wgrad_reduce(partial, G * (chunk == 64 ? 1 : 2), ks, CI, off, off + chunk, CO, CIreal, grad, stream);
+        rc = diag_skip(8) ? P4C_OK : wgrad_reduce(partial, G * (chunk == 64 ? 1 : 2), ks, CI, off, off + chunk, CO, CIreal, grad, stream);
         if (rc != P4C_OK) return rc;
         off += chunk;
     }
@@ -1857,6 +2037,7 @@ int prep_weights_bf16(const float* w, int CO, int CI, int ks, int transpose_flip
 // prep_weights_batch: every weight tensor of a network re-laid in ONE launch (blockIdx.y = job); the job table
 // travels in the kernel arguments.  bf16 = 0 writes the fp32 stream of conv_f32.hip (k = 8q + 4h + s).
 __global__ void __launch_bounds__(256) prep_weights_batch_kernel(PrepBatch pb) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < pb.n_zero) pb.zero_words[threadIdx.x] = 0u;
     const PrepJob& jb = pb.job[blockIdx.y];
     const int total = jb.M_pad * jb.K_pad * jb.ntaps;
     const int kv = pb.bf16 ? 8 : 4;           // k values per lane slot

@@ -34,7 +34,7 @@ struct Layout {
     // saved workspace: activations (element offsets) then normalisation arrays (float offsets from norm_base bytes)
     int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
     // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
-    int64_t wprep, statp, wgradp, nbwdp, k1, k2, f_floats, g_base, G0, G1, G2, TB, DY[NCONV], scratch_bytes;
+    int64_t wprep, statp, wgradp, nbwdp, k1, k2, tickets, f_floats, g_base, G0, G1, G2, TB, DY[NCONV], scratch_bytes;
     int G;  // persistent workgroups of the weight-gradient kernel
 };
 
@@ -54,9 +54,10 @@ inline int prep_w(int compute, const float* w, int CO, int CI, int ks, int tf, i
                                : prep_weights(w, CO, CI, ks, tf, M_pad, K_pad, (float*)out, st);
 }
 inline int conv_fwd(int compute, int storage, const void* in, int CI, const void* wp, int ks, const float* sc, const float* sh,
-                    int relu, void* out, int out_cs, float* statp, int B, int H, int W, int mblocks, hipStream_t st) {
+                    int relu, void* out, int out_cs, float* statp, int B, int H, int W, int mblocks, hipStream_t st,
+                    const BatchFin* fin = nullptr, const RingBwdStats* bst = nullptr, int* nblk_out = nullptr) {
     return compute == P4C_BF16
-               ? conv_fwd_bf16(in, storage, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st)
+               ? conv_fwd_bf16(in, storage, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st, fin, bst, nblk_out)
                : conv_fwd_f32((const float*)in, CI, (const float*)wp, ks, sc, sh, relu, nullptr, (float*)out, out_cs, statp, B, H, W,
                               mblocks, st);
 }
@@ -122,9 +123,10 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     const int64_t tps = conv_tiles_per_sample(d.H, d.W);
     L.statp = off; off += (int64_t)d.B * (tps > 4 * (int64_t)L.G ? tps : 4 * (int64_t)L.G) * 128;
     L.wgradp = off; off += wgrad_partial_floats(96, 3, L.G);
-    L.nbwdp = off; off += (int64_t)d.B * 512 * 128;
+    L.nbwdp = off; off += (int64_t)d.B * NORM_BWD_MAX_BLOCKS * 128;
     L.k1 = off; off += (int64_t)d.B * NF;
     L.k2 = off; off += (int64_t)d.B * NF;
+    L.tickets = off; off += 64;   // ticket counters of the in-kernel finalizes (uint32 words, cleared by the weight preparation)
     L.f_floats = off;
     L.g_base = align256(off * (int64_t)sizeof(float));
     off = 0;
@@ -170,6 +172,8 @@ int prepare_weights(const p4c_halfunet_desc& d, const WS& ws, const float* param
     }
     if (which & 1) pb.job[pb.n++] = {params + L.wout, wslot(ws, 2 * NCONV), d.cout, NF, 1, 0, 64, NF};
     if (which & 2) pb.job[pb.n++] = {params + L.wout, wslot(ws, 2 * NCONV + 1), d.cout, NF, 1, 1, 64, NF};
+    pb.zero_words = reinterpret_cast<unsigned int*>(ws.f(L.tickets));
+    pb.n_zero = 64;
     return prep_weights_batch(pb, st);
 }
 
@@ -181,11 +185,23 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     void* wp = wslot(ws, i);
     const bool batch_stats = (d.norm == 1) || training;
     float* statp = batch_stats ? ws.f(L.statp) : nullptr;
-    P4C_TRY(conv_fwd(d.compute, d.dtype, in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
-                     in_norm ? in_norm->shift : nullptr, in_norm ? 1 : 0, ws.act(L.Y[i]), NF, statp, d.B, H, W, 1, st));
     Norm nm = norm_at(ws, i, d.B);
     float* rm = running ? running + (int64_t)i * 128 : nullptr;
     float* rv = running ? rm + 64 : nullptr;
+    // BatchNorm statistics of a ring-kernel convolution are finished by the kernel itself (its last workgroup): no norm_finalize launch
+    const char* ie = getenv("P4C_NO_INKERNEL_FINALIZE");
+    const bool no_infin = ie && ie[0] == '1';
+    const bool infin = batch_stats && d.norm == 0 && d.compute == P4C_BF16 && !no_infin &&
+                       conv_bf16_is_ring(d.dtype, conv_cin_pad(d, i), 3, 1, NF, d.B, H, W);
+    BatchFin fin{};
+    if (infin) {
+        fin = BatchFin{statp, reinterpret_cast<unsigned int*>(ws.f(L.tickets)), params + L.gamma[i], params + L.beta[i], rm, rv,
+                       nm.scale, nm.shift, nm.mean, nm.rstd, (double)d.B * H * W, d.eps, d.momentum, d.B};
+    }
+    P4C_TRY(conv_fwd(d.compute, d.dtype, in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
+                     in_norm ? in_norm->shift : nullptr, in_norm ? 1 : 0, ws.act(L.Y[i]), NF, statp, d.B, H, W, 1, st,
+                     infin ? &fin : nullptr));
+    if (infin) return P4C_OK;
     if (batch_stats) {
         P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, d.dtype, conv_cin_pad(d, i), d.B, H, W), d.B, (int64_t)H * W, d.norm,
                               d.groups, params + L.gamma[i], params + L.beta[i], d.eps, d.momentum,
@@ -255,7 +271,7 @@ thread_local SideStream g_side;
 // backward through [conv i -> norm -> relu] given dA (grad wrt the post-ReLU activation) in `g`:
 //   dY -> its own buffer; grads of gamma/beta/weight accumulated; if `din` != null: din = dL/d(conv input)
 int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, const void* in, const Norm* in_norm, void* din,
-                   const float* params, float* grads, int training, hipStream_t st) {
+                   const float* params, float* grads, int training, hipStream_t st, int pre_nblk = 0, int* next_nblk = nullptr) {
     const Layout& L = ws.L;
     const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
     Norm nm = norm_at(ws, i, d.B);
@@ -263,7 +279,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
     void* dY = ws.g(L.DY[i]);
     P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
                      (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1), ws.f(L.k2),
-                     grads + L.gamma[i], grads + L.beta[i], dY, st));
+                     grads + L.gamma[i], grads + L.beta[i], dY, st, pre_nblk));
     const int cip = conv_cin_pad(d, i);
     int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
     const int G = ntiles < L.G ? (int)ntiles : L.G;
@@ -284,8 +300,21 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
     } else {
         P4C_TRY(job(st));
     }
+    if (next_nblk) *next_nblk = 0;
     if (din) {
-        P4C_TRY(conv_fwd(d.compute, d.dtype, dY, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, nullptr, d.B, H, W, 1, st));
+        // the input of this convolution is relu(norm(Y[i-1])): its data gradient IS the dA of layer i-1's normalisation backward,
+        // whose pass 1 (sums of g and g * xhat) the ring kernel takes while it stores the gradient tile
+        const char* fe = getenv("P4C_NO_FUSED_REDUCE");   // (read per call: the parity test switches it)
+        const bool fuse_off = fe && fe[0] == '1';
+        const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 && d.B <= RING_BWD_STATS_MAXB &&
+                          conv_bf16_is_ring(d.dtype, NF, 3, 1, 64, d.B, H, W) && 4 * num_cus() <= NORM_BWD_MAX_BLOCKS;
+        if (fuse) {
+            const RingBwdStats bst{in, in_norm->scale, in_norm->shift, in_norm->mean, in_norm->rstd};
+            P4C_TRY(conv_fwd(d.compute, d.dtype, dY, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, ws.f(L.nbwdp), d.B, H, W,
+                             1, st, nullptr, &bst, next_nblk));
+        } else {
+            P4C_TRY(conv_fwd(d.compute, d.dtype, dY, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, nullptr, d.B, H, W, 1, st));
+        }
     }
     return P4C_OK;
 }
@@ -413,8 +442,9 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     }
     // ---- decoder
     Norm nd1 = norm_at(ws, 10, d.B);
-    P4C_TRY(conv_block_bwd(d, ws, 11, G0, ws.act(L.Y[10]), &nd1, G1, params, grads, training, st));
-    P4C_TRY(conv_block_bwd(d, ws, 10, G1, ws.act(L.S), nullptr, G0, params, grads, training, st));
+    int nxt = 0;
+    P4C_TRY(conv_block_bwd(d, ws, 11, G0, ws.act(L.Y[10]), &nd1, G1, params, grads, training, st, 0, &nxt));
+    P4C_TRY(conv_block_bwd(d, ws, 10, G1, ws.act(L.S), nullptr, G0, params, grads, training, st, nxt));
     // G0 = dS, kept until the last level
 
     // ---- encoder levels, deepest first
@@ -431,19 +461,28 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         Norm n2 = norm_at(ws, 2 * k + 1, d.B);
         Norm n1 = norm_at(ws, 2 * k, d.B);
         const void* dP = (k + 1 < NLEV) ? a : nullptr;
+        // (bf16 storage, statistics of the batch in use: enc_out_bwd also takes pass 1 of conv2's normalisation backward)
+        const char* fe = getenv("P4C_NO_FUSED_REDUCE");
+        const bool fuse_off = fe && fe[0] == '1';
+        const bool fuse = !fuse_off && d.dtype == P4C_BF16;
+        int pre = 0;
+        float* part = fuse ? ws.f(L.nbwdp) : nullptr;
         if (k > 0) {
-            P4C_TRY(enc_out_bwd(d.dtype, tx[k - 1], d.H, 1 << k, nullptr, dP, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st));
+            P4C_TRY(enc_out_bwd(d.dtype, tx[k - 1], d.H, 1 << k, nullptr, dP, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st,
+                                n2.mean, n2.rstd, part, &pre));
         } else {
-            P4C_TRY(enc_out_bwd(d.dtype, nullptr, d.H, 1, G0, dP, ws.act(L.Y[1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st));
+            P4C_TRY(enc_out_bwd(d.dtype, nullptr, d.H, 1, G0, dP, ws.act(L.Y[1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st, n2.mean,
+                                n2.rstd, part, &pre));
         }
         // conv2 of the block: input = relu(norm1(Y_k1))
-        P4C_TRY(conv_block_bwd(d, ws, 2 * k + 1, b, ws.act(L.Y[2 * k]), &n1, a, params, grads, training, st));
+        int nxt1 = 0;
+        P4C_TRY(conv_block_bwd(d, ws, 2 * k + 1, b, ws.act(L.Y[2 * k]), &n1, a, params, grads, training, st, pre, &nxt1));
         // conv1 of the block: input = P_k (k>0) or x
         if (k > 0) {
-            P4C_TRY(conv_block_bwd(d, ws, 2 * k, a, ws.act(L.P[k]), nullptr, b, params, grads, training, st));
+            P4C_TRY(conv_block_bwd(d, ws, 2 * k, a, ws.act(L.P[k]), nullptr, b, params, grads, training, st, nxt1));
             void* t = a; a = b; b = t;  // dP_k now in a
         } else {
-            P4C_TRY(conv_block_bwd(d, ws, 0, a, x, nullptr, d.dx_channels > 0 ? dx : nullptr, params, grads, training, st));
+            P4C_TRY(conv_block_bwd(d, ws, 0, a, x, nullptr, d.dx_channels > 0 ? dx : nullptr, params, grads, training, st, nxt1));
         }
     }
     // join: the caller's stream continues only after every weight gradient of this call has been accumulated

@@ -32,13 +32,50 @@ struct PrepBatch {
     PrepJob job[32];
     int n;
     int bf16;         // 1: bf16 stream (conv_bf16.hip), 0: fp32 stream (conv_f32.hip)
+    unsigned int* zero_words;   // ticket counters of the in-kernel finalizes (below): cleared by the same launch
+    int n_zero;
+};
+
+// BatchNorm statistics finished INSIDE the producing kernel: every workgroup leaves ONE slot of channel sums, takes a ticket,
+// and the workgroup that draws the last ticket reduces the slots in a fixed order (bitwise reproducible, fp64 combine) and
+// writes scale / shift / mean / rstd (+ the running statistics) -- what norm_finalize does in a launch of its own (a
+// dependent ~7 us launch per convolution on the forward critical path).  slots == nullptr: off.
+struct BatchFin {
+    float* slots;              // [workgroups][2][64]
+    unsigned int* ticket;      // zero between launches (the last workgroup resets it)
+    const float* gamma;
+    const float* beta;
+    float* running_mean;       // may be null
+    float* running_var;
+    float* scale;              // (B,64) each
+    float* shift;
+    float* mean;
+    float* rstd;
+    double count;              // B*H*W
+    float eps, momentum;
+    int B;
 };
 int prep_weights_batch(const PrepBatch& pb, hipStream_t stream);
 int conv_bf16_stat_slots(int CI, int storage, int B, int H, int W);
 // `storage` = element type of in/out/dout in HBM (P4C_F32 or P4C_BF16)
+// Pass 1 of a normalisation backward taken by the DATA-GRADIENT convolution that produces dA (ring kernel only): with
+// y = the raw forward output the gradient belongs to and its normalisation rows, the kernel leaves in `stat_partial`
+// [b][slot][2][64] the per-(workgroup, wave) sums of g = dA * [relu(y*scale+shift) alive] and of g * xhat -- what
+// norm_bwd_reduce would compute from a read of dA and y (norm_pool.hip); the number of slots per sample goes to *nblk_out.
+struct RingBwdStats {
+    const void* y;            // (B,H,W,64) bf16
+    const float* scale;       // (B,64) each
+    const float* shift;
+    const float* mean;
+    const float* rstd;
+};
+constexpr int RING_BWD_STATS_MAXB = 21;
 int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
-                  int m_blocks, hipStream_t stream);
+                  int m_blocks, hipStream_t stream, const BatchFin* fin = nullptr, const RingBwdStats* bst = nullptr,
+                  int* nblk_out = nullptr);
+// true when conv_fwd_bf16 with these arguments runs the persistent ring kernel (the one that can finish BatchNorm itself)
+bool conv_bf16_is_ring(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W);
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                     const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                     hipStream_t stream);
@@ -53,15 +90,21 @@ int norm_bwd_blocks(int64_t hw);
 // `storage` = element type of activations / activation gradients in HBM (P4C_F32 or P4C_BF16)
 int norm_bwd(int storage, const void* dA, const void* y, const float* scale, const float* shift, const float* mean,
              const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
-             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream);
+             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream, int pre_nblk = 0);
+// partial slots per sample the normalisation backward's buffers are sized for (standalone pass 1: <= 512; producers that take
+// pass 1 themselves -- enc_out_bwd, the ring data-gradient convolution -- may leave up to this many)
+constexpr int NORM_BWD_MAX_BLOCKS = 1024;
 int pool_fwd(int storage, const void* y, const float* scale, const float* shift, int B, int H, int W, void* P,
              hipStream_t stream);
 int upsum_fwd(int storage, const void* const* y, const float* const* scale, const float* const* shift, int B, int H, int W,
               void* S, hipStream_t stream);
 // tx[k-1]: (B,H,W>>k,64) for k = 1..4
 int up_bwd_x4(int storage, const void* dS, int B, int H, int W, void* const* tx, hipStream_t stream);
+// mean / rstd / partial / nblk_out given (bf16 storage): the kernel also takes pass 1 of the normalisation backward of the level's
+// second convolution on the dA it forms; *nblk_out = slots per sample left in `partial` (0: not fused, run the pass as usual)
 int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, const void* dP, const void* y,
-                const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream);
+                const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream,
+                const float* mean = nullptr, const float* rstd = nullptr, float* partial = nullptr, int* nblk_out = nullptr);
 
 // tiles of the conv kernels (for sizing the statistics partial buffers)
 constexpr int CONV_TH = 4;

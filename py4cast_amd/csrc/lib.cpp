@@ -1,5 +1,6 @@
 // Library-wide state of libpy4cast_hip.so: thread-local error message, device queries.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <mutex>
@@ -33,6 +34,15 @@ int num_cus() {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;  // MI355X
     cus[dev].store(n, std::memory_order_release);
     return n;
+}
+
+int diag_skip(int bit) {
+    static const int mask = [] { const char* e = getenv("P4C_DIAG"); return e ? atoi(e) : 0; }();
+    if (!(mask & bit)) return 0;
+    static std::atomic<int> calls[32];
+    int idx = 0;
+    while ((1 << idx) < bit) ++idx;
+    return calls[idx].fetch_add(1) > 400;
 }
 
 int ensure_dyn_smem(const void* kernel, int bytes) {

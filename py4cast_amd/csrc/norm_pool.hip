@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "kernels.hpp"
 
 namespace p4c {
 
@@ -643,14 +644,22 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     enc_out_bwd_bf16x8_kernel(const __bf16* __restrict__ Tx, int Hfull, int s, const __bf16* __restrict__ dS,
                               const __bf16* __restrict__ dP, const __bf16* __restrict__ y, const float* __restrict__ scale,
-                              const float* __restrict__ shift, int Hk, int Wk, __bf16* __restrict__ dA) {
+                              const float* __restrict__ shift, int Hk, int Wk, __bf16* __restrict__ dA,
+                              const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial) {
+    // partial != null: pass 1 of the normalisation backward of THIS level's second convolution (norm_bwd_reduce: the sums of
+    // g = dA * [relu alive] and g * xhat over the pixels of this workgroup) is taken here, on the dA just formed (its
+    // bf16-rounded value, what a separate pass would read back) -- one launch and one read of dA and y less per encoder level
+    __shared__ float red[2][32][65];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    float sc[8], sh[8];
+    float sc[8], sh[8], mu[8], rs[8], a1[8], a2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        sc[j] = dP ? scale[b * C + 8 * c8 + j] : 0.f;
-        sh[j] = dP ? shift[b * C + 8 * c8 + j] : 0.f;
+        sc[j] = (dP || partial) ? scale[b * C + 8 * c8 + j] : 0.f;
+        sh[j] = (dP || partial) ? shift[b * C + 8 * c8 + j] : 0.f;
+        mu[j] = partial ? mean[b * C + 8 * c8 + j] : 0.f;
+        rs[j] = partial ? rstd[b * C + 8 * c8 + j] : 0.f;
+        a1[j] = a2[j] = 0.f;
     }
     const int hw = Hk * Wk;
     const norm_u32x4* dSb = dS ? reinterpret_cast<const norm_u32x4*>(dS + (int64_t)b * hw * C) : nullptr;
@@ -660,9 +669,10 @@ __global__ void __launch_bounds__(256)
     norm_u32x4* ob = reinterpret_cast<norm_u32x4*>(dA + (int64_t)b * hw * C);
     for (int p = blockIdx.x * 32 + pl; p < hw; p += gridDim.x * 32) {
         const int Y = p / Wk, X = p - Y * Wk;
-        float acc[8];
+        float acc[8], ymine[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (partial && !dPb) unpack8(yb[(int64_t)p * 8 + c8], ymine);
         if (dSb) unpack8(dSb[(int64_t)p * 8 + c8], acc);
         if (Txb) {
             int ya = s * Y - s / 2, ye = s * Y + 3 * s / 2 - 1;
@@ -700,9 +710,36 @@ __global__ void __launch_bounds__(256)
                     if (vq > m) { m = vq; arg = q; }
                 }
                 if (arg == me) acc[j] += g[j];
+                if (partial) ymine[j] = me == 0 ? v[0][j] : (me == 1 ? v[1][j] : (me == 2 ? v[2][j] : v[3][j]));
             }
         }
-        ob[(int64_t)p * 8 + c8] = pack8(acc);
+        const norm_u32x4 packed = pack8(acc);
+        ob[(int64_t)p * 8 + c8] = packed;
+        if (partial) {
+            float gr[8];
+            unpack8(packed, gr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = (ymine[j] * sc[j] + sh[j]) > 0.f ? gr[j] : 0.f;
+                a1[j] += g;
+                a2[j] += g * ((ymine[j] - mu[j]) * rs[j]);
+            }
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[0][pl][8 * c8 + j] = a1[j];
+            red[1][pl][8 * c8 + j] = a2[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) sum += red[st][k][c];
+            partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = sum;
+        }
     }
 }
 
@@ -719,6 +756,7 @@ int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw,
                   const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
                   float* shift, float* mean, float* rstd, hipStream_t stream) {
     const int grid = mode == 0 ? C : B * groups;
+    if (diag_skip(1)) return P4C_OK;
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(grid), dim3(256), 0, stream, partial, tiles_per_sample, B, hw, mode,
                        groups, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd);
     P4C_CHECK_LAUNCH("norm_finalize");
@@ -746,19 +784,25 @@ template <typename T>
 static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* shift, const float* mean,
                       const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups,
                       int training, float* partial, float* k1, float* k2, float* dgamma, float* dbeta, T* dY,
-                      hipStream_t stream) {
-    const int nblk = norm_bwd_blocks(hw);
-    if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_REDUCE_V1") == nullptr)
+                      hipStream_t stream, int pre_nblk) {
+    // pre_nblk > 0: pass 1 was taken by the kernel that produced dA (enc_out_bwd / the data-gradient convolution): `partial`
+    // already holds pre_nblk slots per sample
+    const int nblk = pre_nblk > 0 ? pre_nblk : norm_bwd_blocks(hw);
+    const bool skip_reduce = diag_skip(4), skip_fin = diag_skip(2), skip_apply = diag_skip(16);
+    if (skip_reduce || pre_nblk > 0) {
+    } else if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_REDUCE_V1") == nullptr)
         hipLaunchKernelGGL(norm_bwd_reduce_bf16x8_kernel, dim3(nblk, B), dim3(256), 0, stream, (const __bf16*)dA, (const __bf16*)y, scale,
                            shift, mean, rstd, relu, hw, partial);
     else
         hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk, B), dim3(256), 0, stream, dA, y, scale, shift, mean, rstd,
                            relu, hw, partial);
     P4C_CHECK_LAUNCH("norm_bwd_reduce");
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(mode == 0 ? C : groups), dim3(256), 0, stream, partial, nblk, B, hw,
-                       mode, groups, training, gamma, dgamma, dbeta, k1, k2);
+    if (!skip_fin && !(skip_reduce && pre_nblk <= 0))
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(mode == 0 ? C : groups), dim3(256), 0, stream, partial, nblk, B, hw,
+                           mode, groups, training, gamma, dgamma, dbeta, k1, k2);
     P4C_CHECK_LAUNCH("norm_bwd_finalize");
-    if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_APPLY_V1") == nullptr) {
+    if (skip_apply) {
+    } else if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_APPLY_V1") == nullptr) {
         int64_t blocks = (hw + 127) / 128;                       // >= 4 pixel rows of 32 per workgroup
         const int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
         if (blocks > cap) blocks = cap;
@@ -775,12 +819,12 @@ static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* 
 
 int norm_bwd(int storage, const void* dA, const void* y, const float* scale, const float* shift, const float* mean,
              const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
-             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream) {
+             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream, int pre_nblk) {
     if (storage == P4C_BF16)
         return norm_bwd_t<__bf16>((const __bf16*)dA, (const __bf16*)y, scale, shift, mean, rstd, gamma, relu, B, hw, mode,
-                                  groups, training, partial, k1, k2, dgamma, dbeta, (__bf16*)dY, stream);
+                                  groups, training, partial, k1, k2, dgamma, dbeta, (__bf16*)dY, stream, pre_nblk);
     return norm_bwd_t<float>((const float*)dA, (const float*)y, scale, shift, mean, rstd, gamma, relu, B, hw, mode, groups,
-                             training, partial, k1, k2, dgamma, dbeta, (float*)dY, stream);
+                             training, partial, k1, k2, dgamma, dbeta, (float*)dY, stream, pre_nblk);
 }
 
 template <typename T>
@@ -826,14 +870,20 @@ int up_bwd_x4(int storage, const void* dS, int B, int H, int W, void* const* tx,
 
 template <typename T>
 static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP, const T* y, const float* scale,
-                         const float* shift, int B, int Hk, int Wk, T* dA, hipStream_t stream) {
+                         const float* shift, int B, int Hk, int Wk, T* dA, const float* mean, const float* rstd, float* partial,
+                         int* nblk_out, hipStream_t stream) {
+    if (nblk_out) *nblk_out = 0;
     if (std::is_same<T, __bf16>::value && getenv("P4C_ENC_OUT_V1") == nullptr) {
         int64_t blocks = ((int64_t)Hk * Wk + 31) / 32;
-        const int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
+        int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
+        const bool fuse = partial && nblk_out && mean && rstd;
+        if (fuse && cap > NORM_BWD_MAX_BLOCKS) cap = NORM_BWD_MAX_BLOCKS;   // one partial slot per workgroup
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(enc_out_bwd_bf16x8_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const __bf16*)Tx, Hfull, s,
-                           (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale, shift, Hk, Wk, (__bf16*)dA);
+                           (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale, shift, Hk, Wk, (__bf16*)dA, mean, rstd,
+                           fuse ? partial : nullptr);
+        if (fuse) *nblk_out = (int)blocks;
     } else {
         hipLaunchKernelGGL(enc_out_bwd_kernel<T>, dim3(ew_grid((int64_t)B * Hk * Wk * 16)), dim3(256), 0, stream, Tx, Hfull, s,
                            dS, dP, y, scale, shift, B, Hk, Wk, dA);
@@ -842,12 +892,13 @@ static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP
     return P4C_OK;
 }
 int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, const void* dP, const void* y,
-                const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream) {
+                const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream, const float* mean,
+                const float* rstd, float* partial, int* nblk_out) {
     if (storage == P4C_BF16)
         return enc_out_bwd_t<__bf16>((const __bf16*)Tx, Hfull, s, (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale,
-                                     shift, B, Hk, Wk, (__bf16*)dA, stream);
+                                     shift, B, Hk, Wk, (__bf16*)dA, mean, rstd, partial, nblk_out, stream);
     return enc_out_bwd_t<float>((const float*)Tx, Hfull, s, (const float*)dS, (const float*)dP, (const float*)y, scale, shift,
-                                B, Hk, Wk, (float*)dA, stream);
+                                B, Hk, Wk, (float*)dA, mean, rstd, partial, nblk_out, stream);
 }
 
 }  // namespace p4c

@@ -336,40 +336,46 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         tflops = flops / (ms.value * 1e-3) / 1e12
         bf = self._settings.compute_dtype == "bf16"
         peak = 2500.0 if bf else 157.3  # dense MFMA peaks, MI355X_MICROARCH.md
-        wms, wn, wunits = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-        L.lib().p4c_prof_collect(L.PROF_WGRAD3X3_C64, B * H * W, ctypes.byref(wms), ctypes.byref(wn), ctypes.byref(wunits))
-        dms, dn, dunits = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-        L.lib().p4c_prof_collect(L.PROF_CONV3X3_C64_BWD, B * H * W, ctypes.byref(dms), ctypes.byref(dn), ctypes.byref(dunits))
-        dgrad_ms = (dms.value / dn.value) if dn.value else None
         if bf:
             # at the bf16 MFMA rate the kernel is HBM-bound: algorithmic bytes = read 64 ch + write 64 ch per pixel
             esz = 2 if self.act_dtype == torch.bfloat16 else 4
             gbs = 2.0 * 64 * esz * units.value / (ms.value * 1e-3) / 1e9
             kname = "conv3x3_bf16_ring_kernel" if esz == 2 else "conv_fwd_bf16_ws_kernel<f32,64,3>"
-            traffic = None
+            traffic, traffic_source = None, None
             if esz == 2 and (B, H, W) == (2, 512, 512):
-                # HBM bytes per launch of this very launch shape, from the committed rocprofv3 PMC passes
-                import json, os
-                f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
-                if os.path.exists(f):
-                    traffic = json.load(open(f)).get("conv3x3_bf16_ring_kernel", {}).get("hbm_bytes_per_launch")
+                # HBM bytes per launch of this launch shape from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with
+                # the gfx950 corrections): a COMMITTED reference value of an earlier run, not a measurement of this run
+                import json
+                import os
+
+                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                    f = os.path.join(root, "profiles", name)
+                    if os.path.exists(f):
+                        traffic = json.load(open(f)).get("conv3x3_bf16_ring_kernel", {}).get("hbm_bytes_per_launch")
+                        traffic_source = f"profiles/{name} (committed rocprofv3 --pmc passes of an earlier run of this command)"
+                        break
             return {"bound": "hbm", "kernel": kname + " (3x3 conv 64->64, forward-plan launches at full resolution)",
-                    "datagrad_avg_launch_ms_overlapped": dgrad_ms,
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": 2.0 * 64 * esz * B * H * W,
                     "avg_launch_ms": ms.value / n.value, "launches": n.value, "mfma_tflops": tflops,
-                    # context: on random operands the matrix pipe sustains 22.7 ns per v_mfma_f32_32x32x16_bf16 per SIMD
-                    # (power-limited clock, profiles/r01_mfma_rate_microbench.txt) = 1478 TFLOP/s, not the 2500 dense peak
-                    "mfma_sustained_tflops_measured": 1478.0, "mfma_frac_of_sustained": tflops / 1478.0,
-                    "wgrad_avg_launch_ms": (wms.value / wn.value) if wn.value else None}
-        out = {"bound": "mfma", "kernel": "conv_fwd_f32_kernel<64,3,4> (3x3 conv 64->64, forward-plan launches at full resolution)",
-               "datagrad_avg_launch_ms_overlapped": dgrad_ms,
-               "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
-               "avg_launch_ms": ms.value / n.value, "launches": n.value,
-               "flops_per_launch": flops / n.value}
-        if wn.value:
-            out["wgrad_kernel"] = {"avg_launch_ms": wms.value / wn.value, "launches": wn.value,
-                                   "achieved": 2.0 * 9 * 64 * 64 * wunits.value / (wms.value * 1e-3) / 1e12}
+                    # context, a reference value of an earlier micro-benchmark (profiles/r01_mfma_rate_microbench.txt): on random
+                    # operands the matrix pipe sustains 22.7 ns per v_mfma_f32_32x32x16_bf16 per SIMD (power-limited clock)
+                    "mfma_sustained_tflops_reference": 1478.0, "mfma_frac_of_sustained_reference": tflops / 1478.0}
+        return {"bound": "mfma", "kernel": "conv_fwd_f32_kernel<64,3,4> (3x3 conv 64->64, forward-plan launches at full resolution)",
+                "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
+                "avg_launch_ms": ms.value / n.value, "launches": n.value, "flops_per_launch": flops / n.value}
+
+    def launch_times(self, B, H, W):
+        """bench.py, one extra un-timed step with every tagged launch bracketed: average duration of the roofline kernel's
+        data-gradient launches and of the weight-gradient kernel at full resolution (they overlap each other in the backward
+        plan -- main and side stream -- so they are reported next to, not inside, the roofline figure)."""
+        out = {}
+        for key, tag in (("datagrad_avg_launch_ms_overlapped", L.PROF_CONV3X3_C64_BWD), ("wgrad_avg_launch_ms_overlapped", L.PROF_WGRAD3X3_C64)):
+            ms, n, units = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+            L.lib().p4c_prof_collect(tag, B * H * W, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(units))
+            out[key] = (ms.value / n.value) if n.value else None
         return out
 
 
