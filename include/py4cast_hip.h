@@ -209,6 +209,14 @@ int p4c_adamw_step(float* params, const float* grads, float* exp_avg, float* exp
  *   (Sample.load standardisation datasets/base.py:448-452 + NamedTensor.concat + collate_fn :173-195 in one pass). */
 int p4c_unnormalize(const float* x, const float* std, const float* mean, float* out, int64_t rows, int F,
                     p4c_stream_t stream);
+
+/* The same un-normalisation for the output writers (py4cast/io/outputs.py:116-241 take one (lat, lon) plane per time step and
+ * feature: `raw_data.tensor[:, :, idx].cpu().numpy()`, a strided gather + a synchronous copy per plane in the reference):
+ * x (images, N, F) features-last -> out (images, F, N), out[i, f, n] = x[i, n, f] * std[f] + mean[f] (two rounded steps, bit-exact
+ * with lightning.py:1162-1169).  images = B*T.  `out` may be device memory or PINNED HOST memory mapped into the device (the
+ * kernel then streams the planes straight over PCIe; see py4cast_amd/outputs.py). */
+int p4c_unnormalize_planes(const float* x, const float* std, const float* mean, float* out, int64_t images, int64_t N, int F,
+                           p4c_stream_t stream);
 int p4c_pack_standardize(const float* raw, int64_t plane_stride, const float* mean, const float* std, float* out,
                          int64_t rows, int F, p4c_stream_t stream);
 

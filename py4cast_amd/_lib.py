@@ -41,6 +41,7 @@ SIGNATURES = {
     "p4c_scaled_loss_fwd": [P, L, L, P, L, L, P, I, P, P, F, P, I, P, P, I, I, L, I, P],
     "p4c_acc_sums": [P, L, L, P, L, L, P, I, P, P, P, I, I, L, I, P],
     "p4c_unnormalize": [P, P, P, P, L, I, P],
+    "p4c_unnormalize_planes": [P, P, P, P, L, L, I, P],
     "p4c_adamw_step": [P, P, P, P, L, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, L, P],
     "p4c_nan_moments": [P, P, L, P, P, I, L, I, P],
     "p4c_pack_standardize": [P, L, P, P, P, L, I, P],

@@ -497,6 +497,44 @@ extern "C" int p4c_unnormalize(const float* x, const float* std, const float* me
     return P4C_OK;
 }
 
+// un-normalise + features-last -> one plane per feature, through an LDS tile of 64 grid points x F features: global reads are
+// rows of F floats (contiguous), global writes runs of 64 floats per feature (contiguous): both sides coalesced.  The
+// arithmetic is the reference's two rounded steps (x * std, then + mean; contraction is off in this translation unit).
+constexpr int PLANE_PTS = 64;
+__global__ void __launch_bounds__(256)
+    unnormalize_planes_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ mean,
+                              float* __restrict__ out, int64_t N, int F) {
+    extern __shared__ float tile[];   // [PLANE_PTS][F + 1]
+    const int64_t img = blockIdx.y;   // (b, t) index
+    const int64_t n0 = (int64_t)blockIdx.x * PLANE_PTS;
+    const int npts = (int)((N - n0) < PLANE_PTS ? (N - n0) : PLANE_PTS);
+    const float* src = x + (img * N + n0) * F;
+    for (int i = threadIdx.x; i < npts * F; i += 256) {
+        const int pt = i / F, f = i - pt * F;
+        float v = src[i] * std[f];
+        v = v + mean[f];
+        tile[pt * (F + 1) + f] = v;
+    }
+    __syncthreads();
+    float* dst = out + img * F * N + n0;
+    for (int i = threadIdx.x; i < F * PLANE_PTS; i += 256) {
+        const int f = i / PLANE_PTS, pt = i - f * PLANE_PTS;
+        if (pt < npts) dst[(int64_t)f * N + pt] = tile[pt * (F + 1) + f];
+    }
+}
+
+extern "C" int p4c_unnormalize_planes(const float* x, const float* std, const float* mean, float* out, int64_t images,
+                                      int64_t N, int F, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && std && mean && out, "p4c_unnormalize_planes: null pointer");
+    P4C_CHECK_ARG(images > 0 && images < 65536 && N > 0 && F > 0 && F <= 512, "p4c_unnormalize_planes: bad dims");
+    const size_t smem = (size_t)PLANE_PTS * (F + 1) * sizeof(float);
+    P4C_TRY(ensure_dyn_smem((const void*)unnormalize_planes_kernel, PLANE_PTS * 513 * 4));
+    hipLaunchKernelGGL(unnormalize_planes_kernel, dim3((unsigned)((N + PLANE_PTS - 1) / PLANE_PTS), (unsigned)images), dim3(256),
+                       smem, as_stream(stream), x, std, mean, out, N, F);
+    P4C_CHECK_LAUNCH("p4c_unnormalize_planes");
+    return P4C_OK;
+}
+
 extern "C" int p4c_pack_standardize(const float* raw, int64_t plane_stride, const float* mean, const float* std, float* out,
                                     int64_t rows, int F, p4c_stream_t stream) {
     P4C_CHECK_ARG(raw && mean && std && out, "p4c_pack_standardize: null pointer");

@@ -732,11 +732,23 @@ class AutoRegressiveLightning(_Base):
         return mean_loss
 
     def predict_step(self, batch: ItemBatch, batch_idx: int) -> torch.Tensor:
-        """lightning.py:1118-1188: rollout without border forcing, then un-normalise per feature (:1162-1169)."""
+        """lightning.py:1118-1188: rollout without border forcing, then un-normalise per feature (:1162-1169).  With an
+        ``output_stager`` attached (py4cast_amd.outputs.OutputStager) the un-normalised prediction also leaves for the host as
+        feature-major planes in a pinned buffer -- what the GRIB / GIF writers of io/outputs.py consume -- without blocking;
+        ``self.staged_slot`` is the ticket for ``output_stager.wait``."""
+        if batch_idx == 0 and getattr(self, "input_feature_names", None) is not None:
+            if self.input_feature_names != batch.inputs.feature_names:   # lightning.py:1123-1128
+                raise ValueError(
+                    f"Input Feature names mismatch between training and inference. "
+                    f"Training: {self.input_feature_names}, Inference: {batch.inputs.feature_names}"
+                )
         with torch.no_grad():
             preds = self.forward(batch, batch_idx)
             std = self.stats.to_list("std", preds.feature_names).to(preds.tensor)
             mean = self.stats.to_list("mean", preds.feature_names).to(preds.tensor)
+            stager = getattr(self, "output_stager", None)
+            if stager is not None:
+                self.staged_slot = stager.submit(preds, std, mean)   # reads the normalised tensor: before the in-place pass below
             t = preds.tensor.contiguous().float()
             preds.tensor = ops.unnormalize(t, std, mean, out=t)  # one kernel, the reference's two rounded steps
         return preds

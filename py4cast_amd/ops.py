@@ -365,6 +365,23 @@ def unnormalize(x: torch.Tensor, std: torch.Tensor, mean: torch.Tensor, out: tor
     return out
 
 
+def unnormalize_planes(x: torch.Tensor, std: torch.Tensor, mean: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """x (B,T,*S,F) -> (B,T,F,*S): un-normalised, one contiguous plane per (sample, time step, feature) -- the layout the GRIB / GIF
+    writers consume (io/outputs.py:116-241), same two rounded steps as ``unnormalize``."""
+    L.require_cuda(x)
+    x = x.contiguous().float()
+    B, T, F = x.shape[0], x.shape[1], x.shape[-1]
+    spatial = tuple(x.shape[2:-1])
+    N = 1
+    for d in spatial:
+        N *= d
+    if out is None:
+        out = torch.empty((B, T, F) + spatial, dtype=torch.float32, device=x.device)
+    L.call("p4c_unnormalize_planes", L.ptr(x), L.ptr(std.to(x).contiguous()), L.ptr(mean.to(x).contiguous()), L.ptr(out), B * T, N, F,
+           L.stream(x.device))
+    return out
+
+
 def acc_sums(pred: torch.Tensor, target: torch.Tensor, spec: "MaskSpec", climate_means: torch.Tensor) -> torch.Tensor:
     """Spatial means of (p-c)(t-c)m, ((p-c)m)^2, ((t-c)m)^2 -> (3,B,T,F) (MetricACC.update, metrics.py:414-423)."""
     L.require_cuda(pred, target)

@@ -189,3 +189,67 @@ def test_titan_npy_layout_to_device_batch_bit_exact(gpu_device, tmp_path):
     assert batch.inputs.tensor.shape == (B, T_in, H, W, 3) and batch.outputs.tensor.shape == (B, T - T_in, H, W, 3)
     assert torch.equal(batch.inputs.tensor.cpu(), ref[:, :T_in]) and torch.equal(batch.outputs.tensor.cpu(), ref[:, T_in:])
     assert batch.inputs.feature_names == names
+
+
+def test_output_staging_planes_bit_exact_and_overlapped(gpu_device):
+    """8f-3, second half: the un-normalised prediction leaves for the writers as feature-major planes in pinned host memory
+    (py4cast_amd.outputs.OutputStager).  Bit-exact with the reference's per-feature passes (lightning.py:1162-1169, golden vector of
+    the unmodified lines) and with what the reference's writers read (`tensor[:, :, idx].cpu().numpy()`, io/outputs.py:193-197);
+    two batches in flight do not disturb each other; ragged spatial sizes (N not a multiple of the 64-point tile)."""
+    from py4cast_amd import ops
+    from py4cast_amd.namedtensor import NamedTensor
+    from py4cast_amd.outputs import OutputStager
+
+    z = np.load(os.path.join(GOLD, "next_unnormalize.npz"))
+    x = torch.from_numpy(z["x"]).to(gpu_device)                    # (B,T,H,W,F)
+    std, mean = torch.from_numpy(z["std"]).to(gpu_device), torch.from_numpy(z["mean"]).to(gpu_device)
+    planes = ops.unnormalize_planes(x, std, mean)
+    want = np.moveaxis(z["out"], -1, 2)                             # (B,T,F,H,W)
+    assert planes.shape == want.shape and np.array_equal(planes.cpu().numpy(), want)
+
+    g = torch.Generator().manual_seed(2)
+    names = ["batch", "timestep", "lat", "lon", "features"]
+    stager = OutputStager(gpu_device)
+    batches, refs = [], []
+    for i in range(3):
+        y = torch.randn(2, 3, 33, 17, 60, generator=g)
+        s, m = torch.rand(60, generator=g) + 0.5, torch.randn(60, generator=g)
+        ref = y.clone(); ref *= s; ref += m
+        batches.append((NamedTensor(y.to(gpu_device), names, [f"f{k}" for k in range(60)]), s.to(gpu_device), m.to(gpu_device)))
+        refs.append(ref)
+    s0 = stager.submit(*batches[0])
+    s1 = stager.submit(*batches[1])                                  # two batches in flight, two slots
+    for slot, ref in ((s0, refs[0]), (s1, refs[1])):
+        staged = stager.wait(slot)
+        assert staged.planes.shape == (2, 3, 60, 33, 17)
+        for (b, t, f) in ((0, 0, 0), (1, 2, 59), (0, 1, 17)):
+            assert np.array_equal(staged.plane(b, t, f"f{f}"), ref[b, t, :, :, f].numpy())    # the writers' (lat, lon) plane
+        assert np.array_equal(staged.planes, np.moveaxis(ref.numpy(), -1, 2))
+    s2 = stager.submit(*batches[2])                                  # reuses slot 0 after its copy has completed
+    assert s2 == s0 and np.array_equal(stager.wait(s2).planes, np.moveaxis(refs[2].numpy(), -1, 2))
+    # the loop form: writers of batch i run while batch i+1 is on the device
+    seen = []
+    stager.run(range(3), lambda b, i: batches[b][0], batches[0][1], batches[0][2], lambda staged, i: seen.append((i, staged.planes[0, 0, 0, 0, 0])))
+    assert [i for i, _ in seen] == [0, 1, 2]
+
+
+def test_predict_step_stages_outputs(gpu_device):
+    """predict_step with an OutputStager attached: returns the un-normalised NamedTensor as before AND the same numbers arrive on
+    the host as planes."""
+    from helpers import make_batch, make_dataset_info, register_test_models, synthetic_case
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from py4cast_amd.outputs import OutputStager
+
+    register_test_models()
+    case = synthetic_case(seed=8, B=2, T=2, H=16, W=16, F=5, Ff=7, Fs=4, border=0)
+    info = make_dataset_info(case, 7)
+    lm = AutoRegressiveLightning({}, info, None, num_pred_steps_train=2, num_pred_steps_val_test=2, batch_size=2, model_name="TinyConvModel",
+                                 training_strategy="scaled_ar").to(gpu_device)
+    with torch.no_grad():
+        lm.model.w.normal_(0, 0.1)
+    lm.training_step(make_batch(case, gpu_device), 0)          # records the feature names (lightning.py:541-545)
+    lm.output_stager = OutputStager(gpu_device)
+    preds = lm.predict_step(make_batch(case, gpu_device), 0)
+    staged = lm.output_stager.wait(lm.staged_slot)
+    assert np.array_equal(staged.planes, np.moveaxis(preds.tensor.cpu().numpy(), -1, 2))
+    assert staged.feature_names == preds.feature_names
