@@ -41,7 +41,7 @@ class HalfUNetSettings:
     use_ghost: bool = False
     last_activation: str = "Identity"
     absolute_pos_embed: bool = False
-    autopad_enabled: bool = False
+    autopad_enabled: bool = False   # mfai's AutoPaddingModel: grids that are not a multiple of 16 are zero-padded (centred) and cropped
     # MI355X-specific
     norm: str = "batch"  # "batch" (mfai) or "group" (GroupNorm, BASELINE.json north star)
     groups: int = 8
@@ -205,6 +205,14 @@ class HalfUNetMI355X(ModelABC, nn.Module):
                 if p.data_ptr() != base + 4 * o:
                     ok = False
                     break
+        if not ok and params[0].is_cuda:
+            # somebody else (trainer.FlatDDP in sharded mode) may already have laid the parameters out flat, in this order: adopt
+            from .optim import _flat_view
+
+            adopt = _flat_view([p.data for p in params])
+            if adopt is not None and adopt.numel() == self._nparams:
+                self._flat = adopt
+                return adopt
         if not ok:  # first use, or the module was moved / a state_dict replaced storages: re-flatten
             flat = torch.empty(self._nparams, dtype=torch.float32, device=dev)
             for p, (o, n, s) in zip(params, self._param_slices):
@@ -275,9 +283,24 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         return hit
 
     # ---------------------------------------------------------------- nn.Module API
+    def padding_for(self, H: int, W: int):
+        """(top, bottom, left, right) zero padding that takes (H, W) to the next multiple of 16 (four 2x2 poolings), centred as
+        mfai's AutoPaddingModel does (extra row / column at the end); all zeros when the grid already fits."""
+        dh, dw = (-H) % 16, (-W) % 16
+        return dh // 2, dh - dh // 2, dw // 2, dw - dw // 2
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,H,W,in_channels) -> (B,H,W,out_channels)."""
         L.require_cuda(x)
+        H, W = x.shape[1], x.shape[2]
+        top, bottom, left, right = self.padding_for(H, W)
+        if top or bottom or left or right:
+            if not self._settings.autopad_enabled:
+                raise L.P4CError(f"HalfUNetMI355X: grid {H}x{W} must be a multiple of 16 in both dimensions "
+                                 "(or set autopad_enabled, config/CLI/model/halfunet.yaml:26)")
+            # pad -> plan -> crop; both are torch views / copies, differentiable (the padded border's outputs are dropped)
+            y = self.forward(torch.nn.functional.pad(x, (0, 0, left, right, top, bottom)))
+            return y[:, top: top + H, left: left + W, :]
         if x.shape[-1] == self.in_channels and self.cin_pad != self.in_channels:
             x = torch.nn.functional.pad(x, (0, self.cin_pad - self.in_channels))
         elif x.shape[-1] != self.cin_pad:
@@ -306,6 +329,8 @@ class HalfUNetMI355X(ModelABC, nn.Module):
 
         if batch.num_input_steps != 1 or batch.inputs.tensor.dim() != 5:
             return None
+        if any(self.padding_for(batch.inputs.tensor.shape[2], batch.inputs.tensor.shape[3])):
+            return None   # auto-padded grids take the generic per-step path (forward pads and crops around the plan)
         members = getattr(lm.loss, "losses", [])
         if len(members) != 1 or not isinstance(members[0][0], WeightedLoss):
             return None

@@ -70,7 +70,15 @@ class FlatAdamW(torch.optim.AdamW):
         return params, flat_p, flat_g, m, v
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step_shards(self, shards):
+        """Data-parallel sharded step (trainer.FlatDDP(sharded=True)): update only the flat ranges ``[(lo, hi), ...]`` this rank owns
+        (their gradients are the reduce-scattered means); the caller all-gathers the parameters afterwards.  Needs the flat layout."""
+        return self.step(shards=list(shards))
+
+    @torch.no_grad()
+    def step(self, closure=None, shards=None):
+        if shards is not None and len(self.param_groups) != 1:
+            raise RuntimeError("FlatAdamW.step_shards needs a single parameter group")
         if len(self.param_groups) != 1:
             return super().step(closure)
         group = self.param_groups[0]
@@ -78,6 +86,8 @@ class FlatAdamW(torch.optim.AdamW):
             return super().step(closure)
         bufs = self._flat_buffers(group)
         if bufs is None:
+            if shards is not None:
+                raise RuntimeError("FlatAdamW.step_shards: parameters and gradients must be views of flat buffers on the GPU")
             self._flat_state = None
             return super().step(closure)
         loss = None
@@ -91,8 +101,12 @@ class FlatAdamW(torch.optim.AdamW):
             return super().step(closure)
         step = int(steps.pop()) + 1
         beta1, beta2 = group["betas"]
-        L.call("p4c_adamw_step", L.ptr(flat_p), L.ptr(flat_g), L.ptr(m), L.ptr(v), flat_p.numel(), float(group["lr"]),
-               float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]), step, L.stream(flat_p.device))
+        for lo, hi in (shards if shards is not None else [(0, flat_p.numel())]):
+            hi = min(hi, flat_p.numel())   # (FlatDDP pads its buffers to a multiple of the world size: the tail is nobody's)
+            if hi > lo:
+                L.call("p4c_adamw_step", L.ptr(flat_p[lo:hi]), L.ptr(flat_g[lo:hi]), L.ptr(m[lo:hi]), L.ptr(v[lo:hi]), hi - lo,
+                       float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]), step,
+                       L.stream(flat_p.device))
         for p in params:
             self.state[p]["step"] += 1
         L.PARAM_EPOCH[0] += 1   # the kernel wrote the parameters behind autograd's back (tensor._version did not move)

@@ -22,16 +22,33 @@ import torch.distributed as dist
 
 
 class FlatDDP:
-    """Flat-bucket gradient all-reduce (mean over ranks) for one module."""
+    """Flat-bucket gradient exchange (mean over ranks) for one module.
 
-    def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None):
+    * every ``param.grad`` is a view of ONE flat fp32 buffer, so an exchange moves whole buckets, never single tensors;
+    * the collectives are issued on a COMMUNICATION stream that waits for the backward already enqueued on the compute stream;
+      the compute stream is made to wait for them only when ``wait()`` / the next kernel that needs the gradients comes, so the
+      host goes on enqueueing (the optimizer's launch, the next batch's copies) while xGMI is busy;
+    * small models (HalfUNet: 1.8 MB) exchange ONE bucket -- latency-bound, a ring per xGMI link cannot help; above
+      ``single_bucket_bytes`` the flat buffer is cut into ``bucket_bytes`` pieces issued back to back (several collectives in
+      flight keep all seven links of a GPU busy), last layers first (the order their gradients become final in the backward of
+      AR step 0 -- with BPTT nothing is final earlier, SURVEY.md 8e);
+    * ``sharded=True`` (large models, e.g. UNetR++): reduce-scatter instead of all-reduce, the optimizer steps only this rank's
+      shard of every bucket (``shards()``; ``FlatAdamW.step(shards=...)``), then ``all_gather_params`` -- the same bytes on the
+      links as an all-reduce, 1/N of the optimizer work per rank.
+    """
+
+    def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, bucket_bytes: int = 64 << 20,
+                 single_bucket_bytes: int = 16 << 20, sharded: bool = False):
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.world_size = world_size
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self.params = [p for p in module.parameters() if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        pad = (-total) % max(world_size, 1)    # shards of equal size: the flat buffers carry a few unused elements at the end
+        self.total = total
+        self.flat_grad = torch.zeros(total + pad, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
             n = p.numel()
@@ -39,16 +56,54 @@ class FlatDDP:
                 p.grad = self.flat_grad[off : off + n].view_as(p)
             off += n
         self._views_ok = all(p.dtype == torch.float32 for p in self.params)
+        self.sharded = bool(sharded) and world_size > 1
+        # buckets: [lo, hi) element ranges of the flat buffer, each a multiple of world_size long
+        n_all = total + pad
+        if n_all * 4 <= single_bucket_bytes or world_size <= 1:
+            self.buckets = [(0, n_all)]
+        else:
+            per = max(world_size, (bucket_bytes // 4) // max(world_size, 1) * max(world_size, 1))
+            self.buckets = [(lo, min(lo + per, n_all)) for lo in range(0, n_all, per)]
+        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._inflight = False
+        self.flat_param = None
+        if self.sharded:
+            self._flatten_parameters(pad)
         if world_size > 1:
             self.broadcast_parameters()
 
+    # ------------------------------------------------------------------ layout
+    def _flatten_parameters(self, pad: int):
+        """parameters as views of one flat buffer too (what all_gather_params moves); models that already keep their
+        parameters flat (HalfUNetMI355X) are left alone when the layout matches."""
+        flat = torch.zeros(self.total + pad, dtype=torch.float32, device=self.flat_grad.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            flat[off : off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off : off + n].view_as(p)
+            off += n
+        self.flat_param = flat
+
+    def shards(self):
+        """This rank's [lo, hi) ranges, one per bucket (equal split of every bucket)."""
+        out = []
+        for lo, hi in self.buckets:
+            n = (hi - lo) // self.world_size
+            out.append((lo + self.rank * n, lo + (self.rank + 1) * n))
+        return out
+
     def broadcast_parameters(self, src: int = 0):
         """Same initial weights on every rank (DDP's constructor does the same)."""
+        if self.flat_param is not None:
+            dist.broadcast(self.flat_param, src)
+            return
         for p in self.params:
             dist.broadcast(p.data, src)
 
     def zero_grad(self):
         """One fill over the flat buffer instead of one per parameter (``optimizer.zero_grad(set_to_none=False)``)."""
+        self.wait()
         if self._views_ok and self._grads_are_views():
             self.flat_grad.zero_()
         else:
@@ -67,15 +122,71 @@ class FlatDDP:
             off += p.numel()
         return True
 
-    def all_reduce_grads(self):
+    # ------------------------------------------------------------------ exchange
+    def _on_comm_stream(self, fn):
+        """Run the collectives of ``fn`` on the communication stream, ordered after everything enqueued on the compute stream."""
+        if self.comm_stream is None:
+            fn()
+            return
+        self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
+        with torch.cuda.stream(self.comm_stream):
+            fn()
+        self._inflight = True
+
+    def wait(self):
+        """Make the compute stream wait for the exchange in flight (no host synchronisation)."""
+        if self._inflight and self.comm_stream is not None:
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self.comm_stream)
+        self._inflight = False
+
+    def all_reduce_grads(self, wait: bool = True):
+        """Mean of the gradients over the ranks.  ``sharded``: only this rank's shards are complete afterwards (``shards()``)."""
         if self.world_size <= 1:
             return
         if not self._views_ok or not self._grads_are_views():
             self._regather()
-        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-        self.flat_grad.div_(self.world_size)
+        inv = 1.0 / self.world_size
+
+        def exchange():
+            for lo, hi in reversed(self.buckets):       # last layers first
+                piece = self.flat_grad[lo:hi]
+                if self.sharded:
+                    n = (hi - lo) // self.world_size
+                    mine = piece[self.rank * n : (self.rank + 1) * n]
+                    try:
+                        dist.reduce_scatter_tensor(mine, piece, op=dist.ReduceOp.SUM)
+                    except (RuntimeError, NotImplementedError):   # gloo (CPU tests) has no reduce-scatter: same result
+                        dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                    mine.mul_(inv)
+                else:
+                    dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                    piece.mul_(inv)
+
+        self._on_comm_stream(exchange)
+        if wait:
+            self.wait()
         if not self._views_ok:
+            self.wait()
             self._scatter()
+
+    def all_gather_params(self, wait: bool = True):
+        """After a sharded optimizer step: every rank receives the other ranks' updated shards."""
+        if not self.sharded:
+            return
+
+        def gather():
+            for lo, hi in self.buckets:
+                piece = self.flat_param[lo:hi]
+                n = (hi - lo) // self.world_size
+                mine = piece[self.rank * n : (self.rank + 1) * n].clone()
+                try:
+                    dist.all_gather_into_tensor(piece, mine)
+                except (RuntimeError, NotImplementedError):   # backends without the flat form
+                    dist.all_gather([piece[r * n : (r + 1) * n] for r in range(self.world_size)], mine)
+
+        self._on_comm_stream(gather)
+        if wait:
+            self.wait()
 
     # slow path: a grad tensor was replaced (e.g. zero_grad(set_to_none=True)); copy in / re-attach
     def _regather(self):
@@ -260,7 +371,11 @@ class Trainer:
                 if pending == self.accumulate_grad_batches or last_of_epoch:
                     pending = 0
                     ddp.all_reduce_grads()
-                    opt.step()
+                    if ddp.sharded and hasattr(opt, "step_shards"):
+                        opt.step_shards(ddp.shards())
+                        ddp.all_gather_params()
+                    else:
+                        opt.step()
                     if sched is not None:
                         sched.step()
                     ddp.zero_grad()

@@ -73,3 +73,61 @@ def test_rank_zero_setup_is_visible_to_all_ranks_gloo(tmp_path):
     port = 30500 + (os.getpid() % 1000)
     mp.spawn(_graph_worker, args=(world, port, str(tmp_path), ret), nprocs=world, join=True)
     assert ret[0] == ret[1] and ret[0][0] == 81
+
+
+def _bucket_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from py4cast_amd.trainer import FlatDDP
+
+    def make():
+        torch.manual_seed(11)
+        return torch.nn.Sequential(torch.nn.Linear(37, 101), torch.nn.Tanh(), torch.nn.Linear(101, 53), torch.nn.Tanh(), torch.nn.Linear(53, 3))
+
+    out = {}
+    torch.manual_seed(50 + rank)
+    x, y = torch.randn(9, 37), torch.randn(9, 3)
+    for tag, kw in (("single", {}), ("buckets", dict(bucket_bytes=4096, single_bucket_bytes=1024)),
+                    ("sharded", dict(bucket_bytes=4096, single_bucket_bytes=1024, sharded=True))):
+        net = make()
+        ddp = FlatDDP(net, world, **kw)
+        ((net(x) - y) ** 2).mean().backward()
+        ddp.all_reduce_grads()
+        g = ddp.flat_grad[: ddp.total].clone()
+        own = torch.zeros(ddp.flat_grad.numel(), dtype=torch.bool)
+        for lo, hi in ddp.shards():
+            own[lo:hi] = True
+        if tag == "sharded":   # a plain SGD step on the owned shards, then the all-gather makes the parameters whole again
+            with torch.no_grad():
+                for lo, hi in ddp.shards():
+                    ddp.flat_param[lo:hi] -= 0.1 * ddp.flat_grad[lo:hi]
+            ddp.all_gather_params()
+        out[tag] = (g, own[: ddp.total].clone(), len(ddp.buckets), torch.cat([p.detach().reshape(-1) for p in net.parameters()]))
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_bucketed_and_sharded_exchange_gloo():
+    """FlatDDP with several buckets == one bucket; sharded (reduce-scatter, step on the owned shards, all-gather) leaves every rank
+    with the parameters a full all-reduce + full step gives."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 1000)
+    mp.spawn(_bucket_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert a["single"][2] == 1 and a["buckets"][2] > 3 and a["sharded"][2] > 3
+    torch.testing.assert_close(a["single"][0], b["single"][0])
+    torch.testing.assert_close(a["buckets"][0], a["single"][0])           # bucketing changes nothing
+    for r in (a, b):                                                       # the owned shards hold the mean; the two ranks' shards tile the buffer
+        own = r["sharded"][1]
+        torch.testing.assert_close(r["sharded"][0][own], a["single"][0][own])
+    assert bool((a["sharded"][1] ^ b["sharded"][1]).all())
+    # parameters after the sharded SGD step + all-gather == initial - 0.1 * mean gradient, on both ranks
+    torch.manual_seed(11)
+    init = torch.cat([p.detach().reshape(-1) for p in torch.nn.Sequential(torch.nn.Linear(37, 101), torch.nn.Tanh(), torch.nn.Linear(101, 53),
+                                                                         torch.nn.Tanh(), torch.nn.Linear(53, 3)).parameters()])
+    torch.testing.assert_close(a["sharded"][3], init - 0.1 * a["single"][0])
+    torch.testing.assert_close(b["sharded"][3], a["sharded"][3])

@@ -37,3 +37,50 @@ def test_flat_bucket_exchange_over_rccl_single_rank():
         assert float(t.item()) == 1.5
     finally:
         dist.destroy_process_group()
+
+
+def _run(cmd, timeout=600):
+    import subprocess
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs of one node (the driver's multi-GPU box)")
+@pytest.mark.parametrize("sharded", [False, True])
+def test_two_ranks_train_like_one_process_with_the_global_batch(tmp_path, sharded):
+    """Two ranks over RCCL (2 samples each) == one process with the 4 samples: identical parameters on both ranks after three
+    optimizer steps, equal to the single-process run's, and the same loss sequence (GroupNorm: statistics are per sample, so data
+    parallelism changes nothing but the reduction order).  Both exchanges: one all-reduce, and reduce-scatter + sharded AdamW +
+    all-gather."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "dist_check.py")
+    extra = ["sharded"] if sharded else []
+    one = _run([sys.executable, script, str(tmp_path)] + extra)
+    assert one.returncode == 0, one.stderr[-2000:]
+    port = 32500 + os.getpid() % 1000
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), script, str(tmp_path)] + extra)
+    assert two.returncode == 0, two.stderr[-2000:]
+    r0, r1 = torch.load(tmp_path / "rank0_w2.pt"), torch.load(tmp_path / "rank1_w2.pt")
+    ref = torch.load(tmp_path / "rank0_w1.pt")
+    assert torch.equal(r0["params"], r1["params"])
+    torch.testing.assert_close(r0["params"], ref["params"], rtol=2e-3, atol=2e-5)
+    torch.testing.assert_close(torch.tensor(r0["losses"]), torch.tensor(ref["losses"]), rtol=1e-4, atol=0)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs of one node (the driver's multi-GPU box)")
+def test_bench_runs_on_two_gpus():
+    """`python bench.py --gpus 2` (the driver's launch form is the torch.distributed.run line bench.py builds itself): one JSON line
+    from rank 0 with n_gpus == 2 and the whole-job aggregate."""
+    import json
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], 900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak" and out["value"] > 0

@@ -420,3 +420,45 @@ def test_fused_statistics_passes_equal_the_separate_launches(gpu_device, norm, s
     if norm == "batch":
         for n in grads["0"]:
             assert rel_err(grads["0"][n], grads["1"][n]) < (2e-5 if "norm" in n else 1e-6), n
+
+
+# ------------------------------------------------------------------------------------------------ autopad (halfunet.yaml:26)
+def test_halfunet_autopad_matches_padded_oracle_and_trains_on_500x500(gpu_device):
+    """`autopad_enabled: True` as shipped in config/CLI/model/halfunet.yaml: a grid that is not a multiple of 16 is zero-padded
+    (centred), run, and cropped.  fp32 flavour vs the float64 oracle on the padded input (<= 1e-4 forward), gradients through the
+    pad / crop; then one AR training step on a 500 x 500 grid (the Titan-like non-multiple size) through the generic rollout."""
+    import torch.nn.functional as Fn
+
+    from oracle.halfunet import HalfUNetRef
+    from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    H, W, cin, cout = 50, 70, 21, 12
+    torch.manual_seed(6)
+    model = HalfUNetMI355X(cin, cout, (H, W), HalfUNetSettings(autopad_enabled=True))
+    ref = HalfUNetRef(cin, cout).double()
+    ref.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+    model = model.to(gpu_device).train()
+    assert model.padding_for(H, W) == (7, 7, 5, 5) and model.padding_for(64, 80) == (0, 0, 0, 0) and model.padding_for(50, 71) == (7, 7, 4, 5)
+    x = torch.randn(2, H, W, cin, generator=torch.Generator().manual_seed(7))
+    gy = torch.randn(2, H, W, cout, generator=torch.Generator().manual_seed(8))
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = model(xg)
+    y.backward(gy.to(gpu_device))
+    assert y.shape == (2, H, W, cout)
+    xr = x.double().requires_grad_(True)
+    ref.train()
+    yr = ref(Fn.pad(xr.permute(0, 3, 1, 2), (5, 5, 7, 7)))[:, :, 7:7 + H, 5:5 + W].permute(0, 2, 3, 1)
+    yr.backward(gy.double())
+    assert rel_err(y, yr) < 1e-4
+    assert rel_err(xg.grad, xr.grad) < 5e-3
+    with pytest.raises(Exception):
+        HalfUNetMI355X(cin, cout, (H, W), HalfUNetSettings(autopad_enabled=False)).to(gpu_device)(x.to(gpu_device))
+    # 500 x 500, bf16, 2-step rollout + loss + backward (generic path: the model pads and crops around its plan)
+    case = synthetic_case(seed=12, B=1, T=2, H=500, W=500, F=12, Ff=5, Fs=4, border=0)
+    info = make_dataset_info(case, 5)
+    lm = AutoRegressiveLightning({"autopad_enabled": True, "compute_dtype": "bf16", "activation_dtype": "bf16"}, info, None,
+                                 num_pred_steps_train=2, batch_size=1, model_name="HalfUNet", losses=MSE, training_strategy="scaled_ar").to(gpu_device)
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(p.grad).all()) for p in lm.model.parameters())
