@@ -191,7 +191,12 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     // BatchNorm statistics of a ring-kernel convolution are finished by the kernel itself (its last workgroup): no norm_finalize launch
     const char* ie = getenv("P4C_NO_INKERNEL_FINALIZE");
     const bool no_infin = ie && ie[0] == '1';
-    const bool infin = batch_stats && d.norm == 0 && d.compute == P4C_BF16 && !no_infin &&
+    // (below the full resolution only: there the in-kernel tail -- slot store, ticket, the last workgroup's 128 KB read -- costs
+    // ~5 us against ~8 for the launch it replaces and stretches the roofline kernel's launches by that much; on the coarse levels
+    // every launch is latency and one fewer is a clean gain.  P4C_INKERNEL_FINALIZE_ALL=1 turns it on everywhere.)
+    const char* ia = getenv("P4C_INKERNEL_FINALIZE_ALL");
+    const bool all_levels = ia && ia[0] == '1';
+    const bool infin = batch_stats && d.norm == 0 && d.compute == P4C_BF16 && !no_infin && (all_levels || lev > 0) &&
                        conv_bf16_is_ring(d.dtype, conv_cin_pad(d, i), 3, 1, NF, d.B, H, W);
     BatchFin fin{};
     if (infin) {
