@@ -485,6 +485,24 @@ typedef struct p4c_row_mlp_grad_sinks {
 } p4c_row_mlp_grad_sinks;
 int p4c_row_mlp_bwd_accumulate(const p4c_row_mlp_desc* d, const p4c_row_mlp_grad_sinks* sinks, void* workspace, p4c_stream_t stream);
 
+/* ====================================================================================
+ * Tall-skinny products of the efficient paired attention (EPA) of UNETR++ (config/CLI/model/unetrpp.yaml:19-35; the class
+ * comes from mfai v5.0.1, py4cast/models.py:10-20).  Per group g = (sample b, head h) a token matrix X[g] is N x d with
+ * element (n, i) at x + b*x_bs + h*x_hs + n*x_rs + i (strides in elements): operands are addressed in place inside the
+ * qkvv projection's (B, N, 4, heads, d) output or a (B, N, C) token tensor, outputs likewise.  d, e <= 64.
+ * ==================================================================================== */
+/* gram: partial[g][split] (d x e, fp32) = sum over the split's tokens of X[g][n,:]^T Y[g][n,:]; the caller sums the
+ * p4c_ts_gram_splits(N) partials (fixed order).  A shared operand (the E / F projection weights) has bs = hs = 0.
+ * d, e multiples of 4. */
+int p4c_ts_gram_splits(int64_t N);
+int p4c_ts_gram(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const void* y, int y_dtype, int64_t y_bs,
+                int64_t y_hs, int64_t y_rs, float* partial, int B, int heads, int64_t N, int d, int e, p4c_stream_t stream);
+/* apply: out[g] (N x e) = X[g] (N x d) M[g] (d x e, fp32, group stride m_gs elements; 0 = one matrix for all groups)
+ * (+ out when accumulate).  The adjoint of gram: the backward of either is the other. */
+int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, void* out,
+                 int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int accumulate,
+                 p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,162 @@
+"""
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED (mfai v5.0.1 is absent from the reference checkout).
+
+Torch-native restatement of the 2-D UNETR++ selected by ``model_name: UNetRPP`` (config/CLI/model/unetrpp.yaml:19-35: hidden_size
+1024, heads 16 / 4, depths [3,3,3,3], encoder_proj_sizes [64,64,64,32], decoder_proj_size 64, downsampling_rate 4, linear
+up-sampling, instance norm), following the published architecture (Shaker et al. 2022, "UNETR++: Delving into Efficient and
+Accurate 3D Medical Image Segmentation", and its MONAI-style building blocks) in two spatial dimensions as mfai wraps it:
+
+  encoder : stem conv (k = s = downsampling_rate) + GroupNorm, then per stage `depth` transformer blocks, 2x2/s2 conv + GroupNorm
+            between stages; channel widths hidden/8, /4, /2, /1.
+  block   : x + pos_embed;  x + gamma * EPA(LayerNorm(x));  then a residual 3x3 conv block (batch norm) and a 1x1 conv, skip added.
+  EPA     : one qkvv projection (4C), heads split; q and k L2-normalised ALONG THE TOKENS; channel attention
+            softmax(q^T k * t1) (d x d per head) applied to v_CA; spatial attention softmax(q (E k) * t2) over the p projected
+            tokens applied to (F v_SA), E and F sharing one Linear over the token axis; the two halves projected to C/2 each
+            and concatenated.  The matrices are formed literally here (transposes, F.normalize, matmul), which is the
+            independent formulation the product's tall-skinny kernels are checked against.
+  decoder : up-sampling (bilinear + 1x1 conv, or transposed conv) + skip + `depth` transformer blocks; the last stage is a
+            residual conv block at full resolution fed by a full-resolution residual conv block of the input; 1x1 output conv.
+
+Tensors are NCHW inside; ``forward`` takes and returns features-last (B,H,W,C) like the product (the rollout's layout).
+Parameter names equal py4cast_amd.unetrpp.UNetRPPMI355X's (one state_dict).
+"""
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def _norm(name, ch):
+    if name == "instance":
+        return nn.InstanceNorm2d(ch, affine=True)
+    if name == "batch":
+        return nn.BatchNorm2d(ch)
+    raise ValueError(name)
+
+
+class ResBlock(nn.Module):
+    """MONAI's UnetResBlock: conv-norm-lrelu-conv-norm, residual (1x1 conv + norm when the width changes), lrelu."""
+
+    def __init__(self, cin, cout, norm):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1, bias=False)
+        self.norm1, self.norm2 = _norm(norm, cout), _norm(norm, cout)
+        self.down = cin != cout
+        if self.down:
+            self.conv3 = nn.Conv2d(cin, cout, 1, bias=False)
+            self.norm3 = _norm(norm, cout)
+
+    def forward(self, x):
+        r = x
+        y = F.leaky_relu(self.norm1(self.conv1(x)), 0.01)
+        y = self.norm2(self.conv2(y))
+        if self.down:
+            r = self.norm3(self.conv3(r))
+        return F.leaky_relu(y + r, 0.01)
+
+
+class EPA(nn.Module):
+    def __init__(self, tokens, hidden, proj, heads):
+        super().__init__()
+        self.heads = heads
+        self.temperature = nn.Parameter(torch.ones(heads, 1, 1))
+        self.temperature2 = nn.Parameter(torch.ones(heads, 1, 1))
+        self.qkvv = nn.Linear(hidden, hidden * 4, bias=False)
+        self.E = nn.Linear(tokens, proj)          # E and F share these weights
+        self.out_proj = nn.Linear(hidden, hidden // 2)
+        self.out_proj2 = nn.Linear(hidden, hidden // 2)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkvv = self.qkvv(x).reshape(B, N, 4, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        q, k, v_ca, v_sa = (t.transpose(-2, -1) for t in (qkvv[0], qkvv[1], qkvv[2], qkvv[3]))   # (B,h,d,N)
+        k_proj = self.E(k)                      # (B,h,d,p)
+        v_sa_proj = self.E(v_sa)
+        q = F.normalize(q, dim=-1)
+        k = F.normalize(k, dim=-1)
+        attn_ca = ((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1)                  # (B,h,d,d)
+        x_ca = (attn_ca @ v_ca).permute(0, 3, 1, 2).reshape(B, N, C)
+        attn_sa = ((q.permute(0, 1, 3, 2) @ k_proj) * self.temperature2).softmax(dim=-1)          # (B,h,N,p)
+        x_sa = (attn_sa @ v_sa_proj.transpose(-2, -1)).permute(0, 2, 1, 3).reshape(B, N, C)       # token-major, heads side by side
+        return torch.cat([self.out_proj(x_sa), self.out_proj2(x_ca)], dim=-1)
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, tokens, hidden, proj, heads):
+        super().__init__()
+        self.norm = nn.LayerNorm(hidden)
+        self.gamma = nn.Parameter(1e-6 * torch.ones(hidden))
+        self.epa_block = EPA(tokens, hidden, proj, heads)
+        self.conv51 = ResBlock(hidden, hidden, "batch")
+        self.conv8 = nn.Conv2d(hidden, hidden, 1)
+        self.pos_embed = nn.Parameter(torch.zeros(1, tokens, hidden))
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        t = x.reshape(B, C, H * W).permute(0, 2, 1) + self.pos_embed
+        t = t + self.gamma * self.epa_block(self.norm(t))
+        skip = t.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return skip + self.conv8(self.conv51(skip))
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cout, scale, tokens, proj, heads, depth, conv_decoder, linear, norm):
+        super().__init__()
+        self.scale, self.linear = scale, linear
+        if linear:
+            self.up_conv = nn.Conv2d(cin, cout, 1)
+        else:
+            self.up_conv = nn.ConvTranspose2d(cin, cout, scale, stride=scale, bias=False)
+        if conv_decoder:
+            self.decoder_block = nn.ModuleList([ResBlock(cout, cout, norm)])
+        else:
+            self.decoder_block = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens, cout, proj, heads) for _ in range(depth)])])
+
+    def forward(self, x, skip):
+        if self.linear:
+            x = self.up_conv(F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=False))
+        else:
+            x = self.up_conv(x)
+        return self.decoder_block[0](x + skip)
+
+
+class UNetRPP(nn.Module):
+    def __init__(self, in_channels, out_channels, input_shape, hidden_size=1024, num_heads_encoder=16, num_heads_decoder=4,
+                 depths=(3, 3, 3, 3), downsampling_rate=4, decoder_proj_size=64, encoder_proj_sizes=(64, 64, 64, 32),
+                 linear_upsampling=True, norm_name="instance"):
+        super().__init__()
+        H, W = input_shape
+        r = downsampling_rate
+        fs = hidden_size // 16
+        dims = [fs * 2, fs * 4, fs * 8, fs * 16]
+        sizes = [(H // (r * 2**i), W // (r * 2**i)) for i in range(4)]
+        tokens = [h * w for h, w in sizes]
+        self.sizes, self.hidden = sizes, hidden_size
+        self.downsample_layers = nn.ModuleList()
+        self.downsample_layers.append(nn.Sequential(nn.Conv2d(in_channels, dims[0], r, stride=r, bias=False), nn.GroupNorm(in_channels, dims[0])
+                                                    if dims[0] % in_channels == 0 else nn.GroupNorm(1, dims[0])))
+        for i in range(3):
+            self.downsample_layers.append(nn.Sequential(nn.Conv2d(dims[i], dims[i + 1], 2, stride=2, bias=False), nn.GroupNorm(dims[i], dims[i + 1])))
+        self.stages = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens[i], dims[i], encoder_proj_sizes[i], num_heads_encoder)
+                                                     for _ in range(depths[i])]) for i in range(4)])
+        self.encoder1 = ResBlock(in_channels, fs, norm_name)
+        self.decoder5 = UpBlock(dims[3], dims[2], 2, tokens[2], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name)
+        self.decoder4 = UpBlock(dims[2], dims[1], 2, tokens[1], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name)
+        self.decoder3 = UpBlock(dims[1], dims[0], 2, tokens[0], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name)
+        self.decoder2 = UpBlock(dims[0], fs, r, H * W, decoder_proj_size, num_heads_decoder, 3, True, linear_upsampling, norm_name)
+        self.out1 = nn.Conv2d(fs, out_channels, 1)
+
+    def forward(self, x):
+        x = x.permute(0, 3, 1, 2)
+        hidden = []
+        h = x
+        for i in range(4):
+            h = self.stages[i](self.downsample_layers[i](h))
+            hidden.append(h)
+        conv_block = self.encoder1(x)
+        dec3 = self.decoder5(hidden[3], hidden[2])
+        dec2 = self.decoder4(dec3, hidden[1])
+        dec1 = self.decoder3(dec2, hidden[0])
+        out = self.decoder2(dec1, conv_block)
+        return self.out1(out).permute(0, 2, 3, 1)

@@ -1,0 +1,79 @@
+"""Autograd wrappers of the tall-skinny products (include/py4cast_hip.h: p4c_ts_gram / p4c_ts_apply) -- the two kernels the efficient
+paired attention of UNETR++ is made of, forward and backward (each is the other's adjoint).  Token matrices are (B, heads, N, d)
+VIEWS with unit stride in the last dimension and arbitrary strides elsewhere (slices of the qkvv projection, permuted views of
+(B, N, C) tensors): they are addressed in place, nothing is made contiguous.  No CPU fallback."""
+
+import torch
+
+from . import _lib as L
+
+
+def _strides(t: torch.Tensor):
+    if t.dim() != 4 or (t.shape[-1] > 1 and t.stride(3) != 1):
+        raise L.P4CError("tall-skinny ops take (B, heads, N, d) views with unit stride in the last dimension")
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def _gram_raw(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    B, H, N, d = x.shape
+    e = y.shape[-1]
+    ns = L.lib().p4c_ts_gram_splits(N)
+    part = torch.empty(B * H, ns, d, e, dtype=torch.float32, device=x.device)
+    xs, ys = _strides(x), _strides(y)
+    L.call("p4c_ts_gram", L.ptr(x), L.dtype_code(x.dtype), *xs, L.ptr(y), L.dtype_code(y.dtype), *ys, L.ptr(part), B, H, N, d, e,
+           L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * y.element_size()))
+    return (part.sum(dim=1) if ns > 1 else part[:, 0]).view(B, H, d, e)
+
+
+def _apply_raw(x: torch.Tensor, m: torch.Tensor, dtype) -> torch.Tensor:
+    """x (B,H,N,d) @ m (B,H,d,e) fp32 -> (B,H,N,e) view of a fresh (B,N,H,e) tensor (i.e. laid out as (B, N, H*e) tokens)."""
+    B, H, N, d = x.shape
+    e = m.shape[-1]
+    out = torch.empty(B, N, H, e, dtype=dtype, device=x.device)
+    ov = out.permute(0, 2, 1, 3)
+    m = m.float().contiguous()
+    L.call("p4c_ts_apply", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(m), d * e, L.ptr(out), L.dtype_code(dtype), *_strides(ov),
+           B, H, N, d, e, 0, L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * out.element_size()))
+    return ov
+
+
+class _Gram(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        L.require_cuda(x, y)
+        ctx.save_for_backward(x, y)
+        return _gram_raw(x, y)
+
+    @staticmethod
+    def backward(ctx, dc):
+        x, y = ctx.saved_tensors
+        dx = _apply_raw(y, dc.transpose(-1, -2), x.dtype) if ctx.needs_input_grad[0] else None    # dX = Y dC^T
+        dy = _apply_raw(x, dc, y.dtype) if ctx.needs_input_grad[1] else None                      # dY = X dC
+        return dx, dy
+
+
+class _Apply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m, out_dtype):
+        L.require_cuda(x, m)
+        ctx.save_for_backward(x, m)
+        return _apply_raw(x, m, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, m = ctx.saved_tensors
+        if dout.stride(3) != 1:
+            dout = dout.contiguous()
+        dx = _apply_raw(dout, m.transpose(-1, -2), x.dtype) if ctx.needs_input_grad[0] else None  # dX = dO M^T
+        dm = _gram_raw(x, dout).to(m.dtype) if ctx.needs_input_grad[1] else None                  # dM = X^T dO
+        return dx, dm, None
+
+
+def gram(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """(B,H,N,d), (B,H,N,e) -> X^T Y (B,H,d,e) fp32: the reduction over the tokens (d, e multiples of 4, <= 64)."""
+    return _Gram.apply(x, y)
+
+
+def apply(x: torch.Tensor, m: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    """(B,H,N,d) @ (B,H,d,e) -> (B,H,N,e), stored token-major ((B,N,H,e) memory): ``.permute(0,2,1,3).reshape(B,N,H*e)`` is a view."""
+    return _Apply.apply(x, m, out_dtype or x.dtype)

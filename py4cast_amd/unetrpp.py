@@ -1,0 +1,255 @@
+"""
+UNETR++ on MI355X -- the model behind ``model_name: UNetRPP`` (config/CLI/model/unetrpp.yaml:19-35; BASELINE.json configuration 5).
+The reference takes the class from mfai v5.0.1 (py4cast/models.py:10-20), which is absent here: PARITY UNPINNED; the architecture is
+restated from the published one (oracle/unetrpp.py spells out every block) and the arithmetic is checked against that oracle, whose
+attention forms the matrices literally.
+
+What runs where
+* efficient paired attention (EPA), forward and backward: the tall-skinny HIP kernels of csrc/tallskinny.hip through
+  py4cast_amd.ops_ts -- ``gram`` (q^T k, q^T q, k^T k: reductions over the 16 384 ... 256 tokens of a stage) and ``apply``
+  (v A^T, q M, S VP^T: per-token small products), addressed in place inside the qkvv projection's output (no head split /
+  transpose / contiguous copies; the literal formulation makes eight of them per block).  The d x d and d x p matrices in between
+  (normalisation, temperature, softmax) are a few KB per head: torch.
+* LayerNorm of every block: csrc/rows.hip (row LayerNorm).
+* the token-axis projection E = F (a Linear over N), the qkvv / output projections: library GEMMs.
+* convolutions (stem, 2x2 down-sampling, the residual 3x3 blocks, 1x1) and their group / batch / instance norms: torch
+  (MIOpen) -- not yet on native kernels, like the SwinUNetR decoder.
+Input / output are features-last (B, H, W, C); H and W must be multiples of 8 * downsampling_rate.  ``attention_code``
+("torch" | "flash" | "manual" in mfai) is accepted and ignored: all of them are this one fused formulation.
+"""
+
+from dataclasses import dataclass
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib as L
+from . import ops_rows as R
+from . import ops_ts as TS
+from .base import ModelABC, ModelType
+
+try:
+    from dataclasses_json import dataclass_json
+except Exception:  # pragma: no cover
+    def dataclass_json(cls):
+        return cls
+
+
+@dataclass_json
+@dataclass(slots=True)
+class UNetRPPSettings:
+    hidden_size: int = 256
+    num_heads_encoder: int = 4
+    num_heads_decoder: int = 4
+    pos_embed: str = "perceptron"
+    norm_name: str = "instance"
+    dropout_rate: float = 0.0
+    depths: Tuple[int, ...] = (3, 3, 3, 3)
+    conv_op: str = "Conv2d"
+    do_ds: bool = False
+    spatial_dims: int = 2
+    linear_upsampling: bool = False
+    downsampling_rate: int = 4
+    decoder_proj_size: int = 64
+    encoder_proj_sizes: Tuple[int, ...] = (64, 64, 64, 32)
+    add_skip_connections: bool = True
+    attention_code: str = "torch"
+    activation_dtype: str = "f32"   # "bf16": token tensors and convolutions in bf16 (trainer.precision bf16)
+
+
+def _norm(name, ch):
+    if name == "instance":
+        return nn.InstanceNorm2d(ch, affine=True)
+    if name == "batch":
+        return nn.BatchNorm2d(ch)
+    raise NotImplementedError(f"UNetRPP: norm_name={name}")
+
+
+def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    return F.linear(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
+
+
+def _conv(m, x):
+    return m._conv_forward(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
+
+
+def _nrm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """group / batch / instance norm with fp32 parameters and statistics on a tensor of the activation dtype"""
+    return m(x) if x.dtype == torch.float32 else m(x.float()).to(x.dtype)
+
+
+def _layer_norm(m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    C = x.shape[-1]
+    L.require_cuda(x)
+    if (C * x.element_size()) % 16 == 0 and C * x.element_size() <= 1024:
+        return R.row_layer_norm(x.reshape(-1, C), m.weight, m.bias, m.eps).view(x.shape)
+    return F.layer_norm(x.float(), m.normalized_shape, m.weight, m.bias, m.eps).to(x.dtype)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, cin, cout, norm):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1, bias=False)
+        self.norm1, self.norm2 = _norm(norm, cout), _norm(norm, cout)
+        self.down = cin != cout
+        if self.down:
+            self.conv3 = nn.Conv2d(cin, cout, 1, bias=False)
+            self.norm3 = _norm(norm, cout)
+
+    def forward(self, x):
+        r = x
+        y = F.leaky_relu(_nrm(self.norm1, _conv(self.conv1, x)), 0.01)
+        y = _nrm(self.norm2, _conv(self.conv2, y))
+        if self.down:
+            r = _nrm(self.norm3, _conv(self.conv3, r))
+        return F.leaky_relu(y + r, 0.01)
+
+
+class EPA(nn.Module):
+    """Efficient paired attention on the tall-skinny kernels.  With q, k, v_ca, v_sa the (N x d) token matrices of a head:
+        G = q^T k,  nq = ||q columns||,  nk likewise          (gram: three reductions over the tokens)
+        A = softmax(t1 * G / (nq nk^T))                        (d x d, torch)
+        x_ca = v_ca A^T                                        (apply)
+        KP = E(k^T), VP = E(v_sa^T)                            (d x p, the token-axis Linear: library GEMM)
+        S = softmax(t2 * q (KP / nq))                          (apply -> N x p, row softmax)
+        x_sa = S VP^T                                          (apply)
+    Normalising q along the tokens scales COLUMN i of q by 1 / nq_i, which is folded into the small matrices (rows of KP, the
+    outer product under G): the N x d normalised copies of q and k are never formed."""
+
+    def __init__(self, tokens, hidden, proj, heads):
+        super().__init__()
+        self.heads = heads
+        self.temperature = nn.Parameter(torch.ones(heads, 1, 1))
+        self.temperature2 = nn.Parameter(torch.ones(heads, 1, 1))
+        self.qkvv = nn.Linear(hidden, hidden * 4, bias=False)
+        self.E = nn.Linear(tokens, proj)
+        self.out_proj = nn.Linear(hidden, hidden // 2)
+        self.out_proj2 = nn.Linear(hidden, hidden // 2)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        h, d = self.heads, C // self.heads
+        qkvv = _linear(self.qkvv, x).view(B, N, 4, h, d)
+        q, k, v_ca, v_sa = (qkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))          # (B,h,N,d) views, nothing copied
+        if d % 4:
+            raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")
+        eps = 1e-12                                                                        # F.normalize's clamp
+        G = TS.gram(q, k)
+        nq = torch.diagonal(TS.gram(q, q), dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(eps)    # (B,h,d)
+        nk = torch.diagonal(TS.gram(k, k), dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(eps)
+        A = (G / (nq.unsqueeze(-1) * nk.unsqueeze(-2)) * self.temperature).softmax(dim=-1)
+        x_ca = TS.apply(v_ca, A.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
+        # token-axis projection (shared weights): (B, C, N) @ (N, p) for k and v_sa at once -- a library GEMM
+        W, bias = self.E.weight.to(x.dtype), self.E.bias.float()
+        kv = torch.stack([qkvv[:, :, 1].reshape(B, N, C), qkvv[:, :, 3].reshape(B, N, C)], dim=1)   # (B,2,N,C)
+        proj = (kv.transpose(-1, -2) @ W.t()).float() + bias                                         # (B,2,C,p)
+        KP, VP = proj[:, 0].view(B, h, d, -1), proj[:, 1].view(B, h, d, -1)
+        Mq = KP / nq.unsqueeze(-1) * self.temperature2
+        S = TS.apply(q, Mq).softmax(dim=-1)                                                          # (B,h,N,p), token-major memory
+        x_sa = TS.apply(S, VP.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
+        return torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, tokens, hidden, proj, heads):
+        super().__init__()
+        self.norm = nn.LayerNorm(hidden)
+        self.gamma = nn.Parameter(1e-6 * torch.ones(hidden))
+        self.epa_block = EPA(tokens, hidden, proj, heads)
+        self.conv51 = ResBlock(hidden, hidden, "batch")
+        self.conv8 = nn.Conv2d(hidden, hidden, 1)
+        self.pos_embed = nn.Parameter(torch.zeros(1, tokens, hidden))
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        t = x.reshape(B, C, H * W).permute(0, 2, 1) + self.pos_embed.to(x.dtype)
+        t = t + self.gamma.to(x.dtype) * self.epa_block(_layer_norm(self.norm, t.contiguous()))
+        skip = t.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        return skip + _conv(self.conv8, self.conv51(skip))
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cout, scale, tokens, proj, heads, depth, conv_decoder, linear, norm):
+        super().__init__()
+        self.scale, self.linear = scale, linear
+        self.up_conv = nn.Conv2d(cin, cout, 1) if linear else nn.ConvTranspose2d(cin, cout, scale, stride=scale, bias=False)
+        if conv_decoder:
+            self.decoder_block = nn.ModuleList([ResBlock(cout, cout, norm)])
+        else:
+            self.decoder_block = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens, cout, proj, heads) for _ in range(depth)])])
+
+    def forward(self, x, skip):
+        if self.linear:
+            x = _conv(self.up_conv, F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=False))
+        else:
+            x = F.conv_transpose2d(x, self.up_conv.weight.to(x.dtype), None, stride=self.scale)
+        return self.decoder_block[0](x + skip)
+
+
+class UNetRPPMI355X(ModelABC, nn.Module):
+    settings_kls = UNetRPPSettings
+    onnx_supported = False
+    supported_num_spatial_dims = (2,)
+    num_spatial_dims = 2
+    features_last = True
+    model_type = ModelType.VISION_TRANSFORMER
+    register = True
+    is_native_hip = True   # common_step: the precision is the model's (activation_dtype), no torch.autocast around it
+
+    def __init__(self, in_channels: int, out_channels: int, input_shape: Tuple[int, int] = None,
+                 settings: UNetRPPSettings = UNetRPPSettings(), *args, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.input_shape = in_channels, out_channels, input_shape
+        self._settings = s = settings
+        if s.spatial_dims != 2 or s.conv_op != "Conv2d" or s.do_ds or s.dropout_rate != 0.0 or not s.add_skip_connections:
+            raise NotImplementedError("UNetRPPMI355X: 2-D, no deep supervision, no dropout, with skip connections")
+        if s.hidden_size % 16 or len(s.depths) != 4 or len(s.encoder_proj_sizes) != 4:
+            raise NotImplementedError("UNetRPPMI355X: hidden_size must be a multiple of 16, four stages")
+        H, W = input_shape
+        r = s.downsampling_rate
+        if H % (8 * r) or W % (8 * r):
+            raise L.P4CError(f"UNetRPPMI355X: grid {H}x{W} must be a multiple of {8 * r}")
+        fs = s.hidden_size // 16
+        dims = [fs * 2, fs * 4, fs * 8, fs * 16]
+        tokens = [(H // (r * 2**i)) * (W // (r * 2**i)) for i in range(4)]
+        self.act_dtype = torch.bfloat16 if s.activation_dtype == "bf16" else torch.float32
+        self.downsample_layers = nn.ModuleList()
+        g0 = in_channels if dims[0] % in_channels == 0 else 1
+        self.downsample_layers.append(nn.Sequential(nn.Conv2d(in_channels, dims[0], r, stride=r, bias=False), nn.GroupNorm(g0, dims[0])))
+        for i in range(3):
+            self.downsample_layers.append(nn.Sequential(nn.Conv2d(dims[i], dims[i + 1], 2, stride=2, bias=False), nn.GroupNorm(dims[i], dims[i + 1])))
+        self.stages = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens[i], dims[i], s.encoder_proj_sizes[i], s.num_heads_encoder)
+                                                     for _ in range(s.depths[i])]) for i in range(4)])
+        up = (s.decoder_proj_size, s.num_heads_decoder, 3)
+        self.encoder1 = ResBlock(in_channels, fs, s.norm_name)
+        self.decoder5 = UpBlock(dims[3], dims[2], 2, tokens[2], *up, False, s.linear_upsampling, s.norm_name)
+        self.decoder4 = UpBlock(dims[2], dims[1], 2, tokens[1], *up, False, s.linear_upsampling, s.norm_name)
+        self.decoder3 = UpBlock(dims[1], dims[0], 2, tokens[0], *up, False, s.linear_upsampling, s.norm_name)
+        self.decoder2 = UpBlock(dims[0], fs, r, H * W, *up, True, s.linear_upsampling, s.norm_name)
+        self.out1 = nn.Conv2d(fs, out_channels, 1)
+        self.check_required_attributes()
+
+    @property
+    def settings(self):
+        return self._settings
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B,H,W,in_channels) -> (B,H,W,out_channels)."""
+        L.require_cuda(x)
+        out_dtype = x.dtype
+        x = x.permute(0, 3, 1, 2).to(self.act_dtype)
+        hidden, h = [], x
+        for i in range(4):
+            ds = self.downsample_layers[i]
+            h = self.stages[i](_nrm(ds[1], _conv(ds[0], h)))
+            hidden.append(h)
+        conv_block = self.encoder1(x)
+        dec3 = self.decoder5(hidden[3], hidden[2])
+        dec2 = self.decoder4(dec3, hidden[1])
+        dec1 = self.decoder3(dec2, hidden[0])
+        out = self.decoder2(dec1, conv_block)
+        y = _conv(self.out1, out).permute(0, 2, 3, 1)
+        return y if y.dtype == out_dtype or not out_dtype.is_floating_point else y.to(out_dtype)

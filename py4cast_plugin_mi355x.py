@@ -21,6 +21,7 @@ from py4cast_amd.graphlam import GraphLamMI355X, GraphLamSettings  # noqa: F401,
 from py4cast_amd.swinunetr import SwinUNetRMI355X, SwinUNetRSettings  # noqa: F401,E402
 from py4cast_amd.hilam import HiLamMI355X, HiLamSettings  # noqa: F401,E402
 from py4cast_amd.hilamparallel import HiLamParallelMI355X, HiLamParallelSettings  # noqa: F401,E402
+from py4cast_amd.unetrpp import UNetRPPMI355X, UNetRPPSettings  # noqa: F401,E402
 
 if not HAVE_MFAI:
     # stand-alone: take the upstream names so that config/CLI/model/halfunet.yaml / graphlam.yaml work unchanged
@@ -40,6 +41,9 @@ if not HAVE_MFAI:
         register = True
 
     class HiLAMParallel(HiLamParallelMI355X):
+        register = True
+
+    class UNetRPP(UNetRPPMI355X):       # config/CLI/model/unetrpp.yaml:2, tests/test_models.py:160
         register = True
 
 

@@ -1,0 +1,145 @@
+"""UNETR++ (BASELINE configuration 5) on MI355X: the tall-skinny kernels against torch, the model against its float64 oracle
+(parity unpinned: mfai is absent), a 6-step differential-AR rollout through the Lightning module, registry names."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_batch, make_dataset_info, synthetic_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)])
+@pytest.mark.parametrize("B,H,N,d,e", [(2, 4, 1000, 8, 8), (1, 16, 4099, 16, 64), (2, 3, 257, 32, 32), (1, 2, 70, 64, 64), (2, 2, 5000, 12, 36)])
+def test_tall_skinny_gram_and_apply(gpu_device, dtype, tol, B, H, N, d, e):
+    """gram / apply on strided in-place views (slices of a (B,N,4,H,d) projection output) vs float64 matmuls, and their gradients
+    (each kernel is the other's adjoint)."""
+    from py4cast_amd import ops_ts as TS
+
+    g = torch.Generator().manual_seed(N + d)
+    big = torch.randn(B, N, 4, H, d, generator=g).to(gpu_device).to(dtype).requires_grad_(True)
+    yfull = torch.randn(B, N, H, e, generator=g).to(gpu_device).to(dtype).requires_grad_(True)
+    x = big[:, :, 1].permute(0, 2, 1, 3)             # (B,H,N,d) view with strides (N*4*H*d, d, 4*H*d, 1)
+    y = yfull.permute(0, 2, 1, 3)
+    assert not x.is_contiguous()
+    m = torch.randn(B, H, d, e, generator=g).to(gpu_device).requires_grad_(True)
+    G = TS.gram(x, y)
+    O = TS.apply(x, m)
+    xd, yd, md = x.detach().double(), y.detach().double(), m.detach().double()
+    assert G.dtype == torch.float32 and _rel(G, xd.transpose(-1, -2) @ yd) < tol
+    assert O.shape == (B, H, N, e) and O.permute(0, 2, 1, 3).is_contiguous() and _rel(O.float(), xd @ md) < tol
+    wG = torch.randn(G.shape, generator=g).to(gpu_device)
+    wO = torch.randn(B, N, H, e, generator=g).to(gpu_device).permute(0, 2, 1, 3)
+    ((G * wG).sum() + (O.float() * wO).sum()).backward()
+    dx_ref = yd @ wG.double().transpose(-1, -2) + wO.double() @ md.transpose(-1, -2)
+    dy_ref = xd @ wG.double()
+    dm_ref = xd.transpose(-1, -2) @ wO.double()
+    btol = tol * 3
+    assert _rel(big.grad[:, :, 1].permute(0, 2, 1, 3).float(), dx_ref) < btol
+    assert float(big.grad[:, :, 0].abs().sum()) == 0.0
+    assert _rel(yfull.grad.permute(0, 2, 1, 3).float(), dy_ref) < btol
+    assert _rel(m.grad, dm_ref) < btol
+
+
+def _pair(cin, cout, shape, dtype="f32", hidden=256, heads=4, linear=True):
+    from oracle.unetrpp import UNetRPP as Oracle
+    from py4cast_amd.unetrpp import UNetRPPMI355X, UNetRPPSettings
+
+    torch.manual_seed(41)
+    s = UNetRPPSettings(hidden_size=hidden, num_heads_encoder=heads, num_heads_decoder=4, depths=(2, 1, 1, 1), encoder_proj_sizes=(16, 16, 8, 4),
+                        decoder_proj_size=16, linear_upsampling=linear, activation_dtype=dtype)
+    model = UNetRPPMI355X(cin, cout, shape, s)
+    with torch.no_grad():   # the published initialisation (gamma = 1e-6, zero positional embedding) would hide the attention path
+        for n, p in model.named_parameters():
+            if n.endswith("gamma"):
+                p.fill_(0.5)
+            elif n.endswith("pos_embed"):
+                p.normal_(0, 0.1)
+            elif "temperature" in n:
+                p.uniform_(0.5, 1.5)
+    oracle = Oracle(cin, cout, shape, hidden_size=hidden, num_heads_encoder=heads, num_heads_decoder=4, depths=(2, 1, 1, 1),
+                    encoder_proj_sizes=(16, 16, 8, 4), decoder_proj_size=16, linear_upsampling=linear).double()
+    oracle.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in model.state_dict().items()})
+    return model, oracle
+
+
+@pytest.mark.parametrize("linear", [True, False])
+def test_unetrpp_matches_oracle(gpu_device, linear):
+    H, W, cin, cout = 64, 96, 13, 5
+    model, oracle = _pair(cin, cout, (H, W), linear=linear)
+    model = model.to(gpu_device).train()
+    oracle.train()
+    torch.manual_seed(42)
+    x, gy = torch.randn(2, H, W, cin), torch.randn(2, H, W, cout)
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = model(xg)
+    y.backward(gy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    yr = oracle(xr)
+    yr.backward(gy.double())
+    assert y.shape == (2, H, W, cout)
+    assert _rel(y, yr) < 1e-4                      # north-star bar: <= 1e-4 relative in fp32
+    assert _rel(xg.grad, xr.grad) < 2e-3
+    ref = dict(oracle.named_parameters())
+    worst = max((_rel(p.grad, ref[n].grad), n) for n, p in model.named_parameters() if p.grad is not None)
+    assert worst[0] < 5e-3, worst
+    assert all(p.grad is not None for n, p in model.named_parameters())
+
+
+def test_unetrpp_bf16_tracks_fp32(gpu_device):
+    H, W, cin, cout = 64, 64, 13, 5
+    model, oracle = _pair(cin, cout, (H, W), dtype="bf16")
+    model = model.to(gpu_device).train()
+    oracle.train()
+    x = torch.randn(2, H, W, cin, generator=torch.Generator().manual_seed(3))
+    y = model(x.to(gpu_device))
+    assert y.dtype == torch.float32 and _rel(y, oracle(x.double())) < 5e-2
+
+
+def test_unetrpp_six_step_diff_ar_rollout_through_lightning(gpu_device):
+    """BASELINE configuration 5 in small: UNetRPP from the registry, 6-step differential AR (unetrpp.yaml with training_strategy
+    diff_ar), fused update + loss per step, loss and gradients against the oracle network driven through the oracle rollout."""
+    from oracle import losses as olosses
+    from oracle import rollout as orollout
+    from oracle.unetrpp import UNetRPP as Oracle
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from py4cast_amd.models import registry
+
+    assert "UNetRPP" in registry and "UNetRPPMI355X" in registry
+    H = W = 64
+    F, Ff, T = 6, 5, 6
+    case = synthetic_case(seed=51, B=2, T=T, H=H, W=W, F=F, Ff=Ff, border=0)
+    info = make_dataset_info(case, Ff)
+    settings = dict(hidden_size=128, num_heads_encoder=2, num_heads_decoder=2, depths=[1, 1, 1, 1], encoder_proj_sizes=[16, 16, 8, 4],
+                    decoder_proj_size=16, linear_upsampling=True, attention_code="torch")
+    torch.manual_seed(52)
+    lm = AutoRegressiveLightning(settings, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2, model_name="UNetRPP",
+                                 losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+                                 training_strategy="diff_ar").to(gpu_device).train()
+    with torch.no_grad():
+        for n, p in lm.model.named_parameters():
+            if n.endswith("gamma"):
+                p.fill_(0.5)
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    m = lm.model
+    oracle = Oracle(m.in_channels, m.out_channels, (H, W), hidden_size=128, num_heads_encoder=2, num_heads_decoder=2, depths=(1, 1, 1, 1),
+                    encoder_proj_sizes=(16, 16, 8, 4), decoder_proj_size=16, linear_upsampling=True).double().train()
+    oracle.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.cpu() for k, v in m.state_dict().items()})
+    c = {k: (v.double() if v.is_floating_point() else v) for k, v in case.items()}
+    statics = c["statics"].unsqueeze(0).expand(2, *c["statics"].shape)
+    interior = 1.0 - c["border_mask"]
+    pred = orollout.rollout(oracle, c["inputs"], c["forcing"], c["outputs"], statics, c["border_mask"], interior, None, None,
+                            training_strategy="diff_ar")
+    w = olosses.weighted_loss_weights(c["state_weight"], c["diff_std"], "mse")
+    ref = olosses.weighted_loss(pred, c["outputs"], torch.ones_like(pred), w, interior, "mse").mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 2e-4
+    rg = dict(oracle.named_parameters())
+    worst = max((_rel(p.grad, rg[n].grad), n) for n, p in m.named_parameters())
+    assert worst[0] < 3e-2, worst     # six chained networks in fp32 (BatchNorm batch statistics inside): see test_model_gpu.py on BPTT noise

@@ -87,3 +87,36 @@ def test_relative_position_index_is_toeplitz():
         for b in range(16):
             dy, dx = a // ws - b // ws, a % ws - b % ws
             assert idx[a, b] == (dy + ws - 1) * (2 * ws - 1) + dx + ws - 1
+
+
+def test_unetrpp_oracle_epa_matches_brute_force_per_head():
+    """oracle/unetrpp.py::EPA (batched transposes / matmuls) against a per-(sample, head) loop that builds every matrix from its
+    definition: column-normalised q and k, d x d channel attention, token-axis projection E = F, N x p spatial attention."""
+    from oracle.unetrpp import EPA, UNetRPP
+
+    torch.manual_seed(0)
+    B, N, C, h, p = 2, 48, 16, 4, 8
+    d = C // h
+    e = EPA(N, C, p, h).double()
+    with torch.no_grad():
+        e.temperature.uniform_(0.5, 1.5)
+        e.temperature2.uniform_(0.5, 1.5)
+        x = torch.randn(B, N, C, dtype=torch.float64)
+        y = e(x)
+        qkvv = (x @ e.qkvv.weight.t()).view(B, N, 4, h, d)
+        sa, ca = torch.zeros(B, N, C, dtype=torch.float64), torch.zeros(B, N, C, dtype=torch.float64)
+        for b in range(B):
+            for hh in range(h):
+                q, k, v1, v2 = (qkvv[b, :, i, hh] for i in range(4))
+                qn, kn = q / q.norm(dim=0).clamp_min(1e-12), k / k.norm(dim=0).clamp_min(1e-12)
+                A = torch.softmax(qn.t() @ kn * e.temperature[hh, 0, 0], -1)
+                ca[b, :, hh * d:(hh + 1) * d] = v1 @ A.t()
+                KP = (e.E.weight @ k + e.E.bias[:, None]).t()
+                VP = (e.E.weight @ v2 + e.E.bias[:, None]).t()
+                S = torch.softmax(qn @ KP * e.temperature2[hh, 0, 0], -1)
+                sa[b, :, hh * d:(hh + 1) * d] = S @ VP.t()
+        ref = torch.cat([sa @ e.out_proj.weight.t() + e.out_proj.bias, ca @ e.out_proj2.weight.t() + e.out_proj2.bias], -1)
+    assert float((y - ref).abs().max()) < 1e-12
+    net = UNetRPP(7, 3, (64, 64), hidden_size=64, num_heads_encoder=4, num_heads_decoder=4)
+    out = net(torch.randn(1, 64, 64, 7))
+    assert out.shape == (1, 64, 64, 3) and bool(torch.isfinite(out).all())
