@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--features", type=int, default=60)
     ap.add_argument("--pred-steps", type=int, default=3)
     ap.add_argument("--border", type=int, default=0)
+    ap.add_argument("--strategy", default="scaled_ar", choices=["scaled_ar", "diff_ar"],
+                    help="training_strategy (BASELINE configuration 5 -- UNetRPP -- is quoted on 6-step diff_ar: --model UNetRPP "
+                         "--strategy diff_ar --pred-steps 6)")
+    ap.add_argument("--hidden", type=int, default=1024, help="UNetRPP hidden_size (config/CLI/model/unetrpp.yaml:20)")
     ap.add_argument("--hip-graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the micro-batch (rollout + loss + backward) from a HIP graph; auto: only for models that ask for it "
                          "(launch-bound small-kernel models); the roofline object is then measured in eager steps before the timed region")
@@ -178,6 +182,13 @@ def cpu_baseline(args, seconds):
         interior, statics = 1.0 - case["border_mask"], case["statics"].unsqueeze(0)
         model_fn = net
         features_second = False
+    elif args.model.lower().startswith("unetrpp"):
+        from oracle.unetrpp import UNetRPP as OracleUNetRPP
+
+        net = OracleUNetRPP(F + 4 + 5, F, (H, W), hidden_size=args.hidden)   # unetrpp.yaml:19-35 defaults otherwise
+        params = list(net.parameters())
+        model_fn = net
+        features_second = False
     elif args.model.lower().startswith("swin"):
         from oracle.swinunetr import SwinUNetR as OracleSwin
 
@@ -196,7 +207,7 @@ def cpu_baseline(args, seconds):
 
     def one():
         pred = orollout.rollout(model_fn, case["inputs"], case["forcing"], case["outputs"], statics, case["border_mask"],
-                                interior, case["diff_std"], case["diff_mean"], "scaled_ar", 1, False, "train",
+                                interior, case["diff_std"], case["diff_mean"], args.strategy, 1, False, "train",
                                 features_second=features_second)
         loss = olosses.training_loss(pred, case["outputs"], False, [("WeightedLoss", 1.0, dict(weights=wts, interior_mask=interior, kind="mse"))])
         loss.backward()
@@ -298,6 +309,10 @@ def main():
     settings = {}
     if args.model.lower().startswith(("graphlam", "hilam")):
         settings = {"activation_dtype": args.act_dtype or args.dtype, "tmp_dir": os.environ.get("TMPDIR", "/tmp")}
+    elif args.model.lower().startswith("unetrpp"):   # config/CLI/model/unetrpp.yaml:19-35
+        settings = {"hidden_size": args.hidden, "num_heads_encoder": 16, "num_heads_decoder": 4, "depths": [3, 3, 3, 3],
+                    "linear_upsampling": True, "downsampling_rate": 4, "decoder_proj_size": 64, "encoder_proj_sizes": [64, 64, 64, 32],
+                    "attention_code": "torch", "activation_dtype": args.act_dtype or args.dtype}
     elif args.model.lower().startswith("swin"):
         settings = {"activation_dtype": args.act_dtype or args.dtype}
     elif args.model not in ("Identity",):
@@ -307,7 +322,7 @@ def main():
         settings, info, None, num_input_steps=1, num_pred_steps_train=T, num_pred_steps_val_test=T, batch_size=B,
         model_name=args.model,
         losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
-        training_strategy="scaled_ar", learning_rate=1e-3, min_learning_rate=3e-7, num_warmup_steps=1000,
+        training_strategy=args.strategy, learning_rate=1e-3, min_learning_rate=3e-7, num_warmup_steps=1000,
         betas=(0.9, 0.95),
     ).to(device)
     ddp = FlatDDP(lm.model, world)
@@ -474,7 +489,7 @@ def main():
             "dtype": args.dtype if args.model != "Identity" else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.model} scaled_ar rollout T={T}, grid {H}x{W}x{F} (+{Ff} forcings, {Fs} statics), "
+                "workload": f"{args.model} {args.strategy} rollout T={T}, grid {H}x{W}x{F} (+{Ff} forcings, {Fs} statics), "
                             f"WeightedLoss(MSE), AdamW, B={B}/GPU",
                 "global_batch": world * B,
                 "parallelism": f"dp{world}",

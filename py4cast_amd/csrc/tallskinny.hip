@@ -12,15 +12,10 @@
 namespace p4c {
 namespace ts {
 
-constexpr int TOK = 64;      // tokens per LDS tile
 constexpr int MAXD = 64;
-
-template <typename T>
-__device__ __forceinline__ float ldf(const T* p);
-template <>
-__device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
-template <>
-__device__ __forceinline__ float ldf<bf16>(const bf16* p) { return __bfloat162float(*p); }
+constexpr int TOKG = 32;      // tokens per LDS tile of the gram kernel
+constexpr int TOKA = 16;      // tokens per LDS tile of the apply kernel
+constexpr int MAXCOL = 128;   // columns of a token tile held in LDS (heads x width of the chunk of heads a workgroup serves)
 
 struct Mat {             // token matrix of group g = (b, h): element (n, i) at base + b*bs + h*hs + n*rs + i
     const void* base;
@@ -31,16 +26,45 @@ struct MatOut {
     int64_t bs, hs, rs;
 };
 
-// C[g][split] (d x e) partial = sum over the split's tokens of X[n,:]^T Y[n,:]; thread t owns a 4 x 4 block of C (d, e multiples of 4)
+// 4 consecutive elements as fp32 (offsets are multiples of 4 elements: 8-byte / 16-byte aligned accesses)
+__device__ __forceinline__ p4c_f32x4 ld4(const float* p) { return *reinterpret_cast<const p4c_f32x4*>(p); }
+__device__ __forceinline__ p4c_f32x4 ld4(const bf16* p) { return load4f(p); }
+
+// Stage `nt` token rows x `hc` heads x `w` columns (w % 4 == 0) into LDS as fp32, row t at dst + t*ld, head h at column h*w.
+// With heads adjacent in memory (hs == w) consecutive threads read consecutive quads of a row: whole cache lines per row.
+template <typename T>
+__device__ __forceinline__ void stage(float* dst, int ld, const T* src, int64_t rs, int64_t hs, int nt, int tile, int hc, int w) {
+    const int qpr = hc * (w >> 2);                    // quads per row
+    for (int i = threadIdx.x; i < tile * qpr; i += 256) {
+        const int t = i / qpr, q = i - t * qpr;
+        const int h = q / (w >> 2), c = (q - h * (w >> 2)) << 2;
+        p4c_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < nt) v = ld4(src + (int64_t)t * rs + (int64_t)h * hs + c);
+        *reinterpret_cast<p4c_f32x4*>(dst + t * ld + h * w + c) = v;
+    }
+}
+
+// gram: part[b][split][h] (d x e) = sum over the split's tokens of X[b,h][n,:]^T Y[b,h][n,:].
+// A workgroup serves `hc` heads (blockIdx.z) of one sample and one token split; a thread owns one 4 x 4 block of one head's d x e
+// result (a "task"); when there are fewer tasks than threads the tile's tokens are dealt to `groups` thread groups whose sums
+// are combined through LDS at the end (fixed order).
 template <typename TX, typename TY>
-__global__ void __launch_bounds__(256) gram_kernel(Mat X, Mat Y, float* __restrict__ part, int heads, int64_t N, int d, int e, int nsplit) {
-    __shared__ float lx[TOK][MAXD + 1], ly[TOK][MAXD + 1];
-    const int g = blockIdx.x, sp = blockIdx.y;
-    const int b = g / heads, h = g - b * heads;
-    const TX* xb = reinterpret_cast<const TX*>(X.base) + b * X.bs + h * X.hs;
-    const TY* yb = reinterpret_cast<const TY*>(Y.base) + b * Y.bs + h * Y.hs;
-    const int bi = (threadIdx.x >> 4) * 4, bj = (threadIdx.x & 15) * 4;      // 16 x 16 thread grid over up to 64 x 64 outputs
-    const bool live = bi < d && bj < e;
+__global__ void __launch_bounds__(256) gram_kernel(Mat X, Mat Y, float* __restrict__ part, int heads, int64_t N, int d, int e, int nsplit,
+                                                   int hc, int tpg) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * TOKG * (MAXCOL + 4)];
+    const int b = blockIdx.x, sp = blockIdx.y, h0 = blockIdx.z * hc;
+    const int nh = (heads - h0) < hc ? (heads - h0) : hc;
+    const int ldx = nh * d + 4, ldy = nh * e + 4;
+    float* lx = lds;
+    float* ly = lds + TOKG * (MAXCOL + 4);
+    const TX* xb = reinterpret_cast<const TX*>(X.base) + b * X.bs + h0 * X.hs;
+    const TY* yb = reinterpret_cast<const TY*>(Y.base) + b * Y.bs + h0 * Y.hs;
+    const int db = d >> 2, eb = e >> 2;
+    const int ntasks = nh * db * eb;
+    const int groups = 256 / tpg, grp = threadIdx.x / tpg, task = threadIdx.x - grp * tpg;
+    const bool live = task < ntasks;
+    const int th = task / (db * eb), tr = task - th * db * eb;
+    const int ci = th * d + (tr / eb) * 4, cj = th * e + (tr % eb) * 4;
     float acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -48,82 +72,83 @@ __global__ void __launch_bounds__(256) gram_kernel(Mat X, Mat Y, float* __restri
         for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
     const int64_t per = (N + nsplit - 1) / nsplit;
     const int64_t n0 = sp * per, n1 = (n0 + per < N) ? n0 + per : N;
-    for (int64_t t0 = n0; t0 < n1; t0 += TOK) {
-        const int nt = (int)((n1 - t0) < TOK ? (n1 - t0) : TOK);
-        for (int i = threadIdx.x; i < TOK * d; i += 256) {
-            const int r = i / d, c = i - r * d;
-            lx[r][c] = r < nt ? ldf<TX>(xb + (t0 + r) * X.rs + c) : 0.f;
-        }
-        for (int i = threadIdx.x; i < TOK * e; i += 256) {
-            const int r = i / e, c = i - r * e;
-            ly[r][c] = r < nt ? ldf<TY>(yb + (t0 + r) * Y.rs + c) : 0.f;
-        }
+    for (int64_t t0 = n0; t0 < n1; t0 += TOKG) {
+        const int nt = (int)((n1 - t0) < TOKG ? (n1 - t0) : TOKG);
+        __syncthreads();
+        stage<TX>(lx, ldx, xb + t0 * X.rs, X.rs, X.hs, nt, TOKG, nh, d);
+        stage<TY>(ly, ldy, yb + t0 * Y.rs, Y.rs, Y.hs, nt, TOKG, nh, e);
         __syncthreads();
         if (live) {
-#pragma unroll 8
-            for (int r = 0; r < TOK; ++r) {
-                float xv[4], yv[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) { xv[a] = lx[r][bi + a]; yv[a] = ly[r][bj + a]; }
+            for (int t = grp; t < TOKG; t += groups) {
+                const p4c_f32x4 xv = *reinterpret_cast<const p4c_f32x4*>(lx + t * ldx + ci);
+                const p4c_f32x4 yv = *reinterpret_cast<const p4c_f32x4*>(ly + t * ldy + cj);
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_fmaf(xv[a], yv[c], acc[a][c]);
             }
         }
-        __syncthreads();
     }
+    // combine the token groups (group 0 first, then 1, ...): red[grp][task][16]
+    __syncthreads();
+    float* red = lds;
     if (live) {
-        float* dst = part + ((int64_t)g * nsplit + sp) * d * e;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) dst[(bi + a) * e + bj + c] = acc[a][c];
+            for (int c = 0; c < 4; ++c) red[(grp * tpg + task) * 16 + a * 4 + c] = acc[a][c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntasks * 16; i += 256) {
+        const int tk = i >> 4, el = i & 15;
+        float s = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) s += red[(g2 * tpg + tk) * 16 + el];
+        const int hh = tk / (db * eb), r2 = tk - hh * db * eb;
+        const int ii = (r2 / eb) * 4 + (el >> 2), jj = (r2 % eb) * 4 + (el & 3);
+        part[((((int64_t)b * nsplit + sp) * heads + h0 + hh) * d + ii) * e + jj] = s;
     }
 }
 
-// O[g] (N x e) = X[g] (N x d) M[g] (d x e) (+ O when accumulate): 64 tokens x 4 column groups per workgroup, M in LDS
+// apply: O[b,h] (N x e) = X[b,h] (N x d) M[b,h] (d x e) (+ O when accumulate).  A workgroup serves `hc` heads (blockIdx.z) and walks
+// token tiles; a task = (token, head, 4 output columns): d x 4 FMAs from the staged token row and the heads' matrices in LDS.
 template <typename TX, typename TO>
-__global__ void __launch_bounds__(256) apply_kernel(Mat X, const float* __restrict__ M, int64_t m_gs, MatOut O, int heads, int64_t N,
-                                                    int d, int e, int accumulate) {
-    __shared__ float lm[MAXD][MAXD + 1];
-    __shared__ float lx[TOK][MAXD + 1];
-    const int g = blockIdx.x;
-    const int b = g / heads, h = g - b * heads;
-    const TX* xb = reinterpret_cast<const TX*>(X.base) + b * X.bs + h * X.hs;
-    TO* ob = reinterpret_cast<TO*>(O.base) + b * O.bs + h * O.hs;
-    const float* mg = M + (int64_t)g * m_gs;
-    for (int i = threadIdx.x; i < d * e; i += 256) lm[i / e][i % e] = mg[i];
-    const int tok = threadIdx.x >> 2, jg = threadIdx.x & 3;
-    const int ew = (e + 3) / 4;                 // columns per thread (<= 16), column c = jg * ew + k
-    for (int64_t t0 = (int64_t)blockIdx.y * TOK; t0 < N; t0 += (int64_t)gridDim.y * TOK) {
+__global__ void __launch_bounds__(256) apply_kernel(Mat X, const float* __restrict__ M, int64_t m_bs, int64_t m_hs, MatOut O, int heads,
+                                                    int64_t N, int d, int e, int accumulate, int hc) {
+    __shared__ __attribute__((aligned(16))) float lm[8192];                       // hc * d * e floats
+    __shared__ __attribute__((aligned(16))) float lx[TOKA * (MAXCOL + 4)];
+    const int b = blockIdx.x, h0 = blockIdx.z * hc;
+    const int nh = (heads - h0) < hc ? (heads - h0) : hc;
+    const TX* xb = reinterpret_cast<const TX*>(X.base) + b * X.bs + h0 * X.hs;
+    TO* ob = reinterpret_cast<TO*>(O.base) + b * O.bs + h0 * O.hs;
+    for (int i = threadIdx.x; i < nh * d * e; i += 256) {
+        const int hh = i / (d * e);
+        lm[i] = M[b * m_bs + (int64_t)(h0 + hh) * m_hs + (i - hh * d * e)];
+    }
+    const int ldx = nh * d + 4, eb = e >> 2;
+    const int per_tok = nh * eb;
+    for (int64_t t0 = (int64_t)blockIdx.y * TOKA; t0 < N; t0 += (int64_t)gridDim.y * TOKA) {
+        const int nt = (int)((N - t0) < TOKA ? (N - t0) : TOKA);
         __syncthreads();
-        const int nt = (int)((N - t0) < TOK ? (N - t0) : TOK);
-        for (int i = threadIdx.x; i < TOK * d; i += 256) {
-            const int r = i / d, c = i - r * d;
-            lx[r][c] = r < nt ? ldf<TX>(xb + (t0 + r) * X.rs + c) : 0.f;
-        }
+        stage<TX>(lx, ldx, xb + t0 * X.rs, X.rs, X.hs, nt, TOKA, nh, d);
         __syncthreads();
-        if (tok < nt) {
-            float acc[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int task = threadIdx.x; task < nt * per_tok; task += 256) {
+            const int t = task / per_tok, r = task - t * per_tok;
+            const int hh = r / eb, j = (r - hh * eb) << 2;
+            const float* xr = lx + t * ldx + hh * d;
+            const float* mr = lm + hh * d * e + j;
+            p4c_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int i = 0; i < d; ++i) {
-                const float xv = lx[tok][i];
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < ew) acc[k] = __builtin_fmaf(xv, lm[i][jg * ew + k < e ? jg * ew + k : 0], acc[k]);
+                const float xv = xr[i];
+                const p4c_f32x4 mv = *reinterpret_cast<const p4c_f32x4*>(mr + i * e);
+                acc[0] = __builtin_fmaf(xv, mv[0], acc[0]); acc[1] = __builtin_fmaf(xv, mv[1], acc[1]);
+                acc[2] = __builtin_fmaf(xv, mv[2], acc[2]); acc[3] = __builtin_fmaf(xv, mv[3], acc[3]);
             }
-            TO* orow = ob + (t0 + tok) * O.rs;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int c = jg * ew + k;
-                if (k < ew && c < e) {
-                    float v = acc[k];
-                    if (accumulate) v += to_f32<TO>(orow[c]);
-                    orow[c] = from_f32<TO>(v);
-                }
+            TO* op = ob + (t0 + t) * O.rs + (int64_t)hh * O.hs + j;
+            if (accumulate) {
+                const p4c_f32x4 old = ld4(op);
+                acc[0] += old[0]; acc[1] += old[1]; acc[2] += old[2]; acc[3] += old[3];
             }
+            store4f(op, acc);
         }
     }
 }
@@ -134,11 +159,13 @@ __global__ void __launch_bounds__(256) apply_kernel(Mat X, const float* __restri
 using namespace p4c;
 
 extern "C" int p4c_ts_gram_splits(int64_t N) {
-    int64_t s = (N + 2047) / 2048;     // >= 2048 tokens per workgroup
-    if (s > 64) s = 64;
+    int64_t s = (N + 63) / 64;        // two 32-token tiles per workgroup: the launch needs >> 256 workgroups to hide its load ->
+    if (s > 256) s = 256;             // barrier -> compute -> barrier rhythm behind other workgroups of the same CU
     if (s < 1) s = 1;
     return (int)s;
 }
+
+static int pow2_ge_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 extern "C" int p4c_ts_gram(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const void* y, int y_dtype,
                            int64_t y_bs, int64_t y_hs, int64_t y_rs, float* partial, int B, int heads, int64_t N, int d, int e,
@@ -146,11 +173,23 @@ extern "C" int p4c_ts_gram(const void* x, int x_dtype, int64_t x_bs, int64_t x_h
     P4C_CHECK_ARG(x && y && partial, "p4c_ts_gram: null pointer");
     P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
                   "p4c_ts_gram: d, e must be multiples of 4 up to %d (got %d, %d)", ts::MAXD, d, e);
+    P4C_CHECK_ARG(x_bs % 4 == 0 && x_hs % 4 == 0 && x_rs % 4 == 0 && y_bs % 4 == 0 && y_hs % 4 == 0 && y_rs % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                  "p4c_ts_gram: strides must be multiples of 4 elements, bases 16-byte aligned");
     const int ns = p4c_ts_gram_splits(N);
+    // heads per workgroup: at most 256 tasks (4 x 4 result blocks) and MAXCOL staged columns per operand
+    int hc = 256 / ((d / 4) * (e / 4));
+    if (hc > ts::MAXCOL / d) hc = ts::MAXCOL / d;
+    if (hc > ts::MAXCOL / e) hc = ts::MAXCOL / e;
+    if (hc > heads) hc = heads;
+    if (hc < 1) hc = 1;
+    int tpg = pow2_ge_i(hc * (d / 4) * (e / 4));       // threads per token group
+    if (tpg > 256) tpg = 256;
+    if (tpg < 8) tpg = 8;                               // <= 32 token groups: a tile has 32 tokens
     const ts::Mat X{x, x_bs, x_hs, x_rs}, Y{y, y_bs, y_hs, y_rs};
-    const dim3 grid(B * heads, ns);
+    const dim3 grid(B, ns, (heads + hc - 1) / hc);
     hipStream_t st = as_stream(stream);
-#define P4C_GRAM(TX, TY) hipLaunchKernelGGL((ts::gram_kernel<TX, TY>), grid, dim3(256), 0, st, X, Y, partial, heads, N, d, e, ns)
+#define P4C_GRAM(TX, TY) hipLaunchKernelGGL((ts::gram_kernel<TX, TY>), grid, dim3(256), 0, st, X, Y, partial, heads, N, d, e, ns, hc, tpg)
     if (x_dtype == P4C_F32 && y_dtype == P4C_F32) P4C_GRAM(float, float);
     else if (x_dtype == P4C_BF16 && y_dtype == P4C_BF16) P4C_GRAM(bf16, bf16);
     else if (x_dtype == P4C_BF16 && y_dtype == P4C_F32) P4C_GRAM(bf16, float);
@@ -165,15 +204,25 @@ extern "C" int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_
                             void* out, int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e,
                             int accumulate, p4c_stream_t stream) {
     P4C_CHECK_ARG(x && m && out, "p4c_ts_apply: null pointer");
-    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD, "p4c_ts_apply: d, e <= %d", ts::MAXD);
+    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
+                  "p4c_ts_apply: d, e must be multiples of 4 up to %d (got %d, %d)", ts::MAXD, d, e);
+    P4C_CHECK_ARG(x_bs % 4 == 0 && x_hs % 4 == 0 && x_rs % 4 == 0 && o_bs % 4 == 0 && o_hs % 4 == 0 && o_rs % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0,
+                  "p4c_ts_apply: strides must be multiples of 4 elements, bases aligned");
+    int hc = 8192 / (d * e);
+    if (hc > ts::MAXCOL / d) hc = ts::MAXCOL / d;
+    if (hc > heads) hc = heads;
+    if (hc < 1) hc = 1;
+    const int zc = (heads + hc - 1) / hc;
     const ts::Mat X{x, x_bs, x_hs, x_rs};
     const ts::MatOut O{out, o_bs, o_hs, o_rs};
-    int64_t chunks = (N + ts::TOK - 1) / ts::TOK;
-    const int64_t cap = (int64_t)num_cus() * 8 / (B * heads) + 1;
+    int64_t chunks = (N + ts::TOKA - 1) / ts::TOKA;
+    const int64_t cap = (int64_t)num_cus() * 8 / ((int64_t)B * zc) + 1;
     if (chunks > cap) chunks = cap;
-    const dim3 grid(B * heads, (unsigned)chunks);
+    const dim3 grid(B, (unsigned)chunks, zc);
     hipStream_t st = as_stream(stream);
-#define P4C_APPLY(TX, TO) hipLaunchKernelGGL((ts::apply_kernel<TX, TO>), grid, dim3(256), 0, st, X, m, m_gs, O, heads, N, d, e, accumulate)
+    const int64_t m_hs = m_gs, m_bs = m_gs * heads;   // M is (B, heads, d, e) dense, or one matrix for all groups (m_gs == 0)
+#define P4C_APPLY(TX, TO) hipLaunchKernelGGL((ts::apply_kernel<TX, TO>), grid, dim3(256), 0, st, X, m, m_bs, m_hs, O, heads, N, d, e, accumulate, hc)
     if (x_dtype == P4C_F32 && out_dtype == P4C_F32) P4C_APPLY(float, float);
     else if (x_dtype == P4C_BF16 && out_dtype == P4C_BF16) P4C_APPLY(bf16, bf16);
     else if (x_dtype == P4C_BF16 && out_dtype == P4C_F32) P4C_APPLY(bf16, float);

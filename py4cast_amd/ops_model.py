@@ -52,3 +52,58 @@ def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, ks: int, CO: int, CI: int, g
     L.call("p4c_conv_wgrad", L.ptr(x.contiguous()), _compute(compute), L.dtype_code(x.dtype), CIp, ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
            L.ptr(dout.contiguous()), CO, CI, L.ptr(grad), L.ptr(ws), B, H, W, L.stream(x.device))
     return grad
+
+
+# ------------------------------------------------------------------------------ a whole convolution as one autograd node
+def _pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+class _ConvNHWC(torch.autograd.Function):
+    """"same" ks x ks convolution (ks = 1 | 3, stride 1, no bias) to 64 output channels on features-last tensors, all three passes
+    on the native kernels: forward p4c_conv_fwd, data gradient the same kernel on the transposed / flipped weights, weight
+    gradient p4c_conv_wgrad.  x (B,H,W,Cp) with Cp = CI rounded up to 32 (extra channels zero), of the activation dtype."""
+
+    @staticmethod
+    def forward(ctx, x, w, compute):
+        L.require_cuda(x, w)
+        CO, CI, ks, _ = w.shape
+        wp = prep_weights(w.detach().float(), False, 64, x.shape[-1], compute=compute)
+        ctx.save_for_backward(x, w)
+        ctx.compute = compute
+        return conv_fwd(x, wp, ks, compute=compute)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        CO, CI, ks, _ = w.shape
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            mb = (x.shape[-1] + 63) // 64
+            wpt = prep_weights(w.detach().float(), True, 64 * mb, 64, compute=ctx.compute)
+            dx = conv_fwd(dy, wpt, ks, m_blocks=mb, compute=ctx.compute)[..., : x.shape[-1]]
+            if dx.shape[-1] != x.shape[-1] or not dx.is_contiguous():
+                dx = dx.contiguous()
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(CO, CI, ks, ks, dtype=torch.float32, device=x.device)
+            conv_wgrad(x, dy, ks, CO, CI, dw, compute=ctx.compute)
+            dw = dw.to(w.dtype)
+        return dx, dw, None
+
+
+def conv_nhwc_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    CO, CI, ks, ks2 = w.shape
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and CO == 64 and ks == ks2 and ks in (1, 3) and CI <= 96
+            and x.dim() == 4)
+
+
+def conv_nhwc(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x (B,H,W,CI) features-last, w (64,CI,ks,ks) canonical torch weight -> (B,H,W,64).  The input is zero-padded to a multiple of 32
+    channels when needed (one copy); 32 / 64 / 96-channel inputs are taken as they are."""
+    CI = w.shape[1]
+    cp = _pad32(CI)
+    if x.shape[-1] != cp:
+        x = torch.nn.functional.pad(x, (0, cp - x.shape[-1]))
+    compute = "bf16" if x.dtype == torch.bfloat16 else "f32"
+    return _ConvNHWC.apply(x.contiguous(), w, compute)

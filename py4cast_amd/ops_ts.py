@@ -14,15 +14,29 @@ def _strides(t: torch.Tensor):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def _gram_raw(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+MAXD = 64   # columns per kernel call (csrc/tallskinny.hip); wider operands (decoder heads of 128 channels) go in column chunks
+
+
+def _chunks(n):
+    return [(i, min(i + MAXD, n)) for i in range(0, n, MAXD)]
+
+
+def _gram_call(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     B, H, N, d = x.shape
     e = y.shape[-1]
     ns = L.lib().p4c_ts_gram_splits(N)
-    part = torch.empty(B * H, ns, d, e, dtype=torch.float32, device=x.device)
+    part = torch.empty(B, ns, H, d, e, dtype=torch.float32, device=x.device)
     xs, ys = _strides(x), _strides(y)
     L.call("p4c_ts_gram", L.ptr(x), L.dtype_code(x.dtype), *xs, L.ptr(y), L.dtype_code(y.dtype), *ys, L.ptr(part), B, H, N, d, e,
            L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * y.element_size()))
-    return (part.sum(dim=1) if ns > 1 else part[:, 0]).view(B, H, d, e)
+    return part.sum(dim=1) if ns > 1 else part[:, 0]
+
+
+def _gram_raw(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    d, e = x.shape[-1], y.shape[-1]
+    if d <= MAXD and e <= MAXD:
+        return _gram_call(x, y)
+    return torch.cat([torch.cat([_gram_call(x[..., i0:i1], y[..., j0:j1]) for j0, j1 in _chunks(e)], dim=-1) for i0, i1 in _chunks(d)], dim=-2)
 
 
 def _apply_raw(x: torch.Tensor, m: torch.Tensor, dtype) -> torch.Tensor:
@@ -31,9 +45,14 @@ def _apply_raw(x: torch.Tensor, m: torch.Tensor, dtype) -> torch.Tensor:
     e = m.shape[-1]
     out = torch.empty(B, N, H, e, dtype=dtype, device=x.device)
     ov = out.permute(0, 2, 1, 3)
-    m = m.float().contiguous()
-    L.call("p4c_ts_apply", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(m), d * e, L.ptr(out), L.dtype_code(dtype), *_strides(ov),
-           B, H, N, d, e, 0, L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * out.element_size()))
+    m = m.float()
+    for j0, j1 in _chunks(e):
+        oj = ov[..., j0:j1]
+        for k, (i0, i1) in enumerate(_chunks(d)):
+            xi, mi = x[..., i0:i1], m[:, :, i0:i1, j0:j1].contiguous()
+            L.call("p4c_ts_apply", L.ptr(xi), L.dtype_code(x.dtype), *_strides(xi), L.ptr(mi), (i1 - i0) * (j1 - j0), L.ptr(oj),
+                   L.dtype_code(dtype), *_strides(oj), B, H, N, i1 - i0, j1 - j0, int(k > 0), L.stream(x.device),
+                   alg_bytes=B * H * N * ((i1 - i0) * x.element_size() + (j1 - j0) * out.element_size() * (1 + (k > 0))))
     return ov
 
 

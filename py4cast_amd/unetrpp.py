@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
+from . import ops_model as OM
 from . import ops_rows as R
 from . import ops_ts as TS
 from .base import ModelABC, ModelType
@@ -72,6 +73,13 @@ def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
 
 
 def _conv(m, x):
+    """3x3 / 1x1 convolutions to 64 channels from <= 96 (the full-resolution residual blocks at the yaml's hidden_size 1024: the
+    HalfUNet kernels' shapes) run on the native MFMA kernels, features-last in memory (a channels_last tensor's permute is a
+    view); the rest through the library."""
+    if (type(m) is nn.Conv2d and m.bias is None and m.stride == (1, 1) and m.dilation == (1, 1) and m.groups == 1
+            and m.padding == (m.kernel_size[0] // 2,) * 2 and OM.conv_nhwc_supported(x, m.weight)):
+        y = OM.conv_nhwc(x.permute(0, 2, 3, 1), m.weight)                  # (B,H,W,64)
+        return y.permute(0, 3, 1, 2)                                      # NCHW-shaped view of features-last memory (channels_last)
     return m._conv_forward(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
 
 
@@ -230,11 +238,29 @@ class UNetRPPMI355X(ModelABC, nn.Module):
         self.decoder3 = UpBlock(dims[1], dims[0], 2, tokens[0], *up, False, s.linear_upsampling, s.norm_name)
         self.decoder2 = UpBlock(dims[0], fs, r, H * W, *up, True, s.linear_upsampling, s.norm_name)
         self.out1 = nn.Conv2d(fs, out_channels, 1)
+        self.timed_entry_points = ("p4c_ts_gram", "p4c_ts_apply", "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd")
+        self.roofline_from_entry_points = True   # bench.py: time every call of the native entry points above
         self.check_required_attributes()
 
     @property
     def settings(self):
         return self._settings
+
+    def roofline(self, ktimes, B, H, W):
+        """bench.py: achieved HBM rate of the native entry point that takes the most time (algorithmic bytes stated by the wrappers
+        in ops_ts / ops_rows next to each call, over HIP-event durations of every call)."""
+        nbytes = L.kernel_bytes()
+        names = [k for k in ktimes if k in nbytes]
+        if not names:
+            return None
+        name = max(names, key=lambda k: ktimes[k][0] * ktimes[k][1])
+        calls, avg_ms = ktimes[name]
+        gbs = nbytes[name] / (calls * avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": f"{name} (all launches)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                "frac": gbs / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": nbytes[name] / calls,
+                "avg_launch_ms": avg_ms, "launches": calls,
+                "all": {k: {"calls": ktimes[k][0], "avg_ms": round(ktimes[k][1], 4),
+                            "GBps": round(nbytes[k] / (ktimes[k][0] * ktimes[k][1] * 1e-3) / 1e9, 1)} for k in names}}
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B,H,W,in_channels) -> (B,H,W,out_channels)."""

@@ -15,7 +15,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)])
-@pytest.mark.parametrize("B,H,N,d,e", [(2, 4, 1000, 8, 8), (1, 16, 4099, 16, 64), (2, 3, 257, 32, 32), (1, 2, 70, 64, 64), (2, 2, 5000, 12, 36)])
+@pytest.mark.parametrize("B,H,N,d,e", [(2, 4, 1000, 8, 8), (1, 16, 4099, 16, 64), (2, 3, 257, 32, 32), (1, 2, 70, 64, 64), (2, 2, 5000, 12, 36), (1, 2, 300, 128, 128), (1, 3, 200, 128, 32)])
 def test_tall_skinny_gram_and_apply(gpu_device, dtype, tol, B, H, N, d, e):
     """gram / apply on strided in-place views (slices of a (B,N,4,H,d) projection output) vs float64 matmuls, and their gradients
     (each kernel is the other's adjoint)."""
@@ -143,3 +143,30 @@ def test_unetrpp_six_step_diff_ar_rollout_through_lightning(gpu_device):
     rg = dict(oracle.named_parameters())
     worst = max((_rel(p.grad, rg[n].grad), n) for n, p in m.named_parameters())
     assert worst[0] < 3e-2, worst     # six chained networks in fp32 (BatchNorm batch statistics inside): see test_model_gpu.py on BPTT noise
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("CI,ks,H,W", [(69, 3, 24, 40), (64, 3, 16, 32), (69, 1, 12, 36), (10, 3, 8, 8)])
+def test_conv_nhwc_autograd_node(gpu_device, dtype, tol, CI, ks, H, W):
+    """ops_model.conv_nhwc (forward, data gradient for ALL input channels, weight gradient on the native kernels) vs torch's conv2d
+    in float64 on the same (rounded) operands -- the route UNetRPP's full-resolution 64-channel residual blocks take."""
+    import torch.nn.functional as Fn
+
+    from py4cast_amd import ops_model as om
+
+    g = torch.Generator().manual_seed(CI + ks)
+    x = torch.randn(2, H, W, CI, generator=g).to(dtype)
+    w = torch.randn(64, CI, ks, ks, generator=g) * 0.1
+    gy = torch.randn(2, H, W, 64, generator=g).to(dtype)
+    xg = x.to(gpu_device).requires_grad_(True)
+    wg = w.to(gpu_device).requires_grad_(True)
+    y = om.conv_nhwc(xg, wg)
+    y.backward(gy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    wr = (w.to(dtype).double() if dtype == torch.bfloat16 else w.double()).requires_grad_(True)
+    yr = Fn.conv2d(xr.permute(0, 3, 1, 2), wr, padding=ks // 2).permute(0, 2, 3, 1)
+    yr.backward(gy.double())
+    assert y.shape == (2, H, W, 64) and y.dtype == dtype
+    assert _rel(y.float(), yr) < tol
+    assert xg.grad.shape == x.shape and _rel(xg.grad.float(), xr.grad) < tol
+    assert _rel(wg.grad, wr.grad) < (1e-4 if dtype == torch.float32 else 2e-3)
