@@ -503,6 +503,19 @@ int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t
                  int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int accumulate,
                  p4c_stream_t stream);
 
+/* ====================================================================================
+ * Ghost module's cheap operation (HalfUNet with use_ghost, config/CLI/model/halfunet.yaml:22): depthwise 3x3 convolution
+ * (zero padding, no bias) of the 32 primary channels, concatenated behind them.  Tensors are (B,H,W,64) features-last:
+ * channels 0..31 primary, 32..63 depthwise.  w: (32, 9) = torch's (32,1,3,3) depthwise weight.
+ * ==================================================================================== */
+/* out[..., :32] = in[..., :32]; out[..., 32 + c] = sum_tap w[c][tap] * in[p + tap, c]  (in's upper half is ignored) */
+int p4c_ghost_dw_fwd(const void* in, const float* w, void* out, int dtype, int B, int H, int W, p4c_stream_t stream);
+/* din[..., c] = dout[..., c] + sum_tap w[c][tap] * dout[p - tap, 32 + c]; din[..., 32:] = 0 */
+int p4c_ghost_dw_bwd_data(const void* dout, const float* w, void* din, int dtype, int B, int H, int W, p4c_stream_t stream);
+/* partial[blk][c][tap] = partial sums of in[p + tap, c] * dout[p, 32 + c]; blk < p4c_ghost_dw_wgrad_blocks(B,H,W); the caller sums */
+int p4c_ghost_dw_wgrad_blocks(int B, int H, int W);
+int p4c_ghost_dw_wgrad(const void* in, const void* dout, float* partial, int dtype, int B, int H, int W, p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

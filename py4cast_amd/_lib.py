@@ -56,6 +56,10 @@ OTHER = {
     "p4c_num_cus": ([], c_int),
     "p4c_loss_workspace_bytes": ([I, I, L, I], c_size_t),
     "p4c_set_side_stream": ([P, P, I], c_int),
+    "p4c_ghost_dw_fwd": ([P, P, P, I, I, I, I, P], c_int),
+    "p4c_ghost_dw_bwd_data": ([P, P, P, I, I, I, I, P], c_int),
+    "p4c_ghost_dw_wgrad_blocks": ([I, I, I], c_int),
+    "p4c_ghost_dw_wgrad": ([P, P, P, I, I, I, I, P], c_int),
     "p4c_ts_gram_splits": ([L], c_int),
     "p4c_ts_gram": ([P, I, L, L, L, P, I, L, L, L, P, I, I, L, I, I, P], c_int),
     "p4c_ts_apply": ([P, I, L, L, L, P, L, P, I, L, L, L, I, I, L, I, I, I, P], c_int),

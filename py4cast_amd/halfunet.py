@@ -115,8 +115,6 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             unsupported.append(f"dilation={settings.dilation}")
         if settings.bias:
             unsupported.append("bias=True")
-        if settings.use_ghost:
-            unsupported.append("use_ghost=True")
         if settings.last_activation != "Identity":
             unsupported.append(f"last_activation={settings.last_activation}")
         if settings.absolute_pos_embed:
@@ -141,6 +139,10 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         self.timed_entry_points = ("p4c_halfunet_forward", "p4c_halfunet_backward", "p4c_build_x",
                                    "p4c_ar_update_loss_fwd", "p4c_ar_update_loss_fwd_next", "p4c_ar_update_loss_bwd")
 
+        self.use_ghost = bool(settings.use_ghost)
+        if self.use_ghost:
+            self._init_ghost(in_channels, out_channels, settings)
+            return
         # parameters in the order of p4c_halfunet_param_count (include/py4cast_hip.h)
         self._param_slices = []
         off = 0
@@ -178,6 +180,80 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         self._running = None
         self._scratch = {}
         self.check_required_attributes()
+
+    # ---------------------------------------------------------------- Ghost variant (settings.use_ghost)
+    def _init_ghost(self, in_channels, out_channels, settings):
+        """mfai's GhostModule blocks (halfunet.yaml:22): primary 3x3 convolution to 32 channels + depthwise 3x3 "cheap operation" on
+        them, concatenated, normalised, ReLU.  Parameter names as mfai's (``encoder1.enc1ghost1.conv.weight``, ``.sepconv.weight``,
+        ``.bn.*``; restated in oracle/halfunet.py).  The primary convolution runs on the MFMA conv kernels (the 32 real output
+        channels in a 64-channel launch, ops_model.conv_nhwc), the depthwise half on csrc/depthwise.hip (ops_ghost.ghost_dw);
+        normalisation / pooling / up-sampling are torch ops on the features-last tensors.  The fused C++ plan
+        (p4c_halfunet_forward) serves the non-ghost network only; the rollout takes the generic per-step path."""
+        for blk, attr in zip(BLOCKS, BLOCK_ATTR):
+            holder = _Holder()
+            for j in (1, 2):
+                cin = in_channels if (attr == "encoder1" and j == 1) else NF
+                g = _Holder()
+                g.conv, g.sepconv, g.bn = _Holder(), _Holder(), _Holder()
+                w = torch.empty(NF // 2, cin, 3, 3)
+                nn.init.kaiming_uniform_(w, a=5**0.5)
+                g.conv.weight = nn.Parameter(w)
+                wd = torch.empty(NF // 2, 1, 3, 3)
+                nn.init.kaiming_uniform_(wd, a=5**0.5)
+                g.sepconv.weight = nn.Parameter(wd)
+                g.bn.weight, g.bn.bias = nn.Parameter(torch.ones(NF)), nn.Parameter(torch.zeros(NF))
+                if settings.norm == "batch":
+                    g.bn.register_buffer("running_mean", torch.zeros(NF))
+                    g.bn.register_buffer("running_var", torch.ones(NF))
+                    g.bn.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+                setattr(holder, f"{blk}ghost{j}", g)
+            setattr(self, attr, holder)
+        self.outconv = _Holder()
+        w = torch.empty(out_channels, NF, 1, 1)
+        nn.init.kaiming_uniform_(w, a=5**0.5)
+        self.outconv.weight = nn.Parameter(w)
+        self.native_rollout = None          # instance attribute shadows the method: AutoRegressiveLightning takes the generic path
+        self.check_required_attributes()
+
+    def _ghost_module(self, g, x):
+        from . import ops_ghost as OG
+        from . import ops_model as OM
+
+        F = torch.nn.functional
+        w = F.pad(g.conv.weight, (0, 0, 0, 0, 0, 0, 0, NF // 2))            # 32 real output channels of a 64-channel launch
+        y = OG.ghost_dw(OM.conv_nhwc(x, w), g.sepconv.weight)               # (B,H,W,64): [primary | depthwise]
+        v = y.permute(0, 3, 1, 2).float()                                   # NCHW-shaped view of features-last memory
+        if self._settings.norm == "batch":
+            v = F.batch_norm(v, g.bn.running_mean, g.bn.running_var, g.bn.weight, g.bn.bias, self.training, 0.1, 1e-5)
+            if self.training:
+                g.bn.num_batches_tracked += 1
+        else:
+            v = F.group_norm(v, self._settings.groups, g.bn.weight, g.bn.bias, 1e-5)
+        return F.relu(v).to(x.dtype).permute(0, 2, 3, 1)
+
+    def _forward_ghost(self, x):
+        F = torch.nn.functional
+        out_dtype = x.dtype
+        x = x.contiguous().to(self.act_dtype)
+        levels = []
+        h = x
+        for k, (blk, attr) in enumerate(zip(BLOCKS[:5], BLOCK_ATTR[:5])):
+            holder = getattr(self, attr)
+            if k > 0:
+                h = F.max_pool2d(h.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+            h = self._ghost_module(getattr(holder, f"{blk}ghost2"), self._ghost_module(getattr(holder, f"{blk}ghost1"), h))
+            levels.append(h)
+        s = levels[0].float()
+        for k in range(1, 5):
+            up = F.interpolate(levels[k].permute(0, 3, 1, 2).float(), scale_factor=2**k, mode="bilinear", align_corners=False)
+            s = s + up.permute(0, 2, 3, 1)
+        dec = self.decoder
+        d = self._ghost_module(dec.decoderghost2, self._ghost_module(dec.decoderghost1, s.to(self.act_dtype)))
+        from . import ops_model as OM
+
+        wout = F.pad(self.outconv.weight, (0, 0, 0, 0, 0, 0, 0, NF - self.out_channels))
+        y = OM.conv_nhwc(d, wout)[..., : self.out_channels]
+        return y if y.dtype == out_dtype or not out_dtype.is_floating_point else y.to(out_dtype)
 
     @property
     def settings(self):
@@ -301,6 +377,8 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             # pad -> plan -> crop; both are torch views / copies, differentiable (the padded border's outputs are dropped)
             y = self.forward(torch.nn.functional.pad(x, (0, 0, left, right, top, bottom)))
             return y[:, top: top + H, left: left + W, :]
+        if self.use_ghost:
+            return self._forward_ghost(x)
         if x.shape[-1] == self.in_channels and self.cin_pad != self.in_channels:
             x = torch.nn.functional.pad(x, (0, self.cin_pad - self.in_channels))
         elif x.shape[-1] != self.cin_pad:

@@ -154,7 +154,7 @@ def test_halfunet_rejects_unsupported_settings():
     from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings
 
     with pytest.raises(NotImplementedError):
-        HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(use_ghost=True))
+        HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(dilation=2))
     with pytest.raises(NotImplementedError):
         HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(num_filters=32))
 

@@ -462,3 +462,71 @@ def test_halfunet_autopad_matches_padded_oracle_and_trains_on_500x500(gpu_device
     loss = lm.training_step(make_batch(case, gpu_device), 0)
     loss.backward()
     assert bool(torch.isfinite(loss)) and all(bool(torch.isfinite(p.grad).all()) for p in lm.model.parameters())
+
+
+# ------------------------------------------------------------------------------------------------ Ghost module (halfunet.yaml:22)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 24), (1, 7, 33), (3, 64, 64)])
+def test_ghost_depthwise_kernels(gpu_device, dtype, tol, B, H, W):
+    """p4c_ghost_dw_fwd / _bwd_data / _wgrad vs torch's grouped convolution in float64: the cheap operation of the Ghost module."""
+    import torch.nn.functional as Fn
+
+    from py4cast_amd.ops_ghost import ghost_dw
+
+    g = torch.Generator().manual_seed(H * W)
+    y = torch.randn(B, H, W, 64, generator=g).to(dtype)
+    w = torch.randn(32, 1, 3, 3, generator=g) * 0.3
+    go = torch.randn(B, H, W, 64, generator=g).to(dtype)
+    yg = y.to(gpu_device).requires_grad_(True)
+    wg = w.to(gpu_device).requires_grad_(True)
+    out = ghost_dw(yg, wg)
+    out.backward(go.to(gpu_device))
+    yr = y.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    prim = yr[..., :32]
+    ref = torch.cat([prim, Fn.conv2d(prim.permute(0, 3, 1, 2), wr, padding=1, groups=32).permute(0, 2, 3, 1)], dim=-1)
+    ref.backward(go.double())
+    assert torch.equal(out[..., :32], yg[..., :32])
+    assert rel_err(out.float(), ref) < tol
+    assert rel_err(yg.grad.float(), yr.grad) < tol and float(yg.grad[..., 32:].abs().sum()) == 0.0
+    assert rel_err(wg.grad, wr.grad) < max(tol, 2e-5)
+
+
+def test_ghost_halfunet_matches_oracle_and_trains(gpu_device):
+    """HalfUNetSettings(use_ghost=True): Ghost blocks (primary 3x3 to 32 channels on the MFMA conv kernels + depthwise cheap
+    operation on csrc/depthwise.hip) against the float64 oracle's GhostModule network, forward (<= 1e-4) and every gradient;
+    then an AR training step through the Lightning module (generic rollout) in bf16."""
+    from oracle.halfunet import HalfUNetRef
+    from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    H, W, cin, cout = 48, 64, 21, 12
+    torch.manual_seed(9)
+    model = HalfUNetMI355X(cin, cout, (H, W), HalfUNetSettings(use_ghost=True))
+    ref = HalfUNetRef(cin, cout, use_ghost=True).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in model.state_dict().items()})
+    model = model.to(gpu_device).train()
+    ref.train()
+    x = torch.randn(2, H, W, cin, generator=torch.Generator().manual_seed(10))
+    gy = torch.randn(2, H, W, cout, generator=torch.Generator().manual_seed(11))
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = model(xg)
+    y.backward(gy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    yr.backward(gy.double())
+    assert rel_err(y, yr) < 1e-4
+    assert rel_err(xg.grad, xr.grad) < 5e-3
+    rg = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        assert rel_err(p.grad, rg[n].grad) < 5e-3, n
+    for n, b in model.named_buffers():
+        if b.dtype.is_floating_point:
+            assert rel_err(b, dict(ref.named_buffers())[n]) < 1e-4, n
+    case = synthetic_case(seed=13, B=2, T=2, H=32, W=32, F=12, Ff=5, Fs=4, border=0)
+    info = make_dataset_info(case, 5)
+    lm = AutoRegressiveLightning({"use_ghost": True, "compute_dtype": "bf16", "activation_dtype": "bf16"}, info, None,
+                                 num_pred_steps_train=2, batch_size=2, model_name="HalfUNet", losses=MSE, training_strategy="scaled_ar").to(gpu_device)
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    assert bool(torch.isfinite(loss)) and all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in lm.model.parameters())
