@@ -516,6 +516,21 @@ int p4c_ghost_dw_bwd_data(const void* dout, const float* w, void* din, int dtype
 int p4c_ghost_dw_wgrad_blocks(int B, int H, int W);
 int p4c_ghost_dw_wgrad(const void* in, const void* dout, float* partial, int dtype, int B, int H, int W, p4c_stream_t stream);
 
+/* ====================================================================================
+ * InstanceNorm2d(affine) + LeakyReLU (+ residual) on features-last tensors (B, N = H*W, C) -- MONAI's UnetResBlock norm
+ * (config/CLI/model/swinunetr.yaml:23, unetrpp.yaml:24 `norm_name: instance`).  C % 4 == 0, C <= 1024.
+ * ==================================================================================== */
+int p4c_inorm_blocks(int64_t N, int C);
+/* partial[b][blk][2][C], blk < p4c_inorm_blocks(N, C).  dy == NULL: sums of x and x^2 (forward statistics).
+ * dy != NULL: sums of dz = dy * (y > 0 ? 1 : slope) and of dz * xhat, xhat = (x - mean[b,c]) * rstd[b,c] (backward). */
+int p4c_inorm_reduce(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope, float* partial,
+                     int dtype, int B, int64_t N, int C, p4c_stream_t stream);
+/* dy == NULL: out = lrelu(x * scale[b,c] + shift[b,c] (+ res)).
+ * dy != NULL: out = dx = scale * (dz - m1[b,c] - xhat * m2[b,c]); dres (optional) = dz. */
+int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
+                    const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres, int dtype,
+                    int B, int64_t N, int C, p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,9 @@ OTHER = {
     "p4c_ghost_dw_bwd_data": ([P, P, P, I, I, I, I, P], c_int),
     "p4c_ghost_dw_wgrad_blocks": ([I, I, I], c_int),
     "p4c_ghost_dw_wgrad": ([P, P, P, I, I, I, I, P], c_int),
+    "p4c_inorm_blocks": ([L, I], c_int),
+    "p4c_inorm_reduce": ([P, P, P, P, P, F, P, I, I, L, I, P], c_int),
+    "p4c_inorm_apply": ([P, P, P, P, P, P, P, P, P, P, F, P, P, I, I, L, I, P], c_int),
     "p4c_ts_gram_splits": ([L], c_int),
     "p4c_ts_gram": ([P, I, L, L, L, P, I, L, L, L, P, I, I, L, I, I, P], c_int),
     "p4c_ts_apply": ([P, I, L, L, L, P, L, P, I, L, L, L, I, I, L, I, I, I, P], c_int),

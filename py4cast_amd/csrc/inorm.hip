@@ -1,0 +1,164 @@
+// InstanceNorm2d(affine) + LeakyReLU (+ residual) on features-last tensors (B, N = H*W, C), C a multiple of 4 up to 1024 -- the
+// normalisation of MONAI's UnetResBlock (SwinUNetR decoder, config/CLI/model/swinunetr.yaml:23 `norm_name: instance`; UNETR++'s
+// full-resolution blocks).  Statistics are per (sample, channel) over the pixels: two streaming passes each way,
+//   forward : sums of x, x^2                        -> (tiny finalize by the caller) -> y = lrelu(x*scale + shift [+ res])
+//   backward: sums of dz, dz*xhat (dz = dy*lrelu')  -> (tiny finalize)              -> dx = scale*(dz - m1 - xhat*m2), dres = dz
+// HBM-bound; 16 B (fp32) / 8 B (bf16) per lane, channel quads across lanes so that a pixel row is read in whole lines.
+#include "common.hpp"
+
+namespace p4c {
+namespace inorm {
+
+__device__ __forceinline__ p4c_f32x4 ld4(const float* p) { return *reinterpret_cast<const p4c_f32x4*>(p); }
+__device__ __forceinline__ p4c_f32x4 ld4(const bf16* p) { return load4f(p); }
+
+// partial[b][blk][0][c] = sum a, [1][c] = sum a*b over the block's pixels, with
+//   MODE 0 (forward):  a = x,  b = x
+//   MODE 1 (backward): a = dz = dy * (y > 0 ? 1 : slope),  b = xhat = (x - mean) * rstd
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, float slope,
+                                                     float* __restrict__ partial, int64_t N, int C) {
+    extern __shared__ float red[];              // [rows][2][C]
+    const int b = blockIdx.y, cqn = C >> 2;
+    const int rows = 256 / cqn > 0 ? 256 / cqn : 1;
+    const T* xb = x + (int64_t)b * N * C;
+    const T* dyb = MODE ? dy + (int64_t)b * N * C : nullptr;
+    const T* yb = MODE ? y + (int64_t)b * N * C : nullptr;
+    for (int q0 = 0; q0 < cqn; q0 += 256) {     // (C > 1024 never happens; one trip)
+        const int q = q0 + (int)(threadIdx.x % (cqn < 256 ? cqn : 256)), pl = threadIdx.x / (cqn < 256 ? cqn : 256);
+        p4c_f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, mu = s1, rs = s1;
+        const bool live = pl < rows && q < cqn;
+        if (live && MODE) { mu = ld4(mean + b * C + 4 * q); rs = ld4(rstd + b * C + 4 * q); }
+        if (live)
+            for (int64_t p = (int64_t)blockIdx.x * rows + pl; p < N; p += (int64_t)gridDim.x * rows) {
+                const p4c_f32x4 xv = ld4(xb + p * C + 4 * q);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s1[k] += xv[k]; s2[k] = __builtin_fmaf(xv[k], xv[k], s2[k]); }
+                } else {
+                    const p4c_f32x4 g = ld4(dyb + p * C + 4 * q), yv = ld4(yb + p * C + 4 * q);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dz = yv[k] > 0.f ? g[k] : g[k] * slope;
+                        s1[k] += dz;
+                        s2[k] = __builtin_fmaf(dz, (xv[k] - mu[k]) * rs[k], s2[k]);
+                    }
+                }
+            }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { red[(pl * 2 + 0) * C + 4 * q + k] = s1[k]; red[(pl * 2 + 1) * C + 4 * q + k] = s2[k]; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += red[r * 2 * C + i];
+        partial[((int64_t)b * gridDim.x + blockIdx.x) * 2 * C + i] = s;
+    }
+}
+
+// forward: y = lrelu(x * scale[b,c] + shift[b,c] (+ res));  backward (MODE 1): dx = scale * (dz - m1 - xhat * m2), dres = dz
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ dy,
+                                                    const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ m1,
+                                                    const float* __restrict__ m2, float slope, T* __restrict__ out, T* __restrict__ dres,
+                                                    int64_t N, int C) {
+    const int b = blockIdx.y, cqn = C >> 2;
+    const int64_t total = N * cqn;
+    const int64_t base = (int64_t)b * N * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i % cqn);
+        const int64_t off = base + (i / cqn) * C + 4 * q;
+        const p4c_f32x4 xv = ld4(x + off);
+        p4c_f32x4 o;
+        if (MODE == 0) {
+            const p4c_f32x4 sc = ld4(scale + b * C + 4 * q), sh = ld4(shift + b * C + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(xv[k], sc[k], sh[k]);
+            if (res) {
+                const p4c_f32x4 rv = ld4(res + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] += rv[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : o[k] * slope;
+            store4f(out + off, o);
+        } else {
+            const p4c_f32x4 g = ld4(dy + off), yv = ld4(y + off);
+            const p4c_f32x4 sc = ld4(scale + b * C + 4 * q), mu = ld4(mean + b * C + 4 * q), rs = ld4(rstd + b * C + 4 * q);
+            const p4c_f32x4 a1 = ld4(m1 + b * C + 4 * q), a2 = ld4(m2 + b * C + 4 * q);
+            p4c_f32x4 dz;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dz[k] = yv[k] > 0.f ? g[k] : g[k] * slope;
+                o[k] = sc[k] * (dz[k] - a1[k] - (xv[k] - mu[k]) * rs[k] * a2[k]);
+            }
+            store4f(out + off, o);
+            if (dres) store4f(dres + off, dz);
+        }
+    }
+}
+
+static int blocks_for(int64_t N, int rows) {
+    int64_t nb = (N + (int64_t)rows * 8 - 1) / ((int64_t)rows * 8);    // >= 8 pixels per thread row
+    if (nb > 256) nb = 256;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+}  // namespace inorm
+}  // namespace p4c
+
+using namespace p4c;
+
+extern "C" int p4c_inorm_blocks(int64_t N, int C) {
+    const int cqn = C / 4, rows = 256 / cqn > 0 ? 256 / cqn : 1;
+    return inorm::blocks_for(N, rows);
+}
+
+extern "C" int p4c_inorm_reduce(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope,
+                                float* partial, int dtype, int B, int64_t N, int C, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && partial && B > 0 && N > 0 && C > 0 && C % 4 == 0 && C <= 1024, "p4c_inorm_reduce: C must be a multiple of 4 up to 1024");
+    const bool bwd = dy != nullptr;
+    P4C_CHECK_ARG(!bwd || (y && mean && rstd), "p4c_inorm_reduce: the backward sums need y, mean and rstd");
+    const int cqn = C / 4, rows = 256 / cqn > 0 ? 256 / cqn : 1;
+    const dim3 grid(inorm::blocks_for(N, rows), B);
+    const size_t smem = (size_t)rows * 2 * C * sizeof(float);
+    hipStream_t st = as_stream(stream);
+#define P4C_IN_RED(T, M)                                                                                             \
+    do {                                                                                                             \
+        P4C_TRY(ensure_dyn_smem((const void*)inorm::reduce_kernel<T, M>, 64 * 1024));                                \
+        hipLaunchKernelGGL((inorm::reduce_kernel<T, M>), grid, dim3(256), smem, st, (const T*)x, (const T*)dy, (const T*)y, mean, \
+                           rstd, slope, partial, N, C);                                                              \
+    } while (0)
+    if (dtype == P4C_F32) { if (bwd) P4C_IN_RED(float, 1); else P4C_IN_RED(float, 0); }
+    else if (dtype == P4C_BF16) { if (bwd) P4C_IN_RED(bf16, 1); else P4C_IN_RED(bf16, 0); }
+    else return fail(P4C_ERR_INVALID, "p4c_inorm_reduce: bad dtype");
+#undef P4C_IN_RED
+    P4C_CHECK_LAUNCH("p4c_inorm_reduce");
+    return P4C_OK;
+}
+
+extern "C" int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres,
+                               int dtype, int B, int64_t N, int C, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && out && scale && B > 0 && N > 0 && C > 0 && C % 4 == 0, "p4c_inorm_apply: bad arguments");
+    const bool bwd = dy != nullptr;
+    P4C_CHECK_ARG(bwd ? (y && mean && rstd && m1 && m2) : (shift != nullptr), "p4c_inorm_apply: missing operands");
+    int64_t blocks = (N * (C / 4) + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 8 / B + 1;
+    if (blocks > cap) blocks = cap;
+    const dim3 grid((unsigned)blocks, B);
+    hipStream_t st = as_stream(stream);
+#define P4C_IN_APP(T, M)                                                                                                        \
+    hipLaunchKernelGGL((inorm::apply_kernel<T, M>), grid, dim3(256), 0, st, (const T*)x, (const T*)res, (const T*)dy, (const T*)y, scale, \
+                       shift, mean, rstd, m1, m2, slope, (T*)out, (T*)dres, N, C)
+    if (dtype == P4C_F32) { if (bwd) P4C_IN_APP(float, 1); else P4C_IN_APP(float, 0); }
+    else if (dtype == P4C_BF16) { if (bwd) P4C_IN_APP(bf16, 1); else P4C_IN_APP(bf16, 0); }
+    else return fail(P4C_ERR_INVALID, "p4c_inorm_apply: bad dtype");
+#undef P4C_IN_APP
+    P4C_CHECK_LAUNCH("p4c_inorm_apply");
+    return P4C_OK;
+}

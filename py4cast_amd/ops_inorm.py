@@ -1,0 +1,66 @@
+"""InstanceNorm2d(affine) + LeakyReLU (+ residual) on features-last tensors as ONE autograd node on the kernels of csrc/inorm.hip
+(include/py4cast_hip.h: p4c_inorm_reduce / p4c_inorm_apply): two streaming passes each way instead of torch's reductions and
+elementwise chains (the UNETR decoder of SwinUNetR spent a third of its step in them).  No CPU fallback."""
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _reduce(x, dy, y, mean, rstd, slope):
+    B, C = x.shape[0], x.shape[-1]
+    N = x.numel() // (B * C)
+    nb = L.lib().p4c_inorm_blocks(N, C)
+    part = torch.empty(B, nb, 2, C, dtype=torch.float32, device=x.device)
+    L.call("p4c_inorm_reduce", L.ptr(x), L.ptr(dy), L.ptr(y), L.ptr(mean), L.ptr(rstd), float(slope), L.ptr(part), L.dtype_code(x.dtype),
+           B, N, C, L.stream(x.device))
+    return part.sum(dim=1), N       # (B, 2, C): fixed order
+
+
+class _InstNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, eps, slope):
+        L.require_cuda(x)
+        x = x.contiguous()
+        res_c = None if res is None else res.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        sums, N = _reduce(x, None, None, None, None, slope)
+        mean = sums[:, 0] / N
+        var = (sums[:, 1] / N - mean * mean).clamp_min(0)
+        rstd = torch.rsqrt(var + eps)
+        scale = (rstd * weight.float()).contiguous()
+        shift = (bias.float() - mean * scale).contiguous()
+        y = torch.empty_like(x)
+        L.call("p4c_inorm_apply", L.ptr(x), L.ptr(res_c), None, None, L.ptr(scale), L.ptr(shift), None, None, None, None, float(slope),
+               L.ptr(y), None, L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
+        ctx.save_for_backward(x, y, mean.contiguous(), rstd.contiguous(), scale)
+        ctx.slope, ctx.has_res, ctx.pdtype = slope, res is not None, weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd, scale = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[-1]
+        dy = dy.contiguous()
+        sums, N = _reduce(x, dy, y, mean, rstd, ctx.slope)
+        m1, m2 = (sums[:, 0] / N).contiguous(), (sums[:, 1] / N).contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        L.call("p4c_inorm_apply", L.ptr(x), None, L.ptr(dy), L.ptr(y), L.ptr(scale), None, L.ptr(mean), L.ptr(rstd), L.ptr(m1), L.ptr(m2),
+               float(ctx.slope), L.ptr(dx), L.ptr(dres), L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
+        dgamma = sums[:, 1].sum(dim=0).to(ctx.pdtype)
+        dbeta = sums[:, 0].sum(dim=0).to(ctx.pdtype)
+        return dx, dgamma, dbeta, dres, None, None
+
+
+def supported(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024
+
+
+def instance_norm_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, slope: float = 0.01,
+                      res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``leaky_relu(instance_norm(x) * weight + bias (+ res), slope)`` for x (B, *spatial, C) features-last; slope = 1 gives the plain
+    affine instance norm."""
+    return _InstNormAct.apply(x, weight, bias, res, float(eps), float(slope))

@@ -94,16 +94,20 @@ class _ConvNHWC(torch.autograd.Function):
 
 def conv_nhwc_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
     CO, CI, ks, ks2 = w.shape
-    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and CO == 64 and ks == ks2 and ks in (1, 3) and CI <= 96
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and CO <= 64 and ks == ks2 and ks in (1, 3) and CI <= 96
             and x.dim() == 4)
 
 
 def conv_nhwc(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """x (B,H,W,CI) features-last, w (64,CI,ks,ks) canonical torch weight -> (B,H,W,64).  The input is zero-padded to a multiple of 32
-    channels when needed (one copy); 32 / 64 / 96-channel inputs are taken as they are."""
-    CI = w.shape[1]
+    """x (B,H,W,CI) features-last, w (CO<=64,CI<=96,ks,ks) canonical torch weight -> (B,H,W,CO).  The kernels work on 32 / 64 / 96
+    input channels and 64 output channels: the input is zero-padded to a multiple of 32 channels when needed (one copy), fewer
+    output channels run as zero rows of a 64-channel launch and are sliced off (a view)."""
+    CO, CI = w.shape[0], w.shape[1]
     cp = _pad32(CI)
     if x.shape[-1] != cp:
         x = torch.nn.functional.pad(x, (0, cp - x.shape[-1]))
+    if CO < 64:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, 64 - CO))
     compute = "bf16" if x.dtype == torch.bfloat16 else "f32"
-    return _ConvNHWC.apply(x.contiguous(), w, compute)
+    y = _ConvNHWC.apply(x.contiguous(), w, compute)
+    return y if CO == 64 else y[..., :CO]

@@ -209,3 +209,36 @@ def row_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = Non
     if _native_wgrad_ok(x, w.shape[0], w.shape[1]):
         return _RowLinear.apply(x, w, b)
     return F.linear(x, w.to(x.dtype), None if b is None else b.to(x.dtype))
+
+
+class _LinearND(torch.autograd.Function):
+    """y = x W^T + b on (..., K) tensors of the activation dtype with fp32 master weights: library GEMMs for y, dx and dW; the bias
+    gradient is ``ones @ dy`` -- a GEMM too -- instead of a column reduction of dy: under HIP-graph replay at the 512 x 512 sizes the
+    reduction route handed back garbage for exactly the Linear biases of SwinUNetR / UNetRPP (tools/diagnostics/nan_probe.py), and a
+    (1 x R) GEMM is also the cheaper launch."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        wq = w.to(x.dtype)
+        ctx.save_for_backward(x, wq)
+        ctx.has_bias, ctx.wdtype, ctx.bdtype = b is not None, w.dtype, (None if b is None else b.dtype)
+        return F.linear(x, wq, None if b is None else b.to(x.dtype))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        O, K = wq.shape
+        dy2 = dy.reshape(-1, O)
+        x2 = x.reshape(-1, K)
+        dx = (dy2 @ wq).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = (dy2.t() @ x2).to(ctx.wdtype) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            ones = torch.ones(1, dy2.shape[0], dtype=dy2.dtype, device=dy2.device)
+            db = (ones @ dy2)[0].to(ctx.bdtype)
+        return dx, dw, db
+
+
+def linear_nd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear`` for activations of any rank with fp32 parameters (cast once per call), gradients as GEMMs."""
+    return _LinearND.apply(x, w, b)

@@ -11,8 +11,12 @@ What runs where
 * window attention of every Swin block: ONE HIP kernel each way (csrc/attention.hip through py4cast_amd.ops_attention) on the
   (B, Hp, Wp, 3C) output of the qkv Linear -- shift, window partition, head split, bias, mask, softmax, PV and all inverses;
 * LayerNorms of the Swin blocks: csrc/rows.hip (row LayerNorm) when the row fits its limits;
-* Linear layers: library GEMMs; the UNETR decoder's 3x3 / transposed convolutions and instance norms: torch (MIOpen) -- the
-  decoder is NOT yet on native kernels.
+* UNETR decoder (round 2): features-last throughout, no layout change anywhere; its 3x3 / 1x1 convolutions with <= 96 input and
+  <= 64 output channels -- everything from the 1/4 resolution upwards -- on the MFMA conv kernels (ops_model.conv_nhwc: forward,
+  data and weight gradient); the 2x2 transposed convolutions, the patch embedding and the output convolution are GEMMs over
+  pixel blocks (library); instance norm + LeakyReLU + residual add = one native node each (csrc/inorm.hip, ops_inorm).  The four wider
+  convolutions at <= 1/8 resolution still go through MIOpen (_conv_hw).
+* Linear layers: library GEMMs.
 Input / output are features-last (B, H, W, C); H and W must be multiples of 32.
 """
 
@@ -24,6 +28,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
+from . import ops_inorm as ON
+from . import ops_model as OM
 from . import ops_rows as R
 from .base import ModelABC, ModelType
 from .ops_attention import window_attention
@@ -71,7 +77,7 @@ def _layer_norm(m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
 
 
 def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
-    return F.linear(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
+    return R.linear_nd(x, m.weight, m.bias)
 
 
 class SwinBlock(nn.Module):
@@ -117,8 +123,25 @@ class PatchMerging(nn.Module):
         return _linear(self.reduction, _layer_norm(self.norm, x))
 
 
+def _conv_hw(m: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """A bias-free "same" convolution on a features-last tensor (B,H,W,C).  Up to 96 input and 64 output channels -- every
+    convolution of the decoder from the 1/4 resolution upwards, where its time goes -- run on the MFMA conv kernels (forward, data
+    and weight gradient: ops_model.conv_nhwc); the few wider ones at <= 1/8 resolution go through the library in its own layout."""
+    if OM.conv_nhwc_supported(x, m.weight):
+        return OM.conv_nhwc(x, m.weight)
+    y = F.conv2d(x.permute(0, 3, 1, 2).contiguous(), m.weight.to(x.dtype), None, padding=m.padding)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def _inorm(m: nn.InstanceNorm2d, x: torch.Tensor, slope: float = 1.0, res=None) -> torch.Tensor:
+    """leaky_relu(InstanceNorm2d(affine)(x) (+ res), slope) on a features-last tensor as one native node (csrc/inorm.hip): statistics
+    over (H, W) per sample and channel in fp32; slope = 1: no activation."""
+    return ON.instance_norm_act(x, m.weight, m.bias, m.eps, slope, res)
+
+
 class ResBlock(nn.Module):
-    """MONAI's UnetResBlock: conv3x3 - IN - LeakyReLU - conv3x3 - IN, (+ 1x1 conv - IN on the skip when channels differ), LeakyReLU."""
+    """MONAI's UnetResBlock: conv3x3 - IN - LeakyReLU - conv3x3 - IN, (+ 1x1 conv - IN on the skip when channels differ), LeakyReLU.
+    Features-last (B,H,W,C) in and out."""
 
     def __init__(self, cin: int, cout: int):
         super().__init__()
@@ -132,10 +155,9 @@ class ResBlock(nn.Module):
             self.norm3 = nn.InstanceNorm2d(cout, affine=True)
 
     def forward(self, x):
-        out = F.leaky_relu(self.norm1(self.conv1(x)), 0.01)
-        out = self.norm2(self.conv2(out))
-        res = self.norm3(self.conv3(x)) if self.down else x
-        return F.leaky_relu(out + res, 0.01)
+        out = _inorm(self.norm1, _conv_hw(self.conv1, x), 0.01)
+        res = _inorm(self.norm3, _conv_hw(self.conv3, x)) if self.down else x
+        return _inorm(self.norm2, _conv_hw(self.conv2, out), 0.01, res)    # lrelu(norm2(conv2(out)) + res), one pass
 
 
 class UpBlock(nn.Module):
@@ -145,7 +167,14 @@ class UpBlock(nn.Module):
         self.conv_block = ResBlock(2 * cout, cout)
 
     def forward(self, x, skip):
-        return self.conv_block(torch.cat([self.transp_conv(x), skip], dim=1))
+        # 2x2 / stride-2 transposed convolution = one GEMM per pixel block: (B*H*W, cin) @ (cin, 2*2*cout), then the 2x2 outputs of
+        # every input pixel are interleaved into the up-sampled grid
+        B, H, W, cin = x.shape
+        wt = self.transp_conv.weight                                         # (cin, cout, 2, 2)
+        cout = wt.shape[1]
+        wr = wt.permute(0, 2, 3, 1).reshape(cin, 4 * cout).to(x.dtype)
+        up = (x.reshape(-1, cin) @ wr).view(B, H, W, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, cout)
+        return self.conv_block(torch.cat([up, skip], dim=-1))
 
 
 class SwinUNetRMI355X(ModelABC, nn.Module):
@@ -187,29 +216,36 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         self.out = nn.Conv2d(fs, out_channels, 1)
         self.timed_entry_points = ("p4c_window_attn_fwd", "p4c_window_attn_bwd", "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd")
         self.roofline_from_entry_points = True   # bench.py: time every call of the entry points above
+        self.prefers_hip_graph = True            # ~10^3-10^4 launches per training step: replay them from a HIP graph (trainer.GraphedTrainingStep)
         self.check_required_attributes()
 
     @property
     def settings(self) -> SwinUNetRSettings:
         return self._settings
 
-    def _hidden(self, t: torch.Tensor) -> torch.Tensor:
-        """A Swin hidden state handed to the decoder: layer-normalised over channels without affine (MONAI's proj_out), NCHW fp32."""
-        t = t.float()
+    def _hidden(self, t: torch.Tensor, dt) -> torch.Tensor:
+        """A Swin hidden state handed to the decoder: layer-normalised over channels without affine (MONAI's proj_out); stays
+        features-last."""
         if self._settings.normalize:
-            t = F.layer_norm(t, (t.shape[-1],))
-        return t.permute(0, 3, 1, 2).contiguous()
+            t = F.layer_norm(t.float(), (t.shape[-1],))
+        return t.to(dt)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        xin = x.permute(0, 3, 1, 2).contiguous()                   # the conv decoder is channels-second
+        """(B,H,W,C) -> (B,H,W,out).  Everything is features-last: no layout change anywhere in the network."""
+        L.require_cuda(x)
         dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
-        t = self.patch_embed(xin).permute(0, 2, 3, 1).contiguous().to(dt)
-        hidden = [self._hidden(t)]
+        B, H, W, C = x.shape
+        xin = x.to(dt)
+        # patch embedding: 2x2 / stride-2 convolution with bias = a GEMM over the 2x2 patches
+        pw = self.patch_embed.weight                                          # (fs, C, 2, 2)
+        patches = xin.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C)
+        t = R.linear_nd(patches, pw.permute(0, 2, 3, 1).reshape(pw.shape[0], 4 * C), self.patch_embed.bias)
+        hidden = [self._hidden(t, dt)]
         for blocks, merge in zip(self.stages, self.merges):
             for blk in blocks:
                 t = blk(t)
             t = merge(t)
-            hidden.append(self._hidden(t))
+            hidden.append(self._hidden(t, dt))
         enc0 = self.encoder1(xin)
         enc1 = self.encoder2(hidden[0])
         enc2 = self.encoder3(hidden[1])
@@ -220,7 +256,9 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         dec1 = self.decoder3(dec2, enc2)
         dec0 = self.decoder2(dec1, enc1)
         out = self.decoder1(dec0, enc0)
-        return self.out(out).permute(0, 2, 3, 1).contiguous()
+        ow = self.out.weight
+        y = R.linear_nd(out, ow.view(ow.shape[0], ow.shape[1]), self.out.bias)
+        return y if y.dtype == x.dtype or not x.dtype.is_floating_point else y.to(x.dtype)
 
     # ------------------------------------------------------------------ bench.py hook
     def roofline(self, ktimes, B, H, W):

