@@ -292,11 +292,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    # P4C_DIST_SHARE_GPU=1 (tests on a 1-GPU box only): every rank on cuda:0, gloo transport -- exercises the N > 1 code path of this
+    # script (barriers, MAX over ranks, aggregate value); the number it prints is NOT a scaling measurement
+    share_gpu = os.environ.get("P4C_DIST_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from py4cast_amd import _lib as L
     from py4cast_amd.lightning import AutoRegressiveLightning
@@ -437,14 +445,14 @@ def main():
         L.enable_kernel_timing(None)
     L.lib().p4c_prof_enable(0, 0)
     extra = None
-    if rank == 0 and has_roofline and not use_graph and not getattr(lm.model, "roofline_from_entry_points", False) \
-            and hasattr(lm.model, "launch_times"):
+    if has_roofline and not use_graph and not getattr(lm.model, "roofline_from_entry_points", False) \
+            and hasattr(lm.model, "launch_times"):   # (every rank: the step contains the gradient exchange)
         # ONE extra un-timed step with every tagged launch bracketed by events: data-gradient and weight-gradient launch times
         # of the roofline kernel's siblings (they overlap each other in the backward plan, hence reported apart)
         L.lib().p4c_prof_enable(7, 4096)
         step(args.warmup + args.steps)
         torch.cuda.synchronize()
-        extra = lm.model.launch_times(B=B, H=H, W=W)
+        extra = lm.model.launch_times(B=B, H=H, W=W) if rank == 0 else None
         L.lib().p4c_prof_enable(0, 0)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -492,7 +500,7 @@ def main():
                 "workload": f"{args.model} {args.strategy} rollout T={T}, grid {H}x{W}x{F} (+{Ff} forcings, {Fs} statics), "
                             f"WeightedLoss(MSE), AdamW, B={B}/GPU",
                 "global_batch": world * B,
-                "parallelism": f"dp{world}",
+                "parallelism": f"dp{world}" + (" (ranks sharing one GPU over gloo: functional test, not a scaling number)" if share_gpu else ""),
                 "border_size": args.border,
                 "setup_steps": args.setup_steps,
                 "accumulate_grad_batches": args.accumulate,

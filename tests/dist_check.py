@@ -13,11 +13,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main(out_dir, sharded):
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    # P4C_DIST_SHARE_GPU=1: every rank on cuda:0 with the gloo backend (device tensors staged through the host) -- what a 1-GPU box
+    # can run: the ranks' kernels, FlatDDP's communication-stream logic and the sharded optimizer are the real ones, only the
+    # transport is not RCCL
+    share = os.environ.get("P4C_DIST_SHARE_GPU") == "1"
+    local = 0 if share else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     from helpers import make_batch, make_dataset_info, synthetic_case
     from py4cast_amd.lightning import AutoRegressiveLightning
     from py4cast_amd.trainer import FlatDDP
