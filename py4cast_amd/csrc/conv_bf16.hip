@@ -1686,7 +1686,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         Cur lc = cur_init(), sc_ = cur_init();
         // same number of memory operations on every path (see conv3x3_bf16_ring_kernel): exact s_waitcnt counts
         auto load = [&](Img& im) __attribute__((always_inline)) {
-            const bool live = lc.t < t_end;
+            const bool live = lc.t < t_end && !((P4C_EXP & 2) && lc.t > t_begin + 1);
             const int b = live ? lc.b : 0, y0 = live ? lc.ty * TH : 0, x0 = live ? lc.tx * BTW : 0;
             cur_next(lc);
             const __amdgpu_buffer_rsrc_t rsi = make_rsrc(inb + (int64_t)b * H * W * in_cs, (unsigned)(((int64_t)H * W * in_cs - ci_off) * 2));
@@ -1721,7 +1721,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         auto store = [&](const Img& im, char* buf) __attribute__((always_inline)) {
             const int t = sc_.t, b = sc_.b, y0 = sc_.ty * TH, x0 = sc_.tx * BTW;
             cur_next(sc_);
-            if (t >= t_end) return;
+            if (t >= t_end || ((P4C_EXP & 1) && t > t_begin + 1)) return;
             if (MODE >= 2 && b != sc_b) {
                 sc_b = b;
 #pragma unroll
@@ -1805,7 +1805,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             };
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < ((P4C_EXP & 16) ? 0 : 2); ++half) {
                 const int col0 = half * 16;
                 s16x4 bo[TH][2];
 #pragma unroll
