@@ -74,19 +74,48 @@ def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
 
 
 def _conv(m, x):
-    """3x3 / 1x1 convolutions to 64 channels from <= 96 (the full-resolution residual blocks at the yaml's hidden_size 1024: the
-    HalfUNet kernels' shapes) run on the native MFMA kernels, features-last in memory (a channels_last tensor's permute is a
-    view); the rest through the library."""
-    if (type(m) is nn.Conv2d and m.bias is None and m.stride == (1, 1) and m.dilation == (1, 1) and m.groups == 1
-            and m.padding == (m.kernel_size[0] // 2,) * 2 and OM.conv_nhwc_supported(x, m.weight)):
-        y = OM.conv_nhwc(x.permute(0, 2, 3, 1), m.weight)                  # (B,H,W,64)
-        return y.permute(0, 3, 1, 2)                                      # NCHW-shaped view of features-last memory (channels_last)
+    """A convolution on an NCHW-shaped view of features-last memory (channels_last), by shape:
+      * 3x3 / 1x1 "same", bias-free, to 64 channels from <= 96 (the full-resolution residual blocks at the yaml's hidden_size
+        1024: the HalfUNet kernels' shapes): the native MFMA kernels, forward, data and weight gradient;
+      * kernel == stride > 1 without padding (the patch stem and the 2x2 down-samplings): one GEMM over the features-last pixel
+        blocks (ops_rows.linear_nd: gradients as GEMMs too) -- the library's strided weight-gradient kernel for the stem took
+        5 ms per call (405 -> 368 ms per 6-step training step at the 512 x 512 bench sizes);
+      * the rest (the 3x3 blocks wider than 64 channels at <= 1/4 resolution and the 1x1 convolutions with bias): the library.
+        (The 1x1 ones as GEMMs measured slower, and their HIP-graph replays lost the loss to NaN: not used.)"""
+    if type(m) is nn.Conv2d and m.dilation == (1, 1) and m.groups == 1 and m.kernel_size[0] == m.kernel_size[1]:
+        k = m.kernel_size[0]
+        same = m.stride == (1, 1) and m.padding == (k // 2,) * 2
+        if m.bias is None and same and OM.conv_nhwc_supported(x, m.weight):
+            y = OM.conv_nhwc(x.permute(0, 2, 3, 1), m.weight)              # (B,H,W,64)
+            return y.permute(0, 3, 1, 2)                                  # NCHW-shaped view of features-last memory (channels_last)
+        if k > 1 and m.stride == (k, k) and m.padding == (0, 0) and x.shape[2] % k == 0 and x.shape[3] % k == 0:
+            xl = x.permute(0, 2, 3, 1)
+            B, H, W, C = xl.shape
+            if k > 1:
+                xl = xl.reshape(B, H // k, k, W // k, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // k, W // k, k * k * C)
+            w = m.weight.permute(0, 2, 3, 1).reshape(m.weight.shape[0], k * k * C)
+            return R.linear_nd(xl, w, m.bias).permute(0, 3, 1, 2)
     return m._conv_forward(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
+
+
+def _conv_transpose(m: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
+    """kernel == stride transposed convolution (bias-free): (rows, cin) @ (cin, s*s*cout), then the s x s outputs of every input
+    pixel are interleaved into the up-sampled grid (one copy)."""
+    s = m.stride[0]
+    xl = x.permute(0, 2, 3, 1)
+    B, H, W, cin = xl.shape
+    wt = m.weight                                                        # (cin, cout, s, s)
+    cout = wt.shape[1]
+    wr = wt.permute(2, 3, 1, 0).reshape(s * s * cout, cin)               # Linear weight: (outputs, cin)
+    up = R.linear_nd(xl, wr).view(B, H, W, s, s, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H * s, W * s, cout)
+    return up.permute(0, 3, 1, 2)
 
 
 def _nrm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """group / batch / instance norm with fp32 parameters and statistics on a tensor of the activation dtype"""
-    return m(x) if x.dtype == torch.float32 else m(x.float()).to(x.dtype)
+    if x.dtype in (torch.float32, torch.float64) or isinstance(m, nn.BatchNorm2d):   # the library's batch norm takes bf16 activations with fp32 parameters / statistics
+        return m(x)
+    return m(x.float()).to(x.dtype)
 
 
 def _layer_norm(m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
@@ -201,7 +230,7 @@ class UpBlock(nn.Module):
         if self.linear:
             x = _conv(self.up_conv, F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=False))
         else:
-            x = F.conv_transpose2d(x, self.up_conv.weight.to(x.dtype), None, stride=self.scale)
+            x = _conv_transpose(self.up_conv, x)
         return self.decoder_block[0](x + skip)
 
 
