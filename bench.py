@@ -412,6 +412,7 @@ def main():
         L.lib().p4c_prof_filter(B * H * W)
     barrier()
     roof_model = None
+    graph_note = None
     if use_graph:
         # kernel timings for the roofline object come from two eager steps (a replayed graph has no per-call host hooks);
         # then the micro-batch is captured and the warm-up + timed steps replay it
@@ -424,7 +425,12 @@ def main():
         L.enable_kernel_timing(None)
         L.lib().p4c_prof_enable(0, 0)   # no event markers inside a capture
         ddp.zero_grad()
-        graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
+        try:
+            graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
+            graph_note = graphed[0].verified
+        except Exception as exc:  # noqa: BLE001  (not capturable, or a replay that does not reproduce the eager step: stay eager)
+            print(f"bench: HIP graph not used ({type(exc).__name__}: {exc}); eager launching", file=sys.stderr)
+            graphed[0], use_graph, graph_note = None, False, f"rejected: {type(exc).__name__}"
         ddp.zero_grad()
         for i in range(args.warmup):
             step(i)
@@ -504,7 +510,7 @@ def main():
                 "border_size": args.border,
                 "setup_steps": args.setup_steps,
                 "accumulate_grad_batches": args.accumulate,
-                "hip_graph": bool(use_graph),
+                "hip_graph": bool(use_graph), "hip_graph_check": graph_note,
                 "launch_mode_probe": probe,
             },
             "loss": float(loss.detach()),

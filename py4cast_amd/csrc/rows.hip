@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256)
             dg[i] += __shfl_xor(dg[i], o, 64);
             db[i] += __shfl_xor(db[i], o, 64);
         }
-    __shared__ float wred[4][2 * 256];   // C <= 256 (1 KiB rows of fp32)
+    __shared__ float wred[4][2 * 512];   // C <= 512 (1 KiB rows: 256 fp32 or 512 bf16 features)
     const int wv = threadIdx.x >> 6;
     if (sub == 0 && cok) {
 #pragma unroll

@@ -211,6 +211,10 @@ class FlatDDP:
             off += n
 
 
+class GraphReplayMismatch(RuntimeError):
+    """A captured training step whose replay does not reproduce the eager step (GraphedTrainingStep._verify)."""
+
+
 class GraphedTrainingStep:
     """One micro-batch -- ``training_step`` (rollout + loss) and its ``backward`` -- captured in a HIP graph and replayed.
 
@@ -222,7 +226,7 @@ class GraphedTrainingStep:
     Shapes must not change between steps; a module whose step synchronises with the host cannot be captured (the constructor
     raises, nothing is left half-captured)."""
 
-    def __init__(self, module, sample_batch, loss_scale: float = 1.0, warmup: int = 3):
+    def __init__(self, module, sample_batch, loss_scale: float = 1.0, warmup: int = 3, verify: bool = True):
         from .base import ItemBatch
         from .namedtensor import NamedTensor
 
@@ -250,11 +254,22 @@ class GraphedTrainingStep:
 
         gc.collect()
 
+        verify = verify and warmup >= 3
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+
+        def grads():   # every gradient of the module as one fp32 vector (None until the first backward has allocated them)
+            if any(p.grad is None for _, p in named):
+                return None
+            return torch.cat([p.grad.detach().reshape(-1).float() for _, p in named])
+
+        snaps, eager_loss = [], None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for i in range(warmup):      # lazy initialisation (edge sets, kernel attributes, allocator pools) happens here
-                run(i)
+                eager_loss = run(i)
+                if verify and i >= warmup - 3:
+                    snaps.append(grads())
         torch.cuda.current_stream().wait_stream(side)
         from . import _lib as L
 
@@ -266,6 +281,57 @@ class GraphedTrainingStep:
         finally:
             L.CAPTURE_SCOPE[0] = None
         self.warmup_backwards = warmup + 1   # gradient contributions already accumulated by construction: zero_grad() after
+        self.verified = None
+        if verify and all(g is not None for g in snaps):
+            self._verify(named, snaps, eager_loss.clone(), grads)
+            self.warmup_backwards += 1
+
+    def _verify(self, named, snaps, eager_loss, grads):
+        """Replay the captured step once on the captured batch and hold its gradient contribution and loss against the eager
+        warm-up passes on the same batch and weights.  A replay is only as good as every library call inside it is capture-safe,
+        and that is not ours to promise: at the 512 x 512 sizes two library routes returned garbage / NaN from replays while
+        every eager step was fine (the column-sum reduction behind Linear bias gradients, and 1x1 convolutions as bias-epilogue
+        GEMMs -- DESIGN.md 7b).  So the graph has to earn its use: per parameter, the replay's gradient must match the eager one to
+        the level two eager passes match each other (steps with a random element -- masks, dropout -- differ between eager
+        passes too and are not checked), else the constructor raises GraphReplayMismatch and callers stay eager."""
+        g1, g2, g3 = snaps
+        inc_a, inc_b = g2 - g1, g3 - g2          # two eager contributions
+        self.graph.replay()
+        inc_g = grads() - g3
+        graph_loss = self.loss.float()
+        lengths = torch.tensor([p.numel() for _, p in named], device=inc_g.device)
+
+        def per_param(diff, ref):   # relative L2 error of every parameter's gradient
+            num = torch.segment_reduce(diff.double().square(), "sum", lengths=lengths)
+            den = torch.segment_reduce(ref.double().square(), "sum", lengths=lengths)
+            return (num / den.clamp_min(1e-300)).sqrt(), den
+
+        base, den = per_param(inc_b - inc_a, inc_b)
+        got, _ = per_param(inc_g - inc_b, inc_b)
+        live = den > 1e-24 * den.sum()     # a parameter whose gradient is (numerically) nothing has no relative error to judge
+        finite = bool(torch.isfinite(inc_g).all()) or not bool(torch.isfinite(inc_b).all())
+        # two eager passes on one batch and one set of weights that differ by percents: a random element in the step (masks,
+        # dropout), or bf16 activations + atomics whose accumulation order moves LeakyReLU / softmax branches (SwinUNetR and
+        # UNetRPP at 512 x 512).  Such a step is held to its own noise: only a replay far outside it -- or not finite -- fails
+        noisy = bool((base[live] > 5e-2).float().mean() > 0.1) if bool(live.any()) else False
+        floor = 1.0 if noisy else 2e-2
+        tol = torch.maximum(10.0 * base, torch.full_like(base, floor))
+        bad = (live & ~(got <= tol)).nonzero().flatten().tolist()      # `~(<=)`: NaN counts as bad
+        loss_ok = bool(torch.isfinite(graph_loss)) and (   # (a step with a random element has no single eager loss to compare with)
+            noisy or abs(float(graph_loss) - float(eager_loss)) <= 1e-3 * abs(float(eager_loss)) + 1e-6)
+        if bad or not finite or not loss_ok:
+            worst = max(bad, key=lambda i: float(torch.nan_to_num(got[i], nan=float("inf")))) if bad else None
+            raise GraphReplayMismatch(
+                "the replayed training step does not reproduce the eager one: "
+                + (f"{len(bad)} of {len(named)} parameter gradients differ, worst {named[worst][0]} "
+                   f"(relative error {float(got[worst]):.3g}, eager-vs-eager {float(base[worst]):.3g}); " if bad else "")
+                + f"loss eager {float(eager_loss):.6g} vs replay {float(graph_loss):.6g}")
+        worst_got = float(got[live].max()) if bool(live.any()) else 0.0
+        if noisy:
+            self.verified = (f"replay within the step's own eager-vs-eager spread on {len(named)} parameter gradients (non-deterministic step: "
+                             f"median eager-vs-eager {float(base[live].median()):.2g}, median replay-vs-eager {float(got[live].median()):.2g})")
+        else:
+            self.verified = f"replay == eager on {len(named)} parameter gradients (worst relative error {worst_got:.2g})"
 
     def accepts(self, batch) -> bool:
         """The captured graph serves batches of the captured shapes only."""
@@ -279,6 +345,7 @@ class GraphedTrainingStep:
             dst.copy_(src.reshape(dst.shape), non_blocking=True)
         self.graph.replay()
         return self.loss
+
 
 
 class _Logger:
@@ -355,7 +422,13 @@ class Trainer:
                     # running statistics, num_batches_tracked) are restored afterwards
                     saved = ddp.flat_grad.clone()
                     buffers = [(b, b.detach().clone()) for b in module.buffers()]
-                    graphed = GraphedTrainingStep(module, batch, loss_scale=1.0 / self.accumulate_grad_batches)
+                    try:
+                        graphed = GraphedTrainingStep(module, batch, loss_scale=1.0 / self.accumulate_grad_batches)
+                    except GraphReplayMismatch as exc:   # a replay that is not the eager step is not used: stay eager, say so
+                        import warnings
+
+                        warnings.warn(f"HIP-graph replay rejected, training continues with eager launches: {exc}")
+                        use_graph = False
                     ddp.flat_grad.copy_(saved)
                     for b, keep in buffers:
                         b.copy_(keep)

@@ -2,6 +2,7 @@
 mesh-GNN edge gather / segment sum (fp32: exact up to summation order; bf16: one rounding) and the fused Swin window
 attention (bf16 matrix cores: compared with a float64 oracle fed the SAME bf16-rounded operands)."""
 
+import numpy as np
 import pytest
 import torch
 
@@ -354,6 +355,36 @@ def test_row_layer_norm(gpu_device, R, C, dtype, with_res):
         assert torch.equal(rg.grad.cpu(), dy)
 
 
+@pytest.mark.parametrize("dtype,R,C", [(torch.float32, 513, 256), (torch.bfloat16, 513, 256), (torch.bfloat16, 32, 384), (torch.bfloat16, 2048, 384),
+                                       (torch.bfloat16, 300, 320), (torch.bfloat16, 4100, 512), (torch.bfloat16, 5, 512)])
+def test_row_layer_norm_widest_rows(gpu_device, dtype, R, C):
+    """Rows up to the 1 KiB limit (256 fp32 / 512 bf16 features: the LayerNorms of SwinUNetR's third merge and of UNetRPP's 512-wide
+    stages).  Regression: the workgroup's LDS staging of the parameter-gradient partials was sized for 256 features, so bf16
+    rows wider than that got overlapping, racing slots -- gamma / beta gradients that differed from run to run
+    (tools/diagnostics/determinism_probe.py found it; the parity tests of the time stopped at 128 features)."""
+    from py4cast_amd.ops_rows import row_layer_norm
+
+    torch.manual_seed(43)
+    x = (torch.randn(R, C) * 2 + 0.5).to(dtype)
+    gamma, beta, dy = torch.rand(C) + 0.5, torch.randn(C), torch.randn(R, C).to(dtype)
+    outs = []
+    for rep in range(2):
+        xg = x.to(gpu_device).requires_grad_(True)
+        gg, bg = gamma.to(gpu_device).requires_grad_(True), beta.to(gpu_device).requires_grad_(True)
+        y = row_layer_norm(xg, gg, bg, 1e-5)
+        y.backward(dy.to(gpu_device))
+        outs.append((y.detach().cpu(), xg.grad.cpu(), gg.grad.cpu(), bg.grad.cpu()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))          # fixed summation order: bit-identical reruns
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5)
+    yr.backward(dy.double())
+    y, dx, dg, db = outs[0]
+    assert _rel(y, yr.detach()) < (2e-6 if dtype == torch.float32 else 5e-3)
+    assert _rel(dx, xr.grad) < (1e-5 if dtype == torch.float32 else 8e-3)
+    assert _rel(dg, gr.grad) < 1e-5 and _rel(db, br.grad) < 1e-5
+
+
 @pytest.mark.parametrize("R,K", [(5000, 64), (70001, 64), (4096, 16), (9000, 80), (8191, 128), (6000, 48)])
 def test_row_linear_weight_gradient(gpu_device, R, K):
     from py4cast_amd.ops_rows import row_linear
@@ -676,6 +707,88 @@ def test_graphed_training_step_equals_eager(gpu_device, tmp_path):
     step(make_batch(other, gpu_device))                               # gradients accumulate like an eager backward
     torch.cuda.synchronize()
     assert _rel(ddp.flat_grad, 2 * first) < 1e-5
+
+
+def _graph_lm(tmp_path, device, **kw):
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from tests.helpers import make_dataset_info, synthetic_case
+
+    case = synthetic_case(seed=131, B=2, T=2, H=27, W=27, F=5, Ff=5)
+    info = make_dataset_info(case, 5)
+    torch.manual_seed(132)
+    lm = AutoRegressiveLightning(
+        {"tmp_dir": str(tmp_path), "activation_dtype": "f32", "processor_layers": 1}, info, None, num_input_steps=1,
+        num_pred_steps_train=2, batch_size=2, model_name="GraphLam",
+        losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+        training_strategy="scaled_ar", learning_rate=1e-3, **kw)
+    return lm.to(device) if device is not None else lm, case
+
+
+def test_graphed_step_is_verified_against_eager(gpu_device, tmp_path):
+    """The constructor replays once and holds the replay's gradients and loss against the eager warm-up passes: a faithful
+    capture is marked verified; a capture that computes something else than the eager passes (here: a host-side factor that
+    changes at the capture call, the way a capture-unsafe library call changes a replay) raises GraphReplayMismatch; a step with
+    a random element is recognised by its eager passes differing and is held to that spread only."""
+    from py4cast_amd.trainer import FlatDDP, GraphReplayMismatch, GraphedTrainingStep
+    from tests.helpers import make_batch
+
+    lm, case = _graph_lm(tmp_path, gpu_device)
+    ddp = FlatDDP(lm.model, 1)
+    ddp.zero_grad()
+    step = GraphedTrainingStep(lm, make_batch(case, gpu_device))
+    assert step.verified.startswith("replay == eager"), step.verified
+    assert step.warmup_backwards == 5
+    del step
+
+    lm, case = _graph_lm(tmp_path, gpu_device)
+    ddp = FlatDDP(lm.model, 1)
+    ddp.zero_grad()
+    calls, inner = [0], lm.training_step
+
+    def drifting(batch, idx):
+        calls[0] += 1
+        return inner(batch, idx) * (1.0 if calls[0] <= 3 else 1.5)     # the 4th call is the captured one
+    lm.training_step = drifting
+    with pytest.raises(GraphReplayMismatch, match="does not reproduce"):
+        GraphedTrainingStep(lm, make_batch(case, gpu_device))
+
+    lm, case = _graph_lm(tmp_path, gpu_device)
+    ddp = FlatDDP(lm.model, 1)
+    ddp.zero_grad()
+    rng, inner2 = np.random.default_rng(5), lm.training_step
+    lm.training_step = lambda batch, idx: inner2(batch, idx) * float(rng.uniform(0.5, 1.5))     # a step with a random element
+    step = GraphedTrainingStep(lm, make_batch(case, gpu_device))
+    assert step.verified.startswith("replay within the step's own"), step.verified
+
+
+def test_trainer_stays_eager_when_the_replay_is_rejected(gpu_device, tmp_path):
+    """Trainer.fit: a rejected capture is a warning and eager launches, and the run's result is the eager run's."""
+    from py4cast_amd.trainer import Trainer
+    from tests.helpers import make_batch, synthetic_case
+
+    cases = [synthetic_case(seed=140 + i, B=2, T=2, H=27, W=27, F=5, Ff=5) for i in range(4)]
+
+    def train(drift):
+        lm, _ = _graph_lm(tmp_path, None)
+        if drift:
+            calls, inner = [0], lm.training_step
+
+            def drifting(batch, idx):   # call 1: the eager first micro-batch; 2-4: warm-up; 5: the capture
+                calls[0] += 1
+                return inner(batch, idx) * (1.5 if calls[0] == 5 else 1.0)
+            lm.training_step = drifting
+        tr = Trainer(max_epochs=1, device=gpu_device, hip_graph=drift)
+        if drift:
+            with pytest.warns(UserWarning, match="HIP-graph replay rejected"):
+                tr.fit(lm, [make_batch(c, "cpu") for c in cases])
+        else:
+            tr.fit(lm, [make_batch(c, "cpu") for c in cases])
+        return torch.cat([p.detach().reshape(-1).float().cpu() for p in lm.model.parameters()]), tr.global_step
+
+    pe, ne = train(False)
+    pg, ng = train(True)
+    assert ne == ng == 4
+    assert _rel(pg, pe) < 1e-5
 
 
 def test_trainer_fit_with_hip_graph_matches_eager(gpu_device, tmp_path):
