@@ -14,6 +14,8 @@ B, F, T, Ff, Fs = 2, 21, 3, 5, 4
 case = Bn.synthetic_case(1234, B, T, 1, H, W, F, Ff, Fs, 0, device)
 info = Bn.make_info(case, Ff)
 settings = {"activation_dtype": dtype}
+if model.lower().startswith("halfunet"):
+    settings = {"compute_dtype": dtype, "activation_dtype": dtype}
 if model.lower().startswith("unetrpp"):
     settings = {"hidden_size": 1024, "num_heads_encoder": 16, "num_heads_decoder": 4, "depths": [3, 3, 3, 3], "linear_upsampling": True,
                 "downsampling_rate": 4, "decoder_proj_size": 64, "encoder_proj_sizes": [64, 64, 64, 32], "attention_code": "torch", "activation_dtype": dtype}
