@@ -16,6 +16,7 @@ is NCHW; the registry contract allows either.
 """
 
 import ctypes
+import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -109,13 +110,11 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         self.in_channels, self.out_channels, self.input_shape = in_channels, out_channels, input_shape
         self._settings = settings
         unsupported = []
-        if settings.num_filters != NF:
-            unsupported.append(f"num_filters={settings.num_filters} (kernels are built for 64)")
-        if settings.dilation != 1:
+        if settings.num_filters % 2 or settings.num_filters < 2:
+            unsupported.append(f"num_filters={settings.num_filters} (must be even)")
+        if settings.dilation < 1:
             unsupported.append(f"dilation={settings.dilation}")
-        if settings.bias:
-            unsupported.append("bias=True")
-        if settings.last_activation != "Identity":
+        if not hasattr(nn, settings.last_activation):
             unsupported.append(f"last_activation={settings.last_activation}")
         if settings.absolute_pos_embed:
             unsupported.append("absolute_pos_embed=True")
@@ -126,10 +125,15 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         act = settings.activation_dtype or settings.compute_dtype
         if act not in ("f32", "bf16") or (act == "bf16" and settings.compute_dtype != "bf16"):
             unsupported.append(f"activation_dtype={settings.activation_dtype} with compute_dtype={settings.compute_dtype}")
-        if out_channels > NF:
-            unsupported.append(f"out_channels={out_channels} > 64")
-        if pad32(in_channels) > 96:
-            unsupported.append(f"in_channels={in_channels} > 96")
+        # the fused plan (p4c_halfunet_forward / _backward) is built for the yaml's network: 64 filters, no dilation, no bias, no
+        # last activation; every other setting of mfai's HalfUNetSettings runs the module path below (`_forward_modules`)
+        self.module_path = bool(settings.use_ghost or settings.num_filters != NF or settings.dilation != 1 or settings.bias
+                                or settings.last_activation != "Identity")
+        if not self.module_path:
+            if out_channels > NF:
+                unsupported.append(f"out_channels={out_channels} > 64")
+            if pad32(in_channels) > 96:
+                unsupported.append(f"in_channels={in_channels} > 96")
         if unsupported:
             raise NotImplementedError("HalfUNetMI355X: unsupported settings: " + ", ".join(unsupported))
         self.cin_pad = pad32(in_channels)
@@ -140,8 +144,8 @@ class HalfUNetMI355X(ModelABC, nn.Module):
                                    "p4c_ar_update_loss_fwd", "p4c_ar_update_loss_fwd_next", "p4c_ar_update_loss_bwd")
 
         self.use_ghost = bool(settings.use_ghost)
-        if self.use_ghost:
-            self._init_ghost(in_channels, out_channels, settings)
+        if self.module_path:
+            self._init_modules(in_channels, out_channels, settings)
             return
         # parameters in the order of p4c_halfunet_param_count (include/py4cast_hip.h)
         self._param_slices = []
@@ -181,78 +185,130 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         self._scratch = {}
         self.check_required_attributes()
 
-    # ---------------------------------------------------------------- Ghost variant (settings.use_ghost)
-    def _init_ghost(self, in_channels, out_channels, settings):
-        """mfai's GhostModule blocks (halfunet.yaml:22): primary 3x3 convolution to 32 channels + depthwise 3x3 "cheap operation" on
-        them, concatenated, normalised, ReLU.  Parameter names as mfai's (``encoder1.enc1ghost1.conv.weight``, ``.sepconv.weight``,
-        ``.bn.*``; restated in oracle/halfunet.py).  The primary convolution runs on the MFMA conv kernels (the 32 real output
-        channels in a 64-channel launch, ops_model.conv_nhwc), the depthwise half on csrc/depthwise.hip (ops_ghost.ghost_dw);
-        normalisation / pooling / up-sampling are torch ops on the features-last tensors.  The fused C++ plan
-        (p4c_halfunet_forward) serves the non-ghost network only; the rollout takes the generic per-step path."""
+    # ---------------------------------------------------------------- module path: Ghost blocks and the non-default yaml settings
+    def _init_modules(self, in_channels, out_channels, settings):
+        """Every HalfUNetSettings combination the fused plan is not built for (halfunet.yaml:19-26: ``use_ghost``, ``num_filters``
+        other than 64, ``dilation``, ``bias``, ``last_activation``), as a network of per-layer nodes with mfai's parameter names
+        (restated in oracle/halfunet.py): ``encoder1.enc1conv1.{weight,bias}`` / ``enc1norm1.*``, or for Ghost blocks
+        ``encoder1.enc1ghost1.conv.*`` / ``.sepconv.*`` / ``.bn.*``; ``outconv.{weight,bias}``.
+        Convolutions without dilation to <= 64 channels from <= 96 run on the MFMA conv kernels (ops_model.conv_nhwc: forward, data
+        and weight gradient; fewer than 64 output channels as zero rows of a 64-channel launch), the Ghost "cheap operation" at 64
+        filters on csrc/depthwise.hip (ops_ghost.ghost_dw); wider or dilated convolutions go through the library; normalisation,
+        pooling and up-sampling are torch ops on the features-last tensors.  The fused C++ plan (p4c_halfunet_forward) serves the
+        yaml's network only, so the rollout takes the generic per-step path here."""
+        nf = settings.num_filters
+
+        def conv_holder(co, ci, ks, groups=1):
+            h = _Holder()
+            w = torch.empty(co, ci // groups, ks, ks)
+            nn.init.kaiming_uniform_(w, a=5**0.5)
+            h.weight = nn.Parameter(w)
+            if settings.bias:   # nn.Conv2d's default bias initialisation
+                bound = 1.0 / math.sqrt(ci // groups * ks * ks)
+                h.bias = nn.Parameter(torch.empty(co).uniform_(-bound, bound))
+            return h
+
+        def norm_holder():
+            n = _Holder()
+            n.weight, n.bias = nn.Parameter(torch.ones(nf)), nn.Parameter(torch.zeros(nf))
+            if settings.norm == "batch":
+                n.register_buffer("running_mean", torch.zeros(nf))
+                n.register_buffer("running_var", torch.ones(nf))
+                n.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+            return n
+
         for blk, attr in zip(BLOCKS, BLOCK_ATTR):
             holder = _Holder()
             for j in (1, 2):
-                cin = in_channels if (attr == "encoder1" and j == 1) else NF
-                g = _Holder()
-                g.conv, g.sepconv, g.bn = _Holder(), _Holder(), _Holder()
-                w = torch.empty(NF // 2, cin, 3, 3)
-                nn.init.kaiming_uniform_(w, a=5**0.5)
-                g.conv.weight = nn.Parameter(w)
-                wd = torch.empty(NF // 2, 1, 3, 3)
-                nn.init.kaiming_uniform_(wd, a=5**0.5)
-                g.sepconv.weight = nn.Parameter(wd)
-                g.bn.weight, g.bn.bias = nn.Parameter(torch.ones(NF)), nn.Parameter(torch.zeros(NF))
-                if settings.norm == "batch":
-                    g.bn.register_buffer("running_mean", torch.zeros(NF))
-                    g.bn.register_buffer("running_var", torch.ones(NF))
-                    g.bn.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
-                setattr(holder, f"{blk}ghost{j}", g)
+                cin = in_channels if (attr == "encoder1" and j == 1) else nf
+                if self.use_ghost:
+                    g = _Holder()
+                    g.conv, g.sepconv, g.bn = conv_holder(nf // 2, cin, 3), conv_holder(nf // 2, nf // 2, 3, groups=nf // 2), norm_holder()
+                    setattr(holder, f"{blk}ghost{j}", g)
+                else:
+                    setattr(holder, f"{blk}conv{j}", conv_holder(nf, cin, 3))
+                    setattr(holder, f"{blk}norm{j}", norm_holder())
             setattr(self, attr, holder)
-        self.outconv = _Holder()
-        w = torch.empty(out_channels, NF, 1, 1)
-        nn.init.kaiming_uniform_(w, a=5**0.5)
-        self.outconv.weight = nn.Parameter(w)
+        self.outconv = conv_holder(out_channels, nf, 1)
+        self.activation = getattr(nn, settings.last_activation)()
         self.native_rollout = None          # instance attribute shadows the method: AutoRegressiveLightning takes the generic path
         self.check_required_attributes()
+
+    def _conv_module(self, c, x, dilation=1):
+        """"same" convolution of a features-last tensor with the holder's weight (+ bias)."""
+        from . import ops_model as OM
+
+        F = torch.nn.functional
+        w = c.weight
+        if dilation == 1 and OM.conv_nhwc_supported(x, w):
+            y = OM.conv_nhwc(x, w)
+        else:
+            pad = dilation * (w.shape[-1] // 2)
+            y = F.conv2d(x.permute(0, 3, 1, 2), w.to(x.dtype), None, padding=pad, dilation=dilation).permute(0, 2, 3, 1)
+        b = getattr(c, "bias", None)
+        return y if b is None else y + b.to(y.dtype)
+
+    def _norm_relu(self, n, y):
+        F = torch.nn.functional
+        v = y.permute(0, 3, 1, 2).float()                                   # NCHW-shaped view of features-last memory
+        if self._settings.norm == "batch":
+            v = F.batch_norm(v, n.running_mean, n.running_var, n.weight, n.bias, self.training, 0.1, 1e-5)
+            if self.training:
+                n.num_batches_tracked += 1
+        else:
+            v = F.group_norm(v, self._settings.groups, n.weight, n.bias, 1e-5)
+        return F.relu(v).to(y.dtype).permute(0, 2, 3, 1)
 
     def _ghost_module(self, g, x):
         from . import ops_ghost as OG
         from . import ops_model as OM
 
         F = torch.nn.functional
-        w = F.pad(g.conv.weight, (0, 0, 0, 0, 0, 0, 0, NF // 2))            # 32 real output channels of a 64-channel launch
-        y = OG.ghost_dw(OM.conv_nhwc(x, w), g.sepconv.weight)               # (B,H,W,64): [primary | depthwise]
-        v = y.permute(0, 3, 1, 2).float()                                   # NCHW-shaped view of features-last memory
-        if self._settings.norm == "batch":
-            v = F.batch_norm(v, g.bn.running_mean, g.bn.running_var, g.bn.weight, g.bn.bias, self.training, 0.1, 1e-5)
-            if self.training:
-                g.bn.num_batches_tracked += 1
+        nf, dil = self._settings.num_filters, self._settings.dilation
+        if nf == NF and dil == 1 and OM.conv_nhwc_supported(x, g.conv.weight):
+            w = F.pad(g.conv.weight, (0, 0, 0, 0, 0, 0, 0, NF // 2))        # 32 real output channels of a 64-channel launch
+            y = OM.conv_nhwc(x, w)
+            if getattr(g.conv, "bias", None) is not None:
+                y = y + F.pad(g.conv.bias, (0, NF // 2)).to(y.dtype)
+            y = OG.ghost_dw(y, g.sepconv.weight)                            # (B,H,W,64): [primary | depthwise]
+            if getattr(g.sepconv, "bias", None) is not None:
+                y = y + F.pad(g.sepconv.bias, (NF // 2, 0)).to(y.dtype)
         else:
-            v = F.group_norm(v, self._settings.groups, g.bn.weight, g.bn.bias, 1e-5)
-        return F.relu(v).to(x.dtype).permute(0, 2, 3, 1)
+            prim = self._conv_module(g.conv, x, dil)                        # (B,H,W,nf/2)
+            cheap = F.conv2d(prim.permute(0, 3, 1, 2), g.sepconv.weight.to(prim.dtype),
+                             None if getattr(g.sepconv, "bias", None) is None else g.sepconv.bias.to(prim.dtype), padding=1,
+                             groups=nf // 2).permute(0, 2, 3, 1)
+            y = torch.cat([prim, cheap], dim=-1)
+        return self._norm_relu(g.bn, y)
 
-    def _forward_ghost(self, x):
+    def _forward_modules(self, x):
         F = torch.nn.functional
         out_dtype = x.dtype
         x = x.contiguous().to(self.act_dtype)
+        dil = self._settings.dilation
+
+        def block(blk, holder, h):
+            if self.use_ghost:
+                return self._ghost_module(getattr(holder, f"{blk}ghost2"), self._ghost_module(getattr(holder, f"{blk}ghost1"), h))
+            for j in (1, 2):
+                h = self._norm_relu(getattr(holder, f"{blk}norm{j}"), self._conv_module(getattr(holder, f"{blk}conv{j}"), h, dil))
+            return h
+
         levels = []
         h = x
         for k, (blk, attr) in enumerate(zip(BLOCKS[:5], BLOCK_ATTR[:5])):
-            holder = getattr(self, attr)
             if k > 0:
                 h = F.max_pool2d(h.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
-            h = self._ghost_module(getattr(holder, f"{blk}ghost2"), self._ghost_module(getattr(holder, f"{blk}ghost1"), h))
+            h = block(blk, getattr(self, attr), h)
             levels.append(h)
         s = levels[0].float()
         for k in range(1, 5):
             up = F.interpolate(levels[k].permute(0, 3, 1, 2).float(), scale_factor=2**k, mode="bilinear", align_corners=False)
             s = s + up.permute(0, 2, 3, 1)
-        dec = self.decoder
-        d = self._ghost_module(dec.decoderghost2, self._ghost_module(dec.decoderghost1, s.to(self.act_dtype)))
-        from . import ops_model as OM
-
-        wout = F.pad(self.outconv.weight, (0, 0, 0, 0, 0, 0, 0, NF - self.out_channels))
-        y = OM.conv_nhwc(d, wout)[..., : self.out_channels]
+        d = block("decoder", self.decoder, s.to(self.act_dtype))
+        y = self._conv_module(self.outconv, d)
+        if not isinstance(self.activation, nn.Identity):
+            y = self.activation(y.float()).to(y.dtype)
         return y if y.dtype == out_dtype or not out_dtype.is_floating_point else y.to(out_dtype)
 
     @property
@@ -377,8 +433,8 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             # pad -> plan -> crop; both are torch views / copies, differentiable (the padded border's outputs are dropped)
             y = self.forward(torch.nn.functional.pad(x, (0, 0, left, right, top, bottom)))
             return y[:, top: top + H, left: left + W, :]
-        if self.use_ghost:
-            return self._forward_ghost(x)
+        if self.module_path:
+            return self._forward_modules(x)
         if x.shape[-1] == self.in_channels and self.cin_pad != self.in_channels:
             x = torch.nn.functional.pad(x, (0, self.cin_pad - self.in_channels))
         elif x.shape[-1] != self.cin_pad:

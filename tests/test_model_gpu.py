@@ -154,9 +154,14 @@ def test_halfunet_rejects_unsupported_settings():
     from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings
 
     with pytest.raises(NotImplementedError):
-        HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(dilation=2))
+        HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(absolute_pos_embed=True))
     with pytest.raises(NotImplementedError):
-        HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(num_filters=32))
+        HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(num_filters=33))
+    with pytest.raises(NotImplementedError):
+        HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(last_activation="NoSuchActivation"))
+    # dilation / num_filters / bias / last_activation / use_ghost are served by the module path (tests/test_round2_gpu.py)
+    assert HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings(dilation=2)).module_path
+    assert not HalfUNetMI355X(10, 1, (64, 64), HalfUNetSettings()).module_path
 
 
 @pytest.mark.parametrize("T", [1, 3])

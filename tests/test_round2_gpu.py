@@ -530,3 +530,65 @@ def test_ghost_halfunet_matches_oracle_and_trains(gpu_device):
     loss = lm.training_step(make_batch(case, gpu_device), 0)
     loss.backward()
     assert bool(torch.isfinite(loss)) and all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in lm.model.parameters())
+
+
+@pytest.mark.parametrize("kw", [
+    dict(num_filters=32, bias=True, dilation=2, last_activation="Sigmoid"),
+    dict(bias=True),
+    dict(num_filters=96, last_activation="Tanh"),
+    dict(use_ghost=True, bias=True),
+    dict(use_ghost=True, num_filters=48, dilation=2),
+    dict(num_filters=32, norm="group", groups=4),
+], ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_halfunet_yaml_settings_match_oracle(gpu_device, kw):
+    """config/CLI/model/halfunet.yaml:19-26 beyond the defaults -- num_filters, dilation, bias, last_activation, with and without
+    Ghost blocks: the module path of HalfUNetMI355X against the float64 oracle with the same state dict (names and shapes are
+    mfai's), forward <= 1e-4, every gradient and the BatchNorm running statistics."""
+    from oracle.halfunet import HalfUNetRef
+    from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings
+
+    H, W, cin, cout = 48, 64, 21, 12
+    torch.manual_seed(19)
+    model = HalfUNetMI355X(cin, cout, (H, W), HalfUNetSettings(**kw))
+    assert model.module_path and model.native_rollout is None
+    ref = HalfUNetRef(cin, cout, **kw).double()
+    assert set(model.state_dict()) == set(ref.state_dict())
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in model.state_dict().items()})
+    model = model.to(gpu_device).train()
+    ref.train()
+    x = torch.randn(2, H, W, cin, generator=torch.Generator().manual_seed(20))
+    gy = torch.randn(2, H, W, cout, generator=torch.Generator().manual_seed(21))
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = model(xg)
+    y.backward(gy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    yr.backward(gy.double())
+    assert rel_err(y, yr) < 1e-4
+    assert rel_err(xg.grad, xr.grad) < 5e-3
+    rg = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        assert p.grad is not None, n
+        err = float((p.grad.detach().double().cpu() - rg[n].grad).norm())
+        scale = float(rg[n].grad.norm())
+        if n.endswith(".bias") and n[:-4] + "weight" in rg:
+            # a convolution bias in front of a batch norm has a gradient of exactly zero (1e-14 in the fp64 oracle, rounding noise in
+            # fp32): judged against its layer's weight gradient instead of against itself
+            scale = max(scale, 1e-2 * float(rg[n[:-4] + "weight"].grad.norm()))
+        assert err < 5e-3 * scale, (n, err, scale)
+    for n, b in model.named_buffers():
+        if b.dtype.is_floating_point:
+            assert rel_err(b, dict(ref.named_buffers())[n]) < 1e-4, n
+
+
+def test_halfunet_yaml_settings_train_through_lightning(gpu_device):
+    """The same settings through AutoRegressiveLightning (generic rollout, bf16): a finite loss and a gradient on every parameter."""
+    from py4cast_amd.lightning import AutoRegressiveLightning
+
+    case = synthetic_case(seed=23, B=2, T=2, H=32, W=32, F=12, Ff=5, Fs=4, border=0)
+    info = make_dataset_info(case, 5)
+    lm = AutoRegressiveLightning({"num_filters": 32, "bias": True, "dilation": 2, "compute_dtype": "bf16", "activation_dtype": "bf16"}, info, None,
+                                 num_pred_steps_train=2, batch_size=2, model_name="HalfUNet", losses=MSE, training_strategy="scaled_ar").to(gpu_device)
+    loss = lm.training_step(make_batch(case, gpu_device), 0)
+    loss.backward()
+    assert bool(torch.isfinite(loss)) and all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in lm.model.parameters())
