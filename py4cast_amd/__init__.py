@@ -16,3 +16,19 @@ import os as _os
 # and an empty MIOpen cache; scratch notes in DESIGN.md section 8).  FAST mode (immediate-mode heuristics, no benchmarking pass)
 # avoids it.  Respect an explicit user choice.
 _os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+
+# Library GEMMs (Linear layers, token-axis projections, pixel-block convolutions of SwinUNetR / UNetRPP): hipBLASLt's default
+# heuristic picks deep-K stream-K kernels for the skinny shapes of the early Swin stages (K = 24..96 against 10^5 rows) that run at a
+# few hundred GB/s.  PyTorch's TunableOp selects per shape among the library's own solutions; the selections for the bench
+# workloads were tuned once on an MI355X (tools/diagnostics/tune_gemms.sh -> merge_tunable.py) and ship as
+# tuning/tunableop_gfx950.csv, loaded with tuning switched OFF (a lookup per GEMM shape; unknown shapes take the default; the file's
+# validator lines make the library ignore it on another ROCm / hipBLASLt / GPU).  SwinUNetR 55.1 -> 49 ms per step.
+# Here: environment only (torch reads it at its first GEMM; nothing at import touches the device); the file itself is handed to
+# torch.cuda.tunable.read_file by the first native call on a GPU tensor (_lib.require_cuda) -- TunableOp's own file-name variable
+# inserts the device ordinal into the name, which would need one copy per rank.  Respect an explicit user choice (PYTORCH_TUNABLEOP_ENABLED set either way), and P4C_NO_TUNED_GEMMS=1.
+_TUNED_GEMMS = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
+if ("PYTORCH_TUNABLEOP_ENABLED" not in _os.environ and _os.environ.get("P4C_NO_TUNED_GEMMS") != "1"
+        and _os.path.exists(_TUNED_GEMMS)):
+    _os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+    _os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
+    _os.environ["P4C_TUNED_GEMMS_FILE"] = _TUNED_GEMMS   # read by _lib.require_cuda at the first native call on a GPU tensor

@@ -213,7 +213,29 @@ def dtype_code(dt: torch.dtype) -> int:
     raise P4CError(f"unsupported dtype {dt}")
 
 
+_TUNED_GEMMS_LOADED = [False]
+
+
+def _load_tuned_gemms():
+    """Once per process, at the first native call on a GPU tensor: hand the shipped GEMM selections (package __init__) to TunableOp."""
+    _TUNED_GEMMS_LOADED[0] = True
+    path = os.environ.get("P4C_TUNED_GEMMS_FILE")
+    if not path:
+        return
+    try:
+        import torch.cuda.tunable as tunable
+
+        if tunable.is_enabled() and not tunable.tuning_is_enabled():
+            tunable.read_file(path)
+    except Exception as exc:  # noqa: BLE001  (no TunableOp in this build / unreadable file: the library's default selection stays)
+        import warnings
+
+        warnings.warn(f"py4cast_amd: tuned GEMM selections not loaded ({type(exc).__name__}: {exc})")
+
+
 def require_cuda(*tensors):
+    if not _TUNED_GEMMS_LOADED[0] and any(t is not None and t.is_cuda for t in tensors):
+        _load_tuned_gemms()
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise P4CError(

@@ -101,3 +101,37 @@ def test_lazy_masks_behave_like_the_reference_tensors():
     mask, tgt = AutoRegressiveLightning.get_mask_on_nan(Holder(), nt)
     assert isinstance(mask, OnesMask) and tgt is nt
     assert torch.equal(mask * torch.ones_like(t), torch.ones_like(t)) and float(torch.sum(mask)) == t.numel()
+
+
+def test_tuned_gemm_selections_file_and_switches():
+    """py4cast_amd/__init__.py: the shipped TunableOp result file is well-formed (validator header, one 4-field line per shape, no
+    "Default" entries), the import switches TunableOp on with tuning OFF without touching the device, and both an explicit user
+    setting and P4C_NO_TUNED_GEMMS=1 are respected."""
+    import os
+    import subprocess
+    import sys
+
+    import py4cast_amd
+
+    path = os.path.join(os.path.dirname(py4cast_amd.__file__), "tuning", "tunableop_gfx950.csv")
+    lines = [ln.strip() for ln in open(path) if ln.strip()]
+    validators = [ln for ln in lines if ln.startswith("Validator,")]
+    assert {v.split(",")[1] for v in validators} >= {"PT_VERSION", "HIPBLASLT_VERSION", "GCN_ARCH_NAME"}
+    assert any("gfx950" in v for v in validators)
+    entries = [ln.split(",") for ln in lines if not ln.startswith("Validator,")]
+    assert len(entries) > 20 and all(len(e) == 4 and e[2] != "Default" and float(e[3]) > 0 for e in entries)
+    assert len({(e[0], e[1]) for e in entries}) == len(entries)
+
+    probe = ("import os, py4cast_amd; print(os.environ.get('PYTORCH_TUNABLEOP_ENABLED'), os.environ.get('PYTORCH_TUNABLEOP_TUNING'), "
+             "bool(os.environ.get('P4C_TUNED_GEMMS_FILE')))")
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("PYTORCH_TUNABLEOP", "P4C_TUNED", "P4C_NO_TUNED"))}
+        env.update(extra)
+        root = os.path.dirname(os.path.dirname(py4cast_amd.__file__))
+        return subprocess.run([sys.executable, "-c", probe], env=env, cwd=root, capture_output=True, text=True, check=True).stdout.split()
+
+    assert run({}) == ["1", "0", "True"]
+    assert run({"P4C_NO_TUNED_GEMMS": "1"}) == ["None", "None", "False"]
+    assert run({"PYTORCH_TUNABLEOP_ENABLED": "0"}) == ["0", "None", "False"]
+    assert run({"PYTORCH_TUNABLEOP_ENABLED": "1", "PYTORCH_TUNABLEOP_TUNING": "1"}) == ["1", "1", "False"]   # the user's own tuning session

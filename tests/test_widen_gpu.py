@@ -1162,3 +1162,25 @@ def test_instance_norm_act_native(gpu_device, dtype, tol, B, H, W, C, with_res, 
     assert _rel(wg.grad.cpu(), wr.grad) < tol * 4 and _rel(bg.grad.cpu(), br.grad) < tol * 4
     if rr is not None:
         assert _rel(rg.grad.float().cpu(), rr.grad) < tol * 2
+
+
+def test_tuned_gemm_selections_are_loaded_on_first_gpu_call(gpu_device):
+    """_lib.require_cuda hands tuning/tunableop_gfx950.csv to TunableOp at the first native call on a GPU tensor: the process then
+    holds the file's selections (tuning itself stays off) -- unless the validators (ROCm / hipBLASLt / GPU) of this box differ from
+    the file's, in which case the library ignores it and nothing is loaded."""
+    import os
+
+    import torch.cuda.tunable as tunable
+
+    from py4cast_amd import _lib as L
+
+    if os.environ.get("P4C_TUNED_GEMMS_FILE") is None:
+        pytest.skip("tuned GEMM selections switched off by the environment")
+    L.require_cuda(torch.zeros(1, device=gpu_device))
+    assert L._TUNED_GEMMS_LOADED[0]
+    assert tunable.is_enabled() and not tunable.tuning_is_enabled()
+    here = dict(v for v in tunable.get_validators())
+    shipped = dict(ln.strip().split(",")[1:3] for ln in open(os.environ["P4C_TUNED_GEMMS_FILE"]) if ln.startswith("Validator,"))
+    loaded = [r for r in tunable.get_results() if r[2] != "Default"]
+    if all(here.get(k) == v for k, v in shipped.items()):
+        assert len(loaded) >= 20, len(loaded)
