@@ -426,6 +426,25 @@ int p4c_row_linear_wgrad(const void* dy, const void* x, float* dw_db, void* work
                          p4c_stream_t stream);
 
 
+/* Linear layers on token rows (SwinUNetR's qkv / proj / MLP projections, patch merging; py4cast/models.py:10-20 -> mfai SwinUNETR):
+ *   y[r][n] = sum_k x[r][k] M[n][k] (+ bias[n]),  M[n][k] = transposed ? w[k * ldw + n] : w[n * ldw + k]
+ * x (R, K) and y (R, N) bf16 rows with row strides ldx / ldy (elements; views of wider tensors are fine), w the fp32 master weight
+ * (laid out as the bf16 matrix-core operand inside the kernel: no cast launch), bias fp32 or NULL.  Forward: M = W.  Data gradient:
+ * x = dy, w = W, transposed = 1, K and N swapped.  K a multiple of 8 up to 384, N a multiple of 4, operand image within LDS:
+ * p4c_row_gemm_supported(K, N) says whether a shape is served (callers use the library GEMM otherwise). */
+int p4c_row_gemm_supported(int K, int N);
+int p4c_row_gemm(const void* x, int64_t ldx, const float* w, int ldw, int transposed, const float* bias, void* y, int64_t ldy,
+                 int64_t R, int K, int N, p4c_stream_t stream);
+/* Weight and bias gradient of the same layer over R >> N rows:  out is (64 * ceil(N / 64)) x KP floats (overwritten), KP = 32 *
+ * ceil((K + with_bias) / 32):  out[n][k] = dW[n][k] = sum_r dy[r][n] x[r][k] for k < K, and with_bias: out[n][K] = db[n] = sum_r
+ * dy[r][n].  bf16 rows, fp32 accumulation, fixed reduction order (bit-identical reruns).  N, K multiples of 8, K + with_bias <= 224,
+ * N <= 512: p4c_row_gemm_wgrad_supported.  workspace: p4c_row_gemm_wgrad_workspace_bytes(R, N, K, with_bias) bytes. */
+int p4c_row_gemm_wgrad_supported(int N, int K, int with_bias);
+size_t p4c_row_gemm_wgrad_workspace_bytes(int64_t R, int N, int K, int with_bias);
+int p4c_row_gemm_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out, void* workspace, int64_t R, int N, int K,
+                       int with_bias, p4c_stream_t stream);
+
+
 /* Fused row MLP of the GNN models (make_mlp: Linear - SiLU - Linear - LayerNorm, hidden = out = 64 features):
  *   pre  = x W1^T + b1 (+ gather_a[index_a[r]] + gather_b[index_b[r]])      -- the gathered addends are the sender / receiver
  *                                                                              parts of a distributed edge-MLP first layer

@@ -60,6 +60,8 @@ SIGNATURES = {
     "p4c_row_layernorm_fwd": [P, P, P, P, F, P, L, I, I, P],
     "p4c_row_layernorm_bwd": [P, P, P, F, P, P, P, P, L, I, I, P],
     "p4c_row_linear_wgrad": [P, P, P, P, L, I, I, I, P],
+    "p4c_row_gemm": [P, L, P, I, I, P, P, L, L, I, I, P],
+    "p4c_row_gemm_wgrad": [P, L, P, L, P, P, L, I, I, I, P],
     "p4c_row_mlp_fwd": [MP, P],
     "p4c_row_mlp_prepare": [MP, P, P],
     "p4c_row_mlp_bwd": [MP, P, P, P],
@@ -74,6 +76,9 @@ OTHER = {
     "p4c_window_attn_bwd_workspace_bytes": ([I, I, I, I, I], c_size_t),
     "p4c_row_layernorm_bwd_workspace_bytes": ([L, I, I], c_size_t),
     "p4c_row_linear_wgrad_workspace_bytes": ([L, I], c_size_t),
+    "p4c_row_gemm_supported": ([I, I], c_int),
+    "p4c_row_gemm_wgrad_supported": ([I, I, I], c_int),
+    "p4c_row_gemm_wgrad_workspace_bytes": ([L, I, I, I], c_size_t),
     "p4c_row_mlp_bwd_workspace_bytes": ([L, I], c_size_t),
     "p4c_row_mlp_prepared_bytes": ([I], c_size_t),
 }

@@ -211,21 +211,84 @@ def row_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = Non
     return F.linear(x, w.to(x.dtype), None if b is None else b.to(x.dtype))
 
 
+def _rows2d(t: torch.Tensor, C: int) -> torch.Tensor:
+    """(..., C) -> (R, C) rows the row-GEMM kernels can address: unit stride inside a row, 16-byte aligned rows (a view when the
+    tensor already is that, else one copy)."""
+    t2 = t.reshape(-1, C)
+    if t2.stride(1) != 1 or t2.stride(0) % 8 or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+    return t2
+
+
+def _row_gemm_ok(x: torch.Tensor, w: torch.Tensor, b) -> bool:
+    """The native kernels serve bf16 rows with fp32 master parameters, from 1 024 rows (below that the library's ~20 us floor does
+    not matter), in the sizes p4c_row_gemm_supported / _wgrad_supported state (include/py4cast_hip.h)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.float32 and w.dim() == 2 and (b is None or b.dtype == torch.float32)):
+        return False
+    O, K = w.shape
+    R = x.numel() // max(K, 1)
+    if R < 1024 or K % 8 or O % 8:
+        return False
+    # every workgroup lays the weight out as its operand image first: with few rows and a large weight that costs more than the
+    # library's floor (measured: 8 192 rows x (96 -> 288) 26 us against 21; 96 -> 96 11 against 21; tools/diagnostics/linear_micro.py)
+    if 4 * R < 2 * (32 * ((O + 31) // 32)) * (16 * ((K + 15) // 16)):
+        return False
+    lib = L.lib()
+    return bool(lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K) and lib.p4c_row_gemm_wgrad_supported(O, K, int(b is not None)))
+
+
+def _row_gemm(x2: torch.Tensor, w: torch.Tensor, transposed: bool, bias, N: int) -> torch.Tensor:
+    R, K = x2.shape
+    y = torch.empty(R, N, dtype=x2.dtype, device=x2.device)
+    L.call("p4c_row_gemm", L.ptr(x2), x2.stride(0), L.ptr(w), w.stride(0), int(transposed), L.ptr(bias), L.ptr(y), N, R, K, N,
+           L.stream(x2.device), alg_bytes=R * (K + N) * 2)
+    return y
+
+
 class _LinearND(torch.autograd.Function):
-    """y = x W^T + b on (..., K) tensors of the activation dtype with fp32 master weights: library GEMMs for y, dx and dW; the bias
-    gradient is ``ones @ dy`` -- a GEMM too -- instead of a column reduction of dy: under HIP-graph replay at the 512 x 512 sizes the
-    reduction route handed back garbage for exactly the Linear biases of SwinUNetR / UNetRPP (tools/diagnostics/nan_probe.py), and a
-    (1 x R) GEMM is also the cheaper launch."""
+    """y = x W^T + b on (..., K) tensors of the activation dtype with fp32 master weights.
+    bf16 rows in the sizes of SwinUNetR's token layers run on csrc/rowgemm.hip: forward and data gradient as one streaming pass
+    each (the weight goes from its fp32 master to the matrix-core operand inside the kernel), weight and bias gradient as one
+    reduction over the rows in a fixed order.  Everything else uses library GEMMs for y, dx and dW, with the bias gradient as
+    ``ones @ dy`` -- a GEMM too -- instead of a column reduction of dy: under HIP-graph replay at the 512 x 512 sizes the reduction
+    route handed back garbage for exactly the Linear biases of SwinUNetR / UNetRPP (tools/diagnostics/nan_probe.py), and a (1 x R)
+    GEMM is also the cheaper launch."""
 
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.native = _row_gemm_ok(x, w, b)
+        ctx.has_bias, ctx.wdtype, ctx.bdtype = b is not None, w.dtype, (None if b is None else b.dtype)
+        if ctx.native:
+            O, K = w.shape
+            wc = w.detach() if w.stride(1) == 1 else w.detach().contiguous()
+            x2 = _rows2d(x.detach(), K)
+            ctx.save_for_backward(x2, wc)
+            ctx.xshape = x.shape
+            return _row_gemm(x2, wc, False, None if b is None else b.detach().contiguous(), O).view(*x.shape[:-1], O)
         wq = w.to(x.dtype)
         ctx.save_for_backward(x, wq)
-        ctx.has_bias, ctx.wdtype, ctx.bdtype = b is not None, w.dtype, (None if b is None else b.dtype)
         return F.linear(x, wq, None if b is None else b.to(x.dtype))
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.native:
+            x2, wc = ctx.saved_tensors
+            O, K = wc.shape
+            R = x2.shape[0]
+            dy2 = _rows2d(dy, O)
+            dx = _row_gemm(dy2, wc, True, None, K).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+            dw = db = None
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                lib = L.lib()
+                kp = 32 * ((K + int(ctx.has_bias) + 31) // 32)
+                out = torch.empty(64 * ((O + 63) // 64), kp, dtype=torch.float32, device=dy2.device)
+                ws = torch.empty(max(lib.p4c_row_gemm_wgrad_workspace_bytes(R, O, K, int(ctx.has_bias)) // 4, 1), dtype=torch.float32, device=dy2.device)
+                L.call("p4c_row_gemm_wgrad", L.ptr(dy2), dy2.stride(0), L.ptr(x2), x2.stride(0), L.ptr(out), L.ptr(ws), R, O, K, int(ctx.has_bias),
+                       L.stream(dy2.device), alg_bytes=R * (K + O) * 2)
+                dw = out[:O, :K].to(ctx.wdtype)
+                if ctx.has_bias:
+                    db = out[:O, K].to(ctx.bdtype)
+            return dx, dw, db
         x, wq = ctx.saved_tensors
         O, K = wq.shape
         dy2 = dy.reshape(-1, O)

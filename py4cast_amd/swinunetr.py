@@ -214,7 +214,8 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         self.decoder2 = UpBlock(2 * fs, fs)
         self.decoder1 = UpBlock(fs, fs)
         self.out = nn.Conv2d(fs, out_channels, 1)
-        self.timed_entry_points = ("p4c_window_attn_fwd", "p4c_window_attn_bwd", "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd")
+        self.timed_entry_points = ("p4c_window_attn_fwd", "p4c_window_attn_bwd", "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd",
+                                   "p4c_row_gemm", "p4c_row_gemm_wgrad")
         self.roofline_from_entry_points = True   # bench.py: time every call of the entry points above
         self.prefers_hip_graph = True            # ~10^3-10^4 launches per training step: replay them from a HIP graph (trainer.GraphedTrainingStep)
         self.check_required_attributes()

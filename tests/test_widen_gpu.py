@@ -1184,3 +1184,77 @@ def test_tuned_gemm_selections_are_loaded_on_first_gpu_call(gpu_device):
     loaded = [r for r in tunable.get_results() if r[2] != "Default"]
     if all(here.get(k) == v for k, v in shipped.items()):
         assert len(loaded) >= 20, len(loaded)
+
+
+@pytest.mark.parametrize("R,K,O,bias", [
+    (131072, 24, 72, True), (131072, 96, 24, True), (32768 + 17, 48, 144, True), (32768, 192, 48, True), (32768, 96, 384, True), (8192, 96, 96, True),
+    (32768, 96, 48, False), (2049, 24, 24, True), (4100, 40, 104, True), (1500, 8, 8, False), (40000, 200, 136, True), (5000, 64, 64, True)])
+def test_linear_nd_native_rows(gpu_device, R, K, O, bias):
+    """ops_rows.linear_nd on the row-GEMM kernels (csrc/rowgemm.hip: SwinUNetR's token layers): y, dx, dW, db against float64 on the
+    SAME bf16-rounded operands (one rounding of the outputs: <= 2^-8 relative per element for y / dx; the weight and bias gradients
+    are fp32 sums), ragged row counts, widths that are not multiples of the 16 / 32 tiles, and bit-identical reruns."""
+    from py4cast_amd import _lib as L
+    from py4cast_amd.ops_rows import _row_gemm_ok, linear_nd
+
+    torch.manual_seed(51)
+    x = torch.randn(R, K).bfloat16()
+    w, b = torch.randn(O, K) * 0.2, (torch.randn(O) if bias else None)
+    dy = torch.randn(R, O).bfloat16()
+    outs = []
+    for rep in range(2):
+        xg = x.to(gpu_device).requires_grad_(True)
+        wg = w.to(gpu_device).requires_grad_(True)
+        bg = b.to(gpu_device).requires_grad_(True) if bias else None
+        assert _row_gemm_ok(xg, wg, bg)
+        y = linear_nd(xg, wg, bg)
+        y.backward(dy.to(gpu_device))
+        outs.append([y.detach().cpu(), xg.grad.cpu(), wg.grad.cpu()] + ([bg.grad.cpu()] if bias else []))
+    assert all(torch.equal(a, c) for a, c in zip(*outs))
+    wq = w.bfloat16().double()                                  # the kernel rounds the master weight to bf16 for the matrix cores
+    yr = x.double() @ wq.t() + (b.double() if bias else 0.0)
+    dxr = dy.double() @ wq
+    dwr = dy.double().t() @ x.double()
+    y, dx, dw = outs[0][:3]
+    assert y.dtype == torch.bfloat16 and y.shape == (R, O)
+    assert float((y.double() - yr).abs().max() / yr.abs().max()) < 6e-3
+    assert float((dx.double() - dxr).abs().max() / dxr.abs().max()) < 6e-3
+    assert _rel(dw, dwr) < 1e-5
+    if bias:
+        assert _rel(outs[0][3], dy.double().sum(dim=0)) < 1e-5
+
+
+def test_linear_nd_native_on_views_and_fallbacks(gpu_device):
+    """Higher-rank activations, a column slice of a wider tensor (strided rows), a weight that is a view; and the shapes the kernels
+    do not serve (fp32 rows, few rows, odd widths, operand image beyond the LDS) still take the library route."""
+    from py4cast_amd.ops_rows import _row_gemm_ok, linear_nd
+
+    torch.manual_seed(52)
+    big = torch.randn(2, 64, 64, 96, device=gpu_device).bfloat16()
+    x = big[..., 16:64].detach().requires_grad_(True)                      # (2,64,64,48) view with row stride 96
+    wfull = torch.randn(40, 64, device=gpu_device, requires_grad=True)
+    w = wfull[:, 8:56]                                                      # strided weight view (ldw = 64)
+    b = torch.randn(40, device=gpu_device, requires_grad=True)
+    assert _row_gemm_ok(x, w, b)
+    y = linear_nd(x, w, b)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().double().requires_grad_(True)
+    wr = w.detach().bfloat16().double().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, b.detach().double())
+    yr.backward(gy.double())
+    assert y.shape == (2, 64, 64, 40) and _rel(y, yr) < 4e-3
+    assert _rel(x.grad, xr.grad) < 4e-3
+    assert _rel(wfull.grad[:, 8:56], wr.grad) < 1e-5 and float(wfull.grad[:, :8].abs().sum()) == 0.0
+    assert _rel(b.grad, gy.double().sum(dim=(0, 1, 2))) < 1e-5
+    w2 = torch.randn(40, 48, device=gpu_device)
+    assert not _row_gemm_ok(torch.randn(4096, 48, device=gpu_device), w2, None)                   # fp32 rows
+    assert not _row_gemm_ok(torch.randn(100, 48, device=gpu_device).bfloat16(), w2, None)         # few rows
+    assert not _row_gemm_ok(torch.randn(4096, 42, device=gpu_device).bfloat16(), torch.randn(40, 42, device=gpu_device), None)
+    assert not _row_gemm_ok(torch.randn(4096, 384, device=gpu_device).bfloat16(), torch.randn(768, 384, device=gpu_device), None)
+    assert not _row_gemm_ok(torch.randn(8192, 384, device=gpu_device).bfloat16(), torch.randn(96, 384, device=gpu_device), None)   # K beyond the weight-gradient kernel
+    assert not _row_gemm_ok(torch.randn(8192, 96, device=gpu_device).bfloat16(), torch.randn(288, 96, device=gpu_device), None)   # few rows for that weight
+    xs = torch.randn(4096, 42, device=gpu_device).bfloat16().requires_grad_(True)
+    ws = torch.randn(40, 42, device=gpu_device, requires_grad=True)
+    ys = linear_nd(xs, ws, None)
+    ys.sum().backward()
+    assert _rel(ys, xs.detach().double() @ ws.detach().bfloat16().double().t()) < 4e-3 and ws.grad is not None
