@@ -234,7 +234,19 @@ def _row_gemm_ok(x: torch.Tensor, w: torch.Tensor, b) -> bool:
     if 4 * R < 2 * (32 * ((O + 31) // 32)) * (16 * ((K + 15) // 16)):
         return False
     lib = L.lib()
-    return bool(lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K) and lib.p4c_row_gemm_wgrad_supported(O, K, int(b is not None)))
+    return bool(lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K) and _wgrad_chunks(O, K, b is not None) is not None)
+
+
+_WGRAD_KMAX = 192   # input features per weight-gradient launch (the kernel holds 64 x (K + 1) accumulators per workgroup)
+
+
+def _wgrad_chunks(O: int, K: int, has_bias: bool):
+    """Column ranges of x the weight-gradient kernel takes one launch each (wider inputs -- the 4 x 69-channel pixel blocks of
+    SwinUNetR's patch embedding -- go in pieces over strided views of the same rows); None if the layer is out of its range."""
+    chunks = [(k0, min(k0 + _WGRAD_KMAX, K)) for k0 in range(0, K, _WGRAD_KMAX)]
+    if len(chunks) > 4 or not all(L.lib().p4c_row_gemm_wgrad_supported(O, k1 - k0, int(has_bias and k1 == K)) for k0, k1 in chunks):
+        return None
+    return chunks
 
 
 def _row_gemm(x2: torch.Tensor, w: torch.Tensor, transposed: bool, bias, N: int) -> torch.Tensor:
@@ -280,14 +292,18 @@ class _LinearND(torch.autograd.Function):
             dw = db = None
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 lib = L.lib()
-                kp = 32 * ((K + int(ctx.has_bias) + 31) // 32)
-                out = torch.empty(64 * ((O + 63) // 64), kp, dtype=torch.float32, device=dy2.device)
-                ws = torch.empty(max(lib.p4c_row_gemm_wgrad_workspace_bytes(R, O, K, int(ctx.has_bias)) // 4, 1), dtype=torch.float32, device=dy2.device)
-                L.call("p4c_row_gemm_wgrad", L.ptr(dy2), dy2.stride(0), L.ptr(x2), x2.stride(0), L.ptr(out), L.ptr(ws), R, O, K, int(ctx.has_bias),
-                       L.stream(dy2.device), alg_bytes=R * (K + O) * 2)
-                dw = out[:O, :K].to(ctx.wdtype)
-                if ctx.has_bias:
-                    db = out[:O, K].to(ctx.bdtype)
+                parts = []
+                for k0, k1 in _wgrad_chunks(O, K, ctx.has_bias):
+                    kc, ones = k1 - k0, int(ctx.has_bias and k1 == K)     # the bias gradient rides with the last piece
+                    xs = x2[:, k0:k1]
+                    out = torch.empty(64 * ((O + 63) // 64), 32 * ((kc + ones + 31) // 32), dtype=torch.float32, device=dy2.device)
+                    ws = torch.empty(max(lib.p4c_row_gemm_wgrad_workspace_bytes(R, O, kc, ones) // 4, 1), dtype=torch.float32, device=dy2.device)
+                    L.call("p4c_row_gemm_wgrad", L.ptr(dy2), dy2.stride(0), L.ptr(xs), xs.stride(0), L.ptr(out), L.ptr(ws), R, O, kc, ones,
+                           L.stream(dy2.device), alg_bytes=R * (kc + O) * 2)
+                    parts.append(out[:O, :kc])
+                    if ones:
+                        db = out[:O, kc].to(ctx.bdtype)
+                dw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(ctx.wdtype)
             return dx, dw, db
         x, wq = ctx.saved_tensors
         O, K = wq.shape
@@ -303,5 +319,16 @@ class _LinearND(torch.autograd.Function):
 
 
 def linear_nd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``F.linear`` for activations of any rank with fp32 parameters (cast once per call), gradients as GEMMs."""
+    """``F.linear`` for activations of any rank with fp32 parameters: the row-GEMM kernels where they apply (csrc/rowgemm.hip),
+    else library GEMMs (weight cast once per call, gradients as GEMMs)."""
+    O = w.shape[0]
+    if O % 8 and w.dim() == 2 and x.is_cuda and x.numel() // max(w.shape[1], 1) >= 65536:
+        # an output width off the kernels' 8-feature granularity (SwinUNetR's final 24 -> 60 projection over 524 288 pixels, whose
+        # library weight / bias gradients took 290 + 210 us per call): run it with zero rows appended to the weight and slice the
+        # result -- two extra copies of the narrow output tensor against three GEMMs at the library's floor
+        O8 = (O + 7) // 8 * 8
+        wp = F.pad(w, (0, 0, 0, O8 - O))
+        bp = None if b is None else F.pad(b, (0, O8 - O))
+        if _row_gemm_ok(x, wp, bp):
+            return _LinearND.apply(x, wp, bp)[..., :O]
     return _LinearND.apply(x, w, b)

@@ -238,9 +238,12 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         B, H, W, C = x.shape
         xin = x.to(dt)
         # patch embedding: 2x2 / stride-2 convolution with bias = a GEMM over the 2x2 patches
-        pw = self.patch_embed.weight                                          # (fs, C, 2, 2)
-        patches = xin.view(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C)
-        t = R.linear_nd(patches, pw.permute(0, 2, 3, 1).reshape(pw.shape[0], 4 * C), self.patch_embed.bias)
+        pw = self.patch_embed.weight.permute(0, 2, 3, 1)                      # (fs, 2, 2, C)
+        xp, Cp = xin, C
+        if C % 2:   # rows of 4 C features: an even C makes them multiples of 8 (16-byte rows for the row-GEMM kernels); zero weights there
+            xp, pw, Cp = F.pad(xin, (0, 1)), F.pad(pw, (0, 1)), C + 1
+        patches = xp.view(B, H // 2, 2, W // 2, 2, Cp).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * Cp)
+        t = R.linear_nd(patches, pw.reshape(pw.shape[0], 4 * Cp), self.patch_embed.bias)
         hidden = [self._hidden(t, dt)]
         for blocks, merge in zip(self.stages, self.merges):
             for blk in blocks:

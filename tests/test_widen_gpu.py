@@ -1188,7 +1188,7 @@ def test_tuned_gemm_selections_are_loaded_on_first_gpu_call(gpu_device):
 
 @pytest.mark.parametrize("R,K,O,bias", [
     (131072, 24, 72, True), (131072, 96, 24, True), (32768 + 17, 48, 144, True), (32768, 192, 48, True), (32768, 96, 384, True), (8192, 96, 96, True),
-    (32768, 96, 48, False), (2049, 24, 24, True), (4100, 40, 104, True), (1500, 8, 8, False), (40000, 200, 136, True), (5000, 64, 64, True)])
+    (32768, 96, 48, False), (2049, 24, 24, True), (131072, 280, 24, True), (16384, 384, 40, False), (4100, 40, 104, True), (1500, 8, 8, False), (40000, 200, 136, True), (5000, 64, 64, True)])
 def test_linear_nd_native_rows(gpu_device, R, K, O, bias):
     """ops_rows.linear_nd on the row-GEMM kernels (csrc/rowgemm.hip: SwinUNetR's token layers): y, dx, dW, db against float64 on the
     SAME bf16-rounded operands (one rounding of the outputs: <= 2^-8 relative per element for y / dx; the weight and bias gradients
@@ -1221,6 +1221,35 @@ def test_linear_nd_native_rows(gpu_device, R, K, O, bias):
     assert _rel(dw, dwr) < 1e-5
     if bias:
         assert _rel(outs[0][3], dy.double().sum(dim=0)) < 1e-5
+
+
+def test_linear_nd_native_with_an_odd_output_width(gpu_device):
+    """SwinUNetR's final projection (24 -> 60 features over every pixel): 60 is off the kernels' 8-feature granularity, linear_nd
+    appends zero rows to the weight, runs the native kernels and slices."""
+    from py4cast_amd.ops_rows import linear_nd
+
+    torch.manual_seed(53)
+    R, K, O = 2 * 256 * 256, 24, 60
+    x = torch.randn(2, 256, 256, K, device=gpu_device).bfloat16().requires_grad_(True)
+    w = (torch.randn(O, K, device=gpu_device) * 0.2).requires_grad_(True)
+    b = torch.randn(O, device=gpu_device, requires_grad=True)
+    called = []
+    from py4cast_amd import _lib as L
+    orig = L.call
+    L.call = lambda name, *a, **k: (called.append(name), orig(name, *a, **k))[1]
+    try:
+        y = linear_nd(x, w, b)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+    finally:
+        L.call = orig
+    assert "p4c_row_gemm" in called and "p4c_row_gemm_wgrad" in called
+    wq = w.detach().bfloat16().double()
+    yr = x.detach().double() @ wq.t() + b.detach().double()
+    assert y.shape == (2, 256, 256, O) and _rel(y, yr) < 4e-3
+    assert _rel(x.grad, gy.double() @ wq) < 4e-3
+    assert _rel(w.grad, gy.double().reshape(R, O).t() @ x.detach().double().reshape(R, K)) < 1e-5
+    assert _rel(b.grad, gy.double().reshape(R, O).sum(dim=0)) < 1e-5
 
 
 def test_linear_nd_native_on_views_and_fallbacks(gpu_device):
