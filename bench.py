@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--cpu-crop", type=int, default=0, help="debugging: time the CPU baseline on a crop of this size (scaled)")
     ap.add_argument("--no-fp32-flavour", action="store_true",
                     help="skip the short fp32 (parity flavour) measurement reported as `fp32_flavour`")
+    ap.add_argument("--no-larger-batch", action="store_true", help="skip the short `larger_batch` measurement (bf16, --larger-batch samples per GPU)")
+    ap.add_argument("--larger-batch", type=int, default=8)
     return ap.parse_args()
 
 
@@ -234,16 +236,16 @@ def cpu_baseline(args, seconds):
     }
 
 
-def fp32_flavour(args, case, info, device, steps=6, warmup=2):
+def fp32_flavour(args, case, info, device, steps=6, warmup=2, dtype="f32", batch=None):
     from py4cast_amd import _lib as L
     from py4cast_amd.lightning import AutoRegressiveLightning
     from py4cast_amd.trainer import FlatDDP
 
     H, W = args.grid
-    B, T = args.batch, args.pred_steps
+    B, T = batch or args.batch, args.pred_steps
     torch.manual_seed(1234)
     lm = AutoRegressiveLightning(
-        {"compute_dtype": "f32", "activation_dtype": "f32"}, info, None, num_input_steps=1, num_pred_steps_train=T,
+        {"compute_dtype": dtype, "activation_dtype": dtype}, info, None, num_input_steps=1, num_pred_steps_train=T,
         num_pred_steps_val_test=T, batch_size=B, model_name=args.model,
         losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
         training_strategy="scaled_ar", learning_rate=1e-3, min_learning_rate=3e-7, num_warmup_steps=1000, betas=(0.9, 0.95),
@@ -271,7 +273,7 @@ def fp32_flavour(args, case, info, device, steps=6, warmup=2):
     roof = lm.model.roofline({}, B=B, H=H, W=W)
     L.lib().p4c_prof_enable(0, 0)
     return {"value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-            "dtype": "f32", "loss": float(loss.detach()), "roofline": roof}
+            "dtype": dtype, "batch_per_gpu": B, "loss": float(loss.detach()), "roofline": roof}
 
 
 def main():
@@ -511,6 +513,7 @@ def main():
                 "setup_steps": args.setup_steps,
                 "accumulate_grad_batches": args.accumulate,
                 "hip_graph": bool(use_graph), "hip_graph_check": graph_note,
+                "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
                 "launch_mode_probe": probe,
             },
             "loss": float(loss.detach()),
@@ -524,6 +527,14 @@ def main():
             del lm, ddp, opt
             torch.cuda.empty_cache()
             out["fp32_flavour"] = fp32_flavour(args, case, info, device)
+            if not args.no_larger_batch and args.batch < args.larger_batch:
+                # the SAME workload with a per-GPU batch sized for this GPU's memory rather than the reference yaml's 2
+                # (config/CLI/dataset/titan.yaml:7; 15 GiB of 288 at B=8): `value` above stays the B=2 configuration of BASELINE.md
+                torch.cuda.empty_cache()
+                big = synthetic_case(1234 + rank, args.larger_batch, T, 1, H, W, F, Ff, Fs, args.border, device)
+                out["larger_batch"] = fp32_flavour(args, big, info, device, steps=5, warmup=2, dtype="bf16", batch=args.larger_batch)
+                out["larger_batch"]["note"] = ("same rollout / loss / optimizer and model at a per-GPU batch the 288 GB of HBM invite; not the "
+                                               "headline `value` (BASELINE.md fixes B=2 per GPU)")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out))
