@@ -220,21 +220,29 @@ def _rows2d(t: torch.Tensor, C: int) -> torch.Tensor:
     return t2
 
 
-def _row_gemm_ok(x: torch.Tensor, w: torch.Tensor, b) -> bool:
-    """The native kernels serve bf16 rows with fp32 master parameters, from 1 024 rows (below that the library's ~20 us floor does
-    not matter), in the sizes p4c_row_gemm_supported / _wgrad_supported state (include/py4cast_hip.h)."""
+def _row_gemm_mode(x: torch.Tensor, w: torch.Tensor, b) -> str:
+    """Which passes of a Linear the native kernels take: "all" (forward, data gradient, weight + bias gradient) or "" (library).  They serve bf16 rows with fp32 master
+    parameters, from 1 024 rows (below that the library's ~20 us floor does not matter), in the sizes p4c_row_gemm_supported /
+    _wgrad_supported state (include/py4cast_hip.h)."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.float32 and w.dim() == 2 and (b is None or b.dtype == torch.float32)):
-        return False
+        return ""
     O, K = w.shape
     R = x.numel() // max(K, 1)
-    if R < 1024 or K % 8 or O % 8:
-        return False
-    # every workgroup lays the weight out as its operand image first: with few rows and a large weight that costs more than the
-    # library's floor (measured: 8 192 rows x (96 -> 288) 26 us against 21; 96 -> 96 11 against 21; tools/diagnostics/linear_micro.py)
-    if 4 * R < 2 * (32 * ((O + 31) // 32)) * (16 * ((K + 15) // 16)):
-        return False
+    if R < 1024 or K % 8 or O % 8 or _wgrad_chunks(O, K, b is not None) is None:
+        return ""
     lib = L.lib()
-    return bool(lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K) and _wgrad_chunks(O, K, b is not None) is not None)
+    # forward / data gradient: every workgroup lays the weight out as its operand image first; with few rows and a large weight that
+    # costs more than the library's floor (measured: 8 192 rows x (96 -> 288) 26 us against 21, its data gradient 35 against 19;
+    # 96 -> 96 11 against 21; tools/diagnostics/linear_micro.py).  The weight gradient wins in either case (18 against 52 + a bias GEMM)
+    if (4 * R >= 2 * (32 * ((O + 31) // 32)) * (16 * ((K + 15) // 16)) and lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K)):
+        return "all"
+    # (only the weight gradient natively, with library forward / data gradient, was measured too: SwinUNetR 40.6 -> 41.5 ms, UNetRPP
+    # 352 -> 358 -- the extra row copies cost more than the weight gradient gains at these sizes; not used)
+    return ""
+
+
+def _row_gemm_ok(x: torch.Tensor, w: torch.Tensor, b) -> bool:
+    return _row_gemm_mode(x, w, b) == "all"
 
 
 _WGRAD_KMAX = 192   # input features per weight-gradient launch (the kernel holds 64 x (K + 1) accumulators per workgroup)
@@ -268,48 +276,53 @@ class _LinearND(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        ctx.native = _row_gemm_ok(x, w, b)
+        mode = _row_gemm_mode(x, w, b)
+        ctx.mode = mode
         ctx.has_bias, ctx.wdtype, ctx.bdtype = b is not None, w.dtype, (None if b is None else b.dtype)
-        if ctx.native:
+        ctx.xshape = x.shape
+        if mode == "all":
             O, K = w.shape
             wc = w.detach() if w.stride(1) == 1 else w.detach().contiguous()
             x2 = _rows2d(x.detach(), K)
             ctx.save_for_backward(x2, wc)
-            ctx.xshape = x.shape
             return _row_gemm(x2, wc, False, None if b is None else b.detach().contiguous(), O).view(*x.shape[:-1], O)
         wq = w.to(x.dtype)
         ctx.save_for_backward(x, wq)
         return F.linear(x, wq, None if b is None else b.to(x.dtype))
 
     @staticmethod
+    def _native_wgrad(ctx, dy2, x2, O, K):
+        lib = L.lib()
+        R = x2.shape[0]
+        parts, db = [], None
+        for k0, k1 in _wgrad_chunks(O, K, ctx.has_bias):
+            kc, ones = k1 - k0, int(ctx.has_bias and k1 == K)     # the bias gradient rides with the last piece
+            xs = x2[:, k0:k1]
+            out = torch.empty(64 * ((O + 63) // 64), 32 * ((kc + ones + 31) // 32), dtype=torch.float32, device=dy2.device)
+            ws = torch.empty(max(lib.p4c_row_gemm_wgrad_workspace_bytes(R, O, kc, ones) // 4, 1), dtype=torch.float32, device=dy2.device)
+            L.call("p4c_row_gemm_wgrad", L.ptr(dy2), dy2.stride(0), L.ptr(xs), xs.stride(0), L.ptr(out), L.ptr(ws), R, O, kc, ones,
+                   L.stream(dy2.device), alg_bytes=R * (kc + O) * 2)
+            parts.append(out[:O, :kc])
+            if ones:
+                db = out[:O, kc].to(ctx.bdtype)
+        dw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(ctx.wdtype)
+        return dw, db
+
+    @staticmethod
     def backward(ctx, dy):
-        if ctx.native:
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if ctx.mode == "all":
             x2, wc = ctx.saved_tensors
             O, K = wc.shape
-            R = x2.shape[0]
             dy2 = _rows2d(dy, O)
             dx = _row_gemm(dy2, wc, True, None, K).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-            dw = db = None
-            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-                lib = L.lib()
-                parts = []
-                for k0, k1 in _wgrad_chunks(O, K, ctx.has_bias):
-                    kc, ones = k1 - k0, int(ctx.has_bias and k1 == K)     # the bias gradient rides with the last piece
-                    xs = x2[:, k0:k1]
-                    out = torch.empty(64 * ((O + 63) // 64), 32 * ((kc + ones + 31) // 32), dtype=torch.float32, device=dy2.device)
-                    ws = torch.empty(max(lib.p4c_row_gemm_wgrad_workspace_bytes(R, O, kc, ones) // 4, 1), dtype=torch.float32, device=dy2.device)
-                    L.call("p4c_row_gemm_wgrad", L.ptr(dy2), dy2.stride(0), L.ptr(xs), xs.stride(0), L.ptr(out), L.ptr(ws), R, O, kc, ones,
-                           L.stream(dy2.device), alg_bytes=R * (kc + O) * 2)
-                    parts.append(out[:O, :kc])
-                    if ones:
-                        db = out[:O, kc].to(ctx.bdtype)
-                dw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(ctx.wdtype)
+            dw, db = _LinearND._native_wgrad(ctx, dy2, x2, O, K) if want_w else (None, None)
             return dx, dw, db
         x, wq = ctx.saved_tensors
         O, K = wq.shape
         dy2 = dy.reshape(-1, O)
-        x2 = x.reshape(-1, K)
         dx = (dy2 @ wq).view(x.shape) if ctx.needs_input_grad[0] else None
+        x2 = x.reshape(-1, K)
         dw = (dy2.t() @ x2).to(ctx.wdtype) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -329,6 +342,6 @@ def linear_nd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None
         O8 = (O + 7) // 8 * 8
         wp = F.pad(w, (0, 0, 0, O8 - O))
         bp = None if b is None else F.pad(b, (0, O8 - O))
-        if _row_gemm_ok(x, wp, bp):
+        if _row_gemm_mode(x, wp, bp) == "all":
             return _LinearND.apply(x, wp, bp)[..., :O]
     return _LinearND.apply(x, w, b)
