@@ -430,7 +430,7 @@ int p4c_row_linear_wgrad(const void* dy, const void* x, float* dw_db, void* work
  *   y[r][n] = sum_k x[r][k] M[n][k] (+ bias[n]),  M[n][k] = transposed ? w[k * ldw + n] : w[n * ldw + k]
  * x (R, K) and y (R, N) bf16 rows with row strides ldx / ldy (elements; views of wider tensors are fine), w the fp32 master weight
  * (laid out as the bf16 matrix-core operand inside the kernel: no cast launch), bias fp32 or NULL.  Forward: M = W.  Data gradient:
- * x = dy, w = W, transposed = 1, K and N swapped.  K a multiple of 8 up to 384, N a multiple of 4, operand image within LDS:
+ * x = dy, w = W, transposed = 1, K and N swapped.  K a multiple of 8 up to 512, N a multiple of 4, operand image within LDS:
  * p4c_row_gemm_supported(K, N) says whether a shape is served (callers use the library GEMM otherwise). */
 int p4c_row_gemm_supported(int K, int N);
 int p4c_row_gemm(const void* x, int64_t ldx, const float* w, int ldw, int transposed, const float* bias, void* y, int64_t ldy,

@@ -56,14 +56,28 @@ __global__ void __launch_bounds__(256, (S <= 8 ? 2 : 1)) row_gemm_kernel(RowGemm
     __bf16* img = reinterpret_cast<__bf16*>(smem);
     float* lb = reinterpret_cast<float*>(smem + (size_t)tiles * S * 64 * 16);
     {
-        const int total = tiles * S * 64 * 8;
-        for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-            const int j = idx & 7, ln = (idx >> 3) & 63, ts = idx >> 9;
+        // one 16-byte operand piece (8 consecutive k of one n) per thread and trip: two float4 loads of the master weight when its
+        // rows allow it (K is a multiple of 8, so a piece is all inside or all outside the matrix), eight strided ones when transposed
+        const int pieces = tiles * S * 64;
+        const bool vec = !a.transposed && (a.ldw & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.w) & 15) == 0);
+        for (int idx = threadIdx.x; idx < pieces; idx += blockDim.x) {
+            const int ln = idx & 63, ts = idx >> 6;
             const int s = ts % S, tile = ts / S;
-            const int n = 32 * tile + (ln & 31), k = 16 * s + 8 * (ln >> 5) + j;
-            float v = 0.f;
-            if (n < a.N && k < a.K) v = a.transposed ? a.w[(int64_t)k * a.ldw + n] : a.w[(int64_t)n * a.ldw + k];
-            img[idx] = (__bf16)v;
+            const int n = 32 * tile + (ln & 31), k0 = 16 * s + 8 * (ln >> 5);
+            bf16x8 o = zero8();
+            if (n < a.N && k0 < a.K) {
+                if (vec) {
+                    const float4 lo = *reinterpret_cast<const float4*>(a.w + (int64_t)n * a.ldw + k0);
+                    const float4 hi = *reinterpret_cast<const float4*>(a.w + (int64_t)n * a.ldw + k0 + 4);
+                    o[0] = (__bf16)lo.x; o[1] = (__bf16)lo.y; o[2] = (__bf16)lo.z; o[3] = (__bf16)lo.w;
+                    o[4] = (__bf16)hi.x; o[5] = (__bf16)hi.y; o[6] = (__bf16)hi.z; o[7] = (__bf16)hi.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        o[j] = (__bf16)(a.transposed ? a.w[(int64_t)(k0 + j) * a.ldw + n] : a.w[(int64_t)n * a.ldw + k0 + j]);
+                }
+            }
+            *reinterpret_cast<bf16x8*>(img + (int64_t)idx * 8) = o;
         }
         for (int i = threadIdx.x; i < 32 * tiles; i += blockDim.x) lb[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
     }
@@ -262,12 +276,12 @@ __global__ void __launch_bounds__(256) row_gemm_reduce_kernel(const float* __res
     }
 }
 
-constexpr int MAX_S = 24;             // K <= 384 features
-constexpr int FWD_LDS_LIMIT = 120 * 1024;
+constexpr int MAX_S = 32;             // K <= 512 features
+constexpr int FWD_LDS_LIMIT = 144 * 1024;
 
 int fwd_steps(int K) {   // k-steps of 16 the instantiation for K uses (the image is zero-padded to it)
     const int s = (K + 15) / 16;
-    return s <= 4 ? s : s <= 6 ? 6 : s <= 8 ? 8 : s <= 12 ? 12 : s <= 16 ? 16 : 24;
+    return s <= 4 ? s : s <= 6 ? 6 : s <= 8 ? 8 : s <= 12 ? 12 : s <= 16 ? 16 : s <= 24 ? 24 : 32;
 }
 
 int fwd_lds_bytes(int K, int N) {
@@ -329,7 +343,7 @@ extern "C" int p4c_row_gemm_supported(int K, int N) {
 extern "C" int p4c_row_gemm(const void* x, int64_t ldx, const float* w, int ldw, int transposed, const float* bias, void* y, int64_t ldy,
                             int64_t R, int K, int N, p4c_stream_t stream) {
     P4C_CHECK_ARG(x && w && y, "p4c_row_gemm: NULL pointer");
-    P4C_CHECK_ARG(R >= 0 && p4c_row_gemm_supported(K, N), "p4c_row_gemm: unsupported sizes R=%lld K=%d N=%d (K multiple of 8 up to 384, N multiple of 4, "
+    P4C_CHECK_ARG(R >= 0 && p4c_row_gemm_supported(K, N), "p4c_row_gemm: unsupported sizes R=%lld K=%d N=%d (K multiple of 8 up to 512, N multiple of 4, "
                   "weight image within %d KiB of LDS)", (long long)R, K, N, FWD_LDS_LIMIT / 1024);
     P4C_CHECK_ARG(ldx >= K && ldy >= N && ldx % 8 == 0 && ldy % 4 == 0, "p4c_row_gemm: row strides must cover the rows (ldx multiple of 8, ldy of 4)");
     if (R == 0) return P4C_OK;
@@ -344,7 +358,8 @@ extern "C" int p4c_row_gemm(const void* x, int64_t ldx, const float* w, int ldw,
         case 8: return launch_fwd<8>(a, st);
         case 12: return launch_fwd<12>(a, st);
         case 16: return launch_fwd<16>(a, st);
-        default: return launch_fwd<24>(a, st);
+        case 24: return launch_fwd<24>(a, st);
+        default: return launch_fwd<32>(a, st);
     }
 }
 

@@ -231,14 +231,22 @@ def _row_gemm_mode(x: torch.Tensor, w: torch.Tensor, b) -> str:
     if R < 1024 or K % 8 or O % 8 or _wgrad_chunks(O, K, b is not None) is None:
         return ""
     lib = L.lib()
-    # forward / data gradient: every workgroup lays the weight out as its operand image first; with few rows and a large weight that
-    # costs more than the library's floor (measured: 8 192 rows x (96 -> 288) 26 us against 21, its data gradient 35 against 19;
-    # 96 -> 96 11 against 21; tools/diagnostics/linear_micro.py).  The weight gradient wins in either case (18 against 52 + a bias GEMM)
-    if (4 * R >= 2 * (32 * ((O + 31) // 32)) * (16 * ((K + 15) // 16)) and lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K)):
-        return "all"
-    # (only the weight gradient natively, with library forward / data gradient, was measured too: SwinUNetR 40.6 -> 41.5 ms, UNetRPP
-    # 352 -> 358 -- the extra row copies cost more than the weight gradient gains at these sizes; not used)
-    return ""
+    if not (lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K)):
+        return ""
+    # Measured per shape against the (tuned) library GEMMs, tools/diagnostics/linear_micro.py:
+    # * forward / data gradient: every workgroup first lays the weight out as its operand image -- 9 us against the library's 20 us
+    #   floor while the image is small against the rows (bytes <= 4 x rows: 32 KiB at 8 192 rows); the 131 KiB images (128 -> 512)
+    #   lose outright (34 against 20), and in the SwinUNetR step the 74 KiB ones at 8 192 rows did not pay either (40.6 -> 41.0 ms);
+    # * weight + bias gradient: wins for inputs up to 128 features (21 us against 96 + a bias GEMM at 64 -> 128 over 32 768 rows),
+    #   is on par for wider ones over >= 32 768 rows, and loses with fewer (384 features over 8 192 rows: 138 us against 26 + 20).
+    pad = lambda n, m: (n + m - 1) // m * m   # noqa: E731
+    steps = lambda k: next(s for s in (16, 32, 48, 64, 96, 128, 192, 256, 384, 512) if s >= k)   # noqa: E731  (the kernel's instantiations)
+    image = 2 * max(pad(O, 32) * steps(K), pad(K, 32) * steps(O))
+    if image > 80 * 1024 or 4 * R < image:
+        return ""
+    if not (K <= 128 or R >= 32768):
+        return ""
+    return "all"
 
 
 def _row_gemm_ok(x: torch.Tensor, w: torch.Tensor, b) -> bool:

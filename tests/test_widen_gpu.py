@@ -1188,7 +1188,7 @@ def test_tuned_gemm_selections_are_loaded_on_first_gpu_call(gpu_device):
 
 @pytest.mark.parametrize("R,K,O,bias", [
     (131072, 24, 72, True), (131072, 96, 24, True), (32768 + 17, 48, 144, True), (32768, 192, 48, True), (32768, 96, 384, True), (8192, 96, 96, True),
-    (32768, 96, 48, False), (2049, 24, 24, True), (131072, 280, 24, True), (16384, 384, 40, False), (4100, 40, 104, True), (1500, 8, 8, False), (40000, 200, 136, True), (5000, 64, 64, True)])
+    (32768, 96, 48, False), (2049, 24, 24, True), (131072, 280, 24, True), (32768, 384, 40, False), (4100, 40, 104, True), (1500, 8, 8, False), (40000, 200, 104, True), (5000, 64, 64, True)])
 def test_linear_nd_native_rows(gpu_device, R, K, O, bias):
     """ops_rows.linear_nd on the row-GEMM kernels (csrc/rowgemm.hip: SwinUNetR's token layers): y, dx, dW, db against float64 on the
     SAME bf16-rounded operands (one rounding of the outputs: <= 2^-8 relative per element for y / dx; the weight and bias gradients
