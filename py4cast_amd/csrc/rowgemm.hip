@@ -9,7 +9,7 @@
 //   * row_gemm_wgrad_kernel : dW[n][k] = sum_r dY[r][n] X[r][k] and db[n] = sum_r dY[r][n] (as one more column: a ones column
 //     appended to the X tile).  The reduction index is the ROW, so both operands are transposed LDS reads (ds_read_b64_tr_b16) of the
 //     [row][feature] tiles; blockIdx.y takes 64 output features, persistent waves keep the 64 x K accumulator in registers,
-//     per-workgroup partials are summed in a fixed order by row_gemm_reduce_kernel (no atomics: bit-identical reruns).
+//     per-wave partials are summed in a fixed order by row_gemm_reduce_kernel (no atomics: bit-identical reruns).
 #include "common.hpp"
 
 namespace p4c {
@@ -141,13 +141,14 @@ __global__ void __launch_bounds__(256, (S <= 8 ? 2 : 1)) row_gemm_kernel(RowGemm
 
 // ------------------------------------------------------------------------------------------------ weight (+ bias) gradient
 constexpr int WROWS = 64;   // rows per wave tile
+constexpr int WAVE_SLOTS_FROM = 4;   // input tiles (32 columns) from which every wave writes its own partial
 
 struct RowWgradArgs {
     const bf16* dy;     // (R, N), row stride ldy
     int64_t ldy;
     const bf16* x;      // (R, K), row stride ldx
     int64_t ldx;
-    float* partial;     // [gridDim.x][gridDim.y][64][32 * NT]
+    float* partial;     // [gridDim.x][4 waves (NT >= WAVE_SLOTS_FROM) | 1][gridDim.y][64][32 * NT]
     int64_t R;
     int N, K, ones;     // ones: 1 = append the ones column (index K) whose products are the bias gradient
 };
@@ -226,27 +227,40 @@ __global__ void __launch_bounds__(256, 1) row_gemm_wgrad_kernel(RowWgradArgs a) 
         asm volatile("" ::: "memory");
     }
 
-    // per-workgroup partial: the four waves add in wave order through LDS (fixed order)
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);                 // [64][KP]
     const int r = lane & 31;
-    for (int turn = 0; turn < 4; ++turn) {
-        if (wv == turn) {
+    if constexpr (NT >= WAVE_SLOTS_FROM) {
+        // wide inputs: every wave hands its accumulators to its own partial slot (for a fixed accumulator element the 32 lanes of a
+        // half-wave write 128 contiguous bytes).  Adding the four waves through LDS first cost four serial turns of 64 x KP scattered
+        // LDS updates -- ~20 us of a 69 us launch at KP = 224 -- against 4x the partial traffic this way
+        float* dst = a.partial + (((int64_t)blockIdx.x * 4 + wv) * gridDim.y + blockIdx.y) * (64 * KP);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int o = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h, k = 32 * n + r;
-                        if (turn == 0) red[o * KP + k] = acc[m][n][i];
-                        else red[o * KP + k] += acc[m][n][i];
-                    }
-        }
+                for (int i = 0; i < 16; ++i) dst[(32 * m + (i & 3) + 8 * (i >> 2) + 4 * h) * KP + 32 * n + r] = acc[m][n][i];
+    } else {
+        // narrow inputs: the four waves add in wave order through LDS (cheap at <= 96 columns), one partial per workgroup
         __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);                 // [64][KP]
+        for (int turn = 0; turn < 4; ++turn) {
+            if (wv == turn) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int o = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h, k = 32 * n + r;
+                            if (turn == 0) red[o * KP + k] = acc[m][n][i];
+                            else red[o * KP + k] += acc[m][n][i];
+                        }
+            }
+            __syncthreads();
+        }
+        float* dst = a.partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (64 * KP);
+        for (int i = threadIdx.x; i < 64 * KP; i += blockDim.x) dst[i] = red[i];
     }
-    float* dst = a.partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (64 * KP);
-    for (int i = threadIdx.x; i < 64 * KP; i += blockDim.x) dst[i] = red[i];
 }
 
 // out[j] = sum_s partial[s][j], j < n, in a fixed order: a block owns 32 outputs, its 8 thread rows take the slots s = sg (mod 8)
@@ -300,10 +314,13 @@ int fwd_grid(int64_t R) {
 
 int wgrad_nt(int K, int with_bias) { return (K + (with_bias ? 1 : 0) + 31) / 32; }
 
-int wgrad_grid(int64_t R, int chunks) {
+int wgrad_slots_per_wg(int NT) { return NT >= WAVE_SLOTS_FROM ? 4 : 1; }
+
+int wgrad_grid(int64_t R, int chunks, int NT) {
     const int64_t tiles = (R + WROWS - 1) / WROWS;
-    int64_t blocks = (tiles + 7) / 8;          // at least two tiles per wave: a workgroup's fixed costs (clearing its LDS tiles, the
-                                               // four-turn reduction, 14-57 KB of partials) are those of ~1.5 tiles
+    // narrow inputs: at least two tiles per wave (a workgroup's fixed costs -- clearing its LDS tiles, the four-turn reduction, its
+    // partial -- are those of ~1.5 tiles); wide ones (per-wave partials, no reduction turns): one
+    int64_t blocks = NT >= WAVE_SLOTS_FROM ? (tiles + 3) / 4 : (tiles + 7) / 8;
     int64_t cap = num_cus() / chunks;          // one workgroup per CU (the LDS tiles of four waves fill it)
     if (cap < 1) cap = 1;
     if (blocks > cap) blocks = cap;
@@ -370,7 +387,8 @@ extern "C" int p4c_row_gemm_wgrad_supported(int N, int K, int with_bias) {
 extern "C" size_t p4c_row_gemm_wgrad_workspace_bytes(int64_t R, int N, int K, int with_bias) {
     if (R <= 0 || !p4c_row_gemm_wgrad_supported(N, K, with_bias)) return 0;
     const int chunks = (N + 63) / 64;
-    return (size_t)wgrad_grid(R, chunks) * chunks * 64 * 32 * wgrad_nt(K, with_bias) * sizeof(float);
+    const int NT = wgrad_nt(K, with_bias);
+    return (size_t)wgrad_grid(R, chunks, NT) * wgrad_slots_per_wg(NT) * chunks * 64 * 32 * NT * sizeof(float);
 }
 
 extern "C" int p4c_row_gemm_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, float* out, void* workspace, int64_t R, int N,
@@ -380,7 +398,7 @@ extern "C" int p4c_row_gemm_wgrad(const void* dy, int64_t ldy, const void* x, in
                   "(multiples of 8, K (+1 with bias) <= 224, N <= 512)", (long long)R, N, K);
     P4C_CHECK_ARG(ldy >= N && ldx >= K && ldy % 8 == 0 && ldx % 8 == 0, "p4c_row_gemm_wgrad: row strides must be multiples of 8 covering the rows");
     const int chunks = (N + 63) / 64, NT = wgrad_nt(K, with_bias);
-    const int G = wgrad_grid(R, chunks);
+    const int G = wgrad_grid(R, chunks, NT);
     RowWgradArgs a{(const bf16*)dy, ldy, (const bf16*)x, ldx, (float*)workspace, R, N, K, with_bias ? 1 : 0};
     hipStream_t st = as_stream(stream);
     int rc;
@@ -395,7 +413,7 @@ extern "C" int p4c_row_gemm_wgrad(const void* dy, int64_t ldy, const void* x, in
     }
     if (rc != P4C_OK) return rc;
     const int n = chunks * 64 * 32 * NT;
-    hipLaunchKernelGGL(row_gemm_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)workspace, G, n, out);
+    hipLaunchKernelGGL(row_gemm_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, (const float*)workspace, wgrad_slots_per_wg(NT) * G, n, out);
     P4C_CHECK_LAUNCH("row_gemm_reduce");
     return P4C_OK;
 }

@@ -237,14 +237,12 @@ def _row_gemm_mode(x: torch.Tensor, w: torch.Tensor, b) -> str:
     # * forward / data gradient: every workgroup first lays the weight out as its operand image -- 9 us against the library's 20 us
     #   floor while the image is small against the rows (bytes <= 4 x rows: 32 KiB at 8 192 rows); the 131 KiB images (128 -> 512)
     #   lose outright (34 against 20), and in the SwinUNetR step the 74 KiB ones at 8 192 rows did not pay either (40.6 -> 41.0 ms);
-    # * weight + bias gradient: wins for inputs up to 128 features (21 us against 96 + a bias GEMM at 64 -> 128 over 32 768 rows),
-    #   is on par for wider ones over >= 32 768 rows, and loses with fewer (384 features over 8 192 rows: 138 us against 26 + 20).
+    # * weight + bias gradient: 12-31 us per piece of <= 192 input features against the library's 25-190 us + a 20 us bias GEMM
+    #   (64 -> 128 over 32 768 rows: 21 against 96 + 20; 384 -> 96 over 8 192 rows, two pieces: 46 against 26 + 20, the worst case).
     pad = lambda n, m: (n + m - 1) // m * m   # noqa: E731
     steps = lambda k: next(s for s in (16, 32, 48, 64, 96, 128, 192, 256, 384, 512) if s >= k)   # noqa: E731  (the kernel's instantiations)
     image = 2 * max(pad(O, 32) * steps(K), pad(K, 32) * steps(O))
     if image > 80 * 1024 or 4 * R < image:
-        return ""
-    if not (K <= 128 or R >= 32768):
         return ""
     return "all"
 

@@ -26,9 +26,12 @@ for R, K, O in ((131072, 24, 72), (131072, 24, 24), (131072, 24, 96), (131072, 9
     if L.lib().p4c_row_gemm_supported(K, O) and L.lib().p4c_row_gemm_supported(O, K) and OR._wgrad_chunks(O, K, True) is not None:
         g = t(lambda: OR._row_gemm(x, wf, False, bf, O))
         a = t(lambda: OR._row_gemm(dy, wf, True, None, K))
-        class _C:  # a stand-in for the autograd ctx of _LinearND._native_wgrad
-            has_bias, wdtype, bdtype = True, torch.float32, torch.float32
-        c = t(lambda: OR._LinearND._native_wgrad(_C, dy, x, O, K))
+        lib = L.lib()
+        kc = min(K, 192)
+        kp = 32 * ((kc + 1 + 31) // 32)
+        out = torch.empty(64 * ((O + 63) // 64), kp, dtype=torch.float32, device=dev)
+        ws = torch.empty(max(lib.p4c_row_gemm_wgrad_workspace_bytes(R, O, kc, 1) // 4, 1), dtype=torch.float32, device=dev)
+        c = t(lambda: L.call("p4c_row_gemm_wgrad", L.ptr(dy), O, L.ptr(x), K, L.ptr(out), L.ptr(ws), R, O, kc, 1, L.stream(x.device)))   # (first <= 192 input features)
     else:
         g = a = c = float("nan")
     print(f"{R:7d} {K:4d} {O:4d} | {f:7.1f} | {dx:6.1f} | {dw:6.1f} | {g:7.1f} | {a:6.1f} | {c:9.1f} | {R * (K + O) * 2 / 1e6:6.1f}")
