@@ -545,7 +545,9 @@ int p4c_inorm_blocks(int64_t N, int C);
 int p4c_inorm_reduce(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope, float* partial,
                      int dtype, int B, int64_t N, int C, p4c_stream_t stream);
 /* dy == NULL: out = lrelu(x * scale[b,c] + shift[b,c] (+ res)).
- * dy != NULL: out = dx = scale * (dz - m1[b,c] - xhat * m2[b,c]); dres (optional) = dz. */
+ * dy != NULL: out = dx = scale * (dz - m1[b,c] - xhat * m2[b,c]); dres (optional) = dz.
+ * dy != NULL and rstd == NULL: out = dx = scale[b,c] * dz - m1[b,c] - (x - mean[b,c]) * m2[b,c]  (the caller's coefficients as they
+ * are: GroupNorm, whose statistics are shared by the channels of a group -- ops_inorm.group_norm). */
 int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
                     const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres, int dtype,
                     int B, int64_t N, int C, p4c_stream_t stream);

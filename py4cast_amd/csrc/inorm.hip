@@ -59,7 +59,8 @@ __global__ void __launch_bounds__(256) reduce_kernel(const T* __restrict__ x, co
     }
 }
 
-// forward: y = lrelu(x * scale[b,c] + shift[b,c] (+ res));  backward (MODE 1): dx = scale * (dz - m1 - xhat * m2), dres = dz
+// forward: y = lrelu(x * scale[b,c] + shift[b,c] (+ res));  backward (MODE 1): dx = scale * (dz - m1 - xhat * m2), dres = dz;
+// MODE 2 (rstd == NULL): dx = scale * dz - m1 - (x - mean) * m2
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ dy,
                                                     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -88,13 +89,22 @@ __global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, con
             store4f(out + off, o);
         } else {
             const p4c_f32x4 g = ld4(dy + off), yv = ld4(y + off);
-            const p4c_f32x4 sc = ld4(scale + b * C + 4 * q), mu = ld4(mean + b * C + 4 * q), rs = ld4(rstd + b * C + 4 * q);
+            const p4c_f32x4 sc = ld4(scale + b * C + 4 * q), mu = ld4(mean + b * C + 4 * q);
             const p4c_f32x4 a1 = ld4(m1 + b * C + 4 * q), a2 = ld4(m2 + b * C + 4 * q);
             p4c_f32x4 dz;
+            if (MODE == 1) {
+                const p4c_f32x4 rs = ld4(rstd + b * C + 4 * q);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                dz[k] = yv[k] > 0.f ? g[k] : g[k] * slope;
-                o[k] = sc[k] * (dz[k] - a1[k] - (xv[k] - mu[k]) * rs[k] * a2[k]);
+                for (int k = 0; k < 4; ++k) {
+                    dz[k] = yv[k] > 0.f ? g[k] : g[k] * slope;
+                    o[k] = sc[k] * (dz[k] - a1[k] - (xv[k] - mu[k]) * rs[k] * a2[k]);
+                }
+            } else {   // MODE 2: the caller's coefficients as they are (group norm: statistics shared by the channels of a group)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dz[k] = yv[k] > 0.f ? g[k] : g[k] * slope;
+                    o[k] = sc[k] * dz[k] - a1[k] - (xv[k] - mu[k]) * a2[k];
+                }
             }
             store4f(out + off, o);
             if (dres) store4f(dres + off, dz);
@@ -146,7 +156,7 @@ extern "C" int p4c_inorm_apply(const void* x, const void* res, const void* dy, c
                                int dtype, int B, int64_t N, int C, p4c_stream_t stream) {
     P4C_CHECK_ARG(x && out && scale && B > 0 && N > 0 && C > 0 && C % 4 == 0, "p4c_inorm_apply: bad arguments");
     const bool bwd = dy != nullptr;
-    P4C_CHECK_ARG(bwd ? (y && mean && rstd && m1 && m2) : (shift != nullptr), "p4c_inorm_apply: missing operands");
+    P4C_CHECK_ARG(bwd ? (y && mean && m1 && m2) : (shift != nullptr), "p4c_inorm_apply: missing operands");
     int64_t blocks = (N * (C / 4) + 255) / 256;
     const int64_t cap = (int64_t)num_cus() * 8 / B + 1;
     if (blocks > cap) blocks = cap;
@@ -155,8 +165,8 @@ extern "C" int p4c_inorm_apply(const void* x, const void* res, const void* dy, c
 #define P4C_IN_APP(T, M)                                                                                                        \
     hipLaunchKernelGGL((inorm::apply_kernel<T, M>), grid, dim3(256), 0, st, (const T*)x, (const T*)res, (const T*)dy, (const T*)y, scale, \
                        shift, mean, rstd, m1, m2, slope, (T*)out, (T*)dres, N, C)
-    if (dtype == P4C_F32) { if (bwd) P4C_IN_APP(float, 1); else P4C_IN_APP(float, 0); }
-    else if (dtype == P4C_BF16) { if (bwd) P4C_IN_APP(bf16, 1); else P4C_IN_APP(bf16, 0); }
+    if (dtype == P4C_F32) { if (!bwd) P4C_IN_APP(float, 0); else if (rstd) P4C_IN_APP(float, 1); else P4C_IN_APP(float, 2); }
+    else if (dtype == P4C_BF16) { if (!bwd) P4C_IN_APP(bf16, 0); else if (rstd) P4C_IN_APP(bf16, 1); else P4C_IN_APP(bf16, 2); }
     else return fail(P4C_ERR_INVALID, "p4c_inorm_apply: bad dtype");
 #undef P4C_IN_APP
     P4C_CHECK_LAUNCH("p4c_inorm_apply");

@@ -64,3 +64,56 @@ def instance_norm_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
     """``leaky_relu(instance_norm(x) * weight + bias (+ res), slope)`` for x (B, *spatial, C) features-last; slope = 1 gives the plain
     affine instance norm."""
     return _InstNormAct.apply(x, weight, bias, res, float(eps), float(slope))
+
+
+class _GroupNorm(torch.autograd.Function):
+    """GroupNorm(groups, C)(x) * weight + bias on a features-last tensor: per-(sample, channel) sums from p4c_inorm_reduce, the group
+    statistics from them (a few hundred numbers, torch), one streaming apply pass each way (p4c_inorm_apply).  With
+    xhat = (x - mean_g) rstd_g, M1 = mean_g(gamma dy), M2 = mean_g(gamma dy xhat):  dx = rstd_g (gamma_c dy - M1 - xhat M2)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps):
+        L.require_cuda(x)
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        sums, N = _reduce(x, None, None, None, None, 1.0)                   # (B, 2, C): sum x, sum x^2
+        n = float(N * (C // groups))
+        gs = sums.view(B, 2, groups, C // groups).sum(dim=-1)               # (B, 2, G)
+        mean_g = gs[:, 0] / n
+        rstd_g = torch.rsqrt((gs[:, 1] / n - mean_g * mean_g).clamp_min(0) + eps)
+        mean = mean_g.repeat_interleave(C // groups, dim=1).contiguous()    # (B, C)
+        rstd = rstd_g.repeat_interleave(C // groups, dim=1).contiguous()
+        scale = (rstd * weight.float()).contiguous()
+        shift = (bias.float() - mean * scale).contiguous()
+        y = torch.empty_like(x)
+        L.call("p4c_inorm_apply", L.ptr(x), None, None, None, L.ptr(scale), L.ptr(shift), None, None, None, None, 1.0, L.ptr(y), None,
+               L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
+        ctx.save_for_backward(x, mean, rstd, scale, weight)
+        ctx.groups, ctx.pdtype = groups, weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, scale, weight = ctx.saved_tensors
+        B, C, G = x.shape[0], x.shape[-1], ctx.groups
+        dy = dy.contiguous()
+        sums, N = _reduce(x, dy, x, mean, rstd, 1.0)                        # (B, 2, C): sum dy, sum dy xhat  (slope 1: y is not looked at)
+        n = float(N * (C // G))
+        gam = weight.float()
+        m = (sums * gam).view(B, 2, G, C // G).sum(dim=-1) / n              # (B, 2, G): M1, M2
+        M1 = m[:, 0].repeat_interleave(C // G, dim=1)
+        M2 = m[:, 1].repeat_interleave(C // G, dim=1)
+        c1 = (rstd * M1).contiguous()                                       # dx = scale dy - c1 - (x - mean) c2
+        c2 = (rstd * rstd * M2).contiguous()
+        dx = torch.empty_like(x)
+        L.call("p4c_inorm_apply", L.ptr(x), None, L.ptr(dy), L.ptr(x), L.ptr(scale), None, L.ptr(mean), None, L.ptr(c1), L.ptr(c2), 1.0,
+               L.ptr(dx), None, L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
+        return dx, sums[:, 1].sum(dim=0).to(ctx.pdtype), sums[:, 0].sum(dim=0).to(ctx.pdtype), None, None
+
+
+def group_norm(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """``F.group_norm`` for x (B, *spatial, C) features-last (statistics over the spatial positions and the C / groups channels of
+    a group, per sample)."""
+    if x.shape[-1] % groups:
+        raise L.P4CError(f"group_norm: {x.shape[-1]} channels do not divide into {groups} groups")
+    return _GroupNorm.apply(x, weight, bias, int(groups), float(eps))

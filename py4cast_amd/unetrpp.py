@@ -113,6 +113,12 @@ def _conv_transpose(m: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
 
 def _nrm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """group / batch / instance norm with fp32 parameters and statistics on a tensor of the activation dtype"""
+    if isinstance(m, nn.GroupNorm) and x.is_cuda and ON.supported(x.permute(0, 2, 3, 1)):
+        # the stem's GroupNorm (one group over 128 x 128 x 128 values per sample at the yaml's sizes: the library reduces each
+        # sample with ONE workgroup, 340 us): per-channel sums + one streaming pass on the instance-norm kernels
+        # (handed on NCHW-contiguous, as the library's GroupNorm does: with a channels_last result here MIOpen's immediate-mode
+        # heuristics picked other -- CK -- solvers for the 3x3 convolutions downstream and the step took 1 130 ms instead of 570)
+        return ON.group_norm(x.permute(0, 2, 3, 1), m.num_groups, m.weight, m.bias, m.eps).permute(0, 3, 1, 2).contiguous()
     if x.dtype in (torch.float32, torch.float64) or isinstance(m, nn.BatchNorm2d):   # the library's batch norm takes bf16 activations with fp32 parameters / statistics
         return m(x)
     return m(x.float()).to(x.dtype)
@@ -228,7 +234,11 @@ class UpBlock(nn.Module):
 
     def forward(self, x, skip):
         if self.linear:
-            x = _conv(self.up_conv, F.interpolate(x, scale_factor=self.scale, mode="bilinear", align_corners=False))
+            # mfai: up_conv(interpolate(x)).  A 1x1 convolution (per pixel, across channels) and the bilinear interpolation (per
+            # channel, across pixels, weights summing to 1 -- the bias passes through) commute: the convolution runs on the small
+            # grid (1 / scale^2 of the rows) and the interpolation on the convolution's fewer channels; same function, one rounding
+            # moved (decoder2 of the yaml: 128 -> 64 channels at 128 x 128 instead of 512 x 512)
+            x = F.interpolate(_conv(self.up_conv, x), scale_factor=self.scale, mode="bilinear", align_corners=False)
         else:
             x = _conv_transpose(self.up_conv, x)
         return self.decoder_block[0](x + skip)

@@ -1287,3 +1287,28 @@ def test_linear_nd_native_on_views_and_fallbacks(gpu_device):
     ys = linear_nd(xs, ws, None)
     ys.sum().backward()
     assert _rel(ys, xs.detach().double() @ ws.detach().bfloat16().double().t()) < 4e-3 and ws.grad is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,groups", [((2, 32, 48, 128), 1), ((2, 17, 9, 64), 4), ((3, 8, 8, 32), 32), ((1, 64, 64, 256), 8)])
+def test_group_norm_features_last(gpu_device, dtype, shape, groups):
+    """ops_inorm.group_norm (UNetRPP's down-sampling GroupNorms) against F.group_norm in float64: output, dx, dgamma, dbeta."""
+    from py4cast_amd.ops_inorm import group_norm
+
+    torch.manual_seed(61)
+    C = shape[-1]
+    x = (torch.randn(*shape) * 1.5 + 0.3).to(dtype)
+    g, b, dy = torch.rand(C) + 0.5, torch.randn(C), torch.randn(*shape).to(dtype)
+    g[3] = 0.0                                       # a zero weight must not break the backward
+    xg = x.to(gpu_device).requires_grad_(True)
+    gg, bg = g.to(gpu_device).requires_grad_(True), b.to(gpu_device).requires_grad_(True)
+    y = group_norm(xg, groups, gg, bg, 1e-5)
+    y.backward(dy.to(gpu_device))
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.group_norm(xr.permute(0, 3, 1, 2), groups, gr, br, 1e-5).permute(0, 2, 3, 1)
+    yr.backward(dy.double())
+    tol = 3e-6 if dtype == torch.float32 else 6e-3
+    assert _rel(y.detach().cpu(), yr.detach()) < tol
+    assert _rel(xg.grad.cpu(), xr.grad) < (2e-5 if dtype == torch.float32 else 8e-3)
+    assert _rel(gg.grad.cpu(), gr.grad) < 1e-4 and _rel(bg.grad.cpu(), br.grad) < 1e-4
