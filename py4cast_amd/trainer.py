@@ -283,31 +283,65 @@ class GraphedTrainingStep:
         self.warmup_backwards = warmup + 1   # gradient contributions already accumulated by construction: zero_grad() after
         self.verified = None
         if verify and all(g is not None for g in snaps):
-            self._verify(named, snaps, eager_loss.clone(), grads)
-            self.warmup_backwards += 1
+            self._verify(named, snaps, eager_loss.clone(), grads, run)
 
-    def _verify(self, named, snaps, eager_loss, grads):
+    def _verify(self, named, snaps, eager_loss, grads, run):
         """Replay the captured step once on the captured batch and hold its gradient contribution and loss against the eager
         warm-up passes on the same batch and weights.  A replay is only as good as every library call inside it is capture-safe,
         and that is not ours to promise: at the 512 x 512 sizes two library routes returned garbage / NaN from replays while
         every eager step was fine (the column-sum reduction behind Linear bias gradients, and 1x1 convolutions as bias-epilogue
         GEMMs -- DESIGN.md 7b).  So the graph has to earn its use: per parameter, the replay's gradient must match the eager one to
         the level two eager passes match each other (steps with a random element -- masks, dropout -- differ between eager
-        passes too and are not checked), else the constructor raises GraphReplayMismatch and callers stay eager."""
+        passes too and are not checked), else the constructor raises GraphReplayMismatch and callers stay eager.
+        Both failures showed only AFTER an optimizer step (a replay that keeps reading something derived from the parameters at
+        capture time), so the comparison is made twice: on the captured weights, and again after every parameter has been scaled by
+        1 + 2^-7 in place (restored afterwards)."""
         g1, g2, g3 = snaps
         inc_a, inc_b = g2 - g1, g3 - g2          # two eager contributions
         self.graph.replay()
+        self.warmup_backwards += 1
         inc_g = grads() - g3
-        graph_loss = self.loss.float()
+        graph_loss = self.loss.float().clone()
         lengths = torch.tensor([p.numel() for _, p in named], device=inc_g.device)
+        self._compare(named, lengths, inc_a, inc_b, inc_g, eager_loss, graph_loss, "")
+        first = self.verified
+        # ---- the same with changed parameters
+        from . import _lib as L
+
+        params = [p for _, p in named]
+        keep = [p.detach().clone() for p in params]
+        try:
+            with torch.no_grad():
+                torch._foreach_mul_(params, 1.0 + 2.0 ** -7)
+            L.PARAM_EPOCH[0] += 1
+            g4 = grads()
+            eager_loss2 = run(-1).float().clone()
+            g5 = grads()
+            self.graph.replay()
+            self.warmup_backwards += 2
+            g6 = grads()
+            graph_loss2 = self.loss.float().clone()
+            # eager-vs-eager spread: the one measured on the captured weights
+            self._compare(named, lengths, inc_a, g5 - g4, g6 - g5, eager_loss2, graph_loss2, " after a parameter update", spread_ref=inc_b)
+        finally:
+            with torch.no_grad():
+                for p, k in zip(params, keep):
+                    p.copy_(k)
+            L.PARAM_EPOCH[0] += 1
+        self.verified = first + "; also after a parameter update"
+
+    def _compare(self, named, lengths, inc_a, inc_b, inc_g, eager_loss, graph_loss, when, spread_ref=None):
+        """inc_b: the eager contribution the replay's (inc_g) is held against; inc_a (with spread_ref or inc_b): two eager contributions
+        on one set of weights, whose difference is the step's own spread."""
 
         def per_param(diff, ref):   # relative L2 error of every parameter's gradient
             num = torch.segment_reduce(diff.double().square(), "sum", lengths=lengths)
             den = torch.segment_reduce(ref.double().square(), "sum", lengths=lengths)
             return (num / den.clamp_min(1e-300)).sqrt(), den
 
-        base, den = per_param(inc_b - inc_a, inc_b)
-        got, _ = per_param(inc_g - inc_b, inc_b)
+        ref2 = inc_b if spread_ref is None else spread_ref
+        base, _ = per_param(ref2 - inc_a, ref2)
+        got, den = per_param(inc_g - inc_b, inc_b)
         live = den > 1e-24 * den.sum()     # a parameter whose gradient is (numerically) nothing has no relative error to judge
         finite = bool(torch.isfinite(inc_g).all()) or not bool(torch.isfinite(inc_b).all())
         # two eager passes on one batch and one set of weights that differ by percents: a random element in the step (masks,
@@ -322,7 +356,7 @@ class GraphedTrainingStep:
         if bad or not finite or not loss_ok:
             worst = max(bad, key=lambda i: float(torch.nan_to_num(got[i], nan=float("inf")))) if bad else None
             raise GraphReplayMismatch(
-                "the replayed training step does not reproduce the eager one: "
+                f"the replayed training step does not reproduce the eager one{when}: "
                 + (f"{len(bad)} of {len(named)} parameter gradients differ, worst {named[worst][0]} "
                    f"(relative error {float(got[worst]):.3g}, eager-vs-eager {float(base[worst]):.3g}); " if bad else "")
                 + f"loss eager {float(eager_loss):.6g} vs replay {float(graph_loss):.6g}")

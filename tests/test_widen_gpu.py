@@ -736,9 +736,27 @@ def test_graphed_step_is_verified_against_eager(gpu_device, tmp_path):
     ddp = FlatDDP(lm.model, 1)
     ddp.zero_grad()
     step = GraphedTrainingStep(lm, make_batch(case, gpu_device))
-    assert step.verified.startswith("replay == eager"), step.verified
-    assert step.warmup_backwards == 5
+    assert step.verified.startswith("replay == eager") and step.verified.endswith("also after a parameter update"), step.verified
+    assert step.warmup_backwards == 7                # 3 warm-up passes, the capture, replay, eager + replay on changed parameters
     del step
+
+    # a step that keeps something derived from the parameters OUTSIDE the graph (an eager-mode cache hit at capture time): right on
+    # the captured weights, stale after an update -- the second leg of the check
+    lm, case = _graph_lm(tmp_path, gpu_device)
+    ddp = FlatDDP(lm.model, 1)
+    ddp.zero_grad()
+    p0 = next(lm.model.parameters())
+    ref0 = float(p0.detach().abs().mean())
+    cache, inner0 = {}, lm.training_step
+
+    def stale(batch, idx):
+        if cache.get("version") != p0._version:
+            cache["version"], cache["factor"] = p0._version, (p0.detach().abs().mean() / ref0) ** 64
+        return inner0(batch, idx) * cache["factor"]
+    lm.training_step = stale
+    with pytest.raises(GraphReplayMismatch, match="after a parameter update"):
+        GraphedTrainingStep(lm, make_batch(case, gpu_device))
+    assert abs(float(p0.detach().abs().mean()) / ref0 - 1.0) < 1e-6          # the parameters are restored either way
 
     lm, case = _graph_lm(tmp_path, gpu_device)
     ddp = FlatDDP(lm.model, 1)
