@@ -337,6 +337,31 @@ class _LinearND(torch.autograd.Function):
         return dx, dw, db
 
 
+class _AddBias(torch.autograd.Function):
+    """x (..., O) + b (O,), with the bias gradient as a ``ones @ dy`` GEMM instead of autograd's sum_to_size column reduction: in HIP-graph
+    replays of the 512 x 512 UNetRPP step that reduction returned garbage (1e7 x the eager value) for the token-projection biases once
+    the parameters had changed since the capture -- the replay check of trainer.GraphedTrainingStep pins it -- while a GEMM replays
+    correctly (same finding as for the Linear biases, _LinearND)."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        ctx.bdtype = b.dtype
+        return x + b.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = None
+        if ctx.needs_input_grad[1]:
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            ones = torch.ones(1, dy2.shape[0], dtype=dy2.dtype, device=dy2.device)
+            db = (ones @ dy2)[0].to(ctx.bdtype)
+        return dy, db
+
+
+def add_bias(x: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _AddBias.apply(x, b)
+
+
 def linear_nd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``F.linear`` for activations of any rank with fp32 parameters: the row-GEMM kernels where they apply (csrc/rowgemm.hip),
     else library GEMMs (weight cast once per call, gradients as GEMMs)."""
