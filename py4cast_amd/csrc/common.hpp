@@ -41,6 +41,23 @@ int fail(int code, const char* fmt, ...);
         if (rc__ != P4C_OK) return rc__; \
     } while (0)
 
+// Zero-fill of small device buffers as a KERNEL, never hipMemsetAsync: on this stack (ROCm 7.2, gfx950) a memset node captured into
+// a HIP graph writes zeros in the first replay only -- from the second replay on it writes another byte value (0x01 observed;
+// tools/diagnostics/memset_node_probe.py).  That is also what breaks torch's multi-block reductions in replays (they zero their
+// semaphores with a memset), so nothing of ours that may run inside a captured step uses one.
+#if defined(__HIPCC__)
+static __global__ void p4c_zero_words_kernel(unsigned int* p, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+inline hipError_t zero_words_async(void* p, size_t bytes, hipStream_t st) {   // bytes: a multiple of 4
+    const long long n = (long long)(bytes / 4);
+    if (n <= 0) return hipSuccess;
+    const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(p4c_zero_words_kernel, dim3(blocks), dim3(256), 0, st, (unsigned int*)p, n);
+    return hipGetLastError();
+}
+#endif
+
 static inline hipStream_t as_stream(p4c_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Timing diagnostics only (results become wrong): P4C_DIAG bit mask, honoured after the first 400 calls of each site so that

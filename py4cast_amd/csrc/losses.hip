@@ -794,7 +794,7 @@ extern "C" size_t p4c_loss_workspace_bytes(int B, int T, int64_t N, int F) {
 extern "C" int p4c_mask_all_zero_count(const void* mask_or_target, int mask_mode, int64_t bs, int64_t ts, int B, int T,
                                        int64_t N, int F, int32_t* count, p4c_stream_t stream) {
     P4C_CHECK_ARG(count, "p4c_mask_all_zero_count: null count");
-    P4C_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), as_stream(stream)));
+    P4C_CHECK_HIP(zero_words_async(count, sizeof(int32_t), as_stream(stream)));   // (not a memset: common.hpp)
     if (mask_mode == P4C_MASK_NONE) return P4C_OK;
     P4C_CHECK_ARG(mask_or_target, "p4c_mask_all_zero_count: null mask");
     P4C_CHECK_ARG(F <= 64 * LOSS_MAX_ITERS, "p4c_mask_all_zero_count: F too large");

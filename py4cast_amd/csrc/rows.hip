@@ -449,7 +449,7 @@ extern "C" int p4c_row_layernorm_bwd(const void* dy, const void* x, const float*
     P4C_CHECK_ARG(dbeta == dgamma + C, "p4c_row_layernorm_bwd: dbeta must follow dgamma (one (2,C) buffer)");
     hipStream_t s = as_stream(stream);
     if (R == 0) {
-        P4C_CHECK_HIP(hipMemsetAsync(dgamma, 0, 2 * C * sizeof(float), s));
+        P4C_CHECK_HIP(zero_words_async(dgamma, 2 * C * sizeof(float), s));   // (not a memset: common.hpp)
         return P4C_OK;
     }
     const int G = ln_grid(R, 64 >> lpr_log2);
