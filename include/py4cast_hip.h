@@ -326,6 +326,11 @@ typedef struct p4c_halfunet_desc {
  * handles created with hipEventDisableTiming, all owned by the caller and alive until replaced.  side = NULL restores the
  * default (library-created on first use).  Environment: P4C_SIDE_STREAM=0 runs everything on `stream`. */
 int p4c_set_side_stream(p4c_stream_t side, void* const* events, int n_events);
+/* Rewrite a captured, not yet instantiated HIP graph (hipGraph_t): every 1-D memset node becomes a kernel node filling the same bytes
+ * with the same dependencies.  On this stack memset nodes replay a wrong byte value from the second launch on, which breaks library
+ * kernels that zero their scratch with a memset inside the captured region (torch's multi-block reductions).  *replaced / *left: memset
+ * nodes rewritten / left alone (2-D ones). */
+int p4c_graph_replace_memsets(void* graph, int* replaced, int* left);
 
 /* number of floats of the flat parameter vector, laid out in this order (canonical torch layouts):
  *   for block in enc1..enc5, decoder: conv1.weight (64,cin_b,3,3), norm1.weight (64), norm1.bias (64),

@@ -52,6 +52,7 @@ SIGNATURES = {
 }
 OTHER = {
     "p4c_version": ([], c_int),
+    "p4c_graph_replace_memsets": ([P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)], c_int),
     "p4c_last_error": ([], c_char_p),
     "p4c_num_cus": ([], c_int),
     "p4c_loss_workspace_bytes": ([I, I, L, I], c_size_t),

@@ -196,10 +196,7 @@ class EPA(nn.Module):
         # token-axis projection (shared weights): (B, C, N) @ (N, p) for k and v_sa at once -- a library GEMM
         W, bias = self.E.weight.to(x.dtype), self.E.bias.float()
         kv = torch.stack([qkvv[:, :, 1].reshape(B, N, C), qkvv[:, :, 3].reshape(B, N, C)], dim=1)   # (B,2,N,C)
-        if __import__('os').environ.get('P4C_TMP_PLUSBIAS'):
-            proj = (kv.transpose(-1, -2) @ W.t()).float() + bias
-        else:
-            proj = R.add_bias((kv.transpose(-1, -2) @ W.t()).float(), bias)                              # (B,2,C,p); bias gradient as a GEMM
+        proj = R.add_bias((kv.transpose(-1, -2) @ W.t()).float(), bias)                              # (B,2,C,p); bias gradient as a GEMM
         KP, VP = proj[:, 0].view(B, h, d, -1), proj[:, 1].view(B, h, d, -1)
         Mq = KP / nq.unsqueeze(-1) * self.temperature2
         S = TS.apply(q, Mq).softmax(dim=-1)                                                          # (B,h,N,p), token-major memory

@@ -1330,3 +1330,49 @@ def test_group_norm_features_last(gpu_device, dtype, shape, groups):
     assert _rel(y.detach().cpu(), yr.detach()) < tol
     assert _rel(xg.grad.cpu(), xr.grad) < (2e-5 if dtype == torch.float32 else 8e-3)
     assert _rel(gg.grad.cpu(), gr.grad) < 1e-4 and _rel(bg.grad.cpu(), br.grad) < 1e-4
+
+
+def test_graph_memset_nodes_are_rewritten(gpu_device):
+    """csrc/graphfix.hip: a captured backward with a broadcast-added bias (autograd's column reduction zeroes its semaphores with a
+    memset) must give the eager gradients in EVERY replay once p4c_graph_replace_memsets has rewritten the memset nodes -- on this
+    stack the unmodified graph is right in the first replay only (tools/diagnostics/replay_memset_fix_probe.py shows both)."""
+    import ctypes
+
+    from py4cast_amd import _lib as L
+
+    torch.manual_seed(0)
+    bf = torch.bfloat16
+    b = torch.randn(64, device=gpu_device, requires_grad=True)
+    w = torch.randn(64, 64, device=gpu_device, requires_grad=True)
+    b.grad, w.grad = torch.zeros_like(b), torch.zeros_like(w)
+    x = torch.randn(2, 2, 512, 64, device=gpu_device)
+
+    def step():
+        h = (x.to(bf) @ w.to(bf)).float() + b
+        (h.sin() * 1e-3).sum().backward()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        step()
+    replaced, left = ctypes.c_int(), ctypes.c_int()
+    L.check(L.lib().p4c_graph_replace_memsets(ctypes.c_void_p(g.raw_cuda_graph()), ctypes.byref(replaced), ctypes.byref(left)), "replace")
+    assert replaced.value >= 1 and left.value == 0
+    g.instantiate()
+
+    def grads(fn):
+        b.grad.zero_()
+        w.grad.zero_()
+        fn()
+        torch.cuda.synchronize()
+        return b.grad.clone(), w.grad.clone()
+
+    eb, ew = grads(step)
+    for _ in range(4):
+        rb, rw = grads(g.replay)
+        assert torch.equal(rb, eb) and torch.equal(rw, ew)

@@ -1,5 +1,6 @@
-"""UNetRPP at the bench sizes with the token-projection bias added by a broadcasting `+` (P4C_TMP_PLUSBIAS=1): when does the replayed
-gradient of E.bias go wrong -- after a parameter change, or after any eager pass between replays?"""
+"""(Historical: written against a build whose EPA added the token-projection bias with a broadcasting `+`, switched on by
+P4C_TMP_PLUSBIAS=1 -- that switch is gone; the pure-PyTorch reproducers replay_reduce_micro*.py and memset_node_probe.py supersede it.)
+UNetRPP at the bench sizes: when does the replayed gradient of E.bias go wrong -- after a parameter change, or after any eager pass?"""
 import os, sys, torch
 os.environ["P4C_TMP_PLUSBIAS"] = "1"
 sys.path.insert(0, ".")
