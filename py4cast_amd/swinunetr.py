@@ -76,6 +76,36 @@ def _layer_norm(m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     return F.layer_norm(x.float(), m.normalized_shape, m.weight, m.bias, m.eps).to(x.dtype)
 
 
+class _TableRows(torch.autograd.Function):
+    """table[index] for a STATIC index (Swin's relative-position bias: 2 401 = 49 x 49 rows gathered from a (169, heads) table).  The
+    library's backward is a sort-based index_put (60 us per call, 24 calls per step); with the index fixed its inverse is a table
+    too: `rows_of[r]` lists the gradient rows that belong to table row r (padded with the index of an appended zero row), and the
+    gradient is one gather + one sum over that list -- a fixed order, no atomics, no host synchronisation (capturable)."""
+
+    @staticmethod
+    def forward(ctx, table, index, rows_of):
+        ctx.save_for_backward(rows_of)
+        return table[index]
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows_of, = ctx.saved_tensors
+        return F.pad(dy, (0, 0, 0, 1))[rows_of].sum(dim=1), None, None
+
+
+def inverse_index_table(index: torch.Tensor, rows: int) -> torch.Tensor:
+    """(rows, max multiplicity) positions of `index` holding each value, padded with len(index)."""
+    index = index.view(-1)
+    counts = torch.bincount(index, minlength=rows)
+    order = torch.argsort(index, stable=True)
+    out = torch.full((rows, int(counts.max())), index.numel(), dtype=torch.long)
+    start = 0
+    for r, c in enumerate(counts.tolist()):
+        out[r, :c] = order[start:start + c]
+        start += c
+    return out
+
+
 def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     return R.linear_nd(x, m.weight, m.bias)
 
@@ -89,7 +119,9 @@ class SwinBlock(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 2, heads))
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
-        self.register_buffer("relative_position_index", relative_position_index(ws), persistent=False)
+        idx = relative_position_index(ws)
+        self.register_buffer("relative_position_index", idx, persistent=False)
+        self.register_buffer("_rpi_rows_of", inverse_index_table(idx, (2 * ws - 1) ** 2), persistent=False)   # for the gather's backward
         self.norm2 = nn.LayerNorm(dim)
         self.fc1 = nn.Linear(dim, int(dim * mlp_ratio))
         self.fc2 = nn.Linear(int(dim * mlp_ratio), dim)
@@ -103,7 +135,8 @@ class SwinBlock(nn.Module):
         if pb or pr:
             h = F.pad(h, (0, 0, 0, pr, 0, pb))
         N = ws * ws
-        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(N, N, self.heads).permute(2, 0, 1)
+        bias = _TableRows.apply(self.relative_position_bias_table, self.relative_position_index.view(-1),
+                                self._rpi_rows_of).view(N, N, self.heads).permute(2, 0, 1)
         a = window_attention(_linear(self.qkv, h), bias, self.heads, ws, shift)
         a = _linear(self.proj, a)
         if pb or pr:
