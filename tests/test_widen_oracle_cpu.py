@@ -120,3 +120,26 @@ def test_unetrpp_oracle_epa_matches_brute_force_per_head():
     net = UNetRPP(7, 3, (64, 64), hidden_size=64, num_heads_encoder=4, num_heads_decoder=4)
     out = net(torch.randn(1, 64, 64, 7))
     assert out.shape == (1, 64, 64, 3) and bool(torch.isfinite(out).all())
+
+
+def test_static_index_gather_backward_matches_index_put():
+    """swinunetr._TableRows (the relative-position-bias gather with a fixed-order backward over the inverse of its static index)
+    against the plain ``table[index]`` and autograd's index_put backward, for Swin's window sizes."""
+    import torch
+
+    from py4cast_amd.swinunetr import _TableRows, inverse_index_table, relative_position_index
+
+    for ws, heads in ((7, 3), (4, 6), (2, 1)):
+        idx = relative_position_index(ws).view(-1)
+        rows = (2 * ws - 1) ** 2
+        inv = inverse_index_table(idx, rows)
+        assert inv.shape[0] == rows and int((inv < idx.numel()).sum()) == idx.numel()          # every gathered row listed exactly once
+        table = torch.randn(rows, heads, dtype=torch.float64, requires_grad=True)
+        ref = table.detach().clone().requires_grad_(True)
+        g = torch.randn(idx.numel(), heads, dtype=torch.float64)
+        y = _TableRows.apply(table, idx, inv)
+        y.backward(g)
+        yr = ref[idx]
+        yr.backward(g)
+        assert torch.equal(y, yr)
+        assert float((table.grad - ref.grad).abs().max()) < 1e-12
