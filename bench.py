@@ -262,17 +262,22 @@ def fp32_flavour(args, case, info, device, steps=6, warmup=2, dtype="f32", batch
 
     for i in range(2 + warmup):
         step(i)
-    L.lib().p4c_prof_enable(1, steps * T * 3)
+    L.lib().p4c_prof_enable(1, min(steps, 4) * T * 3)
     L.lib().p4c_prof_filter(B * H * W)
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(steps):
         loss = step(warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     roof = lm.model.roofline({}, B=B, H=H, W=W)
     L.lib().p4c_prof_enable(0, 0)
     return {"value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1]},
             "dtype": dtype, "batch_per_gpu": B, "loss": float(loss.detach()), "roofline": roof}
 
 
@@ -532,7 +537,7 @@ def main():
                 # (config/CLI/dataset/titan.yaml:7; 15 GiB of 288 at B=8): `value` above stays the B=2 configuration of BASELINE.md
                 torch.cuda.empty_cache()
                 big = synthetic_case(1234 + rank, args.larger_batch, T, 1, H, W, F, Ff, Fs, args.border, device)
-                out["larger_batch"] = fp32_flavour(args, big, info, device, steps=5, warmup=2, dtype="bf16", batch=args.larger_batch)
+                out["larger_batch"] = fp32_flavour(args, big, info, device, steps=8, warmup=4, dtype="bf16", batch=args.larger_batch)
                 out["larger_batch"]["note"] = ("same rollout / loss / optimizer and model at a per-GPU batch the 288 GB of HBM invite; not the "
                                                "headline `value` (BASELINE.md fixes B=2 per GPU)")
         if not args.no_cpu_baseline and world == 1:
