@@ -274,7 +274,10 @@ class GraphedTrainingStep:
         from . import _lib as L
 
         # keep_graph: the captured hipGraph_t stays accessible until it is instantiated below
-        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+        try:
+            self.graph, rewritable = torch.cuda.CUDAGraph(keep_graph=True), True
+        except TypeError:   # a torch without keep_graph: no access to the captured graph, the replay check below is the only guard
+            self.graph, rewritable = torch.cuda.CUDAGraph(), False
         L.CAPTURE_SCOPE[0] = {}
         try:
             with torch.cuda.graph(self.graph):
@@ -284,13 +287,15 @@ class GraphedTrainingStep:
         # On this stack a memset node of a HIP graph writes the right bytes in the first replay only, and torch's
         # multi-block reductions -- every broadcast-added bias gradient, for one -- zero their semaphores with one: rewrite the
         # memset nodes as fill-kernel nodes before the graph is instantiated (csrc/graphfix.hip)
-        import ctypes
+        self.memset_nodes = None
+        if rewritable:
+            import ctypes
 
-        replaced, left = ctypes.c_int(), ctypes.c_int()
-        L.check(L.lib().p4c_graph_replace_memsets(ctypes.c_void_p(self.graph.raw_cuda_graph()), ctypes.byref(replaced), ctypes.byref(left)),
-                "p4c_graph_replace_memsets")
-        self.memset_nodes = (replaced.value, left.value)
-        self.graph.instantiate()
+            replaced, left = ctypes.c_int(), ctypes.c_int()
+            L.check(L.lib().p4c_graph_replace_memsets(ctypes.c_void_p(self.graph.raw_cuda_graph()), ctypes.byref(replaced), ctypes.byref(left)),
+                    "p4c_graph_replace_memsets")
+            self.memset_nodes = (replaced.value, left.value)
+            self.graph.instantiate()
         self.warmup_backwards = warmup + 1   # gradient contributions already accumulated by construction: zero_grad() after
         self.verified = None
         if verify and all(g is not None for g in snaps):
