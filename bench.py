@@ -266,6 +266,11 @@ def fp32_flavour(args, case, info, device, steps=6, warmup=2, dtype="f32", batch
     L.lib().p4c_prof_filter(B * H * W)
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    import gc
+
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()   # (see main(): no collector pauses inside a ~0.1 s timed region)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(steps):
@@ -273,6 +278,8 @@ def fp32_flavour(args, case, info, device, steps=6, warmup=2, dtype="f32", batch
         marks[i + 1].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if gc_was_enabled:
+        gc.enable()
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     roof = lm.model.roofline({}, B=B, H=H, W=W)
     L.lib().p4c_prof_enable(0, 0)
@@ -444,6 +451,17 @@ def main():
         barrier()
     # one event per step boundary (a record costs the stream a few microseconds against a ~5 ms step): min / median / max
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # The timed region is ~0.1 s: a generational garbage collection of this process (tens of thousands of tracked objects once
+    # torch and the model are loaded) is a 10-50 ms host pause that starves the GPU -- the collector is parked for the timed
+    # steps (collected and frozen first, so nothing is pending), and device allocations inside the region are counted.
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
+    allocs_before = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
+    barrier()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -451,6 +469,10 @@ def main():
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    device_allocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs_before
+    if gc_was_enabled:
+        gc.enable()
+    gc.unfreeze()
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if not use_graph:
         ktimes = L.kernel_times()
@@ -519,6 +541,7 @@ def main():
                 "accumulate_grad_batches": args.accumulate,
                 "hip_graph": bool(use_graph), "hip_graph_check": graph_note,
                 "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
+                "device_allocs_in_timed_region": int(device_allocs),
                 "launch_mode_probe": probe,
             },
             "loss": float(loss.detach()),

@@ -294,6 +294,9 @@ size_t p4c_conv_wgrad_workspace_bytes(int CI_pad, int ks);
 /* rows per sample of p4c_conv_fwd's stat_partial output (pixel tiles, or (workgroup, wave) slots of the
  * persistent bf16 kernel) */
 int p4c_conv_stat_tiles(int compute, int storage, int CI, int B, int H, int W);
+/* the same for a given kernel size (1x1 and 3x3 convolutions of one shape may run different kernels);
+ * p4c_conv_stat_tiles is the ks = 3 value */
+int p4c_conv_stat_tiles_ks(int compute, int storage, int CI, int ks, int B, int H, int W);
 int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_pad, int ks, const float* in_scale, const float* in_shift,
                    int in_relu, const void* dout, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                    p4c_stream_t stream);
@@ -326,6 +329,14 @@ typedef struct p4c_halfunet_desc {
  * handles created with hipEventDisableTiming, all owned by the caller and alive until replaced.  side = NULL restores the
  * default (library-created on first use).  Environment: P4C_SIDE_STREAM=0 runs everything on `stream`. */
 int p4c_set_side_stream(p4c_stream_t side, void* const* events, int n_events);
+/* Deferred join (calling thread, library-owned side stream only): with on = 1, p4c_halfunet_backward returns WITHOUT making
+ * `stream` wait for the weight gradients it put on the side stream -- the gradient buffer is complete only after
+ * p4c_side_stream_join(stream).  For the reverse sweep of a rollout (py4cast/lightning.py:565-662 differentiated): the
+ * full-resolution weight gradients left at the end of one AR step's backward run beside the next step's chain instead of alone.
+ * The caller keeps x / saved / dy of every deferred call alive (and un-reused) until the join; dy may be overwritten by the next
+ * call's producer (the call orders that itself). */
+int p4c_side_stream_defer(int on);
+int p4c_side_stream_join(p4c_stream_t stream);
 /* Rewrite a captured, not yet instantiated HIP graph (hipGraph_t): every 1-D memset node becomes a kernel node filling the same bytes
  * with the same dependencies.  On this stack memset nodes replay a wrong byte value from the second launch on, which breaks library
  * kernels that zero their scratch with a memset inside the captured region (torch's multi-block reductions).  *replaced / *left: memset

@@ -53,6 +53,8 @@ SIGNATURES = {
     "p4c_halfunet_prepare_weights": [DP, P, P, P],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],
     "p4c_halfunet_backward": [DP, P, P, P, P, P, P, P, I, P],
+    "p4c_side_stream_defer": [I],
+    "p4c_side_stream_join": [P],
     "p4c_edge_gather_add_fwd": [P, P, P, P, P, P, L, I, I, I, P],
     "p4c_edge_gather_add_bwd": [P, P, P, P, P, P, P, L, I, I, I, P],
     "p4c_segment_sum": [P, P, P, P, P, L, L, I, I, I, P],
@@ -72,6 +74,7 @@ SIGNATURES = {
 OTHER = {
     "p4c_conv_wgrad_workspace_bytes": ([I, I], c_size_t),
     "p4c_conv_stat_tiles": ([I, I, I, I, I, I], c_int),
+    "p4c_conv_stat_tiles_ks": ([I, I, I, I, I, I, I], c_int),
     "p4c_halfunet_param_count": ([DP], c_int64),
     "p4c_window_attn_bwd_workspace_bytes": ([I, I, I, I, I], c_size_t),
     "p4c_row_layernorm_bwd_workspace_bytes": ([L, I, I], c_size_t),

@@ -1931,7 +1931,8 @@ static int launch_conv_wgrad_bf16(const T* in, const float* in_scale, const floa
 }
 
 // rows per sample of the statistics partial buffer written by conv_fwd_bf16
-int conv_bf16_stat_slots(int CI, int storage, int B, int H, int W) {
+int conv_bf16_stat_slots(int CI, int storage, int B, int H, int W, int ks) {
+    if (conv_bf16_is_rows(storage, CI, ks, 1, 64, B, H, W)) return conv_rows_stat_slots(B, H, W);   // per (workgroup, loader wave)
     const int tiles = ((H + 3) / 4) * ((W + BTW - 1) / BTW);
     if (CI > 64 && storage != P4C_BF16) return tiles;  // per-tile partials (single-buffer kernel, fp32 storage)
     int64_t ntiles = (int64_t)tiles * B;
@@ -1953,15 +1954,27 @@ static int conv_fwd_bf16_t(const T* in, int CI, const void* wp, int ks, const fl
     return fail(P4C_ERR_UNSUPPORTED, "conv_fwd_bf16: unsupported (CI=%d, ks=%d)", CI, ks);
 }
 
-bool conv_bf16_is_ring(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W) {
+static bool is_tile_ring(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W) {
     return storage == P4C_BF16 && CI == 64 && ks == 3 && m_blocks == 1 && out_cs % 8 == 0 && B <= ring::MAXB &&
            (int64_t)H * W * out_cs * 2 < (int64_t)1 << 31;  // per-sample byte offsets of the buffer descriptors are 32-bit
+}
+
+bool conv_bf16_is_ring(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W) {
+    return conv_bf16_is_rows(storage, CI, ks, m_blocks, out_cs, B, H, W) || is_tile_ring(storage, CI, ks, m_blocks, out_cs, B, H, W);
+}
+
+bool conv_bf16_bwd_stats_ok(int storage, int B, int H, int W) {
+    if (conv_bf16_is_rows(storage, 64, 3, 1, 64, B, H, W)) return conv_rows_stat_slots(B, H, W) <= NORM_BWD_MAX_BLOCKS;
+    return is_tile_ring(storage, 64, 3, 1, 64, B, H, W) && B <= RING_BWD_STATS_MAXB && 4 * num_cus() <= NORM_BWD_MAX_BLOCKS;
 }
 
 int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
                   int m_blocks, hipStream_t stream, const BatchFin* fin, const RingBwdStats* bst, int* nblk_out) {
-    if (conv_bf16_is_ring(storage, CI, ks, m_blocks, out_cs, B, H, W))
+    if (conv_bf16_is_rows(storage, CI, ks, m_blocks, out_cs, B, H, W))
+        return launch_conv3x3_bf16_rows(in, wp, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, stream, fin, bst,
+                                        nblk_out);
+    if (is_tile_ring(storage, CI, ks, m_blocks, out_cs, B, H, W))
         return launch_conv3x3_bf16_ring((const __bf16*)in, (const __bf16*)wp, in_scale, in_shift, in_relu, (__bf16*)out, out_cs,
                                         stat_partial, B, H, W, stream, fin, bst, nblk_out);
     if (fin || bst) return fail(P4C_ERR_INVALID, "conv_fwd_bf16: in-kernel statistics need the ring kernel");

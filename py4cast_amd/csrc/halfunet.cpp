@@ -34,7 +34,7 @@ struct Layout {
     // saved workspace: activations (element offsets) then normalisation arrays (float offsets from norm_base bytes)
     int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
     // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
-    int64_t wprep, statp, wgradp, nbwdp, k1, k2, tickets, f_floats, g_base, G0, G1, G2, TB, DY[NCONV], scratch_bytes;
+    int64_t wprep, statp, wgradp, nbwdp, k1, k2, tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
     int G;  // persistent workgroups of the weight-gradient kernel
 };
 
@@ -43,8 +43,8 @@ inline int conv_cin(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin :
 inline int conv_cin_pad(const p4c_halfunet_desc& d, int i) { return i == 0 ? d.cin_pad : NF; }
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
-inline int stat_tiles(int compute, int storage, int CI, int B, int H, int W) {
-    if (compute == P4C_BF16) return conv_bf16_stat_slots(CI, storage, B, H, W);
+inline int stat_tiles(int compute, int storage, int CI, int B, int H, int W, int ks = 3) {
+    if (compute == P4C_BF16) return conv_bf16_stat_slots(CI, storage, B, H, W, ks);
     return ((H + CONV_TH - 1) / CONV_TH) * ((W + CONV_TW - 1) / CONV_TW);
 }
 
@@ -121,7 +121,14 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     off = 0;
     L.wprep = off; off += (int64_t)NWSLOT * WSLOT_FLOATS;
     const int64_t tps = conv_tiles_per_sample(d.H, d.W);
-    L.statp = off; off += (int64_t)d.B * (tps > 4 * (int64_t)L.G ? tps : 4 * (int64_t)L.G) * 128;
+    {
+        int64_t slots = tps > 4 * (int64_t)num_cus() ? tps : 4 * (int64_t)num_cus();
+        for (int k = 0; k < NLEV; ++k) {   // (the row-streaming kernel's slot count depends on the level's shape)
+            const int64_t s = d.compute == P4C_BF16 ? conv_bf16_stat_slots(NF, d.dtype, d.B, L.Hk[k], L.Wk[k], 3) : 0;
+            if (s > slots) slots = s;
+        }
+        L.statp = off; off += (int64_t)d.B * slots * 128;
+    }
     L.wgradp = off; off += wgrad_partial_floats(96, 3, L.G);
     L.nbwdp = off; off += (int64_t)d.B * NORM_BWD_MAX_BLOCKS * 128;
     L.k1 = off; off += (int64_t)d.B * NF;
@@ -136,7 +143,11 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     L.TB = off; off += L.n[0] * NF;  // x-pass outputs of the four up-sampling adjoints: n0*NF*(1/2+1/4+1/8+1/16)
     // dY (gradient wrt the raw conv output) of every conv block in its own buffer: the weight-gradient kernels read them
     // from a side stream while the main stream already overwrites the rotating buffers G0..G2
-    for (int i = 0; i < NCONV; ++i) { L.DY[i] = off; off += L.n[conv_level(i)] * NF; }
+    // (two sets, alternating between consecutive backward calls: with the side-stream join deferred across the AR steps of a
+    // rollout -- p4c_side_stream_defer -- the weight gradients of one call may still be reading their dY while the next call's
+    // chain writes its own)
+    for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < NCONV; ++i) { L.DY[s][i] = off; off += L.n[conv_level(i)] * NF; }
     L.scratch_bytes = L.g_base + off * L.esz;
 }
 
@@ -233,6 +244,22 @@ struct SideStream {
     // kernel after one starts 8 us later in the median, 20 us on average), so several blocks share one
     std::vector<std::function<int(hipStream_t)>> pending;
     int every = 3;   // measured on the benchmark configuration: 1 -> 6.06, 2 -> 5.97, 3 -> 5.91, 4 -> 5.99, 6 -> 6.14 ms per step
+    // Join deferred over several backward calls (p4c_side_stream_defer): the weight gradients left over at the end of one AR
+    // step's backward -- the full-resolution ones, which find nothing to hide behind there -- then run beside the HBM-bound head of
+    // the next AR step's chain instead of alone.  `calls` picks the dY buffer set; set_done[s] is recorded on the side stream after
+    // the last weight-gradient launch of a call that used set s, and the next call that uses s waits for it (two calls later:
+    // long signalled); dy_read is recorded after the 1x1 convolution's weight gradient, which reads the CALLER's dy buffer.
+    bool defer = false;
+    unsigned long long calls = 0;
+    hipEvent_t set_done[2] = {nullptr, nullptr};
+    bool set_recorded[2] = {false, false};
+    hipEvent_t dy_read = nullptr;
+    int own_events() {
+        if (dy_read) return P4C_OK;
+        for (int i = 0; i < 2; ++i) P4C_CHECK_HIP(hipEventCreateWithFlags(&set_done[i], hipEventDisableTiming));
+        P4C_CHECK_HIP(hipEventCreateWithFlags(&dy_read, hipEventDisableTiming));
+        return P4C_OK;
+    }
     int init() {
         if (stream || external) return P4C_OK;
         const char* e = getenv("P4C_SIDE_STREAM");
@@ -281,7 +308,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
     const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
     Norm nm = norm_at(ws, i, d.B);
     const int stats_training = (d.norm == 1) || training;
-    void* dY = ws.g(L.DY[i]);
+    void* dY = ws.g(L.DY[g_side.calls & 1][i]);
     P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
                      (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1), ws.f(L.k2),
                      grads + L.gamma[i], grads + L.beta[i], dY, st, pre_nblk));
@@ -311,8 +338,8 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
         // whose pass 1 (sums of g and g * xhat) the ring kernel takes while it stores the gradient tile
         const char* fe = getenv("P4C_NO_FUSED_REDUCE");   // (read per call: the parity test switches it)
         const bool fuse_off = fe && fe[0] == '1';
-        const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 && d.B <= RING_BWD_STATS_MAXB &&
-                          conv_bf16_is_ring(d.dtype, NF, 3, 1, 64, d.B, H, W) && 4 * num_cus() <= NORM_BWD_MAX_BLOCKS;
+        const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 &&
+                          conv_bf16_bwd_stats_ok(d.dtype, d.B, H, W);
         if (fuse) {
             const RingBwdStats bst{in, in_norm->scale, in_norm->shift, in_norm->mean, in_norm->rstd};
             P4C_TRY(conv_fwd(d.compute, d.dtype, dY, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, ws.f(L.nbwdp), d.B, H, W,
@@ -429,6 +456,18 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     P4C_TRY(g_side.init());
     g_side.next = 0;
     g_side.pending.clear();
+    // (inside a HIP-graph capture nothing may depend on events recorded before it: every call then joins for itself and the
+    // cross-call events are left alone)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool plain_stream = g_side.enabled && !g_side.external && cap == hipStreamCaptureStatusNone;
+    const bool deferring = plain_stream && g_side.defer;
+    if (plain_stream) {
+        P4C_TRY(g_side.own_events());
+        ++g_side.calls;
+        const int set = (int)(g_side.calls & 1);
+        if (g_side.set_recorded[set]) P4C_CHECK_HIP(hipStreamWaitEvent(st, g_side.set_done[set], 0));   // (the call before the previous one)
+    }
     struct BwdPhase { BwdPhase() { prof_set_backward(true); } ~BwdPhase() { prof_set_backward(false); } } bwd_phase;
 
     // ---- output 1x1 conv
@@ -443,6 +482,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         }
         P4C_TRY(conv_wgrad(d.compute, d.dtype, ws.act(L.Y[11]), NF, 1, nd2.scale, nd2.shift, 1, dy, ws.f(L.wgradp), G, d.B, d.H,
                            d.W, d.cout, NF, grads + L.wout, wst));
+        if (deferring) P4C_CHECK_HIP(hipEventRecord(g_side.dy_read, g_side.stream));
         P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
     }
     // ---- decoder
@@ -490,12 +530,36 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
             P4C_TRY(conv_block_bwd(d, ws, 0, a, x, nullptr, d.dx_channels > 0 ? dx : nullptr, params, grads, training, st, nxt1));
         }
     }
-    // join: the caller's stream continues only after every weight gradient of this call has been accumulated
+    // join: the caller's stream continues only after every weight gradient of this call has been accumulated -- unless the
+    // caller defers that to p4c_side_stream_join (then only what the next call may overwrite is ordered: the caller's dy)
     if (g_side.enabled) {
         P4C_TRY(g_side.flush(st));
-        P4C_TRY(g_side.order(g_side.stream, st));
+        if (plain_stream) {
+            const int set = (int)(g_side.calls & 1);
+            P4C_CHECK_HIP(hipEventRecord(g_side.set_done[set], g_side.stream));
+            g_side.set_recorded[set] = true;
+        }
+        if (deferring)
+            P4C_CHECK_HIP(hipStreamWaitEvent(st, g_side.dy_read, 0));
+        else
+            P4C_TRY(g_side.order(g_side.stream, st));
     }
     return P4C_OK;
+}
+
+extern "C" int p4c_side_stream_defer(int on) {
+    g_side.defer = on != 0;
+    return P4C_OK;
+}
+
+extern "C" int p4c_side_stream_join(p4c_stream_t stream) {
+    SideStream& sd = g_side;
+    if (!sd.enabled || !sd.stream || sd.external) return P4C_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(as_stream(stream), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) return P4C_OK;   // (captured calls joined for themselves)
+    sd.next = 0;
+    return sd.order(sd.stream, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------ single-op entry points (tests, reuse)
@@ -509,6 +573,10 @@ extern "C" int p4c_prep_weights(const float* w, int CO, int CI, int ks, int tran
 
 extern "C" int p4c_conv_stat_tiles(int compute, int storage, int CI, int B, int H, int W) {
     return stat_tiles(compute, storage, CI, B, H, W);
+}
+
+extern "C" int p4c_conv_stat_tiles_ks(int compute, int storage, int CI, int ks, int B, int H, int W) {
+    return stat_tiles(compute, storage, CI, B, H, W, ks);
 }
 
 extern "C" int p4c_conv_fwd(const void* in, int compute, int storage, int CI, const void* wprep, int ks,

@@ -56,7 +56,7 @@ struct BatchFin {
     int B;
 };
 int prep_weights_batch(const PrepBatch& pb, hipStream_t stream);
-int conv_bf16_stat_slots(int CI, int storage, int B, int H, int W);
+int conv_bf16_stat_slots(int CI, int storage, int B, int H, int W, int ks = 3);
 // `storage` = element type of in/out/dout in HBM (P4C_F32 or P4C_BF16)
 // Pass 1 of a normalisation backward taken by the DATA-GRADIENT convolution that produces dA (ring kernel only): with
 // y = the raw forward output the gradient belongs to and its normalisation rows, the kernel leaves in `stat_partial`
@@ -74,8 +74,19 @@ int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, c
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
                   int m_blocks, hipStream_t stream, const BatchFin* fin = nullptr, const RingBwdStats* bst = nullptr,
                   int* nblk_out = nullptr);
-// true when conv_fwd_bf16 with these arguments runs the persistent ring kernel (the one that can finish BatchNorm itself)
+// true when conv_fwd_bf16 with these arguments runs one of the two role-split 3x3 64->64 kernels (row-streaming
+// conv3x3_bf16_rows, or the older tile ring conv3x3_bf16_ring for narrow maps): the ones that can finish BatchNorm themselves
 bool conv_bf16_is_ring(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W);
+// true when that kernel can also take pass 1 of a normalisation backward (RingBwdStats) within NORM_BWD_MAX_BLOCKS slots
+bool conv_bf16_bwd_stats_ok(int storage, int B, int H, int W);
+
+// conv_rows.hip: the row-streaming 3x3 64->64 bf16 kernel (forward and data gradient)
+bool conv_bf16_is_rows(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W);
+void conv_rows_geometry(int B, int H, int W, int* nstrips, int* nseg);
+int conv_rows_stat_slots(int B, int H, int W);   // statistics slots per sample ([2][64] floats each)
+int launch_conv3x3_bf16_rows(const void* in, const void* wp, const float* in_scale, const float* in_shift, int in_relu, void* out,
+                             int out_cs, float* stat_partial, int B, int H, int W, hipStream_t stream, const BatchFin* fin,
+                             const RingBwdStats* bst, int* nblk_out);
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                     const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                     hipStream_t stream);

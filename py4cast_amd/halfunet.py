@@ -16,6 +16,7 @@ is NCHW; the registry contract allows either.
 """
 
 import ctypes
+import os
 import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -641,6 +642,28 @@ class _NativeRolloutFn(torch.autograd.Function):
         desc0 = HalfUNetDesc.from_buffer_copy(desc)
         desc0.dx_channels = 0  # the input state of step 0 is data: no gradient needed, skip that conv
         have_next = False
+        # Weight gradients run on the library's side stream.  Their join is deferred over the whole reverse sweep: the
+        # full-resolution ones left over at the end of AR step i's backward then run beside the HBM-bound head of step i-1's
+        # chain instead of alone (P4C_DEFER_JOIN=0: join after every step, the round-2 behaviour).  xs / saveds stay referenced
+        # until the join below -- the side stream reads them.
+        defer = T > 1 and os.environ.get("P4C_DEFER_JOIN", "1") != "0"
+        if defer:
+            L.call("p4c_side_stream_defer", 1)
+        try:
+            return _NativeRolloutFn._sweep(ctx, g_pred, gl, dy, dx, dprev, gflat, flat, scratch, desc, desc0, stream, target, defer)
+        finally:
+            if defer:
+                L.call("p4c_side_stream_defer", 0)
+
+    @staticmethod
+    def _sweep(ctx, g_pred, gl, dy, dx, dprev, gflat, flat, scratch, desc, desc0, stream, target, defer):
+        model = ctx.model
+        B, T, H, W, F, force_border, num_interior, kind, mask_mode = ctx.meta
+        states, outputs, std, interior_flat, weights, count, xs, saveds = ctx.tensors
+        N = H * W
+        sbs_state = (T + 1) * N * F
+        adt, acode = model.act_dtype, L.dtype_code(model.act_dtype)
+        have_next = False
         for i in range(T - 1, -1, -1):
             g_next = dprev if have_next else None
             if g_pred is not None:  # somebody differentiates through the prediction itself: add its slice
@@ -658,8 +681,14 @@ class _NativeRolloutFn(torch.autograd.Function):
             L.call("p4c_halfunet_backward", ctypes.byref(d), L.ptr(xs[i]), L.ptr(flat), L.ptr(dy),
                    L.ptr(dx) if i > 0 else None, L.ptr(gflat), L.ptr(saveds[i]), L.ptr(scratch), int(ctx.training), stream)
             have_next = True
-            xs[i] = None
-            saveds[i] = None  # release the step's activations as soon as its backward is enqueued
+            if not defer:
+                xs[i] = None
+                saveds[i] = None  # release the step's activations as soon as its backward is enqueued
+        if defer:
+            L.call("p4c_side_stream_join", stream)
+            for i in range(T):
+                xs[i] = None
+                saveds[i] = None
         if target is not None:  # already accumulated into param.grad
             return (None,) * (17 + len(model._param_slices))
         grads = tuple(gflat[o : o + n].view(s) for (o, n, s) in model._param_slices)

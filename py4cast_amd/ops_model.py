@@ -22,9 +22,9 @@ def prep_weights(w: torch.Tensor, transpose_flip: bool, M_pad: int, K_pad: int, 
     return out
 
 
-def conv_tiles(B, H, W, CI=64, compute="f32", storage=None):
+def conv_tiles(B, H, W, CI=64, compute="f32", storage=None, ks=3):
     storage = _compute(compute) if storage is None else storage
-    return B * L.lib().p4c_conv_stat_tiles(_compute(compute), storage, CI, B, H, W)
+    return B * L.lib().p4c_conv_stat_tiles_ks(_compute(compute), storage, CI, ks, B, H, W)
 
 
 def conv_fwd(x: torch.Tensor, wprep: torch.Tensor, ks: int, m_blocks: int = 1, in_scale: Optional[torch.Tensor] = None,
@@ -35,7 +35,7 @@ def conv_fwd(x: torch.Tensor, wprep: torch.Tensor, ks: int, m_blocks: int = 1, i
     L.require_cuda(x)
     B, H, W, CI = x.shape
     out = torch.empty(B, H, W, 64 * m_blocks, dtype=x.dtype, device=x.device)
-    stats = torch.empty(conv_tiles(B, H, W, CI, compute, storage=L.dtype_code(x.dtype)), 2, 64, dtype=torch.float32, device=x.device) if want_stats else None
+    stats = torch.empty(conv_tiles(B, H, W, CI, compute, storage=L.dtype_code(x.dtype), ks=ks), 2, 64, dtype=torch.float32, device=x.device) if want_stats else None
     L.call("p4c_conv_fwd", L.ptr(x.contiguous()), _compute(compute), L.dtype_code(x.dtype), CI, L.ptr(wprep), ks, L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
            L.ptr(bias), L.ptr(out), 64 * m_blocks, L.ptr(stats), B, H, W, m_blocks, L.stream(x.device))
     return (out, stats) if want_stats else out
