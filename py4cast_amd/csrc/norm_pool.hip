@@ -868,19 +868,237 @@ int up_bwd_x4(int storage, const void* dS, int B, int H, int W, void* const* tx,
                                : up_bwd_x4_t<float>((const float*)dS, B, H, W, tx, stream);
 }
 
+// ---- round 3: the same arithmetic (same order per element, bit-identical dA) with the memory latency taken out ------------
+// enc_out_bwd_px: one thread per (pixel, channel octet) like enc_out_bwd_bf16x8_kernel, but the up-sampling adjoint's rows of Tx are
+// loaded EIGHT AT A TIME without a branch (weights that are zero are skipped by a select): at level 4 the old loop walked 32
+// dependent loads per pixel (18-20 us per launch for 4 MB of input).
+// enc_out_bwd_blk: one thread per (2x2 pixel block, channel octet) for the fine levels (stride <= 2), where the kernel was bound by
+// vector instructions: the arg-max of a pooling window is evaluated once instead of once per pixel of the window, each y value is
+// loaded once, and a row of Tx serves both pixel rows of the block.
+template <int CHUNK>
+__device__ __forceinline__ void up_adjoint_rows(const norm_u32x4* __restrict__ Txb, int Hfull, int Wk, int Hk, int s, int X, int c8, int Y,
+                                                float (&acc)[8]) {
+    int ya = s * Y - s / 2, ye = s * Y + 3 * s / 2 - 1;
+    if (ya < 0) ya = 0;
+    if (ye > Hfull - 1) ye = Hfull - 1;
+    for (int y0c = ya; y0c <= ye; y0c += CHUNK) {
+        norm_u32x4 t[CHUNK];
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const int yy = y0c + u <= ye ? y0c + u : ye;
+            t[u] = Txb[((int64_t)yy * Wk + X) * 8 + c8];
+        }
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const int yy = y0c + u;
+            int i0, i1; float ly;
+            bilin(yy <= ye ? yy : ye, s, Hk, i0, i1, ly);
+            float w = (i0 == Y ? 1.f - ly : 0.f) + (i1 == Y ? ly : 0.f);
+            if (yy > ye) w = 0.f;
+            float f[8];
+            unpack8(t[u], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = w != 0.f ? acc[j] + w * f[j] : acc[j];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    enc_out_bwd_px_kernel(const __bf16* __restrict__ Tx, int Hfull, int s, const __bf16* __restrict__ dS,
+                          const __bf16* __restrict__ dP, const __bf16* __restrict__ y, const float* __restrict__ scale,
+                          const float* __restrict__ shift, int Hk, int Wk, __bf16* __restrict__ dA,
+                          const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial) {
+    __shared__ float red[2][32][65];
+    const int b = blockIdx.y;
+    const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float sc[8], sh[8], mu[8], rs[8], a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = (dP || partial) ? scale[b * C + 8 * c8 + j] : 0.f;
+        sh[j] = (dP || partial) ? shift[b * C + 8 * c8 + j] : 0.f;
+        mu[j] = partial ? mean[b * C + 8 * c8 + j] : 0.f;
+        rs[j] = partial ? rstd[b * C + 8 * c8 + j] : 0.f;
+        a1[j] = a2[j] = 0.f;
+    }
+    const int hw = Hk * Wk;
+    const norm_u32x4* dSb = dS ? reinterpret_cast<const norm_u32x4*>(dS + (int64_t)b * hw * C) : nullptr;
+    const norm_u32x4* Txb = Tx ? reinterpret_cast<const norm_u32x4*>(Tx + (int64_t)b * Hfull * Wk * C) : nullptr;
+    const norm_u32x4* yb = reinterpret_cast<const norm_u32x4*>(y + (int64_t)b * hw * C);
+    const norm_u32x4* dPb = dP ? reinterpret_cast<const norm_u32x4*>(dP + (int64_t)b * (Hk / 2) * (Wk / 2) * C) : nullptr;
+    norm_u32x4* ob = reinterpret_cast<norm_u32x4*>(dA + (int64_t)b * hw * C);
+    for (int p = blockIdx.x * 32 + pl; p < hw; p += gridDim.x * 32) {
+        const int Y = p / Wk, X = p - Y * Wk;
+        float acc[8], ymine[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        // every load that does not depend on the adjoint's rows goes out first
+        norm_u32x4 v4[4], gq = norm_u32x4{0u, 0u, 0u, 0u}, ym = norm_u32x4{0u, 0u, 0u, 0u};
+        if (dPb) {
+            const int64_t base = ((int64_t)(Y & ~1) * Wk + (X & ~1)) * 8 + c8;
+            v4[0] = yb[base]; v4[1] = yb[base + 8]; v4[2] = yb[base + (int64_t)Wk * 8]; v4[3] = yb[base + (int64_t)Wk * 8 + 8];
+            gq = dPb[((int64_t)(Y / 2) * (Wk / 2) + X / 2) * 8 + c8];
+        } else if (partial) {
+            ym = yb[(int64_t)p * 8 + c8];
+        }
+        if (dSb) unpack8(dSb[(int64_t)p * 8 + c8], acc);
+        if (Txb) up_adjoint_rows<8>(Txb, Hfull, Wk, Hk, s, X, c8, Y, acc);
+        if (partial && !dPb) unpack8(ym, ymine);
+        if (dPb) {
+            float v[4][8], g[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) unpack8(v4[q], v[q]);
+            unpack8(gq, g);
+            const int me = (Y & 1) * 2 + (X & 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int arg = 0;
+                float m = fmaxf(v[0][j] * sc[j] + sh[j], 0.f);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const float vq = fmaxf(v[q][j] * sc[j] + sh[j], 0.f);
+                    if (vq > m) { m = vq; arg = q; }
+                }
+                if (arg == me) acc[j] += g[j];
+                if (partial) ymine[j] = me == 0 ? v[0][j] : (me == 1 ? v[1][j] : (me == 2 ? v[2][j] : v[3][j]));
+            }
+        }
+        const norm_u32x4 packed = pack8(acc);
+        ob[(int64_t)p * 8 + c8] = packed;
+        if (partial) {
+            float gr[8];
+            unpack8(packed, gr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = (ymine[j] * sc[j] + sh[j]) > 0.f ? gr[j] : 0.f;
+                a1[j] += g;
+                a2[j] += g * ((ymine[j] - mu[j]) * rs[j]);
+            }
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[0][pl][8 * c8 + j] = a1[j];
+            red[1][pl][8 * c8 + j] = a2[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) sum += red[st][k][c];
+            partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = sum;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    enc_out_bwd_blk_kernel(const __bf16* __restrict__ Tx, int Hfull, int s, const __bf16* __restrict__ dS,
+                           const __bf16* __restrict__ dP, const __bf16* __restrict__ y, const float* __restrict__ scale,
+                           const float* __restrict__ shift, int Hk, int Wk, __bf16* __restrict__ dA,
+                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial) {
+    // requires dP (a pooled level below) and Hk, Wk even: levels 0 and 1 of the plan
+    __shared__ float red[2][32][65];
+    const int b = blockIdx.y;
+    const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float sc[8], sh[8], mu[8], rs[8], a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[b * C + 8 * c8 + j];
+        sh[j] = shift[b * C + 8 * c8 + j];
+        mu[j] = partial ? mean[b * C + 8 * c8 + j] : 0.f;
+        rs[j] = partial ? rstd[b * C + 8 * c8 + j] : 0.f;
+        a1[j] = a2[j] = 0.f;
+    }
+    const int hw = Hk * Wk, Wb = Wk / 2, nblk = (Hk / 2) * Wb;
+    const norm_u32x4* dSb = dS ? reinterpret_cast<const norm_u32x4*>(dS + (int64_t)b * hw * C) : nullptr;
+    const norm_u32x4* Txb = Tx ? reinterpret_cast<const norm_u32x4*>(Tx + (int64_t)b * Hfull * Wk * C) : nullptr;
+    const norm_u32x4* yb = reinterpret_cast<const norm_u32x4*>(y + (int64_t)b * hw * C);
+    const norm_u32x4* dPb = reinterpret_cast<const norm_u32x4*>(dP + (int64_t)b * nblk * C);
+    norm_u32x4* ob = reinterpret_cast<norm_u32x4*>(dA + (int64_t)b * hw * C);
+    for (int blk = blockIdx.x * 32 + pl; blk < nblk; blk += gridDim.x * 32) {
+        const int by = blk / Wb, bx = blk - by * Wb;
+        const int64_t base = ((int64_t)(2 * by) * Wk + 2 * bx) * 8 + c8;   // pixel q = 2 dy + dx: base + dy * Wk * 8 + dx * 8
+        norm_u32x4 v4[4], d4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v4[q] = yb[base + (int64_t)(q >> 1) * Wk * 8 + (q & 1) * 8];
+            d4[q] = dSb ? dSb[base + (int64_t)(q >> 1) * Wk * 8 + (q & 1) * 8] : norm_u32x4{0u, 0u, 0u, 0u};
+        }
+        const norm_u32x4 gq = dPb[(int64_t)blk * 8 + c8];
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) unpack8(d4[q], acc[q]);
+        if (Txb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) up_adjoint_rows<4>(Txb, Hfull, Wk, Hk, s, 2 * bx + (q & 1), c8, 2 * by + (q >> 1), acc[q]);
+        }
+        float v[4][8], g[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) unpack8(v4[q], v[q]);
+        unpack8(gq, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int arg = 0;
+            float m = fmaxf(v[0][j] * sc[j] + sh[j], 0.f);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const float vq = fmaxf(v[q][j] * sc[j] + sh[j], 0.f);
+                if (vq > m) { m = vq; arg = q; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q][j] = arg == q ? acc[q][j] + g[j] : acc[q][j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const norm_u32x4 packed = pack8(acc[q]);
+            ob[base + (int64_t)(q >> 1) * Wk * 8 + (q & 1) * 8] = packed;
+            if (partial) {
+                float gr[8];
+                unpack8(packed, gr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gg = (v[q][j] * sc[j] + sh[j]) > 0.f ? gr[j] : 0.f;
+                    a1[j] += gg;
+                    a2[j] += gg * ((v[q][j] - mu[j]) * rs[j]);
+                }
+            }
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[0][pl][8 * c8 + j] = a1[j];
+            red[1][pl][8 * c8 + j] = a2[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) sum += red[st][k][c];
+            partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = sum;
+        }
+    }
+}
+
 template <typename T>
 static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP, const T* y, const float* scale,
                          const float* shift, int B, int Hk, int Wk, T* dA, const float* mean, const float* rstd, float* partial,
                          int* nblk_out, hipStream_t stream) {
     if (nblk_out) *nblk_out = 0;
     if (std::is_same<T, __bf16>::value && getenv("P4C_ENC_OUT_V1") == nullptr) {
-        int64_t blocks = ((int64_t)Hk * Wk + 31) / 32;
+        const char* v2 = getenv("P4C_ENC_OUT_V2");   // 0: the round-2 kernel (one thread per pixel, dependent row loads)
+        const bool old = v2 && v2[0] == '0';
+        const bool blk = !old && dP && s <= 2 && Hk % 2 == 0 && Wk % 2 == 0;   // one thread per 2x2 block on the fine levels
+        int64_t blocks = blk ? ((int64_t)(Hk / 2) * (Wk / 2) + 31) / 32 : ((int64_t)Hk * Wk + 31) / 32;
         int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
         const bool fuse = partial && nblk_out && mean && rstd;
         if (fuse && cap > NORM_BWD_MAX_BLOCKS) cap = NORM_BWD_MAX_BLOCKS;   // one partial slot per workgroup
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(enc_out_bwd_bf16x8_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const __bf16*)Tx, Hfull, s,
+        auto kern = old ? enc_out_bwd_bf16x8_kernel : (blk ? enc_out_bwd_blk_kernel : enc_out_bwd_px_kernel);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const __bf16*)Tx, Hfull, s,
                            (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale, shift, Hk, Wk, (__bf16*)dA, mean, rstd,
                            fuse ? partial : nullptr);
         if (fuse) *nblk_out = (int)blocks;
