@@ -274,7 +274,7 @@ def fp32_flavour(args, case, info, device, steps=6, warmup=2, dtype="f32", batch
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(steps):
-        loss = step(warmup + i)
+        loss = step(warmup + i).detach()
         marks[i + 1].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -409,6 +409,16 @@ def main():
         probe = {"eager_ms_per_step": 1e3 * t_eager, "graph_ms_per_step": None if t_graph is None else 1e3 * t_graph,
                  "chosen": "graph" if use_graph else "eager"}
         barrier()
+    # The timed region is ~0.1 s: a generational garbage collection of this process (tens of thousands of tracked objects once
+    # torch and the model are loaded) is a 10-50 ms host pause that starves the GPU.  The collector is parked from here on --
+    # BEFORE the warm-up steps, so that the caching allocator reaches its steady state under the same object lifetimes as the
+    # timed steps (parked only for the timed steps, the second of them grew the pool by one device allocation).
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
     for i in range(args.warmup):
         step(i)
     timed = getattr(lm.model, "timed_entry_points", None) or (
@@ -451,24 +461,24 @@ def main():
         barrier()
     # one event per step boundary (a record costs the stream a few microseconds against a ~5 ms step): min / median / max
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    # The timed region is ~0.1 s: a generational garbage collection of this process (tens of thousands of tracked objects once
-    # torch and the model are loaded) is a 10-50 ms host pause that starves the GPU -- the collector is parked for the timed
-    # steps (collected and frozen first, so nothing is pending), and device allocations inside the region are counted.
-    import gc
-
-    gc.collect()
-    gc.freeze()
-    gc_was_enabled = gc.isenabled()
-    gc.disable()
+    # (collector parked since before the warm-up steps; device allocations inside the timed region are counted)
     allocs_before = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
+    trace_allocs = os.environ.get("P4C_BENCH_TRACE_ALLOCS") == "1"   # debugging: which timed step allocates device memory
+    alloc_steps = []
     for i in range(args.steps):
-        loss = step(args.warmup + i)
+        loss = step(args.warmup + i).detach()   # (holding the loss itself would keep the step's autograd graph -- its state buffers -- alive into the next step)
         marks[i + 1].record()
+        if trace_allocs:
+            n = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
+            if n != allocs_before + len(alloc_steps):
+                alloc_steps.append(i)
     barrier()
     dt = time.perf_counter() - t0
+    if trace_allocs:
+        print(f"bench: device allocations in timed steps {alloc_steps}; reserved {torch.cuda.memory_reserved(device) / 2**20:.0f} MiB", file=sys.stderr)
     device_allocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs_before
     if gc_was_enabled:
         gc.enable()

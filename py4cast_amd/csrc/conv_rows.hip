@@ -30,7 +30,7 @@ namespace p4c {
 #ifdef P4C_STAMPS  // diagnostic build only: s_memtime / s_memrealtime stamps of one compute and one loader wave of workgroup 7
 __device__ unsigned long long* g_rows_stamps = nullptr;
 __device__ __forceinline__ void rows_stamp(int slot) {
-    if (g_rows_stamps && blockIdx.x == 7 && (threadIdx.x & 63) == 0) {
+    if (g_rows_stamps && blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) {
         unsigned long long t;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         g_rows_stamps[2 * slot] = t;
@@ -241,7 +241,7 @@ template <int MODE, bool BST, int MF>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     conv3x3_bf16_rows_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ in_scale,
                              const float* __restrict__ in_shift, __bf16* __restrict__ out, int out_cs,
-                             float* __restrict__ stat_partial, int H, int W, int nstrips, int nseg, BatchFin fin, RingBwdStats bst) {
+                             float* __restrict__ stat_partial, int H, int W, int rows_lo, int rows_rem, BatchFin fin, RingBwdStats bst) {
     using namespace rows;
     typedef Lay<MF> LY;
     constexpr int PIXB = LY::PIXB, RROW = LY::RROW, RINGB = LY::RINGB;
@@ -251,12 +251,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    // workgroup -> (sample, strip, row segment); segments of a strip are balanced to within one row
-    const int seg = blockIdx.x % nseg;
-    const int sidx = blockIdx.x / nseg;
-    const int strip = sidx % nstrips, b = sidx / nstrips;
-    const int y0 = (int)((int64_t)seg * H / nseg);
-    const int R = (int)((int64_t)(seg + 1) * H / nseg) - y0;   // >= 2 (host)
+    // workgroup -> (sample, strip, row segment) = blockIdx (z, y, x); the first H % nseg segments of a strip have one row more
+    // (no divisions on the way into a kernel whose whole job takes a few microseconds on the coarse levels)
+    const int seg = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int nseg = gridDim.x, nstrips = gridDim.y;
+    const int wg_id = (b * nstrips + strip) * nseg + seg, wg_count = nseg * nstrips * gridDim.z;
+    const int y0 = seg * rows_lo + (seg < rows_rem ? seg : rows_rem);
+    const int R = rows_lo + (seg < rows_rem ? 1 : 0);          // >= 2 (host)
     const int x0 = strip * SW;
     const int K = (R + 5) >> 2;                                // intervals of four input rows: ceil((R + 2) / 4)
 
@@ -269,10 +270,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         // Column validity is static per lane (the strip is fixed): slots of columns outside the image get lim = "never active";
         // those LDS columns are zeroed once below and never written, so only ROWS outside the image need the checked path.
         int gofs[NLD], lofs[NLD], lim[NLD];
+        int rr = 0, rem = ltid;   // idx = ltid + 256 it = rr * ROWSLOTS + rem, kept incrementally (no divisions: 256 < ROWSLOTS)
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int idx = ltid + it * 256;
-            const int rr = idx / ROWSLOTS, col = (idx - rr * ROWSLOTS) >> 3;
+            if (it > 0) { rem += 256; if (rem >= ROWSLOTS) { rem -= ROWSLOTS; ++rr; } }
+            const int col = rem >> 3;
             gofs[it] = (rr * W + col) * 128 + 16 * c8;
             lofs[it] = rr * RROW + LY::slot_off(col, c8);
             lim[it] = ((unsigned)(x0 - 1 + col) < (unsigned)W) ? idx : OOB;
@@ -281,11 +284,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int left = x0 == 0 ? 1 : 0;
             const int c_hi = W - x0 + 1 < LW ? W - x0 + 1 : LW;       // first column at or beyond the right image edge
             const int ninv = left + (LW - c_hi);
-            for (int i = ltid; i < NR * ninv * 8; i += 256) {
-                const int s8 = i & 7, ci = (i >> 3) % ninv, rr = (i >> 3) / ninv;
-                const int col = (left && ci == 0) ? 0 : c_hi + ci - left;
-                *reinterpret_cast<u32x4*>(lring + rr * RROW + col * PIXB + 16 * s8) = u32x4{0u, 0u, 0u, 0u};   // (all 8 slots of the pixel: any order)
-            }
+            for (int rz = 0; rz < NR; ++rz)
+                for (int j = ltid; j < ninv * 8; j += 256) {
+                    const int s8 = j & 7, ci = j >> 3;
+                    const int col = (left && ci == 0) ? 0 : c_hi + ci - left;
+                    *reinterpret_cast<u32x4*>(lring + rz * RROW + col * PIXB + 16 * s8) = u32x4{0u, 0u, 0u, 0u};   // (all 8 slots of the pixel: any order)
+                }
         }
         int dofs[NST], sofs[NST];
 #pragma unroll
@@ -490,23 +494,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 // release FENCE (at the end of a kernel that has just written its output map it would write back the XCD's whole L2).
 #pragma unroll
                 for (int j = lane; j < 128; j += 64)   // fixed order over the waves
-                    __hip_atomic_store(fin.slots + (int64_t)blockIdx.x * 128 + j,
+                    __hip_atomic_store(fin.slots + (int64_t)wg_id * 128 + j,
                                        (lred[j] + lred[128 + j]) + (lred[256 + j] + lred[384 + j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) *lflag = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             lds_barrier();
-            if (*lflag != gridDim.x - 1) return;
+            if (*lflag != (unsigned)wg_count - 1) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // invalidate only: the other workgroups' slots are read from memory
             // 256 threads: 32 column quads x 8 slot groups; slots summed in increasing order within a group, groups in order
             const int cq = ltid & 31, sg = ltid >> 5;
             double acc4[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int s0 = sg; s0 < (int)gridDim.x; s0 += 8 * 8) {
+            for (int s0 = sg; s0 < wg_count; s0 += 8 * 8) {
                 p4c_f32x4 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int sl = s0 + 8 * u;
-                    v[u] = sl < (int)gridDim.x ? *(reinterpret_cast<const p4c_f32x4*>(fin.slots + (int64_t)sl * 128) + cq)
+                    v[u] = sl < wg_count ? *(reinterpret_cast<const p4c_f32x4*>(fin.slots + (int64_t)sl * 128) + cq)
                                                : p4c_f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
@@ -719,12 +723,12 @@ int launch_rows_mode(const __bf16* in, const __bf16* wp, const float* in_scale, 
                      const RingBwdStats& bst) {
     if (rows_mfma_shape() == 32) {
         P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 32>, rows::Lay<32>::SMEM));
-        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32>), dim3(B * nstrips * nseg), dim3(512), rows::Lay<32>::SMEM, stream,
-                           in, wp, in_scale, in_shift, out, out_cs, stat_partial, H, W, nstrips, nseg, fin, bst);
+        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream,
+                           in, wp, in_scale, in_shift, out, out_cs, stat_partial, H, W, H / nseg, H % nseg, fin, bst);
     } else {
         P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 16>, rows::Lay<16>::SMEM));
-        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 16>), dim3(B * nstrips * nseg), dim3(512), rows::Lay<16>::SMEM, stream,
-                           in, wp, in_scale, in_shift, out, out_cs, stat_partial, H, W, nstrips, nseg, fin, bst);
+        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 16>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<16>::SMEM, stream,
+                           in, wp, in_scale, in_shift, out, out_cs, stat_partial, H, W, H / nseg, H % nseg, fin, bst);
     }
     return P4C_OK;
 }

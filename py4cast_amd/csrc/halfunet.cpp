@@ -328,7 +328,12 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
     };
     if (g_side.enabled) {
         g_side.pending.push_back(job);
-        if ((int)g_side.pending.size() >= g_side.every) P4C_TRY(g_side.flush(st));
+        // (block 1 closes a batch whatever its size: the full-resolution weight gradient of conv 1 then runs beside the chain of
+        // block 0 instead of after it, and only block 0's is left over when the main stream ends -- with the join deferred over
+        // the AR steps that left-over is exposed once per optimizer step: 240 -> ~60 us)
+        const char* f1 = getenv("P4C_FLUSH_AT_1");   // (A/B switch)
+        const bool at1 = i == 1 && !g_side.external && !(f1 && f1[0] == '0');
+        if ((int)g_side.pending.size() >= g_side.every || at1) P4C_TRY(g_side.flush(st));
     } else {
         P4C_TRY(job(st));
     }
