@@ -1972,7 +1972,7 @@ int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, c
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
                   int m_blocks, hipStream_t stream, const BatchFin* fin, const RingBwdStats* bst, int* nblk_out) {
     if (conv_bf16_is_rows(storage, CI, ks, m_blocks, out_cs, B, H, W))
-        return launch_conv3x3_bf16_rows(in, wp, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, stream, fin, bst,
+        return launch_conv3x3_bf16_rows(in, wp, ks, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, stream, fin, bst,
                                         nblk_out);
     if (is_tile_ring(storage, CI, ks, m_blocks, out_cs, B, H, W))
         return launch_conv3x3_bf16_ring((const __bf16*)in, (const __bf16*)wp, in_scale, in_shift, in_relu, (__bf16*)out, out_cs,

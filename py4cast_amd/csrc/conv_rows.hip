@@ -237,7 +237,7 @@ __device__ __forceinline__ void conv_row16(const bf16x8 (&A)[9][2][2], Acc16& P,
     }
 }
 
-template <int MODE, bool BST, int MF>
+template <int MODE, bool BST, int MF, int KS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     conv3x3_bf16_rows_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ in_scale,
                              const float* __restrict__ in_shift, __bf16* __restrict__ out, int out_cs,
@@ -567,7 +567,59 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (wv == 0) P4C_STAMP(9);
     const int last = R + 1;
     int m = 0;
-    if constexpr (MF == 32) {
+    if constexpr (KS == 1) {
+        // 1x1 convolution on the same machinery (memory-bound: 4 MFMAs per row): only the centre column of the ring rows is
+        // read, output row n is formed from input row n + 1 and -- to keep the staging / drain cadence of the 3x3 kernel --
+        // handed to the memory side one row later, exactly where the 3x3 form finishes it.
+        bf16x8 A1[4];
+        {
+            const char* wsrc = reinterpret_cast<const char*>(wp) + (h * 64 + ct * 32 + r) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) A1[ks] = *reinterpret_cast<const bf16x8*>(wsrc + ks * 2048);
+        }
+        const int lane_base = (32 * ph + r + 1) * PIXB + 16 * h;   // centre column: pixel + 1 (the ring keeps the halo column)
+        int soff[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) soff[g] = (32 * ph + r) * 128 + 8 * h + (((4 * ct + g) ^ (((32 * ph + r) >> 1) & 7)) << 4);
+        f32x16 prev, cur;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[i] = cur[i] = 0.f;
+        if (wv == 0) P4C_STAMP(10);
+        lds_barrier();
+        if (wv == 0) P4C_STAMP(11);
+        for (; m <= last; ++m) {
+            if (m >= 1 && m <= R && !(P4C_EXP & 16)) {
+                const char* rb = lring + (m & 7) * RROW + lane_base;
+                bf16x8 fbq[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fbq[ks] = *reinterpret_cast<const bf16x8*>(rb + ks * 32);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                        cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[ks], fbq[ks], z, 0, 0, 0);
+                    } else {
+                        cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[ks], fbq[ks], cur, 0, 0, 0);
+                    }
+                }
+            }
+            if (m >= 2) {   // output row m - 2 (held since the previous trip) goes to staging row m & 7
+                char* stg = lstg + (m & 7) * SROW;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x2 lo = {prev[4 * g], prev[4 * g + 1]}, hi = {prev[4 * g + 2], prev[4 * g + 3]};
+                    u32x2 o;
+                    o[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(lo, bf16x2));
+                    o[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(hi, bf16x2));
+                    *reinterpret_cast<u32x2*>(stg + soff[g]) = o;
+                }
+            }
+            prev = cur;
+            if (m == last || (m & 3) == 3) lds_barrier();
+        }
+    } else if constexpr (MF == 32) {
         bf16x8 A[9][4];
         {
             const char* wsrc = reinterpret_cast<const char*>(wp) + (h * 64 + ct * 32 + r) * 16;
@@ -717,20 +769,32 @@ static int rows_mfma_shape() {   // 32 (default): v_mfma_f32_32x32x16_bf16; P4C_
     return (e && atoi(e) == 16) ? 16 : 32;
 }
 
-template <int MODE, bool BST>
+template <int MODE, bool BST, int KS>
 int launch_rows_mode(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, __bf16* out, int out_cs,
                      float* stat_partial, int B, int H, int W, int nstrips, int nseg, hipStream_t stream, const BatchFin& fin,
                      const RingBwdStats& bst) {
-    if (rows_mfma_shape() == 32) {
-        P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 32>, rows::Lay<32>::SMEM));
-        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream,
+    if (KS == 1 || rows_mfma_shape() == 32) {
+        P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>, rows::Lay<32>::SMEM));
+        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream,
                            in, wp, in_scale, in_shift, out, out_cs, stat_partial, H, W, H / nseg, H % nseg, fin, bst);
-    } else {
-        P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 16>, rows::Lay<16>::SMEM));
-        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 16>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<16>::SMEM, stream,
+    } else if (KS == 3) {
+        P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 16, 3>, rows::Lay<16>::SMEM));
+        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 16, 3>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<16>::SMEM, stream,
                            in, wp, in_scale, in_shift, out, out_cs, stat_partial, H, W, H / nseg, H % nseg, fin, bst);
     }
     return P4C_OK;
+}
+
+template <int KS>
+int launch_rows_ks(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, int in_relu, __bf16* out, int out_cs,
+                   float* stat_partial, int B, int H, int W, int nstrips, int nseg, hipStream_t stream, const BatchFin& fin,
+                   const RingBwdStats* bst) {
+    if (bst) return launch_rows_mode<0, true, KS>(in, wp, nullptr, nullptr, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, *bst);
+    if (in_scale)
+        return in_relu ? launch_rows_mode<2, false, KS>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{})
+                       : launch_rows_mode<3, false, KS>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{});
+    return in_relu ? launch_rows_mode<1, false, KS>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{})
+                   : launch_rows_mode<0, false, KS>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{});
 }
 
 }  // namespace
@@ -762,7 +826,9 @@ void conv_rows_geometry(int B, int H, int W, int* nstrips_out, int* nseg_out) {
 bool conv_bf16_is_rows(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W) {
     const char* e = getenv("P4C_NO_ROWS");   // (read per call: the A/B scripts and the parity tests switch it)
     const bool off = e && e[0] == '1';
-    return !off && storage == P4C_BF16 && CI == 64 && ks == 3 && m_blocks == 1 && out_cs % 8 == 0 && W > 32 && H >= 8 &&
+    const char* e1 = getenv("P4C_NO_ROWS_1X1");
+    if (ks == 1 && e1 && e1[0] == '1') return false;
+    return !off && storage == P4C_BF16 && CI == 64 && (ks == 3 || ks == 1) && m_blocks == 1 && out_cs % 8 == 0 && W > 32 && H >= 8 &&
            (int64_t)H * W * out_cs * 2 < (int64_t)1 << 31 && (int64_t)H * W * 128 < (int64_t)1 << 31;
 }
 
@@ -772,8 +838,8 @@ int conv_rows_stat_slots(int B, int H, int W) {
     return nstrips * nseg * 4;
 }
 
-int launch_conv3x3_bf16_rows(const void* inv, const void* wpv, const float* in_scale, const float* in_shift, int in_relu, void* outv,
-                             int out_cs, float* stat_partial, int B, int H, int W, hipStream_t stream, const BatchFin* finp,
+int launch_conv3x3_bf16_rows(const void* inv, const void* wpv, int ks, const float* in_scale, const float* in_shift, int in_relu,
+                             void* outv, int out_cs, float* stat_partial, int B, int H, int W, hipStream_t stream, const BatchFin* finp,
                              const RingBwdStats* bst, int* nblk_out) {
     const __bf16* in = (const __bf16*)inv;
     const __bf16* wp = (const __bf16*)wpv;
@@ -782,23 +848,18 @@ int launch_conv3x3_bf16_rows(const void* inv, const void* wpv, const float* in_s
     conv_rows_geometry(B, H, W, &nstrips, &nseg);
     BatchFin fin{};
     if (finp && stat_partial) { fin = *finp; fin.slots = stat_partial; }
-    int rc;
-    prof_begin(P4C_PROF_CONV3X3_C64, (int64_t)B * H * W, stream);
     if (bst) {
         P4C_CHECK_ARG(!in_scale && !in_relu && stat_partial && !finp && out_cs == 64 && nblk_out,
-                      "conv3x3_bf16_rows: backward statistics need a plain 64-channel launch with a partial buffer");
+                      "conv_bf16_rows: backward statistics need a plain 64-channel launch with a partial buffer");
         *nblk_out = nstrips * nseg * 4;
-        rc = launch_rows_mode<0, true>(in, wp, nullptr, nullptr, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, *bst);
-    } else if (in_scale) {
-        rc = in_relu ? launch_rows_mode<2, false>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{})
-                     : launch_rows_mode<3, false>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{});
-    } else {
-        rc = in_relu ? launch_rows_mode<1, false>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{})
-                     : launch_rows_mode<0, false>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{});
     }
-    prof_end(P4C_PROF_CONV3X3_C64, stream);
+    const int tag = ks == 3 ? P4C_PROF_CONV3X3_C64 : 0;
+    if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
+    const int rc = ks == 3 ? launch_rows_ks<3>(in, wp, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, bst)
+                           : launch_rows_ks<1>(in, wp, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, bst);
+    if (tag) prof_end(tag, stream);
     if (rc != P4C_OK) return rc;
-    P4C_CHECK_LAUNCH("conv3x3_bf16_rows");
+    P4C_CHECK_LAUNCH("conv_bf16_rows");
     return P4C_OK;
 }
 

@@ -477,6 +477,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
 
     // ---- output 1x1 conv
     Norm nd2 = norm_at(ws, 11, d.B);
+    int pre11 = 0;
     {
         int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(d.H, d.W);
         const int G = ntiles < L.G ? (int)ntiles : L.G;
@@ -488,12 +489,23 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         P4C_TRY(conv_wgrad(d.compute, d.dtype, ws.act(L.Y[11]), NF, 1, nd2.scale, nd2.shift, 1, dy, ws.f(L.wgradp), G, d.B, d.H,
                            d.W, d.cout, NF, grads + L.wout, wst));
         if (deferring) P4C_CHECK_HIP(hipEventRecord(g_side.dy_read, g_side.stream));
-        P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
+        // the 1x1 data gradient IS the dA of conv 11's normalisation backward: on the row kernel it takes pass 1 of it
+        // (sums of g and g * xhat) while it stores the rows, instead of a norm_bwd_reduce launch over dA and y
+        const char* fe = getenv("P4C_NO_FUSED_REDUCE");
+        const bool fuse11 = !(fe && fe[0] == '1') && d.compute == P4C_BF16 && conv_bf16_is_rows(d.dtype, NF, 1, 1, NF, d.B, d.H, d.W) &&
+                            conv_bf16_bwd_stats_ok(d.dtype, d.B, d.H, d.W);
+        if (fuse11) {
+            const RingBwdStats bst{ws.act(L.Y[11]), nd2.scale, nd2.shift, nd2.mean, nd2.rstd};
+            P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, G0, NF, ws.f(L.nbwdp), d.B, d.H,
+                             d.W, 1, st, nullptr, &bst, &pre11));
+        } else {
+            P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
+        }
     }
     // ---- decoder
     Norm nd1 = norm_at(ws, 10, d.B);
     int nxt = 0;
-    P4C_TRY(conv_block_bwd(d, ws, 11, G0, ws.act(L.Y[10]), &nd1, G1, params, grads, training, st, 0, &nxt));
+    P4C_TRY(conv_block_bwd(d, ws, 11, G0, ws.act(L.Y[10]), &nd1, G1, params, grads, training, st, pre11, &nxt));
     P4C_TRY(conv_block_bwd(d, ws, 10, G1, ws.act(L.S), nullptr, G0, params, grads, training, st, nxt));
     // G0 = dS, kept until the last level
 

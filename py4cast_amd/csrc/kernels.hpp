@@ -84,8 +84,8 @@ bool conv_bf16_bwd_stats_ok(int storage, int B, int H, int W);
 bool conv_bf16_is_rows(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W);
 void conv_rows_geometry(int B, int H, int W, int* nstrips, int* nseg);
 int conv_rows_stat_slots(int B, int H, int W);   // statistics slots per sample ([2][64] floats each)
-int launch_conv3x3_bf16_rows(const void* in, const void* wp, const float* in_scale, const float* in_shift, int in_relu, void* out,
-                             int out_cs, float* stat_partial, int B, int H, int W, hipStream_t stream, const BatchFin* fin,
+int launch_conv3x3_bf16_rows(const void* in, const void* wp, int ks, const float* in_scale, const float* in_shift, int in_relu,
+                             void* out, int out_cs, float* stat_partial, int B, int H, int W, hipStream_t stream, const BatchFin* fin,
                              const RingBwdStats* bst, int* nblk_out);
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                     const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
