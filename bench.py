@@ -543,7 +543,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.model} {args.strategy} rollout T={T}, grid {H}x{W}x{F} (+{Ff} forcings, {Fs} statics), "
-                            f"WeightedLoss(MSE), AdamW, B={B}/GPU",
+                            f"WeightedLoss(MSE), AdamW, B={B}/GPU"
+                            + (" [restated UNETR++ architecture: mfai absent, not checkpoint compatible -- py4cast_amd/unetrpp.py]"
+                               if args.model.lower().startswith("unetrpp") else ""),
                 "global_batch": world * B,
                 "parallelism": f"dp{world}" + (" (ranks sharing one GPU over gloo: functional test, not a scaling number)" if share_gpu else ""),
                 "border_size": args.border,

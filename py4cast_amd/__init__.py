@@ -27,8 +27,8 @@ _os.environ.setdefault("MIOPEN_FIND_MODE", "2")
 # torch.cuda.tunable.read_file by the first native call on a GPU tensor (_lib.require_cuda) -- TunableOp's own file-name variable
 # inserts the device ordinal into the name, which would need one copy per rank.  Respect an explicit user choice (PYTORCH_TUNABLEOP_ENABLED set either way), and P4C_NO_TUNED_GEMMS=1.
 _TUNED_GEMMS = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "tunableop_gfx950.csv")
+# (round 3: nothing is switched on at import any more -- importing this package used to set PYTORCH_TUNABLEOP_ENABLED for the
+# whole host process; now _lib._load_tuned_gemms enables the lookup itself, tuning and file writing off, at that first call)
 if ("PYTORCH_TUNABLEOP_ENABLED" not in _os.environ and _os.environ.get("P4C_NO_TUNED_GEMMS") != "1"
         and _os.path.exists(_TUNED_GEMMS)):
-    _os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
-    _os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
     _os.environ["P4C_TUNED_GEMMS_FILE"] = _TUNED_GEMMS   # read by _lib.require_cuda at the first native call on a GPU tensor

@@ -226,8 +226,17 @@ def _load_tuned_gemms():
     try:
         import torch.cuda.tunable as tunable
 
-        if tunable.is_enabled() and not tunable.tuning_is_enabled():
-            tunable.read_file(path)
+        # lookup on, tuning and result files off: only the shipped selections are consulted, nothing is measured or written,
+        # and a stray tunableop_results*.csv in the working directory is not picked up by a file-name default
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.write_file_on_exit(False)
+        ok = tunable.read_file(path)
+        if ok is False:   # validator lines of the file (torch / ROCm / hipBLASLt / GPU) do not match this stack
+            import warnings
+
+            warnings.warn("py4cast_amd: the shipped GEMM selections were rejected by TunableOp's validators (another torch / "
+                          "ROCm / hipBLASLt build): library-default GEMM kernels are used")
     except Exception as exc:  # noqa: BLE001  (no TunableOp in this build / unreadable file: the library's default selection stays)
         import warnings
 

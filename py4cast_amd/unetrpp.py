@@ -14,6 +14,14 @@ What runs where
 * the token-axis projection E = F (a Linear over N), the qkvv / output projections: library GEMMs.
 * convolutions (stem, 2x2 down-sampling, the residual 3x3 blocks, 1x1) and their group / batch / instance norms: torch
   (MIOpen) -- not yet on native kernels, like the SwinUNetR decoder.
+Known differences from the published UNETR++ block that mfai wraps (advisor review, round 2; NOT checkpoint compatible):
+* the spatial-attention branch is merged head-major per token (``permute(0, 2, 1, 3)``: token n keeps its own heads x d values); the
+  published code writes ``(attn_SA @ v_SA^T).permute(0, 3, 1, 2).reshape(B, N, C)``, a fixed permutation of the (N x C) entries that
+  mixes tokens and channels -- a quirk of that code, not of the method;
+* ``conv8`` is a bare 1x1 convolution here; the published block is ``Sequential(Dropout(0.1), Conv)`` (state-dict keys ``conv8.1.*``)
+  and has two more dropouts on the attention maps -- no dropout is drawn here (deterministic step, HIP-graph capturable);
+mfai 5.0.1 is absent from this container, so which of the two forms it ships could not be checked: the UNetRPP bench line is a
+"restated architecture" figure (bench.py says so in ``config.workload``), same tensor shapes and operation counts.
 Input / output are features-last (B, H, W, C); H and W must be multiples of 8 * downsampling_rate.  ``attention_code``
 ("torch" | "flash" | "manual" in mfai) is accepted and ignored: all of them are this one fused formulation.
 """

@@ -105,7 +105,7 @@ def test_lazy_masks_behave_like_the_reference_tensors():
 
 def test_tuned_gemm_selections_file_and_switches():
     """py4cast_amd/__init__.py: the shipped TunableOp result file is well-formed (validator header, one 4-field line per shape, no
-    "Default" entries), the import switches TunableOp on with tuning OFF without touching the device, and both an explicit user
+    "Default" entries), the import records the file without touching the device or the process-wide TunableOp switches, and both an explicit user
     setting and P4C_NO_TUNED_GEMMS=1 are respected."""
     import os
     import subprocess
@@ -131,7 +131,9 @@ def test_tuned_gemm_selections_file_and_switches():
         root = os.path.dirname(os.path.dirname(py4cast_amd.__file__))
         return subprocess.run([sys.executable, "-c", probe], env=env, cwd=root, capture_output=True, text=True, check=True).stdout.split()
 
-    assert run({}) == ["1", "0", "True"]
+    # (round 3: the import no longer switches TunableOp on for the whole host process; the first native call on a GPU tensor
+    # enables the lookup itself -- tests/test_widen_gpu.py -- and the import only records where the file is)
+    assert run({}) == ["None", "None", "True"]
     assert run({"P4C_NO_TUNED_GEMMS": "1"}) == ["None", "None", "False"]
     assert run({"PYTORCH_TUNABLEOP_ENABLED": "0"}) == ["0", "None", "False"]
     assert run({"PYTORCH_TUNABLEOP_ENABLED": "1", "PYTORCH_TUNABLEOP_TUNING": "1"}) == ["1", "1", "False"]   # the user's own tuning session

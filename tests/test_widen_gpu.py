@@ -828,12 +828,22 @@ def test_trainer_fit_with_hip_graph_matches_eager(gpu_device, tmp_path):
             training_strategy="scaled_ar", learning_rate=1e-3,
         )
         tr = Trainer(max_epochs=1, accumulate_grad_batches=2, device=gpu_device, hip_graph=hip_graph)
+        seen = []
+        lm.on_train_epoch_end = lambda: seen.extend(float(v) for v in lm.training_step_losses)   # what the epoch-end mean is taken over
         tr.fit(lm, [make_batch(c, "cpu") for c in cases])
         assert tr.global_step == 3
-        return torch.cat([p.detach().flatten() for p in lm.model.parameters()]).cpu()
+        losses = [float(v) for v in tr.train_step_losses]
+        return torch.cat([p.detach().flatten() for p in lm.model.parameters()]).cpu(), losses, seen
 
-    eager, graphed = train(False), train(True)
+    (eager, le, se), (graphed, lg, sg) = train(False), train(True)
     assert _rel(graphed, eager) < 1e-5
+    # loss bookkeeping under replay: one entry per micro-batch, each its own value (the replay's loss is ONE static tensor: entries
+    # must be copies), equal to the eager run's; the module's own list holds exactly the training steps -- none of the capture's
+    # warm-up / verification passes
+    assert len(le) == len(lg) == 6 and len(set(lg)) == 6
+    np.testing.assert_allclose(lg, le, rtol=1e-5)
+    assert len(sg) == 6
+    np.testing.assert_allclose(sg, se, rtol=1e-5)
 
 
 @pytest.mark.parametrize("model_name,settings", [("GraphLam", {"activation_dtype": "bf16", "processor_layers": 1}),
