@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--hip-graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the micro-batch (rollout + loss + backward) from a HIP graph; auto: only for models that ask for it "
                          "(launch-bound small-kernel models); the roofline object is then measured in eager steps before the timed region")
+    ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: reduce-scatter + sharded AdamW + all-gather instead of all-reduce + full AdamW (auto: above 16 MB of gradients)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange the gradients after the backward instead of inside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU-baseline budget: iterations are timed until it is spent, at least two")
@@ -347,8 +350,11 @@ def main():
         training_strategy=args.strategy, learning_rate=1e-3, min_learning_rate=3e-7, num_warmup_steps=1000,
         betas=(0.9, 0.95),
     ).to(device)
-    ddp = FlatDDP(lm.model, world)
+    n_grad_bytes = 4 * sum(p.numel() for p in lm.model.parameters() if p.requires_grad)
+    sharded = world > 1 and (args.sharded == "on" or (args.sharded == "auto" and n_grad_bytes > (16 << 20)))
+    ddp = FlatDDP(lm.model, world, sharded=sharded, overlap=not args.no_overlap)
     opt = lm.configure_optimizers()["optimizer"]
+    sharded = sharded and hasattr(opt, "step_shards")
 
     micro = [0]
     use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and getattr(lm.model, "prefers_hip_graph", False))
@@ -359,11 +365,17 @@ def main():
             loss = graphed[0](make_batch(case))
         else:
             loss = lm.training_step(make_batch(case), i)
+            if (micro[0] + 1) % args.accumulate == 0:
+                ddp.arm()   # (N > 1, several buckets: the exchange starts inside this backward)
             (loss / args.accumulate if args.accumulate > 1 else loss).backward()
         micro[0] += 1
         if micro[0] % args.accumulate == 0:   # non-stepping micro-batches neither sync nor step (trainer.yaml:58)
             ddp.all_reduce_grads()
-            opt.step()
+            if sharded:
+                opt.step_shards(ddp.shards())
+                ddp.all_gather_params()
+            else:
+                opt.step()
             ddp.zero_grad()
         return loss
 
@@ -547,6 +559,10 @@ def main():
                             + (" [restated UNETR++ architecture: mfai absent, not checkpoint compatible -- py4cast_amd/unetrpp.py]"
                                if args.model.lower().startswith("unetrpp") else ""),
                 "global_batch": world * B,
+                "gradient_exchange": None if world == 1 else {
+                    "mode": "reduce-scatter + sharded AdamW + all-gather" if sharded else "all-reduce",
+                    "buckets": len(ddp.buckets), "bytes": n_grad_bytes, "overlapped_with_backward": bool(ddp.overlap),
+                    "buckets_issued_inside_last_backward": int(ddp.issued_in_backward)},
                 "parallelism": f"dp{world}" + (" (ranks sharing one GPU over gloo: functional test, not a scaling number)" if share_gpu else ""),
                 "border_size": args.border,
                 "setup_steps": args.setup_steps,

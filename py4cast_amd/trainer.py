@@ -34,11 +34,18 @@ class FlatDDP:
       AR step 0 -- with BPTT nothing is final earlier, SURVEY.md 8e);
     * ``sharded=True`` (large models, e.g. UNetR++): reduce-scatter instead of all-reduce, the optimizer steps only this rank's
       shard of every bucket (``shards()``; ``FlatAdamW.step(shards=...)``), then ``all_gather_params`` -- the same bytes on the
-      links as an all-reduce, 1/N of the optimizer work per rank.
+      links as an all-reduce, 1/N of the optimizer work per rank;
+    * ``overlap=True`` (several buckets, parameters that go through autograd): the exchange starts INSIDE the backward
+      (config/CLI/trainer.yaml:58,62-64 -- what Lightning's DDP does with its reducer).  With BPTT autograd sums a parameter's
+      contributions of all AR steps before its AccumulateGrad node runs, i.e. a gradient becomes final while the backward of AR
+      step 0 passes its layer (the last 1/T of the sweep): a post-accumulate hook counts the parameters of each bucket, and a
+      bucket whose count is complete is issued on the communication stream at once -- buckets strictly in the order last ->
+      first, whatever order the hooks fire in, so that every rank issues the same sequence of collectives.  ``arm()`` before
+      the backward of the micro-batch that steps; ``all_reduce_grads()`` afterwards issues what is left and waits.
     """
 
     def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, bucket_bytes: int = 64 << 20,
-                 single_bucket_bytes: int = 16 << 20, sharded: bool = False):
+                 single_bucket_bytes: int = 16 << 20, sharded: bool = False, overlap: bool = False):
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.world_size = world_size
@@ -66,6 +73,30 @@ class FlatDDP:
             self.buckets = [(lo, min(lo + per, n_all)) for lo in range(0, n_all, per)]
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._inflight = False
+        # ---- exchange overlapped with the backward (see the class docstring)
+        self.overlap = bool(overlap) and world_size > 1 and len(self.buckets) > 1 and self._views_ok
+        self._armed = False
+        self._issued = [False] * len(self.buckets)       # bucket already on the communication stream in this exchange
+        self._pending = [0] * len(self.buckets)          # parameters of the bucket whose gradient is not final yet
+        self.issued_in_backward = 0                      # (diagnostics / tests) buckets issued by hooks in the last armed backward
+        self._bucket_params = [0] * len(self.buckets)
+        self._hooks = []
+        if self.overlap:
+            off = 0
+            starts = [lo for lo, _ in self.buckets]
+            import bisect
+
+            for p in self.params:
+                # a parameter belongs to the LAST bucket it touches: that bucket waits for it, earlier ones it straddles do not
+                # need to (they are issued after it, buckets go last -> first)... a straddling parameter is therefore counted in
+                # BOTH buckets it touches
+                first = bisect.bisect_right(starts, off) - 1
+                last = bisect.bisect_right(starts, off + p.numel() - 1) - 1
+                owners = list(range(first, last + 1))
+                for b in owners:
+                    self._bucket_params[b] += 1
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(owners)))
+                off += p.numel()
         self.flat_param = None
         if self.sharded:
             self._flatten_parameters(pad)
@@ -122,6 +153,56 @@ class FlatDDP:
             off += p.numel()
         return True
 
+    # ------------------------------------------------------------------ exchange overlapped with backward
+    def arm(self):
+        """Call before the backward of the micro-batch whose gradients will be exchanged (the last one of an accumulation window):
+        from now on a bucket goes onto the communication stream the moment the gradients of all its parameters are final."""
+        if not self.overlap:
+            return
+        self.wait()
+        self._armed = True
+        self._issued = [False] * len(self.buckets)
+        self._pending = list(self._bucket_params)
+        self.issued_in_backward = 0
+
+    def _make_hook(self, owners):
+        def hook(_param):
+            if not self._armed:
+                return
+            for b in owners:
+                self._pending[b] -= 1
+            self._issue_ready(from_hook=True)
+        return hook
+
+    def _issue_ready(self, from_hook: bool, force: bool = False):
+        """Issue, last bucket first, every not yet issued bucket that is complete (or all of them with ``force``); stops at the
+        first incomplete one so that the sequence of collectives is the same on every rank."""
+        for b in range(len(self.buckets) - 1, -1, -1):
+            if self._issued[b]:
+                continue
+            if not force and self._pending[b] > 0:
+                break
+            self._issued[b] = True
+            if from_hook:
+                self.issued_in_backward += 1
+            self._on_comm_stream(lambda b=b: self._exchange_bucket(b))
+
+    def _exchange_bucket(self, b: int):
+        lo, hi = self.buckets[b]
+        piece = self.flat_grad[lo:hi]
+        inv = 1.0 / self.world_size
+        if self.sharded:
+            n = (hi - lo) // self.world_size
+            mine = piece[self.rank * n : (self.rank + 1) * n]
+            if dist.get_backend() == "gloo":   # gloo (CPU tests) has no reduce-scatter: same result.  (Chosen by the
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM)   # backend's name: a genuine RCCL failure must surface.)
+            else:
+                dist.reduce_scatter_tensor(mine, piece, op=dist.ReduceOp.SUM)
+            mine.mul_(inv)
+        else:
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+            piece.mul_(inv)
+
     # ------------------------------------------------------------------ exchange
     def _on_comm_stream(self, fn):
         """Run the collectives of ``fn`` on the communication stream, ordered after everything enqueued on the compute stream."""
@@ -145,24 +226,16 @@ class FlatDDP:
             return
         if not self._views_ok or not self._grads_are_views():
             self._regather()
-        inv = 1.0 / self.world_size
+        if self.overlap and self._armed:
+            # what the hooks have not issued yet (parameters that received no gradient in this pass never fire theirs)
+            self._issue_ready(from_hook=False, force=True)
+            self._armed = False
+        else:
+            def exchange():
+                for b in range(len(self.buckets) - 1, -1, -1):       # last layers first
+                    self._exchange_bucket(b)
 
-        def exchange():
-            for lo, hi in reversed(self.buckets):       # last layers first
-                piece = self.flat_grad[lo:hi]
-                if self.sharded:
-                    n = (hi - lo) // self.world_size
-                    mine = piece[self.rank * n : (self.rank + 1) * n]
-                    if dist.get_backend() == "gloo":   # gloo (CPU tests) has no reduce-scatter: same result.  (Chosen by the
-                        dist.all_reduce(piece, op=dist.ReduceOp.SUM)   # backend's name: a genuine RCCL failure must surface.)
-                    else:
-                        dist.reduce_scatter_tensor(mine, piece, op=dist.ReduceOp.SUM)
-                    mine.mul_(inv)
-                else:
-                    dist.all_reduce(piece, op=dist.ReduceOp.SUM)
-                    piece.mul_(inv)
-
-        self._on_comm_stream(exchange)
+            self._on_comm_stream(exchange)
         if wait:
             self.wait()
         if not self._views_ok:
@@ -471,7 +544,7 @@ class Trainer:
             self.estimated_stepping_batches = self.max_steps
         conf = module.configure_optimizers()
         opt, sched = conf["optimizer"], conf.get("lr_scheduler", {}).get("scheduler")
-        ddp = FlatDDP(module)
+        ddp = FlatDDP(module, overlap=True)   # (several buckets and several ranks only: otherwise one exchange after the backward)
         self.train_step_losses = []
         if hasattr(module, "on_train_start"):
             module.on_train_start()
@@ -524,6 +597,8 @@ class Trainer:
                     loss = graphed(batch)
                 else:   # eager; also a batch whose shape differs from the captured one (a short last batch)
                     loss = module.training_step(batch, i)
+                    if pending + 1 == self.accumulate_grad_batches or last_of_epoch:
+                        ddp.arm()   # the micro-batch that steps: buckets go out while its backward is still running
                     (loss / self.accumulate_grad_batches).backward()
                 self.train_step_losses.append(loss.detach().clone() if graphed is not None else loss.detach())
                 pending += 1

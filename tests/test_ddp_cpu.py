@@ -131,3 +131,72 @@ def test_bucketed_and_sharded_exchange_gloo():
                                                                          torch.nn.Tanh(), torch.nn.Linear(53, 3)).parameters()])
     torch.testing.assert_close(a["sharded"][3], init - 0.1 * a["single"][0])
     torch.testing.assert_close(b["sharded"][3], a["sharded"][3])
+
+
+def _overlap_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from py4cast_amd.trainer import FlatDDP
+
+    def make():
+        torch.manual_seed(11)
+        return torch.nn.Sequential(torch.nn.Linear(24, 96), torch.nn.Tanh(), torch.nn.Linear(96, 64), torch.nn.Tanh(), torch.nn.Linear(64, 24))
+
+    torch.manual_seed(70 + rank)
+    x, y = torch.randn(9, 24), torch.randn(9, 3, 24)
+    out = {}
+    for tag, kw in (("after", dict(overlap=False)), ("overlap", dict(overlap=True)), ("overlap_sharded", dict(overlap=True, sharded=True))):
+        net = make()
+        ddp = FlatDDP(net, world, bucket_bytes=4096, single_bucket_bytes=1024, **kw)
+        events = []
+        real = ddp._exchange_bucket
+        ddp._exchange_bucket = lambda b, real=real: (events.append(("bucket", b)), real(b))[1]
+        for micro in range(2):                       # two accumulated micro-batches: only the second one exchanges
+            state, loss = x, 0.0
+            for t in range(3):                       # an AR rollout: every parameter is used three times (BPTT)
+                state = net(state)
+                loss = loss + ((state - y[:, t]) ** 2).mean()
+            if micro == 1:
+                ddp.arm()
+            torch.autograd.backward(loss / 2)
+            events.append(("backward_done", micro))
+        n_in = ddp.issued_in_backward
+        ddp.all_reduce_grads()
+        own = torch.zeros(ddp.flat_grad.numel(), dtype=torch.bool)
+        for lo, hi in ddp.shards():
+            own[lo:hi] = True
+        out[tag] = (ddp.flat_grad[: ddp.total].clone(), events, n_in, len(ddp.buckets), own[: ddp.total].clone())
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_overlaps_the_backward_gloo():
+    """FlatDDP(overlap=True): with BPTT a parameter's gradient is final when autograd has summed its contributions of all AR steps,
+    i.e. inside the backward; its bucket is issued right then -- buckets strictly last -> first on every rank -- and not in the
+    non-stepping micro-batch; the result equals the exchange issued after the backward (all-reduce and reduce-scatter forms)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 32500 + (os.getpid() % 1000)
+    mp.spawn(_overlap_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    nb = a["overlap"][3]
+    assert nb > 3
+    for r in (a, b):
+        ev = r["overlap"][1]
+        first_done, second_done = ev.index(("backward_done", 0)), ev.index(("backward_done", 1))
+        issued = [i for i, e in enumerate(ev) if e[0] == "bucket"]
+        assert all(i > first_done for i in issued)                       # nothing in the non-stepping micro-batch
+        inside = [ev[i][1] for i in issued if i < second_done]
+        assert len(inside) == r["overlap"][2] and len(inside) >= nb - 1  # (the first layer's bucket completes with the sweep itself)
+        order = [ev[i][1] for i in issued]
+        assert order == sorted(order, reverse=True) and len(order) == nb  # last -> first, each bucket once
+        assert [e for e in r["after"][1] if e[0] == "bucket"] and r["after"][2] == 0
+        assert r["after"][1].index(("backward_done", 1)) < min(i for i, e in enumerate(r["after"][1]) if e[0] == "bucket")
+    torch.testing.assert_close(a["overlap"][0], a["after"][0])
+    torch.testing.assert_close(b["overlap"][0], a["after"][0])
+    for r in (a, b):
+        own = r["overlap_sharded"][4]
+        torch.testing.assert_close(r["overlap_sharded"][0][own], a["after"][0][own])
