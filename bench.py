@@ -116,6 +116,23 @@ def make_info(case, Ff):
                        {n: float(case["state_weight"][i]) for i, n in enumerate(names)}, {"input_output": names}, F, Ff)
 
 
+def model_settings(model, dtype, act_dtype=None, hidden=1024):
+    """The settings dict of each registry model as the reference's yaml files give it (config/CLI/model/*.yaml), with the
+    compute / activation types of this run; shared with tests/test_bench_size_gpu.py."""
+    name = model.lower()
+    if name.startswith(("graphlam", "hilam")):
+        return {"activation_dtype": act_dtype or dtype, "tmp_dir": os.environ.get("TMPDIR", "/tmp")}
+    if name.startswith("unetrpp"):   # config/CLI/model/unetrpp.yaml:19-35
+        return {"hidden_size": hidden, "num_heads_encoder": 16, "num_heads_decoder": 4, "depths": [3, 3, 3, 3],
+                "linear_upsampling": True, "downsampling_rate": 4, "decoder_proj_size": 64, "encoder_proj_sizes": [64, 64, 64, 32],
+                "attention_code": "torch", "activation_dtype": act_dtype or dtype}
+    if name.startswith("swin"):
+        return {"activation_dtype": act_dtype or dtype}
+    if model not in ("Identity",):
+        return {"compute_dtype": dtype, "activation_dtype": act_dtype or dtype}
+    return {}
+
+
 def make_batch(case):
     from py4cast_amd.base import ItemBatch
     from py4cast_amd.namedtensor import NamedTensor
@@ -331,17 +348,7 @@ def main():
     B, F, T, Ff, Fs = args.batch, args.features, args.pred_steps, 5, 4
     case = synthetic_case(1234 + rank, B, T, 1, H, W, F, Ff, Fs, args.border, device)
     info = make_info(case, Ff)
-    settings = {}
-    if args.model.lower().startswith(("graphlam", "hilam")):
-        settings = {"activation_dtype": args.act_dtype or args.dtype, "tmp_dir": os.environ.get("TMPDIR", "/tmp")}
-    elif args.model.lower().startswith("unetrpp"):   # config/CLI/model/unetrpp.yaml:19-35
-        settings = {"hidden_size": args.hidden, "num_heads_encoder": 16, "num_heads_decoder": 4, "depths": [3, 3, 3, 3],
-                    "linear_upsampling": True, "downsampling_rate": 4, "decoder_proj_size": 64, "encoder_proj_sizes": [64, 64, 64, 32],
-                    "attention_code": "torch", "activation_dtype": args.act_dtype or args.dtype}
-    elif args.model.lower().startswith("swin"):
-        settings = {"activation_dtype": args.act_dtype or args.dtype}
-    elif args.model not in ("Identity",):
-        settings = {"compute_dtype": args.dtype, "activation_dtype": args.act_dtype or args.dtype}
+    settings = model_settings(args.model, args.dtype, args.act_dtype, args.hidden)
     torch.manual_seed(1234)  # identical initial weights on every rank
     lm = AutoRegressiveLightning(
         settings, info, None, num_input_steps=1, num_pred_steps_train=T, num_pred_steps_val_test=T, batch_size=B,

@@ -230,7 +230,8 @@ def _load_tuned_gemms():
         # and a stray tunableop_results*.csv in the working directory is not picked up by a file-name default
         tunable.enable(True)
         tunable.tuning_enable(False)
-        tunable.write_file_on_exit(False)
+        if hasattr(tunable, "write_file_on_exit"):
+            tunable.write_file_on_exit(False)
         ok = tunable.read_file(path)
         if ok is False:   # validator lines of the file (torch / ROCm / hipBLASLt / GPU) do not match this stack
             import warnings

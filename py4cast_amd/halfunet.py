@@ -467,7 +467,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         if any(self.padding_for(batch.inputs.tensor.shape[2], batch.inputs.tensor.shape[3])):
             return None   # auto-padded grids take the generic per-step path (forward pads and crops around the plan)
         members = getattr(lm.loss, "losses", [])
-        if len(members) != 1 or not isinstance(members[0][0], WeightedLoss):
+        if len(members) != 1 or not isinstance(members[0][0], WeightedLoss) or not members[0][0].fused_capable:
             return None
         wl, wl_weight = members[0]
         weights = wl.weights(tuple(batch.outputs.feature_names), batch.inputs.tensor.device)

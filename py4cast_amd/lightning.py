@@ -404,7 +404,7 @@ class AutoRegressiveLightning(_Base):
         # buffer -- no separate loss passes over the stacked prediction, no torch.stack copy (lightning.py:599-660,816).
         members = getattr(self.loss, "losses", [])
         fuse = (not inference and not ds and num_inter_steps == 1 and len(members) == 1
-                and isinstance(members[0][0], WeightedLoss) and getattr(self, "use_fused_step", True))
+                and isinstance(members[0][0], WeightedLoss) and members[0][0].fused_capable and getattr(self, "use_fused_step", True))
         if fuse:
             wl, wl_weight = members[0]
             f_weights = wl.weights(tuple(batch.outputs.feature_names), device)

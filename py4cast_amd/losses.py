@@ -119,14 +119,20 @@ class Py4CastLoss(ABC):
             raise NameError(f"Loss: {loss} is not defined")
         self.loss_name = loss
         reduction = kwargs.get("reduction", "mean")
-        if loss in SUPPORTED_TORCH_LOSSES and reduction != "none":
+        if hasattr(torch.nn, loss) and reduction != "none":
             # the reference would broadcast a scalar through the weighted sums; py4cast's yaml
             # always sets "none" (halfunet.yaml:3-8).  Refuse rather than silently differ.
             raise ValueError(f'{type(self).__name__}: reduction must be "none" (got {reduction!r})')
 
     @property
     def kind(self) -> int:
+        """Kernel code of the loss (MSELoss / L1Loss: the fused HIP path); other torch losses take the generic torch-op path and the
+        fused rollout asks `fused_capable` first."""
         return ops.loss_kind_code(self.loss_name)
+
+    @property
+    def fused_capable(self) -> bool:
+        return self.loss_name in SUPPORTED_TORCH_LOSSES
 
     @abstractmethod
     def prepare(self, lm, interior_mask: torch.Tensor, dataset_info) -> None:
@@ -184,6 +190,8 @@ class WeightedLoss(Py4CastLoss):
 
     def forward(self, prediction: NamedTensor, target: NamedTensor, mask, reduce_spatial_dim: bool = True,
                 masked_count: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.loss_name not in SUPPORTED_TORCH_LOSSES:
+            return self._forward_generic(prediction, target, mask, reduce_spatial_dim)
         spec, tgt = _mask_spec(mask, target)
         weights = self.weights(tuple(prediction.feature_names), prediction.device)
         if not reduce_spatial_dim:
@@ -191,6 +199,32 @@ class WeightedLoss(Py4CastLoss):
         interior = self._interior_flat(self.lm, prediction.device)
         return ops.weighted_loss(prediction.tensor, tgt, spec, weights, interior, self.num_interior, self.kind,
                                  count=masked_count)
+
+
+    def _forward_generic(self, prediction, target, mask, reduce_spatial_dim):
+        """Any other element-wise ``torch.nn`` loss with ``reduction="none"`` (SmoothL1Loss, HuberLoss, ...; losses.py:25-31 accepts
+        every name torch.nn has): the reference's op sequence (losses.py:143-169) on the device with torch ops -- unfused, differentiable
+        through autograd; the HIP kernels implement the two losses the shipped configurations use."""
+        m, tgt = _dense_mask(mask, target)
+        torch_loss = self.loss(prediction.tensor * m, tgt * m)
+        weights = self.weights(tuple(prediction.feature_names), prediction.device)
+        weighted = torch.sum(torch_loss * weights, dim=-1)
+        if not reduce_spatial_dim:
+            return weighted
+        union = torch.any(m.bool() if m.dtype != torch.bool else m, dim=(0, 1, m.dim() - 1))
+        interior = getattr(self.lm, "interior_mask_s").to(weighted.device)
+        spatial = tuple(range(2, weighted.dim()))
+        return torch.sum(weighted * interior.reshape(weighted.shape[2:]), dim=spatial) / (self.num_interior - (~union).sum())
+
+
+def _dense_mask(mask, target: NamedTensor):
+    """(mask tensor broadcastable against the target, target tensor) for the torch-op paths: the markers are materialised."""
+    if isinstance(mask, NanMask):
+        raw = mask.raw_target
+        return ~torch.isnan(raw), torch.nan_to_num(raw)
+    if mask is None or isinstance(mask, OnesMask):
+        return torch.ones_like(target.tensor, dtype=torch.bool), target.tensor
+    return mask, target.tensor
 
 
 class ScaledLoss(Py4CastLoss):
@@ -204,6 +238,14 @@ class ScaledLoss(Py4CastLoss):
         self.lm = lm
 
     def forward(self, prediction: NamedTensor, target: NamedTensor, mask) -> torch.Tensor:
+        if self.loss_name not in SUPPORTED_TORCH_LOSSES:   # generic torch-op path, losses.py:195-210 (no sqrt: that is MSELoss only)
+            m, tgt = _dense_mask(mask, target)
+            torch_loss = self.loss(prediction.tensor * m, tgt * m)
+            union = torch.any(m.bool() if m.dtype != torch.bool else m, dim=(0, 1, m.dim() - 1))
+            interior = getattr(self.lm, "interior_mask").to(torch_loss.device)
+            spatial = tuple(range(2, torch_loss.dim() - 1))
+            mean_loss = torch.sum(torch_loss * interior.reshape(torch_loss.shape[2:-1] + (1,)), dim=spatial) / (self.num_interior - (~union).sum())
+            return mean_loss * self.weights(tuple(prediction.feature_names), prediction.device)
         spec, tgt = _mask_spec(mask, target)
         std = self.weights(tuple(prediction.feature_names), prediction.device)
         interior = self._interior_flat(self.lm, prediction.device)
