@@ -1626,11 +1626,13 @@ constexpr int NI = (LH * LW * 8 + 255) / 256, ND = TH * BTW * 8 / 256;   // 7 + 
 constexpr int TOT_IN = LH * LW * 8;
 }  // namespace wgws
 
-template <int MODE>
+// NB: `dout` holds dA and the kernel forms dY = alpha * (dA where the forward ReLU was alive) + beta * y + delta while the staging waves load it
+// (kernels.hpp: NormBwdCoef -- pass 2 of the normalisation backward without a launch or a dY map of its own).
+template <int MODE, bool NB>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     conv3x3_wgrad_bf16_ws_kernel(const __bf16* __restrict__ in, const float* __restrict__ in_scale,
                                  const float* __restrict__ in_shift, const __bf16* __restrict__ dout,
-                                 float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip) {
+                                 float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip, NormBwdCoef nb) {
     using namespace wgws;
     constexpr int NTAPS = 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1681,7 +1683,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             gd[it] = (((pix >> 5) * W + (pix & 31)) * 64 + 8 * c8) * 2;
             ld[it] = INB + pix * ROWD + 16 * c8;
         }
-        struct Img { u32x4 a[NI]; u32x4 d[ND]; };
+        struct Img { u32x4 a[NI]; u32x4 d[ND]; u32x4 y[NB ? ND : 1]; };
         Img ta, tb;
         Cur lc = cur_init(), sc_ = cur_init();
         // same number of memory operations on every path (see conv3x3_bf16_ring_kernel): exact s_waitcnt counts
@@ -1691,6 +1693,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             cur_next(lc);
             const __amdgpu_buffer_rsrc_t rsi = make_rsrc(inb + (int64_t)b * H * W * in_cs, (unsigned)(((int64_t)H * W * in_cs - ci_off) * 2));
             const __amdgpu_buffer_rsrc_t rsd = make_rsrc(dout + (int64_t)b * H * W * 64, (unsigned)((int64_t)H * W * 64 * 2));
+            const __amdgpu_buffer_rsrc_t rsy = make_rsrc((NB ? reinterpret_cast<const __bf16*>(nb.y) : dout) + (int64_t)b * H * W * 64,
+                                                         (unsigned)((int64_t)H * W * 64 * 2));
             const int gy0 = y0 - 1, gx0 = x0 - 1;
             if (live && gy0 >= 0 && y0 + TH + 1 <= H && gx0 >= 0 && x0 + BTW + 1 <= W) {
                 const int so = (gy0 * W + gx0) * in_cs * 2, sd = (y0 * W + x0) * 64 * 2;
@@ -1699,6 +1703,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     im.a[it] = __builtin_amdgcn_raw_buffer_load_b128(rsi, (ltid + it * 256 < TOT_IN) ? gi[it] : OOB, so, 0);
 #pragma unroll
                 for (int it = 0; it < ND; ++it) im.d[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, gd[it], sd, 0);
+                if (NB) {
+#pragma unroll
+                    for (int it = 0; it < ND; ++it) im.y[it] = __builtin_amdgcn_raw_buffer_load_b128(rsy, gd[it], sd, 0);
+                }
             } else {
 #pragma unroll
                 for (int it = 0; it < NI; ++it) {
@@ -1711,6 +1719,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const int pix = (ltid + it * 256) >> 3;
                     const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
                     im.d[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, (live & (gy < H) & (gx < W)) ? ((gy * W + gx) * 64 + 8 * c8) * 2 : OOB, 0, 0);
+                    if (NB) im.y[it] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (live & (gy < H) & (gx < W)) ? ((gy * W + gx) * 64 + 8 * c8) * 2 : OOB, 0, 0);
                 }
             }
         };
@@ -1718,10 +1727,29 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int k = 0; k < 4; ++k) sc[k] = sh[k] = f32x2{0.f, 0.f};
         int sc_b = -1;
+        f32x2 nal[4], nbe[4], nde[4], nsc[4], nsh[4];   // NB: alpha, beta, delta, and the forward scale / shift (ReLU mask) of this lane's 8 gradient channels, current sample
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nal[k] = nbe[k] = nde[k] = nsc[k] = nsh[k] = f32x2{0.f, 0.f};
+        int nb_b = -1;
         auto store = [&](const Img& im, char* buf) __attribute__((always_inline)) {
             const int t = sc_.t, b = sc_.b, y0 = sc_.ty * TH, x0 = sc_.tx * BTW;
             cur_next(sc_);
             if (t >= t_end || ((P4C_EXP & 1) && t > t_begin + 1)) return;
+            if (NB && b != nb_b) {   // (a workgroup's tiles change sample a few times per launch at most)
+                nb_b = b;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ch = 8 * c8 + 2 * k;
+                    const f32x2 ga = *reinterpret_cast<const f32x2*>(nb.gamma + ch), rs = *reinterpret_cast<const f32x2*>(nb.rstd + b * 64 + ch);
+                    const f32x2 mu = *reinterpret_cast<const f32x2*>(nb.mean + b * 64 + ch);
+                    const f32x2 q1 = *reinterpret_cast<const f32x2*>(nb.k1 + b * 64 + ch), q2 = *reinterpret_cast<const f32x2*>(nb.k2 + b * 64 + ch);
+                    nsc[k] = *reinterpret_cast<const f32x2*>(nb.scale + b * 64 + ch);
+                    nsh[k] = *reinterpret_cast<const f32x2*>(nb.shift + b * 64 + ch);
+                    nal[k] = rs * ga;
+                    nbe[k] = -(rs * rs) * q2;
+                    nde[k] = rs * rs * q2 * mu - rs * q1;
+                }
+            }
             if (MODE >= 2 && b != sc_b) {
                 sc_b = b;
 #pragma unroll
@@ -1747,7 +1775,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (ltid + it * 256 < TOT_IN) *reinterpret_cast<u32x4*>(buf + li[it]) = o;
             }
 #pragma unroll
-            for (int it = 0; it < ND; ++it) *reinterpret_cast<u32x4*>(buf + ld[it]) = im.d[it];
+            for (int it = 0; it < ND; ++it) {
+                u32x4 o = im.d[it];
+                if (NB) {
+                    // (pixels of the tile outside the image: g and y load as zeros and dY would be delta -- they must stay zero)
+                    const int pix = (ltid + it * 256) >> 3;
+                    const unsigned int keep = ((y0 + (pix >> 5) < H) & (x0 + (pix & 31) < W)) ? 0xffffffffu : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned int g2 = o[k], y2 = im.y[it][k];
+                        const float ylo = __builtin_bit_cast(float, y2 << 16), yhi = __builtin_bit_cast(float, y2 & 0xffff0000u);
+                        const float glo = __builtin_fmaf(ylo, nsc[k].x, nsh[k].x) > 0.f ? __builtin_bit_cast(float, g2 << 16) : 0.f;
+                        const float ghi = __builtin_fmaf(yhi, nsc[k].y, nsh[k].y) > 0.f ? __builtin_bit_cast(float, g2 & 0xffff0000u) : 0.f;
+                        const float lo = __builtin_fmaf(nal[k].x, glo, __builtin_fmaf(nbe[k].x, ylo, nde[k].x));
+                        const float hi = __builtin_fmaf(nal[k].y, ghi, __builtin_fmaf(nbe[k].y, yhi, nde[k].y));
+                        const f32x2 v2 = {lo, hi};
+                        o[k] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v2, bf16x2)) & keep;
+                    }
+                }
+                *reinterpret_cast<u32x4*>(buf + ld[it]) = o;
+            }
         };
 
         load(ta);
@@ -1850,29 +1897,32 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
 }
 
-template <int MODE>
+template <int MODE, bool NB>
 static int launch_wgrad_ws_mode(const __bf16* in, const float* in_scale, const float* in_shift, const __bf16* dout, float* partial,
-                                int G, int B, int H, int W, int in_cs, int ci_off, int part_cip, hipStream_t stream) {
-    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_wgrad_bf16_ws_kernel<MODE>, wgws::SMEM));
-    hipLaunchKernelGGL(conv3x3_wgrad_bf16_ws_kernel<MODE>, dim3(G), dim3(512), wgws::SMEM, stream, in, in_scale, in_shift, dout,
-                       partial, B, H, W, in_cs, ci_off, part_cip);
+                                int G, int B, int H, int W, int in_cs, int ci_off, int part_cip, hipStream_t stream, const NormBwdCoef& nb) {
+    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_wgrad_bf16_ws_kernel<MODE, NB>, wgws::SMEM));
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_ws_kernel<MODE, NB>), dim3(G), dim3(512), wgws::SMEM, stream, in, in_scale, in_shift, dout,
+                       partial, B, H, W, in_cs, ci_off, part_cip, nb);
     return P4C_OK;
 }
 
 static int launch_conv3x3_wgrad_bf16_ws(const __bf16* in, const float* in_scale, const float* in_shift, int in_relu,
                                         const __bf16* dout, float* partial, int G, int B, int H, int W, int in_cs, int ci_off,
-                                        int part_cip, hipStream_t stream) {
+                                        int part_cip, hipStream_t stream, const NormBwdCoef* nbp = nullptr) {
     const int tiles = ((H + 3) / 4) * ((W + BTW - 1) / BTW) * B;
     if (tiles < G) G = tiles;
     const int tag = (in_cs == 64) ? P4C_PROF_WGRAD3X3_C64 : 0;
     if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
     int rc;
+    const NormBwdCoef nb = nbp ? *nbp : NormBwdCoef{};
+#define P4C_WG(M)                                                                                                                  \
+    (nbp ? launch_wgrad_ws_mode<M, true>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb)   \
+         : launch_wgrad_ws_mode<M, false>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb))
     if (in_scale)
-        rc = in_relu ? launch_wgrad_ws_mode<2>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream)
-                     : launch_wgrad_ws_mode<3>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream);
+        rc = in_relu ? P4C_WG(2) : P4C_WG(3);
     else
-        rc = in_relu ? launch_wgrad_ws_mode<1>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream)
-                     : launch_wgrad_ws_mode<0>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream);
+        rc = in_relu ? P4C_WG(1) : P4C_WG(0);
+#undef P4C_WG
     if (tag) prof_end(tag, stream);
     if (rc != P4C_OK) return rc;
     P4C_CHECK_LAUNCH("conv3x3_wgrad_bf16_ws");
@@ -1970,10 +2020,11 @@ bool conv_bf16_bwd_stats_ok(int storage, int B, int H, int W) {
 
 int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
-                  int m_blocks, hipStream_t stream, const BatchFin* fin, const RingBwdStats* bst, int* nblk_out) {
+                  int m_blocks, hipStream_t stream, const BatchFin* fin, const RingBwdStats* bst, int* nblk_out, const NormBwdCoef* nb) {
     if (conv_bf16_is_rows(storage, CI, ks, m_blocks, out_cs, B, H, W))
         return launch_conv3x3_bf16_rows(in, wp, ks, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, stream, fin, bst,
-                                        nblk_out);
+                                        nblk_out, nb);
+    if (nb) return fail(P4C_ERR_INVALID, "conv_fwd_bf16: NormBwdCoef needs the row kernel");
     if (is_tile_ring(storage, CI, ks, m_blocks, out_cs, B, H, W))
         return launch_conv3x3_bf16_ring((const __bf16*)in, (const __bf16*)wp, in_scale, in_shift, in_relu, (__bf16*)out, out_cs,
                                         stat_partial, B, H, W, stream, fin, bst, nblk_out);
@@ -1991,7 +2042,7 @@ int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo
 template <typename T>
 static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                              const T* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
-                             hipStream_t stream) {
+                             hipStream_t stream, const NormBwdCoef* nb) {
     if (diag_skip(32)) return P4C_OK;
     if (CI % 32 != 0 || CI <= 0 || CI > 256) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16: unsupported CI=%d", CI);
     if (ks != 1 && ks != 3) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16: unsupported ks=%d", ks);
@@ -2000,9 +2051,11 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
     for (int off = 0; off < CI;) {
         const int chunk = (CI - off >= 64) ? 64 : 32;
         int rc;
-        if (chunk == 64 && ks == 3 && std::is_same<T, __bf16>::value && B <= wgws::MAXB && getenv("P4C_NO_WGWS") == nullptr)
+        const bool ws_ok = chunk == 64 && ks == 3 && std::is_same<T, __bf16>::value && B <= wgws::MAXB && getenv("P4C_NO_WGWS") == nullptr;
+        if (nb && !ws_ok) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef needs the role-split 3x3 kernel (64-channel chunk, bf16)");
+        if (ws_ok)
             rc = launch_conv3x3_wgrad_bf16_ws((const __bf16*)in, in_scale, in_shift, in_relu, (const __bf16*)dout, partial, G, B, H, W,
-                                              CI, off, CI, stream);
+                                              CI, off, CI, stream, nb);
         else if (chunk == 64 && ks == 3)
             rc = launch_conv_wgrad_bf16<T, 64, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         else if (chunk == 32 && ks == 3)
@@ -2021,12 +2074,13 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
 
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                     const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
-                    hipStream_t stream) {
+                    hipStream_t stream, const NormBwdCoef* nb) {
     if (storage == P4C_BF16)
         return conv_wgrad_bf16_t<__bf16>((const __bf16*)in, CI, ks, in_scale, in_shift, in_relu, (const __bf16*)dout, partial, G,
-                                         B, H, W, CO, CIreal, grad, stream);
+                                         B, H, W, CO, CIreal, grad, stream, nb);
+    if (nb) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef needs bf16 storage");
     return conv_wgrad_bf16_t<float>((const float*)in, CI, ks, in_scale, in_shift, in_relu, (const float*)dout, partial, G, B, H,
-                                    W, CO, CIreal, grad, stream);
+                                    W, CO, CIreal, grad, stream, nullptr);
 }
 
 #ifdef P4C_STAMPS

@@ -17,6 +17,7 @@
 //     drains the previous interval's output rows meanwhile; its 9 loads / 9 LDS stores / 8 LDS reads / 8 stores per lane
 //     and interval are the same instruction stream on every trip (out-of-range offsets instead of branches).
 // LDS: input ring 8 rows x 66 px x 144 B = 74.3 KB | output staging 8 rows x 64 px x 128 B = 64 KB.
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "kernels.hpp"
@@ -88,7 +89,8 @@ template <int MF> struct Lay {
 constexpr int OOB = 0x7fffffff;
 
 // relu(v*scale+shift) on the 2 bf16 channels packed in one word (fp32 arithmetic, one rounding), or parts of it.
-// MODE 0: copy, 1: ReLU, 2: scale/shift + ReLU, 3: scale/shift.
+// MODE 0: copy, 1: ReLU, 2: scale/shift + ReLU, 3: scale/shift.  (MODE 4 of the kernel -- pass 2 of a normalisation backward,
+// kernels.hpp: NormBwdCoef -- has two operands: nb2 below.)
 template <int MODE>
 __device__ __forceinline__ unsigned int xform2(unsigned int w, f32x2 sc, f32x2 sh) {
     if (MODE >= 2) {
@@ -103,6 +105,18 @@ __device__ __forceinline__ unsigned int xform2(unsigned int w, f32x2 sc, f32x2 s
         w = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
     }
     return w;
+}
+
+// dY = alpha * g + beta * y + delta with g = dA where the forward ReLU was alive (y * sc + sh > 0), on the 2 channels packed in the
+// words a2 (dA) / y2 (fp32 arithmetic, one rounding to bf16)
+__device__ __forceinline__ unsigned int nb2(unsigned int a2, unsigned int y2, f32x2 al, f32x2 be, f32x2 de, f32x2 sc, f32x2 sh) {
+    const float ylo = __builtin_bit_cast(float, y2 << 16), yhi = __builtin_bit_cast(float, y2 & 0xffff0000u);
+    const float glo = __builtin_fmaf(ylo, sc.x, sh.x) > 0.f ? __builtin_bit_cast(float, a2 << 16) : 0.f;
+    const float ghi = __builtin_fmaf(yhi, sc.y, sh.y) > 0.f ? __builtin_bit_cast(float, a2 & 0xffff0000u) : 0.f;
+    const float lo = __builtin_fmaf(al.x, glo, __builtin_fmaf(be.x, ylo, de.x));
+    const float hi = __builtin_fmaf(al.y, ghi, __builtin_fmaf(be.y, yhi, de.y));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
 }
 
 // raw buffer descriptor over [base, base+bytes): loads beyond `bytes` return 0 and stores are dropped
@@ -237,12 +251,43 @@ __device__ __forceinline__ void conv_row16(const bf16x8 (&A)[9][2][2], Acc16& P,
     }
 }
 
+// Every argument of the kernel in ONE by-value struct.  The fields of `fin` (in-kernel BatchNorm finalize) and bst.rstd are needed
+// only after the row loop; left to the compiler they are loaded from the kernel-argument segment at entry and stay in ~30 scalar
+// registers for the whole kernel -- with four buffer descriptors and the loop state that overflowed the scalar file, the spilled
+// scalars took vector-register lanes and the loader spilled to scratch (.sgpr_spill_count 54-78).  late_arg() loads a field from the
+// argument segment at the point of use (the pointer is made opaque there, so the load cannot be hoisted).
+struct RowsArgs {
+    const __bf16* in; const __bf16* wp; const float* in_scale; const float* in_shift; __bf16* out; float* stat_partial;
+    int out_cs, H, W, rows_lo, rows_rem, fin_on;
+    RingBwdStats bst;
+    NormBwdCoef nb;
+    BatchFin fin;
+};
+template <typename T>
+__device__ __forceinline__ T late_arg(size_t offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *reinterpret_cast<const T*>(ka + offset);
+#else
+    (void)offset;
+    return T{};
+#endif
+}
+
 template <int MODE, bool BST, int MF, int KS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-    conv3x3_bf16_rows_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wp, const float* __restrict__ in_scale,
-                             const float* __restrict__ in_shift, __bf16* __restrict__ out, int out_cs,
-                             float* __restrict__ stat_partial, int H, int W, int rows_lo, int rows_rem, BatchFin fin, RingBwdStats bst) {
+    conv3x3_bf16_rows_kernel(RowsArgs args) {
     using namespace rows;
+    const __bf16* __restrict__ in = args.in;
+    const __bf16* __restrict__ wp = args.wp;
+    const float* __restrict__ in_scale = args.in_scale;
+    const float* __restrict__ in_shift = args.in_shift;
+    __bf16* __restrict__ out = args.out;
+    float* __restrict__ stat_partial = args.stat_partial;
+    const int out_cs = args.out_cs, H = args.H, W = args.W, rows_lo = args.rows_lo, rows_rem = args.rows_rem;
+    const RingBwdStats& bst = args.bst;   // (scale / shift / mean / y: read during the set-up; rstd late)
+    const NormBwdCoef& nb = args.nb;
     typedef Lay<MF> LY;
     constexpr int PIXB = LY::PIXB, RROW = LY::RROW, RINGB = LY::RINGB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,17 +344,30 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             sofs[j] = row * SROW + col * 128 + ((c8 ^ ((col >> 1) & 7)) << 4);
         }
         // normalisation of this lane's 8 channels (one sample per workgroup)
-        f32x2 sc[4], sh[4];
+        f32x2 sc[4], sh[4], al[4], be[4], dl[4];   // scale, shift of the producing norm (MODE 2 / 3 / 4);  MODE 4: alpha, beta, delta of NormBwdCoef
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            sc[k] = sh[k] = f32x2{0.f, 0.f};
-            if (MODE >= 2) {
+            sc[k] = sh[k] = al[k] = be[k] = dl[k] = f32x2{0.f, 0.f};
+            if (MODE == 2 || MODE == 3) {
                 sc[k] = *reinterpret_cast<const f32x2*>(in_scale + b * 64 + 8 * c8 + 2 * k);
                 sh[k] = *reinterpret_cast<const f32x2*>(in_shift + b * 64 + 8 * c8 + 2 * k);
             }
+            if (MODE == 4) {
+                const int ch = 8 * c8 + 2 * k;
+                const f32x2 ga = *reinterpret_cast<const f32x2*>(nb.gamma + ch), rs = *reinterpret_cast<const f32x2*>(nb.rstd + b * 64 + ch);
+                const f32x2 mu = *reinterpret_cast<const f32x2*>(nb.mean + b * 64 + ch);
+                const f32x2 q1 = *reinterpret_cast<const f32x2*>(nb.k1 + b * 64 + ch), q2 = *reinterpret_cast<const f32x2*>(nb.k2 + b * 64 + ch);
+                sc[k] = *reinterpret_cast<const f32x2*>(nb.scale + b * 64 + ch);
+                sh[k] = *reinterpret_cast<const f32x2*>(nb.shift + b * 64 + ch);
+                al[k] = rs * ga;
+                be[k] = -(rs * rs) * q2;
+                dl[k] = rs * rs * q2 * mu - rs * q1;
+            }
         }
         struct Img { u32x4 s[NLD]; };
-        Img ta;
+        Img ta, ty;   // ty: the y rows of the same slots (MODE 4 only)
+        const __amdgpu_buffer_rsrc_t rs_nby = make_rsrc(MODE == 4 ? reinterpret_cast<const __bf16*>(nb.y) + (int64_t)b * H * W * 64 : in,
+                                                        (unsigned int)H * W * 128u);
         auto load = [&](Img& im, int k) __attribute__((always_inline)) {
             const int m0 = 4 * k;
             int nrows = R + 2 - m0;
@@ -322,6 +380,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int it = 0; it < NLD; ++it)
                     im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (lim[it] < nact) ? gofs[it] : OOB, so, 0);
+                if (MODE == 4) {
+#pragma unroll
+                    for (int it = 0; it < NLD; ++it)
+                        ty.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_nby, (lim[it] < nact) ? gofs[it] : OOB, so, 0);
+                }
             } else {
 #pragma unroll
                 for (int it = 0; it < NLD; ++it) {
@@ -329,6 +392,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const int gy = gy0 + rr, gx = gx0 + ((idx - rr * ROWSLOTS) >> 3);
                     const bool ok = (idx < nact) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
                     im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? (gy * W + gx) * 128 + 16 * c8 : OOB, 0, 0);
+                    if (MODE == 4) ty.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_nby, ok ? (gy * W + gx) * 128 + 16 * c8 : OOB, 0, 0);
                 }
             }
         };
@@ -345,7 +409,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int it = 0; it < NLD; ++it) {
                     u32x4 o = im.s[it];
-                    if (MODE != 0) {
+                    if (MODE == 4) {
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) o[k2] = nb2(o[k2], ty.s[it][k2], al[k2], be[k2], dl[k2], sc[k2], sh[k2]);
+                    } else if (MODE != 0) {
 #pragma unroll
                         for (int k2 = 0; k2 < 4; ++k2) o[k2] = xform2<MODE>(o[k2], sc[k2], sh[k2]);
                     }
@@ -360,7 +427,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const unsigned int keep = (((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W)) ? 0xffffffffu : 0u;
                     u32x4 o = im.s[it];
 #pragma unroll
-                    for (int k2 = 0; k2 < 4; ++k2) o[k2] = xform2<MODE>(o[k2], sc[k2], sh[k2]) & keep;
+                    for (int k2 = 0; k2 < 4; ++k2)
+                        o[k2] = (MODE == 4 ? nb2(o[k2], ty.s[it][k2], al[k2], be[k2], dl[k2], sc[k2], sh[k2]) : xform2<MODE>(o[k2], sc[k2], sh[k2])) & keep;
                     if (lim[it] < nact) *reinterpret_cast<u32x4*>(dst + lofs[it]) = o;
                 }
             }
@@ -424,8 +492,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
             if (BST) {
-                // pass 1 of the normalisation backward on the gradient rows just stored (their rounded values, what a separate
-                // pass would read back): g = dA where the forward ReLU was alive, sums of g and of g * (y - mean)
 #pragma unroll
                 for (int j = 0; j < NST; ++j)
 #pragma unroll
@@ -475,7 +541,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         drain(K);
         if (lwv == 0) P4C_STAMP(2);
 
-        if (fin.slots) {
+        if (args.fin_on) {
+            const BatchFin fin = late_arg<BatchFin>(offsetof(RowsArgs, fin));
             // ---- BatchNorm finished in place (kernels.hpp: BatchFin).  The compute waves have left (their last barrier was the
             // one that released the final staged rows), so barriers from here on are among the four loader waves only.
             float* lred = reinterpret_cast<float*>(lring);                     // [4 waves][128], then doubles [8][128]; the ring is dead
@@ -545,6 +612,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             return;
         }
         if (stat_partial) {
+            const float* brstd = BST ? late_arg<const float*>(offsetof(RowsArgs, bst) + offsetof(RingBwdStats, rstd)) : nullptr;
             // one slot per (workgroup, loader wave) of this sample: [2][64] sums
             const int nslot = nstrips * nseg * 4;
             float* dst = stat_partial + ((int64_t)b * nslot + (strip * nseg + seg) * 4 + lwv) * 128;
@@ -554,7 +622,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 u += __shfl_xor(u, 8); v += __shfl_xor(v, 8);
                 u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
                 u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
-                if (BST) v *= bst.rstd[b * 64 + 8 * c8 + q];   // sums of g * (y - mean) -> sums of g * xhat
+                if (BST) v *= brstd[b * 64 + 8 * c8 + q];   // sums of g * (y - mean) -> sums of g * xhat
                 if (lane < 8) { dst[8 * c8 + q] = u; dst[64 + 8 * c8 + q] = v; }
             }
         }
@@ -772,15 +840,15 @@ static int rows_mfma_shape() {   // 32 (default): v_mfma_f32_32x32x16_bf16; P4C_
 template <int MODE, bool BST, int KS>
 int launch_rows_mode(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, __bf16* out, int out_cs,
                      float* stat_partial, int B, int H, int W, int nstrips, int nseg, hipStream_t stream, const BatchFin& fin,
-                     const RingBwdStats& bst) {
-    if (KS == 1 || rows_mfma_shape() == 32) {
+                     const RingBwdStats& bst, const NormBwdCoef& nb = NormBwdCoef{}) {
+    const RowsArgs args{in, wp, in_scale, in_shift, out, stat_partial, out_cs, H, W, H / nseg, H % nseg, fin.slots ? 1 : 0, bst, nb, fin};
+    if (KS == 1 || MODE == 4 || rows_mfma_shape() == 32) {
         P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>, rows::Lay<32>::SMEM));
-        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream,
-                           in, wp, in_scale, in_shift, out, out_cs, stat_partial, H, W, H / nseg, H % nseg, fin, bst);
-    } else if (KS == 3) {
-        P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 16, 3>, rows::Lay<16>::SMEM));
-        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 16, 3>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<16>::SMEM, stream,
-                           in, wp, in_scale, in_shift, out, out_cs, stat_partial, H, W, H / nseg, H % nseg, fin, bst);
+        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream, args);
+    } else if (KS == 3 && MODE != 4) {
+        constexpr int M16 = MODE == 4 ? 0 : MODE;   // (MODE 4 never takes this branch: keeps the instantiation list short)
+        P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<M16, BST, 16, 3>, rows::Lay<16>::SMEM));
+        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<M16, BST, 16, 3>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<16>::SMEM, stream, args);
     }
     return P4C_OK;
 }
@@ -788,7 +856,12 @@ int launch_rows_mode(const __bf16* in, const __bf16* wp, const float* in_scale, 
 template <int KS>
 int launch_rows_ks(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, int in_relu, __bf16* out, int out_cs,
                    float* stat_partial, int B, int H, int W, int nstrips, int nseg, hipStream_t stream, const BatchFin& fin,
-                   const RingBwdStats* bst) {
+                   const RingBwdStats* bst, const NormBwdCoef* nb) {
+    if (nb && KS == 3) {   // the operand is g and y of a normalisation backward: dY is formed while the rows are staged
+        constexpr int M = KS == 3 ? 4 : 0;
+        if (bst) return fail(P4C_ERR_UNSUPPORTED, "conv_bf16_rows: NormBwdCoef and RingBwdStats in one launch exceed the register file");
+        return launch_rows_mode<M, false, KS>(in, wp, nullptr, nullptr, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{}, *nb);
+    }
     if (bst) return launch_rows_mode<0, true, KS>(in, wp, nullptr, nullptr, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, *bst);
     if (in_scale)
         return in_relu ? launch_rows_mode<2, false, KS>(in, wp, in_scale, in_shift, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{})
@@ -832,6 +905,13 @@ bool conv_bf16_is_rows(int storage, int CI, int ks, int m_blocks, int out_cs, in
            (int64_t)H * W * out_cs * 2 < (int64_t)1 << 31 && (int64_t)H * W * 128 < (int64_t)1 << 31;
 }
 
+bool conv_bf16_norm_bwd_fused_ok(int storage, int CI, int B, int H, int W) {
+    const char* e = getenv("P4C_NO_FUSED_APPLY");   // (A/B switch and parity tests)
+    if (e && e[0] == '1') return false;
+    // data gradient on the row kernel, weight gradient on the role-split kernel (one 64-channel chunk, its sample limit)
+    return CI == 64 && B <= 32 && conv_bf16_is_rows(storage, 64, 3, 1, 64, B, H, W);
+}
+
 int conv_rows_stat_slots(int B, int H, int W) {
     int nstrips, nseg;
     conv_rows_geometry(B, H, W, &nstrips, &nseg);
@@ -840,7 +920,7 @@ int conv_rows_stat_slots(int B, int H, int W) {
 
 int launch_conv3x3_bf16_rows(const void* inv, const void* wpv, int ks, const float* in_scale, const float* in_shift, int in_relu,
                              void* outv, int out_cs, float* stat_partial, int B, int H, int W, hipStream_t stream, const BatchFin* finp,
-                             const RingBwdStats* bst, int* nblk_out) {
+                             const RingBwdStats* bst, int* nblk_out, const NormBwdCoef* nb) {
     const __bf16* in = (const __bf16*)inv;
     const __bf16* wp = (const __bf16*)wpv;
     __bf16* out = (__bf16*)outv;
@@ -855,8 +935,9 @@ int launch_conv3x3_bf16_rows(const void* inv, const void* wpv, int ks, const flo
     }
     const int tag = ks == 3 ? P4C_PROF_CONV3X3_C64 : 0;
     if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
-    const int rc = ks == 3 ? launch_rows_ks<3>(in, wp, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, bst)
-                           : launch_rows_ks<1>(in, wp, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, bst);
+    P4C_CHECK_ARG(!nb || (ks == 3 && !in_scale && !in_relu && nb->y), "conv_bf16_rows: NormBwdCoef needs a plain 3x3 launch");
+    const int rc = ks == 3 ? launch_rows_ks<3>(in, wp, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, bst, nb)
+                           : launch_rows_ks<1>(in, wp, in_scale, in_shift, in_relu, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, bst, nullptr);
     if (tag) prof_end(tag, stream);
     if (rc != P4C_OK) return rc;
     P4C_CHECK_LAUNCH("conv_bf16_rows");

@@ -34,7 +34,7 @@ struct Layout {
     // saved workspace: activations (element offsets) then normalisation arrays (float offsets from norm_base bytes)
     int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
     // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
-    int64_t wprep, statp, wgradp, nbwdp, k1, k2, tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
+    int64_t wprep, statp, wgradp, nbwdp, k1i[2][NCONV], k2i[2][NCONV], tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
     int G;  // persistent workgroups of the weight-gradient kernel
 };
 
@@ -55,17 +55,18 @@ inline int prep_w(int compute, const float* w, int CO, int CI, int ks, int tf, i
 }
 inline int conv_fwd(int compute, int storage, const void* in, int CI, const void* wp, int ks, const float* sc, const float* sh,
                     int relu, void* out, int out_cs, float* statp, int B, int H, int W, int mblocks, hipStream_t st,
-                    const BatchFin* fin = nullptr, const RingBwdStats* bst = nullptr, int* nblk_out = nullptr) {
+                    const BatchFin* fin = nullptr, const RingBwdStats* bst = nullptr, int* nblk_out = nullptr,
+                    const NormBwdCoef* nb = nullptr) {
     return compute == P4C_BF16
-               ? conv_fwd_bf16(in, storage, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st, fin, bst, nblk_out)
+               ? conv_fwd_bf16(in, storage, CI, wp, ks, sc, sh, relu, out, out_cs, statp, B, H, W, mblocks, st, fin, bst, nblk_out, nb)
                : conv_fwd_f32((const float*)in, CI, (const float*)wp, ks, sc, sh, relu, nullptr, (float*)out, out_cs, statp, B, H, W,
                               mblocks, st);
 }
 inline int conv_wgrad(int compute, int storage, const void* in, int CI, int ks, const float* sc, const float* sh, int relu,
                       const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
-                      hipStream_t st) {
+                      hipStream_t st, const NormBwdCoef* nb = nullptr) {
     return compute == P4C_BF16
-               ? conv_wgrad_bf16(in, storage, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st)
+               ? conv_wgrad_bf16(in, storage, CI, ks, sc, sh, relu, dout, partial, G, B, H, W, CO, CIreal, grad, st, nb)
                : conv_wgrad_f32((const float*)in, CI, ks, sc, sh, relu, (const float*)dout, partial, G, B, H, W, CO, CIreal, grad, st);
 }
 
@@ -131,8 +132,13 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     }
     L.wgradp = off; off += wgrad_partial_floats(96, 3, L.G);
     L.nbwdp = off; off += (int64_t)d.B * NORM_BWD_MAX_BLOCKS * 128;
-    L.k1 = off; off += (int64_t)d.B * NF;
-    L.k2 = off; off += (int64_t)d.B * NF;
+    // k1 / k2 of every block's normalisation backward, per gradient-buffer set: the weight-gradient kernels of the side stream read
+    // them (NormBwdCoef) after the main stream has gone on to other blocks -- and, with the deferred join, to the next call
+    for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < NCONV; ++i) {
+            L.k1i[s][i] = off; off += (int64_t)d.B * NF;
+            L.k2i[s][i] = off; off += (int64_t)d.B * NF;
+        }
     L.tickets = off; off += 64;   // ticket counters of the in-kernel finalizes (uint32 words, cleared by the weight preparation)
     L.f_floats = off;
     L.g_base = align256(off * (int64_t)sizeof(float));
@@ -300,23 +306,38 @@ struct SideStream {
 };
 thread_local SideStream g_side;
 
-// backward through [conv i -> norm -> relu] given dA (grad wrt the post-ReLU activation) in `g`:
-//   dY -> its own buffer; grads of gamma/beta/weight accumulated; if `din` != null: din = dL/d(conv input)
-int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, const void* in, const Norm* in_norm, void* din,
+// The dA (gradient wrt the post-ReLU activation) of every conv block lives in the block's own buffer of the current set
+// (Layout::DY): its producer -- the data gradient of the next block, enc_out_bwd, the 1x1 data gradient -- writes it there, the
+// normalisation backward turns it into dY in place (or leaves that to the consumers, below), and the weight gradient reads it from
+// the side stream while the main stream has long moved on.
+inline void* block_grad(const WS& ws, int i) { return ws.g(ws.L.DY[g_side.calls & 1][i]); }
+
+// backward through [conv i -> norm -> relu] given dA in block_grad(i):
+//   grads of gamma/beta/weight accumulated; if `din` != null: din = dL/d(conv input).
+// pre_nblk > 0: the producer of dA took pass 1 of the normalisation backward (partial sums in ws.nbwdp).  Where the consumers can
+// (conv_bf16_norm_bwd_fused_ok, and see `dgrad_takes_pass1`), pass 2 is theirs: no norm_bwd_apply launch, no dY map -- the
+// data-gradient row kernel and the weight-gradient kernel form dY = alpha * g + beta * y + delta while they load dA and y.
+int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* in, const Norm* in_norm, void* din,
                    const float* params, float* grads, int training, hipStream_t st, int pre_nblk = 0, int* next_nblk = nullptr) {
     const Layout& L = ws.L;
     const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
     Norm nm = norm_at(ws, i, d.B);
     const int stats_training = (d.norm == 1) || training;
-    void* dY = ws.g(L.DY[g_side.calls & 1][i]);
-    P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
-                     (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1), ws.f(L.k2),
-                     grads + L.gamma[i], grads + L.beta[i], dY, st, pre_nblk));
+    void* g = block_grad(ws, i);
     const int cip = conv_cin_pad(d, i);
+    // (the data-gradient launch of this block must not also take pass 1 of the next normalisation: both loaders in one kernel
+    // exceed the register file -- so the blocks whose input is a pooled / summed map: conv 10, 2, 4, 6)
+    const bool dgrad_takes_pass1 = din && in_norm && i > 0;
+    const bool nbf = !dgrad_takes_pass1 && d.compute == P4C_BF16 && cip == NF && conv_bf16_norm_bwd_fused_ok(d.dtype, NF, d.B, H, W);
+    P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
+                     (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i]),
+                     grads + L.gamma[i], grads + L.beta[i], nbf ? nullptr : g, st, pre_nblk));
+    const NormBwdCoef nb{ws.act(L.Y[i]), params + L.gamma[i], nm.scale, nm.shift, nm.rstd, nm.mean,
+                         ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i])};
     int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
     const int G = ntiles < L.G ? (int)ntiles : L.G;
-    // the weight gradient needs dY (complete at this point of the main stream) and the saved input: every block has its own dY
-    // buffer, so the launch can be deferred and share its ordering event with the next blocks'
+    // the weight gradient needs dY (complete at this point of the main stream) and the saved input: every block has its own
+    // gradient buffer, so the launch can be deferred and share its ordering event with the next blocks'
     const int compute = d.compute, dtype = d.dtype, Bn = d.B, cin = conv_cin(d, i);
     const float* isc = in_norm ? in_norm->scale : nullptr;
     const float* ish = in_norm ? in_norm->shift : nullptr;
@@ -324,7 +345,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
     float* wpart = ws.f(L.wgradp);
     float* gw = grads + L.w[i];
     auto job = [=](hipStream_t s) {
-        return conv_wgrad(compute, dtype, in, cip, 3, isc, ish, irelu, dY, wpart, G, Bn, H, W, NF, cin, gw, s);
+        return conv_wgrad(compute, dtype, in, cip, 3, isc, ish, irelu, g, wpart, G, Bn, H, W, NF, cin, gw, s, nbf ? &nb : nullptr);
     };
     if (g_side.enabled) {
         g_side.pending.push_back(job);
@@ -340,18 +361,15 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, void* g, con
     if (next_nblk) *next_nblk = 0;
     if (din) {
         // the input of this convolution is relu(norm(Y[i-1])): its data gradient IS the dA of layer i-1's normalisation backward,
-        // whose pass 1 (sums of g and g * xhat) the ring kernel takes while it stores the gradient tile
+        // whose pass 1 (sums of g and g * xhat) the ring / row kernel takes while it stores the gradient rows
         const char* fe = getenv("P4C_NO_FUSED_REDUCE");   // (read per call: the parity test switches it)
         const bool fuse_off = fe && fe[0] == '1';
         const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 &&
                           conv_bf16_bwd_stats_ok(d.dtype, d.B, H, W);
-        if (fuse) {
-            const RingBwdStats bst{in, in_norm->scale, in_norm->shift, in_norm->mean, in_norm->rstd};
-            P4C_TRY(conv_fwd(d.compute, d.dtype, dY, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, ws.f(L.nbwdp), d.B, H, W,
-                             1, st, nullptr, &bst, next_nblk));
-        } else {
-            P4C_TRY(conv_fwd(d.compute, d.dtype, dY, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, nullptr, d.B, H, W, 1, st));
-        }
+        const RingBwdStats bst{in, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
+                               in_norm ? in_norm->mean : nullptr, in_norm ? in_norm->rstd : nullptr};
+        P4C_TRY(conv_fwd(d.compute, d.dtype, g, NF, wslot(ws, NCONV + i), 3, nullptr, nullptr, 0, din, 64, fuse ? ws.f(L.nbwdp) : nullptr,
+                         d.B, H, W, 1, st, nullptr, fuse ? &bst : nullptr, fuse ? next_nblk : nullptr, nbf ? &nb : nullptr));
     }
     return P4C_OK;
 }
@@ -496,17 +514,18 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
                             conv_bf16_bwd_stats_ok(d.dtype, d.B, d.H, d.W);
         if (fuse11) {
             const RingBwdStats bst{ws.act(L.Y[11]), nd2.scale, nd2.shift, nd2.mean, nd2.rstd};
-            P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, G0, NF, ws.f(L.nbwdp), d.B, d.H,
-                             d.W, 1, st, nullptr, &bst, &pre11));
+            P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, block_grad(ws, 11), NF,
+                             ws.f(L.nbwdp), d.B, d.H, d.W, 1, st, nullptr, &bst, &pre11));
         } else {
-            P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, G0, NF, nullptr, d.B, d.H, d.W, 1, st));
+            P4C_TRY(conv_fwd(d.compute, d.dtype, dy, NF, wslot(ws, 2 * NCONV + 1), 1, nullptr, nullptr, 0, block_grad(ws, 11), NF, nullptr,
+                             d.B, d.H, d.W, 1, st));
         }
     }
-    // ---- decoder
+    // ---- decoder (every block's dA goes to that block's own buffer: block_grad)
     Norm nd1 = norm_at(ws, 10, d.B);
     int nxt = 0;
-    P4C_TRY(conv_block_bwd(d, ws, 11, G0, ws.act(L.Y[10]), &nd1, G1, params, grads, training, st, pre11, &nxt));
-    P4C_TRY(conv_block_bwd(d, ws, 10, G1, ws.act(L.S), nullptr, G0, params, grads, training, st, nxt));
+    P4C_TRY(conv_block_bwd(d, ws, 11, ws.act(L.Y[10]), &nd1, block_grad(ws, 10), params, grads, training, st, pre11, &nxt));
+    P4C_TRY(conv_block_bwd(d, ws, 10, ws.act(L.S), nullptr, G0, params, grads, training, st, nxt));
     // G0 = dS, kept until the last level
 
     // ---- encoder levels, deepest first
@@ -530,21 +549,21 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         int pre = 0;
         float* part = fuse ? ws.f(L.nbwdp) : nullptr;
         if (k > 0) {
-            P4C_TRY(enc_out_bwd(d.dtype, tx[k - 1], d.H, 1 << k, nullptr, dP, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st,
-                                n2.mean, n2.rstd, part, &pre));
+            P4C_TRY(enc_out_bwd(d.dtype, tx[k - 1], d.H, 1 << k, nullptr, dP, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, Hk, Wk,
+                                block_grad(ws, 2 * k + 1), st, n2.mean, n2.rstd, part, &pre));
         } else {
-            P4C_TRY(enc_out_bwd(d.dtype, nullptr, d.H, 1, G0, dP, ws.act(L.Y[1]), n2.scale, n2.shift, d.B, Hk, Wk, b, st, n2.mean,
-                                n2.rstd, part, &pre));
+            P4C_TRY(enc_out_bwd(d.dtype, nullptr, d.H, 1, G0, dP, ws.act(L.Y[1]), n2.scale, n2.shift, d.B, Hk, Wk, block_grad(ws, 1), st,
+                                n2.mean, n2.rstd, part, &pre));
         }
-        // conv2 of the block: input = relu(norm1(Y_k1))
+        // conv2 of the block: input = relu(norm1(Y_k1)); its data gradient is conv1's dA
         int nxt1 = 0;
-        P4C_TRY(conv_block_bwd(d, ws, 2 * k + 1, b, ws.act(L.Y[2 * k]), &n1, a, params, grads, training, st, pre, &nxt1));
-        // conv1 of the block: input = P_k (k>0) or x
+        P4C_TRY(conv_block_bwd(d, ws, 2 * k + 1, ws.act(L.Y[2 * k]), &n1, block_grad(ws, 2 * k), params, grads, training, st, pre, &nxt1));
+        // conv1 of the block: input = P_k (k>0) or x; its data gradient is dP_k (into the other of the two rotating buffers)
         if (k > 0) {
-            P4C_TRY(conv_block_bwd(d, ws, 2 * k, a, ws.act(L.P[k]), nullptr, b, params, grads, training, st, nxt1));
+            P4C_TRY(conv_block_bwd(d, ws, 2 * k, ws.act(L.P[k]), nullptr, b, params, grads, training, st, nxt1));
             void* t = a; a = b; b = t;  // dP_k now in a
         } else {
-            P4C_TRY(conv_block_bwd(d, ws, 0, a, x, nullptr, d.dx_channels > 0 ? dx : nullptr, params, grads, training, st, nxt1));
+            P4C_TRY(conv_block_bwd(d, ws, 0, x, nullptr, d.dx_channels > 0 ? dx : nullptr, params, grads, training, st, nxt1));
         }
     }
     // join: the caller's stream continues only after every weight gradient of this call has been accumulated -- unless the

@@ -70,10 +70,29 @@ struct RingBwdStats {
     const float* rstd;
 };
 constexpr int RING_BWD_STATS_MAXB = 21;
+// Pass 2 of a normalisation backward applied by the CONSUMER of dY while it loads its operand (round 3: no norm_bwd_apply launch
+// and no dY map for the blocks whose consumers can do this -- the data-gradient launches that do not also take pass 1 of the next
+// normalisation, i.e. the blocks whose input is a pooled / summed map: conv 10, 2, 4, 6).  The operand map holds dA, and
+//   dY = rstd * (gamma * g - k1 - xhat * k2),  g = dA * [y * scale + shift > 0],  xhat = (y - mean) * rstd
+//      = alpha * g + beta * y + delta   per (sample, channel)
+// with alpha = rstd * gamma, beta = -rstd^2 * k2, delta = rstd^2 * k2 * mean - rstd * k1 (k1, k2 from norm_bwd_finalize).
+struct NormBwdCoef {
+    const void* y;            // (B,H,W,64) bf16: the raw forward output of the block; nullptr = operand is dY itself
+    const float* gamma;       // (64)
+    const float* scale;       // (B,64) each: the forward normalisation of the block (ReLU mask)
+    const float* shift;
+    const float* rstd;
+    const float* mean;
+    const float* k1;
+    const float* k2;
+};
 int conv_fwd_bf16(const void* in, int storage, int CI, const void* wp, int ks, const float* in_scale,
                   const float* in_shift, int in_relu, void* out, int out_cs, float* stat_partial, int B, int H, int W,
                   int m_blocks, hipStream_t stream, const BatchFin* fin = nullptr, const RingBwdStats* bst = nullptr,
-                  int* nblk_out = nullptr);
+                  int* nblk_out = nullptr, const NormBwdCoef* nb = nullptr);
+// true when conv_fwd_bf16 / conv_wgrad_bf16 can take their 64-channel gradient operand through NormBwdCoef (row kernel for the data
+// gradient, the role-split weight-gradient kernel)
+bool conv_bf16_norm_bwd_fused_ok(int storage, int CI, int B, int H, int W);
 // true when conv_fwd_bf16 with these arguments runs one of the two role-split 3x3 64->64 kernels (row-streaming
 // conv3x3_bf16_rows, or the older tile ring conv3x3_bf16_ring for narrow maps): the ones that can finish BatchNorm themselves
 bool conv_bf16_is_ring(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W);
@@ -86,10 +105,10 @@ void conv_rows_geometry(int B, int H, int W, int* nstrips, int* nseg);
 int conv_rows_stat_slots(int B, int H, int W);   // statistics slots per sample ([2][64] floats each)
 int launch_conv3x3_bf16_rows(const void* in, const void* wp, int ks, const float* in_scale, const float* in_shift, int in_relu,
                              void* out, int out_cs, float* stat_partial, int B, int H, int W, hipStream_t stream, const BatchFin* fin,
-                             const RingBwdStats* bst, int* nblk_out);
+                             const RingBwdStats* bst, int* nblk_out, const NormBwdCoef* nb = nullptr);
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                     const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
-                    hipStream_t stream);
+                    hipStream_t stream, const NormBwdCoef* nb = nullptr);
 
 // norm_pool.hip
 int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw, int mode, int groups, const float* gamma,

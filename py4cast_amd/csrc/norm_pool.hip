@@ -801,7 +801,7 @@ static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* 
         hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(mode == 0 ? C : groups), dim3(256), 0, stream, partial, nblk, B, hw,
                            mode, groups, training, gamma, dgamma, dbeta, k1, k2);
     P4C_CHECK_LAUNCH("norm_bwd_finalize");
-    if (skip_apply) {
+    if (skip_apply || dY == nullptr) {   // (dY == nullptr: the consumers apply pass 2 while they load dA and y -- NormBwdCoef)
     } else if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_APPLY_V1") == nullptr) {
         int64_t blocks = (hw + 127) / 128;                       // >= 4 pixel rows of 32 per workgroup
         const int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
