@@ -1618,23 +1618,30 @@ __global__ void __launch_bounds__(256, 1)
 // run the K loop of tile t; one LDS-only barrier per tile.  Tiles are 4 x 32 pixels so that two (input + halo, output
 // gradient) images fit: 2 x (6x34 + 4x32) pixels x 192 B = 125 KB.
 namespace wgws {
-constexpr int TH = 4, LH = TH + 2, LW = BTW + 2, ROWA = 192, ROWD = 192;
-constexpr int INB = LH * LW * ROWA, DOB = TH * BTW * ROWD, BUFB = INB + DOB;
+constexpr int TH = 4, ROWA = 192, ROWD = 192;
 constexpr int MAXB = 32;
-constexpr int SMEM = 2 * BUFB + MAXB * 128 * 4;
-constexpr int NI = (LH * LW * 8 + 255) / 256, ND = TH * BTW * 8 / 256;   // 7 + 4 slots of 16 B per lane and tile
-constexpr int TOT_IN = LH * LW * 8;
+// KS = 3: 4 x 32 output pixels + halo;  KS = 1 (the 1x1 output convolution): no halo, one tap
+template <int KS> struct Geo {
+    static constexpr int HALO = KS / 2, NTAPS = KS * KS;
+    static constexpr int LH = TH + 2 * HALO, LW = BTW + 2 * HALO;
+    static constexpr int INB = LH * LW * ROWA, DOB = TH * BTW * ROWD, BUFB = INB + DOB;
+    static constexpr int SMEM = 2 * BUFB + MAXB * 128 * 4;
+    static constexpr int NI = (LH * LW * 8 + 255) / 256, ND = TH * BTW * 8 / 256;   // 7 (4) + 4 slots of 16 B per lane and tile
+    static constexpr int TOT_IN = LH * LW * 8;
+};
 }  // namespace wgws
 
 // NB: `dout` holds dA and the kernel forms dY = alpha * (dA where the forward ReLU was alive) + beta * y + delta while the staging waves load it
 // (kernels.hpp: NormBwdCoef -- pass 2 of the normalisation backward without a launch or a dY map of its own).
-template <int MODE, bool NB>
+template <int MODE, bool NB, int KS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     conv3x3_wgrad_bf16_ws_kernel(const __bf16* __restrict__ in, const float* __restrict__ in_scale,
                                  const float* __restrict__ in_shift, const __bf16* __restrict__ dout,
                                  float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip, NormBwdCoef nb) {
     using namespace wgws;
-    constexpr int NTAPS = 9;
+    using G = Geo<KS>;
+    constexpr int NTAPS = G::NTAPS, HALO = G::HALO, LH = G::LH, LW = G::LW, INB = G::INB, BUFB = G::BUFB, NI = G::NI, ND = G::ND,
+                  TOT_IN = G::TOT_IN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lnorm = reinterpret_cast<float*>(smem + 2 * BUFB);
 
@@ -1695,8 +1702,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const __amdgpu_buffer_rsrc_t rsd = make_rsrc(dout + (int64_t)b * H * W * 64, (unsigned)((int64_t)H * W * 64 * 2));
             const __amdgpu_buffer_rsrc_t rsy = make_rsrc((NB ? reinterpret_cast<const __bf16*>(nb.y) : dout) + (int64_t)b * H * W * 64,
                                                          (unsigned)((int64_t)H * W * 64 * 2));
-            const int gy0 = y0 - 1, gx0 = x0 - 1;
-            if (live && gy0 >= 0 && y0 + TH + 1 <= H && gx0 >= 0 && x0 + BTW + 1 <= W) {
+            const int gy0 = y0 - HALO, gx0 = x0 - HALO;
+            if (live && gy0 >= 0 && y0 + TH + HALO <= H && gx0 >= 0 && x0 + BTW + HALO <= W) {
                 const int so = (gy0 * W + gx0) * in_cs * 2, sd = (y0 * W + x0) * 64 * 2;
 #pragma unroll
                 for (int it = 0; it < NI; ++it)
@@ -1758,8 +1765,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     sh[k] = *reinterpret_cast<const f32x2*>(lnorm + b * 128 + 64 + 8 * c8 + 2 * k);
                 }
             }
-            const int gy0 = y0 - 1, gx0 = x0 - 1;
-            const bool interior = gy0 >= 0 && y0 + TH + 1 <= H && gx0 >= 0 && x0 + BTW + 1 <= W;
+            const int gy0 = y0 - HALO, gx0 = x0 - HALO;
+            const bool interior = gy0 >= 0 && y0 + TH + HALO <= H && gx0 >= 0 && x0 + BTW + HALO <= W;
 #pragma unroll
             for (int it = 0; it < NI; ++it) {
                 u32x4 o = im.a[it];
@@ -1839,14 +1846,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         // its three column-shifted operands are read once (6 transposed reads) and used by up to nine MFMAs, and the four
         // gradient-row operands of a half tile stay in registers: 88 LDS reads per tile for 72 MFMAs instead of 160 (the reads, not
         // the matrix pipe, bounded this phase: 58 cycles per MFMA at 2.2 reads each).
-        struct AOps { s16x4 a[3][2]; };
+        struct AOps { s16x4 a[KS][2]; };
         for (int tile = t_begin; tile < t_end; ++tile) {
             const char* lin = smem + ((tile - t_begin) & 1) * BUFB;
             const char* ldo = lin + INB;
             auto fetch_a = [&](AOps& o, int j, int col0) __attribute__((always_inline)) {
                 const char* ap0 = lin + (j * LW + col0 + 8 * h + tq) * ROWA + a_col;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
+                for (int kx = 0; kx < KS; ++kx) {
                     o.a[kx][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap0 + kx * ROWA));
                     o.a[kx][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ap0 + (kx + 4) * ROWA));
                 }
@@ -1868,16 +1875,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (j + 1 < LH) fetch_a(ao[(j + 1) & 1], j + 1, col0);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
+                    for (int ky = 0; ky < KS; ++ky) {
                         const int rr = j - ky;
                         if (rr < 0 || rr >= TH) continue;
                         union { s16x4 s[2]; bf16x8 v; } ub;
                         ub.s[0] = bo[rr][0]; ub.s[1] = bo[rr][1];
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
+                        for (int kx = 0; kx < KS; ++kx) {
                             union { s16x4 s[2]; bf16x8 v; } u;
                             u.s[0] = ao[j & 1].a[kx][0]; u.s[1] = ao[j & 1].a[kx][1];
-                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ub.v, acc[ky * 3 + kx], 0, 0, 0);
+                            acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ub.v, acc[ky * KS + kx], 0, 0, 0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1897,24 +1904,32 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
 }
 
-template <int MODE, bool NB>
+template <int MODE, bool NB, int KS = 3>
 static int launch_wgrad_ws_mode(const __bf16* in, const float* in_scale, const float* in_shift, const __bf16* dout, float* partial,
                                 int G, int B, int H, int W, int in_cs, int ci_off, int part_cip, hipStream_t stream, const NormBwdCoef& nb) {
-    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_wgrad_bf16_ws_kernel<MODE, NB>, wgws::SMEM));
-    hipLaunchKernelGGL((conv3x3_wgrad_bf16_ws_kernel<MODE, NB>), dim3(G), dim3(512), wgws::SMEM, stream, in, in_scale, in_shift, dout,
-                       partial, B, H, W, in_cs, ci_off, part_cip, nb);
+    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_wgrad_bf16_ws_kernel<MODE, NB, KS>, wgws::Geo<KS>::SMEM));
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_ws_kernel<MODE, NB, KS>), dim3(G), dim3(512), wgws::Geo<KS>::SMEM, stream, in, in_scale,
+                       in_shift, dout, partial, B, H, W, in_cs, ci_off, part_cip, nb);
     return P4C_OK;
 }
 
 static int launch_conv3x3_wgrad_bf16_ws(const __bf16* in, const float* in_scale, const float* in_shift, int in_relu,
                                         const __bf16* dout, float* partial, int G, int B, int H, int W, int in_cs, int ci_off,
-                                        int part_cip, hipStream_t stream, const NormBwdCoef* nbp = nullptr) {
+                                        int part_cip, hipStream_t stream, const NormBwdCoef* nbp = nullptr, int ks = 3) {
     const int tiles = ((H + 3) / 4) * ((W + BTW - 1) / BTW) * B;
     if (tiles < G) G = tiles;
+    const NormBwdCoef nb = nbp ? *nbp : NormBwdCoef{};
+    if (ks == 1) {   // the 1x1 output convolution: same staging, one tap
+        if (nbp) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef is for the 3x3 blocks");
+#define P4C_WG1(M) launch_wgrad_ws_mode<M, false, 1>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb)
+        P4C_TRY(in_scale ? (in_relu ? P4C_WG1(2) : P4C_WG1(3)) : (in_relu ? P4C_WG1(1) : P4C_WG1(0)));
+#undef P4C_WG1
+        P4C_CHECK_LAUNCH("conv1x1_wgrad_bf16_ws");
+        return P4C_OK;
+    }
     const int tag = (in_cs == 64) ? P4C_PROF_WGRAD3X3_C64 : 0;
     if (tag) prof_begin(tag, (int64_t)B * H * W, stream);
     int rc;
-    const NormBwdCoef nb = nbp ? *nbp : NormBwdCoef{};
 #define P4C_WG(M)                                                                                                                  \
     (nbp ? launch_wgrad_ws_mode<M, true>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb)   \
          : launch_wgrad_ws_mode<M, false>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb))
@@ -2051,11 +2066,12 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
     for (int off = 0; off < CI;) {
         const int chunk = (CI - off >= 64) ? 64 : 32;
         int rc;
-        const bool ws_ok = chunk == 64 && ks == 3 && std::is_same<T, __bf16>::value && B <= wgws::MAXB && getenv("P4C_NO_WGWS") == nullptr;
+        const bool ws_ok = chunk == 64 && (ks == 3 || getenv("P4C_NO_WGWS_1X1") == nullptr) && std::is_same<T, __bf16>::value &&
+                           B <= wgws::MAXB && getenv("P4C_NO_WGWS") == nullptr;
         if (nb && !ws_ok) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef needs the role-split 3x3 kernel (64-channel chunk, bf16)");
         if (ws_ok)
             rc = launch_conv3x3_wgrad_bf16_ws((const __bf16*)in, in_scale, in_shift, in_relu, (const __bf16*)dout, partial, G, B, H, W,
-                                              CI, off, CI, stream, nb);
+                                              CI, off, CI, stream, nb, ks);
         else if (chunk == 64 && ks == 3)
             rc = launch_conv_wgrad_bf16<T, 64, 3>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         else if (chunk == 32 && ks == 3)

@@ -340,27 +340,31 @@ __global__ void __launch_bounds__(256, 1)
 }
 
 // grad[co][ci][tap] += sum_slots partial[slot][tap][ci_pad][64]  for ci in [ci_lo, ci_hi), real channels only.
-// One block per (tap, ci): 16 lanes x 4 output channels (16-byte loads) x 16 slot slices, all of a thread's loads
-// independent; fixed summation order (deterministic).
+// One block per (tap, ci, co group): QL lanes x 4 output channels (16-byte loads) x 256/QL slot slices, all of a thread's loads
+// independent; fixed summation order (deterministic).  QL = 16: one block covers the 64 output channels; QL = 4: four blocks do
+// (the 1x1 convolution has 64 (tap, ci) pairs only -- 64 workgroups walking 256 slots each took 41 us at 2 x 512 x 512).
+template <int QL>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int ntaps, int CI_pad,
                                                            int ci_lo, int ci_hi, int CO, int CI, float* __restrict__ grad) {
-    __shared__ float red[16][64];
+    constexpr int NS = 256 / QL, NCO = 4 * QL, NG = 64 / NCO;
+    __shared__ float red[NS][NCO];
     const int nci = ci_hi - ci_lo;
-    const int tap = blockIdx.x / nci, ci = ci_lo + (blockIdx.x - tap * nci);
-    const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int cg = blockIdx.x % NG, rest = blockIdx.x / NG;
+    const int tap = rest / nci, ci = ci_lo + (rest - tap * nci);
+    const int q = threadIdx.x % QL, sl = threadIdx.x / QL;
     const int64_t stride = (int64_t)ntaps * CI_pad * 64;
-    const float* p = partial + ((int64_t)tap * CI_pad + ci) * 64 + 4 * q;
+    const float* p = partial + ((int64_t)tap * CI_pad + ci) * 64 + cg * NCO + 4 * q;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (int g = sl; g < nslots; g += 16) s += *reinterpret_cast<const f32x4*>(p + g * stride);
+    for (int g = sl; g < nslots; g += NS) s += *reinterpret_cast<const f32x4*>(p + g * stride);
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[sl][4 * q + j] = s[j];
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int co = threadIdx.x;
+    if (threadIdx.x < NCO) {
+        const int co = cg * NCO + threadIdx.x;
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][co];
+        for (int k = 0; k < NS; ++k) t += red[k][threadIdx.x];
         if (co < CO && ci < CI) grad[((int64_t)co * CI + ci) * ntaps + tap] += t;
     }
 }
@@ -422,8 +426,13 @@ int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo
                         hipStream_t stream) {
     if (ci_hi > CI) ci_hi = CI;
     if (ci_hi <= ci_lo) return P4C_OK;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ks * ks * (ci_hi - ci_lo)), dim3(256), 0, stream, partial, nslots, ks * ks,
-                       CI_pad, ci_lo, ci_hi, CO, CI, grad);
+    const int pairs = ks * ks * (ci_hi - ci_lo);
+    if (pairs < 256 && nslots >= 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(pairs * 4), dim3(256), 0, stream, partial, nslots, ks * ks, CI_pad, ci_lo,
+                           ci_hi, CO, CI, grad);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(pairs), dim3(256), 0, stream, partial, nslots, ks * ks, CI_pad, ci_lo, ci_hi,
+                           CO, CI, grad);
     P4C_CHECK_LAUNCH("wgrad_reduce");
     return P4C_OK;
 }

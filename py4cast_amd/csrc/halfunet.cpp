@@ -272,7 +272,15 @@ struct SideStream {
         enabled = !(e && e[0] == '0');
         if (const char* n = getenv("P4C_SIDE_EVERY")) { const int v = atoi(n); if (v > 0) every = v; }
         if (!enabled) return P4C_OK;
-        P4C_CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // (A/B switch P4C_SIDE_PRIO: -1 = lowest, 1 = highest queue priority for the weight-gradient stream)
+        const char* pr = getenv("P4C_SIDE_PRIO");
+        if (pr && pr[0] != '0') {
+            int lo = 0, hi = 0;
+            P4C_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            P4C_CHECK_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, atoi(pr) < 0 ? lo : hi));
+        } else {
+            P4C_CHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        }
         return P4C_OK;
     }
     // run the deferred launches on the side stream after everything enqueued on `from` so far (ONE event for all of them)
