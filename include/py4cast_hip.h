@@ -297,6 +297,9 @@ int p4c_conv_stat_tiles(int compute, int storage, int CI, int B, int H, int W);
 /* the same for a given kernel size (1x1 and 3x3 convolutions of one shape may run different kernels);
  * p4c_conv_stat_tiles is the ks = 3 value */
 int p4c_conv_stat_tiles_ks(int compute, int storage, int CI, int ks, int B, int H, int W);
+/* which kernel p4c_conv_fwd launches for a 64-filter convolution of this shape: 2 = row-streaming kernel (csrc/conv_rows.hip),
+ * 1 = tile-ring kernel, 0 = generic tiled kernel.  (bench.py names the roofline kernel with it.) */
+int p4c_conv_kernel_kind(int compute, int storage, int CI, int ks, int B, int H, int W);
 int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_pad, int ks, const float* in_scale, const float* in_shift,
                    int in_relu, const void* dout, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                    p4c_stream_t stream);

@@ -75,6 +75,7 @@ OTHER = {
     "p4c_conv_wgrad_workspace_bytes": ([I, I], c_size_t),
     "p4c_conv_stat_tiles": ([I, I, I, I, I, I], c_int),
     "p4c_conv_stat_tiles_ks": ([I, I, I, I, I, I, I], c_int),
+    "p4c_conv_kernel_kind": ([I, I, I, I, I, I, I], c_int),
     "p4c_halfunet_param_count": ([DP], c_int64),
     "p4c_window_attn_bwd_workspace_bytes": ([I, I, I, I, I], c_size_t),
     "p4c_row_layernorm_bwd_workspace_bytes": ([L, I, I], c_size_t),

@@ -240,6 +240,10 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
 // chain is latency-bound work on the coarse levels that occupies a few CUs: the weight-gradient kernels (+ their
 // reductions) are enqueued on a second stream, ordered after the dY they read by an event, and joined back into the
 // caller's stream at the end of the call.
+// Ordering events between two streams of ONE device: no timing, and no system-scope release on record -- the consumer is a kernel on
+// the same GPU, for which the agent-scope release at the end of every kernel is enough (tools/diagnostics/event_cost.hip: a record
+// costs the main stream 7.2 us with the fence, 4.6 us without).
+constexpr unsigned kOrderFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 struct SideStream {
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> events;
@@ -262,8 +266,8 @@ struct SideStream {
     hipEvent_t dy_read = nullptr;
     int own_events() {
         if (dy_read) return P4C_OK;
-        for (int i = 0; i < 2; ++i) P4C_CHECK_HIP(hipEventCreateWithFlags(&set_done[i], hipEventDisableTiming));
-        P4C_CHECK_HIP(hipEventCreateWithFlags(&dy_read, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) P4C_CHECK_HIP(hipEventCreateWithFlags(&set_done[i], kOrderFlags));
+        P4C_CHECK_HIP(hipEventCreateWithFlags(&dy_read, kOrderFlags));
         return P4C_OK;
     }
     int init() {
@@ -297,7 +301,7 @@ struct SideStream {
                 return fail(P4C_ERR_INVALID, "p4c_halfunet_backward: the caller's %zu ordering events are used up "
                                              "(p4c_set_side_stream: pass at least 8)", events.size());
             hipEvent_t e;
-            P4C_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            P4C_CHECK_HIP(hipEventCreateWithFlags(&e, kOrderFlags));
             events.push_back(e);
         }
         *ev = events[next++];
@@ -621,6 +625,12 @@ extern "C" int p4c_conv_stat_tiles(int compute, int storage, int CI, int B, int 
 
 extern "C" int p4c_conv_stat_tiles_ks(int compute, int storage, int CI, int ks, int B, int H, int W) {
     return stat_tiles(compute, storage, CI, B, H, W, ks);
+}
+
+extern "C" int p4c_conv_kernel_kind(int compute, int storage, int CI, int ks, int B, int H, int W) {
+    if (compute != P4C_BF16) return 0;
+    if (conv_bf16_is_rows(storage, CI, ks, 1, 64, B, H, W)) return 2;
+    return conv_bf16_is_ring(storage, CI, ks, 1, 64, B, H, W) ? 1 : 0;
 }
 
 extern "C" int p4c_conv_fwd(const void* in, int compute, int storage, int CI, const void* wprep, int ks,

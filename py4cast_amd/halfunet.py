@@ -500,7 +500,8 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             # at the bf16 MFMA rate the kernel is HBM-bound: algorithmic bytes = read 64 ch + write 64 ch per pixel
             esz = 2 if self.act_dtype == torch.bfloat16 else 4
             gbs = 2.0 * 64 * esz * units.value / (ms.value * 1e-3) / 1e9
-            kname = "conv3x3_bf16_ring_kernel" if esz == 2 else "conv_fwd_bf16_ws_kernel<f32,64,3>"
+            kind = L.lib().p4c_conv_kernel_kind(L.BF16, L.BF16 if esz == 2 else L.F32, 64, 3, B, H, W)
+            kname = {2: "conv3x3_bf16_rows_kernel", 1: "conv3x3_bf16_ring_kernel"}.get(kind, "conv_fwd_bf16_ws_kernel<f32,64,3>")
             traffic, traffic_source = None, None
             if esz == 2 and (B, H, W) == (2, 512, 512):
                 # HBM bytes per launch of this launch shape from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with
@@ -509,12 +510,13 @@ class HalfUNetMI355X(ModelABC, nn.Module):
                 import os
 
                 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-                for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
                     f = os.path.join(root, "profiles", name)
                     if os.path.exists(f):
-                        traffic = json.load(open(f)).get("conv3x3_bf16_ring_kernel", {}).get("hbm_bytes_per_launch")
-                        traffic_source = f"profiles/{name} (committed rocprofv3 --pmc passes of an earlier run of this command)"
-                        break
+                        traffic = json.load(open(f)).get(kname, {}).get("hbm_bytes_per_launch")
+                        if traffic is not None:
+                            traffic_source = f"profiles/{name} (committed rocprofv3 --pmc passes of an earlier run of this kernel)"
+                            break
             return {"bound": "hbm", "kernel": kname + " (3x3 conv 64->64, forward-plan launches at full resolution)",
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
                     "traffic_source": traffic_source,

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-3 evidence run (one gpurun call): default bench line, accumulate-10 line, 500-step robustness run, rocprofv3 kernel trace of
+# the bench command, PMC passes of the roofline kernel (separate --pmc runs with --kernel-trace only, as gpurun requires).
+# Outputs under gpurun_out/r03/.
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+O=gpurun_out/r03; mkdir -p $O
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+python3 bench.py --accumulate 10 --no-cpu-baseline --no-fp32-flavour --no-larger-batch > $O/bench_accumulate10.json 2>/dev/null
+python3 bench.py --steps 500 --warmup 20 --no-cpu-baseline --no-fp32-flavour --no-larger-batch > $O/bench_500_steps.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/raw -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-flavour --no-larger-batch --hip-graph off > $O/bench_under_rocprof.json 2> $O/trace.err
+db=$(find $O/raw -name "*.db" | head -1)
+python3 tools/diagnostics/rocpd_stats.py $db $O/kernel_stats.csv $O/one_step_trace.csv
+python3 tools/diagnostics/step_timeline.py $db $O/timeline.csv > $O/timeline.txt 2>&1
+rm -rf $O/raw
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  n=$(echo $c | tr ' ' '_')
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$n -- python3 tools/diagnostics/conv_exp.py > $O/pmc_$n.log 2>&1
+done
+find $O -name "*.csv" -size +20M -delete
+python3 tools/diagnostics/pmc_summary.py $O conv3x3_bf16_rows_kernel $O/pmc_traffic.json $O/pmc_rows > $O/pmc_summary.log 2>&1 \
+  && rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_*
+ls -R $O | head -60
