@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: reduce-scatter + sharded AdamW + all-gather instead of all-reduce + full AdamW (auto: above 16 MB of gradients)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange the gradients after the backward instead of inside it")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="library convolutions on their deterministic solvers (torch.backends.cudnn.deterministic): SwinUNetR / UNetRPP "
+                         "steps then reproduce bit for bit (DESIGN.md 7a)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU-baseline budget: iterations are timed until it is spent, at least two")
@@ -333,6 +336,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.deterministic:
+        torch.backends.cudnn.deterministic = True
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
@@ -575,6 +580,7 @@ def main():
                 "setup_steps": args.setup_steps,
                 "accumulate_grad_batches": args.accumulate,
                 "hip_graph": bool(use_graph), "hip_graph_check": graph_note,
+                "deterministic_library_solvers": bool(torch.backends.cudnn.deterministic),
                 "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
                 "device_allocs_in_timed_region": int(device_allocs),
                 "launch_mode_probe": probe,

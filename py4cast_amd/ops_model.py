@@ -111,3 +111,47 @@ def conv_nhwc(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     compute = "bf16" if x.dtype == torch.bfloat16 else "f32"
     y = _ConvNHWC.apply(x.contiguous(), w, compute)
     return y if CO == 64 else y[..., :CO]
+
+
+class _LibraryConv(torch.autograd.Function):
+    """torch's convolution (MIOpen) for the shapes the MFMA kernels do not serve, pinned to the library's DETERMINISTIC solvers in the
+    forward AND in both gradients.  The default solver choice accumulates with atomics whose order changes from run to run; with bf16
+    activations that rounding noise moves LeakyReLU / softmax branches downstream, and two eager SwinUNetR steps on one batch and one
+    set of weights differed by 19-26 % in their parameter gradients (UNetRPP: 20 %) while every native node was bit-identical.  With
+    these few calls pinned the whole training step reproduces bit for bit (tools/diagnostics/determinism_probe.py,
+    profiles/r03_determinism_probe.txt) at the same speed (SwinUNetR 38.6 vs 38.8 ms per step).  The flag is set around the call only
+    -- the host application's own convolutions keep its setting."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, w)
+        ctx.conf = (tuple(stride), tuple(padding), tuple(dilation), int(groups), None if bias is None else list(bias.shape))
+        keep = torch.backends.cudnn.deterministic
+        torch.backends.cudnn.deterministic = True
+        try:
+            return torch.nn.functional.conv2d(x, w, bias, stride, padding, dilation, groups)
+        finally:
+            torch.backends.cudnn.deterministic = keep
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, groups, bias_sizes = ctx.conf
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], bias_sizes is not None and ctx.needs_input_grad[2]]
+        keep = torch.backends.cudnn.deterministic
+        torch.backends.cudnn.deterministic = True
+        try:
+            gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False,
+                                                             [0, 0], groups, mask)
+        finally:
+            torch.backends.cudnn.deterministic = keep
+        return gx, gw, gb, None, None, None, None
+
+
+def library_conv2d(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
+                   groups: int = 1) -> torch.Tensor:
+    """F.conv2d on the library's deterministic solvers (see _LibraryConv); string paddings ('same') are resolved by torch itself."""
+    if isinstance(padding, str) or not x.is_cuda:
+        return torch.nn.functional.conv2d(x, w, bias, stride, padding, dilation, groups)
+    pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+    return _LibraryConv.apply(x, w, bias, pair(stride), pair(padding), pair(dilation), groups)

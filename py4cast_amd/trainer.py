@@ -453,7 +453,9 @@ class GraphedTrainingStep:
             med = float(base[live].median())
             tol = torch.maximum(torch.maximum(10.0 * base, torch.full_like(base, 3.0 * med)), torch.full_like(base, 5e-2))
         else:
-            tol = torch.maximum(10.0 * base, torch.full_like(base, 2e-2))
+            # (a reproducible step -- every model of the registry since the library convolutions are pinned to deterministic solvers,
+            # ops_model.library_conv2d -- replays the SAME kernels on the same data: measured worst relative error 2.4e-7)
+            tol = torch.maximum(10.0 * base, torch.full_like(base, 1e-3))
         bad = (live & ~(got <= tol)).nonzero().flatten().tolist()      # `~(<=)`: NaN counts as bad
         # the loss is far less noisy than per-parameter gradients (it moves in the 6th digit where gradients move by percents);
         # the whole gradient's norm and direction are checked too
@@ -462,9 +464,9 @@ class GraphedTrainingStep:
         spread = float((ref2 - inc_a).double().norm() / max(float(ref2.double().norm()), 1e-300))
         # (a step with a random element -- a mask draw, dropout -- moves its loss as much as its gradients between two eager
         # passes: the loss bound follows the measured spread there, 0.5 % otherwise)
-        loss_tol = (max(5e-3, 3.0 * spread) if noisy else 1e-3) * abs(float(eager_loss)) + 1e-6
+        loss_tol = (max(5e-3, 3.0 * spread) if noisy else 1e-4) * abs(float(eager_loss)) + 1e-6
         loss_ok = bool(torch.isfinite(graph_loss)) and abs(float(graph_loss) - float(eager_loss)) <= loss_tol
-        whole_ok = finite and abs(gn - en) <= max(10.0 * spread, 2e-2) * en and cosv >= 1.0 - max(50.0 * spread * spread, 1e-3)
+        whole_ok = finite and abs(gn - en) <= max(10.0 * spread, 2e-2 if noisy else 1e-3) * en and cosv >= 1.0 - max(50.0 * spread * spread, 1e-3 if noisy else 1e-5)
         if not whole_ok:
             loss_ok = False
         if bad or not finite or not loss_ok:

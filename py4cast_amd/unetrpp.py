@@ -103,6 +103,9 @@ def _conv(m, x):
                 xl = xl.reshape(B, H // k, k, W // k, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // k, W // k, k * k * C)
             w = m.weight.permute(0, 2, 3, 1).reshape(m.weight.shape[0], k * k * C)
             return R.linear_nd(xl, w, m.bias).permute(0, 3, 1, 2)
+    if type(m) is nn.Conv2d and m.padding_mode == "zeros":
+        return OM.library_conv2d(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype), m.stride, m.padding, m.dilation,
+                                 m.groups)
     return m._conv_forward(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
 
 

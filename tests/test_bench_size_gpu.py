@@ -47,18 +47,20 @@ def _step(lm, case):
     return float(loss), grads
 
 
-@pytest.mark.parametrize("model,T,strategy,loss_tol,deterministic", [
-    ("SwinUNetR", 3, "scaled_ar", 2e-2, False),     # BASELINE configuration 3 (library convolutions with atomics: DESIGN.md 7a)
-    ("GraphLam", 3, "scaled_ar", 2e-3, True),       # configuration 4 (GraphLAM: every kernel native, fixed-order reductions)
-    ("HiLAM", 3, "scaled_ar", 2e-3, True),
-    ("HiLAMParallel", 3, "scaled_ar", 2e-3, True),
-    ("UNetRPP", 6, "diff_ar", 2e-2, False),         # configuration 5 (6-step diff_ar; library convolutions)
+@pytest.mark.parametrize("model,T,strategy,loss_tol", [
+    ("SwinUNetR", 3, "scaled_ar", 2e-2),     # BASELINE configuration 3
+    ("GraphLam", 3, "scaled_ar", 2e-3),      # configuration 4 (GraphLAM: every kernel native, fixed-order reductions)
+    ("HiLAM", 3, "scaled_ar", 2e-3),
+    ("HiLAMParallel", 3, "scaled_ar", 2e-3),
+    ("UNetRPP", 6, "diff_ar", 2e-2),         # configuration 5 (6-step diff_ar)
 ])
-def test_bench_workload_of_every_model_family(gpu_device, tmp_path_factory, model, T, strategy, loss_tol, deterministic):
+def test_bench_workload_of_every_model_family(gpu_device, tmp_path_factory, model, T, strategy, loss_tol):
     """The benchmark workload of each widened model: finite prediction of the right shape, forced borders equal to the targets bit
     for bit, finite gradients for every parameter, the bf16 flavour's loss within `loss_tol` of the fp32-activation flavour's, and a
-    rerun of the same step -- bit-identical loss and gradients where every reduction is ours (the GNNs), loss within 1e-5 and
-    gradient direction within 1e-3 where library kernels with atomics take part."""
+    rerun of the same step with BIT-IDENTICAL loss and gradients: every native reduction has a fixed order, and the few library
+    convolutions left in SwinUNetR / UNetRPP are pinned to deterministic solvers (ops_model.library_conv2d) -- so a race or an
+    uninitialised read anywhere in a step of bench size fails this test (round 2: 19 % eager-vs-eager gradient spread, all of it
+    the library's atomics amplified by bf16 branch flips, profiles/r03_determinism_probe.txt)."""
     import bench
 
     torch.cuda.empty_cache()
@@ -79,14 +81,7 @@ def test_bench_workload_of_every_model_family(gpu_device, tmp_path_factory, mode
         assert np.isfinite(loss) and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
         if dt == "bf16":
             loss2, g2 = _step(lm, case)
-            if deterministic:
-                assert loss2 == loss and torch.equal(g2, g), (loss, loss2, float((g2 - g).abs().max()))
-            else:
-                # (library convolutions with split-K atomics: SwinUNetR moves in the 6th digit, UNetRPP's 6-step rollout through
-                # MIOpen's batch norms / wide convolutions in the 5th -- measured 4.5e-5)
-                assert abs(loss2 - loss) <= (2e-4 if model == "UNetRPP" else 1e-5) * abs(loss), (loss, loss2)
-                cos = float(torch.dot(g.double(), g2.double()) / (g.double().norm() * g2.double().norm()))
-                assert cos > 1 - (1e-2 if model == "UNetRPP" else 1e-3), cos
+            assert loss2 == loss and torch.equal(g2, g), (loss, loss2, float((g2 - g).abs().max()))
             del g2
         out[dt] = loss
         del lm, g

@@ -1,6 +1,6 @@
 """Two eager training steps on one batch and one set of weights: where do they differ?  Loss, per-parameter gradients, and the
 first module (forward order) whose output differs / the first (backward order) whose input gradient differs.
-usage: determinism_probe.py MODEL [H W] [dtype]"""
+usage: [HOOKS=1] [DETERMINISTIC=1] determinism_probe.py MODEL [H W] [dtype]"""
 import sys, os, torch
 sys.path.insert(0, ".")
 import bench as Bn
@@ -10,6 +10,11 @@ model = sys.argv[1]
 H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (512, 512)
 dtype = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 device = torch.device("cuda", 0)
+if os.environ.get("DETERMINISTIC"):   # 1: library convolutions on their deterministic solvers; 2: also torch ops on their deterministic paths
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+    if os.environ["DETERMINISTIC"] == "2":
+        torch.use_deterministic_algorithms(True, warn_only=True)
 B, F, T, Ff, Fs = 2, 21, 3, 5, 4
 case = Bn.synthetic_case(1234, B, T, 1, H, W, F, Ff, Fs, 0, device)
 info = Bn.make_info(case, Ff)
