@@ -409,7 +409,8 @@ int p4c_segment_sum_pair(const void* msg, const int32_t* offsets_a, const int32_
  *   qkv   : (B, Hp, Wp, 3, heads, head_dim)   -- the qkv Linear's output, `dtype` storage; Hp, Wp multiples of ws
  *   bias_t: (heads, N, N) fp32 indexed [head][key][query], N = ws*ws (the relative-position bias, TRANSPOSED); NULL = none
  *   out   : (B, Hp, Wp, heads*head_dim)
- * head_dim in {8,16,32}, ws in 3..8.  Products on the bf16 matrix cores (operands rounded to bf16), softmax in fp32.
+ * head_dim in {8,16,32}, ws in 3..8.  dtype = P4C_BF16: products on the bf16 matrix cores (operands and P rounded to bf16), softmax
+ * in fp32.  dtype = P4C_F32: the fp32-exact flavour -- every product an fp32 FMA chain (<= 2e-6 of a float64 evaluation).
  * ------------------------------------------------------------------------------------ */
 int p4c_window_attn_fwd(const void* qkv, const float* bias_t, void* out, int B, int Hp, int Wp, int heads, int head_dim,
                         int ws, int shift, float scale, int dtype, p4c_stream_t stream);

@@ -15,6 +15,8 @@
 // Backward recomputes the softmax in both orientations (key-on-lane for dV, dK; query-on-lane for dQ and the bias gradient), so
 // no attention matrix is ever stored or transposed through memory; the relative-position-bias gradient accumulates in registers
 // over the windows of a persistent wave (one head per workgroup) and is reduced in a fixed order (no atomics).
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace p4c {
@@ -503,6 +505,278 @@ __global__ void window_attn_dbias_reduce_kernel(const float* __restrict__ partia
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32-EXACT flavour (fp32 activations: the parity flavour of SwinUNetR, held to 1e-4 against the float64 oracle like every other
+// model).  Same task mapping and bias-gradient reduction as above, no matrix cores: one wave per (window, head), LANE = TOKEN, the
+// window's K / V (backward: Q / dO too) rows as fp32 images in LDS which every lane reads row by row (broadcast reads); logits,
+// softmax and both products are fp32 FMA chains over the channels / the keys in index order.  Forward: lane = query.  Backward phase 1:
+// lane = query (P, delta = dO . O, dS -> bias gradient, dQ); phase 2: lane = key (P and dS recomputed from the stored row statistics ->
+// dV, dK).  Slower than the bf16 kernels by the matrix cores' factor; its job is to be right, not fast.
+template <int D> constexpr int exact_fwd_smem() { return BIAS_BYTES + 4 * 2 * 64 * D * 4; }
+template <int D> constexpr int exact_bwd_smem() { return BIAS_BYTES + 4 * (4 * 64 * D * 4 + STAT_BYTES); }
+
+struct KeyRegions {   // bit j: token j of a window lies at row / column >= ws - shift (the wrap-around part of the last windows)
+    unsigned long long yge, xge;
+};
+__device__ __forceinline__ KeyRegions key_regions(const Geo& g) {
+    KeyRegions k{0ull, 0ull};
+    for (int j = 0; j < g.N; ++j) {
+        const int jy = j / g.ws, jx = j - jy * g.ws;
+        if (jy >= g.ws - g.shift) k.yge |= 1ull << j;
+        if (jx >= g.ws - g.shift) k.xge |= 1ull << j;
+    }
+    return k;
+}
+// bit j: token j lies in another wrap-around region than the lane's own token (the shift mask; the relation is symmetric)
+__device__ __forceinline__ unsigned long long masked_tokens(const KeyRegions& kr, const Win& w, bool own_yge, bool own_xge) {
+    unsigned long long m = 0ull;
+    if (w.last_y) m |= own_yge ? ~kr.yge : kr.yge;
+    if (w.last_x) m |= own_xge ? ~kr.xge : kr.xge;
+    return m;
+}
+template <int D>
+__device__ __forceinline__ void load_row_f32(const float* p, bool ok, float* r) {
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 a = ok ? *reinterpret_cast<const f32x4*>(p + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        r[c] = a.x; r[c + 1] = a.y; r[c + 2] = a.z; r[c + 3] = a.w;
+    }
+}
+template <int D>
+__device__ __forceinline__ void put_row_f32(float* img, int tok, const float* r) {
+#pragma unroll
+    for (int c = 0; c < D; c += 4) *reinterpret_cast<f32x4*>(img + tok * D + c) = f32x4{r[c], r[c + 1], r[c + 2], r[c + 3]};
+}
+template <int D>
+__device__ __forceinline__ float dot_row(const float* own, const float* img, int tok) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(img + tok * D + c);
+        acc = __builtin_fmaf(own[c], o.x, acc);
+        acc = __builtin_fmaf(own[c + 1], o.y, acc);
+        acc = __builtin_fmaf(own[c + 2], o.z, acc);
+        acc = __builtin_fmaf(own[c + 3], o.w, acc);
+    }
+    return acc;
+}
+template <int D>
+__device__ __forceinline__ void axpy_row(float a, const float* img, int tok, float* y) {
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(img + tok * D + c);
+        y[c] = __builtin_fmaf(a, o.x, y[c]);
+        y[c + 1] = __builtin_fmaf(a, o.y, y[c + 1]);
+        y[c + 2] = __builtin_fmaf(a, o.z, y[c + 2]);
+        y[c + 3] = __builtin_fmaf(a, o.w, y[c + 3]);
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 1)
+    window_attn_fwd_exact_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_t, float* __restrict__ out, Geo g, float scale,
+                                 int GW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lbias = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* imgK = reinterpret_cast<float*>(smem + BIAS_BYTES) + wv * 2 * 64 * D;
+    float* imgV = imgK + 64 * D;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int head = slot % g.heads, gw = (slot / g.heads) * 8 + xcd;
+    if (gw >= GW) return;
+    stage_bias(lbias, bias_t, head, g.N);
+    __syncthreads();
+    const KeyRegions kr = key_regions(g);
+    const bool ok = lane < g.N;
+    const int wy = lane / g.ws, wx = lane - wy * g.ws;
+    const bool oyge = wy >= g.ws - g.shift, oxge = wx >= g.ws - g.shift;
+    const int nwin = g.B * g.nwy * g.nwx;
+    const int64_t rs = 3 * (int64_t)g.C;
+    const float scale_l2 = scale * LOG2E;
+    for (int w = gw * 4 + wv; w < nwin; w += GW * 4) {
+        const Win win = decode_window(g, w);
+        const int64_t pix = ok ? token_pixel(g, win, wy, wx) : 0;
+        float q[D], t[D];
+        load_row_f32<D>(qkv + pix * rs + head * D, ok, q);
+        load_row_f32<D>(qkv + pix * rs + g.C + head * D, ok, t);
+        put_row_f32<D>(imgK, lane, t);
+        load_row_f32<D>(qkv + pix * rs + 2 * g.C + head * D, ok, t);
+        put_row_f32<D>(imgV, lane, t);
+        lds_order();
+        const unsigned long long masked = masked_tokens(kr, win, oyge, oxge);
+        float sv[64], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) sv[j] = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            if (j < g.N) {   // (uniform; its own basic block keeps the compiler from hoisting the reads of all 64 rows together)
+                float v = dot_row<D>(q, imgK, j) * scale_l2 + lbias[j * BIAS_LD + lane];
+                if ((masked >> j) & 1ull) v += MASK_VALUE * LOG2E;
+                sv[j] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        float sum = 0.f, o[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) o[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            if (j < g.N) {   // (uniform; its own basic block keeps the compiler from hoisting the reads of all 64 rows together)
+                const float pj = __builtin_amdgcn_exp2f(sv[j] - mx);
+                sum += pj;
+                axpy_row<D>(pj, imgV, j, o);
+            }
+        }
+        if (ok) {
+            const float inv = 1.f / sum;
+            float* dst = out + pix * g.C + head * D;
+#pragma unroll
+            for (int c = 0; c < D; c += 4) store4(dst + c, o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
+        }
+        lds_order();
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 1)
+    window_attn_bwd_exact_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_t, const float* __restrict__ dout,
+                                 float* __restrict__ dqkv, float* __restrict__ dbias_partial, Geo g, float scale, int GW) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lbias = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* wbase = reinterpret_cast<float*>(smem + BIAS_BYTES + wv * (4 * 64 * D * 4 + STAT_BYTES));
+    float *imgK = wbase, *imgV = wbase + 64 * D, *imgQ = wbase + 2 * 64 * D, *imgO = wbase + 3 * 64 * D;
+    float *st_m = wbase + 4 * 64 * D, *st_il = st_m + 64, *st_d = st_m + 128;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int head = slot % g.heads, gw = (slot / g.heads) * 8 + xcd;
+    if (gw >= GW) return;
+    stage_bias(lbias, bias_t, head, g.N);
+    __syncthreads();
+    const KeyRegions kr = key_regions(g);
+    const bool ok = lane < g.N;
+    const int wy = lane / g.ws, wx = lane - wy * g.ws;
+    const bool oyge = wy >= g.ws - g.shift, oxge = wx >= g.ws - g.shift;
+    const int nwin = g.B * g.nwy * g.nwx;
+    const int64_t rs = 3 * (int64_t)g.C;
+    const float scale_l2 = scale * LOG2E;
+    float dbias[64];   // query = lane, key = index
+#pragma unroll
+    for (int j = 0; j < 64; ++j) dbias[j] = 0.f;
+
+    for (int w = gw * 4 + wv; w < nwin; w += GW * 4) {
+        const Win win = decode_window(g, w);
+        const int64_t pix = ok ? token_pixel(g, win, wy, wx) : 0;
+        const unsigned long long masked = masked_tokens(kr, win, oyge, oxge);
+        float kown[D], vown[D];
+        {
+            // ---- phase 1: lane = query
+            float q[D], dO[D];
+            load_row_f32<D>(qkv + pix * rs + head * D, ok, q);
+            load_row_f32<D>(qkv + pix * rs + g.C + head * D, ok, kown);
+            load_row_f32<D>(qkv + pix * rs + 2 * g.C + head * D, ok, vown);
+            load_row_f32<D>(dout + pix * g.C + head * D, ok, dO);
+            put_row_f32<D>(imgQ, lane, q);
+            put_row_f32<D>(imgK, lane, kown);
+            put_row_f32<D>(imgV, lane, vown);
+            put_row_f32<D>(imgO, lane, dO);
+            lds_order();
+            float pv[64], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) pv[j] = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                if (j < g.N) {   // (uniform; its own basic block keeps the compiler from hoisting the reads of all 64 rows together)
+                    float v = dot_row<D>(q, imgK, j) * scale_l2 + lbias[j * BIAS_LD + lane];
+                    if ((masked >> j) & 1ull) v += MASK_VALUE * LOG2E;
+                    pv[j] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            float sum = 0.f, o[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) o[c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                if (j < g.N) {   // (uniform; its own basic block keeps the compiler from hoisting the reads of all 64 rows together)
+                    pv[j] = __builtin_amdgcn_exp2f(pv[j] - mx);
+                    sum += pv[j];
+                    axpy_row<D>(pv[j], imgV, j, o);
+                }
+            }
+            const float inv = 1.f / sum;
+            float delta = 0.f;   // sum_j P_ij dP_ij = dO_i . O_i
+#pragma unroll
+            for (int c = 0; c < D; ++c) delta = __builtin_fmaf(dO[c], o[c] * inv, delta);
+            st_m[lane] = mx;
+            st_il[lane] = inv;
+            st_d[lane] = delta;
+            float dq[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) dq[c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                if (j < g.N) {   // (uniform; its own basic block keeps the compiler from hoisting the reads of all 64 rows together)
+                    const float ds = pv[j] * inv * (dot_row<D>(dO, imgV, j) - delta);
+                    dbias[j] += ok ? ds : 0.f;
+                    axpy_row<D>(ds, imgK, j, dq);
+                }
+            }
+            if (ok) {
+                float* dst = dqkv + pix * rs + head * D;
+#pragma unroll
+                for (int c = 0; c < D; c += 4) store4(dst + c, dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale);
+            }
+        }
+        lds_order();
+        {
+            // ---- phase 2: lane = key
+            float dk[D], dv[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) dk[c] = dv[c] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                if (i < g.N) {   // (uniform; its own basic block keeps the compiler from hoisting the reads of all 64 rows together)
+                    float v = dot_row<D>(kown, imgQ, i) * scale_l2 + lbias[lane * BIAS_LD + i];
+                    if ((masked >> i) & 1ull) v += MASK_VALUE * LOG2E;   // (the query's region against this lane's: symmetric)
+                    const float pij = ok ? __builtin_amdgcn_exp2f(v - st_m[i]) * st_il[i] : 0.f;
+                    const float ds = pij * (dot_row<D>(vown, imgO, i) - st_d[i]);
+                    axpy_row<D>(pij, imgO, i, dv);
+                    axpy_row<D>(ds, imgQ, i, dk);
+                }
+            }
+            if (ok) {
+                float* dstk = dqkv + pix * rs + g.C + head * D;
+                float* dstv = dqkv + pix * rs + 2 * g.C + head * D;
+#pragma unroll
+                for (int c = 0; c < D; c += 4) {
+                    store4(dstk + c, dk[c] * scale, dk[c + 1] * scale, dk[c + 2] * scale, dk[c + 3] * scale);
+                    store4(dstv + c, dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+                }
+            }
+        }
+        lds_order();
+    }
+
+    if (dbias_partial) {   // the four waves add their registers in wave order (fixed order, no atomics): [key][query]
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem + BIAS_BYTES);
+        for (int turn = 0; turn < 4; ++turn) {
+            if (wv == turn) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    if (j < g.N) {   // (uniform; its own basic block keeps the compiler from hoisting the reads of all 64 rows together)
+                        if (turn == 0) red[j * 64 + lane] = dbias[j];
+                        else red[j * 64 + lane] += dbias[j];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float* dst = dbias_partial + (int64_t)(gw * g.heads + head) * 4096;
+        for (int i = threadIdx.x; i < 4096; i += blockDim.x) dst[i] = red[i];
+    }
+}
+
 int attn_grid(int heads, int nwin) {
     int GW = (nwin + 3) / 4;
     int cap = (num_cus() * 3 + heads - 1) / heads;   // measured: 4 workgroups per CU is slower (fwd 39 vs 34 us, bwd 240 vs 189 us)
@@ -520,6 +794,35 @@ int check_geo(const char* name, Geo& g, int B, int Hp, int Wp, int heads, int he
     P4C_CHECK_ARG(head_dim == 8 || head_dim == 16 || head_dim == 32, "%s: head_dim %d not in {8,16,32}", name, head_dim);
     P4C_CHECK_ARG(dtype == P4C_F32 || dtype == P4C_BF16, "%s: dtype must be P4C_F32 or P4C_BF16", name);
     g = Geo{B, Hp, Wp, heads, ws, shift, Hp / ws, Wp / ws, ws * ws, heads * head_dim};
+    return P4C_OK;
+}
+
+template <int D>
+int launch_fwd_exact(const void* qkv, const float* bias_t, void* out, const Geo& g, float scale, hipStream_t stream) {
+    constexpr int smem = exact_fwd_smem<D>();
+    P4C_TRY(ensure_dyn_smem((const void*)window_attn_fwd_exact_kernel<D>, smem));
+    const int GW = attn_grid(g.heads, g.B * g.nwy * g.nwx);
+    hipLaunchKernelGGL((window_attn_fwd_exact_kernel<D>), dim3(((GW + 7) / 8) * 8 * g.heads), dim3(256), smem, stream, (const float*)qkv,
+                       bias_t, (float*)out, g, scale, GW);
+    P4C_CHECK_LAUNCH("window_attn_fwd_exact");
+    return P4C_OK;
+}
+
+template <int D>
+int launch_bwd_exact(const void* qkv, const float* bias_t, const void* dout, void* dqkv, float* partial, float* dbias_t, const Geo& g,
+                     float scale, hipStream_t stream) {
+    constexpr int smem = exact_bwd_smem<D>();
+    P4C_TRY(ensure_dyn_smem((const void*)window_attn_bwd_exact_kernel<D>, smem));
+    const int GW = attn_grid(g.heads, g.B * g.nwy * g.nwx);
+    hipLaunchKernelGGL((window_attn_bwd_exact_kernel<D>), dim3(((GW + 7) / 8) * 8 * g.heads), dim3(256), smem, stream, (const float*)qkv,
+                       bias_t, (const float*)dout, (float*)dqkv, partial, g, scale, GW);
+    P4C_CHECK_LAUNCH("window_attn_bwd_exact");
+    if (partial) {
+        const int total = g.heads * g.N * g.N;
+        hipLaunchKernelGGL(window_attn_dbias_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, dbias_t, g.heads,
+                           g.N, GW);
+        P4C_CHECK_LAUNCH("window_attn_dbias_reduce");
+    }
     return P4C_OK;
 }
 
@@ -556,6 +859,13 @@ int launch_bwd(const void* qkv, const float* bias_t, const void* dout, void* dqk
 
 using namespace p4c;
 
+// fp32 activations run the fp32-exact kernels; P4C_ATTN_F32_MFMA=1 sends them through the bf16 matrix-core kernels instead (operands
+// and P rounded to bf16: the round-1/2 behaviour, kept as an A/B switch)
+static bool f32_on_matrix_cores() {
+    const char* e = getenv("P4C_ATTN_F32_MFMA");
+    return e && e[0] == '1';
+}
+
 extern "C" size_t p4c_window_attn_bwd_workspace_bytes(int B, int Hp, int Wp, int heads, int ws) {
     if (B <= 0 || Hp <= 0 || Wp <= 0 || heads <= 0 || ws <= 0) return 0;
     const int nwin = B * (Hp / ws) * (Wp / ws);
@@ -571,6 +881,11 @@ extern "C" int p4c_window_attn_fwd(const void* qkv, const float* bias_t, void* o
     hipStream_t s = as_stream(stream);
 #define P4C_ATTN_FWD(TT, DD) return launch_fwd<TT, DD>(qkv, bias_t, out, g, scale, s)
     if (dtype == P4C_F32) {
+        if (!f32_on_matrix_cores()) {
+            if (head_dim == 8) return launch_fwd_exact<8>(qkv, bias_t, out, g, scale, s);
+            if (head_dim == 16) return launch_fwd_exact<16>(qkv, bias_t, out, g, scale, s);
+            return launch_fwd_exact<32>(qkv, bias_t, out, g, scale, s);
+        }
         if (head_dim == 8) P4C_ATTN_FWD(float, 8);
         if (head_dim == 16) P4C_ATTN_FWD(float, 16);
         P4C_ATTN_FWD(float, 32);
@@ -594,6 +909,11 @@ extern "C" int p4c_window_attn_bwd(const void* qkv, const float* bias_t, const v
     hipStream_t s = as_stream(stream);
 #define P4C_ATTN_BWD(TT, DD) return launch_bwd<TT, DD>(qkv, bias_t, dout, dqkv, partial, dbias_t, g, scale, s)
     if (dtype == P4C_F32) {
+        if (!f32_on_matrix_cores()) {
+            if (head_dim == 8) return launch_bwd_exact<8>(qkv, bias_t, dout, dqkv, partial, dbias_t, g, scale, s);
+            if (head_dim == 16) return launch_bwd_exact<16>(qkv, bias_t, dout, dqkv, partial, dbias_t, g, scale, s);
+            return launch_bwd_exact<32>(qkv, bias_t, dout, dqkv, partial, dbias_t, g, scale, s);
+        }
         if (head_dim == 8) P4C_ATTN_BWD(float, 8);
         if (head_dim == 16) P4C_ATTN_BWD(float, 16);
         P4C_ATTN_BWD(float, 32);

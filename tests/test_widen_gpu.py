@@ -163,10 +163,15 @@ def test_window_attention_forward(gpu_device, case, dtype):
     B, Hp, Wp, heads, d, ws, shift = case
     qkv, bias = _attn_inputs(B, Hp, Wp, heads, d, ws, 11, dtype)
     got = window_attention(qkv.to(gpu_device), bias.to(gpu_device), heads, ws, shift).float().cpu()
+    no_bias = window_attention(qkv.to(gpu_device), None, heads, ws, shift).float().cpu()
+    if dtype == torch.float32:
+        # fp32 activations run the fp32-exact kernels (round 3): held to the float64 oracle on the SAME operands
+        assert _rel(got, owa.window_attention(qkv.double(), bias.double(), heads, ws, shift)) < 2e-6
+        assert _rel(no_bias, owa.window_attention(qkv.double(), None, heads, ws, shift)) < 2e-6
+        return
     ref = owa.window_attention(qkv.bfloat16().double(), bias.double(), heads, ws, shift)  # the operands the MFMAs see
     # P is rounded to bf16 before P @ V (2^-9 relative per element), bf16 outputs add one more rounding
-    assert _rel(got, ref) < (4e-3 if dtype == torch.float32 else 6e-3)
-    no_bias = window_attention(qkv.to(gpu_device), None, heads, ws, shift).float().cpu()
+    assert _rel(got, ref) < 6e-3
     assert _rel(no_bias, owa.window_attention(qkv.bfloat16().double(), None, heads, ws, shift)) < 6e-3
 
 
@@ -183,17 +188,18 @@ def test_window_attention_backward(gpu_device, case, dtype):
     b_g = bias.to(gpu_device).requires_grad_(True)
     out = window_attention(q_g, b_g, heads, ws, shift)
     out.backward(dout.to(gpu_device))
-    q_r = qkv.bfloat16().double().requires_grad_(True)
+    exact = dtype == torch.float32     # fp32 activations: the fp32-exact kernels, float64 oracle on the same operands
+    q_r = (qkv.double() if exact else qkv.bfloat16().double()).requires_grad_(True)
     b_r = bias.double().requires_grad_(True)
-    owa.window_attention(q_r, b_r, heads, ws, shift).backward(dout.bfloat16().double())
+    owa.window_attention(q_r, b_r, heads, ws, shift).backward(dout.double() if exact else dout.bfloat16().double())
     # bf16-rounded P / dS operands: ~1e-2 on individual gradients
-    assert _rel(q_g.grad.float().cpu(), q_r.grad) < 1.5e-2
-    assert _rel(b_g.grad.float().cpu(), b_r.grad) < 1.5e-2
+    assert _rel(q_g.grad.float().cpu(), q_r.grad) < (5e-6 if exact else 1.5e-2)
+    assert _rel(b_g.grad.float().cpu(), b_r.grad) < (5e-6 if exact else 1.5e-2)
     # each of dq, dk, dv on its own (a wrong block would hide in the norm of the others)
     C = heads * d
     for part in range(3):
         sl = slice(part * C, (part + 1) * C)
-        assert _rel(q_g.grad.float().cpu()[..., sl], q_r.grad[..., sl]) < 2e-2
+        assert _rel(q_g.grad.float().cpu()[..., sl], q_r.grad[..., sl]) < (5e-6 if exact else 2e-2)
     # deterministic bias gradient (fixed reduction order)
     q2 = qkv.to(gpu_device).requires_grad_(True)
     b2 = bias.to(gpu_device).requires_grad_(True)
@@ -442,21 +448,25 @@ def test_swinunetr_matches_oracle(gpu_device, ws):
     yr = oracle(xr)
     yr.backward(gy.double())
     assert y.shape == (2, H, W, cout)
-    # attention products run on bf16 matrix cores (operands and P rounded to bf16): 1e-2-level agreement of the network output
-    assert _rel(y.detach().cpu(), yr.detach()) < 2e-2
-    assert _rel(xg.grad.cpu(), xr.grad) < 6e-2
+    # fp32 activations: every product of the network is exact fp32 (fp32 matrix cores, library fp32 GEMMs, the fp32-exact window
+    # attention of round 3) -- the forward is held to 1e-4 like every other model's
+    print("swin fp32 flavour vs float64 oracle: forward", _rel(y.detach().cpu(), yr.detach()), "dx", _rel(xg.grad.cpu(), xr.grad))
+    assert _rel(y.detach().cpu(), yr.detach()) < 1e-4
+    # (gradients pass through LeakyReLU / max decisions of fp32 pre-activations within rounding of a tie: a few 1e-4 ... 1e-3, the
+    # distance torch's own fp32 paths show on such networks -- DESIGN.md 4)
+    assert _rel(xg.grad.cpu(), xr.grad) < 3e-3
     ref = dict(oracle.named_parameters())
     cos = []
     for name, p in model.named_parameters():
         a, b = p.grad.double().cpu().flatten(), ref[name].grad.flatten()
         cos.append(float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30)))
-    assert min(cos) > 0.98, min(cos)
+    print("worst parameter-gradient cosine", min(cos))
+    assert min(cos) > 0.9999, min(cos)
 
 
 def test_swinunetr_rollout_through_lightning(gpu_device):
     """BASELINE configuration 3 in small: SwinUNetR from the registry, 3-step scaled_ar rollout (fused update + loss per step), loss
-    against the oracle network driven through the oracle rollout (attention products on bf16 matrix cores: 1e-2-level agreement),
-    then the bf16 flavour end to end."""
+    against the oracle network driven through the oracle rollout (fp32 flavour: 1e-4), then the bf16 flavour end to end."""
     from oracle import losses as olosses
     from oracle import rollout as orollout
     from oracle.swinunetr import SwinUNetR as OracleSwin
@@ -482,7 +492,8 @@ def test_swinunetr_rollout_through_lightning(gpu_device):
                             c["diff_mean"], "scaled_ar")
     w = olosses.weighted_loss_weights(c["state_weight"], c["diff_std"], "mse")
     ref = olosses.weighted_loss(pred, c["outputs"], torch.ones_like(pred), w, interior, "mse").mean()
-    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 3e-2
+    print("swin fp32 flavour rollout loss vs the oracle rollout:", abs(loss.item() - ref.item()) / abs(ref.item()))
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-4     # (fp32-exact window attention since round 3)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
     lm16 = AutoRegressiveLightning({"activation_dtype": "bf16"}, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2,
                                    model_name="SwinUNetR", losses=mse, training_strategy="scaled_ar").to(gpu_device)
