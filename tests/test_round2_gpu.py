@@ -320,9 +320,13 @@ def test_bench_workload_native_rollout_both_flavours(gpu_device, bench_case):
         torch.cuda.empty_cache()
     l32, l16 = res["f32"][0], res["bf16"][0]
     assert abs(l32 - l16) / l32 < 2e-4, (l32, l16)                              # 272.128 vs 272.159
-    assert rel_err(res["bf16"][2], res["f32"][2]) < 4e-2                         # first AR step's prediction
+    e1 = rel_err(res["bf16"][2], res["f32"][2])
     cos = float(torch.dot(res["f32"][1], res["bf16"][1]) / (res["f32"][1].norm() * res["bf16"][1].norm()))
-    assert cos > 0.8, cos
+    print("bf16 vs fp32 flavour at bench size: loss", abs(l32 - l16) / l32, "first-step prediction", e1, "gradient cosine", cos)
+    # measured (round 3): loss 9.8e-5, first AR step's prediction 2.0e-2 (12 conv layers of bf16 operands and bf16-stored
+    # activations), cosine of the two flavours' full gradient vectors 0.988
+    assert e1 < 3e-2
+    assert cos > 0.97, cos
 
 
 @pytest.mark.parametrize("transform", [False, True])
