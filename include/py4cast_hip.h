@@ -303,6 +303,16 @@ int p4c_conv_kernel_kind(int compute, int storage, int CI, int ks, int B, int H,
 int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_pad, int ks, const float* in_scale, const float* in_shift,
                    int in_relu, const void* dout, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                    p4c_stream_t stream);
+/* The same convolution on bf16 feature maps with FEWER than 64 channels, in place: in (B,H,W,in_c), out (B,H,W,out_c), in_c and
+ * out_c multiples of 8 up to 64 (absent channels are staged as zeros / not stored), weights prepared for 64 x 64 (p4c_prep_weights
+ * with the real CO / CI).  Plain launches of the row kernel only (no input transform, no statistics): what a features-last
+ * `Conv2d(bias=False)` of mfai's SwinUNETR decoder needs forward, for its data gradient (transposed weights) and -- p4c_conv_wgrad_compact,
+ * workspace of p4c_conv_wgrad_workspace_bytes(64, ks) -- for its weight gradient.  p4c_conv_compact_supported: 1 if the shape is served. */
+int p4c_conv_compact_supported(int in_c, int out_c, int ks, int B, int H, int W);
+int p4c_conv_fwd_compact(const void* in, int in_c, const void* wprep, int ks, void* out, int out_c, int B, int H, int W,
+                         p4c_stream_t stream);
+int p4c_conv_wgrad_compact(const void* in, int in_c, int ks, const void* dout, int dout_c, int CO, int CI, float* grad, void* workspace,
+                           int B, int H, int W, p4c_stream_t stream);
 
 /* HalfUNet (the network behind `model_name: HalfUNet`, config/CLI/model/halfunet.yaml): 5 encoder
  * blocks [conv3x3 -> norm -> ReLU] x2 at 64 filters with 2x2 max-pool between, all levels bilinearly

@@ -49,6 +49,8 @@ SIGNATURES = {
     "p4c_prep_weights": [P, I, I, I, I, I, I, P, I, P],
     "p4c_conv_fwd": [P, I, I, I, P, I, P, P, I, P, P, I, P, I, I, I, I, P],
     "p4c_conv_wgrad": [P, I, I, I, I, P, P, I, P, I, I, P, P, I, I, I, P],
+    "p4c_conv_fwd_compact": [P, I, P, I, P, I, I, I, I, P],
+    "p4c_conv_wgrad_compact": [P, I, I, P, I, I, I, P, P, I, I, I, P],
     "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
     "p4c_halfunet_prepare_weights": [DP, P, P, P],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],
@@ -76,6 +78,7 @@ OTHER = {
     "p4c_conv_stat_tiles": ([I, I, I, I, I, I], c_int),
     "p4c_conv_stat_tiles_ks": ([I, I, I, I, I, I, I], c_int),
     "p4c_conv_kernel_kind": ([I, I, I, I, I, I, I], c_int),
+    "p4c_conv_compact_supported": ([I, I, I, I, I, I], c_int),
     "p4c_halfunet_param_count": ([DP], c_int64),
     "p4c_window_attn_bwd_workspace_bytes": ([I, I, I, I, I], c_size_t),
     "p4c_row_layernorm_bwd_workspace_bytes": ([L, I, I], c_size_t),

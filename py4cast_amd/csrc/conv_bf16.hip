@@ -1637,7 +1637,10 @@ template <int MODE, bool NB, int KS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     conv3x3_wgrad_bf16_ws_kernel(const __bf16* __restrict__ in, const float* __restrict__ in_scale,
                                  const float* __restrict__ in_shift, const __bf16* __restrict__ dout,
-                                 float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip, NormBwdCoef nb) {
+                                 float* __restrict__ partial, int B, int H, int W, int in_cs, int ci_off, int part_cip, NormBwdCoef nb,
+                                 int dout_cs) {
+    // (dout_cs: channels per pixel of `dout`, 64 or a smaller multiple of 8 -- "compact" gradients of a convolution with fewer than 64
+    // output channels; likewise in_cs - ci_off may be below 64: absent channel octets are staged as zeros)
     using namespace wgws;
     using G = Geo<KS>;
     constexpr int NTAPS = G::NTAPS, HALO = G::HALO, LH = G::LH, LW = G::LW, INB = G::INB, BUFB = G::BUFB, NI = G::NI, ND = G::ND,
@@ -1657,6 +1660,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (loader) {
         if (t_begin >= t_end) return;
         const int c8 = ltid & 7;
+        const bool in_ch = 8 * c8 < in_cs - ci_off, do_ch = 8 * c8 < dout_cs;
         struct Cur { int t, b, tx, ty; };
         auto cur_init = [&]() __attribute__((always_inline)) {
             Cur c;
@@ -1680,14 +1684,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int it = 0; it < NI; ++it) {
             const int pix = (ltid + it * 256) >> 3;
             const int ly = pix / LW, lx = pix - ly * LW;
-            gi[it] = ((ly * W + lx) * in_cs + 8 * c8) * 2;
+            gi[it] = in_ch ? ((ly * W + lx) * in_cs + 8 * c8) * 2 : OOB;
             li[it] = pix * ROWA + 16 * c8;
             pi[it] = (ly << 8) | lx;
         }
 #pragma unroll
         for (int it = 0; it < ND; ++it) {
             const int pix = (ltid + it * 256) >> 3;
-            gd[it] = (((pix >> 5) * W + (pix & 31)) * 64 + 8 * c8) * 2;
+            gd[it] = do_ch ? (((pix >> 5) * W + (pix & 31)) * dout_cs + 8 * c8) * 2 : OOB;
             ld[it] = INB + pix * ROWD + 16 * c8;
         }
         struct Img { u32x4 a[NI]; u32x4 d[ND]; u32x4 y[NB ? ND : 1]; };
@@ -1699,12 +1703,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int b = live ? lc.b : 0, y0 = live ? lc.ty * TH : 0, x0 = live ? lc.tx * BTW : 0;
             cur_next(lc);
             const __amdgpu_buffer_rsrc_t rsi = make_rsrc(inb + (int64_t)b * H * W * in_cs, (unsigned)(((int64_t)H * W * in_cs - ci_off) * 2));
-            const __amdgpu_buffer_rsrc_t rsd = make_rsrc(dout + (int64_t)b * H * W * 64, (unsigned)((int64_t)H * W * 64 * 2));
+            const __amdgpu_buffer_rsrc_t rsd = make_rsrc(dout + (int64_t)b * H * W * dout_cs, (unsigned)((int64_t)H * W * dout_cs * 2));
             const __amdgpu_buffer_rsrc_t rsy = make_rsrc((NB ? reinterpret_cast<const __bf16*>(nb.y) : dout) + (int64_t)b * H * W * 64,
                                                          (unsigned)((int64_t)H * W * 64 * 2));
             const int gy0 = y0 - HALO, gx0 = x0 - HALO;
             if (live && gy0 >= 0 && y0 + TH + HALO <= H && gx0 >= 0 && x0 + BTW + HALO <= W) {
-                const int so = (gy0 * W + gx0) * in_cs * 2, sd = (y0 * W + x0) * 64 * 2;
+                const int so = (gy0 * W + gx0) * in_cs * 2, sd = (y0 * W + x0) * dout_cs * 2;
 #pragma unroll
                 for (int it = 0; it < NI; ++it)
                     im.a[it] = __builtin_amdgcn_raw_buffer_load_b128(rsi, (ltid + it * 256 < TOT_IN) ? gi[it] : OOB, so, 0);
@@ -1718,14 +1722,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int it = 0; it < NI; ++it) {
                     const int gy = gy0 + (pi[it] >> 8), gx = gx0 + (pi[it] & 255);
-                    const bool ok = live & (ltid + it * 256 < TOT_IN) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                    const bool ok = live & (ltid + it * 256 < TOT_IN) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W) & in_ch;
                     im.a[it] = __builtin_amdgcn_raw_buffer_load_b128(rsi, ok ? ((gy * W + gx) * in_cs + 8 * c8) * 2 : OOB, 0, 0);
                 }
 #pragma unroll
                 for (int it = 0; it < ND; ++it) {
                     const int pix = (ltid + it * 256) >> 3;
                     const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-                    im.d[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, (live & (gy < H) & (gx < W)) ? ((gy * W + gx) * 64 + 8 * c8) * 2 : OOB, 0, 0);
+                    im.d[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, (live & (gy < H) & (gx < W) & do_ch) ? ((gy * W + gx) * dout_cs + 8 * c8) * 2 : OOB, 0, 0);
                     if (NB) im.y[it] = __builtin_amdgcn_raw_buffer_load_b128(rsy, (live & (gy < H) & (gx < W)) ? ((gy * W + gx) * 64 + 8 * c8) * 2 : OOB, 0, 0);
                 }
             }
@@ -1906,22 +1910,24 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 template <int MODE, bool NB, int KS = 3>
 static int launch_wgrad_ws_mode(const __bf16* in, const float* in_scale, const float* in_shift, const __bf16* dout, float* partial,
-                                int G, int B, int H, int W, int in_cs, int ci_off, int part_cip, hipStream_t stream, const NormBwdCoef& nb) {
+                                int G, int B, int H, int W, int in_cs, int ci_off, int part_cip, hipStream_t stream, const NormBwdCoef& nb,
+                                int dout_cs = 64) {
     P4C_TRY(ensure_dyn_smem((const void*)conv3x3_wgrad_bf16_ws_kernel<MODE, NB, KS>, wgws::Geo<KS>::SMEM));
     hipLaunchKernelGGL((conv3x3_wgrad_bf16_ws_kernel<MODE, NB, KS>), dim3(G), dim3(512), wgws::Geo<KS>::SMEM, stream, in, in_scale,
-                       in_shift, dout, partial, B, H, W, in_cs, ci_off, part_cip, nb);
+                       in_shift, dout, partial, B, H, W, in_cs, ci_off, part_cip, nb, dout_cs);
     return P4C_OK;
 }
 
 static int launch_conv3x3_wgrad_bf16_ws(const __bf16* in, const float* in_scale, const float* in_shift, int in_relu,
                                         const __bf16* dout, float* partial, int G, int B, int H, int W, int in_cs, int ci_off,
-                                        int part_cip, hipStream_t stream, const NormBwdCoef* nbp = nullptr, int ks = 3) {
+                                        int part_cip, hipStream_t stream, const NormBwdCoef* nbp = nullptr, int ks = 3, int dout_cs = 64) {
     const int tiles = ((H + 3) / 4) * ((W + BTW - 1) / BTW) * B;
     if (tiles < G) G = tiles;
     const NormBwdCoef nb = nbp ? *nbp : NormBwdCoef{};
+    if (nbp && dout_cs != 64) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef needs 64-channel gradients");
     if (ks == 1) {   // the 1x1 output convolution: same staging, one tap
         if (nbp) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef is for the 3x3 blocks");
-#define P4C_WG1(M) launch_wgrad_ws_mode<M, false, 1>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb)
+#define P4C_WG1(M) launch_wgrad_ws_mode<M, false, 1>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb, dout_cs)
         P4C_TRY(in_scale ? (in_relu ? P4C_WG1(2) : P4C_WG1(3)) : (in_relu ? P4C_WG1(1) : P4C_WG1(0)));
 #undef P4C_WG1
         P4C_CHECK_LAUNCH("conv1x1_wgrad_bf16_ws");
@@ -1932,7 +1938,7 @@ static int launch_conv3x3_wgrad_bf16_ws(const __bf16* in, const float* in_scale,
     int rc;
 #define P4C_WG(M)                                                                                                                  \
     (nbp ? launch_wgrad_ws_mode<M, true>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb)   \
-         : launch_wgrad_ws_mode<M, false>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb))
+         : launch_wgrad_ws_mode<M, false>(in, in_scale, in_shift, dout, partial, G, B, H, W, in_cs, ci_off, part_cip, stream, nb, dout_cs))
     if (in_scale)
         rc = in_relu ? P4C_WG(2) : P4C_WG(3);
     else
@@ -2097,6 +2103,18 @@ int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in
     if (nb) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef needs bf16 storage");
     return conv_wgrad_bf16_t<float>((const float*)in, CI, ks, in_scale, in_shift, in_relu, (const float*)dout, partial, G, B, H,
                                     W, CO, CIreal, grad, stream, nullptr);
+}
+
+// Weight gradient of a plain convolution with compact channel counts (conv_rows.hip: CPT): in (B,H,W,in_cs), dout (B,H,W,dout_cs),
+// both <= 64 channels (multiples of 8); one role-split launch + the fixed-order reduction.  partial: conv_wgrad workspace of CI_pad 64.
+int conv_wgrad_bf16_compact(const void* in, int in_cs, int ks, const void* dout, int dout_cs, float* partial, int G, int B, int H, int W,
+                            int CO, int CIreal, float* grad, hipStream_t stream) {
+    if (in_cs <= 0 || dout_cs <= 0 || in_cs > 64 || dout_cs > 64 || in_cs % 8 || dout_cs % 8 || (ks != 1 && ks != 3) || B > wgws::MAXB)
+        return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16_compact: unsupported shape (%d / %d channels, ks %d, B %d)", in_cs, dout_cs, ks, B);
+    P4C_TRY(launch_conv3x3_wgrad_bf16_ws((const __bf16*)in, nullptr, nullptr, 0, (const __bf16*)dout, partial, G, B, H, W, in_cs, 0, 64, stream,
+                                         nullptr, ks, dout_cs));
+    const int tiles = ((H + 3) / 4) * ((W + BTW - 1) / BTW) * B;
+    return wgrad_reduce(partial, tiles < G ? tiles : G, ks, 64, 0, 64, CO, CIreal, grad, stream);
 }
 
 #ifdef P4C_STAMPS

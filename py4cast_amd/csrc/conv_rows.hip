@@ -258,7 +258,7 @@ __device__ __forceinline__ void conv_row16(const bf16x8 (&A)[9][2][2], Acc16& P,
 // argument segment at the point of use (the pointer is made opaque there, so the load cannot be hoisted).
 struct RowsArgs {
     const __bf16* in; const __bf16* wp; const float* in_scale; const float* in_shift; __bf16* out; float* stat_partial;
-    int out_cs, H, W, rows_lo, rows_rem, fin_on;
+    int out_cs, H, W, rows_lo, rows_rem, fin_on, in_cs;
     RingBwdStats bst;
     NormBwdCoef nb;
     BatchFin fin;
@@ -275,9 +275,13 @@ __device__ __forceinline__ T late_arg(size_t offset) {
 #endif
 }
 
-template <int MODE, bool BST, int MF, int KS>
+// CPT ("compact channels", plain launches only): the input has in_cs <= 64 channels per pixel and the output out_cs <= 64 (multiples
+// of 8) -- channel slots beyond them are loaded as zeros / not stored, so a 24- or 48-channel feature map is convolved in place
+// instead of through a zero-padded 64-channel copy and a sliced 64-channel result (SwinUNetR's decoder levels).
+template <int MODE, bool BST, int MF, int KS, bool CPT = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     conv3x3_bf16_rows_kernel(RowsArgs args) {
+    static_assert(!CPT || (MODE == 0 && !BST && MF == 32), "compact channels: plain launches only");
     using namespace rows;
     const __bf16* __restrict__ in = args.in;
     const __bf16* __restrict__ wp = args.wp;
@@ -309,7 +313,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (wv >= 4) {
         // ------------------------------------------------------------ memory side
         const int ltid = threadIdx.x - 256, lwv = wv - 4, c8 = ltid & 7;
-        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in + (int64_t)b * H * W * 64, (unsigned int)H * W * 128u);
+        const int ipb = CPT ? args.in_cs * 2 : 128;   // bytes per input pixel
+        const bool in_ch = !CPT || 8 * c8 < args.in_cs, out_ch = !CPT || 8 * c8 < out_cs;   // this lane's channel octet exists
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in + (int64_t)b * H * W * (ipb >> 1), (unsigned int)H * W * (unsigned int)ipb);
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(out + (int64_t)b * H * W * out_cs, (unsigned int)H * W * out_cs * 2u);
         // per-lane tables: slot `it` of a staged group of four input rows (row-major, 528 slots per row)
         // Column validity is static per lane (the strip is fixed): slots of columns outside the image get lim = "never active";
@@ -321,7 +327,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int idx = ltid + it * 256;
             if (it > 0) { rem += 256; if (rem >= ROWSLOTS) { rem -= ROWSLOTS; ++rr; } }
             const int col = rem >> 3;
-            gofs[it] = (rr * W + col) * 128 + 16 * c8;
+            gofs[it] = in_ch ? (rr * W + col) * ipb + 16 * c8 : OOB;   // (an absent octet loads as zeros and is staged as such)
             lofs[it] = rr * RROW + LY::slot_off(col, c8);
             lim[it] = ((unsigned)(x0 - 1 + col) < (unsigned)W) ? idx : OOB;
         }
@@ -340,7 +346,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int j = 0; j < NST; ++j) {
             const int px = (ltid + j * 256) >> 3, row = px >> 6, col = px & 63;
-            dofs[j] = ((row * W + col) * out_cs + 8 * c8) * 2;
+            dofs[j] = out_ch ? ((row * W + col) * out_cs + 8 * c8) * 2 : OOB;
             sofs[j] = row * SROW + col * 128 + ((c8 ^ ((col >> 1) & 7)) << 4);
         }
         // normalisation of this lane's 8 channels (one sample per workgroup)
@@ -376,7 +382,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int nact = nrows * ROWSLOTS;
             const int gy0 = y0 - 1 + m0, gx0 = x0 - 1;
             if (gy0 >= 0 && gy0 + nrows <= H) {
-                const int so = (gy0 * W + gx0) * 128;   // rows inside the image: one scalar offset + the lane's table
+                const int so = (gy0 * W + gx0) * ipb;   // rows inside the image: one scalar offset + the lane's table
 #pragma unroll
                 for (int it = 0; it < NLD; ++it)
                     im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (lim[it] < nact) ? gofs[it] : OOB, so, 0);
@@ -390,8 +396,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int it = 0; it < NLD; ++it) {
                     const int idx = ltid + it * 256, rr = idx / ROWSLOTS;   // (rows outside the image: first / last interval of a strip only)
                     const int gy = gy0 + rr, gx = gx0 + ((idx - rr * ROWSLOTS) >> 3);
-                    const bool ok = (idx < nact) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-                    im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? (gy * W + gx) * 128 + 16 * c8 : OOB, 0, 0);
+                    const bool ok = (idx < nact) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W) & in_ch;
+                    im.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? (gy * W + gx) * ipb + 16 * c8 : OOB, 0, 0);
                     if (MODE == 4) ty.s[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_nby, ok ? (gy * W + gx) * 128 + 16 * c8 : OOB, 0, 0);
                 }
             }
@@ -488,7 +494,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const int n = n0 + (px >> 6), gx = x0 + (px & 63);
                     const bool valid = ((unsigned)n < (unsigned)R) & (gx < W);
                     if (!valid) v[j] = u32x4{0u, 0u, 0u, 0u};   // keeps the statistics below unmasked
-                    __builtin_amdgcn_raw_buffer_store_b128(v[j], rs_out, (valid && !(P4C_EXP & 4)) ? (((y0 + n) * W + gx) * out_cs + 8 * c8) * 2 : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v[j], rs_out, (valid && out_ch && !(P4C_EXP & 4)) ? (((y0 + n) * W + gx) * out_cs + 8 * c8) * 2 : OOB, 0, 0);
                 }
             }
             if (BST) {
@@ -841,7 +847,7 @@ template <int MODE, bool BST, int KS>
 int launch_rows_mode(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, __bf16* out, int out_cs,
                      float* stat_partial, int B, int H, int W, int nstrips, int nseg, hipStream_t stream, const BatchFin& fin,
                      const RingBwdStats& bst, const NormBwdCoef& nb = NormBwdCoef{}) {
-    const RowsArgs args{in, wp, in_scale, in_shift, out, stat_partial, out_cs, H, W, H / nseg, H % nseg, fin.slots ? 1 : 0, bst, nb, fin};
+    const RowsArgs args{in, wp, in_scale, in_shift, out, stat_partial, out_cs, H, W, H / nseg, H % nseg, fin.slots ? 1 : 0, 64, bst, nb, fin};
     if (KS == 1 || MODE == 4 || rows_mfma_shape() == 32) {
         P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>, rows::Lay<32>::SMEM));
         hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream, args);
@@ -871,6 +877,15 @@ int launch_rows_ks(const __bf16* in, const __bf16* wp, const float* in_scale, co
 }
 
 }  // namespace
+
+template <int KS>
+int launch_rows_compact(const __bf16* in, int in_cs, const __bf16* wp, __bf16* out, int out_cs, int B, int H, int W, int nstrips, int nseg,
+                        hipStream_t stream) {
+    const RowsArgs args{in, wp, nullptr, nullptr, out, nullptr, out_cs, H, W, H / nseg, H % nseg, 0, in_cs, RingBwdStats{}, NormBwdCoef{}, BatchFin{}};
+    P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<0, false, 32, KS, true>, rows::Lay<32>::SMEM));
+    hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<0, false, 32, KS, true>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream, args);
+    return P4C_OK;
+}
 
 // Strip / segment geometry of a launch: nstrips 64-pixel strips per sample, each cut into nseg row segments (one workgroup
 // each).  nseg minimises (waves of workgroups over the CUs) x (rows per segment + the fixed cost of a workgroup, ~6 rows).
@@ -910,6 +925,24 @@ bool conv_bf16_norm_bwd_fused_ok(int storage, int CI, int B, int H, int W) {
     if (e && e[0] == '1') return false;
     // data gradient on the row kernel, weight gradient on the role-split kernel (one 64-channel chunk, its sample limit)
     return CI == 64 && B <= 32 && conv_bf16_is_rows(storage, 64, 3, 1, 64, B, H, W);
+}
+
+// plain convolution with compact channel counts (see CPT): in (B,H,W,in_cs) -> out (B,H,W,out_cs), weights prepared for 64 x 64
+bool conv_rows_compact_ok(int storage, int in_cs, int out_cs, int ks, int B, int H, int W) {
+    return in_cs > 0 && out_cs > 0 && in_cs <= 64 && out_cs <= 64 && in_cs % 8 == 0 && out_cs % 8 == 0 &&
+           conv_bf16_is_rows(storage, 64, ks, 1, 64, B, H, W);
+}
+int launch_conv_bf16_rows_compact(const void* in, int in_cs, const void* wp, int ks, void* out, int out_cs, int B, int H, int W,
+                                  hipStream_t stream) {
+    if (!conv_rows_compact_ok(P4C_BF16, in_cs, out_cs, ks, B, H, W))
+        return fail(P4C_ERR_UNSUPPORTED, "conv_bf16_rows_compact: unsupported shape (%d -> %d channels, ks %d, %dx%dx%d)", in_cs, out_cs, ks, B, H, W);
+    int nstrips, nseg;
+    conv_rows_geometry(B, H, W, &nstrips, &nseg);
+    const int rc = ks == 3 ? launch_rows_compact<3>((const __bf16*)in, in_cs, (const __bf16*)wp, (__bf16*)out, out_cs, B, H, W, nstrips, nseg, stream)
+                           : launch_rows_compact<1>((const __bf16*)in, in_cs, (const __bf16*)wp, (__bf16*)out, out_cs, B, H, W, nstrips, nseg, stream);
+    if (rc != P4C_OK) return rc;
+    P4C_CHECK_LAUNCH("conv_bf16_rows_compact");
+    return P4C_OK;
 }
 
 int conv_rows_stat_slots(int B, int H, int W) {

@@ -666,3 +666,23 @@ extern "C" int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_p
     return conv_wgrad(compute, storage, in, CI_pad, ks, in_scale, in_shift, in_relu, dout, (float*)workspace, G, B, H, W, CO,
                       CI, grad, as_stream(stream));
 }
+
+// ---- plain bf16 convolution on feature maps with fewer than 64 channels, in place (row kernel; SwinUNetR's 24- / 48-channel levels)
+extern "C" int p4c_conv_compact_supported(int in_c, int out_c, int ks, int B, int H, int W) {
+    return (conv_rows_compact_ok(P4C_BF16, in_c, out_c, ks, B, H, W) && B <= 32) ? 1 : 0;
+}
+
+extern "C" int p4c_conv_fwd_compact(const void* in, int in_c, const void* wprep, int ks, void* out, int out_c, int B, int H, int W,
+                                    p4c_stream_t stream) {
+    P4C_CHECK_ARG(in && wprep && out, "p4c_conv_fwd_compact: null pointer");
+    return launch_conv_bf16_rows_compact(in, in_c, wprep, ks, out, out_c, B, H, W, as_stream(stream));
+}
+
+extern "C" int p4c_conv_wgrad_compact(const void* in, int in_c, int ks, const void* dout, int dout_c, int CO, int CI, float* grad,
+                                      void* workspace, int B, int H, int W, p4c_stream_t stream) {
+    P4C_CHECK_ARG(in && dout && grad && workspace, "p4c_conv_wgrad_compact: null pointer");
+    P4C_CHECK_ARG(CO <= dout_c && CI <= in_c, "p4c_conv_wgrad_compact: CO <= dout_c and CI <= in_c");
+    int64_t ntiles = (int64_t)B * conv_tiles_per_sample(H, W);
+    const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
+    return conv_wgrad_bf16_compact(in, in_c, ks, dout, dout_c, (float*)workspace, G, B, H, W, CO, CI, grad, as_stream(stream));
+}

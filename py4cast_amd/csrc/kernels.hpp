@@ -109,6 +109,12 @@ int launch_conv3x3_bf16_rows(const void* in, const void* wp, int ks, const float
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                     const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                     hipStream_t stream, const NormBwdCoef* nb = nullptr);
+// plain convolution / its weight gradient on feature maps with fewer than 64 channels, in place (no padded copies): row kernel only
+bool conv_rows_compact_ok(int storage, int in_cs, int out_cs, int ks, int B, int H, int W);
+int launch_conv_bf16_rows_compact(const void* in, int in_cs, const void* wp, int ks, void* out, int out_cs, int B, int H, int W,
+                                  hipStream_t stream);
+int conv_wgrad_bf16_compact(const void* in, int in_cs, int ks, const void* dout, int dout_cs, float* partial, int G, int B, int H, int W,
+                            int CO, int CIreal, float* grad, hipStream_t stream);
 
 // norm_pool.hip
 int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw, int mode, int groups, const float* gamma,

@@ -1,6 +1,7 @@
 """Thin wrappers over the single-op model entry points (p4c_conv_fwd / p4c_conv_wgrad / p4c_prep_weights):
 used by the parity tests and available for composing other conv models behind the plugin API."""
 
+import os
 from typing import Optional
 
 import torch
@@ -92,6 +93,50 @@ class _ConvNHWC(torch.autograd.Function):
         return dx, dw, None
 
 
+class _ConvCompact(torch.autograd.Function):
+    """The same convolution on bf16 feature maps with fewer than 64 channels, IN PLACE (p4c_conv_fwd_compact / p4c_conv_wgrad_compact):
+    x (B,H,W,C) with C a multiple of 8 up to 64, CO likewise -- no zero-padded 64-channel copy of x, no sliced 64-channel result, and in
+    the backward no zero-filled 64-channel gradient: the row kernel stages absent channel octets as zeros and stores only the present
+    ones.  (SwinUNetR's decoder at 24 / 48 channels: these copies were most of its 552 layout-copy launches per training step.)"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        L.require_cuda(x, w)
+        CO, CI, ks, _ = w.shape
+        B, H, W, C = x.shape
+        wp = prep_weights(w.detach().float(), False, 64, 64, compute="bf16")
+        out = torch.empty(B, H, W, CO, dtype=x.dtype, device=x.device)
+        L.call("p4c_conv_fwd_compact", L.ptr(x), C, L.ptr(wp), ks, L.ptr(out), CO, B, H, W, L.stream(x.device))
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        CO, CI, ks, _ = w.shape
+        B, H, W, C = x.shape
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wpt = prep_weights(w.detach().float(), True, 64, 64, compute="bf16")
+            dx = torch.empty_like(x)
+            L.call("p4c_conv_fwd_compact", L.ptr(dy), CO, L.ptr(wpt), ks, L.ptr(dx), C, B, H, W, L.stream(x.device))
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(CO, CI, ks, ks, dtype=torch.float32, device=x.device)
+            ws = torch.empty(L.lib().p4c_conv_wgrad_workspace_bytes(64, ks) // 4, dtype=torch.float32, device=x.device)
+            L.call("p4c_conv_wgrad_compact", L.ptr(x), C, ks, L.ptr(dy), CO, CO, CI, L.ptr(dw), L.ptr(ws), B, H, W, L.stream(x.device))
+            dw = dw.to(w.dtype)
+        return dx, dw
+
+
+def _compact_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    CO, CI, ks, _ = w.shape
+    B, H, W, C = x.shape
+    return (x.dtype == torch.bfloat16 and C == CI and C % 8 == 0 and CO % 8 == 0 and C <= 64 and CO <= 64 and (C < 64 or CO < 64)
+            and os.environ.get("P4C_NO_COMPACT_CONV") != "1"
+            and bool(L.lib().p4c_conv_compact_supported(C, CO, ks, B, H, W)))
+
+
 def conv_nhwc_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
     CO, CI, ks, ks2 = w.shape
     return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and CO <= 64 and ks == ks2 and ks in (1, 3) and CI <= 96
@@ -103,6 +148,8 @@ def conv_nhwc(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     input channels and 64 output channels: the input is zero-padded to a multiple of 32 channels when needed (one copy), fewer
     output channels run as zero rows of a 64-channel launch and are sliced off (a view)."""
     CO, CI = w.shape[0], w.shape[1]
+    if _compact_ok(x, w):
+        return _ConvCompact.apply(x.contiguous(), w)
     cp = _pad32(CI)
     if x.shape[-1] != cp:
         x = torch.nn.functional.pad(x, (0, cp - x.shape[-1]))

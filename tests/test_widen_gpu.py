@@ -1397,3 +1397,39 @@ def test_graph_memset_nodes_are_rewritten(gpu_device):
     for _ in range(4):
         rb, rw = grads(g.replay)
         assert torch.equal(rb, eb) and torch.equal(rw, ew)
+
+
+# ----------------------------------------------------------------------------------------- compact-channel convolutions (round 3)
+@pytest.mark.parametrize("shape", [(2, 72, 96, 24, 24, 3), (2, 64, 128, 48, 24, 1), (1, 40, 80, 24, 48, 3), (2, 64, 96, 64, 24, 3),
+                                   (2, 48, 72, 48, 64, 3), (2, 512, 512, 48, 24, 3)])
+def test_compact_channel_convolution_equals_the_padded_route(gpu_device, shape, monkeypatch):
+    """ops_model.conv_nhwc on bf16 maps with fewer than 64 channels: the in-place route (p4c_conv_fwd_compact / p4c_conv_wgrad_compact:
+    absent channel octets staged as zeros, only present ones stored) against the zero-padded 64-channel route it replaces -- same
+    kernels, same operands: output and data gradient IDENTICAL, weight gradient to fp32 rounding -- and against float64 on the bf16 operands."""
+    from py4cast_amd import ops_model as om
+
+    B, H, W, C, CO, ks = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, H, W, C, generator=g).bfloat16().to(gpu_device)
+    w = (torch.randn(CO, C, ks, ks, generator=g) * 0.1).to(gpu_device)
+    dy = torch.randn(B, H, W, CO, generator=g).bfloat16().to(gpu_device)
+    res = {}
+    for route in ("compact", "padded"):
+        monkeypatch.setenv("P4C_NO_COMPACT_CONV", "0" if route == "compact" else "1")
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        assert om._compact_ok(xr, wr) == (route == "compact")
+        y = om.conv_nhwc(xr, wr)
+        assert y.shape == (B, H, W, CO) and (route == "padded" or y.is_contiguous())
+        y.backward(dy)
+        res[route] = (y.detach(), xr.grad.detach(), wr.grad.detach())
+    for a, b in zip(res["compact"][:2], res["padded"][:2]):     # output and data gradient: the row kernel either way
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())
+    # (the padded route pads 24 channels to 32 and takes the tiled weight-gradient kernel for them: another summation order)
+    assert _rel(res["compact"][2].cpu(), res["padded"][2].cpu()) < 5e-6
+    if H <= 128:
+        x64, w64 = x.double().permute(0, 3, 1, 2).requires_grad_(True), w.bfloat16().double().requires_grad_(True)
+        ref = torch.nn.functional.conv2d(x64, w64, padding=ks // 2)
+        ref.backward(dy.double().permute(0, 3, 1, 2))
+        assert _rel(res["compact"][0].float().permute(0, 3, 1, 2).cpu(), ref.detach().cpu()) < 8e-3
+        assert _rel(res["compact"][1].float().permute(0, 3, 1, 2).cpu(), x64.grad.cpu()) < 8e-3
+        assert _rel(res["compact"][2].cpu(), w64.grad.cpu()) < 2e-3
