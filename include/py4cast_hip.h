@@ -582,6 +582,17 @@ int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* 
                     const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres, int dtype,
                     int B, int64_t N, int C, p4c_stream_t stream);
 
+/* The statistics of one normalisation from its partial sums, one launch each way (instead of a dozen tiny torch launches):
+ *   forward : mean, rstd, scale = rstd * gamma, shift = beta - mean * scale  -- all (B, C) fp32; statistics per channel (groups = 0:
+ *             instance norm) or per group of C / groups channels (GroupNorm; at most 64 channels per group);
+ *   backward: groups = 0: c1 = S0 / N, c2 = S1 / N (the m1 / m2 of p4c_inorm_apply);  groups > 0: the GroupNorm coefficients
+ *             c1 = rstd * mean_g(gamma S0), c2 = rstd^2 * mean_g(gamma S1) of p4c_inorm_apply's rstd == NULL form;
+ *             dgamma[c] = sum_b S1[b,c], dbeta[c] = sum_b S0[b,c] (written), S0 / S1 = the two backward sums of p4c_inorm_reduce. */
+int p4c_inorm_finalize_fwd(const float* partial, int nblk, int B, int64_t N, int C, int groups, const float* gamma, const float* beta,
+                           float eps, float* mean, float* rstd, float* scale, float* shift, p4c_stream_t stream);
+int p4c_inorm_finalize_bwd(const float* partial, int nblk, int B, int64_t N, int C, int groups, const float* gamma, const float* rstd,
+                           float* c1, float* c2, float* dgamma, float* dbeta, p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,110 @@ static int blocks_for(int64_t N, int rows) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Statistics finalize: what ops_inorm did with a dozen tiny torch launches per normalisation (partial.sum, /N, mean^2, clamp, rsqrt,
+// casts, muls, contiguous ...: ~1 500 launches per SwinUNetR training step) as ONE launch each way.
+// cpg = channels per statistics group (1: instance norm; C / groups: group norm); a workgroup owns whole groups: CB channels,
+// CB = 64 rounded down to a multiple of cpg (the host guarantees cpg <= 64).  Threads = CB channels x SL slices over the partial
+// blocks; sums in a fixed order (slice-strided, then a tree over the slices), the per-group math in double.
+//   forward : mean, rstd, scale = rstd * gamma, shift = beta - mean * scale            -- all (B, C)
+//   backward: mode 0 (instance): c1 = S0 / N, c2 = S1 / N            (p4c_inorm_apply forms dx = scale (dz - c1 - xhat c2))
+//             mode 1 (group)   : c1 = rstd M1, c2 = rstd^2 M2 with M1 / M2 = mean over the group of gamma S0 / gamma S1
+//             and dgamma[c] = sum_b S1[b, c], dbeta[c] = sum_b S0[b, c] (written, not accumulated), b in order.
+__device__ __forceinline__ void slice_sums(const float* __restrict__ part, int nb, int C, int c, int sl, int SL, float* red0, float* red1,
+                                           int tid_c, int CBp) {
+    const bool active = sl < SL;            // (256 threads need not be a multiple of the channel block: the rest only meet the barriers)
+    if (active) {
+        float s0 = 0.f, s1 = 0.f;
+        if (c < C)
+            for (int k = sl; k < nb; k += SL) {
+                s0 += part[((int64_t)k * 2 + 0) * C + c];
+                s1 += part[((int64_t)k * 2 + 1) * C + c];
+            }
+        red0[sl * CBp + tid_c] = s0;
+        red1[sl * CBp + tid_c] = s1;
+    }
+    __syncthreads();
+    for (int off = SL >> 1; off > 0; off >>= 1) {
+        if (active && sl < off) {
+            red0[sl * CBp + tid_c] += red0[(sl + off) * CBp + tid_c];
+            red1[sl * CBp + tid_c] += red1[(sl + off) * CBp + tid_c];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) finalize_fwd_kernel(const float* __restrict__ part, int nb, int C, int cpg, double n_group,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
+                                                           float* __restrict__ shift, int CB, int SL) {
+    __shared__ float red0[256], red1[256];
+    const int b = blockIdx.y, tid_c = threadIdx.x % CB, sl = threadIdx.x / CB;
+    const int c = blockIdx.x * CB + tid_c;
+    slice_sums(part + (int64_t)b * nb * 2 * C, nb, C, c, sl, SL, red0, red1, tid_c, CB);
+    if (sl == 0 && c < C) {
+        const int g0 = tid_c - tid_c % cpg;
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = 0; j < cpg; ++j) { s0 += (double)red0[g0 + j]; s1 += (double)red1[g0 + j]; }
+        const double mu = s0 / n_group;
+        double var = s1 / n_group - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)eps)), m = (float)mu;
+        const float sc = r * gamma[c];
+        mean[(int64_t)b * C + c] = m;
+        rstd[(int64_t)b * C + c] = r;
+        scale[(int64_t)b * C + c] = sc;
+        shift[(int64_t)b * C + c] = beta[c] - m * sc;
+    }
+}
+
+__global__ void __launch_bounds__(256) finalize_bwd_kernel(const float* __restrict__ part, int nb, int B, int C, int cpg, double n_group,
+                                                           int mode, const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                           float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int CB, int SL) {
+    __shared__ float red0[256], red1[256];
+    const int tid_c = threadIdx.x % CB, sl = threadIdx.x / CB;
+    const int c = blockIdx.x * CB + tid_c;
+    float dg = 0.f, db = 0.f;
+    for (int b = 0; b < B; ++b) {
+        slice_sums(part + (int64_t)b * nb * 2 * C, nb, C, c, sl, SL, red0, red1, tid_c, CB);
+        if (sl == 0 && c < C) {
+            const float S0 = red0[tid_c], S1 = red1[tid_c];
+            db += S0;
+            dg += S1;
+            if (mode == 0) {
+                c1[(int64_t)b * C + c] = (float)((double)S0 / n_group);
+                c2[(int64_t)b * C + c] = (float)((double)S1 / n_group);
+            } else {
+                const int g0 = tid_c - tid_c % cpg, cg0 = c - tid_c % cpg;
+                double m1 = 0.0, m2 = 0.0;
+                for (int j = 0; j < cpg; ++j) {
+                    m1 += (double)gamma[cg0 + j] * (double)red0[g0 + j];
+                    m2 += (double)gamma[cg0 + j] * (double)red1[g0 + j];
+                }
+                const double r = (double)rstd[(int64_t)b * C + c];
+                c1[(int64_t)b * C + c] = (float)(r * m1 / n_group);
+                c2[(int64_t)b * C + c] = (float)(r * r * m2 / n_group);
+            }
+        }
+        __syncthreads();
+    }
+    if (sl == 0 && c < C) {
+        dgamma[c] = dg;
+        dbeta[c] = db;
+    }
+}
+
+static void finalize_geometry(int C, int cpg, int* CB, int* SL, int* blocks) {
+    int cb = 64 - 64 % cpg;
+    if (cb > C) cb = C;
+    int sl = 1;
+    while (sl * 2 * cb <= 256) sl *= 2;   // power of two slices (tree)
+    *CB = cb;
+    *SL = sl;
+    *blocks = (C + cb - 1) / cb;
+}
+
 }  // namespace inorm
 }  // namespace p4c
 
@@ -170,5 +274,32 @@ extern "C" int p4c_inorm_apply(const void* x, const void* res, const void* dy, c
     else return fail(P4C_ERR_INVALID, "p4c_inorm_apply: bad dtype");
 #undef P4C_IN_APP
     P4C_CHECK_LAUNCH("p4c_inorm_apply");
+    return P4C_OK;
+}
+
+extern "C" int p4c_inorm_finalize_fwd(const float* partial, int nblk, int B, int64_t N, int C, int groups, const float* gamma, const float* beta,
+                                      float eps, float* mean, float* rstd, float* scale, float* shift, p4c_stream_t stream) {
+    P4C_CHECK_ARG(partial && gamma && beta && mean && rstd && scale && shift && B > 0 && N > 0 && nblk > 0, "p4c_inorm_finalize_fwd: bad arguments");
+    const int cpg = groups > 0 ? C / groups : 1;
+    P4C_CHECK_ARG(C > 0 && (groups <= 0 || C % groups == 0) && cpg <= 64, "p4c_inorm_finalize_fwd: at most 64 channels per group (C %d, groups %d)", C, groups);
+    int CB, SL, blocks;
+    inorm::finalize_geometry(C, cpg, &CB, &SL, &blocks);
+    hipLaunchKernelGGL(inorm::finalize_fwd_kernel, dim3(blocks, B), dim3(256), 0, as_stream(stream), partial, nblk, C, cpg, (double)N * cpg, gamma,
+                       beta, eps, mean, rstd, scale, shift, CB, SL);
+    P4C_CHECK_LAUNCH("p4c_inorm_finalize_fwd");
+    return P4C_OK;
+}
+
+extern "C" int p4c_inorm_finalize_bwd(const float* partial, int nblk, int B, int64_t N, int C, int groups, const float* gamma, const float* rstd,
+                                      float* c1, float* c2, float* dgamma, float* dbeta, p4c_stream_t stream) {
+    P4C_CHECK_ARG(partial && c1 && c2 && dgamma && dbeta && B > 0 && N > 0 && nblk > 0, "p4c_inorm_finalize_bwd: bad arguments");
+    const int cpg = groups > 0 ? C / groups : 1;
+    P4C_CHECK_ARG(C > 0 && (groups <= 0 || (C % groups == 0 && gamma && rstd)) && cpg <= 64,
+                  "p4c_inorm_finalize_bwd: at most 64 channels per group; the group form needs gamma and rstd");
+    int CB, SL, blocks;
+    inorm::finalize_geometry(C, cpg, &CB, &SL, &blocks);
+    hipLaunchKernelGGL(inorm::finalize_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), partial, nblk, B, C, cpg, (double)N * cpg,
+                       groups > 0 ? 1 : 0, gamma, rstd, c1, c2, dgamma, dbeta, CB, SL);
+    P4C_CHECK_LAUNCH("p4c_inorm_finalize_bwd");
     return P4C_OK;
 }

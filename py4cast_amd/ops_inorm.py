@@ -9,14 +9,43 @@ import torch
 from . import _lib as L
 
 
-def _reduce(x, dy, y, mean, rstd, slope):
+def _partials(x, dy, y, mean, rstd, slope):
+    """p4c_inorm_reduce: per-block partial sums (B, nb, 2, C)"""
     B, C = x.shape[0], x.shape[-1]
     N = x.numel() // (B * C)
     nb = L.lib().p4c_inorm_blocks(N, C)
     part = torch.empty(B, nb, 2, C, dtype=torch.float32, device=x.device)
     L.call("p4c_inorm_reduce", L.ptr(x), L.ptr(dy), L.ptr(y), L.ptr(mean), L.ptr(rstd), float(slope), L.ptr(part), L.dtype_code(x.dtype),
            B, N, C, L.stream(x.device))
+    return part, nb, N
+
+
+def _reduce(x, dy, y, mean, rstd, slope):
+    part, _, N = _partials(x, dy, y, mean, rstd, slope)
     return part.sum(dim=1), N       # (B, 2, C): fixed order
+
+
+def _f32(p):
+    return p.detach() if p.dtype == torch.float32 else p.detach().float()
+
+
+def _finalize_fwd(part, nb, N, C, groups, weight, bias, eps):
+    """mean, rstd, scale, shift (B, C) from the partial sums in ONE launch (p4c_inorm_finalize_fwd)"""
+    B = part.shape[0]
+    st = torch.empty(4, B, C, dtype=torch.float32, device=part.device)
+    L.call("p4c_inorm_finalize_fwd", L.ptr(part), nb, B, N, C, groups, L.ptr(_f32(weight)), L.ptr(_f32(bias)), float(eps), L.ptr(st[0]), L.ptr(st[1]),
+           L.ptr(st[2]), L.ptr(st[3]), L.stream(part.device))
+    return st[0], st[1], st[2], st[3]
+
+
+def _finalize_bwd(part, nb, N, C, groups, weight, rstd):
+    """c1, c2 (B, C) and dgamma, dbeta (C) from the backward partial sums in ONE launch (p4c_inorm_finalize_bwd)"""
+    B = part.shape[0]
+    co = torch.empty(2, B, C, dtype=torch.float32, device=part.device)
+    dgb = torch.empty(2, C, dtype=torch.float32, device=part.device)
+    L.call("p4c_inorm_finalize_bwd", L.ptr(part), nb, B, N, C, groups, L.ptr(_f32(weight)) if groups else None, L.ptr(rstd) if groups else None,
+           L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]), L.stream(part.device))
+    return co[0], co[1], dgb[0], dgb[1]
 
 
 class _InstNormAct(torch.autograd.Function):
@@ -26,16 +55,12 @@ class _InstNormAct(torch.autograd.Function):
         x = x.contiguous()
         res_c = None if res is None else res.contiguous()
         B, C = x.shape[0], x.shape[-1]
-        sums, N = _reduce(x, None, None, None, None, slope)
-        mean = sums[:, 0] / N
-        var = (sums[:, 1] / N - mean * mean).clamp_min(0)
-        rstd = torch.rsqrt(var + eps)
-        scale = (rstd * weight.float()).contiguous()
-        shift = (bias.float() - mean * scale).contiguous()
+        part, nb, N = _partials(x, None, None, None, None, slope)
+        mean, rstd, scale, shift = _finalize_fwd(part, nb, N, C, 0, weight, bias, eps)
         y = torch.empty_like(x)
         L.call("p4c_inorm_apply", L.ptr(x), L.ptr(res_c), None, None, L.ptr(scale), L.ptr(shift), None, None, None, None, float(slope),
                L.ptr(y), None, L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
-        ctx.save_for_backward(x, y, mean.contiguous(), rstd.contiguous(), scale)
+        ctx.save_for_backward(x, y, mean, rstd, scale)
         ctx.slope, ctx.has_res, ctx.pdtype = slope, res is not None, weight.dtype
         return y
 
@@ -44,15 +69,13 @@ class _InstNormAct(torch.autograd.Function):
         x, y, mean, rstd, scale = ctx.saved_tensors
         B, C = x.shape[0], x.shape[-1]
         dy = dy.contiguous()
-        sums, N = _reduce(x, dy, y, mean, rstd, ctx.slope)
-        m1, m2 = (sums[:, 0] / N).contiguous(), (sums[:, 1] / N).contiguous()
+        part, nb, N = _partials(x, dy, y, mean, rstd, ctx.slope)
+        m1, m2, dgamma, dbeta = _finalize_bwd(part, nb, N, C, 0, None, None)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         L.call("p4c_inorm_apply", L.ptr(x), None, L.ptr(dy), L.ptr(y), L.ptr(scale), None, L.ptr(mean), L.ptr(rstd), L.ptr(m1), L.ptr(m2),
                float(ctx.slope), L.ptr(dx), L.ptr(dres), L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
-        dgamma = sums[:, 1].sum(dim=0).to(ctx.pdtype)
-        dbeta = sums[:, 0].sum(dim=0).to(ctx.pdtype)
-        return dx, dgamma, dbeta, dres, None, None
+        return dx, dgamma.to(ctx.pdtype), dbeta.to(ctx.pdtype), dres, None, None
 
 
 def supported(x: torch.Tensor) -> bool:
@@ -76,15 +99,20 @@ class _GroupNorm(torch.autograd.Function):
         L.require_cuda(x)
         x = x.contiguous()
         B, C = x.shape[0], x.shape[-1]
-        sums, N = _reduce(x, None, None, None, None, 1.0)                   # (B, 2, C): sum x, sum x^2
-        n = float(N * (C // groups))
-        gs = sums.view(B, 2, groups, C // groups).sum(dim=-1)               # (B, 2, G)
-        mean_g = gs[:, 0] / n
-        rstd_g = torch.rsqrt((gs[:, 1] / n - mean_g * mean_g).clamp_min(0) + eps)
-        mean = mean_g.repeat_interleave(C // groups, dim=1).contiguous()    # (B, C)
-        rstd = rstd_g.repeat_interleave(C // groups, dim=1).contiguous()
-        scale = (rstd * weight.float()).contiguous()
-        shift = (bias.float() - mean * scale).contiguous()
+        ctx.native = C // groups <= 64
+        if ctx.native:   # statistics of the groups in one launch (p4c_inorm_finalize_fwd)
+            part, nb, N = _partials(x, None, None, None, None, 1.0)
+            mean, rstd, scale, shift = _finalize_fwd(part, nb, N, C, groups, weight, bias, eps)
+        else:
+            sums, N = _reduce(x, None, None, None, None, 1.0)                   # (B, 2, C): sum x, sum x^2
+            n = float(N * (C // groups))
+            gs = sums.view(B, 2, groups, C // groups).sum(dim=-1)               # (B, 2, G)
+            mean_g = gs[:, 0] / n
+            rstd_g = torch.rsqrt((gs[:, 1] / n - mean_g * mean_g).clamp_min(0) + eps)
+            mean = mean_g.repeat_interleave(C // groups, dim=1).contiguous()    # (B, C)
+            rstd = rstd_g.repeat_interleave(C // groups, dim=1).contiguous()
+            scale = (rstd * weight.float()).contiguous()
+            shift = (bias.float() - mean * scale).contiguous()
         y = torch.empty_like(x)
         L.call("p4c_inorm_apply", L.ptr(x), None, None, None, L.ptr(scale), L.ptr(shift), None, None, None, None, 1.0, L.ptr(y), None,
                L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
@@ -97,18 +125,23 @@ class _GroupNorm(torch.autograd.Function):
         x, mean, rstd, scale, weight = ctx.saved_tensors
         B, C, G = x.shape[0], x.shape[-1], ctx.groups
         dy = dy.contiguous()
-        sums, N = _reduce(x, dy, x, mean, rstd, 1.0)                        # (B, 2, C): sum dy, sum dy xhat  (slope 1: y is not looked at)
-        n = float(N * (C // G))
-        gam = weight.float()
-        m = (sums * gam).view(B, 2, G, C // G).sum(dim=-1) / n              # (B, 2, G): M1, M2
-        M1 = m[:, 0].repeat_interleave(C // G, dim=1)
-        M2 = m[:, 1].repeat_interleave(C // G, dim=1)
-        c1 = (rstd * M1).contiguous()                                       # dx = scale dy - c1 - (x - mean) c2
-        c2 = (rstd * rstd * M2).contiguous()
+        if ctx.native:
+            part, nb, N = _partials(x, dy, x, mean, rstd, 1.0)                   # sum dy, sum dy xhat  (slope 1: y is not looked at)
+            c1, c2, dgamma, dbeta = _finalize_bwd(part, nb, N, C, G, weight, rstd)
+        else:
+            sums, N = _reduce(x, dy, x, mean, rstd, 1.0)                        # (B, 2, C)
+            n = float(N * (C // G))
+            gam = weight.float()
+            m = (sums * gam).view(B, 2, G, C // G).sum(dim=-1) / n              # (B, 2, G): M1, M2
+            M1 = m[:, 0].repeat_interleave(C // G, dim=1)
+            M2 = m[:, 1].repeat_interleave(C // G, dim=1)
+            c1 = (rstd * M1).contiguous()                                       # dx = scale dy - c1 - (x - mean) c2
+            c2 = (rstd * rstd * M2).contiguous()
+            dgamma, dbeta = sums[:, 1].sum(dim=0), sums[:, 0].sum(dim=0)
         dx = torch.empty_like(x)
         L.call("p4c_inorm_apply", L.ptr(x), None, L.ptr(dy), L.ptr(x), L.ptr(scale), None, L.ptr(mean), None, L.ptr(c1), L.ptr(c2), 1.0,
                L.ptr(dx), None, L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
-        return dx, sums[:, 1].sum(dim=0).to(ctx.pdtype), sums[:, 0].sum(dim=0).to(ctx.pdtype), None, None
+        return dx, dgamma.to(ctx.pdtype), dbeta.to(ctx.pdtype), None, None
 
 
 def group_norm(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
