@@ -493,15 +493,27 @@ __global__ void __launch_bounds__(256, 1)
     }
 }
 
-// dbias_t[head][k][q] = sum over the workgroups of that head, in workgroup order
-__global__ void window_attn_dbias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dbias_t, int heads, int N,
-                                                int GW) {
+// dbias_t[head][k][q] = sum over the workgroups of that head: 32 outputs x 8 slices of the workgroup index per block, the slices
+// combined in slice order (fixed order; one thread walking all GW partials of an output took 35 us at GW = 256)
+__global__ void __launch_bounds__(256) window_attn_dbias_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dbias_t,
+                                                                       int heads, int N, int GW) {
+    __shared__ float red[8][33];
     const int total = heads * N * N;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
+    float s = 0.f;
+    if (i < total) {
         const int q = i % N, k = (i / N) % N, hd = i / (N * N);
-        float s = 0.f;
-        for (int gw = 0; gw < GW; ++gw) s += partial[((int64_t)(gw * heads + hd)) * 4096 + k * 64 + q];
-        dbias_t[i] = s;
+        const float* p = partial + (int64_t)hd * 4096 + k * 64 + q;
+        for (int gw = sl; gw < GW; gw += 8) s += p[(int64_t)gw * heads * 4096];
+    }
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        float t = red[0][e];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += red[j][e];
+        dbias_t[i] = t;
     }
 }
 
@@ -819,7 +831,7 @@ int launch_bwd_exact(const void* qkv, const float* bias_t, const void* dout, voi
     P4C_CHECK_LAUNCH("window_attn_bwd_exact");
     if (partial) {
         const int total = g.heads * g.N * g.N;
-        hipLaunchKernelGGL(window_attn_dbias_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, dbias_t, g.heads,
+        hipLaunchKernelGGL(window_attn_dbias_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, partial, dbias_t, g.heads,
                            g.N, GW);
         P4C_CHECK_LAUNCH("window_attn_dbias_reduce");
     }
@@ -847,7 +859,7 @@ int launch_bwd(const void* qkv, const float* bias_t, const void* dout, void* dqk
     P4C_CHECK_LAUNCH("window_attn_bwd");
     if (partial) {
         const int total = g.heads * g.N * g.N;
-        hipLaunchKernelGGL(window_attn_dbias_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, partial, dbias_t, g.heads,
+        hipLaunchKernelGGL(window_attn_dbias_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, partial, dbias_t, g.heads,
                            g.N, GW);
         P4C_CHECK_LAUNCH("window_attn_dbias_reduce");
     }
