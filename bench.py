@@ -499,6 +499,9 @@ def main():
             n = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
             if n != allocs_before + len(alloc_steps):
                 alloc_steps.append(i)
+    # wall time of the enqueue loop per step: with a full launch queue it tracks the GPU's step time (back-pressure); the host's own
+    # cost of a step, measured with an empty queue, is ~1.9 ms (tools/diagnostics/host_time.py)
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3
     barrier()
     dt = time.perf_counter() - t0
     if trace_allocs:
@@ -583,6 +586,7 @@ def main():
                 "deterministic_library_solvers": bool(torch.backends.cudnn.deterministic),
                 "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
                 "device_allocs_in_timed_region": int(device_allocs),
+                "host_loop_ms_per_step": round(host_enqueue_ms, 3),
                 "launch_mode_probe": probe,
             },
             "loss": float(loss.detach()),
