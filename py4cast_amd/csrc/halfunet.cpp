@@ -253,7 +253,9 @@ struct SideStream {
     // weight-gradient launches waiting for their ordering event: an event record costs the MAIN stream a bubble (rocprofv3: the
     // kernel after one starts 8 us later in the median, 20 us on average), so several blocks share one
     std::vector<std::function<int(hipStream_t)>> pending;
-    int every = 3;   // measured on the benchmark configuration: 1 -> 6.06, 2 -> 5.97, 3 -> 5.91, 4 -> 5.99, 6 -> 6.14 ms per step
+    // measured on the benchmark configuration -- round 1: 1 -> 6.06, 2 -> 5.97, 3 -> 5.91, 4 -> 5.99, 6 -> 6.14 ms per step;
+    // round 3 (fence-free events, deferred join): 1 -> 5.19, 2 -> 5.156, 3 -> 5.168, 4 -> 5.29, 6 -> 5.39, 12 -> 5.38
+    int every = 2;
     // Join deferred over several backward calls (p4c_side_stream_defer): the weight gradients left over at the end of one AR
     // step's backward -- the full-resolution ones, which find nothing to hide behind there -- then run beside the HBM-bound head of
     // the next AR step's chain instead of alone.  `calls` picks the dY buffer set; set_done[s] is recorded on the side stream after
