@@ -342,7 +342,11 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     // (the data-gradient launch of this block must not also take pass 1 of the next normalisation: both loaders in one kernel
     // exceed the register file -- so the blocks whose input is a pooled / summed map: conv 10, 2, 4, 6)
     const bool dgrad_takes_pass1 = din && in_norm && i > 0;
-    const bool nbf = !dgrad_takes_pass1 && d.compute == P4C_BF16 && cip == NF && conv_bf16_norm_bwd_fused_ok(d.dtype, NF, d.B, H, W);
+    // Consumer-side pass 2 for EVERY block: where the data-gradient launch would also take pass 1 of the next normalisation (both
+    // loaders in one kernel exceed the register file) it gives that up and a norm_bwd_reduce launch (2 reads) takes it -- instead of
+    // a norm_bwd_apply launch (2 reads + 1 write) here: 4.96 -> 4.91 ms per step.  P4C_NB_ALL=0: the earlier split.
+    static const bool nb_all = [] { const char* e = getenv("P4C_NB_ALL"); return !(e && e[0] == '0'); }();
+    const bool nbf = (!dgrad_takes_pass1 || nb_all) && d.compute == P4C_BF16 && cip == NF && conv_bf16_norm_bwd_fused_ok(d.dtype, NF, d.B, H, W);
     P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
                      (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i]),
                      grads + L.gamma[i], grads + L.beta[i], nbf ? nullptr : g, st, pre_nblk));
@@ -378,7 +382,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
         // whose pass 1 (sums of g and g * xhat) the ring / row kernel takes while it stores the gradient rows
         const char* fe = getenv("P4C_NO_FUSED_REDUCE");   // (read per call: the parity test switches it)
         const bool fuse_off = fe && fe[0] == '1';
-        const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 &&
+        const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 && !(nbf && dgrad_takes_pass1) &&
                           conv_bf16_bwd_stats_ok(d.dtype, d.B, H, W);
         const RingBwdStats bst{in, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
                                in_norm ? in_norm->mean : nullptr, in_norm ? in_norm->rstd : nullptr};
