@@ -1813,8 +1813,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (MODE >= 2) {
             for (int i = ltid; i < B * 64; i += 256) {
                 const int b = i >> 6, c = i & 63;
-                lnorm[b * 128 + c] = in_scale[(int64_t)b * in_cs + ci_off + c];
-                lnorm[b * 128 + 64 + c] = in_shift[(int64_t)b * in_cs + ci_off + c];
+                const bool have = ci_off + c < in_cs;   // (a half-empty remainder chunk has no channels beyond in_cs)
+                lnorm[b * 128 + c] = have ? in_scale[(int64_t)b * in_cs + ci_off + c] : 0.f;
+                lnorm[b * 128 + 64 + c] = have ? in_shift[(int64_t)b * in_cs + ci_off + c] : 0.f;
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -1904,7 +1905,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ci = ci_off + cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            pbase[((int64_t)t * part_cip + ci) * 64 + cot * 32 + r] = acc[t][i];
+            if (ci < part_cip) pbase[((int64_t)t * part_cip + ci) * 64 + cot * 32 + r] = acc[t][i];   // (a 32-channel remainder runs as a half-empty chunk)
         }
 }
 
@@ -2072,7 +2073,12 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
     for (int off = 0; off < CI;) {
         const int chunk = (CI - off >= 64) ? 64 : 32;
         int rc;
-        const bool ws_ok = chunk == 64 && (ks == 3 || getenv("P4C_NO_WGWS_1X1") == nullptr) && std::is_same<T, __bf16>::value &&
+        // (P4C_WGWS_REM=1, A/B switch: the 32-channel remainder of a 96-channel input -- the first convolution -- on the role-split
+        // kernel as a half-empty 64-channel chunk, absent channel octets staged as zeros; it then takes NormBwdCoef.  Measured:
+        // neutral without NormBwdCoef, 0.04 ms per step SLOWER with it -- block 0's weight gradient is the tail of the backward and
+        // both of its launches then read y as well -- so the tiled kernel and the norm_bwd_apply launch stay the default)
+        const bool rem_ws = chunk == 32 && ks == 3 && off > 0 && getenv("P4C_WGWS_REM") != nullptr;
+        const bool ws_ok = (chunk == 64 || rem_ws) && (ks == 3 || getenv("P4C_NO_WGWS_1X1") == nullptr) && std::is_same<T, __bf16>::value &&
                            B <= wgws::MAXB && getenv("P4C_NO_WGWS") == nullptr;
         if (nb && !ws_ok) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef needs the role-split 3x3 kernel (64-channel chunk, bf16)");
         if (ws_ok)
@@ -2087,11 +2093,17 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
         else
             rc = launch_conv_wgrad_bf16<T, 32, 1>(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, CI, off, CI, stream);
         if (rc != P4C_OK) return rc;
-        rc = diag_skip(8) ? P4C_OK : wgrad_reduce(partial, G * (chunk == 64 ? 1 : 2), ks, CI, off, off + chunk, CO, CIreal, grad, stream);
+        rc = diag_skip(8) ? P4C_OK : wgrad_reduce(partial, G * ((chunk == 64 || ws_ok) ? 1 : 2), ks, CI, off, off + chunk, CO, CIreal, grad, stream);
         if (rc != P4C_OK) return rc;
         off += chunk;
     }
     return P4C_OK;
+}
+
+// every chunk of this weight gradient runs on the role-split kernel, i.e. the launch takes NormBwdCoef
+bool conv_wgrad_bf16_takes_nb(int storage, int CI, int ks, int B) {
+    if (storage != P4C_BF16 || ks != 3 || B > wgws::MAXB || getenv("P4C_NO_WGWS")) return false;
+    return CI % 64 == 0 || (CI % 64 == 32 && CI > 64 && getenv("P4C_WGWS_REM") != nullptr);
 }
 
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,

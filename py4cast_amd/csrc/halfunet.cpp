@@ -346,7 +346,10 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     // loaders in one kernel exceed the register file) it gives that up and a norm_bwd_reduce launch (2 reads) takes it -- instead of
     // a norm_bwd_apply launch (2 reads + 1 write) here: 4.96 -> 4.91 ms per step.  P4C_NB_ALL=0: the earlier split.
     static const bool nb_all = [] { const char* e = getenv("P4C_NB_ALL"); return !(e && e[0] == '0'); }();
-    const bool nbf = (!dgrad_takes_pass1 || nb_all) && d.compute == P4C_BF16 && cip == NF && conv_bf16_norm_bwd_fused_ok(d.dtype, NF, d.B, H, W);
+    // (the first convolution's 96-channel input: its weight gradient runs as a 64-channel chunk + a half-empty one, both on the
+    // role-split kernel -- conv_wgrad_bf16_takes_nb -- and its data gradient, state channels only, is a 64 -> 64 launch)
+    const bool nbf = (!dgrad_takes_pass1 || nb_all) && d.compute == P4C_BF16 && conv_bf16_norm_bwd_fused_ok(d.dtype, NF, d.B, H, W) &&
+                     (cip == NF || (nb_all && getenv("P4C_NO_NB0") == nullptr && conv_wgrad_bf16_takes_nb(d.dtype, cip, 3, d.B)));
     P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
                      (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i]),
                      grads + L.gamma[i], grads + L.beta[i], nbf ? nullptr : g, st, pre_nblk));

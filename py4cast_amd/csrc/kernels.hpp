@@ -110,6 +110,7 @@ int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in
                     const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                     hipStream_t stream, const NormBwdCoef* nb = nullptr);
 // plain convolution / its weight gradient on feature maps with fewer than 64 channels, in place (no padded copies): row kernel only
+bool conv_wgrad_bf16_takes_nb(int storage, int CI, int ks, int B);
 bool conv_rows_compact_ok(int storage, int in_cs, int out_cs, int ks, int B, int H, int W);
 int launch_conv_bf16_rows_compact(const void* in, int in_cs, const void* wp, int ks, void* out, int out_cs, int B, int H, int W,
                                   hipStream_t stream);
