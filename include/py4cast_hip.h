@@ -259,6 +259,26 @@ int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g
                            int kind, int mask_mode, void* dy, int dy_dtype, int y_cs, float* dprev, int64_t dprev_bs,
                            int B, int64_t N, int F, float keep_prev, p4c_stream_t stream);
 
+/* The fused step that ALSO saves d loss_elem / d pred of every element (2 (pred - target) mask for MSE, sign for L1) as bf16 rows --
+ * lgrad: (N, F) per sample, batch stride lgrad_bs elements, 16-byte aligned -- and the backward that reads them instead of the new
+ * state and the target: at F = 60 the backward reads 120 instead of 480 bytes per grid point (the forward writes 120 more).  The
+ * saved values are rounded to bf16 (2^-9 relative), the precision the network gradient dy is stored in anyway: used by the bf16
+ * flavour of the native rollout; the fp32 flavour keeps p4c_ar_update_loss_bwd.  x_next may be NULL (last AR step).
+ * 16-byte path only (as p4c_ar_update_loss_fwd_next); P4C_ERR_UNSUPPORTED otherwise. */
+int p4c_ar_update_loss_fwd_next_saved(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                                      const float* target, int64_t tgt_bs, const float* std, const float* mean,
+                                      const float* border_mask, const float* interior_mask, float* new_state, int64_t new_bs,
+                                      const float* weights, float num_interior, const int32_t* masked_count, int kind,
+                                      int mask_mode, float* loss_out, int64_t loss_stride, void* workspace, int B, int64_t N,
+                                      int F, float keep_prev, void* x_next, int c_pad, const float* statics, int64_t statics_bs,
+                                      int Fs, const float* forcing_next, int64_t forcing_bs, int Ff, void* lgrad, int64_t lgrad_bs,
+                                      p4c_stream_t stream);
+int p4c_ar_update_loss_bwd_saved(const float* g_next, int64_t g_next_bs, const void* g_next2, int g2_dtype, int g2_cs,
+                                 const float* gloss, int64_t gloss_stride, const void* lgrad, int64_t lgrad_bs, const float* std,
+                                 const float* interior_mask, int force_border, const float* weights, float num_interior,
+                                 const int32_t* masked_count, int kind, int mask_mode, void* dy, int dy_dtype, int y_cs,
+                                 float* dprev, int64_t dprev_bs, int B, int64_t N, int F, float keep_prev, p4c_stream_t stream);
+
 /* ====================================================================================
  * Model kernels -- the network arithmetic the reference obtains from mfai v5.0.1
  * (py4cast/models.py:10-20; model forward at py4cast/lightning.py:591-596) and, underneath,

@@ -49,6 +49,9 @@ SIGNATURES = {
     "p4c_ar_update_loss_fwd_next": [P, L, P, I, I, P, L, P, P, P, P, P, L, P, F, P, I, I, P, L, P, I, L, I, F,
                                     P, I, P, L, I, P, L, I, P],
     "p4c_ar_update_loss_bwd": [P, L, P, I, I, P, L, P, L, P, L, P, P, I, P, F, P, I, I, P, I, I, P, L, I, L, I, F, P],
+    "p4c_ar_update_loss_fwd_next_saved": [P, L, P, I, I, P, L, P, P, P, P, P, L, P, F, P, I, I, P, L, P, I, L, I, F,
+                                          P, I, P, L, I, P, L, I, P, L, P],
+    "p4c_ar_update_loss_bwd_saved": [P, L, P, I, I, P, L, P, L, P, P, I, P, F, P, I, I, P, I, I, P, L, I, L, I, F, P],
 }
 OTHER = {
     "p4c_version": ([], c_int),

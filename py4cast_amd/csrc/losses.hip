@@ -490,6 +490,10 @@ struct NextX {
     const float* forcing;
     int64_t forcing_bs;
     int Ff;
+    // optional: d loss_elem / d pred of every element as bf16 rows (N, F) per sample -- what the backward otherwise recomputes
+    // from the new state and the target (480 bytes per grid point read again; 120 written here and read there instead)
+    void* lgrad;
+    int64_t lgrad_bs;
 };
 typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -523,7 +527,9 @@ __global__ void __launch_bounds__(256)
     const float* tsrc = nullptr;
     int64_t tstride = 0;
     TY* xn = nullptr;
-    if (NEXT) {
+    bf16* lgr = nullptr;
+    if (NEXT && nx.lgrad) lgr = reinterpret_cast<bf16*>(nx.lgrad) + (int64_t)b * nx.lgrad_bs;
+    if (NEXT && nx.x) {
         xn = reinterpret_cast<TY*>(nx.x) + (int64_t)b * N * nx.c_pad;
         const int c0 = F + 4 * q, o_forc = F + nx.Fs, c_in = F + nx.Fs + nx.Ff;
         if (c0 < nx.c_pad) {
@@ -539,7 +545,7 @@ __global__ void __launch_bounds__(256)
     }
     const int64_t stride = (int64_t)gridDim.x * 4 * PP;
     for (int64_t n = ((int64_t)blockIdx.x * 4 + wv) * PP + pp; n < N; n += stride) {
-        if (NEXT && tkind != 4) {
+        if (NEXT && xn && tkind != 4) {
             v4f tq = {0, 0, 0, 0};
             if (tkind == 0) tq = *reinterpret_cast<const v4f_a4*>(tsrc + n * tstride);
             else if (tkind == 1) {
@@ -558,7 +564,7 @@ __global__ void __launch_bounds__(256)
         v4f pv = {0, 0, 0, 0};
         if (prev) pv = *reinterpret_cast<const v4f*>(prev + (int64_t)b * prev_bs + e);
         v4f tg = *reinterpret_cast<const v4f*>(target + (int64_t)b * tgt_bs + e);
-        v4f o;
+        v4f o, lg;
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -578,9 +584,11 @@ __global__ void __launch_bounds__(256)
             if (border_mask) pr = bm * t0 + im * pr;
             o[j] = pr;
             s += loss_elem(pr, t0, m, kind) * w[j];
+            if (NEXT) lg[j] = loss_elem_grad(pr, t0, m, kind);
         }
         *reinterpret_cast<v4f*>(new_state + (int64_t)b * new_bs + e) = o;
-        if (NEXT) store4f(xn + n * nx.c_pad + 4 * q, o);
+        if (NEXT && xn) store4f(xn + n * nx.c_pad + 4 * q, o);
+        if (NEXT && lgr) store4f(lgr + e, lg);
         acc += s * im;
     }
     acc = wave_sum(acc);
@@ -589,7 +597,8 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <typename TY>
+// SAVED: `new_state` holds bf16 rows of d loss_elem / d pred written by the forward (NextX::lgrad; stride new_bs), `target` is unused
+template <typename TY, bool SAVED = false>
 __global__ void __launch_bounds__(256)
     ar_update_loss_bwd_v4_kernel(const float* __restrict__ g_next, int64_t g_next_bs, const TY* __restrict__ g_next2,
                                  int g2_cs, const float* __restrict__ gloss, int64_t gloss_stride,
@@ -620,8 +629,13 @@ __global__ void __launch_bounds__(256)
             const float sc = scale * im;
             const float blend = force_border ? im : 1.0f;
             const int64_t e = n * F + 4 * q;
-            const v4f ns = *reinterpret_cast<const v4f*>(new_state + (int64_t)b * new_bs + e);
-            const v4f tg = *reinterpret_cast<const v4f*>(target + (int64_t)b * tgt_bs + e);
+            v4f ns = {0, 0, 0, 0}, tg = {0, 0, 0, 0}, lgv = {0, 0, 0, 0};
+            if (SAVED) {
+                lgv = load4f(reinterpret_cast<const bf16*>(new_state) + (int64_t)b * new_bs + e);
+            } else {
+                ns = *reinterpret_cast<const v4f*>(new_state + (int64_t)b * new_bs + e);
+                tg = *reinterpret_cast<const v4f*>(target + (int64_t)b * tgt_bs + e);
+            }
             v4f g1 = {0, 0, 0, 0}, g2 = {0, 0, 0, 0};
             if (g_next) g1 = *reinterpret_cast<const v4f*>(g_next + (int64_t)b * g_next_bs + e);
             if (g_next2) g2 = load4f(g_next2 + ((int64_t)b * N + n) * g2_cs + 4 * q);
@@ -633,7 +647,7 @@ __global__ void __launch_bounds__(256)
                     m = (t0 != t0) ? 0.0f : 1.0f;
                     t0 = nan_to_zero(t0);
                 }
-                float g = sc * w[j] * loss_elem_grad(ns[j], t0, m, kind);
+                float g = sc * w[j] * (SAVED ? lgv[j] : loss_elem_grad(ns[j], t0, m, kind));
                 if (g_next) g += g1[j];
                 if (g_next2) g += g2[j];
                 gp[j] = g * blend;
@@ -1022,10 +1036,66 @@ extern "C" int p4c_ar_update_loss_fwd_next(const float* prev, int64_t prev_bs, c
                   "p4c_ar_update_loss_fwd_next: c_pad / Fs must be multiples of 4 and c_pad >= F + Fs + Ff");
     P4C_CHECK_ARG(c_pad / 4 - F / 4 <= pow2_ge64(F / 4), "p4c_ar_update_loss_fwd_next: too many tail channels for one pass");
     P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE, "p4c_ar_update_loss_fwd_next: the NaN-mask input channel is built by p4c_build_x");
-    NextX nx{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff};
+    NextX nx{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff, nullptr, 0};
     return ar_update_loss_fwd_impl(prev, prev_bs, y, y_dtype, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask,
                                    new_state, new_bs, weights, num_interior, masked_count, kind, mask_mode, loss_out,
                                    loss_stride, workspace, B, N, F, keep_prev, &nx, stream);
+}
+
+// The same fused step that ALSO saves d loss_elem / d pred of every element as bf16 rows (lgrad: (N, F) per sample, batch stride
+// lgrad_bs elements) for p4c_ar_update_loss_bwd_saved.  x_next may be NULL (the last AR step: nothing follows).
+extern "C" int p4c_ar_update_loss_fwd_next_saved(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
+                                                 const float* target, int64_t tgt_bs, const float* std, const float* mean,
+                                                 const float* border_mask, const float* interior_mask, float* new_state,
+                                                 int64_t new_bs, const float* weights, float num_interior,
+                                                 const int32_t* masked_count, int kind, int mask_mode, float* loss_out,
+                                                 int64_t loss_stride, void* workspace, int B, int64_t N, int F, float keep_prev,
+                                                 void* x_next, int c_pad, const float* statics, int64_t statics_bs, int Fs,
+                                                 const float* forcing_next, int64_t forcing_bs, int Ff, void* lgrad, int64_t lgrad_bs,
+                                                 p4c_stream_t stream) {
+    P4C_CHECK_ARG(lgrad && lgrad_bs % 4 == 0 && aligned16(lgrad), "p4c_ar_update_loss_fwd_next_saved: lgrad must be 16-byte aligned rows");
+    if (x_next) {
+        P4C_CHECK_ARG(statics && forcing_next, "p4c_ar_update_loss_fwd_next_saved: null pointer");
+        P4C_CHECK_ARG(c_pad % 4 == 0 && c_pad >= F + Fs + Ff && Fs % 4 == 0 && Fs >= 0 && Ff >= 0,
+                      "p4c_ar_update_loss_fwd_next_saved: c_pad / Fs must be multiples of 4 and c_pad >= F + Fs + Ff");
+        P4C_CHECK_ARG(c_pad / 4 - F / 4 <= pow2_ge64(F / 4), "p4c_ar_update_loss_fwd_next_saved: too many tail channels for one pass");
+        P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE, "p4c_ar_update_loss_fwd_next_saved: the NaN-mask input channel is built by p4c_build_x");
+    }
+    NextX nx{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff, lgrad, lgrad_bs};
+    return ar_update_loss_fwd_impl(prev, prev_bs, y, y_dtype, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask,
+                                   new_state, new_bs, weights, num_interior, masked_count, kind, mask_mode, loss_out,
+                                   loss_stride, workspace, B, N, F, keep_prev, &nx, stream);
+}
+
+// Backward of the fused step from the saved loss gradients (bf16 rows written by p4c_ar_update_loss_fwd_next_saved) instead of the
+// new state and the target: 120 instead of 480 bytes read per grid point at F = 60.  16-byte path only (F % 4 == 0, aligned rows).
+extern "C" int p4c_ar_update_loss_bwd_saved(const float* g_next, int64_t g_next_bs, const void* g_next2, int g2_dtype, int g2_cs,
+                                            const float* gloss, int64_t gloss_stride, const void* lgrad, int64_t lgrad_bs,
+                                            const float* std, const float* interior_mask, int force_border, const float* weights,
+                                            float num_interior, const int32_t* masked_count, int kind, int mask_mode, void* dy,
+                                            int dy_dtype, int y_cs, float* dprev, int64_t dprev_bs, int B, int64_t N, int F,
+                                            float keep_prev, p4c_stream_t stream) {
+    P4C_CHECK_ARG(lgrad && interior_mask && weights && dy, "p4c_ar_update_loss_bwd_saved: null pointer");
+    P4C_CHECK_ARG(F > 0 && y_cs >= F && (dy_dtype == P4C_F32 || dy_dtype == P4C_BF16), "p4c_ar_update_loss_bwd_saved: bad F / y_cs / dtype");
+    P4C_CHECK_ARG(dy_dtype == g2_dtype || !g_next2, "p4c_ar_update_loss_bwd_saved: g_next2 dtype must equal dy dtype");
+    const bool ok = F % 4 == 0 && y_cs % 4 == 0 && y_cs / 4 <= 64 && g_next_bs % 4 == 0 && lgrad_bs % 4 == 0 && dprev_bs % 4 == 0 &&
+                    g2_cs % 4 == 0 && aligned16(g_next) && aligned16(g_next2) && aligned16(lgrad) && aligned16(dy) && aligned16(dprev) &&
+                    aligned16(weights) && aligned16(std);
+    if (!ok) return fail(P4C_ERR_UNSUPPORTED, "p4c_ar_update_loss_bwd_saved: needs the 16-byte path (F %% 4 == 0, aligned rows)");
+    const int FP4 = pow2_ge64(y_cs / 4);
+    const int nblk4 = loss_blocks(N, 64 / FP4, B);
+    if (dy_dtype == P4C_F32)
+        hipLaunchKernelGGL((ar_update_loss_bwd_v4_kernel<float, true>), dim3(nblk4, B), dim3(256), 0, as_stream(stream), g_next, g_next_bs,
+                           (const float*)g_next2, g2_cs, gloss, gloss_stride, (const float*)lgrad, lgrad_bs, nullptr, 0, std, interior_mask,
+                           force_border, weights, num_interior, masked_count, kind, mask_mode, (float*)dy, y_cs, dprev, dprev_bs, N, F,
+                           keep_prev, FP4);
+    else
+        hipLaunchKernelGGL((ar_update_loss_bwd_v4_kernel<bf16, true>), dim3(nblk4, B), dim3(256), 0, as_stream(stream), g_next, g_next_bs,
+                           (const bf16*)g_next2, g2_cs, gloss, gloss_stride, (const float*)lgrad, lgrad_bs, nullptr, 0, std, interior_mask,
+                           force_border, weights, num_interior, masked_count, kind, mask_mode, (bf16*)dy, y_cs, dprev, dprev_bs, N, F,
+                           keep_prev, FP4);
+    P4C_CHECK_LAUNCH("p4c_ar_update_loss_bwd_saved");
+    return P4C_OK;
 }
 
 extern "C" int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g_next2, int g2_dtype,

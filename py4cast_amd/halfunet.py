@@ -588,6 +588,11 @@ class _NativeRolloutFn(torch.autograd.Function):
         fuse_next = ((not mask_on_nan) and F % 4 == 0 and F <= 64 and Fs % 4 == 0 and cpad % 4 == 0
                      and cpad // 4 - F // 4 <= lanes)
         x_next = None
+        # bf16 flavour, training: the update kernel also saves the loss gradient of every element as bf16 rows and the backward reads
+        # those instead of the new state and the target (480 -> 120 bytes per grid point; P4C_SAVE_LOSS_GRAD=0: recompute)
+        save_lg = (keep_saved and adt == torch.bfloat16 and fuse_next and mask_mode == L.MASK_NONE
+                   and os.environ.get("P4C_SAVE_LOSS_GRAD", "1") != "0")
+        lgrads = torch.empty(T, B, N, F, dtype=torch.bfloat16, device=dev) if save_lg else None
         for i in range(T):
             prev, sbs_prev = (inputs[:, 0], sbs_input) if i == 0 else (states[:, i], sbs_state)
             if x_next is not None:
@@ -605,7 +610,12 @@ class _NativeRolloutFn(torch.autograd.Function):
                          L.ptr(states[:, i + 1]), sbs_state, L.ptr(weights), num_interior, L.ptr(count), kind, mask_mode,
                          L.ptr(loss[:, i]), T, L.ptr(ws), B, N, F, 1.0)
             x_next = None
-            if fuse_next and i + 1 < T:
+            if save_lg:
+                last = i + 1 == T
+                x_next = None if last else torch.empty(B, H, W, cpad, dtype=adt, device=dev)
+                L.call("p4c_ar_update_loss_fwd_next_saved", *step_args, L.ptr(x_next), cpad, L.ptr(st), sbs, Fs,
+                       L.ptr(None if last else forcing[:, i + 1]), T * N * Ff, Ff, L.ptr(lgrads[i]), N * F, stream)
+            elif fuse_next and i + 1 < T:
                 x_next = torch.empty(B, H, W, cpad, dtype=adt, device=dev)
                 L.call("p4c_ar_update_loss_fwd_next", *step_args, L.ptr(x_next), cpad, L.ptr(st), sbs, Fs,
                        L.ptr(forcing[:, i + 1]), T * N * Ff, Ff, stream)
@@ -617,6 +627,7 @@ class _NativeRolloutFn(torch.autograd.Function):
         ctx.model, ctx.desc, ctx.training = model, desc, training
         ctx.meta = (B, T, H, W, F, force_border, num_interior, kind, mask_mode)
         ctx.tensors = (states, outputs, std, interior_flat, weights, count, xs, saveds)
+        ctx.lgrads = lgrads
         ctx.set_materialize_grads(False)
         pred = states[:, 1:]
         return pred, loss
@@ -674,11 +685,17 @@ class _NativeRolloutFn(torch.autograd.Function):
                 else:
                     dprev.add_(g_pred[:, i])
                 g_next = dprev
-            L.call("p4c_ar_update_loss_bwd", L.ptr(g_next), N * F, L.ptr(dx if have_next else None), acode, NF,
-                   L.ptr(gl[:, i]) if gl is not None else None, T, L.ptr(states[:, i + 1]), sbs_state, L.ptr(outputs[:, i]),
-                   T * N * F, L.ptr(std), L.ptr(interior_flat), int(force_border), L.ptr(weights), num_interior,
-                   L.ptr(count), kind, mask_mode, L.ptr(dy), acode, NF, L.ptr(dprev) if i > 0 else None, N * F, B, N, F,
-                   1.0, stream)
+            if ctx.lgrads is not None:
+                L.call("p4c_ar_update_loss_bwd_saved", L.ptr(g_next), N * F, L.ptr(dx if have_next else None), acode, NF,
+                       L.ptr(gl[:, i]) if gl is not None else None, T, L.ptr(ctx.lgrads[i]), N * F, L.ptr(std), L.ptr(interior_flat),
+                       int(force_border), L.ptr(weights), num_interior, L.ptr(count), kind, mask_mode, L.ptr(dy), acode, NF,
+                       L.ptr(dprev) if i > 0 else None, N * F, B, N, F, 1.0, stream)
+            else:
+                L.call("p4c_ar_update_loss_bwd", L.ptr(g_next), N * F, L.ptr(dx if have_next else None), acode, NF,
+                       L.ptr(gl[:, i]) if gl is not None else None, T, L.ptr(states[:, i + 1]), sbs_state, L.ptr(outputs[:, i]),
+                       T * N * F, L.ptr(std), L.ptr(interior_flat), int(force_border), L.ptr(weights), num_interior,
+                       L.ptr(count), kind, mask_mode, L.ptr(dy), acode, NF, L.ptr(dprev) if i > 0 else None, N * F, B, N, F,
+                       1.0, stream)
             d = desc if i > 0 else desc0
             L.call("p4c_halfunet_backward", ctypes.byref(d), L.ptr(xs[i]), L.ptr(flat), L.ptr(dy),
                    L.ptr(dx) if i > 0 else None, L.ptr(gflat), L.ptr(saveds[i]), L.ptr(scratch), int(ctx.training), stream)
