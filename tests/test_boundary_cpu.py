@@ -137,3 +137,35 @@ def test_tuned_gemm_selections_file_and_switches():
     assert run({"P4C_NO_TUNED_GEMMS": "1"}) == ["None", "None", "False"]
     assert run({"PYTORCH_TUNABLEOP_ENABLED": "0"}) == ["0", "None", "False"]
     assert run({"PYTORCH_TUNABLEOP_ENABLED": "1", "PYTORCH_TUNABLEOP_TUNING": "1"}) == ["1", "1", "False"]   # the user's own tuning session
+
+
+def test_library_conv2d_pins_determinism_only_around_the_call():
+    """ops_model.library_conv2d (the few convolutions of SwinUNetR / UNetRPP the MFMA kernels do not serve) pins the library's
+    deterministic solvers for its own forward and backward and leaves the host application's setting alone; on the CPU it is
+    F.conv2d."""
+    import torch
+
+    from py4cast_amd import ops_model as om
+
+    x = torch.randn(2, 5, 9, 11, requires_grad=True)
+    w = torch.randn(7, 5, 3, 3, requires_grad=True)
+    b = torch.randn(7, requires_grad=True)
+    for keep in (False, True):
+        torch.backends.cudnn.deterministic = keep
+        try:
+            y = om.library_conv2d(x, w, b, padding=(1, 1))
+            ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+            assert torch.equal(y, ref)
+            gx, gw, gb = torch.autograd.grad(y, (x, w, b), torch.ones_like(y))
+            rx, rw, rb = torch.autograd.grad(ref, (x, w, b), torch.ones_like(ref))
+            assert torch.allclose(gx, rx) and torch.allclose(gw, rw) and torch.allclose(gb, rb)
+            assert torch.backends.cudnn.deterministic is keep
+        finally:
+            torch.backends.cudnn.deterministic = False
+    # the autograd node itself (what runs on the GPU), on CPU tensors: same numbers, flag restored after forward and backward
+    y2 = om._LibraryConv.apply(x, w, b, (1, 1), (1, 1), (1, 1), 1)
+    assert torch.allclose(y2, torch.nn.functional.conv2d(x, w, b, padding=1), atol=1e-5)
+    g2 = torch.autograd.grad(y2, (x, w, b), torch.ones_like(y2))
+    r2 = torch.autograd.grad(torch.nn.functional.conv2d(x, w, b, padding=1), (x, w, b), torch.ones_like(y2))
+    assert all(torch.allclose(a, c, atol=1e-4) for a, c in zip(g2, r2))
+    assert torch.backends.cudnn.deterministic is False
