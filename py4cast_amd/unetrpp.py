@@ -170,6 +170,30 @@ class ResBlock(nn.Module):
         return F.leaky_relu(y + r, 0.01)
 
 
+class _SplitQKVV(torch.autograd.Function):
+    """q, k, v_ca, v_sa as (B, h, N, d) views of the (B, N, 4, h, d) projection -- as one autograd node.  Through autograd's own view
+    nodes each of the four gradients came back as a zero-filled full-size tensor plus a copy, and the four were then summed (four
+    fills, four copies and three additions of the whole (B, N, 4C) tensor per block); here the four gradients are copied into one
+    buffer."""
+
+    @staticmethod
+    def forward(ctx, qkvv):
+        ctx.shape = qkvv.shape
+        return tuple(qkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, N, _, h, d = ctx.shape
+        ref = next(g for g in grads if g is not None)
+        out = torch.empty(B, N, 4, h, d, dtype=ref.dtype, device=ref.device)
+        for i, g in enumerate(grads):
+            if g is None:
+                out[:, :, i].zero_()
+            else:
+                out[:, :, i].copy_(g.permute(0, 2, 1, 3))
+        return out
+
+
 class EPA(nn.Module):
     """Efficient paired attention on the tall-skinny kernels.  With q, k, v_ca, v_sa the (N x d) token matrices of a head:
         G = q^T k,  nq = ||q columns||,  nk likewise          (gram: three reductions over the tokens)
@@ -195,7 +219,7 @@ class EPA(nn.Module):
         B, N, C = x.shape
         h, d = self.heads, C // self.heads
         qkvv = _linear(self.qkvv, x).view(B, N, 4, h, d)
-        q, k, v_ca, v_sa = (qkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))          # (B,h,N,d) views, nothing copied
+        q, k, v_ca, v_sa = _SplitQKVV.apply(qkvv)                                          # (B,h,N,d) views, nothing copied
         if d % 4:
             raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")
         eps = 1e-12                                                                        # F.normalize's clamp
@@ -206,7 +230,7 @@ class EPA(nn.Module):
         x_ca = TS.apply(v_ca, A.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
         # token-axis projection (shared weights): (B, C, N) @ (N, p) for k and v_sa at once -- a library GEMM
         W, bias = self.E.weight.to(x.dtype), self.E.bias.float()
-        kv = torch.stack([qkvv[:, :, 1].reshape(B, N, C), qkvv[:, :, 3].reshape(B, N, C)], dim=1)   # (B,2,N,C)
+        kv = torch.stack([k.permute(0, 2, 1, 3).reshape(B, N, C), v_sa.permute(0, 2, 1, 3).reshape(B, N, C)], dim=1)   # (B,2,N,C)
         proj = R.add_bias((kv.transpose(-1, -2) @ W.t()).float(), bias)                              # (B,2,C,p); bias gradient as a GEMM
         KP, VP = proj[:, 0].view(B, h, d, -1), proj[:, 1].view(B, h, d, -1)
         Mq = KP / nq.unsqueeze(-1) * self.temperature2
