@@ -1,5 +1,5 @@
 import sys, torch, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from py4cast_amd import ops_model as om
 dev = torch.device('cuda:0')
 B, H, W = 2, 512, 512
