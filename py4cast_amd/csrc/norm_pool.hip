@@ -827,8 +827,67 @@ int norm_bwd(int storage, const void* dA, const void* y, const float* scale, con
                              training, partial, k1, k2, dgamma, dbeta, (float*)dY, stream, pre_nblk);
 }
 
+// pool_fwd for bf16 storage: 16-byte accesses (8 channels per thread), the sample's scale / shift in registers (grid.y = sample),
+// two output pixels in flight, 32-bit index arithmetic -- the same fp32 arithmetic per element as pool_fwd_kernel
+__global__ void __launch_bounds__(256)
+    pool_fwd_bf16x8_kernel(const __bf16* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int H, int W,
+                           __bf16* __restrict__ P) {
+    const int b = blockIdx.y;
+    const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[b * C + 8 * c8 + j]; sh[j] = shift[b * C + 8 * c8 + j]; }
+    const int Ho = H / 2, Wo = W / 2, npx = Ho * Wo;
+    const norm_u32x4* yb = reinterpret_cast<const norm_u32x4*>(y + (int64_t)b * H * W * C);
+    norm_u32x4* pb = reinterpret_cast<norm_u32x4*>(P + (int64_t)b * npx * C);
+    const int stride = gridDim.x * 32;
+    for (int p0 = blockIdx.x * 32 + pl; p0 < npx; p0 += 2 * stride) {
+        norm_u32x4 v[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + u * stride;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = norm_u32x4{0u, 0u, 0u, 0u};
+            if (p < npx) {
+                const int Y = p / Wo, X = p - Y * Wo;
+                const int64_t base = ((int64_t)(2 * Y) * W + 2 * X) * 8 + c8;
+                v[u][0] = yb[base];
+                v[u][1] = yb[base + 8];
+                v[u][2] = yb[base + (int64_t)W * 8];
+                v[u][3] = yb[base + (int64_t)W * 8 + 8];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = p0 + u * stride;
+            if (p >= npx) continue;
+            float m[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float f[8];
+                unpack8(v[u][k], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+                    m[j] = k == 0 ? a : fmaxf(m[j], a);
+                }
+            }
+            pb[(int64_t)p * 8 + c8] = pack8(m);
+        }
+    }
+}
+
 template <typename T>
 static int pool_fwd_t(const T* y, const float* scale, const float* shift, int B, int H, int W, T* P, hipStream_t stream) {
+    if (std::is_same<T, __bf16>::value && getenv("P4C_POOL_V1") == nullptr && (int64_t)(H / 2) * (W / 2) < ((int64_t)1 << 30)) {
+        int64_t blocks = ((int64_t)(H / 2) * (W / 2) + 63) / 64;   // two pixel rows of 32 per workgroup and trip
+        const int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1) + 1;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(pool_fwd_bf16x8_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const __bf16*)y, scale, shift, H, W,
+                           (__bf16*)P);
+        P4C_CHECK_LAUNCH("pool_fwd");
+        return P4C_OK;
+    }
     hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * 16)), dim3(256), 0, stream, y,
                        scale, shift, B, H, W, P);
     P4C_CHECK_LAUNCH("pool_fwd");
