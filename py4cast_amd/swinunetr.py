@@ -251,6 +251,7 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
                                    "p4c_row_gemm", "p4c_row_gemm_wgrad")
         self.roofline_from_entry_points = True   # bench.py: time every call of the entry points above
         self.prefers_hip_graph = True            # ~10^3-10^4 launches per training step: replay them from a HIP graph (trainer.GraphedTrainingStep)
+        self._unit_affine = {}                   # (C, device) -> constant (ones, zeros) rows of the hidden states' non-affine LayerNorm
         self.check_required_attributes()
 
     @property
@@ -261,7 +262,16 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         """A Swin hidden state handed to the decoder: layer-normalised over channels without affine (MONAI's proj_out); stays
         features-last."""
         if self._settings.normalize:
-            t = F.layer_norm(t.float(), (t.shape[-1],))
+            C = t.shape[-1]
+            if (C * t.element_size()) % 16 == 0 and C * t.element_size() <= 1024:
+                # the native row LayerNorm with constant unit weight / zero bias (statistics in fp32 from the rows as they are): the
+                # library route was a cast to fp32, an fp32 LayerNorm and a cast back -- 130 us for the first hidden state alone
+                key = (C, t.device)
+                if key not in self._unit_affine:
+                    self._unit_affine[key] = (torch.ones(C, device=t.device), torch.zeros(C, device=t.device))
+                g, b = self._unit_affine[key]
+                return R.row_layer_norm(t.reshape(-1, C), g, b, 1e-5).view(t.shape).to(dt)
+            t = F.layer_norm(t.float(), (C,))
         return t.to(dt)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
