@@ -128,24 +128,31 @@ static int blocks_for(int64_t N, int rows) {
 //   backward: mode 0 (instance): c1 = S0 / N, c2 = S1 / N            (p4c_inorm_apply forms dx = scale (dz - c1 - xhat c2))
 //             mode 1 (group)   : c1 = rstd M1, c2 = rstd^2 M2 with M1 / M2 = mean over the group of gamma S0 / gamma S1
 //             and dgamma[c] = sum_b S1[b, c], dbeta[c] = sum_b S0[b, c] (written, not accumulated), b in order.
-__device__ __forceinline__ void slice_sums(const float* __restrict__ part, int nb, int C, int c, int sl, int SL, float* red0, float* red1,
-                                           int tid_c, int CBp) {
-    const bool active = sl < SL;            // (256 threads need not be a multiple of the channel block: the rest only meet the barriers)
+// per-channel sums of one sample's partial blocks into red0 / red1[0 .. CB): threads = (CB / 4 channel quads) x SL slices over the
+// blocks (16-byte loads; CB is a multiple of 4 -- finalize_geometry), slices combined by a tree, every sum in a fixed order
+__device__ __forceinline__ void slice_sums(const float* __restrict__ part, int nb, int C, int c_lo, int CB, int SL, float* red0, float* red1) {
+    const int nq = CB >> 2;
+    const int q = threadIdx.x % nq, sl = threadIdx.x / nq;
+    const bool active = sl < SL;            // (256 threads need not be a multiple of the quads: the rest only meet the barriers)
+    const int c = c_lo + 4 * q;
     if (active) {
-        float s0 = 0.f, s1 = 0.f;
+        p4c_f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         if (c < C)
             for (int k = sl; k < nb; k += SL) {
-                s0 += part[((int64_t)k * 2 + 0) * C + c];
-                s1 += part[((int64_t)k * 2 + 1) * C + c];
+                s0 += *reinterpret_cast<const p4c_f32x4*>(part + ((int64_t)k * 2 + 0) * C + c);
+                s1 += *reinterpret_cast<const p4c_f32x4*>(part + ((int64_t)k * 2 + 1) * C + c);
             }
-        red0[sl * CBp + tid_c] = s0;
-        red1[sl * CBp + tid_c] = s1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red0[sl * CB + 4 * q + j] = s0[j]; red1[sl * CB + 4 * q + j] = s1[j]; }
     }
     __syncthreads();
     for (int off = SL >> 1; off > 0; off >>= 1) {
         if (active && sl < off) {
-            red0[sl * CBp + tid_c] += red0[(sl + off) * CBp + tid_c];
-            red1[sl * CBp + tid_c] += red1[(sl + off) * CBp + tid_c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red0[sl * CB + 4 * q + j] += red0[(sl + off) * CB + 4 * q + j];
+                red1[sl * CB + 4 * q + j] += red1[(sl + off) * CB + 4 * q + j];
+            }
         }
         __syncthreads();
     }
@@ -155,11 +162,11 @@ __global__ void __launch_bounds__(256) finalize_fwd_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
                                                            float* __restrict__ shift, int CB, int SL) {
-    __shared__ float red0[256], red1[256];
-    const int b = blockIdx.y, tid_c = threadIdx.x % CB, sl = threadIdx.x / CB;
-    const int c = blockIdx.x * CB + tid_c;
-    slice_sums(part + (int64_t)b * nb * 2 * C, nb, C, c, sl, SL, red0, red1, tid_c, CB);
-    if (sl == 0 && c < C) {
+    __shared__ float red0[1024], red1[1024];
+    const int b = blockIdx.y, c_lo = blockIdx.x * CB;
+    slice_sums(part + (int64_t)b * nb * 2 * C, nb, C, c_lo, CB, SL, red0, red1);
+    const int tid_c = threadIdx.x, c = c_lo + tid_c;
+    if (tid_c < CB && c < C) {
         const int g0 = tid_c - tid_c % cpg;
         double s0 = 0.0, s1 = 0.0;
         for (int j = 0; j < cpg; ++j) { s0 += (double)red0[g0 + j]; s1 += (double)red1[g0 + j]; }
@@ -179,13 +186,13 @@ __global__ void __launch_bounds__(256) finalize_bwd_kernel(const float* __restri
                                                            int mode, const float* __restrict__ gamma, const float* __restrict__ rstd,
                                                            float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int CB, int SL) {
-    __shared__ float red0[256], red1[256];
-    const int tid_c = threadIdx.x % CB, sl = threadIdx.x / CB;
-    const int c = blockIdx.x * CB + tid_c;
+    __shared__ float red0[1024], red1[1024];
+    const int c_lo = blockIdx.x * CB;
+    const int tid_c = threadIdx.x, c = c_lo + tid_c;
     float dg = 0.f, db = 0.f;
     for (int b = 0; b < B; ++b) {
-        slice_sums(part + (int64_t)b * nb * 2 * C, nb, C, c, sl, SL, red0, red1, tid_c, CB);
-        if (sl == 0 && c < C) {
+        slice_sums(part + (int64_t)b * nb * 2 * C, nb, C, c_lo, CB, SL, red0, red1);
+        if (tid_c < CB && c < C) {
             const float S0 = red0[tid_c], S1 = red1[tid_c];
             db += S0;
             dg += S1;
@@ -206,17 +213,20 @@ __global__ void __launch_bounds__(256) finalize_bwd_kernel(const float* __restri
         }
         __syncthreads();
     }
-    if (sl == 0 && c < C) {
+    if (tid_c < CB && c < C) {
         dgamma[c] = dg;
         dbeta[c] = db;
     }
 }
 
 static void finalize_geometry(int C, int cpg, int* CB, int* SL, int* blocks) {
-    int cb = 64 - 64 % cpg;
-    if (cb > C) cb = C;
+    // whole groups per workgroup, a multiple of 4 channels (16-byte loads of the partials): lcm(cpg, 4) divides CB
+    int unit = cpg;
+    while (unit % 4) unit += cpg;
+    int cb = unit <= 64 ? 64 - 64 % unit : unit;
+    if (cb > C) cb = C;                   // (C is a multiple of 4 and of cpg: so is C itself)
     int sl = 1;
-    while (sl * 2 * cb <= 256) sl *= 2;   // power of two slices (tree)
+    while (sl * 2 * (cb / 4) <= 256 && sl * 2 * cb <= 1024) sl *= 2;   // power of two slices (tree), red0 / red1 hold SL x CB floats
     *CB = cb;
     *SL = sl;
     *blocks = (C + cb - 1) / cb;
