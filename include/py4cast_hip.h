@@ -571,6 +571,16 @@ int p4c_ts_gram(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t 
 int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, void* out,
                  int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int accumulate,
                  p4c_stream_t stream);
+/* The small matrices of one EPA block in one launch each way (all fp32, contiguous): G = q^T k, Gq = q^T q, Gk = k^T k (B, heads, d, d)
+ * from p4c_ts_gram, KP (B, heads, d, p), temperatures t1 / t2 (heads):
+ *   nq_i = max(sqrt(max(Gq_ii, 0)), 1e-12), nk_j likewise;  A = softmax_j(t1 G_ij / (nq_i nk_j));  Mq_ic = t2 KP_ic / nq_i.
+ * Forward writes At = A^T, Mq, nq, nk (B, heads, d).  Backward: dG, dGq, dGk (zero off the diagonal), dKP and per-(b, head) partials of
+ * the temperature gradients, (B, heads) each, which the caller sums over b.  d <= 64. */
+int p4c_epa_small_fwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, float* At, float* Mq,
+                      float* nq, float* nk, int B, int heads, int d, int p, p4c_stream_t stream);
+int p4c_epa_small_bwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, const float* At,
+                      const float* nq, const float* nk, const float* dAt, const float* dMq, float* dG, float* dGq, float* dGk, float* dKP,
+                      float* dt1_part, float* dt2_part, int B, int heads, int d, int p, p4c_stream_t stream);
 
 /* ====================================================================================
  * Ghost module's cheap operation (HalfUNet with use_ghost, config/CLI/model/halfunet.yaml:22): depthwise 3x3 convolution

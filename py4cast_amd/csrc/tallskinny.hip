@@ -232,3 +232,123 @@ extern "C" int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_
     P4C_CHECK_LAUNCH("p4c_ts_apply");
     return P4C_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The small matrices of one EPA block (UNETR++ efficient paired attention; py4cast_amd/unetrpp.py::EPA) in ONE launch each way.
+// Per (sample, head), with G = q^T k, Gq = q^T q, Gk = k^T k (d x d, from p4c_ts_gram) and KP (d x p):
+//   nq_i = max(sqrt(max(Gq_ii, 0)), eps), nk_j likewise;   A = softmax_j(t1 G_ij / (nq_i nk_j));   Mq_ic = t2 KP_ic / nq_i
+// forward writes At = A^T (what the apply kernel multiplies v with), Mq, nq, nk.  As torch ops this was ~14 launches forward and ~35
+// backward per block (clamps, square roots, outer products, broadcast reductions ...), ~6 000 per UNetRPP training step.
+// One workgroup per (b, h); thread -> row i; everything in fp32, sums in index order (deterministic).
+namespace p4c {
+namespace ts {
+constexpr float EPA_EPS = 1e-12f;   // F.normalize's clamp
+
+__global__ void __launch_bounds__(64) epa_small_fwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
+                                                           const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
+                                                           float* __restrict__ At, float* __restrict__ Mq, float* __restrict__ nq_out,
+                                                           float* __restrict__ nk_out, int heads, int d, int p) {
+    __shared__ float nk[64];
+    const int g = blockIdx.x, h = g % heads, i = threadIdx.x;
+    const float* Gg = G + (int64_t)g * d * d;
+    float nqi = 1.f;
+    if (i < d) {
+        nqi = fmaxf(sqrtf(fmaxf(Gq[(int64_t)g * d * d + i * d + i], 0.f)), EPA_EPS);
+        const float nki = fmaxf(sqrtf(fmaxf(Gk[(int64_t)g * d * d + i * d + i], 0.f)), EPA_EPS);
+        nk[i] = nki;
+        nq_out[(int64_t)g * d + i] = nqi;
+        nk_out[(int64_t)g * d + i] = nki;
+    }
+    __syncthreads();
+    if (i >= d) return;
+    const float s1 = t1[h], s2 = t2[h];
+    float mx = -INFINITY;
+    for (int j = 0; j < d; ++j) mx = fmaxf(mx, Gg[i * d + j] / (nqi * nk[j]) * s1);
+    float sum = 0.f;
+    for (int j = 0; j < d; ++j) sum += expf(Gg[i * d + j] / (nqi * nk[j]) * s1 - mx);
+    const float inv = 1.f / sum;
+    for (int j = 0; j < d; ++j) At[(int64_t)g * d * d + j * d + i] = expf(Gg[i * d + j] / (nqi * nk[j]) * s1 - mx) * inv;
+    for (int c = 0; c < p; ++c) Mq[(int64_t)g * d * p + i * p + c] = KP[(int64_t)g * d * p + i * p + c] / nqi * s2;
+}
+
+// backward: dG, dGq, dGk (zero off the diagonal), dKP, and per-(b, h) partials of dt1 / dt2 (the caller sums them over b)
+__global__ void __launch_bounds__(64) epa_small_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
+                                                           const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
+                                                           const float* __restrict__ At, const float* __restrict__ nq_in, const float* __restrict__ nk_in,
+                                                           const float* __restrict__ dAt, const float* __restrict__ dMq, float* __restrict__ dG,
+                                                           float* __restrict__ dGq, float* __restrict__ dGk, float* __restrict__ dKP,
+                                                           float* __restrict__ dt1_part, float* __restrict__ dt2_part, int heads, int d, int p) {
+    __shared__ float nk[64], col[64][65], red1[64], red2[64];
+    const int g = blockIdx.x, h = g % heads, i = threadIdx.x;
+    const int64_t o2 = (int64_t)g * d * d, op = (int64_t)g * d * p;
+    if (i < d) nk[i] = nk_in[(int64_t)g * d + i];
+    __syncthreads();
+    const float s1 = t1[h], s2 = t2[h];
+    float a1 = 0.f, a2 = 0.f, dnq = 0.f;
+    const float nqi = i < d ? nq_in[(int64_t)g * d + i] : 1.f;
+    if (i < d) {
+        float dot = 0.f;                                    // sum_j dA_ij A_ij
+        for (int j = 0; j < d; ++j) dot += dAt[o2 + j * d + i] * At[o2 + j * d + i];
+        for (int j = 0; j < d; ++j) {
+            const float a = At[o2 + j * d + i];
+            const float dz = a * (dAt[o2 + j * d + i] - dot);          // softmax backward
+            const float r = G[o2 + i * d + j] / (nqi * nk[j]);
+            a1 += dz * r;                                   // dt1
+            const float dr = dz * s1;
+            dG[o2 + i * d + j] = dr / (nqi * nk[j]);
+            dnq -= dr * r / nqi;
+            col[i][j] = -dr * r;                            // contribution to dnk_j (/ nk_j below), summed over i by thread j
+        }
+        for (int c = 0; c < p; ++c) {
+            const float dm = dMq[op + i * p + c], kp = KP[op + i * p + c];
+            dKP[op + i * p + c] = dm * s2 / nqi;
+            a2 += dm * kp / nqi;                            // dt2
+            dnq -= dm * kp * s2 / (nqi * nqi);
+        }
+    }
+    red1[i] = a1;
+    red2[i] = a2;
+    __syncthreads();
+    if (i < d) {
+        float dnk = 0.f;
+        for (int r2 = 0; r2 < d; ++r2) dnk += col[r2][i];
+        dnk /= nk[i];
+        // n = max(sqrt(max(x, 0)), eps): dn/dx = 1 / (2 sqrt(x)) where x > 0 and sqrt(x) > eps, else 0
+        const float xq = Gq[o2 + i * d + i], xk = Gk[o2 + i * d + i];
+        const float gq = (xq > 0.f && sqrtf(xq) > EPA_EPS) ? dnq * 0.5f / sqrtf(xq) : 0.f;
+        const float gk = (xk > 0.f && sqrtf(xk) > EPA_EPS) ? dnk * 0.5f / sqrtf(xk) : 0.f;
+        for (int j = 0; j < d; ++j) {
+            dGq[o2 + i * d + j] = j == i ? gq : 0.f;
+            dGk[o2 + i * d + j] = j == i ? gk : 0.f;
+        }
+    }
+    if (i == 0) {
+        float u = 0.f, v = 0.f;
+        for (int r2 = 0; r2 < d; ++r2) { u += red1[r2]; v += red2[r2]; }
+        dt1_part[g] = u;
+        dt2_part[g] = v;
+    }
+}
+}  // namespace ts
+}  // namespace p4c
+
+extern "C" int p4c_epa_small_fwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, float* At,
+                                 float* Mq, float* nq, float* nk, int B, int heads, int d, int p, p4c_stream_t stream) {
+    P4C_CHECK_ARG(G && Gq && Gk && KP && t1 && t2 && At && Mq && nq && nk, "p4c_epa_small_fwd: null pointer");
+    P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0, "p4c_epa_small_fwd: head width 1..64 (got %d)", d);
+    hipLaunchKernelGGL(ts::epa_small_fwd_kernel, dim3(B * heads), dim3(64), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, Mq, nq, nk, heads, d, p);
+    P4C_CHECK_LAUNCH("p4c_epa_small_fwd");
+    return P4C_OK;
+}
+
+extern "C" int p4c_epa_small_bwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2,
+                                 const float* At, const float* nq, const float* nk, const float* dAt, const float* dMq, float* dG, float* dGq,
+                                 float* dGk, float* dKP, float* dt1_part, float* dt2_part, int B, int heads, int d, int p, p4c_stream_t stream) {
+    P4C_CHECK_ARG(G && Gq && Gk && KP && t1 && t2 && At && nq && nk && dAt && dMq && dG && dGq && dGk && dKP && dt1_part && dt2_part,
+                  "p4c_epa_small_bwd: null pointer");
+    P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0, "p4c_epa_small_bwd: head width 1..64 (got %d)", d);
+    hipLaunchKernelGGL(ts::epa_small_bwd_kernel, dim3(B * heads), dim3(64), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, nq, nk, dAt, dMq, dG, dGq,
+                       dGk, dKP, dt1_part, dt2_part, heads, d, p);
+    P4C_CHECK_LAUNCH("p4c_epa_small_bwd");
+    return P4C_OK;
+}

@@ -96,3 +96,45 @@ def gram(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 def apply(x: torch.Tensor, m: torch.Tensor, out_dtype=None) -> torch.Tensor:
     """(B,H,N,d) @ (B,H,d,e) -> (B,H,N,e), stored token-major ((B,N,H,e) memory): ``.permute(0,2,1,3).reshape(B,N,H*e)`` is a view."""
     return _Apply.apply(x, m, out_dtype or x.dtype)
+
+
+class _EpaSmall(torch.autograd.Function):
+    """The small matrices of an EPA block as one native launch each way (p4c_epa_small_fwd / _bwd; see csrc/tallskinny.hip):
+    (G, Gq, Gk (B,h,d,d) fp32, KP (B,h,d,p) fp32, t1, t2 (h,1,1)) -> At = softmax(t1 G / (nq nk^T))^T (B,h,d,d), Mq = t2 KP / nq (B,h,d,p)."""
+
+    @staticmethod
+    def forward(ctx, G, Gq, Gk, KP, t1, t2):
+        L.require_cuda(G, KP)
+        B, H, d, _ = G.shape
+        p = KP.shape[-1]
+        G, Gq, Gk, KP = (t.detach().float().contiguous() for t in (G, Gq, Gk, KP))
+        t1f, t2f = t1.detach().float().reshape(-1).contiguous(), t2.detach().float().reshape(-1).contiguous()
+        At = torch.empty(B, H, d, d, dtype=torch.float32, device=G.device)
+        Mq = torch.empty(B, H, d, p, dtype=torch.float32, device=G.device)
+        nq = torch.empty(2, B, H, d, dtype=torch.float32, device=G.device)
+        L.call("p4c_epa_small_fwd", L.ptr(G), L.ptr(Gq), L.ptr(Gk), L.ptr(KP), L.ptr(t1f), L.ptr(t2f), L.ptr(At), L.ptr(Mq), L.ptr(nq[0]),
+               L.ptr(nq[1]), B, H, d, p, L.stream(G.device))
+        ctx.save_for_backward(G, Gq, Gk, KP, t1f, t2f, At, nq)
+        ctx.tshape, ctx.tdtype = t1.shape, t1.dtype
+        return At, Mq
+
+    @staticmethod
+    def backward(ctx, dAt, dMq):
+        G, Gq, Gk, KP, t1f, t2f, At, nq = ctx.saved_tensors
+        B, H, d, _ = G.shape
+        p = KP.shape[-1]
+        dAt = torch.zeros_like(At) if dAt is None else dAt.float().contiguous()
+        dMq = torch.zeros_like(KP) if dMq is None else dMq.float().contiguous()
+        out = torch.empty(3, B, H, d, d, dtype=torch.float32, device=G.device)
+        dKP = torch.empty_like(KP)
+        dt = torch.empty(2, B, H, dtype=torch.float32, device=G.device)
+        L.call("p4c_epa_small_bwd", L.ptr(G), L.ptr(Gq), L.ptr(Gk), L.ptr(KP), L.ptr(t1f), L.ptr(t2f), L.ptr(At), L.ptr(nq[0]), L.ptr(nq[1]),
+               L.ptr(dAt), L.ptr(dMq), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(dKP), L.ptr(dt[0]), L.ptr(dt[1]), B, H, d, p,
+               L.stream(G.device))
+        dts = dt.sum(dim=1)                                             # (2, H): over the samples, fixed order
+        return out[0], out[1], out[2], dKP, dts[0].view(ctx.tshape).to(ctx.tdtype), dts[1].view(ctx.tshape).to(ctx.tdtype)
+
+
+def epa_small(G, Gq, Gk, KP, t1, t2):
+    """(At, Mq) of an EPA block from its gram matrices, the token projection KP and the two temperatures (see _EpaSmall)."""
+    return _EpaSmall.apply(G, Gq, Gk, KP, t1, t2)

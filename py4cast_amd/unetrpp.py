@@ -26,6 +26,7 @@ Input / output are features-last (B, H, W, C); H and W must be multiples of 8 * 
 ("torch" | "flash" | "manual" in mfai) is accepted and ignored: all of them are this one fused formulation.
 """
 
+import os
 from dataclasses import dataclass
 from typing import Tuple
 
@@ -223,17 +224,24 @@ class EPA(nn.Module):
         if d % 4:
             raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")
         eps = 1e-12                                                                        # F.normalize's clamp
-        G = TS.gram(q, k)
-        nq = torch.diagonal(TS.gram(q, q), dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(eps)    # (B,h,d)
-        nk = torch.diagonal(TS.gram(k, k), dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(eps)
-        A = (G / (nq.unsqueeze(-1) * nk.unsqueeze(-2)) * self.temperature).softmax(dim=-1)
-        x_ca = TS.apply(v_ca, A.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
+        G, Gq, Gk = TS.gram(q, k), TS.gram(q, q), TS.gram(k, k)
+        fused_small = d <= 64 and x.is_cuda and os.environ.get("P4C_NO_EPA_SMALL") != "1"
+        if not fused_small:
+            nq = torch.diagonal(Gq, dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(eps)    # (B,h,d)
+            nk = torch.diagonal(Gk, dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(eps)
+            A = (G / (nq.unsqueeze(-1) * nk.unsqueeze(-2)) * self.temperature).softmax(dim=-1)
+            x_ca = TS.apply(v_ca, A.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
         # token-axis projection (shared weights): (B, C, N) @ (N, p) for k and v_sa at once -- a library GEMM
         W, bias = self.E.weight.to(x.dtype), self.E.bias.float()
         kv = torch.stack([k.permute(0, 2, 1, 3).reshape(B, N, C), v_sa.permute(0, 2, 1, 3).reshape(B, N, C)], dim=1)   # (B,2,N,C)
         proj = R.add_bias((kv.transpose(-1, -2) @ W.t()).float(), bias)                              # (B,2,C,p); bias gradient as a GEMM
         KP, VP = proj[:, 0].view(B, h, d, -1), proj[:, 1].view(B, h, d, -1)
-        Mq = KP / nq.unsqueeze(-1) * self.temperature2
+        if fused_small:
+            # the small matrices (norms, channel-attention softmax, scaled projection) in one native launch each way: ops_ts.epa_small
+            At, Mq = TS.epa_small(G, Gq, Gk, KP, self.temperature, self.temperature2)
+            x_ca = TS.apply(v_ca, At).permute(0, 2, 1, 3).reshape(B, N, C)
+        else:
+            Mq = KP / nq.unsqueeze(-1) * self.temperature2
         S = TS.apply(q, Mq).softmax(dim=-1)                                                          # (B,h,N,p), token-major memory
         x_sa = TS.apply(S, VP.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
         return torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)

@@ -183,3 +183,34 @@ def test_conv_nhwc_autograd_node(gpu_device, dtype, tol, CI, ks, H, W):
     assert _rel(y.float(), yr) < tol
     assert xg.grad.shape == x.shape and _rel(xg.grad.float(), xr.grad) < tol
     assert _rel(wg.grad, wr.grad) < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 8, 64), (2, 16, 16, 64), (1, 16, 32, 64), (2, 16, 64, 32), (2, 4, 16, 64)])
+def test_epa_small_matrices_native_node(gpu_device, shape):
+    """ops_ts.epa_small (p4c_epa_small_fwd / _bwd: norms, channel-attention softmax and the scaled token projection of an EPA block in
+    one launch each way) against the torch op chain it replaces, in float64, values and every gradient."""
+    from py4cast_amd import ops_ts as TS
+
+    B, H, d, p = shape
+    g = torch.Generator().manual_seed(11)
+    q, k = torch.randn(B, H, 200, d, generator=g), torch.randn(B, H, 200, d, generator=g)
+    G0, Gq0, Gk0 = q.transpose(-1, -2) @ k, q.transpose(-1, -2) @ q, k.transpose(-1, -2) @ k
+    KP0 = torch.randn(B, H, d, p, generator=g)
+    t10, t20 = torch.rand(H, 1, 1, generator=g) + 0.5, torch.rand(H, 1, 1, generator=g) + 0.5
+    dAt, dMq = torch.randn(B, H, d, d, generator=g), torch.randn(B, H, d, p, generator=g)
+
+    def chain(G, Gq, Gk, KP, t1, t2):
+        nq = torch.diagonal(Gq, dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(1e-12)
+        nk = torch.diagonal(Gk, dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(1e-12)
+        A = (G / (nq.unsqueeze(-1) * nk.unsqueeze(-2)) * t1).softmax(dim=-1)
+        return A.transpose(-1, -2), KP / nq.unsqueeze(-1) * t2
+
+    ref_in = [t.double().requires_grad_(True) for t in (G0, Gq0, Gk0, KP0, t10, t20)]
+    At_r, Mq_r = chain(*ref_in)
+    (At_r * dAt.double()).sum().add((Mq_r * dMq.double()).sum()).backward()
+    dev_in = [t.to(gpu_device).requires_grad_(True) for t in (G0, Gq0, Gk0, KP0, t10, t20)]
+    At, Mq = TS.epa_small(*dev_in)
+    ((At * dAt.to(gpu_device)).sum() + (Mq * dMq.to(gpu_device)).sum()).backward()
+    assert _rel(At.detach().cpu(), At_r.detach()) < 2e-6 and _rel(Mq.detach().cpu(), Mq_r.detach()) < 2e-6
+    for name, a, b in zip(("G", "Gq", "Gk", "KP", "t1", "t2"), dev_in, ref_in):
+        assert _rel(a.grad.cpu(), b.grad) < 2e-5, name
