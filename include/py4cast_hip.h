@@ -577,10 +577,15 @@ int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t
  * Forward writes At = A^T, Mq, nq, nk (B, heads, d).  Backward: dG, dGq, dGk (zero off the diagonal), dKP and per-(b, head) partials of
  * the temperature gradients, (B, heads) each, which the caller sums over b.  d <= 64. */
 int p4c_epa_small_fwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, float* At, float* Mq,
-                      float* nq, float* nk, int B, int heads, int d, int p, p4c_stream_t stream);
+                      float* nq, float* nk, int B, int heads, int d, int p, int diag_only, p4c_stream_t stream);
 int p4c_epa_small_bwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, const float* At,
                       const float* nq, const float* nk, const float* dAt, const float* dMq, float* dG, float* dGq, float* dGk, float* dKP,
-                      float* dt1_part, float* dt2_part, int B, int heads, int d, int p, p4c_stream_t stream);
+                      float* dt1_part, float* dt2_part, int B, int heads, int d, int p, int diag_only, p4c_stream_t stream);
+/* diag_only = 1: Gq / Gk (and dGq / dGk) are the DIAGONALS (B, heads, d) -- the column sums of squares of q and k that
+ * p4c_ts_gram_norms produces next to q^T k: partial (B, splits, heads, d*e + d + e) = [X^T Y | sum_n X_ni^2 | sum_n Y_nj^2] (bf16 token
+ * matrices; the caller sums the splits, fixed order). */
+int p4c_ts_gram_norms(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const void* y, int y_dtype, int64_t y_bs,
+                      int64_t y_hs, int64_t y_rs, float* partial, int B, int heads, int64_t N, int d, int e, p4c_stream_t stream);
 
 /* ====================================================================================
  * Ghost module's cheap operation (HalfUNet with use_ghost, config/CLI/model/halfunet.yaml:22): depthwise 3x3 convolution

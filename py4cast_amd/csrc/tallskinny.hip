@@ -48,7 +48,9 @@ __device__ __forceinline__ void stage(float* dst, int ld, const T* src, int64_t 
 // A workgroup serves `hc` heads (blockIdx.z) of one sample and one token split; a thread owns one 4 x 4 block of one head's d x e
 // result (a "task"); when there are fewer tasks than threads the tile's tokens are dealt to `groups` thread groups whose sums
 // are combined through LDS at the end (fixed order).
-template <typename TX, typename TY>
+// NORMS: the partial of a (b, split, head) is d*e + d + e floats: X^T Y, then the column sums of squares of X and of Y (what EPA
+// normalises q and k by) -- accumulated by the tasks of block column / block row 0 from the values they hold anyway.
+template <typename TX, typename TY, bool NORMS = false>
 __global__ void __launch_bounds__(256) gram_kernel(Mat X, Mat Y, float* __restrict__ part, int heads, int64_t N, int d, int e, int nsplit,
                                                    int hc, int tpg) {
     __shared__ __attribute__((aligned(16))) float lds[2 * TOKG * (MAXCOL + 4)];
@@ -70,6 +72,8 @@ __global__ void __launch_bounds__(256) gram_kernel(Mat X, Mat Y, float* __restri
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+    float nx[4] = {0.f, 0.f, 0.f, 0.f}, ny[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool own_x = NORMS && live && (tr % eb) == 0, own_y = NORMS && live && (tr / eb) == 0;
     const int64_t per = (N + nsplit - 1) / nsplit;
     const int64_t n0 = sp * per, n1 = (n0 + per < N) ? n0 + per : N;
     for (int64_t t0 = n0; t0 < n1; t0 += TOKG) {
@@ -86,26 +90,50 @@ __global__ void __launch_bounds__(256) gram_kernel(Mat X, Mat Y, float* __restri
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_fmaf(xv[a], yv[c], acc[a][c]);
+                if (own_x) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) nx[a] = __builtin_fmaf(xv[a], xv[a], nx[a]);
+                }
+                if (own_y) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ny[c] = __builtin_fmaf(yv[c], yv[c], ny[c]);
+                }
             }
         }
     }
-    // combine the token groups (group 0 first, then 1, ...): red[grp][task][16]
+    // combine the token groups (group 0 first, then 1, ...): red[grp][task][16 (+ 8)]
     __syncthreads();
     float* red = lds;
+    constexpr int RS = NORMS ? 24 : 16;
+    const int pstride = NORMS ? d * e + d + e : d * e;
     if (live) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) red[(grp * tpg + task) * 16 + a * 4 + c] = acc[a][c];
+            for (int c = 0; c < 4; ++c) red[(grp * tpg + task) * RS + a * 4 + c] = acc[a][c];
+        if (NORMS) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { red[(grp * tpg + task) * RS + 16 + a] = nx[a]; red[(grp * tpg + task) * RS + 20 + a] = ny[a]; }
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ntasks * 16; i += 256) {
-        const int tk = i >> 4, el = i & 15;
-        float s = 0.f;
-        for (int g2 = 0; g2 < groups; ++g2) s += red[(g2 * tpg + tk) * 16 + el];
+    float* pb = part + (((int64_t)b * nsplit + sp) * heads + h0) * pstride;
+    for (int i = threadIdx.x; i < ntasks * RS; i += 256) {
+        const int tk = i / RS, el = i - tk * RS;
         const int hh = tk / (db * eb), r2 = tk - hh * db * eb;
+        if (el >= 16) {   // column sums of squares: owned by the tasks of block column 0 (X) / block row 0 (Y)
+            const bool isx = el < 20;
+            if (isx ? (r2 % eb) != 0 : (r2 / eb) != 0) continue;
+            float s = 0.f;
+            for (int g2 = 0; g2 < groups; ++g2) s += red[(g2 * tpg + tk) * RS + el];
+            if (isx) pb[(int64_t)hh * pstride + d * e + (r2 / eb) * 4 + (el - 16)] = s;
+            else pb[(int64_t)hh * pstride + d * e + d + (r2 % eb) * 4 + (el - 20)] = s;
+            continue;
+        }
+        float s = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) s += red[(g2 * tpg + tk) * RS + el];
         const int ii = (r2 / eb) * 4 + (el >> 2), jj = (r2 % eb) * 4 + (el & 3);
-        part[((((int64_t)b * nsplit + sp) * heads + h0 + hh) * d + ii) * e + jj] = s;
+        pb[(int64_t)hh * pstride + ii * e + jj] = s;
     }
 }
 
@@ -200,6 +228,33 @@ extern "C" int p4c_ts_gram(const void* x, int x_dtype, int64_t x_bs, int64_t x_h
     return P4C_OK;
 }
 
+// X^T Y together with the column sums of squares of X and Y: partial (B, splits, heads, d*e + d + e) (see gram_kernel<NORMS>)
+extern "C" int p4c_ts_gram_norms(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const void* y, int y_dtype,
+                                 int64_t y_bs, int64_t y_hs, int64_t y_rs, float* partial, int B, int heads, int64_t N, int d, int e,
+                                 p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && y && partial, "p4c_ts_gram_norms: null pointer");
+    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
+                  "p4c_ts_gram_norms: d, e must be multiples of 4 up to %d (got %d, %d)", ts::MAXD, d, e);
+    P4C_CHECK_ARG(x_dtype == P4C_BF16 && y_dtype == P4C_BF16, "p4c_ts_gram_norms: bf16 token matrices");
+    P4C_CHECK_ARG(x_bs % 4 == 0 && x_hs % 4 == 0 && x_rs % 4 == 0 && y_bs % 4 == 0 && y_hs % 4 == 0 && y_rs % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                  "p4c_ts_gram_norms: strides must be multiples of 4 elements, bases 16-byte aligned");
+    const int ns = p4c_ts_gram_splits(N);
+    int hc = 256 / ((d / 4) * (e / 4));
+    if (hc > ts::MAXCOL / d) hc = ts::MAXCOL / d;
+    if (hc > ts::MAXCOL / e) hc = ts::MAXCOL / e;
+    if (hc > heads) hc = heads;
+    if (hc < 1) hc = 1;
+    int tpg = pow2_ge_i(hc * (d / 4) * (e / 4));
+    if (tpg > 256) tpg = 256;
+    if (tpg < 8) tpg = 8;
+    const ts::Mat X{x, x_bs, x_hs, x_rs}, Y{y, y_bs, y_hs, y_rs};
+    const dim3 grid(B, ns, (heads + hc - 1) / hc);
+    hipLaunchKernelGGL((ts::gram_kernel<bf16, bf16, true>), grid, dim3(256), 0, as_stream(stream), X, Y, partial, heads, N, d, e, ns, hc, tpg);
+    P4C_CHECK_LAUNCH("p4c_ts_gram_norms");
+    return P4C_OK;
+}
+
 extern "C" int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs,
                             void* out, int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e,
                             int accumulate, p4c_stream_t stream) {
@@ -247,14 +302,15 @@ constexpr float EPA_EPS = 1e-12f;   // F.normalize's clamp
 __global__ void __launch_bounds__(64) epa_small_fwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
                                                            const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
                                                            float* __restrict__ At, float* __restrict__ Mq, float* __restrict__ nq_out,
-                                                           float* __restrict__ nk_out, int heads, int d, int p) {
+                                                           float* __restrict__ nk_out, int heads, int d, int p, int dstride) {
+    // dstride = d: Gq / Gk are the full (d x d) q^T q / k^T k, only their diagonals are read;  dstride = 1: they ARE the diagonals (B, h, d)
     __shared__ float nk[64];
     const int g = blockIdx.x, h = g % heads, i = threadIdx.x;
     const float* Gg = G + (int64_t)g * d * d;
     float nqi = 1.f;
     if (i < d) {
-        nqi = fmaxf(sqrtf(fmaxf(Gq[(int64_t)g * d * d + i * d + i], 0.f)), EPA_EPS);
-        const float nki = fmaxf(sqrtf(fmaxf(Gk[(int64_t)g * d * d + i * d + i], 0.f)), EPA_EPS);
+        nqi = fmaxf(sqrtf(fmaxf(Gq[(int64_t)g * d * dstride + i * dstride + (dstride > 1 ? i : 0)], 0.f)), EPA_EPS);
+        const float nki = fmaxf(sqrtf(fmaxf(Gk[(int64_t)g * d * dstride + i * dstride + (dstride > 1 ? i : 0)], 0.f)), EPA_EPS);
         nk[i] = nki;
         nq_out[(int64_t)g * d + i] = nqi;
         nk_out[(int64_t)g * d + i] = nki;
@@ -277,7 +333,8 @@ __global__ void __launch_bounds__(64) epa_small_bwd_kernel(const float* __restri
                                                            const float* __restrict__ At, const float* __restrict__ nq_in, const float* __restrict__ nk_in,
                                                            const float* __restrict__ dAt, const float* __restrict__ dMq, float* __restrict__ dG,
                                                            float* __restrict__ dGq, float* __restrict__ dGk, float* __restrict__ dKP,
-                                                           float* __restrict__ dt1_part, float* __restrict__ dt2_part, int heads, int d, int p) {
+                                                           float* __restrict__ dt1_part, float* __restrict__ dt2_part, int heads, int d, int p,
+                                                           int dstride) {
     __shared__ float nk[64], col[64][65], red1[64], red2[64];
     const int g = blockIdx.x, h = g % heads, i = threadIdx.x;
     const int64_t o2 = (int64_t)g * d * d, op = (int64_t)g * d * p;
@@ -314,12 +371,18 @@ __global__ void __launch_bounds__(64) epa_small_bwd_kernel(const float* __restri
         for (int r2 = 0; r2 < d; ++r2) dnk += col[r2][i];
         dnk /= nk[i];
         // n = max(sqrt(max(x, 0)), eps): dn/dx = 1 / (2 sqrt(x)) where x > 0 and sqrt(x) > eps, else 0
-        const float xq = Gq[o2 + i * d + i], xk = Gk[o2 + i * d + i];
+        const int64_t od = (int64_t)g * d * dstride + i * dstride;
+        const float xq = Gq[od + (dstride > 1 ? i : 0)], xk = Gk[od + (dstride > 1 ? i : 0)];
         const float gq = (xq > 0.f && sqrtf(xq) > EPA_EPS) ? dnq * 0.5f / sqrtf(xq) : 0.f;
         const float gk = (xk > 0.f && sqrtf(xk) > EPA_EPS) ? dnk * 0.5f / sqrtf(xk) : 0.f;
-        for (int j = 0; j < d; ++j) {
-            dGq[o2 + i * d + j] = j == i ? gq : 0.f;
-            dGk[o2 + i * d + j] = j == i ? gk : 0.f;
+        if (dstride > 1) {
+            for (int j = 0; j < d; ++j) {
+                dGq[o2 + i * d + j] = j == i ? gq : 0.f;
+                dGk[o2 + i * d + j] = j == i ? gk : 0.f;
+            }
+        } else {
+            dGq[od] = gq;
+            dGk[od] = gk;
         }
     }
     if (i == 0) {
@@ -333,22 +396,24 @@ __global__ void __launch_bounds__(64) epa_small_bwd_kernel(const float* __restri
 }  // namespace p4c
 
 extern "C" int p4c_epa_small_fwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, float* At,
-                                 float* Mq, float* nq, float* nk, int B, int heads, int d, int p, p4c_stream_t stream) {
+                                 float* Mq, float* nq, float* nk, int B, int heads, int d, int p, int diag_only, p4c_stream_t stream) {
     P4C_CHECK_ARG(G && Gq && Gk && KP && t1 && t2 && At && Mq && nq && nk, "p4c_epa_small_fwd: null pointer");
     P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0, "p4c_epa_small_fwd: head width 1..64 (got %d)", d);
-    hipLaunchKernelGGL(ts::epa_small_fwd_kernel, dim3(B * heads), dim3(64), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, Mq, nq, nk, heads, d, p);
+    hipLaunchKernelGGL(ts::epa_small_fwd_kernel, dim3(B * heads), dim3(64), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, Mq, nq, nk, heads, d, p,
+                       diag_only ? 1 : d);
     P4C_CHECK_LAUNCH("p4c_epa_small_fwd");
     return P4C_OK;
 }
 
 extern "C" int p4c_epa_small_bwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2,
                                  const float* At, const float* nq, const float* nk, const float* dAt, const float* dMq, float* dG, float* dGq,
-                                 float* dGk, float* dKP, float* dt1_part, float* dt2_part, int B, int heads, int d, int p, p4c_stream_t stream) {
+                                 float* dGk, float* dKP, float* dt1_part, float* dt2_part, int B, int heads, int d, int p, int diag_only,
+                                 p4c_stream_t stream) {
     P4C_CHECK_ARG(G && Gq && Gk && KP && t1 && t2 && At && nq && nk && dAt && dMq && dG && dGq && dGk && dKP && dt1_part && dt2_part,
                   "p4c_epa_small_bwd: null pointer");
     P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0, "p4c_epa_small_bwd: head width 1..64 (got %d)", d);
     hipLaunchKernelGGL(ts::epa_small_bwd_kernel, dim3(B * heads), dim3(64), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, nq, nk, dAt, dMq, dG, dGq,
-                       dGk, dKP, dt1_part, dt2_part, heads, d, p);
+                       dGk, dKP, dt1_part, dt2_part, heads, d, p, diag_only ? 1 : d);
     P4C_CHECK_LAUNCH("p4c_epa_small_bwd");
     return P4C_OK;
 }

