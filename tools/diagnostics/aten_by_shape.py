@@ -18,7 +18,7 @@ ddp = FlatDDP(lm.model, 1)
 for _ in range(2):
     ddp.zero_grad(); lm.training_step(Bn.make_batch(case), 0).backward()
 torch.cuda.synchronize(); ddp.zero_grad()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     lm.training_step(Bn.make_batch(case), 0).backward(); torch.cuda.synchronize()
 rows = []
 for ev in prof.key_averages(group_by_input_shape=True):
@@ -27,3 +27,12 @@ for ev in prof.key_averages(group_by_input_shape=True):
         rows.append((t, ev.count, ev.key, str(ev.input_shapes)[:80]))
 for t, n, k, shp in sorted(rows, reverse=True)[:26]:
     print(f"{t/1e3:7.2f} ms {n:4d}x {k:28s} {shp}")
+# where do the copies / casts of the full-resolution 64-channel maps come from?  (first frame of this package on the Python stack)
+want = {"aten::copy_", "aten::_to_copy", "aten::contiguous", "aten::clone"}
+by = collections.Counter()
+for e in prof.events():
+    if e.name in want and e.input_shapes and list(e.input_shapes[0]) in ([2, 64, 512, 512], [2, 512, 512, 64]):
+        fr = next((f for f in (e.stack or []) if "py4cast_amd/" in f), "<no python frame: autograd>")
+        by[(e.name, fr.split("py4cast_amd/")[-1][:70])] += 1
+for (n, fr), c in by.most_common(14):
+    print(f"{c:4d}x {n:16s} {fr}")
