@@ -156,7 +156,10 @@ class ResBlock(nn.Module):
             self.norm3 = _norm(norm, cout)
 
     def forward(self, x):
-        if isinstance(self.norm1, nn.InstanceNorm2d) and x.is_contiguous(memory_format=torch.channels_last) and ON.supported(x.permute(0, 2, 3, 1)):
+        # (the norms act on the convolutions' OUTPUT channels: encoder1's 69-channel input is no obstacle)
+        cout = self.conv1.weight.shape[0]
+        if (isinstance(self.norm1, nn.InstanceNorm2d) and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
+                and x.dtype in (torch.float32, torch.bfloat16) and cout % 4 == 0 and cout <= 1024):
             # instance-norm blocks on features-last memory (the full-resolution blocks): norm + LeakyReLU (+ residual) as native nodes
             inorm = lambda m, t, slope=1.0, res=None: ON.instance_norm_act(  # noqa: E731
                 t.permute(0, 2, 3, 1), m.weight, m.bias, m.eps, slope, None if res is None else res.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
@@ -268,6 +271,19 @@ class TransformerBlock(nn.Module):
         return skip + _conv(self.conv8, self.conv51(skip))
 
 
+class _FeaturesLast(torch.autograd.Function):
+    """An NCHW-contiguous tensor as an NCHW-shaped view of features-last memory (one copy), its gradient handed back NCHW-contiguous
+    (one copy) whatever layout it arrives in."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
 class UpBlock(nn.Module):
     def __init__(self, cin, cout, scale, tokens, proj, heads, depth, conv_decoder, linear, norm):
         super().__init__()
@@ -287,6 +303,12 @@ class UpBlock(nn.Module):
             x = F.interpolate(_conv(self.up_conv, x), scale_factor=self.scale, mode="bilinear", align_corners=False)
         else:
             x = _conv_transpose(self.up_conv, x)
+        if self.linear and isinstance(self.decoder_block[0], ResBlock) and x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+            # decoder2: the interpolated x is NCHW-contiguous and so was the sum -- which sent the full-resolution residual block's three
+            # instance norms through the library in fp32 (two casts each) and its convolutions through a layout copy.  _FeaturesLast
+            # hands the block an NCHW-shaped view of features-last memory and the interpolation an NCHW-contiguous gradient (its
+            # backward on a channels_last gradient is an atomics kernel: 7.9 s per step, not reproducible)
+            return self.decoder_block[0](skip + _FeaturesLast.apply(x))
         return self.decoder_block[0](x + skip)
 
 
@@ -371,5 +393,7 @@ class UNetRPPMI355X(ModelABC, nn.Module):
         dec2 = self.decoder4(dec3, hidden[1])
         dec1 = self.decoder3(dec2, hidden[0])
         out = self.decoder2(dec1, conv_block)
-        y = _conv(self.out1, out).permute(0, 2, 3, 1)
+        # (the 1x1 output convolution has a bias and goes to the library: NCHW-contiguous input -- on an NCHW-shaped view of features-last
+        # memory the library's deterministic solver for this shape took 1.1 s per step)
+        y = _conv(self.out1, out.contiguous()).permute(0, 2, 3, 1)
         return y if y.dtype == out_dtype or not out_dtype.is_floating_point else y.to(out_dtype)
