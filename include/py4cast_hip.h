@@ -564,10 +564,17 @@ int p4c_row_mlp_bwd_accumulate(const p4c_row_mlp_desc* d, const p4c_row_mlp_grad
  * p4c_ts_gram_splits(N) partials (fixed order).  A shared operand (the E / F projection weights) has bs = hs = 0.
  * d, e multiples of 4. */
 int p4c_ts_gram_splits(int64_t N);
+/* bf16 x bf16 with d, e multiples of 8 and 16-byte aligned rows runs on the matrix cores (both operands transposed LDS reads of
+ * [token][column] tiles, 64 x 64 result blocks, any width); p4c_ts_gram_wide_ok says whether a (dtypes, d, e) is served that way. */
+int p4c_ts_gram_wide_ok(int x_dtype, int y_dtype, int d, int e);
 int p4c_ts_gram(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const void* y, int y_dtype, int64_t y_bs,
                 int64_t y_hs, int64_t y_rs, float* partial, int B, int heads, int64_t N, int d, int e, p4c_stream_t stream);
 /* apply: out[g] (N x e) = X[g] (N x d) M[g] (d x e, fp32, group stride m_gs elements; 0 = one matrix for all groups)
  * (+ out when accumulate).  The adjoint of gram: the backward of either is the other. */
+/* bf16 token matrices with d, e multiples of 8, d <= 256 (any e) and strides / bases that are multiples of 8 elements / 16 bytes run on
+ * the matrix cores (O^T = M^T X^T: a lane's operand is ONE 16-byte load of its token's row, M^T of the heads in LDS) and are not
+ * limited to 64 columns; p4c_ts_apply_wide_ok says whether a (dtype, d, e) is served that way (P4C_TS_NO_MFMA=1 turns it off). */
+int p4c_ts_apply_wide_ok(int x_dtype, int out_dtype, int d, int e);
 int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, void* out,
                  int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int accumulate,
                  p4c_stream_t stream);

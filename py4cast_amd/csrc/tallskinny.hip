@@ -181,6 +181,281 @@ __global__ void __launch_bounds__(256) apply_kernel(Mat X, const float* __restri
     }
 }
 
+
+// ---- apply on the matrix cores (bf16 token matrices) ------------------------------------------------------------------------
+// O^T = M^T X^T per (sample, head): the A operand is M^T (rows = output columns), the B operand X^T (columns = tokens), so a lane of
+// v_mfma_f32_32x32x16_bf16 needs eight consecutive reduction indices of ONE token -- a single 16-byte load of its row of X straight
+// from HBM, no staging of the token matrix at all -- and ends up with 4 consecutive output columns of its token per 8-row block of the
+// accumulator; the two lanes of a token trade halves (v_permlane32_swap) and store 16 bytes each.  M^T of the workgroup's heads
+// (64 output columns x d, bf16) sits in LDS.  A workgroup = 4 waves = `hw` heads x 4/hw token tiles of 32; blockIdx.z = (head group,
+// 64-column block of the output).  KC = 16-wide reduction chunks (d <= 16 KC): every load of a tile is in flight before its first MFMA.
+typedef float ts_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 ts_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ts_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int ts_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int ts_u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename TO, int KC>
+__global__ void __launch_bounds__(256) apply_mfma_kernel(Mat X, const float* __restrict__ M, int64_t m_bs, int64_t m_hs, MatOut O, int heads,
+                                                         int64_t N, int d, int e, int accumulate, int hw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lmt[];          // hw x 64 x ldm bf16: M^T of the heads served
+    constexpr int DP = KC * 16, LDM = DP + 8;
+    const int b = blockIdx.x, ncp = (e + 63) >> 6;
+    const int cp = blockIdx.z % ncp, h0 = (blockIdx.z / ncp) * hw;
+    const int nh = (heads - h0) < hw ? (heads - h0) : hw;
+    const int c0 = cp * 64;
+    const int ncols = (e - c0) < 64 ? (e - c0) : 64;                               // multiple of 8
+    for (int i = threadIdx.x; i < hw * DP * 16; i += 256) {
+        const int c4 = (i & 15) << 2, r = i >> 4, k = r % DP, hh = r / DP;
+        p4c_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (hh < nh && k < d && c4 < ncols) v = load4f(M + b * m_bs + (int64_t)(h0 + hh) * m_hs + (int64_t)k * e + c0 + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 t = (__bf16)v[j];
+            lmt[(hh * 64 + c4 + j) * LDM + k] = __builtin_bit_cast(unsigned short, t);
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hh = wave % hw, tg = wave / hw, ntg = 4 / hw;
+    if (hh >= nh) return;
+    const int r32 = lane & 31, kg = lane >> 5;
+    const bf16* xb = reinterpret_cast<const bf16*>(X.base) + b * X.bs + (int64_t)(h0 + hh) * X.hs + kg * 8;
+    TO* ob = reinterpret_cast<TO*>(O.base) + b * O.bs + (int64_t)(h0 + hh) * O.hs + c0;
+    const bool two = ncols > 32;
+    const unsigned short* la = lmt + (hh * 64 + r32) * LDM + kg * 8;
+    const int64_t ntiles = (N + 31) >> 5;
+    for (int64_t tile = (int64_t)blockIdx.y * ntg + tg; tile < ntiles; tile += (int64_t)gridDim.y * ntg) {
+        const int64_t n = tile * 32 + r32;
+        const bool live = n < N;
+        const bf16* xr = xb + n * X.rs;
+        ts_bf16x8 xv[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            ts_u32x4 u = {0u, 0u, 0u, 0u};
+            if (live && kc * 16 + kg * 8 < d) u = *reinterpret_cast<const ts_u32x4*>(xr + kc * 16);
+            xv[kc] = __builtin_bit_cast(ts_bf16x8, u);
+        }
+        ts_f32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const ts_bf16x8 a0 = __builtin_bit_cast(ts_bf16x8, *reinterpret_cast<const ts_u32x4*>(la + kc * 16));
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xv[kc], acc[0], 0, 0, 0);
+            if (two) {
+                const ts_bf16x8 a1 = __builtin_bit_cast(ts_bf16x8, *reinterpret_cast<const ts_u32x4*>(la + 32 * LDM + kc * 16));
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xv[kc], acc[1], 0, 0, 0);
+            }
+        }
+        // accumulator element 4 j + i of a lane = output column 8 j + 4 kg + i of its token
+        TO* op = ob + n * O.rs;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q == 1 && !two) continue;
+            if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = q * 32 + 8 * j + 4 * kg;
+                    if (live && col < ncols) {
+                        p4c_f32x4 v = {acc[q][4 * j], acc[q][4 * j + 1], acc[q][4 * j + 2], acc[q][4 * j + 3]};
+                        float* o4 = reinterpret_cast<float*>(op) + col;
+                        if (accumulate) {
+                            const p4c_f32x4 old = load4f(o4);
+                            v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
+                        }
+                        store4f(o4, v);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const int col = q * 32 + 16 * m2 + 8 * kg;          // after the trade: 8 consecutive columns per lane
+                    const bool st = live && col < ncols;
+                    float lo[4], hi[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[i] = acc[q][8 * m2 + i];
+                        hi[i] = acc[q][8 * m2 + 4 + i];
+                    }
+                    if (accumulate) {
+                        // read-modify-write without the trade (rare: the second apply of a gram_norms backward): 8-byte pieces, the
+                        // lane's own 4 columns of the two 8-row blocks (fp32 values swapped between lanes came back wrong from the
+                        // compiler here -- both results of v_permlane32_swap read as the first one)
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const int c4 = q * 32 + 16 * m2 + 8 * half + 4 * kg;
+                            if (live && c4 < ncols) {
+                                bf16* o4 = reinterpret_cast<bf16*>(op) + c4;
+                                const p4c_f32x4 old = load4f(o4);
+                                const float* sv = half ? hi : lo;
+                                store4f(o4, p4c_f32x4{sv[0] + old[0], sv[1] + old[1], sv[2] + old[2], sv[3] + old[3]});
+                            }
+                        }
+                    } else {
+                        ts_bf16x4 pa, pb;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { pa[i] = (__bf16)lo[i]; pb[i] = (__bf16)hi[i]; }
+                        const ts_u32x2 ua = __builtin_bit_cast(ts_u32x2, pa), ub = __builtin_bit_cast(ts_u32x2, pb);
+                        const ts_u32x2 s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+                        const ts_u32x2 s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+                        if (st) *reinterpret_cast<ts_u32x4*>(reinterpret_cast<bf16*>(op) + col) = ts_u32x4{s0.x, s1.x, s0.y, s1.y};
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+// ---- gram on the matrix cores (bf16 token matrices) -------------------------------------------------------------------------
+// G = X^T Y reduces over the tokens, so BOTH operands of v_mfma_f32_32x32x16_bf16 are transposed reads (ds_read_b64_tr_b16) of
+// [token][column] images in LDS, exactly as in a weight gradient (csrc/rowgemm.hip).  A workgroup = 2 waves serves one (sample, head),
+// one token split and one 64 x 64 block of the result; each wave stages its own 32-token tiles (16-byte loads of the rows, in place in
+// the strided views), the two waves add in wave order through LDS: one partial per (sample, split, head), summed by the caller in a
+// fixed order -- bit-identical reruns.  NORMS: the column sums of squares of X and Y come from the loader's registers (a lane always
+// stages the same 8 columns), reduced in lane order through LDS.
+typedef short ts_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int GROWS = 32;                    // tokens per tile
+constexpr int GROWB = 64 * 2 + 16;           // bytes per image row: 64 columns + padding (conflict-free transposed reads)
+
+__device__ __forceinline__ ts_bf16x8 read_tr(const char* p) {
+    union { ts_s16x4 s[2]; ts_bf16x8 v; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ts_s16x4 __attribute__((address_space(3)))*)(p));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ts_s16x4 __attribute__((address_space(3)))*)(p + 4 * GROWB));
+    return u.v;
+}
+
+template <int MT, int NT, bool NORMS>
+__global__ void __launch_bounds__(128) gram_mfma_kernel(Mat X, Mat Y, float* __restrict__ part, int heads, int64_t N, int d, int e, int nsplit,
+                                                        int pstride) {
+    constexpr int IMG = GROWS * GROWB;
+    constexpr int MAIN = 4 * IMG > 64 * 64 * 4 ? 4 * IMG : 64 * 64 * 4;             // the four images (4 x 4.5 KB), later the 64 x 64 sum
+    __shared__ __attribute__((aligned(16))) char smem[MAIN + (NORMS ? 2 * 2 * 64 * 8 * 4 : 0)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads, sp = blockIdx.y;
+    const int eblocks = (e + 63) >> 6;
+    const int i0 = 64 * (blockIdx.z / eblocks), j0 = 64 * (blockIdx.z % eblocks);
+    const int dcols = (d - i0) < 64 ? (d - i0) : 64, ecols = (e - j0) < 64 ? (e - j0) : 64;
+    const int dv = dcols >> 3, ev = ecols >> 3;                              // 16-byte vectors per staged row
+    char* imgX = smem + wv * 2 * IMG;
+    char* imgY = imgX + IMG;
+    const bf16* xb = reinterpret_cast<const bf16*>(X.base) + b * X.bs + (int64_t)h * X.hs + i0;
+    const bf16* yb = reinterpret_cast<const bf16*>(Y.base) + b * Y.bs + (int64_t)h * Y.hs + j0;
+    for (int i = lane; i < 2 * IMG / 16; i += 64) reinterpret_cast<ts_u32x4*>(imgX)[i] = ts_u32x4{0u, 0u, 0u, 0u};   // padding columns stay zero
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+
+    ts_f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    float nx[8], ny[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nx[j] = ny[j] = 0.f;
+
+    const int64_t ntiles = (N + GROWS - 1) / GROWS;
+    const int64_t tps = (ntiles + nsplit - 1) / nsplit;
+    const int64_t tend = ((int64_t)(sp + 1) * tps) < ntiles ? ((int64_t)(sp + 1) * tps) : ntiles;
+    const int i16 = lane & 15, tg = (lane >> 4) & 1, hh = lane >> 5;
+    for (int64_t t = (int64_t)sp * tps + wv; t < tend; t += 2) {
+        const int64_t row0 = t * GROWS;
+        for (int v = lane; v < GROWS * dv; v += 64) {
+            const int rr = v / dv, c = v - rr * dv;
+            ts_u32x4 q = {0u, 0u, 0u, 0u};
+            if (row0 + rr < N) q = *reinterpret_cast<const ts_u32x4*>(xb + (row0 + rr) * X.rs + 8 * c);
+            *reinterpret_cast<ts_u32x4*>(imgX + rr * GROWB + c * 16) = q;
+            if (NORMS) {
+                const ts_bf16x8 f = __builtin_bit_cast(ts_bf16x8, q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nx[j] = __builtin_fmaf((float)f[j], (float)f[j], nx[j]);
+            }
+        }
+        for (int v = lane; v < GROWS * ev; v += 64) {
+            const int rr = v / ev, c = v - rr * ev;
+            ts_u32x4 q = {0u, 0u, 0u, 0u};
+            if (row0 + rr < N) q = *reinterpret_cast<const ts_u32x4*>(yb + (row0 + rr) * Y.rs + 8 * c);
+            *reinterpret_cast<ts_u32x4*>(imgY + rr * GROWB + c * 16) = q;
+            if (NORMS) {
+                const ts_bf16x8 f = __builtin_bit_cast(ts_bf16x8, q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ny[j] = __builtin_fmaf((float)f[j], (float)f[j], ny[j]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < GROWS / 16; ++ks) {
+            // lane (column 32 tile + (lane & 31), half hh) receives tokens 16 ks + 8 hh + j, j = 0..7, of its column
+            const int rbase = 16 * ks + 8 * hh + (i16 >> 2);
+            const int coff = (tg * 16 + (i16 & 3) * 4) * 2;
+            ts_bf16x8 av[MT], bv[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[m] = read_tr(imgX + rbase * GROWB + 64 * m + coff);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bv[n] = read_tr(imgY + rbase * GROWB + 64 * n + coff);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // the two waves add in wave order through LDS: red[i][j], 64 x 64 floats over the images
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    float* nbuf = reinterpret_cast<float*>(smem + MAIN);                     // [X | Y][wave][lane][8]
+    const int r = lane & 31;
+    for (int turn = 0; turn < 2; ++turn) {
+        if (wv == turn) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int o = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh, k = 32 * n + r;
+                        if (turn == 0) red[o * 64 + k] = acc[m][n][i];
+                        else red[o * 64 + k] += acc[m][n][i];
+                    }
+        }
+        __syncthreads();
+    }
+    if (NORMS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            nbuf[(wv * 64 + lane) * 8 + j] = nx[j];
+            nbuf[((2 + wv) * 64 + lane) * 8 + j] = ny[j];
+        }
+        __syncthreads();
+    }
+    float* pb = part + (((int64_t)b * nsplit + sp) * heads + h) * pstride;
+    for (int i = threadIdx.x; i < dcols * ecols; i += 128) {
+        const int ii = i / ecols, jj = i - ii * ecols;
+        pb[(int64_t)(i0 + ii) * e + j0 + jj] = red[ii * 64 + jj];
+    }
+    if (NORMS) {
+        // column 8 c + j was staged by the lanes with lane % dv == c (64 % dv == 0: a lane keeps its columns from tile to tile)
+        for (int i = threadIdx.x; i < dcols + ecols; i += 128) {
+            const bool isx = i < dcols;
+            const int col = isx ? i : i - dcols, nv = isx ? dv : ev;
+            const int c = col >> 3, j = col & 7;
+            const float* src = nbuf + (isx ? 0 : 2 * 64 * 8);
+            float sacc = 0.f;
+            for (int w = 0; w < 2; ++w)
+                for (int l = c; l < 64; l += nv) sacc += src[(w * 64 + l) * 8 + j];
+            pb[(int64_t)d * e + (isx ? 0 : d) + col] = sacc;
+        }
+    }
+}
+
 }  // namespace ts
 }  // namespace p4c
 
@@ -195,11 +470,42 @@ extern "C" int p4c_ts_gram_splits(int64_t N) {
 
 static int pow2_ge_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// the matrix-core form serves bf16 x bf16 with d, e multiples of 8 (any width: 64 x 64 result blocks in blockIdx.z)
+extern "C" int p4c_ts_gram_wide_ok(int x_dtype, int y_dtype, int d, int e) {
+    static const bool off = [] { const char* v = getenv("P4C_TS_NO_MFMA"); return v && v[0] == '1'; }();
+    return !off && x_dtype == P4C_BF16 && y_dtype == P4C_BF16 && d > 0 && e > 0 && d % 8 == 0 && e % 8 == 0;
+}
+
+static bool gram_mfma_aligned(const void* x, int64_t x_bs, int64_t x_hs, int64_t x_rs, const void* y, int64_t y_bs, int64_t y_hs, int64_t y_rs) {
+    return x_bs % 8 == 0 && x_hs % 8 == 0 && x_rs % 8 == 0 && y_bs % 8 == 0 && y_hs % 8 == 0 && y_rs % 8 == 0 &&
+           (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+}
+
+template <bool NORMS>
+static void launch_gram_mfma(const ts::Mat& X, const ts::Mat& Y, float* partial, int B, int heads, int64_t N, int d, int e, int ns, hipStream_t st) {
+    const dim3 grid(B * heads, ns, ((d + 63) / 64) * ((e + 63) / 64));
+    const int pstride = d * e + (NORMS ? d + e : 0);
+    const bool m2 = d > 32, n2 = e > 32;
+#define P4C_GRAM_M(MT, NT) hipLaunchKernelGGL((ts::gram_mfma_kernel<MT, NT, NORMS>), grid, dim3(128), 0, st, X, Y, partial, heads, N, d, e, ns, pstride)
+    if (m2 && n2) P4C_GRAM_M(2, 2);
+    else if (m2) P4C_GRAM_M(2, 1);
+    else if (n2) P4C_GRAM_M(1, 2);
+    else P4C_GRAM_M(1, 1);
+#undef P4C_GRAM_M
+}
+
 extern "C" int p4c_ts_gram(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const void* y, int y_dtype,
                            int64_t y_bs, int64_t y_hs, int64_t y_rs, float* partial, int B, int heads, int64_t N, int d, int e,
                            p4c_stream_t stream) {
     P4C_CHECK_ARG(x && y && partial, "p4c_ts_gram: null pointer");
-    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
+    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0, "p4c_ts_gram: empty problem");
+    if (p4c_ts_gram_wide_ok(x_dtype, y_dtype, d, e) && gram_mfma_aligned(x, x_bs, x_hs, x_rs, y, y_bs, y_hs, y_rs)) {
+        const ts::Mat Xm{x, x_bs, x_hs, x_rs}, Ym{y, y_bs, y_hs, y_rs};
+        launch_gram_mfma<false>(Xm, Ym, partial, B, heads, N, d, e, p4c_ts_gram_splits(N), as_stream(stream));
+        P4C_CHECK_LAUNCH("p4c_ts_gram");
+        return P4C_OK;
+    }
+    P4C_CHECK_ARG(d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
                   "p4c_ts_gram: d, e must be multiples of 4 up to %d (got %d, %d)", ts::MAXD, d, e);
     P4C_CHECK_ARG(x_bs % 4 == 0 && x_hs % 4 == 0 && x_rs % 4 == 0 && y_bs % 4 == 0 && y_hs % 4 == 0 && y_rs % 4 == 0 &&
                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
@@ -236,6 +542,13 @@ extern "C" int p4c_ts_gram_norms(const void* x, int x_dtype, int64_t x_bs, int64
     P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
                   "p4c_ts_gram_norms: d, e must be multiples of 4 up to %d (got %d, %d)", ts::MAXD, d, e);
     P4C_CHECK_ARG(x_dtype == P4C_BF16 && y_dtype == P4C_BF16, "p4c_ts_gram_norms: bf16 token matrices");
+    if (p4c_ts_gram_wide_ok(x_dtype, y_dtype, d, e) && (64 % (d / 8)) == 0 && (64 % (e / 8)) == 0 &&
+        gram_mfma_aligned(x, x_bs, x_hs, x_rs, y, y_bs, y_hs, y_rs)) {
+        const ts::Mat Xm{x, x_bs, x_hs, x_rs}, Ym{y, y_bs, y_hs, y_rs};
+        launch_gram_mfma<true>(Xm, Ym, partial, B, heads, N, d, e, p4c_ts_gram_splits(N), as_stream(stream));
+        P4C_CHECK_LAUNCH("p4c_ts_gram_norms");
+        return P4C_OK;
+    }
     P4C_CHECK_ARG(x_bs % 4 == 0 && x_hs % 4 == 0 && x_rs % 4 == 0 && y_bs % 4 == 0 && y_hs % 4 == 0 && y_rs % 4 == 0 &&
                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                   "p4c_ts_gram_norms: strides must be multiples of 4 elements, bases 16-byte aligned");
@@ -255,11 +568,52 @@ extern "C" int p4c_ts_gram_norms(const void* x, int x_dtype, int64_t x_bs, int64
     return P4C_OK;
 }
 
+// the matrix-core form serves bf16 token matrices with d, e multiples of 8 and d <= 256 (any e): no 64-column chunking by the caller
+extern "C" int p4c_ts_apply_wide_ok(int x_dtype, int out_dtype, int d, int e) {
+    static const bool off = [] { const char* v = getenv("P4C_TS_NO_MFMA"); return v && v[0] == '1'; }();
+    return !off && x_dtype == P4C_BF16 && (out_dtype == P4C_BF16 || out_dtype == P4C_F32) && d > 0 && e > 0 && d % 8 == 0 && e % 8 == 0 && d <= 256;
+}
+
+template <typename TO>
+static void launch_apply_mfma(const ts::Mat& X, const float* m, int64_t m_bs, int64_t m_hs, const ts::MatOut& O, int B, int heads, int64_t N,
+                              int d, int e, int accumulate, hipStream_t st) {
+    const int kc = d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : d <= 128 ? 8 : 16;
+    int hw = heads >= 4 ? 4 : heads >= 2 ? 2 : 1;
+    while (hw > 1 && hw * 64 * (kc * 16 + 8) * 2 > 65536) hw >>= 1;      // M^T of the heads a workgroup serves: <= 64 KB of LDS
+    const size_t lds = (size_t)hw * 64 * (kc * 16 + 8) * 2;
+    const int ntg = 4 / hw, zc = ((heads + hw - 1) / hw) * ((e + 63) / 64);
+    const int64_t ntiles = (N + 31) / 32;
+    int64_t ny = (ntiles + ntg - 1) / ntg;
+    const int64_t cap = (int64_t)num_cus() * 8 / ((int64_t)B * zc) + 1;
+    if (ny > cap) ny = cap;
+    const dim3 grid(B, (unsigned)ny, zc);
+#define P4C_APPLY_M(KC) hipLaunchKernelGGL((ts::apply_mfma_kernel<TO, KC>), grid, dim3(256), lds, st, X, m, m_bs, m_hs, O, heads, N, d, e, accumulate, hw)
+    switch (kc) {
+        case 1: P4C_APPLY_M(1); break;
+        case 2: P4C_APPLY_M(2); break;
+        case 4: P4C_APPLY_M(4); break;
+        case 8: P4C_APPLY_M(8); break;
+        default: P4C_APPLY_M(16); break;
+    }
+#undef P4C_APPLY_M
+}
+
 extern "C" int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs,
                             void* out, int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e,
                             int accumulate, p4c_stream_t stream) {
     P4C_CHECK_ARG(x && m && out, "p4c_ts_apply: null pointer");
-    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
+    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0, "p4c_ts_apply: empty problem");
+    if (p4c_ts_apply_wide_ok(x_dtype, out_dtype, d, e) && x_bs % 8 == 0 && x_hs % 8 == 0 && x_rs % 8 == 0 && o_bs % 8 == 0 && o_hs % 8 == 0 &&
+        o_rs % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(m) & 15) == 0 && m_gs % 4 == 0) {
+        const ts::Mat Xm{x, x_bs, x_hs, x_rs};
+        const ts::MatOut Om{out, o_bs, o_hs, o_rs};
+        if (out_dtype == P4C_BF16) launch_apply_mfma<bf16>(Xm, m, m_gs * heads, m_gs, Om, B, heads, N, d, e, accumulate, as_stream(stream));
+        else launch_apply_mfma<float>(Xm, m, m_gs * heads, m_gs, Om, B, heads, N, d, e, accumulate, as_stream(stream));
+        P4C_CHECK_LAUNCH("p4c_ts_apply");
+        return P4C_OK;
+    }
+    P4C_CHECK_ARG(d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
                   "p4c_ts_apply: d, e must be multiples of 4 up to %d (got %d, %d)", ts::MAXD, d, e);
     P4C_CHECK_ARG(x_bs % 4 == 0 && x_hs % 4 == 0 && x_rs % 4 == 0 && o_bs % 4 == 0 && o_hs % 4 == 0 && o_rs % 4 == 0 &&
                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0,

@@ -21,6 +21,14 @@ def _chunks(n):
     return [(i, min(i + MAXD, n)) for i in range(0, n, MAXD)]
 
 
+def _gram_wide(x, y) -> bool:
+    """Served by the matrix-core gram kernel (csrc/tallskinny.hip: gram_mfma_kernel): any width in one launch."""
+    if not L.lib().p4c_ts_gram_wide_ok(L.dtype_code(x.dtype), L.dtype_code(y.dtype), x.shape[-1], y.shape[-1]):
+        return False
+    al = lambda t: all(v % 8 == 0 for v in _strides(t)) and t.data_ptr() % 16 == 0
+    return al(x) and al(y)
+
+
 def _gram_call(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     B, H, N, d = x.shape
     e = y.shape[-1]
@@ -34,9 +42,17 @@ def _gram_call(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 def _gram_raw(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     d, e = x.shape[-1], y.shape[-1]
-    if d <= MAXD and e <= MAXD:
+    if (d <= MAXD and e <= MAXD) or _gram_wide(x, y):
         return _gram_call(x, y)
     return torch.cat([torch.cat([_gram_call(x[..., i0:i1], y[..., j0:j1]) for j0, j1 in _chunks(e)], dim=-1) for i0, i1 in _chunks(d)], dim=-2)
+
+
+def _wide(x, out_view, d, e) -> bool:
+    """Served by the matrix-core apply kernel (csrc/tallskinny.hip: apply_mfma_kernel), which has no 64-column limit?"""
+    if not L.lib().p4c_ts_apply_wide_ok(L.dtype_code(x.dtype), L.dtype_code(out_view.dtype), d, e):
+        return False
+    al = lambda t: all(v % 8 == 0 for v in _strides(t)) and t.data_ptr() % 16 == 0
+    return al(x) and al(out_view)
 
 
 def _apply_raw(x: torch.Tensor, m: torch.Tensor, dtype) -> torch.Tensor:
@@ -46,6 +62,11 @@ def _apply_raw(x: torch.Tensor, m: torch.Tensor, dtype) -> torch.Tensor:
     out = torch.empty(B, N, H, e, dtype=dtype, device=x.device)
     ov = out.permute(0, 2, 1, 3)
     m = m.float()
+    if _wide(x, ov, d, e):      # matrix-core kernel: any width in one launch
+        m = m.contiguous()
+        L.call("p4c_ts_apply", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(m), d * e, L.ptr(ov), L.dtype_code(dtype), *_strides(ov),
+               B, H, N, d, e, 0, L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * out.element_size()))
+        return ov
     for j0, j1 in _chunks(e):
         oj = ov[..., j0:j1]
         for k, (i0, i1) in enumerate(_chunks(d)):

@@ -46,6 +46,59 @@ def test_tall_skinny_gram_and_apply(gpu_device, dtype, tol, B, H, N, d, e):
     assert _rel(m.grad, dm_ref) < btol
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,N,d,e", [(2, 4, 1000, 32, 32), (2, 4, 515, 32, 64), (1, 4, 300, 64, 32), (1, 3, 257, 128, 128), (2, 4, 256, 256, 256),
+                                       (1, 1, 100, 64, 8), (1, 2, 33, 8, 72), (1, 5, 64, 24, 40), (1, 4, 256, 256, 32)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_apply_on_matrix_cores(gpu_device, B, H, N, d, e, out_dtype):
+    """The matrix-core form of apply (csrc/tallskinny.hip: apply_mfma_kernel; bf16 token matrices, any width in one launch) against
+    float64 on the same bf16-rounded operands (the small matrix rounded to bf16 as the kernel does), ragged token counts, head counts
+    that do not fill a workgroup, in-place strided views, fp32 / bf16 outputs, and the accumulating form."""
+    from py4cast_amd import _lib as L, ops_ts as TS
+
+    g = torch.Generator().manual_seed(N * 7 + d + e)
+    big = torch.randn(B, N, 4, H, d, generator=g).to(gpu_device).to(torch.bfloat16)
+    x = big[:, :, 2].permute(0, 2, 1, 3)
+    m = torch.randn(B, H, d, e, generator=g).to(gpu_device)
+    assert TS._wide(x, torch.empty(B, N, H, e, dtype=out_dtype, device=gpu_device).permute(0, 2, 1, 3), d, e)
+    O = TS._apply_raw(x, m, out_dtype)
+    ref = x.double() @ m.to(torch.bfloat16).double()
+    scale = float(ref.abs().max())
+    err = float((O.double() - ref).abs().max()) / scale
+    assert err < (1e-5 if out_dtype == torch.float32 else 4e-3), err
+    # accumulate into what is there
+    full = torch.randn(B, N + 3, H, e, generator=g).to(gpu_device).to(out_dtype)     # three guard rows behind each sample's tokens
+    base, guard = full[:, :N].clone(), full[:, N:].clone()
+    out = full[:, :N].permute(0, 2, 1, 3)
+    L.call("p4c_ts_apply", L.ptr(x), L.dtype_code(x.dtype), *TS._strides(x), L.ptr(m), d * e, L.ptr(out), L.dtype_code(out_dtype), *TS._strides(out),
+           B, H, N, d, e, 1, L.stream(x.device))
+    ref2 = ref + base.permute(0, 2, 1, 3).double()
+    err2 = float((out.double() - ref2).abs().max()) / scale
+    assert err2 < (1e-5 if out_dtype == torch.float32 else 4e-3), err2
+    assert torch.equal(full[:, N:], guard)       # stores are masked by token
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,N,d,e", [(2, 4, 5000, 32, 64), (2, 4, 256, 256, 256), (1, 5, 64, 24, 40), (1, 2, 33, 8, 72), (1, 3, 1000, 128, 32),
+                                       (2, 4, 16384, 32, 32), (1, 1, 31, 64, 64)])
+def test_gram_on_matrix_cores(gpu_device, B, H, N, d, e):
+    """The matrix-core form of gram (csrc/tallskinny.hip: gram_mfma_kernel; bf16 token matrices, any width in one launch) against
+    float64 on the same bf16 operands: ragged token counts (partial tiles, empty splits), widths that are not multiples of 32 or 64,
+    in-place strided views; two runs are bit-identical (fixed-order sums, no atomics)."""
+    from py4cast_amd import ops_ts as TS
+
+    g = torch.Generator().manual_seed(N * 3 + d + e)
+    big = torch.randn(B, N, 4, H, d, generator=g).to(gpu_device).to(torch.bfloat16)
+    x = big[:, :, 3].permute(0, 2, 1, 3)
+    y = torch.randn(B, N, H, e, generator=g).to(gpu_device).to(torch.bfloat16).permute(0, 2, 1, 3)
+    assert TS._gram_wide(x, y)
+    G = TS._gram_raw(x, y)
+    ref = x.double().transpose(-1, -2) @ y.double()
+    assert G.shape == (B, H, d, e) and G.dtype == torch.float32
+    assert float((G.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    assert torch.equal(G, TS._gram_raw(x, y))
+
+
 def _pair(cin, cout, shape, dtype="f32", hidden=256, heads=4, linear=True):
     from oracle.unetrpp import UNetRPP as Oracle
     from py4cast_amd.unetrpp import UNetRPPMI355X, UNetRPPSettings
