@@ -578,6 +578,13 @@ int p4c_ts_apply_wide_ok(int x_dtype, int out_dtype, int d, int e);
 int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, void* out,
                  int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int accumulate,
                  p4c_stream_t stream);
+/* apply with a fused epilogue over each token's output row (bf16 in / out, matrix-core form: d, e multiples of 8, d <= 256, e <= 64):
+ *   epi = 1: out = softmax_row(X M)                                        -- S = softmax(q Mq) without the logits reaching memory
+ *   epi = 2: out = S * (X M - rowsum(X M * S)), S (B, heads, N, e) bf16     -- the softmax backward of the products X M = dS
+ * (the spatial branch of EPA, py4cast_amd/ops_ts.py::epa_spatial: no N x p softmax passes either way). */
+int p4c_ts_apply_softmax(const void* x, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, void* out, int64_t o_bs,
+                         int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int epi, const void* s, int64_t s_bs,
+                         int64_t s_hs, int64_t s_rs, p4c_stream_t stream);
 /* The small matrices of one EPA block in one launch each way (all fp32, contiguous): G = q^T k, Gq = q^T q, Gk = k^T k (B, heads, d, d)
  * from p4c_ts_gram, KP (B, heads, d, p), temperatures t1 / t2 (heads):
  *   nq_i = max(sqrt(max(Gq_ii, 0)), 1e-12), nk_j likewise;  A = softmax_j(t1 G_ij / (nq_i nk_j));  Mq_ic = t2 KP_ic / nq_i.

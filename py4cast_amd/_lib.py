@@ -73,6 +73,7 @@ OTHER = {
     "p4c_ts_gram": ([P, I, L, L, L, P, I, L, L, L, P, I, I, L, I, I, P], c_int),
     "p4c_ts_apply_wide_ok": ([I, I, I, I], c_int),
     "p4c_ts_gram_wide_ok": ([I, I, I, I], c_int),
+    "p4c_ts_apply_softmax": ([P, L, L, L, P, L, P, L, L, L, I, I, L, I, I, I, P, L, L, L, P], c_int),
     "p4c_ts_apply": ([P, I, L, L, L, P, L, P, I, L, L, L, I, I, L, I, I, I, P], c_int),
     "p4c_epa_small_fwd": ([P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P], c_int),
     "p4c_epa_small_bwd": ([P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P], c_int),

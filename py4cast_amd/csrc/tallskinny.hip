@@ -195,9 +195,12 @@ typedef __bf16 ts_bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int ts_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int ts_u32x2 __attribute__((ext_vector_type(2)));
 
-template <typename TO, int KC>
+// EPI (e <= 64: a token's whole output row sits in the two lanes of its token): 1 = row softmax of the products before they are stored
+// (S = softmax(q Mq): the logits never reach memory); 2 = softmax backward: the products are dS, the stored values
+// S (dS - sum_j dS_j S_j) with S read in the accumulator layout -- the spatial branch of EPA without the N x p softmax passes.
+template <typename TO, int KC, int EPI = 0>
 __global__ void __launch_bounds__(256) apply_mfma_kernel(Mat X, const float* __restrict__ M, int64_t m_bs, int64_t m_hs, MatOut O, int heads,
-                                                         int64_t N, int d, int e, int accumulate, int hw) {
+                                                         int64_t N, int d, int e, int accumulate, int hw, Mat S) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lmt[];          // hw x 64 x ldm bf16: M^T of the heads served
     constexpr int DP = KC * 16, LDM = DP + 8;
     const int b = blockIdx.x, ncp = (e + 63) >> 6;
@@ -252,6 +255,54 @@ __global__ void __launch_bounds__(256) apply_mfma_kernel(Mat X, const float* __r
         }
         // accumulator element 4 j + i of a lane = output column 8 j + 4 kg + i of its token
         TO* op = ob + n * O.rs;
+        if constexpr (EPI == 1) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (q * 32 + 8 * (v >> 2) + 4 * kg + (v & 3) < ncols) mx = fmaxf(mx, acc[q][v]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const bool in = q * 32 + 8 * (v >> 2) + 4 * kg + (v & 3) < ncols;
+                    const float ex = in ? __expf(acc[q][v] - mx) : 0.f;
+                    acc[q][v] = ex;
+                    sum += ex;
+                }
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[q][v] *= inv;
+        }
+        if constexpr (EPI == 2) {
+            const bf16* sp = reinterpret_cast<const bf16*>(S.base) + b * S.bs + (int64_t)(h0 + hh) * S.hs + n * S.rs + c0;
+            float sv[2][16];
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = q * 32 + 8 * j + 4 * kg;
+                    p4c_f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                    if (live && col < ncols) t = load4f(sp + col);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        sv[q][4 * j + i] = t[i];
+                        dot = __builtin_fmaf(acc[q][4 * j + i], t[i], dot);
+                    }
+                }
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[q][v] = sv[q][v] * (acc[q][v] - dot);
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             if (q == 1 && !two) continue;
@@ -574,9 +625,9 @@ extern "C" int p4c_ts_apply_wide_ok(int x_dtype, int out_dtype, int d, int e) {
     return !off && x_dtype == P4C_BF16 && (out_dtype == P4C_BF16 || out_dtype == P4C_F32) && d > 0 && e > 0 && d % 8 == 0 && e % 8 == 0 && d <= 256;
 }
 
-template <typename TO>
+template <typename TO, int EPI = 0>
 static void launch_apply_mfma(const ts::Mat& X, const float* m, int64_t m_bs, int64_t m_hs, const ts::MatOut& O, int B, int heads, int64_t N,
-                              int d, int e, int accumulate, hipStream_t st) {
+                              int d, int e, int accumulate, hipStream_t st, const ts::Mat& S = ts::Mat{nullptr, 0, 0, 0}) {
     const int kc = d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : d <= 128 ? 8 : 16;
     int hw = heads >= 4 ? 4 : heads >= 2 ? 2 : 1;
     while (hw > 1 && hw * 64 * (kc * 16 + 8) * 2 > 65536) hw >>= 1;      // M^T of the heads a workgroup serves: <= 64 KB of LDS
@@ -587,7 +638,7 @@ static void launch_apply_mfma(const ts::Mat& X, const float* m, int64_t m_bs, in
     const int64_t cap = (int64_t)num_cus() * 8 / ((int64_t)B * zc) + 1;
     if (ny > cap) ny = cap;
     const dim3 grid(B, (unsigned)ny, zc);
-#define P4C_APPLY_M(KC) hipLaunchKernelGGL((ts::apply_mfma_kernel<TO, KC>), grid, dim3(256), lds, st, X, m, m_bs, m_hs, O, heads, N, d, e, accumulate, hw)
+#define P4C_APPLY_M(KC) hipLaunchKernelGGL((ts::apply_mfma_kernel<TO, KC, EPI>), grid, dim3(256), lds, st, X, m, m_bs, m_hs, O, heads, N, d, e, accumulate, hw, S)
     switch (kc) {
         case 1: P4C_APPLY_M(1); break;
         case 2: P4C_APPLY_M(2); break;
@@ -639,6 +690,31 @@ extern "C" int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_
     else return fail(P4C_ERR_INVALID, "p4c_ts_apply: bad dtype");
 #undef P4C_APPLY
     P4C_CHECK_LAUNCH("p4c_ts_apply");
+    return P4C_OK;
+}
+
+// apply with a fused epilogue over the token's output row (bf16, matrix-core form only; e <= 64):
+//   epi = 1: out = softmax_row(X M)                                     (s unused)
+//   epi = 2: out = S * (X M - rowsum(X M * S)), S (B, heads, N, e) bf16  (the softmax backward of the products X M = dS)
+extern "C" int p4c_ts_apply_softmax(const void* x, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, void* out, int64_t o_bs,
+                                    int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int epi, const void* s, int64_t s_bs,
+                                    int64_t s_hs, int64_t s_rs, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && m && out && B > 0 && heads > 0 && N > 0, "p4c_ts_apply_softmax: null pointer / empty problem");
+    P4C_CHECK_ARG(epi == 1 || (epi == 2 && s), "p4c_ts_apply_softmax: epi must be 1 (softmax) or 2 (softmax backward, with S)");
+    P4C_CHECK_ARG(p4c_ts_apply_wide_ok(P4C_BF16, P4C_BF16, d, e) && e <= 64, "p4c_ts_apply_softmax: bf16, d, e multiples of 8, d <= 256, e <= 64 (got %d, %d)", d, e);
+    P4C_CHECK_ARG(x_bs % 8 == 0 && x_hs % 8 == 0 && x_rs % 8 == 0 && o_bs % 8 == 0 && o_hs % 8 == 0 && o_rs % 8 == 0 && m_gs % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(m) & 15) == 0,
+                  "p4c_ts_apply_softmax: strides must be multiples of 8 elements, bases 16-byte aligned");
+    const ts::Mat Xm{x, x_bs, x_hs, x_rs};
+    const ts::MatOut Om{out, o_bs, o_hs, o_rs};
+    if (epi == 1) {
+        launch_apply_mfma<bf16, 1>(Xm, m, m_gs * heads, m_gs, Om, B, heads, N, d, e, 0, as_stream(stream));
+    } else {
+        P4C_CHECK_ARG(s_bs % 4 == 0 && s_hs % 4 == 0 && s_rs % 4 == 0 && (reinterpret_cast<uintptr_t>(s) & 7) == 0, "p4c_ts_apply_softmax: S strides must be multiples of 4 elements");
+        const ts::Mat Sm{s, s_bs, s_hs, s_rs};
+        launch_apply_mfma<bf16, 2>(Xm, m, m_gs * heads, m_gs, Om, B, heads, N, d, e, 0, as_stream(stream), Sm);
+    }
+    P4C_CHECK_LAUNCH("p4c_ts_apply_softmax");
     return P4C_OK;
 }
 

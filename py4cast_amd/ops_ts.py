@@ -185,6 +185,58 @@ def gram_norms(x: torch.Tensor, y: torch.Tensor):
     return _GramNorms.apply(x, y)
 
 
+def spatial_fused_ok(q: torch.Tensor, p: int) -> bool:
+    """Can ``epa_spatial`` serve these token matrices (bf16, matrix-core apply, p <= 64, 16-byte aligned rows)?"""
+    d = q.shape[-1]
+    if q.dtype != torch.bfloat16 or p > 64 or not L.lib().p4c_ts_apply_wide_ok(L.dtype_code(q.dtype), L.dtype_code(q.dtype), d, p):
+        return False
+    return bool(L.lib().p4c_ts_apply_wide_ok(L.dtype_code(q.dtype), L.dtype_code(q.dtype), p, d)) and \
+        all(v % 8 == 0 for v in _strides(q)) and q.data_ptr() % 16 == 0
+
+
+def _apply_softmax(x, m, epi, s=None):
+    B, H, N, d = x.shape
+    e = m.shape[-1]
+    out = torch.empty(B, N, H, e, dtype=x.dtype, device=x.device)
+    ov = out.permute(0, 2, 1, 3)
+    m = m.float().contiguous()
+    ss = _strides(s) if s is not None else (0, 0, 0)
+    L.call("p4c_ts_apply_softmax", L.ptr(x), *_strides(x), L.ptr(m), d * e, L.ptr(ov), *_strides(ov), B, H, N, d, e, epi,
+           L.ptr(s) if s is not None else None, *ss, L.stream(x.device),
+           alg_bytes=B * H * N * (d + e * (2 if s is not None else 1)) * x.element_size())
+    return ov
+
+
+class _EpaSpatial(torch.autograd.Function):
+    """The spatial branch of EPA as one node: x_sa = softmax(q Mq) VP^T with the row softmax -- and, backward, the softmax adjoint -- in
+    the epilogue of the apply that produces its argument (p4c_ts_apply_softmax): S is written once and read once forward, the N x p
+    logits and their gradient never exist in memory (as separate ops: two more passes over (B, heads, N, p) each way)."""
+
+    @staticmethod
+    def forward(ctx, q, Mq, VPt):
+        L.require_cuda(q, Mq, VPt)
+        S = _apply_softmax(q, Mq, 1)                       # (B,h,N,p), token-major
+        x = _apply_raw(S, VPt, q.dtype)                    # (B,h,N,d)
+        ctx.save_for_backward(q, Mq, VPt, S)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        q, Mq, VPt, S = ctx.saved_tensors
+        if dx.stride(3) != 1 or any(v % 8 for v in _strides(dx)) or dx.data_ptr() % 16:
+            dx = dx.contiguous()
+        dL = _apply_softmax(dx, VPt.transpose(-1, -2), 2, S)        # dS = dx VP, then the softmax adjoint in the epilogue
+        dVPt = _gram_raw(S, dx).to(VPt.dtype) if ctx.needs_input_grad[2] else None
+        dq = _apply_raw(dL, Mq.transpose(-1, -2), q.dtype) if ctx.needs_input_grad[0] else None
+        dMq = _gram_raw(q, dL).to(Mq.dtype) if ctx.needs_input_grad[1] else None
+        return dq, dMq, dVPt
+
+
+def epa_spatial(q: torch.Tensor, Mq: torch.Tensor, VPt: torch.Tensor) -> torch.Tensor:
+    """softmax(q (B,h,N,d) @ Mq (B,h,d,p), dim=-1) @ VPt (B,h,p,d) -> (B,h,N,d) token-major; see ``spatial_fused_ok``."""
+    return _EpaSpatial.apply(q, Mq, VPt)
+
+
 class _EpaSmall(torch.autograd.Function):
     """The small matrices of an EPA block as one native launch each way (p4c_epa_small_fwd / _bwd; see csrc/tallskinny.hip):
     (G, Gq, Gk (B,h,d,d) fp32, KP (B,h,d,p) fp32, t1, t2 (h,1,1)) -> At = softmax(t1 G / (nq nk^T))^T (B,h,d,d), Mq = t2 KP / nq (B,h,d,p)."""

@@ -248,8 +248,12 @@ class EPA(nn.Module):
             x_ca = TS.apply(v_ca, At).permute(0, 2, 1, 3).reshape(B, N, C)
         else:
             Mq = KP / nq.unsqueeze(-1) * self.temperature2
-        S = TS.apply(q, Mq).softmax(dim=-1)                                                          # (B,h,N,p), token-major memory
-        x_sa = TS.apply(S, VP.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
+        if x.is_cuda and os.environ.get("P4C_NO_EPA_SPATIAL") != "1" and TS.spatial_fused_ok(q, Mq.shape[-1]):
+            # softmax (and its adjoint) in the epilogue of the apply that produces its argument: ops_ts.epa_spatial
+            x_sa = TS.epa_spatial(q, Mq, VP.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
+        else:
+            S = TS.apply(q, Mq).softmax(dim=-1)                                                      # (B,h,N,p), token-major memory
+            x_sa = TS.apply(S, VP.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
         return torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)
 
 

@@ -99,6 +99,35 @@ def test_gram_on_matrix_cores(gpu_device, B, H, N, d, e):
     assert torch.equal(G, TS._gram_raw(x, y))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,N,d,p", [(2, 16, 4099, 8, 64), (2, 4, 1000, 32, 64), (1, 16, 257, 64, 32), (1, 3, 70, 16, 24), (2, 16, 16384, 8, 64)])
+def test_epa_spatial_branch_fused(gpu_device, B, H, N, d, p):
+    """softmax(q Mq) VP^T as one node with the softmax / its adjoint in the apply epilogues (p4c_ts_apply_softmax) against float64 on
+    the same bf16 q: output, and the gradients of q, Mq, VP^T."""
+    from py4cast_amd import ops_ts as TS
+
+    g = torch.Generator().manual_seed(N + d * p)
+    big = torch.randn(B, N, 4, H, d, generator=g).to(gpu_device).to(torch.bfloat16).requires_grad_(True)
+    q = big[:, :, 0].permute(0, 2, 1, 3)
+    Mq = (torch.randn(B, H, d, p, generator=g) * 0.7).to(gpu_device).requires_grad_(True)
+    VPt = torch.randn(B, H, p, d, generator=g).to(gpu_device).requires_grad_(True)
+    assert TS.spatial_fused_ok(q, p)
+    x = TS.epa_spatial(q, Mq, VPt)
+    w = torch.randn(B, N, H, d, generator=g).to(gpu_device).permute(0, 2, 1, 3)
+    (x.float() * w).sum().backward()
+    qd = q.detach().double().requires_grad_(True)
+    Md = Mq.detach().to(torch.bfloat16).double().requires_grad_(True)     # the kernel's operand: the small matrix rounded to bf16
+    Vd = VPt.detach().double().requires_grad_(True)
+    ref = (qd @ Md).softmax(dim=-1) @ Vd
+    (ref * w.double()).sum().backward()
+    assert x.shape == (B, H, N, d) and x.permute(0, 2, 1, 3).is_contiguous()
+    assert _rel(x.float(), ref) < 8e-3
+    assert _rel(big.grad[:, :, 0].permute(0, 2, 1, 3).float(), qd.grad) < 2e-2
+    assert float(big.grad[:, :, 1:].abs().sum()) == 0.0
+    assert _rel(Mq.grad, Md.grad) < 2e-2
+    assert _rel(VPt.grad, Vd.grad) < 2e-2
+
+
 def _pair(cin, cout, shape, dtype="f32", hidden=256, heads=4, linear=True):
     from oracle.unetrpp import UNetRPP as Oracle
     from py4cast_amd.unetrpp import UNetRPPMI355X, UNetRPPSettings
