@@ -1,14 +1,15 @@
-"""Per-launch time of the tall-skinny kernels at the UNetRPP bench shapes (hidden 1024: head widths 32 / 64 / 128 / 256 at
-16 384 / 4 096 / 1 024 / 256 tokens, B = 2, 4 heads), HIP events over a replayed graph of 20 calls; algorithmic bytes / time against 8 TB/s.
+"""Per-launch time of the tall-skinny kernels at the UNetRPP bench shapes (hidden 1024, HEADS heads (default 16: head widths 8 / 16 /
+32 / 64; HEADS=4: 32 / 64 / 128 / 256, the widths the VALU kernels took in 64-column chunks) at 16 384 / 4 096 / 1 024 / 256 tokens, B = 2), HIP events over a replayed graph of 20 calls; algorithmic bytes / time against 8 TB/s.
 P4C_TS_NO_MFMA=1 times the VALU kernels (in 64-column chunks) for comparison."""
 import os, sys, torch
 sys.path.insert(0, ".")
 from py4cast_amd import ops_ts as TS
 
 dev = torch.device("cuda", 0)
-B, H = 2, 4
+import os
+B, H = 2, int(os.environ.get('HEADS', '16'))
 rows = []
-for N, d, p in [(16384, 32, 64), (4096, 64, 64), (1024, 128, 64), (256, 256, 32)]:
+for N, d, p in [(16384, 128 // H, 64), (4096, 256 // H, 64), (1024, 512 // H, 64), (256, 1024 // H, 32)]:
     qkvv = torch.randn(B, N, 4, H, d, device=dev).to(torch.bfloat16)
     q, k = qkvv[:, :, 0].permute(0, 2, 1, 3), qkvv[:, :, 1].permute(0, 2, 1, 3)
     S = torch.randn(B, N, H, p, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
