@@ -398,6 +398,13 @@ class AutoRegressiveLightning(_Base):
         prev_states = batch.inputs
         prediction_list = []
         T = batch.num_pred_steps
+        # A model may take its input straight from build_x in the layout its first kernels want -- (dtype, channel count padded with
+        # zeros), e.g. bf16 rows of 96 channels -- instead of fp32 rows it would cast and pad itself (two passes over the full-resolution
+        # input per AR step, and their adjoints); its output may then come back in that dtype too (the state update takes any).
+        x_format = {}
+        fmt = getattr(self.model, "rollout_input_format", None)
+        if fmt is not None and not self.channels_last and not self.model.features_second and getattr(self, "use_rollout_input_format", True):
+            x_format = {"dtype": fmt[0], "c_pad": fmt[1]}
         keep_prev = 0.0 if ds else 1.0
         # Any nn.Module model: when the configured loss is a single WeightedLoss, every AR step's state update, border
         # forcing and loss column are ONE kernel (p4c_ar_update_loss_fwd) writing straight into the (B,T,...) prediction
@@ -420,7 +427,7 @@ class AutoRegressiveLightning(_Base):
                 blocks = None
                 if self.mask_ratio != 0 and batch.forcing.tensor.dim() == 5:
                     blocks = ops.BlockMask.draw(batch.forcing.tensor.shape[2], batch.forcing.tensor.shape[3], self.mask_ratio, device)
-                x = self._next_x(batch, prev_states, i, blocks=blocks)
+                x = self._next_x(batch, prev_states, i, blocks=blocks, **x_format)
                 if self.channels_last:
                     x = x.to(memory_format=torch.channels_last)
                 if self.mask_ratio != 0 and blocks is None:

@@ -23,6 +23,8 @@ Input / output are features-last (B, H, W, C); H and W must be multiples of 32.
 from dataclasses import dataclass, field
 from typing import Tuple
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -284,13 +286,20 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         """(B,H,W,C) -> (B,H,W,out).  Everything is features-last: no layout change anywhere in the network."""
         L.require_cuda(x)
         dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
-        B, H, W, C = x.shape
+        B, H, W, Cx = x.shape
+        C = self.in_channels
+        if Cx != C and (Cx < C or self.rollout_input_format is None or Cx != self.rollout_input_format[1]):
+            raise L.P4CError(f"SwinUNetRMI355X: {Cx} input channels, expected {C}")
         xin = x.to(dt)
         # patch embedding: 2x2 / stride-2 convolution with bias = a GEMM over the 2x2 patches
         pw = self.patch_embed.weight.permute(0, 2, 3, 1)                      # (fs, 2, 2, C)
         xp, Cp = xin, C
         if C % 2:   # rows of 4 C features: an even C makes them multiples of 8 (16-byte rows for the row-GEMM kernels); zero weights there
-            xp, pw, Cp = F.pad(xin, (0, 1)), F.pad(pw, (0, 1)), C + 1
+            pw, Cp = F.pad(pw, (0, 1)), C + 1
+        if Cx > C:      # input already zero-padded by build_x (rollout_input_format): a channel slice of it, no padded copy
+            xp = xin[..., :Cp]
+        elif C % 2:
+            xp = F.pad(xin, (0, 1))
         patches = xp.view(B, H // 2, 2, W // 2, 2, Cp).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * Cp)
         t = R.linear_nd(patches, pw.reshape(pw.shape[0], 4 * Cp), self.patch_embed.bias)
         hidden = [self._hidden(t, dt)]
@@ -312,6 +321,15 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         ow = self.out.weight
         y = R.linear_nd(out, ow.view(ow.shape[0], ow.shape[1]), self.out.bias)
         return y if y.dtype == x.dtype or not x.dtype.is_floating_point else y.to(x.dtype)
+
+    @property
+    def rollout_input_format(self):
+        """(dtype, channel count) the rollout's build_x should emit for this model: bf16 rows zero-padded to the 32-channel multiple
+        the first convolutions run on -- otherwise every AR step casts the fp32 input, pads it to an even channel count for the patch
+        GEMM and to 96 channels for each of encoder1's two convolutions (and runs the adjoints of all that).  fp32 flavour: None."""
+        if self._settings.activation_dtype != "bf16" or self.in_channels > 96 or os.environ.get("P4C_NO_ROLLOUT_FORMAT") == "1":
+            return None
+        return torch.bfloat16, (self.in_channels + 31) // 32 * 32
 
     # ------------------------------------------------------------------ bench.py hook
     def roofline(self, ktimes, B, H, W):

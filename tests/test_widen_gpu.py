@@ -504,6 +504,41 @@ def test_swinunetr_rollout_through_lightning(gpu_device):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in lm16.model.parameters())
 
 
+@pytest.mark.gpu
+def test_swinunetr_takes_its_input_straight_from_build_x(gpu_device):
+    """``rollout_input_format``: the bf16 flavour asks the rollout for bf16 rows zero-padded to 32 channels (no cast / pad passes per AR
+    step) and hands bf16 back.  Same loss (the same bf16 values enter the network either way) and the same gradients up to the bf16
+    rounding of the summed input gradient, against the fp32-rows route (``use_rollout_input_format = False``)."""
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from tests.helpers import make_batch, make_dataset_info, synthetic_case
+
+    H, W, F, Ff, T = 64, 64, 6, 5, 3
+    case = synthetic_case(seed=57, B=2, T=T, H=H, W=W, F=F, Ff=Ff, border=2)
+    info = make_dataset_info(case, Ff)
+    mse = [{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}]
+    torch.manual_seed(58)
+    lm = AutoRegressiveLightning({"activation_dtype": "bf16"}, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2,
+                                 model_name="SwinUNetR", losses=mse, training_strategy="scaled_ar").to(gpu_device)
+    fmt = lm.model.rollout_input_format
+    assert fmt == (torch.bfloat16, 32) and lm.model.in_channels < 32
+    seen = []
+    hook = lm.model.register_forward_pre_hook(lambda mod, args: seen.append((args[0].dtype, args[0].shape[-1])))
+    out = {}
+    for use in (True, False):
+        lm.use_rollout_input_format = use
+        lm.zero_grad(set_to_none=True)
+        loss = lm.training_step(make_batch(case, gpu_device), 0)
+        loss.backward()
+        out[use] = (loss.item(), torch.cat([p.grad.float().flatten() for p in lm.model.parameters()]))
+    hook.remove()
+    assert seen[:T] == [(torch.bfloat16, 32)] * T and seen[T:] == [(torch.float32, lm.model.in_channels)] * T
+    (la, ga), (lb, gb) = out[True], out[False]
+    assert abs(la - lb) / abs(lb) < 1e-5
+    cos = float((ga.double() * gb.double()).sum() / (ga.double().norm() * gb.double().norm()))
+    assert cos > 0.9995 and float((ga - gb).norm() / gb.norm()) < 3e-2
+    assert lm.model.__class__(lm.model.in_channels, lm.model.out_channels, (H, W)).rollout_input_format is None   # fp32 flavour: exact path
+
+
 # ----------------------------------------------------------------------------------------- HiLAM (hierarchical mesh GNN)
 def test_hilam_matches_oracle(gpu_device, tmp_path):
     from oracle.hilam import HiLam as OracleHiLam

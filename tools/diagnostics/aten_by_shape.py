@@ -6,7 +6,9 @@ from py4cast_amd.lightning import AutoRegressiveLightning
 from py4cast_amd.trainer import FlatDDP
 from torch.profiler import ProfilerActivity, profile
 device = torch.device("cuda", 0)
-model, strategy, T = "UNetRPP", "diff_ar", 2
+import os
+model = os.environ.get("MODEL", "UNetRPP")
+strategy, T = ("diff_ar", 2) if model == "UNetRPP" else ("scaled_ar", 3)
 B, F, Ff, Fs, H, W = 2, 60, 5, 4, 512, 512
 case = Bn.synthetic_case(1234, B, T, 1, H, W, F, Ff, Fs, 0, device)
 info = Bn.make_info(case, Ff)
@@ -27,12 +29,15 @@ for ev in prof.key_averages(group_by_input_shape=True):
         rows.append((t, ev.count, ev.key, str(ev.input_shapes)[:80]))
 for t, n, k, shp in sorted(rows, reverse=True)[:26]:
     print(f"{t/1e3:7.2f} ms {n:4d}x {k:28s} {shp}")
-# where do the copies / casts of the full-resolution 64-channel maps come from?  (first frame of this package on the Python stack)
-want = {"aten::copy_", "aten::_to_copy", "aten::contiguous", "aten::clone"}
+# where do the copies / casts come from?  (first frame of this package on the Python stack, per input shape)
+want = {"aten::copy_", "aten::_to_copy", "aten::contiguous", "aten::clone", "aten::add", "aten::add_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul"}
 by = collections.Counter()
+tm = collections.Counter()
 for e in prof.events():
-    if e.name in want and e.input_shapes and list(e.input_shapes[0]) in ([2, 64, 512, 512], [2, 512, 512, 64]):
+    if e.name in want and e.input_shapes and getattr(e, "device_time_total", 0) > 0:
         fr = next((f for f in (e.stack or []) if "py4cast_amd/" in f), "<no python frame: autograd>")
-        by[(e.name, fr.split("py4cast_amd/")[-1][:70])] += 1
-for (n, fr), c in by.most_common(14):
-    print(f"{c:4d}x {n:16s} {fr}")
+        k = (e.name, str(list(e.input_shapes[0]))[:28], fr.split("py4cast_amd/")[-1][:60])
+        by[k] += 1
+        tm[k] += e.device_time_total
+for k, t in tm.most_common(40):
+    print(f"{t/1e3:7.3f} ms {by[k]:4d}x {k[0]:16s} {k[1]:28s} {k[2]}")
