@@ -99,11 +99,15 @@ def _conv(m, x):
             return y.permute(0, 3, 1, 2)                                  # NCHW-shaped view of features-last memory (channels_last)
         if k > 1 and m.stride == (k, k) and m.padding == (0, 0) and x.shape[2] % k == 0 and x.shape[3] % k == 0:
             xl = x.permute(0, 2, 3, 1)
+            if xl.shape[-1] > m.in_channels:      # zero-padded rows from build_x (rollout_input_format): the real channels only
+                xl = xl[..., : m.in_channels]
             B, H, W, C = xl.shape
             if k > 1:
                 xl = xl.reshape(B, H // k, k, W // k, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // k, W // k, k * k * C)
             w = m.weight.permute(0, 2, 3, 1).reshape(m.weight.shape[0], k * k * C)
             return R.linear_nd(xl, w, m.bias).permute(0, 3, 1, 2)
+    if isinstance(m, nn.Conv2d) and x.shape[1] > m.in_channels:      # zero-padded rows from build_x: the library takes the real channels
+        x = x[:, : m.in_channels]
     if type(m) is nn.Conv2d and m.padding_mode == "zeros":
         return OM.library_conv2d(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype), m.stride, m.padding, m.dilation,
                                  m.groups)
@@ -382,10 +386,21 @@ class UNetRPPMI355X(ModelABC, nn.Module):
                 "all": {k: {"calls": ktimes[k][0], "avg_ms": round(ktimes[k][1], 4),
                             "GBps": round(nbytes[k] / (ktimes[k][0] * ktimes[k][1] * 1e-3) / 1e9, 1)} for k in names}}
 
+    @property
+    def rollout_input_format(self):
+        """(dtype, channel count) the rollout's build_x should emit for this model (see SwinUNetRMI355X.rollout_input_format): bf16 rows
+        zero-padded to the 32-channel multiple the full-resolution convolutions of encoder1 run on; the stem reads the real channels."""
+        if self.act_dtype != torch.bfloat16 or self.in_channels > 96 or os.environ.get("P4C_NO_ROLLOUT_FORMAT") == "1":
+            return None
+        return torch.bfloat16, (self.in_channels + 31) // 32 * 32
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B,H,W,in_channels) -> (B,H,W,out_channels)."""
         L.require_cuda(x)
         out_dtype = x.dtype
+        fmt = self.rollout_input_format
+        if x.shape[-1] != self.in_channels and (fmt is None or x.shape[-1] != fmt[1] or x.dtype != fmt[0]):
+            raise L.P4CError(f"UNetRPPMI355X: {x.shape[-1]} input channels, expected {self.in_channels}")
         x = x.to(self.act_dtype).contiguous().permute(0, 3, 1, 2)   # NCHW-shaped view of features-last memory (channels_last)
         hidden, h = [], x
         for i in range(4):
