@@ -117,6 +117,28 @@ def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None
     return x if res is None else x + res
 
 
+def grid_rows(model: nn.Module, x: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    """(B, N, C) grid input as (B*N, C') rows of the activation dtype.  Rows that arrive zero-padded from build_x
+    (``rollout_input_format``) go to the fused MLP as they are (its K is a multiple of 16; the weight image knows the real width)."""
+    B, N, C = x.shape
+    rows = x.reshape(B * N, C).to(dt)
+    if C != model.in_channels:
+        fmt = rollout_format(model)
+        if fmt is None or C != fmt[1] or x.dtype != fmt[0]:
+            raise L.P4CError(f"{type(model).__name__}: {C} input features, expected {model.in_channels}")
+        if not _fusable(model.grid_embedder, rows):
+            rows = rows[:, : model.in_channels]
+    return rows
+
+
+def rollout_format(model: nn.Module):
+    """(dtype, feature count) the rollout's build_x should emit for a mesh-GNN: bf16 rows zero-padded to the fused MLP's multiple of 16
+    -- otherwise every AR step casts the fp32 rows and pads them (two passes over the grid input, and their adjoints).  fp32: None."""
+    if model._settings.activation_dtype != "bf16" or model.in_channels > M.MAX_K or os.environ.get("P4C_NO_ROLLOUT_FORMAT") == "1":
+        return None
+    return torch.bfloat16, (model.in_channels + 15) // 16 * 16
+
+
 def cached_static_embeddings(model: nn.Module, embedders, feats, B: int, dt: torch.dtype):
     """Embeddings of the graph's static edge / mesh-node features, batch-expanded.  They depend on the parameters only, so the AR
     steps of one rollout (the model is called once per step, py4cast/lightning.py:591-596) share them: computed once per parameter
@@ -287,11 +309,15 @@ class GraphLamMI355X(ModelABC, nn.Module):
         feats = (self.g2m_features, self.m2g_features, self.m2m_features, self.mesh_static_features)
         return cached_static_embeddings(self, embedders, feats, B, dt)
 
+    @property
+    def rollout_input_format(self):
+        return rollout_format(self)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, N, _ = x.shape
         dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
         es = self._edges(B, x.device)
-        grid = _run(self.grid_embedder, x.reshape(B * N, -1).to(dt))
+        grid = _run(self.grid_embedder, grid_rows(self, x, dt))
         g2m_e, m2g_e, m2m_e, mesh = self._static_embeddings(B, dt)
         mesh = self.g2m_gnn(grid, mesh, g2m_e, es["g2m"])
         grid = _run(self.encoding_grid_mlp, grid, res=grid)

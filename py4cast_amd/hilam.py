@@ -17,7 +17,7 @@ from torch import nn
 from . import ops_graph as G
 from .base import ModelABC, ModelType
 from .graph_build import HiMeshGraph, build_hierarchical_graph, hi_graph_path
-from .graphlam import GraphLamMI355X, InteractionNet, _run, cached_static_embeddings, make_mlp
+from .graphlam import GraphLamMI355X, InteractionNet, _run, cached_static_embeddings, grid_rows, make_mlp, rollout_format
 
 try:
     from dataclasses_json import dataclass_json
@@ -134,11 +134,15 @@ class HiLamMI355X(ModelABC, nn.Module):
             self._edge_cache[key] = sets
         return self._edge_cache[key]
 
+    @property
+    def rollout_input_format(self):
+        return rollout_format(self)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, N, _ = x.shape
         dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
         es, Lv = self._edges(B, x.device), self.num_levels
-        grid = _run(self.grid_embedder, x.reshape(B * N, -1).to(dt))
+        grid = _run(self.grid_embedder, grid_rows(self, x, dt))
         embedders = [self.g2m_embedder, self.m2g_embedder] + list(self.mesh_embedders) + list(self.mesh_same_embedders) \
             + list(self.mesh_up_embedders) + list(self.mesh_down_embedders)
         names = ["g2m_features", "m2g_features"] + [f"mesh_pos_{l}" for l in range(Lv)] + [f"same_features_{l}" for l in range(Lv)] \

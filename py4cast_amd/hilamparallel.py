@@ -23,7 +23,7 @@ from . import ops_graph as G
 from . import ops_mlp as M
 from . import ops_rows as R
 from . import graphlam as _gl
-from .graphlam import _run, cached_static_embeddings, make_mlp
+from .graphlam import _run, cached_static_embeddings, grid_rows, make_mlp
 from .hilam import HiLamMI355X, HiLamSettings
 
 try:
@@ -109,7 +109,7 @@ class HiLamParallelMI355X(HiLamMI355X):
         B, N, _ = x.shape
         dt = torch.bfloat16 if self._settings.activation_dtype == "bf16" else torch.float32
         es, Lv = self._edges(B, x.device), self.num_levels
-        grid = _run(self.grid_embedder, x.reshape(B * N, -1).to(dt))
+        grid = _run(self.grid_embedder, grid_rows(self, x, dt))
         embedders = [self.g2m_embedder, self.m2g_embedder] + list(self.mesh_embedders) + list(self.mesh_same_embedders) \
             + list(self.mesh_up_embedders) + list(self.mesh_down_embedders)
         names = ["g2m_features", "m2g_features"] + [f"mesh_pos_{l}" for l in range(Lv)] + [f"same_features_{l}" for l in range(Lv)] \

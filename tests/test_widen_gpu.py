@@ -924,6 +924,41 @@ def test_widened_models_validate_and_predict(gpu_device, tmp_path, model_name, s
     assert torch.isfinite(pt).all() and pt.shape[:2] == (2, 2) and pt.shape[-1] == 5
 
 
+@pytest.mark.parametrize("model_name", ["GraphLam", "HiLAM", "HiLAMParallel"])
+def test_mesh_gnns_take_their_input_straight_from_build_x(gpu_device, tmp_path, model_name):
+    """``rollout_input_format`` of the mesh GNNs (bf16 flavour): bf16 rows zero-padded to the fused MLP's multiple of 16 from build_x
+    -- same loss and the same gradients (up to the bf16 rounding of the input gradient) as with fp32 rows cast and padded by the model."""
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from tests.helpers import make_batch, make_dataset_info, synthetic_case
+
+    H = W = 27
+    T = 3
+    case = synthetic_case(seed=171, B=2, T=T, H=H, W=W, F=5, Ff=5)
+    info = make_dataset_info(case, 5)
+    torch.manual_seed(172)
+    lm = AutoRegressiveLightning(
+        {"activation_dtype": "bf16", "processor_layers": 1, "tmp_dir": str(tmp_path)}, info, None, num_input_steps=1, num_pred_steps_train=T,
+        batch_size=2, model_name=model_name, losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
+        training_strategy="scaled_ar").to(gpu_device)
+    cin = lm.model.in_channels
+    assert lm.model.rollout_input_format == (torch.bfloat16, (cin + 15) // 16 * 16) and cin % 16
+    seen = []
+    hook = lm.model.register_forward_pre_hook(lambda mod, args: seen.append((args[0].dtype, args[0].shape[-1])))
+    out = {}
+    for use in (True, False):
+        lm.use_rollout_input_format = use
+        lm.zero_grad(set_to_none=True)
+        loss = lm.training_step(make_batch(case, gpu_device), 0)
+        loss.backward()
+        out[use] = (loss.item(), torch.cat([p.grad.float().flatten() for p in lm.model.parameters() if p.grad is not None]))
+    hook.remove()
+    assert seen[:T] == [(torch.bfloat16, (cin + 15) // 16 * 16)] * T and seen[T:] == [(torch.float32, cin)] * T
+    (la, ga), (lb, gb) = out[True], out[False]
+    assert abs(la - lb) / abs(lb) < 1e-5
+    cos = float((ga.double() * gb.double()).sum() / (ga.double().norm() * gb.double().norm()))
+    assert cos > 0.9995, cos
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 4e-2)])
 def test_hilamparallel_matches_oracle(gpu_device, tmp_path, dtype, tol):
     from oracle.hilam import HiLamParallel as OracleHiLamParallel
