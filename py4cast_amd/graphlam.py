@@ -96,7 +96,16 @@ def _fusable(mlp: nn.Sequential, x: torch.Tensor) -> bool:
     return M.supported(x, mlp[0].weight, mlp[2].weight) and x.shape[0] >= 1
 
 
-def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+def output_rows(model: nn.Module, grid: torch.Tensor, x: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    """The output MLP on the grid rows -> (B, N, out_channels) in x's dtype; inside the py4cast_amd rollout (``rollout_padded_output``
+    set by the caller) the fused kernel's 64-wide rows go out as they are: the state update reads the first out_channels features,
+    and neither the sliced copy nor -- backward -- a zero-filled 64-wide gradient and a copy into it exist."""
+    if model.rollout_padded_output and _fusable(model.output_map, grid):
+        return _run(model.output_map, grid, keep_pad=True).to(x.dtype).reshape(B, N, -1)
+    return _run(model.output_map, grid).to(x.dtype).reshape(B, N, model.out_channels)
+
+
+def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None, keep_pad: bool = False) -> torch.Tensor:
     """An MLP on rows of x's dtype; ``res`` is added to the result.  bf16 rows of the standard shape take ONE fused kernel each way
     (ops_mlp.row_mlp); other shapes run layer by layer (library GEMMs + the row LayerNorm / weight-gradient kernels)."""
     if _fusable(mlp, x):
@@ -105,7 +114,7 @@ def _run(mlp: nn.Sequential, x: torch.Tensor, res: Optional[torch.Tensor] = None
                                  None if ln is None else ln.weight, None if ln is None else ln.bias,
                                  1e-5 if ln is None else ln.eps, res=res, want_out=res is None, grads_in_place=GRADS_IN_PLACE)
         y = out if res is None else out_res
-        return y if mlp[2].out_features == 64 else y[:, : mlp[2].out_features]
+        return y if mlp[2].out_features == 64 or keep_pad else y[:, : mlp[2].out_features]
     for m in mlp:
         if isinstance(m, nn.Linear):
             x = _linear(m, x)
@@ -309,6 +318,8 @@ class GraphLamMI355X(ModelABC, nn.Module):
         feats = (self.g2m_features, self.m2g_features, self.m2m_features, self.mesh_static_features)
         return cached_static_embeddings(self, embedders, feats, B, dt)
 
+    rollout_padded_output = False   # set by the rollout around its calls: rows wider than out_channels are welcome (see output_rows)
+
     @property
     def rollout_input_format(self):
         return rollout_format(self)
@@ -324,7 +335,7 @@ class GraphLamMI355X(ModelABC, nn.Module):
         for layer in self.processor:
             mesh, m2m_e = layer(mesh, mesh, m2m_e, es["m2m"])
         grid = self.m2g_gnn(mesh, grid, m2g_e, es["m2g"])
-        return _run(self.output_map, grid).to(x.dtype).reshape(B, N, self.out_channels)
+        return output_rows(self, grid, x, B, N)
 
     # ------------------------------------------------------------------ bench.py hook
     def roofline(self, ktimes, B, H, W):

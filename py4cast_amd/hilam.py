@@ -17,7 +17,7 @@ from torch import nn
 from . import ops_graph as G
 from .base import ModelABC, ModelType
 from .graph_build import HiMeshGraph, build_hierarchical_graph, hi_graph_path
-from .graphlam import GraphLamMI355X, InteractionNet, _run, cached_static_embeddings, grid_rows, make_mlp, rollout_format
+from .graphlam import GraphLamMI355X, InteractionNet, _run, cached_static_embeddings, grid_rows, make_mlp, output_rows, rollout_format
 
 try:
     from dataclasses_json import dataclass_json
@@ -134,6 +134,8 @@ class HiLamMI355X(ModelABC, nn.Module):
             self._edge_cache[key] = sets
         return self._edge_cache[key]
 
+    rollout_padded_output = False   # (see graphlam.output_rows)
+
     @property
     def rollout_input_format(self):
         return rollout_format(self)
@@ -170,4 +172,4 @@ class HiLamMI355X(ModelABC, nn.Module):
         for l in range(Lv - 2, -1, -1):                                     # read-out, top-down
             levels[l] = self.mesh_read_gnns[l](levels[l + 1], levels[l], down_e[l], es[f"down{l}"])
         grid = self.m2g_gnn(levels[0], grid, m2g_e, es["m2g"])
-        return _run(self.output_map, grid).to(x.dtype).reshape(B, N, self.out_channels)
+        return output_rows(self, grid, x, B, N)

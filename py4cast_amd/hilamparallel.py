@@ -23,7 +23,7 @@ from . import ops_graph as G
 from . import ops_mlp as M
 from . import ops_rows as R
 from . import graphlam as _gl
-from .graphlam import _run, cached_static_embeddings, grid_rows, make_mlp
+from .graphlam import _run, cached_static_embeddings, grid_rows, make_mlp, output_rows
 from .hilam import HiLamMI355X, HiLamSettings
 
 try:
@@ -128,4 +128,4 @@ class HiLamParallelMI355X(HiLamMI355X):
         for l in range(Lv - 2, -1, -1):                                     # read-out, top-down
             levels[l] = self.mesh_read_gnns[l](levels[l + 1], levels[l], down_e[l], es[f"down{l}"])
         grid = self.m2g_gnn(levels[0], grid, m2g_e, es["m2g"])
-        return _run(self.output_map, grid).to(x.dtype).reshape(B, N, self.out_channels)
+        return output_rows(self, grid, x, B, N)

@@ -434,6 +434,14 @@ class AutoRegressiveLightning(_Base):
                     x = self.mask_tensor(x)   # graph layout: the reference's unpacking raises ValueError (3-d x), so does this
                 if self.model.features_second:  # lightning.py:591-596
                     y = features_second_to_last(self.model(features_last_to_second(x)))
+                elif x_format and hasattr(self.model, "rollout_padded_output"):
+                    # the state update reads the first F features of rows of any width / float dtype: a model whose last kernel
+                    # writes rows wider than out_channels (64-wide MLP / GEMM outputs) may hand them over as they are
+                    self.model.rollout_padded_output = True
+                    try:
+                        y = self.model(x)
+                    finally:
+                        self.model.rollout_padded_output = False
                 else:
                     y = self.model(x)
 

@@ -319,8 +319,17 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         dec0 = self.decoder2(dec1, enc1)
         out = self.decoder1(dec0, enc0)
         ow = self.out.weight
-        y = R.linear_nd(out, ow.view(ow.shape[0], ow.shape[1]), self.out.bias)
+        w2, b2, O = ow.view(ow.shape[0], ow.shape[1]), self.out.bias, ow.shape[0]
+        if self.rollout_padded_output and O % 8 and out.dtype == torch.bfloat16:
+            # inside the rollout rows wider than out_channels are welcome (the state update reads the first out_channels features):
+            # zero weight rows up to a multiple of 8 put the output head (524 288 rows x 24 -> 60) on the row-GEMM kernels -- 60 outputs
+            # keep them away, and the library GEMMs of this tall-skinny shape take 90 us forward alone
+            pad = (-O) % 8
+            w2, b2 = F.pad(w2, (0, 0, 0, pad)), None if b2 is None else F.pad(b2, (0, pad))
+        y = R.linear_nd(out, w2, b2)
         return y if y.dtype == x.dtype or not x.dtype.is_floating_point else y.to(x.dtype)
+
+    rollout_padded_output = False   # set by the rollout around its calls: rows wider than out_channels are welcome
 
     @property
     def rollout_input_format(self):
