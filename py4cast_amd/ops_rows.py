@@ -118,6 +118,30 @@ def weight_as(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return wq
 
 
+class _ParamAs(torch.autograd.Function):
+    """A parameter in the activation dtype, differentiable: the cast itself is ``weight_as`` -- once per parameter version (and per
+    HIP-graph capture), not once per AR step -- and the gradient goes back as one cast.  (What ``torch.autocast``'s weight cache does
+    for the reference: the AR steps of a rollout share the casts of the fp32 master weights.)"""
+
+    @staticmethod
+    def forward(ctx, w, dtype):
+        ctx.dt = w.dtype
+        return weight_as(w, dtype).detach()      # a fresh tensor object on the cached storage (the node's output must be its own)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt), None
+
+
+def param_as(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """``w.to(dtype)`` for a parameter used by several AR steps: cached cast forward, plain cast backward."""
+    if w.dtype == dtype:
+        return w
+    if not w.is_cuda or not w.is_contiguous():
+        return w.to(dtype)
+    return _ParamAs.apply(w, dtype)
+
+
 class _RowLinearSink(torch.autograd.Function):
     """``x @ W^T`` on bf16 rows whose weight gradient the backward ADDS into ``gw`` -- the view of the parameter's ``.grad`` that
     corresponds to W -- instead of handing it to autograd.  W is typically a column block of a wider Linear (the sender / receiver

@@ -170,7 +170,7 @@ def _conv_hw(m: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     and weight gradient: ops_model.conv_nhwc); the few wider ones at <= 1/8 resolution go through the library in its own layout."""
     if OM.conv_nhwc_supported(x, m.weight):
         return OM.conv_nhwc(x, m.weight)
-    y = OM.library_conv2d(x.permute(0, 3, 1, 2).contiguous(), m.weight.to(x.dtype), None, padding=m.padding)
+    y = OM.library_conv2d(x.permute(0, 3, 1, 2).contiguous(), R.param_as(m.weight, x.dtype), None, padding=m.padding)
     return y.permute(0, 2, 3, 1).contiguous()
 
 

@@ -109,8 +109,8 @@ def _conv(m, x):
     if isinstance(m, nn.Conv2d) and x.shape[1] > m.in_channels:      # zero-padded rows from build_x: the library takes the real channels
         x = x[:, : m.in_channels]
     if type(m) is nn.Conv2d and m.padding_mode == "zeros":
-        return OM.library_conv2d(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype), m.stride, m.padding, m.dilation,
-                                 m.groups)
+        return OM.library_conv2d(x, R.param_as(m.weight, x.dtype), None if m.bias is None else R.param_as(m.bias, x.dtype), m.stride,
+                                 m.padding, m.dilation, m.groups)
     return m._conv_forward(x, m.weight.to(x.dtype), None if m.bias is None else m.bias.to(x.dtype))
 
 
@@ -242,7 +242,7 @@ class EPA(nn.Module):
             A = (G / (nq.unsqueeze(-1) * nk.unsqueeze(-2)) * self.temperature).softmax(dim=-1)
             x_ca = TS.apply(v_ca, A.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
         # token-axis projection (shared weights): (B, C, N) @ (N, p) for k and v_sa at once -- a library GEMM
-        W, bias = self.E.weight.to(x.dtype), self.E.bias.float()
+        W, bias = R.param_as(self.E.weight, x.dtype), self.E.bias.float()
         kv = torch.stack([k.permute(0, 2, 1, 3).reshape(B, N, C), v_sa.permute(0, 2, 1, 3).reshape(B, N, C)], dim=1)   # (B,2,N,C)
         proj = R.add_bias((kv.transpose(-1, -2) @ W.t()).float(), bias)                              # (B,2,C,p); bias gradient as a GEMM
         KP, VP = proj[:, 0].view(B, h, d, -1), proj[:, 1].view(B, h, d, -1)
@@ -273,8 +273,8 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        t = x.reshape(B, C, H * W).permute(0, 2, 1) + self.pos_embed.to(x.dtype)
-        t = t + self.gamma.to(x.dtype) * self.epa_block(_layer_norm(self.norm, t.contiguous()))
+        t = x.reshape(B, C, H * W).permute(0, 2, 1) + R.param_as(self.pos_embed, x.dtype)
+        t = t + R.param_as(self.gamma, x.dtype) * self.epa_block(_layer_norm(self.norm, t.contiguous()))
         skip = t.reshape(B, H, W, C).permute(0, 3, 1, 2)
         return skip + _conv(self.conv8, self.conv51(skip))
 
