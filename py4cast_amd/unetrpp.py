@@ -386,6 +386,8 @@ class UNetRPPMI355X(ModelABC, nn.Module):
                 "all": {k: {"calls": ktimes[k][0], "avg_ms": round(ktimes[k][1], 4),
                             "GBps": round(nbytes[k] / (ktimes[k][0] * ktimes[k][1] * 1e-3) / 1e9, 1)} for k in names}}
 
+    rollout_padded_output = False   # set by the rollout around its calls: rows wider than out_channels are welcome
+
     @property
     def rollout_input_format(self):
         """(dtype, channel count) the rollout's build_x should emit for this model (see SwinUNetRMI355X.rollout_input_format): bf16 rows
@@ -414,5 +416,18 @@ class UNetRPPMI355X(ModelABC, nn.Module):
         out = self.decoder2(dec1, conv_block)
         # (the 1x1 output convolution has a bias and goes to the library: NCHW-contiguous input -- on an NCHW-shaped view of features-last
         # memory the library's deterministic solver for this shape took 1.1 s per step)
-        y = _conv(self.out1, out.contiguous()).permute(0, 2, 3, 1)
+        o1 = self.out1
+        if (out.dtype == torch.bfloat16 and o1.kernel_size == (1, 1) and out.permute(0, 2, 3, 1).is_contiguous() and o1.in_channels % 8 == 0
+                and os.environ.get("P4C_NO_OUT1_ROWS") != "1"):
+            # the 1x1 output convolution (with bias) as a GEMM over the features-last pixel rows: no NCHW copy of the 64-channel map in
+            # front of the library, no permuted result; inside the rollout the 60 outputs are padded to 64 (zero weight rows) and go
+            # out as they are -- the row-GEMM kernel takes multiples of 8, the state update reads the first out_channels features
+            O = o1.out_channels
+            w2, b2 = o1.weight.view(O, o1.in_channels), o1.bias
+            if self.rollout_padded_output and O % 8:
+                pad = (-O) % 8
+                w2, b2 = F.pad(w2, (0, 0, 0, pad)), None if b2 is None else F.pad(b2, (0, pad))
+            y = R.linear_nd(out.permute(0, 2, 3, 1), w2, b2)
+        else:
+            y = _conv(o1, out.contiguous()).permute(0, 2, 3, 1)
         return y if y.dtype == out_dtype or not out_dtype.is_floating_point else y.to(out_dtype)

@@ -355,6 +355,8 @@ def test_unetrpp_takes_its_input_straight_from_build_x(gpu_device):
     hook.remove()
     assert seen[:T] == [(torch.bfloat16, 32)] * T and seen[T:] == [(torch.float32, lm.model.in_channels)] * T
     (la, ga), (lb, gb) = out[True], out[False]
-    assert abs(la - lb) / abs(lb) < 1e-5
+    # (inside the rollout the 6-feature output head runs on the row-GEMM kernel, padded to 8 outputs, instead of the library's GEMM:
+    # the bf16 outputs differ by a rounding here and there)
+    assert abs(la - lb) / abs(lb) < 1e-3, (la, lb)
     cos = float((ga.double() * gb.double()).sum() / (ga.double().norm() * gb.double().norm()))
-    assert cos > 0.9995, cos
+    assert cos > 0.999, cos
