@@ -96,7 +96,8 @@ CAPTURE_SCOPE = [None]
 
 
 def _base(t):
-    return t._base if t._base is not None else t
+    t = t._base if t._base is not None else t
+    return getattr(t, "_p4c_owner", t)      # a rollout's per-step stand-in of a parameter (trainer.RolloutParamProxies): the parameter
 
 
 def owner_refs(tensors):

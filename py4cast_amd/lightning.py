@@ -21,6 +21,7 @@ What changed relative to the reference, and why:
 """
 
 import math
+import os
 from copy import deepcopy
 from functools import cached_property
 from pathlib import Path
@@ -401,6 +402,23 @@ class AutoRegressiveLightning(_Base):
         # A model may take its input straight from build_x in the layout its first kernels want -- (dtype, channel count padded with
         # zeros), e.g. bf16 rows of 96 channels -- instead of fp32 rows it would cast and pad itself (two passes over the full-resolution
         # input per AR step, and their adjoints); its output may then come back in that dtype too (the state update takes any).
+        # (single process, gradients on, several model calls): per-call stand-ins of the parameters, trainer.RolloutParamProxies.
+        # By default only while the step is being captured into a HIP graph: swapping the parameters in costs the host ~1.5 ms per
+        # model call (SwinUNetR eager: 62.8 -> 67.1 ms per step), nothing in a replay (30.3 -> 29.7); ``use_param_proxies`` forces it.
+        proxies = None
+        want = getattr(self, "use_param_proxies", None)
+        if want is None:
+            want = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if (not inference and torch.is_grad_enabled() and T * num_inter_steps > 1 and getattr(self.model, "rollout_param_proxies", False)
+                and want and os.environ.get("P4C_NO_PARAM_PROXIES") != "1"
+                and not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)):
+            from .trainer import RolloutParamProxies
+
+            proxies = self.__dict__.get("_param_proxies")
+            if proxies is None or proxies.model is not self.model:
+                proxies = self.__dict__["_param_proxies"] = RolloutParamProxies(self.model)
+            proxies.begin()
+        call_model = self.model if proxies is None else proxies.call
         x_format = {}
         fmt = getattr(self.model, "rollout_input_format", None)
         if fmt is not None and not self.channels_last and not self.model.features_second and getattr(self, "use_rollout_input_format", True):
@@ -439,11 +457,11 @@ class AutoRegressiveLightning(_Base):
                     # writes rows wider than out_channels (64-wide MLP / GEMM outputs) may hand them over as they are
                     self.model.rollout_padded_output = True
                     try:
-                        y = self.model(x)
+                        y = call_model(x)
                     finally:
                         self.model.rollout_padded_output = False
                 else:
-                    y = self.model(x)
+                    y = call_model(x)
 
                 last_prev = None if ds else prev_states.select_tensor_dim("timestep", -1)
                 if ds:  # lightning.py:611-621: update the coarse forcing's common features
@@ -477,8 +495,12 @@ class AutoRegressiveLightning(_Base):
         if fuse:
             pred_out = NamedTensor.new_like(f_states.type_as(batch.outputs.tensor), batch.outputs)
             pred_out.fused_loss = torch.stack(f_losses, dim=1) * wl_weight
+            if proxies is not None:
+                proxies.attach(pred_out.fused_loss)
             return pred_out, batch.outputs
         prediction = torch.stack(prediction_list, dim=1)
+        if proxies is not None:
+            proxies.attach(prediction)
         if inference:
             pred_out = NamedTensor(prediction.type(self.output_dtype), self.output_dim_names, self.output_feature_names)
         else:

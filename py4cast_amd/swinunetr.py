@@ -330,6 +330,7 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         return y if y.dtype == x.dtype or not x.dtype.is_floating_point else y.to(x.dtype)
 
     rollout_padded_output = False   # set by the rollout around its calls: rows wider than out_channels are welcome
+    rollout_param_proxies = True    # the rollout may run each AR step on stand-ins of the parameters (trainer.RolloutParamProxies)
 
     @property
     def rollout_input_format(self):

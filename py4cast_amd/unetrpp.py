@@ -387,6 +387,7 @@ class UNetRPPMI355X(ModelABC, nn.Module):
                             "GBps": round(nbytes[k] / (ktimes[k][0] * ktimes[k][1] * 1e-3) / 1e9, 1)} for k in names}}
 
     rollout_padded_output = False   # set by the rollout around its calls: rows wider than out_channels are welcome
+    rollout_param_proxies = True    # the rollout may run each AR step on stand-ins of the parameters (trainer.RolloutParamProxies)
 
     @property
     def rollout_input_format(self):

@@ -541,6 +541,43 @@ def test_swinunetr_takes_its_input_straight_from_build_x(gpu_device):
     assert lm.model.__class__(lm.model.in_channels, lm.model.out_channels, (H, W)).rollout_input_format is None   # fp32 flavour: exact path
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name,dtype", [("SwinUNetR", "bf16"), ("SwinUNetR", "f32"), ("UNetRPP", "bf16")])
+def test_rollout_on_parameter_stand_ins(gpu_device, model_name, dtype):
+    """``RolloutParamProxies``: each AR step on detached leaf views of the parameters, one multi-tensor accumulation at the end of
+    the backward instead of one AccumulateGrad kernel per parameter and step -- same loss, same gradients (another order of fp32
+    additions), twice in a row (the stand-ins are reused), and with gradient accumulation over two micro-batches."""
+    from py4cast_amd.lightning import AutoRegressiveLightning
+    from tests.helpers import make_batch, make_dataset_info, synthetic_case
+
+    H, W, F, Ff, T = 64, 64, 6, 5, 3
+    case = synthetic_case(seed=77, B=2, T=T, H=H, W=W, F=F, Ff=Ff, border=0 if model_name == "UNetRPP" else 2)
+    info = make_dataset_info(case, Ff)
+    mse = [{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}]
+    settings = {"activation_dtype": dtype}
+    if model_name == "UNetRPP":
+        settings.update(hidden_size=128, num_heads_encoder=2, num_heads_decoder=2, depths=[1, 1, 1, 1], encoder_proj_sizes=[16, 16, 8, 4],
+                        decoder_proj_size=16, linear_upsampling=True, attention_code="torch")
+    torch.manual_seed(78)
+    lm = AutoRegressiveLightning(settings, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2, model_name=model_name,
+                                 losses=mse, training_strategy="diff_ar" if model_name == "UNetRPP" else "scaled_ar").to(gpu_device).train()
+    assert lm.model.rollout_param_proxies
+    out = {}
+    for use in (True, False, "twice"):
+        lm.use_param_proxies = bool(use)
+        lm.zero_grad(set_to_none=(use is False))      # with and without existing gradient buffers
+        n = 2 if use == "twice" else 1
+        for _ in range(n):
+            loss = lm.training_step(make_batch(case, gpu_device), 0)
+            loss.backward()
+        out[use] = (loss.item(), torch.cat([p.grad.float().flatten() for p in lm.model.parameters()]))
+    (la, ga), (lb, gb), (lc, gc) = out[True], out[False], out["twice"]
+    assert la == lb == lc
+    assert float((ga - gb).norm() / gb.norm()) < 2e-6 and float((ga - gb).abs().max() / gb.abs().max()) < 1e-5
+    assert float((gc - 2 * gb).norm() / (2 * gb).norm()) < 2e-6
+    assert all(q.grad is None for s in lm._param_proxies.sets for q in s.values())
+
+
 # ----------------------------------------------------------------------------------------- HiLAM (hierarchical mesh GNN)
 def test_hilam_matches_oracle(gpu_device, tmp_path):
     from oracle.hilam import HiLam as OracleHiLam
