@@ -758,20 +758,24 @@ def test_row_mlp_row_aligned_addend(gpu_device):
     assert torch.equal(rg.grad.cpu(), dyr)
 
 
-def test_graphed_training_step_equals_eager(gpu_device, tmp_path):
+@pytest.mark.parametrize("model_name", ["GraphLam", "SwinUNetR"])
+def test_graphed_training_step_equals_eager(gpu_device, tmp_path, model_name):
     """HIP-graph replay of rollout + loss + backward (trainer.GraphedTrainingStep): same loss and gradients as the eager step, on
-    new batch contents copied into the static inputs."""
+    new batch contents copied into the static inputs.  (SwinUNetR: the captured rollout runs on parameter stand-ins,
+    trainer.RolloutParamProxies, the eager one does not.)"""
     from py4cast_amd.lightning import AutoRegressiveLightning
     from py4cast_amd.trainer import FlatDDP, GraphedTrainingStep
     from tests.helpers import make_batch, make_dataset_info, synthetic_case
 
-    case = synthetic_case(seed=101, B=2, T=2, H=27, W=27, F=5, Ff=5)
-    other = synthetic_case(seed=102, B=2, T=2, H=27, W=27, F=5, Ff=5)
+    HW = 27 if model_name == "GraphLam" else 64
+    case = synthetic_case(seed=101, B=2, T=2, H=HW, W=HW, F=5, Ff=5)
+    other = synthetic_case(seed=102, B=2, T=2, H=HW, W=HW, F=5, Ff=5)
     info = make_dataset_info(case, 5)
     torch.manual_seed(103)
+    settings = {"tmp_dir": str(tmp_path), "activation_dtype": "bf16", "processor_layers": 2} if model_name == "GraphLam" else {"activation_dtype": "bf16"}
     lm = AutoRegressiveLightning(
-        {"tmp_dir": str(tmp_path), "activation_dtype": "bf16", "processor_layers": 2}, info, None, num_input_steps=1,
-        num_pred_steps_train=2, batch_size=2, model_name="GraphLam",
+        settings, info, None, num_input_steps=1,
+        num_pred_steps_train=2, batch_size=2, model_name=model_name,
         losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
         training_strategy="scaled_ar",
     ).to(gpu_device)
@@ -792,6 +796,8 @@ def test_graphed_training_step_equals_eager(gpu_device, tmp_path):
     step(make_batch(other, gpu_device))                               # gradients accumulate like an eager backward
     torch.cuda.synchronize()
     assert _rel(ddp.flat_grad, 2 * first) < 1e-5
+    if model_name == "SwinUNetR":
+        assert lm._param_proxies.sets and len(lm._param_proxies.sets) == 2     # the capture did run on stand-ins, one set per AR step
 
 
 def _graph_lm(tmp_path, device, **kw):
