@@ -589,7 +589,7 @@ int p4c_ts_apply_softmax(const void* x, int64_t x_bs, int64_t x_hs, int64_t x_rs
  * from p4c_ts_gram, KP (B, heads, d, p), temperatures t1 / t2 (heads):
  *   nq_i = max(sqrt(max(Gq_ii, 0)), 1e-12), nk_j likewise;  A = softmax_j(t1 G_ij / (nq_i nk_j));  Mq_ic = t2 KP_ic / nq_i.
  * Forward writes At = A^T, Mq, nq, nk (B, heads, d).  Backward: dG, dGq, dGk (zero off the diagonal), dKP and per-(b, head) partials of
- * the temperature gradients, (B, heads) each, which the caller sums over b.  d <= 64. */
+ * the temperature gradients, (B, heads) each, which the caller sums over b.  d <= 64; forward: p <= 64. */
 int p4c_epa_small_fwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, float* At, float* Mq,
                       float* nq, float* nk, int B, int heads, int d, int p, int diag_only, p4c_stream_t stream);
 int p4c_epa_small_bwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, const float* At,

@@ -724,81 +724,127 @@ extern "C" int p4c_ts_apply_softmax(const void* x, int64_t x_bs, int64_t x_hs, i
 //   nq_i = max(sqrt(max(Gq_ii, 0)), eps), nk_j likewise;   A = softmax_j(t1 G_ij / (nq_i nk_j));   Mq_ic = t2 KP_ic / nq_i
 // forward writes At = A^T (what the apply kernel multiplies v with), Mq, nq, nk.  As torch ops this was ~14 launches forward and ~35
 // backward per block (clamps, square roots, outer products, broadcast reductions ...), ~6 000 per UNetRPP training step.
-// One workgroup per (b, h); thread -> row i; everything in fp32, sums in index order (deterministic).
+// One workgroup per (b, h); everything in fp32, sums in a fixed order (deterministic).
 namespace p4c {
 namespace ts {
 constexpr float EPA_EPS = 1e-12f;   // F.normalize's clamp
 
-__global__ void __launch_bounds__(64) epa_small_fwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
-                                                           const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
-                                                           float* __restrict__ At, float* __restrict__ Mq, float* __restrict__ nq_out,
-                                                           float* __restrict__ nk_out, int heads, int d, int p, int dstride) {
+// Workgroup = 256 threads = row i (threadIdx.x & 63) x slice s (threadIdx.x >> 6): a slice takes the columns j = s (mod 4) of its row's
+// inner loops (and the projection columns c = s (mod 4)); the four slices' partial maxima / sums meet in LDS and are added in slice
+// order (deterministic).  G (d x d, row-major) and KP are staged through LDS with coalesced loads: a thread per row walking its
+// row in global memory touched 64 cache lines per instruction (the first version: one 64-thread wave per (b, h), 20 / 36 us per launch).
+constexpr int EPA_LD = 65;
+
+__device__ __forceinline__ void epa_stage(float* dst, const float* __restrict__ src, int rows, int cols) {
+    for (int e = threadIdx.x; e < rows * cols; e += 256) {
+        const int r = e / cols, c = e - r * cols;
+        dst[r * EPA_LD + c] = src[e];
+    }
+}
+
+__global__ void __launch_bounds__(256) epa_small_fwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
+                                                            const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
+                                                            float* __restrict__ At, float* __restrict__ Mq, float* __restrict__ nq_out,
+                                                            float* __restrict__ nk_out, int heads, int d, int p, int dstride) {
     // dstride = d: Gq / Gk are the full (d x d) q^T q / k^T k, only their diagonals are read;  dstride = 1: they ARE the diagonals (B, h, d)
-    __shared__ float nk[64];
-    const int g = blockIdx.x, h = g % heads, i = threadIdx.x;
-    const float* Gg = G + (int64_t)g * d * d;
-    float nqi = 1.f;
-    if (i < d) {
-        nqi = fmaxf(sqrtf(fmaxf(Gq[(int64_t)g * d * dstride + i * dstride + (dstride > 1 ? i : 0)], 0.f)), EPA_EPS);
-        const float nki = fmaxf(sqrtf(fmaxf(Gk[(int64_t)g * d * dstride + i * dstride + (dstride > 1 ? i : 0)], 0.f)), EPA_EPS);
-        nk[i] = nki;
-        nq_out[(int64_t)g * d + i] = nqi;
-        nk_out[(int64_t)g * d + i] = nki;
+    __shared__ float nq[64], nk[64], gl[64 * EPA_LD], kl[64 * EPA_LD], part[4][64];
+    const int g = blockIdx.x, h = g % heads, i = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    epa_stage(gl, G + (int64_t)g * d * d, d, d);
+    epa_stage(kl, KP + (int64_t)g * d * p, d, p);
+    if (threadIdx.x < d) {
+        const int64_t od = (int64_t)g * d * dstride + i * dstride + (dstride > 1 ? i : 0);
+        const float a = fmaxf(sqrtf(fmaxf(Gq[od], 0.f)), EPA_EPS), c = fmaxf(sqrtf(fmaxf(Gk[od], 0.f)), EPA_EPS);
+        nq[i] = a;
+        nk[i] = c;
+        nq_out[(int64_t)g * d + i] = a;
+        nk_out[(int64_t)g * d + i] = c;
     }
     __syncthreads();
-    if (i >= d) return;
+    const bool row = i < d;
     const float s1 = t1[h], s2 = t2[h];
+    const float nqi = row ? nq[i] : 1.f;
     float mx = -INFINITY;
-    for (int j = 0; j < d; ++j) mx = fmaxf(mx, Gg[i * d + j] / (nqi * nk[j]) * s1);
+    if (row)
+        for (int j = sl; j < d; j += 4) mx = fmaxf(mx, gl[i * EPA_LD + j] / (nqi * nk[j]) * s1);
+    part[sl][i] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(part[0][i], part[1][i]), fmaxf(part[2][i], part[3][i]));
+    __syncthreads();
     float sum = 0.f;
-    for (int j = 0; j < d; ++j) sum += expf(Gg[i * d + j] / (nqi * nk[j]) * s1 - mx);
-    const float inv = 1.f / sum;
-    for (int j = 0; j < d; ++j) At[(int64_t)g * d * d + j * d + i] = expf(Gg[i * d + j] / (nqi * nk[j]) * s1 - mx) * inv;
-    for (int c = 0; c < p; ++c) Mq[(int64_t)g * d * p + i * p + c] = KP[(int64_t)g * d * p + i * p + c] / nqi * s2;
+    if (row)
+        for (int j = sl; j < d; j += 4) sum += expf(gl[i * EPA_LD + j] / (nqi * nk[j]) * s1 - mx);
+    part[sl][i] = sum;
+    __syncthreads();
+    if (row) {
+        const float inv = 1.f / (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]);
+        for (int j = sl; j < d; j += 4) At[(int64_t)g * d * d + j * d + i] = expf(gl[i * EPA_LD + j] / (nqi * nk[j]) * s1 - mx) * inv;
+    }
+    // Mq rows: coalesced over c (thread -> column), rows dealt to the 4 x 64 / p' thread groups
+    for (int e = threadIdx.x; e < d * p; e += 256) {
+        const int r = e / p, c = e - r * p;
+        Mq[(int64_t)g * d * p + e] = kl[r * EPA_LD + c] / nq[r] * s2;
+    }
 }
 
 // backward: dG, dGq, dGk (zero off the diagonal), dKP, and per-(b, h) partials of dt1 / dt2 (the caller sums them over b)
-__global__ void __launch_bounds__(64) epa_small_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
-                                                           const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
-                                                           const float* __restrict__ At, const float* __restrict__ nq_in, const float* __restrict__ nk_in,
-                                                           const float* __restrict__ dAt, const float* __restrict__ dMq, float* __restrict__ dG,
-                                                           float* __restrict__ dGq, float* __restrict__ dGk, float* __restrict__ dKP,
-                                                           float* __restrict__ dt1_part, float* __restrict__ dt2_part, int heads, int d, int p,
-                                                           int dstride) {
-    __shared__ float nk[64], col[64][65], red1[64], red2[64];
-    const int g = blockIdx.x, h = g % heads, i = threadIdx.x;
+__global__ void __launch_bounds__(256) epa_small_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
+                                                            const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
+                                                            const float* __restrict__ At, const float* __restrict__ nq_in, const float* __restrict__ nk_in,
+                                                            const float* __restrict__ dAt, const float* __restrict__ dMq, float* __restrict__ dG,
+                                                            float* __restrict__ dGq, float* __restrict__ dGk, float* __restrict__ dKP,
+                                                            float* __restrict__ dt1_part, float* __restrict__ dt2_part, int heads, int d, int p,
+                                                            int dstride) {
+    __shared__ float nq[64], nk[64], gl[64 * EPA_LD], col[64 * EPA_LD];
+    __shared__ float pa[4][64], pb[4][64], pc[4][64];
+    const int g = blockIdx.x, h = g % heads, i = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t o2 = (int64_t)g * d * d, op = (int64_t)g * d * p;
-    if (i < d) nk[i] = nk_in[(int64_t)g * d + i];
+    epa_stage(gl, G + o2, d, d);
+    if (threadIdx.x < d) {
+        nq[i] = nq_in[(int64_t)g * d + i];
+        nk[i] = nk_in[(int64_t)g * d + i];
+    }
     __syncthreads();
+    const bool row = i < d;
     const float s1 = t1[h], s2 = t2[h];
+    const float nqi = row ? nq[i] : 1.f;
+    float dot = 0.f;                                        // sum_j dA_ij A_ij
+    if (row)
+        for (int j = sl; j < d; j += 4) dot += dAt[o2 + j * d + i] * At[o2 + j * d + i];
+    pa[sl][i] = dot;
+    __syncthreads();
+    dot = ((pa[0][i] + pa[1][i]) + pa[2][i]) + pa[3][i];
+    __syncthreads();
     float a1 = 0.f, a2 = 0.f, dnq = 0.f;
-    const float nqi = i < d ? nq_in[(int64_t)g * d + i] : 1.f;
-    if (i < d) {
-        float dot = 0.f;                                    // sum_j dA_ij A_ij
-        for (int j = 0; j < d; ++j) dot += dAt[o2 + j * d + i] * At[o2 + j * d + i];
-        for (int j = 0; j < d; ++j) {
+    if (row) {
+        for (int j = sl; j < d; j += 4) {
             const float a = At[o2 + j * d + i];
             const float dz = a * (dAt[o2 + j * d + i] - dot);          // softmax backward
-            const float r = G[o2 + i * d + j] / (nqi * nk[j]);
+            const float r = gl[i * EPA_LD + j] / (nqi * nk[j]);
             a1 += dz * r;                                   // dt1
             const float dr = dz * s1;
-            dG[o2 + i * d + j] = dr / (nqi * nk[j]);
+            gl[i * EPA_LD + j] = dr / (nqi * nk[j]);        // dG_ij (the element is this thread's own: read above, stored below)
             dnq -= dr * r / nqi;
-            col[i][j] = -dr * r;                            // contribution to dnk_j (/ nk_j below), summed over i by thread j
+            col[i * EPA_LD + j] = -dr * r;                  // contribution to dnk_j (/ nk_j below), summed over i
         }
-        for (int c = 0; c < p; ++c) {
+        for (int c = sl; c < p; c += 4) {                   // (d x p: a row per thread, its cache lines shared by the row's four slices)
             const float dm = dMq[op + i * p + c], kp = KP[op + i * p + c];
             dKP[op + i * p + c] = dm * s2 / nqi;
             a2 += dm * kp / nqi;                            // dt2
             dnq -= dm * kp * s2 / (nqi * nqi);
         }
     }
-    red1[i] = a1;
-    red2[i] = a2;
+    pa[sl][i] = a1;
+    pb[sl][i] = a2;
+    pc[sl][i] = dnq;
     __syncthreads();
-    if (i < d) {
+    for (int e = threadIdx.x; e < d * d; e += 256) {        // coalesced stores of the staged results
+        const int r = e / d, c = e - r * d;
+        dG[o2 + e] = gl[r * EPA_LD + c];
+    }
+    if (row && sl == 0) {
+        dnq = ((pc[0][i] + pc[1][i]) + pc[2][i]) + pc[3][i];
         float dnk = 0.f;
-        for (int r2 = 0; r2 < d; ++r2) dnk += col[r2][i];
+        for (int r2 = 0; r2 < d; ++r2) dnk += col[r2 * EPA_LD + i];
         dnk /= nk[i];
         // n = max(sqrt(max(x, 0)), eps): dn/dx = 1 / (2 sqrt(x)) where x > 0 and sqrt(x) > eps, else 0
         const int64_t od = (int64_t)g * d * dstride + i * dstride;
@@ -815,9 +861,12 @@ __global__ void __launch_bounds__(64) epa_small_bwd_kernel(const float* __restri
             dGk[od] = gk;
         }
     }
-    if (i == 0) {
+    if (threadIdx.x == 0) {
         float u = 0.f, v = 0.f;
-        for (int r2 = 0; r2 < d; ++r2) { u += red1[r2]; v += red2[r2]; }
+        for (int r2 = 0; r2 < d; ++r2) {
+            u += ((pa[0][r2] + pa[1][r2]) + pa[2][r2]) + pa[3][r2];
+            v += ((pb[0][r2] + pb[1][r2]) + pb[2][r2]) + pb[3][r2];
+        }
         dt1_part[g] = u;
         dt2_part[g] = v;
     }
@@ -828,8 +877,8 @@ __global__ void __launch_bounds__(64) epa_small_bwd_kernel(const float* __restri
 extern "C" int p4c_epa_small_fwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, float* At,
                                  float* Mq, float* nq, float* nk, int B, int heads, int d, int p, int diag_only, p4c_stream_t stream) {
     P4C_CHECK_ARG(G && Gq && Gk && KP && t1 && t2 && At && Mq && nq && nk, "p4c_epa_small_fwd: null pointer");
-    P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0, "p4c_epa_small_fwd: head width 1..64 (got %d)", d);
-    hipLaunchKernelGGL(ts::epa_small_fwd_kernel, dim3(B * heads), dim3(64), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, Mq, nq, nk, heads, d, p,
+    P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0 && p <= 64, "p4c_epa_small_fwd: head width / projection size 1..64 (got %d, %d)", d, p);
+    hipLaunchKernelGGL(ts::epa_small_fwd_kernel, dim3(B * heads), dim3(256), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, Mq, nq, nk, heads, d, p,
                        diag_only ? 1 : d);
     P4C_CHECK_LAUNCH("p4c_epa_small_fwd");
     return P4C_OK;
@@ -842,7 +891,7 @@ extern "C" int p4c_epa_small_bwd(const float* G, const float* Gq, const float* G
     P4C_CHECK_ARG(G && Gq && Gk && KP && t1 && t2 && At && nq && nk && dAt && dMq && dG && dGq && dGk && dKP && dt1_part && dt2_part,
                   "p4c_epa_small_bwd: null pointer");
     P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0, "p4c_epa_small_bwd: head width 1..64 (got %d)", d);
-    hipLaunchKernelGGL(ts::epa_small_bwd_kernel, dim3(B * heads), dim3(64), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, nq, nk, dAt, dMq, dG, dGq,
+    hipLaunchKernelGGL(ts::epa_small_bwd_kernel, dim3(B * heads), dim3(256), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, nq, nk, dAt, dMq, dG, dGq,
                        dGk, dKP, dt1_part, dt2_part, heads, d, p, diag_only ? 1 : d);
     P4C_CHECK_LAUNCH("p4c_epa_small_bwd");
     return P4C_OK;

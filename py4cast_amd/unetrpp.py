@@ -231,7 +231,7 @@ class EPA(nn.Module):
         if d % 4:
             raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")
         eps = 1e-12                                                                        # F.normalize's clamp
-        fused_small = d <= 64 and x.is_cuda and os.environ.get("P4C_NO_EPA_SMALL") != "1"
+        fused_small = d <= 64 and self.E.out_features <= 64 and x.is_cuda and os.environ.get("P4C_NO_EPA_SMALL") != "1"
         if fused_small and x.dtype == torch.bfloat16 and os.environ.get("P4C_NO_GRAM_NORMS") != "1":
             G, Gq, Gk = TS.gram_norms(q, k)          # q^T k and the squared column norms of q and k from one pass over q and k
         else:
