@@ -208,10 +208,13 @@ __global__ void __launch_bounds__(256) apply_mfma_kernel(Mat X, const float* __r
     const int nh = (heads - h0) < hw ? (heads - h0) : hw;
     const int c0 = cp * 64;
     const int ncols = (e - c0) < 64 ? (e - c0) : 64;                               // multiple of 8
-    for (int i = threadIdx.x; i < hw * DP * 16; i += 256) {
-        const int c4 = (i & 15) << 2, r = i >> 4, k = r % DP, hh = r / DP;
+    const bool two = ncols > 32;
+    // (rows of the image beyond ncols are never multiplied with anything stored: only the live column quads are staged)
+    const int cq = (ncols + 3) >> 2, cqa = two ? 16 : (ncols > 0 ? 8 : 0);        // live quads; quads read by the MFMAs (32 / 64 image rows)
+    for (int i = threadIdx.x; i < hw * DP * cqa; i += 256) {
+        const int c4 = (i % cqa) << 2, r = i / cqa, k = r % DP, hh = r / DP;
         p4c_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (hh < nh && k < d && c4 < ncols) v = load4f(M + b * m_bs + (int64_t)(h0 + hh) * m_hs + (int64_t)k * e + c0 + c4);
+        if (hh < nh && k < d && (c4 >> 2) < cq) v = load4f(M + b * m_bs + (int64_t)(h0 + hh) * m_hs + (int64_t)k * e + c0 + c4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const __bf16 t = (__bf16)v[j];
@@ -225,7 +228,6 @@ __global__ void __launch_bounds__(256) apply_mfma_kernel(Mat X, const float* __r
     const int r32 = lane & 31, kg = lane >> 5;
     const bf16* xb = reinterpret_cast<const bf16*>(X.base) + b * X.bs + (int64_t)(h0 + hh) * X.hs + kg * 8;
     TO* ob = reinterpret_cast<TO*>(O.base) + b * O.bs + (int64_t)(h0 + hh) * O.hs + c0;
-    const bool two = ncols > 32;
     const unsigned short* la = lmt + (hh * 64 + r32) * LDM + kg * 8;
     const int64_t ntiles = (N + 31) >> 5;
     for (int64_t tile = (int64_t)blockIdx.y * ntg + tg; tile < ntiles; tile += (int64_t)gridDim.y * ntg) {
@@ -635,7 +637,8 @@ static void launch_apply_mfma(const ts::Mat& X, const float* m, int64_t m_bs, in
     const int ntg = 4 / hw, zc = ((heads + hw - 1) / hw) * ((e + 63) / 64);
     const int64_t ntiles = (N + 31) / 32;
     int64_t ny = (ntiles + ntg - 1) / ntg;
-    const int64_t cap = (int64_t)num_cus() * 8 / ((int64_t)B * zc) + 1;
+    static const int wgs_per_cu = [] { const char* v = getenv("P4C_TS_APPLY_WGS"); return v ? atoi(v) : 4; }();
+    const int64_t cap = (int64_t)num_cus() * wgs_per_cu / ((int64_t)B * zc) + 1;     // several tiles per wave: M^T is staged once per workgroup
     if (ny > cap) ny = cap;
     const dim3 grid(B, (unsigned)ny, zc);
 #define P4C_APPLY_M(KC) hipLaunchKernelGGL((ts::apply_mfma_kernel<TO, KC, EPI>), grid, dim3(256), lds, st, X, m, m_bs, m_hs, O, heads, N, d, e, accumulate, hw, S)
