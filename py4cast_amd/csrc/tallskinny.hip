@@ -515,8 +515,13 @@ __global__ void __launch_bounds__(128) gram_mfma_kernel(Mat X, Mat Y, float* __r
 using namespace p4c;
 
 extern "C" int p4c_ts_gram_splits(int64_t N) {
-    int64_t s = (N + 63) / 64;        // two 32-token tiles per workgroup: the launch needs >> 256 workgroups to hide its load ->
-    if (s > 256) s = 256;             // barrier -> compute -> barrier rhythm behind other workgroups of the same CU
+    // tokens per split (P4C_TS_SPLIT_TOKENS; from 4 096 tokens 256 = eight 32-token tiles: four per wave of the matrix-core kernel, whose
+    // per-workgroup costs -- clearing the images, the LDS sum of the two waves, one partial per result block -- a single tile per wave
+    // did not amortise; with (sample, head) groups in blockIdx.x the launches still have hundreds of workgroups).
+    static const int forced = [] { const char* v = getenv("P4C_TS_SPLIT_TOKENS"); const int n = v ? atoi(v) : 0; return n > 0 && n < 32 ? 32 : n; }();
+    const int per = forced ? forced : (N >= 4096 ? 256 : 64);      // (measured per stage, profiles/r03_ts_micro.txt: the short stages keep 64)
+    int64_t s = (N + per - 1) / per;
+    if (s > 256) s = 256;
     if (s < 1) s = 1;
     return (int)s;
 }
