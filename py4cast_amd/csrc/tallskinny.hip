@@ -7,6 +7,10 @@
 // Both are HBM-streaming passes over the token matrices (arithmetic intensity <= 2*min(d,e)/esz flop per byte, far below the
 // ridge for the stages that matter: d = 8..32 at N = 16 384..1 024), operands addressed in place inside the (B, N, 4, heads, d)
 // output of the qkvv projection / the (B, N, C) token tensor through (group, row) strides: no permute / contiguous copies.
+// Two forms of each: fp32-exact VALU kernels on fp32 LDS tiles (gram_kernel / apply_kernel: the fp32 parity flavour, widths that are
+// not multiples of 8, unaligned views; d, e <= 64 per launch) and, for bf16 token matrices, the matrix-core kernels further down
+// (gram_mfma_kernel / apply_mfma_kernel: any width in one launch, the row softmax of the spatial branch and its adjoint as apply
+// epilogues) -- per-shape times of both in profiles/r03_ts_micro.txt (tools/diagnostics/ts_micro.py).
 #include "common.hpp"
 
 namespace p4c {
