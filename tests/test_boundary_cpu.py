@@ -169,3 +169,47 @@ def test_library_conv2d_pins_determinism_only_around_the_call():
     r2 = torch.autograd.grad(torch.nn.functional.conv2d(x, w, b, padding=1), (x, w, b), torch.ones_like(y2))
     assert all(torch.allclose(a, c, atol=1e-4) for a, c in zip(g2, r2))
     assert torch.backends.cudnn.deterministic is False
+
+
+def test_rollout_param_proxies_accumulate_like_autograd():
+    """trainer.RolloutParamProxies on a toy rollout (plain torch, CPU): T chained calls of one module on per-call stand-ins of its
+    parameters, gradients added into ``param.grad`` by the callback at the end of the backward -- equal to autograd's own accumulation,
+    with and without existing gradient buffers, over two micro-batches, and the stand-ins are reused from step to step."""
+    import torch
+    from torch import nn
+
+    from py4cast_amd.trainer import RolloutParamProxies
+
+    torch.manual_seed(5)
+    net = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.BatchNorm1d(16), nn.Linear(16, 6)).double()
+    x0 = torch.randn(8, 6, dtype=torch.float64)
+
+    def rollout(call):
+        x, out = x0, []
+        for _ in range(3):
+            x = x + call(x)
+            out.append(x)
+        return torch.stack(out)
+
+    ref = rollout(net)
+    ref.square().mean().backward()
+    want = [p.grad.clone() for p in net.parameters()]
+    running = net[2].running_mean.clone()
+
+    prox = RolloutParamProxies(net)
+    for existing in (False, True):
+        net.zero_grad(set_to_none=not existing)
+        n = 2 if existing else 1
+        for _ in range(n):
+            prox.begin()
+            res = rollout(prox.call)
+            prox.attach(res)
+            res.square().mean().backward()
+        for p, w in zip(net.parameters(), want):
+            torch.testing.assert_close(p.grad, n * w, rtol=1e-12, atol=1e-14)
+        assert all(q.grad is None for st in prox.sets for q in st.values()) and len(prox.sets) == 3
+    assert not torch.equal(net[2].running_mean, running)       # buffers are the module's own: batch statistics kept moving
+    ids = [id(q) for st in prox.sets for q in st.values()]
+    prox.begin()
+    rollout(prox.call)
+    assert ids == [id(q) for st in prox.sets for q in st.values()]     # reused, not rebuilt
