@@ -279,3 +279,104 @@ class _EpaSmall(torch.autograd.Function):
 def epa_small(G, Gq, Gk, KP, t1, t2):
     """(At, Mq) of an EPA block from its gram matrices, the token projection KP and the two temperatures (see _EpaSmall)."""
     return _EpaSmall.apply(G, Gq, Gk, KP, t1, t2)
+
+
+class _EpaCore(torch.autograd.Function):
+    """The whole efficient paired attention between the qkvv projection and the two output projections as ONE autograd node
+    (bf16 flavour, d, p <= 64): qkvv (B, N, 4, heads, d) -> (x_sa, x_ca), both (B, heads, N, d) token-major.  The pieces are the
+    kernels of this module (gram with norms, the small-matrix kernel, apply, apply with the softmax epilogues) and the library GEMM of
+    the token-axis projection E; what the node adds is the BACKWARD's bookkeeping: dq, dk, dv_ca, dv_sa are written straight into one
+    (B, N, 4, heads, d) gradient by accumulating applies -- through separate nodes autograd added q's and k's two contributions each
+    with its own kernel and a fifth node copied the four gradients into that buffer (four copies + two additions per block)."""
+
+    @staticmethod
+    def forward(ctx, qkvv, W, bias, t1, t2):
+        L.require_cuda(qkvv, W)
+        B, N, _, H, d = qkvv.shape
+        C, p, dt = H * d, W.shape[0], qkvv.dtype
+        q, k, vca, vsa = (qkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))
+        # q^T k with the squared column norms of q and k
+        ns = L.lib().p4c_ts_gram_splits(N)
+        part = torch.empty(B, ns, H, d * d + 2 * d, dtype=torch.float32, device=qkvv.device)
+        L.call("p4c_ts_gram_norms", L.ptr(q), L.dtype_code(dt), *_strides(q), L.ptr(k), L.dtype_code(dt), *_strides(k), L.ptr(part), B, H, N, d, d,
+               L.stream(qkvv.device), alg_bytes=B * H * N * 2 * d * q.element_size())
+        tot = part.sum(dim=1) if ns > 1 else part[:, 0]
+        G = tot[..., : d * d].reshape(B, H, d, d).contiguous()
+        n2 = tot[..., d * d:].contiguous()                                   # (B,H,2d): |q columns|^2, |k columns|^2
+        nq2, nk2 = n2[..., :d].contiguous(), n2[..., d:].contiguous()
+        # token-axis projection of k and v_sa (shared weights): a library GEMM over (B, 2, C, N) x (N, p)
+        from .ops_rows import weight_as
+
+        W16 = weight_as(W, dt)                                               # (p, N)
+        kv = torch.stack([k.permute(0, 2, 1, 3).reshape(B, N, C), vsa.permute(0, 2, 1, 3).reshape(B, N, C)], dim=1)   # (B,2,N,C)
+        proj = (kv.transpose(-1, -2) @ W16.t()).float() + bias.float()       # (B,2,C,p)
+        KP, VP = proj[:, 0].reshape(B, H, d, p).contiguous(), proj[:, 1].reshape(B, H, d, p).contiguous()
+        t1f, t2f = t1.detach().float().reshape(-1).contiguous(), t2.detach().float().reshape(-1).contiguous()
+        At = torch.empty(B, H, d, d, dtype=torch.float32, device=qkvv.device)
+        Mq = torch.empty(B, H, d, p, dtype=torch.float32, device=qkvv.device)
+        nrm = torch.empty(2, B, H, d, dtype=torch.float32, device=qkvv.device)
+        L.call("p4c_epa_small_fwd", L.ptr(G), L.ptr(nq2), L.ptr(nk2), L.ptr(KP), L.ptr(t1f), L.ptr(t2f), L.ptr(At), L.ptr(Mq), L.ptr(nrm[0]),
+               L.ptr(nrm[1]), B, H, d, p, 1, L.stream(qkvv.device))
+        x_ca = _apply_raw(vca, At, dt)
+        S = _apply_softmax(q, Mq, 1)
+        x_sa = _apply_raw(S, VP.transpose(-1, -2), dt)
+        ctx.save_for_backward(qkvv, W16, kv, G, nq2, nk2, KP, VP, t1f, t2f, At, Mq, nrm, S)
+        ctx.meta = (W.dtype, bias.dtype, t1.shape, t1.dtype)
+        return x_sa, x_ca
+
+    @staticmethod
+    def backward(ctx, dx_sa, dx_ca):
+        qkvv, W16, kv, G, nq2, nk2, KP, VP, t1f, t2f, At, Mq, nrm, S = ctx.saved_tensors
+        wdt, bdt, tshape, tdt = ctx.meta
+        B, N, _, H, d = qkvv.shape
+        C, p, dt = H * d, KP.shape[-1], qkvv.dtype
+        q, k, vca, vsa = (qkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))
+        ok = lambda t: t.stride(3) == 1 and all(v % 8 == 0 for v in _strides(t)) and t.data_ptr() % 16 == 0   # noqa: E731
+        dx_sa = dx_sa if ok(dx_sa) else dx_sa.contiguous()
+        dx_ca = dx_ca if ok(dx_ca) else dx_ca.contiguous()
+        dqkvv = torch.empty_like(qkvv)
+        dq, dk, dvca, dvsa = (dqkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))
+        # channel branch x_ca = v_ca At
+        _apply_into(dvca, dx_ca, At.transpose(-1, -2), False)
+        dAt = _gram_raw(vca, dx_ca)
+        # spatial branch x_sa = softmax(q Mq) VP^T
+        dL = _apply_softmax(dx_sa, VP, 2, S)                                 # dS = dx VP, softmax adjoint in the epilogue
+        dVP = _gram_raw(S, dx_sa).transpose(-1, -2)                          # d(VP^T) = S^T dx  ->  dVP (B,H,d,p)
+        _apply_into(dq, dL, Mq.transpose(-1, -2), False)                     # dq, first contribution
+        dMq = _gram_raw(q, dL)
+        # small matrices
+        dG = torch.empty(B, H, d, d, dtype=torch.float32, device=G.device)
+        dn = torch.empty(2, B, H, d, dtype=torch.float32, device=G.device)
+        dKP = torch.empty_like(KP)
+        dtp = torch.empty(2, B, H, dtype=torch.float32, device=G.device)
+        L.call("p4c_epa_small_bwd", L.ptr(G), L.ptr(nq2), L.ptr(nk2), L.ptr(KP), L.ptr(t1f), L.ptr(t2f), L.ptr(At), L.ptr(nrm[0]), L.ptr(nrm[1]),
+               L.ptr(dAt.float().contiguous()), L.ptr(dMq.float().contiguous()), L.ptr(dG), L.ptr(dn[0]), L.ptr(dn[1]), L.ptr(dKP), L.ptr(dtp[0]),
+               L.ptr(dtp[1]), B, H, d, p, 1, L.stream(G.device))
+        dts = dtp.sum(dim=1)
+        # token-axis projection: proj = kv^T W16^T + bias
+        g = torch.stack([dKP.reshape(B, C, p), dVP.reshape(B, C, p)], dim=1)         # (B,2,C,p) fp32
+        dbias = g.sum(dim=(0, 1, 2)).to(bdt)
+        g16 = g.to(dt)
+        dkv = (g16 @ W16).transpose(-1, -2)                                          # (B,2,N,C) view of (B,2,C,N)
+        dW = torch.bmm(g16.reshape(2 * B, C, p).transpose(1, 2), kv.reshape(2 * B, N, C).transpose(1, 2)).sum(dim=0).to(wdt)   # (p,N)
+        dk.copy_(dkv[:, 0].reshape(B, N, H, d).permute(0, 2, 1, 3))                   # k: first contribution
+        dvsa.copy_(dkv[:, 1].reshape(B, N, H, d).permute(0, 2, 1, 3))
+        # q^T k and the norms: dq += k dG^T + 2 q diag(dnq2),  dk += q dG + 2 k diag(dnk2)
+        _apply_into(dq, k, dG.transpose(-1, -2), True)
+        _apply_into(dq, q, torch.diag_embed(2.0 * dn[0]), True)
+        _apply_into(dk, q, dG, True)
+        _apply_into(dk, k, torch.diag_embed(2.0 * dn[1]), True)
+        return dqkvv, dW, dbias, dts[0].view(tshape).to(tdt), dts[1].view(tshape).to(tdt)
+
+
+def epa_core_ok(qkvv: torch.Tensor, p: int) -> bool:
+    """bf16 qkvv (B, N, 4, heads, d) with d, p multiples of 8 up to 64 and 16-byte aligned head rows."""
+    if qkvv.dim() != 5 or qkvv.dtype != torch.bfloat16 or not qkvv.is_contiguous():
+        return False
+    d = qkvv.shape[-1]
+    return d % 8 == 0 and p % 8 == 0 and d <= 64 and p <= 64 and 64 % (d // 8) == 0 and spatial_fused_ok(qkvv[:, :, 0].permute(0, 2, 1, 3), p)
+
+
+def epa_core(qkvv, W, bias, t1, t2):
+    """(x_sa, x_ca) of an EPA block from its qkvv projection, the token-axis Linear E (weight (p, N), bias) and the temperatures."""
+    return _EpaCore.apply(qkvv, W, bias, t1, t2)

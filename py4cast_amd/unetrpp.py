@@ -227,6 +227,11 @@ class EPA(nn.Module):
         B, N, C = x.shape
         h, d = self.heads, C // self.heads
         qkvv = _linear(self.qkvv, x).view(B, N, 4, h, d)
+        if x.is_cuda and os.environ.get("P4C_EPA_CORE") != "0" and TS.epa_core_ok(qkvv, self.E.out_features):
+            # the attention between the projections as one node: its backward writes dq / dk / dv straight into the gradient of qkvv
+            x_sa, x_ca = TS.epa_core(qkvv, self.E.weight, self.E.bias, self.temperature, self.temperature2)
+            x_sa, x_ca = (t.permute(0, 2, 1, 3).reshape(B, N, C) for t in (x_sa, x_ca))
+            return torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)
         q, k, v_ca, v_sa = _SplitQKVV.apply(qkvv)                                          # (B,h,N,d) views, nothing copied
         if d % 4:
             raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")

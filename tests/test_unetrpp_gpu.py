@@ -360,3 +360,33 @@ def test_unetrpp_takes_its_input_straight_from_build_x(gpu_device):
     assert abs(la - lb) / abs(lb) < 1e-3, (la, lb)
     cos = float((ga.double() * gb.double()).sum() / (ga.double().norm() * gb.double().norm()))
     assert cos > 0.999, cos
+
+
+@pytest.mark.parametrize("N,hidden,heads,proj", [(256, 64, 4, 16), (1024, 128, 16, 64), (4096, 128, 4, 32)])
+def test_epa_core_as_one_node(gpu_device, monkeypatch, N, hidden, heads, proj):
+    """The attention between the projections as ONE autograd node (ops_ts.epa_core: dq / dk / dv written straight into the gradient of
+    the qkvv projection) against the same module composed of separate nodes: identical output (same kernels, same order), gradients
+    equal up to the bf16 rounding of sums taken in another order."""
+    from py4cast_amd.unetrpp import EPA
+
+    torch.manual_seed(N + heads)
+    m = EPA(N, hidden, proj, heads).to(gpu_device)
+    with torch.no_grad():
+        m.temperature.uniform_(0.5, 1.5)
+        m.temperature2.uniform_(0.5, 1.5)
+    x0 = torch.randn(2, N, hidden, generator=torch.Generator().manual_seed(7)).to(gpu_device).to(torch.bfloat16)
+    w = torch.randn(2, N, hidden, generator=torch.Generator().manual_seed(8)).to(gpu_device)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("P4C_EPA_CORE", flag)
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        (y.float() * w).sum().backward()
+        out[flag] = (y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in m.named_parameters()})
+    (ya, xa, ga), (yb, xb, gb) = out["1"], out["0"]
+    print("epa_core vs composed: output", _rel(ya, yb), "dx", _rel(xa, xb), {n: round(_rel(ga[n], gb[n]), 5) for n in ga})
+    assert _rel(ya, yb) < 2e-3
+    assert _rel(xa, xb) < 2e-2
+    for n in ga:
+        assert _rel(ga[n], gb[n]) < 2e-2, n
