@@ -308,7 +308,7 @@ class _EpaCore(torch.autograd.Function):
         from .ops_rows import weight_as
 
         W16 = weight_as(W, dt)                                               # (p, N)
-        kv = torch.stack([k.permute(0, 2, 1, 3).reshape(B, N, C), vsa.permute(0, 2, 1, 3).reshape(B, N, C)], dim=1)   # (B,2,N,C)
+        kv = qkvv[:, :, 1::2].permute(0, 2, 1, 3, 4).reshape(B, 2, N, C)      # k and v_sa token-major, ONE strided copy: (B,2,N,C)
         proj = (kv.transpose(-1, -2) @ W16.t()).float() + bias.float()       # (B,2,C,p)
         KP, VP = proj[:, 0].reshape(B, H, d, p).contiguous(), proj[:, 1].reshape(B, H, d, p).contiguous()
         t1f, t2f = t1.detach().float().reshape(-1).contiguous(), t2.detach().float().reshape(-1).contiguous()
@@ -359,13 +359,13 @@ class _EpaCore(torch.autograd.Function):
         g16 = g.to(dt)
         dkv = (g16 @ W16).transpose(-1, -2)                                          # (B,2,N,C) view of (B,2,C,N)
         dW = torch.bmm(g16.reshape(2 * B, C, p).transpose(1, 2), kv.reshape(2 * B, N, C).transpose(1, 2)).sum(dim=0).to(wdt)   # (p,N)
-        dk.copy_(dkv[:, 0].reshape(B, N, H, d).permute(0, 2, 1, 3))                   # k: first contribution
-        dvsa.copy_(dkv[:, 1].reshape(B, N, H, d).permute(0, 2, 1, 3))
+        dqkvv[:, :, 1::2].copy_(dkv.reshape(B, 2, N, H, d).permute(0, 2, 1, 3, 4))    # dk (first contribution) and dv_sa: one copy
         # q^T k and the norms: dq += k dG^T + 2 q diag(dnq2),  dk += q dG + 2 k diag(dnk2)
+        D = torch.diag_embed(dn * 2.0)                                               # (2,B,H,d,d)
         _apply_into(dq, k, dG.transpose(-1, -2), True)
-        _apply_into(dq, q, torch.diag_embed(2.0 * dn[0]), True)
+        _apply_into(dq, q, D[0], True)
         _apply_into(dk, q, dG, True)
-        _apply_into(dk, k, torch.diag_embed(2.0 * dn[1]), True)
+        _apply_into(dk, k, D[1], True)
         return dqkvv, dW, dbias, dts[0].view(tshape).to(tdt), dts[1].view(tshape).to(tdt)
 
 
