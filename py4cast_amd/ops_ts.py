@@ -302,8 +302,7 @@ class _EpaCore(torch.autograd.Function):
                L.stream(qkvv.device), alg_bytes=B * H * N * 2 * d * q.element_size())
         tot = part.sum(dim=1) if ns > 1 else part[:, 0]
         G = tot[..., : d * d].reshape(B, H, d, d).contiguous()
-        n2 = tot[..., d * d:].contiguous()                                   # (B,H,2d): |q columns|^2, |k columns|^2
-        nq2, nk2 = n2[..., :d].contiguous(), n2[..., d:].contiguous()
+        nq2, nk2 = tot[..., d * d: d * d + d].contiguous(), tot[..., d * d + d:].contiguous()   # (B,H,d): |q columns|^2, |k columns|^2
         # token-axis projection of k and v_sa (shared weights): a library GEMM over (B, 2, C, N) x (N, p)
         from .ops_rows import weight_as
 
