@@ -90,7 +90,7 @@ def grad_view(t: Optional[torch.Tensor]):
     t = None, False when there is no such buffer (no .grad yet, another dtype or layout)."""
     if t is None:
         return None
-    base = t._base if t._base is not None else t
+    base = L._base(t)      # (the parameter behind a slice, or behind a rollout's per-step stand-in of it)
     g = base.grad
     if (not base.is_leaf or g is None or g.dtype != torch.float32 or g.shape != base.shape or g.stride() != base.stride()
             or t.dtype != torch.float32):
