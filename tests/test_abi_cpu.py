@@ -28,6 +28,22 @@ def test_library_exports_every_declared_symbol():
     assert handle.p4c_version() == 100
 
 
+def test_tall_skinny_dispatch_rules_of_the_library():
+    """Host-side rules of the EPA kernels (no GPU call): which (dtype, width) pairs the matrix-core kernels take -- what
+    py4cast_amd/ops_ts.py asks before it chunks a product into 64-column launches -- and the token splits of ``gram``."""
+    from py4cast_amd import _lib
+
+    h, F32, BF16 = _lib.lib(), _lib.F32, _lib.BF16
+    assert h.p4c_ts_apply_wide_ok(BF16, BF16, 32, 64) == 1 and h.p4c_ts_apply_wide_ok(BF16, F32, 256, 256) == 1
+    assert h.p4c_ts_apply_wide_ok(F32, F32, 32, 64) == 0          # the fp32 flavour keeps the exact VALU kernels
+    assert h.p4c_ts_apply_wide_ok(BF16, BF16, 12, 36) == 0        # widths off the 8-column granularity
+    assert h.p4c_ts_apply_wide_ok(BF16, BF16, 264, 8) == 0        # reduction wider than the 16 chunks of 16 a lane holds
+    assert h.p4c_ts_gram_wide_ok(BF16, BF16, 256, 256) == 1 and h.p4c_ts_gram_wide_ok(BF16, F32, 32, 32) == 0
+    assert h.p4c_ts_gram_wide_ok(BF16, BF16, 24, 40) == 1 and h.p4c_ts_gram_wide_ok(BF16, BF16, 20, 40) == 0
+    # 256 tokens per split from 4 096 tokens, 64 below; never more than 256 splits
+    assert [h.p4c_ts_gram_splits(n) for n in (31, 256, 1024, 4096, 16384, 1 << 20)] == [1, 4, 16, 16, 64, 256]
+
+
 def test_no_cpu_fallback():
     from py4cast_amd import _lib, ops
 
