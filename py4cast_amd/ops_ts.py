@@ -340,7 +340,7 @@ class _EpaCore(torch.autograd.Function):
         dAt = _gram_raw(vca, dx_ca)
         # spatial branch x_sa = softmax(q Mq) VP^T
         dL = _apply_softmax(dx_sa, VP, 2, S)                                 # dS = dx VP, softmax adjoint in the epilogue
-        dVP = _gram_raw(S, dx_sa).transpose(-1, -2)                          # d(VP^T) = S^T dx  ->  dVP (B,H,d,p)
+        dVP = _gram_raw(dx_sa, S)                                            # d(VP^T) = S^T dx, i.e. dVP = dx^T S (B,H,d,p)
         _apply_into(dq, dL, Mq.transpose(-1, -2), False)                     # dq, first contribution
         dMq = _gram_raw(q, dL)
         # small matrices
