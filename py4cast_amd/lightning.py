@@ -399,9 +399,6 @@ class AutoRegressiveLightning(_Base):
         prev_states = batch.inputs
         prediction_list = []
         T = batch.num_pred_steps
-        # A model may take its input straight from build_x in the layout its first kernels want -- (dtype, channel count padded with
-        # zeros), e.g. bf16 rows of 96 channels -- instead of fp32 rows it would cast and pad itself (two passes over the full-resolution
-        # input per AR step, and their adjoints); its output may then come back in that dtype too (the state update takes any).
         # (single process, gradients on, several model calls): per-call stand-ins of the parameters, trainer.RolloutParamProxies.
         # By default only while the step is being captured into a HIP graph: swapping the parameters in costs the host ~1.5 ms per
         # model call (SwinUNetR eager: 62.8 -> 67.1 ms per step), nothing in a replay (30.3 -> 29.7); ``use_param_proxies`` forces it.
@@ -419,6 +416,9 @@ class AutoRegressiveLightning(_Base):
                 proxies = self.__dict__["_param_proxies"] = RolloutParamProxies(self.model)
             proxies.begin()
         call_model = self.model if proxies is None else proxies.call
+        # A model may take its input straight from build_x in the layout its first kernels want -- (dtype, channel count padded with
+        # zeros), e.g. bf16 rows of 96 channels -- instead of fp32 rows it would cast and pad itself (two passes over the full-resolution
+        # input per AR step, and their adjoints); its output may then come back in that dtype too (the state update takes any).
         x_format = {}
         fmt = getattr(self.model, "rollout_input_format", None)
         if fmt is not None and not self.channels_last and not self.model.features_second and getattr(self, "use_rollout_input_format", True):
