@@ -281,6 +281,22 @@ def epa_small(G, Gq, Gk, KP, t1, t2):
     return _EpaSmall.apply(G, Gq, Gk, KP, t1, t2)
 
 
+_TWO_EYE = {}
+
+
+def _two_eye(d: int, device) -> torch.Tensor:
+    """2 I (d x d), made once per device -- and once per HIP-graph capture (a tensor made while capturing lives in the graph's pool and
+    holds nothing until a replay has run: it must not leak into the process-wide cache)."""
+    key = ("two_eye", d, str(device))
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    cache = L.capture_cache() if capturing else _TWO_EYE
+    if cache is None:
+        return 2.0 * torch.eye(d, dtype=torch.float32, device=device)
+    if key not in cache:
+        cache[key] = 2.0 * torch.eye(d, dtype=torch.float32, device=device)
+    return cache[key]
+
+
 class _EpaCore(torch.autograd.Function):
     """The whole efficient paired attention between the qkvv projection and the two output projections as ONE autograd node
     (bf16 flavour, d, p <= 64): qkvv (B, N, 4, heads, d) -> (x_sa, x_ca), both (B, heads, N, d) token-major.  The pieces are the
@@ -307,9 +323,9 @@ class _EpaCore(torch.autograd.Function):
         from .ops_rows import weight_as
 
         W16 = weight_as(W, dt)                                               # (p, N)
-        kv = qkvv[:, :, 1::2].permute(0, 2, 1, 3, 4).reshape(B, 2, N, C)      # k and v_sa token-major, ONE strided copy: (B,2,N,C)
-        proj = (kv.transpose(-1, -2) @ W16.t()).float() + bias.float()       # (B,2,C,p)
-        KP, VP = proj[:, 0].reshape(B, H, d, p).contiguous(), proj[:, 1].reshape(B, H, d, p).contiguous()
+        kv = qkvv[:, :, 1::2].permute(2, 0, 1, 3, 4).reshape(2, B, N, C)      # k and v_sa token-major, ONE strided copy: (2,B,N,C)
+        proj = (kv.transpose(-1, -2) @ W16.t()).float() + bias.float()       # (2,B,C,p): KP and VP are its two contiguous halves
+        KP, VP = proj[0].view(B, H, d, p), proj[1].view(B, H, d, p)
         t1f, t2f = t1.detach().float().reshape(-1).contiguous(), t2.detach().float().reshape(-1).contiguous()
         At = torch.empty(B, H, d, d, dtype=torch.float32, device=qkvv.device)
         Mq = torch.empty(B, H, d, p, dtype=torch.float32, device=qkvv.device)
@@ -353,14 +369,14 @@ class _EpaCore(torch.autograd.Function):
                L.ptr(dtp[1]), B, H, d, p, 1, L.stream(G.device))
         dts = dtp.sum(dim=1)
         # token-axis projection: proj = kv^T W16^T + bias
-        g = torch.stack([dKP.reshape(B, C, p), dVP.reshape(B, C, p)], dim=1)         # (B,2,C,p) fp32
+        g = torch.stack([dKP.reshape(B, C, p), dVP.reshape(B, C, p)], dim=0)         # (2,B,C,p) fp32
         dbias = g.sum(dim=(0, 1, 2)).to(bdt)
         g16 = g.to(dt)
-        dkv = (g16 @ W16).transpose(-1, -2)                                          # (B,2,N,C) view of (B,2,C,N)
+        dkv = (g16 @ W16).transpose(-1, -2)                                          # (2,B,N,C) view of (2,B,C,N)
         dW = torch.bmm(g16.reshape(2 * B, C, p).transpose(1, 2), kv.reshape(2 * B, N, C).transpose(1, 2)).sum(dim=0).to(wdt)   # (p,N)
-        dqkvv[:, :, 1::2].copy_(dkv.reshape(B, 2, N, H, d).permute(0, 2, 1, 3, 4))    # dk (first contribution) and dv_sa: one copy
+        dqkvv[:, :, 1::2].copy_(dkv.reshape(2, B, N, H, d).permute(1, 2, 0, 3, 4))    # dk (first contribution) and dv_sa: one copy
         # q^T k and the norms: dq += k dG^T + 2 q diag(dnq2),  dk += q dG + 2 k diag(dnk2)
-        D = torch.diag_embed(dn * 2.0)                                               # (2,B,H,d,d)
+        D = dn.unsqueeze(-1) * _two_eye(d, dn.device)                                # (2,B,H,d,d) = 2 diag(dn), one launch
         _apply_into(dq, k, dG.transpose(-1, -2), True)
         _apply_into(dq, q, D[0], True)
         _apply_into(dk, q, dG, True)
