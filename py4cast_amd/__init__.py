@@ -32,3 +32,11 @@ _TUNED_GEMMS = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuni
 if ("PYTORCH_TUNABLEOP_ENABLED" not in _os.environ and _os.environ.get("P4C_NO_TUNED_GEMMS") != "1"
         and _os.path.exists(_TUNED_GEMMS)):
     _os.environ["P4C_TUNED_GEMMS_FILE"] = _TUNED_GEMMS   # read by _lib.require_cuda at the first native call on a GPU tensor
+
+
+def invalidate_param_caches():
+    """Parameter storage was written behind autograd's back (``p.data.copy_``, a collective into ``p.data``): drop what the ops
+    cached per parameter version.  See INTEGRATION.md, "Parameter caches"."""
+    from . import _lib
+
+    _lib.invalidate_param_caches()

@@ -88,6 +88,16 @@ _lib = None
 # bumped whenever a kernel updates parameters through raw pointers (FlatAdamW): caches of re-laid parameters key on it as well
 # as on tensor._version
 PARAM_EPOCH = [0]
+
+
+def invalidate_param_caches():
+    """Tell the per-parameter caches (bf16 casts, re-laid weight images) that parameter storage was written behind autograd's
+    back: ``p.data.copy_`` (an EMA / SWA swap), a third-party optimizer that writes through ``.data``, a collective into
+    ``p.data``.  ``tensor._version`` does not move for such writes; FlatAdamW, FlatDDP.broadcast_parameters and
+    FlatDDP.all_gather_params call this themselves ("Parameter caches")."""
+    PARAM_EPOCH[0] += 1
+
+
 # Values derived from the parameters (re-laid weight images, bf16 copies of weight blocks) are cached per parameter version in
 # eager mode.  Inside a HIP-graph capture they must be produced by kernels of THAT graph (a replay has to see the current
 # parameters), but once per capture is enough: the capturing code (trainer.GraphedTrainingStep) opens a scope, the ops keep what

@@ -662,11 +662,22 @@ class _NativeRolloutFn(torch.autograd.Function):
         defer = T > 1 and os.environ.get("P4C_DEFER_JOIN", "1") != "0"
         if defer:
             L.call("p4c_side_stream_defer", 1)
+        ok = False
         try:
-            return _NativeRolloutFn._sweep(ctx, g_pred, gl, dy, dx, dprev, gflat, flat, scratch, desc, desc0, stream, target, defer)
+            out = _NativeRolloutFn._sweep(ctx, g_pred, gl, dy, dx, dprev, gflat, flat, scratch, desc, desc0, stream, target, defer)
+            ok = True
+            return out
         finally:
             if defer:
                 L.call("p4c_side_stream_defer", 0)
+                if not ok:
+                    # the sweep raised between two calls: weight gradients already on the side stream still read xs / saveds / dy,
+                    # which the unwinding is about to release to the allocator -- make the caller's stream (the one the allocator
+                    # orders re-use on) wait for them first.  (The join itself must not mask the original error.)
+                    try:
+                        L.call("p4c_side_stream_join", stream)
+                    except Exception:  # noqa: BLE001
+                        pass
 
     @staticmethod
     def _sweep(ctx, g_pred, gl, dy, dx, dprev, gflat, flat, scratch, desc, desc0, stream, target, defer):

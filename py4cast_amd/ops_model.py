@@ -2,6 +2,7 @@
 used by the parity tests and available for composing other conv models behind the plugin API."""
 
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -160,6 +161,34 @@ def conv_nhwc(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return y if CO == 64 else y[..., :CO]
 
 
+class _DeterministicSolvers:
+    """``torch.backends.cudnn.deterministic = True`` for the duration of one library call.  The flag is process-global and the
+    backward runs on autograd's worker thread: the toggle is serialised by a lock and counted, so that overlapping calls (a forward
+    on the main thread, a backward of another graph on the engine thread) restore the HOST's value exactly once, after the last of
+    them has left.  (A host convolution on a third thread may still observe the pinned flag while a call of ours is inside; set
+    ``torch.backends.cudnn.deterministic`` yourself, as ``bench.py --deterministic`` does, to take the toggle out altogether.)"""
+
+    _lock = threading.Lock()
+    _depth = 0
+    _keep = False
+
+    def __enter__(self):
+        cls = _DeterministicSolvers
+        with cls._lock:
+            if cls._depth == 0:
+                cls._keep = torch.backends.cudnn.deterministic
+                torch.backends.cudnn.deterministic = True
+            cls._depth += 1
+
+    def __exit__(self, *exc):
+        cls = _DeterministicSolvers
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0:
+                torch.backends.cudnn.deterministic = cls._keep
+        return False
+
+
 class _LibraryConv(torch.autograd.Function):
     """torch's convolution (MIOpen) for the shapes the MFMA kernels do not serve, pinned to the library's DETERMINISTIC solvers in the
     forward AND in both gradients.  The default solver choice accumulates with atomics whose order changes from run to run; with bf16
@@ -173,25 +202,17 @@ class _LibraryConv(torch.autograd.Function):
     def forward(ctx, x, w, bias, stride, padding, dilation, groups):
         ctx.save_for_backward(x, w)
         ctx.conf = (tuple(stride), tuple(padding), tuple(dilation), int(groups), None if bias is None else list(bias.shape))
-        keep = torch.backends.cudnn.deterministic
-        torch.backends.cudnn.deterministic = True
-        try:
+        with _DeterministicSolvers():
             return torch.nn.functional.conv2d(x, w, bias, stride, padding, dilation, groups)
-        finally:
-            torch.backends.cudnn.deterministic = keep
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         stride, padding, dilation, groups, bias_sizes = ctx.conf
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], bias_sizes is not None and ctx.needs_input_grad[2]]
-        keep = torch.backends.cudnn.deterministic
-        torch.backends.cudnn.deterministic = True
-        try:
+        with _DeterministicSolvers():
             gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, bias_sizes, list(stride), list(padding), list(dilation), False,
                                                              [0, 0], groups, mask)
-        finally:
-            torch.backends.cudnn.deterministic = keep
         return gx, gw, gb, None, None, None, None
 
 

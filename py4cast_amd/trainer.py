@@ -126,6 +126,9 @@ class FlatDDP:
 
     def broadcast_parameters(self, src: int = 0):
         """Same initial weights on every rank (DDP's constructor does the same)."""
+        from . import _lib as L
+
+        L.invalidate_param_caches()   # (written through .data: tensor._version does not move)
         if self.flat_param is not None:
             dist.broadcast(self.flat_param, src)
             return
@@ -160,6 +163,13 @@ class FlatDDP:
         if not self.overlap:
             return
         self.wait()
+        if not self._grads_are_views():
+            # a grad tensor was replaced since the last exchange (optimizer.zero_grad(set_to_none=True), module.zero_grad(), a
+            # `p.grad = ...` assignment): a bucket issued from a hook would reduce the flat buffer's stale bytes while the real
+            # gradient sits elsewhere.  Stay un-armed: all_reduce_grads() then regathers and runs the ordinary exchange.
+            self._armed = False
+            self.issued_in_backward = 0
+            return
         self._armed = True
         self._issued = [False] * len(self.buckets)
         self._pending = list(self._bucket_params)
@@ -225,6 +235,12 @@ class FlatDDP:
         if self.world_size <= 1:
             return
         if not self._views_ok or not self._grads_are_views():
+            if self._armed:
+                # a gradient tensor was replaced DURING the armed backward: whatever the hooks issued reduced bytes that were not
+                # the gradient.  Let those collectives finish, then exchange every bucket again from the regathered buffer (every
+                # rank takes this branch together: it follows from the program, not from data).
+                self.wait()
+                self._issued = [False] * len(self.buckets)
             self._regather()
         if self.overlap and self._armed:
             # what the hooks have not issued yet (parameters that received no gradient in this pass never fire theirs)
@@ -258,6 +274,9 @@ class FlatDDP:
                     dist.all_gather_into_tensor(piece, mine)
 
         self._on_comm_stream(gather)
+        from . import _lib as L
+
+        L.invalidate_param_caches()   # (the other ranks' shards arrive through the flat buffer: tensor._version does not move)
         if wait:
             self.wait()
 
@@ -294,7 +313,11 @@ class RolloutParamProxies:
     UNetRPP training step, 4 % of its kernel time).  Here call t runs on detached leaf views of the parameters (same storage, their own
     ``.grad``: the first contribution is kept by reference, no kernel) and one callback at the end of the backward adds the T gradient
     sets into ``param.grad`` with multi-tensor launches (``torch._foreach_add_``: a few dozen launches).  Same sums in a different
-    order of additions.  Single-process only: a gradient exchange driven by per-parameter hooks (FlatDDP, N > 1) never sees these."""
+    order of additions.  Single-process only: a gradient exchange driven by per-parameter hooks (FlatDDP, N > 1) never sees these.
+
+    Contract: the transfer runs as an autograd-engine callback of every backward that reaches the tensor given to ``attach`` (any
+    number of backwards: ``retain_graph``, several losses); gradients a backward left in the stand-ins WITHOUT reaching that tensor
+    are transferred by the next ``begin()`` -- never dropped."""
 
     def __init__(self, model: torch.nn.Module):
         self.model = model
@@ -303,6 +326,8 @@ class RolloutParamProxies:
         self.used = 0
 
     def begin(self):
+        if self.used:
+            self.finalize()   # (a backward that never reached the attached tensor left its gradients in the stand-ins: keep them)
         self.used = 0
 
     def call(self, x):
@@ -312,7 +337,7 @@ class RolloutParamProxies:
         self.used += 1
         for n, p in self.named:
             q = prox.get(n)
-            if q is None or q.data_ptr() != p.data_ptr() or q.shape != p.shape or q.grad is not None:
+            if q is None or q.data_ptr() != p.data_ptr() or q.shape != p.shape:
                 q = p.detach().requires_grad_(True)
                 q._p4c_owner = p      # caches keyed on the owner of a weight's storage (weight images, casts) see the parameter
                 prox[n] = q
@@ -344,7 +369,7 @@ class RolloutParamProxies:
                         src.append(g)
                 if tgt:
                     torch._foreach_add_(tgt, src)
-        self.used = 0
+        # (`used` stays: a second backward through the same rollout finds its stand-ins here again; begin() resets it)
 
 
 class GraphedTrainingStep:
@@ -640,6 +665,9 @@ class Trainer:
 
                     host_random = float(getattr(module, "mask_ratio", 0) or 0) != 0 or any(
                         isinstance(m_, torch.nn.modules.dropout._DropoutNd) and m_.p > 0 for m_ in module.modules())
+                    # (the warm-up passes draw random numbers too: the training run's generators continue where they were)
+                    rng_cpu = torch.get_rng_state()
+                    rng_dev = torch.cuda.get_rng_state(self.device) if self.device.type == "cuda" else None
                     try:
                         if host_random:
                             # a host-side random element (the block mask is drawn on the CPU and copied, lightning.py:580-581;
@@ -649,13 +677,25 @@ class Trainer:
                     except GraphReplayMismatch as exc:   # a replay that is not the eager step is not used: stay eager, say so
                         warnings.warn(f"HIP-graph replay rejected, training continues with eager launches: {exc}")
                         use_graph = False
-                    except Exception as exc:  # noqa: BLE001  (a step that cannot be captured at all: also eager, not a crash)
+                    except torch.cuda.OutOfMemoryError:
+                        raise   # not a property of the capture: the eager step would meet the same wall, far from its cause
+                    except RuntimeError as exc:
+                        # Only what says "this step cannot be captured" turns into eager launches: an operation that is not
+                        # permitted while a stream is capturing (a synchronising call, a blocking copy, an allocation outside the
+                        # graph's pool).  Anything else -- an illegal address, a failed launch, a library error -- is a device
+                        # fault and must surface here.
+                        msg = str(exc).lower()
+                        if not any(k in msg for k in ("captur", "graph", "operation not permitted", "streamcapture")):
+                            raise
                         warnings.warn(f"HIP-graph capture failed ({type(exc).__name__}: {exc}); training continues with eager launches")
                         use_graph, graphed = False, None
                     finally:
                         ddp.flat_grad.copy_(saved)
                         for b, keep in buffers:
                             b.copy_(keep)
+                        torch.set_rng_state(rng_cpu)
+                        if rng_dev is not None:
+                            torch.cuda.set_rng_state(rng_dev, self.device)
                 if graphed is not None and graphed.accepts(batch):
                     loss = graphed(batch)
                 else:   # eager; also a batch whose shape differs from the captured one (a short last batch)

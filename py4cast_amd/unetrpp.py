@@ -4,16 +4,20 @@ The reference takes the class from mfai v5.0.1 (py4cast/models.py:10-20), which 
 restated from the published one (oracle/unetrpp.py spells out every block) and the arithmetic is checked against that oracle, whose
 attention forms the matrices literally.
 
-What runs where
-* efficient paired attention (EPA), forward and backward: the tall-skinny HIP kernels of csrc/tallskinny.hip through
-  py4cast_amd.ops_ts -- ``gram`` (q^T k, q^T q, k^T k: reductions over the 16 384 ... 256 tokens of a stage) and ``apply``
-  (v A^T, q M, S VP^T: per-token small products), addressed in place inside the qkvv projection's output (no head split /
-  transpose / contiguous copies; the literal formulation makes eight of them per block).  The d x d and d x p matrices in between
-  (normalisation, temperature, softmax) are a few KB per head: torch.
+What runs where (state after round 3; DESIGN.md section 7b has the numbers)
+* efficient paired attention (EPA), forward and backward, as ONE autograd node (``ops_ts.epa_core``): the tall-skinny HIP kernels
+  of csrc/tallskinny.hip on the matrix cores -- ``gram`` (q^T k with the squared column norms of q and k from one pass over the
+  16 384 ... 256 tokens of a stage) and ``apply`` (v A^T, q M, S VP^T: per-token small products, the spatial branch's softmax and
+  its adjoint in their epilogues), addressed in place inside the qkvv projection's output (no head split / transpose / contiguous
+  copies; the literal formulation makes eight of them per block).  The d x d and d x p matrices in between (column norms,
+  temperature, channel softmax, scaled token projection) are ONE native launch each way (``p4c_epa_small_fwd/bwd``).
 * LayerNorm of every block: csrc/rows.hip (row LayerNorm).
-* the token-axis projection E = F (a Linear over N), the qkvv / output projections: library GEMMs.
-* convolutions (stem, 2x2 down-sampling, the residual 3x3 blocks, 1x1) and their group / batch / instance norms: torch
-  (MIOpen) -- not yet on native kernels, like the SwinUNetR decoder.
+* the two full-resolution 64-channel residual blocks (encoder1 / decoder2): the MFMA convolution kernels of csrc/conv_rows.hip /
+  conv_bf16.hip + the native instance-norm nodes (csrc/inorm.hip); the 1 x 1 output head: a row GEMM (csrc/rowgemm.hip) over the
+  features-last pixel rows; the patch stem / 2 x 2 down-samplings / transposed convolutions: GEMMs over pixel blocks.
+* still library calls (MIOpen pinned to its deterministic solvers through ``OM.library_conv2d``, hipBLASLt): the 3 x 3 / 1 x 1
+  convolutions and the batch norms of the 128 ... 1024-channel blocks at <= 1/4 resolution, the token-axis projection E = F (a
+  Linear over N) and the qkvv / output projections.
 Known differences from the published UNETR++ block that mfai wraps (advisor review, round 2; NOT checkpoint compatible):
 * the spatial-attention branch is merged head-major per token (``permute(0, 2, 1, 3)``: token n keeps its own heads x d values); the
   published code writes ``(attn_SA @ v_SA^T).permute(0, 3, 1, 2).reshape(B, N, C)``, a fixed permutation of the (N x C) entries that

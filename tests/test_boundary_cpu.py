@@ -213,3 +213,61 @@ def test_rollout_param_proxies_accumulate_like_autograd():
     prox.begin()
     rollout(prox.call)
     assert ids == [id(q) for st in prox.sets for q in st.values()]     # reused, not rebuilt
+
+
+def test_rollout_param_proxies_keep_every_backward():
+    """ADVICE r3 (trainer.py:325): a SECOND backward through one rollout (retain_graph, two losses) and a backward that never reaches
+    the attached tensor must not lose gradients: the first is transferred by the same engine callback, the second by the next
+    ``begin()``."""
+    import torch
+    from torch import nn
+
+    from py4cast_amd.trainer import RolloutParamProxies
+
+    torch.manual_seed(6)
+    net = nn.Sequential(nn.Linear(5, 12), nn.Tanh(), nn.Linear(12, 5)).double()
+    x0 = torch.randn(7, 5, dtype=torch.float64)
+
+    def rollout(call):
+        x, out = x0, []
+        for _ in range(3):
+            x = x + call(x)
+            out.append(x)
+        return torch.stack(out)
+
+    # two losses, two backwards through the same graph
+    ref = rollout(net)
+    ref.square().mean().backward(retain_graph=True)
+    ref.abs().mean().backward()
+    want2 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    prox = RolloutParamProxies(net)
+    prox.begin()
+    res = rollout(prox.call)
+    prox.attach(res)
+    res.square().mean().backward(retain_graph=True)
+    res.abs().mean().backward()
+    for p, w in zip(net.parameters(), want2):
+        torch.testing.assert_close(p.grad, w, rtol=1e-12, atol=1e-14)
+
+    # a backward from an intermediate tensor that is NOT the attached one: the gradients wait in the stand-ins for begin()
+    net.zero_grad(set_to_none=True)
+    side = {}
+
+    def call_and_keep(x):
+        y = prox.call(x)
+        side.setdefault("first", y)
+        return y
+
+    ref_first = net(x0)
+    ref_first.square().mean().backward()
+    want1 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    prox.begin()
+    res = rollout(call_and_keep)
+    prox.attach(res)
+    side["first"].square().mean().backward()         # never reaches `res`: no callback
+    assert all(p.grad is None for p in net.parameters())
+    prox.begin()                                      # the next rollout flushes them
+    for p, w in zip(net.parameters(), want1):
+        torch.testing.assert_close(p.grad, w, rtol=1e-12, atol=1e-14)

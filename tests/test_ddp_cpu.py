@@ -200,3 +200,70 @@ def test_gradient_exchange_overlaps_the_backward_gloo():
     for r in (a, b):
         own = r["overlap_sharded"][4]
         torch.testing.assert_close(r["overlap_sharded"][0][own], a["after"][0][own])
+        # sharded AND overlapped: the reduce-scatters too are issued inside the stepping backward, last -> first, each bucket once
+        ev = r["overlap_sharded"][1]
+        first_done, second_done = ev.index(("backward_done", 0)), ev.index(("backward_done", 1))
+        issued = [i for i, e in enumerate(ev) if e[0] == "bucket"]
+        assert all(i > first_done for i in issued)
+        inside = [ev[i][1] for i in issued if i < second_done]
+        assert len(inside) == r["overlap_sharded"][2] and len(inside) >= r["overlap_sharded"][3] - 1
+        order = [ev[i][1] for i in issued]
+        assert order == sorted(order, reverse=True) and len(order) == r["overlap_sharded"][3]
+    assert bool((a["overlap_sharded"][4] ^ b["overlap_sharded"][4]).all())   # the two ranks' shards tile the buffer
+
+
+def _replaced_grads_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from py4cast_amd.trainer import FlatDDP
+
+    def make():
+        torch.manual_seed(11)
+        return torch.nn.Sequential(torch.nn.Linear(24, 96), torch.nn.Tanh(), torch.nn.Linear(96, 64), torch.nn.Tanh(), torch.nn.Linear(64, 24))
+
+    torch.manual_seed(90 + rank)
+    x, y = torch.randn(9, 24), torch.randn(9, 24)
+    out = {}
+    for tag in ("views", "set_to_none", "replaced_in_backward"):
+        net = make()
+        ddp = FlatDDP(net, world, bucket_bytes=4096, single_bucket_bytes=1024, overlap=True)
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        if tag == "set_to_none":
+            opt.zero_grad(set_to_none=True)      # what a host loop that does not know about FlatDDP.zero_grad does
+        ddp.arm()
+        armed = ddp._armed
+        loss = ((net(x) - y) ** 2).mean()
+        if tag == "replaced_in_backward":
+            # a gradient tensor swapped for another one while the armed backward runs (a hook that assigns p.grad)
+            first = next(net.parameters())
+            first.register_post_accumulate_grad_hook(lambda p: setattr(p, "grad", p.grad.clone()))
+        loss.backward()
+        n_in = ddp.issued_in_backward
+        ddp.all_reduce_grads()
+        grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        out[tag] = (grads.clone(), ddp.flat_grad[: ddp.total].clone(), armed, n_in, ddp._grads_are_views())
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_overlap_with_replaced_gradient_tensors_gloo():
+    """ADVICE r3 (trainer.py:157): after ``zero_grad(set_to_none=True)`` (or any ``p.grad = ...``) the gradients are no longer views
+    of the flat bucket.  ``arm()`` then stays un-armed -- no hook may reduce the stale flat buffer -- and ``all_reduce_grads`` takes
+    the regather path; a tensor replaced DURING an armed backward makes it exchange every bucket again.  Either way every rank ends
+    with the same mean the view path gives, and the gradients are views again."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 1000)
+    mp.spawn(_replaced_grads_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert a["views"][2] and a["views"][3] >= 1                    # the plain case is armed and overlaps
+    assert not a["set_to_none"][2] and a["set_to_none"][3] == 0    # un-armed: nothing issued from hooks
+    for tag in ("set_to_none", "replaced_in_backward"):
+        for r in (a, b):
+            torch.testing.assert_close(r[tag][0], a["views"][0])   # same mean as the view path, on both ranks
+            torch.testing.assert_close(r[tag][1], a["views"][1])
+            assert r[tag][4]                                       # p.grad is its slice of the flat bucket again
+    torch.testing.assert_close(a["views"][0], b["views"][0])
