@@ -18,7 +18,7 @@
 // K ordering: an MFMA 32x32x2 step consumes 2 channels (one per lane half h).  Channels are taken
 // in groups of 8: sub-step s of group q uses channel 8q + 4h + s, so each lane reads its 4 channels
 // of a pixel as ONE 16-byte LDS read (ds_read_b128) and its 4 weights as one 16-byte global load.
-#include "common.hpp"
+#include "kernels.hpp"
 
 namespace p4c {
 
@@ -344,12 +344,12 @@ __global__ void __launch_bounds__(256, 1)
 // independent; fixed summation order (deterministic).  QL = 16: one block covers the 64 output channels; QL = 4: four blocks do
 // (the 1x1 convolution has 64 (tap, ci) pairs only -- 64 workgroups walking 256 slots each took 41 us at 2 x 512 x 512).
 template <int QL>
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int ntaps, int CI_pad,
-                                                           int ci_lo, int ci_hi, int CO, int CI, float* __restrict__ grad) {
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ partial, int nslots, int ntaps, int CI_pad, int ci_lo,
+                                                   int ci_hi, int CO, int CI, float* __restrict__ grad, int block) {
     constexpr int NS = 256 / QL, NCO = 4 * QL, NG = 64 / NCO;
     __shared__ float red[NS][NCO];
     const int nci = ci_hi - ci_lo;
-    const int cg = blockIdx.x % NG, rest = blockIdx.x / NG;
+    const int cg = block % NG, rest = block / NG;
     const int tap = rest / nci, ci = ci_lo + (rest - tap * nci);
     const int q = threadIdx.x % QL, sl = threadIdx.x / QL;
     const int64_t stride = (int64_t)ntaps * CI_pad * 64;
@@ -367,6 +367,26 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         for (int k = 0; k < NS; ++k) t += red[k][threadIdx.x];
         if (co < CO && ci < CI) grad[((int64_t)co * CI + ci) * ntaps + tap] += t;
     }
+}
+
+template <int QL>
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int ntaps, int CI_pad,
+                                                           int ci_lo, int ci_hi, int CO, int CI, float* __restrict__ grad) {
+    wgrad_reduce_block<QL>(partial, nslots, ntaps, CI_pad, ci_lo, ci_hi, CO, CI, grad, blockIdx.x);
+}
+
+// every recorded job in one launch: block -> (job, block of that job) through the prefix table in the kernel arguments; each job
+// is summed exactly as its own wgrad_reduce_kernel<16> launch would (same slices, same order: bitwise the same gradient)
+struct WgradBatchArgs {
+    WgradReduceJob job[WGRAD_BATCH_MAX];
+    int first[WGRAD_BATCH_MAX + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(WgradBatchArgs a) {
+    int j = 0;
+    while (j + 1 < a.n && (int)blockIdx.x >= a.first[j + 1]) ++j;
+    const WgradReduceJob& J = a.job[j];
+    wgrad_reduce_block<16>(J.partial, J.nslots, J.ntaps, J.CI_pad, J.ci_lo, J.ci_hi, J.CO, J.CI, J.grad, (int)blockIdx.x - a.first[j]);
 }
 
 template <int CI, int KS, int TH>
@@ -422,10 +442,34 @@ int conv_fwd_f32(const float* in, int CI, const float* wp, int ks, const float* 
     return fail(P4C_ERR_UNSUPPORTED, "conv_fwd_f32: unsupported (CI=%d, ks=%d): CI must be 32/64/96, ks 1/3", CI, ks);
 }
 
+static thread_local WgradCollect* g_wgrad_collect = nullptr;
+void wgrad_collect_into(WgradCollect* c) { g_wgrad_collect = c; }
+
+int wgrad_reduce_batch(const WgradCollect& c, hipStream_t stream) {
+    if (c.n == 0) return P4C_OK;
+    WgradBatchArgs a;
+    a.n = c.n;
+    int blocks = 0;
+    for (int j = 0; j < c.n; ++j) {
+        a.job[j] = c.job[j];
+        a.first[j] = blocks;
+        blocks += c.job[j].ntaps * (c.job[j].ci_hi - c.job[j].ci_lo);
+    }
+    a.first[c.n] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    P4C_CHECK_LAUNCH("wgrad_reduce_batch");
+    return P4C_OK;
+}
+
 int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo, int ci_hi, int CO, int CI, float* grad,
                         hipStream_t stream) {
     if (ci_hi > CI) ci_hi = CI;
     if (ci_hi <= ci_lo) return P4C_OK;
+    if (WgradCollect* c = g_wgrad_collect) {
+        if (c->n == WGRAD_BATCH_MAX) return fail(P4C_ERR_INVALID, "wgrad_reduce: more than %d deferred reductions in one batch", WGRAD_BATCH_MAX);
+        c->job[c->n++] = WgradReduceJob{partial, grad, nslots, ks * ks, CI_pad, ci_lo, ci_hi, CO, CI};
+        return P4C_OK;
+    }
     const int pairs = ks * ks * (ci_hi - ci_lo);
     if (pairs < 256 && nslots >= 64)
         hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(pairs * 4), dim3(256), 0, stream, partial, nslots, ks * ks, CI_pad, ci_lo,

@@ -34,7 +34,7 @@ struct Layout {
     // saved workspace: activations (element offsets) then normalisation arrays (float offsets from norm_base bytes)
     int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
     // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
-    int64_t wprep, statp, wgradp, nbwdp, k1i[2][NCONV], k2i[2][NCONV], tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
+    int64_t wprep, statp, wgradp[NCONV + 1], nbwdp, k1i[2][NCONV], k2i[2][NCONV], tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
     int G;  // persistent workgroups of the weight-gradient kernel
 };
 
@@ -130,7 +130,14 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
         }
         L.statp = off; off += (int64_t)d.B * slots * 128;
     }
-    L.wgradp = off; off += wgrad_partial_floats(96, 3, L.G);
+    // per-workgroup weight-gradient partials, one region per convolution (NCONV: the 1x1 output convolution): the reductions of a
+    // backward call run as ONE launch at its end (wgrad_reduce_batch), so every launch's partials live until then
+    for (int i = 0; i <= NCONV; ++i) {
+        const int lev = i < NCONV ? conv_level(i) : 0;
+        int64_t tiles = (int64_t)d.B * conv_tiles_per_sample(L.Hk[lev], L.Wk[lev]);
+        const int g = tiles < L.G ? (int)tiles : L.G;
+        L.wgradp[i] = off; off += wgrad_partial_floats(i < NCONV ? conv_cin_pad(d, i) : NF, i < NCONV ? 3 : 1, g);
+    }
     L.nbwdp = off; off += (int64_t)d.B * NORM_BWD_MAX_BLOCKS * 128;
     // k1 / k2 of every block's normalisation backward, per gradient-buffer set: the weight-gradient kernels of the side stream read
     // them (NormBwdCoef) after the main stream has gone on to other blocks -- and, with the deferred join, to the next call
@@ -363,7 +370,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     const float* isc = in_norm ? in_norm->scale : nullptr;
     const float* ish = in_norm ? in_norm->shift : nullptr;
     const int irelu = in_norm ? 1 : 0;
-    float* wpart = ws.f(L.wgradp);
+    float* wpart = ws.f(L.wgradp[i]);
     float* gw = grads + L.w[i];
     auto job = [=](hipStream_t s) {
         return conv_wgrad(compute, dtype, in, cip, 3, isc, ish, irelu, g, wpart, G, Bn, H, W, NF, cin, gw, s, nbf ? &nb : nullptr);
@@ -513,6 +520,14 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         if (g_side.set_recorded[set]) P4C_CHECK_HIP(hipStreamWaitEvent(st, g_side.set_done[set], 0));   // (the call before the previous one)
     }
     struct BwdPhase { BwdPhase() { prof_set_backward(true); } ~BwdPhase() { prof_set_backward(false); } } bwd_phase;
+    // the per-workgroup partials of this call's 14 weight gradients are reduced by ONE launch at the end of the call (they were 14
+    // dependent ~8 us launches on the weight-gradient stream, 42 per 3-step rollout); P4C_WGRAD_BATCH=0: one launch each, as before
+    static const bool batch_reduce = [] { const char* e = getenv("P4C_WGRAD_BATCH"); return !(e && e[0] == '0'); }();
+    WgradCollect reduce_jobs;
+    struct Collect {
+        explicit Collect(WgradCollect* c) { wgrad_collect_into(c); }
+        ~Collect() { wgrad_collect_into(nullptr); }
+    } collect(batch_reduce ? &reduce_jobs : nullptr);
 
     // ---- output 1x1 conv
     Norm nd2 = norm_at(ws, 11, d.B);
@@ -525,7 +540,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
             P4C_TRY(g_side.order(st, g_side.stream));   // after everything the caller enqueued before this call (dy, ...)
             wst = g_side.stream;
         }
-        P4C_TRY(conv_wgrad(d.compute, d.dtype, ws.act(L.Y[11]), NF, 1, nd2.scale, nd2.shift, 1, dy, ws.f(L.wgradp), G, d.B, d.H,
+        P4C_TRY(conv_wgrad(d.compute, d.dtype, ws.act(L.Y[11]), NF, 1, nd2.scale, nd2.shift, 1, dy, ws.f(L.wgradp[NCONV]), G, d.B, d.H,
                            d.W, d.cout, NF, grads + L.wout, wst));
         if (deferring) P4C_CHECK_HIP(hipEventRecord(g_side.dy_read, g_side.stream));
         // the 1x1 data gradient IS the dA of conv 11's normalisation backward: on the row kernel it takes pass 1 of it
@@ -591,6 +606,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     // caller defers that to p4c_side_stream_join (then only what the next call may overwrite is ordered: the caller's dy)
     if (g_side.enabled) {
         P4C_TRY(g_side.flush(st));
+        P4C_TRY(wgrad_reduce_batch(reduce_jobs, g_side.stream));
         if (plain_stream) {
             const int set = (int)(g_side.calls & 1);
             P4C_CHECK_HIP(hipEventRecord(g_side.set_done[set], g_side.stream));
@@ -600,6 +616,8 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
             P4C_CHECK_HIP(hipStreamWaitEvent(st, g_side.dy_read, 0));
         else
             P4C_TRY(g_side.order(g_side.stream, st));
+    } else {
+        P4C_TRY(wgrad_reduce_batch(reduce_jobs, st));
     }
     return P4C_OK;
 }

@@ -18,6 +18,22 @@ static inline int64_t wgrad_partial_floats(int CI_pad, int ks, int G) { return (
 
 int wgrad_reduce(const float* partial, int nslots, int ks, int CI_pad, int ci_lo, int ci_hi, int CO, int CI, float* grad,
                  hipStream_t stream);
+// Deferred reductions: while a collector is installed on the calling thread (WgradCollect), wgrad_reduce() records its job instead
+// of launching, and wgrad_reduce_batch() reduces all of them in ONE launch -- every weight gradient of a network call (the HalfUNet
+// backward plan: 14 dependent ~8 us launches per call on the weight-gradient stream otherwise).  Each job must own its partial
+// buffer until the batch has run; jobs of one batch must write disjoint gradient elements.
+struct WgradReduceJob {
+    const float* partial;
+    float* grad;
+    int nslots, ntaps, CI_pad, ci_lo, ci_hi, CO, CI;
+};
+constexpr int WGRAD_BATCH_MAX = 24;
+struct WgradCollect {
+    WgradReduceJob job[WGRAD_BATCH_MAX];
+    int n = 0;
+};
+void wgrad_collect_into(WgradCollect* c);   // nullptr: wgrad_reduce launches again
+int wgrad_reduce_batch(const WgradCollect& c, hipStream_t stream);
 
 // conv_bf16.hip (bf16 matrix cores, fp32 storage)
 int prep_weights_bf16(const float* w, int CO, int CI, int ks, int transpose_flip, int M_pad, int K_pad, void* out,

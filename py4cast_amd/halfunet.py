@@ -529,6 +529,59 @@ class HalfUNetMI355X(ModelABC, nn.Module):
                 "achieved": tflops, "peak": peak, "unit": "TFLOP/s", "frac": tflops / peak, "traffic": None,
                 "avg_launch_ms": ms.value / n.value, "launches": n.value, "flops_per_launch": flops / n.value}
 
+    def step_algorithmic_bytes(self, B, H, W, F, Fs, Ff, T):
+        """bench.py, `roofline.step`: HBM bytes one training step (T-step rollout + loss + BPTT + AdamW) has to move in the plan's own
+        formulation -- every launch's compulsory reads and writes, each map counted once per launch that needs it, nothing for halos,
+        per-workgroup partials, statistics or parameters (< 1 % together).  Table (also in DESIGN.md section 6): M = one 64-channel
+        map at full resolution in the activation type, level k of the U-Net moves M / 4^k.
+        Returns (total bytes, {family: bytes})."""
+        esz = 2 if self.act_dtype == torch.bfloat16 else 4
+        n0 = float(B * H * W)
+        M = 64.0 * esz * n0
+        q = [0.25 ** k for k in range(5)]
+        cpad = self.cin_pad
+        fwd = {
+            "conv 3x3 first (x -> 64)": cpad * esz * n0 + M,
+            "conv 3x3 64->64 full resolution (enc1.2, dec.1, dec.2)": 3 * 2 * M,
+            "conv 3x3 64->64 coarse levels (8 launches)": sum(2 * 2 * M * q[k] for k in range(1, 5)),
+            "max-pool (4)": sum(M * q[k] + M * q[k + 1] for k in range(4)),
+            "up-sample + sum of the five levels": M * sum(q) + M,
+            "conv 1x1 output": 2 * M,
+        }
+        # backward of one AR step.  Per 3x3 block at level k: pass 1 of the normalisation backward (dA + y; where its producer
+        # takes it -- the 1x1 data gradient for block 11, enc_out_bwd for blocks 1, 3, 5, 7, 9 -- only y is read again), the data
+        # gradient (dA + y in, dX out; pass 2 of the normalisation backward is formed on the way in), the weight gradient
+        # (x + dA + y in).  The first convolution's data gradient exists only where the previous state needs one (AR steps > 0).
+        lev = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 0, 0]
+        fused_p1 = {11, 1, 3, 5, 7, 9}
+        nbwd = sum((1 if i in fused_p1 else 2) * M * q[lev[i]] for i in range(12))
+        wgrad = sum((2 * M + (cpad * esz * n0 if i == 0 else M)) * q[lev[i]] for i in range(12))
+        dgrad_rest = sum(3 * M * q[lev[i]] for i in range(1, 12))
+        bwd = {
+            "conv 1x1: data gradient (dy in, dA out) + weight gradient (y + dy)": 2 * M + 2 * M,
+            "normalisation backward, pass 1 (12 blocks)": nbwd,
+            "conv 3x3 data gradients (blocks 1..11)": dgrad_rest,
+            "conv 3x3 weight gradients (12 blocks)": wgrad,
+            "up-sampling adjoints, x pass (dS in, four half-width maps out)": M + M * (0.5 + 0.25 + 0.125 + 0.0625),
+            "encoder outputs' gradients (y pass of the adjoint + pool adjoint + ReLU mask: enc_out_bwd, 5 levels)":
+                sum((M * (0.5 ** k if k else 1.0)) + (M * q[k + 1] if k < 4 else 0.0) + 2 * M * q[k] for k in range(5)),
+        }
+        dgrad0 = 3 * M   # AR steps 1 .. T-1
+        f4 = 4.0 * n0
+        rollout = {
+            "build_x (AR step 0)": f4 * (F + Fs + Ff) + cpad * esz * n0,
+            "state update + loss forward (prev, target, y in; new state, saved loss gradient out)": T * (f4 * 3 * F + 2 * esz * F * n0),
+            "next network input emitted by the update (AR steps 0 .. T-2)": (T - 1) * (f4 * (Fs + Ff) + cpad * esz * n0),
+            "state update + loss backward": T * (esz * F * n0 + M) + (T - 1) * (2 * f4 * F + esz * F * n0),
+        }
+        table = {f"forward: {k}": T * v for k, v in fwd.items()}
+        table.update({f"backward: {k}": T * v for k, v in bwd.items()})
+        table["backward: conv 3x3 first, data gradient (AR steps > 0)"] = (T - 1) * dgrad0
+        table.update({f"rollout: {k}": v for k, v in rollout.items()})
+        npar = float(sum(p.numel() for p in self.parameters()))
+        table["optimizer (AdamW: p, g, m, v in; p, m, v out) + gradient clear"] = 4.0 * npar * 8
+        return sum(table.values()), table
+
     def launch_times(self, B, H, W):
         """bench.py, one extra un-timed step with every tagged launch bracketed: average duration of the roofline kernel's
         data-gradient launches and of the weight-gradient kernel at full resolution (they overlap each other in the backward
