@@ -323,6 +323,18 @@ int p4c_conv_kernel_kind(int compute, int storage, int CI, int ks, int B, int H,
 int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_pad, int ks, const float* in_scale, const float* in_shift,
                    int in_relu, const void* dout, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                    p4c_stream_t stream);
+/* The weight gradient of a 3x3 convolution 64 -> 64 on bf16 maps inside a [conv -> norm -> ReLU] block, taken from dA -- the gradient
+ * with respect to the block's post-ReLU activation -- instead of dY: pass 2 of the normalisation backward is applied while the operand
+ * is staged,  dY = rstd * (gamma * g - k1 - xhat * k2),  g = dA * [y * nscale + nshift > 0],  xhat = (y - mean) * rstd,  with y the
+ * block's raw convolution output (B,H,W,64) bf16, gamma (64), nscale / nshift / rstd / mean / k1 / k2 (B,64) fp32 (k1, k2: the sums of
+ * g and g * xhat over the statistics' support, divided by its size -- what the normalisation backward's pass 1 leaves).  What the
+ * HalfUNet backward plan does for every block (no dY map in memory); exported for tests and reuse.  Other arguments as p4c_conv_wgrad. */
+int p4c_conv_wgrad_nb(const void* in, const float* in_scale, const float* in_shift, int in_relu, const void* dA, const void* y,
+                      const float* gamma, const float* nscale, const float* nshift, const float* rstd, const float* mean,
+                      const float* k1, const float* k2, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
+                      p4c_stream_t stream);
+/* which kernel the 3x3 64 -> 64 weight gradient of this shape runs on: 1 = row-streaming kernel (csrc/conv_wgrad_rows.hip), 0 = tile kernel */
+int p4c_conv_wgrad_kernel_kind(int storage, int B, int H, int W);
 /* The same convolution on bf16 feature maps with FEWER than 64 channels, in place: in (B,H,W,in_c), out (B,H,W,out_c), in_c and
  * out_c multiples of 8 up to 64 (absent channels are staged as zeros / not stored), weights prepared for 64 x 64 (p4c_prep_weights
  * with the real CO / CI).  Plain launches of the row kernel only (no input transform, no statistics): what a features-last

@@ -51,6 +51,8 @@ SIGNATURES = {
     "p4c_conv_wgrad": [P, I, I, I, I, P, P, I, P, I, I, P, P, I, I, I, P],
     "p4c_conv_fwd_compact": [P, I, P, I, P, I, I, I, I, P],
     "p4c_conv_wgrad_compact": [P, I, I, P, I, I, I, P, P, I, I, I, P],
+    "p4c_conv_wgrad_nb": [P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, P, P, I, I, I, P],
+    "p4c_conv_wgrad_kernel_kind": [I, I, I, I],
     "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
     "p4c_halfunet_prepare_weights": [DP, P, P, P],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],

@@ -2070,6 +2070,12 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
     if (ks != 1 && ks != 3) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16: unsupported ks=%d", ks);
     const int tiles = ((H + 7) / 8) * ((W + BTW - 1) / BTW) * B;
     if (tiles < G) G = tiles;
+    if (std::is_same<T, __bf16>::value && CI == 64 && conv_wgrad_rows_ok(P4C_BF16, CI, 0, 64, ks, G, B, H, W)) {
+        // maps at least 64 pixels wide: the row-streaming kernel (conv_wgrad_rows.hip); same partial layout, same reduction
+        int nslots = 0;
+        P4C_TRY(launch_conv3x3_wgrad_bf16_rows(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, stream, nb, &nslots));
+        return diag_skip(8) ? P4C_OK : wgrad_reduce(partial, nslots, 3, 64, 0, 64, CO, CIreal, grad, stream);
+    }
     for (int off = 0; off < CI;) {
         const int chunk = (CI - off >= 64) ? 64 : 32;
         int rc;

@@ -35,7 +35,7 @@ struct Layout {
     int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
     // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
     int64_t wprep, statp, wgradp[NCONV + 1], nbwdp, k1i[2][NCONV], k2i[2][NCONV], tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
-    int G;  // persistent workgroups of the weight-gradient kernel
+    int G, G_tail;  // workgroups of the weight-gradient kernels (beside the backward chain / at the very end of a rollout's backward)
 };
 
 inline int conv_level(int i) { return i < 10 ? i / 2 : 0; }
@@ -115,10 +115,17 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     for (int i = 0; i < NCONV; ++i) { L.norm[i] = off; off += 4 * (int64_t)d.B * NF; }
     L.saved_bytes = L.norm_base + off * (int64_t)sizeof(float);
 
-    // The weight-gradient kernels run beside the main stream's kernels: 3/4 of the CUs measured best (fewer per-workgroup
-    // partials to write and reduce, and CUs left to the kernels they overlap); P4C_WGRAD_G overrides for experiments.
-    L.G = d.compute == P4C_BF16 ? num_cus() * 3 / 4 : num_cus();   // (fp32 matrix cores: the kernel is MFMA-bound, all CUs)
+    // The weight-gradient kernels run beside the main stream's kernels, and every one of their workgroups holds a whole CU (LDS,
+    // registers) for the ~100 us of its segment: HALF of the CUs measured best (round 4, row-streaming kernel: 64 / 96 / 112 / 128 /
+    // 144 / 160 / 192 / 256 workgroups -> 5.41 / 4.83 / 4.79 / 4.74 / 4.81 / 4.83 / 4.92 / 5.24 ms per step on one box,
+    // profiles/r04_wgrad_workgroups_ab.txt) -- the other half stays free for the backward chain's own kernels, and there are fewer
+    // per-workgroup partials to write and reduce.  The weight gradients of the last two blocks of the LAST backward call of a
+    // rollout (AR step 0: nothing is left to overlap with) take the whole chip: G_tail.  P4C_WGRAD_G / P4C_WGRAD_G_TAIL override.
+    L.G = d.compute == P4C_BF16 ? num_cus() / 2 : num_cus();   // (fp32 matrix cores: the kernel is MFMA-bound, all CUs)
     if (const char* e = getenv("P4C_WGRAD_G")) { const int g = atoi(e); if (g > 0 && g <= num_cus()) L.G = g; }
+    L.G_tail = num_cus();
+    if (const char* e = getenv("P4C_WGRAD_G_TAIL")) { const int g = atoi(e); if (g > 0 && g <= num_cus()) L.G_tail = g; }
+    if (L.G_tail < L.G) L.G_tail = L.G;
     off = 0;
     L.wprep = off; off += (int64_t)NWSLOT * WSLOT_FLOATS;
     const int64_t tps = conv_tiles_per_sample(d.H, d.W);
@@ -135,7 +142,7 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     for (int i = 0; i <= NCONV; ++i) {
         const int lev = i < NCONV ? conv_level(i) : 0;
         int64_t tiles = (int64_t)d.B * conv_tiles_per_sample(L.Hk[lev], L.Wk[lev]);
-        const int g = tiles < L.G ? (int)tiles : L.G;
+        const int g = tiles < L.G_tail ? (int)tiles : L.G_tail;
         L.wgradp[i] = off; off += wgrad_partial_floats(i < NCONV ? conv_cin_pad(d, i) : NF, i < NCONV ? 3 : 1, g);
     }
     L.nbwdp = off; off += (int64_t)d.B * NORM_BWD_MAX_BLOCKS * 128;
@@ -363,7 +370,10 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     const NormBwdCoef nb{ws.act(L.Y[i]), params + L.gamma[i], nm.scale, nm.shift, nm.rstd, nm.mean,
                          ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i])};
     int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
-    const int G = ntiles < L.G ? (int)ntiles : L.G;
+    // (dx_channels == 0: the call that closes a rollout's backward -- AR step 0 needs no input gradient -- whose last two weight
+    // gradients find no chain left to run beside)
+    const int Gl = (d.dx_channels == 0 && i <= 1) ? L.G_tail : L.G;
+    const int G = ntiles < Gl ? (int)ntiles : Gl;
     // the weight gradient needs dY (complete at this point of the main stream) and the saved input: every block has its own
     // gradient buffer, so the launch can be deferred and share its ordering event with the next blocks'
     const int compute = d.compute, dtype = d.dtype, Bn = d.B, cin = conv_cin(d, i);
@@ -692,6 +702,27 @@ extern "C" int p4c_conv_wgrad(const void* in, int compute, int storage, int CI_p
     const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
     return conv_wgrad(compute, storage, in, CI_pad, ks, in_scale, in_shift, in_relu, dout, (float*)workspace, G, B, H, W, CO,
                       CI, grad, as_stream(stream));
+}
+
+extern "C" int p4c_conv_wgrad_nb(const void* in, const float* in_scale, const float* in_shift, int in_relu, const void* dA, const void* y,
+                                 const float* gamma, const float* nscale, const float* nshift, const float* rstd, const float* mean,
+                                 const float* k1, const float* k2, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
+                                 p4c_stream_t stream) {
+    P4C_CHECK_ARG(in && dA && y && gamma && nscale && nshift && rstd && mean && k1 && k2 && grad && workspace, "p4c_conv_wgrad_nb: null pointer");
+    P4C_CHECK_ARG(CO <= 64 && CI <= 64, "p4c_conv_wgrad_nb: CO and CI must be <= 64");
+    P4C_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "p4c_conv_wgrad_nb: scale and shift go together");
+    if (!conv_wgrad_bf16_takes_nb(P4C_BF16, 64, 3, B)) return fail(P4C_ERR_UNSUPPORTED, "p4c_conv_wgrad_nb: unsupported batch size %d", B);
+    int64_t ntiles = (int64_t)B * conv_tiles_per_sample(H, W);
+    const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
+    const NormBwdCoef nb{y, gamma, nscale, nshift, rstd, mean, k1, k2};
+    return conv_wgrad(P4C_BF16, P4C_BF16, in, 64, 3, in_scale, in_shift, in_relu, dA, (float*)workspace, G, B, H, W, CO, CI, grad,
+                      as_stream(stream), &nb);
+}
+
+extern "C" int p4c_conv_wgrad_kernel_kind(int storage, int B, int H, int W) {
+    int64_t ntiles = (int64_t)B * conv_tiles_per_sample(H, W);
+    const int G = ntiles < num_cus() ? (int)ntiles : num_cus();
+    return conv_wgrad_rows_ok(storage, 64, 0, 64, 3, G, B, H, W) ? 1 : 0;
 }
 
 // ---- plain bf16 convolution on feature maps with fewer than 64 channels, in place (row kernel; SwinUNetR's 24- / 48-channel levels)

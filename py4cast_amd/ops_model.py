@@ -56,6 +56,19 @@ def conv_wgrad(x: torch.Tensor, dout: torch.Tensor, ks: int, CO: int, CI: int, g
     return grad
 
 
+def conv_wgrad_nb(x: torch.Tensor, dA: torch.Tensor, y: torch.Tensor, gamma, nscale, nshift, rstd, mean, k1, k2, CO: int, CI: int,
+                  grad: torch.Tensor, in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None, in_relu: bool = False):
+    """grad (CO,CI,3,3) += weight gradient of a 3x3 64 -> 64 convolution whose gradient operand is dA of its [norm -> ReLU]: pass 2 of the
+    normalisation backward is applied on the way in (p4c_conv_wgrad_nb; bf16 maps)."""
+    L.require_cuda(x, dA, y, grad)
+    B, H, W, _ = x.shape
+    ws = torch.empty(L.lib().p4c_conv_wgrad_workspace_bytes(64, 3) // 4, dtype=torch.float32, device=x.device)
+    L.call("p4c_conv_wgrad_nb", L.ptr(x.contiguous()), L.ptr(in_scale), L.ptr(in_shift), int(in_relu), L.ptr(dA.contiguous()), L.ptr(y.contiguous()),
+           L.ptr(gamma), L.ptr(nscale), L.ptr(nshift), L.ptr(rstd), L.ptr(mean), L.ptr(k1), L.ptr(k2), CO, CI, L.ptr(grad), L.ptr(ws), B, H, W,
+           L.stream(x.device))
+    return grad
+
+
 # ------------------------------------------------------------------------------ a whole convolution as one autograd node
 def _pad32(c: int) -> int:
     return (c + 31) // 32 * 32
