@@ -402,6 +402,9 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
         // whose pass 1 (sums of g and g * xhat) the ring / row kernel takes while it stores the gradient rows
         const char* fe = getenv("P4C_NO_FUSED_REDUCE");   // (read per call: the parity test switches it)
         const bool fuse_off = fe && fe[0] == '1';
+        // (round 4 re-tried both roles in one launch with the roles' constants kept in LDS and the drain's tables computed: 137 -> 59
+        // spilled registers, the data-gradient launch 55 -> 120 us, the step 4.79 -> 5.36 ms: the loader's images -- 72 registers of
+        // prefetched dA / y rows plus 32 of y rows for the drain -- are what does not fit, not the constants)
         const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 && !(nbf && dgrad_takes_pass1) &&
                           conv_bf16_bwd_stats_ok(d.dtype, d.B, H, W);
         const RingBwdStats bst{in, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
