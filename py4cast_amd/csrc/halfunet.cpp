@@ -35,7 +35,7 @@ struct Layout {
     int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
     // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
     int64_t wprep, statp, wgradp[NCONV + 1], nbwdp, k1i[2][NCONV], k2i[2][NCONV], tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
-    int G, G_tail;  // workgroups of the weight-gradient kernels (beside the backward chain / at the very end of a rollout's backward)
+    int G;  // workgroups of the weight-gradient kernels
 };
 
 inline int conv_level(int i) { return i < 10 ? i / 2 : 0; }
@@ -119,13 +119,12 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     // registers) for the ~100 us of its segment: HALF of the CUs measured best (round 4, row-streaming kernel: 64 / 96 / 112 / 128 /
     // 144 / 160 / 192 / 256 workgroups -> 5.41 / 4.83 / 4.79 / 4.74 / 4.81 / 4.83 / 4.92 / 5.24 ms per step on one box,
     // profiles/r04_wgrad_workgroups_ab.txt) -- the other half stays free for the backward chain's own kernels, and there are fewer
-    // per-workgroup partials to write and reduce.  The weight gradients of the last two blocks of the LAST backward call of a
-    // rollout (AR step 0: nothing is left to overlap with) take the whole chip: G_tail.  P4C_WGRAD_G / P4C_WGRAD_G_TAIL override.
+    // per-workgroup partials to write and reduce.  P4C_WGRAD_G overrides.  Measured and dropped in round 4: the last two weight
+    // gradients of a rollout's backward on the whole chip (nothing is left to overlap with there: no difference), and partials that
+    // ACCUMULATE over the AR steps of a rollout with one reduction at the join (the read-modify-write epilogue exposes the partials'
+    // memory latency at the end of every launch: weight-gradient launches 104 -> 141 us, the step 4.96 -> 6.33 ms).
     L.G = d.compute == P4C_BF16 ? num_cus() / 2 : num_cus();   // (fp32 matrix cores: the kernel is MFMA-bound, all CUs)
     if (const char* e = getenv("P4C_WGRAD_G")) { const int g = atoi(e); if (g > 0 && g <= num_cus()) L.G = g; }
-    L.G_tail = num_cus();
-    if (const char* e = getenv("P4C_WGRAD_G_TAIL")) { const int g = atoi(e); if (g > 0 && g <= num_cus()) L.G_tail = g; }
-    if (L.G_tail < L.G) L.G_tail = L.G;
     off = 0;
     L.wprep = off; off += (int64_t)NWSLOT * WSLOT_FLOATS;
     const int64_t tps = conv_tiles_per_sample(d.H, d.W);
@@ -142,7 +141,7 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     for (int i = 0; i <= NCONV; ++i) {
         const int lev = i < NCONV ? conv_level(i) : 0;
         int64_t tiles = (int64_t)d.B * conv_tiles_per_sample(L.Hk[lev], L.Wk[lev]);
-        const int g = tiles < L.G_tail ? (int)tiles : L.G_tail;
+        const int g = tiles < L.G ? (int)tiles : L.G;
         L.wgradp[i] = off; off += wgrad_partial_floats(i < NCONV ? conv_cin_pad(d, i) : NF, i < NCONV ? 3 : 1, g);
     }
     L.nbwdp = off; off += (int64_t)d.B * NORM_BWD_MAX_BLOCKS * 128;
@@ -370,10 +369,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     const NormBwdCoef nb{ws.act(L.Y[i]), params + L.gamma[i], nm.scale, nm.shift, nm.rstd, nm.mean,
                          ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i])};
     int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
-    // (dx_channels == 0: the call that closes a rollout's backward -- AR step 0 needs no input gradient -- whose last two weight
-    // gradients find no chain left to run beside)
-    const int Gl = (d.dx_channels == 0 && i <= 1) ? L.G_tail : L.G;
-    const int G = ntiles < Gl ? (int)ntiles : Gl;
+    const int G = ntiles < L.G ? (int)ntiles : L.G;
     // the weight gradient needs dY (complete at this point of the main stream) and the saved input: every block has its own
     // gradient buffer, so the launch can be deferred and share its ordering event with the next blocks'
     const int compute = d.compute, dtype = d.dtype, Bn = d.B, cin = conv_cin(d, i);
