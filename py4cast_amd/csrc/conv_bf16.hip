@@ -2070,15 +2070,22 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
     if (ks != 1 && ks != 3) return fail(P4C_ERR_UNSUPPORTED, "conv_wgrad_bf16: unsupported ks=%d", ks);
     const int tiles = ((H + 7) / 8) * ((W + BTW - 1) / BTW) * B;
     if (tiles < G) G = tiles;
-    if (std::is_same<T, __bf16>::value && CI == 64 && conv_wgrad_rows_ok(P4C_BF16, CI, 0, 64, ks, G, B, H, W)) {
-        // maps at least 64 pixels wide: the row-streaming kernel (conv_wgrad_rows.hip); same partial layout, same reduction
-        int nslots = 0;
-        P4C_TRY(launch_conv3x3_wgrad_bf16_rows(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, stream, nb, &nslots));
-        return diag_skip(8) ? P4C_OK : wgrad_reduce(partial, nslots, 3, 64, 0, 64, CO, CIreal, grad, stream);
-    }
     for (int off = 0; off < CI;) {
         const int chunk = (CI - off >= 64) ? 64 : 32;
         int rc;
+        if (std::is_same<T, __bf16>::value && conv_wgrad_rows_ok(P4C_BF16, CI, off, 64, ks, G, B, H, W)) {
+            // maps at least 64 pixels wide: the row-streaming kernel (conv_wgrad_rows.hip), one launch per chunk -- the 96-channel
+            // first convolution as a full chunk and a THIN one (its real channels beyond 64: one octet at 69 inputs); same partial
+            // layout, same reduction
+            int nslots = 0;
+            if (off < CIreal) {
+                P4C_TRY(launch_conv3x3_wgrad_bf16_rows(in, in_scale, in_shift, in_relu, dout, partial, G, B, H, W, stream, nb, &nslots, CI, off,
+                                                       CIreal, CI));
+                if (!diag_skip(8)) P4C_TRY(wgrad_reduce(partial, nslots, 3, CI, off, off + chunk, CO, CIreal, grad, stream));
+            }
+            off += chunk;
+            continue;
+        }
         // (P4C_WGWS_REM=1, A/B switch: the 32-channel remainder of a 96-channel input -- the first convolution -- on the role-split
         // kernel as a half-empty 64-channel chunk, absent channel octets staged as zeros; it then takes NormBwdCoef.  Measured:
         // neutral without NormBwdCoef, 0.04 ms per step SLOWER with it -- block 0's weight gradient is the tail of the backward and

@@ -86,9 +86,12 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }
 
+// x: (B,H,W,in_cs) with the chunk's channels at ci_off .. ci_off + 8 n_oct - 1 (n_oct <= 8 octets: absent ones are staged as zeros);
+// partial: [workgroup][9][part_cip][64], the chunk writes channels ci_off .. of it (the 96-channel first convolution runs as a full
+// chunk and a thin one into the same buffer)
 struct WgRowsArgs {
     const __bf16* x; const float* x_scale; const float* x_shift; const __bf16* dout; float* partial;
-    int H, W, rows_lo, rows_rem;
+    int H, W, rows_lo, rows_rem, in_cs, ci_off, n_oct, part_cip;
     NormBwdCoef nb;
 };
 
@@ -100,7 +103,8 @@ struct BRow { s16x4 v[4][2]; };   // the four K-step operands of one dY row (two
 template <bool H0, bool H1, bool H2>
 __device__ __forceinline__ void wg_row(f32x16 (&acc)[9], BRow& bn, BRow& bm, BRow& bo, s16x4 (&fa)[2][3][2], const char* xr,
                                        const char* dr, const char* xr_next, const char* dr_next, bool pf, bool pfb,
-                                       const int (&xoff)[3], int doff) {
+                                       const int (&xoff)[3], int doff, bool active) {
+    if (!active) return;   // (a thin chunk: this wave's 32 input channels do not exist -- wave-uniform)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const bool last = s == 3;
@@ -157,7 +161,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (wv >= 4) {
         // ------------------------------------------------------------ memory side
         const int ltid = threadIdx.x - 256, c8 = ltid & 7;
-        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x + (int64_t)b * H * W * 64, (unsigned int)H * W * 128u);
+        const int in_cs = args.in_cs, xpb = in_cs * 2;   // bytes per pixel of x
+        const bool in_ch = c8 < args.n_oct;               // this lane's channel octet exists in the chunk
+        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x + (int64_t)b * H * W * in_cs + args.ci_off,
+                                                      (unsigned int)(((int64_t)H * W * in_cs - args.ci_off) * 2));
         const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(dout + (int64_t)b * H * W * 64, (unsigned int)H * W * 128u);
         const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(NB ? reinterpret_cast<const __bf16*>(nb.y) + (int64_t)b * H * W * 64 : dout,
                                                       (unsigned int)H * W * 128u);
@@ -168,7 +175,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int idx = ltid + it * 256;
             if (it > 0) { rem += 256; if (rem >= XSLOTS) { rem -= XSLOTS; ++rr; } }
             const int col = rem >> 3;
-            gx[it] = (rr * W + col) * 128 + 16 * c8;
+            gx[it] = in_ch ? (rr * W + col) * xpb + 16 * c8 : OOB;   // (an absent octet loads as zeros and is staged as such)
             lx[it] = rr * XROW + slot_off(col, c8);
             limx[it] = ((unsigned)(x0 - 1 + col) < (unsigned)W) ? idx : OOB;   // columns outside the image: never loaded, zeroed below
         }
@@ -191,9 +198,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             sc[k] = sh[k] = al[k] = be[k] = dl[k] = nsc[k] = nsh[k] = f32x2{0.f, 0.f};
-            if (MODE >= 2) {
-                sc[k] = *reinterpret_cast<const f32x2*>(args.x_scale + b * 64 + 8 * c8 + 2 * k);
-                sh[k] = *reinterpret_cast<const f32x2*>(args.x_shift + b * 64 + 8 * c8 + 2 * k);
+            if (MODE >= 2 && in_ch) {
+                sc[k] = *reinterpret_cast<const f32x2*>(args.x_scale + (int64_t)b * in_cs + args.ci_off + 8 * c8 + 2 * k);
+                sh[k] = *reinterpret_cast<const f32x2*>(args.x_shift + (int64_t)b * in_cs + args.ci_off + 8 * c8 + 2 * k);
             }
             if (NB) {
                 const int ch = 8 * c8 + 2 * k;
@@ -219,7 +226,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int nactx = nxr * XSLOTS, nactd = ndr * 512;
             const int gy0 = y0 - 1 + m0, gx0 = x0 - 1;
             if (gy0 >= 0 && gy0 + nxr <= H) {
-                const int so = (gy0 * W + gx0) * 128;
+                const int so = (gy0 * W + gx0) * xpb;
 #pragma unroll
                 for (int it = 0; it < NLX; ++it)
                     im.a[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (limx[it] < nactx) ? gx[it] : OOB, so, 0);
@@ -228,8 +235,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int it = 0; it < NLX; ++it) {
                     const int idx = ltid + it * 256, r4 = idx / XSLOTS;
                     const int gy = gy0 + r4, gxx = gx0 + ((idx - r4 * XSLOTS) >> 3);
-                    const bool ok = (idx < nactx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gxx < (unsigned)W);
-                    im.a[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (gy * W + gxx) * 128 + 16 * c8 : OOB, 0, 0);
+                    const bool ok = (idx < nactx) & ((unsigned)gy < (unsigned)H) & ((unsigned)gxx < (unsigned)W) & in_ch;
+                    im.a[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (gy * W + gxx) * xpb + 16 * c8 : OOB, 0, 0);
                 }
             }
             const int sd = ((y0 + m0) * W + x0) * 128;   // (dY rows of a segment are always inside the image)
@@ -301,6 +308,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const bool active = cit * 4 < args.n_oct;   // this wave's 32 input channels exist (a thin chunk keeps waves 2, 3 idle)
     BRow s0, s1, s2;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -313,7 +321,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     auto drow = [&](int mm) __attribute__((always_inline)) { return (const char*)dring + (mm & 7) * DROW; };
     lds_barrier();   // the first interval's rows are staged
 #pragma unroll
-    for (int j = 0; j < 6; ++j) fa[0][j >> 1][j & 1] = tr_read(xrow(0) + xoff[j >> 1] + (j & 1) * 512);
+    for (int j = 0; j < 6; ++j) fa[0][j >> 1][j & 1] = tr_read(xrow(0) + xoff[j >> 1] + (j & 1) * 512);   // (idle waves: harmless reads)
 #pragma unroll
     for (int j = 0; j < 2; ++j) s0.v[0][j] = tr_read(drow(0) + doff + j * 512);
     // BN / BM / BO: the dY operand sets of rows m / m-1 / m-2; BO receives step 0 of row m+1 (it is the next row's BN)
@@ -321,7 +329,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     {                                                                                                                     \
         const bool pf = ((m & 3) != 3) && (m != last);                                                                    \
         const bool nextb = m + 1 < R;                                                                                     \
-        wg_row<H0, H1, H2>(acc, BN, BM, BO, fa, xrow(m), drow(m), xrow(m + 1), drow(m + 1), pf, pf && nextb, xoff, doff); \
+        wg_row<H0, H1, H2>(acc, BN, BM, BO, fa, xrow(m), drow(m), xrow(m + 1), drow(m + 1), pf, pf && nextb, xoff, doff, active); \
         if (m == last) {                                                                                                  \
             lds_barrier();                                                                                                \
         } else if ((m & 3) == 3) {                                                                                        \
@@ -354,13 +362,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #undef P4C_WROW
     // C[ci][co]: lane = co (r), register i -> ci = (i & 3) + 8 (i >> 2) + 4 h.  One partial per workgroup.
     const int wg_id = (b * nstrips + strip) * nseg + seg;
-    float* pbase = args.partial + (int64_t)wg_id * 9 * 64 * 64;
+    const int part_cip = args.part_cip;
+    float* pbase = args.partial + (int64_t)wg_id * 9 * part_cip * 64;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int ci = cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            pbase[(t * 64 + ci) * 64 + cot * 32 + r] = acc[t][i];
+            const int ci = args.ci_off + cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (ci < part_cip) pbase[(t * part_cip + ci) * 64 + cot * 32 + r] = acc[t][i];   // (idle waves: zeros for their existing padding channels)
         }
 }
 
@@ -390,19 +399,26 @@ static void wgrad_rows_geometry(int G, int B, int H, int W, int* nstrips_out, in
     *nseg_out = nseg;
 }
 
+// in_cs: channels per pixel of x (a multiple of 8); the chunk starts at channel ci_off (a multiple of 32)
 bool conv_wgrad_rows_ok(int storage, int in_cs, int ci_off, int dout_cs, int ks, int G, int B, int H, int W) {
     const char* e = getenv("P4C_NO_WGRAD_ROWS");   // (read per call: A/B scripts and the parity tests switch it)
     if (e && e[0] == '1') return false;
-    return storage == P4C_BF16 && in_cs == 64 && ci_off == 0 && dout_cs == 64 && ks == 3 && W % wr::SW == 0 && H >= wr::MIN_ROWS &&
-           B * (W / wr::SW) <= G && (int64_t)H * W * 128 < (int64_t)1 << 31;
+    return storage == P4C_BF16 && in_cs >= 8 && in_cs % 8 == 0 && ci_off % 32 == 0 && ci_off < in_cs && dout_cs == 64 && ks == 3 &&
+           W % wr::SW == 0 && H >= wr::MIN_ROWS && B * (W / wr::SW) <= G && (int64_t)H * W * in_cs * 2 < (int64_t)1 << 31;
 }
 
-// partial: [nslots][9][64][64] floats, *nslots_out = workgroups launched (<= G)
+// One chunk of at most 64 input channels: channels ci_off .. min(ci_off + 64, ci_real rounded up to 8) of x (B,H,W,in_cs).
+// partial: [nslots][9][part_cip][64] floats, *nslots_out = workgroups launched (<= G; the same for every chunk of a shape)
 int launch_conv3x3_wgrad_bf16_rows(const void* x, const float* x_scale, const float* x_shift, int x_relu, const void* dout, float* partial,
-                                   int G, int B, int H, int W, hipStream_t stream, const NormBwdCoef* nbp, int* nslots_out) {
+                                   int G, int B, int H, int W, hipStream_t stream, const NormBwdCoef* nbp, int* nslots_out, int in_cs,
+                                   int ci_off, int ci_real, int part_cip) {
     int nstrips, nseg;
     wgrad_rows_geometry(G, B, H, W, &nstrips, &nseg);
-    const WgRowsArgs a{(const __bf16*)x, x_scale, x_shift, (const __bf16*)dout, partial, H, W, H / nseg, H % nseg, nbp ? *nbp : NormBwdCoef{}};
+    int hi = ci_real < in_cs ? ci_real : in_cs;   // channels beyond the real ones are zero padding of x: not loaded
+    int n_oct = (hi - ci_off + 7) / 8;
+    n_oct = n_oct > 8 ? 8 : (n_oct < 1 ? 1 : n_oct);
+    const WgRowsArgs a{(const __bf16*)x, x_scale, x_shift, (const __bf16*)dout, partial, H, W, H / nseg, H % nseg, in_cs, ci_off, n_oct,
+                       part_cip, nbp ? *nbp : NormBwdCoef{}};
     *nslots_out = B * nstrips * nseg;
     const bool nb = nbp != nullptr && nbp->y != nullptr;
     prof_begin(P4C_PROF_WGRAD3X3_C64, (int64_t)B * H * W, stream);

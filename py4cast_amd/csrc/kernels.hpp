@@ -125,11 +125,12 @@ int launch_conv3x3_bf16_rows(const void* in, const void* wp, int ks, const float
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,
                     const void* dout, float* partial, int G, int B, int H, int W, int CO, int CIreal, float* grad,
                     hipStream_t stream, const NormBwdCoef* nb = nullptr);
-// conv_wgrad_rows.hip: the row-streaming weight gradient of the 3x3 64 -> 64 convolution (maps at least 64 pixels wide, W % 64 == 0);
-// partial: [*nslots_out <= G][9][64][64] floats for wgrad_reduce
+// conv_wgrad_rows.hip: the row-streaming weight gradient of the 3x3 convolution to 64 output channels, one chunk of <= 64 input channels
+// per launch (maps at least 64 pixels wide, W % 64 == 0); partial: [*nslots_out <= G][9][part_cip][64] floats for wgrad_reduce
 bool conv_wgrad_rows_ok(int storage, int in_cs, int ci_off, int dout_cs, int ks, int G, int B, int H, int W);
 int launch_conv3x3_wgrad_bf16_rows(const void* x, const float* x_scale, const float* x_shift, int x_relu, const void* dout, float* partial,
-                                   int G, int B, int H, int W, hipStream_t stream, const NormBwdCoef* nb, int* nslots_out);
+                                   int G, int B, int H, int W, hipStream_t stream, const NormBwdCoef* nb, int* nslots_out, int in_cs = 64,
+                                   int ci_off = 0, int ci_real = 64, int part_cip = 64);
 // plain convolution / its weight gradient on feature maps with fewer than 64 channels, in place (no padded copies): row kernel only
 bool conv_wgrad_bf16_takes_nb(int storage, int CI, int ks, int B);
 bool conv_rows_compact_ok(int storage, int in_cs, int out_cs, int ks, int B, int H, int W);

@@ -129,3 +129,38 @@ def test_row_streaming_wgrad_is_reproducible(gpu_device):
     a = om.conv_wgrad(x, dy, 3, 64, 64, torch.zeros(64, 64, 3, 3, device=gpu_device), compute="bf16")
     b = om.conv_wgrad(x, dy, 3, 64, 64, torch.zeros(64, 64, 3, 3, device=gpu_device), compute="bf16")
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 128), (2, 512, 512)])
+@pytest.mark.parametrize("transform", [False, True])
+def test_row_streaming_wgrad_of_the_first_convolution(gpu_device, monkeypatch, B, H, W, transform):
+    """The 69 -> 64 first convolution (x padded to 96 channels): a full 64-channel chunk and a THIN chunk -- the five real channels
+    beyond 64: one octet loaded, half of the matrix waves idle -- into one partial buffer; against float64 and the tile kernels."""
+    from py4cast_amd import ops_model as om
+
+    g = torch.Generator(device=gpu_device).manual_seed(17)
+    CIp, CI, CO = 96, 69, 64
+    x = torch.randn(B, H, W, CIp, generator=g, device=gpu_device)
+    x[..., CI:] = 0
+    x = x.bfloat16()
+    dy = torch.randn(B, H, W, 64, generator=g, device=gpu_device).bfloat16()
+    scale = (torch.rand(B, CIp, generator=g, device=gpu_device) + 0.5) if transform else None
+    shift = (torch.randn(B, CIp, generator=g, device=gpu_device) * 0.3) if transform else None
+    xin = x.float()
+    if transform:
+        xin = torch.relu(xin * scale[:, None, None, :] + shift[:, None, None, :])
+    xin = xin.bfloat16().double()[..., :CI]
+    xp = torch.nn.functional.pad(xin, (0, 0, 1, 1, 1, 1))
+    ref = torch.zeros(CO, CI, 3, 3, dtype=torch.float64, device=gpu_device)
+    dyd = dy.double().reshape(-1, 64)
+    for ky in range(3):
+        for kx in range(3):
+            ref[:, :, ky, kx] = dyd.t() @ xp[:, ky:ky + H, kx:kx + W, :].reshape(-1, CI)
+    res = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("P4C_NO_WGRAD_ROWS", off)
+        grad = torch.zeros(CO, CI, 3, 3, device=gpu_device)
+        om.conv_wgrad(x, dy, 3, CO, CI, grad, scale, shift, transform, compute="bf16")
+        res[off] = grad
+    assert rel_err(res["0"], ref) < 5e-4, rel_err(res["0"], ref)
+    assert rel_err(res["0"], res["1"]) < 5e-5

@@ -25,7 +25,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
             for r in rows:
                 w.writerow({k: (r[k][:100] if k == "Kernel_Name" else r[k]) for k in keep})
         for r in rows:
-            flavour = r["Kernel_Name"].split(kern, 1)[1].split("(", 1)[0]
+            flavour = r["Kernel_Name"].split(kern, 1)[1].split("(", 1)[0] + " grid " + str(int(float(r["Grid_Size"])) // 512) + " wg"
             vals[r["Counter_Name"]][flavour].append(float(r["Counter_Value"]))
 
 def mean(v):
