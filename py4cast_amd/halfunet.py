@@ -510,7 +510,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
                 import os
 
                 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-                for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+                for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
                     f = os.path.join(root, "profiles", name)
                     if os.path.exists(f):
                         traffic = json.load(open(f)).get(kname, {}).get("hbm_bytes_per_launch")
