@@ -271,3 +271,29 @@ def test_rollout_param_proxies_keep_every_backward():
     prox.begin()                                      # the next rollout flushes them
     for p, w in zip(net.parameters(), want1):
         torch.testing.assert_close(p.grad, w, rtol=1e-12, atol=1e-14)
+
+
+def test_step_byte_model_of_the_bench_roofline():
+    """`roofline.step` of the bench line divides HalfUNetMI355X.step_algorithmic_bytes by the step time: the model is plain arithmetic
+    (no GPU) -- its total at the benchmark configuration, its families, and how it scales."""
+    from py4cast_amd.halfunet import HalfUNetMI355X, HalfUNetSettings
+
+    m = HalfUNetMI355X(69, 60, (512, 512), HalfUNetSettings(compute_dtype="bf16"))
+    tot, tab = m.step_algorithmic_bytes(2, 512, 512, 60, 4, 5, 3)
+    assert abs(tot - sum(tab.values())) < 1.0
+    assert abs(tot / 1e9 - 15.34) < 0.02                       # DESIGN.md section 6
+    M = 64 * 2 * 2 * 512 * 512                                 # one 64-channel bf16 map at full resolution
+    assert tab["forward: conv 3x3 64->64 full resolution (enc1.2, dec.1, dec.2)"] == 3 * 3 * 2 * M
+    assert tab["forward: conv 3x3 first (x -> 64)"] == 3 * (96 * 2 * 2 * 512 * 512 + M)
+    # one AR step more adds one forward + one backward of the network and the rollout kernels' per-step parts; nothing else
+    tot4, _ = m.step_algorithmic_bytes(2, 512, 512, 60, 4, 5, 4)
+    tot2, _ = m.step_algorithmic_bytes(2, 512, 512, 60, 4, 5, 2)
+    assert abs((tot4 - tot) - (tot - tot2)) < 1.0
+    # twice the pixels, twice the bytes (the optimizer's share aside)
+    totw, tabw = m.step_algorithmic_bytes(2, 512, 1024, 60, 4, 5, 3)
+    opt = [k for k in tab if k.startswith("optimizer")][0]
+    assert abs((totw - tabw[opt]) - 2 * (tot - tab[opt])) < 1.0
+    # the fp32 flavour moves 4-byte activations
+    m32 = HalfUNetMI355X(69, 60, (512, 512), HalfUNetSettings(compute_dtype="f32", activation_dtype="f32"))
+    t32, _ = m32.step_algorithmic_bytes(2, 512, 512, 60, 4, 5, 3)
+    assert t32 > 1.5 * tot
