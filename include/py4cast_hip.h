@@ -259,6 +259,19 @@ int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g
                            int kind, int mask_mode, void* dy, int dy_dtype, int y_cs, float* dprev, int64_t dprev_bs,
                            int B, int64_t N, int F, float keep_prev, p4c_stream_t stream);
 
+/* The network's 1x1 output convolution AND the fused AR step in one pass (HalfUNet, bf16 maps): y = relu(a * a_scale + a_shift) wout^T
+ * is formed on the matrix cores per 32 grid points, rounded to bf16 exactly where the two-kernel route stores it, and consumed in
+ * registers by the state update / border forcing / weighted loss / next-input emission / saved loss gradient of
+ * p4c_ar_update_loss_fwd_next_saved (same arguments, same arithmetic, same new state; the loss is summed in another order).  y is
+ * never written.  a: (B,N,64) bf16; a_scale / a_shift: (B,64); wout: (cout,64) fp32, F <= cout <= 64, F even; x_next (c_pad <= 96,
+ * even) and lgrad may be NULL; no NaN masks. */
+int p4c_out_conv_update_loss_fwd(const void* a, const float* a_scale, const float* a_shift, const float* wout, int cout,
+                                 const float* prev, int64_t prev_bs, const float* target, int64_t tgt_bs, const float* std,
+                                 const float* mean, const float* border_mask, const float* interior_mask, float* new_state,
+                                 int64_t new_bs, const float* weights, float num_interior, const int32_t* masked_count, int kind,
+                                 float* loss_out, int64_t loss_stride, void* workspace, int B, int64_t N, int F, float keep_prev,
+                                 void* x_next, int c_pad, const float* statics, int64_t statics_bs, int Fs, const float* forcing_next,
+                                 int64_t forcing_bs, int Ff, void* lgrad, int64_t lgrad_bs, p4c_stream_t stream);
 /* The fused step that ALSO saves d loss_elem / d pred of every element (2 (pred - target) mask for MSE, sign for L1) as bf16 rows --
  * lgrad: (N, F) per sample, batch stride lgrad_bs elements, 16-byte aligned -- and the backward that reads them instead of the new
  * state and the target: at F = 60 the backward reads 120 instead of 480 bytes per grid point (the forward writes 120 more).  The
@@ -367,6 +380,8 @@ typedef struct p4c_halfunet_desc {
     int32_t weights_prepared; /* 1: p4c_halfunet_prepare_weights() ran on this scratch workspace since the parameters
                                  last changed (e.g. once per rollout); forward/backward then skip their own
                                  re-layout of the weights.  0: each call prepares what it needs (one extra launch). */
+    int32_t skip_out_conv;    /* forward only: 1 = stop before the 1x1 output convolution (y may be NULL): the caller runs it fused with
+                                 the AR step, p4c_out_conv_update_loss_fwd on the tensors p4c_halfunet_tail names.  Backward is the same. */
 } p4c_halfunet_desc;
 
 /* Side stream of the calling thread for p4c_halfunet_backward (weight gradients run beside the backward chain, ordered by
@@ -402,6 +417,11 @@ int p4c_halfunet_workspace_bytes(const p4c_halfunet_desc* d, size_t* saved_bytes
 int p4c_halfunet_prepare_weights(const p4c_halfunet_desc* d, const float* params, void* scratch, p4c_stream_t stream);
 int p4c_halfunet_forward(const p4c_halfunet_desc* d, const void* x, const float* params, float* running, void* y,
                          void* saved, void* scratch, int training, p4c_stream_t stream);
+/* The operands of the network's last layer inside the workspaces of a forward call: *a = raw output of the decoder's second block
+ * (B,H,W,64) in `saved`, *a_scale / *a_shift = its normalisation (B,64) fp32 in `saved` (ReLU follows), *wout = the 1x1 output
+ * convolution's weight (cout,64) fp32 inside `params`. */
+int p4c_halfunet_tail(const p4c_halfunet_desc* d, const float* params, void* saved, const void** a, const float** a_scale,
+                      const float** a_shift, const float** wout);
 /* dy: (B,H,W,64) (channels >= cout ignored); dx: (B,H,W,64) or NULL (first dx_channels channels valid);
  * grads: flat, same layout as params, ACCUMULATED into (+=). */
 int p4c_halfunet_backward(const p4c_halfunet_desc* d, const void* x, const float* params, const void* dy, void* dx,

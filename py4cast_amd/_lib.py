@@ -49,6 +49,11 @@ SIGNATURES = {
     "p4c_ar_update_loss_fwd_next": [P, L, P, I, I, P, L, P, P, P, P, P, L, P, F, P, I, I, P, L, P, I, L, I, F,
                                     P, I, P, L, I, P, L, I, P],
     "p4c_ar_update_loss_bwd": [P, L, P, I, I, P, L, P, L, P, L, P, P, I, P, F, P, I, I, P, I, I, P, L, I, L, I, F, P],
+    # a, a_scale, a_shift, wout, cout | prev, prev_bs, target, tgt_bs, std, mean, border, interior, new_state, new_bs, weights, num_interior,
+    # masked_count, kind, loss_out, loss_stride, workspace, B, N, F, keep_prev | x_next, c_pad, statics, statics_bs, Fs, forcing, forcing_bs, Ff,
+    # lgrad, lgrad_bs, stream
+    "p4c_out_conv_update_loss_fwd": [P, P, P, P, I, P, L, P, L, P, P, P, P, P, L, P, F, P, I, P, L, P, I, L, I, F,
+                                     P, I, P, L, I, P, L, I, P, L, P],
     "p4c_ar_update_loss_fwd_next_saved": [P, L, P, I, I, P, L, P, P, P, P, P, L, P, F, P, I, I, P, L, P, I, L, I, F,
                                           P, I, P, L, I, P, L, I, P, L, P],
     "p4c_ar_update_loss_bwd_saved": [P, L, P, I, I, P, L, P, L, P, P, I, P, F, P, I, I, P, I, I, P, L, I, L, I, F, P],

@@ -14,7 +14,7 @@ class HalfUNetDesc(ctypes.Structure):
         ("cin", c_int32), ("cin_pad", c_int32), ("cout", c_int32), ("dx_channels", c_int32),
         ("dtype", c_int32), ("norm", c_int32), ("groups", c_int32), ("has_bias", c_int32),
         ("eps", c_float), ("momentum", c_float), ("compute", c_int32),
-        ("weights_prepared", c_int32),
+        ("weights_prepared", c_int32), ("skip_out_conv", c_int32),
     ]
 
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
     "p4c_halfunet_prepare_weights": [DP, P, P, P],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],
+    "p4c_halfunet_tail": [DP, P, P, P, P, P, P],
     "p4c_halfunet_backward": [DP, P, P, P, P, P, P, P, I, P],
     "p4c_side_stream_defer": [I],
     "p4c_side_stream_join": [P],

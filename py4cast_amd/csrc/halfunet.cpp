@@ -118,7 +118,7 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     // The weight-gradient kernels run beside the main stream's kernels, and every one of their workgroups holds a whole CU (LDS,
     // registers) for the ~100 us of its segment: HALF of the CUs measured best (round 4, row-streaming kernel: 64 / 96 / 112 / 128 /
     // 144 / 160 / 192 / 256 workgroups -> 5.41 / 4.83 / 4.79 / 4.74 / 4.81 / 4.83 / 4.92 / 5.24 ms per step on one box,
-    // profiles/r04_wgrad_workgroups_ab.txt) -- the other half stays free for the backward chain's own kernels, and there are fewer
+    // profiles/r04_step_ab_runs.txt) -- the other half stays free for the backward chain's own kernels, and there are fewer
     // per-workgroup partials to write and reduce.  P4C_WGRAD_G overrides.  Measured and dropped in round 4: the last two weight
     // gradients of a rollout's backward on the whole chip (nothing is left to overlap with there: no difference), and partials that
     // ACCUMULATE over the AR steps of a rollout with one reduction at the join (the read-modify-write epilogue exposes the partials'
@@ -461,7 +461,7 @@ extern "C" int p4c_halfunet_prepare_weights(const p4c_halfunet_desc* dp, const f
 extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* x, const float* params, float* running,
                                     void* y, void* savedv, void* scratchv, int training, p4c_stream_t stream) {
     P4C_TRY(check_desc(dp));
-    P4C_CHECK_ARG(x && params && y && savedv && scratchv, "p4c_halfunet_forward: null pointer");
+    P4C_CHECK_ARG(x && params && (y || dp->skip_out_conv) && savedv && scratchv, "p4c_halfunet_forward: null pointer");
     const p4c_halfunet_desc& d = *dp;
     Layout L;
     make_layout(d, L);
@@ -495,8 +495,24 @@ extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* x, 
     Norm nd1 = norm_at(ws, 10, d.B);
     P4C_TRY(conv_block_fwd(d, ws, 11, ws.act(L.Y[10]), &nd1, params, running, training, st));
     Norm nd2 = norm_at(ws, 11, d.B);
-    // 1x1 output conv on relu(norm(Y_dec2)); last activation = Identity
+    // 1x1 output conv on relu(norm(Y_dec2)); last activation = Identity  (skip_out_conv: the caller fuses it with the AR step)
+    if (d.skip_out_conv) return P4C_OK;
     P4C_TRY(conv_fwd(d.compute, d.dtype, ws.act(L.Y[11]), NF, wslot(ws, 2 * NCONV), 1, nd2.scale, nd2.shift, 1, y, NF, nullptr, d.B, d.H, d.W, 1, st));
+    return P4C_OK;
+}
+
+extern "C" int p4c_halfunet_tail(const p4c_halfunet_desc* dp, const float* params, void* savedv, const void** a, const float** a_scale,
+                                 const float** a_shift, const float** wout) {
+    P4C_TRY(check_desc(dp));
+    P4C_CHECK_ARG(params && savedv && a && a_scale && a_shift && wout, "p4c_halfunet_tail: null pointer");
+    Layout L;
+    make_layout(*dp, L);
+    const WS ws{L, (char*)savedv, nullptr};
+    const Norm n = norm_at(ws, 11, dp->B);
+    *a = ws.act(L.Y[11]);
+    *a_scale = n.scale;
+    *a_shift = n.shift;
+    *wout = params + L.wout;
     return P4C_OK;
 }
 

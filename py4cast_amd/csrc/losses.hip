@@ -8,6 +8,8 @@
 // workspace + a tiny finalize kernel); no float atomics.
 //
 // Compiled with -ffp-contract=off (see rollout.hip).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace p4c {
@@ -1065,6 +1067,250 @@ extern "C" int p4c_ar_update_loss_fwd_next_saved(const float* prev, int64_t prev
     return ar_update_loss_fwd_impl(prev, prev_bs, y, y_dtype, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask,
                                    new_state, new_bs, weights, num_interior, masked_count, kind, mask_mode, loss_out,
                                    loss_stride, workspace, B, N, F, keep_prev, &nx, stream);
+}
+
+// ------------------------------------------------------------------ output convolution + state update + loss in ONE pass
+// The network's last layer -- mfai's HalfUNet ends in a 1x1 convolution on relu(norm(a)) (py4cast/lightning.py:591-596) -- and the rest
+// of the AR step (residual / scaled-residual update, border forcing, weighted loss, next step's network input, saved loss gradient:
+// lightning.py:599-633, losses.py:130-169, lightning.py:711-767) as one kernel: the convolution's output y (B,N,64) is never written
+// to memory and read back (134 MB each way per AR step at 2 x 512 x 512) and its launch disappears.  This is the north star's "fused
+// normalise-residual-loss epilogue" of the model's last convolution.
+//   * y is rounded to bf16 exactly where the two-kernel route stores it, and the update is the SAME loop body as
+//     ar_update_loss_fwd_v4_kernel (the reference's op order): new state, next input and saved loss gradients are the two-kernel
+//     route's bits; the loss is the same sum in another order.
+// 16-byte path conditions as p4c_ar_update_loss_fwd_next; no NaN masks (mask_mode NONE).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+struct OutConvArgs {
+    const bf16* a; const float* a_scale; const float* a_shift; const float* wout; int cout;
+    const float* prev; int64_t prev_bs; const float* target; int64_t tgt_bs; const float* std; const float* mean;
+    const float* border_mask; const float* interior_mask; float* new_state; int64_t new_bs; const float* weights;
+    int kind; float* partial; int64_t N; int F; float keep_prev;
+    NextX nx;
+};
+
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
+
+// Layout of the work: a wave takes 32 consecutive grid points at a time.
+//   front end: y^T = W relu(norm(a))^T on the matrix cores -- A = W (M = output feature; bf16 fragments in LDS, laid once per workgroup),
+//     B = the activations (N = grid point: a lane's fragment is 16 bytes of its point's row, straight from HBM, normalised in
+//     registers with the sample's scale / shift from LDS) -- the accumulator then holds, per lane, 4 consecutive features of its
+//     grid point per register quad: rounded to bf16 they go to a per-wave LDS tile [32 points][64 features] as 8-byte pieces;
+//   back end: the loop body of ar_update_loss_fwd_v4_kernel, unchanged -- a lane owns 4 consecutive features of a grid point, 16-byte
+//     accesses to prev / target / new state / next input / saved loss gradients -- with y read from the LDS tile instead of HBM.
+__global__ void __launch_bounds__(256) out_conv_update_loss_fwd_kernel(OutConvArgs g, int FP4) {
+    __shared__ float red[4];
+    __shared__ bf16x8_t wimg[2 * 4 * 64];                   // A fragments: (T, ks, lane) = W[32 T + (l & 31)][16 ks + 8 (l >> 5) .. + 7]
+    __shared__ float lsc[64], lsh[64];
+    __shared__ __attribute__((aligned(16))) bf16 ytile[4][32 * 64];   // per wave: y of its 32 grid points, bf16, [point][feature]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int64_t N = g.N;
+    const int F = g.F;
+    for (int t = threadIdx.x; t < 2 * 4 * 64; t += 256) {
+        const int l = t & 63, ks = (t >> 6) & 3, T = t >> 8;
+        const int co = 32 * T + (l & 31), k0 = 16 * ks + 8 * (l >> 5);
+        v4f lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (co < g.cout) {
+            lo = *reinterpret_cast<const v4f*>(g.wout + (int64_t)co * 64 + k0);
+            hi = *reinterpret_cast<const v4f*>(g.wout + (int64_t)co * 64 + k0 + 4);
+        }
+        bf16x8_t w8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w8[j] = (__bf16)lo[j]; w8[4 + j] = (__bf16)hi[j]; }
+        wimg[t] = w8;
+    }
+    if (threadIdx.x < 64) {
+        lsc[threadIdx.x] = g.a_scale[b * 64 + threadIdx.x];
+        lsh[threadIdx.x] = g.a_shift[b * 64 + threadIdx.x];
+    }
+    __syncthreads();
+    // ---- back end: per-lane constants exactly as in ar_update_loss_fwd_v4_kernel<bf16, true>
+    const int PP = 64 / FP4;
+    const int pp = lane / FP4, q = lane % FP4;
+    const bool act = 4 * q < F;
+    v4f w = {0, 0, 0, 0}, sd = {1, 1, 1, 1}, mn = {0, 0, 0, 0};
+    if (act) {
+        w = *reinterpret_cast<const v4f*>(g.weights + 4 * q);
+        if (g.std) {
+            sd = *reinterpret_cast<const v4f*>(g.std + 4 * q);
+            mn = *reinterpret_cast<const v4f*>(g.mean + 4 * q);
+        }
+    }
+    const NextX& nx = g.nx;
+    int tkind = 4;  // 0: 16 bytes from one source, 1: last 1..3 forcing values, 2: zeros, 4: none
+    int tvalid = 0;
+    const float* tsrc = nullptr;
+    int64_t tstride = 0;
+    bf16* xn = nullptr;
+    bf16* lgr = nullptr;
+    if (nx.lgrad) lgr = reinterpret_cast<bf16*>(nx.lgrad) + (int64_t)b * nx.lgrad_bs;
+    if (nx.x) {
+        xn = reinterpret_cast<bf16*>(nx.x) + (int64_t)b * N * nx.c_pad;
+        const int c0 = F + 4 * q, o_forc = F + nx.Fs, c_in = F + nx.Fs + nx.Ff;
+        if (c0 < nx.c_pad) {
+            if (c0 >= c_in) tkind = 2;
+            else if (c0 + 3 < o_forc) { tkind = 0; tsrc = nx.statics + (int64_t)b * nx.statics_bs + (c0 - F); tstride = nx.Fs; }
+            else {
+                tsrc = nx.forcing + (int64_t)b * nx.forcing_bs + (c0 - o_forc);
+                tstride = nx.Ff;
+                tvalid = c_in - c0 < 4 ? c_in - c0 : 4;
+                tkind = tvalid == 4 ? 0 : 1;
+            }
+        }
+    }
+    const bf16* ab = g.a + (int64_t)b * N * 64;
+    bf16* yt = ytile[wv];
+    float acc = 0.0f;
+    const int64_t ntiles = (N + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t n0 = tile * 32;
+        // ---- front end  (prefetching the next tile's rows of `a` during the back end measured SLOWER: 5.00 vs 4.87 ms per step)
+        {
+            f32x16_t y0, y1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y0[i] = y1[i] = 0.f;
+            const int64_t np = n0 + r;
+            u32x4_t cur[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                cur[ks] = u32x4_t{0u, 0u, 0u, 0u};
+                if (np < N) cur[ks] = *reinterpret_cast<const u32x4_t*>(ab + np * 64 + 16 * ks + 8 * h);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const v4f s0 = *reinterpret_cast<const v4f*>(lsc + 16 * ks + 8 * h), s1 = *reinterpret_cast<const v4f*>(lsc + 16 * ks + 8 * h + 4);
+                const v4f t0 = *reinterpret_cast<const v4f*>(lsh + 16 * ks + 8 * h), t1 = *reinterpret_cast<const v4f*>(lsh + 16 * ks + 8 * h + 4);
+                const float scv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                const float shv[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                u32x4_t o;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    // relu(a * scale + shift), fp32, one rounding to bf16: what the 1x1 convolution's loader stages (conv_rows.hip: xform2<2>)
+                    const unsigned int wd = cur[ks][k2];
+                    const float lo = __builtin_fmaf(__builtin_bit_cast(float, wd << 16), scv[2 * k2], shv[2 * k2]);
+                    const float hi = __builtin_fmaf(__builtin_bit_cast(float, wd & 0xffff0000u), scv[2 * k2 + 1], shv[2 * k2 + 1]);
+                    const s16x2_t z = {0, 0};
+                    o[k2] = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16(lo, hi)), z));
+                }
+                const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, o);
+                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wimg[(0 * 4 + ks) * 64 + lane], bf, y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wimg[(1 * 4 + ks) * 64 + lane], bf, y1, 0, 0, 0);
+            }
+            // C[feature][point]: lane = point r (+ half h), register quad gq -> features 32 T + 8 gq + 4 h .. + 3
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x16_t& yy = T == 0 ? y0 : y1;
+                    u32x2_t o;
+                    o[0] = pack_bf16(yy[4 * gq], yy[4 * gq + 1]);
+                    o[1] = pack_bf16(yy[4 * gq + 2], yy[4 * gq + 3]);
+                    // (8-byte slot 8 T + 2 gq + h of the point's row, XOR-ed with the point index: the 16 lanes of a store group share
+                    // the slot index and would hit the same two banks otherwise)
+                    *reinterpret_cast<u32x2_t*>(yt + r * 64 + 4 * ((8 * T + 2 * gq + h) ^ (r & 15))) = o;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the tile is this wave's own: no workgroup barrier)
+        // ---- back end: ar_update_loss_fwd_v4_kernel's loop body on the tile's grid points, y from LDS
+        for (int it = 0; it < 32; it += PP) {
+            const int pl = it + pp;
+            const int64_t n = n0 + pl;
+            if (n >= N) continue;
+            if (xn && tkind != 4) {
+                v4f tq = {0, 0, 0, 0};
+                if (tkind == 0) tq = *reinterpret_cast<const v4f_a4*>(tsrc + n * tstride);
+                else if (tkind == 1) {
+                    const float* pf = tsrc + n * tstride;
+                    tq[0] = pf[0];
+                    if (tvalid > 1) tq[1] = pf[1];
+                    if (tvalid > 2) tq[2] = pf[2];
+                }
+                store4f(xn + n * nx.c_pad + F + 4 * q, tq);
+            }
+            if (!act) continue;
+            const float im = g.interior_mask[n];
+            const float bm = g.border_mask ? g.border_mask[n] : 0.0f;
+            const int64_t e = n * F + 4 * q;
+            const v4f yv = load4f(yt + pl * 64 + 4 * (q ^ (pl & 15)));
+            v4f pv = {0, 0, 0, 0};
+            if (g.prev) pv = *reinterpret_cast<const v4f*>(g.prev + (int64_t)b * g.prev_bs + e);
+            const v4f tg = *reinterpret_cast<const v4f*>(g.target + (int64_t)b * g.tgt_bs + e);
+            v4f o, lg;
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float p0 = pv[j], t0 = tg[j];
+                float pr;
+                if (g.std) {
+                    pr = p0 * g.keep_prev + yv[j] * sd[j];
+                    pr = pr + mn[j];
+                } else {
+                    pr = p0 * g.keep_prev + yv[j];
+                }
+                if (g.border_mask) pr = bm * t0 + im * pr;
+                o[j] = pr;
+                s += loss_elem(pr, t0, 1.0f, g.kind) * w[j];
+                lg[j] = loss_elem_grad(pr, t0, 1.0f, g.kind);
+            }
+            *reinterpret_cast<v4f*>(g.new_state + (int64_t)b * g.new_bs + e) = o;
+            if (xn) store4f(xn + n * nx.c_pad + 4 * q, o);
+            if (lgr) store4f(lgr + e, lg);
+            acc += s * im;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the tile's reads are done before the next tile overwrites it)
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) g.partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int p4c_out_conv_update_loss_fwd(const void* a, const float* a_scale, const float* a_shift, const float* wout, int cout,
+                                            const float* prev, int64_t prev_bs, const float* target, int64_t tgt_bs, const float* std,
+                                            const float* mean, const float* border_mask, const float* interior_mask, float* new_state,
+                                            int64_t new_bs, const float* weights, float num_interior, const int32_t* masked_count,
+                                            int kind, float* loss_out, int64_t loss_stride, void* workspace, int B, int64_t N, int F,
+                                            float keep_prev, void* x_next, int c_pad, const float* statics, int64_t statics_bs, int Fs,
+                                            const float* forcing_next, int64_t forcing_bs, int Ff, void* lgrad, int64_t lgrad_bs,
+                                            p4c_stream_t stream) {
+    P4C_CHECK_ARG(a && a_scale && a_shift && wout && target && interior_mask && new_state && weights && loss_out && workspace,
+                  "p4c_out_conv_update_loss_fwd: null pointer");
+    P4C_CHECK_ARG(prev || keep_prev == 0.0f, "p4c_out_conv_update_loss_fwd: prev is null but keep_prev != 0");
+    P4C_CHECK_ARG((std == nullptr) == (mean == nullptr), "p4c_out_conv_update_loss_fwd: std and mean go together");
+    P4C_CHECK_ARG(cout >= F && cout <= 64 && F > 0 && F % 4 == 0, "p4c_out_conv_update_loss_fwd: needs F <= cout <= 64, F a multiple of 4");
+    P4C_CHECK_ARG(aligned16(a) && aligned16(wout), "p4c_out_conv_update_loss_fwd: a and wout must be 16-byte aligned");
+    P4C_CHECK_ARG(prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 && aligned16(prev) && aligned16(target) && aligned16(new_state) &&
+                      aligned16(weights) && aligned16(std) && aligned16(mean),
+                  "p4c_out_conv_update_loss_fwd: rows must be 16-byte aligned (as p4c_ar_update_loss_fwd_next)");
+    if (x_next) {
+        P4C_CHECK_ARG(statics && forcing_next, "p4c_out_conv_update_loss_fwd: null pointer");
+        P4C_CHECK_ARG(c_pad % 4 == 0 && c_pad >= F + Fs + Ff && Fs % 4 == 0 && Fs >= 0 && Ff >= 0,
+                      "p4c_out_conv_update_loss_fwd: c_pad / Fs must be multiples of 4 and c_pad >= F + Fs + Ff");
+        P4C_CHECK_ARG(c_pad / 4 - F / 4 <= pow2_ge64(F / 4), "p4c_out_conv_update_loss_fwd: too many tail channels for one pass");
+    }
+    P4C_CHECK_ARG(!lgrad || (lgrad_bs % 4 == 0 && aligned16(lgrad)), "p4c_out_conv_update_loss_fwd: lgrad must be 16-byte aligned rows");
+    const int FP4 = pow2_ge64(F / 4);
+    const int nblk = loss_blocks(N, 32, B);
+    OutConvArgs g{(const bf16*)a, a_scale, a_shift, wout, cout, prev, prev_bs, target, tgt_bs, std, mean, border_mask, interior_mask,
+                  new_state, new_bs, weights, kind, (float*)workspace, N, F, keep_prev,
+                  NextX{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff, lgrad, lgrad_bs}};
+    hipLaunchKernelGGL(out_conv_update_loss_fwd_kernel, dim3(nblk, B), dim3(256), 0, as_stream(stream), g, FP4);
+    P4C_CHECK_LAUNCH("p4c_out_conv_update_loss_fwd");
+    hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const float*)workspace, nblk, num_interior,
+                       masked_count, loss_out, loss_stride, B);
+    P4C_CHECK_LAUNCH("p4c_out_conv_update_loss_fwd(final)");
+    return P4C_OK;
 }
 
 // Backward of the fused step from the saved loss gradients (bf16 rows written by p4c_ar_update_loss_fwd_next_saved) instead of the

@@ -546,7 +546,9 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             "conv 3x3 64->64 coarse levels (8 launches)": sum(2 * 2 * M * q[k] for k in range(1, 5)),
             "max-pool (4)": sum(M * q[k] + M * q[k + 1] for k in range(4)),
             "up-sample + sum of the five levels": M * sum(q) + M,
-            "conv 1x1 output": 2 * M,
+            # (bf16 flavour: the 1x1 output convolution runs inside the AR step's kernel -- p4c_out_conv_update_loss_fwd --, its
+            # output is neither written nor read back)
+            "conv 1x1 output": M if esz == 2 else 2 * M,
         }
         # backward of one AR step.  Per 3x3 block at level k: pass 1 of the normalisation backward (dA + y; where its producer
         # takes it -- the 1x1 data gradient for block 11, enc_out_bwd for blocks 1, 3, 5, 7, 9 -- only y is read again), the data
@@ -570,7 +572,8 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         f4 = 4.0 * n0
         rollout = {
             "build_x (AR step 0)": f4 * (F + Fs + Ff) + cpad * esz * n0,
-            "state update + loss forward (prev, target, y in; new state, saved loss gradient out)": T * (f4 * 3 * F + 2 * esz * F * n0),
+            "state update + loss forward (prev, target, y in; new state, saved loss gradient out)":
+                T * (f4 * 3 * F + (1 if esz == 2 else 2) * esz * F * n0),
             "next network input emitted by the update (AR steps 0 .. T-2)": (T - 1) * (f4 * (Fs + Ff) + cpad * esz * n0),
             "state update + loss backward": T * (esz * F * n0 + M) + (T - 1) * (2 * f4 * F + esz * F * n0),
         }
@@ -646,6 +649,14 @@ class _NativeRolloutFn(torch.autograd.Function):
         save_lg = (keep_saved and adt == torch.bfloat16 and fuse_next and mask_mode == L.MASK_NONE
                    and os.environ.get("P4C_SAVE_LOSS_GRAD", "1") != "0")
         lgrads = torch.empty(T, B, N, F, dtype=torch.bfloat16, device=dev) if save_lg else None
+        # bf16 flavour: the network's 1x1 output convolution runs INSIDE the AR step's kernel (p4c_out_conv_update_loss_fwd: y is
+        # never written and read back, one launch less per AR step; same new state bit for bit; P4C_FUSED_TAIL=0: the two-kernel route)
+        fused_tail = (adt == torch.bfloat16 and fuse_next and mask_mode == L.MASK_NONE and model.out_channels >= F
+                      and os.environ.get("P4C_FUSED_TAIL", "1") != "0")
+        desc_fwd = desc
+        if fused_tail:
+            desc_fwd = HalfUNetDesc.from_buffer_copy(desc)
+            desc_fwd.skip_out_conv = 1
         for i in range(T):
             prev, sbs_prev = (inputs[:, 0], sbs_input) if i == 0 else (states[:, i], sbs_state)
             if x_next is not None:
@@ -656,8 +667,24 @@ class _NativeRolloutFn(torch.autograd.Function):
                        L.ptr(x), acode, cpad, B, 1, N, F, Fs, Ff, mask_on_nan, 0, stream)
             if saved is None or keep_saved:
                 saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
-            L.call("p4c_halfunet_forward", ctypes.byref(desc), L.ptr(x), L.ptr(flat), L.ptr(model._running), L.ptr(y),
-                   L.ptr(saved), L.ptr(scratch), int(training), stream)
+            L.call("p4c_halfunet_forward", ctypes.byref(desc_fwd), L.ptr(x), L.ptr(flat), L.ptr(model._running),
+                   None if fused_tail else L.ptr(y), L.ptr(saved), L.ptr(scratch), int(training), stream)
+            if fused_tail:
+                last = i + 1 == T
+                x_next = None if last else torch.empty(B, H, W, cpad, dtype=adt, device=dev)
+                ta, tsc, tsh, tw = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+                L.call("p4c_halfunet_tail", ctypes.byref(desc_fwd), L.ptr(flat), L.ptr(saved), ctypes.byref(ta), ctypes.byref(tsc),
+                       ctypes.byref(tsh), ctypes.byref(tw))
+                L.call("p4c_out_conv_update_loss_fwd", ta, tsc, tsh, tw, model.out_channels,
+                       L.ptr(prev), sbs_prev, L.ptr(outputs[:, i]), T * N * F, L.ptr(std), L.ptr(mean),
+                       L.ptr(border_flat if force_border else None), L.ptr(interior_flat), L.ptr(states[:, i + 1]), sbs_state,
+                       L.ptr(weights), num_interior, L.ptr(count), kind, L.ptr(loss[:, i]), T, L.ptr(ws), B, N, F, 1.0,
+                       L.ptr(x_next), cpad, L.ptr(st), sbs, Fs, L.ptr(None if last else forcing[:, i + 1]), T * N * Ff, Ff,
+                       L.ptr(lgrads[i]) if save_lg else None, N * F, stream)
+                if keep_saved:
+                    xs.append(x)
+                    saveds.append(saved)
+                continue
             step_args = (L.ptr(prev), sbs_prev, L.ptr(y), acode, NF, L.ptr(outputs[:, i]),
                          T * N * F, L.ptr(std), L.ptr(mean), L.ptr(border_flat if force_border else None), L.ptr(interior_flat),
                          L.ptr(states[:, i + 1]), sbs_state, L.ptr(weights), num_interior, L.ptr(count), kind, mask_mode,
