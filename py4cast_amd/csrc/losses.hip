@@ -1175,34 +1175,19 @@ __global__ void __launch_bounds__(256) out_conv_update_loss_fwd_kernel(OutConvAr
     const int64_t ntiles = (N + 31) / 32;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t n0 = tile * 32;
-        // ---- front end
+        // ---- front end  (measured SLOWER, profiles/r04_step_ab_runs.txt: prefetching the next tile's rows of `a` during the back end
+        // -- 5.00 vs 4.87 ms per step --, and staging the rows through the LDS tile with whole-row loads -- 5.10 vs 4.95)
         {
             f32x16_t y0, y1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) y0[i] = y1[i] = 0.f;
-            // the 32 rows of `a` enter through the wave's LDS tile: whole 128-byte rows per 8 lanes from HBM (a lane reading 16 bytes of
-            // ITS OWN row touches every line four times in four instructions and is L1-bound: 137 us per launch that way), 16-byte
-            // slots XOR-ed with the point index so that the fragment reads below -- lane = point -- are conflict-free
-            {
-                const int c8 = lane & 7, p8 = lane >> 3;
-                u32x4_t rows4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t np = n0 + 8 * u + p8;
-                    rows4[u] = u32x4_t{0u, 0u, 0u, 0u};
-                    if (np < N) rows4[u] = *reinterpret_cast<const u32x4_t*>(ab + np * 64 + 8 * c8);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int pl = 8 * u + p8;
-                    *reinterpret_cast<u32x4_t*>(yt + pl * 64 + 8 * (c8 ^ (pl & 7))) = rows4[u];
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t np = n0 + r;
             u32x4_t cur[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) cur[ks] = *reinterpret_cast<const u32x4_t*>(yt + r * 64 + 8 * ((2 * ks + h) ^ (r & 7)));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (every fragment is in registers before y overwrites the tile)
+            for (int ks = 0; ks < 4; ++ks) {
+                cur[ks] = u32x4_t{0u, 0u, 0u, 0u};
+                if (np < N) cur[ks] = *reinterpret_cast<const u32x4_t*>(ab + np * 64 + 16 * ks + 8 * h);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const v4f s0 = *reinterpret_cast<const v4f*>(lsc + 16 * ks + 8 * h), s1 = *reinterpret_cast<const v4f*>(lsc + 16 * ks + 8 * h + 4);
