@@ -8,6 +8,8 @@
 // workspace + a tiny finalize kernel); no float atomics.
 //
 // Compiled with -ffp-contract=off (see rollout.hip).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -480,6 +482,7 @@ __global__ void nan_moments_final_kernel(const float* __restrict__ partial, int 
 // whose stride is a multiple of 4: a lane owns 4 consecutive features of a grid point, so every access is a
 // 16-byte load/store and a wave covers 64/FP4 grid points per iteration.
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int norm4u __attribute__((ext_vector_type(4)));
 
 // optional extra output of the fused step: the NEXT AR step's network input in the padded layout of p4c_build_x
 // (new state | statics | next step's forcing | zero padding), so that the state just computed is not read again
@@ -661,7 +664,219 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// ------------------------------------------------------------------ fused AR update + loss for ANY feature count ("flat" kernels)
+// The 16-byte kernels above need F % 4 == 0 (a lane owns 4 features of ONE grid point).  The reference's shipped Titan configuration
+// has F = 21 (config/CLI/dataset/titan.yaml:38-76), which left that shape to the scalar kernels: one grid point per wave instruction,
+// 21 of 64 lanes busy -- 299 us per backward launch at 2 x 512 x 640 (1.3 TB/s), 10 % of the training step.  Here the (N, F) fp32
+// arrays (previous state, target, new state, upstream gradients, saved loss gradients) are streamed FLAT, 16 bytes per lane whatever
+// F is (a lane's 4 consecutive elements may straddle two grid points), and the ROW tensors of the network -- y / dy / dx with 64
+// channels per grid point, the next network input with c_pad -- pass through LDS tiles of 64 grid points, loaded / stored as whole rows
+// with 16-byte slots.  Same arithmetic per element as the scalar kernels (bit-identical new state, dy, dprev); the loss is the same
+// sum in another order.  Needs N * F % 4 == 0 per sample, 16-byte aligned rows, no NaN masks.
+constexpr int FLAT_P = 64;   // grid points per tile
+
+// (pl, f) of flat element e of a tile, e < 4096, F <= 64: exact multiply-shift division
+__device__ __forceinline__ void flat_pf(int e, int F, unsigned rcp, int& pl, int& f) {
+    pl = (int)(((unsigned)e * rcp) >> 20);
+    f = e - pl * F;
+}
+
+template <typename TY>
+__global__ void __launch_bounds__(256)
+    ar_update_loss_fwd_flat_kernel(const float* __restrict__ prev, int64_t prev_bs, const TY* __restrict__ y, int y_cs,
+                                   const float* __restrict__ target, int64_t tgt_bs, const float* __restrict__ std,
+                                   const float* __restrict__ mean, const float* __restrict__ border_mask,
+                                   const float* __restrict__ interior_mask, float* __restrict__ new_state, int64_t new_bs,
+                                   const float* __restrict__ weights, int kind, float* __restrict__ partial, int64_t N, int F,
+                                   float keep_prev, NextX nx) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    // LDS: y tile [64][y_cs] | x tile [64][c_pad] (next input, if any) | per-feature constants 3 x 64 floats | masks 2 x 64 floats
+    TY* ytile = reinterpret_cast<TY*>(fsm);
+    TY* xtile = ytile + FLAT_P * y_cs;
+    float* cst = reinterpret_cast<float*>(xtile + (nx.x ? FLAT_P * nx.c_pad : 0));
+    float* msk = cst + 3 * 64;
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.y;
+    const unsigned rcp = ((1u << 20) + F - 1) / F;
+    if (tid < 64) {
+        const bool ok = tid < F;
+        cst[tid] = ok ? weights[tid] : 0.f;
+        cst[64 + tid] = (ok && std) ? std[tid] : 1.f;
+        cst[128 + tid] = (ok && mean) ? mean[tid] : 0.f;
+    }
+    const float* prevb = prev ? prev + (int64_t)b * prev_bs : nullptr;
+    const float* tgtb = target + (int64_t)b * tgt_bs;
+    float* newb = new_state + (int64_t)b * new_bs;
+    const TY* yb = y + (int64_t)b * N * y_cs;
+    TY* xn = nx.x ? reinterpret_cast<TY*>(nx.x) + (int64_t)b * N * nx.c_pad : nullptr;
+    bf16* lgr = nx.lgrad ? reinterpret_cast<bf16*>(nx.lgrad) + (int64_t)b * nx.lgrad_bs : nullptr;
+    const float* stat = xn ? nx.statics + (int64_t)b * nx.statics_bs : nullptr;
+    const float* forc = xn ? nx.forcing + (int64_t)b * nx.forcing_bs : nullptr;
+    const int yslots = y_cs * (int)sizeof(TY) / 16, xslots = xn ? nx.c_pad * (int)sizeof(TY) / 16 : 0;
+    const int64_t ntiles = (N + FLAT_P - 1) / FLAT_P;
+    float acc = 0.f;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t n0 = t * FLAT_P;
+        const int np = (int)((N - n0) < FLAT_P ? (N - n0) : FLAT_P);
+        __syncthreads();   // (the previous tile's rows are out; the constants are in)
+        // ---- stage: y rows (whole rows, 16-byte slots), the masks of the tile's grid points
+        for (int sl = tid; sl < np * yslots; sl += 256)
+            reinterpret_cast<norm4u*>(ytile)[sl] = reinterpret_cast<const norm4u*>(yb + n0 * y_cs)[sl];
+        if (tid < 64) {
+            const bool ok = tid < np;
+            msk[tid] = ok ? interior_mask[n0 + tid] : 0.f;
+            msk[64 + tid] = (ok && border_mask) ? border_mask[n0 + tid] : 0.f;
+        }
+        // ---- the next input's channels F .. c_pad - 1: statics | next forcing | zeros (lightning.py:760-765)
+        if (xn) {
+            const int ntail = nx.c_pad - F;
+            for (int i = tid; i < np * ntail; i += 256) {
+                const int pl = i / ntail, c = i - pl * ntail;
+                float v = 0.f;
+                if (c < nx.Fs) v = stat[(n0 + pl) * nx.Fs + c];
+                else if (c < nx.Fs + nx.Ff) v = forc[(n0 + pl) * nx.Ff + (c - nx.Fs)];
+                xtile[pl * nx.c_pad + F + c] = from_f32<TY>(v);
+            }
+        }
+        __syncthreads();
+        // ---- flat phase: 4 consecutive elements of the (np, F) block per lane and trip
+        const int nel = np * F;   // a multiple of 4 (host: N * F % 4 == 0; tiles of 64 grid points)
+        for (int e0 = 4 * tid; e0 < nel; e0 += 4 * 256) {
+            const int64_t E = n0 * F + e0;
+            v4f pv = {0, 0, 0, 0};
+            if (prevb) pv = *reinterpret_cast<const v4f*>(prevb + E);
+            const v4f tg = *reinterpret_cast<const v4f*>(tgtb + E);
+            int pl, f;
+            flat_pf(e0, F, rcp, pl, f);
+            v4f o, lg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float yv = to_f32<TY>(ytile[pl * y_cs + f]);
+                const float im = msk[pl], bm = msk[64 + pl];
+                const float p0 = pv[j], t0 = tg[j];
+                float pr;
+                if (std) {
+                    pr = p0 * keep_prev + yv * cst[64 + f];
+                    pr = pr + cst[128 + f];
+                } else {
+                    pr = p0 * keep_prev + yv;
+                }
+                if (border_mask) pr = bm * t0 + im * pr;
+                o[j] = pr;
+                acc += (loss_elem(pr, t0, 1.0f, kind) * cst[f]) * im;
+                lg[j] = loss_elem_grad(pr, t0, 1.0f, kind);
+                if (xn) xtile[pl * nx.c_pad + f] = from_f32<TY>(pr);
+                if (++f == F) { f = 0; ++pl; }
+            }
+            *reinterpret_cast<v4f*>(newb + E) = o;
+            if (lgr) store4f(lgr + E, lg);
+        }
+        if (xn) {
+            __syncthreads();
+            for (int sl = tid; sl < np * xslots; sl += 256)
+                reinterpret_cast<norm4u*>(xn + n0 * nx.c_pad)[sl] = reinterpret_cast<const norm4u*>(xtile)[sl];
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (tid == 0) partial[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// SAVED: `new_state` holds the bf16 rows of d loss_elem / d pred the forward saved (stride new_bs), `target` is unused
+template <typename TY, bool SAVED>
+__global__ void __launch_bounds__(256)
+    ar_update_loss_bwd_flat_kernel(const float* __restrict__ g_next, int64_t g_next_bs, const TY* __restrict__ g_next2, int g2_cs,
+                                   const float* __restrict__ gloss, int64_t gloss_stride, const float* __restrict__ new_state,
+                                   int64_t new_bs, const float* __restrict__ target, int64_t tgt_bs, const float* __restrict__ std,
+                                   const float* __restrict__ interior_mask, int force_border, const float* __restrict__ weights,
+                                   float num_interior, const int32_t* __restrict__ masked_count, int kind, TY* __restrict__ dy,
+                                   int y_cs, float* dprev, int64_t dprev_bs, int64_t N, int F, float keep_prev) {
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    // LDS: g2 tile [64][g2_cs] (upstream gradient rows, if any) | dy tile [64][y_cs] | weights, std 2 x 64 floats | interior mask 64 floats
+    TY* g2tile = reinterpret_cast<TY*>(fsm);
+    TY* dytile = g2tile + (g_next2 ? FLAT_P * g2_cs : 0);
+    float* cst = reinterpret_cast<float*>(dytile + FLAT_P * y_cs);
+    float* msk = cst + 2 * 64;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const unsigned rcp = ((1u << 20) + F - 1) / F;
+    const float denom = num_interior - (masked_count ? (float)(*masked_count) : 0.0f);
+    const float scale = gloss ? gloss[(int64_t)b * gloss_stride] / denom : 0.0f;
+    if (tid < 64) {
+        const bool ok = tid < F;
+        cst[tid] = ok ? weights[tid] : 0.f;
+        cst[64 + tid] = (ok && std) ? std[tid] : 1.f;
+    }
+    // channels F .. y_cs - 1 of dy are zero: cleared once, the flat phase only ever writes channels < F
+    for (int i = tid; i < FLAT_P * y_cs; i += 256) dytile[i] = from_f32<TY>(0.f);
+    const float* g1b = g_next ? g_next + (int64_t)b * g_next_bs : nullptr;
+    const TY* g2b = g_next2 ? g_next2 + (int64_t)b * N * g2_cs : nullptr;
+    const float* nsb = SAVED ? nullptr : new_state + (int64_t)b * new_bs;
+    const bf16* lgb = SAVED ? reinterpret_cast<const bf16*>(new_state) + (int64_t)b * new_bs : nullptr;
+    const float* tgtb = SAVED ? nullptr : target + (int64_t)b * tgt_bs;
+    TY* dyb = dy + (int64_t)b * N * y_cs;
+    float* dpb = dprev ? dprev + (int64_t)b * dprev_bs : nullptr;
+    const int gslots = g2_cs * (int)sizeof(TY) / 16, yslots = y_cs * (int)sizeof(TY) / 16;
+    const int64_t ntiles = (N + FLAT_P - 1) / FLAT_P;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t n0 = t * FLAT_P;
+        const int np = (int)((N - n0) < FLAT_P ? (N - n0) : FLAT_P);
+        __syncthreads();   // (the previous tile's dy rows are out)
+        if (g2b)
+            for (int sl = tid; sl < np * gslots; sl += 256)
+                reinterpret_cast<norm4u*>(g2tile)[sl] = reinterpret_cast<const norm4u*>(g2b + n0 * g2_cs)[sl];
+        if (tid < 64) msk[tid] = tid < np ? interior_mask[n0 + tid] : 0.f;
+        __syncthreads();
+        const int nel = np * F;
+        for (int e0 = 4 * tid; e0 < nel; e0 += 4 * 256) {
+            const int64_t E = n0 * F + e0;
+            v4f ns = {0, 0, 0, 0}, tg = {0, 0, 0, 0}, lgv = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+            if (SAVED) {
+                lgv = load4f(lgb + E);
+            } else {
+                ns = *reinterpret_cast<const v4f*>(nsb + E);
+                tg = *reinterpret_cast<const v4f*>(tgtb + E);
+            }
+            if (g1b) g1 = *reinterpret_cast<const v4f*>(g1b + E);
+            int pl, f;
+            flat_pf(e0, F, rcp, pl, f);
+            v4f gp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float im = msk[pl];
+                const float sc = scale * im;
+                const float blend = force_border ? im : 1.0f;
+                float g = sc * cst[f] * (SAVED ? lgv[j] : loss_elem_grad(ns[j], tg[j], 1.0f, kind));
+                if (g1b) g += g1[j];
+                if (g2b) g += to_f32<TY>(g2tile[pl * g2_cs + f]);
+                gp[j] = g * blend;
+                dytile[pl * y_cs + f] = from_f32<TY>(std ? gp[j] * cst[64 + f] : gp[j]);
+                if (++f == F) { f = 0; ++pl; }
+            }
+            if (dpb) *reinterpret_cast<v4f*>(dpb + E) = gp * keep_prev;
+        }
+        __syncthreads();
+        for (int sl = tid; sl < np * yslots; sl += 256)
+            reinterpret_cast<norm4u*>(dyb + n0 * y_cs)[sl] = reinterpret_cast<const norm4u*>(dytile)[sl];
+    }
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// the flat kernels' conditions (beyond "the 16-byte kernels do not apply"): no NaN masks (checked by the callers), F <= 64,
+// whole 16-byte slots per row of the row tensors, N * F % 4 == 0, 16-byte aligned bases and batch strides
+// P4C_FORCE_FLAT_STEP=1 (tests): the flat kernels also where the 16-byte ones apply -- same results element for element
+static inline bool force_flat() {
+    const char* e = getenv("P4C_FORCE_FLAT_STEP");
+    return e && e[0] == '1';
+}
+static inline bool flat_ok(int F, int64_t N, int row_cs, int esz) {
+    const char* e = getenv("P4C_NO_FLAT_STEP");   // (read per call: the parity tests switch the flat kernels off)
+    if (e && e[0] == '1') return false;
+    return F > 0 && F <= 64 && row_cs >= F && (row_cs * esz) % 16 == 0 && row_cs <= 256 && (N * F) % 4 == 0;
+}
 
 // ------------------------------------------------------------------ fused AR update + loss (training path)
 // grid: (nblk, B).  One (b, t=i) column of the loss.
@@ -969,9 +1184,11 @@ static int ar_update_loss_fwd_impl(const float* prev, int64_t prev_bs, const voi
     P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE || mask_mode == P4C_MASK_FROM_NAN,
                   "p4c_ar_update_loss_fwd: only MASK_NONE / MASK_FROM_NAN are fused");
     P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS && y_cs >= F, "p4c_ar_update_loss_fwd: bad F / y_cs");
-    if ((y_dtype == P4C_F32 || y_dtype == P4C_BF16) && F % 4 == 0 && F <= 64 && y_cs % 4 == 0 && prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 &&
+    if (!force_flat() && (y_dtype == P4C_F32 || y_dtype == P4C_BF16) && F % 4 == 0 && F <= 64 && y_cs % 4 == 0 && prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 &&
         aligned16(prev) && aligned16(y) && aligned16(target) && aligned16(new_state) && aligned16(weights) && aligned16(std) &&
-        aligned16(mean)) {
+        aligned16(mean) &&
+        (!next || !next->x || (next->c_pad % 4 == 0 && next->Fs % 4 == 0 && next->c_pad / 4 - F / 4 <= pow2_ge64(F / 4))) &&
+        (!next || !next->lgrad || (next->lgrad_bs % 4 == 0 && aligned16(next->lgrad)))) {
         const int FP4 = pow2_ge64(F / 4);
         const int nblk4 = loss_blocks(N, 64 / FP4, B);
         NextX nx{};
@@ -992,7 +1209,41 @@ static int ar_update_loss_fwd_impl(const float* prev, int64_t prev_bs, const voi
         P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(final)");
         return P4C_OK;
     }
-    if (next) return fail(P4C_ERR_UNSUPPORTED, "p4c_ar_update_loss_fwd_next: needs the 16-byte path (F %% 4 == 0, F <= 64, aligned rows)");
+    // ---- any other feature count (the shipped Titan configuration has F = 21): the flat kernels
+    {
+        const int esz = y_dtype == P4C_BF16 ? 2 : 4;
+        bool ok = (y_dtype == P4C_F32 || y_dtype == P4C_BF16) && mask_mode == P4C_MASK_NONE && flat_ok(F, N, y_cs, esz) && prev_bs % 4 == 0 &&
+                  tgt_bs % 4 == 0 && new_bs % 4 == 0 && aligned16(prev) && aligned16(y) && aligned16(target) && aligned16(new_state);
+        if (ok && next && next->x)
+            ok = (next->c_pad * esz) % 16 == 0 && next->c_pad <= 256 && next->c_pad >= F + next->Fs + next->Ff && aligned16(next->x);
+        if (ok && next && next->lgrad) ok = next->lgrad_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(next->lgrad) & 7) == 0;
+        if (ok) {
+            NextX nx{};
+            if (next) nx = *next;
+            const int64_t ntiles = (N + FLAT_P - 1) / FLAT_P;
+            int nblk = loss_blocks(N, FLAT_P / 4, B);
+            if (nblk > ntiles) nblk = (int)ntiles;
+            const size_t smem = (size_t)FLAT_P * y_cs * esz + (nx.x ? (size_t)FLAT_P * nx.c_pad * esz : 0) + 5 * 64 * sizeof(float);
+            if (y_dtype == P4C_F32) {
+                P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_fwd_flat_kernel<float>, (int)smem));
+                hipLaunchKernelGGL(ar_update_loss_fwd_flat_kernel<float>, dim3(nblk, B), dim3(256), smem, as_stream(stream), prev, prev_bs,
+                                   (const float*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs, weights,
+                                   kind, (float*)workspace, N, F, keep_prev, nx);
+            } else {
+                P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_fwd_flat_kernel<bf16>, (int)smem));
+                hipLaunchKernelGGL(ar_update_loss_fwd_flat_kernel<bf16>, dim3(nblk, B), dim3(256), smem, as_stream(stream), prev, prev_bs,
+                                   (const bf16*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs, weights,
+                                   kind, (float*)workspace, N, F, keep_prev, nx);
+            }
+            P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(flat)");
+            hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const float*)workspace, nblk,
+                               num_interior, masked_count, loss_out, loss_stride, B);
+            P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(final)");
+            return P4C_OK;
+        }
+    }
+    if (next) return fail(P4C_ERR_UNSUPPORTED, "p4c_ar_update_loss_fwd_next: needs the 16-byte path (F %% 4 == 0, F <= 64, aligned rows) or the "
+                                               "flat path (F <= 64, N * F %% 4 == 0, whole 16-byte slots per row, aligned rows, no NaN masks)");
     const int FP = pow2_ge64(F), iters = (F + FP - 1) / FP;
     const int nblk = loss_blocks(N, 64 / FP, B);
 #define P4C_LAUNCH_FWD(TY)                                                                                              \
@@ -1034,9 +1285,7 @@ extern "C" int p4c_ar_update_loss_fwd_next(const float* prev, int64_t prev_bs, c
                                            void* x_next, int c_pad, const float* statics, int64_t statics_bs, int Fs,
                                            const float* forcing_next, int64_t forcing_bs, int Ff, p4c_stream_t stream) {
     P4C_CHECK_ARG(x_next && statics && forcing_next, "p4c_ar_update_loss_fwd_next: null pointer");
-    P4C_CHECK_ARG(c_pad % 4 == 0 && c_pad >= F + Fs + Ff && Fs % 4 == 0 && Fs >= 0 && Ff >= 0,
-                  "p4c_ar_update_loss_fwd_next: c_pad / Fs must be multiples of 4 and c_pad >= F + Fs + Ff");
-    P4C_CHECK_ARG(c_pad / 4 - F / 4 <= pow2_ge64(F / 4), "p4c_ar_update_loss_fwd_next: too many tail channels for one pass");
+    P4C_CHECK_ARG(c_pad >= F + Fs + Ff && Fs >= 0 && Ff >= 0, "p4c_ar_update_loss_fwd_next: c_pad must be >= F + Fs + Ff");
     P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE, "p4c_ar_update_loss_fwd_next: the NaN-mask input channel is built by p4c_build_x");
     NextX nx{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff, nullptr, 0};
     return ar_update_loss_fwd_impl(prev, prev_bs, y, y_dtype, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask,
@@ -1055,12 +1304,10 @@ extern "C" int p4c_ar_update_loss_fwd_next_saved(const float* prev, int64_t prev
                                                  void* x_next, int c_pad, const float* statics, int64_t statics_bs, int Fs,
                                                  const float* forcing_next, int64_t forcing_bs, int Ff, void* lgrad, int64_t lgrad_bs,
                                                  p4c_stream_t stream) {
-    P4C_CHECK_ARG(lgrad && lgrad_bs % 4 == 0 && aligned16(lgrad), "p4c_ar_update_loss_fwd_next_saved: lgrad must be 16-byte aligned rows");
+    P4C_CHECK_ARG(lgrad && lgrad_bs % 4 == 0, "p4c_ar_update_loss_fwd_next_saved: lgrad rows must be 8-byte aligned");
     if (x_next) {
         P4C_CHECK_ARG(statics && forcing_next, "p4c_ar_update_loss_fwd_next_saved: null pointer");
-        P4C_CHECK_ARG(c_pad % 4 == 0 && c_pad >= F + Fs + Ff && Fs % 4 == 0 && Fs >= 0 && Ff >= 0,
-                      "p4c_ar_update_loss_fwd_next_saved: c_pad / Fs must be multiples of 4 and c_pad >= F + Fs + Ff");
-        P4C_CHECK_ARG(c_pad / 4 - F / 4 <= pow2_ge64(F / 4), "p4c_ar_update_loss_fwd_next_saved: too many tail channels for one pass");
+        P4C_CHECK_ARG(c_pad >= F + Fs + Ff && Fs >= 0 && Ff >= 0, "p4c_ar_update_loss_fwd_next_saved: c_pad must be >= F + Fs + Ff");
         P4C_CHECK_ARG(mask_mode == P4C_MASK_NONE, "p4c_ar_update_loss_fwd_next_saved: the NaN-mask input channel is built by p4c_build_x");
     }
     NextX nx{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff, lgrad, lgrad_bs};
@@ -1325,10 +1572,35 @@ extern "C" int p4c_ar_update_loss_bwd_saved(const float* g_next, int64_t g_next_
     P4C_CHECK_ARG(lgrad && interior_mask && weights && dy, "p4c_ar_update_loss_bwd_saved: null pointer");
     P4C_CHECK_ARG(F > 0 && y_cs >= F && (dy_dtype == P4C_F32 || dy_dtype == P4C_BF16), "p4c_ar_update_loss_bwd_saved: bad F / y_cs / dtype");
     P4C_CHECK_ARG(dy_dtype == g2_dtype || !g_next2, "p4c_ar_update_loss_bwd_saved: g_next2 dtype must equal dy dtype");
-    const bool ok = F % 4 == 0 && y_cs % 4 == 0 && y_cs / 4 <= 64 && g_next_bs % 4 == 0 && lgrad_bs % 4 == 0 && dprev_bs % 4 == 0 &&
+    const bool ok = !force_flat() && F % 4 == 0 && y_cs % 4 == 0 && y_cs / 4 <= 64 && g_next_bs % 4 == 0 && lgrad_bs % 4 == 0 && dprev_bs % 4 == 0 &&
                     g2_cs % 4 == 0 && aligned16(g_next) && aligned16(g_next2) && aligned16(lgrad) && aligned16(dy) && aligned16(dprev) &&
                     aligned16(weights) && aligned16(std);
-    if (!ok) return fail(P4C_ERR_UNSUPPORTED, "p4c_ar_update_loss_bwd_saved: needs the 16-byte path (F %% 4 == 0, aligned rows)");
+    if (!ok) {   // any other feature count: the flat kernel
+        const int esz = dy_dtype == P4C_BF16 ? 2 : 4;
+        const bool fok = mask_mode == P4C_MASK_NONE && flat_ok(F, N, y_cs, esz) && (!g_next2 || flat_ok(F, N, g2_cs, esz)) && g_next_bs % 4 == 0 &&
+                         lgrad_bs % 4 == 0 && dprev_bs % 4 == 0 && aligned16(g_next) && aligned16(g_next2) &&
+                         (reinterpret_cast<uintptr_t>(lgrad) & 7) == 0 && aligned16(dy) && aligned16(dprev);
+        if (!fok)
+            return fail(P4C_ERR_UNSUPPORTED, "p4c_ar_update_loss_bwd_saved: needs the 16-byte path (F %% 4 == 0, aligned rows) or the flat path "
+                                             "(F <= 64, N * F %% 4 == 0, whole 16-byte slots per row, aligned rows, no NaN masks)");
+        const int64_t ntiles = (N + FLAT_P - 1) / FLAT_P;
+        int nblk = loss_blocks(N, FLAT_P / 4, B);
+        if (nblk > ntiles) nblk = (int)ntiles;
+        const size_t smem = (size_t)FLAT_P * y_cs * esz + (g_next2 ? (size_t)FLAT_P * g2_cs * esz : 0) + 3 * 64 * sizeof(float);
+        if (dy_dtype == P4C_F32) {
+            P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_bwd_flat_kernel<float, true>, (int)smem));
+            hipLaunchKernelGGL((ar_update_loss_bwd_flat_kernel<float, true>), dim3(nblk, B), dim3(256), smem, as_stream(stream), g_next, g_next_bs,
+                               (const float*)g_next2, g2_cs, gloss, gloss_stride, (const float*)lgrad, lgrad_bs, nullptr, 0, std, interior_mask,
+                               force_border, weights, num_interior, masked_count, kind, (float*)dy, y_cs, dprev, dprev_bs, N, F, keep_prev);
+        } else {
+            P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_bwd_flat_kernel<bf16, true>, (int)smem));
+            hipLaunchKernelGGL((ar_update_loss_bwd_flat_kernel<bf16, true>), dim3(nblk, B), dim3(256), smem, as_stream(stream), g_next, g_next_bs,
+                               (const bf16*)g_next2, g2_cs, gloss, gloss_stride, (const float*)lgrad, lgrad_bs, nullptr, 0, std, interior_mask,
+                               force_border, weights, num_interior, masked_count, kind, (bf16*)dy, y_cs, dprev, dprev_bs, N, F, keep_prev);
+        }
+        P4C_CHECK_LAUNCH("p4c_ar_update_loss_bwd_saved(flat)");
+        return P4C_OK;
+    }
     const int FP4 = pow2_ge64(y_cs / 4);
     const int nblk4 = loss_blocks(N, 64 / FP4, B);
     if (dy_dtype == P4C_F32)
@@ -1357,7 +1629,7 @@ extern "C" int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, co
                   "p4c_ar_update_loss_bwd: only MASK_NONE / MASK_FROM_NAN are fused");
     P4C_CHECK_ARG(F > 0 && F <= 64 * LOSS_MAX_ITERS && y_cs >= F, "p4c_ar_update_loss_bwd: bad F / y_cs");
     P4C_CHECK_ARG(dy_dtype == g2_dtype || !g_next2, "p4c_ar_update_loss_bwd: g_next2 dtype must equal dy dtype");
-    if ((dy_dtype == P4C_F32 || dy_dtype == P4C_BF16) && F % 4 == 0 && y_cs % 4 == 0 && y_cs <= 256 && g_next_bs % 4 == 0 && new_bs % 4 == 0 &&
+    if (!force_flat() && (dy_dtype == P4C_F32 || dy_dtype == P4C_BF16) && F % 4 == 0 && y_cs % 4 == 0 && y_cs <= 256 && g_next_bs % 4 == 0 && new_bs % 4 == 0 &&
         tgt_bs % 4 == 0 && dprev_bs % 4 == 0 && g2_cs % 4 == 0 && aligned16(g_next) && aligned16(g_next2) &&
         aligned16(new_state) && aligned16(target) && aligned16(dy) && aligned16(dprev) && aligned16(weights) &&
         aligned16(std)) {
@@ -1375,6 +1647,32 @@ extern "C" int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, co
                                    tgt_bs, std, interior_mask, force_border, weights, num_interior, masked_count, kind,
                                    mask_mode, (bf16*)dy, y_cs, dprev, dprev_bs, N, F, keep_prev, FP4);
             P4C_CHECK_LAUNCH("p4c_ar_update_loss_bwd(v4)");
+            return P4C_OK;
+        }
+    }
+    {   // any other feature count: the flat kernel (see ar_update_loss_bwd_flat_kernel)
+        const int esz = dy_dtype == P4C_BF16 ? 2 : 4;
+        if ((dy_dtype == P4C_F32 || dy_dtype == P4C_BF16) && mask_mode == P4C_MASK_NONE && flat_ok(F, N, y_cs, esz) &&
+            (!g_next2 || flat_ok(F, N, g2_cs, esz)) && g_next_bs % 4 == 0 && new_bs % 4 == 0 && tgt_bs % 4 == 0 && dprev_bs % 4 == 0 &&
+            aligned16(g_next) && aligned16(g_next2) && aligned16(new_state) && aligned16(target) && aligned16(dy) && aligned16(dprev)) {
+            const int64_t ntiles = (N + FLAT_P - 1) / FLAT_P;
+            int nblk = loss_blocks(N, FLAT_P / 4, B);
+            if (nblk > ntiles) nblk = (int)ntiles;
+            const size_t smem = (size_t)FLAT_P * y_cs * esz + (g_next2 ? (size_t)FLAT_P * g2_cs * esz : 0) + 3 * 64 * sizeof(float);
+            if (dy_dtype == P4C_F32) {
+                P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_bwd_flat_kernel<float, false>, (int)smem));
+                hipLaunchKernelGGL((ar_update_loss_bwd_flat_kernel<float, false>), dim3(nblk, B), dim3(256), smem, as_stream(stream), g_next,
+                                   g_next_bs, (const float*)g_next2, g2_cs, gloss, gloss_stride, new_state, new_bs, target, tgt_bs, std,
+                                   interior_mask, force_border, weights, num_interior, masked_count, kind, (float*)dy, y_cs, dprev, dprev_bs, N,
+                                   F, keep_prev);
+            } else {
+                P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_bwd_flat_kernel<bf16, false>, (int)smem));
+                hipLaunchKernelGGL((ar_update_loss_bwd_flat_kernel<bf16, false>), dim3(nblk, B), dim3(256), smem, as_stream(stream), g_next,
+                                   g_next_bs, (const bf16*)g_next2, g2_cs, gloss, gloss_stride, new_state, new_bs, target, tgt_bs, std,
+                                   interior_mask, force_border, weights, num_interior, masked_count, kind, (bf16*)dy, y_cs, dprev, dprev_bs, N,
+                                   F, keep_prev);
+            }
+            P4C_CHECK_LAUNCH("p4c_ar_update_loss_bwd(flat)");
             return P4C_OK;
         }
     }

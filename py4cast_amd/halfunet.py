@@ -641,8 +641,14 @@ class _NativeRolloutFn(torch.autograd.Function):
         lanes = 1
         while lanes < F // 4:
             lanes *= 2  # lanes per grid point of the 16-byte update kernel; each also owns one tail quad of x_next
-        fuse_next = ((not mask_on_nan) and F % 4 == 0 and F <= 64 and Fs % 4 == 0 and cpad % 4 == 0
-                     and cpad // 4 - F // 4 <= lanes)
+        v4_next = ((not mask_on_nan) and F % 4 == 0 and F <= 64 and Fs % 4 == 0 and cpad % 4 == 0
+                   and cpad // 4 - F // 4 <= lanes)
+        # any other feature count (the shipped Titan configuration has 21 features): the flat kernels of csrc/losses.hip -- (N, F)
+        # arrays streamed flat, the network's row tensors through LDS tiles -- take the same fused step
+        esz = 2 if adt == torch.bfloat16 else 4
+        flat_next = ((not mask_on_nan) and F <= 64 and (N * F) % 4 == 0 and (cpad * esz) % 16 == 0 and cpad <= 256
+                     and os.environ.get("P4C_NO_FLAT_STEP", "0") != "1")
+        fuse_next = v4_next or flat_next
         x_next = None
         # bf16 flavour, training: the update kernel also saves the loss gradient of every element as bf16 rows and the backward reads
         # those instead of the new state and the target (480 -> 120 bytes per grid point; P4C_SAVE_LOSS_GRAD=0: recompute)
@@ -651,7 +657,7 @@ class _NativeRolloutFn(torch.autograd.Function):
         lgrads = torch.empty(T, B, N, F, dtype=torch.bfloat16, device=dev) if save_lg else None
         # bf16 flavour: the network's 1x1 output convolution runs INSIDE the AR step's kernel (p4c_out_conv_update_loss_fwd: y is
         # never written and read back, one launch less per AR step; same new state bit for bit; P4C_FUSED_TAIL=0: the two-kernel route)
-        fused_tail = (adt == torch.bfloat16 and fuse_next and mask_mode == L.MASK_NONE and model.out_channels >= F
+        fused_tail = (adt == torch.bfloat16 and v4_next and mask_mode == L.MASK_NONE and model.out_channels >= F
                       and os.environ.get("P4C_FUSED_TAIL", "1") != "0")
         desc_fwd = desc
         if fused_tail:
