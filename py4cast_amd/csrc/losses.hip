@@ -731,13 +731,13 @@ __global__ void __launch_bounds__(256)
         // ---- the next input's channels F .. c_pad - 1: statics | next forcing | zeros (lightning.py:760-765)
         if (xn) {
             const int ntail = nx.c_pad - F;
-            for (int i = tid; i < np * ntail; i += 256) {
-                const int pl = i / ntail, c = i - pl * ntail;
-                float v = 0.f;
-                if (c < nx.Fs) v = stat[(n0 + pl) * nx.Fs + c];
-                else if (c < nx.Fs + nx.Ff) v = forc[(n0 + pl) * nx.Ff + (c - nx.Fs)];
-                xtile[pl * nx.c_pad + F + c] = from_f32<TY>(v);
-            }
+            for (int pl = tid >> 6; pl < np; pl += 4)          // a wave per grid point, a lane per channel: no divisions
+                for (int c = tid & 63; c < ntail; c += 64) {
+                    float v = 0.f;
+                    if (c < nx.Fs) v = stat[(n0 + pl) * nx.Fs + c];
+                    else if (c < nx.Fs + nx.Ff) v = forc[(n0 + pl) * nx.Ff + (c - nx.Fs)];
+                    xtile[pl * nx.c_pad + F + c] = from_f32<TY>(v);
+                }
         }
         __syncthreads();
         // ---- flat phase: 4 consecutive elements of the (np, F) block per lane and trip
