@@ -346,6 +346,20 @@ int p4c_conv_wgrad_nb(const void* in, const float* in_scale, const float* in_shi
                       const float* gamma, const float* nscale, const float* nshift, const float* rstd, const float* mean,
                       const float* k1, const float* k2, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                       p4c_stream_t stream);
+/* The whole backward of a 1x1 convolution from 64 channels behind a [conv -> norm -> ReLU] block (the HalfUNet's output convolution:
+ * mfai's `outconv`) in ONE pass over its operands, bf16 maps (csrc/out_conv_bwd.hip):
+ *   dA (B,N,64) = the data gradient (wprep_dgrad: p4c_prep_weights(w, CO, 64, ks 1, transpose_flip 1, 64, 64, compute P4C_BF16));
+ *   stat_partial (B, p4c_out_conv_bwd_slots, 2, 64) = per-workgroup sums of g and g * xhat, g = dA * [y * scale + shift > 0],
+ *     xhat = (y - mean) * rstd -- pass 1 of the block's normalisation backward (y: the block's raw convolution output, (B,N,64) bf16;
+ *     scale / shift / mean / rstd (B,64) fp32);
+ *   grad_w (CO,64) += sum over pixels of dy[px][co] * relu(y[px][ci] * scale + shift)  (fixed-order reduction of per-workgroup
+ *     partials in `workspace`, p4c_out_conv_bwd_workspace_bytes).
+ * dy (B,N,64) bf16 with channels >= CO zero.  What the HalfUNet backward plan runs for its last layer; exported for tests and reuse. */
+int p4c_out_conv_bwd_slots(int B, int64_t N);
+size_t p4c_out_conv_bwd_workspace_bytes(int B, int64_t N);
+int p4c_out_conv_bwd(const void* dy, const void* wprep_dgrad, const void* y, const float* scale, const float* shift, const float* mean,
+                     const float* rstd, void* dA, float* stat_partial, int CO, float* grad_w, void* workspace, int B, int64_t N,
+                     p4c_stream_t stream);
 /* which kernel the 3x3 64 -> 64 weight gradient of this shape runs on: 1 = row-streaming kernel (csrc/conv_wgrad_rows.hip), 0 = tile kernel */
 int p4c_conv_wgrad_kernel_kind(int storage, int B, int H, int W);
 /* The same convolution on bf16 feature maps with FEWER than 64 channels, in place: in (B,H,W,in_c), out (B,H,W,out_c), in_c and

@@ -34,7 +34,7 @@ struct Layout {
     // saved workspace: activations (element offsets) then normalisation arrays (float offsets from norm_base bytes)
     int64_t Y[NCONV], P[NLEV], S, act_elems, norm_base, norm[NCONV], saved_bytes;
     // scratch: fp32 region (float offsets) then gradient buffers (element offsets from g_base bytes)
-    int64_t wprep, statp, wgradp[NCONV + 1], nbwdp, k1i[2][NCONV], k2i[2][NCONV], tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
+    int64_t wprep, statp, wgradp[NCONV + 1], ocbp[2], nbwdp, k1i[2][NCONV], k2i[2][NCONV], tickets, f_floats, g_base, G0, G1, G2, TB, DY[2][NCONV], scratch_bytes;
     int G;  // workgroups of the weight-gradient kernels
 };
 
@@ -143,6 +143,13 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
         int64_t tiles = (int64_t)d.B * conv_tiles_per_sample(L.Hk[lev], L.Wk[lev]);
         const int g = tiles < L.G ? (int)tiles : L.G;
         L.wgradp[i] = off; off += wgrad_partial_floats(i < NCONV ? conv_cin_pad(d, i) : NF, i < NCONV ? 3 : 1, g);
+    }
+    // the fused backward of the output convolution (out_conv_bwd.hip) runs on the MAIN stream and leaves one partial per workgroup for
+    // the call's batched reduction, which runs on the weight-gradient stream -- with the join deferred over the AR steps, possibly after
+    // the next call's launch: two regions, alternating like the dY sets
+    for (int s = 0; s < 2; ++s) {
+        L.ocbp[s] = off;
+        if (d.dtype == P4C_BF16) off += (int64_t)d.B * out_conv_bwd_slots(d.B, (int64_t)d.H * d.W) * 4096;
     }
     L.nbwdp = off; off += (int64_t)d.B * NORM_BWD_MAX_BLOCKS * 128;
     // k1 / k2 of every block's normalisation backward, per gradient-buffer set: the weight-gradient kernels of the side stream read
@@ -557,7 +564,15 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     // ---- output 1x1 conv
     Norm nd2 = norm_at(ws, 11, d.B);
     int pre11 = 0;
-    {
+    // bf16 storage: data gradient, pass 1 of conv 11's normalisation backward and the weight gradient in ONE pass over dy and Y[11] on
+    // the main stream (out_conv_bwd.hip) -- nothing on the weight-gradient stream reads the caller's dy then
+    const bool fused_out = d.compute == P4C_BF16 && out_conv_bwd_ok(d.dtype, d.B, (int64_t)d.H * d.W);
+    if (fused_out) {
+        float* wpart = ws.f(L.ocbp[g_side.calls & 1]);
+        P4C_TRY(launch_out_conv_bwd(dy, wslot(ws, 2 * NCONV + 1), ws.act(L.Y[11]), nd2.scale, nd2.shift, nd2.mean, nd2.rstd,
+                                    block_grad(ws, 11), ws.f(L.nbwdp), wpart, d.B, (int64_t)d.H * d.W, st, &pre11));
+        P4C_TRY(wgrad_reduce(wpart, d.B * pre11, 1, NF, 0, NF, d.cout, NF, grads + L.wout, st));   // (recorded for the batch, or launched here)
+    } else {
         int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(d.H, d.W);
         const int G = ntiles < L.G ? (int)ntiles : L.G;
         hipStream_t wst = st;
@@ -630,6 +645,8 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     // join: the caller's stream continues only after every weight gradient of this call has been accumulated -- unless the
     // caller defers that to p4c_side_stream_join (then only what the next call may overwrite is ordered: the caller's dy)
     if (g_side.enabled) {
+        // (the batched reduction also reads partials the main stream wrote -- out_conv_bwd: ordered after it even with nothing pending)
+        if (g_side.pending.empty()) P4C_TRY(g_side.order(st, g_side.stream));
         P4C_TRY(g_side.flush(st));
         P4C_TRY(wgrad_reduce_batch(reduce_jobs, g_side.stream));
         if (plain_stream) {
@@ -637,9 +654,9 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
             P4C_CHECK_HIP(hipEventRecord(g_side.set_done[set], g_side.stream));
             g_side.set_recorded[set] = true;
         }
-        if (deferring)
-            P4C_CHECK_HIP(hipStreamWaitEvent(st, g_side.dy_read, 0));
-        else
+        if (deferring) {
+            if (!fused_out) P4C_CHECK_HIP(hipStreamWaitEvent(st, g_side.dy_read, 0));
+        } else
             P4C_TRY(g_side.order(g_side.stream, st));
     } else {
         P4C_TRY(wgrad_reduce_batch(reduce_jobs, st));
@@ -732,6 +749,24 @@ extern "C" int p4c_conv_wgrad_nb(const void* in, const float* in_scale, const fl
     const NormBwdCoef nb{y, gamma, nscale, nshift, rstd, mean, k1, k2};
     return conv_wgrad(P4C_BF16, P4C_BF16, in, 64, 3, in_scale, in_shift, in_relu, dA, (float*)workspace, G, B, H, W, CO, CI, grad,
                       as_stream(stream), &nb);
+}
+
+extern "C" int p4c_out_conv_bwd_slots(int B, int64_t N) { return out_conv_bwd_slots(B, N); }
+
+extern "C" size_t p4c_out_conv_bwd_workspace_bytes(int B, int64_t N) {
+    return (size_t)B * out_conv_bwd_slots(B, N) * 4096 * sizeof(float);
+}
+
+extern "C" int p4c_out_conv_bwd(const void* dy, const void* wprep_dgrad, const void* y, const float* scale, const float* shift,
+                                const float* mean, const float* rstd, void* dA, float* stat_partial, int CO, float* grad_w, void* workspace,
+                                int B, int64_t N, p4c_stream_t stream) {
+    P4C_CHECK_ARG(dy && wprep_dgrad && y && scale && shift && mean && rstd && dA && stat_partial && grad_w && workspace,
+                  "p4c_out_conv_bwd: null pointer");
+    P4C_CHECK_ARG(CO > 0 && CO <= 64, "p4c_out_conv_bwd: CO must be in 1..64");
+    if (!out_conv_bwd_ok(P4C_BF16, B, N)) return fail(P4C_ERR_UNSUPPORTED, "p4c_out_conv_bwd: unsupported shape (B %d, N %lld)", B, (long long)N);
+    int nblk = 0;
+    P4C_TRY(launch_out_conv_bwd(dy, wprep_dgrad, y, scale, shift, mean, rstd, dA, stat_partial, (float*)workspace, B, N, as_stream(stream), &nblk));
+    return wgrad_reduce((const float*)workspace, B * nblk, 1, 64, 0, 64, CO, 64, grad_w, as_stream(stream));
 }
 
 extern "C" int p4c_conv_wgrad_kernel_kind(int storage, int B, int H, int W) {

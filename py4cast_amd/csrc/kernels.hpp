@@ -131,6 +131,14 @@ bool conv_wgrad_rows_ok(int storage, int in_cs, int ci_off, int dout_cs, int ks,
 int launch_conv3x3_wgrad_bf16_rows(const void* x, const float* x_scale, const float* x_shift, int x_relu, const void* dout, float* partial,
                                    int G, int B, int H, int W, hipStream_t stream, const NormBwdCoef* nb, int* nslots_out, int in_cs = 64,
                                    int ci_off = 0, int ci_real = 64, int part_cip = 64);
+// out_conv_bwd.hip: the whole backward of a 1x1 convolution from 64 channels in one pass -- data gradient dA (B,N,64), pass 1 of the
+// normalisation backward of the block before it (statistics slots [B][slots][2][64], as RingBwdStats leaves them) and per-workgroup
+// weight-gradient partials [B * slots][64 ci][64 co] for wgrad_reduce (ks = 1, CI_pad = 64)
+bool out_conv_bwd_ok(int storage, int B, int64_t N);
+int out_conv_bwd_slots(int B, int64_t N);   // workgroups per sample
+int launch_out_conv_bwd(const void* dy, const void* wp_dgrad, const void* y, const float* scale, const float* shift, const float* mean,
+                        const float* rstd, void* dA, float* stat_partial, float* wpartial, int B, int64_t N, hipStream_t stream,
+                        int* nblk_out);
 // plain convolution / its weight gradient on feature maps with fewer than 64 channels, in place (no padded copies): row kernel only
 bool conv_wgrad_bf16_takes_nb(int storage, int CI, int ks, int B);
 bool conv_rows_compact_ok(int storage, int in_cs, int out_cs, int ks, int B, int H, int W);

@@ -69,6 +69,23 @@ def conv_wgrad_nb(x: torch.Tensor, dA: torch.Tensor, y: torch.Tensor, gamma, nsc
     return grad
 
 
+def out_conv_bwd(dy: torch.Tensor, w: torch.Tensor, y: torch.Tensor, scale, shift, mean, rstd, grad_w: torch.Tensor):
+    """The whole backward of a 1x1 convolution from 64 channels behind [conv -> norm -> ReLU] in one pass (p4c_out_conv_bwd; bf16 maps):
+    dy (B,N,64) with channels >= CO zero, w (CO,64) fp32, y (B,N,64) the block's raw output, scale / shift / mean / rstd (B,64).
+    Returns dA (B,N,64) bf16 and the statistics slots (B, slots, 2, 64) of pass 1 of the normalisation backward; grad_w (CO,64) +=."""
+    L.require_cuda(dy, w, y, grad_w)
+    B, N, _ = dy.shape
+    CO = w.shape[0]
+    wp = prep_weights(w.detach().float().reshape(CO, 64, 1, 1), True, 64, 64, compute="bf16")
+    slots = L.lib().p4c_out_conv_bwd_slots(B, N)
+    dA = torch.empty(B, N, 64, dtype=torch.bfloat16, device=dy.device)
+    stats = torch.empty(B, slots, 2, 64, dtype=torch.float32, device=dy.device)
+    ws = torch.empty(L.lib().p4c_out_conv_bwd_workspace_bytes(B, N) // 4, dtype=torch.float32, device=dy.device)
+    L.call("p4c_out_conv_bwd", L.ptr(dy.contiguous()), L.ptr(wp), L.ptr(y.contiguous()), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(rstd),
+           L.ptr(dA), L.ptr(stats), CO, L.ptr(grad_w), L.ptr(ws), B, N, L.stream(dy.device))
+    return dA, stats
+
+
 # ------------------------------------------------------------------------------ a whole convolution as one autograd node
 def _pad32(c: int) -> int:
     return (c + 31) // 32 * 32
