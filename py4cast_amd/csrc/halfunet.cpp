@@ -346,13 +346,27 @@ thread_local SideStream g_side;
 // the side stream while the main stream has long moved on.
 inline void* block_grad(const WS& ws, int i) { return ws.g(ws.L.DY[g_side.calls & 1][i]); }
 
+// In-kernel finish of a normalisation backward's pass 1 (kernels.hpp: BwdFin; BatchNorm, bf16 storage): ticket word 1 of the plan's
+// counters (word 0: the forward's BatchFin), or nullptr = every pass is finished by a norm_bwd_finalize launch
+inline unsigned int* bwd_ticket(const p4c_halfunet_desc& d, const WS& ws) {
+    return (d.norm == 0 && d.dtype == P4C_BF16) ? reinterpret_cast<unsigned int*>(ws.f(ws.L.tickets)) + 1 : nullptr;
+}
+inline BwdFin bwd_fin(const p4c_halfunet_desc& d, const WS& ws, int i, const float* params, float* grads, int training) {
+    const Layout& L = ws.L;
+    const int lev = conv_level(i);
+    return BwdFin{bwd_ticket(d, ws), params + L.gamma[i], grads + L.gamma[i], grads + L.beta[i], ws.f(L.k1i[g_side.calls & 1][i]),
+                  ws.f(L.k2i[g_side.calls & 1][i]), (float)d.B * (float)((int64_t)L.Hk[lev] * L.Wk[lev]), d.B,
+                  ((d.norm == 1) || training) ? 1 : 0};
+}
+
 // backward through [conv i -> norm -> relu] given dA in block_grad(i):
 //   grads of gamma/beta/weight accumulated; if `din` != null: din = dL/d(conv input).
 // pre_nblk > 0: the producer of dA took pass 1 of the normalisation backward (partial sums in ws.nbwdp).  Where the consumers can
 // (conv_bf16_norm_bwd_fused_ok, and see `dgrad_takes_pass1`), pass 2 is theirs: no norm_bwd_apply launch, no dY map -- the
 // data-gradient row kernel and the weight-gradient kernel form dY = alpha * g + beta * y + delta while they load dA and y.
 int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* in, const Norm* in_norm, void* din,
-                   const float* params, float* grads, int training, hipStream_t st, int pre_nblk = 0, int* next_nblk = nullptr) {
+                   const float* params, float* grads, int training, hipStream_t st, int pre_nblk = 0, int* next_nblk = nullptr,
+                   bool pre_finalized = false) {
     const Layout& L = ws.L;
     const int lev = conv_level(i), H = L.Hk[lev], W = L.Wk[lev];
     Norm nm = norm_at(ws, i, d.B);
@@ -372,7 +386,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
                      (cip == NF || (nb_all && getenv("P4C_NO_NB0") == nullptr && conv_wgrad_bf16_takes_nb(d.dtype, cip, 3, d.B)));
     P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
                      (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i]),
-                     grads + L.gamma[i], grads + L.beta[i], nbf ? nullptr : g, st, pre_nblk));
+                     grads + L.gamma[i], grads + L.beta[i], nbf ? nullptr : g, st, pre_nblk, bwd_ticket(d, ws), pre_finalized));
     const NormBwdCoef nb{ws.act(L.Y[i]), params + L.gamma[i], nm.scale, nm.shift, nm.rstd, nm.mean,
                          ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i])};
     int64_t ntiles = (int64_t)d.B * conv_tiles_per_sample(H, W);
@@ -623,17 +637,20 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         const bool fuse_off = fe && fe[0] == '1';
         const bool fuse = !fuse_off && d.dtype == P4C_BF16;
         int pre = 0;
+        bool finished = false;   // (few slots: enc_out_bwd's last workgroup also finishes the pass -- BwdFin)
         float* part = fuse ? ws.f(L.nbwdp) : nullptr;
+        const BwdFin fin = bwd_fin(d, ws, 2 * k + 1, params, grads, training);
         if (k > 0) {
             P4C_TRY(enc_out_bwd(d.dtype, tx[k - 1], d.H, 1 << k, nullptr, dP, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, Hk, Wk,
-                                block_grad(ws, 2 * k + 1), st, n2.mean, n2.rstd, part, &pre));
+                                block_grad(ws, 2 * k + 1), st, n2.mean, n2.rstd, part, &pre, &fin, &finished));
         } else {
             P4C_TRY(enc_out_bwd(d.dtype, nullptr, d.H, 1, G0, dP, ws.act(L.Y[1]), n2.scale, n2.shift, d.B, Hk, Wk, block_grad(ws, 1), st,
-                                n2.mean, n2.rstd, part, &pre));
+                                n2.mean, n2.rstd, part, &pre, &fin, &finished));
         }
         // conv2 of the block: input = relu(norm1(Y_k1)); its data gradient is conv1's dA
         int nxt1 = 0;
-        P4C_TRY(conv_block_bwd(d, ws, 2 * k + 1, ws.act(L.Y[2 * k]), &n1, block_grad(ws, 2 * k), params, grads, training, st, pre, &nxt1));
+        P4C_TRY(conv_block_bwd(d, ws, 2 * k + 1, ws.act(L.Y[2 * k]), &n1, block_grad(ws, 2 * k), params, grads, training, st, pre, &nxt1,
+                               finished));
         // conv1 of the block: input = P_k (k>0) or x; its data gradient is dP_k (into the other of the two rotating buffers)
         if (k > 0) {
             P4C_TRY(conv_block_bwd(d, ws, 2 * k, ws.act(L.P[k]), nullptr, b, params, grads, training, st, nxt1));

@@ -71,6 +71,21 @@ struct BatchFin {
     float eps, momentum;
     int B;
 };
+// The same for the normalisation BACKWARD (BatchNorm): a kernel that leaves pass-1 slots [B][nblk][2][64] (norm_bwd_reduce,
+// enc_out_bwd) lets its last workgroup do what norm_bwd_finalize does in a launch of its own -- d(gamma) += sum g * xhat,
+// d(beta) += sum g, k1 / k2 (B,64) -- when there are few enough slots for one workgroup to sum (bwd_fin_max_slots(): the coarse
+// levels, where the dependent ~6 us launch is pure latency on the backward chain).  ticket == nullptr: off.
+struct BwdFin {
+    unsigned int* ticket;      // zero between launches (the last workgroup resets it)
+    const float* gamma;
+    float* dgamma;
+    float* dbeta;
+    float* k1;                 // (B,64) each
+    float* k2;
+    float count;               // B*H*W
+    int B, training;
+};
+int bwd_fin_max_slots();       // B * nblk up to which a producer finishes in place (P4C_BWD_INFIN_MAX; 0: never)
 int prep_weights_batch(const PrepBatch& pb, hipStream_t stream);
 int conv_bf16_stat_slots(int CI, int storage, int B, int H, int W, int ks = 3);
 // `storage` = element type of in/out/dout in HBM (P4C_F32 or P4C_BF16)
@@ -157,7 +172,8 @@ int norm_bwd_blocks(int64_t hw);
 // `storage` = element type of activations / activation gradients in HBM (P4C_F32 or P4C_BF16)
 int norm_bwd(int storage, const void* dA, const void* y, const float* scale, const float* shift, const float* mean,
              const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
-             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream, int pre_nblk = 0);
+             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream, int pre_nblk = 0,
+             unsigned int* fin_ticket = nullptr, bool pre_finalized = false);
 // partial slots per sample the normalisation backward's buffers are sized for (standalone pass 1: <= 512; producers that take
 // pass 1 themselves -- enc_out_bwd, the ring data-gradient convolution -- may leave up to this many)
 constexpr int NORM_BWD_MAX_BLOCKS = 1024;
@@ -171,7 +187,8 @@ int up_bwd_x4(int storage, const void* dS, int B, int H, int W, void* const* tx,
 // second convolution on the dA it forms; *nblk_out = slots per sample left in `partial` (0: not fused, run the pass as usual)
 int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, const void* dP, const void* y,
                 const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream,
-                const float* mean = nullptr, const float* rstd = nullptr, float* partial = nullptr, int* nblk_out = nullptr);
+                const float* mean = nullptr, const float* rstd = nullptr, float* partial = nullptr, int* nblk_out = nullptr,
+                const BwdFin* fin = nullptr, bool* finalized_out = nullptr);
 
 // tiles of the conv kernels (for sizing the statistics partial buffers)
 constexpr int CONV_TH = 4;

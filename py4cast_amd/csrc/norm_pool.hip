@@ -171,6 +171,62 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// Epilogue shared by the kernels that take pass 1 of a normalisation backward (grid (nblk, B), 256 threads): red[st][pl][c] holds the
+// 32 pixel lanes' sums of g (st 0) and g * xhat (st 1); the workgroup's slot goes to partial[b][blockIdx.x][st][c].  With fin.ticket
+// set the LAST workgroup of the launch then finishes the pass (kernels.hpp: BwdFin) -- the slots summed in a fixed order whichever
+// workgroup comes last: bitwise reproducible.
+__device__ __forceinline__ void bwd_slot_finish(float (&red)[2][32][65], float* __restrict__ partial, const BwdFin& fin) {
+    const int b = blockIdx.y, nblk = gridDim.x;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += red[st][k][c];
+        float* dst = partial + (((int64_t)b * nblk + blockIdx.x) * 2 + st) * 64 + c;
+        if (fin.ticket) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (write-through: see conv_rows.hip, BatchFin)
+        else *dst = s;
+    }
+    if (!fin.ticket) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every slot store of this workgroup is acknowledged (and red[] is free)
+    unsigned int* lflag = reinterpret_cast<unsigned int*>(&red[0][0][0]);
+    float* lsum = &red[1][0][0];   // [8][128] (16-byte aligned: the kernels declare red so)
+    const int nslots = nblk * gridDim.y;
+    if (threadIdx.x == 0) *lflag = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*lflag != (unsigned)nslots - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // invalidate only: the other workgroups' slots are read from memory
+    // 256 threads: 32 column quads of the 128 sums x 8 slot groups; slots in increasing order within a group, groups in order
+    const int cq = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = sg; s0 < nslots; s0 += 64) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sl = s0 + 8 * u;
+            v[u] = sl < nslots ? *(reinterpret_cast<const f32x4*>(partial + (int64_t)sl * 128) + cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    __syncthreads();   // (lflag has been read by everyone)
+    *reinterpret_cast<f32x4*>(lsum + sg * 128 + 4 * cq) = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        float tot1 = 0.f, tot2 = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) { tot1 += lsum[g8 * 128 + c]; tot2 += lsum[g8 * 128 + 64 + c]; }
+        fin.dgamma[c] += tot2;
+        fin.dbeta[c] += tot1;
+        const float ga = fin.gamma[c];
+        const float a = fin.training ? ga * tot1 / fin.count : 0.f, bb = fin.training ? ga * tot2 / fin.count : 0.f;
+        for (int bi = 0; bi < fin.B; ++bi) { fin.k1[bi * C + c] = a; fin.k2[bi * C + c] = bb; }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The same pass for bf16 storage with 16-byte loads (8 channels per thread, 8 threads per pixel, 32 pixels per block iteration)
 // and four iterations of both tensors in flight per thread: the 8-byte-per-lane form above streams the full-resolution maps at
 // 3.6 TB/s (37 us per launch, rocprofv3), this one is what the row kernels of rows.hip reach (>5 TB/s).  Same partial layout.
@@ -185,8 +241,8 @@ __device__ __forceinline__ void unpack8(const norm_u32x4& v, float* f) {
 __global__ void __launch_bounds__(256)
     norm_bwd_reduce_bf16x8_kernel(const __bf16* __restrict__ dA, const __bf16* __restrict__ y, const float* __restrict__ scale,
                                   const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                  int relu, int64_t hw, float* __restrict__ partial) {
-    __shared__ float red[2][32][65];
+                                  int relu, int64_t hw, float* __restrict__ partial, BwdFin fin) {
+    __shared__ __attribute__((aligned(16))) float red[2][32][65];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;   // 32 pixels per block iteration
     float sc[8], sh[8], mu[8], rs[8], a1[8], a2[8];
@@ -229,14 +285,7 @@ __global__ void __launch_bounds__(256)
         red[0][pl][8 * c8 + j] = a1[j];
         red[1][pl][8 * c8 + j] = a2[j];
     }
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) s += red[st][k][c];
-        partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = s;
-    }
+    bwd_slot_finish(red, partial, fin);
 }
 
 // pass 1b: reduce partials; accumulate dgamma/dbeta; emit per-(b,c) k1,k2 so that
@@ -649,7 +698,7 @@ __global__ void __launch_bounds__(256)
     // partial != null: pass 1 of the normalisation backward of THIS level's second convolution (norm_bwd_reduce: the sums of
     // g = dA * [relu alive] and g * xhat over the pixels of this workgroup) is taken here, on the dA just formed (its
     // bf16-rounded value, what a separate pass would read back) -- one launch and one read of dA and y less per encoder level
-    __shared__ float red[2][32][65];
+    __shared__ __attribute__((aligned(16))) float red[2][32][65];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
     float sc[8], sh[8], mu[8], rs[8], a1[8], a2[8];
@@ -771,6 +820,11 @@ int norm_eval(int B, const float* gamma, const float* beta, float eps, const flo
     return P4C_OK;
 }
 
+int bwd_fin_max_slots() {
+    if (const char* e = getenv("P4C_BWD_INFIN_MAX")) return atoi(e);   // (read per call: A/B scripts and the parity tests switch it)
+    return 256;
+}
+
 int norm_bwd_blocks(int64_t hw) {
     int64_t nblk = (hw + 16 * 8 - 1) / (16 * 8);  // >= 8 pixels per thread row
     if (nblk > 512) nblk = 512;
@@ -784,16 +838,23 @@ template <typename T>
 static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* shift, const float* mean,
                       const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups,
                       int training, float* partial, float* k1, float* k2, float* dgamma, float* dbeta, T* dY,
-                      hipStream_t stream, int pre_nblk) {
+                      hipStream_t stream, int pre_nblk, unsigned int* fin_ticket, bool pre_finalized) {
     // pre_nblk > 0: pass 1 was taken by the kernel that produced dA (enc_out_bwd / the data-gradient convolution): `partial`
     // already holds pre_nblk slots per sample
     const int nblk = pre_nblk > 0 ? pre_nblk : norm_bwd_blocks(hw);
-    const bool skip_reduce = diag_skip(4), skip_fin = diag_skip(2), skip_apply = diag_skip(16);
+    const bool skip_reduce = diag_skip(4), skip_apply = diag_skip(16);
+    bool skip_fin = diag_skip(2) || pre_finalized;
     if (skip_reduce || pre_nblk > 0) {
-    } else if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_REDUCE_V1") == nullptr)
+    } else if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_REDUCE_V1") == nullptr) {
+        // BatchNorm with few slots: the launch's last workgroup finishes the pass (no norm_bwd_finalize launch)
+        BwdFin fin{};
+        if (fin_ticket && mode == 0 && (int64_t)B * nblk <= bwd_fin_max_slots()) {
+            fin = BwdFin{fin_ticket, gamma, dgamma, dbeta, k1, k2, (float)B * (float)hw, B, training};
+            skip_fin = true;
+        }
         hipLaunchKernelGGL(norm_bwd_reduce_bf16x8_kernel, dim3(nblk, B), dim3(256), 0, stream, (const __bf16*)dA, (const __bf16*)y, scale,
-                           shift, mean, rstd, relu, hw, partial);
-    else
+                           shift, mean, rstd, relu, hw, partial, fin);
+    } else
         hipLaunchKernelGGL(norm_bwd_reduce_kernel<T>, dim3(nblk, B), dim3(256), 0, stream, dA, y, scale, shift, mean, rstd,
                            relu, hw, partial);
     P4C_CHECK_LAUNCH("norm_bwd_reduce");
@@ -819,12 +880,13 @@ static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* 
 
 int norm_bwd(int storage, const void* dA, const void* y, const float* scale, const float* shift, const float* mean,
              const float* rstd, const float* gamma, int relu, int B, int64_t hw, int mode, int groups, int training,
-             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream, int pre_nblk) {
+             float* partial, float* k1, float* k2, float* dgamma, float* dbeta, void* dY, hipStream_t stream, int pre_nblk,
+             unsigned int* fin_ticket, bool pre_finalized) {
     if (storage == P4C_BF16)
         return norm_bwd_t<__bf16>((const __bf16*)dA, (const __bf16*)y, scale, shift, mean, rstd, gamma, relu, B, hw, mode,
-                                  groups, training, partial, k1, k2, dgamma, dbeta, (__bf16*)dY, stream, pre_nblk);
+                                  groups, training, partial, k1, k2, dgamma, dbeta, (__bf16*)dY, stream, pre_nblk, fin_ticket, pre_finalized);
     return norm_bwd_t<float>((const float*)dA, (const float*)y, scale, shift, mean, rstd, gamma, relu, B, hw, mode, groups,
-                             training, partial, k1, k2, dgamma, dbeta, (float*)dY, stream, pre_nblk);
+                             training, partial, k1, k2, dgamma, dbeta, (float*)dY, stream, pre_nblk, fin_ticket, pre_finalized);
 }
 
 // pool_fwd for bf16 storage: 16-byte accesses (8 channels per thread), the sample's scale / shift in registers (grid.y = sample),
@@ -966,8 +1028,8 @@ __global__ void __launch_bounds__(256)
     enc_out_bwd_px_kernel(const __bf16* __restrict__ Tx, int Hfull, int s, const __bf16* __restrict__ dS,
                           const __bf16* __restrict__ dP, const __bf16* __restrict__ y, const float* __restrict__ scale,
                           const float* __restrict__ shift, int Hk, int Wk, __bf16* __restrict__ dA,
-                          const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial) {
-    __shared__ float red[2][32][65];
+                          const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial, BwdFin fin) {
+    __shared__ __attribute__((aligned(16))) float red[2][32][65];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
     float sc[8], sh[8], mu[8], rs[8], a1[8], a2[8];
@@ -1040,14 +1102,7 @@ __global__ void __launch_bounds__(256)
             red[0][pl][8 * c8 + j] = a1[j];
             red[1][pl][8 * c8 + j] = a2[j];
         }
-        __syncthreads();
-        if (threadIdx.x < 128) {
-            const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
-            float sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) sum += red[st][k][c];
-            partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = sum;
-        }
+        bwd_slot_finish(red, partial, fin);
     }
 }
 
@@ -1055,9 +1110,9 @@ __global__ void __launch_bounds__(256)
     enc_out_bwd_blk_kernel(const __bf16* __restrict__ Tx, int Hfull, int s, const __bf16* __restrict__ dS,
                            const __bf16* __restrict__ dP, const __bf16* __restrict__ y, const float* __restrict__ scale,
                            const float* __restrict__ shift, int Hk, int Wk, __bf16* __restrict__ dA,
-                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial) {
+                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ partial, BwdFin fin) {
     // requires dP (a pooled level below) and Hk, Wk even: levels 0 and 1 of the plan
-    __shared__ float red[2][32][65];
+    __shared__ __attribute__((aligned(16))) float red[2][32][65];
     const int b = blockIdx.y;
     const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
     float sc[8], sh[8], mu[8], rs[8], a1[8], a2[8];
@@ -1130,22 +1185,16 @@ __global__ void __launch_bounds__(256)
             red[0][pl][8 * c8 + j] = a1[j];
             red[1][pl][8 * c8 + j] = a2[j];
         }
-        __syncthreads();
-        if (threadIdx.x < 128) {
-            const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
-            float sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) sum += red[st][k][c];
-            partial[(((int64_t)b * gridDim.x + blockIdx.x) * 2 + st) * 64 + c] = sum;
-        }
+        bwd_slot_finish(red, partial, fin);
     }
 }
 
 template <typename T>
 static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP, const T* y, const float* scale,
                          const float* shift, int B, int Hk, int Wk, T* dA, const float* mean, const float* rstd, float* partial,
-                         int* nblk_out, hipStream_t stream) {
+                         int* nblk_out, hipStream_t stream, const BwdFin* finp, bool* finalized_out) {
     if (nblk_out) *nblk_out = 0;
+    if (finalized_out) *finalized_out = false;
     if (std::is_same<T, __bf16>::value && getenv("P4C_ENC_OUT_V1") == nullptr) {
         const char* v2 = getenv("P4C_ENC_OUT_V2");   // 0: the round-2 kernel (one thread per pixel, dependent row loads)
         const bool old = v2 && v2[0] == '0';
@@ -1156,11 +1205,19 @@ static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP
         if (fuse && cap > NORM_BWD_MAX_BLOCKS) cap = NORM_BWD_MAX_BLOCKS;   // one partial slot per workgroup
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
-        auto kern = old ? enc_out_bwd_bf16x8_kernel : (blk ? enc_out_bwd_blk_kernel : enc_out_bwd_px_kernel);
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const __bf16*)Tx, Hfull, s,
-                           (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale, shift, Hk, Wk, (__bf16*)dA, mean, rstd,
-                           fuse ? partial : nullptr);
+        // few slots (the coarse levels): the last workgroup also finishes the pass (BwdFin) -- no norm_bwd_finalize launch
+        const bool infin = fuse && !old && finp && finp->ticket && finalized_out && blocks * B <= bwd_fin_max_slots();
+        const BwdFin fin = infin ? *finp : BwdFin{};
+        if (old)
+            hipLaunchKernelGGL(enc_out_bwd_bf16x8_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream, (const __bf16*)Tx, Hfull, s,
+                               (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale, shift, Hk, Wk, (__bf16*)dA, mean, rstd,
+                               fuse ? partial : nullptr);
+        else
+            hipLaunchKernelGGL(blk ? enc_out_bwd_blk_kernel : enc_out_bwd_px_kernel, dim3((unsigned)blocks, B), dim3(256), 0, stream,
+                               (const __bf16*)Tx, Hfull, s, (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale, shift, Hk, Wk,
+                               (__bf16*)dA, mean, rstd, fuse ? partial : nullptr, fin);
         if (fuse) *nblk_out = (int)blocks;
+        if (infin) *finalized_out = true;
     } else {
         hipLaunchKernelGGL(enc_out_bwd_kernel<T>, dim3(ew_grid((int64_t)B * Hk * Wk * 16)), dim3(256), 0, stream, Tx, Hfull, s,
                            dS, dP, y, scale, shift, B, Hk, Wk, dA);
@@ -1170,12 +1227,12 @@ static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP
 }
 int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, const void* dP, const void* y,
                 const float* scale, const float* shift, int B, int Hk, int Wk, void* dA, hipStream_t stream, const float* mean,
-                const float* rstd, float* partial, int* nblk_out) {
+                const float* rstd, float* partial, int* nblk_out, const BwdFin* fin, bool* finalized_out) {
     if (storage == P4C_BF16)
         return enc_out_bwd_t<__bf16>((const __bf16*)Tx, Hfull, s, (const __bf16*)dS, (const __bf16*)dP, (const __bf16*)y, scale,
-                                     shift, B, Hk, Wk, (__bf16*)dA, mean, rstd, partial, nblk_out, stream);
+                                     shift, B, Hk, Wk, (__bf16*)dA, mean, rstd, partial, nblk_out, stream, fin, finalized_out);
     return enc_out_bwd_t<float>((const float*)Tx, Hfull, s, (const float*)dS, (const float*)dP, (const float*)y, scale, shift,
-                                B, Hk, Wk, (float*)dA, mean, rstd, partial, nblk_out, stream);
+                                B, Hk, Wk, (float*)dA, mean, rstd, partial, nblk_out, stream, fin, finalized_out);
 }
 
 }  // namespace p4c
