@@ -554,13 +554,15 @@ class HalfUNetMI355X(ModelABC, nn.Module):
         # takes it -- the 1x1 data gradient for block 11, enc_out_bwd for blocks 1, 3, 5, 7, 9 -- only y is read again), the data
         # gradient (dA + y in, dX out; pass 2 of the normalisation backward is formed on the way in), the weight gradient
         # (x + dA + y in).  The first convolution's data gradient exists only where the previous state needs one (AR steps > 0).
+        # bf16 flavour: the 1x1 convolution's data gradient, weight gradient and block 11's pass 1 are ONE kernel (out_conv_bwd.hip):
+        # dy + y in, dA out.
         lev = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 0, 0]
         fused_p1 = {11, 1, 3, 5, 7, 9}
-        nbwd = sum((1 if i in fused_p1 else 2) * M * q[lev[i]] for i in range(12))
+        nbwd = sum((0 if (i == 11 and esz == 2) else 1 if i in fused_p1 else 2) * M * q[lev[i]] for i in range(12))
         wgrad = sum((2 * M + (cpad * esz * n0 if i == 0 else M)) * q[lev[i]] for i in range(12))
         dgrad_rest = sum(3 * M * q[lev[i]] for i in range(1, 12))
         bwd = {
-            "conv 1x1: data gradient (dy in, dA out) + weight gradient (y + dy)": 2 * M + 2 * M,
+            "conv 1x1: data gradient (dy in, dA out) + weight gradient (y + dy)": 3 * M if esz == 2 else 2 * M + 2 * M,
             "normalisation backward, pass 1 (12 blocks)": nbwd,
             "conv 3x3 data gradients (blocks 1..11)": dgrad_rest,
             "conv 3x3 weight gradients (12 blocks)": wgrad,
