@@ -715,6 +715,17 @@ __global__ void __launch_bounds__(256)
     const float* forc = xn ? nx.forcing + (int64_t)b * nx.forcing_bs : nullptr;
     const int yslots = y_cs * (int)sizeof(TY) / 16, xslots = xn ? nx.c_pad * (int)sizeof(TY) / 16 : 0;
     const int64_t ntiles = (N + FLAT_P - 1) / FLAT_P;
+    // statics / forcing rows as flat 16-byte streams (whole tiles start on 16-byte boundaries; <= 64 channels each for the
+    // multiply-shift division); otherwise a lane per channel
+    const bool tail_flat = xn && nx.Fs > 0 && nx.Ff > 0 && nx.Fs <= 64 && nx.Ff <= 64 && nx.statics_bs % 4 == 0 && nx.forcing_bs % 4 == 0 &&
+                           (reinterpret_cast<uintptr_t>(nx.statics) & 15) == 0 && (reinterpret_cast<uintptr_t>(nx.forcing) & 15) == 0 &&
+                           (N * nx.Fs) % 4 == 0 && (N * nx.Ff) % 4 == 0;
+    const unsigned rcp_s = tail_flat ? ((1u << 20) + nx.Fs - 1) / nx.Fs : 0u, rcp_f = tail_flat ? ((1u << 20) + nx.Ff - 1) / nx.Ff : 0u;
+    if (tail_flat)   // the zero padding beyond the forcing channels: laid once, never written again
+        for (int i = tid; i < FLAT_P * (nx.c_pad - F - nx.Fs - nx.Ff); i += 256) {
+            const int w = nx.c_pad - F - nx.Fs - nx.Ff, pl = i / w;
+            xtile[pl * nx.c_pad + F + nx.Fs + nx.Ff + (i - pl * w)] = from_f32<TY>(0.f);
+        }
     float acc = 0.f;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int64_t n0 = t * FLAT_P;
@@ -729,7 +740,30 @@ __global__ void __launch_bounds__(256)
             msk[64 + tid] = (ok && border_mask) ? border_mask[n0 + tid] : 0.f;
         }
         // ---- the next input's channels F .. c_pad - 1: statics | next forcing | zeros (lightning.py:760-765)
-        if (xn) {
+        if (xn && tail_flat) {
+            // statics and forcing streamed FLAT like the state (16 bytes per lane; the zero padding was laid once, above)
+            const int nst = np * nx.Fs, nfo = np * nx.Ff;
+            for (int e0 = 4 * tid; e0 < nst; e0 += 4 * 256) {
+                const v4f v = *reinterpret_cast<const v4f*>(stat + n0 * nx.Fs + e0);
+                int pl, f;
+                flat_pf(e0, nx.Fs, rcp_s, pl, f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (e0 + j < nst) xtile[pl * nx.c_pad + F + f] = from_f32<TY>(v[j]);
+                    if (++f == nx.Fs) { f = 0; ++pl; }
+                }
+            }
+            for (int e0 = 4 * tid; e0 < nfo; e0 += 4 * 256) {
+                const v4f v = *reinterpret_cast<const v4f*>(forc + n0 * nx.Ff + e0);
+                int pl, f;
+                flat_pf(e0, nx.Ff, rcp_f, pl, f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (e0 + j < nfo) xtile[pl * nx.c_pad + F + nx.Fs + f] = from_f32<TY>(v[j]);
+                    if (++f == nx.Ff) { f = 0; ++pl; }
+                }
+            }
+        } else if (xn) {
             const int ntail = nx.c_pad - F;
             for (int pl = tid >> 6; pl < np; pl += 4)          // a wave per grid point, a lane per channel: no divisions
                 for (int c = tid & 63; c < ntail; c += 64) {
