@@ -681,23 +681,71 @@ __device__ __forceinline__ void flat_pf(int e, int F, unsigned rcp, int& pl, int
     f = e - pl * F;
 }
 
-template <typename TY>
+// FRONT (bf16 rows only): the y tile is not read from memory but FORMED -- the network's 1x1 output convolution on relu(norm(a)) runs on
+// the matrix cores at the head of every tile (the front end of out_conv_update_loss_fwd_kernel below: the same MFMA chain per element
+// as the convolution's own launch, one rounding to bf16), so y is never written and read back for feature counts off the 16-byte grid
+// either (the shipped Titan configuration: F = 21).  A wave = 32 grid points x 32 output features; the tile's 8-byte slots are XOR-ed
+// with the grid-point index like that kernel's.
+struct FlatFront {
+    const bf16* a;            // (B,N,64) bf16: raw output of the network's last block
+    const float* a_scale;     // (B,64) each
+    const float* a_shift;
+    const float* wout;        // (cout,64) fp32
+    int cout;
+};
+typedef float ff_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ff_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ff_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ff_bf16x2 __attribute__((ext_vector_type(2)));
+typedef short ff_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int ff_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int ff_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int ff_pack(float lo, float hi) {
+    const ff_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, ff_bf16x2));
+}
+
+template <typename TY, bool FRONT = false>
 __global__ void __launch_bounds__(256)
     ar_update_loss_fwd_flat_kernel(const float* __restrict__ prev, int64_t prev_bs, const TY* __restrict__ y, int y_cs,
                                    const float* __restrict__ target, int64_t tgt_bs, const float* __restrict__ std,
                                    const float* __restrict__ mean, const float* __restrict__ border_mask,
                                    const float* __restrict__ interior_mask, float* __restrict__ new_state, int64_t new_bs,
                                    const float* __restrict__ weights, int kind, float* __restrict__ partial, int64_t N, int F,
-                                   float keep_prev, NextX nx) {
+                                   float keep_prev, NextX nx, FlatFront fa) {
+    static_assert(!FRONT || std::is_same<TY, bf16>::value, "the fused front end forms bf16 rows");
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     // LDS: y tile [64][y_cs] | x tile [64][c_pad] (next input, if any) | per-feature constants 3 x 64 floats | masks 2 x 64 floats
+    //      | FRONT: A fragments of the 1x1 weight 2 x 4 x 64 x 16 bytes | the sample's scale, shift 2 x 64 floats
     TY* ytile = reinterpret_cast<TY*>(fsm);
     TY* xtile = ytile + FLAT_P * y_cs;
     float* cst = reinterpret_cast<float*>(xtile + (nx.x ? FLAT_P * nx.c_pad : 0));
     float* msk = cst + 3 * 64;
+    ff_bf16x8* wimg = reinterpret_cast<ff_bf16x8*>(msk + 2 * 64);
+    float* lsc = reinterpret_cast<float*>(wimg + 2 * 4 * 64);
+    float* lsh = lsc + 64;
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.y;
+    if (FRONT) {
+        for (int t = tid; t < 2 * 4 * 64; t += 256) {   // (T, ks, lane) = W[32 T + (l & 31)][16 ks + 8 (l >> 5) .. + 7]
+            const int l = t & 63, ks = (t >> 6) & 3, T = t >> 8;
+            const int co = 32 * T + (l & 31), k0 = 16 * ks + 8 * (l >> 5);
+            v4f lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+            if (co < fa.cout) {
+                lo = *reinterpret_cast<const v4f*>(fa.wout + (int64_t)co * 64 + k0);
+                hi = *reinterpret_cast<const v4f*>(fa.wout + (int64_t)co * 64 + k0 + 4);
+            }
+            ff_bf16x8 w8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w8[j] = (__bf16)lo[j]; w8[4 + j] = (__bf16)hi[j]; }
+            wimg[t] = w8;
+        }
+        if (tid < 64) {
+            lsc[tid] = fa.a_scale[b * 64 + tid];
+            lsh[tid] = fa.a_shift[b * 64 + tid];
+        }
+    }
     const unsigned rcp = ((1u << 20) + F - 1) / F;
     if (tid < 64) {
         const bool ok = tid < F;
@@ -732,8 +780,52 @@ __global__ void __launch_bounds__(256)
         const int np = (int)((N - n0) < FLAT_P ? (N - n0) : FLAT_P);
         __syncthreads();   // (the previous tile's rows are out; the constants are in)
         // ---- stage: y rows (whole rows, 16-byte slots), the masks of the tile's grid points
-        for (int sl = tid; sl < np * yslots; sl += 256)
-            reinterpret_cast<norm4u*>(ytile)[sl] = reinterpret_cast<const norm4u*>(yb + n0 * y_cs)[sl];
+        if (FRONT) {
+            // y^T = W relu(norm(a))^T for this wave's 32 grid points x 32 features (the first trip's barrier above covers wimg / lsc)
+            const int r = lane & 31, h = lane >> 5, pb = wv & 1, T = wv >> 1;
+            if (32 * T < fa.cout) {
+                const int64_t pn = n0 + 32 * pb + r;
+                const bf16* ab = fa.a + (int64_t)b * N * 64;
+                ff_u32x4 cur[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    cur[ks] = ff_u32x4{0u, 0u, 0u, 0u};
+                    if (pn < N) cur[ks] = *reinterpret_cast<const ff_u32x4*>(ab + pn * 64 + 16 * ks + 8 * h);
+                }
+                ff_f32x16 yy;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) yy[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const v4f s0 = *reinterpret_cast<const v4f*>(lsc + 16 * ks + 8 * h), s1 = *reinterpret_cast<const v4f*>(lsc + 16 * ks + 8 * h + 4);
+                    const v4f t0 = *reinterpret_cast<const v4f*>(lsh + 16 * ks + 8 * h), t1 = *reinterpret_cast<const v4f*>(lsh + 16 * ks + 8 * h + 4);
+                    const float scv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                    const float shv[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                    ff_u32x4 o;
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; ++k2) {
+                        // relu(a * scale + shift), fp32, one rounding to bf16: what the 1x1 convolution's loader stages (conv_rows.hip: xform2<2>)
+                        const unsigned int wd = cur[ks][k2];
+                        const float lo = __builtin_fmaf(__builtin_bit_cast(float, wd << 16), scv[2 * k2], shv[2 * k2]);
+                        const float hi = __builtin_fmaf(__builtin_bit_cast(float, wd & 0xffff0000u), scv[2 * k2 + 1], shv[2 * k2 + 1]);
+                        const ff_s16x2 z = {0, 0};
+                        o[k2] = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(ff_s16x2, ff_pack(lo, hi)), z));
+                    }
+                    yy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wimg[(T * 4 + ks) * 64 + lane], __builtin_bit_cast(ff_bf16x8, o), yy, 0, 0, 0);
+                }
+                // C[feature][point]: lane = point r (+ half h), register quad gq -> features 32 T + 8 gq + 4 h .. + 3
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    ff_u32x2 o;
+                    o[0] = ff_pack(yy[4 * gq], yy[4 * gq + 1]);
+                    o[1] = ff_pack(yy[4 * gq + 2], yy[4 * gq + 3]);
+                    *reinterpret_cast<ff_u32x2*>(reinterpret_cast<bf16*>(ytile) + (32 * pb + r) * 64 + 4 * ((8 * T + 2 * gq + h) ^ (r & 15))) = o;
+                }
+            }
+        } else {
+            for (int sl = tid; sl < np * yslots; sl += 256)
+                reinterpret_cast<norm4u*>(ytile)[sl] = reinterpret_cast<const norm4u*>(yb + n0 * y_cs)[sl];
+        }
         if (tid < 64) {
             const bool ok = tid < np;
             msk[tid] = ok ? interior_mask[n0 + tid] : 0.f;
@@ -786,7 +878,7 @@ __global__ void __launch_bounds__(256)
             v4f o, lg;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float yv = to_f32<TY>(ytile[pl * y_cs + f]);
+                const float yv = to_f32<TY>(FRONT ? ytile[pl * 64 + 4 * ((f >> 2) ^ (pl & 15)) + (f & 3)] : ytile[pl * y_cs + f]);
                 const float im = msk[pl], bm = msk[64 + pl];
                 const float p0 = pv[j], t0 = tg[j];
                 float pr;
@@ -1262,12 +1354,12 @@ static int ar_update_loss_fwd_impl(const float* prev, int64_t prev_bs, const voi
                 P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_fwd_flat_kernel<float>, (int)smem));
                 hipLaunchKernelGGL(ar_update_loss_fwd_flat_kernel<float>, dim3(nblk, B), dim3(256), smem, as_stream(stream), prev, prev_bs,
                                    (const float*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs, weights,
-                                   kind, (float*)workspace, N, F, keep_prev, nx);
+                                   kind, (float*)workspace, N, F, keep_prev, nx, FlatFront{});
             } else {
                 P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_fwd_flat_kernel<bf16>, (int)smem));
                 hipLaunchKernelGGL(ar_update_loss_fwd_flat_kernel<bf16>, dim3(nblk, B), dim3(256), smem, as_stream(stream), prev, prev_bs,
                                    (const bf16*)y, y_cs, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs, weights,
-                                   kind, (float*)workspace, N, F, keep_prev, nx);
+                                   kind, (float*)workspace, N, F, keep_prev, nx, FlatFront{});
             }
             P4C_CHECK_LAUNCH("p4c_ar_update_loss_fwd(flat)");
             hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const float*)workspace, nblk,
@@ -1570,8 +1662,34 @@ extern "C" int p4c_out_conv_update_loss_fwd(const void* a, const float* a_scale,
                   "p4c_out_conv_update_loss_fwd: null pointer");
     P4C_CHECK_ARG(prev || keep_prev == 0.0f, "p4c_out_conv_update_loss_fwd: prev is null but keep_prev != 0");
     P4C_CHECK_ARG((std == nullptr) == (mean == nullptr), "p4c_out_conv_update_loss_fwd: std and mean go together");
-    P4C_CHECK_ARG(cout >= F && cout <= 64 && F > 0 && F % 4 == 0, "p4c_out_conv_update_loss_fwd: needs F <= cout <= 64, F a multiple of 4");
+    P4C_CHECK_ARG(cout >= F && cout <= 64 && F > 0, "p4c_out_conv_update_loss_fwd: needs 0 < F <= cout <= 64");
     P4C_CHECK_ARG(aligned16(a) && aligned16(wout), "p4c_out_conv_update_loss_fwd: a and wout must be 16-byte aligned");
+    if (F % 4 != 0 || force_flat()) {
+        // any feature count: the flat AR-step kernel with the convolution as its front end (conditions of the flat path)
+        bool ok = flat_ok(F, N, 64, 2) && prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 && aligned16(prev) && aligned16(target) &&
+                  aligned16(new_state);
+        if (ok && x_next) ok = statics && forcing_next && (c_pad * 2) % 16 == 0 && c_pad <= 256 && c_pad >= F + Fs + Ff && aligned16(x_next);
+        if (ok && lgrad) ok = lgrad_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(lgrad) & 7) == 0;
+        if (!ok)
+            return fail(P4C_ERR_UNSUPPORTED, "p4c_out_conv_update_loss_fwd: F %% 4 != 0 needs the flat path (F <= 64, N * F %% 4 == 0, whole 16-byte "
+                                             "slots per row of x_next, aligned rows)");
+        const NextX nx{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff, lgrad, lgrad_bs};
+        const FlatFront fa{(const bf16*)a, a_scale, a_shift, wout, cout};
+        const int64_t ntiles = (N + FLAT_P - 1) / FLAT_P;
+        int nblk = loss_blocks(N, FLAT_P / 4, B);
+        if (nblk > ntiles) nblk = (int)ntiles;
+        const size_t smem = (size_t)FLAT_P * 64 * 2 + (x_next ? (size_t)FLAT_P * c_pad * 2 : 0) + 5 * 64 * sizeof(float) + 2 * 4 * 64 * 16 +
+                            2 * 64 * sizeof(float);
+        P4C_TRY(ensure_dyn_smem((const void*)ar_update_loss_fwd_flat_kernel<bf16, true>, (int)smem));
+        hipLaunchKernelGGL((ar_update_loss_fwd_flat_kernel<bf16, true>), dim3(nblk, B), dim3(256), smem, as_stream(stream), prev, prev_bs,
+                           (const bf16*)nullptr, 64, target, tgt_bs, std, mean, border_mask, interior_mask, new_state, new_bs, weights, kind,
+                           (float*)workspace, N, F, keep_prev, nx, fa);
+        P4C_CHECK_LAUNCH("p4c_out_conv_update_loss_fwd(flat)");
+        hipLaunchKernelGGL(weighted_loss_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const float*)workspace, nblk, num_interior,
+                           masked_count, loss_out, loss_stride, B);
+        P4C_CHECK_LAUNCH("p4c_out_conv_update_loss_fwd(final)");
+        return P4C_OK;
+    }
     P4C_CHECK_ARG(prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 && aligned16(prev) && aligned16(target) && aligned16(new_state) &&
                       aligned16(weights) && aligned16(std) && aligned16(mean),
                   "p4c_out_conv_update_loss_fwd: rows must be 16-byte aligned (as p4c_ar_update_loss_fwd_next)");

@@ -659,8 +659,9 @@ class _NativeRolloutFn(torch.autograd.Function):
         lgrads = torch.empty(T, B, N, F, dtype=torch.bfloat16, device=dev) if save_lg else None
         # bf16 flavour: the network's 1x1 output convolution runs INSIDE the AR step's kernel (p4c_out_conv_update_loss_fwd: y is
         # never written and read back, one launch less per AR step; same new state bit for bit; P4C_FUSED_TAIL=0: the two-kernel route)
-        fused_tail = (adt == torch.bfloat16 and v4_next and mask_mode == L.MASK_NONE and model.out_channels >= F
-                      and os.environ.get("P4C_FUSED_TAIL", "1") != "0")
+        # (feature counts off the 16-byte grid: the flat kernel takes the convolution as its front end)
+        fused_tail = (adt == torch.bfloat16 and (v4_next or (flat_next and F % 4 != 0)) and mask_mode == L.MASK_NONE
+                      and model.out_channels >= F and os.environ.get("P4C_FUSED_TAIL", "1") != "0")
         desc_fwd = desc
         if fused_tail:
             desc_fwd = HalfUNetDesc.from_buffer_copy(desc)

@@ -27,6 +27,12 @@ def rel_err(got, ref):
     (2, 32, 64, 60, 4, 5, 96, 0, False, True, False, True),      # no border forcing, last AR step (no next input)
     (3, 21, 37, 20, 4, 8, 32, 0, True, False, True, False),      # unscaled update (diff_ar), c_pad 32, no saved gradients
     (2, 64, 64, 32, 0, 0, 32, 1, True, True, True, True),        # nothing but the state in the next input
+    # feature counts off the 16-byte grid: the flat AR-step kernel with the convolution as its front end (round 4)
+    (2, 64, 80, 21, 4, 21, 64, 0, True, True, True, True),       # the shipped Titan feature counts (C_in = 46 -> 64)
+    (1, 8, 125, 21, 4, 21, 64, 1, True, True, True, True),       # N = 1000: a partial last tile; L1
+    (2, 27, 76, 5, 3, 2, 32, 0, False, True, False, True),       # odd static / forcing counts, no border forcing, last AR step
+    (3, 16, 16, 13, 0, 0, 32, 0, True, False, True, False),      # unscaled update, nothing but the state in the next input
+    (2, 32, 64, 62, 1, 1, 64, 0, True, True, True, True),        # rows nearly full: both feature halves of the front end
 ])
 def test_fused_output_conv_and_ar_step_vs_two_kernels(gpu_device, B, H, W, F, Fs, Ff, cpad, kind, border, scaled, nxt, lg):
     from py4cast_amd import _lib as L
@@ -88,16 +94,16 @@ def test_fused_output_conv_and_ar_step_vs_two_kernels(gpu_device, B, H, W, F, Fs
 
 
 @pytest.mark.parametrize("losses", [MSE, L1])
-@pytest.mark.parametrize("H,W", [(64, 96), (48, 80)])
-def test_rollout_with_the_fused_tail_equals_the_two_kernel_route(gpu_device, monkeypatch, losses, H, W):
+@pytest.mark.parametrize("H,W,F,Ff", [(64, 96, 60, 5), (48, 80, 60, 5), (64, 80, 21, 21)])
+def test_rollout_with_the_fused_tail_equals_the_two_kernel_route(gpu_device, monkeypatch, losses, H, W, F, Ff):
     """HalfUNet bf16 training step through the native rollout: P4C_FUSED_TAIL=1 (default) vs 0 -- predictions equal bit for bit, the
     loss to summation order, and therefore the parameter gradients bit for bit as well (the saved loss gradients are the same bits);
     also the no-grad (validation) rollout."""
     import bench
     from py4cast_amd.lightning import AutoRegressiveLightning
 
-    case = bench.synthetic_case(91, 2, 3, 1, H, W, 60, 5, 4, 4, gpu_device)
-    info = bench.make_info(case, 5)
+    case = bench.synthetic_case(91, 2, 3, 1, H, W, F, Ff, 4, 4, gpu_device)
+    info = bench.make_info(case, Ff)
     res = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("P4C_FUSED_TAIL", mode)
