@@ -1,6 +1,6 @@
 """Summarise the separate `rocprofv3 --pmc <group> --kernel-trace --output-format csv` passes of tools/diagnostics/conv_exp.py into
 the per-launch figures kept as profiles/rNN_pmc_traffic.json, and keep the raw counter rows of the roofline kernel.
-usage: python tools/diagnostics/pmc_summary.py <dir with pmc_<GROUP>/ sub-directories> <kernel substring> <out.json> <raw rows dir>
+usage: python tools/diagnostics/pmc_summary.py <dir with pmc_<GROUP>/ sub-directories> <kernel substring> <out.json> <raw rows dir> [algorithmic bytes per launch]
 FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 32-B requests as 64-B units for 16-B/lane streaming reads and is doubled
 (MI355X_MICROARCH.md, HBM section)."""
 import csv
@@ -39,7 +39,7 @@ allf = [x for v in vals.get("FETCH_SIZE", {}).values() for x in v]
 allw = [x for v in vals.get("WRITE_SIZE", {}).values() for x in v]
 if allf and allw:
     hbm = (2.0 * mean(allf) + mean(allw)) * 1024
-    alg = 2.0 * 64 * 2 * 2 * 512 * 512
+    alg = float(sys.argv[5]) if len(sys.argv) > 5 else 2.0 * 64 * 2 * 2 * 512 * 512
     res[kern] = {"FETCH_SIZE_KiB": mean(allf), "WRITE_SIZE_KiB": mean(allw), "hbm_bytes_per_launch": round(hbm),
                  "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 3)}
 busy, act = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", {}), vals.get("GRBM_GUI_ACTIVE", {})
