@@ -68,8 +68,8 @@ constexpr int SROW = SW * 128;         // one staged output row
 constexpr int NS = 8;
 constexpr int STGB = NS * SROW;
 constexpr int ROWSLOTS = LW * 8;       // 16-byte slots per input row
-constexpr int NLD = 9;                 // slots per loader lane and interval: 4 rows x 528 = 2112 <= 9 x 256
-constexpr int NST = 8;                 // output slots per loader lane and interval: 4 rows x 512 = 8 x 256
+// (per loader lane and interval of IV rows -- IV = 4, or 2 where both normalisation-backward roles share a launch: input slots
+//  NLD = ceil(IV x 528 / 256) = 9 | 5, output slots NST = IV x 512 / 256 = 8 | 4: constants of the kernel)
 // LDS layout of an input pixel, by MFMA shape (MF = 32: v_mfma_f32_32x32x16_bf16, MF = 16: v_mfma_f32_16x16x32_bf16):
 //   MF 32: 144 bytes (64 bf16 channels + 16 B pad): a B operand is `row base + immediate`; the 16 pixels of a ds_read_b128
 //          service group (one channel slice) fall in 16 different bank quads;
@@ -278,11 +278,17 @@ __device__ __forceinline__ T late_arg(size_t offset) {
 // CPT ("compact channels", plain launches only): the input has in_cs <= 64 channels per pixel and the output out_cs <= 64 (multiples
 // of 8) -- channel slots beyond them are loaded as zeros / not stored, so a 24- or 48-channel feature map is convolved in place
 // instead of through a zero-padded 64-channel copy and a sliced 64-channel result (SwinUNetR's decoder levels).
-template <int MODE, bool BST, int MF, int KS, bool CPT = false>
+// IV: input rows per interval (one workgroup barrier each).  4 everywhere but in the launch that takes BOTH normalisation-backward roles
+// (MODE 4 + BST: pass 2 of this block's on the way in, pass 1 of the next one's in the drain): its loader would hold 72 registers of
+// prefetched dA / y rows + 64 of output / y rows for the drain -- 137 spilled registers; with two rows per interval the images are
+// half that and the kernel has none (240 registers).
+template <int MODE, bool BST, int MF, int KS, bool CPT = false, int IV = 4>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     conv3x3_bf16_rows_kernel(RowsArgs args) {
     static_assert(!CPT || (MODE == 0 && !BST && MF == 32), "compact channels: plain launches only");
+    static_assert(IV == 4 || IV == 2, "rows per interval");
     using namespace rows;
+    constexpr int NLD = (IV * ROWSLOTS + 255) / 256, NST = IV * 2;
     const __bf16* __restrict__ in = args.in;
     const __bf16* __restrict__ wp = args.wp;
     const float* __restrict__ in_scale = args.in_scale;
@@ -308,7 +314,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int y0 = seg * rows_lo + (seg < rows_rem ? seg : rows_rem);
     const int R = rows_lo + (seg < rows_rem ? 1 : 0);          // >= 2 (host)
     const int x0 = strip * SW;
-    const int K = (R + 5) >> 2;                                // intervals of four input rows: ceil((R + 2) / 4)
+    const int K = (R + 2 + IV - 1) / IV;                       // intervals of IV input rows: ceil((R + 2) / IV)
 
     if (wv >= 4) {
         // ------------------------------------------------------------ memory side
@@ -375,9 +381,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const __amdgpu_buffer_rsrc_t rs_nby = make_rsrc(MODE == 4 ? reinterpret_cast<const __bf16*>(nb.y) + (int64_t)b * H * W * 64 : in,
                                                         (unsigned int)H * W * 128u);
         auto load = [&](Img& im, int k) __attribute__((always_inline)) {
-            const int m0 = 4 * k;
+            const int m0 = IV * k;
             int nrows = R + 2 - m0;
-            nrows = nrows > 4 ? 4 : (nrows < 0 ? 0 : nrows);
+            nrows = nrows > IV ? IV : (nrows < 0 ? 0 : nrows);
             if ((P4C_EXP & 2) && k > 1) nrows = 0;
             const int nact = nrows * ROWSLOTS;
             const int gy0 = y0 - 1 + m0, gx0 = x0 - 1;
@@ -403,9 +409,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         };
         auto store = [&](const Img& im, int k) __attribute__((always_inline)) {
-            const int m0 = 4 * k;
+            const int m0 = IV * k;
             int nrows = R + 2 - m0;
-            nrows = nrows > 4 ? 4 : (nrows < 0 ? 0 : nrows);
+            nrows = nrows > IV ? IV : (nrows < 0 ? 0 : nrows);
             if ((P4C_EXP & 1) && k > 1) nrows = 0;
             const int nact = nrows * ROWSLOTS;
             char* dst = lring + (m0 & 7) * RROW;
@@ -460,8 +466,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(BST ? reinterpret_cast<const __bf16*>(bst.y) + (int64_t)b * H * W * 64 : in,
                                                       (unsigned int)H * W * 128u);
         auto yload = [&](int k) __attribute__((always_inline)) {   // y rows of the group drain(k) handles
-            const int n0 = 4 * k - 6;
-            if (n0 >= 0 && n0 + 4 <= R && x0 + SW <= W) {
+            const int n0 = IV * k - IV - 2;
+            if (n0 >= 0 && n0 + IV <= R && x0 + SW <= W) {
                 const int so = ((y0 + n0) * W + x0) * 128;
 #pragma unroll
                 for (int j = 0; j < NST; ++j) yq[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, dofs[j], so, 0);
@@ -475,14 +481,14 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
         };
-        // drain(k): the four output rows 4k-6 .. 4k-3 the compute waves staged during interval k-1
+        // drain(k): the IV output rows IV (k-1) - 2 .. the compute waves staged during interval k-1 (IV = 4: rows 4k-6 .. 4k-3)
         auto drain = [&](int k) __attribute__((always_inline)) {
-            const int n0 = 4 * k - 6;
-            const char* stg = lstg + (((k - 1) & 1) * 4) * SROW;
+            const int n0 = IV * k - IV - 2;
+            const char* stg = lstg + ((IV * (k - 1)) & 7) * SROW;
             u32x4 v[NST];
 #pragma unroll
             for (int j = 0; j < NST; ++j) v[j] = *reinterpret_cast<const u32x4*>(stg + sofs[j]);
-            if (n0 >= 0 && n0 + 4 <= R && x0 + SW <= W) {
+            if (n0 >= 0 && n0 + IV <= R && x0 + SW <= W) {
                 const int so = ((y0 + n0) * W + x0) * out_cs * 2;
 #pragma unroll
                 for (int j = 0; j < NST; ++j)
@@ -691,7 +697,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
             prev = cur;
-            if (m == last || (m & 3) == 3) lds_barrier();
+            if (m == last || (m & (IV - 1)) == IV - 1) lds_barrier();
         }
     } else if constexpr (MF == 32) {
         bf16x8 A[9][4];
@@ -723,7 +729,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         issue3(rbase(0));
 #define P4C_ROW(HP, HQ, HS, P, Q, S)                                                                                        \
     {                                                                                                                       \
-        const bool pf = ((m & 3) != 3) && (m != last);                                                                      \
+        const bool pf = ((m & (IV - 1)) != IV - 1) && (m != last);                                                          \
         if (wv == 0) P4C_STAMP_ROW(300 + 2 * m);                                                                            \
         conv_row<HP, HQ, HS>(A, P, Q, S, fb, rbase(m), rbase(m + 1), pf, lstg + (m & 7) * SROW, soff);                     \
         if (wv == 0) P4C_STAMP_ROW(301 + 2 * m);                                                                            \
@@ -731,7 +737,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             P4C_STAMP(700 + 8 * (m >> 2) + 2 * wv);                                                                         \
             lds_barrier();                                                                                                  \
             P4C_STAMP(701 + 8 * (m >> 2) + 2 * wv);                                                                         \
-        } else if ((m & 3) == 3) {                                                                                          \
+        } else if ((m & (IV - 1)) == IV - 1) {                                                                              \
             P4C_STAMP(700 + 8 * (m >> 2) + 2 * wv);                                                                         \
             lds_barrier();                                                                                                  \
             P4C_STAMP(701 + 8 * (m >> 2) + 2 * wv);                                                                         \
@@ -799,7 +805,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         issue3();
 #define P4C_ROW(HP, HQ, HS, P, Q, S)                                                                                        \
     {                                                                                                                       \
-        const bool pf = ((m & 3) != 3) && (m != last);                                                                      \
+        const bool pf = ((m & (IV - 1)) != IV - 1) && (m != last);                                                          \
         const int delta = (m & 7) == 7 ? -7 * RROW : RROW;                                                                  \
         if (wv == 0) P4C_STAMP_ROW(300 + 2 * m);                                                                            \
         conv_row16<HP, HQ, HS>(A, P, Q, S, fb, boff, delta, pf, lring, lstg + (m & 7) * SROW, soff);                        \
@@ -808,7 +814,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             P4C_STAMP(700 + 8 * (m >> 2) + 2 * wv);                                                                         \
             lds_barrier();                                                                                                  \
             P4C_STAMP(701 + 8 * (m >> 2) + 2 * wv);                                                                         \
-        } else if ((m & 3) == 3) {                                                                                          \
+        } else if ((m & (IV - 1)) == IV - 1) {                                                                              \
             P4C_STAMP(700 + 8 * (m >> 2) + 2 * wv);                                                                         \
             lds_barrier();                                                                                                  \
             P4C_STAMP(701 + 8 * (m >> 2) + 2 * wv);                                                                         \
@@ -843,14 +849,14 @@ static int rows_mfma_shape() {   // 32 (default): v_mfma_f32_32x32x16_bf16; P4C_
     return (e && atoi(e) == 16) ? 16 : 32;
 }
 
-template <int MODE, bool BST, int KS>
+template <int MODE, bool BST, int KS, int IV = 4>
 int launch_rows_mode(const __bf16* in, const __bf16* wp, const float* in_scale, const float* in_shift, __bf16* out, int out_cs,
                      float* stat_partial, int B, int H, int W, int nstrips, int nseg, hipStream_t stream, const BatchFin& fin,
                      const RingBwdStats& bst, const NormBwdCoef& nb = NormBwdCoef{}) {
     const RowsArgs args{in, wp, in_scale, in_shift, out, stat_partial, out_cs, H, W, H / nseg, H % nseg, fin.slots ? 1 : 0, 64, bst, nb, fin};
     if (KS == 1 || MODE == 4 || rows_mfma_shape() == 32) {
-        P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>, rows::Lay<32>::SMEM));
-        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32, KS>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream, args);
+        P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<MODE, BST, 32, KS, false, IV>, rows::Lay<32>::SMEM));
+        hipLaunchKernelGGL((conv3x3_bf16_rows_kernel<MODE, BST, 32, KS, false, IV>), dim3(nseg, nstrips, B), dim3(512), rows::Lay<32>::SMEM, stream, args);
     } else if (KS == 3 && MODE != 4) {
         constexpr int M16 = MODE == 4 ? 0 : MODE;   // (MODE 4 never takes this branch: keeps the instantiation list short)
         P4C_TRY(ensure_dyn_smem((const void*)conv3x3_bf16_rows_kernel<M16, BST, 16, 3>, rows::Lay<16>::SMEM));
@@ -865,7 +871,8 @@ int launch_rows_ks(const __bf16* in, const __bf16* wp, const float* in_scale, co
                    const RingBwdStats* bst, const NormBwdCoef* nb) {
     if (nb && KS == 3) {   // the operand is g and y of a normalisation backward: dY is formed while the rows are staged
         constexpr int M = KS == 3 ? 4 : 0;
-        if (bst) return fail(P4C_ERR_UNSUPPORTED, "conv_bf16_rows: NormBwdCoef and RingBwdStats in one launch exceed the register file");
+        // both roles in one launch: two rows per interval (half-size loader images: see the kernel's IV)
+        if (bst) return launch_rows_mode<M, true, KS, 2>(in, wp, nullptr, nullptr, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, *bst, *nb);
         return launch_rows_mode<M, false, KS>(in, wp, nullptr, nullptr, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, RingBwdStats{}, *nb);
     }
     if (bst) return launch_rows_mode<0, true, KS>(in, wp, nullptr, nullptr, out, out_cs, stat_partial, B, H, W, nstrips, nseg, stream, fin, *bst);

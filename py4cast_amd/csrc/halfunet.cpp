@@ -419,10 +419,16 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
         // whose pass 1 (sums of g and g * xhat) the ring / row kernel takes while it stores the gradient rows
         const char* fe = getenv("P4C_NO_FUSED_REDUCE");   // (read per call: the parity test switches it)
         const bool fuse_off = fe && fe[0] == '1';
-        // (round 4 re-tried both roles in one launch with the roles' constants kept in LDS and the drain's tables computed: 137 -> 59
-        // spilled registers, the data-gradient launch 55 -> 120 us, the step 4.79 -> 5.36 ms: the loader's images -- 72 registers of
-        // prefetched dA / y rows plus 32 of y rows for the drain -- are what does not fit, not the constants)
-        const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 && !(nbf && dgrad_takes_pass1) &&
+        // Both roles in one launch -- pass 2 of this block's normalisation backward in the loader, pass 1 of the next block's in the
+        // drain -- do not fit the register file at four rows per interval (137 spilled registers; 59 with the roles' constants in
+        // LDS: 55 -> 120 us per launch, the step 4.79 -> 5.36 ms).  At TWO rows per interval (half-size loader images, no spills:
+        // the row kernel's IV) the launch works -- 70 us at full resolution against 50 + a 35 us norm_bwd_reduce launch, 15 launches
+        // fewer per step -- but the step does not get faster: 4.60 vs 4.61 ms at 2x512x512x60, 4.88 vs 4.82 at the Titan shape
+        // (profiles/r04_step_ab_runs.txt block 20: the weight-gradient stream pays for what the chain saves).  Kept behind
+        // P4C_NB_BST=1, parity-tested both ways (tests/test_bwd_infin_gpu.py).
+        const char* nbe = getenv("P4C_NB_BST");   // (read per call: the parity test switches it)
+        const bool nb_bst = nbe && nbe[0] == '1';
+        const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 && (!(nbf && dgrad_takes_pass1) || nb_bst) &&
                           conv_bf16_bwd_stats_ok(d.dtype, d.B, H, W);
         const RingBwdStats bst{in, in_norm ? in_norm->scale : nullptr, in_norm ? in_norm->shift : nullptr,
                                in_norm ? in_norm->mean : nullptr, in_norm ? in_norm->rstd : nullptr};

@@ -79,3 +79,34 @@ def test_train_mode_step_with_the_in_kernel_finish(gpu_device, monkeypatch, norm
         assert torch.equal(a, b)
     else:
         assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.99, rel_err(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 48, 80), (2, 256, 256), (2, 80, 192), (1, 128, 512)])
+def test_both_normalisation_backward_roles_in_one_data_gradient_launch(gpu_device, monkeypatch, shape):
+    """Round 4: the data-gradient launch of a 64 -> 64 block applies pass 2 of its own normalisation backward in its loader AND takes
+    pass 1 of the next block's in its drain (the row kernel at two rows per interval; csrc/conv_rows.hip: IV; P4C_NB_BST=1 -- measured no
+    faster, so the plan's default is P4C_NB_BST=0: pass 1 as a norm_bwd_reduce launch over dA and y).  Eval-mode BatchNorm: every dA is bit-identical on both routes, d(gamma) / d(beta) are
+    the same sums in another order; train mode: direction check (see tests/test_round2_gpu.py: fused statistics passes)."""
+    B, H, W = shape
+    x = torch.randn(B, H, W, 69, generator=torch.Generator().manual_seed(4)).to(gpu_device)
+    gy = torch.randn(B, H, W, 60, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    model = _model(gpu_device, H, W).eval()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("P4C_NB_BST", mode)
+        res[mode] = _grads(model, x, gy, calls=2)
+    assert torch.equal(res["1"][0], res["0"][0])
+    for n in res["0"][1]:
+        e = rel_err(res["1"][1][n], res["0"][1][n])
+        if "norm" in n:
+            assert e < 2e-5, (n, e)
+        else:
+            assert e == 0.0, (n, e)
+    model.train()
+    for mode in ("1", "0"):
+        monkeypatch.setenv("P4C_NB_BST", mode)
+        res[mode] = _grads(model, x, gy)
+    flat = lambda d: torch.cat([v.flatten() for v in d.values()]).double()
+    a, b = flat(res["1"][1]), flat(res["0"][1])
+    assert torch.isfinite(a).all()
+    assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.98, rel_err(a, b)
