@@ -1664,15 +1664,21 @@ extern "C" int p4c_out_conv_update_loss_fwd(const void* a, const float* a_scale,
     P4C_CHECK_ARG((std == nullptr) == (mean == nullptr), "p4c_out_conv_update_loss_fwd: std and mean go together");
     P4C_CHECK_ARG(cout >= F && cout <= 64 && F > 0, "p4c_out_conv_update_loss_fwd: needs 0 < F <= cout <= 64");
     P4C_CHECK_ARG(aligned16(a) && aligned16(wout), "p4c_out_conv_update_loss_fwd: a and wout must be 16-byte aligned");
-    if (F % 4 != 0 || force_flat()) {
-        // any feature count: the flat AR-step kernel with the convolution as its front end (conditions of the flat path)
-        bool ok = flat_ok(F, N, 64, 2) && prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 && aligned16(prev) && aligned16(target) &&
-                  aligned16(new_state);
-        if (ok && x_next) ok = statics && forcing_next && (c_pad * 2) % 16 == 0 && c_pad <= 256 && c_pad >= F + Fs + Ff && aligned16(x_next);
-        if (ok && lgrad) ok = lgrad_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(lgrad) & 7) == 0;
-        if (!ok)
+    // The flat AR-step kernel with the convolution as its front end serves ANY feature count -- and where both forms apply it is the
+    // faster one (2 x 512 x 512 x 60: 127 against 138 us per launch, profiles/r04_step_ab_runs.txt block 21; same bits) -- so the
+    // 16-byte form below is what is left when the flat path's conditions fail.  P4C_TAIL_V4=1: prefer the 16-byte form (A/B).
+    bool flat_possible = flat_ok(F, N, 64, 2) && prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 && aligned16(prev) && aligned16(target) &&
+                         aligned16(new_state);
+    if (flat_possible && x_next) flat_possible = statics && forcing_next && (c_pad * 2) % 16 == 0 && c_pad <= 256 && c_pad >= F + Fs + Ff && aligned16(x_next);
+    if (flat_possible && lgrad) flat_possible = lgrad_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(lgrad) & 7) == 0;
+    const char* tv4 = getenv("P4C_TAIL_V4");
+    const bool prefer_v4 = tv4 && tv4[0] == '1' && !force_flat();
+    if (F % 4 != 0 || force_flat() || (flat_possible && !prefer_v4)) {
+        const bool ok = flat_possible;
+        if (!ok && F % 4 != 0)
             return fail(P4C_ERR_UNSUPPORTED, "p4c_out_conv_update_loss_fwd: F %% 4 != 0 needs the flat path (F <= 64, N * F %% 4 == 0, whole 16-byte "
                                              "slots per row of x_next, aligned rows)");
+        if (ok) {
         const NextX nx{x_next, c_pad, statics, statics_bs, Fs, forcing_next, forcing_bs, Ff, lgrad, lgrad_bs};
         const FlatFront fa{(const bf16*)a, a_scale, a_shift, wout, cout};
         const int64_t ntiles = (N + FLAT_P - 1) / FLAT_P;
@@ -1689,6 +1695,7 @@ extern "C" int p4c_out_conv_update_loss_fwd(const void* a, const float* a_scale,
                            masked_count, loss_out, loss_stride, B);
         P4C_CHECK_LAUNCH("p4c_out_conv_update_loss_fwd(final)");
         return P4C_OK;
+        }
     }
     P4C_CHECK_ARG(prev_bs % 4 == 0 && tgt_bs % 4 == 0 && new_bs % 4 == 0 && aligned16(prev) && aligned16(target) && aligned16(new_state) &&
                       aligned16(weights) && aligned16(std) && aligned16(mean),

@@ -246,8 +246,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 // workgroups per sample: three per CU over the batch, one tile each at least, within the statistics buffer's slots
 int out_conv_bwd_slots(int B, int64_t N) {
     const int64_t ntiles = (N + ocb::TP - 1) / ocb::TP;
-    int per_cu = 3;
-    if (const char* e = getenv("P4C_OCB_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 8) per_cu = v; }
+    // (read ONCE per process: the workspace layout and every launch must agree on the slot count)
+    static const int per_cu = [] {
+        int v = 3;
+        if (const char* e = getenv("P4C_OCB_PER_CU")) { const int u = atoi(e); if (u > 0 && u <= 8) v = u; }
+        return v;
+    }();
     int64_t n = ((int64_t)num_cus() * per_cu + B - 1) / B;
     if (n > ntiles) n = ntiles;
     if (n > NORM_BWD_MAX_BLOCKS) n = NORM_BWD_MAX_BLOCKS;

@@ -309,6 +309,63 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// build_x for feature counts off the 16-byte grid (round 4; the shipped Titan configuration: 21 features, 4 statics, 21 forcings):
+// the (N, F) / (N, Fs) / (N, Ff) fp32 sources are streamed FLAT, 16 bytes per lane -- a lane's 4 elements may straddle two grid points;
+// (point, channel) of an element by an exact multiply-shift division -- into an LDS tile of 64 rows [c_pad] that goes out as whole rows
+// in 16-byte slots (the scheme of the flat AR-step kernels, losses.hip).  The quad kernel above gathers such rows element by element
+// (122 us at 2 x 512 x 640 x 46 -> 64: 1.6 TB/s).  Same values, bit for bit (a conversion per element, no arithmetic).
+constexpr int BX_P = 64;   // grid points per tile
+__device__ __forceinline__ void bx_pf(int e, int F, unsigned rcp, int& pl, int& f) {   // e < 4096, F <= 64
+    pl = (int)(((unsigned)e * rcp) >> 20);
+    f = e - pl * F;
+}
+typedef unsigned int bx_u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename TX>
+__global__ void __launch_bounds__(256)
+    build_x_flat_kernel(const float* __restrict__ prev, int64_t prev_bs, int64_t prev_ts, const float* __restrict__ statics,
+                        int64_t statics_bs, const float* __restrict__ forcing, int64_t forcing_bs, TX* __restrict__ x, int c_pad,
+                        int T_in, int64_t N, int F, int Fs, int Ff, int n_prev_ch) {
+    extern __shared__ __attribute__((aligned(16))) char bsm[];
+    TX* xtile = reinterpret_cast<TX*>(bsm);
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int c_in = n_prev_ch + Fs + Ff;
+    // the zero padding: laid once, never written again
+    for (int i = tid; i < BX_P * (c_pad - c_in); i += 256) {
+        const int w = c_pad - c_in, pl = i / w;
+        xtile[pl * c_pad + c_in + (i - pl * w)] = from_f32<TX>(0.f);
+    }
+    const unsigned rcp_p = n_prev_ch ? ((1u << 20) + F - 1) / F : 0u;
+    const unsigned rcp_s = Fs ? ((1u << 20) + Fs - 1) / Fs : 0u, rcp_f = Ff ? ((1u << 20) + Ff - 1) / Ff : 0u;
+    const int xslots = c_pad * (int)sizeof(TX) / 16;
+    const int64_t ntiles = (N + BX_P - 1) / BX_P;
+    auto stream_in = [&](const float* src, int C, unsigned rcp, int c_off, int np) __attribute__((always_inline)) {
+        const int nel = np * C;   // a multiple of 4 (host)
+        for (int e0 = 4 * tid; e0 < nel; e0 += 4 * 256) {
+            const v4f v = *reinterpret_cast<const v4f*>(src + e0);
+            int pl, f;
+            bx_pf(e0, C, rcp, pl, f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xtile[pl * c_pad + c_off + f] = from_f32<TX>(v[j]);
+                if (++f == C) { f = 0; ++pl; }
+            }
+        }
+    };
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t n0 = t * BX_P;
+        const int np = (int)((N - n0) < BX_P ? (N - n0) : BX_P);
+        __syncthreads();   // (the previous tile's rows are out)
+        for (int ti = 0; ti * F < n_prev_ch; ++ti)
+            stream_in(prev + (int64_t)b * prev_bs + (int64_t)ti * prev_ts + n0 * F, F, rcp_p, ti * F, np);
+        if (Fs) stream_in(statics + (int64_t)b * statics_bs + n0 * Fs, Fs, rcp_s, n_prev_ch, np);
+        if (Ff) stream_in(forcing + (int64_t)b * forcing_bs + n0 * Ff, Ff, rcp_f, n_prev_ch + Fs, np);
+        __syncthreads();
+        for (int sl = tid; sl < np * xslots; sl += 256)
+            reinterpret_cast<bx_u32x4*>(x + ((int64_t)b * N + n0) * c_pad)[sl] = reinterpret_cast<const bx_u32x4*>(xtile)[sl];
+    }
+}
+
 static inline int stream_grid(int64_t total_pixels, int PP) {
     // memory-bound: cap at ~8 blocks of 256 threads per CU and grid-stride the rest
     int64_t waves = (total_pixels + PP - 1) / PP;
@@ -337,6 +394,36 @@ static int build_x_impl(const float* prev, int64_t prev_bs, int64_t prev_ts, con
     const int iters = (c_pad + FP - 1) / FP;
     P4C_CHECK_ARG(iters <= K1_MAX_ITERS, "p4c_build_x: c_pad %d too large (max %d)", c_pad, 64 * K1_MAX_ITERS);
     const bool odd = c_pad % 4 != 0;   // the exact C_in of a generic model (e.g. 69): fp32 rows, unaligned vector stores
+    // flat streams through an LDS tile of rows wherever its alignment conditions hold: any feature count, and faster than the quad
+    // kernel where that one applies too (2 x 512 x 512, 69 -> 96 channels: 45 against 71 us)  (P4C_NO_FLAT_STEP=1: the quad kernel below)
+    {
+        const int esz = x_dtype == P4C_BF16 ? 2 : 4;
+        const char* nf = getenv("P4C_NO_FLAT_STEP");
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const bool flat = !(nf && nf[0] == '1') && !mask_on_nan && !bm.selected && (x_dtype == P4C_F32 || x_dtype == P4C_BF16) && c_pad <= 256 &&
+                          (c_pad * esz) % 16 == 0 && al16(x) && F <= 64 && Fs <= 64 && Ff <= 64 &&
+                          (n_prev_ch > 0 ? ((N * F) % 4 == 0 && prev_bs % 4 == 0 && prev_ts % 4 == 0 && al16(prev)) : true) &&
+                          (Fs == 0 || ((N * Fs) % 4 == 0 && statics_bs % 4 == 0 && al16(statics))) &&
+                          (Ff == 0 || ((N * Ff) % 4 == 0 && forcing_bs % 4 == 0 && al16(forcing)));
+        if (flat) {
+            const int64_t ntiles = (N + BX_P - 1) / BX_P;
+            int64_t blocks = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
+            if (blocks > ntiles) blocks = ntiles;
+            if (blocks < 1) blocks = 1;
+            const size_t smem = (size_t)BX_P * c_pad * esz;
+            if (x_dtype == P4C_F32) {
+                P4C_TRY(ensure_dyn_smem((const void*)build_x_flat_kernel<float>, (int)smem));
+                hipLaunchKernelGGL(build_x_flat_kernel<float>, dim3((unsigned)blocks, B), dim3(256), smem, as_stream(stream), prev, prev_bs, prev_ts,
+                                   statics, statics_bs, forcing, forcing_bs, (float*)x, c_pad, T_in, N, F, Fs, Ff, n_prev_ch);
+            } else {
+                P4C_TRY(ensure_dyn_smem((const void*)build_x_flat_kernel<bf16>, (int)smem));
+                hipLaunchKernelGGL(build_x_flat_kernel<bf16>, dim3((unsigned)blocks, B), dim3(256), smem, as_stream(stream), prev, prev_bs, prev_ts,
+                                   statics, statics_bs, forcing, forcing_bs, (bf16*)x, c_pad, T_in, N, F, Fs, Ff, n_prev_ch);
+            }
+            P4C_CHECK_LAUNCH("p4c_build_x(flat)");
+            return P4C_OK;
+        }
+    }
     if (!mask_on_nan && !bm.selected && c_pad <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
         ((x_dtype == P4C_F32) || (x_dtype == P4C_BF16 && !odd))) {
         const int FP4 = pow2_ge((c_pad + 3) / 4);

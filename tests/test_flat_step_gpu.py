@@ -155,3 +155,36 @@ def test_flat_kernels_for_feature_counts_off_the_16_byte_grid(gpu_device, monkey
     assert rel_err(dps, gp) < 1e-6
     assert rel_err(dys[..., :F].float(), (gp * c["std"]).to(dt).float()) < 1e-6
     assert float(dys[..., F:].float().abs().max()) == 0.0        # channels >= F of dy are zero
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,N,T_in,F,Fs,Ff,cpad", [
+    (2, 64 * 80, 1, 21, 4, 21, 64),      # the shipped Titan feature counts (C_in = 46 -> 64)
+    (1, 1000, 1, 21, 4, 21, 64),         # a partial last tile
+    (2, 2052, 2, 5, 3, 2, 32),           # two input time steps, odd static / forcing counts
+    (3, 772, 1, 62, 1, 1, 64),           # rows full
+    (2, 512 * 640, 1, 21, 4, 21, 64),    # the Titan grid
+    (2, 64 * 96, 1, 60, 4, 5, 96),       # the benchmark's counts: the quad kernel serves them; the flat kernel forced on
+])
+def test_flat_build_x_equals_the_quad_kernel(gpu_device, monkeypatch, dt, B, N, T_in, F, Fs, Ff, cpad):
+    """p4c_build_x for feature counts off the 16-byte grid streams its sources flat through an LDS tile of rows (csrc/rollout.hip:
+    build_x_flat_kernel; lightning.py:711-767): bit for bit what the quad kernel writes (P4C_NO_FLAT_STEP=1) -- a conversion per
+    element, no arithmetic -- and what torch.cat gives."""
+    from py4cast_amd import ops
+
+    g = torch.Generator(device=gpu_device).manual_seed(41)
+    prev = torch.randn(B, T_in, N, F, generator=g, device=gpu_device)
+    st = torch.rand(B, N, Fs, generator=g, device=gpu_device)
+    fo = torch.rand(B, N, Ff, generator=g, device=gpu_device)
+    res = {}
+    for mode in ("flat", "quad"):
+        monkeypatch.setenv("P4C_NO_FLAT_STEP", "1" if mode == "quad" else "0")
+        monkeypatch.setenv("P4C_FORCE_FLAT_STEP", "1" if mode == "flat" else "0")
+        res[mode] = ops.build_x(prev, st, fo, c_pad=cpad, dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(res["flat"]), _bits(res["quad"]))
+    want = torch.zeros(B, N, cpad, device=gpu_device)
+    want[..., : T_in * F] = prev.permute(0, 2, 1, 3).reshape(B, N, T_in * F)
+    want[..., T_in * F: T_in * F + Fs] = st
+    want[..., T_in * F + Fs: T_in * F + Fs + Ff] = fo
+    assert torch.equal(_bits(res["flat"].reshape(B, N, cpad)), _bits(want.to(dt)))
