@@ -693,16 +693,16 @@ struct FlatFront {
     const float* wout;        // (cout,64) fp32
     int cout;
 };
-typedef float ff_f32x16 __attribute__((ext_vector_type(16)));
-typedef float ff_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 ff_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 ff_bf16x2 __attribute__((ext_vector_type(2)));
-typedef short ff_s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int ff_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int ff_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int ff_pack(float lo, float hi) {
-    const ff_f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, ff_bf16x2));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename TY, bool FRONT = false>
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(256)
     TY* xtile = ytile + FLAT_P * y_cs;
     float* cst = reinterpret_cast<float*>(xtile + (nx.x ? FLAT_P * nx.c_pad : 0));
     float* msk = cst + 3 * 64;
-    ff_bf16x8* wimg = reinterpret_cast<ff_bf16x8*>(msk + 2 * 64);
+    bf16x8_t* wimg = reinterpret_cast<bf16x8_t*>(msk + 2 * 64);
     float* lsc = reinterpret_cast<float*>(wimg + 2 * 4 * 64);
     float* lsh = lsc + 64;
     __shared__ float red[4];
@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(256)
                 lo = *reinterpret_cast<const v4f*>(fa.wout + (int64_t)co * 64 + k0);
                 hi = *reinterpret_cast<const v4f*>(fa.wout + (int64_t)co * 64 + k0 + 4);
             }
-            ff_bf16x8 w8;
+            bf16x8_t w8;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { w8[j] = (__bf16)lo[j]; w8[4 + j] = (__bf16)hi[j]; }
             wimg[t] = w8;
@@ -786,13 +786,13 @@ __global__ void __launch_bounds__(256)
             if (32 * T < fa.cout) {
                 const int64_t pn = n0 + 32 * pb + r;
                 const bf16* ab = fa.a + (int64_t)b * N * 64;
-                ff_u32x4 cur[4];
+                u32x4_t cur[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    cur[ks] = ff_u32x4{0u, 0u, 0u, 0u};
-                    if (pn < N) cur[ks] = *reinterpret_cast<const ff_u32x4*>(ab + pn * 64 + 16 * ks + 8 * h);
+                    cur[ks] = u32x4_t{0u, 0u, 0u, 0u};
+                    if (pn < N) cur[ks] = *reinterpret_cast<const u32x4_t*>(ab + pn * 64 + 16 * ks + 8 * h);
                 }
-                ff_f32x16 yy;
+                f32x16_t yy;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) yy[i] = 0.f;
 #pragma unroll
@@ -801,25 +801,25 @@ __global__ void __launch_bounds__(256)
                     const v4f t0 = *reinterpret_cast<const v4f*>(lsh + 16 * ks + 8 * h), t1 = *reinterpret_cast<const v4f*>(lsh + 16 * ks + 8 * h + 4);
                     const float scv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
                     const float shv[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-                    ff_u32x4 o;
+                    u32x4_t o;
 #pragma unroll
                     for (int k2 = 0; k2 < 4; ++k2) {
                         // relu(a * scale + shift), fp32, one rounding to bf16: what the 1x1 convolution's loader stages (conv_rows.hip: xform2<2>)
                         const unsigned int wd = cur[ks][k2];
                         const float lo = __builtin_fmaf(__builtin_bit_cast(float, wd << 16), scv[2 * k2], shv[2 * k2]);
                         const float hi = __builtin_fmaf(__builtin_bit_cast(float, wd & 0xffff0000u), scv[2 * k2 + 1], shv[2 * k2 + 1]);
-                        const ff_s16x2 z = {0, 0};
-                        o[k2] = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(ff_s16x2, ff_pack(lo, hi)), z));
+                        const s16x2_t z = {0, 0};
+                        o[k2] = __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pack_bf16(lo, hi)), z));
                     }
-                    yy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wimg[(T * 4 + ks) * 64 + lane], __builtin_bit_cast(ff_bf16x8, o), yy, 0, 0, 0);
+                    yy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wimg[(T * 4 + ks) * 64 + lane], __builtin_bit_cast(bf16x8_t, o), yy, 0, 0, 0);
                 }
                 // C[feature][point]: lane = point r (+ half h), register quad gq -> features 32 T + 8 gq + 4 h .. + 3
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    ff_u32x2 o;
-                    o[0] = ff_pack(yy[4 * gq], yy[4 * gq + 1]);
-                    o[1] = ff_pack(yy[4 * gq + 2], yy[4 * gq + 3]);
-                    *reinterpret_cast<ff_u32x2*>(reinterpret_cast<bf16*>(ytile) + (32 * pb + r) * 64 + 4 * ((8 * T + 2 * gq + h) ^ (r & 15))) = o;
+                    u32x2_t o;
+                    o[0] = pack_bf16(yy[4 * gq], yy[4 * gq + 1]);
+                    o[1] = pack_bf16(yy[4 * gq + 2], yy[4 * gq + 3]);
+                    *reinterpret_cast<u32x2_t*>(reinterpret_cast<bf16*>(ytile) + (32 * pb + r) * 64 + 4 * ((8 * T + 2 * gq + h) ^ (r & 15))) = o;
                 }
             }
         } else {
@@ -1452,14 +1452,6 @@ extern "C" int p4c_ar_update_loss_fwd_next_saved(const float* prev, int64_t prev
 //     ar_update_loss_fwd_v4_kernel (the reference's op order): new state, next input and saved loss gradients are the two-kernel
 //     route's bits; the loss is the same sum in another order.
 // 16-byte path conditions as p4c_ar_update_loss_fwd_next; no NaN masks (mask_mode NONE).
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef short s16x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-
 struct OutConvArgs {
     const bf16* a; const float* a_scale; const float* a_shift; const float* wout; int cout;
     const float* prev; int64_t prev_bs; const float* target; int64_t tgt_bs; const float* std; const float* mean;
@@ -1467,11 +1459,6 @@ struct OutConvArgs {
     int kind; float* partial; int64_t N; int F; float keep_prev;
     NextX nx;
 };
-
-__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
-}
 
 // Layout of the work: a wave takes 32 consecutive grid points at a time.
 //   front end: y^T = W relu(norm(a))^T on the matrix cores -- A = W (M = output feature; bf16 fragments in LDS, laid once per workgroup),
