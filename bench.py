@@ -560,6 +560,17 @@ def main():
                                 "unit": "GB/s", "frac": tot / step_s / 1e9 / HBM_PEAK_GBS, "ms_per_step": step_s * 1e3,
                                 "floor_ms_at_peak": tot / (HBM_PEAK_GBS * 1e9) * 1e3,
                                 "bytes_by_family_mb": {k: round(v / 1e6, 1) for k, v in table.items()}}
+                # measured HBM bytes of a whole step, when a committed PMC run of THIS configuration exists (separate rocprofv3 --pmc
+                # FETCH_SIZE / WRITE_SIZE passes over every dispatch, tools/diagnostics/r04_pmc_step.sh): only for the default shape
+                tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_traffic_step.json")
+                if (B, H, W, F, Fs, Ff, T) == (2, 512, 512, 60, 4, 5, 3) and args.dtype == "bf16" and os.path.exists(tfile):
+                    try:
+                        hb = json.load(open(tfile)).get("hbm_bytes_per_step", {}).get("total")
+                        if hb:
+                            roof["step"]["traffic"] = hb
+                            roof["step"]["traffic_source"] = "profiles/r04_pmc_traffic_step.json (committed rocprofv3 --pmc passes of an earlier run)"
+                    except (OSError, ValueError):
+                        pass
             wg = (extra or {}).get("wgrad_avg_launch_ms_overlapped")
             if wg and roof.get("bound") == "hbm":
                 # the weight-gradient kernel of the same layers, in the step (it runs beside the backward chain on the side stream):
