@@ -263,8 +263,11 @@ int p4c_ar_update_loss_bwd(const float* g_next, int64_t g_next_bs, const void* g
  * is formed on the matrix cores per 32 grid points, rounded to bf16 exactly where the two-kernel route stores it, and consumed in
  * registers by the state update / border forcing / weighted loss / next-input emission / saved loss gradient of
  * p4c_ar_update_loss_fwd_next_saved (same arguments, same arithmetic, same new state; the loss is summed in another order).  y is
- * never written.  a: (B,N,64) bf16; a_scale / a_shift: (B,64); wout: (cout,64) fp32, F <= cout <= 64, F even; x_next (c_pad <= 96,
- * even) and lgrad may be NULL; no NaN masks. */
+ * never written.  a: (B,N,64) bf16; a_scale / a_shift: (B,64); wout: (cout,64) fp32, F <= cout <= 64; x_next and lgrad may be NULL;
+ * no NaN masks.  Two forms, same bits: the FLAT one (any F <= 64 with N * F a multiple of 4, rows of x_next whole 16-byte slots,
+ * c_pad <= 256, 16-byte aligned fp32 rows: the (N, F) arrays are streamed flat, 16 bytes per lane, the convolution heads every
+ * 64-point tile) wherever those conditions hold -- the shipped Titan configuration's F = 21 included --, otherwise the 16-byte form
+ * (F, Fs, c_pad multiples of 4, at most pow2_ge(F / 4) tail quads).  P4C_NO_FLAT_STEP=1 / P4C_TAIL_V4=1 prefer the 16-byte form. */
 int p4c_out_conv_update_loss_fwd(const void* a, const float* a_scale, const float* a_shift, const float* wout, int cout,
                                  const float* prev, int64_t prev_bs, const float* target, int64_t tgt_bs, const float* std,
                                  const float* mean, const float* border_mask, const float* interior_mask, float* new_state,
