@@ -94,6 +94,9 @@ int p4c_prof_collect(int tag, int64_t min_units, double* total_ms, int* count, d
  * statics: (B,N,Fs) with batch stride statics_bs (0 = broadcast one (N,Fs) map);
  * forcing: time-selected (B,N,Ff) with batch stride forcing_bs.
  * x: (B,N,c_pad) dense, dtype x_dtype; channels >= C_in are written as zeros.
+ * Three kernels, the same values bit for bit: flat streams through an LDS tile of 64 rows (round 4: any feature counts <= 64 each,
+ * 16-byte aligned sources with N * F / N * Fs / N * Ff multiples of 4, rows of x whole 16-byte slots, no NaN mask), a lane per
+ * output quad (c_pad % 4 == 0), a lane per element (everything else, the NaN mask, the masked-auto-encoder block mask).
  */
 int p4c_build_x(const float* prev, int64_t prev_bs, int64_t prev_ts, const float* statics, int64_t statics_bs,
                 const float* forcing, int64_t forcing_bs, void* x, int x_dtype, int c_pad, int B, int T_in,
@@ -238,8 +241,11 @@ int p4c_ar_update_loss_fwd(const float* prev, int64_t prev_bs, const void* y, in
 /* The same step, additionally emitting the NEXT AR step's network input x_next (B,N,c_pad) in the dtype / padded
  * layout of p4c_build_x with T_in = 1: [new state (F) | statics (Fs) | forcing of the next step (Ff) | zeros], so the
  * state just computed is not read back by a separate p4c_build_x ("feed next step", lightning.py:636-656 + 711-767).
- * x_next has the dtype of y.  Needs the 16-byte path (F % 4 == 0, F <= 64, Fs % 4 == 0, aligned rows) and
- * mask_mode == P4C_MASK_NONE; returns P4C_ERR_UNSUPPORTED otherwise (call p4c_build_x then). */
+ * x_next has the dtype of y.  Needs mask_mode == P4C_MASK_NONE and one of two paths: the 16-byte path (F % 4 == 0, F <= 64,
+ * Fs % 4 == 0, aligned rows: a lane owns 4 features of one grid point) or, for ANY feature count F <= 64 -- the shipped Titan
+ * configuration has 21 --, the flat path (round 4: N * F % 4 == 0, rows of y / x_next whole 16-byte slots, c_pad <= 256, 16-byte
+ * aligned fp32 rows; the (N, F) arrays are streamed flat, the row tensors pass through LDS tiles of 64 grid points; the same values
+ * bit for bit); returns P4C_ERR_UNSUPPORTED otherwise (call p4c_build_x then).  P4C_NO_FLAT_STEP=1 turns the flat path off. */
 int p4c_ar_update_loss_fwd_next(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
                                 const float* target, int64_t tgt_bs, const float* std, const float* mean,
                                 const float* border_mask, const float* interior_mask, float* new_state, int64_t new_bs,
@@ -280,7 +286,7 @@ int p4c_out_conv_update_loss_fwd(const void* a, const float* a_scale, const floa
  * state and the target: at F = 60 the backward reads 120 instead of 480 bytes per grid point (the forward writes 120 more).  The
  * saved values are rounded to bf16 (2^-9 relative), the precision the network gradient dy is stored in anyway: used by the bf16
  * flavour of the native rollout; the fp32 flavour keeps p4c_ar_update_loss_bwd.  x_next may be NULL (last AR step).
- * 16-byte path only (as p4c_ar_update_loss_fwd_next); P4C_ERR_UNSUPPORTED otherwise. */
+ * 16-byte or flat path (as p4c_ar_update_loss_fwd_next); P4C_ERR_UNSUPPORTED otherwise. */
 int p4c_ar_update_loss_fwd_next_saved(const float* prev, int64_t prev_bs, const void* y, int y_dtype, int y_cs,
                                       const float* target, int64_t tgt_bs, const float* std, const float* mean,
                                       const float* border_mask, const float* interior_mask, float* new_state, int64_t new_bs,
