@@ -496,13 +496,41 @@ extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* x, 
     const WS ws{L, (char*)savedv, (char*)scratchv};
     if (!d.weights_prepared) P4C_TRY(prepare_weights(d, ws, params, 1, st));
 
-    // encoder
+    // encoder.  Levels 2 .. 4 (BatchNorm with batch statistics, bf16 maps) can run as one persistent launch instead of 3 max-pools + 6
+    // convolution launches (coarse_fwd.hip; P4C_COARSE_FWD=1) -- measured SLOWER (925 against 673 us per forward: its grid-wide barriers
+    // cost more than the kernel boundaries they replace), so it is off unless asked for
+    const bool coarse = d.norm == 0 && training && d.compute == P4C_BF16 && coarse_fwd_ok(d.dtype, d.B, L.Hk[2], L.Wk[2]) &&
+                        (int64_t)d.B * 4 * num_cus() * 128 >= (int64_t)coarse_fwd_scratch_floats();
     for (int k = 0; k < NLEV; ++k) {
+        if (coarse && k == 2) {
+            Norm top = norm_at(ws, 3, d.B);
+            void* P[3];
+            void* Y[3][2];
+            const void* wp[3][2];
+            const float *gm[3][2], *bt[3][2];
+            float *rm[3][2], *rv[3][2], *nm[3][2];
+            for (int lv = 0; lv < 3; ++lv) {
+                P[lv] = ws.act(L.P[lv + 2]);
+                for (int j = 0; j < 2; ++j) {
+                    const int i = 2 * (lv + 2) + j;
+                    Y[lv][j] = ws.act(L.Y[i]);
+                    wp[lv][j] = wslot(ws, i);
+                    gm[lv][j] = params + L.gamma[i];
+                    bt[lv][j] = params + L.beta[i];
+                    rm[lv][j] = running ? running + (int64_t)i * 128 : nullptr;
+                    rv[lv][j] = running ? running + (int64_t)i * 128 + 64 : nullptr;
+                    nm[lv][j] = norm_at(ws, i, d.B).scale;
+                }
+            }
+            P4C_TRY(launch_coarse_fwd(ws.act(L.Y[3]), top.scale, top.shift, P, Y, wp, gm, bt, rm, rv, nm, ws.f(L.statp),
+                                      reinterpret_cast<unsigned int*>(ws.f(L.tickets)) + 4, d.B, L.Hk[2], L.Wk[2], d.eps, d.momentum, st));
+            break;
+        }
         const void* in = k == 0 ? x : ws.act(L.P[k]);
         P4C_TRY(conv_block_fwd(d, ws, 2 * k, in, nullptr, params, running, training, st));
         Norm n1 = norm_at(ws, 2 * k, d.B);
         P4C_TRY(conv_block_fwd(d, ws, 2 * k + 1, ws.act(L.Y[2 * k]), &n1, params, running, training, st));
-        if (k + 1 < NLEV) {
+        if (k + 1 < NLEV && !(coarse && k == 1)) {
             Norm n2 = norm_at(ws, 2 * k + 1, d.B);
             P4C_TRY(pool_fwd(d.dtype, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, L.Hk[k], L.Wk[k], ws.act(L.P[k + 1]), st));
         }
