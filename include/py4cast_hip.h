@@ -697,6 +697,44 @@ int p4c_inorm_finalize_fwd(const float* partial, int nblk, int B, int64_t N, int
 int p4c_inorm_finalize_bwd(const float* partial, int nblk, int B, int64_t N, int C, int groups, const float* gamma, const float* rstd,
                            float* c1, float* c2, float* dgamma, float* dbeta, p4c_stream_t stream);
 
+/* ====================================================================================
+ * Wide-channel GEMMs / implicit-GEMM convolutions on the bf16 matrix cores (csrc/gemm.hip, round 5): the 3x3 / 1x1 convolutions of
+ * 128 ... 1024 channels with their batch norms and the qkvv / out_proj / fc1 / fc2 / reduction Linears of the UNETR++ and SwinUNETR
+ * configurations (config/CLI/model/unetrpp.yaml:19-35, swinunetr.yaml:19-30; the reference takes both classes from mfai,
+ * py4cast/models.py:10-20, where these are torch.nn.Conv2d / BatchNorm2d / Linear calls).
+ * ==================================================================================== */
+/* bf16 operand images of an fp32 master weight in the torch layout (CO, CI, taps) -- taps = 9: (CO, CI, 3, 3); taps = 1: a Linear's
+ * (out, in) or a 1x1 convolution: fwd[co][tap][ci] = w[co][ci][tap] (forward), dgrad[ci][tap'][co] = w[co][ci][taps-1-tap'] (data
+ * gradient: the same kernel on the transposed, tap-flipped image).  Either output may be NULL. */
+int p4c_gemm_prep_weight(const float* w, int CO, int CI, int taps, void* fwd, void* dgrad, p4c_stream_t stream);
+/* C (M, N) bf16 = epilogue(A x Bimg^T), Bimg (N, K) bf16 with K contiguous (p4c_gemm_prep_weight), fp32 accumulation.
+ * taps = 1: A = (M, K) bf16 rows, row stride lda.  taps = 9: A = an NHWC map (batch, H, W, Cin), M = batch * H * W pixels, pixel
+ * stride lda >= Cin, K = 9 * Cin: the 3x3 "same" convolution with zero padding (no im2col buffer).
+ * Epilogue, in this order: + bias[n] (fp32, optional); act = 1: the bf16-rounded pre-activation goes to aux_out (row stride ldaux) and
+ * GELU (erf form) of it on; act = 2: times GELU'(aux_in) (the data gradient through a GELU); + res[m][n] (bf16, row stride ldr,
+ * optional); rounded to bf16 into C (row stride ldc).  stats (optional): [p4c_gemm_nt_stat_blocks][2][N] fp32 column sums and sums of
+ * squares of the ROUNDED output (batch-norm statistics; p4c_bnorm_finalize).  N, K, every row stride: multiples of 8.
+ * Deep reductions run split-K: workspace of p4c_gemm_nt_workspace_bytes(M, N, K) bytes (0 = not needed), slabs summed in a fixed
+ * order (reruns are bit-identical). */
+size_t p4c_gemm_nt_workspace_bytes(int M, int N, int K);
+int p4c_gemm_nt_stat_blocks(int M, int N, int K);
+int p4c_gemm_nt(const void* A, int64_t lda, const void* Bimg, int M, int N, int K, int H, int W, int Cin, int taps, const float* bias,
+                const void* res, int64_t ldr, int act, const void* aux_in, void* aux_out, int64_t ldaux, void* C, int64_t ldc,
+                float* stats, void* workspace, p4c_stream_t stream);
+/* Weight (+ bias) gradient: dw (Mo, Cin, taps) fp32 in the torch layout = sum over the R rows of dy[r][:Mo]^T (x) x[r] -- taps = 9:
+ * x's 3x3 neighbourhood of pixel r (x = the NHWC map, R = batch * H * W) --, db (Mo) = column sums of dy (or NULL).  dy / x bf16 rows
+ * with strides ldp / ldq (multiples of 8).  Split over the rows, fp32 slabs summed in a fixed order.  workspace:
+ * p4c_gemm_tn_workspace_bytes(R, Mo, taps * Cin) bytes. */
+size_t p4c_gemm_tn_workspace_bytes(int R, int Mo, int No);
+int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t ldq, int R, int Mo, int H, int W, int Cin, int taps, float* dw,
+                float* db, void* workspace, p4c_stream_t stream);
+/* BatchNorm2d (training mode) statistics from column partial sums [nblk][2][C] over `count` values per channel: mean, rstd,
+ * scale = gamma rstd, shift = beta - mean scale (C each, fp32); running_mean / running_var (optional) get torch's momentum update
+ * with the unbiased variance. */
+int p4c_bnorm_finalize(const float* partial, int nblk, double count, int C, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                       p4c_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

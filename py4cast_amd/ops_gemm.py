@@ -1,0 +1,313 @@
+"""Autograd wrappers of the wide-channel GEMM / implicit-GEMM convolution kernels (csrc/gemm.hip; include/py4cast_hip.h:
+p4c_gemm_prep_weight, p4c_gemm_nt, p4c_gemm_tn, p4c_bnorm_finalize).
+
+They carry what mfai's UNETR++ / SwinUNETR (py4cast/models.py:10-20; config/CLI/model/unetrpp.yaml:19-35, swinunetr.yaml:19-30) express as
+``nn.Linear`` / ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.GELU`` calls, on features-last bf16 activations with fp32 master parameters:
+
+* ``linear(x, w, b, res)``            y = x W^T + b (+ res)                       -- forward, data gradient, weight + bias gradient native
+* ``mlp(x, w1, b1, w2, b2, res)``     y = gelu(x W1^T + b1) W2^T + b2 (+ res)     -- ONE autograd node: GELU in the first product's
+  epilogue, GELU' in the epilogue of the second product's data gradient (no elementwise launch either way)
+* ``conv3x3(x, w, res, stats)``       3x3 "same" convolution of an NHWC map, no im2col buffer; optionally the per-channel sums of the
+  output for the batch norm that follows
+* ``batch_norm_act(y, stats, ...)``   BatchNorm2d (training statistics from the producer's sums, running statistics updated) +
+  LeakyReLU (+ residual) as one node on the streaming kernels of csrc/inorm.hip (a batch norm is an instance norm of the batch seen
+  as one sample)
+
+No CPU fallback: every entry point raises on CPU tensors."""
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_GELU_FWD, ACT_GELU_BWD = 0, 1, 2
+
+_WIMG = {}   # eager mode: (address, shape, strides, taps) -> (parameter version, (fwd image, dgrad image), owners)
+
+
+def weight_images(w: torch.Tensor, taps: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bf16 operand images of an fp32 master weight (CO, CI[, 3, 3]): ([CO][taps][CI], [CI][taps'][CO]); once per parameter version
+    in eager mode and once per HIP-graph capture (the AR steps of a rollout share them)."""
+    L.require_cuda(w)
+    if w.dtype != torch.float32:
+        raise L.P4CError(f"weight_images: fp32 master weights expected, got {w.dtype}")
+    wd = w.detach()
+    if not wd.is_contiguous():
+        wd = wd.contiguous()
+    CO, CI = wd.shape[0], wd.shape[1]
+    key = ("wimg", w.data_ptr(), tuple(w.shape), tuple(w.stride()), taps)
+    ver = (L.PARAM_EPOCH[0], w._version)
+    cache = _WIMG if not torch.cuda.is_current_stream_capturing() else L.capture_cache()
+    if cache is not None:
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver and L.owners_alive(hit[2], (w,)):
+            return hit[1]
+    fwd = torch.empty(CO, taps * CI, dtype=torch.bfloat16, device=w.device)
+    dgr = torch.empty(CI, taps * CO, dtype=torch.bfloat16, device=w.device)
+    L.call("p4c_gemm_prep_weight", L.ptr(wd), CO, CI, taps, L.ptr(fwd), L.ptr(dgr), L.stream(w.device))
+    if cache is not None:
+        cache[key] = (ver, (fwd, dgr), L.owner_refs((w,)))
+    return fwd, dgr
+
+
+def _rows(t: torch.Tensor, C: int) -> torch.Tensor:
+    """(..., C) -> (R, C) rows with unit stride inside a row, a row stride that is a multiple of 8 and a 16-byte aligned base"""
+    t2 = t.reshape(-1, C)
+    if t2.stride(1) != 1 or t2.stride(0) % 8 or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+    return t2
+
+
+def _f32(p: Optional[torch.Tensor]):
+    if p is None:
+        return None
+    p = p.detach()
+    return p.contiguous() if p.dtype == torch.float32 else p.float().contiguous()
+
+
+def gemm_nt(A: torch.Tensor, img: torch.Tensor, N: int, K: int, conv=None, bias=None, res=None, act=ACT_NONE, aux_in=None,
+            want_stats=False, out=None):
+    """C = epilogue(A x img^T).  A: (M, >= K) bf16 rows, or with conv = (H, W, Cin) the NHWC map as (M = batch H W, Cin-or-wider)
+    rows.  Returns (C, aux_out or None, stats or None); `out`: a preallocated (M, >= N) row view to write into."""
+    lib = L.lib()
+    M = A.shape[0]
+    H, W, Cin, taps = (conv[0], conv[1], conv[2], 9) if conv is not None else (0, 0, 0, 1)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=A.device) if out is None else out
+    aux_out = torch.empty(M, N, dtype=torch.bfloat16, device=A.device) if act == ACT_GELU_FWD else None
+    aux = aux_out if act == ACT_GELU_FWD else aux_in
+    stats = None
+    if want_stats:
+        stats = torch.empty(lib.p4c_gemm_nt_stat_blocks(M, N, K), 2, N, dtype=torch.float32, device=A.device)
+    nbytes = lib.p4c_gemm_nt_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=A.device) if nbytes else None
+    L.call("p4c_gemm_nt", L.ptr(A), A.stride(0), L.ptr(img), M, N, K, H, W, Cin, taps, L.ptr(bias), L.ptr(res),
+           0 if res is None else res.stride(0), act, L.ptr(aux_in), L.ptr(aux_out), 0 if aux is None else aux.stride(0), L.ptr(C), C.stride(0),
+           L.ptr(stats), L.ptr(ws), L.stream(A.device), alg_bytes=2 * (M * (K if conv is None else Cin) + N * K + M * N))
+    return C, aux_out, stats
+
+
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, Mo: int, Cin: int, conv=None, want_bias=False):
+    """dW (Mo, Cin[, 3, 3]) fp32 and db (Mo) or None from dy (R, >= Mo) and x (R, >= Cin) bf16 rows (conv = (H, W): x is the NHWC map)"""
+    lib = L.lib()
+    R = dy.shape[0]
+    taps, H, W = (9, conv[0], conv[1]) if conv is not None else (1, 0, 0)
+    dw = torch.empty((Mo, Cin, 3, 3) if conv is not None else (Mo, Cin), dtype=torch.float32, device=dy.device)
+    db = torch.empty(Mo, dtype=torch.float32, device=dy.device) if want_bias else None
+    ws = torch.empty(max(lib.p4c_gemm_tn_workspace_bytes(R, Mo, taps * Cin) // 4, 1), dtype=torch.float32, device=dy.device)
+    L.call("p4c_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), R, Mo, H, W, Cin, taps, L.ptr(dw), L.ptr(db), L.ptr(ws),
+           L.stream(dy.device), alg_bytes=2 * R * (Mo + Cin) + 4 * Mo * Cin * taps)
+    return dw, db
+
+
+def supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """bf16 activations on the GPU, fp32 master weight, channel counts on the kernels' 8-element granularity"""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.float32 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, res):
+        O, K = w.shape
+        x2 = _rows(x.detach(), K)
+        fwd, dgr = weight_images(w, 1)
+        r2 = None if res is None else _rows(res.detach(), O)
+        y, _, _ = gemm_nt(x2, fwd, O, K, bias=_f32(b), res=r2)
+        ctx.save_for_backward(x2, dgr)
+        ctx.xshape, ctx.has_bias, ctx.has_res = x.shape, b is not None, res is not None
+        ctx.wdtype, ctx.bdtype, ctx.OK = w.dtype, (None if b is None else b.dtype), (O, K)
+        return y.view(*x.shape[:-1], O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, dgr = ctx.saved_tensors
+        O, K = ctx.OK
+        dy2 = _rows(dy, O)
+        dx = gemm_nt(dy2, dgr, K, O)[0].view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = gemm_tn(dy2, x2, O, K, want_bias=ctx.has_bias)
+            dw = dw.to(ctx.wdtype)
+            db = None if db is None else db.to(ctx.bdtype)
+        return dx, dw, db, (dy if ctx.has_res else None)
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear(x, w, b) (+ res)`` for bf16 activations of any rank with fp32 master parameters (in / out features multiples of 8)"""
+    L.require_cuda(x)
+    if not supported(x, w):
+        raise L.P4CError(f"ops_gemm.linear: unsupported operands ({x.dtype}, weight {tuple(w.shape)} {w.dtype})")
+    return _Linear.apply(x, w, b, res)
+
+
+class _MLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res):
+        Hd, K = w1.shape
+        O = w2.shape[0]
+        x2 = _rows(x.detach(), K)
+        f1, d1 = weight_images(w1, 1)
+        f2, d2 = weight_images(w2, 1)
+        g, h, _ = gemm_nt(x2, f1, Hd, K, bias=_f32(b1), act=ACT_GELU_FWD)
+        r2 = None if res is None else _rows(res.detach(), O)
+        y, _, _ = gemm_nt(g, f2, O, Hd, bias=_f32(b2), res=r2)
+        ctx.save_for_backward(x2, g, h, d1, d2)
+        ctx.xshape, ctx.dims, ctx.has_res = x.shape, (K, Hd, O), res is not None
+        ctx.dt = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        return y.view(*x.shape[:-1], O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, h, d1, d2 = ctx.saved_tensors
+        K, Hd, O = ctx.dims
+        dy2 = _rows(dy, O)
+        dh = gemm_nt(dy2, d2, Hd, O, act=ACT_GELU_BWD, aux_in=h)[0]            # (dy W2) * gelu'(h)
+        dw2, db2 = gemm_tn(dy2, g, O, Hd, want_bias=ctx.dt[3] is not None)
+        dx = gemm_nt(dh, d1, K, Hd)[0].view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw1, db1 = gemm_tn(dh, x2, Hd, K, want_bias=ctx.dt[1] is not None)
+        return (dx, dw1.to(ctx.dt[0]), None if db1 is None else db1.to(ctx.dt[1]), dw2.to(ctx.dt[2]),
+                None if db2 is None else db2.to(ctx.dt[3]), (dy if ctx.has_res else None))
+
+
+def mlp(x, w1, b1, w2, b2, res=None) -> torch.Tensor:
+    """``F.linear(F.gelu(F.linear(x, w1, b1)), w2, b2) (+ res)`` as one autograd node"""
+    L.require_cuda(x)
+    if not (supported(x, w1) and supported(x, w2)):
+        raise L.P4CError("ops_gemm.mlp: unsupported operands")
+    return _MLP.apply(x, w1, b1, w2, b2, res)
+
+
+class _Conv(torch.autograd.Function):
+    """y (B,H,W,Co) = conv(x (B,H,W,>=Ci), w (Co,Ci,k,k)) (+ bias) (+ res), k = 3 ("same", zero padding) or 1; second output: the column
+    sums of y for a batch norm (not differentiable: the norm's backward accounts for them analytically)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, want_stats):
+        Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]
+        B, H, W_, Cx = x.shape
+        taps = k * k
+        xm = _rows(x.detach(), Cx)
+        fwd, dgr = weight_images(w, taps)
+        r2 = None if res is None else _rows(res.detach(), Co)
+        if taps == 9:
+            y, _, stats = gemm_nt(xm, fwd, Co, 9 * Ci, conv=(H, W_, Ci), bias=_f32(b), res=r2, want_stats=want_stats)
+        else:
+            y, _, stats = gemm_nt(xm, fwd, Co, Ci, bias=_f32(b), res=r2, want_stats=want_stats)
+        ctx.save_for_backward(xm, dgr)
+        ctx.geom, ctx.has_bias, ctx.has_res = (B, H, W_, Cx, Co, Ci, taps), b is not None, res is not None
+        ctx.wdtype, ctx.bdtype, ctx.wshape = w.dtype, (None if b is None else b.dtype), w.shape
+        y = y.view(B, H, W_, Co)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        xm, dgr = ctx.saved_tensors
+        B, H, W_, Cx, Co, Ci, taps = ctx.geom
+        dy2 = _rows(dy, Co)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if taps == 9:
+                dx = gemm_nt(dy2, dgr, Ci, 9 * Co, conv=(H, W_, Co))[0]
+            else:
+                dx = gemm_nt(dy2, dgr, Ci, Co)[0]
+            if Cx > Ci:      # the map was wider than the weight's input channels (zero-padded rows): no gradient there
+                dx = torch.nn.functional.pad(dx, (0, Cx - Ci))
+            dx = dx.view(B, H, W_, Cx)
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = gemm_tn(dy2, xm, Co, Ci, conv=(H, W_) if taps == 9 else None, want_bias=ctx.has_bias)
+            dw = dw.view(ctx.wshape).to(ctx.wdtype)
+            db = None if db is None else db.to(ctx.bdtype)
+        return dx, dw, db, (dy if ctx.has_res else None), None
+
+
+def conv_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and w.dtype == torch.float32 and w.dim() == 4
+            and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3) and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
+            and x.shape[-1] >= w.shape[1] and x.shape[-1] % 8 == 0)
+
+
+def conv2d_nhwc(x, w, b=None, res=None, want_stats=False):
+    """3x3 "same" / 1x1 convolution of a features-last map; returns y, or (y, stats) with want_stats"""
+    L.require_cuda(x)
+    if not conv_supported(x, w):
+        raise L.P4CError(f"ops_gemm.conv2d_nhwc: unsupported operands (x {tuple(x.shape)} {x.dtype}, w {tuple(w.shape)} {w.dtype})")
+    y, stats = _Conv.apply(x, w, b, res, bool(want_stats))
+    return (y, stats) if want_stats else y
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """out = lrelu(batch_norm(y) (+ res), slope) for y (B,H,W,C) features-last: statistics over (B,H,W) per channel from the producer's
+    partial sums (training) or the running statistics (eval); the streaming kernels of csrc/inorm.hip with the batch as ONE sample."""
+
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, res, running_mean, running_var, training, momentum, eps, slope):
+        yc = y.contiguous()
+        C = yc.shape[-1]
+        N = yc.numel() // C
+        dev = yc.device
+        st = torch.empty(4, C, dtype=torch.float32, device=dev)
+        g32, b32 = _f32(gamma), _f32(beta)
+        if training:
+            if stats is None:   # no producer sums: one reduction pass (p4c_inorm_reduce)
+                nb = L.lib().p4c_inorm_blocks(N, C)
+                stats = torch.empty(nb, 2, C, dtype=torch.float32, device=dev)
+                L.call("p4c_inorm_reduce", L.ptr(yc), None, None, None, None, 1.0, L.ptr(stats), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev))
+            L.call("p4c_bnorm_finalize", L.ptr(stats), stats.shape[0], float(N), C, L.ptr(g32), L.ptr(b32), float(eps), float(momentum),
+                   L.ptr(running_mean), L.ptr(running_var), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]), L.stream(dev))
+        else:
+            st[0] = running_mean
+            st[1] = torch.rsqrt(running_var.float() + eps)
+            st[2] = st[1] * (1.0 if g32 is None else g32)
+            st[3] = (0.0 if b32 is None else b32) - st[0] * st[2]
+        out = torch.empty_like(yc)
+        rc = None if res is None else res.contiguous()
+        L.call("p4c_inorm_apply", L.ptr(yc), L.ptr(rc), None, None, L.ptr(st[2]), L.ptr(st[3]), None, None, None, None, float(slope),
+               L.ptr(out), None, L.dtype_code(yc.dtype), 1, N, C, L.stream(dev))
+        ctx.save_for_backward(yc, out, st)
+        ctx.slope, ctx.has_res, ctx.training = float(slope), res is not None, bool(training)
+        ctx.gdtype = None if gamma is None else gamma.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        yc, out, st = ctx.saved_tensors
+        C = yc.shape[-1]
+        N = yc.numel() // C
+        dev = yc.device
+        dout = dout.contiguous()
+        nb = L.lib().p4c_inorm_blocks(N, C)
+        part = torch.empty(1, nb, 2, C, dtype=torch.float32, device=dev)
+        L.call("p4c_inorm_reduce", L.ptr(yc), L.ptr(dout), L.ptr(out), L.ptr(st[0]), L.ptr(st[1]), ctx.slope, L.ptr(part), L.dtype_code(yc.dtype),
+               1, N, C, L.stream(dev))
+        co = torch.empty(2, C, dtype=torch.float32, device=dev)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        L.call("p4c_inorm_finalize_bwd", L.ptr(part), nb, 1, N, C, 0, None, None, L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]),
+               L.stream(dev))
+        if not ctx.training:
+            co.zero_()          # running statistics are constants: dy = scale * dz
+        dy = torch.empty_like(yc)
+        dres = torch.empty_like(yc) if ctx.has_res else None
+        L.call("p4c_inorm_apply", L.ptr(yc), None, L.ptr(dout), L.ptr(out), L.ptr(st[2]), None, L.ptr(st[0]), L.ptr(st[1]), L.ptr(co[0]),
+               L.ptr(co[1]), ctx.slope, L.ptr(dy), L.ptr(dres), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev))
+        dg = None if ctx.gdtype is None else dgb[0].to(ctx.gdtype)
+        db = None if ctx.gdtype is None else dgb[1].to(ctx.gdtype)
+        return dy, None, dg, db, dres, None, None, None, None, None, None
+
+
+def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=None):
+    """``leaky_relu(bn(y) (+ res), slope)`` for a features-last y (B,H,W,C) and a torch.nn.BatchNorm2d module `bn` (its parameters,
+    running statistics, momentum, eps and training flag); `stats`: the producer's column sums (conv2d_nhwc(..., want_stats=True)) or
+    None.  slope = 1: no activation."""
+    L.require_cuda(y)
+    if y.dtype not in (torch.bfloat16, torch.float32) or y.shape[-1] % 4 or y.shape[-1] > 1024:
+        raise L.P4CError(f"ops_gemm.batch_norm_act: unsupported map {tuple(y.shape)} {y.dtype}")
+    training = bn.training or bn.running_mean is None
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None and not torch.cuda.is_current_stream_capturing():
+        bn.num_batches_tracked.add_(1)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return _BatchNormAct.apply(y, stats if training else None, bn.weight, bn.bias, res, rm, rv, training, mom, bn.eps, float(slope))

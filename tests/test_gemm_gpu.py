@@ -1,0 +1,270 @@
+"""
+The wide-channel GEMM / implicit-GEMM convolution kernels (csrc/gemm.hip, round 5) against float64 on the SAME bf16-rounded operands
+(reference products on the device in float64): Linear forward / data gradient / weight + bias gradient, the fused MLP node (GELU in
+the epilogues), the 3x3 "same" and 1x1 convolutions with their gradients, the batch-norm statistics from the convolution's drain and
+the BatchNorm2d + LeakyReLU (+ residual) node against torch.nn.BatchNorm2d in float64; ragged sizes (rows, features off the 128 / 64
+tile sizes), the split-K shapes of the deep UNETR++ stages, bit-identical reruns.
+Tolerances: bf16 outputs <= 4e-3 (half a bf16 ulp is 2e-3 relative) of the reference's largest magnitude per element and <= 2e-3 in
+the 2-norm; fp32 weight gradients <= 5e-4 in the 2-norm.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, ref):
+    got, ref = got.detach().double(), ref.detach().double()
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+def close_bf16(got, ref, what):
+    got, ref = got.detach().double(), ref.detach().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    worst = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    assert worst <= 6e-3 and rel(got, ref) <= 3e-3, f"{what}: max {worst:.2e}, 2-norm {rel(got, ref):.2e}"
+
+
+def rnd(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=dev) * scale)
+
+
+LINEAR_CASES = [
+    # R, K, N, bias, res
+    (1000, 128, 512, True, False),       # ragged rows
+    (32768, 128, 512, False, False),     # UNETR++ stage 0 qkvv: 256 x 4 tiles
+    (512, 1024, 4096, True, True),       # stage 3 qkvv: deep K -> split-K
+    (2048, 192, 576, True, False),       # Swin stage 3 qkv (features off the tile sizes)
+    (130, 24, 72, True, True),           # tiny, K = 24 (one partial k-block)
+    (8192, 512, 256, True, True),        # out_proj with residual
+]
+
+
+@pytest.mark.parametrize("R,K,N,has_bias,has_res", LINEAR_CASES)
+def test_linear_forward_and_gradients_vs_float64(gpu_device, R, K, N, has_bias, has_res):
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    x = rnd((R, K), dev, 1).bfloat16().requires_grad_()
+    w = (rnd((N, K), dev, 2) / K ** 0.5).requires_grad_()
+    b = rnd((N,), dev, 3).requires_grad_() if has_bias else None
+    res = rnd((R, N), dev, 4).bfloat16().requires_grad_() if has_res else None
+    dy = rnd((R, N), dev, 5).bfloat16()
+    y = G.linear(x, w, b, res)
+    y.backward(dy)
+    xd, wd = x.detach().double(), w.detach().bfloat16().double()
+    ref = xd @ wd.t()
+    if has_bias:
+        ref = ref + b.detach().double()
+    if has_res:
+        ref = ref + res.detach().double()
+    close_bf16(y, ref, "y")
+    dyd = dy.double()
+    close_bf16(x.grad, dyd @ wd, "dx")
+    assert rel(w.grad, dyd.t() @ xd) <= 5e-4
+    if has_bias:
+        assert rel(b.grad, dyd.sum(0)) <= 5e-4
+    if has_res:
+        assert torch.equal(res.grad, dy)
+    # bit-identical rerun (fixed-order split-K and slab sums)
+    x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    y2 = G.linear(x2, w2, None if b is None else b.detach(), None if res is None else res.detach())
+    y2.backward(dy)
+    assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad) and torch.equal(w2.grad, w.grad)
+
+
+def test_linear_on_strided_rows_and_nd_input(gpu_device):
+    """rows that are a column slice of a wider tensor (row stride > K) and a 4-D input"""
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    wide = rnd((2, 16, 24, 160), dev, 7).bfloat16()
+    x = wide[..., 32:128]                       # K = 96, row stride 160, base offset 64 B
+    w = rnd((136, 96), dev, 8) / 10
+    y = G.linear(x, w)
+    close_bf16(y, x.double() @ w.bfloat16().double().t(), "y")
+    assert y.shape == (2, 16, 24, 136)
+
+
+@pytest.mark.parametrize("R,K,Hd", [(3000, 96, 384), (512, 384, 1536), (16384, 48, 192)])
+def test_mlp_node_vs_float64(gpu_device, R, K, Hd):
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    x = rnd((R, K), dev, 11).bfloat16().requires_grad_()
+    w1 = (rnd((Hd, K), dev, 12) / K ** 0.5).requires_grad_()
+    b1 = rnd((Hd,), dev, 13, 0.5).requires_grad_()
+    w2 = (rnd((K, Hd), dev, 14) / Hd ** 0.5).requires_grad_()
+    b2 = rnd((K,), dev, 15, 0.5).requires_grad_()
+    dy = rnd((R, K), dev, 16).bfloat16()
+    y = G.mlp(x, w1, b1, w2, b2, res=x)
+    y.backward(dy)
+    # reference in float64 with the roundings the node makes: pre-activation h and g = gelu(h) are stored as bf16
+    xd = x.detach().double().requires_grad_()
+    w1d, w2d = w1.detach().bfloat16().double().requires_grad_(), w2.detach().bfloat16().double().requires_grad_()
+    b1d, b2d = b1.detach().double().requires_grad_(), b2.detach().double().requires_grad_()
+    h = (xd @ w1d.t() + b1d)
+    g = F.gelu(h.detach().bfloat16().double() + (h - h.detach()))            # value rounded, gradient through
+    g = g.detach().bfloat16().double() + (g - g.detach())
+    ref = g @ w2d.t() + b2d + xd
+    ref.backward(dy.double())
+    close_bf16(y, ref, "y")
+    close_bf16(x.grad, xd.grad, "dx")
+    assert rel(w1.grad, w1d.grad) <= 3e-3 and rel(w2.grad, w2d.grad) <= 1e-3      # dh is rounded to bf16 before the first layer's products
+    assert rel(b1.grad, b1d.grad) <= 3e-3 and rel(b2.grad, b2d.grad) <= 5e-4
+
+
+CONV_CASES = [
+    # B, H, W, Ci, Co, k
+    (2, 32, 32, 128, 128, 3),
+    (2, 16, 16, 256, 256, 3),       # split-K
+    (1, 20, 12, 64, 136, 3),        # ragged map, outputs off the tile width
+    (2, 16, 16, 1024, 1024, 3),     # UNETR++ stage 3 (K = 9216: 8 splits)
+    (2, 24, 40, 96, 48, 3),         # Swin decoder widths
+    (2, 16, 16, 512, 512, 1),       # 1x1 (conv8)
+    (3, 128, 128, 128, 128, 3),     # 3 x 128 tiles of rows, no split
+]
+
+
+def conv_ref(x, w, k):
+    """float64 convolution of the bf16-rounded operands on the device: one matmul per tap"""
+    B, H, W, Ci = x.shape
+    Co = w.shape[0]
+    xd, wd = x.double(), w.bfloat16().double()
+    if k == 1:
+        return (xd.reshape(-1, Ci) @ wd.reshape(Co, Ci).t()).view(B, H, W, Co)
+    xp = F.pad(xd, (0, 0, 1, 1, 1, 1))
+    y = torch.zeros(B, H, W, Co, dtype=torch.float64, device=x.device)
+    for ky in range(3):
+        for kx in range(3):
+            y += (xp[:, ky:ky + H, kx:kx + W, :].reshape(-1, Ci) @ wd[:, :, ky, kx].t()).view(B, H, W, Co)
+    return y
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,k", CONV_CASES)
+def test_convolution_forward_and_gradients_vs_float64(gpu_device, B, H, W, Ci, Co, k):
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    x = rnd((B, H, W, Ci), dev, 21).bfloat16().requires_grad_()
+    w = (rnd((Co, Ci, k, k), dev, 22) / (Ci * k * k) ** 0.5).requires_grad_()
+    dy = rnd((B, H, W, Co), dev, 23).bfloat16()
+    y, stats = G.conv2d_nhwc(x, w, want_stats=True)
+    y.backward(dy)
+    ref = conv_ref(x.detach(), w.detach(), k)
+    close_bf16(y, ref, "y")
+    # statistics of the ROUNDED output, from the drain
+    yd = y.detach().double().reshape(-1, Co)
+    s = stats.double().sum(0)
+    assert float(((s[0] - yd.sum(0)).abs() / yd.abs().sum(0).clamp_min(1e-30)).max()) <= 1e-5
+    assert rel(s[1], (yd * yd).sum(0)) <= 1e-5
+    # data gradient = convolution of dy with the transposed, flipped kernel; weight gradient = sum over pixels
+    dyd = dy.double()
+    wt = w.detach().transpose(0, 1).flip(2, 3).contiguous() if k == 3 else w.detach().transpose(0, 1).contiguous()
+    close_bf16(x.grad, conv_ref(dy, wt, k), "dx")
+    xd = x.detach().double()
+    if k == 3:
+        xp = F.pad(xd, (0, 0, 1, 1, 1, 1))
+        gw = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, device=dev)
+        for ky in range(3):
+            for kx in range(3):
+                gw[:, :, ky, kx] = dyd.reshape(-1, Co).t() @ xp[:, ky:ky + H, kx:kx + W, :].reshape(-1, Ci)
+    else:
+        gw = (dyd.reshape(-1, Co).t() @ xd.reshape(-1, Ci)).view(Co, Ci, 1, 1)
+    assert rel(w.grad, gw) <= 5e-4
+    # reruns are bit-identical
+    x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    y2, stats2 = G.conv2d_nhwc(x2, w2, want_stats=True)
+    y2.backward(dy)
+    assert torch.equal(y2, y) and torch.equal(stats2, stats) and torch.equal(x2.grad, x.grad) and torch.equal(w2.grad, w.grad)
+
+
+def test_convolution_with_bias_residual_and_wider_input_map(gpu_device):
+    """1x1 convolution with bias + residual (UNETR++'s conv8), and a 3x3 one reading the first 64 channels of a 96-channel map"""
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    x = rnd((2, 16, 16, 256), dev, 31).bfloat16().requires_grad_()
+    w = (rnd((256, 256, 1, 1), dev, 32) / 16).requires_grad_()
+    b = rnd((256,), dev, 33).requires_grad_()
+    skip = rnd((2, 16, 16, 256), dev, 34).bfloat16().requires_grad_()
+    dy = rnd((2, 16, 16, 256), dev, 35).bfloat16()
+    y = G.conv2d_nhwc(x, w, b, res=skip)
+    y.backward(dy)
+    close_bf16(y, conv_ref(x.detach(), w.detach(), 1) + b.detach().double() + skip.detach().double(), "y")
+    assert rel(b.grad, dy.double().sum((0, 1, 2))) <= 5e-4 and torch.equal(skip.grad, dy)
+    xw = rnd((1, 24, 24, 96), dev, 36).bfloat16().requires_grad_()
+    w3 = (rnd((64, 64, 3, 3), dev, 37) / 24).requires_grad_()
+    y3 = G.conv2d_nhwc(xw, w3)
+    y3.backward(torch.ones_like(y3))
+    close_bf16(y3, conv_ref(xw.detach()[..., :64], w3.detach(), 3), "y3")
+    assert float(xw.grad[..., 64:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C,slope,with_res", [(128, 0.01, False), (256, 0.01, True), (1024, 1.0, False)])
+def test_batch_norm_node_vs_torch_float64(gpu_device, C, slope, with_res):
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    B, H, W = 2, 16, 16
+    x = rnd((B, H, W, C // 2), dev, 41).bfloat16()
+    w = rnd((C, C // 2, 3, 3), dev, 42) / (C * 4.5) ** 0.5
+    bn = torch.nn.BatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * rnd((C,), dev, 43))
+        bn.bias.copy_(0.1 * rnd((C,), dev, 44))
+    ref_bn = torch.nn.BatchNorm2d(C).to(dev).double()
+    ref_bn.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    res = rnd((B, H, W, C), dev, 45).bfloat16().requires_grad_() if with_res else None
+    dy = rnd((B, H, W, C), dev, 46).bfloat16()
+    y, stats = G.conv2d_nhwc(x, w, want_stats=True)
+    yl = y.detach().requires_grad_()
+    out = G.batch_norm_act(yl, stats, bn, slope, res)
+    out.backward(dy)
+    yr = yl.detach().double().requires_grad_()
+    rr = None if res is None else res.detach().double().requires_grad_()
+    o = ref_bn(yr.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    if rr is not None:
+        o = o + rr
+    o = F.leaky_relu(o, slope) if slope != 1.0 else o
+    o.backward(dy.double())
+    close_bf16(out, o, "out")
+    close_bf16(yl.grad, yr.grad, "dy")
+    assert rel(bn.weight.grad, ref_bn.weight.grad) <= 5e-3 and rel(bn.bias.grad, ref_bn.bias.grad) <= 5e-3
+    assert rel(bn.running_mean, ref_bn.running_mean) <= 1e-4 and rel(bn.running_var, ref_bn.running_var) <= 1e-4
+    if with_res:
+        close_bf16(res.grad, rr.grad, "dres")
+    # eval mode: running statistics
+    bn.eval(), ref_bn.eval()
+    oe = G.batch_norm_act(y.detach(), None, bn, slope, None)
+    re_ = ref_bn(y.detach().double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    close_bf16(oe, F.leaky_relu(re_, slope) if slope != 1.0 else re_, "eval out")
+
+
+def test_weight_images_follow_the_parameter_version(gpu_device):
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    w = torch.nn.Parameter(rnd((64, 32, 3, 3), dev, 51))
+    f1, d1 = G.weight_images(w, 9)
+    assert G.weight_images(w, 9)[0] is f1
+    ref = w.detach().permute(0, 2, 3, 1).reshape(64, 9 * 32).bfloat16()
+    assert torch.equal(f1, ref)
+    refd = w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(32, 9 * 64).bfloat16()
+    assert torch.equal(d1, refd)
+    with torch.no_grad():
+        w.mul_(2.0)
+    f2, _ = G.weight_images(w, 9)
+    assert f2 is not f1 and torch.equal(f2, (ref.float() * 2).bfloat16())
+
+
+def test_no_cpu_path(gpu_device):
+    from py4cast_amd import _lib as L
+    from py4cast_amd import ops_gemm as G
+
+    with pytest.raises(L.P4CError):
+        G.linear(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(8, 8))
+    with pytest.raises(L.P4CError):
+        G.conv2d_nhwc(torch.zeros(1, 4, 4, 8, dtype=torch.bfloat16), torch.zeros(8, 8, 3, 3))
