@@ -117,8 +117,9 @@ __device__ __forceinline__ void epi_piece(const Epi& e, float (&v)[8], int64_t m
     }
 }
 
-// column sums of the 16 row groups (threadIdx.x >> 4) of a 256-thread block, thread's 8 columns = 8 * (threadIdx.x & 15) ..:
+// column sums of the NRG row groups (threadIdx.x >> 4) of a 16 NRG-thread block, thread's 8 columns = 8 * (threadIdx.x & 15) ..:
 // fixed order, written to stats[blk][0 / 1][n0 + col].  red: 16 * 2 * 128 floats of LDS (free at this point).
+template <int NRG>
 __device__ __forceinline__ void stats_block_reduce(float* red, const float (&s1)[8], const float (&s2)[8], float* stats, int blk,
                                                    int n0, int N) {
     const int ch = threadIdx.x & 15, rg = threadIdx.x >> 4;
@@ -128,11 +129,13 @@ __device__ __forceinline__ void stats_block_reduce(float* red, const float (&s1)
         red[(rg * 2 + 1) * 128 + ch * 8 + j] = s2[j];
     }
     __syncthreads();
-    const int which = threadIdx.x >> 7, col = threadIdx.x & 127;
-    float t = 0.f;
+    if (threadIdx.x < 256) {
+        const int which = threadIdx.x >> 7, col = threadIdx.x & 127;
+        float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) t += red[(g * 2 + which) * 128 + col];
-    if (n0 + col < N) stats[((int64_t)blk * 2 + which) * N + n0 + col] = t;
+        for (int g = 0; g < NRG; ++g) t += red[(g * 2 + which) * 128 + col];
+        if (n0 + col < N) stats[((int64_t)blk * 2 + which) * N + n0 + col] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ NT kernel
@@ -153,26 +156,52 @@ struct NtArgs {
 // ds_read_b128 lane group fall on the 16 different 16-byte slots of the 256-byte bank row)
 __device__ __forceinline__ int nt_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
+#ifndef P4C_NT_EXP
+#define P4C_NT_EXP 0      // timing experiments of diagnostic builds only (results become wrong): 1 no epilogue, 2 no products, 4 no A loads, 8 no B loads
+#endif
+constexpr int NT_STAGES = 4;                 // LDS ring: 4 x (A 16 KB + B 16 KB); k-blocks t+1 .. t+3 in flight while t is multiplied
+constexpr int NT_STAGE_BYTES = 32768;
+typedef __attribute__((address_space(3))) char* lds_ptr;
+
+// One direct-to-LDS load (buffer_load_dwordx4 ... lds): 64 lanes x 16 bytes land at lds_addr + 16 lane (lds_addr wave-uniform); an
+// out-of-range offset lands as zeros.  Inline asm ON PURPOSE: given the builtin, hipcc (ROCm 7.2) orders every later ds_read behind
+// the transfer with s_waitcnt vmcnt(0) -- the whole ring drained before each k-step (the round's first version ran that way: 41 us
+// instead of 20 for the stage-0 weight gradient).  The kernels count these loads themselves (s_waitcnt vmcnt(N) + s_barrier before the
+// reads).  M0 is saved and restored around the statement (the compiler owns it).
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned int voff, unsigned int lds_addr) {
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned int lds_address(const void* p) { return (unsigned int)(size_t)((lds_ptr)p); }
+
 template <bool CONV>
-__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(NtArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][A 16 KB | B 16 KB]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+__global__ void __launch_bounds__(512, 2) gemm_nt_kernel(NtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [4][A 16 KB | B 16 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, tm = tile % a.tiles_m, tn = tile / a.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int kb0 = split * a.kb_per_split;
     int kb1 = kb0 + a.kb_per_split;
     if (kb1 > a.nkb) kb1 = a.nkb;
+    const int nblk = kb1 - kb0;
 
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A, a.a_bytes), rsB = make_rsrc(a.B, a.b_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.A, (P4C_NT_EXP & 4) ? 0u : a.a_bytes), rsB = make_rsrc(a.B, (P4C_NT_EXP & 8) ? 0u : a.b_bytes);
+    const unsigned int smem_lds = lds_address(smem);
 
-    // loader role: chunk c of rows lr + 32 it (it = 0..3) of both tiles
-    const int c = tid & 7, lr = tid >> 3;
-    unsigned int a_row[4], b_row[4];         // byte offsets of the rows (OOB: row outside the matrix)
-    int py[4], px[4];
+    // loader role (every wave).  Both tiles go to LDS by direct loads (buffer_load ... lds): one wave instruction fills 1 KiB = 8
+    // tile rows, lane -> (row 8 q + (lane >> 3), 16-byte slot lane & 7); the slot holds chunk slot ^ ((row >> 1) & 7) of the row
+    // (nt_off), so the swizzle is applied to the SOURCE address.  Wave wv issues pieces q = 2 wv + it (it = 0, 1) of both tiles, one
+    // piece after each k-step's products (the matrix pipe works on them while the piece is issued); out-of-range offsets (rows beyond
+    // the matrix, k beyond K, the convolution's zero padding) land as zeros.
+    unsigned int a_row[2], b_row[2];         // byte offsets of the rows (OOB: row outside the matrix)
+    int py[2], px[2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int m = m0 + lr + 32 * it, n = n0 + lr + 32 * it;
+    for (int it = 0; it < 2; ++it) {
+        const int row = 16 * wv + 8 * it + (lane >> 3);
+        const int m = m0 + row, n = n0 + row;
         a_row[it] = m < a.M ? (unsigned int)((int64_t)m * a.lda * 2) : OOB;
         b_row[it] = n < a.N ? (unsigned int)((int64_t)n * a.ldb * 2) : OOB;
         if (CONV) {
@@ -181,78 +210,82 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(NtArgs a) {
             px[it] = p - py[it] * a.W;
         }
     }
-    int k = kb0 * BK + c * 8;                // this thread's k of the current block
-    int tap = 0, ci = k;
-    if (CONV) { tap = k / a.Cin; ci = k - tap * a.Cin; }
-
-    u32x4 ra[4], rb[4];
-    auto issue = [&]() __attribute__((always_inline)) {
-        const bool kin = k < a.K;
-        if (CONV) {
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const int shift = (dy * a.W + dx) * (int)a.lda * 2 + ci * 2;
+    // the chunk a lane fetches: (lane & 7) ^ (4 it + (lane >> 4))
+    int kq[2], tap[2], ci[2];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 2; ++it) {
+        const int c = (lane & 7) ^ ((it << 2) | (lane >> 4));
+        kq[it] = kb0 * BK + c * 8;
+        tap[it] = 0;
+        ci[it] = kq[it];
+        if (CONV) { tap[it] = kq[it] / a.Cin; ci[it] = kq[it] - tap[it] * a.Cin; }
+    }
+    // piece 0: A it 0, 1: B it 0, 2: A it 1, 3: B it 1 of the k-block the lane's k state points at
+    auto issue_piece = [&](int stage, int piece) __attribute__((always_inline)) {
+        const unsigned int base = smem_lds + stage * NT_STAGE_BYTES + wv * 2048;
+        const int it = piece >> 1;
+        const bool kin = kq[it] < a.K;
+        if ((piece & 1) == 0) {
+            unsigned int oa;
+            if (CONV) {
+                const int dy = tap[it] / 3 - 1, dx = tap[it] - (tap[it] / 3) * 3 - 1;
+                const int shift = (dy * a.W + dx) * (int)a.lda * 2 + ci[it] * 2;
                 const bool ok = kin && a_row[it] != OOB && (unsigned)(py[it] + dy) < (unsigned)a.H && (unsigned)(px[it] + dx) < (unsigned)a.W;
-                ra[it] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_row[it] + shift : OOB, 0, 0);
+                oa = ok ? a_row[it] + shift : OOB;
+            } else {
+                oa = (kin && a_row[it] != OOB) ? a_row[it] + kq[it] * 2 : OOB;
             }
+            dma16(rsA, oa, base + it * 1024);
         } else {
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-                ra[it] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (kin && a_row[it] != OOB) ? a_row[it] + k * 2 : OOB, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            rb[it] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (kin && b_row[it] != OOB) ? b_row[it] + k * 2 : OOB, 0, 0);
-        k += BK;
-        if (CONV) {
-            ci += BK;
-            while (ci >= a.Cin) { ci -= a.Cin; ++tap; }
-        }
-    };
-    auto stash = [&](int buf) __attribute__((always_inline)) {
-        char* ba = smem + buf * 32768;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            *reinterpret_cast<u32x4*>(ba + nt_off(lr + 32 * it, c)) = ra[it];
-            *reinterpret_cast<u32x4*>(ba + 16384 + nt_off(lr + 32 * it, c)) = rb[it];
-        }
-    };
-
-    // compute role: wave (wn, wm) owns n rows 64 wn .. +63 (MFMA A operand, i) x m rows 64 wm .. +63 (B operand, j)
-    const int wn = wv & 1, wm = wv >> 1, r = lane & 31, h = lane >> 5;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-
-    if (kb0 < kb1) {
-        issue();
-        stash(0);
-        __syncthreads();
-        for (int kb = kb0; kb < kb1; ++kb) {
-            const int cur = (kb - kb0) & 1;
-            const bool more = kb + 1 < kb1;
-            if (more) issue();
-            const char* ba = smem + cur * 32768;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 wf[2], xf[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    wf[i] = *reinterpret_cast<const bf16x8*>(ba + 16384 + nt_off(64 * wn + 32 * i + r, 2 * s + h));
-                    xf[i] = *reinterpret_cast<const bf16x8*>(ba + nt_off(64 * wm + 32 * i + r, 2 * s + h));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            const unsigned int ob = (kin && b_row[it] != OOB) ? b_row[it] + kq[it] * 2 : OOB;
+            dma16(rsB, ob, base + 16384 + it * 1024);
+            kq[it] += BK;             // both pieces of this `it` are out: on to the next k-block
+            if (CONV) {
+                ci[it] += BK;
+                while (ci[it] >= a.Cin) { ci[it] -= a.Cin; ++tap[it]; }
             }
-            if (more) stash(cur ^ 1);
-            __syncthreads();
+        }
+    };
+
+    // compute role: wave (wn, wm) owns n rows 64 wn .. +63 (MFMA A operand, i) x m rows 32 wm .. +31 (B operand, j)
+    const int wn = wv & 1, wm = wv >> 1, r = lane & 31, h = lane >> 5;
+    f32x16 acc[2];
+    acc[0] = zero16();
+    acc[1] = zero16();
+
+#pragma unroll
+    for (int p = 0; p < NT_STAGES - 1; ++p)
+        if (p < nblk) {
+#pragma unroll
+            for (int piece = 0; piece < 4; ++piece) issue_piece(p, piece);
+        }
+    for (int t = 0; t < nblk; ++t) {
+        // block t has landed once at most the pieces of the (up to two) younger blocks are outstanding: 4 direct loads per block and wave
+        const int younger = nblk - 1 - t;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of block t are in LDS; every wave is done reading block t - 1
+        asm volatile("" ::: "memory");
+        const bool more = t + NT_STAGES - 1 < nblk;
+        const int nstage = (t + NT_STAGES - 1) & (NT_STAGES - 1);     // the stage block t - 1 occupied
+        const char* ba = smem + (t & (NT_STAGES - 1)) * NT_STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(ba + nt_off(32 * wm + r, 2 * s + h));
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(ba + 16384 + nt_off(64 * wn + r, 2 * s + h));
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(ba + 16384 + nt_off(64 * wn + 32 + r, 2 * s + h));
+            if (!(P4C_NT_EXP & 2)) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf, acc[1], 0, 0, 0);
+            } else {
+                asm volatile("" :: "v"(w0), "v"(w1), "v"(xf));
+            }
+            if (more) issue_piece(nstage, s);
         }
     }
+    __syncthreads();        // the staging tile below reuses stage 0
+    if ((P4C_NT_EXP & 1) && acc[0][0] != 12345.678f) return;
 
     // ---- epilogue: two phases of 64 output rows through an fp32 LDS tile [64][132]
     float* stage = reinterpret_cast<float*>(smem);
@@ -264,21 +297,19 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(NtArgs a) {
     float* slab = a.splits > 1 ? a.partial + ((int64_t)split * gridDim.x + tile) * (BM * BN) : nullptr;
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
-        if (wm == ph) {
+        if ((wm >> 1) == ph) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        *reinterpret_cast<f32x4*>(stage + (32 * j + r) * 132 + 64 * wn + 32 * i + 8 * q + 4 * h) = v;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(stage + (32 * (wm & 1) + r) * 132 + 64 * wn + 32 * i + 8 * q + 4 * h) = v;
+                }
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = rg + 16 * it;
+        for (int it = 0; it < 2; ++it) {
+            const int row = rg + 32 * it;
             const int64_t m = m0 + 64 * ph + row;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * 132 + ch * 8);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * 132 + ch * 8 + 4);
@@ -292,7 +323,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(NtArgs a) {
         }
         __syncthreads();
     }
-    if (!slab && a.e.stats) stats_block_reduce(stage, s1, s2, a.e.stats, tm, n0, a.N);
+    if (!slab && a.e.stats) stats_block_reduce<32>(stage, s1, s2, a.e.stats, tm, n0, a.N);
 }
 
 // sums the split-K slabs of one 32-row band of a tile in split order, then the epilogue.  grid (tiles, 4)
@@ -326,7 +357,7 @@ __global__ void __launch_bounds__(256) gemm_nt_reduce_kernel(NtRedArgs a) {
             epi_piece(a.e, v, m, n, s1, s2);
         }
     }
-    if (a.e.stats) stats_block_reduce(red, s1, s2, a.e.stats, tm * 4 + band, tn * BN, a.N);
+    if (a.e.stats) stats_block_reduce<16>(red, s1, s2, a.e.stats, tm * 4 + band, tn * BN, a.N);
 }
 
 // ------------------------------------------------------------------------------------------------ TN kernel (weight gradients)
@@ -340,111 +371,151 @@ struct TnArgs {
     int tiles_i, tiles_j;
     int nrb, splits, rb_per_split;
     float* partial;         // [split][tile][128][128]
-    float* bias_partial;    // [split][tiles_i][128] or NULL
+    float* bias_partial;    // [split][tiles_i][4][128] or NULL
 };
 
-constexpr int TN_ROW = 320;                  // bytes per LDS row of 128 bf16 (+ 64: the 4 rows of a transposed read hit 4 bank quarters)
-constexpr int TN_TILE = 64 * TN_ROW;         // 20 480 B
+#ifndef P4C_TN_EXP
+#define P4C_TN_EXP 0      // timing experiments of diagnostic builds only (results become wrong): 1 no slab stores, 2 no products, 4 no loads
+#endif
+constexpr int TN_STAGES = 4;
+constexpr int TN_STAGE_BYTES = 32768;        // P tile [64 r][128] bf16 (16 KB) | Q tile (16 KB), 256-byte rows
+// 16-byte chunk ch (0..15) of tile row `row` sits in slot ch ^ tn_swz(row): the four rows of a transposed read (ds_read_b64_tr_b16)
+// and the two 16-column blocks of a 32-lane half then cover the 256-byte bank row exactly once (conflict-free)
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 template <bool CONV, bool BIAS>
-__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][P tile | Q tile]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+__global__ void __launch_bounds__(512, 2) gemm_tn_kernel(TnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [4][P tile | Q tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, ti = tile % a.tiles_i, tj = tile / a.tiles_i;
     const int i0 = ti * 128, j0 = tj * 128;
     const int split = blockIdx.y;
     const int rb0 = split * a.rb_per_split;
     int rb1 = rb0 + a.rb_per_split;
     if (rb1 > a.nrb) rb1 = a.nrb;
+    const int nblk = rb1 - rb0;
 
-    const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.P, a.p_bytes), rsQ = make_rsrc(a.Q, a.q_bytes);
-    // loader role: 16-byte chunk ch (8 columns) of rows lr + 16 it of both tiles
-    const int ch = tid & 15, lr = tid >> 4;
-    const bool p_ok = i0 + ch * 8 < a.Mo, q_ok = j0 + ch * 8 < a.No;
-    int tap = 0, ci = j0 + ch * 8, dy = 0, dx = 0;
-    if (CONV) {
-        tap = ci / a.Cin;
-        ci -= tap * a.Cin;
-        dy = tap / 3 - 1;
-        dx = tap - (tap / 3) * 3 - 1;
+    const __amdgpu_buffer_rsrc_t rsP = make_rsrc(a.P, (P4C_TN_EXP & 4) ? 0u : a.p_bytes), rsQ = make_rsrc(a.Q, (P4C_TN_EXP & 4) ? 0u : a.q_bytes);
+    const unsigned int smem_lds = lds_address(smem);
+    // loader role (every wave): direct loads to LDS, one wave instruction = 1 KiB = 4 tile rows; lane -> (row 4 q + (lane >> 4), slot
+    // lane & 15) fetches chunk slot ^ tn_swz(row).  Wave wv issues pieces q = 2 wv + it of both tiles.
+    // Per piece the lane keeps the byte offsets of its row in P and Q and, for a convolution, the pixel (y, x) of that row: all of it
+    // advances by 64 rows per k-block without a division or a 64-bit product in the loop.
+    int rrow[2], py[2], px[2];
+    unsigned int p_off[2], q_off[2];
+    int qdy[2], qdx[2];
+    bool p_ok[2], q_ok[2];
+    const unsigned int p_step = (unsigned int)(64 * a.ldp * 2), q_step = (unsigned int)(64 * a.ldq * 2);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = 8 * wv + 4 * it + (lane >> 4);
+        const int chk = (lane & 15) ^ tn_swz(row);
+        const int rr = rb0 * 64 + row;
+        rrow[it] = rr;
+        p_ok[it] = i0 + chk * 8 < a.Mo;
+        q_ok[it] = j0 + chk * 8 < a.No;
+        p_off[it] = (unsigned int)((int64_t)rr * a.ldp * 2) + (unsigned int)(i0 + chk * 8) * 2;
+        qdy[it] = 0;
+        qdx[it] = 0;
+        py[it] = 0;
+        px[it] = 0;
+        if (CONV) {
+            int col = j0 + chk * 8;
+            const int tap = col / a.Cin;
+            col -= tap * a.Cin;
+            qdy[it] = tap / 3 - 1;
+            qdx[it] = tap - (tap / 3) * 3 - 1;
+            q_off[it] = (unsigned int)((int64_t)rr * a.ldq * 2 + ((qdy[it] * a.W + qdx[it]) * (int)a.ldq + col) * 2);
+            const int p = rr % (a.H * a.W);
+            py[it] = p / a.W;
+            px[it] = p - py[it] * a.W;
+        } else {
+            q_off[it] = (unsigned int)((int64_t)rr * a.ldq * 2) + (unsigned int)(j0 + chk * 8) * 2;
+        }
     }
-    const unsigned int p_col = (unsigned int)(i0 + ch * 8) * 2;
-    const int q_shift = CONV ? ((dy * a.W + dx) * (int)a.ldq + ci) * 2 : (j0 + ch * 8) * 2;
-    float bs[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bs[j] = 0.f;
-
-    u32x4 rp[4], rq[4];
-    auto issue = [&](int rb) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rr = rb * 64 + lr + 16 * it;
-            const bool in = rr < a.R;
-            rp[it] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (in && p_ok) ? (unsigned int)((int64_t)rr * a.ldp * 2) + p_col : OOB, 0, 0);
-            bool ok = in && q_ok;
+    auto issue_piece = [&](int stage, int piece) __attribute__((always_inline)) {
+        const unsigned int base = smem_lds + stage * TN_STAGE_BYTES + wv * 2048;
+        const int it = piece >> 1;
+        const bool in = rrow[it] < a.R;
+        if ((piece & 1) == 0) {
+            dma16(rsP, (in && p_ok[it]) ? p_off[it] : OOB, base + it * 1024);
+        } else {
+            bool ok = in && q_ok[it];
+            if (CONV) ok = ok && (unsigned)(py[it] + qdy[it]) < (unsigned)a.H && (unsigned)(px[it] + qdx[it]) < (unsigned)a.W;
+            dma16(rsQ, ok ? q_off[it] : OOB, base + 16384 + it * 1024);
+            rrow[it] += 64;
+            p_off[it] += p_step;
+            q_off[it] += q_step;
             if (CONV) {
-                const int p = rr % (a.H * a.W);
-                const int y = p / a.W, x = p - y * a.W;
-                ok = ok && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W;
-            }
-            rq[it] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, ok ? (unsigned int)((int64_t)rr * a.ldq * 2 + q_shift) : OOB, 0, 0);
-        }
-    };
-    auto stash = [&](int buf) __attribute__((always_inline)) {
-        char* bp = smem + buf * (2 * TN_TILE);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            *reinterpret_cast<u32x4*>(bp + (lr + 16 * it) * TN_ROW + ch * 16) = rp[it];
-            *reinterpret_cast<u32x4*>(bp + TN_TILE + (lr + 16 * it) * TN_ROW + ch * 16) = rq[it];
-            if (BIAS) {
-                float v[8];
-                unpack8(rp[it], v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bs[j] += v[j];
+                px[it] += 64;
+                while (px[it] >= a.W) { px[it] -= a.W; ++py[it]; }
+                while (py[it] >= a.H) py[it] -= a.H;
             }
         }
     };
 
+    // compute role: wave (wi, wj) owns output rows i 64 wi .. +63 (MFMA A operand) x columns j 32 wj .. +31 (B operand)
     const int wi = wv & 1, wj = wv >> 1, h = lane >> 5, i16 = lane & 15, tg = (lane >> 4) & 1;
-    f32x16 acc[2][2];
+    const int q4 = i16 >> 2, p4 = i16 & 3;
+    // transposed-read byte address inside a tile for k-step 0: rows 8 h + q4 (+ 4 for the second read), the 16 columns of block cb
+    auto tr_addr = [&](int cb, int sec) __attribute__((always_inline)) {
+        const int chunk = (cb >> 3) + 2 * tg + (p4 >> 1);
+        return 256 * (8 * h + q4 + 4 * sec) + 16 * (chunk ^ ((q4 << 2) | ((2 * h + sec) & 3))) + 8 * (p4 & 1);
+    };
+    int pa[2][2], qa[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int sec = 0; sec < 2; ++sec) {
+        pa[0][sec] = tr_addr(64 * wi, sec);
+        pa[1][sec] = tr_addr(64 * wi + 32, sec);
+        qa[sec] = 16384 + tr_addr(32 * wj, sec);
+    }
+    f32x16 acc[2], accb[2];
+    acc[0] = zero16(); acc[1] = zero16(); accb[0] = zero16(); accb[1] = zero16();
+    const bool do_bias = BIAS && tj == 0;     // wave wj sums P's columns over the rows of k-step s == wj: four partial sums per column
+    bf16x8 ones;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-    // transposed-read address of this lane inside a tile, for k-step 0 / operand block 0
-    const int tr_base = (8 * h + (i16 >> 2)) * TN_ROW + (tg * 16 + (i16 & 3) * 4) * 2;
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    if (rb0 < rb1) {
-        issue(rb0);
-        stash(0);
-        __syncthreads();
-        for (int rb = rb0; rb < rb1; ++rb) {
-            const int cur = (rb - rb0) & 1;
-            const bool more = rb + 1 < rb1;
-            if (more) issue(rb + 1);
-            const char* bp = smem + cur * (2 * TN_TILE);
+    auto tr2 = [&](const char* p) __attribute__((always_inline)) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    };
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 pf[2], qf[2];
+    for (int p = 0; p < TN_STAGES - 1; ++p)
+        if (p < nblk) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    union { s16x4 v[2]; bf16x8 f; } up, uq;
-                    const char* pp = bp + tr_base + 16 * s * TN_ROW + (64 * wi + 32 * i) * 2;
-                    const char* qq = bp + TN_TILE + tr_base + 16 * s * TN_ROW + (64 * wj + 32 * i) * 2;
-                    up.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pp));
-                    up.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pp + 4 * TN_ROW));
-                    uq.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(qq));
-                    uq.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(qq + 4 * TN_ROW));
-                    pf[i] = up.f;
-                    qf[i] = uq.f;
-                }
+            for (int piece = 0; piece < 4; ++piece) issue_piece(p, piece);
+        }
+    for (int t = 0; t < nblk; ++t) {
+        const int younger = nblk - 1 - t;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = t + TN_STAGES - 1 < nblk;
+        const int nstage = (t + TN_STAGES - 1) & (TN_STAGES - 1);
+        const char* bp = smem + (t & (TN_STAGES - 1)) * TN_STAGE_BYTES;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[i], qf[j], acc[i][j], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            union { s16x4 v[2]; bf16x8 f; } u0, u1, uq;
+            u0.v[0] = tr2(bp + pa[0][0] + 4096 * s);
+            u0.v[1] = tr2(bp + pa[0][1] + 4096 * s);
+            u1.v[0] = tr2(bp + pa[1][0] + 4096 * s);
+            u1.v[1] = tr2(bp + pa[1][1] + 4096 * s);
+            uq.v[0] = tr2(bp + qa[0] + 4096 * s);
+            uq.v[1] = tr2(bp + qa[1] + 4096 * s);
+            if (!(P4C_TN_EXP & 2)) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u0.f, uq.f, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u1.f, uq.f, acc[1], 0, 0, 0);
+            } else {
+                asm volatile("" :: "v"(u0.f), "v"(u1.f), "v"(uq.f));
             }
-            if (more) stash(cur ^ 1);
-            __syncthreads();
+            if (do_bias && s == wj) {      // column sums of P on the matrix pipe: times a block of ones
+                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u0.f, ones, accb[0], 0, 0, 0);
+                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u1.f, ones, accb[1], 0, 0, 0);
+            }
+            if (more) issue_piece(nstage, s);
         }
     }
     // slab [i][j]: accumulator register e of lane (r, h) is element (i = (e & 3) + 8 (e >> 2) + 4 h, j = r): 128-byte row pieces
@@ -453,56 +524,56 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int e = 0; e < 16; ++e)
+            if (!(P4C_TN_EXP & 1) || acc[i][e] == 12345.678f)
+                slab[(64 * wi + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * 128 + 32 * wj + r] = acc[i][e];
+    if (do_bias && r == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                slab[(64 * wi + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * 128 + 64 * wj + 32 * j + r] = acc[i][j][e];
-    if (BIAS && tj == 0) {
-        float* red = reinterpret_cast<float*>(smem);      // [16][128]
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[lr * 128 + ch * 8 + j] = bs[j];
-        __syncthreads();
-        if (tid < 128) {
-            float t = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) t += red[g * 128 + tid];
-            a.bias_partial[((int64_t)split * a.tiles_i + ti) * 128 + tid] = t;
-        }
+                a.bias_partial[(((int64_t)split * a.tiles_i + ti) * 4 + wj) * 128 + 64 * wi + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h] = accb[i][e];
     }
 }
 
-// dW[(i * Cin + ci) * taps + tap] = sum_s slab[s][tile(i, j)][i % 128][j % 128], j = tap * Cin + ci;  db[i] = sum_s bias_partial[s][..][i]
+// dW[(i * Cin + ci) * taps + tap] = sum_s slab[s][tile(i, j)][i % 128][j % 128], j = tap * Cin + ci;  db[i] = sum over (s, wj) of
+// bias_partial.  One workgroup = output row i x a chunk of <= 512 input channels: the slab pieces are read along j (coalesced, four
+// splits in flight, summed in split order), turned through LDS and written along the torch layout's (ci, tap) order (coalesced).
 struct TnRedArgs {
     const float* partial;
     const float* bias_partial;
     float* dw;
     float* db;
-    int splits, tiles, tiles_i, Mo, No, Cin, taps;
+    int splits, tiles, tiles_i, Mo, No, Cin, taps, cchunk;
 };
 __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;      // quad index over [Mo][No / 4]
-    const int nq = a.No >> 2;
-    if (q < (int64_t)a.Mo * nq) {
-        const int i = (int)(q / nq), j = (int)(q - (int64_t)i * nq) * 4;
-        const int tile = (j >> 7) * a.tiles_i + (i >> 7);
-        const float* p = a.partial + (int64_t)tile * (128 * 128) + (i & 127) * 128 + (j & 127);
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < a.splits; ++s) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)s * a.tiles * (128 * 128));
-            t += v;
-        }
-        if (a.taps == 1) {
-            *reinterpret_cast<f32x4*>(a.dw + (int64_t)i * a.No + j) = t;
-        } else {
-            const int tap = j / a.Cin, ci = j - tap * a.Cin;         // Cin % 4 == 0: the quad stays inside one tap
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a.dw[((int64_t)i * a.Cin + ci + e) * a.taps + tap] = t[e];
-        }
-    }
-    if (a.db && q < a.Mo) {
-        const int i = (int)q;
+    __shared__ float turn[9 * 512];
+    const int i = blockIdx.y, c0 = blockIdx.x * a.cchunk;
+    const int cn = a.Cin - c0 < a.cchunk ? a.Cin - c0 : a.cchunk;
+    const int64_t sstride = (int64_t)a.tiles * (128 * 128);
+    for (int e = threadIdx.x; e < a.taps * cn; e += 256) {
+        const int tap = e / cn, c = e - tap * cn;
+        const int j = tap * a.Cin + c0 + c;
+        const float* p = a.partial + ((int64_t)(j >> 7) * a.tiles_i + (i >> 7)) * (128 * 128) + (i & 127) * 128 + (j & 127);
         float t = 0.f;
-        for (int s = 0; s < a.splits; ++s) t += a.bias_partial[((int64_t)s * a.tiles_i + (i >> 7)) * 128 + (i & 127)];
+        int s = 0;
+        for (; s + 4 <= a.splits; s += 4) {
+            const float v0 = p[s * sstride], v1 = p[(s + 1) * sstride], v2 = p[(s + 2) * sstride], v3 = p[(s + 3) * sstride];
+            t = (((t + v0) + v1) + v2) + v3;
+        }
+        for (; s < a.splits; ++s) t += p[s * sstride];
+        turn[tap * cn + c] = t;
+    }
+    __syncthreads();
+    float* out = a.dw + ((int64_t)i * a.Cin + c0) * a.taps;
+    for (int e = threadIdx.x; e < a.taps * cn; e += 256) {
+        const int c = e / a.taps, tap = e - c * a.taps;
+        out[e] = turn[tap * cn + c];
+    }
+    if (a.db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int s = 0; s < a.splits; ++s)
+            for (int w = 0; w < 4; ++w) t += a.bias_partial[(((int64_t)s * a.tiles_i + (i >> 7)) * 4 + w) * 128 + (i & 127)];
         a.db[i] = t;
     }
 }
@@ -566,8 +637,9 @@ __global__ void __launch_bounds__(256) bnorm_finalize_kernel(const float* __rest
 }
 
 int pick_splits(int tiles, int nblocks) {
-    // fill ~2 workgroups per CU; at least 4 k-blocks per split so that a slab's traffic stays below its products' time
-    const int want = 2 * num_cus();
+    // one workgroup per CU (the kernels' LDS rings fill it); at least 4 k-blocks per split so that a slab's traffic stays below
+    // its products' time
+    const int want = num_cus();
     int s = (want + tiles - 1) / tiles;
     if (s > nblocks / 4) s = nblocks / 4;
     if (s < 1) s = 1;
@@ -644,14 +716,14 @@ extern "C" int p4c_gemm_nt(const void* A, int64_t lda, const void* Bimg, int M, 
     a.partial = (float*)workspace;
     a.e.bias = bias; a.e.res = (const bf16*)res; a.e.ldr = ldr; a.e.aux_in = (const bf16*)aux_in; a.e.aux_out = (bf16*)aux_out;
     a.e.ldaux = ldaux; a.e.C = (bf16*)C; a.e.ldc = ldc; a.e.stats = stats; a.e.act = act;
-    const int tiles = a.tiles_m * a.tiles_n, smem = 65536;
+    const int tiles = a.tiles_m * a.tiles_n, smem = NT_STAGES * NT_STAGE_BYTES;
     hipStream_t st = as_stream(stream);
     if (taps == 9) {
         P4C_TRY(ensure_dyn_smem((const void*)gemm_nt_kernel<true>, smem));
-        hipLaunchKernelGGL((gemm_nt_kernel<true>), dim3(tiles, a.splits), dim3(256), smem, st, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<true>), dim3(tiles, a.splits), dim3(512), smem, st, a);
     } else {
         P4C_TRY(ensure_dyn_smem((const void*)gemm_nt_kernel<false>, smem));
-        hipLaunchKernelGGL((gemm_nt_kernel<false>), dim3(tiles, a.splits), dim3(256), smem, st, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<false>), dim3(tiles, a.splits), dim3(512), smem, st, a);
     }
     P4C_CHECK_LAUNCH("gemm_nt");
     if (a.splits > 1) {
@@ -676,7 +748,7 @@ extern "C" size_t p4c_gemm_tn_workspace_bytes(int R, int Mo, int No) {
     if (R <= 0 || Mo <= 0 || No <= 0) return 0;
     int ti, tj, nrb, s, rbps;
     tn_plan(R, Mo, No, &ti, &tj, &nrb, &s, &rbps);
-    return ((size_t)s * ti * tj * 128 * 128 + (size_t)s * ti * 128) * sizeof(float);
+    return ((size_t)s * ti * tj * 128 * 128 + (size_t)s * ti * 4 * 128) * sizeof(float);
 }
 
 // dW (Mo, Cin, taps) fp32 = sum over the R rows of dy^T (x) [x or its 3x3 im2col view], db (Mo) = column sums of dy (or NULL)
@@ -696,20 +768,23 @@ extern "C" int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t l
     const int tiles = a.tiles_i * a.tiles_j;
     a.partial = (float*)workspace;
     a.bias_partial = db ? (float*)workspace + (size_t)a.splits * tiles * 128 * 128 : nullptr;
-    const int smem = 2 * 2 * TN_TILE;
+    const int smem = TN_STAGES * TN_STAGE_BYTES;
     hipStream_t st = as_stream(stream);
 #define P4C_TN_LAUNCH(CV, BS)                                                                         \
     do {                                                                                              \
         P4C_TRY(ensure_dyn_smem((const void*)gemm_tn_kernel<CV, BS>, smem));                          \
-        hipLaunchKernelGGL((gemm_tn_kernel<CV, BS>), dim3(tiles, a.splits), dim3(256), smem, st, a);  \
+        hipLaunchKernelGGL((gemm_tn_kernel<CV, BS>), dim3(tiles, a.splits), dim3(512), smem, st, a);  \
     } while (0)
     if (taps == 9) { if (db) P4C_TN_LAUNCH(true, true); else P4C_TN_LAUNCH(true, false); }
     else { if (db) P4C_TN_LAUNCH(false, true); else P4C_TN_LAUNCH(false, false); }
 #undef P4C_TN_LAUNCH
     P4C_CHECK_LAUNCH("gemm_tn");
-    TnRedArgs r{a.partial, a.bias_partial, dw, db, a.splits, tiles, a.tiles_i, Mo, a.No, Cin, taps};
-    const int64_t quads = (int64_t)Mo * (a.No / 4);
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, r);
+    // input channels per workgroup of the reduction: as many as keep >= ~1024 workgroups (a workgroup's splits are summed serially)
+    int cchunk = 512;
+    while (cchunk > 32 && (int64_t)((Cin + cchunk - 1) / cchunk) * Mo < 1024) cchunk >>= 1;
+    if (cchunk > Cin) cchunk = Cin;
+    TnRedArgs r{a.partial, a.bias_partial, dw, db, a.splits, tiles, a.tiles_i, Mo, a.No, Cin, taps, cchunk};
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((Cin + cchunk - 1) / cchunk, Mo), dim3(256), 0, st, r);
     P4C_CHECK_LAUNCH("gemm_tn_reduce");
     return P4C_OK;
 }
