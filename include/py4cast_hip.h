@@ -523,6 +523,15 @@ int p4c_row_layernorm_fwd(const void* x, const void* res, const float* gamma, co
 size_t p4c_row_layernorm_bwd_workspace_bytes(int64_t R, int C, int dtype);
 int p4c_row_layernorm_bwd(const void* dy, const void* x, const float* gamma, float eps, void* dx, float* dgamma, float* dbeta,
                           void* workspace, int64_t R, int C, int dtype, p4c_stream_t stream);
+/* (x + add) -> LayerNorm on rows of up to 2 KiB (UNETR++'s token rows with their positional embedding, 128 ... 1024 features):
+ * t[r] = x[r] + add[r % add_rows] (add may be NULL: t = x), sum_out[r] = t[r] (optional), out[r] = LayerNorm(t[r]) * gamma + beta.
+ * Backward: dt = LN_backward(dy; t) + extra (extra, optional: the gradient reaching t from its other consumers), dgamma / dbeta as
+ * p4c_row_layernorm_bwd; workspace p4c_row_add_layernorm_bwd_workspace_bytes(R, C). */
+int p4c_row_add_layernorm_fwd(const void* x, const void* add, int64_t add_rows, const float* gamma, const float* beta, float eps,
+                              void* sum_out, void* out, int64_t R, int C, int dtype, p4c_stream_t stream);
+size_t p4c_row_add_layernorm_bwd_workspace_bytes(int64_t R, int C);
+int p4c_row_add_layernorm_bwd(const void* dy, const void* t, const void* extra, const float* gamma, float eps, void* dt, float* dgamma,
+                              float* dbeta, void* workspace, int64_t R, int C, int dtype, p4c_stream_t stream);
 /* Weight and bias gradient of y = x W^T + b over R >> O rows:  dw_db[0 .. O*K) = dW[o][k] = sum_r dy[r][o] x[r][k],
  * dw_db[O*K .. O*K+O) = db[o] = sum_r dy[r][o]  (fp32, overwritten).  O = 64, K a multiple of 16 up to 128, bf16 rows
  * (bf16 matrix cores, fp32 accumulation, fixed reduction order).  workspace: p4c_row_linear_wgrad_workspace_bytes(R, K). */
@@ -734,6 +743,12 @@ int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t ldq, int R, 
 int p4c_bnorm_finalize(const float* partial, int nblk, double count, int C, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
                        p4c_stream_t stream);
+
+/* Bilinear up-sampling of a features-last bf16 map (B, H, W, C) by an integer factor (torch interpolate, align_corners = False),
+ * + skip (B, H*scale, W*scale, C) when given -- mfai's UnetrUpBlock with `linear_upsampling: true` (config/CLI/model/unetrpp.yaml:29).
+ * Backward in gather form (fixed order, no atomics): dx from dout; the skip's gradient is dout.  C a multiple of 8. */
+int p4c_upsample_bilinear_fwd(const void* x, const void* skip, void* out, int B, int H, int W, int C, int scale, p4c_stream_t stream);
+int p4c_upsample_bilinear_bwd(const void* dout, void* dx, int B, int H, int W, int C, int scale, p4c_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,10 @@ SIGNATURES = {
     "p4c_row_mlp_bwd_accumulate": [MP, SP, P, P],
     "p4c_window_attn_fwd": [P, P, P, I, I, I, I, I, I, I, F, I, P],
     "p4c_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
+    "p4c_row_add_layernorm_fwd": [P, P, L, P, P, F, P, P, L, I, I, P],
+    "p4c_row_add_layernorm_bwd": [P, P, P, P, F, P, P, P, P, L, I, I, P],
+    "p4c_upsample_bilinear_fwd": [P, P, P, I, I, I, I, I, P],
+    "p4c_upsample_bilinear_bwd": [P, P, I, I, I, I, I, P],
     "p4c_gemm_prep_weight": [P, I, I, I, P, P, P],
     "p4c_gemm_nt": [P, L, P, I, I, I, I, I, I, I, P, P, L, I, P, P, L, P, L, P, P, P],
     "p4c_gemm_tn": [P, L, P, L, I, I, I, I, I, I, P, P, P, P],
@@ -98,6 +102,7 @@ OTHER = {
     "p4c_row_gemm_wgrad_workspace_bytes": ([L, I, I, I], c_size_t),
     "p4c_row_mlp_bwd_workspace_bytes": ([L, I], c_size_t),
     "p4c_row_mlp_prepared_bytes": ([I], c_size_t),
+    "p4c_row_add_layernorm_bwd_workspace_bytes": ([L, I], c_size_t),
     "p4c_gemm_nt_workspace_bytes": ([I, I, I], c_size_t),
     "p4c_gemm_nt_stat_blocks": ([I, I, I], c_int),
     "p4c_gemm_tn_workspace_bytes": ([I, I, I], c_size_t),

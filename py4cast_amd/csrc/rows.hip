@@ -202,6 +202,157 @@ __global__ void __launch_bounds__(256)
         partial[(int64_t)blockIdx.x * 2 * C + j] = ((wred[0][j] + wred[1][j]) + wred[2][j]) + wred[3][j];
 }
 
+// ---------------------------------------------------------------- (x + add) -> LayerNorm, rows up to 2 KiB
+// t = x + add[r % add_rows] (add == NULL: t = x), sum_out = t (optional), out = LN(t) * gamma + beta.  One row per wave (64 lanes x NCH
+// 16-byte chunks): UNETR++'s token rows (128 ... 1024 bf16 features) with the positional embedding (one (N, C) table for every sample)
+// added on the way in -- the block's residual t and its normalised copy from ONE read of x.
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256)
+    row_add_layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ add, int64_t add_rows, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, T* __restrict__ sum_out, T* __restrict__ out, int64_t R, int C) {
+    constexpr int NV = Vec16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int chunks = C / NV;
+    const float inv_c = 1.f / (float)C;
+    for (int64_t r = wave; r < R; r += nwaves) {
+        float f[NCH][NV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + 64 * k;
+            const bool ok = ch < chunks;
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (ok) v = reinterpret_cast<const u32x4*>(x)[r * chunks + ch];
+            Vec16<T>::unpack(v, f[k]);
+            if (add && ok) {
+                float a[NV];
+                Vec16<T>::unpack(reinterpret_cast<const u32x4*>(add)[(r % add_rows) * chunks + ch], a);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) f[k][i] += a[i];
+                const u32x4 tv = Vec16<T>::pack(f[k]);
+                Vec16<T>::unpack(tv, f[k]);          // the statistics are those of the STORED sum (what the backward re-reads)
+                if (sum_out) reinterpret_cast<u32x4*>(sum_out)[r * chunks + ch] = tv;
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += f[k][i];
+        }
+        const float mean = row_sum(s, 64) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const bool ok = lane + 64 * k < chunks;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f[k][i] = ok ? f[k][i] - mean : 0.f;
+                q += f[k][i] * f[k][i];
+            }
+        }
+        const float rstd = rsqrtf(row_sum(q, 64) * inv_c + eps);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < chunks) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) f[k][i] = f[k][i] * rstd * gamma[ch * NV + i] + beta[ch * NV + i];
+                reinterpret_cast<u32x4*>(out)[r * chunks + ch] = Vec16<T>::pack(f[k]);
+            }
+        }
+    }
+}
+
+// dt = LN_backward(dy; t) (+ extra: the gradient that reaches t from its other consumers), partial dgamma / dbeta per workgroup
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256)
+    row_add_layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ t, const T* __restrict__ extra, const float* __restrict__ gamma,
+                                 float eps, T* __restrict__ dt, float* __restrict__ partial, int64_t R, int C) {
+    constexpr int NV = Vec16<T>::N;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    const int chunks = C / NV;
+    const float inv_c = 1.f / (float)C;
+    float g[NCH][NV], dg[NCH][NV], db[NCH][NV];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            g[k][i] = lane + 64 * k < chunks ? gamma[(lane + 64 * k) * NV + i] : 0.f;
+            dg[k][i] = db[k][i] = 0.f;
+        }
+    for (int64_t r = wave; r < R; r += nwaves) {
+        float f[NCH][NV], d[NCH][NV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + 64 * k;
+            u32x4 vx = u32x4{0, 0, 0, 0}, vd = vx;
+            if (ch < chunks) {
+                vx = reinterpret_cast<const u32x4*>(t)[r * chunks + ch];
+                vd = reinterpret_cast<const u32x4*>(dy)[r * chunks + ch];
+            }
+            Vec16<T>::unpack(vx, f[k]);
+            Vec16<T>::unpack(vd, d[k]);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += f[k][i];
+        }
+        const float mean = row_sum(s, 64) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const bool ok = lane + 64 * k < chunks;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f[k][i] = ok ? f[k][i] - mean : 0.f;
+                q += f[k][i] * f[k][i];
+            }
+        }
+        const float rstd = rsqrtf(row_sum(q, 64) * inv_c + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f[k][i] *= rstd;
+                dg[k][i] += d[k][i] * f[k][i];
+                db[k][i] += d[k][i];
+                d[k][i] *= g[k][i];
+                m1 += d[k][i];
+                m2 += d[k][i] * f[k][i];
+            }
+        m1 = row_sum(m1, 64) * inv_c;
+        m2 = row_sum(m2, 64) * inv_c;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < chunks) {
+                float e[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) e[i] = 0.f;
+                if (extra) Vec16<T>::unpack(reinterpret_cast<const u32x4*>(extra)[r * chunks + ch], e);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) d[k][i] = rstd * (d[k][i] - m1 - f[k][i] * m2) + e[i];
+                reinterpret_cast<u32x4*>(dt)[r * chunks + ch] = Vec16<T>::pack(d[k]);
+            }
+        }
+    }
+    __shared__ float wred[4][2 * 1024];   // C <= 1024 (2 KiB bf16 rows) / 512 (fp32)
+    const int Cp = C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < chunks) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                wred[wv][ch * NV + i] = dg[k][i];
+                wred[wv][Cp + ch * NV + i] = db[k][i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * C; j += blockDim.x)
+        partial[(int64_t)blockIdx.x * 2 * C + j] = ((wred[0][j] + wred[1][j]) + wred[2][j]) + wred[3][j];
+}
+
 // out[j] = sum_s partial[s][j], j < n, in a fixed order: a block owns 32 outputs, its 8 thread rows take the slots s = sg (mod 8)
 // with four independent partial sums each, then the 8 rows are added in order through LDS.
 __global__ void __launch_bounds__(256) row_param_reduce_kernel(const float* __restrict__ partial, int slots, int n, float* __restrict__ out) {
@@ -461,6 +612,60 @@ extern "C" int p4c_row_layernorm_bwd(const void* dy, const void* x, const float*
         hipLaunchKernelGGL(row_layernorm_bwd_kernel<bf16>, dim3(G), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, eps,
                            (bf16*)dx, partial, R, C, lpr_log2);
     P4C_CHECK_LAUNCH("row_layernorm_bwd");
+    hipLaunchKernelGGL(row_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, partial, G, 2 * C, dgamma);
+    P4C_CHECK_LAUNCH("row_param_reduce");
+    return P4C_OK;
+}
+
+static int add_ln_grid(int64_t R) {
+    int64_t blocks = (R + 3) / 4;
+    const int64_t cap = (int64_t)p4c::num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+static int add_ln_check(const char* name, int64_t R, int C, int dtype, int* nch) {
+    P4C_CHECK_ARG(R >= 0 && C > 0 && (dtype == P4C_F32 || dtype == P4C_BF16), "%s: bad sizes / dtype", name);
+    const int esz = dtype == P4C_F32 ? 4 : 2;
+    P4C_CHECK_ARG((C * esz) % 16 == 0 && C * esz <= 2048, "%s: a row (C=%d x %d B) must be a multiple of 16 bytes, at most 2 KiB", name, C, esz);
+    *nch = C * esz > 1024 ? 2 : 1;
+    return P4C_OK;
+}
+
+extern "C" int p4c_row_add_layernorm_fwd(const void* x, const void* add, int64_t add_rows, const float* gamma, const float* beta, float eps,
+                                         void* sum_out, void* out, int64_t R, int C, int dtype, p4c_stream_t stream) {
+    int nch;
+    P4C_TRY(add_ln_check("p4c_row_add_layernorm_fwd", R, C, dtype, &nch));
+    P4C_CHECK_ARG(x && gamma && beta && out && (!add || add_rows > 0), "p4c_row_add_layernorm_fwd: NULL pointer");
+    if (R == 0) return P4C_OK;
+    hipStream_t s = as_stream(stream);
+    const int G = add_ln_grid(R);
+#define P4C_LAUNCH_ALN(T, N) hipLaunchKernelGGL((row_add_layernorm_fwd_kernel<T, N>), dim3(G), dim3(256), 0, s, (const T*)x, (const T*)add, add_rows, gamma, beta, eps, (T*)sum_out, (T*)out, R, C)
+    if (dtype == P4C_F32) { if (nch == 2) P4C_LAUNCH_ALN(float, 2); else P4C_LAUNCH_ALN(float, 1); }
+    else { if (nch == 2) P4C_LAUNCH_ALN(bf16, 2); else P4C_LAUNCH_ALN(bf16, 1); }
+#undef P4C_LAUNCH_ALN
+    P4C_CHECK_LAUNCH("row_add_layernorm_fwd");
+    return P4C_OK;
+}
+
+extern "C" size_t p4c_row_add_layernorm_bwd_workspace_bytes(int64_t R, int C) {
+    if (R <= 0 || C <= 0) return 0;
+    return (size_t)add_ln_grid(R) * 2 * C * sizeof(float);
+}
+
+extern "C" int p4c_row_add_layernorm_bwd(const void* dy, const void* t, const void* extra, const float* gamma, float eps, void* dt, float* dgamma,
+                                         float* dbeta, void* workspace, int64_t R, int C, int dtype, p4c_stream_t stream) {
+    int nch;
+    P4C_TRY(add_ln_check("p4c_row_add_layernorm_bwd", R, C, dtype, &nch));
+    P4C_CHECK_ARG(dy && t && gamma && dt && dgamma && dbeta && workspace && R > 0, "p4c_row_add_layernorm_bwd: NULL pointer / no rows");
+    P4C_CHECK_ARG(dbeta == dgamma + C, "p4c_row_add_layernorm_bwd: dbeta must follow dgamma (one (2,C) buffer)");
+    hipStream_t s = as_stream(stream);
+    const int G = add_ln_grid(R);
+    float* partial = reinterpret_cast<float*>(workspace);
+#define P4C_LAUNCH_ALNB(T, N) hipLaunchKernelGGL((row_add_layernorm_bwd_kernel<T, N>), dim3(G), dim3(256), 0, s, (const T*)dy, (const T*)t, (const T*)extra, gamma, eps, (T*)dt, partial, R, C)
+    if (dtype == P4C_F32) { if (nch == 2) P4C_LAUNCH_ALNB(float, 2); else P4C_LAUNCH_ALNB(float, 1); }
+    else { if (nch == 2) P4C_LAUNCH_ALNB(bf16, 2); else P4C_LAUNCH_ALNB(bf16, 1); }
+#undef P4C_LAUNCH_ALNB
+    P4C_CHECK_LAUNCH("row_add_layernorm_bwd");
     hipLaunchKernelGGL(row_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, partial, G, 2 * C, dgamma);
     P4C_CHECK_LAUNCH("row_param_reduce");
     return P4C_OK;

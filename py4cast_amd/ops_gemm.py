@@ -140,6 +140,46 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, r
     return _Linear.apply(x, w, b, res)
 
 
+class _CatLinearRes(torch.autograd.Function):
+    """res + cat(xa Wa^T + ba, xb Wb^T + bb) along the features: two GEMMs whose epilogues write the two column halves of ONE output
+    tensor (row stride = the full width) and add the matching halves of the residual"""
+
+    @staticmethod
+    def forward(ctx, xa, wa, ba, xb, wb, bb, res):
+        Oa, Ka = wa.shape
+        Ob, Kb = wb.shape
+        xa2, xb2 = _rows(xa.detach(), Ka), _rows(xb.detach(), Kb)
+        r2 = _rows(res.detach(), Oa + Ob)
+        fa, da = weight_images(wa, 1)
+        fb, db_ = weight_images(wb, 1)
+        y = torch.empty(xa2.shape[0], Oa + Ob, dtype=torch.bfloat16, device=xa.device)
+        gemm_nt(xa2, fa, Oa, Ka, bias=_f32(ba), res=r2[:, :Oa], out=y[:, :Oa])
+        gemm_nt(xb2, fb, Ob, Kb, bias=_f32(bb), res=r2[:, Oa:], out=y[:, Oa:])
+        ctx.save_for_backward(xa2, xb2, da, db_)
+        ctx.meta = (xa.shape, xb.shape, Oa, Ka, Ob, Kb, wa.dtype, ba.dtype, wb.dtype, bb.dtype)
+        return y.view(*res.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa2, xb2, da, db_ = ctx.saved_tensors
+        sa, sb, Oa, Ka, Ob, Kb, wadt, badt, wbdt, bbdt = ctx.meta
+        dy2 = _rows(dy, Oa + Ob)
+        dya, dyb = dy2[:, :Oa], dy2[:, Oa:]
+        dxa = gemm_nt(dya, da, Ka, Oa)[0].view(sa)
+        dxb = gemm_nt(dyb, db_, Kb, Ob)[0].view(sb)
+        dwa, dba = gemm_tn(dya, xa2, Oa, Ka, want_bias=True)
+        dwb, dbb = gemm_tn(dyb, xb2, Ob, Kb, want_bias=True)
+        return dxa, dwa.to(wadt), dba.to(badt), dxb, dwb.to(wbdt), dbb.to(bbdt), dy
+
+
+def cat_linear_res(xa, wa, ba, xb, wb, bb, res) -> torch.Tensor:
+    """``res + torch.cat([F.linear(xa, wa, ba), F.linear(xb, wb, bb)], -1)`` as one autograd node (bf16 rows, fp32 parameters)"""
+    L.require_cuda(xa)
+    if not (supported(xa, wa) and supported(xb, wb)) or (wa.shape[0] % 8) or (wb.shape[0] % 8):
+        raise L.P4CError("ops_gemm.cat_linear_res: unsupported operands")
+    return _CatLinearRes.apply(xa, wa, ba, xb, wb, bb, res)
+
+
 class _MLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res):
@@ -311,3 +351,33 @@ def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=N
         bn.num_batches_tracked.add_(1)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return _BatchNormAct.apply(y, stats if training else None, bn.weight, bn.bias, res, rm, rv, training, mom, bn.eps, float(slope))
+
+
+class _UpsampleAdd(torch.autograd.Function):
+    """bilinear up-sampling by an integer factor (align_corners = False) of a features-last bf16 map, + skip: csrc/resize.hip"""
+
+    @staticmethod
+    def forward(ctx, x, skip, scale):
+        xc = x.contiguous()
+        B, H, W, C = xc.shape
+        sc = None if skip is None else skip.contiguous()
+        out = torch.empty(B, H * scale, W * scale, C, dtype=xc.dtype, device=xc.device)
+        L.call("p4c_upsample_bilinear_fwd", L.ptr(xc), L.ptr(sc), L.ptr(out), B, H, W, C, scale, L.stream(xc.device))
+        ctx.geom, ctx.has_skip = (B, H, W, C, scale), skip is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, H, W, C, scale = ctx.geom
+        dout = dout.contiguous()
+        dx = torch.empty(B, H, W, C, dtype=dout.dtype, device=dout.device)
+        L.call("p4c_upsample_bilinear_bwd", L.ptr(dout), L.ptr(dx), B, H, W, C, scale, L.stream(dout.device))
+        return dx, (dout if ctx.has_skip else None), None
+
+
+def upsample_add(x: torch.Tensor, skip: Optional[torch.Tensor], scale: int) -> torch.Tensor:
+    """``F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=False) (+ skip)`` on features-last (B,H,W,C) bf16 maps"""
+    L.require_cuda(x)
+    if x.dtype != torch.bfloat16 or x.dim() != 4 or x.shape[-1] % 8 or not (1 <= int(scale) <= 8):
+        raise L.P4CError(f"ops_gemm.upsample_add: unsupported map {tuple(x.shape)} {x.dtype} scale {scale}")
+    return _UpsampleAdd.apply(x, skip, int(scale))

@@ -400,3 +400,60 @@ def linear_nd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None
         if _row_gemm_mode(x, wp, bp) == "all":
             return _LinearND.apply(x, wp, bp)[..., :O]
     return _LinearND.apply(x, w, b)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """t = x + add (add: one (N, C) table broadcast over the leading dimension, or None), ln = LayerNorm(t) * gamma + beta -- both
+    returned: t is the block's residual, ln its normalised copy (csrc/rows.hip: p4c_row_add_layernorm_fwd / _bwd, rows up to 2 KiB).
+    Backward: ONE pass gives dt = LN_backward(d ln) + d t; the table's gradient is its sum over the leading dimension."""
+
+    @staticmethod
+    def forward(ctx, x, add, gamma, beta, eps):
+        L.require_cuda(x)
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        R = x2.shape[0]
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        a2, arows = None, 0
+        if add is not None:
+            a2 = weight_as(add, x.dtype).reshape(-1, C)      # cast once per parameter version / capture
+            arows = a2.shape[0]
+            if R % arows:
+                raise L.P4CError("add_layer_norm: the table's rows must divide the rows")
+        t = torch.empty_like(x2) if add is not None else x2
+        ln = torch.empty_like(x2)
+        L.call("p4c_row_add_layernorm_fwd", L.ptr(x2), L.ptr(a2), arows, L.ptr(g), L.ptr(b), float(eps), L.ptr(t if add is not None else None),
+               L.ptr(ln), R, C, L.dtype_code(x2.dtype), L.stream(x2.device), alg_bytes=R * C * x2.element_size() * (2 + (add is not None)))
+        ctx.save_for_backward(t, g)
+        ctx.eps, ctx.shape, ctx.arows = float(eps), x.shape, arows
+        ctx.dtypes = (gamma.dtype, None if add is None else add.dtype, None if add is None else add.shape)
+        return t.view(x.shape), ln.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dt_in, dln):
+        t, g = ctx.saved_tensors
+        R, C = t.shape
+        dln = dln.reshape(R, C).contiguous()
+        extra = None if dt_in is None else dt_in.reshape(R, C).contiguous()
+        dt = torch.empty_like(t)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=t.device)
+        ws = torch.empty(max(L.lib().p4c_row_add_layernorm_bwd_workspace_bytes(R, C) // 4, 1), dtype=torch.float32, device=t.device)
+        L.call("p4c_row_add_layernorm_bwd", L.ptr(dln), L.ptr(t), L.ptr(extra), L.ptr(g), ctx.eps, L.ptr(dt), L.ptr(dgb), L.ptr(dgb[1]), L.ptr(ws),
+               R, C, L.dtype_code(t.dtype), L.stream(t.device), alg_bytes=R * C * t.element_size() * (3 + (extra is not None)))
+        gdt, adt, ashape = ctx.dtypes
+        dadd = None
+        if ctx.arows:
+            dadd = dt.view(-1, ctx.arows, C).sum(dim=0, dtype=torch.float32).to(adt).view(ashape)
+        return dt.view(ctx.shape), dadd, dgb[0].to(gdt), dgb[1].to(gdt), None
+
+
+def add_layer_norm_supported(x: torch.Tensor) -> bool:
+    nbytes = x.shape[-1] * x.element_size()
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and nbytes % 16 == 0 and nbytes <= 2048
+
+
+def add_layer_norm(x: torch.Tensor, add: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """``t = x + add; return t, F.layer_norm(t, (C,), gamma, beta, eps)`` for (..., C) activations, add (N, C) or (1, N, C) or None"""
+    return _AddLayerNorm.apply(x, add, gamma, beta, float(eps))

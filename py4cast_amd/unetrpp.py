@@ -39,6 +39,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
+from . import ops_gemm as G
 from . import ops_inorm as ON
 from . import ops_model as OM
 from . import ops_rows as R
@@ -82,8 +83,22 @@ def _norm(name, ch):
     raise NotImplementedError(f"UNetRPP: norm_name={name}")
 
 
+def _native(x: torch.Tensor) -> bool:
+    """bf16 activations on the GPU: the round-5 kernels (csrc/gemm.hip) carry the wide Linears / convolutions / batch norms"""
+    return x.is_cuda and x.dtype == torch.bfloat16 and os.environ.get("P4C_UNETRPP_LIBRARY") != "1"
+
+
+def _lin(x: torch.Tensor, w: torch.Tensor, b=None, res=None) -> torch.Tensor:
+    """x W^T + b (+ res): the streaming row-GEMM kernels for the narrow layers they were measured on (csrc/rowgemm.hip), the tiled
+    MFMA GEMM for the rest (csrc/gemm.hip), library GEMMs only for the fp32 flavour / odd widths"""
+    if _native(x) and G.supported(x, w) and not R._row_gemm_ok(x, w, b):
+        return G.linear(x, w, b, res)
+    y = R.linear_nd(x, w, b)
+    return y if res is None else y + res
+
+
 def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
-    return R.linear_nd(x, m.weight, m.bias)
+    return _lin(x, m.weight, m.bias)
 
 
 def _conv(m, x):
@@ -109,7 +124,12 @@ def _conv(m, x):
             if k > 1:
                 xl = xl.reshape(B, H // k, k, W // k, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // k, W // k, k * k * C)
             w = m.weight.permute(0, 2, 3, 1).reshape(m.weight.shape[0], k * k * C)
-            return R.linear_nd(xl, w, m.bias).permute(0, 3, 1, 2)
+            return _lin(xl, w, m.bias).permute(0, 3, 1, 2)
+    if (type(m) is nn.Conv2d and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros" and m.stride == (1, 1)
+            and m.kernel_size[0] == m.kernel_size[1] and m.kernel_size[0] in (1, 3) and m.padding == (m.kernel_size[0] // 2,) * 2
+            and _native(x) and x.permute(0, 2, 3, 1).is_contiguous() and G.conv_supported(x.permute(0, 2, 3, 1), m.weight)):
+        # 3x3 "same" / 1x1 at any width: the implicit-GEMM kernel on the features-last map (no im2col, no layout change)
+        return G.conv2d_nhwc(x.permute(0, 2, 3, 1), m.weight, m.bias).permute(0, 3, 1, 2)
     if isinstance(m, nn.Conv2d) and x.shape[1] > m.in_channels:      # zero-padded rows from build_x: the library takes the real channels
         x = x[:, : m.in_channels]
     if type(m) is nn.Conv2d and m.padding_mode == "zeros":
@@ -127,7 +147,7 @@ def _conv_transpose(m: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
     wt = m.weight                                                        # (cin, cout, s, s)
     cout = wt.shape[1]
     wr = wt.permute(2, 3, 1, 0).reshape(s * s * cout, cin)               # Linear weight: (outputs, cin)
-    up = R.linear_nd(xl, wr).view(B, H, W, s, s, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H * s, W * s, cout)
+    up = _lin(xl, wr).view(B, H, W, s, s, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, H * s, W * s, cout)
     return up.permute(0, 3, 1, 2)
 
 
@@ -138,7 +158,8 @@ def _nrm(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
         # sample with ONE workgroup, 340 us): per-channel sums + one streaming pass on the instance-norm kernels
         # (handed on NCHW-contiguous, as the library's GroupNorm does: with a channels_last result here MIOpen's immediate-mode
         # heuristics picked other -- CK -- solvers for the 3x3 convolutions downstream and the step took 1 130 ms instead of 570)
-        return ON.group_norm(x.permute(0, 2, 3, 1), m.num_groups, m.weight, m.bias, m.eps).permute(0, 3, 1, 2).contiguous()
+        y = ON.group_norm(x.permute(0, 2, 3, 1), m.num_groups, m.weight, m.bias, m.eps).permute(0, 3, 1, 2)
+        return y if _native(x) else y.contiguous()      # (no library convolution downstream on the native path: the layout stays)
     if x.dtype in (torch.float32, torch.float64) or isinstance(m, nn.BatchNorm2d):   # the library's batch norm takes bf16 activations with fp32 parameters / statistics
         return m(x)
     return m(x.float()).to(x.dtype)
@@ -174,6 +195,19 @@ class ResBlock(nn.Module):
             y = inorm(self.norm1, _conv(self.conv1, x).contiguous(memory_format=torch.channels_last), 0.01)
             r = inorm(self.norm3, _conv(self.conv3, x).contiguous(memory_format=torch.channels_last)) if self.down else x
             return inorm(self.norm2, _conv(self.conv2, y).contiguous(memory_format=torch.channels_last), 0.01, r)
+        if (isinstance(self.norm1, nn.BatchNorm2d) and _native(x) and x.permute(0, 2, 3, 1).is_contiguous()
+                and G.conv_supported(x.permute(0, 2, 3, 1), self.conv1.weight) and cout % 8 == 0 and cout <= 1024):
+            # the 128 ... 1024-channel blocks of the transformer stages: implicit-GEMM convolutions whose drain leaves the batch-norm
+            # sums, BatchNorm2d + LeakyReLU (+ residual) as one streaming node each way (ops_gemm: csrc/gemm.hip + csrc/inorm.hip)
+            xl = x.permute(0, 2, 3, 1)
+            y1, st1 = G.conv2d_nhwc(xl, self.conv1.weight, want_stats=True)
+            a1 = G.batch_norm_act(y1, st1, self.norm1, 0.01)
+            y2, st2 = G.conv2d_nhwc(a1, self.conv2.weight, want_stats=True)
+            rl = xl
+            if self.down:
+                y3, st3 = G.conv2d_nhwc(xl, self.conv3.weight, want_stats=True)
+                rl = G.batch_norm_act(y3, st3, self.norm3, 1.0)
+            return G.batch_norm_act(y2, st2, self.norm2, 0.01, rl).permute(0, 3, 1, 2)
         r = x
         y = F.leaky_relu(_nrm(self.norm1, _conv(self.conv1, x)), 0.01)
         y = _nrm(self.norm2, _conv(self.conv2, y))
@@ -227,7 +261,19 @@ class EPA(nn.Module):
         self.out_proj = nn.Linear(hidden, hidden // 2)
         self.out_proj2 = nn.Linear(hidden, hidden // 2)
 
-    def forward(self, x):
+    def _project_out(self, x_sa, x_ca, res, gamma):
+        """cat(out_proj(x_sa), out_proj2(x_ca)) -- or, given the block's residual t and layer scale gamma, t + gamma * that cat with
+        gamma folded into the two weights and both halves written by the GEMMs' epilogues (no cat, no scale, no add launch)."""
+        if res is None or not (_native(x_sa) and G.supported(x_sa, self.out_proj.weight) and self.out_proj.weight.shape[0] % 8 == 0):
+            y = torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)
+            return y if res is None else res + R.param_as(gamma, y.dtype) * y
+        h = self.out_proj.weight.shape[0]
+        g1, g2 = gamma[:h], gamma[h:]
+        return G.cat_linear_res(x_sa, g1.unsqueeze(1) * self.out_proj.weight, g1 * self.out_proj.bias,
+                                x_ca, g2.unsqueeze(1) * self.out_proj2.weight, g2 * self.out_proj2.bias, res)
+
+    def forward(self, x, res=None, gamma=None):
+        """res / gamma given: returns res + gamma * EPA(x) (the transformer block's residual update)"""
         B, N, C = x.shape
         h, d = self.heads, C // self.heads
         qkvv = _linear(self.qkvv, x).view(B, N, 4, h, d)
@@ -235,7 +281,7 @@ class EPA(nn.Module):
             # the attention between the projections as one node: its backward writes dq / dk / dv straight into the gradient of qkvv
             x_sa, x_ca = TS.epa_core(qkvv, self.E.weight, self.E.bias, self.temperature, self.temperature2)
             x_sa, x_ca = (t.permute(0, 2, 1, 3).reshape(B, N, C) for t in (x_sa, x_ca))
-            return torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)
+            return self._project_out(x_sa, x_ca, res, gamma)
         q, k, v_ca, v_sa = _SplitQKVV.apply(qkvv)                                          # (B,h,N,d) views, nothing copied
         if d % 4:
             raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")
@@ -267,7 +313,7 @@ class EPA(nn.Module):
         else:
             S = TS.apply(q, Mq).softmax(dim=-1)                                                      # (B,h,N,p), token-major memory
             x_sa = TS.apply(S, VP.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
-        return torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)
+        return self._project_out(x_sa, x_ca, res, gamma)
 
 
 class TransformerBlock(nn.Module):
@@ -282,6 +328,17 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
+        xl = x.permute(0, 2, 3, 1)
+        if _native(x) and xl.is_contiguous() and R.add_layer_norm_supported(xl) and C % 16 == 0:
+            # features-last all the way: (x + pos) and its LayerNorm from one read, the EPA's two output projections write
+            # t + gamma * (...) from their epilogues, the 1x1 conv8 adds its bias and the skip in its epilogue
+            t, ln = R.add_layer_norm(xl.reshape(B, H * W, C), self.pos_embed, self.norm.weight, self.norm.bias, self.norm.eps)
+            t = self.epa_block(ln, res=t, gamma=self.gamma)
+            skip = t.reshape(B, H, W, C)
+            r = self.conv51(skip.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+            if G.conv_supported(r, self.conv8.weight):
+                return G.conv2d_nhwc(r, self.conv8.weight, self.conv8.bias, res=skip).permute(0, 3, 1, 2)
+            return (skip + _conv(self.conv8, r.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         t = x.reshape(B, C, H * W).permute(0, 2, 1) + R.param_as(self.pos_embed, x.dtype)
         t = t + R.param_as(self.gamma, x.dtype) * self.epa_block(_layer_norm(self.norm, t.contiguous()))
         skip = t.reshape(B, H, W, C).permute(0, 3, 1, 2)
@@ -312,6 +369,12 @@ class UpBlock(nn.Module):
             self.decoder_block = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens, cout, proj, heads) for _ in range(depth)])])
 
     def forward(self, x, skip):
+        if (self.linear and _native(x) and x.shape[1] % 8 == 0 and self.up_conv.out_channels % 8 == 0 and float(self.scale).is_integer()
+                and x.permute(0, 2, 3, 1).is_contiguous()):
+            # 1x1 convolution on the small grid (it commutes with the interpolation, see below), then up-sample + skip in one native pass
+            # (csrc/resize.hip: features-last both ways, gather-form backward -- no atomics, no layout copies)
+            y = _conv(self.up_conv, x).permute(0, 2, 3, 1)
+            return self.decoder_block[0](G.upsample_add(y, skip.permute(0, 2, 3, 1), int(self.scale)).permute(0, 3, 1, 2))
         if self.linear:
             # mfai: up_conv(interpolate(x)).  A 1x1 convolution (per pixel, across channels) and the bilinear interpolation (per
             # channel, across pixels, weights summing to 1 -- the bias passes through) commute: the convolution runs on the small

@@ -268,3 +268,58 @@ def test_no_cpu_path(gpu_device):
         G.linear(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(8, 8))
     with pytest.raises(L.P4CError):
         G.conv2d_nhwc(torch.zeros(1, 4, 4, 8, dtype=torch.bfloat16), torch.zeros(8, 8, 3, 3))
+
+
+@pytest.mark.parametrize("B,H,W,C,scale,with_skip", [(2, 16, 16, 64, 2, True), (1, 12, 20, 128, 4, True), (2, 8, 8, 256, 2, False)])
+def test_bilinear_upsample_add_vs_torch_float64(gpu_device, B, H, W, C, scale, with_skip):
+    """csrc/resize.hip against F.interpolate(bilinear, align_corners=False) (+ skip) in float64: forward, and the gather-form backward
+    against autograd's; bit-identical reruns"""
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    x = rnd((B, H, W, C), dev, 61).bfloat16().requires_grad_()
+    skip = rnd((B, H * scale, W * scale, C), dev, 62).bfloat16().requires_grad_() if with_skip else None
+    dy = rnd((B, H * scale, W * scale, C), dev, 63).bfloat16()
+    y = G.upsample_add(x, skip, scale)
+    y.backward(dy)
+    xd = x.detach().double().requires_grad_()
+    ref = F.interpolate(xd.permute(0, 3, 1, 2), scale_factor=scale, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    if with_skip:
+        ref = ref + skip.detach().double()
+    ref.backward(dy.double())
+    close_bf16(y, ref, "y")
+    close_bf16(x.grad, xd.grad, "dx")
+    if with_skip:
+        assert torch.equal(skip.grad, dy)
+    x2 = x.detach().clone().requires_grad_()
+    y2 = G.upsample_add(x2, None if skip is None else skip.detach(), scale)
+    y2.backward(dy)
+    assert torch.equal(y2, y) and torch.equal(x2.grad, x.grad)
+
+
+@pytest.mark.parametrize("R,C,N", [(512, 1024, 256), (4096, 128, 2048), (300, 520, 100)])
+def test_add_layer_norm_vs_float64(gpu_device, R, C, N):
+    """(x + pos) -> LayerNorm on rows up to 2 KiB (csrc/rows.hip): both outputs and every gradient against float64"""
+    from py4cast_amd import ops_rows as RW
+
+    dev = gpu_device
+    B = R // N if R % N == 0 else 1
+    if R % N:
+        N = R
+    x = rnd((B, N, C), dev, 71).bfloat16().requires_grad_()
+    pos = (0.1 * rnd((1, N, C), dev, 72)).requires_grad_()
+    g = (1 + 0.1 * rnd((C,), dev, 73)).requires_grad_()
+    b = (0.1 * rnd((C,), dev, 74)).requires_grad_()
+    dt, dln = rnd((B, N, C), dev, 75).bfloat16(), rnd((B, N, C), dev, 76).bfloat16()
+    t, ln = RW.add_layer_norm(x, pos, g, b, 1e-5)
+    (t.float() * dt.float()).sum().backward(retain_graph=True) if False else torch.autograd.backward([t, ln], [dt, dln])
+    xd, pd = x.detach().double().requires_grad_(), pos.detach().bfloat16().double().requires_grad_()
+    gd, bd = g.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    tr = xd + pd
+    trr = tr.detach().bfloat16().double() + (tr - tr.detach())          # the stored (rounded) sum is what is normalised
+    lr = F.layer_norm(trr, (C,), gd, bd, 1e-5)
+    torch.autograd.backward([tr, lr], [dt.double(), dln.double()])
+    close_bf16(t, tr, "t")
+    close_bf16(ln, lr, "ln")
+    close_bf16(x.grad, xd.grad, "dx")
+    assert rel(pos.grad, pd.grad) <= 5e-3 and rel(g.grad, gd.grad) <= 2e-3 and rel(b.grad, bd.grad) <= 2e-3
