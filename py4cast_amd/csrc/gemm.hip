@@ -613,13 +613,21 @@ __global__ void __launch_bounds__(256) bnorm_finalize_kernel(const float* __rest
                                                              float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                              float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
                                                              float* __restrict__ shift) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    // a workgroup owns 32 channels; its 8 thread rows take the partial blocks b = row (mod 8), then the rows are added in order
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, row = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += (double)partial[((int64_t)b * 2 + 0) * C + c];
-        s2 += (double)partial[((int64_t)b * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int b = row; b < nblk; b += 8) {
+            s1 += (double)partial[((int64_t)b * 2 + 0) * C + c];
+            s2 += (double)partial[((int64_t)b * 2 + 1) * C + c];
+        }
+    red[0][row][cl] = s1;
+    red[1][row][cl] = s2;
+    __syncthreads();
+    if (row != 0 || c >= C) return;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) { s1 += red[0][r][cl]; s2 += red[1][r][cl]; }
     const double mu = s1 / count;
     double var = s2 / count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -793,7 +801,7 @@ extern "C" int p4c_bnorm_finalize(const float* partial, int nblk, double count, 
                                   float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
                                   float* shift, p4c_stream_t stream) {
     P4C_CHECK_ARG(partial && mean && rstd && scale && shift && nblk > 0 && C > 0 && count > 0, "p4c_bnorm_finalize: bad arguments");
-    hipLaunchKernelGGL(bnorm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), partial, nblk, count, C, gamma, beta, eps,
+    hipLaunchKernelGGL(bnorm_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, as_stream(stream), partial, nblk, count, C, gamma, beta, eps,
                        momentum, running_mean, running_var, mean, rstd, scale, shift);
     P4C_CHECK_LAUNCH("bnorm_finalize");
     return P4C_OK;
