@@ -732,11 +732,12 @@ int p4c_gemm_nt(const void* A, int64_t lda, const void* Bimg, int M, int N, int 
                 float* stats, void* workspace, p4c_stream_t stream);
 /* Weight (+ bias) gradient: dw (Mo, Cin, taps) fp32 in the torch layout = sum over the R rows of dy[r][:Mo]^T (x) x[r] -- taps = 9:
  * x's 3x3 neighbourhood of pixel r (x = the NHWC map, R = batch * H * W) --, db (Mo) = column sums of dy (or NULL).  dy / x bf16 rows
- * with strides ldp / ldq (multiples of 8).  Split over the rows, fp32 slabs summed in a fixed order.  workspace:
+ * with strides ldp / ldq (multiples of 8).  Split over the rows, fp32 slabs summed in a fixed order.  accumulate = 1: dw / db are ADDED
+ * to (a parameter's .grad buffer: no AccumulateGrad launch per AR step).  workspace:
  * p4c_gemm_tn_workspace_bytes(R, Mo, taps * Cin) bytes. */
 size_t p4c_gemm_tn_workspace_bytes(int R, int Mo, int No);
 int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t ldq, int R, int Mo, int H, int W, int Cin, int taps, float* dw,
-                float* db, void* workspace, p4c_stream_t stream);
+                float* db, int accumulate, void* workspace, p4c_stream_t stream);
 /* BatchNorm2d (training mode) statistics from column partial sums [nblk][2][C] over `count` values per channel: mean, rstd,
  * scale = gamma rstd, shift = beta - mean scale (C each, fp32); running_mean / running_var (optional) get torch's momentum update
  * with the unbiased variance. */

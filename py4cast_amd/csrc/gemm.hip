@@ -544,7 +544,7 @@ struct TnRedArgs {
     const float* bias_partial;
     float* dw;
     float* db;
-    int splits, tiles, tiles_i, Mo, No, Cin, taps, cchunk;
+    int splits, tiles, tiles_i, Mo, No, Cin, taps, cchunk, accumulate;
 };
 __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
     __shared__ float turn[9 * 512];
@@ -568,13 +568,13 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
     float* out = a.dw + ((int64_t)i * a.Cin + c0) * a.taps;
     for (int e = threadIdx.x; e < a.taps * cn; e += 256) {
         const int c = e / a.taps, tap = e - c * a.taps;
-        out[e] = turn[tap * cn + c];
+        out[e] = a.accumulate ? out[e] + turn[tap * cn + c] : turn[tap * cn + c];
     }
     if (a.db && blockIdx.x == 0 && threadIdx.x == 0) {
         float t = 0.f;
         for (int s = 0; s < a.splits; ++s)
             for (int w = 0; w < 4; ++w) t += a.bias_partial[(((int64_t)s * a.tiles_i + (i >> 7)) * 4 + w) * 128 + (i & 127)];
-        a.db[i] = t;
+        a.db[i] = a.accumulate ? a.db[i] + t : t;
     }
 }
 
@@ -761,7 +761,7 @@ extern "C" size_t p4c_gemm_tn_workspace_bytes(int R, int Mo, int No) {
 
 // dW (Mo, Cin, taps) fp32 = sum over the R rows of dy^T (x) [x or its 3x3 im2col view], db (Mo) = column sums of dy (or NULL)
 extern "C" int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t ldq, int R, int Mo, int H, int W, int Cin, int taps,
-                           float* dw, float* db, void* workspace, p4c_stream_t stream) {
+                           float* dw, float* db, int accumulate, void* workspace, p4c_stream_t stream) {
     P4C_CHECK_ARG(dy && x && dw && workspace, "p4c_gemm_tn: NULL pointer");
     P4C_CHECK_ARG(R > 0 && Mo > 0 && Cin > 0 && Mo % 8 == 0 && Cin % 8 == 0 && (taps == 1 || taps == 9), "p4c_gemm_tn: R=%d Mo=%d Cin=%d taps=%d", R, Mo,
                   Cin, taps);
@@ -791,7 +791,7 @@ extern "C" int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t l
     int cchunk = 512;
     while (cchunk > 32 && (int64_t)((Cin + cchunk - 1) / cchunk) * Mo < 1024) cchunk >>= 1;
     if (cchunk > Cin) cchunk = Cin;
-    TnRedArgs r{a.partial, a.bias_partial, dw, db, a.splits, tiles, a.tiles_i, Mo, a.No, Cin, taps, cchunk};
+    TnRedArgs r{a.partial, a.bias_partial, dw, db, a.splits, tiles, a.tiles_i, Mo, a.No, Cin, taps, cchunk, accumulate ? 1 : 0};
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((Cin + cchunk - 1) / cchunk, Mo), dim3(256), 0, st, r);
     P4C_CHECK_LAUNCH("gemm_tn_reduce");
     return P4C_OK;

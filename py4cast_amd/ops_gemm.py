@@ -87,17 +87,44 @@ def gemm_nt(A: torch.Tensor, img: torch.Tensor, N: int, K: int, conv=None, bias=
     return C, aux_out, stats
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor, Mo: int, Cin: int, conv=None, want_bias=False):
-    """dW (Mo, Cin[, 3, 3]) fp32 and db (Mo) or None from dy (R, >= Mo) and x (R, >= Cin) bf16 rows (conv = (H, W): x is the NHWC map)"""
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, Mo: int, Cin: int, conv=None, want_bias=False, sink=None):
+    """dW (Mo, Cin[, 3, 3]) fp32 and db (Mo) or None from dy (R, >= Mo) and x (R, >= Cin) bf16 rows (conv = (H, W): x is the NHWC map).
+    sink = (gw, gb): ADD both into these fp32 buffers (views of the parameters' .grad) instead, and return (None, None)."""
     lib = L.lib()
     R = dy.shape[0]
     taps, H, W = (9, conv[0], conv[1]) if conv is not None else (1, 0, 0)
-    dw = torch.empty((Mo, Cin, 3, 3) if conv is not None else (Mo, Cin), dtype=torch.float32, device=dy.device)
-    db = torch.empty(Mo, dtype=torch.float32, device=dy.device) if want_bias else None
+    if sink is not None:
+        dw, db = sink
+    else:
+        dw = torch.empty((Mo, Cin, 3, 3) if conv is not None else (Mo, Cin), dtype=torch.float32, device=dy.device)
+        db = torch.empty(Mo, dtype=torch.float32, device=dy.device) if want_bias else None
     ws = torch.empty(max(lib.p4c_gemm_tn_workspace_bytes(R, Mo, taps * Cin) // 4, 1), dtype=torch.float32, device=dy.device)
-    L.call("p4c_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), R, Mo, H, W, Cin, taps, L.ptr(dw), L.ptr(db), L.ptr(ws),
-           L.stream(dy.device), alg_bytes=2 * R * (Mo + Cin) + 4 * Mo * Cin * taps)
-    return dw, db
+    L.call("p4c_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), R, Mo, H, W, Cin, taps, L.ptr(dw), L.ptr(db), int(sink is not None),
+           L.ptr(ws), L.stream(dy.device), alg_bytes=2 * R * (Mo + Cin) + 4 * Mo * Cin * taps)
+    return (None, None) if sink is not None else (dw, db)
+
+
+# Weight / bias gradients are ADDED straight into the parameters' .grad buffers by the reduction kernel (p4c_gemm_tn, accumulate = 1)
+# instead of being returned for autograd's AccumulateGrad -- one small `+=` launch per parameter and AR step otherwise (and per
+# stand-in of trainer.RolloutParamProxies).  Only when the parameter (and its bias) already HAS a contiguous fp32 gradient buffer
+# (FlatDDP / the trainer allocate them; otherwise the ordinary path runs); set to False for code that needs torch.autograd.grad()
+# with respect to these parameters.  Same convention as graphlam.GRADS_IN_PLACE.
+GRADS_IN_PLACE = True
+
+
+def _sink(w, b):
+    """(gw, gb) views of the .grad buffers of a weight and its bias (gb None without a bias), or None when the gradients must go
+    through autograd"""
+    # (called inside Function.forward, where grad mode is off: requires_grad of the inputs says whether a backward will come)
+    if not (GRADS_IN_PLACE and w.requires_grad and (b is None or b.requires_grad)):
+        return None
+    from .ops_rows import grad_view
+
+    gw = grad_view(w)
+    gb = None if b is None else grad_view(b)
+    if gw is None or gw is False or gb is False or not gw.is_contiguous() or (gb is not None and not gb.is_contiguous()):
+        return None
+    return gw, gb
 
 
 def supported(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -116,6 +143,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, dgr)
         ctx.xshape, ctx.has_bias, ctx.has_res = x.shape, b is not None, res is not None
         ctx.wdtype, ctx.bdtype, ctx.OK = w.dtype, (None if b is None else b.dtype), (O, K)
+        ctx.sink = _sink(w, b)
         return y.view(*x.shape[:-1], O)
 
     @staticmethod
@@ -126,8 +154,8 @@ class _Linear(torch.autograd.Function):
         dx = gemm_nt(dy2, dgr, K, O)[0].view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = gemm_tn(dy2, x2, O, K, want_bias=ctx.has_bias)
-            dw = dw.to(ctx.wdtype)
+            dw, db = gemm_tn(dy2, x2, O, K, want_bias=ctx.has_bias, sink=ctx.sink)
+            dw = None if dw is None else dw.to(ctx.wdtype)
             db = None if db is None else db.to(ctx.bdtype)
         return dx, dw, db, (dy if ctx.has_res else None)
 
@@ -157,6 +185,7 @@ class _CatLinearRes(torch.autograd.Function):
         gemm_nt(xb2, fb, Ob, Kb, bias=_f32(bb), res=r2[:, Oa:], out=y[:, Oa:])
         ctx.save_for_backward(xa2, xb2, da, db_)
         ctx.meta = (xa.shape, xb.shape, Oa, Ka, Ob, Kb, wa.dtype, ba.dtype, wb.dtype, bb.dtype)
+        ctx.sinks = (_sink(wa, ba), _sink(wb, bb))
         return y.view(*res.shape)
 
     @staticmethod
@@ -167,9 +196,10 @@ class _CatLinearRes(torch.autograd.Function):
         dya, dyb = dy2[:, :Oa], dy2[:, Oa:]
         dxa = gemm_nt(dya, da, Ka, Oa)[0].view(sa)
         dxb = gemm_nt(dyb, db_, Kb, Ob)[0].view(sb)
-        dwa, dba = gemm_tn(dya, xa2, Oa, Ka, want_bias=True)
-        dwb, dbb = gemm_tn(dyb, xb2, Ob, Kb, want_bias=True)
-        return dxa, dwa.to(wadt), dba.to(badt), dxb, dwb.to(wbdt), dbb.to(bbdt), dy
+        dwa, dba = gemm_tn(dya, xa2, Oa, Ka, want_bias=True, sink=ctx.sinks[0])
+        dwb, dbb = gemm_tn(dyb, xb2, Ob, Kb, want_bias=True, sink=ctx.sinks[1])
+        cast = lambda t, dt: None if t is None else t.to(dt)      # noqa: E731
+        return dxa, cast(dwa, wadt), cast(dba, badt), dxb, cast(dwb, wbdt), cast(dbb, bbdt), dy
 
 
 def cat_linear_res(xa, wa, ba, xb, wb, bb, res) -> torch.Tensor:
@@ -194,6 +224,7 @@ class _MLP(torch.autograd.Function):
         ctx.save_for_backward(x2, g, h, d1, d2)
         ctx.xshape, ctx.dims, ctx.has_res = x.shape, (K, Hd, O), res is not None
         ctx.dt = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        ctx.sinks = (_sink(w1, b1), _sink(w2, b2))
         return y.view(*x.shape[:-1], O)
 
     @staticmethod
@@ -202,11 +233,11 @@ class _MLP(torch.autograd.Function):
         K, Hd, O = ctx.dims
         dy2 = _rows(dy, O)
         dh = gemm_nt(dy2, d2, Hd, O, act=ACT_GELU_BWD, aux_in=h)[0]            # (dy W2) * gelu'(h)
-        dw2, db2 = gemm_tn(dy2, g, O, Hd, want_bias=ctx.dt[3] is not None)
+        dw2, db2 = gemm_tn(dy2, g, O, Hd, want_bias=ctx.dt[3] is not None, sink=ctx.sinks[1])
         dx = gemm_nt(dh, d1, K, Hd)[0].view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw1, db1 = gemm_tn(dh, x2, Hd, K, want_bias=ctx.dt[1] is not None)
-        return (dx, dw1.to(ctx.dt[0]), None if db1 is None else db1.to(ctx.dt[1]), dw2.to(ctx.dt[2]),
-                None if db2 is None else db2.to(ctx.dt[3]), (dy if ctx.has_res else None))
+        dw1, db1 = gemm_tn(dh, x2, Hd, K, want_bias=ctx.dt[1] is not None, sink=ctx.sinks[0])
+        cast = lambda t, dt: None if t is None else t.to(dt)      # noqa: E731
+        return (dx, cast(dw1, ctx.dt[0]), cast(db1, ctx.dt[1]), cast(dw2, ctx.dt[2]), cast(db2, ctx.dt[3]), (dy if ctx.has_res else None))
 
 
 def mlp(x, w1, b1, w2, b2, res=None) -> torch.Tensor:
@@ -236,6 +267,7 @@ class _Conv(torch.autograd.Function):
         ctx.save_for_backward(xm, dgr)
         ctx.geom, ctx.has_bias, ctx.has_res = (B, H, W_, Cx, Co, Ci, taps), b is not None, res is not None
         ctx.wdtype, ctx.bdtype, ctx.wshape = w.dtype, (None if b is None else b.dtype), w.shape
+        ctx.sink = _sink(w, b)
         y = y.view(B, H, W_, Co)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -258,8 +290,8 @@ class _Conv(torch.autograd.Function):
             dx = dx.view(B, H, W_, Cx)
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = gemm_tn(dy2, xm, Co, Ci, conv=(H, W_) if taps == 9 else None, want_bias=ctx.has_bias)
-            dw = dw.view(ctx.wshape).to(ctx.wdtype)
+            dw, db = gemm_tn(dy2, xm, Co, Ci, conv=(H, W_) if taps == 9 else None, want_bias=ctx.has_bias, sink=ctx.sink)
+            dw = None if dw is None else dw.view(ctx.wshape).to(ctx.wdtype)
             db = None if db is None else db.to(ctx.bdtype)
         return dx, dw, db, (dy if ctx.has_res else None), None
 

@@ -91,8 +91,10 @@ def grad_view(t: Optional[torch.Tensor]):
     if t is None:
         return None
     base = L._base(t)      # (the parameter behind a slice, or behind a rollout's per-step stand-in of it)
+    if not base.is_leaf:       # (a derived weight: reading .grad of a non-leaf warns)
+        return False
     g = base.grad
-    if (not base.is_leaf or g is None or g.dtype != torch.float32 or g.shape != base.shape or g.stride() != base.stride()
+    if (g is None or g.dtype != torch.float32 or g.shape != base.shape or g.stride() != base.stride()
             or t.dtype != torch.float32):
         return False
     return g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset() + g.storage_offset())

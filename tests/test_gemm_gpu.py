@@ -323,3 +323,33 @@ def test_add_layer_norm_vs_float64(gpu_device, R, C, N):
     close_bf16(ln, lr, "ln")
     close_bf16(x.grad, xd.grad, "dx")
     assert rel(pos.grad, pd.grad) <= 5e-3 and rel(g.grad, gd.grad) <= 2e-3 and rel(b.grad, bd.grad) <= 2e-3
+
+
+def test_weight_gradients_accumulate_into_existing_grad_buffers(gpu_device):
+    """GRADS_IN_PLACE: with .grad buffers in place the reduction kernel ADDS dW / db into them (no AccumulateGrad launch); the sums
+    equal the ordinary path's, for a Linear with bias, a 3x3 convolution and a parameter seen through a detached stand-in
+    (trainer.RolloutParamProxies)."""
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    x = rnd((600, 64), dev, 81).bfloat16()
+    dy = rnd((600, 136), dev, 82).bfloat16()
+    w, b = torch.nn.Parameter(rnd((136, 64), dev, 83) / 8), torch.nn.Parameter(rnd((136,), dev, 84))
+    G.linear(x, w, b).backward(dy)                       # no buffers yet: through autograd
+    ref_w, ref_b = w.grad.clone(), b.grad.clone()
+    w.grad.fill_(1.0), b.grad.fill_(2.0)
+    G.linear(x, w, b).backward(dy)                       # buffers exist: added in place
+    assert torch.allclose(w.grad, ref_w + 1.0, rtol=0, atol=1e-5 * float(ref_w.abs().max())) and torch.allclose(b.grad, ref_b + 2.0, rtol=0, atol=1e-4)
+    # a stand-in of the parameter (same storage, owner attribute): the owner's buffer receives the sum
+    q = w.detach().requires_grad_(True)
+    q._p4c_owner = w
+    w.grad.zero_()
+    G.linear(x, q, None).backward(dy)
+    assert q.grad is None and torch.allclose(w.grad, ref_w, rtol=0, atol=1e-5 * float(ref_w.abs().max()))
+    xc = rnd((2, 16, 16, 64), dev, 85).bfloat16()
+    dyc = rnd((2, 16, 16, 72), dev, 86).bfloat16()
+    wc = torch.nn.Parameter(rnd((72, 64, 3, 3), dev, 87) / 24)
+    G.conv2d_nhwc(xc, wc).backward(dyc)
+    ref_c = wc.grad.clone()
+    G.conv2d_nhwc(xc, wc).backward(dyc)
+    assert torch.allclose(wc.grad, 2 * ref_c, rtol=0, atol=1e-5 * float(ref_c.abs().max()))
