@@ -31,6 +31,7 @@ from torch import nn
 
 from . import _lib as L
 from . import ops_inorm as ON
+from . import ops_gemm as G
 from . import ops_model as OM
 from . import ops_rows as R
 from .base import ModelABC, ModelType
@@ -108,8 +109,29 @@ def inverse_index_table(index: torch.Tensor, rows: int) -> torch.Tensor:
     return out
 
 
+def _native(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.bfloat16 and os.environ.get("P4C_SWIN_LIBRARY") != "1"
+
+
+def _lin(x: torch.Tensor, w: torch.Tensor, b=None, res=None) -> torch.Tensor:
+    """x W^T + b (+ res): the streaming row-GEMM kernels (csrc/rowgemm.hip) for the two large stages' narrow layers they were measured
+    on, the tiled MFMA GEMM with its fused epilogue (csrc/gemm.hip, round 5) for the deep stages' wide ones -- library GEMMs only for
+    the fp32 flavour / widths off the 8-feature granularity"""
+    if _native(x) and G.supported(x, w) and not R._row_gemm_ok(x, w, b):
+        return G.linear(x, w, b, res)
+    y = R.linear_nd(x, w, b)
+    return y if res is None else y + res
+
+
 def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
-    return R.linear_nd(x, m.weight, m.bias)
+    return _lin(x, m.weight, m.bias)
+
+
+def _mlp(fc1: nn.Linear, fc2: nn.Linear, x: torch.Tensor, res: torch.Tensor) -> torch.Tensor:
+    """res + fc2(gelu(fc1(x))): one autograd node with GELU / GELU' in the GEMM epilogues where the tiled GEMM carries both layers"""
+    if (_native(x) and G.supported(x, fc1.weight) and G.supported(x, fc2.weight) and not R._row_gemm_ok(x, fc1.weight, fc1.bias)):
+        return G.mlp(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, res)
+    return res + _linear(fc2, F.gelu(_linear(fc1, x)))
 
 
 class SwinBlock(nn.Module):
@@ -140,11 +162,11 @@ class SwinBlock(nn.Module):
         bias = _TableRows.apply(self.relative_position_bias_table, self.relative_position_index.view(-1),
                                 self._rpi_rows_of).view(N, N, self.heads).permute(2, 0, 1)
         a = window_attention(_linear(self.qkv, h), bias, self.heads, ws, shift)
-        a = _linear(self.proj, a)
         if pb or pr:
-            a = a[:, :H, :W, :]
-        x = x + a
-        return x + _linear(self.fc2, F.gelu(_linear(self.fc1, _layer_norm(self.norm2, x))))
+            x = x + _linear(self.proj, a)[:, :H, :W, :]
+        else:
+            x = _lin(a, self.proj.weight, self.proj.bias, res=x)       # the residual in the projection's epilogue
+        return _mlp(self.fc1, self.fc2, _layer_norm(self.norm2, x), x)
 
 
 class PatchMerging(nn.Module):
@@ -170,6 +192,8 @@ def _conv_hw(m: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     and weight gradient: ops_model.conv_nhwc); the few wider ones at <= 1/8 resolution go through the library in its own layout."""
     if OM.conv_nhwc_supported(x, m.weight):
         return OM.conv_nhwc(x, m.weight)
+    if _native(x) and m.bias is None and G.conv_supported(x, m.weight) and m.kernel_size[0] in (1, 3) and m.padding == (m.kernel_size[0] // 2,) * 2:
+        return G.conv2d_nhwc(x.contiguous(), m.weight)       # the wide ones (96 ... 384 channels): implicit GEMM, csrc/gemm.hip
     y = OM.library_conv2d(x.permute(0, 3, 1, 2).contiguous(), R.param_as(m.weight, x.dtype), None, padding=m.padding)
     return y.permute(0, 2, 3, 1).contiguous()
 
@@ -213,8 +237,11 @@ class UpBlock(nn.Module):
         B, H, W, cin = x.shape
         wt = self.transp_conv.weight                                         # (cin, cout, 2, 2)
         cout = wt.shape[1]
-        wr = wt.permute(0, 2, 3, 1).reshape(cin, 4 * cout).to(x.dtype)
-        up = (x.reshape(-1, cin) @ wr).view(B, H, W, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, cout)
+        if _native(x) and cin % 8 == 0 and cout % 2 == 0:
+            up = _lin(x.reshape(-1, cin), wt.permute(2, 3, 1, 0).reshape(4 * cout, cin))
+        else:
+            up = x.reshape(-1, cin) @ wt.permute(0, 2, 3, 1).reshape(cin, 4 * cout).to(x.dtype)
+        up = up.view(B, H, W, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, cout)
         return self.conv_block(torch.cat([up, skip], dim=-1))
 
 
