@@ -340,6 +340,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # each rank of the node on its own block of host cores, before anything of this process touches the GPU (trainer.pin_rank_to_cores)
+    from py4cast_amd.trainer import pin_rank_to_cores
+
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    affinity = pin_rank_to_cores(local_rank, local_world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     # P4C_DIST_SHARE_GPU=1 (tests on a 1-GPU box only): every rank on cuda:0, gloo transport -- exercises the N > 1 code path of this
     # script (barriers, MAX over ranks, aggregate value); the number it prints is NOT a scaling measurement
@@ -412,12 +417,16 @@ def main():
         step(-1 - i)
     barrier()
     probe = None
-    if args.hip_graph == "auto" and not use_graph and hasattr(lm.model, "native_rollout") and world == 1:
-        # Launch-mode probe (also outside the W + K contract).  The native HalfUNet step is ~300 launches: issued eagerly they cost
-        # the host ~3.4 ms, less than the GPU needs, and eager launching is then ~7 % FASTER than replaying the captured step -- but
-        # on a slow or busy host the step becomes host-bound, and the replay (one launch) is the faster way.  Measure both, keep one.
-        # (Single-process runs only: with several ranks the eager mode is kept -- a capture next to RCCL's watchdog threads is a
-        # risk the measurement does not need; `--hip-graph on` still forces the replay there.)
+    graph_single_stream = False
+    if args.hip_graph == "auto" and not use_graph and hasattr(lm.model, "native_rollout"):
+        # Launch-mode probe (also outside the W + K contract).  The native HalfUNet step is ~230 launches: issued eagerly they cost
+        # the host ~2 ms, less than the GPU needs, and eager launching is then faster than replaying the captured step -- but on a
+        # slow or busy host (eight ranks on one node) the step becomes host-bound, and a replay (one launch) is the faster way.
+        # Three modes are measured: eager, the captured two-stream step, and the captured step with the weight gradients on the
+        # main stream (the two-stream capture is dealt over four hardware queues and loses its overlap; the one-stream replay costs
+        # what eager costs on the GPU and nothing on the host: profiles/r04_graph_vs_eager.txt).  With several ranks every rank
+        # measures, the MAXIMA over the ranks decide, so all ranks pick the same mode (captures hold no collective: the gradient
+        # exchange stays outside the graph).
         def per_step(n):
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -426,24 +435,37 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
 
-        t_eager, captured = per_step(3), True
-        try:
-            from py4cast_amd.trainer import GraphedTrainingStep
+        from py4cast_amd.trainer import GraphedTrainingStep
 
+        def graph_time(single):
+            L.lib().p4c_side_stream_enable(0 if single else 1)
+            t, ok = float("inf"), True
+            try:
+                ddp.zero_grad()
+                graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
+            except Exception as exc:  # noqa: BLE001  (a step that cannot be captured simply stays eager)
+                print(f"bench: HIP-graph probe failed ({type(exc).__name__}: {exc}); eager launching", file=sys.stderr)
+                graphed[0], ok = None, False
             ddp.zero_grad()
-            graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
-        except Exception as exc:  # noqa: BLE001  (a step that cannot be captured simply stays eager)
-            print(f"bench: HIP-graph probe failed ({type(exc).__name__}: {exc}); eager launching", file=sys.stderr)
-            graphed[0], captured = None, False
-        ddp.zero_grad()
-        per_step(1)                # (run on every rank whether or not its capture worked: the ranks' collective counts stay equal)
-        t_second = per_step(3)
-        t_graph = t_second if captured else None
-        graphed[0] = None
-        ddp.zero_grad()
-        use_graph = t_graph is not None and t_graph < 0.97 * t_eager
-        probe = {"eager_ms_per_step": 1e3 * t_eager, "graph_ms_per_step": None if t_graph is None else 1e3 * t_graph,
-                 "chosen": "graph" if use_graph else "eager"}
+            per_step(1)            # (run on every rank whether or not its capture worked: the ranks' collective counts stay equal)
+            t_run = per_step(3)
+            graphed[0] = None
+            ddp.zero_grad()
+            L.lib().p4c_side_stream_enable(1)
+            return t_run if ok else t
+
+        times = [per_step(3), graph_time(False), graph_time(True)]
+        if world > 1:
+            tt = torch.tensor([min(t, 1e9) for t in times], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            times = [float(v) if float(v) < 1e9 else float("inf") for v in tt.tolist()]
+        t_eager, t_graph, t_graph1 = times
+        best_graph = min(t_graph, t_graph1)
+        use_graph = best_graph < 0.97 * t_eager
+        graph_single_stream = use_graph and t_graph1 <= t_graph
+        ms = lambda t: None if t == float("inf") else 1e3 * t      # noqa: E731
+        probe = {"eager_ms_per_step": ms(t_eager), "graph_ms_per_step": ms(t_graph), "graph_single_stream_ms_per_step": ms(t_graph1),
+                 "agreed_over_ranks": world, "chosen": ("graph, single stream" if graph_single_stream else "graph") if use_graph else "eager"}
         barrier()
     # The timed region is ~0.1 s: a generational garbage collection of this process (tens of thousands of tracked objects once
     # torch and the model are loaded) is a 10-50 ms host pause that starves the GPU.  The collector is parked from here on --
@@ -485,6 +507,8 @@ def main():
         L.enable_kernel_timing(None)
         L.lib().p4c_prof_enable(0, 0)   # no event markers inside a capture
         ddp.zero_grad()
+        if graph_single_stream:
+            L.lib().p4c_side_stream_enable(0)
         try:
             graphed[0] = GraphedTrainingStep(lm, make_batch(case), loss_scale=1.0 / args.accumulate)
             graph_note = graphed[0].verified
@@ -538,10 +562,13 @@ def main():
         torch.cuda.synchronize()
         extra = lm.model.launch_times(B=B, H=H, W=W) if rank == 0 else None
         L.lib().p4c_prof_enable(0, 0)
+    affinity_all = None
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt, host_enqueue_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, host_enqueue_ms = float(tmax[0].item()), float(tmax[1].item())      # (host loop: the slowest rank's)
+        affinity_all = [None] * world
+        torch.distributed.all_gather_object(affinity_all, affinity)
 
     if rank == 0:
         N = H * W
@@ -629,6 +656,7 @@ def main():
                 "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
                 "device_allocs_in_timed_region": int(device_allocs),
                 "host_loop_ms_per_step": round(host_enqueue_ms, 3),
+                "host_cores_per_rank": affinity_all if world > 1 else affinity,
                 "launch_mode_probe": probe,
             },
             "loss": float(loss.detach()),

@@ -410,7 +410,7 @@ typedef struct p4c_halfunet_desc {
 /* Side stream of the calling thread for p4c_halfunet_backward (weight gradients run beside the backward chain, ordered by
  * events and joined before the call returns control of `stream`): `side` a hipStream_t, `events` n_events >= 8 hipEvent_t
  * handles created with hipEventDisableTiming, all owned by the caller and alive until replaced.  side = NULL restores the
- * default (library-created on first use).  Environment: P4C_SIDE_STREAM=0 runs everything on `stream`. */
+ * default (library-created on first use).  p4c_side_stream_enable(0) runs everything on `stream`. */
 int p4c_set_side_stream(p4c_stream_t side, void* const* events, int n_events);
 /* Deferred join (calling thread, library-owned side stream only): with on = 1, p4c_halfunet_backward returns WITHOUT making
  * `stream` wait for the weight gradients it put on the side stream -- the gradient buffer is complete only after
@@ -419,6 +419,10 @@ int p4c_set_side_stream(p4c_stream_t side, void* const* events, int n_events);
  * The caller keeps x / saved / dy of every deferred call alive (and un-reused) until the join; dy may be overwritten by the next
  * call's producer (the call orders that itself). */
 int p4c_side_stream_defer(int on);
+/* on = 0: the weight gradients run on the caller's stream like everything else (a host that cannot keep two streams fed; the
+ * single-stream HIP-graph capture); on = 1: beside the backward chain again.  Between steps only (nothing in flight on the side
+ * stream). */
+int p4c_side_stream_enable(int on);
 int p4c_side_stream_join(p4c_stream_t stream);
 /* Rewrite a captured, not yet instantiated HIP graph (hipGraph_t): every 1-D memset node becomes a kernel node filling the same bytes
  * with the same dependencies.  On this stack memset nodes replay a wrong byte value from the second launch on, which breaks library
@@ -445,7 +449,8 @@ int p4c_halfunet_forward(const p4c_halfunet_desc* d, const void* x, const float*
  * convolution's weight (cout,64) fp32 inside `params`. */
 int p4c_halfunet_tail(const p4c_halfunet_desc* d, const float* params, void* saved, const void** a, const float** a_scale,
                       const float** a_shift, const float** wout);
-/* dy: (B,H,W,64) (channels >= cout ignored); dx: (B,H,W,64) or NULL (first dx_channels channels valid);
+/* dy: (B,H,W,64), channels >= cout must be ZERO (the fused backward of the output convolution feeds all 64 to the matrix cores
+ * against zero weight rows: NaN / Inf garbage there would reach every upstream gradient; the in-tree rollout zero-fills them); dx: (B,H,W,64) or NULL (first dx_channels channels valid);
  * grads: flat, same layout as params, ACCUMULATED into (+=). */
 int p4c_halfunet_backward(const p4c_halfunet_desc* d, const void* x, const float* params, const void* dy, void* dx,
                           float* grads, void* saved, void* scratch, int training, p4c_stream_t stream);

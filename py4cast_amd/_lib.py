@@ -176,6 +176,38 @@ def lib():
     return _lib
 
 
+DIAG_LIB_PATH = os.path.join(_HERE, "libpy4cast_hip_diag.so")
+_diag = None
+
+
+class use_diagnostic_library:
+    """Context manager: route every call of this process to libpy4cast_hip_diag.so (``make -C py4cast_amd/csrc diag``) -- the same
+    sources built with -DP4C_DIAG_BUILD, where the P4C_* environment switches that select an older kernel / another geometry are
+    live.  The product library reads none of them.  For the A/B parity tests and tools/diagnostics only."""
+
+    def __enter__(self):
+        global _lib, _diag
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise P4CError(f"{DIAG_LIB_PATH} not found: run `make -C py4cast_amd/csrc diag` (or __graft_entry__.build())")
+        lib()
+        if _diag is None:
+            _diag = ctypes.CDLL(DIAG_LIB_PATH)
+            _declare(_diag, SIGNATURES, OTHER)
+            from . import _lib_model
+
+            _declare(_diag, _lib_model.SIGNATURES, _lib_model.OTHER)
+        self._saved = _lib
+        _lib = _diag
+        invalidate_param_caches()      # derived tensors of the other library's plans are not this one's
+        return _diag
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        invalidate_param_caches()
+        return False
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().p4c_last_error()

@@ -60,6 +60,7 @@ SIGNATURES = {
     "p4c_halfunet_tail": [DP, P, P, P, P, P, P],
     "p4c_halfunet_backward": [DP, P, P, P, P, P, P, P, I, P],
     "p4c_side_stream_defer": [I],
+    "p4c_side_stream_enable": [I],
     "p4c_side_stream_join": [P],
     "p4c_edge_gather_add_fwd": [P, P, P, P, P, P, L, I, I, I, P],
     "p4c_edge_gather_add_bwd": [P, P, P, P, P, P, P, L, I, I, I, P],

@@ -874,7 +874,7 @@ using namespace p4c;
 // fp32 activations run the fp32-exact kernels; P4C_ATTN_F32_MFMA=1 sends them through the bf16 matrix-core kernels instead (operands
 // and P rounded to bf16: the round-1/2 behaviour, kept as an A/B switch)
 static bool f32_on_matrix_cores() {
-    const char* e = getenv("P4C_ATTN_F32_MFMA");
+    const char* e = diag_env("P4C_ATTN_F32_MFMA");
     return e && e[0] == '1';
 }
 

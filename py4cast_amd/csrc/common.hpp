@@ -60,6 +60,17 @@ inline hipError_t zero_words_async(void* p, size_t bytes, hipStream_t st) {   //
 
 static inline hipStream_t as_stream(p4c_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A/B switches (P4C_* environment variables that select an older kernel, a geometry, a timing experiment) exist in DIAGNOSTIC builds
+// only: `make diag` (-DP4C_DIAG_BUILD) -> libpy4cast_hip_diag.so, loaded by tools/diagnostics and by the A/B parity tests.  In the
+// product library every switch compiles to its default -- one path per shape, and a deployment cannot differ silently from the
+// measured configuration through its environment.
+#include <stdlib.h>
+#ifdef P4C_DIAG_BUILD
+static inline const char* diag_env(const char* name) { return getenv(name); }
+#else
+static inline const char* diag_env(const char*) { return nullptr; }
+#endif
+
 // Timing diagnostics only (results become wrong): P4C_DIAG bit mask, honoured after the first 400 calls of each site so that
 // buffers hold plausible values.  1: skip forward norm_finalize, 2: skip norm_bwd_finalize, 4: skip norm_bwd_reduce too,
 // 8: skip wgrad_reduce, 16: skip norm_bwd_apply.

@@ -2090,9 +2090,9 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
         // kernel as a half-empty 64-channel chunk, absent channel octets staged as zeros; it then takes NormBwdCoef.  Measured:
         // neutral without NormBwdCoef, 0.04 ms per step SLOWER with it -- block 0's weight gradient is the tail of the backward and
         // both of its launches then read y as well -- so the tiled kernel and the norm_bwd_apply launch stay the default)
-        const bool rem_ws = chunk == 32 && ks == 3 && off > 0 && getenv("P4C_WGWS_REM") != nullptr;
-        const bool ws_ok = (chunk == 64 || rem_ws) && (ks == 3 || getenv("P4C_NO_WGWS_1X1") == nullptr) && std::is_same<T, __bf16>::value &&
-                           B <= wgws::MAXB && getenv("P4C_NO_WGWS") == nullptr;
+        const bool rem_ws = chunk == 32 && ks == 3 && off > 0 && diag_env("P4C_WGWS_REM") != nullptr;
+        const bool ws_ok = (chunk == 64 || rem_ws) && (ks == 3 || diag_env("P4C_NO_WGWS_1X1") == nullptr) && std::is_same<T, __bf16>::value &&
+                           B <= wgws::MAXB && diag_env("P4C_NO_WGWS") == nullptr;
         if (nb && !ws_ok) return fail(P4C_ERR_INVALID, "conv_wgrad_bf16: NormBwdCoef needs the role-split 3x3 kernel (64-channel chunk, bf16)");
         if (ws_ok)
             rc = launch_conv3x3_wgrad_bf16_ws((const __bf16*)in, in_scale, in_shift, in_relu, (const __bf16*)dout, partial, G, B, H, W,
@@ -2115,8 +2115,8 @@ static int conv_wgrad_bf16_t(const T* in, int CI, int ks, const float* in_scale,
 
 // every chunk of this weight gradient runs on the role-split kernel, i.e. the launch takes NormBwdCoef
 bool conv_wgrad_bf16_takes_nb(int storage, int CI, int ks, int B) {
-    if (storage != P4C_BF16 || ks != 3 || B > wgws::MAXB || getenv("P4C_NO_WGWS")) return false;
-    return CI % 64 == 0 || (CI % 64 == 32 && CI > 64 && getenv("P4C_WGWS_REM") != nullptr);
+    if (storage != P4C_BF16 || ks != 3 || B > wgws::MAXB || diag_env("P4C_NO_WGWS")) return false;
+    return CI % 64 == 0 || (CI % 64 == 32 && CI > 64 && diag_env("P4C_WGWS_REM") != nullptr);
 }
 
 int conv_wgrad_bf16(const void* in, int storage, int CI, int ks, const float* in_scale, const float* in_shift, int in_relu,

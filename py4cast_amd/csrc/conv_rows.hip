@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 static int rows_mfma_shape() {   // 32 (default): v_mfma_f32_32x32x16_bf16; P4C_ROWS_MFMA=16: v_mfma_f32_16x16x32_bf16 (A/B runs: 15 % faster in a bare MFMA loop, tools/diagnostics/mfma_power.hip, but 2-5 % slower here -- its 16-cycle MFMAs leave the memory-side waves half the issue slots)
-    const char* e = getenv("P4C_ROWS_MFMA");
+    const char* e = diag_env("P4C_ROWS_MFMA");
     return (e && atoi(e) == 16) ? 16 : 32;
 }
 
@@ -899,7 +899,7 @@ int launch_rows_compact(const __bf16* in, int in_cs, const __bf16* wp, __bf16* o
 void conv_rows_geometry(int B, int H, int W, int* nstrips_out, int* nseg_out) {
     const int nstrips = (W + rows::SW - 1) / rows::SW;
     int best = 1;
-    if (const char* e = getenv("P4C_ROWS_NSEG")) {
+    if (const char* e = diag_env("P4C_ROWS_NSEG")) {
         best = atoi(e);
     } else {
         const int cus = num_cus();
@@ -919,16 +919,16 @@ void conv_rows_geometry(int B, int H, int W, int* nstrips_out, int* nseg_out) {
 }
 
 bool conv_bf16_is_rows(int storage, int CI, int ks, int m_blocks, int out_cs, int B, int H, int W) {
-    const char* e = getenv("P4C_NO_ROWS");   // (read per call: the A/B scripts and the parity tests switch it)
+    const char* e = diag_env("P4C_NO_ROWS");   // (read per call: the A/B scripts and the parity tests switch it)
     const bool off = e && e[0] == '1';
-    const char* e1 = getenv("P4C_NO_ROWS_1X1");
+    const char* e1 = diag_env("P4C_NO_ROWS_1X1");
     if (ks == 1 && e1 && e1[0] == '1') return false;
     return !off && storage == P4C_BF16 && CI == 64 && (ks == 3 || ks == 1) && m_blocks == 1 && out_cs % 8 == 0 && W > 32 && H >= 8 &&
            (int64_t)H * W * out_cs * 2 < (int64_t)1 << 31 && (int64_t)H * W * 128 < (int64_t)1 << 31;
 }
 
 bool conv_bf16_norm_bwd_fused_ok(int storage, int CI, int B, int H, int W) {
-    const char* e = getenv("P4C_NO_FUSED_APPLY");   // (A/B switch and parity tests)
+    const char* e = diag_env("P4C_NO_FUSED_APPLY");   // (A/B switch and parity tests)
     if (e && e[0] == '1') return false;
     // data gradient on the row kernel, weight gradient on the role-split kernel (one 64-channel chunk, its sample limit)
     return CI == 64 && B <= 32 && conv_bf16_is_rows(storage, 64, 3, 1, 64, B, H, W);

@@ -391,7 +391,7 @@ int launch_mode(const WgRowsArgs& a, bool nb, int nseg, int nstrips, int B, hipS
 static void wgrad_rows_geometry(int G, int B, int H, int W, int* nstrips_out, int* nseg_out) {
     const int nstrips = W / wr::SW;
     int nseg = G / (B * nstrips);
-    if (const char* e = getenv("P4C_WGROWS_NSEG")) nseg = atoi(e);   // (experiments; still clamped to the buffer)
+    if (const char* e = diag_env("P4C_WGROWS_NSEG")) nseg = atoi(e);   // (experiments; still clamped to the buffer)
     if (nseg > G / (B * nstrips)) nseg = G / (B * nstrips);
     if (nseg > H / wr::MIN_ROWS) nseg = H / wr::MIN_ROWS;
     if (nseg < 1) nseg = 1;
@@ -401,7 +401,7 @@ static void wgrad_rows_geometry(int G, int B, int H, int W, int* nstrips_out, in
 
 // in_cs: channels per pixel of x (a multiple of 8); the chunk starts at channel ci_off (a multiple of 32)
 bool conv_wgrad_rows_ok(int storage, int in_cs, int ci_off, int dout_cs, int ks, int G, int B, int H, int W) {
-    const char* e = getenv("P4C_NO_WGRAD_ROWS");   // (read per call: A/B scripts and the parity tests switch it)
+    const char* e = diag_env("P4C_NO_WGRAD_ROWS");   // (read per call: A/B scripts and the parity tests switch it)
     if (e && e[0] == '1') return false;
     return storage == P4C_BF16 && in_cs >= 8 && in_cs % 8 == 0 && ci_off % 32 == 0 && ci_off < in_cs && dout_cs == 64 && ks == 3 &&
            W % wr::SW == 0 && H >= wr::MIN_ROWS && B * (W / wr::SW) <= G && (int64_t)H * W * in_cs * 2 < (int64_t)1 << 31;

@@ -124,7 +124,7 @@ void make_layout(const p4c_halfunet_desc& d, Layout& L) {
     // ACCUMULATE over the AR steps of a rollout with one reduction at the join (the read-modify-write epilogue exposes the partials'
     // memory latency at the end of every launch: weight-gradient launches 104 -> 141 us, the step 4.96 -> 6.33 ms).
     L.G = d.compute == P4C_BF16 ? num_cus() / 2 : num_cus();   // (fp32 matrix cores: the kernel is MFMA-bound, all CUs)
-    if (const char* e = getenv("P4C_WGRAD_G")) { const int g = atoi(e); if (g > 0 && g <= num_cus()) L.G = g; }
+    if (const char* e = diag_env("P4C_WGRAD_G")) { const int g = atoi(e); if (g > 0 && g <= num_cus()) L.G = g; }
     off = 0;
     L.wprep = off; off += (int64_t)NWSLOT * WSLOT_FLOATS;
     const int64_t tps = conv_tiles_per_sample(d.H, d.W);
@@ -226,12 +226,12 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     float* rm = running ? running + (int64_t)i * 128 : nullptr;
     float* rv = running ? rm + 64 : nullptr;
     // BatchNorm statistics of a ring-kernel convolution are finished by the kernel itself (its last workgroup): no norm_finalize launch
-    const char* ie = getenv("P4C_NO_INKERNEL_FINALIZE");
+    const char* ie = diag_env("P4C_NO_INKERNEL_FINALIZE");
     const bool no_infin = ie && ie[0] == '1';
     // (below the full resolution only: there the in-kernel tail -- slot store, ticket, the last workgroup's 128 KB read -- costs
     // ~5 us against ~8 for the launch it replaces and stretches the roofline kernel's launches by that much; on the coarse levels
     // every launch is latency and one fewer is a clean gain.  P4C_INKERNEL_FINALIZE_ALL=1 turns it on everywhere.)
-    const char* ia = getenv("P4C_INKERNEL_FINALIZE_ALL");
+    const char* ia = diag_env("P4C_INKERNEL_FINALIZE_ALL");
     const bool all_levels = ia && ia[0] == '1';
     const bool infin = batch_stats && d.norm == 0 && d.compute == P4C_BF16 && !no_infin && (all_levels || lev > 0) &&
                        conv_bf16_is_ring(d.dtype, conv_cin_pad(d, i), 3, 1, NF, d.B, H, W);
@@ -294,12 +294,12 @@ struct SideStream {
     }
     int init() {
         if (stream || external) return P4C_OK;
-        const char* e = getenv("P4C_SIDE_STREAM");
+        const char* e = diag_env("P4C_SIDE_STREAM");
         enabled = !(e && e[0] == '0');
-        if (const char* n = getenv("P4C_SIDE_EVERY")) { const int v = atoi(n); if (v > 0) every = v; }
+        if (const char* n = diag_env("P4C_SIDE_EVERY")) { const int v = atoi(n); if (v > 0) every = v; }
         if (!enabled) return P4C_OK;
         // (A/B switch P4C_SIDE_PRIO: -1 = lowest, 1 = highest queue priority for the weight-gradient stream)
-        const char* pr = getenv("P4C_SIDE_PRIO");
+        const char* pr = diag_env("P4C_SIDE_PRIO");
         if (pr && pr[0] != '0') {
             int lo = 0, hi = 0;
             P4C_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -379,11 +379,11 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     // Consumer-side pass 2 for EVERY block: where the data-gradient launch would also take pass 1 of the next normalisation (both
     // loaders in one kernel exceed the register file) it gives that up and a norm_bwd_reduce launch (2 reads) takes it -- instead of
     // a norm_bwd_apply launch (2 reads + 1 write) here: 4.96 -> 4.91 ms per step.  P4C_NB_ALL=0: the earlier split.
-    static const bool nb_all = [] { const char* e = getenv("P4C_NB_ALL"); return !(e && e[0] == '0'); }();
+    static const bool nb_all = [] { const char* e = diag_env("P4C_NB_ALL"); return !(e && e[0] == '0'); }();
     // (the first convolution's 96-channel input: its weight gradient runs as a 64-channel chunk + a half-empty one, both on the
     // role-split kernel -- conv_wgrad_bf16_takes_nb -- and its data gradient, state channels only, is a 64 -> 64 launch)
     const bool nbf = (!dgrad_takes_pass1 || nb_all) && d.compute == P4C_BF16 && conv_bf16_norm_bwd_fused_ok(d.dtype, NF, d.B, H, W) &&
-                     (cip == NF || (nb_all && getenv("P4C_NO_NB0") == nullptr && conv_wgrad_bf16_takes_nb(d.dtype, cip, 3, d.B)));
+                     (cip == NF || (nb_all && diag_env("P4C_NO_NB0") == nullptr && conv_wgrad_bf16_takes_nb(d.dtype, cip, 3, d.B)));
     P4C_TRY(norm_bwd(d.dtype, g, ws.act(L.Y[i]), nm.scale, nm.shift, nm.mean, nm.rstd, params + L.gamma[i], 1, d.B,
                      (int64_t)H * W, d.norm, d.groups, stats_training, ws.f(L.nbwdp), ws.f(L.k1i[g_side.calls & 1][i]), ws.f(L.k2i[g_side.calls & 1][i]),
                      grads + L.gamma[i], grads + L.beta[i], nbf ? nullptr : g, st, pre_nblk, bwd_ticket(d, ws), pre_finalized));
@@ -407,7 +407,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
         // (block 1 closes a batch whatever its size: the full-resolution weight gradient of conv 1 then runs beside the chain of
         // block 0 instead of after it, and only block 0's is left over when the main stream ends -- with the join deferred over
         // the AR steps that left-over is exposed once per optimizer step: 240 -> ~60 us)
-        const char* f1 = getenv("P4C_FLUSH_AT_1");   // (A/B switch)
+        const char* f1 = diag_env("P4C_FLUSH_AT_1");   // (A/B switch)
         const bool at1 = i == 1 && !g_side.external && !(f1 && f1[0] == '0');
         if ((int)g_side.pending.size() >= g_side.every || at1) P4C_TRY(g_side.flush(st));
     } else {
@@ -417,7 +417,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
     if (din) {
         // the input of this convolution is relu(norm(Y[i-1])): its data gradient IS the dA of layer i-1's normalisation backward,
         // whose pass 1 (sums of g and g * xhat) the ring / row kernel takes while it stores the gradient rows
-        const char* fe = getenv("P4C_NO_FUSED_REDUCE");   // (read per call: the parity test switches it)
+        const char* fe = diag_env("P4C_NO_FUSED_REDUCE");   // (read per call: the parity test switches it)
         const bool fuse_off = fe && fe[0] == '1';
         // Both roles in one launch -- pass 2 of this block's normalisation backward in the loader, pass 1 of the next block's in the
         // drain -- do not fit the register file at four rows per interval (137 spilled registers; 59 with the roles' constants in
@@ -426,7 +426,7 @@ int conv_block_bwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
         // fewer per step -- but the step does not get faster: 4.60 vs 4.61 ms at 2x512x512x60, 4.88 vs 4.82 at the Titan shape
         // (profiles/r04_step_ab_runs.txt block 20: the weight-gradient stream pays for what the chain saves).  Kept behind
         // P4C_NB_BST=1, parity-tested both ways (tests/test_bwd_infin_gpu.py).
-        const char* nbe = getenv("P4C_NB_BST");   // (read per call: the parity test switches it)
+        const char* nbe = diag_env("P4C_NB_BST");   // (read per call: the parity test switches it)
         const bool nb_bst = nbe && nbe[0] == '1';
         const bool fuse = !fuse_off && next_nblk && in_norm && i > 0 && d.compute == P4C_BF16 && (!(nbf && dgrad_takes_pass1) || nb_bst) &&
                           conv_bf16_bwd_stats_ok(d.dtype, d.B, H, W);
@@ -496,41 +496,14 @@ extern "C" int p4c_halfunet_forward(const p4c_halfunet_desc* dp, const void* x, 
     const WS ws{L, (char*)savedv, (char*)scratchv};
     if (!d.weights_prepared) P4C_TRY(prepare_weights(d, ws, params, 1, st));
 
-    // encoder.  Levels 2 .. 4 (BatchNorm with batch statistics, bf16 maps) can run as one persistent launch instead of 3 max-pools + 6
-    // convolution launches (coarse_fwd.hip; P4C_COARSE_FWD=1) -- measured SLOWER (925 against 673 us per forward: its grid-wide barriers
-    // cost more than the kernel boundaries they replace), so it is off unless asked for
-    const bool coarse = d.norm == 0 && training && d.compute == P4C_BF16 && coarse_fwd_ok(d.dtype, d.B, L.Hk[2], L.Wk[2]) &&
-                        (int64_t)d.B * 4 * num_cus() * 128 >= (int64_t)coarse_fwd_scratch_floats();
+    // encoder (a persistent one-launch form of levels 2 .. 4 with grid-wide barriers was built in round 4, measured slower -- 925
+    // against 673 us per forward -- and removed in round 5: profiles/r04_step_ab_runs.txt block 25, profiles/HISTORY.md)
     for (int k = 0; k < NLEV; ++k) {
-        if (coarse && k == 2) {
-            Norm top = norm_at(ws, 3, d.B);
-            void* P[3];
-            void* Y[3][2];
-            const void* wp[3][2];
-            const float *gm[3][2], *bt[3][2];
-            float *rm[3][2], *rv[3][2], *nm[3][2];
-            for (int lv = 0; lv < 3; ++lv) {
-                P[lv] = ws.act(L.P[lv + 2]);
-                for (int j = 0; j < 2; ++j) {
-                    const int i = 2 * (lv + 2) + j;
-                    Y[lv][j] = ws.act(L.Y[i]);
-                    wp[lv][j] = wslot(ws, i);
-                    gm[lv][j] = params + L.gamma[i];
-                    bt[lv][j] = params + L.beta[i];
-                    rm[lv][j] = running ? running + (int64_t)i * 128 : nullptr;
-                    rv[lv][j] = running ? running + (int64_t)i * 128 + 64 : nullptr;
-                    nm[lv][j] = norm_at(ws, i, d.B).scale;
-                }
-            }
-            P4C_TRY(launch_coarse_fwd(ws.act(L.Y[3]), top.scale, top.shift, P, Y, wp, gm, bt, rm, rv, nm, ws.f(L.statp),
-                                      reinterpret_cast<unsigned int*>(ws.f(L.tickets)) + 4, d.B, L.Hk[2], L.Wk[2], d.eps, d.momentum, st));
-            break;
-        }
         const void* in = k == 0 ? x : ws.act(L.P[k]);
         P4C_TRY(conv_block_fwd(d, ws, 2 * k, in, nullptr, params, running, training, st));
         Norm n1 = norm_at(ws, 2 * k, d.B);
         P4C_TRY(conv_block_fwd(d, ws, 2 * k + 1, ws.act(L.Y[2 * k]), &n1, params, running, training, st));
-        if (k + 1 < NLEV && !(coarse && k == 1)) {
+        if (k + 1 < NLEV) {
             Norm n2 = norm_at(ws, 2 * k + 1, d.B);
             P4C_TRY(pool_fwd(d.dtype, ws.act(L.Y[2 * k + 1]), n2.scale, n2.shift, d.B, L.Hk[k], L.Wk[k], ws.act(L.P[k + 1]), st));
         }
@@ -602,7 +575,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     struct BwdPhase { BwdPhase() { prof_set_backward(true); } ~BwdPhase() { prof_set_backward(false); } } bwd_phase;
     // the per-workgroup partials of this call's 14 weight gradients are reduced by ONE launch at the end of the call (they were 14
     // dependent ~8 us launches on the weight-gradient stream, 42 per 3-step rollout); P4C_WGRAD_BATCH=0: one launch each, as before
-    static const bool batch_reduce = [] { const char* e = getenv("P4C_WGRAD_BATCH"); return !(e && e[0] == '0'); }();
+    static const bool batch_reduce = [] { const char* e = diag_env("P4C_WGRAD_BATCH"); return !(e && e[0] == '0'); }();
     WgradCollect reduce_jobs;
     struct Collect {
         explicit Collect(WgradCollect* c) { wgrad_collect_into(c); }
@@ -633,7 +606,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         if (deferring) P4C_CHECK_HIP(hipEventRecord(g_side.dy_read, g_side.stream));
         // the 1x1 data gradient IS the dA of conv 11's normalisation backward: on the row kernel it takes pass 1 of it
         // (sums of g and g * xhat) while it stores the rows, instead of a norm_bwd_reduce launch over dA and y
-        const char* fe = getenv("P4C_NO_FUSED_REDUCE");
+        const char* fe = diag_env("P4C_NO_FUSED_REDUCE");
         const bool fuse11 = !(fe && fe[0] == '1') && d.compute == P4C_BF16 && conv_bf16_is_rows(d.dtype, NF, 1, 1, NF, d.B, d.H, d.W) &&
                             conv_bf16_bwd_stats_ok(d.dtype, d.B, d.H, d.W);
         if (fuse11) {
@@ -667,7 +640,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         Norm n1 = norm_at(ws, 2 * k, d.B);
         const void* dP = (k + 1 < NLEV) ? a : nullptr;
         // (bf16 storage, statistics of the batch in use: enc_out_bwd also takes pass 1 of conv2's normalisation backward)
-        const char* fe = getenv("P4C_NO_FUSED_REDUCE");
+        const char* fe = diag_env("P4C_NO_FUSED_REDUCE");
         const bool fuse_off = fe && fe[0] == '1';
         const bool fuse = !fuse_off && d.dtype == P4C_BF16;
         int pre = 0;
@@ -712,6 +685,18 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     } else {
         P4C_TRY(wgrad_reduce_batch(reduce_jobs, st));
     }
+    return P4C_OK;
+}
+
+// Weight gradients beside the backward chain (on: the default) or on the caller's stream like everything else (off).  For hosts
+// that cannot keep two streams fed -- eight ranks sharing one host -- and for the single-stream HIP-graph capture (a two-stream
+// capture is replayed over four hardware queues and loses the overlap: profiles/r04_graph_vs_eager.txt).  Call between steps only:
+// nothing of a previous step may be in flight on the side stream (p4c_side_stream_join / a stream synchronisation first).
+extern "C" int p4c_side_stream_enable(int on) {
+    P4C_TRY(g_side.init());
+    if (g_side.external) return P4C_OK;     // the caller's own stream: its decision
+    if (on && !g_side.stream) P4C_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    g_side.enabled = on != 0;
     return P4C_OK;
 }
 

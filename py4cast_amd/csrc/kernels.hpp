@@ -154,15 +154,6 @@ int out_conv_bwd_slots(int B, int64_t N);   // workgroups per sample
 int launch_out_conv_bwd(const void* dy, const void* wp_dgrad, const void* y, const float* scale, const float* shift, const float* mean,
                         const float* rstd, void* dA, float* stat_partial, float* wpartial, int B, int64_t N, hipStream_t stream,
                         int* nblk_out);
-// coarse_fwd.hip: the forward of HalfUNet encoder levels 2 .. 4 (max-pool, two [conv3x3 -> BatchNorm statistics] each) as ONE persistent
-// launch with grid-wide barriers in global memory (P4C_COARSE_FWD=1).  Arrays are indexed [level - 2][conv 0 | 1]; nrm: scale | shift |
-// mean | rstd, (B,64) each; slots: coarse_fwd_scratch_floats() floats; sync: three zeroed 32-bit words (the kernel leaves them zero)
-bool coarse_fwd_ok(int storage, int B, int H2, int W2);
-size_t coarse_fwd_scratch_floats();
-int launch_coarse_fwd(const void* y_top, const float* top_scale, const float* top_shift, void* const* P, void* const (*Y)[2],
-                      const void* const (*wp)[2], const float* const (*gamma)[2], const float* const (*beta)[2], float* const (*rmean)[2],
-                      float* const (*rvar)[2], float* const (*nrm)[2], float* slots, unsigned int* sync, int B, int H2, int W2, float eps,
-                      float momentum, hipStream_t stream);
 // plain convolution / its weight gradient on feature maps with fewer than 64 channels, in place (no padded copies): row kernel only
 bool conv_wgrad_bf16_takes_nb(int storage, int CI, int ks, int B);
 bool conv_rows_compact_ok(int storage, int in_cs, int out_cs, int ks, int B, int H, int W);

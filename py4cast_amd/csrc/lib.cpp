@@ -37,7 +37,7 @@ int num_cus() {
 }
 
 int diag_skip(int bit) {
-    static const int mask = [] { const char* e = getenv("P4C_DIAG"); return e ? atoi(e) : 0; }();
+    static const int mask = [] { const char* e = diag_env("P4C_DIAG"); return e ? atoi(e) : 0; }();
     if (!(mask & bit)) return 0;
     static std::atomic<int> calls[32];
     int idx = 0;

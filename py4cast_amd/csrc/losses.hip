@@ -995,11 +995,11 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // whole 16-byte slots per row of the row tensors, N * F % 4 == 0, 16-byte aligned bases and batch strides
 // P4C_FORCE_FLAT_STEP=1 (tests): the flat kernels also where the 16-byte ones apply -- same results element for element
 static inline bool force_flat() {
-    const char* e = getenv("P4C_FORCE_FLAT_STEP");
+    const char* e = diag_env("P4C_FORCE_FLAT_STEP");
     return e && e[0] == '1';
 }
 static inline bool flat_ok(int F, int64_t N, int row_cs, int esz) {
-    const char* e = getenv("P4C_NO_FLAT_STEP");   // (read per call: the parity tests switch the flat kernels off)
+    const char* e = diag_env("P4C_NO_FLAT_STEP");   // (read per call: the parity tests switch the flat kernels off)
     if (e && e[0] == '1') return false;
     return F > 0 && F <= 64 && row_cs >= F && (row_cs * esz) % 16 == 0 && row_cs <= 256 && (N * F) % 4 == 0;
 }
@@ -1658,7 +1658,7 @@ extern "C" int p4c_out_conv_update_loss_fwd(const void* a, const float* a_scale,
                          aligned16(new_state);
     if (flat_possible && x_next) flat_possible = statics && forcing_next && (c_pad * 2) % 16 == 0 && c_pad <= 256 && c_pad >= F + Fs + Ff && aligned16(x_next);
     if (flat_possible && lgrad) flat_possible = lgrad_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(lgrad) & 7) == 0;
-    const char* tv4 = getenv("P4C_TAIL_V4");
+    const char* tv4 = diag_env("P4C_TAIL_V4");
     const bool prefer_v4 = tv4 && tv4[0] == '1' && !force_flat();
     if (F % 4 != 0 || force_flat() || (flat_possible && !prefer_v4)) {
         const bool ok = flat_possible;

@@ -821,7 +821,7 @@ int norm_eval(int B, const float* gamma, const float* beta, float eps, const flo
 }
 
 int bwd_fin_max_slots() {
-    if (const char* e = getenv("P4C_BWD_INFIN_MAX")) return atoi(e);   // (read per call: A/B scripts and the parity tests switch it)
+    if (const char* e = diag_env("P4C_BWD_INFIN_MAX")) return atoi(e);   // (read per call: A/B scripts and the parity tests switch it)
     return 256;
 }
 
@@ -845,7 +845,7 @@ static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* 
     const bool skip_reduce = diag_skip(4), skip_apply = diag_skip(16);
     bool skip_fin = diag_skip(2) || pre_finalized;
     if (skip_reduce || pre_nblk > 0) {
-    } else if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_REDUCE_V1") == nullptr) {
+    } else if (std::is_same<T, __bf16>::value && diag_env("P4C_NORM_REDUCE_V1") == nullptr) {
         // BatchNorm with few slots: the launch's last workgroup finishes the pass (no norm_bwd_finalize launch)
         BwdFin fin{};
         if (fin_ticket && mode == 0 && (int64_t)B * nblk <= bwd_fin_max_slots()) {
@@ -863,7 +863,7 @@ static int norm_bwd_t(const T* dA, const T* y, const float* scale, const float* 
                            mode, groups, training, gamma, dgamma, dbeta, k1, k2);
     P4C_CHECK_LAUNCH("norm_bwd_finalize");
     if (skip_apply || dY == nullptr) {   // (dY == nullptr: the consumers apply pass 2 while they load dA and y -- NormBwdCoef)
-    } else if (std::is_same<T, __bf16>::value && getenv("P4C_NORM_APPLY_V1") == nullptr) {
+    } else if (std::is_same<T, __bf16>::value && diag_env("P4C_NORM_APPLY_V1") == nullptr) {
         int64_t blocks = (hw + 127) / 128;                       // >= 4 pixel rows of 32 per workgroup
         const int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1);
         if (blocks > cap) blocks = cap;
@@ -941,7 +941,7 @@ __global__ void __launch_bounds__(256)
 
 template <typename T>
 static int pool_fwd_t(const T* y, const float* scale, const float* shift, int B, int H, int W, T* P, hipStream_t stream) {
-    if (std::is_same<T, __bf16>::value && getenv("P4C_POOL_V1") == nullptr && (int64_t)(H / 2) * (W / 2) < ((int64_t)1 << 30)) {
+    if (std::is_same<T, __bf16>::value && diag_env("P4C_POOL_V1") == nullptr && (int64_t)(H / 2) * (W / 2) < ((int64_t)1 << 30)) {
         int64_t blocks = ((int64_t)(H / 2) * (W / 2) + 63) / 64;   // two pixel rows of 32 per workgroup and trip
         const int64_t cap = (int64_t)num_cus() * 8 / (B > 0 ? B : 1) + 1;
         if (blocks > cap) blocks = cap;
@@ -1195,8 +1195,8 @@ static int enc_out_bwd_t(const T* Tx, int Hfull, int s, const T* dS, const T* dP
                          int* nblk_out, hipStream_t stream, const BwdFin* finp, bool* finalized_out) {
     if (nblk_out) *nblk_out = 0;
     if (finalized_out) *finalized_out = false;
-    if (std::is_same<T, __bf16>::value && getenv("P4C_ENC_OUT_V1") == nullptr) {
-        const char* v2 = getenv("P4C_ENC_OUT_V2");   // 0: the round-2 kernel (one thread per pixel, dependent row loads)
+    if (std::is_same<T, __bf16>::value && diag_env("P4C_ENC_OUT_V1") == nullptr) {
+        const char* v2 = diag_env("P4C_ENC_OUT_V2");   // 0: the round-2 kernel (one thread per pixel, dependent row loads)
         const bool old = v2 && v2[0] == '0';
         const bool blk = !old && dP && s <= 2 && Hk % 2 == 0 && Wk % 2 == 0;   // one thread per 2x2 block on the fine levels
         int64_t blocks = blk ? ((int64_t)(Hk / 2) * (Wk / 2) + 31) / 32 : ((int64_t)Hk * Wk + 31) / 32;

@@ -249,7 +249,7 @@ int out_conv_bwd_slots(int B, int64_t N) {
     // (read ONCE per process: the workspace layout and every launch must agree on the slot count)
     static const int per_cu = [] {
         int v = 3;
-        if (const char* e = getenv("P4C_OCB_PER_CU")) { const int u = atoi(e); if (u > 0 && u <= 8) v = u; }
+        if (const char* e = diag_env("P4C_OCB_PER_CU")) { const int u = atoi(e); if (u > 0 && u <= 8) v = u; }
         return v;
     }();
     int64_t n = ((int64_t)num_cus() * per_cu + B - 1) / B;
@@ -260,7 +260,7 @@ int out_conv_bwd_slots(int B, int64_t N) {
 }
 
 bool out_conv_bwd_ok(int storage, int B, int64_t N) {
-    const char* e = getenv("P4C_FUSED_OUT_BWD");   // (read per call: A/B scripts and the parity tests switch it)
+    const char* e = diag_env("P4C_FUSED_OUT_BWD");   // (read per call: A/B scripts and the parity tests switch it)
     if (e && e[0] == '0') return false;
     return storage == P4C_BF16 && B > 0 && N > 0 && N * 128 < ((int64_t)1 << 31);
 }

@@ -398,7 +398,7 @@ static int build_x_impl(const float* prev, int64_t prev_bs, int64_t prev_ts, con
     // kernel where that one applies too (2 x 512 x 512, 69 -> 96 channels: 45 against 71 us)  (P4C_NO_FLAT_STEP=1: the quad kernel below)
     {
         const int esz = x_dtype == P4C_BF16 ? 2 : 4;
-        const char* nf = getenv("P4C_NO_FLAT_STEP");
+        const char* nf = diag_env("P4C_NO_FLAT_STEP");
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         const bool flat = !(nf && nf[0] == '1') && !mask_on_nan && !bm.selected && (x_dtype == P4C_F32 || x_dtype == P4C_BF16) && c_pad <= 256 &&
                           (c_pad * esz) % 16 == 0 && al16(x) && F <= 64 && Fs <= 64 && Ff <= 64 &&

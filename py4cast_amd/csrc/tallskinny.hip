@@ -522,7 +522,7 @@ extern "C" int p4c_ts_gram_splits(int64_t N) {
     // tokens per split (P4C_TS_SPLIT_TOKENS; from 4 096 tokens 256 = eight 32-token tiles: four per wave of the matrix-core kernel, whose
     // per-workgroup costs -- clearing the images, the LDS sum of the two waves, one partial per result block -- a single tile per wave
     // did not amortise; with (sample, head) groups in blockIdx.x the launches still have hundreds of workgroups).
-    static const int forced = [] { const char* v = getenv("P4C_TS_SPLIT_TOKENS"); const int n = v ? atoi(v) : 0; return n > 0 && n < 32 ? 32 : n; }();
+    static const int forced = [] { const char* v = diag_env("P4C_TS_SPLIT_TOKENS"); const int n = v ? atoi(v) : 0; return n > 0 && n < 32 ? 32 : n; }();
     const int per = forced ? forced : (N >= 4096 ? 256 : 64);      // (measured per stage, profiles/r03_ts_micro.txt: the short stages keep 64)
     int64_t s = (N + per - 1) / per;
     if (s > 256) s = 256;
@@ -534,7 +534,7 @@ static int pow2_ge_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // the matrix-core form serves bf16 x bf16 with d, e multiples of 8 (any width: 64 x 64 result blocks in blockIdx.z)
 extern "C" int p4c_ts_gram_wide_ok(int x_dtype, int y_dtype, int d, int e) {
-    static const bool off = [] { const char* v = getenv("P4C_TS_NO_MFMA"); return v && v[0] == '1'; }();
+    static const bool off = [] { const char* v = diag_env("P4C_TS_NO_MFMA"); return v && v[0] == '1'; }();
     return !off && x_dtype == P4C_BF16 && y_dtype == P4C_BF16 && d > 0 && e > 0 && d % 8 == 0 && e % 8 == 0;
 }
 
@@ -632,7 +632,7 @@ extern "C" int p4c_ts_gram_norms(const void* x, int x_dtype, int64_t x_bs, int64
 
 // the matrix-core form serves bf16 token matrices with d, e multiples of 8 and d <= 256 (any e): no 64-column chunking by the caller
 extern "C" int p4c_ts_apply_wide_ok(int x_dtype, int out_dtype, int d, int e) {
-    static const bool off = [] { const char* v = getenv("P4C_TS_NO_MFMA"); return v && v[0] == '1'; }();
+    static const bool off = [] { const char* v = diag_env("P4C_TS_NO_MFMA"); return v && v[0] == '1'; }();
     return !off && x_dtype == P4C_BF16 && (out_dtype == P4C_BF16 || out_dtype == P4C_F32) && d > 0 && e > 0 && d % 8 == 0 && e % 8 == 0 && d <= 256;
 }
 
@@ -646,7 +646,7 @@ static void launch_apply_mfma(const ts::Mat& X, const float* m, int64_t m_bs, in
     const int ntg = 4 / hw, zc = ((heads + hw - 1) / hw) * ((e + 63) / 64);
     const int64_t ntiles = (N + 31) / 32;
     int64_t ny = (ntiles + ntg - 1) / ntg;
-    static const int wgs_per_cu = [] { const char* v = getenv("P4C_TS_APPLY_WGS"); return v ? atoi(v) : 4; }();
+    static const int wgs_per_cu = [] { const char* v = diag_env("P4C_TS_APPLY_WGS"); return v ? atoi(v) : 4; }();
     const int64_t cap = (int64_t)num_cus() * wgs_per_cu / ((int64_t)B * zc) + 1;     // several tiles per wave: M^T is staged once per workgroup
     if (ny > cap) ny = cap;
     const dim3 grid(B, (unsigned)ny, zc);

@@ -240,6 +240,17 @@ class FlatDDP:
                 # the gradient.  Let those collectives finish, then exchange every bucket again from the regathered buffer (every
                 # rank takes this branch together: it follows from the program, not from data).
                 self.wait()
+                if self.sharded and any(self._issued):
+                    # a reduce-scatter already overwrote this rank's shard of those buckets with the MEAN and left the rest of the
+                    # piece with local (RCCL) or summed (gloo) values: the parameters whose gradients still lived in the flat buffer
+                    # cannot be exchanged a second time from it.  There is no copy to restore them from -- refuse
+                    # loudly instead of stepping with a silently wrong gradient.
+                    self._armed = False
+                    raise RuntimeError(
+                        "FlatDDP(sharded=True, overlap=True): a gradient tensor was replaced during an armed backward after "
+                        f"{sum(self._issued)} bucket(s) had been reduce-scattered from the hooks; the flat buffer no longer holds the "
+                        "local gradients of those buckets.  Keep p.grad in place during backward (no zero_grad(set_to_none=True) / "
+                        "p.grad = ... inside it), or construct FlatDDP with overlap=False or sharded=False.")
                 self._issued = [False] * len(self.buckets)
             self._regather()
         if self.overlap and self._armed:
@@ -307,6 +318,26 @@ class GraphReplayMismatch(RuntimeError):
     """A captured training step whose replay does not reproduce the eager step (GraphedTrainingStep._verify)."""
 
 
+def pin_rank_to_cores(local_rank: int, local_world: int):
+    """Give each rank of a node its own contiguous block of the cores this process may run on (``os.sched_setaffinity``), BEFORE the
+    rank's first GPU call: eight Python ranks, their autograd threads and RCCL's proxy threads otherwise wander over one another's
+    cores (the reference's own 4-GPU runs lose 25-49 % per rank to the host, doc/num_steps.md:119-143).  Contiguous blocks keep a rank
+    on one NUMA node where the core numbering follows the sockets.  Returns the sorted core list of this rank, or None when nothing
+    was changed (one rank, fewer cores than ranks, no affinity interface, P4C_NO_AFFINITY=1)."""
+    import os
+
+    if local_world <= 1 or os.environ.get("P4C_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // local_world
+    if per < 1:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(per, torch.get_num_threads())))
+    return mine
+
+
 class RolloutParamProxies:
     """Per-AR-step stand-ins for a module's parameters.  The T model calls of a rollout share their parameters, so autograd adds T
     gradient contributions per parameter one kernel at a time (``AccumulateGrad``: 478 parameters x 6 steps = 2 400 tiny launches per
@@ -324,10 +355,17 @@ class RolloutParamProxies:
         self.named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.sets = []        # reused from step to step: [{name: stand-in}]
         self.used = 0
+        self.dirty = False    # stand-ins were handed out since the last transfer (their .grad may hold something)
 
     def begin(self):
-        if self.used:
-            self.finalize()   # (a backward that never reached the attached tensor left its gradients in the stand-ins: keep them)
+        if self.dirty:
+            # a backward that never reached the attached tensor left its gradients in the stand-ins: keep them -- they belong to
+            # the PREVIOUS step and arrive after its zero_grad (a host that wants them in time calls finalize() itself)
+            import warnings
+
+            warnings.warn("RolloutParamProxies: gradients of the previous rollout were still in the stand-ins (its backward did not "
+                          "reach the attached tensor); they are added to .grad now")
+            self.finalize()
         self.used = 0
 
     def call(self, x):
@@ -335,6 +373,7 @@ class RolloutParamProxies:
             self.sets.append({})
         prox = self.sets[self.used]
         self.used += 1
+        self.dirty = True
         for n, p in self.named:
             q = prox.get(n)
             if q is None or q.data_ptr() != p.data_ptr() or q.shape != p.shape:
@@ -353,6 +392,7 @@ class RolloutParamProxies:
         return None
 
     def finalize(self):
+        self.dirty = False
         with torch.no_grad():
             for prox in self.sets[: self.used]:
                 tgt, src = [], []

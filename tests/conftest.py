@@ -37,3 +37,15 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def diag_library():
+    """Tests that flip P4C_* A/B switches (an older kernel as the reference of a newer one, a forced geometry) run on the diagnostic
+    build of the library: the product library compiles every switch to its default (csrc/common.hpp::diag_env)."""
+    from py4cast_amd import _lib
+
+    if not os.path.exists(_lib.DIAG_LIB_PATH):
+        pytest.skip("libpy4cast_hip_diag.so not built (make -C py4cast_amd/csrc diag)")
+    with _lib.use_diagnostic_library():
+        yield

@@ -7,7 +7,7 @@ P4C_BWD_INFIN_MAX=0 turns it off (every pass finished by a launch of its own): s
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("diag_library")]   # (flips P4C_* A/B switches: diagnostic build)
 
 
 def rel_err(got, ref):

@@ -244,6 +244,20 @@ def _replaced_grads_worker(rank, world, port, ret):
         ddp.all_reduce_grads()
         grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
         out[tag] = (grads.clone(), ddp.flat_grad[: ddp.total].clone(), armed, n_in, ddp._grads_are_views())
+    # the same replacement with sharded=True.  The hook-issued reduce-scatters have already overwritten this rank's shards
+    # with means: a second exchange would mix means with raw sums, so all_reduce_grads must refuse (both ranks, same branch)
+    net = make()
+    ddp = FlatDDP(net, world, bucket_bytes=4096, single_bucket_bytes=1024, overlap=True, sharded=True)
+    ddp.arm()
+    loss = ((net(x) - y) ** 2).mean()
+    first = next(net.parameters())
+    first.register_post_accumulate_grad_hook(lambda p: setattr(p, "grad", p.grad.clone()))
+    loss.backward()
+    try:
+        ddp.all_reduce_grads()
+        out["sharded_replaced"] = (ddp.issued_in_backward, None)
+    except RuntimeError as exc:
+        out["sharded_replaced"] = (ddp.issued_in_backward, str(exc))
     ret[rank] = out
     dist.destroy_process_group()
 
@@ -267,3 +281,6 @@ def test_overlap_with_replaced_gradient_tensors_gloo():
             torch.testing.assert_close(r[tag][1], a["views"][1])
             assert r[tag][4]                                       # p.grad is its slice of the flat bucket again
     torch.testing.assert_close(a["views"][0], b["views"][0])
+    for r in (a, b):     # sharded + overlapped + replaced during the backward: refused loudly on every rank, never a silent wrong mean
+        n_in, msg = r["sharded_replaced"]
+        assert n_in >= 1 and msg is not None and "reduce-scattered" in msg

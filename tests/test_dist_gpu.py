@@ -138,3 +138,10 @@ def test_bench_two_ranks_sharing_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak" and out["value"] > 0
     assert abs(out["value"] - 2 * 2 * 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]     # whole-job aggregate = ranks x B / step time
+    # host safety of the N > 1 path: every rank on its own cores, and ONE launch mode agreed over the ranks
+    cores = out["config"]["host_cores_per_rank"]
+    if os.cpu_count() >= 2:
+        assert len(cores) == 2 and cores[0] and cores[1] and not set(cores[0]) & set(cores[1]), cores
+    probe = out["config"]["launch_mode_probe"]
+    assert probe is not None and probe["agreed_over_ranks"] == 2 and probe["chosen"] in ("eager", "graph", "graph, single stream")
+    assert out["config"]["hip_graph"] == (probe["chosen"] != "eager")

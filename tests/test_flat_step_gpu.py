@@ -11,7 +11,7 @@ the loss is the same sum in another order (<= 1e-6).
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("diag_library")]   # (flips P4C_* A/B switches: diagnostic build)
 
 
 def rel_err(got, ref):

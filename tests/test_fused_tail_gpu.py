@@ -10,7 +10,7 @@ import ctypes
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("diag_library")]   # (flips P4C_* A/B switches: diagnostic build)
 
 MSE = [{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}]
 L1 = [{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "L1Loss", "reduction": "none"}}]

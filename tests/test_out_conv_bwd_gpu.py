@@ -9,7 +9,7 @@ of the last block's normalisation backward and the weight gradient in one pass o
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("diag_library")]   # (flips P4C_* A/B switches: diagnostic build)
 
 MSE = [{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}]
 

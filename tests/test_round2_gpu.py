@@ -12,7 +12,7 @@ import torch
 from conftest import GOLDEN_DIR
 from helpers import (GRID_DIMS, TinyConvModel, make_batch, make_dataset_info, register_test_models, synthetic_case)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("diag_library")]   # (flips P4C_* A/B switches: diagnostic build)
 
 MSE = [{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}]
 
