@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--strategy", default="scaled_ar", choices=["scaled_ar", "diff_ar"],
                     help="training_strategy (BASELINE configuration 5 -- UNetRPP -- is quoted on 6-step diff_ar: --model UNetRPP "
                          "--strategy diff_ar --pred-steps 6)")
+    ap.add_argument("--no-native-share", action="store_true", help="skip the extra profiled step that measures the share of GPU kernel "
+                    "time spent in this repository's kernels")
     ap.add_argument("--hidden", type=int, default=1024, help="UNetRPP hidden_size (config/CLI/model/unetrpp.yaml:20)")
     ap.add_argument("--hip-graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the micro-batch (rollout + loss + backward) from a HIP graph; auto: only for models that ask for it "
@@ -323,6 +325,33 @@ def fp32_flavour(args, case, info, device, steps=6, warmup=2, dtype="f32", batch
             "dtype": dtype, "batch_per_gpu": B, "loss": float(loss.detach()), "roofline": roof}
 
 
+def native_share_of_one_step(step_fn):
+    """Share of GPU kernel time spent in this repository's kernels (names under p4c::) in ONE extra eager step, from the profiler's
+    device-side kernel records (roctracer through torch.profiler); the rest is library code (ATen element-wise / reductions / copies,
+    hipBLASLt, MIOpen).  Returns (share, {category: ms}, kernel count) or None when the profiler records no device activity."""
+    from torch.profiler import ProfilerActivity, profile
+
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step_fn()
+        torch.cuda.synchronize()
+    cat, n = {}, 0
+    for ev in prof.events():
+        t = getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0)
+        if not t or getattr(ev, "device_type", None) is None or "DeviceType.CUDA" not in str(ev.device_type):
+            continue
+        name = ev.name
+        k = ("native" if ("p4c" in name) else "hipBLASLt" if name.startswith("Cijk") else
+             "MIOpen" if any(w in name for w in ("MIOpen", "Im2d2Col", "Col2Im", "SubTensorOp", "miopen", "igemm", "naive_conv")) else
+             "ATen" if "at::" in name else "other")
+        cat[k] = cat.get(k, 0.0) + t / 1e3
+        n += 1
+    tot = sum(cat.values())
+    if n == 0 or tot <= 0:
+        return None
+    return cat.get("native", 0.0) / tot, {k: round(v, 3) for k, v in sorted(cat.items())}, n
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -495,13 +524,17 @@ def main():
     barrier()
     roof_model = None
     graph_note = None
+    work = None
     if use_graph:
         # kernel timings for the roofline object come from two eager steps (a replayed graph has no per-call host hooks);
         # then the micro-batch is captured and the warm-up + timed steps replay it
         from py4cast_amd.trainer import GraphedTrainingStep
 
+        L.WORK[0] = {"bytes": 0.0, "flops": 0.0, "calls": 0, "unstated": 0}
         for i in range(2):
             step(args.warmup + i)
+        work, L.WORK[0] = L.WORK[0], None
+        work = {k: v / 2 for k, v in work.items()}        # per step
         ktimes = L.kernel_times()
         roof_model = lm.model.roofline(ktimes, B=B, H=H, W=W) if (rank == 0 and hasattr(lm.model, "roofline")) else None
         L.enable_kernel_timing(None)
@@ -563,6 +596,18 @@ def main():
         extra = lm.model.launch_times(B=B, H=H, W=W) if rank == 0 else None
         L.lib().p4c_prof_enable(0, 0)
     affinity_all = None
+    share = None
+    if rank == 0 and world == 1 and not args.no_native_share:
+        saved_graph, graphed[0] = graphed[0], None          # one EAGER step under the profiler (a replay has the same kernels)
+        if work is None:
+            L.WORK[0] = {"bytes": 0.0, "flops": 0.0, "calls": 0, "unstated": 0}
+        try:
+            share = native_share_of_one_step(lambda: step(args.warmup + args.steps + 1))
+        except Exception as exc:  # noqa: BLE001  (no device tracing in this environment: the field stays null)
+            print(f"bench: native share not measured ({type(exc).__name__}: {exc})", file=sys.stderr)
+        if work is None:
+            work, L.WORK[0] = L.WORK[0], None
+        graphed[0] = saved_graph
     if world > 1:
         tmax = torch.tensor([dt, host_enqueue_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -607,6 +652,17 @@ def main():
                                          "algorithmic_bytes_per_launch": ab, "avg_launch_ms": wg,
                                          "achieved": ab / (wg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": ab / (wg * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if roof is not None and "step" not in roof and work and work["bytes"] > 0:
+            # the widened models: the whole step against both roofs from the algorithmic bytes / matrix flops that the wrappers of
+            # the native entry points state call by call (py4cast_amd/_lib.py::WORK; library calls state nothing: `unstated_calls`)
+            step_s = dt / args.steps
+            roof["step"] = {"bound": "hbm", "algorithmic_bytes": work["bytes"], "achieved": work["bytes"] / step_s / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": work["bytes"] / step_s / 1e9 / HBM_PEAK_GBS,
+                            "ms_per_step": step_s * 1e3, "floor_ms_at_peak": work["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3,
+                            "matrix_flops": work["flops"], "matrix_tflops": work["flops"] / step_s / 1e12,
+                            "matrix_frac_of_bf16_peak": work["flops"] / step_s / 1e12 / 2500.0,
+                            "native_calls": int(work["calls"]), "unstated_calls": int(work["unstated"]),
+                            "note": "bytes / flops as stated by the wrappers of the native entry points, one eager step"}
         if roof is None and ktimes and not hasattr(lm.model, "roofline"):
             # HBM-bound rollout kernels: algorithmic bytes per launch
             alg = {
@@ -660,6 +716,8 @@ def main():
                 "launch_mode_probe": probe,
             },
             "loss": float(loss.detach()),
+            "native_share": None if share is None else {"of_gpu_kernel_time": round(share[0], 4), "ms_by_origin": share[1], "kernels": share[2],
+                                                        "note": "one eager step under torch.profiler: kernels named p4c:: are this repository's"},
             "roofline": roof,
             "kernel_ms": {k: {"calls": v[0], "avg_ms": round(v[1], 4)} for k, v in ktimes.items()},
         }

@@ -245,8 +245,23 @@ def kernel_bytes():
     return out
 
 
-def call(name: str, *args, alg_bytes=None):
-    """alg_bytes: the call's algorithmic HBM bytes (roofline bookkeeping of bench.py; ignored unless timing is enabled)."""
+# bench.py's step-level roofline of the widened models: with WORK[0] a dict, every native call adds the algorithmic HBM bytes / matrix
+# flops its wrapper states ({"bytes": .., "flops": .., "calls": .., "unstated": ..}); None = off (no cost on the product path)
+WORK = [None]
+
+
+def call(name: str, *args, alg_bytes=None, alg_flops=None):
+    """alg_bytes / alg_flops: the call's algorithmic HBM bytes and matrix flops (roofline bookkeeping of bench.py; ignored unless
+    timing / work counting is enabled)."""
+    w = WORK[0]
+    if w is not None:
+        w["calls"] += 1
+        if alg_bytes is None:
+            w["unstated"] += 1
+        else:
+            w["bytes"] += alg_bytes
+        if alg_flops:
+            w["flops"] += alg_flops
     if _TIMED is not None and name in _TIMED:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()  # torch's current stream == the stream handed to the library

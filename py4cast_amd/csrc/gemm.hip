@@ -197,28 +197,42 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_kernel(NtArgs a) {
     // piece after each k-step's products (the matrix pipe works on them while the piece is issued); out-of-range offsets (rows beyond
     // the matrix, k beyond K, the convolution's zero padding) land as zeros.
     unsigned int a_row[2], b_row[2];         // byte offsets of the rows (OOB: row outside the matrix)
-    int py[2], px[2];
+    unsigned int vmask[2];                   // convolution: bit t = tap t of this row's pixel reads inside the image
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int row = 16 * wv + 8 * it + (lane >> 3);
         const int m = m0 + row, n = n0 + row;
         a_row[it] = m < a.M ? (unsigned int)((int64_t)m * a.lda * 2) : OOB;
         b_row[it] = n < a.N ? (unsigned int)((int64_t)n * a.ldb * 2) : OOB;
-        if (CONV) {
+        vmask[it] = 0u;
+        if (CONV && m < a.M) {
             const int p = m % (a.H * a.W);
-            py[it] = p / a.W;
-            px[it] = p - py[it] * a.W;
+            const int y = p / a.W, x = p - y * a.W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)(y + t / 3 - 1) < (unsigned)a.H && (unsigned)(x + t % 3 - 1) < (unsigned)a.W) vmask[it] |= 1u << t;
         }
     }
     // the chunk a lane fetches: (lane & 7) ^ (4 it + (lane >> 4))
-    int kq[2], tap[2], ci[2];
+    // k state of the lane's chunk, advanced by 64 per k-block; convolution: (tap, ci) of k and the byte shift of that tap's source
+    // pixel + channel -- recomputed only when ci wraps into the next tap (no division, no tap arithmetic in the steady state)
+    int kq[2], tap[2], ci[2], shift[2];
+    auto tap_shift = [&](int t, int c) __attribute__((always_inline)) {
+        const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;
+        return ((dy * a.W + dx) * (int)a.lda + c) * 2;
+    };
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int c = (lane & 7) ^ ((it << 2) | (lane >> 4));
         kq[it] = kb0 * BK + c * 8;
         tap[it] = 0;
         ci[it] = kq[it];
-        if (CONV) { tap[it] = kq[it] / a.Cin; ci[it] = kq[it] - tap[it] * a.Cin; }
+        shift[it] = 0;
+        if (CONV) {
+            tap[it] = kq[it] / a.Cin;
+            ci[it] = kq[it] - tap[it] * a.Cin;
+            shift[it] = tap_shift(tap[it], ci[it]);
+        }
     }
     // piece 0: A it 0, 1: B it 0, 2: A it 1, 3: B it 1 of the k-block the lane's k state points at
     auto issue_piece = [&](int stage, int piece) __attribute__((always_inline)) {
@@ -228,21 +242,23 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_kernel(NtArgs a) {
         if ((piece & 1) == 0) {
             unsigned int oa;
             if (CONV) {
-                const int dy = tap[it] / 3 - 1, dx = tap[it] - (tap[it] / 3) * 3 - 1;
-                const int shift = (dy * a.W + dx) * (int)a.lda * 2 + ci[it] * 2;
-                const bool ok = kin && a_row[it] != OOB && (unsigned)(py[it] + dy) < (unsigned)a.H && (unsigned)(px[it] + dx) < (unsigned)a.W;
-                oa = ok ? a_row[it] + shift : OOB;
+                const bool ok = kin && ((vmask[it] >> tap[it]) & 1u);
+                oa = ok ? a_row[it] + shift[it] : OOB;
             } else {
                 oa = (kin && a_row[it] != OOB) ? a_row[it] + kq[it] * 2 : OOB;
             }
-            dma16(rsA, oa, base + it * 1024);
+            if (!(P4C_NT_EXP & 16)) dma16(rsA, oa, base + it * 1024); else asm volatile("" :: "v"(oa));
         } else {
             const unsigned int ob = (kin && b_row[it] != OOB) ? b_row[it] + kq[it] * 2 : OOB;
-            dma16(rsB, ob, base + 16384 + it * 1024);
+            if (!(P4C_NT_EXP & 16)) dma16(rsB, ob, base + 16384 + it * 1024); else asm volatile("" :: "v"(ob));
             kq[it] += BK;             // both pieces of this `it` are out: on to the next k-block
             if (CONV) {
                 ci[it] += BK;
-                while (ci[it] >= a.Cin) { ci[it] -= a.Cin; ++tap[it]; }
+                shift[it] += 2 * BK;
+                if (ci[it] >= a.Cin) {
+                    do { ci[it] -= a.Cin; ++tap[it]; } while (ci[it] >= a.Cin);
+                    shift[it] = tap_shift(tap[it], ci[it]);
+                }
             }
         }
     };
@@ -548,33 +564,56 @@ struct TnRedArgs {
 };
 __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
     __shared__ float turn[9 * 512];
+    __shared__ float part[256];
     const int i = blockIdx.y, c0 = blockIdx.x * a.cchunk;
     const int cn = a.Cin - c0 < a.cchunk ? a.Cin - c0 : a.cchunk;
+    const int ne = a.taps * cn;
     const int64_t sstride = (int64_t)a.tiles * (128 * 128);
-    for (int e = threadIdx.x; e < a.taps * cn; e += 256) {
-        const int tap = e / cn, c = e - tap * cn;
-        const int j = tap * a.Cin + c0 + c;
-        const float* p = a.partial + ((int64_t)(j >> 7) * a.tiles_i + (i >> 7)) * (128 * 128) + (i & 127) * 128 + (j & 127);
+    // P threads per element (a power of two) when the workgroup has fewer elements than threads: thread p sums the splits
+    // s = p (mod P) in order, the P sums are added in the order p = 0 .. P-1 -- a fixed order whatever the launch geometry
+    int P = 1;
+    while (P < 16 && 2 * P * ne <= 256 && 2 * P <= a.splits) P *= 2;
+    for (int e0 = 0; e0 < ne; e0 += 256 / P) {
+        const int e = e0 + (int)threadIdx.x / P, p = (int)threadIdx.x % P;
         float t = 0.f;
-        int s = 0;
-        for (; s + 4 <= a.splits; s += 4) {
-            const float v0 = p[s * sstride], v1 = p[(s + 1) * sstride], v2 = p[(s + 2) * sstride], v3 = p[(s + 3) * sstride];
-            t = (((t + v0) + v1) + v2) + v3;
+        if (e < ne) {
+            const int tap = e / cn, c = e - tap * cn;
+            const int j = tap * a.Cin + c0 + c;
+            const float* q = a.partial + ((int64_t)(j >> 7) * a.tiles_i + (i >> 7)) * (128 * 128) + (i & 127) * 128 + (j & 127);
+            int s = p;
+            for (; s + 3 * P < a.splits; s += 4 * P) {
+                const float v0 = q[s * sstride], v1 = q[(s + P) * sstride], v2 = q[(s + 2 * P) * sstride], v3 = q[(s + 3 * P) * sstride];
+                t = (((t + v0) + v1) + v2) + v3;
+            }
+            for (; s < a.splits; s += P) t += q[s * sstride];
         }
-        for (; s < a.splits; ++s) t += p[s * sstride];
-        turn[tap * cn + c] = t;
+        if (P > 1) {
+            part[threadIdx.x] = t;
+            __syncthreads();
+            if (p == 0 && e < ne) {
+                for (int k = 1; k < P; ++k) t += part[threadIdx.x + k];
+            }
+            __syncthreads();
+        }
+        if (p == 0 && e < ne) {
+            const int tap = e / cn, c = e - tap * cn;
+            turn[tap * cn + c] = t;
+        }
     }
     __syncthreads();
     float* out = a.dw + ((int64_t)i * a.Cin + c0) * a.taps;
-    for (int e = threadIdx.x; e < a.taps * cn; e += 256) {
+    for (int e = threadIdx.x; e < ne; e += 256) {
         const int c = e / a.taps, tap = e - c * a.taps;
-        out[e] = a.accumulate ? out[e] + turn[tap * cn + c] : turn[tap * cn + c];
+        const float v = turn[tap * cn + c];
+        out[e] = a.accumulate ? out[e] + v : v;
     }
-    if (a.db && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.db && blockIdx.x == 0 && threadIdx.x < 64) {
+        // the 4 * splits partial column sums: lane l takes the entries k = l (mod 64) in order, then a fixed shuffle tree
         float t = 0.f;
-        for (int s = 0; s < a.splits; ++s)
-            for (int w = 0; w < 4; ++w) t += a.bias_partial[(((int64_t)s * a.tiles_i + (i >> 7)) * 4 + w) * 128 + (i & 127)];
-        a.db[i] = a.accumulate ? a.db[i] + t : t;
+        for (int k = threadIdx.x; k < 4 * a.splits; k += 64)
+            t += a.bias_partial[(((int64_t)(k >> 2) * a.tiles_i + (i >> 7)) * 4 + (k & 3)) * 128 + (i & 127)];
+        t = wave_sum(t);
+        if (threadIdx.x == 0) a.db[i] = a.accumulate ? a.db[i] + t : t;
     }
 }
 

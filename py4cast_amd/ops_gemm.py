@@ -83,7 +83,7 @@ def gemm_nt(A: torch.Tensor, img: torch.Tensor, N: int, K: int, conv=None, bias=
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=A.device) if nbytes else None
     L.call("p4c_gemm_nt", L.ptr(A), A.stride(0), L.ptr(img), M, N, K, H, W, Cin, taps, L.ptr(bias), L.ptr(res),
            0 if res is None else res.stride(0), act, L.ptr(aux_in), L.ptr(aux_out), 0 if aux is None else aux.stride(0), L.ptr(C), C.stride(0),
-           L.ptr(stats), L.ptr(ws), L.stream(A.device), alg_bytes=2 * (M * (K if conv is None else Cin) + N * K + M * N))
+           L.ptr(stats), L.ptr(ws), L.stream(A.device), alg_bytes=2 * (M * (K if conv is None else Cin) + N * K + M * N), alg_flops=2 * M * N * K)
     return C, aux_out, stats
 
 
@@ -100,7 +100,7 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, Mo: int, Cin: int, conv=None, wan
         db = torch.empty(Mo, dtype=torch.float32, device=dy.device) if want_bias else None
     ws = torch.empty(max(lib.p4c_gemm_tn_workspace_bytes(R, Mo, taps * Cin) // 4, 1), dtype=torch.float32, device=dy.device)
     L.call("p4c_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), R, Mo, H, W, Cin, taps, L.ptr(dw), L.ptr(db), int(sink is not None),
-           L.ptr(ws), L.stream(dy.device), alg_bytes=2 * R * (Mo + Cin) + 4 * Mo * Cin * taps)
+           L.ptr(ws), L.stream(dy.device), alg_bytes=2 * R * (Mo + Cin) + 4 * Mo * Cin * taps, alg_flops=2 * R * Mo * Cin * taps)
     return (None, None) if sink is not None else (dw, db)
 
 
@@ -338,7 +338,7 @@ class _BatchNormAct(torch.autograd.Function):
         out = torch.empty_like(yc)
         rc = None if res is None else res.contiguous()
         L.call("p4c_inorm_apply", L.ptr(yc), L.ptr(rc), None, None, L.ptr(st[2]), L.ptr(st[3]), None, None, None, None, float(slope),
-               L.ptr(out), None, L.dtype_code(yc.dtype), 1, N, C, L.stream(dev))
+               L.ptr(out), None, L.dtype_code(yc.dtype), 1, N, C, L.stream(dev), alg_bytes=yc.numel() * yc.element_size() * (2 + (rc is not None)))
         ctx.save_for_backward(yc, out, st)
         ctx.slope, ctx.has_res, ctx.training = float(slope), res is not None, bool(training)
         ctx.gdtype = None if gamma is None else gamma.dtype
@@ -354,7 +354,7 @@ class _BatchNormAct(torch.autograd.Function):
         nb = L.lib().p4c_inorm_blocks(N, C)
         part = torch.empty(1, nb, 2, C, dtype=torch.float32, device=dev)
         L.call("p4c_inorm_reduce", L.ptr(yc), L.ptr(dout), L.ptr(out), L.ptr(st[0]), L.ptr(st[1]), ctx.slope, L.ptr(part), L.dtype_code(yc.dtype),
-               1, N, C, L.stream(dev))
+               1, N, C, L.stream(dev), alg_bytes=3 * yc.numel() * yc.element_size())
         co = torch.empty(2, C, dtype=torch.float32, device=dev)
         dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
         L.call("p4c_inorm_finalize_bwd", L.ptr(part), nb, 1, N, C, 0, None, None, L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]),
@@ -364,7 +364,8 @@ class _BatchNormAct(torch.autograd.Function):
         dy = torch.empty_like(yc)
         dres = torch.empty_like(yc) if ctx.has_res else None
         L.call("p4c_inorm_apply", L.ptr(yc), None, L.ptr(dout), L.ptr(out), L.ptr(st[2]), None, L.ptr(st[0]), L.ptr(st[1]), L.ptr(co[0]),
-               L.ptr(co[1]), ctx.slope, L.ptr(dy), L.ptr(dres), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev))
+               L.ptr(co[1]), ctx.slope, L.ptr(dy), L.ptr(dres), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev),
+               alg_bytes=yc.numel() * yc.element_size() * (4 + ctx.has_res))
         dg = None if ctx.gdtype is None else dgb[0].to(ctx.gdtype)
         db = None if ctx.gdtype is None else dgb[1].to(ctx.gdtype)
         return dy, None, dg, db, dres, None, None, None, None, None, None
@@ -394,7 +395,8 @@ class _UpsampleAdd(torch.autograd.Function):
         B, H, W, C = xc.shape
         sc = None if skip is None else skip.contiguous()
         out = torch.empty(B, H * scale, W * scale, C, dtype=xc.dtype, device=xc.device)
-        L.call("p4c_upsample_bilinear_fwd", L.ptr(xc), L.ptr(sc), L.ptr(out), B, H, W, C, scale, L.stream(xc.device))
+        L.call("p4c_upsample_bilinear_fwd", L.ptr(xc), L.ptr(sc), L.ptr(out), B, H, W, C, scale, L.stream(xc.device),
+               alg_bytes=2 * (xc.numel() + out.numel() * (1 + (sc is not None))))
         ctx.geom, ctx.has_skip = (B, H, W, C, scale), skip is not None
         return out
 
@@ -403,7 +405,8 @@ class _UpsampleAdd(torch.autograd.Function):
         B, H, W, C, scale = ctx.geom
         dout = dout.contiguous()
         dx = torch.empty(B, H, W, C, dtype=dout.dtype, device=dout.device)
-        L.call("p4c_upsample_bilinear_bwd", L.ptr(dout), L.ptr(dx), B, H, W, C, scale, L.stream(dout.device))
+        L.call("p4c_upsample_bilinear_bwd", L.ptr(dout), L.ptr(dx), B, H, W, C, scale, L.stream(dout.device),
+               alg_bytes=2 * (dout.numel() + dx.numel()))
         return dx, (dout if ctx.has_skip else None), None
 
 

@@ -283,7 +283,7 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         self.decoder1 = UpBlock(fs, fs)
         self.out = nn.Conv2d(fs, out_channels, 1)
         self.timed_entry_points = ("p4c_window_attn_fwd", "p4c_window_attn_bwd", "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd",
-                                   "p4c_row_gemm", "p4c_row_gemm_wgrad")
+                                   "p4c_row_gemm", "p4c_row_gemm_wgrad", "p4c_gemm_nt", "p4c_gemm_tn")
         self.roofline_from_entry_points = True   # bench.py: time every call of the entry points above
         self.prefers_hip_graph = True            # ~10^3-10^4 launches per training step: replay them from a HIP graph (trainer.GraphedTrainingStep)
         self._unit_affine = {}                   # (C, device) -> constant (ones, zeros) rows of the hidden states' non-affine LayerNorm

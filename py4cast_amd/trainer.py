@@ -404,9 +404,13 @@ class RolloutParamProxies:
                     q.grad = None
                     if p.grad is None:
                         p.grad = g.clone()
-                    else:
+                    elif g.dtype == p.grad.dtype and g.shape == p.grad.shape and g.is_contiguous() and p.grad.is_contiguous():
                         tgt.append(p.grad)
                         src.append(g)
+                    else:
+                        # kept out of the multi-tensor call: ONE pair off its fast route (another dtype, a strided view) sends the
+                        # whole list down torch's per-tensor fallback -- one launch per parameter and AR step again
+                        p.grad.add_(g)
                 if tgt:
                     torch._foreach_add_(tgt, src)
         # (`used` stays: a second backward through the same rollout finds its stand-ins here again; begin() resets it)

@@ -433,7 +433,7 @@ class UNetRPPMI355X(ModelABC, nn.Module):
         self.decoder3 = UpBlock(dims[1], dims[0], 2, tokens[0], *up, False, s.linear_upsampling, s.norm_name)
         self.decoder2 = UpBlock(dims[0], fs, r, H * W, *up, True, s.linear_upsampling, s.norm_name)
         self.out1 = nn.Conv2d(fs, out_channels, 1)
-        self.timed_entry_points = ("p4c_ts_gram", "p4c_ts_apply", "p4c_row_layernorm_fwd", "p4c_row_layernorm_bwd")
+        self.timed_entry_points = ("p4c_ts_gram", "p4c_ts_apply", "p4c_row_add_layernorm_fwd", "p4c_row_add_layernorm_bwd", "p4c_gemm_nt", "p4c_gemm_tn")
         self.roofline_from_entry_points = True   # bench.py: time every call of the native entry points above
         self.prefers_hip_graph = True            # ~10^3-10^4 launches per training step: replay them from a HIP graph (trainer.GraphedTrainingStep)
         self.check_required_attributes()

@@ -38,11 +38,16 @@ for ev in prof.events():
     t = getattr(ev, "self_device_time_total", 0)
     if t <= 0 or not ev.name.startswith("aten::"):
         continue
-    frame = next((s for s in ev.stack if "py4cast_amd" in s or "bench.py" in s), None)
-    if frame is None:
-        frame = "(autograd engine / no python frame): " + (ev.stack[0] if ev.stack else "")
-    by[(ev.name, frame.strip()[:150])][0] += t
-    by[(ev.name, frame.strip()[:150])][1] += 1
+    # nearest enclosing op that is not an aten op: a custom autograd Function, an autograd node, a module call
+    par, owner = ev.cpu_parent, None
+    while par is not None:
+        if not par.name.startswith("aten::"):
+            owner = par.name
+            break
+        par = par.cpu_parent
+    key = (ev.name, (owner or "(top level python)")[:110])
+    by[key][0] += t
+    by[key][1] += 1
     tot += t
 print("aten self device time of one training step (T=%d): %.2f ms" % (T, tot / 1e3))
 for (n, f), (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:70]:
