@@ -634,15 +634,10 @@ def main():
                                 "bytes_by_family_mb": {k: round(v / 1e6, 1) for k, v in table.items()}}
                 # measured HBM bytes of a whole step, when a committed PMC run of THIS configuration exists (separate rocprofv3 --pmc
                 # FETCH_SIZE / WRITE_SIZE passes over every dispatch, tools/diagnostics/r04_pmc_step.sh): only for the default shape
-                tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_traffic_step.json")
-                if (B, H, W, F, Fs, Ff, T) == (2, 512, 512, 60, 4, 5, 3) and args.dtype == "bf16" and os.path.exists(tfile):
-                    try:
-                        hb = json.load(open(tfile)).get("hbm_bytes_per_step", {}).get("total")
-                        if hb:
-                            roof["step"]["traffic"] = hb
-                            roof["step"]["traffic_source"] = "profiles/r04_pmc_traffic_step.json (committed rocprofv3 --pmc passes of an earlier run)"
-                    except (OSError, ValueError):
-                        pass
+                if (B, H, W, F, Fs, Ff, T) == (2, 512, 512, 60, 4, 5, 3) and args.dtype == "bf16":
+                    hb, src = L.committed_traffic(("r05_pmc_traffic_step.json", "r04_pmc_traffic_step.json"), ("hbm_bytes_per_step", "total"))
+                    roof["step"]["traffic"] = hb
+                    roof["step"]["traffic_source"] = src
             wg = (extra or {}).get("wgrad_avg_launch_ms_overlapped")
             if wg and roof.get("bound") == "hbm":
                 # the weight-gradient kernel of the same layers, in the step (it runs beside the backward chain on the side stream):

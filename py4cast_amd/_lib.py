@@ -176,6 +176,50 @@ def lib():
     return _lib
 
 
+def kernel_sources_sha16() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources of this tree (csrc/*.hip, *.cpp, *.hpp, the C header): what a committed
+    PMC traffic figure under profiles/ was measured on.  bench.py reports such a figure as `traffic` only when it matches the running
+    tree; a changed kernel keeps the pointer to the file and a null number."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    root = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.cpp")) + glob.glob(os.path.join(root, "*.hpp")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "py4cast_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(names, key=None):
+    """(value, source note) from the first of the profiles/ JSON files `names` that exists: the value only if the file records the
+    kernel sources of THIS tree (kernel_sources_sha16), else None with a note that names the file as stale."""
+    import json
+
+    root = os.path.dirname(_HERE)
+    for name in names:
+        f = os.path.join(root, "profiles", name)
+        if not os.path.exists(f):
+            continue
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        sha = d.get("kernel_sources_sha16")
+        val = d
+        for k in (key or ()):
+            val = val.get(k, {}) if isinstance(val, dict) else None
+        if not isinstance(val, (int, float)):
+            continue
+        if sha == kernel_sources_sha16():
+            return val, f"profiles/{name} (committed rocprofv3 --pmc passes on this tree's kernel sources, sha {sha})"
+        return None, (f"profiles/{name} holds {val:.4g} B measured on other kernel sources (sha {sha}; this tree: "
+                      f"{kernel_sources_sha16()}): not reported as this run's traffic")
+    return None, None
+
+
 DIAG_LIB_PATH = os.path.join(_HERE, "libpy4cast_hip_diag.so")
 _diag = None
 

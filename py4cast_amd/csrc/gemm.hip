@@ -8,18 +8,25 @@
 //                    gradient: dy) or the im2col view of an NHWC map (3x3 "same" convolution: k = tap * Cin + ci, rows outside the
 //                    image read as zeros through out-of-range buffer offsets -- no im2col buffer exists); B = a prepared bf16 image
 //                    of the weight ([N][K]; the data gradient uses the transposed / tap-flipped image, so it is this same kernel).
-//                    128 x 128 x 64 tiles, 4 waves of 64 x 64 (2 x 2 v_mfma_f32_32x32x16_bf16 accumulators), LDS tiles XOR-swizzled
-//                    for conflict-free ds_read_b128 fragments, register-staged double buffering (loads of tile t+1 in flight during
-//                    the products of tile t, written after them: one barrier per k-block), split-K over blockIdx.y for the deep
-//                    stages (fp32 slabs, summed in a fixed order by gemm_nt_reduce_kernel).
+//                    128 x 128 x 64 tiles, 8 waves (two per SIMD) of 64 x 32 outputs (2 v_mfma_f32_32x32x16_bf16 accumulators),
+//                    LDS tiles XOR-swizzled for conflict-free ds_read_b128 fragments.  A 4-stage LDS ring is filled by direct-to-LDS
+//                    loads (buffer_load ... lds, the swizzle applied to the SOURCE address, zeros for out-of-range offsets), one 1-KiB
+//                    piece issued after each k-step's products, k-blocks t+1 .. t+3 in flight while t is multiplied, counted
+//                    s_waitcnt vmcnt + one s_barrier per k-block.  Split-K over blockIdx.y for the deep stages (fp32 slabs, summed in
+//                    a fixed order by gemm_nt_reduce_kernel).
 //                    Epilogue (in the kernel when splits == 1, else in the reduce kernel; staged through LDS so that every store is
 //                    a whole 16-byte piece of a row): + bias, GELU (saving the pre-activation) or GELU' (data gradient of fc2),
 //                    + residual, bf16 rounding, per-column sums / sums of squares of the rounded output (batch-norm statistics).
+//                    Measured (profiles/r05_gemm_micro.txt): 3x3 conv 128 -> 128 on 2 x 128 x 128 in 20 us (470 TFLOP/s; the library
+//                    route it replaces: 260 us); the loop runs at the rate the L2 -> LDS path delivers 32 KiB per k-block and CU
+//                    (~0.6 us: 13 TB/s chip-wide), not at the matrix pipe's (0.25 us) -- larger tiles / input-row reuse are the
+//                    open item.
 //   gemm_tn_kernel   D[i][j] = sum_r P(r,i) Q(r,j): both operands STRIDED along the reduction index (rows / pixels) -- the weight
-//                    gradient (P = dy, Q = x or its im2col view).  [64 r][128] LDS tiles with 320-byte rows, fragments by
-//                    ds_read_b64_tr_b16 (conflict-free at that stride), split over r (fp32 slabs), bias gradient = column sums of P
-//                    accumulated by the loader threads.  gemm_tn_reduce_kernel sums the slabs in a fixed order and writes the
-//                    gradient in the canonical torch layout [co][ci][kh][kw].
+//                    gradient (P = dy, Q = x or its im2col view).  Same ring; [64 r][128] tiles with 256-byte rows whose 16-byte
+//                    chunks are XOR-swizzled by the row so that ds_read_b64_tr_b16 fragments are conflict-free; split over r (fp32
+//                    slabs); bias gradient = column sums of P on the matrix pipe (a block of ones as the other operand, spread over
+//                    the four j-waves).  gemm_tn_reduce_kernel sums the slabs in a fixed order, turns (tap, ci) -> (ci, tap) through
+//                    LDS and writes -- or adds into the parameter's .grad -- the gradient in the torch layout [co][ci][kh][kw].
 // Every reduction has a fixed order: reruns are bit-identical.
 #include "common.hpp"
 

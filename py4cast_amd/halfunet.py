@@ -504,19 +504,10 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             kname = {2: "conv3x3_bf16_rows_kernel", 1: "conv3x3_bf16_ring_kernel"}.get(kind, "conv_fwd_bf16_ws_kernel<f32,64,3>")
             traffic, traffic_source = None, None
             if esz == 2 and (B, H, W) == (2, 512, 512):
-                # HBM bytes per launch of this launch shape from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with
-                # the gfx950 corrections): a COMMITTED reference value of an earlier run, not a measurement of this run
-                import json
-                import os
-
-                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-                for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
-                    f = os.path.join(root, "profiles", name)
-                    if os.path.exists(f):
-                        traffic = json.load(open(f)).get(kname, {}).get("hbm_bytes_per_launch")
-                        if traffic is not None:
-                            traffic_source = f"profiles/{name} (committed rocprofv3 --pmc passes of an earlier run of this kernel)"
-                            break
+                # HBM bytes per launch of this launch shape from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with the
+                # gfx950 corrections): a committed figure, reported only when it was measured on this tree's kernel sources
+                traffic, traffic_source = L.committed_traffic(("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"),
+                                                              (kname, "hbm_bytes_per_launch"))
             return {"bound": "hbm", "kernel": kname + " (3x3 conv 64->64, forward-plan launches at full resolution)",
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,
                     "traffic_source": traffic_source,

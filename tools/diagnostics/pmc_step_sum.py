@@ -40,5 +40,9 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     write = res["WRITE_SIZE"]["mean_KiB_per_step"] * 1024
     res["hbm_bytes_per_step"] = {"read": round(fetch), "written": round(write), "total": round(fetch + write)}
 res["largest_kernels_KiB_per_step"] = fam_tot
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from py4cast_amd._lib import kernel_sources_sha16   # noqa: E402
+
+res["kernel_sources_sha16"] = kernel_sources_sha16()   # bench.py reports the figure only for a tree with these kernel sources
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "largest_kernels_KiB_per_step"}, indent=1))

@@ -46,5 +46,9 @@ busy, act = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", {}), vals.get("GRBM_GUI_ACTIVE"
 if busy and act:
     res["MfmaUtil_percent"] = {fl: round(100.0 * (mean(busy[fl]) / 1024) / (mean(act[fl]) / 8), 1) for fl in busy if fl in act}
     res["MfmaUtil_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from py4cast_amd._lib import kernel_sources_sha16   # noqa: E402
+
+res["kernel_sources_sha16"] = kernel_sources_sha16()   # bench.py reports the figure only for a tree with these kernel sources
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
