@@ -23,9 +23,9 @@ def make_mlp(blueprint, layer_norm=True):
 
 
 class InteractionNet(nn.Module):
-    def __init__(self, hidden, hidden_layers=1, update_edges=True):
+    def __init__(self, hidden, hidden_layers=1, update_edges=True, aggr="sum"):
         super().__init__()
-        self.update_edges = update_edges
+        self.update_edges, self.aggr = update_edges, aggr     # neural-lam: PyG MessagePassing aggr = "sum" | "mean"
         self.edge_mlp = make_mlp([3 * hidden] + [hidden] * (hidden_layers + 1))
         self.aggr_mlp = make_mlp([2 * hidden] + [hidden] * (hidden_layers + 1))
 
@@ -33,12 +33,15 @@ class InteractionNet(nn.Module):
         # (B, N, C) node tensors, (B, E, C) edge tensors; index (2, E) [sender, receiver]
         msg = self.edge_mlp(torch.cat([edge_rep, send_rep[:, index[0]], rec_rep[:, index[1]]], dim=-1))
         agg = torch.zeros_like(rec_rep).index_add_(1, index[1], msg)
+        if self.aggr == "mean":
+            deg = torch.zeros(rec_rep.shape[1], dtype=rec_rep.dtype, device=rec_rep.device).index_add_(0, index[1], torch.ones_like(index[1], dtype=rec_rep.dtype))
+            agg = agg / deg.clamp_min(1).view(1, -1, 1)
         rec_rep = rec_rep + self.aggr_mlp(torch.cat([rec_rep, agg], dim=-1))
         return (rec_rep, edge_rep + msg) if self.update_edges else rec_rep
 
 
 class GraphLam(nn.Module):
-    def __init__(self, in_channels, out_channels, graph, hidden=64, hidden_layers=1, processor_layers=4):
+    def __init__(self, in_channels, out_channels, graph, hidden=64, hidden_layers=1, processor_layers=4, mesh_aggr="sum"):
         super().__init__()
         self.graph = graph  # dict: g2m, m2m, m2g (2,E) long; *_feat (E,3); mesh_pos (M,2)
         bp = [hidden] * (hidden_layers + 1)
@@ -49,7 +52,7 @@ class GraphLam(nn.Module):
         self.m2m_embedder = make_mlp([3] + bp)
         self.g2m_gnn = InteractionNet(hidden, hidden_layers, update_edges=False)
         self.encoding_grid_mlp = make_mlp([hidden] + bp)
-        self.processor = nn.ModuleList([InteractionNet(hidden, hidden_layers) for _ in range(processor_layers)])
+        self.processor = nn.ModuleList([InteractionNet(hidden, hidden_layers, aggr=mesh_aggr) for _ in range(processor_layers)])
         self.m2g_gnn = InteractionNet(hidden, hidden_layers, update_edges=False)
         self.output_map = make_mlp(bp + [out_channels], layer_norm=False)
 

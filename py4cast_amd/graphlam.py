@@ -188,9 +188,11 @@ def cached_static_embeddings(model: nn.Module, embedders, feats, B: int, dt: tor
 class InteractionNet(nn.Module):
     """neural-lam's InteractionNet; parameter layout identical to the concat formulation (edge_mlp.0.weight is (C, 3C))."""
 
-    def __init__(self, hidden: int, hidden_layers: int = 1, update_edges: bool = True):
+    def __init__(self, hidden: int, hidden_layers: int = 1, update_edges: bool = True, aggr: str = "sum"):
         super().__init__()
-        self.hidden, self.update_edges = hidden, update_edges
+        if aggr not in ("sum", "mean"):
+            raise NotImplementedError(f"InteractionNet: aggr={aggr!r} (neural-lam: 'sum' or 'mean')")
+        self.hidden, self.update_edges, self.aggr = hidden, update_edges, aggr
         self.edge_mlp = make_mlp([3 * hidden] + [hidden] * (hidden_layers + 1))
         self.aggr_mlp = make_mlp([2 * hidden] + [hidden] * (hidden_layers + 1))
 
@@ -226,6 +228,10 @@ class InteractionNet(nn.Module):
             msg = _run(self.edge_mlp[2:], h)
             new_edge = edge_rep + msg if self.update_edges else None
         agg = G.aggregate_sum(msg, edges)
+        if self.aggr == "mean":      # neural-lam's mesh_aggr: mean -- the sum over a receiver's edges divided by their number
+            B = agg.shape[0] // edges.n_dst if agg.shape[0] != edges.n_dst else 1
+            inv = edges.inv_degree(agg.dtype)
+            agg = agg * (inv if B == 1 else inv.repeat(B, 1))
         al0, al1, aln = self.aggr_mlp[0], self.aggr_mlp[2], self.aggr_mlp[3]
         if rec_rep.dtype == torch.bfloat16 and C == 64 and rec_rep.shape[0] >= 1:
             # Linear over cat[x_r, agg] = x_r W[:, :C]^T (small library GEMM, row-aligned addend) + agg W[:, C:]^T (fused kernel's x)
@@ -253,8 +259,8 @@ class GraphLamMI355X(ModelABC, nn.Module):
         super().__init__()
         self.in_channels, self.out_channels, self.input_shape = in_channels, out_channels, input_shape
         self._settings = settings
-        if settings.mesh_aggr != "sum":
-            raise NotImplementedError("mesh_aggr: only 'sum' is implemented (the reference yaml's value)")
+        if settings.mesh_aggr not in ("sum", "mean"):
+            raise NotImplementedError(f"mesh_aggr={settings.mesh_aggr!r}: 'sum' (the reference yaml's value) or 'mean'")
         path = graph_path(settings.tmp_dir, input_shape, settings.mesh_levels)
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path}: run {type(self).__name__}.rank_zero_setup(settings, meshgrid) first "
@@ -277,7 +283,8 @@ class GraphLamMI355X(ModelABC, nn.Module):
         self.m2m_embedder = make_mlp([3] + bp)
         self.g2m_gnn = InteractionNet(h, L_, update_edges=False)
         self.encoding_grid_mlp = make_mlp([h] + bp)
-        self.processor = nn.ModuleList([InteractionNet(h, L_, update_edges=True) for _ in range(settings.processor_layers)])
+        self.processor = nn.ModuleList([InteractionNet(h, L_, update_edges=True, aggr=settings.mesh_aggr)    # (the mesh processor only,
+                                        for _ in range(settings.processor_layers)])                           # as in neural-lam)
         self.m2g_gnn = InteractionNet(h, L_, update_edges=False)
         self.output_map = make_mlp(bp + [out_channels], layer_norm=False)
         self.timed_entry_points = ("p4c_edge_gather_add_fwd", "p4c_edge_gather_add_bwd", "p4c_segment_sum",

@@ -27,7 +27,18 @@ class EdgeSet:
         self.by_dst = _csr(self.dst, self.n_dst)
         self.by_src = _csr(self.src, self.n_src)
 
+    def inv_degree(self, dtype: torch.dtype) -> torch.Tensor:
+        """(n_dst, 1): 1 / number of incoming edges of every receiver (1 for a receiver without edges: its sum is zero anyway) --
+        the factor that turns the segment sum into neural-lam's ``aggr="mean"`` (``mesh_aggr: mean``)"""
+        key = ("inv_degree", dtype)
+        cache = self.__dict__.setdefault("_derived", {})
+        if key not in cache or cache[key].device != self.dst.device:
+            off = self.by_dst[0].to(torch.int64)
+            cache[key] = (1.0 / (off[1:] - off[:-1]).clamp_min(1).to(torch.float32)).to(dtype).unsqueeze(1)
+        return cache[key]
+
     def to(self, device):
+        self.__dict__.pop("_derived", None)
         for k in ("src", "dst"):
             setattr(self, k, getattr(self, k).to(device))
         self.by_dst = tuple(t.to(device) for t in self.by_dst)

@@ -238,26 +238,29 @@ def test_window_attention_rejects_bad_shapes(gpu_device):
 
 
 # ----------------------------------------------------------------------------------------- GraphLAM on the edge kernels
-def _graphlam_pair(tmp_path, H, W, cin, cout, dtype="f32"):
+def _graphlam_pair(tmp_path, H, W, cin, cout, dtype="f32", mesh_aggr="sum"):
     from oracle.graphlam import GraphLam as OracleGraphLam
     from py4cast_amd.graphlam import GraphLamMI355X, GraphLamSettings
 
     ys, xs = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
-    st = GraphLamSettings(tmp_dir=str(tmp_path), activation_dtype=dtype)
+    st = GraphLamSettings(tmp_dir=str(tmp_path), activation_dtype=dtype, mesh_aggr=mesh_aggr)
     GraphLamMI355X.rank_zero_setup(st, torch.stack([xs, ys]))
     torch.manual_seed(21)
     model = GraphLamMI355X(cin, cout, (H, W), st)
     graph = {k: getattr(model, f"{k}_index") for k in ("g2m", "m2m", "m2g")}
     graph.update({f"{k}_feat": getattr(model, f"{k}_features") for k in ("g2m", "m2m", "m2g")})
     graph["mesh_pos"] = model.mesh_static_features
-    oracle = OracleGraphLam(cin, cout, graph).double()
+    oracle = OracleGraphLam(cin, cout, graph, mesh_aggr=mesh_aggr).double()
     oracle.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
     return model, oracle
 
 
-def test_graphlam_matches_oracle(gpu_device, tmp_path):
+@pytest.mark.parametrize("mesh_aggr", ["sum", "mean"])
+def test_graphlam_matches_oracle(gpu_device, tmp_path, mesh_aggr):
+    """mesh_aggr: sum is the reference yaml's value (config/CLI/model/graphlam.yaml:25); mean -- neural-lam's other choice -- divides
+    every receiver's sum by its number of incoming edges in the mesh processor"""
     H, W, cin, cout = 36, 45, 13, 5
-    model, oracle = _graphlam_pair(tmp_path, H, W, cin, cout)
+    model, oracle = _graphlam_pair(tmp_path, H, W, cin, cout, mesh_aggr=mesh_aggr)
     model = model.to(gpu_device)
     torch.manual_seed(22)
     x = torch.randn(2, H * W, cin)
