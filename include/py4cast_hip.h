@@ -552,8 +552,11 @@ int p4c_row_linear_wgrad(const void* dy, const void* x, float* dw_db, void* work
  * x = dy, w = W, transposed = 1, K and N swapped.  K a multiple of 8 up to 512, N a multiple of 4, operand image within LDS:
  * p4c_row_gemm_supported(K, N) says whether a shape is served (callers use the library GEMM otherwise). */
 int p4c_row_gemm_supported(int K, int N);
+/* Fused epilogue (round 5), in this order: act = 1: the bf16-rounded pre-activation goes to aux (row stride ldaux) and GELU (erf form) of
+ * it on; act = 2: times GELU'(aux) (the data gradient through a GELU); then + res[r][n] (bf16 rows, stride ldres; res may be y itself:
+ * accumulate).  act = 0, res = NULL: the plain product. */
 int p4c_row_gemm(const void* x, int64_t ldx, const float* w, int ldw, int transposed, const float* bias, void* y, int64_t ldy,
-                 int64_t R, int K, int N, p4c_stream_t stream);
+                 int64_t R, int K, int N, const void* res, int64_t ldres, int act, void* aux, int64_t ldaux, p4c_stream_t stream);
 /* Weight and bias gradient of the same layer over R >> N rows:  out is (64 * ceil(N / 64)) x KP floats (overwritten), KP = 32 *
  * ceil((K + with_bias) / 32):  out[n][k] = dW[n][k] = sum_r dy[r][n] x[r][k] for k < K, and with_bias: out[n][K] = db[n] = sum_r
  * dy[r][n].  bf16 rows, fp32 accumulation, fixed reduction order (bit-identical reruns).  N, K multiples of 8, K + with_bias <= 224,

@@ -45,7 +45,19 @@ struct RowGemmArgs {
     int64_t ldy;
     int64_t R;
     int K, N;
+    // fused epilogue (round 5): act 1 = the bf16-rounded pre-activation goes to aux (row stride ldaux), GELU (erf) of it on;
+    // act 2 = times GELU'(aux) (data gradient through the GELU); then + res (row stride ldres; may alias y: accumulate)
+    const bf16* res;
+    int64_t ldres;
+    bf16* aux;
+    int64_t ldaux;
+    int act;
 };
+
+__device__ __forceinline__ float rg_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float rg_gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 
 // LDS: image[(tile * S + s) * 64 + lane] = 8 bf16 = M[32 tile + (lane & 31)][16 s + 8 (lane >> 5) + j], zero outside (N, K); then
 // the bias as floats [32 * tiles]
@@ -124,11 +136,27 @@ __global__ void __launch_bounds__(256, (S <= 8 ? 2 : 1)) row_gemm_kernel(RowGemm
                     const int n = 32 * (c0 + u) + 8 * q + 4 * h;      // accumulator element 4 q + e <-> feature n + e of the lane's row
                     if (live && n < a.N) {
                         const float4 bv = *reinterpret_cast<const float4*>(lb + n);
+                        float v[4] = {acc[u][4 * q] + bv.x, acc[u][4 * q + 1] + bv.y, acc[u][4 * q + 2] + bv.z, acc[u][4 * q + 3] + bv.w};
+                        if (a.act == 1) {
+                            bf16x4 hq;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hq[e] = (__bf16)v[e];
+                            *reinterpret_cast<bf16x4*>(a.aux + row * a.ldaux + n) = hq;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = rg_gelu((float)hq[e]);      // of the STORED pre-activation
+                        } else if (a.act == 2) {
+                            const bf16x4 hq = *reinterpret_cast<const bf16x4*>(a.aux + row * a.ldaux + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= rg_gelu_grad((float)hq[e]);
+                        }
+                        if (a.res) {
+                            const bf16x4 rq = *reinterpret_cast<const bf16x4*>(a.res + row * a.ldres + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rq[e];
+                        }
                         bf16x4 o;
-                        o[0] = (__bf16)(acc[u][4 * q] + bv.x);
-                        o[1] = (__bf16)(acc[u][4 * q + 1] + bv.y);
-                        o[2] = (__bf16)(acc[u][4 * q + 2] + bv.z);
-                        o[3] = (__bf16)(acc[u][4 * q + 3] + bv.w);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
                         *reinterpret_cast<bf16x4*>(yrow + n) = o;
                     }
                 }
@@ -358,13 +386,15 @@ extern "C" int p4c_row_gemm_supported(int K, int N) {
 }
 
 extern "C" int p4c_row_gemm(const void* x, int64_t ldx, const float* w, int ldw, int transposed, const float* bias, void* y, int64_t ldy,
-                            int64_t R, int K, int N, p4c_stream_t stream) {
+                            int64_t R, int K, int N, const void* res, int64_t ldres, int act, void* aux, int64_t ldaux, p4c_stream_t stream) {
     P4C_CHECK_ARG(x && w && y, "p4c_row_gemm: NULL pointer");
     P4C_CHECK_ARG(R >= 0 && p4c_row_gemm_supported(K, N), "p4c_row_gemm: unsupported sizes R=%lld K=%d N=%d (K multiple of 8 up to 512, N multiple of 4, "
                   "weight image within %d KiB of LDS)", (long long)R, K, N, FWD_LDS_LIMIT / 1024);
     P4C_CHECK_ARG(ldx >= K && ldy >= N && ldx % 8 == 0 && ldy % 4 == 0, "p4c_row_gemm: row strides must cover the rows (ldx multiple of 8, ldy of 4)");
+    P4C_CHECK_ARG(act >= 0 && act <= 2 && (act == 0 || (aux && ldaux >= N && ldaux % 4 == 0)), "p4c_row_gemm: act 1 / 2 need the aux rows (ldaux multiple of 4)");
+    P4C_CHECK_ARG(!res || (ldres >= N && ldres % 4 == 0), "p4c_row_gemm: residual row stride must be a multiple of 4 covering the rows");
     if (R == 0) return P4C_OK;
-    RowGemmArgs a{(const bf16*)x, ldx, w, ldw, transposed, bias, (bf16*)y, ldy, R, K, N};
+    RowGemmArgs a{(const bf16*)x, ldx, w, ldw, transposed, bias, (bf16*)y, ldy, R, K, N, (const bf16*)res, ldres, (bf16*)aux, ldaux, act};
     hipStream_t st = as_stream(stream);
     switch (fwd_steps(K)) {
         case 1: return launch_fwd<1>(a, st);

@@ -6,6 +6,7 @@ efficient); LayerNorm (+ residual) and the weight gradients (64 x K outputs, red
 kernels of csrc/rows.hip.  No CPU fallback.
 """
 
+import os
 from typing import Optional
 
 import torch
@@ -56,14 +57,40 @@ def _native_wgrad_ok(x: torch.Tensor, O: int, K: int) -> bool:
     return x.dtype == torch.bfloat16 and O == 64 and K % 16 == 0 and 16 <= K <= 128 and x.shape[0] >= 4096
 
 
+def _rg_native(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """the GNNs' 64-feature projections on the streaming row-GEMM kernel (any row count) instead of a library GEMM: bf16 rows, an fp32
+    master weight (a column block of a wider Linear is fine: its row stride is passed on) in the sizes of p4c_row_gemm_supported"""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1 and x.dim() == 2):
+        return False
+    O, K = w.shape
+    if K % 8 or O % 8 or x.shape[0] < 1 or os.environ.get("P4C_GNN_LIBRARY_GEMM") == "1":
+        return False
+    lib = L.lib()
+    return bool(lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K))
+
+
+def _rg_fwd(x, w, b=None):
+    return _row_gemm(_rows2d(x, w.shape[1]), w.detach(), False, None if b is None else b.detach().float().contiguous(), w.shape[0])
+
+
+def _rg_dgrad(dy, w, acc=None):
+    """dy W (+ acc, in place when given)"""
+    return _row_gemm(_rows2d(dy, w.shape[0]), w.detach(), True, None, w.shape[1], res=acc, out=acc)
+
+
 class _RowLinear(torch.autograd.Function):
-    """y = x W^T + b with W, b fp32 masters and bf16 rows: library GEMMs for y and dx, p4c_row_linear_wgrad for dW, db."""
+    """y = x W^T + b with W, b fp32 masters and bf16 rows: the row-GEMM kernel (library GEMMs off its sizes) for y and dx,
+    p4c_row_linear_wgrad for dW, db."""
 
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.native = _rg_native(x, w)
+        ctx.has_bias, ctx.pdtype = b is not None, w.dtype
+        if ctx.native:
+            ctx.save_for_backward(x, w.detach())
+            return _rg_fwd(x, w, b)
         wq = w.to(x.dtype)
         ctx.save_for_backward(x, wq)
-        ctx.has_bias, ctx.pdtype = b is not None, w.dtype
         return F.linear(x, wq, None if b is None else b.to(x.dtype))
 
     @staticmethod
@@ -72,7 +99,7 @@ class _RowLinear(torch.autograd.Function):
         dy = dy.contiguous()
         R, K = x.shape
         O = wq.shape[0]
-        dx = dy @ wq if ctx.needs_input_grad[0] else None
+        dx = (_rg_dgrad(dy, wq) if ctx.native else dy @ wq) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             buf = torch.empty(O * K + O, dtype=torch.float32, device=x.device)
@@ -154,9 +181,13 @@ class _RowLinearSink(torch.autograd.Function):
     def forward(ctx, x, w, gw):
         # w (the live parameter view) is an input so that the node is recorded even when x needs no gradient; its gradient slot
         # returns None: autograd must not also accumulate what the backward adds itself
+        ctx.native = _rg_native(x, w)
+        ctx.gw = gw
+        if ctx.native:
+            ctx.save_for_backward(x, w.detach())
+            return _rg_fwd(x, w)
         wq = weight_as(w, x.dtype)
         ctx.save_for_backward(x, wq)
-        ctx.gw = gw
         return F.linear(x, wq)
 
     @staticmethod
@@ -165,7 +196,7 @@ class _RowLinearSink(torch.autograd.Function):
         dy = dy.contiguous()
         R, K = x.shape
         O = wq.shape[0]
-        dx = dy @ wq if ctx.needs_input_grad[0] else None
+        dx = (_rg_dgrad(dy, wq) if ctx.native else dy @ wq) if ctx.needs_input_grad[0] else None
         _sink_weight_grad(x, dy, ctx.gw)
         return dx, None, None
 
@@ -193,9 +224,13 @@ class _RowLinearMulti(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n, *args):
         ws, gws = args[:n], args[n:]
+        ctx.native = all(_rg_native(x, w) for w in ws)
+        ctx.gws, ctx.n = gws, n
+        if ctx.native:
+            ctx.save_for_backward(x, *[w.detach() for w in ws])
+            return tuple(_rg_fwd(x, w) for w in ws)
         wqs = [weight_as(w, x.dtype) for w in ws]
         ctx.save_for_backward(x, *wqs)
-        ctx.gws, ctx.n = gws, n
         return tuple(F.linear(x, wq) for wq in wqs)
 
     @staticmethod
@@ -207,7 +242,10 @@ class _RowLinearMulti(torch.autograd.Function):
                 continue
             dy = dy.contiguous()
             if ctx.needs_input_grad[0]:
-                dx = dy @ wq if dx is None else dx.addmm_(dy, wq)
+                if ctx.native:
+                    dx = _rg_dgrad(dy, wq, acc=dx)        # (the sum over the projections inside the kernel's epilogue)
+                else:
+                    dx = dy @ wq if dx is None else dx.addmm_(dy, wq)
             _sink_weight_grad(x, dy, gw)
         return (dx, None) + (None,) * (2 * ctx.n)
 
@@ -234,6 +272,8 @@ def row_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = Non
             return _RowLinearSink.apply(x, w, gw)
     if _native_wgrad_ok(x, w.shape[0], w.shape[1]):
         return _RowLinear.apply(x, w, b)
+    # (few rows -- the upper mesh levels -- or widths off the tall-skinny weight-gradient kernel stay on the library: the row-GEMM
+    # weight gradient + its reduction are two launches where the library needs one; measured: HiLAM 44.2 -> 46.8 ms per step with them)
     return F.linear(x, w.to(x.dtype), None if b is None else b.to(x.dtype))
 
 
@@ -250,10 +290,16 @@ def _row_gemm_mode(x: torch.Tensor, w: torch.Tensor, b) -> str:
     """Which passes of a Linear the native kernels take: "all" (forward, data gradient, weight + bias gradient) or "" (library).  They serve bf16 rows with fp32 master
     parameters, from 1 024 rows (below that the library's ~20 us floor does not matter), in the sizes p4c_row_gemm_supported /
     _wgrad_supported state (include/py4cast_hip.h)."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.float32 and w.dim() == 2 and (b is None or b.dtype == torch.float32)):
+    if not (x.is_cuda and x.dtype == torch.bfloat16):
+        return ""
+    return _row_gemm_mode_rows(x.numel() // max(w.shape[-1], 1), w, b)
+
+
+def _row_gemm_mode_rows(R: int, w: torch.Tensor, b) -> str:
+    """_row_gemm_mode for R bf16 rows on the GPU"""
+    if not (w.dtype == torch.float32 and w.dim() == 2 and (b is None or b.dtype == torch.float32)):
         return ""
     O, K = w.shape
-    R = x.numel() // max(K, 1)
     if R < 1024 or K % 8 or O % 8 or _wgrad_chunks(O, K, b is not None) is None:
         return ""
     lib = L.lib()
@@ -289,12 +335,34 @@ def _wgrad_chunks(O: int, K: int, has_bias: bool):
     return chunks
 
 
-def _row_gemm(x2: torch.Tensor, w: torch.Tensor, transposed: bool, bias, N: int) -> torch.Tensor:
+def _row_gemm(x2: torch.Tensor, w: torch.Tensor, transposed: bool, bias, N: int, res=None, act: int = 0, aux=None, out=None) -> torch.Tensor:
+    """csrc/rowgemm.hip: y = x2 M^T (+ bias) with the fused epilogue of p4c_row_gemm (act 1: GELU, pre-activation to `aux`; act 2:
+    times GELU'(aux); + res).  out: write into this (R, N) tensor (may be `res` itself: accumulate)."""
     R, K = x2.shape
-    y = torch.empty(R, N, dtype=x2.dtype, device=x2.device)
-    L.call("p4c_row_gemm", L.ptr(x2), x2.stride(0), L.ptr(w), w.stride(0), int(transposed), L.ptr(bias), L.ptr(y), N, R, K, N,
-           L.stream(x2.device), alg_bytes=R * (K + N) * 2)
+    y = torch.empty(R, N, dtype=x2.dtype, device=x2.device) if out is None else out
+    L.call("p4c_row_gemm", L.ptr(x2), x2.stride(0), L.ptr(w), w.stride(0), int(transposed), L.ptr(bias), L.ptr(y), y.stride(0), R, K, N,
+           L.ptr(res), 0 if res is None else res.stride(0), int(act), L.ptr(aux), 0 if aux is None else aux.stride(0),
+           L.stream(x2.device), alg_bytes=R * (K + N * (1 + (res is not None) + (act != 0))) * 2, alg_flops=2 * R * K * N)
     return y
+
+
+def _native_wgrad_fn(dy2, x2, O, K, has_bias, wdtype, bdtype):
+    """(dW, db) of a Linear from its rows on p4c_row_gemm_wgrad (pieces of <= _WGRAD_KMAX input features)"""
+    lib = L.lib()
+    R = x2.shape[0]
+    parts, db = [], None
+    for k0, k1 in _wgrad_chunks(O, K, has_bias):
+        kc, ones = k1 - k0, int(has_bias and k1 == K)     # the bias gradient rides with the last piece
+        xs = x2[:, k0:k1]
+        out = torch.empty(64 * ((O + 63) // 64), 32 * ((kc + ones + 31) // 32), dtype=torch.float32, device=dy2.device)
+        ws = torch.empty(max(lib.p4c_row_gemm_wgrad_workspace_bytes(R, O, kc, ones) // 4, 1), dtype=torch.float32, device=dy2.device)
+        L.call("p4c_row_gemm_wgrad", L.ptr(dy2), dy2.stride(0), L.ptr(xs), xs.stride(0), L.ptr(out), L.ptr(ws), R, O, kc, ones,
+               L.stream(dy2.device), alg_bytes=R * (kc + O) * 2)
+        parts.append(out[:O, :kc])
+        if ones:
+            db = out[:O, kc].to(bdtype)
+    dw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(wdtype)
+    return dw, db
 
 
 class _LinearND(torch.autograd.Function):
@@ -307,38 +375,29 @@ class _LinearND(torch.autograd.Function):
     GEMM is also the cheaper launch."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, res=None, force=False):
         mode = _row_gemm_mode(x, w, b)
+        if force and mode != "all" and x.is_cuda and x.dtype == torch.bfloat16 and _wgrad_chunks(w.shape[0], w.shape[1], b is not None) is not None:
+            mode = "all"       # the caller has checked the kernels' size limits and wants them whatever the row count (the mesh GNNs)
         ctx.mode = mode
         ctx.has_bias, ctx.wdtype, ctx.bdtype = b is not None, w.dtype, (None if b is None else b.dtype)
-        ctx.xshape = x.shape
+        ctx.xshape, ctx.has_res = x.shape, res is not None
         if mode == "all":
             O, K = w.shape
             wc = w.detach() if w.stride(1) == 1 else w.detach().contiguous()
             x2 = _rows2d(x.detach(), K)
             ctx.save_for_backward(x2, wc)
-            return _row_gemm(x2, wc, False, None if b is None else b.detach().contiguous(), O).view(*x.shape[:-1], O)
+            r2 = None if res is None else _rows2d(res.detach(), O)      # the residual in the product's epilogue
+            return _row_gemm(x2, wc, False, None if b is None else b.detach().contiguous(), O, res=r2).view(*x.shape[:-1], O)
+        if res is not None:
+            raise L.P4CError("_LinearND: a fused residual needs the row-GEMM kernels (callers add it themselves otherwise)")
         wq = w.to(x.dtype)
         ctx.save_for_backward(x, wq)
         return F.linear(x, wq, None if b is None else b.to(x.dtype))
 
     @staticmethod
     def _native_wgrad(ctx, dy2, x2, O, K):
-        lib = L.lib()
-        R = x2.shape[0]
-        parts, db = [], None
-        for k0, k1 in _wgrad_chunks(O, K, ctx.has_bias):
-            kc, ones = k1 - k0, int(ctx.has_bias and k1 == K)     # the bias gradient rides with the last piece
-            xs = x2[:, k0:k1]
-            out = torch.empty(64 * ((O + 63) // 64), 32 * ((kc + ones + 31) // 32), dtype=torch.float32, device=dy2.device)
-            ws = torch.empty(max(lib.p4c_row_gemm_wgrad_workspace_bytes(R, O, kc, ones) // 4, 1), dtype=torch.float32, device=dy2.device)
-            L.call("p4c_row_gemm_wgrad", L.ptr(dy2), dy2.stride(0), L.ptr(xs), xs.stride(0), L.ptr(out), L.ptr(ws), R, O, kc, ones,
-                   L.stream(dy2.device), alg_bytes=R * (kc + O) * 2)
-            parts.append(out[:O, :kc])
-            if ones:
-                db = out[:O, kc].to(ctx.bdtype)
-        dw = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).to(ctx.wdtype)
-        return dw, db
+        return _native_wgrad_fn(dy2, x2, O, K, ctx.has_bias, ctx.wdtype, ctx.bdtype)
 
     @staticmethod
     def backward(ctx, dy):
@@ -349,7 +408,7 @@ class _LinearND(torch.autograd.Function):
             dy2 = _rows2d(dy, O)
             dx = _row_gemm(dy2, wc, True, None, K).view(ctx.xshape) if ctx.needs_input_grad[0] else None
             dw, db = _LinearND._native_wgrad(ctx, dy2, x2, O, K) if want_w else (None, None)
-            return dx, dw, db
+            return dx, dw, db, (dy if ctx.has_res else None), None
         x, wq = ctx.saved_tensors
         O, K = wq.shape
         dy2 = dy.reshape(-1, O)
@@ -360,7 +419,59 @@ class _LinearND(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             ones = torch.ones(1, dy2.shape[0], dtype=dy2.dtype, device=dy2.device)
             db = (ones @ dy2)[0].to(ctx.bdtype)
-        return dx, dw, db
+        return dx, dw, db, None, None
+
+
+class _RowMLP(torch.autograd.Function):
+    """res + fc2(gelu(fc1(x))) on bf16 token rows as ONE autograd node on the streaming row-GEMM kernels (csrc/rowgemm.hip): GELU in the
+    first product's epilogue (the pre-activation h saved), bias + residual in the second's; backward: (dy W2) * GELU'(h) in the
+    epilogue of the second layer's data gradient -- no element-wise launch either way (SwinUNETR's two large stages)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res):
+        Hd, K = w1.shape
+        O = w2.shape[0]
+        x2 = _rows2d(x.detach(), K)
+        w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
+        h = torch.empty(x2.shape[0], Hd, dtype=x2.dtype, device=x2.device)
+        g = _row_gemm(x2, w1c, False, b1.detach().contiguous(), Hd, act=1, aux=h)
+        r2 = None if res is None else _rows2d(res.detach(), O)
+        y = _row_gemm(g, w2c, False, b2.detach().contiguous(), O, res=r2)
+        ctx.save_for_backward(x2, g, h, w1c, w2c)
+        ctx.xshape, ctx.has_res, ctx.dts = x.shape, res is not None, (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        ctx.has_bias, ctx.wdtype = True, w1.dtype
+        return y.view(*x.shape[:-1], O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, h, w1c, w2c = ctx.saved_tensors
+        Hd, K = w1c.shape
+        O = w2c.shape[0]
+        dy2 = _rows2d(dy, O)
+        dh = _row_gemm(dy2, w2c, True, None, Hd, act=2, aux=h)
+        ctx.bdtype = ctx.dts[3]
+        dw2, db2 = _LinearND._native_wgrad(ctx, dy2, g, O, Hd)
+        dx = _row_gemm(dh, w1c, True, None, K).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        ctx.bdtype = ctx.dts[1]
+        dw1, db1 = _LinearND._native_wgrad(ctx, dh, x2, Hd, K)
+        return dx, dw1.to(ctx.dts[0]), db1, dw2.to(ctx.dts[2]), db2, (dy if ctx.has_res else None)
+
+
+def row_mlp_gelu_ok(x: torch.Tensor, w1, b1, w2, b2) -> bool:
+    return (b1 is not None and b2 is not None and _row_gemm_ok(x, w1, b1)
+            and _row_gemm_mode_rows(x.numel() // max(w1.shape[1], 1), w2, b2) == "all")
+
+
+def row_mlp_gelu(x, w1, b1, w2, b2, res=None) -> torch.Tensor:
+    """``F.linear(F.gelu(F.linear(x, w1, b1)), w2, b2) (+ res)`` on the row-GEMM kernels (check row_mlp_gelu_ok first)"""
+    return _RowMLP.apply(x, w1, b1, w2, b2, res)
+
+
+def linear_res(x: torch.Tensor, w: torch.Tensor, b, res: torch.Tensor) -> torch.Tensor:
+    """``F.linear(x, w, b) + res`` with the residual in the row-GEMM's epilogue where those kernels serve the layer"""
+    if _row_gemm_ok(x, w, b):
+        return _LinearND.apply(x, w, b, res)
+    return _LinearND.apply(x, w, b) + res
 
 
 class _AddBias(torch.autograd.Function):

@@ -119,8 +119,9 @@ def _lin(x: torch.Tensor, w: torch.Tensor, b=None, res=None) -> torch.Tensor:
     the fp32 flavour / widths off the 8-feature granularity"""
     if _native(x) and G.supported(x, w) and not R._row_gemm_ok(x, w, b):
         return G.linear(x, w, b, res)
-    y = R.linear_nd(x, w, b)
-    return y if res is None else y + res
+    if res is not None:
+        return R.linear_res(x, w, b, res)
+    return R.linear_nd(x, w, b)
 
 
 def _linear(m: nn.Linear, x: torch.Tensor) -> torch.Tensor:
@@ -131,6 +132,8 @@ def _mlp(fc1: nn.Linear, fc2: nn.Linear, x: torch.Tensor, res: torch.Tensor) -> 
     """res + fc2(gelu(fc1(x))): one autograd node with GELU / GELU' in the GEMM epilogues where the tiled GEMM carries both layers"""
     if (_native(x) and G.supported(x, fc1.weight) and G.supported(x, fc2.weight) and not R._row_gemm_ok(x, fc1.weight, fc1.bias)):
         return G.mlp(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, res)
+    if _native(x) and R.row_mlp_gelu_ok(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias):
+        return R.row_mlp_gelu(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, res)       # the two large stages: streaming row GEMMs
     return res + _linear(fc2, F.gelu(_linear(fc1, x)))
 
 

@@ -353,3 +353,37 @@ def test_weight_gradients_accumulate_into_existing_grad_buffers(gpu_device):
     ref_c = wc.grad.clone()
     G.conv2d_nhwc(xc, wc).backward(dyc)
     assert torch.allclose(wc.grad, 2 * ref_c, rtol=0, atol=1e-5 * float(ref_c.abs().max()))
+
+
+@pytest.mark.parametrize("R,K,Hd", [(8192, 24, 96), (16500, 48, 192)])
+def test_row_gemm_mlp_node_vs_float64(gpu_device, R, K, Hd):
+    """The streaming row-GEMM kernels' fused epilogues (csrc/rowgemm.hip, round 5): res + fc2(gelu(fc1(x))) as one node -- GELU / GELU'
+    and the residual inside the products -- against float64 with the node's roundings (h and g stored as bf16)."""
+    from py4cast_amd import ops_rows as RW
+
+    dev = gpu_device
+    x = rnd((R, K), dev, 91).bfloat16().requires_grad_()
+    w1 = (rnd((Hd, K), dev, 92) / K ** 0.5).requires_grad_()
+    b1 = rnd((Hd,), dev, 93, 0.5).requires_grad_()
+    w2 = (rnd((K, Hd), dev, 94) / Hd ** 0.5).requires_grad_()
+    b2 = rnd((K,), dev, 95, 0.5).requires_grad_()
+    dy = rnd((R, K), dev, 96).bfloat16()
+    assert RW.row_mlp_gelu_ok(x, w1, b1, w2, b2)
+    y = RW.row_mlp_gelu(x, w1, b1, w2, b2, res=x)
+    y.backward(dy)
+    xd = x.detach().double().requires_grad_()
+    w1d, w2d = w1.detach().bfloat16().double().requires_grad_(), w2.detach().bfloat16().double().requires_grad_()
+    b1d, b2d = b1.detach().double().requires_grad_(), b2.detach().double().requires_grad_()
+    h = xd @ w1d.t() + b1d
+    g = F.gelu(h.detach().bfloat16().double() + (h - h.detach()))
+    g = g.detach().bfloat16().double() + (g - g.detach())
+    ref = g @ w2d.t() + b2d + xd
+    ref.backward(dy.double())
+    close_bf16(y, ref, "y")
+    close_bf16(x.grad, xd.grad, "dx")
+    assert rel(w1.grad, w1d.grad) <= 3e-3 and rel(w2.grad, w2d.grad) <= 1e-3 and rel(b1.grad, b1d.grad) <= 3e-3 and rel(b2.grad, b2d.grad) <= 5e-4
+    # a projection with the residual in its epilogue, and accumulation into an existing tensor
+    w = (rnd((K, K), dev, 97) / K ** 0.5)
+    b = rnd((K,), dev, 98)
+    z = RW.linear_res(x.detach(), w, b, x.detach())
+    close_bf16(z, x.detach().double() @ w.bfloat16().double().t() + b.double() + x.detach().double(), "linear_res")
