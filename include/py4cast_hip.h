@@ -355,6 +355,14 @@ int p4c_conv_wgrad_nb(const void* in, const float* in_scale, const float* in_shi
                       const float* gamma, const float* nscale, const float* nshift, const float* rstd, const float* mean,
                       const float* k1, const float* k2, int CO, int CI, float* grad, void* workspace, int B, int H, int W,
                       p4c_stream_t stream);
+/* x pass of the adjoint of HalfUNet's decoder merge (mfai's HalfUNet sums `F.interpolate(level_k, scale_factor=2^k, mode="bilinear")`,
+ * k = 1..4, at full resolution; its backward runs under py4cast/lightning.py:591-596 / training_step :806-831), all four levels from
+ * ONE read of the (B,H,W,64) gradient dS:  tx_k[b,y,X,:] = sum_x wx_k(x,X) dS[b,y,x,:],  tx_k is (B,H,W/2^k,64), align_corners=False
+ * weights (border columns take the clamped taps).  bf16 storage with W % 64 == 0 runs as a banded GEMM on the matrix cores
+ * (csrc/upbwd_mfma.hip), otherwise on the vector ALU; W % 16 == 0 required.  The y pass is part of the backward plan. */
+int p4c_upsample_sum_bwd_x(int storage, const void* dS, int B, int H, int W, void* tx1, void* tx2, void* tx3, void* tx4,
+                           p4c_stream_t stream);
+
 /* The whole backward of a 1x1 convolution from 64 channels behind a [conv -> norm -> ReLU] block (the HalfUNet's output convolution:
  * mfai's `outconv`) in ONE pass over its operands, bf16 maps (csrc/out_conv_bwd.hip):
  *   dA (B,N,64) = the data gradient (wprep_dgrad: p4c_prep_weights(w, CO, 64, ks 1, transpose_flip 1, 64, 64, compute P4C_BF16));

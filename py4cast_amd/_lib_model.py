@@ -54,6 +54,7 @@ SIGNATURES = {
     "p4c_conv_wgrad_nb": [P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, P, P, I, I, I, P],
     "p4c_conv_wgrad_kernel_kind": [I, I, I, I],
     "p4c_out_conv_bwd": [P, P, P, P, P, P, P, P, P, I, P, P, I, L, P],
+    "p4c_upsample_sum_bwd_x": [I, P, I, I, I, P, P, P, P, P],
     "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
     "p4c_halfunet_prepare_weights": [DP, P, P, P],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],

@@ -805,6 +805,15 @@ extern "C" int p4c_out_conv_bwd(const void* dy, const void* wprep_dgrad, const v
     return wgrad_reduce((const float*)workspace, B * nblk, 1, 64, 0, 64, CO, 64, grad_w, as_stream(stream));
 }
 
+extern "C" int p4c_upsample_sum_bwd_x(int storage, const void* dS, int B, int H, int W, void* tx1, void* tx2, void* tx3, void* tx4,
+                                     p4c_stream_t stream) {
+    P4C_CHECK_ARG(dS && tx1 && tx2 && tx3 && tx4, "p4c_upsample_sum_bwd_x: null pointer");
+    P4C_CHECK_ARG(storage == P4C_F32 || storage == P4C_BF16, "p4c_upsample_sum_bwd_x: storage must be P4C_F32 or P4C_BF16");
+    P4C_CHECK_ARG(B > 0 && H > 0 && W >= 16 && W % 16 == 0, "p4c_upsample_sum_bwd_x: W must be a positive multiple of 16");
+    void* tx[4] = {tx1, tx2, tx3, tx4};
+    return up_bwd_x4(storage, dS, B, H, W, tx, as_stream(stream));
+}
+
 extern "C" int p4c_conv_wgrad_kernel_kind(int storage, int B, int H, int W) {
     int64_t ntiles = (int64_t)B * conv_tiles_per_sample(H, W);
     const int G = ntiles < num_cus() ? (int)ntiles : num_cus();

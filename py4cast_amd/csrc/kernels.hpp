@@ -183,6 +183,9 @@ int upsum_fwd(int storage, const void* const* y, const float* const* scale, cons
               void* S, hipStream_t stream);
 // tx[k-1]: (B,H,W>>k,64) for k = 1..4
 int up_bwd_x4(int storage, const void* dS, int B, int H, int W, void* const* tx, hipStream_t stream);
+// upbwd_mfma.hip: the same pass for bf16 rows with W % 64 == 0 as one small GEMM per row strip (interpolation matrix x dS)
+bool up_bwd_x4_mfma_ok(int B, int H, int W);
+int launch_up_bwd_x4_mfma(const void* dS, int64_t rows, int W, void* const* tx, hipStream_t stream);
 // mean / rstd / partial / nblk_out given (bf16 storage): the kernel also takes pass 1 of the normalisation backward of the level's
 // second convolution on the dA it forms; *nblk_out = slots per sample left in `partial` (0: not fused, run the pass as usual)
 int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, const void* dP, const void* y,

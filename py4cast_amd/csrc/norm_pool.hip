@@ -980,6 +980,9 @@ template <typename T>
 static int up_bwd_x4_t(const T* dS, int B, int H, int W, void* const* tx, hipStream_t stream) {
     UpBwdOut<T> o;
     for (int k = 0; k < 4; ++k) o.tx[k] = (T*)tx[k];
+    // bf16 rows in whole 64-pixel strips: the banded interpolation matrix on the matrix cores (upbwd_mfma.hip)
+    if (std::is_same<T, __bf16>::value && up_bwd_x4_mfma_ok(B, H, W) && diag_env("P4C_UPBWD_VALU") == nullptr)
+        return launch_up_bwd_x4_mfma((const void*)dS, (int64_t)B * H, W, tx, stream);
     hipLaunchKernelGGL(up_bwd_x4_kernel<T>, dim3(B * H * ((W + 63) / 64)), dim3(256), 0, stream, dS, H, W, o);
     P4C_CHECK_LAUNCH("up_bwd_x4");
     return P4C_OK;
