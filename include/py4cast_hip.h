@@ -536,6 +536,15 @@ int p4c_row_layernorm_fwd(const void* x, const void* res, const float* gamma, co
 size_t p4c_row_layernorm_bwd_workspace_bytes(int64_t R, int C, int dtype);
 int p4c_row_layernorm_bwd(const void* dy, const void* x, const float* gamma, float eps, void* dx, float* dgamma, float* dbeta,
                           void* workspace, int64_t R, int C, int dtype, p4c_stream_t stream);
+/* The same two passes on rows that are the tokens of (B, Hp, Wp) maps of which only [0,H) x [0,W) are real -- Swin pads every map to
+ * a multiple of its window (MONAI SwinTransformerBlock.forward: `F.pad(norm1(x), ...)` ... `x[:, :h, :w, :]`; the class reaches py4cast
+ * through mfai, py4cast/models.py:10-20, and runs under py4cast/lightning.py:591-596).  A stage kept in the PADDED layout needs
+ * `F.pad(norm1(x))` only: out rows of padding tokens are ZERO whatever x holds there; their dy is ignored (dx = 0, no contribution to
+ * dgamma / dbeta).  R must be a multiple of Hp * Wp; Hp = Wp = 0 (or H = Hp, W = Wp): no mask. */
+int p4c_row_layernorm_fwd_masked(const void* x, const void* res, const float* gamma, const float* beta, float eps, void* out, int64_t R,
+                                 int C, int dtype, int Hp, int Wp, int H, int W, p4c_stream_t stream);
+int p4c_row_layernorm_bwd_masked(const void* dy, const void* x, const float* gamma, float eps, void* dx, float* dgamma, float* dbeta,
+                                 void* workspace, int64_t R, int C, int dtype, int Hp, int Wp, int H, int W, p4c_stream_t stream);
 /* (x + add) -> LayerNorm on rows of up to 2 KiB (UNETR++'s token rows with their positional embedding, 128 ... 1024 features):
  * t[r] = x[r] + add[r % add_rows] (add may be NULL: t = x), sum_out[r] = t[r] (optional), out[r] = LayerNorm(t[r]) * gamma + beta.
  * Backward: dt = LN_backward(dy; t) + extra (extra, optional: the gradient reaching t from its other consumers), dgamma / dbeta as

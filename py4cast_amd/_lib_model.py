@@ -69,6 +69,8 @@ SIGNATURES = {
     "p4c_segment_sum_pair": [P, P, P, P, L, P, P, P, L, L, I, I, P],
     "p4c_row_layernorm_fwd": [P, P, P, P, F, P, L, I, I, P],
     "p4c_row_layernorm_bwd": [P, P, P, F, P, P, P, P, L, I, I, P],
+    "p4c_row_layernorm_fwd_masked": [P, P, P, P, F, P, L, I, I, I, I, I, I, P],
+    "p4c_row_layernorm_bwd_masked": [P, P, P, F, P, P, P, P, L, I, I, I, I, I, I, P],
     "p4c_row_linear_wgrad": [P, P, P, P, L, I, I, I, P],
     "p4c_row_gemm": [P, L, P, I, I, P, P, L, L, I, I, P, L, I, P, L, P],
     "p4c_row_gemm_wgrad": [P, L, P, L, P, P, L, I, I, I, P],

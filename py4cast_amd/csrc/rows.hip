@@ -59,11 +59,23 @@ __device__ __forceinline__ float row_sum(float v, int lpr) {
     return v;
 }
 
+// rows = tokens of (B, Hp, Wp) maps of which only [0,H) x [0,W) are real (Swin pads its maps to multiples of the window): Hp = 0 -> no mask
+struct RowMask {
+    int Hp, Wp, H, W;
+    __device__ __forceinline__ bool masked(int64_t r) const {
+        if (Hp == 0) return false;
+        const unsigned rem = (unsigned)(r % ((int64_t)Hp * Wp));
+        const unsigned y = rem / (unsigned)Wp, x = rem - y * (unsigned)Wp;
+        return y >= (unsigned)H || x >= (unsigned)W;
+    }
+};
+
 // ---------------------------------------------------------------- LayerNorm forward: out = LN(x) * gamma + beta (+ res)
 template <typename T>
 __global__ void __launch_bounds__(256)
     row_layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gamma,
-                             const float* __restrict__ beta, float eps, T* __restrict__ out, int64_t R, int C, int lpr_log2) {
+                             const float* __restrict__ beta, float eps, T* __restrict__ out, int64_t R, int C, int lpr_log2,
+                             RowMask mk) {
     constexpr int NV = Vec16<T>::N;
     const int lane = threadIdx.x & 63, lpr = 1 << lpr_log2, rpw = 64 >> lpr_log2;
     const int chunk = lane & (lpr - 1), sub = lane >> lpr_log2;
@@ -107,8 +119,9 @@ __global__ void __launch_bounds__(256)
                 q += f[i] * f[i];
             }
             const float rstd = rsqrtf(row_sum(q, lpr) * inv_c + eps);
+            const bool pad = mk.masked(r0 + u * rpw + sub);   // a padding token: the row is ZERO (F.pad of the normalised map)
 #pragma unroll
-            for (int i = 0; i < NV; ++i) f[i] = f[i] * rstd * g[i] + b[i] + fr[i];
+            for (int i = 0; i < NV; ++i) f[i] = pad ? 0.f : f[i] * rstd * g[i] + b[i] + fr[i];
             if (ok[u]) reinterpret_cast<u32x4*>(out)[(r0 + u * rpw + sub) * chunks + chunk] = Vec16<T>::pack(f);
         }
     }
@@ -120,7 +133,7 @@ __global__ void __launch_bounds__(256)
 template <typename T>
 __global__ void __launch_bounds__(256)
     row_layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma, float eps,
-                             T* __restrict__ dx, float* __restrict__ partial, int64_t R, int C, int lpr_log2) {
+                             T* __restrict__ dx, float* __restrict__ partial, int64_t R, int C, int lpr_log2, RowMask mk) {
     constexpr int NV = Vec16<T>::N;
     const int lane = threadIdx.x & 63, lpr = 1 << lpr_log2, rpw = 64 >> lpr_log2;
     const int chunk = lane & (lpr - 1), sub = lane >> lpr_log2;
@@ -145,7 +158,7 @@ __global__ void __launch_bounds__(256)
             vx[u] = vd[u] = u32x4{0, 0, 0, 0};
             if (ok[u]) {
                 vx[u] = reinterpret_cast<const u32x4*>(x)[r * chunks + chunk];
-                vd[u] = reinterpret_cast<const u32x4*>(dy)[r * chunks + chunk];
+                if (!mk.masked(r)) vd[u] = reinterpret_cast<const u32x4*>(dy)[r * chunks + chunk];   // (padding token: no gradient)
             }
         }
 #pragma unroll
@@ -566,22 +579,38 @@ int launch_wgrad(const void* dy, const void* x, float* partial, int64_t R, int G
 
 using namespace p4c;
 
-extern "C" int p4c_row_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, float eps, void* out,
-                                     int64_t R, int C, int dtype, p4c_stream_t stream) {
+static int check_mask(const char* who, int64_t R, int Hp, int Wp, int H, int W, RowMask* mk) {
+    *mk = RowMask{0, 0, 0, 0};
+    if (Hp == 0 && Wp == 0) return P4C_OK;
+    P4C_CHECK_ARG(Hp > 0 && Wp > 0 && H > 0 && W > 0 && H <= Hp && W <= Wp && R % ((int64_t)Hp * Wp) == 0,
+                  "%s: rows (%lld) must be whole (Hp %d, Wp %d) maps holding the real (H %d, W %d) one", who, (long long)R, Hp, Wp, H, W);
+    if (H < Hp || W < Wp) *mk = RowMask{Hp, Wp, H, W};
+    return P4C_OK;
+}
+
+extern "C" int p4c_row_layernorm_fwd_masked(const void* x, const void* res, const float* gamma, const float* beta, float eps, void* out,
+                                            int64_t R, int C, int dtype, int Hp, int Wp, int H, int W, p4c_stream_t stream) {
     int lpr_log2;
     int rc = check_rows("p4c_row_layernorm_fwd", R, C, dtype, &lpr_log2);
     if (rc != P4C_OK) return rc;
     P4C_CHECK_ARG(x && gamma && beta && out, "p4c_row_layernorm_fwd: NULL pointer");
+    RowMask mk;
+    P4C_TRY(check_mask("p4c_row_layernorm_fwd_masked", R, Hp, Wp, H, W, &mk));
     if (R == 0) return P4C_OK;
     const int G = ln_grid(R, 64 >> lpr_log2);
     if (dtype == P4C_F32)
         hipLaunchKernelGGL(row_layernorm_fwd_kernel<float>, dim3(G), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)res,
-                           gamma, beta, eps, (float*)out, R, C, lpr_log2);
+                           gamma, beta, eps, (float*)out, R, C, lpr_log2, mk);
     else
         hipLaunchKernelGGL(row_layernorm_fwd_kernel<bf16>, dim3(G), dim3(256), 0, as_stream(stream), (const bf16*)x, (const bf16*)res,
-                           gamma, beta, eps, (bf16*)out, R, C, lpr_log2);
+                           gamma, beta, eps, (bf16*)out, R, C, lpr_log2, mk);
     P4C_CHECK_LAUNCH("row_layernorm_fwd");
     return P4C_OK;
+}
+
+extern "C" int p4c_row_layernorm_fwd(const void* x, const void* res, const float* gamma, const float* beta, float eps, void* out,
+                                     int64_t R, int C, int dtype, p4c_stream_t stream) {
+    return p4c_row_layernorm_fwd_masked(x, res, gamma, beta, eps, out, R, C, dtype, 0, 0, 0, 0, stream);
 }
 
 extern "C" size_t p4c_row_layernorm_bwd_workspace_bytes(int64_t R, int C, int dtype) {
@@ -591,13 +620,16 @@ extern "C" size_t p4c_row_layernorm_bwd_workspace_bytes(int64_t R, int C, int dt
     return (size_t)ln_grid(R, 64 >> lpr_log2) * 2 * C * sizeof(float);
 }
 
-extern "C" int p4c_row_layernorm_bwd(const void* dy, const void* x, const float* gamma, float eps, void* dx, float* dgamma,
-                                     float* dbeta, void* workspace, int64_t R, int C, int dtype, p4c_stream_t stream) {
+extern "C" int p4c_row_layernorm_bwd_masked(const void* dy, const void* x, const float* gamma, float eps, void* dx, float* dgamma,
+                                            float* dbeta, void* workspace, int64_t R, int C, int dtype, int Hp, int Wp, int H, int W,
+                                            p4c_stream_t stream) {
     int lpr_log2;
     int rc = check_rows("p4c_row_layernorm_bwd", R, C, dtype, &lpr_log2);
     if (rc != P4C_OK) return rc;
     P4C_CHECK_ARG(dy && x && gamma && dx && dgamma && dbeta && workspace, "p4c_row_layernorm_bwd: NULL pointer");
     P4C_CHECK_ARG(dbeta == dgamma + C, "p4c_row_layernorm_bwd: dbeta must follow dgamma (one (2,C) buffer)");
+    RowMask mk;
+    P4C_TRY(check_mask("p4c_row_layernorm_bwd_masked", R, Hp, Wp, H, W, &mk));
     hipStream_t s = as_stream(stream);
     if (R == 0) {
         P4C_CHECK_HIP(zero_words_async(dgamma, 2 * C * sizeof(float), s));   // (not a memset: common.hpp)
@@ -607,14 +639,19 @@ extern "C" int p4c_row_layernorm_bwd(const void* dy, const void* x, const float*
     float* partial = reinterpret_cast<float*>(workspace);
     if (dtype == P4C_F32)
         hipLaunchKernelGGL(row_layernorm_bwd_kernel<float>, dim3(G), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, eps,
-                           (float*)dx, partial, R, C, lpr_log2);
+                           (float*)dx, partial, R, C, lpr_log2, mk);
     else
         hipLaunchKernelGGL(row_layernorm_bwd_kernel<bf16>, dim3(G), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, eps,
-                           (bf16*)dx, partial, R, C, lpr_log2);
+                           (bf16*)dx, partial, R, C, lpr_log2, mk);
     P4C_CHECK_LAUNCH("row_layernorm_bwd");
     hipLaunchKernelGGL(row_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, partial, G, 2 * C, dgamma);
     P4C_CHECK_LAUNCH("row_param_reduce");
     return P4C_OK;
+}
+
+extern "C" int p4c_row_layernorm_bwd(const void* dy, const void* x, const float* gamma, float eps, void* dx, float* dgamma,
+                                     float* dbeta, void* workspace, int64_t R, int C, int dtype, p4c_stream_t stream) {
+    return p4c_row_layernorm_bwd_masked(dy, x, gamma, eps, dx, dgamma, dbeta, workspace, R, C, dtype, 0, 0, 0, 0, stream);
 }
 
 static int add_ln_grid(int64_t R) {

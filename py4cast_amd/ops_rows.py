@@ -17,20 +17,21 @@ from . import _lib as L
 
 class _LayerNormRes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps: float):
+    def forward(ctx, x, res, gamma, beta, eps: float, mask=None):
         L.require_cuda(x)
         x = x.contiguous()
         R, C = x.shape
+        mk = (0, 0, 0, 0) if mask is None else tuple(int(v) for v in mask)   # (Hp, Wp, H, W): rows of padding tokens -> zero
         if res is not None:
             res = res.contiguous()
             if res.dtype != x.dtype or res.shape != x.shape:
                 raise L.P4CError("row_layer_norm: residual must match x in shape and dtype")
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         out = torch.empty_like(x)
-        L.call("p4c_row_layernorm_fwd", L.ptr(x), L.ptr(res), L.ptr(g), L.ptr(b), float(eps), L.ptr(out), R, C,
-               L.dtype_code(x.dtype), L.stream(x.device), alg_bytes=R * C * x.element_size() * (2 + (res is not None)))
+        L.call("p4c_row_layernorm_fwd_masked", L.ptr(x), L.ptr(res), L.ptr(g), L.ptr(b), float(eps), L.ptr(out), R, C,
+               L.dtype_code(x.dtype), *mk, L.stream(x.device), alg_bytes=R * C * x.element_size() * (2 + (res is not None)))
         ctx.save_for_backward(x, g)
-        ctx.eps, ctx.has_res, ctx.pdtype = float(eps), res is not None, gamma.dtype
+        ctx.eps, ctx.has_res, ctx.pdtype, ctx.mk = float(eps), res is not None, gamma.dtype, mk
         return out
 
     @staticmethod
@@ -42,15 +43,16 @@ class _LayerNormRes(torch.autograd.Function):
         dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
         nbytes = L.lib().p4c_row_layernorm_bwd_workspace_bytes(R, C, L.dtype_code(x.dtype))
         ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
-        L.call("p4c_row_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(g), ctx.eps, L.ptr(dx), L.ptr(dgb), L.ptr(dgb[1]), L.ptr(ws), R, C,
-               L.dtype_code(x.dtype), L.stream(x.device), alg_bytes=3 * R * C * x.element_size())
-        return dx, (dy if ctx.has_res else None), dgb[0].to(ctx.pdtype), dgb[1].to(ctx.pdtype), None
+        L.call("p4c_row_layernorm_bwd_masked", L.ptr(dy), L.ptr(x), L.ptr(g), ctx.eps, L.ptr(dx), L.ptr(dgb), L.ptr(dgb[1]), L.ptr(ws), R, C,
+               L.dtype_code(x.dtype), *ctx.mk, L.stream(x.device), alg_bytes=3 * R * C * x.element_size())
+        return dx, (dy if ctx.has_res else None), dgb[0].to(ctx.pdtype), dgb[1].to(ctx.pdtype), None, None
 
 
 def row_layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
-                   res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``LayerNorm(x) * gamma + beta (+ res)`` on rows: x (R, C)."""
-    return _LayerNormRes.apply(x, res, gamma, beta, eps)
+                   res: Optional[torch.Tensor] = None, mask=None) -> torch.Tensor:
+    """``LayerNorm(x) * gamma + beta (+ res)`` on rows: x (R, C).  mask = (Hp, Wp, H, W): the rows are the tokens of (B, Hp, Wp) maps
+    whose real extent is (H, W) -- rows of padding tokens come out ZERO and take no gradient (Swin's `F.pad(norm1(x))`)."""
+    return _LayerNormRes.apply(x, res, gamma, beta, eps, mask)
 
 
 def _native_wgrad_ok(x: torch.Tensor, O: int, K: int) -> bool:

@@ -71,11 +71,20 @@ def relative_position_index(ws: int) -> torch.Tensor:
     return rel.sum(-1)
 
 
-def _layer_norm(m: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+def _row_ln_ok(x: torch.Tensor) -> bool:
+    C = x.shape[-1]
+    return (C * x.element_size()) % 16 == 0 and C * x.element_size() <= 1024
+
+
+def _layer_norm(m: nn.LayerNorm, x: torch.Tensor, real=None) -> torch.Tensor:
+    """real = (H, W): x is a PADDED map (B,Hp,Wp,C) whose tokens beyond (H, W) are padding -- their rows come out zero"""
     C = x.shape[-1]
     L.require_cuda(x)   # the model has no CPU path (rows beyond the kernel's limits use the GPU library's LayerNorm)
-    if (C * x.element_size()) % 16 == 0 and C * x.element_size() <= 1024:
-        return R.row_layer_norm(x.reshape(-1, C), m.weight, m.bias, m.eps).view(x.shape)
+    if _row_ln_ok(x):
+        mask = None if real is None else (x.shape[1], x.shape[2], real[0], real[1])
+        return R.row_layer_norm(x.reshape(-1, C), m.weight, m.bias, m.eps, mask=mask).view(x.shape)
+    if real is not None:
+        raise L.P4CError("SwinUNetRMI355X: a padded stage needs the native row LayerNorm")
     return F.layer_norm(x.float(), m.normalized_shape, m.weight, m.bias, m.eps).to(x.dtype)
 
 
@@ -153,12 +162,18 @@ class SwinBlock(nn.Module):
         self.fc1 = nn.Linear(dim, int(dim * mlp_ratio))
         self.fc2 = nn.Linear(int(dim * mlp_ratio), dim)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, real=None) -> torch.Tensor:
+        """real = (H, W): x arrives PADDED to multiples of the window (B,Hp,Wp,C) and stays so (`padded_stage`): MONAI's per-block
+        `F.pad(norm1(x))` ... `x[:, :h, :w]` becomes a LayerNorm that writes zero rows for the padding tokens -- everything after it is
+        row-wise or the attention itself, so the real tokens see exactly the same numbers and the padding rows of the residual stream
+        (never read by a real token: norm1 masks them again) carry no gradient."""
         B, H, W, C = x.shape
         ws = self.ws
+        if real is not None:
+            H, W = real
         shift = self.shift if min(H, W) > ws else 0
-        h = _layer_norm(self.norm1, x)
-        pb, pr = (-H) % ws, (-W) % ws
+        h = _layer_norm(self.norm1, x, real)
+        pb, pr = (0, 0) if real is not None else ((-H) % ws, (-W) % ws)
         if pb or pr:
             h = F.pad(h, (0, 0, 0, pr, 0, pb))
         N = ws * ws
@@ -170,6 +185,23 @@ class SwinBlock(nn.Module):
         else:
             x = _lin(a, self.proj.weight, self.proj.bias, res=x)       # the residual in the projection's epilogue
         return _mlp(self.fc1, self.fc2, _layer_norm(self.norm2, x), x)
+
+
+def padded_stage(blocks, t: torch.Tensor) -> torch.Tensor:
+    """The blocks of one Swin stage.  A map that is not a multiple of the window (512 x 512 input, window 7: 256, 128, 64, 32 -> 259, 133,
+    70, 35) is padded ONCE for the stage instead of once per block (and cropped once: a view, the patch merging gathers from it):
+    per block that was a fill + a copy forward, a slice + an add, and their zero fill / copy / add backward -- 1.3 ms of the 25 ms step."""
+    B, H, W, C = t.shape
+    ws = blocks[0].ws
+    pb, pr = (-H) % ws, (-W) % ws
+    if not (pb or pr) or not (t.is_cuda and _row_ln_ok(t)) or os.environ.get("P4C_SWIN_PAD_PER_BLOCK") == "1":
+        for blk in blocks:
+            t = blk(t)
+        return t
+    t = F.pad(t, (0, 0, 0, pr, 0, pb))
+    for blk in blocks:
+        t = blk(t, real=(H, W))
+    return t[:, :H, :W, :]
 
 
 class PatchMerging(nn.Module):
@@ -334,8 +366,7 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         t = R.linear_nd(patches, pw.reshape(pw.shape[0], 4 * Cp), self.patch_embed.bias)
         hidden = [self._hidden(t, dt)]
         for blocks, merge in zip(self.stages, self.merges):
-            for blk in blocks:
-                t = blk(t)
+            t = padded_stage(blocks, t)
             t = merge(t)
             hidden.append(self._hidden(t, dt))
         enc0 = self.encoder1(xin)

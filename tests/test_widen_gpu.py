@@ -1551,3 +1551,58 @@ def test_compact_channel_convolution_equals_the_padded_route(gpu_device, shape, 
         assert _rel(res["compact"][0].float().permute(0, 3, 1, 2).cpu(), ref.detach().cpu()) < 8e-3
         assert _rel(res["compact"][1].float().permute(0, 3, 1, 2).cpu(), x64.grad.cpu()) < 8e-3
         assert _rel(res["compact"][2].cpu(), w64.grad.cpu()) < 2e-3
+
+
+def test_masked_row_layer_norm_is_pad_of_layer_norm(gpu_device):
+    """p4c_row_layernorm_*_masked: LayerNorm over the tokens of padded (B,Hp,Wp) maps = F.pad(LayerNorm(real tokens)) forward; backward
+    the padding rows take no gradient and give none to gamma / beta (MONAI SwinTransformerBlock: F.pad(norm1(x)) per block)."""
+    from py4cast_amd.ops_rows import row_layer_norm
+
+    B, Hp, Wp, H, W, C = 2, 14, 21, 11, 17, 48
+    torch.manual_seed(3)
+    for dt in (torch.float32, torch.bfloat16):
+        xp = torch.randn(B, Hp, Wp, C).to(dt)
+        g, b = torch.randn(C), torch.randn(C)
+        dy = torch.randn(B, Hp, Wp, C).to(dt)
+        xg = xp.to(gpu_device).requires_grad_(True)
+        gg, bg = g.to(gpu_device).requires_grad_(True), b.to(gpu_device).requires_grad_(True)
+        y = row_layer_norm(xg.reshape(-1, C), gg, bg, 1e-5, mask=(Hp, Wp, H, W)).view(B, Hp, Wp, C)
+        y.backward(dy.to(gpu_device))
+        xr = xp.double().requires_grad_(True)
+        gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+        yr = torch.nn.functional.pad(torch.nn.functional.layer_norm(xr[:, :H, :W], (C,), gr, br, 1e-5), (0, 0, 0, Wp - W, 0, Hp - H))
+        yr.backward(dy.double())
+        tol = 1e-5 if dt == torch.float32 else 1e-2
+        assert float(y[:, H:].abs().max()) == 0.0 and float(y[:, :, W:].abs().max()) == 0.0
+        assert _rel(y.detach().float().cpu(), yr.detach()) < tol
+        assert float(xg.grad[:, H:].abs().max()) == 0.0 and float(xg.grad[:, :, W:].abs().max()) == 0.0
+        assert _rel(xg.grad.float().cpu(), xr.grad) < tol
+        assert _rel(gg.grad.cpu(), gr.grad) < (1e-5 if dt == torch.float32 else 2e-3)
+        assert _rel(bg.grad.cpu(), br.grad) < (1e-5 if dt == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_swin_stage_padded_once_equals_padding_every_block(gpu_device, monkeypatch, dtype):
+    """swinunetr.padded_stage (round 5): the stage kept in the padded layout against MONAI's per-block pad / crop order
+    (P4C_SWIN_PAD_PER_BLOCK=1) -- same forward and gradients up to the rounding of the residual add (fp32: 1e-6 level)."""
+    H, W, cin, cout = 64, 96, 9, 4      # 32 x 48 tokens, window 7: every stage pads
+    model, _ = _swin_pair(cin, cout, (H, W), dtype=dtype)
+    model = model.to(gpu_device)
+    torch.manual_seed(53)
+    x, gy = torch.randn(2, H, W, cin, device=gpu_device), torch.randn(2, H, W, cout, device=gpu_device)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = model(xg)
+        y.backward(gy)
+        return y.detach().float(), xg.grad.float(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+
+    y1, dx1, g1 = run()
+    monkeypatch.setenv("P4C_SWIN_PAD_PER_BLOCK", "1")
+    y0, dx0, g0 = run()
+    tol = 2e-5 if dtype == "f32" else 3e-2
+    assert _rel(y1, y0) < tol, _rel(y1, y0)
+    assert _rel(dx1, dx0) < (2e-4 if dtype == "f32" else 0.15), _rel(dx1, dx0)   # (bf16: LeakyReLU / max decisions flip on rounding noise)
+    cos = [float(torch.dot(g1[n].flatten(), g0[n].flatten()) / (g1[n].norm() * g0[n].norm()).clamp_min(1e-30)) for n in g0]
+    assert min(cos) > (0.99999 if dtype == "f32" else 0.995), min(cos)

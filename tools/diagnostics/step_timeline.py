@@ -1,13 +1,20 @@
 """Critical-path view of ONE optimizer step from a rocprofv3 rocpd database: per stream (queue) busy time, gaps between
 consecutive kernels of the main stream, time where only the side stream runs.
-usage: python tools/diagnostics/step_timeline.py <results.db> [out.csv]"""
+usage: python tools/diagnostics/step_timeline.py <results.db> [out.csv] [name of the step's last kernel]"""
 import sqlite3, sys, collections, re
 
 con = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in con.execute("pragma table_info(kernels)").fetchall()]
 qcol = next((c for c in ("queue_id", "stream_id", "queue", "stream") if c in cols), None)
 ks = con.execute(f"select name, start, end, {qcol or 0} from kernels order by start").fetchall()
-marks = [i for i, k in enumerate(ks) if "adamw_kernel" in k[0]]
+marker = sys.argv[3] if len(sys.argv) > 3 else "adamw_kernel"   # the LAST kernel of a step (one launch per step)
+marks = [i for i, k in enumerate(ks) if marker in k[0]]
+if len(marks) < 2:
+    cnt = collections.Counter(k[0] for k in ks)
+    print("marker %r: %d launches; candidates (kernels launched a few times):" % (marker, len(marks)))
+    for n, c in sorted(cnt.items(), key=lambda kv: kv[1])[:30]:
+        print("   %5d  %s" % (c, n[:150]))
+    sys.exit(1)
 lo, hi = marks[-2] + 1, marks[-1] + 1
 step = ks[lo:hi]
 t0 = step[0][1]
