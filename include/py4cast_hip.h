@@ -741,6 +741,18 @@ int p4c_inorm_finalize_bwd(const float* partial, int nblk, int B, int64_t N, int
  * (out, in) or a 1x1 convolution: fwd[co][tap][ci] = w[co][ci][tap] (forward), dgrad[ci][tap'][co] = w[co][ci][taps-1-tap'] (data
  * gradient: the same kernel on the transposed, tap-flipped image).  Either output may be NULL. */
 int p4c_gemm_prep_weight(const float* w, int CO, int CI, int taps, void* fwd, void* dgrad, p4c_stream_t stream);
+/* The same with a per-output-channel scale folded in: images of rowscale[co] * w[co] (fp32 product, one bf16 rounding) and, with a bias,
+ * bias_out[co] = rowscale[co] * bias[co] (fp32).  UNETR++'s transformer block `t + gamma * epa(norm(t))` (layer scale gamma, the class comes
+ * through mfai: py4cast/models.py:10-20, config/CLI/model/unetrpp.yaml:19-35): gamma rides in the output projections' weights, so the
+ * projection's epilogue writes t + gamma * (...) directly.  rowscale NULL = p4c_gemm_prep_weight; bias / bias_out NULL together. */
+int p4c_gemm_prep_weight_scaled(const float* w, const float* rowscale, const float* bias, float* bias_out, int CO, int CI, int taps,
+                                void* fwd, void* dgrad, p4c_stream_t stream);
+/* Backward bookkeeping of such a layer (z = x W^T + b, y = gamma (.) z) from the RAW gradients of p4c_gemm_tn on the unscaled dy
+ * (dw_raw (CO,K) = dy^T x, db_raw (CO) = column sums of dy):  dw = gamma (.) dw_raw,  db = gamma (.) db_raw,
+ * dgamma[c] = <dw_raw[c,:], w[c,:]> + b[c] db_raw[c]  (= sum_r dy[r,c] z[r,c], without z).  accumulate != 0: ADD into dw / db / dgamma
+ * (the parameters' gradient buffers).  b, db_raw, db NULL together.  Fixed-order sums. */
+int p4c_gemm_scale_fold_bwd(const float* dw_raw, const float* db_raw, const float* w, const float* b, const float* gamma, int CO, int K,
+                            float* dw, float* db, float* dgamma, int accumulate, p4c_stream_t stream);
 /* C (M, N) bf16 = epilogue(A x Bimg^T), Bimg (N, K) bf16 with K contiguous (p4c_gemm_prep_weight), fp32 accumulation.
  * taps = 1: A = (M, K) bf16 rows, row stride lda.  taps = 9: A = an NHWC map (batch, H, W, Cin), M = batch * H * W pixels, pixel
  * stride lda >= Cin, K = 9 * Cin: the 3x3 "same" convolution with zero padding (no im2col buffer).

@@ -376,7 +376,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 }
 
 // every recorded job in one launch: block -> (job, block of that job) through the prefix table in the kernel arguments; each job
-// is summed exactly as its own wgrad_reduce_kernel<16> launch would (same slices, same order: bitwise the same gradient)
+// is summed exactly as a wgrad_reduce_kernel<16> launch of its own would (same slices, same order).  The standalone wgrad_reduce
+// below takes the <4> form for short jobs with many slots (pairs < 256, nslots >= 64: the 1x1 output convolution fed by
+// out_conv_bwd's partials) -- 64 slot slices instead of 16, another order of the same fp32 sum: that one gradient is NOT bitwise
+// the same between the batched plan and P4C_WGRAD_BATCH=0 / p4c_out_conv_bwd on its own (both fixed orders, both deterministic)
 struct WgradBatchArgs {
     WgradReduceJob job[WGRAD_BATCH_MAX];
     int first[WGRAD_BATCH_MAX + 1];

@@ -627,16 +627,23 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
 // ------------------------------------------------------------------------------------------------ weight images
 // fwd[co][tap][ci] = w[co][ci][tap] and dgrad[ci][tap'][co] = w[co][ci][taps - 1 - tap'] as bf16, from the fp32 master in the torch
 // layout [CO][CI][taps]; one workgroup per 32 x 32 (co, ci) block, through LDS so that reads and writes are row pieces.
+// rowscale (CO floats or NULL): the images hold rowscale[co] * w[co] (fp32 product, one rounding) -- a per-output-channel scale of the
+// layer (UNETR++'s layer scale gamma) folded into its weight; bias_out[co] = rowscale[co] * bias[co] comes with it (block (0, y)).
 __global__ void __launch_bounds__(256) gemm_prep_kernel(const float* __restrict__ w, int CO, int CI, int taps, bf16* __restrict__ fwd,
-                                                        bf16* __restrict__ dgrad) {
+                                                        bf16* __restrict__ dgrad, const float* __restrict__ rowscale,
+                                                        const float* __restrict__ bias, float* __restrict__ bias_out) {
     extern __shared__ float tilew[];          // [32 co][32 ci * taps + 1]
     const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
     const int rowlen = 32 * taps, ld = rowlen + 1;
     for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {
         const int c = idx / rowlen, e = idx - c * rowlen;            // e = ci_local * taps + tap
         const int ci = ci0 + e / taps;
-        tilew[c * ld + e] = (co0 + c < CO && ci < CI) ? w[((int64_t)(co0 + c) * CI + ci0) * taps + e] : 0.f;
+        float v = (co0 + c < CO && ci < CI) ? w[((int64_t)(co0 + c) * CI + ci0) * taps + e] : 0.f;
+        if (rowscale && co0 + c < CO) v *= rowscale[co0 + c];
+        tilew[c * ld + e] = v;
     }
+    if (bias_out && blockIdx.x == 0 && threadIdx.x < 32 && co0 + threadIdx.x < CO)
+        bias_out[co0 + threadIdx.x] = (rowscale ? rowscale[co0 + threadIdx.x] : 1.f) * bias[co0 + threadIdx.x];
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {
         {   // fwd: (co, tap, ci) with ci fastest
@@ -707,13 +714,63 @@ int pick_splits(int tiles, int nblocks) {
 using namespace p4c;
 using namespace p4c::gemm;
 
-extern "C" int p4c_gemm_prep_weight(const float* w, int CO, int CI, int taps, void* fwd, void* dgrad, p4c_stream_t stream) {
+extern "C" int p4c_gemm_prep_weight_scaled(const float* w, const float* rowscale, const float* bias, float* bias_out, int CO, int CI,
+                                           int taps, void* fwd, void* dgrad, p4c_stream_t stream) {
     P4C_CHECK_ARG(w && (fwd || dgrad), "p4c_gemm_prep_weight: NULL pointer");
     P4C_CHECK_ARG(CO > 0 && CI > 0 && (taps == 1 || taps == 9), "p4c_gemm_prep_weight: CO, CI > 0, taps 1 or 9");
+    P4C_CHECK_ARG((bias == nullptr) == (bias_out == nullptr), "p4c_gemm_prep_weight_scaled: bias and bias_out come together");
     const int smem = 32 * (32 * taps + 1) * 4;
     hipLaunchKernelGGL(gemm_prep_kernel, dim3((CI + 31) / 32, (CO + 31) / 32), dim3(256), smem, as_stream(stream), w, CO, CI, taps, (bf16*)fwd,
-                       (bf16*)dgrad);
+                       (bf16*)dgrad, rowscale, bias, bias_out);
     P4C_CHECK_LAUNCH("gemm_prep");
+    return P4C_OK;
+}
+
+extern "C" int p4c_gemm_prep_weight(const float* w, int CO, int CI, int taps, void* fwd, void* dgrad, p4c_stream_t stream) {
+    return p4c_gemm_prep_weight_scaled(w, nullptr, nullptr, nullptr, CO, CI, taps, fwd, dgrad, stream);
+}
+
+// Backward of a layer whose weight and bias were scaled per output channel (z = x W^T + b, y = gamma (.) z): from the RAW gradients
+// dW_raw = dy^T x and db_raw = sum dy (p4c_gemm_tn on the unscaled dy):
+//   dW = gamma (.) dW_raw,   db = gamma (.) db_raw,   dgamma[c] = <dW_raw[c,:], W[c,:]> + b[c] db_raw[c]     (= sum_r dy[r,c] z[r,c])
+// one workgroup per output channel, fixed-order sums; accumulate: add into dw / db / dgamma (the parameters' .grad) instead of writing.
+namespace p4c { namespace gemm {
+__global__ void __launch_bounds__(256) scale_fold_bwd_kernel(const float* __restrict__ dw_raw, const float* __restrict__ db_raw,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             const float* __restrict__ gamma, int K, float* __restrict__ dw,
+                                                             float* __restrict__ db, float* __restrict__ dgamma, int accumulate) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const float g = gamma[c];
+    float dot = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float r = dw_raw[(int64_t)c * K + k];
+        dot += r * w[(int64_t)c * K + k];
+        const float v = g * r;
+        dw[(int64_t)c * K + k] = accumulate ? dw[(int64_t)c * K + k] + v : v;
+    }
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = (red[0] + red[1]) + (red[2] + red[3]);
+        const float dbr = db_raw ? db_raw[c] : 0.f;
+        if (b) t += b[c] * dbr;
+        dgamma[c] = accumulate ? dgamma[c] + t : t;
+        if (db) db[c] = accumulate ? db[c] + g * dbr : g * dbr;
+    }
+}
+}}  // namespace p4c::gemm
+
+extern "C" int p4c_gemm_scale_fold_bwd(const float* dw_raw, const float* db_raw, const float* w, const float* b, const float* gamma, int CO,
+                                       int K, float* dw, float* db, float* dgamma, int accumulate, p4c_stream_t stream) {
+    P4C_CHECK_ARG(dw_raw && w && gamma && dw && dgamma, "p4c_gemm_scale_fold_bwd: NULL pointer");
+    P4C_CHECK_ARG((b == nullptr) == (db_raw == nullptr) && (b == nullptr) == (db == nullptr),
+                  "p4c_gemm_scale_fold_bwd: b, db_raw and db come together");
+    P4C_CHECK_ARG(CO > 0 && K > 0, "p4c_gemm_scale_fold_bwd: CO, K > 0");
+    hipLaunchKernelGGL(p4c::gemm::scale_fold_bwd_kernel, dim3(CO), dim3(256), 0, as_stream(stream), dw_raw, db_raw, w, b, gamma, K, dw, db,
+                       dgamma, accumulate);
+    P4C_CHECK_LAUNCH("gemm_scale_fold_bwd");
     return P4C_OK;
 }
 

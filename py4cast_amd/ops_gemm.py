@@ -51,6 +51,32 @@ def weight_images(w: torch.Tensor, taps: int) -> Tuple[torch.Tensor, torch.Tenso
     return fwd, dgr
 
 
+def scaled_images(w: torch.Tensor, b: Optional[torch.Tensor], g: torch.Tensor):
+    """(forward image, data-gradient image, g * b or None) of the layer ``g (.) (x W^T + b)`` -- a per-output-channel scale (UNETR++'s
+    layer scale) folded into the weight images by the preparation kernel; cached like weight_images on the versions of w, b and g."""
+    L.require_cuda(w)
+    if w.dtype != torch.float32 or g.dtype != torch.float32 or (b is not None and b.dtype != torch.float32):
+        raise L.P4CError("scaled_images: fp32 master parameters expected")
+    wd, gd = w.detach().contiguous(), g.detach().contiguous()
+    bd = None if b is None else b.detach().contiguous()
+    CO, CI = wd.shape
+    key = ("wimg_scaled", w.data_ptr(), tuple(w.shape), tuple(w.stride()), g.data_ptr(), None if b is None else b.data_ptr())
+    ver = (L.PARAM_EPOCH[0], w._version, g._version, None if b is None else b._version)
+    owners = (w, g) if b is None else (w, g, b)
+    cache = _WIMG if not torch.cuda.is_current_stream_capturing() else L.capture_cache()
+    if cache is not None:
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver and L.owners_alive(hit[2], owners):
+            return hit[1]
+    fwd = torch.empty(CO, CI, dtype=torch.bfloat16, device=w.device)
+    dgr = torch.empty(CI, CO, dtype=torch.bfloat16, device=w.device)
+    beff = None if b is None else torch.empty(CO, dtype=torch.float32, device=w.device)
+    L.call("p4c_gemm_prep_weight_scaled", L.ptr(wd), L.ptr(gd), L.ptr(bd), L.ptr(beff), CO, CI, 1, L.ptr(fwd), L.ptr(dgr), L.stream(w.device))
+    if cache is not None:
+        cache[key] = (ver, (fwd, dgr, beff), L.owner_refs(owners))
+    return fwd, dgr, beff
+
+
 def _rows(t: torch.Tensor, C: int) -> torch.Tensor:
     """(..., C) -> (R, C) rows with unit stride inside a row, a row stride that is a multiple of 8 and a 16-byte aligned base"""
     t2 = t.reshape(-1, C)
@@ -169,45 +195,81 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, r
 
 
 class _CatLinearRes(torch.autograd.Function):
-    """res + cat(xa Wa^T + ba, xb Wb^T + bb) along the features: two GEMMs whose epilogues write the two column halves of ONE output
-    tensor (row stride = the full width) and add the matching halves of the residual"""
+    """res + gamma (.) cat(xa Wa^T + ba, xb Wb^T + bb) along the features (gamma optional): two GEMMs whose epilogues write the two
+    column halves of ONE output tensor (row stride = the full width) and add the matching halves of the residual.  gamma rides in the
+    weight images and the bias (scaled_images: prepared once per step, not once per AR step); backward takes the RAW weight / bias
+    gradients of the unscaled dy and one small launch per half turns them into dW, db and dgamma (p4c_gemm_scale_fold_bwd) -- as
+    separate autograd nodes the four products gamma * W, gamma * b cost 4 launches forward and ~16 backward per block and AR step."""
 
     @staticmethod
-    def forward(ctx, xa, wa, ba, xb, wb, bb, res):
+    def forward(ctx, xa, wa, ba, xb, wb, bb, res, gamma):
         Oa, Ka = wa.shape
         Ob, Kb = wb.shape
         xa2, xb2 = _rows(xa.detach(), Ka), _rows(xb.detach(), Kb)
         r2 = _rows(res.detach(), Oa + Ob)
-        fa, da = weight_images(wa, 1)
-        fb, db_ = weight_images(wb, 1)
+        if gamma is None:
+            fa, da = weight_images(wa, 1)
+            fb, db_ = weight_images(wb, 1)
+            bea, beb = _f32(ba), _f32(bb)
+        else:
+            fa, da, bea = scaled_images(wa, ba, gamma[:Oa])
+            fb, db_, beb = scaled_images(wb, bb, gamma[Oa:])
         y = torch.empty(xa2.shape[0], Oa + Ob, dtype=torch.bfloat16, device=xa.device)
-        gemm_nt(xa2, fa, Oa, Ka, bias=_f32(ba), res=r2[:, :Oa], out=y[:, :Oa])
-        gemm_nt(xb2, fb, Ob, Kb, bias=_f32(bb), res=r2[:, Oa:], out=y[:, Oa:])
-        ctx.save_for_backward(xa2, xb2, da, db_)
+        gemm_nt(xa2, fa, Oa, Ka, bias=bea, res=r2[:, :Oa], out=y[:, :Oa])
+        gemm_nt(xb2, fb, Ob, Kb, bias=beb, res=r2[:, Oa:], out=y[:, Oa:])
         ctx.meta = (xa.shape, xb.shape, Oa, Ka, Ob, Kb, wa.dtype, ba.dtype, wb.dtype, bb.dtype)
         ctx.sinks = (_sink(wa, ba), _sink(wb, bb))
+        ctx.scaled = gamma is not None
+        if ctx.scaled:
+            from .ops_rows import grad_view
+
+            gg = grad_view(gamma) if (GRADS_IN_PLACE and gamma.requires_grad) else False
+            ctx.gsink = gg if (gg is not None and gg is not False and gg.is_contiguous()) else None
+            ctx.save_for_backward(xa2, xb2, da, db_, wa.detach(), ba.detach(), wb.detach(), bb.detach(), gamma.detach())
+        else:
+            ctx.save_for_backward(xa2, xb2, da, db_)
         return y.view(*res.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        xa2, xb2, da, db_ = ctx.saved_tensors
         sa, sb, Oa, Ka, Ob, Kb, wadt, badt, wbdt, bbdt = ctx.meta
         dy2 = _rows(dy, Oa + Ob)
         dya, dyb = dy2[:, :Oa], dy2[:, Oa:]
-        dxa = gemm_nt(dya, da, Ka, Oa)[0].view(sa)
-        dxb = gemm_nt(dyb, db_, Kb, Ob)[0].view(sb)
-        dwa, dba = gemm_tn(dya, xa2, Oa, Ka, want_bias=True, sink=ctx.sinks[0])
-        dwb, dbb = gemm_tn(dyb, xb2, Ob, Kb, want_bias=True, sink=ctx.sinks[1])
         cast = lambda t, dt: None if t is None else t.to(dt)      # noqa: E731
-        return dxa, cast(dwa, wadt), cast(dba, badt), dxb, cast(dwb, wbdt), cast(dbb, bbdt), dy
+        if not ctx.scaled:
+            xa2, xb2, da, db_ = ctx.saved_tensors
+            dxa = gemm_nt(dya, da, Ka, Oa)[0].view(sa)
+            dxb = gemm_nt(dyb, db_, Kb, Ob)[0].view(sb)
+            dwa, dba = gemm_tn(dya, xa2, Oa, Ka, want_bias=True, sink=ctx.sinks[0])
+            dwb, dbb = gemm_tn(dyb, xb2, Ob, Kb, want_bias=True, sink=ctx.sinks[1])
+            return dxa, cast(dwa, wadt), cast(dba, badt), dxb, cast(dwb, wbdt), cast(dbb, bbdt), dy, None
+        xa2, xb2, da, db_, wa, ba, wb, bb, gamma = ctx.saved_tensors
+        dxa = gemm_nt(dya, da, Ka, Oa)[0].view(sa)          # (the images carry gamma: dx = (gamma (.) dy) W)
+        dxb = gemm_nt(dyb, db_, Kb, Ob)[0].view(sb)
+        in_place = ctx.sinks[0] is not None and ctx.sinks[1] is not None and ctx.gsink is not None
+        dgamma = ctx.gsink if in_place else torch.empty(Oa + Ob, dtype=torch.float32, device=dy.device)
+        outs = []
+        for dyh, xh, w, b, O, K, sink, g, dg in ((dya, xa2, wa, ba, Oa, Ka, ctx.sinks[0], gamma[:Oa], dgamma[:Oa]),
+                                                  (dyb, xb2, wb, bb, Ob, Kb, ctx.sinks[1], gamma[Oa:], dgamma[Oa:])):
+            dw_raw, db_raw = gemm_tn(dyh, xh, O, K, want_bias=True)
+            dw, db = sink if in_place else (torch.empty_like(dw_raw), torch.empty_like(db_raw))
+            L.call("p4c_gemm_scale_fold_bwd", L.ptr(dw_raw), L.ptr(db_raw), L.ptr(_f32(w)), L.ptr(_f32(b)), L.ptr(_f32(g)), O, K, L.ptr(dw), L.ptr(db),
+                   L.ptr(dg), int(in_place), L.stream(dy.device), alg_bytes=4 * O * K * (3 + in_place))
+            outs.append((None, None) if in_place else (dw, db))
+        (dwa, dba), (dwb, dbb) = outs
+        return (dxa, cast(dwa, wadt), cast(dba, badt), dxb, cast(dwb, wbdt), cast(dbb, bbdt), dy,
+                None if in_place else dgamma.to(gamma.dtype))
 
 
-def cat_linear_res(xa, wa, ba, xb, wb, bb, res) -> torch.Tensor:
-    """``res + torch.cat([F.linear(xa, wa, ba), F.linear(xb, wb, bb)], -1)`` as one autograd node (bf16 rows, fp32 parameters)"""
+def cat_linear_res(xa, wa, ba, xb, wb, bb, res, gamma=None) -> torch.Tensor:
+    """``res + gamma * torch.cat([F.linear(xa, wa, ba), F.linear(xb, wb, bb)], -1)`` (gamma: a vector over the features or None) as one
+    autograd node (bf16 rows, fp32 parameters)"""
     L.require_cuda(xa)
     if not (supported(xa, wa) and supported(xb, wb)) or (wa.shape[0] % 8) or (wb.shape[0] % 8):
         raise L.P4CError("ops_gemm.cat_linear_res: unsupported operands")
-    return _CatLinearRes.apply(xa, wa, ba, xb, wb, bb, res)
+    if gamma is not None and (ba is None or bb is None or gamma.dtype != torch.float32 or gamma.numel() != wa.shape[0] + wb.shape[0]):
+        raise L.P4CError("ops_gemm.cat_linear_res: gamma needs fp32 parameters with biases and one entry per output feature")
+    return _CatLinearRes.apply(xa, wa, ba, xb, wb, bb, res, gamma)
 
 
 class _MLP(torch.autograd.Function):

@@ -268,9 +268,12 @@ class EPA(nn.Module):
             y = torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)
             return y if res is None else res + R.param_as(gamma, y.dtype) * y
         h = self.out_proj.weight.shape[0]
-        g1, g2 = gamma[:h], gamma[h:]
-        return G.cat_linear_res(x_sa, g1.unsqueeze(1) * self.out_proj.weight, g1 * self.out_proj.bias,
-                                x_ca, g2.unsqueeze(1) * self.out_proj2.weight, g2 * self.out_proj2.bias, res)
+        if os.environ.get("P4C_UNETRPP_GAMMA_MUL") == "1":      # the round's first form: gamma * W, gamma * b as torch products
+            g1, g2 = gamma[:h], gamma[h:]
+            return G.cat_linear_res(x_sa, g1.unsqueeze(1) * self.out_proj.weight, g1 * self.out_proj.bias,
+                                    x_ca, g2.unsqueeze(1) * self.out_proj2.weight, g2 * self.out_proj2.bias, res)
+        return G.cat_linear_res(x_sa, self.out_proj.weight, self.out_proj.bias, x_ca, self.out_proj2.weight, self.out_proj2.bias, res,
+                                gamma=gamma)
 
     def forward(self, x, res=None, gamma=None):
         """res / gamma given: returns res + gamma * EPA(x) (the transformer block's residual update)"""

@@ -387,3 +387,51 @@ def test_row_gemm_mlp_node_vs_float64(gpu_device, R, K, Hd):
     b = rnd((K,), dev, 98)
     z = RW.linear_res(x.detach(), w, b, x.detach())
     close_bf16(z, x.detach().double() @ w.bfloat16().double().t() + b.double() + x.detach().double(), "linear_res")
+
+
+@pytest.mark.parametrize("R,K,O", [(1000, 128, 64), (512, 1024, 512), (4096, 256, 128)])
+def test_cat_linear_with_layer_scale_vs_float64(gpu_device, R, K, O):
+    """res + gamma * cat(xa Wa^T + ba, xb Wb^T + bb) (UNETR++'s `t + gamma * epa(...)`): gamma folded into the weight images by the
+    preparation kernel, dW / db / dgamma from the raw gradients by p4c_gemm_scale_fold_bwd.  Against float64 on the same bf16 rows,
+    through autograd (no gradient buffers) and in place (buffers exist: everything is ADDED, nothing returned)."""
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    xa, xb = rnd((R, K), dev, 91).bfloat16(), rnd((R, K), dev, 92).bfloat16()
+    res, dy = rnd((R, 2 * O), dev, 93).bfloat16(), rnd((R, 2 * O), dev, 94).bfloat16()
+    P = lambda t: torch.nn.Parameter(t)   # noqa: E731
+    wa, wb = P(rnd((O, K), dev, 95) / K ** 0.5), P(rnd((O, K), dev, 96) / K ** 0.5)
+    ba, bb, gamma = P(rnd((O,), dev, 97)), P(rnd((O,), dev, 98)), P(rnd((2 * O,), dev, 99))
+    xag, xbg, resg = (t.clone().requires_grad_(True) for t in (xa, xb, res))
+    y = G.cat_linear_res(xag, wa, ba, xbg, wb, bb, resg, gamma=gamma)
+    y.backward(dy)
+    # float64 reference with the operands the kernels see: bf16 rows, bf16(gamma * W) images, fp32 gamma * b
+    d = lambda t: t.detach().double()   # noqa: E731
+    xar, xbr, rr = (d(t).requires_grad_(True) for t in (xa, xb, res))
+    war, wbr, bar, bbr, gr = (d(t).requires_grad_(True) for t in (wa, wb, ba, bb, gamma))
+    z = torch.cat([F.linear(xar, war, bar), F.linear(xbr, wbr, bbr)], dim=-1)
+    yr = rr + gr * z
+    yr.backward(d(dy))
+    close_bf16(y, yr, "y")
+    close_bf16(xag.grad, xar.grad, "dxa")
+    close_bf16(xbg.grad, xbr.grad, "dxb")
+    assert torch.equal(resg.grad, dy)
+    for got, ref, what in ((wa.grad, war.grad, "dWa"), (wb.grad, wbr.grad, "dWb"), (ba.grad, bar.grad, "dba"), (bb.grad, bbr.grad, "dbb"),
+                           (gamma.grad, gr.grad, "dgamma")):
+        # (the forward rounds gamma * W to bf16 for the images -- the gradients use the fp32 masters: 5e-4 like every weight gradient here;
+        # dgamma sums products with z = x W^T of the UNROUNDED weight: same bar)
+        assert rel(got, ref) <= 5e-4, (what, rel(got, ref))
+    # second pass: the buffers exist -> added in place, bit-identical increments
+    first = [p.grad.clone() for p in (wa, wb, ba, bb, gamma)]
+    G.cat_linear_res(xa, wa, ba, xb, wb, bb, res, gamma=gamma).backward(dy)
+    for p, f in zip((wa, wb, ba, bb, gamma), first):
+        assert torch.allclose(p.grad, 2 * f, rtol=0, atol=2e-6 * float(f.abs().max()))
+    # and the same numbers as the torch-product form it replaces (gamma * W, gamma * b as autograd nodes)
+    for p in (wa, wb, ba, bb, gamma):
+        p.grad = None
+    h = O
+    y2 = G.cat_linear_res(xa, gamma[:h].unsqueeze(1) * wa, gamma[:h] * ba, xb, gamma[h:].unsqueeze(1) * wb, gamma[h:] * bb, res)
+    assert torch.equal(y2, y.detach())
+    y2.backward(dy)
+    for p, f, what in zip((wa, wb, ba, bb, gamma), first, ("dWa", "dWb", "dba", "dbb", "dgamma")):
+        assert rel(p.grad, f) <= 1e-5, (what, rel(p.grad, f))

@@ -1581,28 +1581,39 @@ def test_masked_row_layer_norm_is_pad_of_layer_norm(gpu_device):
         assert _rel(bg.grad.cpu(), br.grad) < (1e-5 if dt == torch.float32 else 2e-3)
 
 
+def _swin_grads(gpu_device, dtype, x, gy, shape, cin, cout):
+    model, _ = _swin_pair(cin, cout, shape, dtype=dtype)     # (seeded: the same weights for every flavour)
+    model = model.to(gpu_device)
+    xg = x.clone().requires_grad_(True)
+    y = model(xg)
+    y.backward(gy)
+    return y.detach().float(), xg.grad.float(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_swin_stage_padded_once_equals_padding_every_block(gpu_device, monkeypatch, dtype):
     """swinunetr.padded_stage (round 5): the stage kept in the padded layout against MONAI's per-block pad / crop order
-    (P4C_SWIN_PAD_PER_BLOCK=1) -- same forward and gradients up to the rounding of the residual add (fp32: 1e-6 level)."""
+    (P4C_SWIN_PAD_PER_BLOCK=1).  fp32 flavour: the same forward and gradients to the 1e-5 level (another order of a few fp32 sums).
+    bf16 flavour: the two orders round the residual add differently (epilogue of the projection against a separate bf16 add), and on
+    this random network bf16 noise alone moves parameter gradients by cosines of 0.95-0.99 -- so both are measured against the fp32
+    flavour of the same weights: the padded stage must be as close to it as the per-block order is."""
     H, W, cin, cout = 64, 96, 9, 4      # 32 x 48 tokens, window 7: every stage pads
-    model, _ = _swin_pair(cin, cout, (H, W), dtype=dtype)
-    model = model.to(gpu_device)
     torch.manual_seed(53)
     x, gy = torch.randn(2, H, W, cin, device=gpu_device), torch.randn(2, H, W, cout, device=gpu_device)
-
-    def run():
-        model.zero_grad(set_to_none=True)
-        xg = x.clone().requires_grad_(True)
-        y = model(xg)
-        y.backward(gy)
-        return y.detach().float(), xg.grad.float(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
-
-    y1, dx1, g1 = run()
+    cosines = lambda g, ref: [float(torch.dot(g[n].flatten(), ref[n].flatten()) / (g[n].norm() * ref[n].norm()).clamp_min(1e-30)) for n in ref]  # noqa: E731
+    y1, dx1, g1 = _swin_grads(gpu_device, dtype, x, gy, (H, W), cin, cout)
     monkeypatch.setenv("P4C_SWIN_PAD_PER_BLOCK", "1")
-    y0, dx0, g0 = run()
-    tol = 2e-5 if dtype == "f32" else 3e-2
-    assert _rel(y1, y0) < tol, _rel(y1, y0)
-    assert _rel(dx1, dx0) < (2e-4 if dtype == "f32" else 0.15), _rel(dx1, dx0)   # (bf16: LeakyReLU / max decisions flip on rounding noise)
-    cos = [float(torch.dot(g1[n].flatten(), g0[n].flatten()) / (g1[n].norm() * g0[n].norm()).clamp_min(1e-30)) for n in g0]
-    assert min(cos) > (0.99999 if dtype == "f32" else 0.995), min(cos)
+    y0, dx0, g0 = _swin_grads(gpu_device, dtype, x, gy, (H, W), cin, cout)
+    if dtype == "f32":
+        assert _rel(y1, y0) < 2e-5, _rel(y1, y0)
+        assert _rel(dx1, dx0) < 2e-4, _rel(dx1, dx0)
+        assert min(cosines(g1, g0)) > 0.99999
+        return
+    monkeypatch.delenv("P4C_SWIN_PAD_PER_BLOCK")
+    yr, dxr, gr = _swin_grads(gpu_device, "f32", x, gy, (H, W), cin, cout)
+    print("bf16 vs fp32 flavour: forward padded / per block", _rel(y1, yr), _rel(y0, yr), "dx", _rel(dx1, dxr), _rel(dx0, dxr))
+    assert _rel(y1, yr) < 1.25 * _rel(y0, yr) + 1e-3
+    assert _rel(dx1, dxr) < 1.25 * _rel(dx0, dxr) + 1e-3
+    c1, c0 = cosines(g1, gr), cosines(g0, gr)
+    print("worst / mean parameter-gradient cosine against the fp32 flavour: padded", min(c1), sum(c1) / len(c1), "per block", min(c0), sum(c0) / len(c0))
+    assert min(c1) > min(c0) - 0.03 and sum(c1) / len(c1) > sum(c0) / len(c0) - 0.005
