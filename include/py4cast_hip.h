@@ -667,6 +667,14 @@ int p4c_ts_apply_wide_ok(int x_dtype, int out_dtype, int d, int e);
 int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, void* out,
                  int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int accumulate,
                  p4c_stream_t stream);
+/* The same product with M given TRANSPOSED in memory (m_t: per group an (e x d) row-major matrix, M[k][c] = m_t[c * d + k]) -- the
+ * adjoint applies of an EPA block multiply with At^T, Mq^T, dG^T, VP^T; matrix-core kernel only: p4c_ts_apply_mt_ok says whether the
+ * operands meet its alignment / width conditions (otherwise transpose and call p4c_ts_apply). */
+int p4c_ts_apply_mt_ok(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, const void* out,
+                       int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int d, int e);
+int p4c_ts_apply_mt(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m_t, int64_t m_gs, void* out,
+                    int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int accumulate,
+                    p4c_stream_t stream);
 /* apply with a fused epilogue over each token's output row (bf16 in / out, matrix-core form: d, e multiples of 8, d <= 256, e <= 64):
  *   epi = 1: out = softmax_row(X M)                                        -- S = softmax(q Mq) without the logits reaching memory
  *   epi = 2: out = S * (X M - rowsum(X M * S)), S (B, heads, N, e) bf16     -- the softmax backward of the products X M = dS

@@ -80,6 +80,8 @@ OTHER = {
     "p4c_ts_gram_wide_ok": ([I, I, I, I], c_int),
     "p4c_ts_apply_softmax": ([P, L, L, L, P, L, P, L, L, L, I, I, L, I, I, I, P, L, L, L, P], c_int),
     "p4c_ts_apply": ([P, I, L, L, L, P, L, P, I, L, L, L, I, I, L, I, I, I, P], c_int),
+    "p4c_ts_apply_mt": ([P, I, L, L, L, P, L, P, I, L, L, L, I, I, L, I, I, I, P], c_int),
+    "p4c_ts_apply_mt_ok": ([P, I, L, L, L, P, L, P, I, L, L, L, I, I], c_int),
     "p4c_epa_small_fwd": ([P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P], c_int),
     "p4c_epa_small_bwd": ([P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P], c_int),
     "p4c_ts_gram_norms": ([P, I, L, L, L, P, I, L, L, L, P, I, I, L, I, I, P], c_int),

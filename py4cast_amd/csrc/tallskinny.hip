@@ -204,7 +204,9 @@ typedef unsigned int ts_u32x2 __attribute__((ext_vector_type(2)));
 // S (dS - sum_j dS_j S_j) with S read in the accumulator layout -- the spatial branch of EPA without the N x p softmax passes.
 template <typename TO, int KC, int EPI = 0>
 __global__ void __launch_bounds__(256) apply_mfma_kernel(Mat X, const float* __restrict__ M, int64_t m_bs, int64_t m_hs, MatOut O, int heads,
-                                                         int64_t N, int d, int e, int accumulate, int hw, Mat S) {
+                                                         int64_t N, int d, int e, int accumulate, int hw, Mat S, int mt) {
+    // mt: M is given TRANSPOSED in memory ((e x d) row-major per group: element (k, c) at c * d + k) -- the adjoint applies of a block
+    // multiply with At^T, Mq^T, dG^T, VP^T; reading them as stored saves the small strided copy each one cost
     extern __shared__ __attribute__((aligned(16))) unsigned short lmt[];          // hw x 64 x ldm bf16: M^T of the heads served
     constexpr int DP = KC * 16, LDM = DP + 8;
     const int b = blockIdx.x, ncp = (e + 63) >> 6;
@@ -218,7 +220,13 @@ __global__ void __launch_bounds__(256) apply_mfma_kernel(Mat X, const float* __r
     for (int i = threadIdx.x; i < hw * DP * cqa; i += 256) {
         const int c4 = (i % cqa) << 2, r = i / cqa, k = r % DP, hh = r / DP;
         p4c_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (hh < nh && k < d && (c4 >> 2) < cq) v = load4f(M + b * m_bs + (int64_t)(h0 + hh) * m_hs + (int64_t)k * e + c0 + c4);
+        if (hh < nh && k < d && (c4 >> 2) < cq) {
+            const float* mg = M + b * m_bs + (int64_t)(h0 + hh) * m_hs;
+            if (!mt) v = load4f(mg + (int64_t)k * e + c0 + c4);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (c0 + c4 + j < e) ? mg[(int64_t)(c0 + c4 + j) * d + k] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const __bf16 t = (__bf16)v[j];
@@ -638,7 +646,7 @@ extern "C" int p4c_ts_apply_wide_ok(int x_dtype, int out_dtype, int d, int e) {
 
 template <typename TO, int EPI = 0>
 static void launch_apply_mfma(const ts::Mat& X, const float* m, int64_t m_bs, int64_t m_hs, const ts::MatOut& O, int B, int heads, int64_t N,
-                              int d, int e, int accumulate, hipStream_t st, const ts::Mat& S = ts::Mat{nullptr, 0, 0, 0}) {
+                              int d, int e, int accumulate, hipStream_t st, const ts::Mat& S = ts::Mat{nullptr, 0, 0, 0}, int mt = 0) {
     const int kc = d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : d <= 128 ? 8 : 16;
     int hw = heads >= 4 ? 4 : heads >= 2 ? 2 : 1;
     while (hw > 1 && hw * 64 * (kc * 16 + 8) * 2 > 65536) hw >>= 1;      // M^T of the heads a workgroup serves: <= 64 KB of LDS
@@ -650,7 +658,7 @@ static void launch_apply_mfma(const ts::Mat& X, const float* m, int64_t m_bs, in
     const int64_t cap = (int64_t)num_cus() * wgs_per_cu / ((int64_t)B * zc) + 1;     // several tiles per wave: M^T is staged once per workgroup
     if (ny > cap) ny = cap;
     const dim3 grid(B, (unsigned)ny, zc);
-#define P4C_APPLY_M(KC) hipLaunchKernelGGL((ts::apply_mfma_kernel<TO, KC, EPI>), grid, dim3(256), lds, st, X, m, m_bs, m_hs, O, heads, N, d, e, accumulate, hw, S)
+#define P4C_APPLY_M(KC) hipLaunchKernelGGL((ts::apply_mfma_kernel<TO, KC, EPI>), grid, dim3(256), lds, st, X, m, m_bs, m_hs, O, heads, N, d, e, accumulate, hw, S, mt)
     switch (kc) {
         case 1: P4C_APPLY_M(1); break;
         case 2: P4C_APPLY_M(2); break;
@@ -661,14 +669,40 @@ static void launch_apply_mfma(const ts::Mat& X, const float* m, int64_t m_bs, in
 #undef P4C_APPLY_M
 }
 
+static bool apply_mfma_route(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, const void* out,
+                             int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int d, int e) {
+    return p4c_ts_apply_wide_ok(x_dtype, out_dtype, d, e) && x_bs % 8 == 0 && x_hs % 8 == 0 && x_rs % 8 == 0 && o_bs % 8 == 0 && o_hs % 8 == 0 &&
+           o_rs % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(m) & 15) == 0 && m_gs % 4 == 0;
+}
+
+extern "C" int p4c_ts_apply_mt_ok(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs,
+                                  const void* out, int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int d, int e) {
+    return apply_mfma_route(x, x_dtype, x_bs, x_hs, x_rs, m, m_gs, out, out_dtype, o_bs, o_hs, o_rs, d, e) ? 1 : 0;
+}
+
+extern "C" int p4c_ts_apply_mt(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m_t, int64_t m_gs,
+                               void* out, int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e,
+                               int accumulate, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && m_t && out, "p4c_ts_apply_mt: null pointer");
+    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0, "p4c_ts_apply_mt: empty problem");
+    if (!apply_mfma_route(x, x_dtype, x_bs, x_hs, x_rs, m_t, m_gs, out, out_dtype, o_bs, o_hs, o_rs, d, e))
+        return fail(P4C_ERR_UNSUPPORTED, "p4c_ts_apply_mt: operands off the matrix-core kernel's conditions (p4c_ts_apply_mt_ok)");
+    const ts::Mat Xm{x, x_bs, x_hs, x_rs};
+    const ts::MatOut Om{out, o_bs, o_hs, o_rs};
+    const ts::Mat none{nullptr, 0, 0, 0};
+    if (out_dtype == P4C_BF16) launch_apply_mfma<bf16>(Xm, m_t, m_gs * heads, m_gs, Om, B, heads, N, d, e, accumulate, as_stream(stream), none, 1);
+    else launch_apply_mfma<float>(Xm, m_t, m_gs * heads, m_gs, Om, B, heads, N, d, e, accumulate, as_stream(stream), none, 1);
+    P4C_CHECK_LAUNCH("p4c_ts_apply_mt");
+    return P4C_OK;
+}
+
 extern "C" int p4c_ts_apply(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs,
                             void* out, int out_dtype, int64_t o_bs, int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e,
                             int accumulate, p4c_stream_t stream) {
     P4C_CHECK_ARG(x && m && out, "p4c_ts_apply: null pointer");
     P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0, "p4c_ts_apply: empty problem");
-    if (p4c_ts_apply_wide_ok(x_dtype, out_dtype, d, e) && x_bs % 8 == 0 && x_hs % 8 == 0 && x_rs % 8 == 0 && o_bs % 8 == 0 && o_hs % 8 == 0 &&
-        o_rs % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(m) & 15) == 0 && m_gs % 4 == 0) {
+    if (apply_mfma_route(x, x_dtype, x_bs, x_hs, x_rs, m, m_gs, out, out_dtype, o_bs, o_hs, o_rs, d, e)) {
         const ts::Mat Xm{x, x_bs, x_hs, x_rs};
         const ts::MatOut Om{out, o_bs, o_hs, o_rs};
         if (out_dtype == P4C_BF16) launch_apply_mfma<bf16>(Xm, m, m_gs * heads, m_gs, Om, B, heads, N, d, e, accumulate, as_stream(stream));

@@ -55,6 +55,29 @@ def _wide(x, out_view, d, e) -> bool:
     return al(x) and al(out_view)
 
 
+def _stored_transposed(m: torch.Tensor):
+    """m (B,H,d,e) fp32 that is the transposed VIEW of a contiguous (B,H,e,d) tensor -> that tensor, else None"""
+    if m.dtype == torch.float32 and m.dim() == 4 and not m.is_contiguous() and m.shape[-1] > 1 and m.shape[-2] > 1:
+        t = m.transpose(-1, -2)
+        if t.is_contiguous():
+            return t
+    return None
+
+
+def _apply_call(x, m, ov, B, H, N, d, e, accumulate):
+    """out (+)= x @ m on the matrix-core kernel; a transposed view of a stored matrix is read as stored (p4c_ts_apply_mt), anything
+    else is made contiguous first"""
+    args_x = (L.ptr(x), L.dtype_code(x.dtype), *_strides(x))
+    args_o = (L.ptr(ov), L.dtype_code(ov.dtype), *_strides(ov))
+    nbytes = B * H * N * (d * x.element_size() + e * ov.element_size() * (1 + int(accumulate)))
+    mt = _stored_transposed(m)
+    if mt is not None and L.lib().p4c_ts_apply_mt_ok(*args_x, L.ptr(mt), d * e, *args_o, d, e):
+        L.call("p4c_ts_apply_mt", *args_x, L.ptr(mt), d * e, *args_o, B, H, N, d, e, int(accumulate), L.stream(x.device), alg_bytes=nbytes)
+        return
+    m = m.float().contiguous()
+    L.call("p4c_ts_apply", *args_x, L.ptr(m), d * e, *args_o, B, H, N, d, e, int(accumulate), L.stream(x.device), alg_bytes=nbytes)
+
+
 def _apply_raw(x: torch.Tensor, m: torch.Tensor, dtype) -> torch.Tensor:
     """x (B,H,N,d) @ m (B,H,d,e) fp32 -> (B,H,N,e) view of a fresh (B,N,H,e) tensor (i.e. laid out as (B, N, H*e) tokens)."""
     B, H, N, d = x.shape
@@ -63,9 +86,7 @@ def _apply_raw(x: torch.Tensor, m: torch.Tensor, dtype) -> torch.Tensor:
     ov = out.permute(0, 2, 1, 3)
     m = m.float()
     if _wide(x, ov, d, e):      # matrix-core kernel: any width in one launch
-        m = m.contiguous()
-        L.call("p4c_ts_apply", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(m), d * e, L.ptr(ov), L.dtype_code(dtype), *_strides(ov),
-               B, H, N, d, e, 0, L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * out.element_size()))
+        _apply_call(x, m, ov, B, H, N, d, e, False)
         return ov
     for j0, j1 in _chunks(e):
         oj = ov[..., j0:j1]
@@ -123,10 +144,7 @@ def _apply_into(out_view, x, m, accumulate):
     """out_view (B,H,N,e) (+)= x (B,H,N,d) @ m (B,H,d,e): p4c_ts_apply into an existing token-major buffer (d, e <= 64)."""
     B, H, N, d = x.shape
     e = m.shape[-1]
-    m = m.float().contiguous()
-    L.call("p4c_ts_apply", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(m), d * e, L.ptr(out_view), L.dtype_code(out_view.dtype),
-           *_strides(out_view), B, H, N, d, e, int(accumulate), L.stream(x.device),
-           alg_bytes=B * H * N * (d * x.element_size() + e * out_view.element_size() * (1 + int(accumulate))))
+    _apply_call(x, m.float(), out_view, B, H, N, d, e, accumulate)
 
 
 class _GramNorms(torch.autograd.Function):

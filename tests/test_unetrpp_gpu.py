@@ -76,6 +76,14 @@ def test_apply_on_matrix_cores(gpu_device, B, H, N, d, e, out_dtype):
     err2 = float((out.double() - ref2).abs().max()) / scale
     assert err2 < (1e-5 if out_dtype == torch.float32 else 4e-3), err2
     assert torch.equal(full[:, N:], guard)       # stores are masked by token
+    # the small matrix stored TRANSPOSED (p4c_ts_apply_mt: read as stored, no strided copy): bit-identical to the copy route
+    mt = m.transpose(-1, -2).contiguous()                                       # (B,H,e,d) in memory
+    assert TS._stored_transposed(mt.transpose(-1, -2)).data_ptr() == mt.data_ptr() and TS._stored_transposed(m) is None
+    O2 = TS._apply_raw(x, mt.transpose(-1, -2), out_dtype)
+    assert torch.equal(O2, O)
+    out2 = base.clone().permute(0, 2, 1, 3)
+    TS._apply_into(out2, x, mt.transpose(-1, -2), True)
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.gpu
