@@ -9,14 +9,6 @@ cd $R
 O=gpurun_out/r05; mkdir -p $O
 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $O/gpu_tests.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
-python3 bench.py > $O/halfunet_bf16_bench_default.json 2> $O/bench_default.err
-python3 bench.py --grid 512 640 --features 21 --forcings 21 --border 10 --no-cpu-baseline > $O/titan_shape_bench.json 2> $O/bench_titan.err
-python3 bench.py --steps 500 --warmup 20 --no-cpu-baseline --no-fp32-flavour --no-larger-batch --no-native-share > $O/halfunet_bf16_bench_500_steps.json 2>/dev/null
-rocprofv3 --kernel-trace --stats -d $O/raw -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-flavour --no-larger-batch --no-native-share --hip-graph off > $O/halfunet_bf16_bench_under_rocprof.json 2> $O/trace.err
-db=$(find $O/raw -name "*.db" | head -1)
-python3 tools/diagnostics/rocpd_stats.py $db $O/halfunet_bf16_kernel_stats.csv $O/halfunet_bf16_one_step_trace.csv
-python3 tools/diagnostics/step_timeline.py $db $O/timeline.csv > $O/halfunet_bf16_step_timeline.txt 2>&1
-rm -rf $O/raw $O/timeline.csv
 # PMC: the roofline kernel alone (conv_exp.py), the whole step, the new implicit-GEMM convolution
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   n=$(echo $c | tr ' ' '_')
@@ -38,6 +30,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/diagnostics/pmc_step_sum.py gpurun_out/r05pmcstep $O/pmc_traffic_step.json > $O/pmc_step.log 2>&1
 rm -rf gpurun_out/r05pmcstep
+# the traffic files of THIS tree go where bench.py looks them up (profiles/, keyed on the kernel sources' hash) before the bench lines run
+for f in pmc_traffic pmc_traffic_gemm_nt pmc_traffic_gemm_tn pmc_traffic_step; do [ -s $O/$f.json ] && cp $O/$f.json profiles/r05_$f.json; done
+python3 bench.py > $O/halfunet_bf16_bench_default.json 2> $O/bench_default.err
+python3 bench.py --grid 512 640 --features 21 --forcings 21 --border 10 --no-cpu-baseline > $O/titan_shape_bench.json 2> $O/bench_titan.err
+python3 bench.py --steps 500 --warmup 20 --no-cpu-baseline --no-fp32-flavour --no-larger-batch --no-native-share > $O/halfunet_bf16_bench_500_steps.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/raw -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-flavour --no-larger-batch --no-native-share --hip-graph off > $O/halfunet_bf16_bench_under_rocprof.json 2> $O/trace.err
+db=$(find $O/raw -name "*.db" | head -1)
+python3 tools/diagnostics/rocpd_stats.py $db $O/halfunet_bf16_kernel_stats.csv $O/halfunet_bf16_one_step_trace.csv
+python3 tools/diagnostics/step_timeline.py $db $O/timeline.csv > $O/halfunet_bf16_step_timeline.txt 2>&1
+rm -rf $O/raw $O/timeline.csv
 # the widened models
 python3 bench.py --model SwinUNetR --cpu-seconds 5 > $O/swinunetr_bf16_bench.json 2>/dev/null
 python3 bench.py --model UNetRPP --strategy diff_ar --pred-steps 6 --steps 5 --warmup 2 --cpu-seconds 5 > $O/unetrpp_bf16_bench.json 2>/dev/null
