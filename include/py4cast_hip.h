@@ -429,8 +429,10 @@ int p4c_set_side_stream(p4c_stream_t side, void* const* events, int n_events);
 int p4c_side_stream_defer(int on);
 /* on = 0: the weight gradients run on the caller's stream like everything else (a host that cannot keep two streams fed; the
  * single-stream HIP-graph capture); on = 1: beside the backward chain again.  Between steps only (nothing in flight on the side
- * stream). */
+ * stream).  PROCESS-wide (round 6): the setting reaches p4c_halfunet_backward on whichever host thread runs it (autograd's device
+ * thread, not the caller's).  p4c_side_stream_launch_count: weight-gradient launches this process has issued to a side stream. */
 int p4c_side_stream_enable(int on);
+long long p4c_side_stream_launch_count(void);
 int p4c_side_stream_join(p4c_stream_t stream);
 /* Rewrite a captured, not yet instantiated HIP graph (hipGraph_t): every 1-D memset node becomes a kernel node filling the same bytes
  * with the same dependencies.  On this stack memset nodes replay a wrong byte value from the second launch on, which breaks library
@@ -642,6 +644,31 @@ typedef struct p4c_row_mlp_grad_sinks {
     float* dbeta;
 } p4c_row_mlp_grad_sinks;
 int p4c_row_mlp_bwd_accumulate(const p4c_row_mlp_desc* d, const p4c_row_mlp_grad_sinks* sinks, void* workspace, p4c_stream_t stream);
+
+/* Mesh-GNN launch grouping (round 6; csrc/nodeproj.hip).  An InteractionNet of GraphLAM / HiLAM (config/CLI/model/graphlam.yaml:19-26,
+ * hilam.yaml, hilamparallel.yaml; classes taken at py4cast/models.py:66-89) multiplies a node tensor x (R, 64) bf16 with up to three
+ * 64 x 64 blocks of wider fp32 Linear weights (the sender / receiver parts of the distributed edge-MLP first layer and the receiver part
+ * of the node-update MLP's): W_i[o][k] = w[i][o * ldw[i] + k].  One launch per direction for all n <= 3 blocks:
+ *   fwd:   y[i] = x W_i^T                                  (R, 64) bf16 each
+ *   dgrad: dx   = sum_i dy[i] W_i (+ acc)                  acc (R, 64) bf16 or NULL; may be dx itself
+ *   wgrad: dw[i][o * ld_dw[i] + k] += sum_r dy[i][r][o] x[r][k]   fp32, through the reduction queue below (dw[i] NULL: dropped);
+ *          workspace: p4c_node_proj_wgrad_workspace_bytes(R, n) bytes, owned by the call until its reduction has been enqueued
+ * bf16 matrix cores with fp32 accumulation, fixed summation order (bit-identical reruns). */
+int p4c_node_proj_fwd(const void* x, int64_t R, int n, const float* const* w, const int32_t* ldw, void* const* y, p4c_stream_t stream);
+int p4c_node_proj_dgrad(const void* const* dy, int64_t R, int n, const float* const* w, const int32_t* ldw, void* dx, const void* acc,
+                        p4c_stream_t stream);
+size_t p4c_node_proj_wgrad_workspace_bytes(int64_t R, int n);
+int p4c_node_proj_wgrad(const void* const* dy, const void* x, int64_t R, int n, float* const* dw, const int32_t* ld_dw, void* workspace,
+                        p4c_stream_t stream);
+/* Reduction queue of the parameter-gradient partials that p4c_row_mlp_bwd_accumulate and p4c_node_proj_wgrad leave.  By default each
+ * call enqueues its own reduction launch.  After p4c_grad_reduce_defer(1) the reductions are queued instead (process-wide; the
+ * workspaces must stay alive) and p4c_grad_reduce_flush(stream) -- the stream of the backward -- reduces all queued jobs, 32 per launch,
+ * in submission order: ~550 dependent 5 us launches of a HiLAM step become ~20, and the accumulated gradients are bit-identical.
+ * p4c_grad_reduce_defer returns the previous setting (on = -1: drop the queued jobs -- a backward pass that died before its flush -- and
+ * reduce at once again); p4c_grad_reduce_pending the number of queued jobs. */
+int p4c_grad_reduce_defer(int on);
+int p4c_grad_reduce_pending(void);
+int p4c_grad_reduce_flush(p4c_stream_t stream);
 
 /* ====================================================================================
  * Tall-skinny products of the efficient paired attention (EPA) of UNETR++ (config/CLI/model/unetrpp.yaml:19-35; the class

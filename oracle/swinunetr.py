@@ -48,6 +48,11 @@ class PatchMerging(nn.Module):
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
 
     def forward(self, x):
+        # (B, H, W, C): an odd grid is zero-padded at the bottom / right first, as MONAI's PatchMergingV2 and transformers'
+        # SwinPatchMerging do (pinned to the latter: tests/golden/make_golden_swin_merge.py)
+        H, W = x.shape[1], x.shape[2]
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], dim=-1)
         return self.reduction(self.norm(x))
 

@@ -78,6 +78,11 @@ SIGNATURES = {
     "p4c_row_mlp_prepare": [MP, P, P],
     "p4c_row_mlp_bwd": [MP, P, P, P],
     "p4c_row_mlp_bwd_accumulate": [MP, SP, P, P],
+    "p4c_node_proj_fwd": [P, L, I, P, P, P, P],
+    "p4c_node_proj_dgrad": [P, L, I, P, P, P, P, P],
+    "p4c_node_proj_wgrad": [P, P, L, I, P, P, P, P],
+    "p4c_grad_reduce_defer": [I],
+    "p4c_grad_reduce_flush": [P],
     "p4c_window_attn_fwd": [P, P, P, I, I, I, I, I, I, I, F, I, P],
     "p4c_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
     "p4c_row_add_layernorm_fwd": [P, P, L, P, P, F, P, P, L, I, I, P],
@@ -108,6 +113,9 @@ OTHER = {
     "p4c_row_gemm_wgrad_workspace_bytes": ([L, I, I, I], c_size_t),
     "p4c_row_mlp_bwd_workspace_bytes": ([L, I], c_size_t),
     "p4c_row_mlp_prepared_bytes": ([I], c_size_t),
+    "p4c_node_proj_wgrad_workspace_bytes": ([L, I], c_size_t),
+    "p4c_grad_reduce_pending": ([], c_int),
+    "p4c_side_stream_launch_count": ([], ctypes.c_longlong),
     "p4c_row_add_layernorm_bwd_workspace_bytes": ([L, I], c_size_t),
     "p4c_gemm_nt_workspace_bytes": ([I, I, I], c_size_t),
     "p4c_gemm_nt_stat_blocks": ([I, I, I], c_int),

@@ -9,6 +9,7 @@
 //                        normalisation coefficients and weight gradients are always fp32.
 #include <stdlib.h>
 
+#include <atomic>
 #include <functional>
 #include <vector>
 
@@ -264,6 +265,7 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
 // the same GPU, for which the agent-scope release at the end of every kernel is enough (tools/diagnostics/event_cost.hip: a record
 // costs the main stream 7.2 us with the fence, 4.6 us without).
 constexpr unsigned kOrderFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+void count_side_launches(long long n);
 struct SideStream {
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> events;
@@ -313,6 +315,7 @@ struct SideStream {
     int flush(hipStream_t from) {
         if (pending.empty()) return P4C_OK;
         P4C_TRY(order(from, stream));
+        count_side_launches((long long)pending.size());
         for (auto& job : pending) P4C_TRY(job(stream));
         pending.clear();
         return P4C_OK;
@@ -339,6 +342,19 @@ struct SideStream {
     }
 };
 thread_local SideStream g_side;
+// p4c_side_stream_enable is PROCESS-wide: a host sets it from its main thread, the backward runs on autograd's device
+// thread, whose own (thread-local) SideStream would never see a thread-local flag.  -1 = never asked: each thread's default.
+std::atomic<int> g_side_enable_request{-1};
+// weight-gradient jobs this process has issued to a side stream (p4c_side_stream_launch_count: what the single-stream test asserts on)
+std::atomic<long long> g_side_launches{0};
+void count_side_launches(long long n) { g_side_launches.fetch_add(n); }
+int apply_side_request() {
+    const int req = g_side_enable_request.load();
+    if (req < 0 || g_side.external) return P4C_OK;
+    if (req && !g_side.stream) P4C_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
+    g_side.enabled = req != 0;
+    return P4C_OK;
+}
 
 // The dA (gradient wrt the post-ReLU activation) of every conv block lives in the block's own buffer of the current set
 // (Layout::DY): its producer -- the data gradient of the next block, enc_out_bwd, the 1x1 data gradient -- writes it there, the
@@ -558,6 +574,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
     void *G0 = ws.g(L.G0), *G1 = ws.g(L.G1), *G2 = ws.g(L.G2), *TB = ws.g(L.TB);
     if (!d.weights_prepared) P4C_TRY(prepare_weights(d, ws, params, 2, st));
     P4C_TRY(g_side.init());
+    P4C_TRY(apply_side_request());
     g_side.next = 0;
     g_side.pending.clear();
     // (inside a HIP-graph capture nothing may depend on events recorded before it: every call then joins for itself and the
@@ -600,6 +617,7 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
         if (g_side.enabled) {
             P4C_TRY(g_side.order(st, g_side.stream));   // after everything the caller enqueued before this call (dy, ...)
             wst = g_side.stream;
+            count_side_launches(1);
         }
         P4C_TRY(conv_wgrad(d.compute, d.dtype, ws.act(L.Y[11]), NF, 1, nd2.scale, nd2.shift, 1, dy, ws.f(L.wgradp[NCONV]), G, d.B, d.H,
                            d.W, d.cout, NF, grads + L.wout, wst));
@@ -693,12 +711,12 @@ extern "C" int p4c_halfunet_backward(const p4c_halfunet_desc* dp, const void* x,
 // capture is replayed over four hardware queues and loses the overlap: profiles/r04_graph_vs_eager.txt).  Call between steps only:
 // nothing of a previous step may be in flight on the side stream (p4c_side_stream_join / a stream synchronisation first).
 extern "C" int p4c_side_stream_enable(int on) {
+    g_side_enable_request.store(on != 0 ? 1 : 0);     // every thread's next p4c_halfunet_backward applies it (the calling thread: now)
     P4C_TRY(g_side.init());
-    if (g_side.external) return P4C_OK;     // the caller's own stream: its decision
-    if (on && !g_side.stream) P4C_CHECK_HIP(hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking));
-    g_side.enabled = on != 0;
-    return P4C_OK;
+    return apply_side_request();
 }
+
+extern "C" long long p4c_side_stream_launch_count(void) { return g_side_launches.load(); }
 
 extern "C" int p4c_side_stream_defer(int on) {
     g_side.defer = on != 0;

@@ -193,6 +193,20 @@ int enc_out_bwd(int storage, const void* Tx, int Hfull, int s, const void* dS, c
                 const float* mean = nullptr, const float* rstd = nullptr, float* partial = nullptr, int* nblk_out = nullptr,
                 const BwdFin* fin = nullptr, bool* finalized_out = nullptr);
 
+// nodeproj.hip: queue of parameter-gradient reductions (mesh GNNs).  A job sums `slots` partials of n floats in a fixed order and ADDS the
+// result into the gradient buffers p[] (+=): GRAD_JOB_MLP = the layout of mlp.hip's partials (p = dw1, dw2, db1, db2, dgamma, dbeta; ld[0] =
+// row stride of dw1), GRAD_JOB_PROJ = up to three 64 x 64 blocks (p[i] with row stride ld[i]).  Launched at once, or -- while
+// p4c_grad_reduce_defer(1) is in force -- queued until p4c_grad_reduce_flush reduces all queued jobs GRAD_BATCH per launch.
+constexpr int GRAD_JOB_MLP = 0, GRAD_JOB_PROJ = 1;
+struct GradReduceJob {
+    const float* partial;
+    int slots, n, kind, K;
+    float* p[6];
+    int ld[3];
+    int k_real, o_real;
+};
+int grad_reduce_submit(const GradReduceJob& job, hipStream_t stream);
+
 // tiles of the conv kernels (for sizing the statistics partial buffers)
 constexpr int CONV_TH = 4;
 constexpr int CONV_TW = 32;

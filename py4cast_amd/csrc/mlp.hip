@@ -785,47 +785,13 @@ __global__ void __launch_bounds__(256) mlp_param_reduce_kernel(const float* __re
     }
 }
 
-// the same sums ADDED into the parameters' gradient buffers (the roles of the n = 64 K + 4096 + 256 entries are fixed by the layout)
+// the same sums ADDED into the parameters' gradient buffers: a job for the reduction queue of nodeproj.hip (grad_reduce_submit: at once,
+// or batched with the other jobs of the backward while p4c_grad_reduce_defer is on)
 struct GradSinks {
     float* dw1; int ld_dw1, k_real;
     float* dw2; int o_real;
     float* db1; float* db2; float* dgamma; float* dbeta;
 };
-__global__ void __launch_bounds__(256) mlp_param_reduce_acc_kernel(const float* __restrict__ partial, int slots, int n, int K, GradSinks g) {
-    __shared__ float red[8][33];
-    const int jj = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + jj;
-    float s0 = 0.f, s1 = 0.f;
-    if (j < n) {
-        int s = sg;
-        for (; s + 8 < slots; s += 16) {
-            s0 += partial[(int64_t)s * n + j];
-            s1 += partial[(int64_t)(s + 8) * n + j];
-        }
-        for (; s < slots; s += 8) s0 += partial[(int64_t)s * n + j];
-    }
-    red[sg][jj] = s0 + s1;
-    __syncthreads();
-    if (sg == 0 && j < n) {
-        float t = red[0][jj];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][jj];
-        const int w2_0 = HID * K, b1_0 = w2_0 + HID * HID;
-        if (j < w2_0) {
-            const int o = j / K, k = j - o * K;
-            if (g.dw1 && k < g.k_real) g.dw1[(int64_t)o * g.ld_dw1 + k] += t;
-        } else if (j < b1_0) {
-            const int o = (j - w2_0) >> 6;
-            if (g.dw2 && o < g.o_real) g.dw2[j - w2_0] += t;
-        } else {
-            const int which = (j - b1_0) >> 6, c = (j - b1_0) & 63;
-            if (which == 0 && g.db1) g.db1[c] += t;
-            if (which == 1 && g.db2 && c < g.o_real) g.db2[c] += t;
-            if (which == 2 && g.dgamma) g.dgamma[c] += t;
-            if (which == 3 && g.dbeta) g.dbeta[c] += t;
-        }
-    }
-}
 
 int mlp_grid(int64_t R, int per_cu) {
     const int64_t tiles = (R + 31) / 32;
@@ -868,10 +834,14 @@ int launch_bwd(const MlpArgs& a, float* grads, const GradSinks* sinks, hipStream
         hipLaunchKernelGGL((row_mlp_bwd_kernel<KS, false>), dim3(G), dim3(256), smem, s, a);
     P4C_CHECK_LAUNCH("row_mlp_bwd");
     const int n = partial_floats<KS>();
-    if (sinks)
-        hipLaunchKernelGGL(mlp_param_reduce_acc_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, 16 * KS, *sinks);
-    else
-        hipLaunchKernelGGL(mlp_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, grads);
+    if (sinks) {
+        GradReduceJob job{};
+        job.partial = a.partial; job.slots = G; job.n = n; job.kind = GRAD_JOB_MLP; job.K = 16 * KS;
+        job.p[0] = sinks->dw1; job.p[1] = sinks->dw2; job.p[2] = sinks->db1; job.p[3] = sinks->db2; job.p[4] = sinks->dgamma; job.p[5] = sinks->dbeta;
+        job.ld[0] = sinks->ld_dw1; job.k_real = sinks->k_real; job.o_real = sinks->o_real;
+        return grad_reduce_submit(job, s);
+    }
+    hipLaunchKernelGGL(mlp_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, grads);
     P4C_CHECK_LAUNCH("mlp_param_reduce");
     return P4C_OK;
 }

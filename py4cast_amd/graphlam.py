@@ -26,6 +26,7 @@ from torch import nn
 from . import _lib as L
 from . import ops_graph as G
 from . import ops_mlp as M
+from . import ops_nodeproj as NP
 from . import ops_rows as R
 from .base import ModelABC, ModelType
 from .graph_build import MeshGraph, build_mesh_graph, graph_path
@@ -201,17 +202,17 @@ class InteractionNet(nn.Module):
         lin0, lin1, ln = self.edge_mlp[0], self.edge_mlp[2], self.edge_mlp[3]
         part = None
         if edge_rep.dtype == torch.bfloat16 and C == 64 and edge_rep.shape[0] >= 1:
-            # sender / receiver parts of the first Linear once per NODE (small library GEMMs), everything per EDGE in one kernel:
+            # sender / receiver parts of the first Linear once per NODE, everything per EDGE in one kernel:
             # e W_e + a[src] + b[dst] + bias -> SiLU -> Linear -> LayerNorm -> msg (and edge_rep + msg)
-            # the projections of one node tensor are one autograd node (their input gradients accumulate inside the GEMMs); `part`
-            # is the receiver part of the node-update MLP's first Linear, used after the aggregation below
+            # the projections of one node tensor are ONE launch each way (ops_nodeproj.node_proj: their input gradients are one K = 64 n
+            # product, their weight gradients one launch into the batched reduction); `part` is the receiver part of the node-update
+            # MLP's first Linear, used after the aggregation below
             al0 = self.aggr_mlp[0]
             if send_rep is rec_rep:
-                a, b, part = R.row_linear_multi(rec_rep, [lin0.weight[:, C:2 * C], lin0.weight[:, 2 * C:], al0.weight[:, :C]],
-                                                grads_in_place=GRADS_IN_PLACE)
+                a, b, part = NP.node_proj(rec_rep, [lin0.weight[:, C:2 * C], lin0.weight[:, 2 * C:], al0.weight[:, :C]], GRADS_IN_PLACE)
             else:
-                a = R.row_linear(send_rep, lin0.weight[:, C:2 * C], grads_in_place=GRADS_IN_PLACE)
-                b, part = R.row_linear_multi(rec_rep, [lin0.weight[:, 2 * C:], al0.weight[:, :C]], grads_in_place=GRADS_IN_PLACE)
+                a, = NP.node_proj(send_rep, [lin0.weight[:, C:2 * C]], GRADS_IN_PLACE)
+                b, part = NP.node_proj(rec_rep, [lin0.weight[:, 2 * C:], al0.weight[:, :C]], GRADS_IN_PLACE)
             msg, new_edge = M.row_mlp(edge_rep, lin0.weight[:, :C], lin0.bias, lin1.weight, lin1.bias, ln.weight, ln.bias, ln.eps,
                                       ga=a, gb=b, edges=edges, res=edge_rep if self.update_edges else None,
                                       grads_in_place=GRADS_IN_PLACE)
@@ -236,7 +237,7 @@ class InteractionNet(nn.Module):
         if rec_rep.dtype == torch.bfloat16 and C == 64 and rec_rep.shape[0] >= 1:
             # Linear over cat[x_r, agg] = x_r W[:, :C]^T (small library GEMM, row-aligned addend) + agg W[:, C:]^T (fused kernel's x)
             if part is None:
-                part = R.row_linear(rec_rep, al0.weight[:, :C], grads_in_place=GRADS_IN_PLACE)
+                part, = NP.node_proj(rec_rep, [al0.weight[:, :C]], GRADS_IN_PLACE)
             _, rec_rep = M.row_mlp(agg, al0.weight[:, C:], al0.bias, al1.weight, al1.bias, aln.weight, aln.bias, aln.eps,
                                    ga=part, res=rec_rep, want_out=False, grads_in_place=GRADS_IN_PLACE)
         else:

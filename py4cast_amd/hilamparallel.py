@@ -21,7 +21,7 @@ from torch import nn
 
 from . import ops_graph as G
 from . import ops_mlp as M
-from . import ops_rows as R
+from . import ops_nodeproj as NP
 from . import graphlam as _gl
 from .graphlam import _run, cached_static_embeddings, grid_rows, make_mlp, output_rows
 from .hilam import HiLamMI355X, HiLamSettings
@@ -54,8 +54,11 @@ def _edge_messages(mlp: nn.Sequential, send, rec, edge_rep, edges: G.EdgeSet):
     C = edge_rep.shape[1]
     lin0, lin1, ln = mlp[0], mlp[2], mlp[3]
     if edge_rep.dtype == torch.bfloat16 and C == 64:
-        a = R.row_linear(send, lin0.weight[:, C:2 * C], grads_in_place=_gl.GRADS_IN_PLACE)
-        b = R.row_linear(rec, lin0.weight[:, 2 * C:], grads_in_place=_gl.GRADS_IN_PLACE)
+        if send is rec:
+            a, b = NP.node_proj(rec, [lin0.weight[:, C:2 * C], lin0.weight[:, 2 * C:]], _gl.GRADS_IN_PLACE)
+        else:
+            a, = NP.node_proj(send, [lin0.weight[:, C:2 * C]], _gl.GRADS_IN_PLACE)
+            b, = NP.node_proj(rec, [lin0.weight[:, 2 * C:]], _gl.GRADS_IN_PLACE)
         return M.row_mlp(edge_rep, lin0.weight[:, :C], lin0.bias, lin1.weight, lin1.bias, ln.weight, ln.bias, ln.eps,
                          ga=a, gb=b, edges=edges, res=edge_rep, grads_in_place=_gl.GRADS_IN_PLACE)
     base = F.linear(edge_rep, lin0.weight[:, :C], lin0.bias)
@@ -68,7 +71,7 @@ def _node_update(mlp: nn.Sequential, rec, agg):
     C = rec.shape[1]
     al0, al1, aln = mlp[0], mlp[2], mlp[3]
     if rec.dtype == torch.bfloat16 and C == 64:
-        part = R.row_linear(rec, al0.weight[:, :C], grads_in_place=_gl.GRADS_IN_PLACE)
+        part, = NP.node_proj(rec, [al0.weight[:, :C]], _gl.GRADS_IN_PLACE)
         return M.row_mlp(agg, al0.weight[:, C:], al0.bias, al1.weight, al1.bias, aln.weight, aln.bias, aln.eps, ga=part, res=rec,
                          want_out=False, grads_in_place=_gl.GRADS_IN_PLACE)[1]
     return _run(mlp, torch.cat([rec, agg], dim=-1), res=rec)

@@ -120,6 +120,9 @@ class _RowMLP(torch.autograd.Function):
             p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
             gs = RowMlpGradSinks(dw1=p(sw1), ld_dw1=0 if sw1 is None else sw1.stride(0), db1=p(sb1), dw2=p(sw2), db2=p(sb2),
                                  dgamma=p(sg), dbeta=p(sb))
+            from .ops_nodeproj import GradQueue
+
+            GradQueue.begin(ws)    # the partials' reduction joins the batched ones at the end of this backward pass
             L.call("p4c_row_mlp_bwd_accumulate", ctypes.byref(d), ctypes.byref(gs), L.ptr(ws), L.stream(x.device), alg_bytes=nbytes)
             dw1 = dw2 = db1 = db2 = dgam = dbet = None
         else:

@@ -1,0 +1,131 @@
+"""Launch grouping for the mesh GNNs (include/py4cast_hip.h: p4c_node_proj_fwd / _dgrad / _wgrad, p4c_grad_reduce_defer / _flush;
+csrc/nodeproj.hip).
+
+GraphLAM / HiLAM / HiLAMParallel (config/CLI/model/graphlam.yaml:19-26, hilam.yaml, hilamparallel.yaml; taken from mfai at
+py4cast/models.py:66-89) apply ~190 InteractionNets per optimizer step, most of them on mesh levels of a few dozen to a few thousand
+rows, where a launch costs its latency whatever it computes.  Two things cut the number of dependent launches:
+
+* ``node_proj``: the 64 x 64 blocks of the distributed first Linears that multiply one node tensor (sender / receiver part of the edge
+  MLP, receiver part of the node-update MLP) as ONE launch forward, one for the data gradient (K = 64 n) and one for the weight
+  gradients -- instead of n row-GEMMs each way plus, per block, a weight-gradient product, its reduction and a ``+=``;
+* ``GradQueue``: the reductions of the parameter-gradient partials (this module's and ops_mlp.row_mlp's) are queued during a backward
+  pass and run 32 jobs per launch when the autograd engine finishes the pass (``queue_callback``), in submission order: bit-identical
+  to reducing after every call, ~550 dependent 5 us launches fewer per HiLAM step.
+
+No CPU fallback.
+"""
+
+import ctypes
+from typing import List, Sequence
+
+import torch
+
+from . import _lib as L
+from .ops_rows import grad_view, row_linear
+
+_P3 = ctypes.c_void_p * 3
+_I3 = ctypes.c_int32 * 3
+
+
+class GradQueue:
+    """Deferred reduction of the gradient partials of ONE backward pass.  ``begin(keep)`` (from inside an autograd Function's backward)
+    switches the library to queueing, registers the flush with the engine once per pass and keeps ``keep`` (the partials' workspace)
+    alive until the flush has been enqueued.  Outside a backward pass (no graph task) nothing is deferred."""
+
+    enabled = True          # False: every call reduces at once (the A/B reference of tests/test_nodeproj_gpu.py)
+    _task = -1
+    _keep: List[torch.Tensor] = []
+    _stream = None
+
+    @classmethod
+    def begin(cls, keep: torch.Tensor) -> None:
+        if not cls.enabled:
+            return
+        task = torch._C._current_graph_task_id()
+        if task < 0:
+            return
+        if cls._task != task:
+            if cls._task >= 0:      # a pass that died before its callback ran: its queued jobs are void
+                L.lib().p4c_grad_reduce_defer(-1)
+                cls._keep = []
+            cls._task = task
+            cls._stream = torch.cuda.current_stream(keep.device)
+            L.lib().p4c_grad_reduce_defer(1)
+            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+        cls._keep.append(keep)
+
+    @classmethod
+    def flush(cls) -> None:
+        if cls._task < 0:
+            return
+        try:
+            L.check(L.lib().p4c_grad_reduce_flush(ctypes.c_void_p(cls._stream.cuda_stream)), "p4c_grad_reduce_flush")
+        finally:
+            L.lib().p4c_grad_reduce_defer(0)
+            cls._task, cls._keep, cls._stream = -1, [], None
+
+
+def _arr(tensors: Sequence[torch.Tensor]):
+    return _P3(*[t.data_ptr() for t in tensors], *([None] * (3 - len(tensors))))
+
+
+def _lds(tensors: Sequence[torch.Tensor]):
+    return _I3(*[t.stride(0) for t in tensors], *([64] * (3 - len(tensors))))
+
+
+class _NodeProj(torch.autograd.Function):
+    """(x W_1^T, ..., x W_n^T) for bf16 node rows x (R, 64) and 64 x 64 blocks W_i of fp32 master weights, as one autograd node whose
+    backward ADDS every weight gradient into ``gws[i]`` -- the view of the parameter's ``.grad`` that corresponds to W_i."""
+
+    @staticmethod
+    def forward(ctx, x, n, *args):
+        ws, gws = args[:n], args[n:]
+        x = x.contiguous()
+        R = x.shape[0]
+        ys = [torch.empty(R, 64, dtype=x.dtype, device=x.device) for _ in range(n)]
+        wd = [w.detach() for w in ws]
+        L.call("p4c_node_proj_fwd", L.ptr(x), R, n, _arr(wd), _lds(wd), _arr(ys), L.stream(x.device),
+               alg_bytes=R * 128 * (1 + n) + n * 64 * 64 * 4, alg_flops=2 * R * 64 * 64 * n)
+        ctx.save_for_backward(x, *wd)
+        ctx.gws, ctx.n = gws, n
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, *wd = ctx.saved_tensors
+        n, R = ctx.n, x.shape[0]
+        live = [i for i in range(n) if dys[i] is not None]
+        if not live:
+            return (None, None) + (None,) * (2 * n)
+        dyl = [dys[i].contiguous() for i in live]
+        wl = [wd[i] for i in live]
+        m = len(live)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.call("p4c_node_proj_dgrad", _arr(dyl), R, m, _arr(wl), _lds(wl), L.ptr(dx), None, L.stream(x.device),
+                   alg_bytes=R * 128 * (1 + m) + m * 64 * 64 * 4, alg_flops=2 * R * 64 * 64 * m)
+        gl = [ctx.gws[i] for i in live]
+        ws = torch.empty(max(L.lib().p4c_node_proj_wgrad_workspace_bytes(R, m) // 4, 1), dtype=torch.float32, device=x.device)
+        GradQueue.begin(ws)
+        L.call("p4c_node_proj_wgrad", _arr(dyl), L.ptr(x), R, m, _arr(gl), _lds(gl), L.ptr(ws), L.stream(x.device),
+               alg_bytes=R * 128 * (1 + m) + ws.numel() * 4, alg_flops=2 * R * 64 * 64 * m)
+        return (dx, None) + (None,) * (2 * n)
+
+
+def node_proj_ok(x: torch.Tensor, weights) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 64 and x.shape[0] >= 1 and 1 <= len(weights) <= 3
+            and all(w.dtype == torch.float32 and w.dim() == 2 and tuple(w.shape) == (64, 64) and w.stride(1) == 1 for w in weights))
+
+
+def node_proj(x: torch.Tensor, weights, grads_in_place: bool = True):
+    """``[x @ w.T for w in weights]``: bf16 rows of 64 features, up to three 64 x 64 fp32 blocks (column slices of wider Linear weights
+    are fine).  With gradient buffers on every weight (FlatDDP / Trainer allocate them) ONE launch per direction (module docstring);
+    otherwise one ``ops_rows.row_linear`` each (autograd-returned weight gradients)."""
+    L.require_cuda(x)
+    weights = list(weights)
+    if grads_in_place and node_proj_ok(x, weights) and torch.is_grad_enabled() and all(w.requires_grad for w in weights):
+        gws = [grad_view(w) for w in weights]
+        if all(g is not None and g is not False and g.stride(1) == 1 for g in gws):
+            return _NodeProj.apply(x, len(weights), *weights, *gws)
+    return tuple(row_linear(x, w, grads_in_place=grads_in_place) for w in weights)

@@ -213,11 +213,13 @@ class PatchMerging(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         # [x(0::2,0::2) | x(1::2,0::2) | x(0::2,1::2) | x(1::2,1::2)] along the channels (MONAI's order) as ONE gather of the 2 x 2
         # patches: the concatenation of four strided slices cost, backward, four zero fills, four strided copies and three additions
+        # an odd grid is zero-padded at the bottom / right first (MONAI's PatchMergingV2, transformers' SwinPatchMerging: the golden
+        # vectors of tests/golden/make_golden_swin_merge.py pin order, padding, LayerNorm and reduction)
         B, H, W, C = x.shape
-        if H % 2 == 0 and W % 2 == 0:
-            x = x.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, H // 2, W // 2, 4 * C)
-        else:
-            x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], dim=-1)
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+            H, W = H + H % 2, W + W % 2
+        x = x.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).reshape(B, H // 2, W // 2, 4 * C)
         return _linear(self.reduction, _layer_norm(self.norm, x))
 
 

@@ -566,3 +566,39 @@ def test_training_reduces_loss_and_bf16_tracks_fp32(gpu_device):
         traj[dt] = losses
     for a, b in zip(traj["f32"], traj["bf16"]):
         assert abs(a - b) / abs(a) < 0.08, (traj["f32"], traj["bf16"])
+
+
+def test_side_stream_switch_reaches_the_backward_thread(gpu_device):
+    """p4c_side_stream_enable is process-wide: called from the host's main thread it must reach p4c_halfunet_backward on
+    autograd's device thread.  Off: no weight-gradient launch goes to a side stream and the gradients equal the two-stream run's bit for
+    bit (the same kernels in the same order per buffer); on again: they go beside the chain."""
+    from py4cast_amd import _lib as L
+
+    _, model = _make_pair(69, 60, "batch", gpu_device)
+    model.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 64, 69, generator=g).to(gpu_device)
+    gy = torch.randn(2, 64, 64, 60, generator=g).to(gpu_device)
+    lib = L.lib()
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        before = lib.p4c_side_stream_launch_count()
+        xg = x.clone().requires_grad_(True)
+        (model(xg) * gy).sum().backward()
+        torch.cuda.synchronize()
+        return lib.p4c_side_stream_launch_count() - before, [p.grad.clone() for p in model.parameters()] + [xg.grad.clone()]
+
+    try:
+        L.call("p4c_side_stream_enable", 1)
+        n_on, g_on = run()
+        L.call("p4c_side_stream_enable", 0)
+        n_off, g_off = run()
+        L.call("p4c_side_stream_enable", 1)
+        n_again, _ = run()
+    finally:
+        L.call("p4c_side_stream_enable", 1)
+    assert n_on > 0 and n_again == n_on
+    assert n_off == 0
+    for a, b in zip(g_on, g_off):
+        assert torch.equal(a, b)

@@ -58,3 +58,33 @@ def test_oracle_swin_block_reproduces_transformers_layer(path):
     ref_out, ref_dx = torch.from_numpy(z["out"]), torch.from_numpy(z["dx"])
     assert float((out - ref_out).abs().max() / ref_out.abs().max()) <= 1e-6
     assert float((x.grad - ref_dx).abs().max() / ref_dx.abs().max()) <= 1e-6
+
+
+MERGE_FILES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "swin_merge_*.npz")))
+
+
+def test_merge_fixtures_present():
+    assert len(MERGE_FILES) == 3
+
+
+@pytest.mark.parametrize("path", MERGE_FILES, ids=[os.path.basename(p)[11:-4] for p in MERGE_FILES])
+def test_oracle_patch_merging_reproduces_transformers(path):
+    """oracle/swinunetr.py::PatchMerging against transformers' SwinPatchMerging (tests/golden/make_golden_swin_merge.py): the 2 x 2
+    concatenation order and the padding of odd grids bit for bit (an index map through the same slicing), output and input gradient
+    <= 1e-6 in float64"""
+    from oracle.swinunetr import PatchMerging
+
+    meta, z = load(path)
+    m = PatchMerging(meta["dim"]).double()
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith("w_")})
+    H, W, C = meta["H"], meta["W"], meta["dim"]
+    probe = PatchMerging(C).double()       # identity norm / reduction: the merged layout itself
+    probe.norm, probe.reduction = torch.nn.Identity(), torch.nn.Identity()
+    idx = torch.arange(H * W * C, dtype=torch.float64).view(1, H, W, C) + 1.0
+    assert np.array_equal(probe(idx).long().numpy(), z["merge_index"])
+    x = torch.from_numpy(z["x"]).double().requires_grad_(True)
+    out = m(x)
+    out.backward(torch.from_numpy(z["gy"]).double())
+    ref_out, ref_dx = torch.from_numpy(z["out"]), torch.from_numpy(z["dx"])
+    assert float((out - ref_out).abs().max() / ref_out.abs().max()) <= 1e-6
+    assert float((x.grad - ref_dx).abs().max() / ref_dx.abs().max()) <= 1e-6
