@@ -621,6 +621,8 @@ typedef struct p4c_row_mlp_desc {
     void* dx;                /* (rows, k) bf16 or NULL */
     void* dpre;              /* (rows, 64) bf16 or NULL: gradient of the pre-activation = gradient of the gathered rows before
                                 their p4c_segment_sum over index_a / index_b */
+    int32_t dx_plus_dy_res;  /* backward, k = 64, res IS x (an edge update e <- e + MLP(e, ..)): dx receives dx + dy_res, the whole
+                                gradient of that one tensor, summed in fp32 before the rounding (round 6) */
 } p4c_row_mlp_desc;
 /* Re-lays w1, b1, w2, b2, gamma, beta (as described by d) into the operand images both kernels use: `prepared` needs
  * p4c_row_mlp_prepared_bytes(k) bytes and stays valid until a parameter changes. */

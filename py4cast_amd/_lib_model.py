@@ -29,7 +29,7 @@ class RowMlpDesc(ctypes.Structure):
         ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("o_real", c_int32), ("gamma", c_void_p), ("beta", c_void_p),
         ("eps", c_float), ("gather_a", c_void_p), ("index_a", c_void_p), ("gather_b", c_void_p), ("index_b", c_void_p),
         ("res", c_void_p), ("out", c_void_p), ("out_res", c_void_p), ("prepared", c_void_p), ("dy", c_void_p), ("dy_res", c_void_p), ("dx", c_void_p),
-        ("dpre", c_void_p),
+        ("dpre", c_void_p), ("dx_plus_dy_res", c_int32),
     ]
 
 

@@ -54,6 +54,7 @@ struct MlpArgs {
     bf16* dpre;             // gradient of the pre-activation (R, 64): the gradient of ga / gb rows before their segment sums; or NULL
     float* partial;         // per-workgroup parameter-gradient partials
     const void* prepared;   // constants + weight operand images as laid out in LDS (p4c_row_mlp_prepare), or NULL
+    int dx_add_dyr;         // backward, K = 64: dx += dy_res (res IS x: both gradients of the one tensor in one store)
     int64_t R;
 };
 
@@ -147,29 +148,54 @@ __device__ __forceinline__ void build_consts(float* lc, const MlpArgs& a, int ti
 }
 
 
-// constants + weight images into LDS: a 16-byte-per-thread copy of the prepared blob, or built from the raw fp32 parameters
+// constants + weight images into LDS: a 16-byte-per-thread copy of the prepared blob, or built from the raw fp32 parameters.
+// The copy is split into its loads (all in flight at once: ONE memory round trip -- as a `dst[i] = src[i]` loop over a run-time
+// trip count it was 5 / 9 dependent round trips, ~4 / ~7 us of a small-grid launch that computes for ~4) and its LDS stores, so that
+// a kernel can issue its first tile's row loads in between.  Workgroups are 256 threads.
+template <int KS, bool BWD>
+struct StagedParams {
+    static constexpr int NKT = (16 * KS + 31) / 32;
+    static constexpr int bytes = 4 * HID * 4 + (BWD ? (2 * KS + 8 + 8 + 4 * NKT) : (2 * KS + 8)) * 1024;
+    static constexpr int N16 = bytes / 16, IT = (N16 + 255) / 256;
+    uint4 v[IT];
+    __device__ __forceinline__ void load(const MlpArgs& a) {
+        // (without a prepared blob the same loads read the first weight -- valid memory, results unused: one instruction stream)
+        const uint4* src = reinterpret_cast<const uint4*>(a.prepared ? a.prepared : (const void*)a.w2);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = a.prepared ? threadIdx.x + 256 * it : 0;
+            v[it] = src[i < N16 ? i : N16 - 1];
+        }
+    }
+    __device__ __forceinline__ void store(char* smem, const MlpArgs& a) const {
+        if (a.prepared) {
+            uint4* dst = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int i = threadIdx.x + 256 * it;
+                if (i < N16) dst[i] = v[it];
+            }
+            return;
+        }
+        float* lc = reinterpret_cast<float*>(smem);
+        bf16* w1img = reinterpret_cast<bf16*>(smem + 4 * HID * 4);
+        bf16* w2img = w1img + 2 * KS * 512;
+        build_consts(lc, a, threadIdx.x, blockDim.x);
+        build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false, threadIdx.x, blockDim.x);
+        build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true, threadIdx.x, blockDim.x);
+        if (BWD) {
+            bf16* w2timg = w2img + 8 * 512;
+            bf16* w1timg = w2timg + 8 * 512;
+            build_image(w2timg, 2, 4, a.w2, HID, HID, a.Oreal, true, true, threadIdx.x, blockDim.x);
+            build_image(w1timg, NKT, 4, a.w1, a.ldw1, a.Kreal, HID, true, true, threadIdx.x, blockDim.x);
+        }
+    }
+};
 template <int KS, bool BWD>
 __device__ __forceinline__ void stage_parameters(char* smem, const MlpArgs& a) {
-    constexpr int NKT = (16 * KS + 31) / 32;
-    constexpr int bytes = 4 * HID * 4 + (BWD ? (2 * KS + 8 + 8 + 4 * NKT) : (2 * KS + 8)) * 1024;
-    if (a.prepared) {
-        const uint4* src = reinterpret_cast<const uint4*>(a.prepared);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = threadIdx.x; i < bytes / 16; i += blockDim.x) dst[i] = src[i];
-        return;
-    }
-    float* lc = reinterpret_cast<float*>(smem);
-    bf16* w1img = reinterpret_cast<bf16*>(smem + 4 * HID * 4);
-    bf16* w2img = w1img + 2 * KS * 512;
-    build_consts(lc, a, threadIdx.x, blockDim.x);
-    build_image(w1img, 2, KS, a.w1, a.ldw1, HID, a.Kreal, false, false, threadIdx.x, blockDim.x);
-    build_image(w2img, 2, 4, a.w2, HID, a.Oreal, HID, false, true, threadIdx.x, blockDim.x);
-    if (BWD) {
-        bf16* w2timg = w2img + 8 * 512;
-        bf16* w1timg = w2timg + 8 * 512;
-        build_image(w2timg, 2, 4, a.w2, HID, HID, a.Oreal, true, true, threadIdx.x, blockDim.x);
-        build_image(w1timg, NKT, 4, a.w1, a.ldw1, a.Kreal, HID, true, true, threadIdx.x, blockDim.x);
-    }
+    StagedParams<KS, BWD> sp;
+    sp.load(a);
+    sp.store(smem, a);
 }
 
 // the same images written to global memory once per parameter version (every launch of the fused kernels then copies them)
@@ -370,6 +396,7 @@ template <int KS> constexpr int bwd_weights_bytes() { return (2 * KS + 8 + 8 + 4
 template <int KS> constexpr int bwd_lds_bytes() { return 4 * HID * 4 + bwd_weights_bytes<KS>() + 4 * wave_img_bytes<KS>(); }
 // floats of one workgroup's partial: dW1 [64][K] | dW2 [64][64] | db1 | db2 | dgamma | dbeta
 template <int KS> constexpr int partial_floats() { return HID * 16 * KS + HID * HID + 4 * HID; }
+constexpr int PER_WAVE_MAX_G = 16;   // workgroups up to which every wave leaves its own partial slot (see the end of row_mlp_bwd_kernel)
 
 // A lane of the accumulator layout owns features 8q + 4h .. +3 (q = 0..7) of its row: eight 8-byte pieces, interleaved with those
 // of its partner lane (same row, other half h).  Loaded as such, a wave instruction touches 32 rows x 16 bytes; instead each lane
@@ -425,8 +452,6 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
     char* imgDP = imgDZ + 32 * PROW;
     char* imgDG = imgDP + 32 * PROW;
     char* imgDD = imgDG + 32 * PROW;
-    stage_parameters<KS, true>(smem, a);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     const int64_t ntiles = (a.R + 31) / 32;
@@ -474,16 +499,23 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
         if (a.gb) load_row_chunks(a.gb + (int64_t)jb * HID, h, true, g.b);
     };
 
+    // Prologue: the first tile's index and row loads go out BEFORE the parameter images are staged, the gathers (which need the
+    // indices) between the staging's loads and its LDS stores: index -> gather and parameters -> LDS overlap instead of following
+    // each other (most launches of a hierarchical GNN are one tile per wave: the prologue IS the kernel there).
     TileIn<KS> cur, nxt;
     TileGather gcur, gnxt;
     int ja_n = 0, jb_n = 0;
     {
         int ja, jb;
         load_idx(wave, ja, jb);
-        if (GATHER) load_gather(gcur, ja, jb);
         load_in(cur, wave);
+        StagedParams<KS, true> sp;
+        sp.load(a);
+        if (GATHER) load_gather(gcur, ja, jb);
         load_idx(wave + nwaves, ja_n, jb_n);
+        sp.store(smem, a);
     }
+    __syncthreads();
 
     if (P4C_MLP_EXP & 16) { nxt = cur; gnxt = gcur; }
     for (int64_t tIdx = wave; tIdx < ntiles; tIdx += nwaves) {
@@ -641,6 +673,14 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
                 for (int sp = 0; sp < 4; ++sp)
                     acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wop(w1timg, 4, kt, sp, lane), acc_op(pre + 16 * (sp >> 1), sp & 1), acc[kt], 0, 0, 0);
             }
+            if (KS == 4 && a.dx_add_dyr) {   // (accumulator element 4 g + e of tile kt <-> feature 32 kt + 8 g + 4 h + e = piece 4 kt + g)
+                bf16x4 pr[8];
+                trade_pieces(cur.dyr, pr);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[kt][j] += (float)pr[(4 * kt + (j >> 2)) & 7][j & 3];
+            }
             // the reverse trade of load_row_chunks: 16-byte stores of the chunk 16 i + 8 h .. +7
 #pragma unroll
             for (int i = 0; i < KS; ++i) {
@@ -708,24 +748,16 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
         if (GATHER) gcur = gnxt;
     }
 
-    // ---- per-workgroup partial (the four waves add in wave order through LDS: fixed order), then one global partial per workgroup
-    __syncthreads();
-    // every wave that had a tile stores its sums to its OWN slot (weights and images are dead: the whole LDS allocation is free),
-    // then all threads add the slots in wave order -- fixed order, no read-modify-write turns (four serial turns of LDS round
-    // trips were 15 us of a launch that is otherwise ~18: most backward launches of a hierarchical GNN are a few tiles)
+    // ---- parameter-gradient partials.  Small grids (<= PER_WAVE_MAX_G workgroups: the upper mesh levels, where the launch is its
+    // own latency): every wave that had a tile stores its sums straight to its OWN global slot (waves 0 .. min(tiles, 4 G) - 1:
+    // contiguous) -- no barrier, no pass through LDS.  Larger grids: the four waves of a workgroup add in wave order through LDS
+    // (fixed order) and leave one partial per workgroup (4 x less partial traffic where it counts).
     constexpr int PF = partial_floats<KS>();
     static_assert(4 * PF * 4 <= bwd_lds_bytes<KS>(), "a reduction slot per wave must fit the kernel's LDS");
-    float* red = reinterpret_cast<float*>(smem) + wv * PF;
     constexpr int OFF_W2 = HID * K, OFF_B1 = OFF_W2 + HID * HID, OFF_B2 = OFF_B1 + HID, OFF_G = OFF_B2 + HID, OFF_BT = OFF_G + HID;
+    const bool per_wave = (int)gridDim.x <= PER_WAVE_MAX_G;
     const bool contributed = wave < ntiles;   // wave 0 of a workgroup always has a tile
-    if (contributed) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            db1[j] = lane8_sum(db1[j]);
-            db2[j] = lane8_sum(db2[j]);
-            dgam[j] = lane8_sum(dgam[j]);
-            dbet[j] = lane8_sum(dbet[j]);
-        }
+    auto write_sums = [&](float* red) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -748,16 +780,37 @@ __global__ void __launch_bounds__(256, 1) row_mlp_bwd_kernel(MlpArgs a) {
                 red[OFF_G + c] = dgam[j];
                 red[OFF_BT + c] = dbet[j];
             }
+    };
+    if (contributed) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            db1[j] = lane8_sum(db1[j]);
+            db2[j] = lane8_sum(db2[j]);
+            dgam[j] = lane8_sum(dgam[j]);
+            dbet[j] = lane8_sum(dbet[j]);
+        }
     }
+    if (per_wave) {
+        if (contributed) write_sums(a.partial + wave * (int64_t)PF);
+        return;
+    }
+    __syncthreads();           // weights and images are dead from here: the whole LDS allocation is free
+    if (contributed) write_sums(reinterpret_cast<float*>(smem) + wv * PF);
     __syncthreads();
     const int64_t left = ntiles - (int64_t)blockIdx.x * 4;
     const int nact = left >= 4 ? 4 : (int)left;
-    const float* slot = reinterpret_cast<const float*>(smem);
-    float* dst = a.partial + (int64_t)blockIdx.x * PF;
-    for (int i = threadIdx.x; i < PF; i += blockDim.x) {
-        float t = slot[i];
-        for (int w = 1; w < nact; ++w) t += slot[w * PF + i];
-        dst[i] = t;
+    const f32x4* slot = reinterpret_cast<const f32x4*>(smem);
+    f32x4* dst = reinterpret_cast<f32x4*>(a.partial + (int64_t)blockIdx.x * PF);
+    static_assert(PF % 4 == 0, "the partial is summed in 16-byte pieces");
+    constexpr int PF4 = PF / 4, RIT = (PF4 + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+        const int i = threadIdx.x + 256 * it;
+        if (i < PF4) {
+            f32x4 t = slot[i];
+            for (int w = 1; w < nact; ++w) t += slot[w * PF4 + i];
+            dst[i] = t;
+        }
     }
 }
 
@@ -802,6 +855,14 @@ int mlp_grid(int64_t R, int per_cu) {
     return (int)blocks;
 }
 
+// partial slots a backward launch over R rows leaves (what its reduction job sums)
+int mlp_bwd_slots(int64_t R) {
+    const int G = mlp_grid(R, 1);
+    if (G > PER_WAVE_MAX_G) return G;
+    const int64_t tiles = (R + 31) / 32;
+    return (int)(tiles < 4 * (int64_t)G ? tiles : 4 * (int64_t)G);
+}
+
 int check_args(const char* name, const MlpArgs& a, int K) {
     P4C_CHECK_ARG(a.R > 0, "%s: R must be positive", name);
     P4C_CHECK_ARG(K % 16 == 0 && K >= 16 && K <= 80, "%s: K = %d input features (multiples of 16 up to 80; pad)", name, K);
@@ -836,12 +897,12 @@ int launch_bwd(const MlpArgs& a, float* grads, const GradSinks* sinks, hipStream
     const int n = partial_floats<KS>();
     if (sinks) {
         GradReduceJob job{};
-        job.partial = a.partial; job.slots = G; job.n = n; job.kind = GRAD_JOB_MLP; job.K = 16 * KS;
+        job.partial = a.partial; job.slots = mlp_bwd_slots(a.R); job.n = n; job.kind = GRAD_JOB_MLP; job.K = 16 * KS;
         job.p[0] = sinks->dw1; job.p[1] = sinks->dw2; job.p[2] = sinks->db1; job.p[3] = sinks->db2; job.p[4] = sinks->dgamma; job.p[5] = sinks->dbeta;
         job.ld[0] = sinks->ld_dw1; job.k_real = sinks->k_real; job.o_real = sinks->o_real;
         return grad_reduce_submit(job, s);
     }
-    hipLaunchKernelGGL(mlp_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, G, n, grads);
+    hipLaunchKernelGGL(mlp_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.partial, mlp_bwd_slots(a.R), n, grads);
     P4C_CHECK_LAUNCH("mlp_param_reduce");
     return P4C_OK;
 }
@@ -858,7 +919,7 @@ static MlpArgs to_args(const p4c_row_mlp_desc* d) {
     a.ga = (const bf16*)d->gather_a; a.ia = d->index_a; a.gb = (const bf16*)d->gather_b; a.ib = d->index_b;
     a.res = (const bf16*)d->res; a.out = (bf16*)d->out; a.out_res = (bf16*)d->out_res;
     a.dy = (const bf16*)d->dy; a.dy_res = (const bf16*)d->dy_res; a.dx = (bf16*)d->dx; a.dpre = (bf16*)d->dpre;
-    a.partial = nullptr; a.R = d->rows; a.prepared = d->prepared;
+    a.partial = nullptr; a.R = d->rows; a.prepared = d->prepared; a.dx_add_dyr = d->dx_plus_dy_res;
     return a;
 }
 
@@ -881,7 +942,7 @@ extern "C" int p4c_row_mlp_fwd(const p4c_row_mlp_desc* d, p4c_stream_t stream) {
 
 extern "C" size_t p4c_row_mlp_bwd_workspace_bytes(int64_t rows, int k) {
     if (rows <= 0 || k <= 0) return 0;
-    return (size_t)mlp_grid(rows, 1) * (HID * (size_t)k + HID * HID + 4 * HID) * sizeof(float);
+    return (size_t)mlp_bwd_slots(rows) * (HID * (size_t)k + HID * HID + 4 * HID) * sizeof(float);
 }
 
 static int row_mlp_bwd_common(const char* name, const p4c_row_mlp_desc* d, float* grads, const GradSinks* sinks, void* workspace,
@@ -890,6 +951,7 @@ static int row_mlp_bwd_common(const char* name, const p4c_row_mlp_desc* d, float
     int rc = check_args(name, a, d->k);
     if (rc != P4C_OK) return rc;
     P4C_CHECK_ARG(a.dy || a.dy_res, "%s: no upstream gradient", name);
+    P4C_CHECK_ARG(!a.dx_add_dyr || (d->k == 64 && a.dx && a.dy_res), "%s: dx_plus_dy_res needs k = 64, dx and dy_res", name);
     a.partial = reinterpret_cast<float*>(workspace);
     hipStream_t s = as_stream(stream);
     switch (d->k / 16) {

@@ -68,7 +68,11 @@ template <int NP, bool DGRAD>
 __device__ __forceinline__ void build_images(__bf16* img, const NodeProjArgs& a) {
     constexpr int TILES = DGRAD ? 2 : 2 * NP, S = DGRAD ? 4 * NP : 4;
     constexpr int pieces = TILES * S * 64;
-    for (int idx = threadIdx.x; idx < pieces; idx += 256) {
+    static_assert(pieces % 256 == 0, "whole trips of the 256-thread workgroup");
+    // (a compile-time trip count: unrolled, every trip's weight loads are in flight together -- one memory round trip per launch)
+#pragma unroll
+    for (int it = 0; it < pieces / 256; ++it) {
+        const int idx = threadIdx.x + 256 * it;
         const int ln = idx & 63, ts = idx >> 6;
         const int s = ts % S, tile = ts / S;
         const int m = 32 * tile + (ln & 31), k0 = 16 * s + 8 * (ln >> 5);

@@ -200,19 +200,22 @@ class InteractionNet(nn.Module):
     def forward(self, send_rep, rec_rep, edge_rep, edges: G.EdgeSet):
         C = self.hidden
         lin0, lin1, ln = self.edge_mlp[0], self.edge_mlp[2], self.edge_mlp[3]
-        part = None
+        part, rec_res = None, rec_rep
         if edge_rep.dtype == torch.bfloat16 and C == 64 and edge_rep.shape[0] >= 1:
             # sender / receiver parts of the first Linear once per NODE, everything per EDGE in one kernel:
             # e W_e + a[src] + b[dst] + bias -> SiLU -> Linear -> LayerNorm -> msg (and edge_rep + msg)
             # the projections of one node tensor are ONE launch each way (ops_nodeproj.node_proj: their input gradients are one K = 64 n
             # product, their weight gradients one launch into the batched reduction); `part` is the receiver part of the node-update
             # MLP's first Linear, used after the aggregation below
+            # (rec_res IS rec_rep, handed back by the projection node: the residual's gradient is then summed inside that node's
+            # data-gradient launch instead of by an element-wise launch of autograd's)
             al0 = self.aggr_mlp[0]
             if send_rep is rec_rep:
-                a, b, part = NP.node_proj(rec_rep, [lin0.weight[:, C:2 * C], lin0.weight[:, 2 * C:], al0.weight[:, :C]], GRADS_IN_PLACE)
+                a, b, part, rec_res = NP.node_proj(rec_rep, [lin0.weight[:, C:2 * C], lin0.weight[:, 2 * C:], al0.weight[:, :C]],
+                                                   GRADS_IN_PLACE, passthrough=True)
             else:
                 a, = NP.node_proj(send_rep, [lin0.weight[:, C:2 * C]], GRADS_IN_PLACE)
-                b, part = NP.node_proj(rec_rep, [lin0.weight[:, 2 * C:], al0.weight[:, :C]], GRADS_IN_PLACE)
+                b, part, rec_res = NP.node_proj(rec_rep, [lin0.weight[:, 2 * C:], al0.weight[:, :C]], GRADS_IN_PLACE, passthrough=True)
             msg, new_edge = M.row_mlp(edge_rep, lin0.weight[:, :C], lin0.bias, lin1.weight, lin1.bias, ln.weight, ln.bias, ln.eps,
                                       ga=a, gb=b, edges=edges, res=edge_rep if self.update_edges else None,
                                       grads_in_place=GRADS_IN_PLACE)
@@ -237,9 +240,9 @@ class InteractionNet(nn.Module):
         if rec_rep.dtype == torch.bfloat16 and C == 64 and rec_rep.shape[0] >= 1:
             # Linear over cat[x_r, agg] = x_r W[:, :C]^T (small library GEMM, row-aligned addend) + agg W[:, C:]^T (fused kernel's x)
             if part is None:
-                part, = NP.node_proj(rec_rep, [al0.weight[:, :C]], GRADS_IN_PLACE)
+                part, rec_res = NP.node_proj(rec_rep, [al0.weight[:, :C]], GRADS_IN_PLACE, passthrough=True)
             _, rec_rep = M.row_mlp(agg, al0.weight[:, C:], al0.bias, al1.weight, al1.bias, aln.weight, aln.bias, aln.eps,
-                                   ga=part, res=rec_rep, want_out=False, grads_in_place=GRADS_IN_PLACE)
+                                   ga=part, res=rec_res, want_out=False, grads_in_place=GRADS_IN_PLACE)
         else:
             rec_rep = _run(self.aggr_mlp, torch.cat([rec_rep, agg], dim=-1), res=rec_rep)
         if self.update_edges:

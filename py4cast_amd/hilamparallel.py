@@ -71,7 +71,7 @@ def _node_update(mlp: nn.Sequential, rec, agg):
     C = rec.shape[1]
     al0, al1, aln = mlp[0], mlp[2], mlp[3]
     if rec.dtype == torch.bfloat16 and C == 64:
-        part, = NP.node_proj(rec, [al0.weight[:, :C]], _gl.GRADS_IN_PLACE)
+        part, rec = NP.node_proj(rec, [al0.weight[:, :C]], _gl.GRADS_IN_PLACE, passthrough=True)
         return M.row_mlp(agg, al0.weight[:, C:], al0.bias, al1.weight, al1.bias, aln.weight, aln.bias, aln.eps, ga=part, res=rec,
                          want_out=False, grads_in_place=_gl.GRADS_IN_PLACE)[1]
     return _run(mlp, torch.cat([rec, agg], dim=-1), res=rec)

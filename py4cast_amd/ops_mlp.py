@@ -57,8 +57,9 @@ def _prepared(d: RowMlpDesc, K: int, tensors, device, owners=None) -> torch.Tens
 class _RowMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges: Optional[EdgeSet], eps: float, want_out: bool, sinks=None,
-                owners=None):
+                owners=None, res_is_x: bool = False):
         R, K = x.shape
+        ctx.res_is_x = bool(res_is_x) and K == 64
         x = x.contiguous()
         for t in (w1, w2):
             if t.dtype != torch.float32 or t.stride(1) != 1:
@@ -99,7 +100,7 @@ class _RowMLP(torch.autograd.Function):
         dy = None if dout is None else dout.contiguous()
         dyr = None if dout_res is None else dout_res.contiguous()
         if dy is None and dyr is None:
-            return (None,) * 14
+            return (None,) * 16
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty_like(x) if need_dx else None
         gathered = ga is not None or gb is not None
@@ -111,6 +112,9 @@ class _RowMLP(torch.autograd.Function):
         d = _desc(x, K, w1.detach(), b1, w2, b2, gamma, beta, ctx.eps, ga, ia, gb, ib, None, None, None, dy, dyr, dx, dpre)
         blob = ctx.prepared_blob   # the images the forward used (the parameters cannot have changed in between: autograd checks)
         d.prepared = blob.data_ptr()
+        # res IS x (an edge update): the kernel stores dx + dy_res, the whole gradient of that tensor (no element-wise launch of autograd's)
+        fold_res = ctx.res_is_x and has_res and need_dx and dyr is not None
+        d.dx_plus_dy_res = int(fold_res)
         rows_io = 1 + (dy is not None) + (dyr is not None) + need_dx * K / 64 + gathered
         n_gath = sum(min(R, t.shape[0]) for t in (ga, gb) if t is not None)
         nbytes = R * K * 2 + (rows_io - 1) * R * 128 + n_gath * 128 + 4 * R * ((ga is not None) + (gb is not None))
@@ -145,8 +149,8 @@ class _RowMLP(torch.autograd.Function):
             else:
                 dga = _segment_sum_raw(dpre, *edges.by_src, edges.n_src) if want_a else None
                 dgb = _segment_sum_raw(dpre, *edges.by_dst, edges.n_dst) if want_b else None
-        dres = dyr if has_res else None
-        return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None, None, None
+        dres = dyr if (has_res and not fold_res) else None
+        return dx, dw1, db1, dw2, db2, dgam, dbet, dga, dgb, dres, None, None, None, None, None, None
 
 
 def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=None, beta=None, eps: float = 1e-5,
@@ -157,6 +161,7 @@ def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=N
     ga / gb: (n_src, 64) / (n_dst, 64) rows added to the pre-activation through edges.src / edges.dst; with ``edges=None`` they
     are row-aligned addends (R, 64) -- e.g. the other half of a Linear over a concatenation of two 64-feature sources."""
     L.require_cuda(x)
+    res_is_x = res is x and x.shape[1] == 64
     kp = (-x.shape[1]) % 16
     if kp:
         x = F.pad(x, (0, kp))
@@ -167,7 +172,7 @@ def row_mlp(x: torch.Tensor, w1: torch.Tensor, b1, w2: torch.Tensor, b2, gamma=N
         # LIVE so that the node is recorded even when neither x nor the addends / residual need a gradient (first AR step of an
         # embedder: all inputs are data) -- its slot returns None in the backward, as _RowLinearSink does for its weight
         b1, w2, b2, gamma, beta = (None if t is None else t.detach() for t in (b1, w2, b2, gamma, beta))
-    return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out, sinks, owners)
+    return _RowMLP.apply(x, w1, b1, w2, b2, gamma, beta, ga, gb, res, edges, eps, want_out, sinks, owners, res_is_x)
 
 
 from .ops_rows import grad_view as _grad_view  # noqa: E402  (one definition, shared with ops_rows.row_linear)

@@ -75,42 +75,46 @@ def _lds(tensors: Sequence[torch.Tensor]):
 
 class _NodeProj(torch.autograd.Function):
     """(x W_1^T, ..., x W_n^T) for bf16 node rows x (R, 64) and 64 x 64 blocks W_i of fp32 master weights, as one autograd node whose
-    backward ADDS every weight gradient into ``gws[i]`` -- the view of the parameter's ``.grad`` that corresponds to W_i."""
+    backward ADDS every weight gradient into ``gws[i]`` -- the view of the parameter's ``.grad`` that corresponds to W_i.
+    ``passthrough``: x itself is returned as one more output (the residual operand of the node-update MLP): its gradient then arrives
+    HERE and is added inside the data-gradient launch instead of by an element-wise launch of autograd's."""
 
     @staticmethod
-    def forward(ctx, x, n, *args):
+    def forward(ctx, x, n, passthrough, *args):
         ws, gws = args[:n], args[n:]
-        x = x.contiguous()
-        R = x.shape[0]
-        ys = [torch.empty(R, 64, dtype=x.dtype, device=x.device) for _ in range(n)]
+        xc = x.contiguous()
+        R = xc.shape[0]
+        ys = [torch.empty(R, 64, dtype=xc.dtype, device=xc.device) for _ in range(n)]
         wd = [w.detach() for w in ws]
-        L.call("p4c_node_proj_fwd", L.ptr(x), R, n, _arr(wd), _lds(wd), _arr(ys), L.stream(x.device),
+        L.call("p4c_node_proj_fwd", L.ptr(xc), R, n, _arr(wd), _lds(wd), _arr(ys), L.stream(xc.device),
                alg_bytes=R * 128 * (1 + n) + n * 64 * 64 * 4, alg_flops=2 * R * 64 * 64 * n)
-        ctx.save_for_backward(x, *wd)
-        ctx.gws, ctx.n = gws, n
-        return tuple(ys)
+        ctx.save_for_backward(xc, *wd)
+        ctx.gws, ctx.n, ctx.passthrough = gws, n, passthrough
+        return tuple(ys) + ((x,) if passthrough else ())
 
     @staticmethod
     def backward(ctx, *dys):
         x, *wd = ctx.saved_tensors
         n, R = ctx.n, x.shape[0]
+        none = (None,) * (2 + 2 * n)
+        dres = dys[n].contiguous() if (ctx.passthrough and dys[n] is not None) else None
         live = [i for i in range(n) if dys[i] is not None]
         if not live:
-            return (None, None) + (None,) * (2 * n)
+            return (dres,) + none
         dyl = [dys[i].contiguous() for i in live]
         wl = [wd[i] for i in live]
         m = len(live)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.call("p4c_node_proj_dgrad", _arr(dyl), R, m, _arr(wl), _lds(wl), L.ptr(dx), None, L.stream(x.device),
-                   alg_bytes=R * 128 * (1 + m) + m * 64 * 64 * 4, alg_flops=2 * R * 64 * 64 * m)
+            L.call("p4c_node_proj_dgrad", _arr(dyl), R, m, _arr(wl), _lds(wl), L.ptr(dx), L.ptr(dres), L.stream(x.device),
+                   alg_bytes=R * 128 * (1 + m + (dres is not None)) + m * 64 * 64 * 4, alg_flops=2 * R * 64 * 64 * m)
         gl = [ctx.gws[i] for i in live]
         ws = torch.empty(max(L.lib().p4c_node_proj_wgrad_workspace_bytes(R, m) // 4, 1), dtype=torch.float32, device=x.device)
         GradQueue.begin(ws)
         L.call("p4c_node_proj_wgrad", _arr(dyl), L.ptr(x), R, m, _arr(gl), _lds(gl), L.ptr(ws), L.stream(x.device),
                alg_bytes=R * 128 * (1 + m) + ws.numel() * 4, alg_flops=2 * R * 64 * 64 * m)
-        return (dx, None) + (None,) * (2 * n)
+        return (dx,) + none
 
 
 def node_proj_ok(x: torch.Tensor, weights) -> bool:
@@ -118,14 +122,15 @@ def node_proj_ok(x: torch.Tensor, weights) -> bool:
             and all(w.dtype == torch.float32 and w.dim() == 2 and tuple(w.shape) == (64, 64) and w.stride(1) == 1 for w in weights))
 
 
-def node_proj(x: torch.Tensor, weights, grads_in_place: bool = True):
+def node_proj(x: torch.Tensor, weights, grads_in_place: bool = True, passthrough: bool = False):
     """``[x @ w.T for w in weights]``: bf16 rows of 64 features, up to three 64 x 64 fp32 blocks (column slices of wider Linear weights
     are fine).  With gradient buffers on every weight (FlatDDP / Trainer allocate them) ONE launch per direction (module docstring);
-    otherwise one ``ops_rows.row_linear`` each (autograd-returned weight gradients)."""
+    otherwise one ``ops_rows.row_linear`` each (autograd-returned weight gradients).  ``passthrough``: x is appended to the results --
+    use THAT tensor as the residual of the node update that follows, and its gradient is summed inside the data-gradient launch."""
     L.require_cuda(x)
     weights = list(weights)
     if grads_in_place and node_proj_ok(x, weights) and torch.is_grad_enabled() and all(w.requires_grad for w in weights):
         gws = [grad_view(w) for w in weights]
         if all(g is not None and g is not False and g.stride(1) == 1 for g in gws):
-            return _NodeProj.apply(x, len(weights), *weights, *gws)
-    return tuple(row_linear(x, w, grads_in_place=grads_in_place) for w in weights)
+            return _NodeProj.apply(x, len(weights), bool(passthrough), *weights, *gws)
+    return tuple(row_linear(x, w, grads_in_place=grads_in_place) for w in weights) + ((x,) if passthrough else ())

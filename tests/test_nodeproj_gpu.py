@@ -154,3 +154,73 @@ def test_queue_flushes_more_jobs_than_one_launch_holds(gpu_device):
     assert lib.p4c_grad_reduce_pending() == 0
     assert lib.p4c_grad_reduce_defer(1) == 0 and lib.p4c_grad_reduce_defer(-1) == 1 and lib.p4c_grad_reduce_defer(0) == 0
     L.check(lib.p4c_grad_reduce_flush(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def test_node_proj_passthrough_sums_the_residual_gradient_inside_the_launch(gpu_device):
+    """passthrough=True hands x back as one more output; a gradient arriving there (the node update's residual) is added inside the
+    data-gradient launch: x.grad = sum_i dy_i W_i + d(res) against float64, and equals the route without passthrough up to the bf16
+    rounding of the intermediate sum"""
+    from py4cast_amd.ops_nodeproj import node_proj
+
+    wide, aggr = _weights(gpu_device, 61)
+    wide.grad, aggr.grad = torch.zeros_like(wide), torch.zeros_like(aggr)
+    torch.manual_seed(62)
+    R = 1458
+    x = torch.randn(R, 64, device=gpu_device).bfloat16().requires_grad_(True)
+    blocks = [wide[:, 128:], aggr[:, :64]]
+    cots = [torch.randn(R, 64, device=gpu_device).bfloat16() for _ in range(3)]
+    b, part, xr = node_proj(x, blocks, passthrough=True)
+    assert xr.data_ptr() == x.data_ptr() and xr.requires_grad
+    ((b.float() * cots[0].float()).sum() + (part.float() * cots[1].float()).sum() + (xr.float() * cots[2].float()).sum()).backward()
+    ref = cots[0].double() @ blocks[0].detach().bfloat16().double() + cots[1].double() @ blocks[1].detach().bfloat16().double() + cots[2].double()
+    assert _rel(x.grad, ref) < 4e-3
+    got = x.grad.clone()
+    x.grad = None
+    b, part = node_proj(x, blocks)
+    ((b.float() * cots[0].float()).sum() + (part.float() * cots[1].float()).sum() + (x.float() * cots[2].float()).sum()).backward()
+    assert _rel(got, x.grad) < 1e-2
+    # only the residual gradient arrives: it passes through unchanged
+    x.grad = None
+    _, _, xr = node_proj(x, blocks, passthrough=True)
+    (xr.float() * cots[2].float()).sum().backward()
+    assert torch.equal(x.grad, cots[2])
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_row_mlp_with_res_is_x_folds_both_gradients_into_dx(gpu_device, gather):
+    """an edge update e <- e + MLP(e, ...): res IS x, the kernel stores dx + dy_res (p4c_row_mlp_desc.dx_plus_dy_res); equal to the two
+    separate gradients summed by autograd up to one bf16 rounding, parameter gradients bit-identical"""
+    from py4cast_amd import ops_graph as G
+    from py4cast_amd.ops_mlp import row_mlp
+
+    torch.manual_seed(71)
+    R, N = 3001, 257
+    e0 = torch.randn(R, 64, device=gpu_device).bfloat16()
+    ga = torch.randn(N, 64, device=gpu_device).bfloat16()
+    src, dst = torch.randint(0, N, (R,)), torch.randint(0, N, (R,))
+    es = G.EdgeSet(src, dst, N, N).to(gpu_device) if gather else None
+    cot = [torch.randn(R, 64, device=gpu_device).bfloat16() for _ in range(2)]
+
+    def run(same):
+        wide, _ = _weights(gpu_device, 72)
+        torch.manual_seed(73)
+        b1, b2, beta = [(torch.randn(64, device=gpu_device) * 0.1).requires_grad_(True) for _ in range(3)]
+        w2 = (torch.randn(64, 64, device=gpu_device) * 0.1).requires_grad_(True)
+        gamma = (torch.rand(64, device=gpu_device) + 0.5).requires_grad_(True)
+        params = [wide, b1, w2, b2, gamma, beta]
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        e = e0.clone().requires_grad_(True)
+        r = e if same else e0.clone().requires_grad_(True)
+        kw = dict(ga=ga, gb=ga, edges=es) if gather else {}
+        msg, new_e = row_mlp(e, wide[:, :64], b1, w2, b2, gamma, beta, 1e-5, res=r, grads_in_place=True, **kw)
+        ((msg.float() * cot[0].float()).sum() + (new_e.float() * cot[1].float()).sum()).backward()
+        total = e.grad.float() if same else e.grad.float() + r.grad.float()
+        return msg.detach(), new_e.detach(), total, [p.grad.clone() for p in params]
+
+    m1, n1, g1, p1 = run(True)
+    m0, n0, g0, p0 = run(False)
+    assert torch.equal(m1, m0) and torch.equal(n1, n0)
+    assert _rel(g1, g0) < 4e-3
+    for a, b in zip(p1, p0):
+        assert torch.equal(a, b)
