@@ -14,6 +14,9 @@ Accurate 3D Medical Image Segmentation", and its MONAI-style building blocks) in
             tokens applied to (F v_SA), E and F sharing one Linear over the token axis; the two halves projected to C/2 each
             and concatenated.  The matrices are formed literally here (transposes, F.normalize, matmul), which is the
             independent formulation the product's tall-skinny kernels are checked against.
+  published_block (default, round 6): the block exactly as the published code / mfai's wrapper writes it -- x_SA merged by
+            ``permute(0, 3, 1, 2).reshape(B, N, C)``, ``conv8 = Sequential(Dropout2d(0.1), Conv2d)``, ``E`` also registered as ``F``, the two
+            attention dropouts; published_block=False: the restated block of rounds 2-5 (x_SA head-major per token, bare conv8).
   decoder : up-sampling (bilinear + 1x1 conv, or transposed conv) + skip + `depth` transformer blocks; the last stage is a
             residual conv block at full resolution fed by a full-resolution residual conv block of the input; 1x1 output conv.
 
@@ -57,13 +60,16 @@ class ResBlock(nn.Module):
 
 
 class EPA(nn.Module):
-    def __init__(self, tokens, hidden, proj, heads):
+    def __init__(self, tokens, hidden, proj, heads, published=False, attn_drop=0.0):
         super().__init__()
-        self.heads = heads
+        self.heads, self.published = heads, published
         self.temperature = nn.Parameter(torch.ones(heads, 1, 1))
         self.temperature2 = nn.Parameter(torch.ones(heads, 1, 1))
         self.qkvv = nn.Linear(hidden, hidden * 4, bias=False)
         self.E = nn.Linear(tokens, proj)          # E and F share these weights
+        if published:                             # the published module list: ``self.E = self.F = nn.Linear(..)`` + the two attention dropouts
+            self.F = self.E
+            self.attn_drop, self.attn_drop_2 = nn.Dropout(attn_drop), nn.Dropout(attn_drop)
         self.out_proj = nn.Linear(hidden, hidden // 2)
         self.out_proj2 = nn.Linear(hidden, hidden // 2)
 
@@ -76,20 +82,27 @@ class EPA(nn.Module):
         q = F.normalize(q, dim=-1)
         k = F.normalize(k, dim=-1)
         attn_ca = ((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1)                  # (B,h,d,d)
+        if self.published:
+            attn_ca = self.attn_drop(attn_ca)
         x_ca = (attn_ca @ v_ca).permute(0, 3, 1, 2).reshape(B, N, C)
         attn_sa = ((q.permute(0, 1, 3, 2) @ k_proj) * self.temperature2).softmax(dim=-1)          # (B,h,N,p)
-        x_sa = (attn_sa @ v_sa_proj.transpose(-2, -1)).permute(0, 2, 1, 3).reshape(B, N, C)       # token-major, heads side by side
+        if self.published:
+            # as the published code writes it: the (B, d, h, N) order read as (N, C) -- a fixed permutation that mixes tokens and channels
+            x_sa = (self.attn_drop_2(attn_sa) @ v_sa_proj.transpose(-2, -1)).permute(0, 3, 1, 2).reshape(B, N, C)
+        else:
+            x_sa = (attn_sa @ v_sa_proj.transpose(-2, -1)).permute(0, 2, 1, 3).reshape(B, N, C)   # token-major, heads side by side
         return torch.cat([self.out_proj(x_sa), self.out_proj2(x_ca)], dim=-1)
 
 
 class TransformerBlock(nn.Module):
-    def __init__(self, tokens, hidden, proj, heads):
+    def __init__(self, tokens, hidden, proj, heads, published=False, conv8_dropout=0.0, attn_drop=0.0):
         super().__init__()
         self.norm = nn.LayerNorm(hidden)
         self.gamma = nn.Parameter(1e-6 * torch.ones(hidden))
-        self.epa_block = EPA(tokens, hidden, proj, heads)
+        self.epa_block = EPA(tokens, hidden, proj, heads, published, attn_drop)
         self.conv51 = ResBlock(hidden, hidden, "batch")
-        self.conv8 = nn.Conv2d(hidden, hidden, 1)
+        # published: Sequential(Dropout(0.1, False), Conv) -> state-dict keys conv8.1.*
+        self.conv8 = nn.Sequential(nn.Dropout2d(conv8_dropout, False), nn.Conv2d(hidden, hidden, 1)) if published else nn.Conv2d(hidden, hidden, 1)
         self.pos_embed = nn.Parameter(torch.zeros(1, tokens, hidden))
 
     def forward(self, x):
@@ -101,7 +114,7 @@ class TransformerBlock(nn.Module):
 
 
 class UpBlock(nn.Module):
-    def __init__(self, cin, cout, scale, tokens, proj, heads, depth, conv_decoder, linear, norm):
+    def __init__(self, cin, cout, scale, tokens, proj, heads, depth, conv_decoder, linear, norm, block_kw=None):
         super().__init__()
         self.scale, self.linear = scale, linear
         if linear:
@@ -111,7 +124,8 @@ class UpBlock(nn.Module):
         if conv_decoder:
             self.decoder_block = nn.ModuleList([ResBlock(cout, cout, norm)])
         else:
-            self.decoder_block = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens, cout, proj, heads) for _ in range(depth)])])
+            self.decoder_block = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens, cout, proj, heads, **(block_kw or {}))
+                                                                for _ in range(depth)])])
 
     def forward(self, x, skip):
         if self.linear:
@@ -124,8 +138,9 @@ class UpBlock(nn.Module):
 class UNetRPP(nn.Module):
     def __init__(self, in_channels, out_channels, input_shape, hidden_size=1024, num_heads_encoder=16, num_heads_decoder=4,
                  depths=(3, 3, 3, 3), downsampling_rate=4, decoder_proj_size=64, encoder_proj_sizes=(64, 64, 64, 32),
-                 linear_upsampling=True, norm_name="instance"):
+                 linear_upsampling=True, norm_name="instance", published_block=True, conv8_dropout=0.1, dropout_rate=0.0):
         super().__init__()
+        bkw = dict(published=bool(published_block), conv8_dropout=float(conv8_dropout), attn_drop=float(dropout_rate))
         H, W = input_shape
         r = downsampling_rate
         fs = hidden_size // 16
@@ -138,13 +153,13 @@ class UNetRPP(nn.Module):
                                                     if dims[0] % in_channels == 0 else nn.GroupNorm(1, dims[0])))
         for i in range(3):
             self.downsample_layers.append(nn.Sequential(nn.Conv2d(dims[i], dims[i + 1], 2, stride=2, bias=False), nn.GroupNorm(dims[i], dims[i + 1])))
-        self.stages = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens[i], dims[i], encoder_proj_sizes[i], num_heads_encoder)
+        self.stages = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens[i], dims[i], encoder_proj_sizes[i], num_heads_encoder, **bkw)
                                                      for _ in range(depths[i])]) for i in range(4)])
         self.encoder1 = ResBlock(in_channels, fs, norm_name)
-        self.decoder5 = UpBlock(dims[3], dims[2], 2, tokens[2], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name)
-        self.decoder4 = UpBlock(dims[2], dims[1], 2, tokens[1], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name)
-        self.decoder3 = UpBlock(dims[1], dims[0], 2, tokens[0], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name)
-        self.decoder2 = UpBlock(dims[0], fs, r, H * W, decoder_proj_size, num_heads_decoder, 3, True, linear_upsampling, norm_name)
+        self.decoder5 = UpBlock(dims[3], dims[2], 2, tokens[2], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name, bkw)
+        self.decoder4 = UpBlock(dims[2], dims[1], 2, tokens[1], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name, bkw)
+        self.decoder3 = UpBlock(dims[1], dims[0], 2, tokens[0], decoder_proj_size, num_heads_decoder, 3, False, linear_upsampling, norm_name, bkw)
+        self.decoder2 = UpBlock(dims[0], fs, r, H * W, decoder_proj_size, num_heads_decoder, 3, True, linear_upsampling, norm_name, bkw)
         self.out1 = nn.Conv2d(fs, out_channels, 1)
 
     def forward(self, x):

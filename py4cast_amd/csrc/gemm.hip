@@ -187,7 +187,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_kernel(NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4][A 16 KB | B 16 KB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x, tm = tile % a.tiles_m, tn = tile / a.tiles_m;
+    // XCD-aware tile order (round 6).  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), and for the
+    // convolution a 128-row M tile is one image row at W = 128 whose two halo rows belong to the neighbouring tiles: with tile =
+    // blockIdx.x every input row was pulled into three L2s (PMC: 3 x the map fetched, r05_pmc_traffic_gemm_nt.json).  The bijective
+    // remap of cdna_hip_programming.md (T1) gives each XCD a CONTIGUOUS band of tiles: a row is shared inside one L2, only the band
+    // edges are fetched twice.  A pure speed choice: any placement computes the same tiles.
+    int tile;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+        if (P4C_NT_EXP & 32) tile = blockIdx.x;
+    }
+    const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int kb0 = split * a.kb_per_split;

@@ -4,28 +4,30 @@ The reference takes the class from mfai v5.0.1 (py4cast/models.py:10-20), which 
 restated from the published one (oracle/unetrpp.py spells out every block) and the arithmetic is checked against that oracle, whose
 attention forms the matrices literally.
 
-What runs where (state after round 3; DESIGN.md section 7b has the numbers)
+What runs where (state after round 6; DESIGN.md section 7 has the numbers)
 * efficient paired attention (EPA), forward and backward, as ONE autograd node (``ops_ts.epa_core``): the tall-skinny HIP kernels
   of csrc/tallskinny.hip on the matrix cores -- ``gram`` (q^T k with the squared column norms of q and k from one pass over the
   16 384 ... 256 tokens of a stage) and ``apply`` (v A^T, q M, S VP^T: per-token small products, the spatial branch's softmax and
   its adjoint in their epilogues), addressed in place inside the qkvv projection's output (no head split / transpose / contiguous
   copies; the literal formulation makes eight of them per block).  The d x d and d x p matrices in between (column norms,
   temperature, channel softmax, scaled token projection) are ONE native launch each way (``p4c_epa_small_fwd/bwd``).
-* LayerNorm of every block: csrc/rows.hip (row LayerNorm).
+* (x + pos_embed) and its LayerNorm: one pass of csrc/rows.hip; qkvv / out_proj / out_proj2 / conv8 / the 2 x 2 down-samplings /
+  the 1 x 1 up-convolutions and every 128 ... 1024-channel 3 x 3 convolution with its batch norm: csrc/gemm.hip (tiled GEMM and
+  implicit-GEMM convolution with bias / residual / statistics epilogues, round 5); bilinear up-sampling + skip: csrc/resize.hip.
 * the two full-resolution 64-channel residual blocks (encoder1 / decoder2): the MFMA convolution kernels of csrc/conv_rows.hip /
-  conv_bf16.hip + the native instance-norm nodes (csrc/inorm.hip); the 1 x 1 output head: a row GEMM (csrc/rowgemm.hip) over the
-  features-last pixel rows; the patch stem / 2 x 2 down-samplings / transposed convolutions: GEMMs over pixel blocks.
-* still library calls (MIOpen pinned to its deterministic solvers through ``OM.library_conv2d``, hipBLASLt): the 3 x 3 / 1 x 1
-  convolutions and the batch norms of the 128 ... 1024-channel blocks at <= 1/4 resolution, the token-axis projection E = F (a
-  Linear over N) and the qkvv / output projections.
-Known differences from the published UNETR++ block that mfai wraps (advisor review, round 2; NOT checkpoint compatible):
-* the spatial-attention branch is merged head-major per token (``permute(0, 2, 1, 3)``: token n keeps its own heads x d values); the
-  published code writes ``(attn_SA @ v_SA^T).permute(0, 3, 1, 2).reshape(B, N, C)``, a fixed permutation of the (N x C) entries that
-  mixes tokens and channels -- a quirk of that code, not of the method;
-* ``conv8`` is a bare 1x1 convolution here; the published block is ``Sequential(Dropout(0.1), Conv)`` (state-dict keys ``conv8.1.*``)
-  and has two more dropouts on the attention maps -- no dropout is drawn here (deterministic step, HIP-graph capturable);
-mfai 5.0.1 is absent from this container, so which of the two forms it ships could not be checked: the UNetRPP bench line is a
-"restated architecture" figure (bench.py says so in ``config.workload``), same tensor shapes and operation counts.
+  conv_bf16.hip + the native instance-norm nodes (csrc/inorm.hip); the 1 x 1 output head: a row GEMM (csrc/rowgemm.hip).
+* still a library call: the token-axis projection E = F (a Linear over N, hipBLASLt).
+
+``UNetRPPSettings.published_block`` (round 6, default True) selects the block AS PUBLISHED (Shaker et al., the code mfai wraps), so
+that state dicts have the published keys and a checkpoint trained there means the same function here:
+* the spatial-attention branch is merged as the published code writes it, ``(attn_SA @ v_SA^T).permute(0, 3, 1, 2).reshape(B, N, C)``
+  -- a fixed permutation of the (N x C) entries that mixes tokens and channels (one gather copy per block here);
+* ``conv8 = Sequential(Dropout2d(0.1), Conv2d)`` (keys ``conv8.1.*``; the channel dropout is drawn in training mode, p =
+  ``conv8_dropout``), ``E`` and ``F`` are one Linear registered under both names (keys ``E.*`` and ``F.*``), and the two attention
+  dropouts exist as modules (p = ``dropout_rate``, which must be 0 here);
+``published_block=False`` is the restated block of rounds 2-5: x_SA merged head-major per token (``permute(0, 2, 1, 3)``: a free view of
+the kernels' output), a bare ``conv8`` convolution, no dropout (a bit-reproducible step).  mfai 5.0.1 is absent from this container, so
+both forms are checked against oracle/unetrpp.py with the same switch (PARITY UNPINNED); bench.py names the form it ran.
 Input / output are features-last (B, H, W, C); H and W must be multiples of 8 * downsampling_rate.  ``attention_code``
 ("torch" | "flash" | "manual" in mfai) is accepted and ignored: all of them are this one fused formulation.
 """
@@ -73,6 +75,8 @@ class UNetRPPSettings:
     add_skip_connections: bool = True
     attention_code: str = "torch"
     activation_dtype: str = "f32"   # "bf16": token tensors and convolutions in bf16 (trainer.precision bf16)
+    published_block: bool = True    # the transformer block as published / as mfai wraps it (module docstring); False: the restated block
+    conv8_dropout: float = 0.1      # published_block: p of the channel dropout in front of conv8 (hard-coded 0.1 in the published code)
 
 
 def _norm(name, ch):
@@ -251,15 +255,25 @@ class EPA(nn.Module):
     Normalising q along the tokens scales COLUMN i of q by 1 / nq_i, which is folded into the small matrices (rows of KP, the
     outer product under G): the N x d normalised copies of q and k are never formed."""
 
-    def __init__(self, tokens, hidden, proj, heads):
+    def __init__(self, tokens, hidden, proj, heads, published=False, attn_drop=0.0):
         super().__init__()
-        self.heads = heads
+        self.heads, self.published = heads, published
         self.temperature = nn.Parameter(torch.ones(heads, 1, 1))
         self.temperature2 = nn.Parameter(torch.ones(heads, 1, 1))
         self.qkvv = nn.Linear(hidden, hidden * 4, bias=False)
         self.E = nn.Linear(tokens, proj)
+        if published:      # the published module list: E and F are ONE Linear under two names, two (identity at p = 0) attention dropouts
+            self.F = self.E
+            self.attn_drop, self.attn_drop_2 = nn.Dropout(attn_drop), nn.Dropout(attn_drop)
         self.out_proj = nn.Linear(hidden, hidden // 2)
         self.out_proj2 = nn.Linear(hidden, hidden // 2)
+
+    def _merge_sa(self, x_sa, B, N, C):
+        """(B, h, N, d) -> (B, N, C): head-major per token (restated block: a view of the kernels' token-major output), or the published
+        code's ``permute(0, 3, 1, 2).reshape(B, N, C)`` -- the (B, d, h, N) order read as (N, C): one gather copy"""
+        if self.published:
+            return x_sa.permute(0, 3, 1, 2).reshape(B, N, C)
+        return x_sa.permute(0, 2, 1, 3).reshape(B, N, C)
 
     def _project_out(self, x_sa, x_ca, res, gamma):
         """cat(out_proj(x_sa), out_proj2(x_ca)) -- or, given the block's residual t and layer scale gamma, t + gamma * that cat with
@@ -283,8 +297,7 @@ class EPA(nn.Module):
         if x.is_cuda and os.environ.get("P4C_EPA_CORE") != "0" and TS.epa_core_ok(qkvv, self.E.out_features):
             # the attention between the projections as one node: its backward writes dq / dk / dv straight into the gradient of qkvv
             x_sa, x_ca = TS.epa_core(qkvv, self.E.weight, self.E.bias, self.temperature, self.temperature2)
-            x_sa, x_ca = (t.permute(0, 2, 1, 3).reshape(B, N, C) for t in (x_sa, x_ca))
-            return self._project_out(x_sa, x_ca, res, gamma)
+            return self._project_out(self._merge_sa(x_sa, B, N, C), x_ca.permute(0, 2, 1, 3).reshape(B, N, C), res, gamma)
         q, k, v_ca, v_sa = _SplitQKVV.apply(qkvv)                                          # (B,h,N,d) views, nothing copied
         if d % 4:
             raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")
@@ -312,25 +325,34 @@ class EPA(nn.Module):
             Mq = KP / nq.unsqueeze(-1) * self.temperature2
         if x.is_cuda and os.environ.get("P4C_NO_EPA_SPATIAL") != "1" and TS.spatial_fused_ok(q, Mq.shape[-1]):
             # softmax (and its adjoint) in the epilogue of the apply that produces its argument: ops_ts.epa_spatial
-            x_sa = TS.epa_spatial(q, Mq, VP.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
+            x_sa = self._merge_sa(TS.epa_spatial(q, Mq, VP.transpose(-1, -2)), B, N, C)
         else:
             S = TS.apply(q, Mq).softmax(dim=-1)                                                      # (B,h,N,p), token-major memory
-            x_sa = TS.apply(S, VP.transpose(-1, -2)).permute(0, 2, 1, 3).reshape(B, N, C)
+            x_sa = self._merge_sa(TS.apply(S, VP.transpose(-1, -2)), B, N, C)
         return self._project_out(x_sa, x_ca, res, gamma)
 
 
 class TransformerBlock(nn.Module):
-    def __init__(self, tokens, hidden, proj, heads):
+    def __init__(self, tokens, hidden, proj, heads, published=False, conv8_dropout=0.0, attn_drop=0.0):
         super().__init__()
         self.norm = nn.LayerNorm(hidden)
         self.gamma = nn.Parameter(1e-6 * torch.ones(hidden))
-        self.epa_block = EPA(tokens, hidden, proj, heads)
+        self.epa_block = EPA(tokens, hidden, proj, heads, published, attn_drop)
         self.conv51 = ResBlock(hidden, hidden, "batch")
-        self.conv8 = nn.Conv2d(hidden, hidden, 1)
+        # published: Sequential(Dropout(0.1, False), Conv) -- state-dict keys conv8.1.*
+        self.conv8 = nn.Sequential(nn.Dropout2d(conv8_dropout, False), nn.Conv2d(hidden, hidden, 1)) if published else nn.Conv2d(hidden, hidden, 1)
+        self.published = published
         self.pos_embed = nn.Parameter(torch.zeros(1, tokens, hidden))
+
+    def _conv8_in(self, r_nchw):
+        """the channel dropout in front of conv8 (published block, training mode, p > 0) on an NCHW-shaped tensor"""
+        if self.published and self.training and self.conv8[0].p > 0:
+            return self.conv8[0](r_nchw)
+        return r_nchw
 
     def forward(self, x):
         B, C, H, W = x.shape
+        conv8 = self.conv8[1] if self.published else self.conv8
         xl = x.permute(0, 2, 3, 1)
         if _native(x) and xl.is_contiguous() and R.add_layer_norm_supported(xl) and C % 16 == 0:
             # features-last all the way: (x + pos) and its LayerNorm from one read, the EPA's two output projections write
@@ -338,14 +360,14 @@ class TransformerBlock(nn.Module):
             t, ln = R.add_layer_norm(xl.reshape(B, H * W, C), self.pos_embed, self.norm.weight, self.norm.bias, self.norm.eps)
             t = self.epa_block(ln, res=t, gamma=self.gamma)
             skip = t.reshape(B, H, W, C)
-            r = self.conv51(skip.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
-            if G.conv_supported(r, self.conv8.weight):
-                return G.conv2d_nhwc(r, self.conv8.weight, self.conv8.bias, res=skip).permute(0, 3, 1, 2)
-            return (skip + _conv(self.conv8, r.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            r = self._conv8_in(self.conv51(skip.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+            if G.conv_supported(r, conv8.weight) and r.is_contiguous():
+                return G.conv2d_nhwc(r, conv8.weight, conv8.bias, res=skip).permute(0, 3, 1, 2)
+            return (skip + _conv(conv8, r.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
         t = x.reshape(B, C, H * W).permute(0, 2, 1) + R.param_as(self.pos_embed, x.dtype)
         t = t + R.param_as(self.gamma, x.dtype) * self.epa_block(_layer_norm(self.norm, t.contiguous()))
         skip = t.reshape(B, H, W, C).permute(0, 3, 1, 2)
-        return skip + _conv(self.conv8, self.conv51(skip))
+        return skip + _conv(conv8, self._conv8_in(self.conv51(skip)))
 
 
 class _FeaturesLast(torch.autograd.Function):
@@ -362,14 +384,15 @@ class _FeaturesLast(torch.autograd.Function):
 
 
 class UpBlock(nn.Module):
-    def __init__(self, cin, cout, scale, tokens, proj, heads, depth, conv_decoder, linear, norm):
+    def __init__(self, cin, cout, scale, tokens, proj, heads, depth, conv_decoder, linear, norm, block_kw=None):
         super().__init__()
         self.scale, self.linear = scale, linear
         self.up_conv = nn.Conv2d(cin, cout, 1) if linear else nn.ConvTranspose2d(cin, cout, scale, stride=scale, bias=False)
         if conv_decoder:
             self.decoder_block = nn.ModuleList([ResBlock(cout, cout, norm)])
         else:
-            self.decoder_block = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens, cout, proj, heads) for _ in range(depth)])])
+            self.decoder_block = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens, cout, proj, heads, **(block_kw or {}))
+                                                                for _ in range(depth)])])
 
     def forward(self, x, skip):
         if (self.linear and _native(x) and x.shape[1] % 8 == 0 and self.up_conv.out_channels % 8 == 0 and float(self.scale).is_integer()
@@ -427,14 +450,17 @@ class UNetRPPMI355X(ModelABC, nn.Module):
         self.downsample_layers.append(nn.Sequential(nn.Conv2d(in_channels, dims[0], r, stride=r, bias=False), nn.GroupNorm(g0, dims[0])))
         for i in range(3):
             self.downsample_layers.append(nn.Sequential(nn.Conv2d(dims[i], dims[i + 1], 2, stride=2, bias=False), nn.GroupNorm(dims[i], dims[i + 1])))
-        self.stages = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens[i], dims[i], s.encoder_proj_sizes[i], s.num_heads_encoder)
+        if not 0.0 <= s.conv8_dropout < 1.0:
+            raise ValueError("UNetRPPMI355X: conv8_dropout must be in [0, 1)")
+        bkw = dict(published=bool(s.published_block), conv8_dropout=float(s.conv8_dropout), attn_drop=float(s.dropout_rate))
+        self.stages = nn.ModuleList([nn.Sequential(*[TransformerBlock(tokens[i], dims[i], s.encoder_proj_sizes[i], s.num_heads_encoder, **bkw)
                                                      for _ in range(s.depths[i])]) for i in range(4)])
         up = (s.decoder_proj_size, s.num_heads_decoder, 3)
         self.encoder1 = ResBlock(in_channels, fs, s.norm_name)
-        self.decoder5 = UpBlock(dims[3], dims[2], 2, tokens[2], *up, False, s.linear_upsampling, s.norm_name)
-        self.decoder4 = UpBlock(dims[2], dims[1], 2, tokens[1], *up, False, s.linear_upsampling, s.norm_name)
-        self.decoder3 = UpBlock(dims[1], dims[0], 2, tokens[0], *up, False, s.linear_upsampling, s.norm_name)
-        self.decoder2 = UpBlock(dims[0], fs, r, H * W, *up, True, s.linear_upsampling, s.norm_name)
+        self.decoder5 = UpBlock(dims[3], dims[2], 2, tokens[2], *up, False, s.linear_upsampling, s.norm_name, bkw)
+        self.decoder4 = UpBlock(dims[2], dims[1], 2, tokens[1], *up, False, s.linear_upsampling, s.norm_name, bkw)
+        self.decoder3 = UpBlock(dims[1], dims[0], 2, tokens[0], *up, False, s.linear_upsampling, s.norm_name, bkw)
+        self.decoder2 = UpBlock(dims[0], fs, r, H * W, *up, True, s.linear_upsampling, s.norm_name, bkw)
         self.out1 = nn.Conv2d(fs, out_channels, 1)
         self.timed_entry_points = ("p4c_ts_gram", "p4c_ts_apply", "p4c_row_add_layernorm_fwd", "p4c_row_add_layernorm_bwd", "p4c_gemm_nt", "p4c_gemm_tn")
         self.roofline_from_entry_points = True   # bench.py: time every call of the native entry points above

@@ -136,13 +136,13 @@ def test_epa_spatial_branch_fused(gpu_device, B, H, N, d, p):
     assert _rel(VPt.grad, Vd.grad) < 2e-2
 
 
-def _pair(cin, cout, shape, dtype="f32", hidden=256, heads=4, linear=True):
+def _pair(cin, cout, shape, dtype="f32", hidden=256, heads=4, linear=True, published=True):
     from oracle.unetrpp import UNetRPP as Oracle
     from py4cast_amd.unetrpp import UNetRPPMI355X, UNetRPPSettings
 
     torch.manual_seed(41)
     s = UNetRPPSettings(hidden_size=hidden, num_heads_encoder=heads, num_heads_decoder=4, depths=(2, 1, 1, 1), encoder_proj_sizes=(16, 16, 8, 4),
-                        decoder_proj_size=16, linear_upsampling=linear, activation_dtype=dtype)
+                        decoder_proj_size=16, linear_upsampling=linear, activation_dtype=dtype, published_block=published, conv8_dropout=0.0)
     model = UNetRPPMI355X(cin, cout, shape, s)
     with torch.no_grad():   # the published initialisation (gamma = 1e-6, zero positional embedding) would hide the attention path
         for n, p in model.named_parameters():
@@ -153,20 +153,24 @@ def _pair(cin, cout, shape, dtype="f32", hidden=256, heads=4, linear=True):
             elif "temperature" in n:
                 p.uniform_(0.5, 1.5)
     oracle = Oracle(cin, cout, shape, hidden_size=hidden, num_heads_encoder=heads, num_heads_decoder=4, depths=(2, 1, 1, 1),
-                    encoder_proj_sizes=(16, 16, 8, 4), decoder_proj_size=16, linear_upsampling=linear).double()
-    oracle.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in model.state_dict().items()})
+                    encoder_proj_sizes=(16, 16, 8, 4), decoder_proj_size=16, linear_upsampling=linear, published_block=published,
+                    conv8_dropout=0.0).double()
+    oracle.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in model.state_dict().items()})   # (strict: the same keys)
     return model, oracle
 
 
+@pytest.mark.parametrize("published", [True, False])
 @pytest.mark.parametrize("linear", [True, False])
-def test_unetrpp_matches_oracle(gpu_device, linear):
-    """Forward: always within the north-star bar.  Gradients: the network has ~10^6 LeakyReLU sites, and a pre-activation within
-    fp32 rounding of zero (|z| ~ 1e-6, about one site per draw at this size) takes the other branch in fp32 than in the fp64 oracle:
-    that site's gradient changes by O(1) and every gradient downstream by ~1e-3 -- a property of fp32, not of the kernels
-    (tools/diagnostics/unetrpp_grad_probe6.py pins one such site: -2.8e-7 in fp64, +1.3e-6 in fp32).  So the gradients are held to
-    the tight bar on a draw without such a site (a real defect fails every draw), and to a loose sanity bound on every draw."""
+def test_unetrpp_matches_oracle(gpu_device, linear, published):
+    """Both forms of the transformer block (UNetRPPSettings.published_block: as published / as mfai wraps it, and the restated one)
+    against the oracle with the same switch.  Forward: always within the north-star bar.  Gradients: the network has ~10^6 LeakyReLU
+    sites, and a pre-activation within fp32 rounding of zero (|z| ~ 1e-6, about one site per draw at this size) takes the other branch
+    in fp32 than in the fp64 oracle: that site's gradient changes by O(1) and every gradient downstream by ~1e-3 -- a property of fp32,
+    not of the kernels (tools/diagnostics/unetrpp_grad_probe6.py pins one such site: -2.8e-7 in fp64, +1.3e-6 in fp32).  So every draw
+    is held to a loose sanity bound and AT LEAST FOUR OF THE SIX draws to the tight 1e-4 bar (a real defect fails every draw; the
+    draws that miss it are reported with the tensor that moved most)."""
     H, W, cin, cout = 64, 96, 13, 5
-    model, oracle = _pair(cin, cout, (H, W), linear=linear)
+    model, oracle = _pair(cin, cout, (H, W), linear=linear, published=published)
     model = model.to(gpu_device).train()
     oracle.train()
     ref = dict(oracle.named_parameters())
@@ -188,10 +192,53 @@ def test_unetrpp_matches_oracle(gpu_device, linear):
         dx = _rel(xg.grad, xr.grad)
         worst = max((_rel(p.grad, ref[n].grad), n) for n, p in model.named_parameters())
         assert dx < 5e-2 and worst[0] < 2e-1, (seed, dx, worst)     # sanity on every draw (a branch flip moves small gradients by percents)
-        seen.append((seed, dx, worst))
-        if dx < 1e-4 and worst[0] < 1e-4:
-            return
-    raise AssertionError(f"no draw met the 1e-4 gradient bar: {seen}")
+        seen.append((seed, dx, worst, dx < 1e-4 and worst[0] < 1e-4))
+    tight = [s for s in seen if s[3]]
+    assert len(tight) >= 4, f"only {len(tight)} of 6 draws met the 1e-4 gradient bar; the others (seed, dx, worst tensor): {[s[:3] for s in seen if not s[3]]}"
+
+
+def test_unetrpp_published_block_has_the_published_state_dict(gpu_device):
+    """published_block=True: the keys a checkpoint of the published code / mfai's wrapper carries -- ``conv8.1.*`` (conv8 =
+    Sequential(Dropout2d, Conv2d)), ``epa_block.E.*`` AND ``epa_block.F.*`` (one Linear under two names) -- load strictly; the restated
+    block has ``conv8.*`` and no ``F``; the channel dropout in front of conv8 is drawn in training mode only (p = conv8_dropout, 0.1 as
+    published) and both forms compute the same function when x_SA's merge is undone by hand (the merge is the ONLY functional
+    difference at p = 0)."""
+    from py4cast_amd.unetrpp import UNetRPPMI355X, UNetRPPSettings
+
+    kw = dict(hidden_size=128, num_heads_encoder=2, num_heads_decoder=2, depths=(1, 1, 1, 1), encoder_proj_sizes=(16, 16, 8, 4), decoder_proj_size=16,
+              linear_upsampling=True)
+    torch.manual_seed(7)
+    pub = UNetRPPMI355X(9, 4, (64, 64), UNetRPPSettings(**kw))                      # defaults: published_block=True, conv8_dropout=0.1
+    old = UNetRPPMI355X(9, 4, (64, 64), UNetRPPSettings(published_block=False, **kw))
+    kp, ko = set(pub.state_dict()), set(old.state_dict())
+    assert "stages.0.0.conv8.1.weight" in kp and "stages.0.0.conv8.1.bias" in kp and "stages.0.0.conv8.weight" not in kp
+    assert "stages.0.0.epa_block.F.weight" in kp and "stages.0.0.epa_block.E.weight" in kp
+    assert "stages.0.0.conv8.weight" in ko and not any(".F." in k for k in ko)
+    assert len(list(pub.parameters())) == len(list(old.parameters()))              # E / F is ONE parameter pair
+    assert pub.stages[0][0].epa_block.F is pub.stages[0][0].epa_block.E and pub.stages[0][0].conv8[0].p == 0.1
+    # a published-form state dict loads strictly (also from the restated keys after renaming)
+    sd = old.state_dict()
+    ren = {k.replace(".conv8.", ".conv8.1."): v for k, v in sd.items()}
+    ren.update({k.replace(".E.", ".F."): v for k, v in sd.items() if ".epa_block.E." in k})
+    pub.load_state_dict(ren, strict=True)
+    pub, old = pub.to(gpu_device), old.to(gpu_device)
+    with torch.no_grad():
+        for m in (pub, old):
+            for n, p in m.named_parameters():
+                if n.endswith("gamma"):
+                    p.fill_(0.5)
+    x = torch.randn(2, 64, 64, 9, generator=torch.Generator().manual_seed(8)).to(gpu_device)
+    pub.eval(), old.eval()
+    with torch.no_grad():
+        ye1, ye2, yo = pub(x), pub(x), old(x)
+    assert torch.equal(ye1, ye2)                                                   # eval: no draw
+    assert float((ye1 - yo).abs().max()) > 1e-4                                     # the x_SA merge differs: another function
+    pub.train()
+    with torch.no_grad():
+        torch.manual_seed(1); a = pub(x)
+        torch.manual_seed(2); b = pub(x)
+        torch.manual_seed(1); c = pub(x)
+    assert not torch.equal(a, b) and torch.equal(a, c)                              # training: drawn, reproducible under the seed
 
 
 def test_unetrpp_bf16_tracks_fp32(gpu_device):
@@ -219,7 +266,7 @@ def test_unetrpp_six_step_diff_ar_rollout_through_lightning(gpu_device):
     case = synthetic_case(seed=51, B=2, T=T, H=H, W=W, F=F, Ff=Ff, border=0)
     info = make_dataset_info(case, Ff)
     settings = dict(hidden_size=128, num_heads_encoder=2, num_heads_decoder=2, depths=[1, 1, 1, 1], encoder_proj_sizes=[16, 16, 8, 4],
-                    decoder_proj_size=16, linear_upsampling=True, attention_code="torch")
+                    decoder_proj_size=16, linear_upsampling=True, attention_code="torch", conv8_dropout=0.0)   # published block, no draw
     torch.manual_seed(52)
     lm = AutoRegressiveLightning(settings, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2, model_name="UNetRPP",
                                  losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],
@@ -232,7 +279,7 @@ def test_unetrpp_six_step_diff_ar_rollout_through_lightning(gpu_device):
     loss.backward()
     m = lm.model
     oracle = Oracle(m.in_channels, m.out_channels, (H, W), hidden_size=128, num_heads_encoder=2, num_heads_decoder=2, depths=(1, 1, 1, 1),
-                    encoder_proj_sizes=(16, 16, 8, 4), decoder_proj_size=16, linear_upsampling=True).double().train()
+                    encoder_proj_sizes=(16, 16, 8, 4), decoder_proj_size=16, linear_upsampling=True, conv8_dropout=0.0).double().train()
     oracle.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.cpu() for k, v in m.state_dict().items()})
     c = {k: (v.double() if v.is_floating_point() else v) for k, v in case.items()}
     statics = c["statics"].unsqueeze(0).expand(2, *c["statics"].shape)
@@ -345,7 +392,7 @@ def test_unetrpp_takes_its_input_straight_from_build_x(gpu_device):
     case = synthetic_case(seed=61, B=2, T=T, H=H, W=W, F=F, Ff=Ff, border=0)
     info = make_dataset_info(case, Ff)
     settings = dict(hidden_size=128, num_heads_encoder=2, num_heads_decoder=2, depths=[1, 1, 1, 1], encoder_proj_sizes=[16, 16, 8, 4],
-                    decoder_proj_size=16, linear_upsampling=True, attention_code="torch", activation_dtype="bf16")
+                    decoder_proj_size=16, linear_upsampling=True, attention_code="torch", activation_dtype="bf16", conv8_dropout=0.0)
     torch.manual_seed(62)
     lm = AutoRegressiveLightning(settings, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2, model_name="UNetRPP",
                                  losses=[{"class": "WeightedLoss", "weight": 1.0, "params": {"loss": "MSELoss", "reduction": "none"}}],

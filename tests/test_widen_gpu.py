@@ -560,7 +560,7 @@ def test_rollout_on_parameter_stand_ins(gpu_device, model_name, dtype):
     settings = {"activation_dtype": dtype}
     if model_name == "UNetRPP":
         settings.update(hidden_size=128, num_heads_encoder=2, num_heads_decoder=2, depths=[1, 1, 1, 1], encoder_proj_sizes=[16, 16, 8, 4],
-                        decoder_proj_size=16, linear_upsampling=True, attention_code="torch")
+                        decoder_proj_size=16, linear_upsampling=True, attention_code="torch", conv8_dropout=0.0)   # (equal-loss reruns: no draw)
     torch.manual_seed(78)
     lm = AutoRegressiveLightning(settings, info, None, num_input_steps=1, num_pred_steps_train=T, batch_size=2, model_name=model_name,
                                  losses=mse, training_strategy="diff_ar" if model_name == "UNetRPP" else "scaled_ar").to(gpu_device).train()

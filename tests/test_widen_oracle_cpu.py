@@ -122,6 +122,56 @@ def test_unetrpp_oracle_epa_matches_brute_force_per_head():
     assert out.shape == (1, 64, 64, 3) and bool(torch.isfinite(out).all())
 
 
+def test_unetrpp_oracle_published_block():
+    """oracle/unetrpp.py with published_block=True: the EPA against a per-(sample, head) loop whose spatial branch is merged exactly
+    as the published code writes it -- ``(attn_SA @ v_SA^T).permute(0, 3, 1, 2).reshape(B, N, C)`` --, the published state-dict keys
+    (conv8.1.*, E.* and F.* for ONE Linear), the conv8 channel dropout drawn in training mode only."""
+    from oracle.unetrpp import EPA, TransformerBlock, UNetRPP
+
+    torch.manual_seed(1)
+    B, N, C, h, p = 2, 48, 16, 4, 8
+    d = C // h
+    e = EPA(N, C, p, h, published=True).double()
+    assert e.F is e.E and {"E.weight", "E.bias", "F.weight", "F.bias"} <= set(e.state_dict())
+    with torch.no_grad():
+        e.temperature.uniform_(0.5, 1.5)
+        e.temperature2.uniform_(0.5, 1.5)
+        x = torch.randn(B, N, C, dtype=torch.float64)
+        y = e(x)
+        qkvv = (x @ e.qkvv.weight.t()).view(B, N, 4, h, d)
+        T = torch.zeros(B, h, N, d, dtype=torch.float64)
+        ca = torch.zeros(B, N, C, dtype=torch.float64)
+        for b in range(B):
+            for hh in range(h):
+                q, k, v1, v2 = (qkvv[b, :, i, hh] for i in range(4))
+                qn, kn = q / q.norm(dim=0).clamp_min(1e-12), k / k.norm(dim=0).clamp_min(1e-12)
+                ca[b, :, hh * d:(hh + 1) * d] = v1 @ torch.softmax(qn.t() @ kn * e.temperature[hh, 0, 0], -1).t()
+                KP = (e.E.weight @ k + e.E.bias[:, None]).t()
+                VP = (e.F.weight @ v2 + e.F.bias[:, None]).t()
+                T[b, hh] = torch.softmax(qn @ KP * e.temperature2[hh, 0, 0], -1) @ VP.t()
+        sa = T.permute(0, 3, 1, 2).reshape(B, N, C)          # the published merge
+        ref = torch.cat([sa @ e.out_proj.weight.t() + e.out_proj.bias, ca @ e.out_proj2.weight.t() + e.out_proj2.bias], -1)
+        assert float((y - ref).abs().max()) < 1e-12
+        assert float((y - EPA(N, C, p, h).double()(x)).abs().max()) > 0      # (sanity: the restated module is another object / function)
+    blk = TransformerBlock(64, 16, 8, 4, published=True, conv8_dropout=0.1)
+    assert isinstance(blk.conv8, torch.nn.Sequential) and isinstance(blk.conv8[0], torch.nn.Dropout2d) and blk.conv8[0].p == 0.1
+    assert {"conv8.1.weight", "conv8.1.bias"} <= set(blk.state_dict()) and "conv8.weight" not in blk.state_dict()
+    net = UNetRPP(7, 3, (64, 64), hidden_size=64, num_heads_encoder=4, num_heads_decoder=4)      # defaults: published, p = 0.1
+    xin = torch.randn(1, 64, 64, 7)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("gamma"):
+                p_.fill_(0.5)
+        net.eval()
+        a, b = net(xin), net(xin)
+        net.train()
+        torch.manual_seed(3); c = net(xin)
+        torch.manual_seed(4); dd = net(xin)
+    assert torch.equal(a, b) and not torch.equal(c, dd)
+    old = UNetRPP(7, 3, (64, 64), hidden_size=64, num_heads_encoder=4, num_heads_decoder=4, published_block=False)
+    assert "stages.0.0.conv8.weight" in old.state_dict() and not any(".F." in k for k in old.state_dict())
+
+
 def test_static_index_gather_backward_matches_index_put():
     """swinunetr._TableRows (the relative-position-bias gather with a fixed-order backward over the inverse of its static index)
     against the plain ``table[index]`` and autograd's index_put backward, for Swin's window sizes."""
