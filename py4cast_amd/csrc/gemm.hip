@@ -187,16 +187,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_kernel(NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // [4][A 16 KB | B 16 KB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware tile order (round 6).  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), and for the
-    // convolution a 128-row M tile is one image row at W = 128 whose two halo rows belong to the neighbouring tiles: with tile =
-    // blockIdx.x every input row was pulled into three L2s (PMC: 3 x the map fetched, r05_pmc_traffic_gemm_nt.json).  The bijective
-    // remap of cdna_hip_programming.md (T1) gives each XCD a CONTIGUOUS band of tiles: a row is shared inside one L2, only the band
-    // edges are fetched twice.  A pure speed choice: any placement computes the same tiles.
-    int tile;
-    {
+    // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2); for the convolution a 128-row M
+    // tile is one image row at W = 128 whose two halo rows belong to the neighbouring tiles, so with tile = blockIdx.x every input row
+    // is pulled into three L2s (PMC: 3 x the map fetched, r05_pmc_traffic_gemm_nt.json).  Round 6 measured the bijective XCD remap of
+    // cdna_hip_programming.md (T1: each XCD a CONTIGUOUS band of tiles, a row shared inside one L2) -- P4C_NT_EXP bit 32 builds it --
+    // and it is SLOWER or equal on every bench shape (profiles/r06_ab_runs.txt 4: 128 -> 128 at 128^2 21.0 vs 20.7 us, 256 -> 256 at 64^2
+    // 29.3 vs 24.4, 192 -> 96 at 64^2 20.4 vs 17.1; UNETR++ step 138.1 vs 138.2 ms): the loop is not limited by the bytes L2 fetches
+    // (they come from the 256 MB Infinity Cache at these sizes) but by the L2 -> LDS delivery per CU, and 32 neighbouring workgroups on
+    // one XCD reading the same rows in lock step queue on the same L2 channels.  The round-robin order stays.
+    int tile = blockIdx.x;
+    if (P4C_NT_EXP & 32) {
         const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
-        if (P4C_NT_EXP & 32) tile = blockIdx.x;
     }
     const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;

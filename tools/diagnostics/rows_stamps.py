@@ -16,7 +16,7 @@ wp = om.prep_weights(w, False, 64, 64, compute="bf16")
 kw = {"plain": {}, "stats": dict(want_stats=True), "ts": dict(in_scale=sc, in_shift=sh, in_relu=True, want_stats=True)}[mode]
 buf = torch.zeros(4096, dtype=torch.int64, device=dev)
 h = ctypes.CDLL(L.LIB_PATH)
-for _ in range(200):
+for _ in range(int(os.environ.get("WARM", "200"))):   # WARM=50000: ~2 s of back-to-back launches before the stamped ones (DVFS settled)
     om.conv_fwd(x, wp, 3, compute="bf16", **kw)
 torch.cuda.synchronize()
 h.p4c_debug_set_rows_stamps(ctypes.c_void_p(buf.data_ptr()))
