@@ -788,6 +788,8 @@ def _main(args, others=None):
                 "device_allocs_in_timed_region": int(device_allocs),
                 "host_loop_ms_per_step": round(host_enqueue_ms, 3),
                 "host_cores_per_rank": affinity_all if world > 1 else affinity,
+                "host_affinity_policy": __import__("py4cast_amd.trainer", fromlist=["AFFINITY_POLICY"]).AFFINITY_POLICY[0],
+                "environment_settings": L.environment_settings(),
                 "launch_mode_probe": probe,
             },
             "loss": float(loss.detach()),

@@ -415,6 +415,14 @@ typedef struct p4c_halfunet_desc {
                                  the AR step, p4c_out_conv_update_loss_fwd on the tensors p4c_halfunet_tail names.  Backward is the same. */
 } p4c_halfunet_desc;
 
+/* The first convolution of the plan at 65..72 input channels (the benchmark's 69 = 60 state + 5 forcing + 4 static features,
+ * py4cast/lightning.py:256-261) runs, in the bf16 flavour, as a 64-channel row launch on channels 0..63 + this tail pass (round 6,
+ * csrc/conv_thin.hip): y (B,H,W,64) bf16, in place, += conv3x3 of the channels 64 .. cin-1 of x (B,H,W,x_cs) bf16 with the fp32 master
+ * weight w [64][cin][3][3]; stat_partial (or NULL): p4c_first_conv_tail_slots(B,H,W) slots of [2][64] channel sums / sums of squares of
+ * the stored y per sample.  W a multiple of 32, x_cs >= 72 a multiple of 8. */
+int p4c_first_conv_tail_slots(int B, int H, int W);
+int p4c_first_conv_tail(const void* x, int x_cs, int cin, const float* w, void* y, float* stat_partial, int B, int H, int W, p4c_stream_t stream);
+
 /* Side stream of the calling thread for p4c_halfunet_backward (weight gradients run beside the backward chain, ordered by
  * events and joined before the call returns control of `stream`): `side` a hipStream_t, `events` n_events >= 8 hipEvent_t
  * handles created with hipEventDisableTiming, all owned by the caller and alive until replaced.  side = NULL restores the

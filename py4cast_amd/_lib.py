@@ -254,6 +254,24 @@ class use_diagnostic_library:
         return False
 
 
+def diag_switch(name: str):
+    """The value of a P4C_* ROUTE switch (an older kernel / a library route as the A/B reference of the native one), or None.  Like the C
+    library's diag_env (csrc/common.hpp) these switches exist in DIAGNOSTIC mode only -- inside ``use_diagnostic_library()``, which the
+    A/B parity tests (tests/conftest.py::diag_library) and tools/diagnostics enter: the product package reads no route switch from the
+    environment, so a deployment cannot differ silently from the measured configuration.  The settings that ARE read from
+    the environment are documented ones and bench.py echoes them (config.environment_settings): P4C_NO_AFFINITY, P4C_NO_TUNED_GEMMS,
+    P4C_LIB_PATH."""
+    if _diag is not None and _lib is _diag:
+        return os.environ.get(name)
+    return None
+
+
+def environment_settings():
+    """the documented environment settings in force (bench.py: config.environment_settings)"""
+    return {k: os.environ[k] for k in ("P4C_NO_AFFINITY", "P4C_NO_TUNED_GEMMS", "P4C_LIB_PATH", "PYTORCH_TUNABLEOP_ENABLED", "MIOPEN_FIND_MODE")
+            if k in os.environ}
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().p4c_last_error()

@@ -55,6 +55,7 @@ SIGNATURES = {
     "p4c_conv_wgrad_kernel_kind": [I, I, I, I],
     "p4c_out_conv_bwd": [P, P, P, P, P, P, P, P, P, I, P, P, I, L, P],
     "p4c_upsample_sum_bwd_x": [I, P, I, I, I, P, P, P, P, P],
+    "p4c_first_conv_tail": [P, I, I, P, P, P, I, I, I, P],
     "p4c_halfunet_workspace_bytes": [DP, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)],
     "p4c_halfunet_prepare_weights": [DP, P, P, P],
     "p4c_halfunet_forward": [DP, P, P, P, P, P, P, I, P],
@@ -99,6 +100,7 @@ SIGNATURES = {
 OTHER = {
     "p4c_conv_wgrad_workspace_bytes": ([I, I], c_size_t),
     "p4c_out_conv_bwd_slots": ([I, L], c_int),
+    "p4c_first_conv_tail_slots": ([I, I, I], c_int),
     "p4c_out_conv_bwd_workspace_bytes": ([I, L], c_size_t),
     "p4c_conv_stat_tiles": ([I, I, I, I, I, I], c_int),
     "p4c_conv_stat_tiles_ks": ([I, I, I, I, I, I, I], c_int),

@@ -952,6 +952,20 @@ int launch_conv_bf16_rows_compact(const void* in, int in_cs, const void* wp, int
     return P4C_OK;
 }
 
+// the first 64 channels of pixels that are `pixel_channels` channels apart (the CPT instantiation: its input channel count doubles as
+// the pixel stride, every channel octet below 64 exists)
+int launch_conv_bf16_rows_wide_pixels(const void* in, int pixel_channels, const void* wp, void* out, int B, int H, int W, hipStream_t stream) {
+    if (pixel_channels < 64 || pixel_channels % 8 || !conv_bf16_is_rows(P4C_BF16, 64, 3, 1, 64, B, H, W) ||
+        (int64_t)H * W * pixel_channels * 2 >= (int64_t)1 << 31)
+        return fail(P4C_ERR_UNSUPPORTED, "conv_bf16_rows_wide_pixels: unsupported shape (%d-channel pixels, %dx%dx%d)", pixel_channels, B, H, W);
+    int nstrips, nseg;
+    conv_rows_geometry(B, H, W, &nstrips, &nseg);
+    const int rc = launch_rows_compact<3>((const __bf16*)in, pixel_channels, (const __bf16*)wp, (__bf16*)out, 64, B, H, W, nstrips, nseg, stream);
+    if (rc != P4C_OK) return rc;
+    P4C_CHECK_LAUNCH("conv_bf16_rows_wide_pixels");
+    return P4C_OK;
+}
+
 int conv_rows_stat_slots(int B, int H, int W) {
     int nstrips, nseg;
     conv_rows_geometry(B, H, W, &nstrips, &nseg);

@@ -23,7 +23,7 @@ constexpr int NLEV = 5;      // encoder levels
 constexpr int NCONV = 12;    // 3x3 convs: enc k conv j -> 2(k-1)+j-1 ; decoder -> 10, 11
 // prepared-weight cache in the scratch workspace: slot i = conv i forward, NCONV + i = conv i data gradient,
 // 2*NCONV / 2*NCONV + 1 = 1x1 output conv forward / data gradient
-constexpr int NWSLOT = 2 * NCONV + 2;
+constexpr int NWSLOT = 2 * NCONV + 3;   // forward + data-gradient images of the 3x3 blocks, the two of the 1x1 output conv, the first conv's 64-channel row image
 constexpr int64_t WSLOT_FLOATS = 9 * 96 * 64;
 
 struct Layout {
@@ -209,6 +209,9 @@ int prepare_weights(const p4c_halfunet_desc& d, const WS& ws, const float* param
         if (which & 2) pb.job[pb.n++] = {params + L.w[i], wslot(ws, NCONV + i), NF, conv_cin(d, i), 9, 1, 64, NF};
     }
     if (which & 1) pb.job[pb.n++] = {params + L.wout, wslot(ws, 2 * NCONV), d.cout, NF, 1, 0, 64, NF};
+    // the first convolution as a 64-channel row launch + tail (conv_thin.hip): the row kernel's image of input channels 0..63
+    if ((which & 1) && first_conv_split_ok(d.compute, d.dtype, d.cin, d.cin_pad, d.B, d.H, d.W))
+        pb.job[pb.n++] = {params + L.w[0], wslot(ws, 2 * NCONV + 2), NF, d.cin, 9, 0, 64, NF};
     if (which & 2) pb.job[pb.n++] = {params + L.wout, wslot(ws, 2 * NCONV + 1), d.cout, NF, 1, 1, 64, NF};
     pb.zero_words = reinterpret_cast<unsigned int*>(ws.f(L.tickets));
     pb.n_zero = 64;
@@ -241,12 +244,21 @@ int conv_block_fwd(const p4c_halfunet_desc& d, const WS& ws, int i, const void* 
         fin = BatchFin{statp, reinterpret_cast<unsigned int*>(ws.f(L.tickets)), params + L.gamma[i], params + L.beta[i], rm, rv,
                        nm.scale, nm.shift, nm.mean, nm.rstd, (double)d.B * H * W, d.eps, d.momentum, d.B};
     }
-    P4C_TRY(conv_fwd(d.compute, d.dtype, in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
-                     in_norm ? in_norm->shift : nullptr, in_norm ? 1 : 0, ws.act(L.Y[i]), NF, statp, d.B, H, W, 1, st,
-                     infin ? &fin : nullptr));
+    int ntiles = stat_tiles(d.compute, d.dtype, conv_cin_pad(d, i), d.B, H, W);
+    if (i == 0 && !in_norm && first_conv_split_ok(d.compute, d.dtype, d.cin, d.cin_pad, d.B, H, W)) {
+        // 69 -> 64 at the benchmark's channel count: a 64-channel row launch on channels 0..63 of the 96-channel pixels, then the tail
+        // adds the product of the channels beyond 64 and takes the statistics of the result (conv_thin.hip)
+        P4C_TRY(launch_conv_bf16_rows_wide_pixels(in, d.cin_pad, wslot(ws, 2 * NCONV + 2), ws.act(L.Y[i]), d.B, H, W, st));
+        P4C_TRY(launch_first_conv_tail(in, d.cin_pad, d.cin, params + L.w[0], ws.act(L.Y[i]), statp, d.B, H, W, st));
+        ntiles = first_conv_tail_slots(d.B, H, W);
+    } else {
+        P4C_TRY(conv_fwd(d.compute, d.dtype, in, conv_cin_pad(d, i), wp, 3, in_norm ? in_norm->scale : nullptr,
+                         in_norm ? in_norm->shift : nullptr, in_norm ? 1 : 0, ws.act(L.Y[i]), NF, statp, d.B, H, W, 1, st,
+                         infin ? &fin : nullptr));
+    }
     if (infin) return P4C_OK;
     if (batch_stats) {
-        P4C_TRY(norm_finalize(statp, stat_tiles(d.compute, d.dtype, conv_cin_pad(d, i), d.B, H, W), d.B, (int64_t)H * W, d.norm,
+        P4C_TRY(norm_finalize(statp, ntiles, d.B, (int64_t)H * W, d.norm,
                               d.groups, params + L.gamma[i], params + L.beta[i], d.eps, d.momentum,
                               d.norm == 0 ? rm : nullptr, d.norm == 0 ? rv : nullptr, nm.scale, nm.shift, nm.mean, nm.rstd, st));
     } else {

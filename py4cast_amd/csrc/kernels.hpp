@@ -162,6 +162,15 @@ int launch_conv_bf16_rows_compact(const void* in, int in_cs, const void* wp, int
 int conv_wgrad_bf16_compact(const void* in, int in_cs, int ks, const void* dout, int dout_cs, float* partial, int G, int B, int H, int W,
                             int CO, int CIreal, float* grad, hipStream_t stream);
 
+// conv_thin.hip: the first convolution at 65..72 input channels (the benchmark's 69) as a 64-channel row launch on channels 0..63 of
+// the wide pixels + a tail pass that adds the product of the channels beyond 64 to y in place and takes the statistics of the result
+bool first_conv_split_ok(int compute, int storage, int cin, int cin_pad, int B, int H, int W);
+int first_conv_tail_slots(int B, int H, int W);     // statistics slots ([2][64] floats) per sample the tail leaves
+int launch_first_conv_tail(const void* x, int x_cs, int cin, const float* w, void* y, float* stat_partial, int B, int H, int W, hipStream_t stream);
+// conv_rows.hip: plain 3x3 convolution 64 -> 64 whose input pixels are `pixel_channels` (> 64, multiple of 8) channels apart (the
+// first 64 channels of each are read)
+int launch_conv_bf16_rows_wide_pixels(const void* in, int pixel_channels, const void* wp, void* out, int B, int H, int W, hipStream_t stream);
+
 // norm_pool.hip
 int norm_finalize(const float* partial, int tiles_per_sample, int B, int64_t hw, int mode, int groups, const float* gamma,
                   const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,

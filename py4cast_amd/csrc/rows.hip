@@ -246,6 +246,8 @@ __global__ void __launch_bounds__(256)
                 const u32x4 tv = Vec16<T>::pack(f[k]);
                 Vec16<T>::unpack(tv, f[k]);          // the statistics are those of the STORED sum (what the backward re-reads)
                 if (sum_out) reinterpret_cast<u32x4*>(sum_out)[r * chunks + ch] = tv;
+            } else if (sum_out && ok) {
+                reinterpret_cast<u32x4*>(sum_out)[r * chunks + ch] = v;     // add == NULL: t = x, written all the same (the header's contract)
             }
 #pragma unroll
             for (int i = 0; i < NV; ++i) s += f[k][i];

@@ -144,7 +144,7 @@ def grid_rows(model: nn.Module, x: torch.Tensor, dt: torch.dtype) -> torch.Tenso
 def rollout_format(model: nn.Module):
     """(dtype, feature count) the rollout's build_x should emit for a mesh-GNN: bf16 rows zero-padded to the fused MLP's multiple of 16
     -- otherwise every AR step casts the fp32 rows and pads them (two passes over the grid input, and their adjoints).  fp32: None."""
-    if model._settings.activation_dtype != "bf16" or model.in_channels > M.MAX_K or os.environ.get("P4C_NO_ROLLOUT_FORMAT") == "1":
+    if model._settings.activation_dtype != "bf16" or model.in_channels > M.MAX_K or L.diag_switch("P4C_NO_ROLLOUT_FORMAT") == "1":
         return None
     return torch.bfloat16, (model.in_channels + 15) // 16 * 16
 

@@ -640,19 +640,19 @@ class _NativeRolloutFn(torch.autograd.Function):
         # arrays streamed flat, the network's row tensors through LDS tiles -- take the same fused step
         esz = 2 if adt == torch.bfloat16 else 4
         flat_next = ((not mask_on_nan) and F <= 64 and (N * F) % 4 == 0 and (cpad * esz) % 16 == 0 and cpad <= 256
-                     and os.environ.get("P4C_NO_FLAT_STEP", "0") != "1")
+                     and L.diag_switch("P4C_NO_FLAT_STEP") != "1")
         fuse_next = v4_next or flat_next
         x_next = None
         # bf16 flavour, training: the update kernel also saves the loss gradient of every element as bf16 rows and the backward reads
         # those instead of the new state and the target (480 -> 120 bytes per grid point; P4C_SAVE_LOSS_GRAD=0: recompute)
         save_lg = (keep_saved and adt == torch.bfloat16 and fuse_next and mask_mode == L.MASK_NONE
-                   and os.environ.get("P4C_SAVE_LOSS_GRAD", "1") != "0")
+                   and L.diag_switch("P4C_SAVE_LOSS_GRAD") != "0")
         lgrads = torch.empty(T, B, N, F, dtype=torch.bfloat16, device=dev) if save_lg else None
         # bf16 flavour: the network's 1x1 output convolution runs INSIDE the AR step's kernel (p4c_out_conv_update_loss_fwd: y is
         # never written and read back, one launch less per AR step; same new state bit for bit; P4C_FUSED_TAIL=0: the two-kernel route)
         # (feature counts off the 16-byte grid: the flat kernel takes the convolution as its front end)
         fused_tail = (adt == torch.bfloat16 and (v4_next or (flat_next and F % 4 != 0)) and mask_mode == L.MASK_NONE
-                      and model.out_channels >= F and os.environ.get("P4C_FUSED_TAIL", "1") != "0")
+                      and model.out_channels >= F and L.diag_switch("P4C_FUSED_TAIL") != "0")
         desc_fwd = desc
         if fused_tail:
             desc_fwd = HalfUNetDesc.from_buffer_copy(desc)
@@ -739,7 +739,7 @@ class _NativeRolloutFn(torch.autograd.Function):
         # full-resolution ones left over at the end of AR step i's backward then run beside the HBM-bound head of step i-1's
         # chain instead of alone (P4C_DEFER_JOIN=0: join after every step, the round-2 behaviour).  xs / saveds stay referenced
         # until the join below -- the side stream reads them.
-        defer = T > 1 and os.environ.get("P4C_DEFER_JOIN", "1") != "0"
+        defer = T > 1 and L.diag_switch("P4C_DEFER_JOIN") != "0"
         if defer:
             L.call("p4c_side_stream_defer", 1)
         ok = False

@@ -407,7 +407,7 @@ class AutoRegressiveLightning(_Base):
         if want is None:
             want = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if (not inference and torch.is_grad_enabled() and T * num_inter_steps > 1 and getattr(self.model, "rollout_param_proxies", False)
-                and want and os.environ.get("P4C_NO_PARAM_PROXIES") != "1"
+                and want and L.diag_switch("P4C_NO_PARAM_PROXIES") != "1"
                 and not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)):
             from .trainer import RolloutParamProxies
 

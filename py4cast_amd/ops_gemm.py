@@ -441,9 +441,12 @@ def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=N
     if y.dtype not in (torch.bfloat16, torch.float32) or y.shape[-1] % 4 or y.shape[-1] > 1024:
         raise L.P4CError(f"ops_gemm.batch_norm_act: unsupported map {tuple(y.shape)} {y.dtype}")
     training = bn.training or bn.running_mean is None
+    if bn.momentum is None and training and bn.track_running_stats:
+        # torch: the cumulative moving average, factor 1 / num_batches_tracked -- a per-step value the fused finalize does not take
+        raise L.P4CError("ops_gemm.batch_norm_act: BatchNorm2d(momentum=None) (cumulative average) is not served; give a momentum")
     mom = 0.1 if bn.momentum is None else bn.momentum
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None and not torch.cuda.is_current_stream_capturing():
-        bn.num_batches_tracked.add_(1)
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)      # a device add: captured into a HIP graph like the kernels around it (replays advance it)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return _BatchNormAct.apply(y, stats if training else None, bn.weight, bn.bias, res, rm, rv, training, mom, bn.eps, float(slope))
 

@@ -164,7 +164,7 @@ def _compact_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
     CO, CI, ks, _ = w.shape
     B, H, W, C = x.shape
     return (x.dtype == torch.bfloat16 and C == CI and C % 8 == 0 and CO % 8 == 0 and C <= 64 and CO <= 64 and (C < 64 or CO < 64)
-            and os.environ.get("P4C_NO_COMPACT_CONV") != "1"
+            and L.diag_switch("P4C_NO_COMPACT_CONV") != "1"
             and bool(L.lib().p4c_conv_compact_supported(C, CO, ks, B, H, W)))
 
 

@@ -65,7 +65,7 @@ def _rg_native(x: torch.Tensor, w: torch.Tensor) -> bool:
     if not (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1 and x.dim() == 2):
         return False
     O, K = w.shape
-    if K % 8 or O % 8 or x.shape[0] < 1 or os.environ.get("P4C_GNN_LIBRARY_GEMM") == "1":
+    if K % 8 or O % 8 or x.shape[0] < 1 or L.diag_switch("P4C_GNN_LIBRARY_GEMM") == "1":
         return False
     lib = L.lib()
     return bool(lib.p4c_row_gemm_supported(K, O) and lib.p4c_row_gemm_supported(O, K))
@@ -132,10 +132,10 @@ def grad_view(t: Optional[torch.Tensor]):
 _WCAST = {}   # eager mode: (address, shape, strides, dtype) -> (parameter version, copy in the rows' dtype)
 
 
-def weight_as(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """``w.detach().to(dtype)`` (contiguous), once per parameter version in eager mode and once per HIP-graph capture: the three AR
-    steps of a rollout use the same weight blocks, and a cast is a launch."""
-    key = ("wcast", w.data_ptr(), tuple(w.shape), tuple(w.stride()), dtype)
+def weight_as(w: torch.Tensor, dtype: torch.dtype, transposed: bool = False) -> torch.Tensor:
+    """``w.detach().to(dtype)`` (contiguous; ``transposed``: of ``w.t()``), once per parameter version in eager mode and once per
+    HIP-graph capture: the three AR steps of a rollout use the same weight blocks, and a cast is a launch."""
+    key = ("wcast_t" if transposed else "wcast", w.data_ptr(), tuple(w.shape), tuple(w.stride()), dtype)
     ver = (L.PARAM_EPOCH[0], w._version)
     capturing = torch.cuda.is_current_stream_capturing()
     cache = _WCAST if not capturing else L.capture_cache()
@@ -143,7 +143,7 @@ def weight_as(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         hit = cache.get(key)
         if hit is not None and hit[0] == ver and L.owners_alive(hit[2], (w,)):
             return hit[1]
-    wq = w.detach().to(dtype).contiguous()
+    wq = (w.detach().t() if transposed else w.detach()).to(dtype).contiguous()
     if cache is not None:
         cache[key] = (ver, wq, L.owner_refs((w,)))
     return wq

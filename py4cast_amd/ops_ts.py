@@ -337,12 +337,28 @@ class _EpaCore(torch.autograd.Function):
         tot = part.sum(dim=1) if ns > 1 else part[:, 0]
         G = tot[..., : d * d].reshape(B, H, d, d).contiguous()
         nq2, nk2 = tot[..., d * d: d * d + d].contiguous(), tot[..., d * d + d:].contiguous()   # (B,H,d): |q columns|^2, |k columns|^2
-        # token-axis projection of k and v_sa (shared weights): a library GEMM over (B, 2, C, N) x (N, p)
+        # token-axis projection of k and v_sa (shared weights E = F): KP[b,h] = k[b,h]^T W^T + bias, (d x p) per head
         from .ops_rows import weight_as
 
         W16 = weight_as(W, dt)                                               # (p, N)
-        kv = qkvv[:, :, 1::2].permute(2, 0, 1, 3, 4).reshape(2, B, N, C)      # k and v_sa token-major, ONE strided copy: (2,B,N,C)
-        proj = (kv.transpose(-1, -2) @ W16.t()).float() + bias.float()       # (2,B,C,p): KP and VP are its two contiguous halves
+        if _token_proj_native(qkvv, p):
+            # round 6 (diagnostic route, measured no faster): the projection IS a gram product of the head's token matrix with the
+            # (N x p) matrix W^T shared by all heads (strides 0 over sample and head): k and v_sa are read IN PLACE inside qkvv by the
+            # tall-skinny kernel -- no (2, B, N, C) gather of them (16 MB per block at the first stage)
+            Wt = weight_as(W, dt, transposed=True)                           # (N, p), once per parameter version
+            Wv = Wt.view(1, 1, N, p).expand(B, H, N, p)
+            proj = torch.empty(2, B, H, d, p, dtype=torch.float32, device=qkvv.device)
+            for i, x in enumerate((k, vsa)):
+                part = _gram_partial(x, Wv)                                  # (B, splits, H, d, p)
+                if part.shape[1] > 1:
+                    torch.sum(part, dim=1, out=proj[i])
+                else:
+                    proj[i].copy_(part[:, 0])
+            proj += bias.float()
+            kv = None
+        else:
+            kv = qkvv[:, :, 1::2].permute(2, 0, 1, 3, 4).reshape(2, B, N, C)      # k and v_sa token-major, ONE strided copy: (2,B,N,C)
+            proj = (kv.transpose(-1, -2) @ W16.t()).float() + bias.float()       # (2,B,C,p): KP and VP are its two contiguous halves
         KP, VP = proj[0].view(B, H, d, p), proj[1].view(B, H, d, p)
         t1f, t2f = t1.detach().float().reshape(-1).contiguous(), t2.detach().float().reshape(-1).contiguous()
         At = torch.empty(B, H, d, d, dtype=torch.float32, device=qkvv.device)
@@ -353,7 +369,8 @@ class _EpaCore(torch.autograd.Function):
         x_ca = _apply_raw(vca, At, dt)
         S = _apply_softmax(q, Mq, 1)
         x_sa = _apply_raw(S, VP.transpose(-1, -2), dt)
-        ctx.save_for_backward(qkvv, W16, kv, G, nq2, nk2, KP, VP, t1f, t2f, At, Mq, nrm, S)
+        ctx.native_proj = kv is None
+        ctx.save_for_backward(qkvv, W16, Wt if kv is None else kv, G, nq2, nk2, KP, VP, t1f, t2f, At, Mq, nrm, S)
         ctx.meta = (W.dtype, bias.dtype, t1.shape, t1.dtype)
         return x_sa, x_ca
 
@@ -389,10 +406,29 @@ class _EpaCore(torch.autograd.Function):
         # token-axis projection: proj = kv^T W16^T + bias
         g = torch.stack([dKP.reshape(B, C, p), dVP.reshape(B, C, p)], dim=0)         # (2,B,C,p) fp32
         dbias = g.sum(dim=(0, 1, 2)).to(bdt)
-        g16 = g.to(dt)
-        dkv = (g16 @ W16).transpose(-1, -2)                                          # (2,B,N,C) view of (2,B,C,N)
-        dW = torch.bmm(g16.reshape(2 * B, C, p).transpose(1, 2), kv.reshape(2 * B, N, C).transpose(1, 2)).sum(dim=0).to(wdt)   # (p,N)
-        dqkvv[:, :, 1::2].copy_(dkv.reshape(2, B, N, H, d).permute(1, 2, 0, 3, 4))    # dk (first contribution) and dv_sa: one copy
+        if ctx.native_proj:
+            # the adjoints as tall-skinny products on the operands in place: dk = W^T dKP^T and dv_sa = W^T dVP^T per head (apply with
+            # the shared (N x p) matrix as the token operand: first contributions, written straight into dqkvv), dW^T = sum over
+            # samples of k[b] (N x C) dKP[b] (C x p) + the same for v_sa (apply over ALL heads' channels at once, accumulated in a
+            # fixed order into one fp32 (N x p) matrix) -- no bf16 copy of g, no (2,B,N,C) gradient tensor, no scatter copy
+            Wt = kv
+            Wv = Wt.view(1, 1, N, p).expand(B, H, N, p)
+            _apply_into(dk, Wv, dKP.transpose(-1, -2), False)
+            _apply_into(dvsa, Wv, dVP.transpose(-1, -2), False)
+            dWt = torch.empty(1, N, 1, p, dtype=torch.float32, device=G.device)
+            dWv = dWt.permute(0, 2, 1, 3)                                            # (1,1,N,p) token-major view
+            first = True
+            for b in range(B):
+                for i, gm in ((1, dKP), (3, dVP)):
+                    xb = qkvv[b:b + 1, :, i].reshape(1, N, 1, C).permute(0, 2, 1, 3)   # (1,1,N,C): all heads' channels of sample b, in place
+                    _apply_into(dWv, xb, gm[b].reshape(1, 1, C, p), not first)
+                    first = False
+            dW = dWt.view(N, p).t().to(wdt)                                          # (p, N)
+        else:
+            g16 = g.to(dt)
+            dkv = (g16 @ W16).transpose(-1, -2)                                          # (2,B,N,C) view of (2,B,C,N)
+            dW = torch.bmm(g16.reshape(2 * B, C, p).transpose(1, 2), kv.reshape(2 * B, N, C).transpose(1, 2)).sum(dim=0).to(wdt)   # (p,N)
+            dqkvv[:, :, 1::2].copy_(dkv.reshape(2, B, N, H, d).permute(1, 2, 0, 3, 4))    # dk (first contribution) and dv_sa: one copy
         # q^T k and the norms: dq += k dG^T + 2 q diag(dnq2),  dk += q dG + 2 k diag(dnk2)
         D = dn.unsqueeze(-1) * _two_eye(d, dn.device)                                # (2,B,H,d,d) = 2 diag(dn), one launch
         _apply_into(dq, k, dG.transpose(-1, -2), True)
@@ -400,6 +436,34 @@ class _EpaCore(torch.autograd.Function):
         _apply_into(dk, q, dG, True)
         _apply_into(dk, k, D[1], True)
         return dqkvv, dW, dbias, dts[0].view(tshape).to(tdt), dts[1].view(tshape).to(tdt)
+
+
+def _gram_partial(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """the per-split partials (B, splits, H, d, e) of X^T Y (p4c_ts_gram): the caller sums them where it wants the result"""
+    B, H, N, d = x.shape
+    e = y.shape[-1]
+    ns = L.lib().p4c_ts_gram_splits(N)
+    part = torch.empty(B, ns, H, d, e, dtype=torch.float32, device=x.device)
+    L.call("p4c_ts_gram", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(y), L.dtype_code(y.dtype), *_strides(y), L.ptr(part), B, H, N, d, e,
+           L.stream(x.device), alg_bytes=B * H * N * d * x.element_size() + N * e * y.element_size())
+    return part
+
+
+TOKEN_PROJ_MIN_TOKENS = 2048   # from here on the (2, B, N, C) gather of k / v_sa is worth avoiding (below: the library GEMM on a small copy)
+
+
+def _token_proj_native(qkvv: torch.Tensor, p: int) -> bool:
+    """EPA's token-axis projection on the tall-skinny kernels, k / v_sa read in place (see _EpaCore.forward): the stages with many
+    tokens, whose whole token rows (C = heads x d channels) fit the matrix-core apply kernel (C <= 256) for the weight gradient"""
+    B, N, _, H, d = qkvv.shape
+    C = H * d
+    # Measured in round 6 (profiles/r06_ab_runs.txt 6): the UNETR++ step is NOT faster this way -- 137.8 ms against 136.8 with the
+    # gather + library GEMM (the shared (N x p) operand is re-read by every (sample, head) group, the weight gradient is four
+    # accumulating passes over an fp32 (N x p) matrix) -- so the library route stays the product's; this one is a diagnostic switch.
+    if L.diag_switch("P4C_EPA_NATIVE_PROJ") != "1" or N < TOKEN_PROJ_MIN_TOKENS or C > 256 or C % 8 or p % 8:
+        return False
+    lib, bf, f32 = L.lib(), L.dtype_code(torch.bfloat16), L.dtype_code(torch.float32)
+    return bool(lib.p4c_ts_gram_wide_ok(bf, bf, d, p) and lib.p4c_ts_apply_wide_ok(bf, bf, p, d) and lib.p4c_ts_apply_wide_ok(bf, f32, C, p))
 
 
 def epa_core_ok(qkvv: torch.Tensor, p: int) -> bool:

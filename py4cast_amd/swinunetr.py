@@ -119,7 +119,7 @@ def inverse_index_table(index: torch.Tensor, rows: int) -> torch.Tensor:
 
 
 def _native(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype == torch.bfloat16 and os.environ.get("P4C_SWIN_LIBRARY") != "1"
+    return x.is_cuda and x.dtype == torch.bfloat16 and L.diag_switch("P4C_SWIN_LIBRARY") != "1"
 
 
 def _lin(x: torch.Tensor, w: torch.Tensor, b=None, res=None) -> torch.Tensor:
@@ -194,7 +194,7 @@ def padded_stage(blocks, t: torch.Tensor) -> torch.Tensor:
     B, H, W, C = t.shape
     ws = blocks[0].ws
     pb, pr = (-H) % ws, (-W) % ws
-    if not (pb or pr) or not (t.is_cuda and _row_ln_ok(t)) or os.environ.get("P4C_SWIN_PAD_PER_BLOCK") == "1":
+    if not (pb or pr) or not (t.is_cuda and _row_ln_ok(t)) or L.diag_switch("P4C_SWIN_PAD_PER_BLOCK") == "1":
         for blk in blocks:
             t = blk(t)
         return t
@@ -400,7 +400,7 @@ class SwinUNetRMI355X(ModelABC, nn.Module):
         """(dtype, channel count) the rollout's build_x should emit for this model: bf16 rows zero-padded to the 32-channel multiple
         the first convolutions run on -- otherwise every AR step casts the fp32 input, pads it to an even channel count for the patch
         GEMM and to 96 channels for each of encoder1's two convolutions (and runs the adjoints of all that).  fp32 flavour: None."""
-        if self._settings.activation_dtype != "bf16" or self.in_channels > 96 or os.environ.get("P4C_NO_ROLLOUT_FORMAT") == "1":
+        if self._settings.activation_dtype != "bf16" or self.in_channels > 96 or L.diag_switch("P4C_NO_ROLLOUT_FORMAT") == "1":
             return None
         return torch.bfloat16, (self.in_channels + 31) // 32 * 32
 

@@ -318,23 +318,80 @@ class GraphReplayMismatch(RuntimeError):
     """A captured training step whose replay does not reproduce the eager step (GraphedTrainingStep._verify)."""
 
 
-def pin_rank_to_cores(local_rank: int, local_world: int):
-    """Give each rank of a node its own contiguous block of the cores this process may run on (``os.sched_setaffinity``), BEFORE the
-    rank's first GPU call: eight Python ranks, their autograd threads and RCCL's proxy threads otherwise wander over one another's
-    cores (the reference's own 4-GPU runs lose 25-49 % per rank to the host, doc/num_steps.md:119-143).  Contiguous blocks keep a rank
-    on one NUMA node where the core numbering follows the sockets.  Returns the sorted core list of this rank, or None when nothing
-    was changed (one rank, fewer cores than ranks, no affinity interface, P4C_NO_AFFINITY=1)."""
+AFFINITY_POLICY = [None]   # what pin_rank_to_cores decided for this process (bench.py: config.host_affinity_policy)
+
+
+def _cpu_topology(cpus):
+    """{cpu: (numa node, package, core id)} from /sys (Linux); None where that is not readable"""
+    import glob
     import os
 
-    if local_world <= 1 or os.environ.get("P4C_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+    node_of = {}
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        try:
+            node = int(os.path.basename(d)[4:])
+            for part in open(os.path.join(d, "cpulist")).read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                for c in range(int(lo), int(hi or lo) + 1):
+                    node_of[c] = node
+        except (OSError, ValueError):
+            return None
+    topo = {}
+    for c in cpus:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            topo[c] = (node_of.get(c, 0), int(open(base + "physical_package_id").read()), int(open(base + "core_id").read()))
+        except (OSError, ValueError):
+            return None
+    return topo
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int):
+    """Give each rank of a node its own set of the cores this process may run on (``os.sched_setaffinity``), BEFORE the rank's first
+    GPU call: eight Python ranks, their autograd threads and RCCL's proxy threads otherwise wander over one another's cores (the
+    reference's own 4-GPU runs lose 25-49 % per rank to the host, doc/num_steps.md:119-143).
+    Topology-aware: the CPUs are grouped by NUMA node and PHYSICAL core (/sys/devices/system/cpu/*/topology) -- on an SMT
+    host the ids are typically socket 0, socket 1, socket-0 siblings, socket-1 siblings, and contiguous slices of the id list would hand
+    rank r and rank r + N/2 the two hyper-threads of the same cores; a rank gets whole physical cores (all their hardware threads),
+    ranks are dealt over the NUMA nodes in blocks (ranks 0..N/k-1 on node 0, ...), which is also how the GPUs of a node are usually
+    attached.  Nothing is changed when the launcher has already bound this rank (the inherited affinity is narrower than the machine:
+    numactl / torchrun binding), with one rank, with fewer physical cores than ranks, or with P4C_NO_AFFINITY=1.
+    Returns the sorted CPU list of this rank or None; AFFINITY_POLICY[0] names what was decided."""
+    import os
+
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        AFFINITY_POLICY[0] = "unchanged (one rank per host or no affinity interface)"
         return None
-    cores = sorted(os.sched_getaffinity(0))
-    per = len(cores) // local_world
-    if per < 1:
+    if os.environ.get("P4C_NO_AFFINITY") == "1":
+        AFFINITY_POLICY[0] = "unchanged (P4C_NO_AFFINITY=1)"
         return None
-    mine = cores[local_rank * per:(local_rank + 1) * per]
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < (os.cpu_count() or len(allowed)):
+        AFFINITY_POLICY[0] = f"unchanged (the launcher bound this rank to {len(allowed)} of {os.cpu_count()} CPUs)"
+        return None
+    topo = _cpu_topology(allowed)
+    if topo is None:
+        per = len(allowed) // local_world
+        if per < 1:
+            AFFINITY_POLICY[0] = "unchanged (fewer CPUs than ranks)"
+            return None
+        mine = allowed[local_rank * per:(local_rank + 1) * per]
+        AFFINITY_POLICY[0] = f"contiguous slice of the CPU ids ({per} per rank; topology not readable)"
+    else:
+        cores = {}      # (node, package, core) -> hardware threads
+        for c, key in topo.items():
+            cores.setdefault(key, []).append(c)
+        ordered = sorted(cores)                      # by NUMA node, then package, then core
+        per = len(ordered) // local_world
+        if per < 1:
+            AFFINITY_POLICY[0] = "unchanged (fewer physical cores than ranks)"
+            return None
+        mine = sorted(c for key in ordered[local_rank * per:(local_rank + 1) * per] for c in cores[key])
+        nodes = sorted({topo[c][0] for c in mine})
+        AFFINITY_POLICY[0] = (f"{per} physical cores per rank ({len(mine)} hardware threads), whole cores, ranks in blocks over the NUMA "
+                              f"nodes; this rank: node(s) {nodes}")
     os.sched_setaffinity(0, mine)
-    torch.set_num_threads(max(1, min(per, torch.get_num_threads())))
+    torch.set_num_threads(max(1, min(len(mine), torch.get_num_threads())))
     return mine
 
 

@@ -89,7 +89,7 @@ def _norm(name, ch):
 
 def _native(x: torch.Tensor) -> bool:
     """bf16 activations on the GPU: the round-5 kernels (csrc/gemm.hip) carry the wide Linears / convolutions / batch norms"""
-    return x.is_cuda and x.dtype == torch.bfloat16 and os.environ.get("P4C_UNETRPP_LIBRARY") != "1"
+    return x.is_cuda and x.dtype == torch.bfloat16 and L.diag_switch("P4C_UNETRPP_LIBRARY") != "1"
 
 
 def _lin(x: torch.Tensor, w: torch.Tensor, b=None, res=None) -> torch.Tensor:
@@ -282,7 +282,7 @@ class EPA(nn.Module):
             y = torch.cat([_linear(self.out_proj, x_sa), _linear(self.out_proj2, x_ca)], dim=-1)
             return y if res is None else res + R.param_as(gamma, y.dtype) * y
         h = self.out_proj.weight.shape[0]
-        if os.environ.get("P4C_UNETRPP_GAMMA_MUL") == "1":      # the round's first form: gamma * W, gamma * b as torch products
+        if L.diag_switch("P4C_UNETRPP_GAMMA_MUL") == "1":      # the round's first form: gamma * W, gamma * b as torch products
             g1, g2 = gamma[:h], gamma[h:]
             return G.cat_linear_res(x_sa, g1.unsqueeze(1) * self.out_proj.weight, g1 * self.out_proj.bias,
                                     x_ca, g2.unsqueeze(1) * self.out_proj2.weight, g2 * self.out_proj2.bias, res)
@@ -294,7 +294,7 @@ class EPA(nn.Module):
         B, N, C = x.shape
         h, d = self.heads, C // self.heads
         qkvv = _linear(self.qkvv, x).view(B, N, 4, h, d)
-        if x.is_cuda and os.environ.get("P4C_EPA_CORE") != "0" and TS.epa_core_ok(qkvv, self.E.out_features):
+        if x.is_cuda and L.diag_switch("P4C_EPA_CORE") != "0" and TS.epa_core_ok(qkvv, self.E.out_features):
             # the attention between the projections as one node: its backward writes dq / dk / dv straight into the gradient of qkvv
             x_sa, x_ca = TS.epa_core(qkvv, self.E.weight, self.E.bias, self.temperature, self.temperature2)
             return self._project_out(self._merge_sa(x_sa, B, N, C), x_ca.permute(0, 2, 1, 3).reshape(B, N, C), res, gamma)
@@ -302,8 +302,8 @@ class EPA(nn.Module):
         if d % 4:
             raise L.P4CError(f"UNetRPP: head width {d} must be a multiple of 4")
         eps = 1e-12                                                                        # F.normalize's clamp
-        fused_small = d <= 64 and self.E.out_features <= 64 and x.is_cuda and os.environ.get("P4C_NO_EPA_SMALL") != "1"
-        if fused_small and x.dtype == torch.bfloat16 and os.environ.get("P4C_NO_GRAM_NORMS") != "1":
+        fused_small = d <= 64 and self.E.out_features <= 64 and x.is_cuda and L.diag_switch("P4C_NO_EPA_SMALL") != "1"
+        if fused_small and x.dtype == torch.bfloat16 and L.diag_switch("P4C_NO_GRAM_NORMS") != "1":
             G, Gq, Gk = TS.gram_norms(q, k)          # q^T k and the squared column norms of q and k from one pass over q and k
         else:
             G, Gq, Gk = TS.gram(q, k), TS.gram(q, q), TS.gram(k, k)
@@ -323,7 +323,7 @@ class EPA(nn.Module):
             x_ca = TS.apply(v_ca, At).permute(0, 2, 1, 3).reshape(B, N, C)
         else:
             Mq = KP / nq.unsqueeze(-1) * self.temperature2
-        if x.is_cuda and os.environ.get("P4C_NO_EPA_SPATIAL") != "1" and TS.spatial_fused_ok(q, Mq.shape[-1]):
+        if x.is_cuda and L.diag_switch("P4C_NO_EPA_SPATIAL") != "1" and TS.spatial_fused_ok(q, Mq.shape[-1]):
             # softmax (and its adjoint) in the epilogue of the apply that produces its argument: ops_ts.epa_spatial
             x_sa = self._merge_sa(TS.epa_spatial(q, Mq, VP.transpose(-1, -2)), B, N, C)
         else:
@@ -494,7 +494,7 @@ class UNetRPPMI355X(ModelABC, nn.Module):
     def rollout_input_format(self):
         """(dtype, channel count) the rollout's build_x should emit for this model (see SwinUNetRMI355X.rollout_input_format): bf16 rows
         zero-padded to the 32-channel multiple the full-resolution convolutions of encoder1 run on; the stem reads the real channels."""
-        if self.act_dtype != torch.bfloat16 or self.in_channels > 96 or os.environ.get("P4C_NO_ROLLOUT_FORMAT") == "1":
+        if self.act_dtype != torch.bfloat16 or self.in_channels > 96 or L.diag_switch("P4C_NO_ROLLOUT_FORMAT") == "1":
             return None
         return torch.bfloat16, (self.in_channels + 31) // 32 * 32
 
@@ -520,7 +520,7 @@ class UNetRPPMI355X(ModelABC, nn.Module):
         # memory the library's deterministic solver for this shape took 1.1 s per step)
         o1 = self.out1
         if (out.dtype == torch.bfloat16 and o1.kernel_size == (1, 1) and out.permute(0, 2, 3, 1).is_contiguous() and o1.in_channels % 8 == 0
-                and os.environ.get("P4C_NO_OUT1_ROWS") != "1"):
+                and L.diag_switch("P4C_NO_OUT1_ROWS") != "1"):
             # the 1x1 output convolution (with bias) as a GEMM over the features-last pixel rows: no NCHW copy of the 64-channel map in
             # front of the library, no permuted result; inside the rollout the 60 outputs are padded to 64 (zero weight rows) and go
             # out as they are -- the row-GEMM kernel takes multiples of 8, the state update reads the first out_channels features

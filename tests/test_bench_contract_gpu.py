@@ -47,7 +47,7 @@ def test_default_run_reports_the_other_baseline_configurations(gpu_device):
     `other_configs` = {name: {ms_per_step, native_share, roofline_step_frac, workload}} (here on a small grid and a narrow UNETR++)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--grid", "128", "128", "--hidden", "256",
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--grid", "128", "128", "--hidden", "512",
                           "--no-cpu-baseline", "--no-fp32-flavour", "--no-larger-batch", "--hip-graph", "off"],
                          capture_output=True, text=True, timeout=1500, env=env, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]

@@ -284,3 +284,42 @@ def test_overlap_with_replaced_gradient_tensors_gloo():
     for r in (a, b):     # sharded + overlapped + replaced during the backward: refused loudly on every rank, never a silent wrong mean
         n_in, msg = r["sharded_replaced"]
         assert n_in >= 1 and msg is not None and "reduce-scattered" in msg
+
+
+def test_rank_pinning_hands_out_whole_physical_cores_per_numa_node(monkeypatch):
+    """pin_rank_to_cores on an SMT host whose CPU ids run socket 0, socket 1, socket-0 siblings, socket-1 siblings: every
+    rank gets whole physical cores (both hardware threads), ranks 0..N/2-1 on node 0 and the rest on node 1, no CPU twice; a rank the
+    launcher has already bound (inherited affinity narrower than the machine) is left alone; P4C_NO_AFFINITY=1 likewise."""
+    import os
+
+    from py4cast_amd import trainer as T
+
+    ncore = 16                                        # 2 sockets x 8 cores x 2 threads = 32 CPUs
+    topo = {}
+    for cpu in range(32):
+        core = cpu % ncore
+        topo[cpu] = (core // 8, core // 8, core % 8)  # (numa node, package, core id): cpu and cpu + 16 are siblings
+    pinned = {}
+    monkeypatch.setattr(T, "_cpu_topology", lambda cpus: {c: topo[c] for c in cpus})
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(32)))
+    monkeypatch.setattr(os, "cpu_count", lambda: 32)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: pinned.__setitem__("cpus", sorted(cpus)))
+    monkeypatch.setattr(T.torch, "set_num_threads", lambda n: None)
+    monkeypatch.delenv("P4C_NO_AFFINITY", raising=False)
+    seen = []
+    for r in range(4):
+        mine = T.pin_rank_to_cores(r, 4)
+        assert mine == pinned["cpus"] and len(mine) == 8
+        assert all((c + 16) % 32 in mine for c in mine)                      # both hardware threads of every core
+        assert len({topo[c][0] for c in mine}) == 1 and topo[mine[0]][0] == r // 2
+        assert "physical cores per rank" in T.AFFINITY_POLICY[0]
+        seen += mine
+    assert sorted(seen) == list(range(32))
+    # contiguous id slices would have given rank 0 the cpus 0..7 WITHOUT their siblings 16..23
+    assert T.pin_rank_to_cores(0, 4) == [0, 1, 2, 3, 16, 17, 18, 19]
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)))   # bound by the launcher
+    assert T.pin_rank_to_cores(1, 4) is None and "launcher bound" in T.AFFINITY_POLICY[0]
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(32)))
+    monkeypatch.setenv("P4C_NO_AFFINITY", "1")
+    assert T.pin_rank_to_cores(1, 4) is None and "P4C_NO_AFFINITY" in T.AFFINITY_POLICY[0]
+    assert T.pin_rank_to_cores(0, 1) is None

@@ -417,8 +417,8 @@ def test_unetrpp_takes_its_input_straight_from_build_x(gpu_device):
     assert cos > 0.999, cos
 
 
-@pytest.mark.parametrize("N,hidden,heads,proj", [(256, 64, 4, 16), (1024, 128, 16, 64), (4096, 128, 4, 32)])
-def test_epa_core_as_one_node(gpu_device, monkeypatch, N, hidden, heads, proj):
+@pytest.mark.parametrize("N,hidden,heads,proj", [(256, 64, 4, 16), (1024, 128, 16, 64), (4096, 128, 4, 32), (16384, 128, 16, 64), (4096, 256, 16, 64)])
+def test_epa_core_as_one_node(gpu_device, monkeypatch, diag_library, N, hidden, heads, proj):
     """The attention between the projections as ONE autograd node (ops_ts.epa_core: dq / dk / dv written straight into the gradient of
     the qkvv projection) against the same module composed of separate nodes: identical output (same kernels, same order), gradients
     equal up to the bf16 rounding of sums taken in another order."""
@@ -445,6 +445,24 @@ def test_epa_core_as_one_node(gpu_device, monkeypatch, N, hidden, heads, proj):
     assert _rel(xa, xb) < 2e-2
     for n in ga:
         assert _rel(ga[n], gb[n]) < 2e-2, n
+    if N >= 2048 and hidden <= 256:
+        # round 6: the token-axis projection E = F on the tall-skinny kernels with k / v_sa read in place (ops_ts._token_proj_native; a
+        # diagnostic route -- measured no faster than the (2,B,N,C) gather + library GEMM, which stays the product's) gives the same node
+        from py4cast_amd import ops_ts as TS
+
+        monkeypatch.setenv("P4C_EPA_CORE", "1")
+        monkeypatch.setenv("P4C_EPA_NATIVE_PROJ", "1")
+        assert TS._token_proj_native(torch.empty(2, N, 4, heads, hidden // heads, dtype=torch.bfloat16, device=gpu_device), proj)
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        (y.float() * w).sum().backward()
+        gl = {n: p.grad.float().clone() for n, p in m.named_parameters()}
+        assert _rel(ya, y.detach().float()) < 2e-3 and _rel(xa, x.grad.float()) < 2e-2
+        for n in ga:
+            assert _rel(ga[n], gl[n]) < 2e-2, n
+        monkeypatch.delenv("P4C_EPA_NATIVE_PROJ")
+        assert not TS._token_proj_native(torch.empty(2, N, 4, heads, hidden // heads, dtype=torch.bfloat16, device=gpu_device), proj)
 
 
 def test_unetrpp_bf16_step_makes_no_library_convolution_and_tracks_the_oracle(gpu_device, monkeypatch):

@@ -1520,7 +1520,7 @@ def test_graph_memset_nodes_are_rewritten(gpu_device):
 # ----------------------------------------------------------------------------------------- compact-channel convolutions (round 3)
 @pytest.mark.parametrize("shape", [(2, 72, 96, 24, 24, 3), (2, 64, 128, 48, 24, 1), (1, 40, 80, 24, 48, 3), (2, 64, 96, 64, 24, 3),
                                    (2, 48, 72, 48, 64, 3), (2, 512, 512, 48, 24, 3)])
-def test_compact_channel_convolution_equals_the_padded_route(gpu_device, shape, monkeypatch):
+def test_compact_channel_convolution_equals_the_padded_route(gpu_device, shape, monkeypatch, diag_library):
     """ops_model.conv_nhwc on bf16 maps with fewer than 64 channels: the in-place route (p4c_conv_fwd_compact / p4c_conv_wgrad_compact:
     absent channel octets staged as zeros, only present ones stored) against the zero-padded 64-channel route it replaces -- same
     kernels, same operands: output and data gradient IDENTICAL, weight gradient to fp32 rounding -- and against float64 on the bf16 operands."""
@@ -1591,7 +1591,7 @@ def _swin_grads(gpu_device, dtype, x, gy, shape, cin, cout):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_swin_stage_padded_once_equals_padding_every_block(gpu_device, monkeypatch, dtype):
+def test_swin_stage_padded_once_equals_padding_every_block(gpu_device, monkeypatch, diag_library, dtype):
     """swinunetr.padded_stage (round 5): the stage kept in the padded layout against MONAI's per-block pad / crop order
     (P4C_SWIN_PAD_PER_BLOCK=1).  fp32 flavour: the same forward and gradients to the 1e-5 level (another order of a few fp32 sums).
     bf16 flavour: the two orders round the residual add differently (epilogue of the projection against a separate bf16 add), and on
