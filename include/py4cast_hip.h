@@ -765,6 +765,17 @@ int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* 
                     const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres, int dtype,
                     int B, int64_t N, int C, p4c_stream_t stream);
 
+/* p4c_inorm_reduce with the finalize INSIDE the launch (round 6): the workgroup that draws the last ticket turns the partial sums of all
+ * samples into the statistics, exactly as p4c_inorm_finalize_fwd / _bwd would (same summation order: bit-identical) -- one dependent
+ * 5-8 us launch less per normalisation each way.  Instance form only (one channel per statistics group).  ticket: one zeroed uint32 in
+ * device memory per launch in flight (the last workgroup resets it).
+ *   fwd: mean, rstd, scale = rstd gamma, shift = beta - mean scale     (B, C) each
+ *   bwd: c1 = sum dz / N, c2 = sum dz xhat / N (B, C); dgamma, dbeta (C), written (sums over the samples in order) */
+int p4c_inorm_reduce_finalize_fwd(const void* x, float* partial, unsigned int* ticket, const float* gamma, const float* beta, float eps,
+                                  float* mean, float* rstd, float* scale, float* shift, int dtype, int B, int64_t N, int C, p4c_stream_t stream);
+int p4c_inorm_reduce_finalize_bwd(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope,
+                                  float* partial, unsigned int* ticket, float* c1, float* c2, float* dgamma, float* dbeta, int dtype, int B,
+                                  int64_t N, int C, p4c_stream_t stream);
 /* The statistics of one normalisation from its partial sums, one launch each way (instead of a dozen tiny torch launches):
  *   forward : mean, rstd, scale = rstd * gamma, shift = beta - mean * scale  -- all (B, C) fp32; statistics per channel (groups = 0:
  *             instance norm) or per group of C / groups channels (GroupNorm; at most 64 channels per group);

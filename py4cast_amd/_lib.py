@@ -73,6 +73,8 @@ OTHER = {
     "p4c_inorm_reduce": ([P, P, P, P, P, F, P, I, I, L, I, P], c_int),
     "p4c_inorm_apply": ([P, P, P, P, P, P, P, P, P, P, F, P, P, I, I, L, I, P], c_int),
     "p4c_inorm_finalize_fwd": ([P, I, I, L, I, I, P, P, F, P, P, P, P, P], c_int),
+    "p4c_inorm_reduce_finalize_fwd": ([P, P, P, P, P, F, P, P, P, P, I, I, L, I, P], c_int),
+    "p4c_inorm_reduce_finalize_bwd": ([P, P, P, P, P, F, P, P, P, P, P, P, I, I, L, I, P], c_int),
     "p4c_inorm_finalize_bwd": ([P, I, I, L, I, I, P, P, P, P, P, P, P], c_int),
     "p4c_ts_gram_splits": ([L], c_int),
     "p4c_ts_gram": ([P, I, L, L, L, P, I, L, L, L, P, I, I, L, I, I, P], c_int),

@@ -12,14 +12,34 @@ namespace inorm {
 __device__ __forceinline__ p4c_f32x4 ld4(const float* p) { return *reinterpret_cast<const p4c_f32x4*>(p); }
 __device__ __forceinline__ p4c_f32x4 ld4(const bf16* p) { return load4f(p); }
 
+// Finalize INSIDE the reduce launch (round 6): the workgroup that draws the last ticket turns the partials of all samples into the
+// statistics -- what p4c_inorm_finalize_fwd / _bwd do in a launch of their own (a dependent 5-8 us launch per normalisation each way:
+// ~160 per SwinUNETR training step, the finalize launches of UNETR++'s full-resolution blocks and batch norms).  Instance form only
+// (one channel per statistics group).  The partials go out as device-scope (write-through) stores, the ticket follows once they are
+// acknowledged, the last workgroup invalidates before it reads them (the pattern of the row kernel's BatchFin); it sums them with the
+// same slice_sums() and the same per-channel expressions as the finalize kernels: bit-identical statistics.
+struct InFin {
+    unsigned int* ticket;     // zero between launches (the last workgroup resets it); nullptr: no in-kernel finalize
+    const float* gamma;       // forward
+    const float* beta;
+    float eps;
+    float* o0;                // forward: mean, rstd, scale, shift (B, C);  backward: c1, c2 (B, C), dgamma, dbeta (C)
+    float* o1;
+    float* o2;
+    float* o3;
+    double n_group;           // pixels per statistics group
+    int CB, SL;               // finalize_geometry(C, 1)
+};
+__device__ void finalize_in_kernel(const InFin& f, bool bwd, const float* partial, int nb, int B, int C, float* red0, float* red1);
+
 // partial[b][blk][0][c] = sum a, [1][c] = sum a*b over the block's pixels, with
 //   MODE 0 (forward):  a = x,  b = x
 //   MODE 1 (backward): a = dz = dy * (y > 0 ? 1 : slope),  b = xhat = (x - mean) * rstd
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, float slope,
-                                                     float* __restrict__ partial, int64_t N, int C) {
-    extern __shared__ float red[];              // [rows][2][C]
+                                                     float* __restrict__ partial, int64_t N, int C, InFin fin) {
+    extern __shared__ float red[];              // [rows][2][C]  (>= 2048 floats: the in-kernel finalize reuses it)
     const int b = blockIdx.y, cqn = C >> 2;
     const int rows = 256 / cqn > 0 ? 256 / cqn : 1;
     const T* xb = x + (int64_t)b * N * C;
@@ -55,8 +75,18 @@ __global__ void __launch_bounds__(256) reduce_kernel(const T* __restrict__ x, co
     for (int i = threadIdx.x; i < 2 * C; i += 256) {
         float s = 0.f;
         for (int r = 0; r < rows; ++r) s += red[r * 2 * C + i];
-        partial[((int64_t)b * gridDim.x + blockIdx.x) * 2 * C + i] = s;
+        __hip_atomic_store(partial + ((int64_t)b * gridDim.x + blockIdx.x) * 2 * C + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (!fin.ticket) return;
+    __shared__ unsigned int lflag;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's partial stores are acknowledged
+    __syncthreads();                                        // ... and every wave's
+    if (threadIdx.x == 0) lflag = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (lflag != gridDim.x * gridDim.y - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // invalidate only: the other workgroups' partials are read from memory
+    if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    finalize_in_kernel(fin, MODE == 1, partial, (int)gridDim.x, (int)gridDim.y, C, red, red + 1024);
 }
 
 // forward: y = lrelu(x * scale[b,c] + shift[b,c] (+ res));  backward (MODE 1): dx = scale * (dz - m1 - xhat * m2), dres = dz;
@@ -158,6 +188,43 @@ __device__ __forceinline__ void slice_sums(const float* __restrict__ part, int n
     }
 }
 
+// instance form (one channel per group) of both finalizes for ALL samples, by one workgroup of 256 threads (see InFin)
+__device__ void finalize_in_kernel(const InFin& f, bool bwd, const float* partial, int nb, int B, int C, float* red0, float* red1) {
+    const int tid_c = threadIdx.x;
+    for (int c_lo = 0; c_lo < C; c_lo += f.CB) {
+        const int c = c_lo + tid_c;
+        const bool mine = tid_c < f.CB && c < C;
+        float dg = 0.f, db = 0.f;
+        for (int b = 0; b < B; ++b) {
+            __syncthreads();
+            slice_sums(partial + (int64_t)b * nb * 2 * C, nb, C, c_lo, f.CB, f.SL, red0, red1);
+            if (mine) {
+                if (!bwd) {
+                    const double mu = (double)red0[tid_c] / f.n_group;
+                    double var = (double)red1[tid_c] / f.n_group - mu * mu;
+                    var = var > 0.0 ? var : 0.0;
+                    const float r = (float)(1.0 / sqrt(var + (double)f.eps)), m = (float)mu;
+                    const float sc = r * f.gamma[c];
+                    f.o0[(int64_t)b * C + c] = m;
+                    f.o1[(int64_t)b * C + c] = r;
+                    f.o2[(int64_t)b * C + c] = sc;
+                    f.o3[(int64_t)b * C + c] = f.beta[c] - m * sc;
+                } else {
+                    const float S0 = red0[tid_c], S1 = red1[tid_c];
+                    db += S0;
+                    dg += S1;
+                    f.o0[(int64_t)b * C + c] = (float)((double)S0 / f.n_group);
+                    f.o1[(int64_t)b * C + c] = (float)((double)S1 / f.n_group);
+                }
+            }
+        }
+        if (bwd && mine) {
+            f.o2[c] = dg;
+            f.o3[c] = db;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) finalize_fwd_kernel(const float* __restrict__ part, int nb, int C, int cpg, double n_group,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
@@ -242,20 +309,21 @@ extern "C" int p4c_inorm_blocks(int64_t N, int C) {
     return inorm::blocks_for(N, rows);
 }
 
-extern "C" int p4c_inorm_reduce(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope,
-                                float* partial, int dtype, int B, int64_t N, int C, p4c_stream_t stream) {
+static int inorm_reduce_launch(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope, float* partial,
+                               int dtype, int B, int64_t N, int C, const inorm::InFin& fin, p4c_stream_t stream) {
     P4C_CHECK_ARG(x && partial && B > 0 && N > 0 && C > 0 && C % 4 == 0 && C <= 1024, "p4c_inorm_reduce: C must be a multiple of 4 up to 1024");
     const bool bwd = dy != nullptr;
     P4C_CHECK_ARG(!bwd || (y && mean && rstd), "p4c_inorm_reduce: the backward sums need y, mean and rstd");
     const int cqn = C / 4, rows = 256 / cqn > 0 ? 256 / cqn : 1;
     const dim3 grid(inorm::blocks_for(N, rows), B);
-    const size_t smem = (size_t)rows * 2 * C * sizeof(float);
+    size_t smem = (size_t)rows * 2 * C * sizeof(float);
+    if (smem < 2048 * sizeof(float)) smem = 2048 * sizeof(float);
     hipStream_t st = as_stream(stream);
 #define P4C_IN_RED(T, M)                                                                                             \
     do {                                                                                                             \
         P4C_TRY(ensure_dyn_smem((const void*)inorm::reduce_kernel<T, M>, 64 * 1024));                                \
         hipLaunchKernelGGL((inorm::reduce_kernel<T, M>), grid, dim3(256), smem, st, (const T*)x, (const T*)dy, (const T*)y, mean, \
-                           rstd, slope, partial, N, C);                                                              \
+                           rstd, slope, partial, N, C, fin);                                                         \
     } while (0)
     if (dtype == P4C_F32) { if (bwd) P4C_IN_RED(float, 1); else P4C_IN_RED(float, 0); }
     else if (dtype == P4C_BF16) { if (bwd) P4C_IN_RED(bf16, 1); else P4C_IN_RED(bf16, 0); }
@@ -263,6 +331,31 @@ extern "C" int p4c_inorm_reduce(const void* x, const void* dy, const void* y, co
 #undef P4C_IN_RED
     P4C_CHECK_LAUNCH("p4c_inorm_reduce");
     return P4C_OK;
+}
+
+extern "C" int p4c_inorm_reduce(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope,
+                                float* partial, int dtype, int B, int64_t N, int C, p4c_stream_t stream) {
+    return inorm_reduce_launch(x, dy, y, mean, rstd, slope, partial, dtype, B, N, C, inorm::InFin{}, stream);
+}
+
+extern "C" int p4c_inorm_reduce_finalize_fwd(const void* x, float* partial, unsigned int* ticket, const float* gamma, const float* beta, float eps,
+                                             float* mean, float* rstd, float* scale, float* shift, int dtype, int B, int64_t N, int C,
+                                             p4c_stream_t stream) {
+    P4C_CHECK_ARG(ticket && gamma && beta && mean && rstd && scale && shift, "p4c_inorm_reduce_finalize_fwd: NULL pointer");
+    inorm::InFin fin{ticket, gamma, beta, eps, mean, rstd, scale, shift, (double)N, 0, 0};
+    int blocks;
+    inorm::finalize_geometry(C > 0 ? C : 4, 1, &fin.CB, &fin.SL, &blocks);
+    return inorm_reduce_launch(x, nullptr, nullptr, nullptr, nullptr, 1.f, partial, dtype, B, N, C, fin, stream);
+}
+
+extern "C" int p4c_inorm_reduce_finalize_bwd(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope,
+                                             float* partial, unsigned int* ticket, float* c1, float* c2, float* dgamma, float* dbeta, int dtype,
+                                             int B, int64_t N, int C, p4c_stream_t stream) {
+    P4C_CHECK_ARG(ticket && dy && c1 && c2 && dgamma && dbeta, "p4c_inorm_reduce_finalize_bwd: NULL pointer");
+    inorm::InFin fin{ticket, nullptr, nullptr, 0.f, c1, c2, dgamma, dbeta, (double)N, 0, 0};
+    int blocks;
+    inorm::finalize_geometry(C > 0 ? C : 4, 1, &fin.CB, &fin.SL, &blocks);
+    return inorm_reduce_launch(x, dy, y, mean, rstd, slope, partial, dtype, B, N, C, fin, stream);
 }
 
 extern "C" int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,

@@ -413,14 +413,21 @@ class _BatchNormAct(torch.autograd.Function):
         N = yc.numel() // C
         dev = yc.device
         dout = dout.contiguous()
+        from . import ops_inorm as ON
+
         nb = L.lib().p4c_inorm_blocks(N, C)
         part = torch.empty(1, nb, 2, C, dtype=torch.float32, device=dev)
-        L.call("p4c_inorm_reduce", L.ptr(yc), L.ptr(dout), L.ptr(out), L.ptr(st[0]), L.ptr(st[1]), ctx.slope, L.ptr(part), L.dtype_code(yc.dtype),
-               1, N, C, L.stream(dev), alg_bytes=3 * yc.numel() * yc.element_size())
         co = torch.empty(2, C, dtype=torch.float32, device=dev)
         dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
-        L.call("p4c_inorm_finalize_bwd", L.ptr(part), nb, 1, N, C, 0, None, None, L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]),
-               L.stream(dev))
+        if ON.FUSED_FINALIZE:    # the coefficients and dgamma / dbeta from the reduce launch's last workgroup (csrc/inorm.hip: InFin)
+            L.call("p4c_inorm_reduce_finalize_bwd", L.ptr(yc), L.ptr(dout), L.ptr(out), L.ptr(st[0]), L.ptr(st[1]), ctx.slope, L.ptr(part),
+                   ON.next_ticket(dev), L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev),
+                   alg_bytes=3 * yc.numel() * yc.element_size())
+        else:
+            L.call("p4c_inorm_reduce", L.ptr(yc), L.ptr(dout), L.ptr(out), L.ptr(st[0]), L.ptr(st[1]), ctx.slope, L.ptr(part), L.dtype_code(yc.dtype),
+                   1, N, C, L.stream(dev), alg_bytes=3 * yc.numel() * yc.element_size())
+            L.call("p4c_inorm_finalize_bwd", L.ptr(part), nb, 1, N, C, 0, None, None, L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]),
+                   L.stream(dev))
         if not ctx.training:
             co.zero_()          # running statistics are constants: dy = scale * dz
         dy = torch.empty_like(yc)

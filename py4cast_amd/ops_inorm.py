@@ -9,6 +9,30 @@ import torch
 from . import _lib as L
 
 
+_TICKETS = {}      # device -> (zeroed uint32 slots, next slot): the tickets of the in-kernel finalize (csrc/inorm.hip: InFin)
+# Measured in round 6 (profiles/r06_ab_runs.txt 7) and NOT taken: SwinUNETR 26.8 ms with the in-kernel finalize against 25.65 with the
+# finalize launch, UNETR++ 143.9 against 137.7 -- the standalone finalize spreads its (sample, channel chunk) pairs over workgroups,
+# the last workgroup of the reduce launch walks them one after the other (C = 384: 12 serial slice sums) behind write-through stores and
+# a fence, and under HIP-graph replay the small dependent launch it saves costs ~2 us.  False = the product route; True is kept for the
+# parity tests of the entry points (tests/test_inorm_fin_gpu.py).
+FUSED_FINALIZE = False
+
+
+def next_ticket(device) -> int:
+    """address of a zeroed uint32 for one launch with an in-kernel finalize.  The last workgroup of that launch resets its ticket, so
+    a slot is reusable as soon as the launch has finished; launches of one stream run in order and far fewer than the 1 024 slots are
+    ever in flight, so the slots are dealt round-robin.  Allocated once per device OUTSIDE any HIP-graph capture (a captured launch
+    keeps the address)."""
+    key = str(device)
+    ent = _TICKETS.get(key)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.P4CError("ops_inorm: the ticket pool must exist before a HIP-graph capture (run one eager step first)")
+        ent = _TICKETS[key] = [torch.zeros(1024, dtype=torch.int32, device=device), 0]
+    ent[1] = (ent[1] + 1) % 1024
+    return ent[0].data_ptr() + 4 * ent[1]
+
+
 def _partials(x, dy, y, mean, rstd, slope):
     """p4c_inorm_reduce: per-block partial sums (B, nb, 2, C)"""
     B, C = x.shape[0], x.shape[-1]
@@ -55,8 +79,18 @@ class _InstNormAct(torch.autograd.Function):
         x = x.contiguous()
         res_c = None if res is None else res.contiguous()
         B, C = x.shape[0], x.shape[-1]
-        part, nb, N = _partials(x, None, None, None, None, slope)
-        mean, rstd, scale, shift = _finalize_fwd(part, nb, N, C, 0, weight, bias, eps)
+        if FUSED_FINALIZE:      # statistics finished by the reduce launch's last workgroup (no finalize launch)
+            N = x.numel() // (B * C)
+            nb = L.lib().p4c_inorm_blocks(N, C)
+            part = torch.empty(B, nb, 2, C, dtype=torch.float32, device=x.device)
+            st = torch.empty(4, B, C, dtype=torch.float32, device=x.device)
+            L.call("p4c_inorm_reduce_finalize_fwd", L.ptr(x), L.ptr(part), next_ticket(x.device), L.ptr(_f32(weight)), L.ptr(_f32(bias)), float(eps),
+                   L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]), L.dtype_code(x.dtype), B, N, C, L.stream(x.device),
+                   alg_bytes=x.numel() * x.element_size())
+            mean, rstd, scale, shift = st[0], st[1], st[2], st[3]
+        else:
+            part, nb, N = _partials(x, None, None, None, None, slope)
+            mean, rstd, scale, shift = _finalize_fwd(part, nb, N, C, 0, weight, bias, eps)
         y = torch.empty_like(x)
         L.call("p4c_inorm_apply", L.ptr(x), L.ptr(res_c), None, None, L.ptr(scale), L.ptr(shift), None, None, None, None, float(slope),
                L.ptr(y), None, L.dtype_code(x.dtype), B, N, C, L.stream(x.device))
@@ -69,8 +103,19 @@ class _InstNormAct(torch.autograd.Function):
         x, y, mean, rstd, scale = ctx.saved_tensors
         B, C = x.shape[0], x.shape[-1]
         dy = dy.contiguous()
-        part, nb, N = _partials(x, dy, y, mean, rstd, ctx.slope)
-        m1, m2, dgamma, dbeta = _finalize_bwd(part, nb, N, C, 0, None, None)
+        if FUSED_FINALIZE:
+            N = x.numel() // (B * C)
+            nb = L.lib().p4c_inorm_blocks(N, C)
+            part = torch.empty(B, nb, 2, C, dtype=torch.float32, device=x.device)
+            co = torch.empty(2, B, C, dtype=torch.float32, device=x.device)
+            dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)
+            L.call("p4c_inorm_reduce_finalize_bwd", L.ptr(x), L.ptr(dy), L.ptr(y), L.ptr(mean), L.ptr(rstd), float(ctx.slope), L.ptr(part),
+                   next_ticket(x.device), L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]), L.dtype_code(x.dtype), B, N, C,
+                   L.stream(x.device), alg_bytes=3 * x.numel() * x.element_size())
+            m1, m2, dgamma, dbeta = co[0], co[1], dgb[0], dgb[1]
+        else:
+            part, nb, N = _partials(x, dy, y, mean, rstd, ctx.slope)
+            m1, m2, dgamma, dbeta = _finalize_bwd(part, nb, N, C, 0, None, None)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         L.call("p4c_inorm_apply", L.ptr(x), None, L.ptr(dy), L.ptr(y), L.ptr(scale), None, L.ptr(mean), L.ptr(rstd), L.ptr(m1), L.ptr(m2),

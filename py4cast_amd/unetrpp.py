@@ -262,11 +262,35 @@ class EPA(nn.Module):
         self.temperature2 = nn.Parameter(torch.ones(heads, 1, 1))
         self.qkvv = nn.Linear(hidden, hidden * 4, bias=False)
         self.E = nn.Linear(tokens, proj)
-        if published:      # the published module list: E and F are ONE Linear under two names, two (identity at p = 0) attention dropouts
-            self.F = self.E
+        if published:
+            # the published module list: ``self.E = self.F = nn.Linear(..)`` -- ONE Linear under two names -- and two attention dropouts
+            # (identity at p = 0).  The alias is NOT registered as a second sub-module here: torch.func.functional_call (the rollout's
+            # per-step parameter stand-ins, trainer.RolloutParamProxies) swaps tensors per NAME and leaves a twice-registered module
+            # holding the stand-in afterwards.  The state dict carries the published keys all the same: ``F.*`` is added on save and
+            # accepted on load by the two hooks below; ``self.F`` is a property.
             self.attn_drop, self.attn_drop_2 = nn.Dropout(attn_drop), nn.Dropout(attn_drop)
+            self._register_state_dict_hook(EPA._add_f_keys)
+            self._register_load_state_dict_pre_hook(EPA._take_f_keys)
         self.out_proj = nn.Linear(hidden, hidden // 2)
         self.out_proj2 = nn.Linear(hidden, hidden // 2)
+
+    @property
+    def F(self):
+        """the published code's second name of the token-axis Linear (``self.E = self.F = nn.Linear(input_size, proj_size)``)"""
+        return self.E
+
+    @staticmethod
+    def _add_f_keys(module, state_dict, prefix, local_metadata):
+        for k in ("weight", "bias"):
+            if prefix + "E." + k in state_dict:
+                state_dict[prefix + "F." + k] = state_dict[prefix + "E." + k]
+
+    @staticmethod
+    def _take_f_keys(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for k in ("weight", "bias"):
+            f = state_dict.pop(prefix + "F." + k, None)
+            if f is not None and prefix + "E." + k not in state_dict:
+                state_dict[prefix + "E." + k] = f       # a checkpoint that kept only the second name
 
     def _merge_sa(self, x_sa, B, N, C):
         """(B, h, N, d) -> (B, N, C): head-major per token (restated block: a view of the kernels' token-major output), or the published
