@@ -713,7 +713,7 @@ def _main(args, others=None):
                 # measured HBM bytes of a whole step, when a committed PMC run of THIS configuration exists (separate rocprofv3 --pmc
                 # FETCH_SIZE / WRITE_SIZE passes over every dispatch, tools/diagnostics/r04_pmc_step.sh): only for the default shape
                 if (B, H, W, F, Fs, Ff, T) == (2, 512, 512, 60, 4, 5, 3) and args.dtype == "bf16":
-                    hb, src = L.committed_traffic(("r05_pmc_traffic_step.json", "r04_pmc_traffic_step.json"), ("hbm_bytes_per_step", "total"))
+                    hb, src = L.committed_traffic(("r06_pmc_traffic_step.json", "r05_pmc_traffic_step.json", "r04_pmc_traffic_step.json"), ("hbm_bytes_per_step", "total"))
                     roof["step"]["traffic"] = hb
                     roof["step"]["traffic_source"] = src
             wg = (extra or {}).get("wgrad_avg_launch_ms_overlapped")

@@ -6,11 +6,17 @@ GNN: grid/mesh/edge embedders (MLP = Linear-SiLU-Linear-LayerNorm), InteractionN
 InteractionNets on the mesh, InteractionNet mesh->grid, output MLP.  PARITY UNPINNED against mfai (absent here); the
 arithmetic is checked against oracle/graphlam.py, which runs the same parameters through index_select / cat / index_add_.
 
-What runs where
-* every Linear / LayerNorm: torch (hipBLASLt GEMMs -- plain library GEMMs, 2 GFLOP each on 262k grid nodes);
-* every edge pass: the HIP kernels of csrc/graph.hip through py4cast_amd.ops_graph -- the first Linear of an edge MLP is
-  distributed over ``cat[e, x_s[src], x_r[dst]]`` (three small GEMMs on E / N_s / N_r rows instead of one on an E x 3C gather),
-  gather + add + SiLU is one kernel, aggregation is a CSR segment sum (no atomics, reproducible).
+What runs where (bf16 activations, ``activation_dtype: bf16``; state after round 6)
+* every MLP (Linear - SiLU - Linear - LayerNorm [+ residual], hidden 64): ONE fused kernel each way (csrc/mlp.hip through
+  py4cast_amd.ops_mlp.row_mlp); on edges the first Linear is distributed over ``cat[e, x_s[src], x_r[dst]]`` and the sender / receiver
+  parts enter the kernel as gathered addends, so nothing of size E x 3C is ever formed;
+* the node projections of that distributed first Linear (and the receiver half of the node-update MLP's): ONE launch per direction for
+  all blocks that multiply the same node tensor (csrc/nodeproj.hip through py4cast_amd.ops_nodeproj.node_proj), the residual's gradient
+  summed inside the data-gradient launch;
+* aggregation: a CSR segment sum (csrc/graph.hip; no atomics, reproducible), its adjoint an edge gather;
+* parameter gradients: added straight into the parameters' ``.grad`` buffers by one batched reduction per backward pass
+  (ops_nodeproj.GradQueue) -- no per-parameter AccumulateGrad launch, no per-call reduction launch;
+* the fp32 flavour (``activation_dtype: f32``, parity) keeps library GEMMs for the Linears and the row LayerNorm / gather kernels.
 The batch dimension is folded into the node dimension (edge lists replicated with node offsets, cached per batch size).
 Graph models receive (B, ngrid, C_in) and return (B, ngrid, F) (py4cast/lightning.py:526-535).
 """

@@ -506,7 +506,7 @@ class HalfUNetMI355X(ModelABC, nn.Module):
             if esz == 2 and (B, H, W) == (2, 512, 512):
                 # HBM bytes per launch of this launch shape from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE with the
                 # gfx950 corrections): a committed figure, reported only when it was measured on this tree's kernel sources
-                traffic, traffic_source = L.committed_traffic(("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"),
+                traffic, traffic_source = L.committed_traffic(("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"),
                                                               (kname, "hbm_bytes_per_launch"))
             return {"bound": "hbm", "kernel": kname + " (3x3 conv 64->64, forward-plan launches at full resolution)",
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": traffic,

@@ -7,8 +7,8 @@ level its own node-update MLP (neural-lam's ``edge_chunk_sizes`` / ``aggr_chunk_
 exchange information in every layer instead of sweeping down and up.  PARITY UNPINNED against mfai (absent here); checked
 against oracle/hilam.py::HiLamParallel.
 
-Per layer and edge set: node projections of the distributed first Linear (small library GEMMs), ONE fused row-MLP kernel over the
-set's edges (ops_mlp.row_mlp with gathered addends), one CSR segment sum into its receiver level; per level the messages of its
+Per layer and edge set: node projections of the distributed first Linear (one launch per node tensor and direction,
+ops_nodeproj.node_proj), ONE fused row-MLP kernel over the set's edges (ops_mlp.row_mlp with gathered addends), one CSR segment sum into its receiver level; per level the messages of its
 (up to three) incoming edge sets are added and one fused node-update kernel runs.
 """
 

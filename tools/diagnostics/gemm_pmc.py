@@ -13,7 +13,10 @@ import torch
 from py4cast_amd import ops_gemm as G
 
 dev = torch.device("cuda:0")
-for (B, H, W, C) in [(2, 128, 128, 128), (1, 16, 16, 1024)]:
+which = sys.argv[1] if len(sys.argv) > 1 else "all"      # conv128 | conv1024 | linear | all (one shape per profiled process: the two
+shapes = {"conv128": [(2, 128, 128, 128)], "conv1024": [(1, 16, 16, 1024)], "linear": [],   # convolutions launch the same grid size)
+          "all": [(2, 128, 128, 128), (1, 16, 16, 1024)]}[which]
+for (B, H, W, C) in shapes:
     x = torch.randn(B, H, W, C, device=dev).bfloat16().view(-1, C)
     dy = torch.randn(B, H, W, C, device=dev).bfloat16().view(-1, C)
     w = torch.randn(C, C, 3, 3, device=dev) / (9 * C) ** 0.5
@@ -21,9 +24,10 @@ for (B, H, W, C) in [(2, 128, 128, 128), (1, 16, 16, 1024)]:
     for _ in range(20):
         G.gemm_nt(x, fwd, C, 9 * C, conv=(H, W, C), want_stats=True)
         G.gemm_tn(dy, x, C, C, conv=(H, W))
-xl = torch.randn(32768, 128, device=dev).bfloat16()
-wl = torch.randn(128, 128, device=dev) / 128 ** 0.5
-fwd, _ = G.weight_images(wl, 1)
-for _ in range(20):
-    G.gemm_nt(xl, fwd, 128, 128)
+if which in ("linear", "all"):
+    xl = torch.randn(32768, 128, device=dev).bfloat16()
+    wl = torch.randn(128, 128, device=dev) / 128 ** 0.5
+    fwd, _ = G.weight_images(wl, 1)
+    for _ in range(20):
+        G.gemm_nt(xl, fwd, 128, 128)
 torch.cuda.synchronize()

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out/r06; mkdir -p $O
-python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $O/gpu_tests.txt
+python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^FAILED|^ERROR" | tail -12 > $O/gpu_tests.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
 PM="FETCH_SIZE|WRITE_SIZE|SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE|SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 IFS='|'; for c in $PM; do
