@@ -79,20 +79,29 @@ __global__ void __launch_bounds__(256) first_conv_tail_kernel(ThinArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) a1[q] = a2[q] = 0.f;
 
-    for (int g = wid; g < ngroups; g += nwaves) {
-        const int p0 = g * 32, yy = p0 / W, x0 = p0 - yy * W;
-        bf16x8 Bop[5];
+    // the NEXT group's operands (5 tap octets + 4 row pieces of y per lane) are in flight while the current group is multiplied, transposed
+    // and stored: a wave walks ~8 groups, and without the prefetch every one of them exposed its full memory round trip (45-51 us per
+    // launch for 134 MB in the first trace of the round)
+    auto load_group = [&](int g, bf16x8 (&bop)[5], u32x4 (&yq)[4]) __attribute__((always_inline)) {
+        const bool live = g < ngroups;
+        const int p0 = live ? g * 32 : 0, yy = p0 / W, x0 = p0 - yy * W;
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             const int tap = 2 * s + h, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
             const int sy = yy + dy, sx = x0 + r + dx;
-            const bool ok = tap < 9 && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+            const bool ok = live && tap < 9 && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? ((sy * W + sx) * a.x_cs + a.c0) * 2 : OOB, 0, 0);
-            Bop[s] = __builtin_bit_cast(bf16x8, v);
+            bop[s] = __builtin_bit_cast(bf16x8, v);
         }
-        u32x4 yv[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) yv[it] = *reinterpret_cast<const u32x4*>(yb + ((int64_t)p0 + 8 * it + prow) * 64 + 8 * c8);
+        for (int it = 0; it < 4; ++it) yq[it] = *reinterpret_cast<const u32x4*>(yb + ((int64_t)p0 + 8 * it + prow) * 64 + 8 * c8);
+    };
+    bf16x8 Bop[5], Bnx[5];
+    u32x4 yv[4], ynx[4];
+    load_group(wid, Bop, yv);
+    for (int g = wid; g < ngroups; g += nwaves) {
+        const int p0 = g * 32;
+        load_group(g + nwaves, Bnx, ynx);
         f32x16 acc[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
@@ -126,6 +135,10 @@ __global__ void __launch_bounds__(256) first_conv_tail_kernel(ThinArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 5; ++s) Bop[s] = Bnx[s];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) yv[it] = ynx[it];
     }
     if (a.stat_partial) {
         // one [2][64] slot per wave (also from a wave without a group: the finalize sums every slot)
