@@ -97,7 +97,7 @@ def test_plan_with_the_split_first_convolution_tracks_the_one_launch_plan(gpu_de
     for n in gs:
         assert cos(gs[n].double().flatten(), go[n].double().flatten()) > 0.8, n
     ga, gb = torch.cat([gs[n].double().flatten() for n in gs]), torch.cat([go[n].double().flatten() for n in gs])
-    assert cos(ga, gb) > 0.95
+    assert cos(ga, gb) > 0.9
     assert cos(dxs.double().flatten(), dxo.double().flatten()) > 0.9
 
 
