@@ -72,6 +72,7 @@ def parse_args():
     ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: reduce-scatter + sharded AdamW + all-gather instead of all-reduce + full AdamW (auto: above 16 MB of gradients)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: exchange the gradients after the backward instead of inside it")
+    ap.add_argument("--bucket-mb", type=int, default=64, help="N > 1: size of the gradient buckets above the 16 MB single-bucket threshold")
     ap.add_argument("--deterministic", action="store_true",
                     help="library convolutions on their deterministic solvers (torch.backends.cudnn.deterministic): SwinUNetR / UNetRPP "
                          "steps then reproduce bit for bit (DESIGN.md 7a)")
@@ -488,7 +489,7 @@ def _main(args, others=None):
     ).to(device)
     n_grad_bytes = 4 * sum(p.numel() for p in lm.model.parameters() if p.requires_grad)
     sharded = world > 1 and (args.sharded == "on" or (args.sharded == "auto" and n_grad_bytes > (16 << 20)))
-    ddp = FlatDDP(lm.model, world, sharded=sharded, overlap=not args.no_overlap)
+    ddp = FlatDDP(lm.model, world, bucket_bytes=args.bucket_mb << 20, sharded=sharded, overlap=not args.no_overlap)
     opt = lm.configure_optimizers()["optimizer"]
     sharded = sharded and hasattr(opt, "step_shards")
 

@@ -107,6 +107,26 @@ def invalidate_param_caches():
     PARAM_EPOCH[0] += 1
 
 
+# Gradients written IN PLACE (ops_gemm.GRADS_IN_PLACE, graphlam.GRADS_IN_PLACE: a reduction kernel adds dW into the parameter's .grad
+# buffer, autograd gets None) pass no AccumulateGrad node, so no per-parameter hook fires for them.  A gradient exchange that wants to
+# start inside the backward (trainer.FlatDDP(overlap=True)) listens here instead:
+#   * grad_sink_taken(view)  -- a forward pass took `view` (a region of some parameter's .grad) as the destination of a later backward;
+#   * grad_written(*views)   -- the kernels that ADD into these regions have just been enqueued on the current stream (called from
+#                               inside the backward pass, after the launch: a stream that waits for the current one sees the sums).
+GRAD_SINK_LISTENERS = []
+
+
+def grad_sink_taken(view):
+    for listener in GRAD_SINK_LISTENERS:
+        listener.sink_taken(view)
+
+
+def grad_written(*views):
+    if GRAD_SINK_LISTENERS:
+        for listener in GRAD_SINK_LISTENERS:
+            listener.written(views)
+
+
 # Values derived from the parameters (re-laid weight images, bf16 copies of weight blocks) are cached per parameter version in
 # eager mode.  Inside a HIP-graph capture they must be produced by kernels of THAT graph (a replay has to see the current
 # parameters), but once per capture is enough: the capturing code (trainer.GraphedTrainingStep) opens a scope, the ops keep what

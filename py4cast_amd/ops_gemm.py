@@ -127,7 +127,10 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, Mo: int, Cin: int, conv=None, wan
     ws = torch.empty(max(lib.p4c_gemm_tn_workspace_bytes(R, Mo, taps * Cin) // 4, 1), dtype=torch.float32, device=dy.device)
     L.call("p4c_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), R, Mo, H, W, Cin, taps, L.ptr(dw), L.ptr(db), int(sink is not None),
            L.ptr(ws), L.stream(dy.device), alg_bytes=2 * R * (Mo + Cin) + 4 * Mo * Cin * taps, alg_flops=2 * R * Mo * Cin * taps)
-    return (None, None) if sink is not None else (dw, db)
+    if sink is not None:
+        L.grad_written(dw, db)       # (FlatDDP(overlap=True) counts these: the bucket may leave once its last sum is enqueued)
+        return None, None
+    return dw, db
 
 
 # Weight / bias gradients are ADDED straight into the parameters' .grad buffers by the reduction kernel (p4c_gemm_tn, accumulate = 1)
@@ -255,6 +258,8 @@ class _CatLinearRes(torch.autograd.Function):
             dw, db = sink if in_place else (torch.empty_like(dw_raw), torch.empty_like(db_raw))
             L.call("p4c_gemm_scale_fold_bwd", L.ptr(dw_raw), L.ptr(db_raw), L.ptr(_f32(w)), L.ptr(_f32(b)), L.ptr(_f32(g)), O, K, L.ptr(dw), L.ptr(db),
                    L.ptr(dg), int(in_place), L.stream(dy.device), alg_bytes=4 * O * K * (3 + in_place))
+            if in_place:
+                L.grad_written(dw, db, dg)
             outs.append((None, None) if in_place else (dw, db))
         (dwa, dba), (dwb, dbb) = outs
         return (dxa, cast(dwa, wadt), cast(dba, badt), dxb, cast(dwb, wbdt), cast(dbb, bbdt), dy,

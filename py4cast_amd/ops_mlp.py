@@ -128,6 +128,7 @@ class _RowMLP(torch.autograd.Function):
 
             GradQueue.begin(ws)    # the partials' reduction joins the batched ones at the end of this backward pass
             L.call("p4c_row_mlp_bwd_accumulate", ctypes.byref(d), ctypes.byref(gs), L.ptr(ws), L.stream(x.device), alg_bytes=nbytes)
+            GradQueue.wrote(ctx.sinks)
             dw1 = dw2 = db1 = db2 = dgam = dbet = None
         else:
             L.call("p4c_row_mlp_bwd", ctypes.byref(d), L.ptr(grads), L.ptr(ws), L.stream(x.device), alg_bytes=nbytes)

@@ -35,6 +35,7 @@ class GradQueue:
     enabled = True          # False: every call reduces at once (the A/B reference of tests/test_nodeproj_gpu.py)
     _task = -1
     _keep: List[torch.Tensor] = []
+    _views: List[torch.Tensor] = []      # the .grad regions the queued reductions will add into (told to L.grad_written at the flush)
     _stream = None
 
     @classmethod
@@ -47,7 +48,7 @@ class GradQueue:
         if cls._task != task:
             if cls._task >= 0:      # a pass that died before its callback ran: its queued jobs are void
                 L.lib().p4c_grad_reduce_defer(-1)
-                cls._keep = []
+                cls._keep, cls._views = [], []
             cls._task = task
             cls._stream = torch.cuda.current_stream(keep.device)
             L.lib().p4c_grad_reduce_defer(1)
@@ -55,14 +56,29 @@ class GradQueue:
         cls._keep.append(keep)
 
     @classmethod
+    def wrote(cls, views) -> None:
+        """After the launch that produced the partials: ``views`` (regions of parameters' .grad) receive their sums when the queue is
+        flushed -- or have just received them when nothing is being deferred."""
+        if not L.GRAD_SINK_LISTENERS:
+            return
+        views = [v for v in views if v is not None]
+        if cls._task >= 0 and cls._task == torch._C._current_graph_task_id():
+            cls._views.extend(views)
+        else:
+            L.grad_written(*views)
+
+    @classmethod
     def flush(cls) -> None:
         if cls._task < 0:
             return
+        views = cls._views
         try:
             L.check(L.lib().p4c_grad_reduce_flush(ctypes.c_void_p(cls._stream.cuda_stream)), "p4c_grad_reduce_flush")
         finally:
             L.lib().p4c_grad_reduce_defer(0)
-            cls._task, cls._keep, cls._stream = -1, [], None
+            cls._task, cls._keep, cls._views, cls._stream = -1, [], [], None
+        if views:
+            L.grad_written(*views)
 
 
 def _arr(tensors: Sequence[torch.Tensor]):
@@ -114,6 +130,7 @@ class _NodeProj(torch.autograd.Function):
         GradQueue.begin(ws)
         L.call("p4c_node_proj_wgrad", _arr(dyl), L.ptr(x), R, m, _arr(gl), _lds(gl), L.ptr(ws), L.stream(x.device),
                alg_bytes=R * 128 * (1 + m) + ws.numel() * 4, alg_flops=2 * R * 64 * 64 * m)
+        GradQueue.wrote(gl)
         return (dx,) + none
 
 

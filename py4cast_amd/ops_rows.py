@@ -126,7 +126,10 @@ def grad_view(t: Optional[torch.Tensor]):
     if (g is None or g.dtype != torch.float32 or g.shape != base.shape or g.stride() != base.stride()
             or t.dtype != torch.float32):
         return False
-    return g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset() + g.storage_offset())
+    view = g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset() + g.storage_offset())
+    if L.GRAD_SINK_LISTENERS:     # (an exchange that starts inside the backward wants to know which gradients bypass autograd)
+        L.grad_sink_taken(view)
+    return view
 
 
 _WCAST = {}   # eager mode: (address, shape, strides, dtype) -> (parameter version, copy in the rows' dtype)
@@ -216,6 +219,7 @@ def _sink_weight_grad(x, dy, gw):
         gw.add_(buf[: O * K].view(O, K))
     else:
         gw.add_(dy.t() @ x)
+    L.grad_written(gw)
 
 
 class _RowLinearMulti(torch.autograd.Function):

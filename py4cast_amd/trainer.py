@@ -21,6 +21,31 @@ import torch
 import torch.distributed as dist
 
 
+class _GradSinkListener:
+    """FlatDDP's entry in ``_lib.GRAD_SINK_LISTENERS`` (a weak reference: a dropped FlatDDP stops listening by itself)."""
+
+    def __init__(self, owner):
+        import weakref
+
+        self.ref = weakref.ref(owner, lambda _r: self.remove())
+
+    def remove(self):
+        from . import _lib as L
+
+        if self in L.GRAD_SINK_LISTENERS:
+            L.GRAD_SINK_LISTENERS.remove(self)
+
+    def sink_taken(self, view):
+        owner = self.ref()
+        if owner is not None:
+            owner._sink_taken(view)
+
+    def written(self, views):
+        owner = self.ref()
+        if owner is not None:
+            owner._written(views)
+
+
 class FlatDDP:
     """Flat-bucket gradient exchange (mean over ranks) for one module.
 
@@ -42,6 +67,15 @@ class FlatDDP:
       bucket whose count is complete is issued on the communication stream at once -- buckets strictly in the order last ->
       first, whatever order the hooks fire in, so that every rank issues the same sequence of collectives.  ``arm()`` before
       the backward of the micro-batch that steps; ``all_reduce_grads()`` afterwards issues what is left and waits.
+    * gradients written IN PLACE (``ops_gemm.GRADS_IN_PLACE`` / ``graphlam.GRADS_IN_PLACE``: a reduction kernel adds dW into the
+      ``.grad`` view, autograd sees None -- UNETR++'s 100+ MB of them) pass no AccumulateGrad node and fire no hook.  The ops
+      report them instead (``_lib.grad_sink_taken`` in the forward, ``_lib.grad_written`` right after the adding kernel is
+      enqueued in the backward).  With BPTT such a parameter receives one write per use; how many is LEARNED: the first armed
+      backward after a parameter's gradient was seen to go in place only counts (writes, hook firings) and keeps the parameter's
+      buckets back; from the next one on the parameter is final at its last expected event and its bucket leaves inside the
+      backward like the others (what ``DistributedDataParallel(static_graph=True)`` does with its first iteration).  A pass with
+      FEWER events than learned leaves the bucket to ``all_reduce_grads`` and re-learns; an event that arrives for a bucket already
+      on the wire (a program whose use counts grow from step to step) raises inside the backward -- never a silent wrong mean.
     """
 
     def __init__(self, module: torch.nn.Module, world_size: Optional[int] = None, bucket_bytes: int = 64 << 20,
@@ -81,12 +115,20 @@ class FlatDDP:
         self.issued_in_backward = 0                      # (diagnostics / tests) buckets issued by hooks in the last armed backward
         self._bucket_params = [0] * len(self.buckets)
         self._hooks = []
+        self._owners = []            # parameter -> the buckets it touches
+        self._param_starts = []      # parameter -> its first element in the flat buffer
+        self._inplace = set()        # parameters whose gradient (also) arrives in place, past autograd (see the class docstring)
+        self._profile = {}           # such a parameter -> (in-place writes, hook firings) of one armed backward, once learned
+        self._seen = []
+        self._done = []
+        self._ptr_param = {}         # address of a .grad region handed to an op -> parameter (memo of _param_of)
+        self._listener = None
         if self.overlap:
             off = 0
             starts = [lo for lo, _ in self.buckets]
             import bisect
 
-            for p in self.params:
+            for i, p in enumerate(self.params):
                 # a parameter belongs to the LAST bucket it touches: that bucket waits for it, earlier ones it straddles do not
                 # need to (they are issued after it, buckets go last -> first)... a straddling parameter is therefore counted in
                 # BOTH buckets it touches
@@ -95,8 +137,14 @@ class FlatDDP:
                 owners = list(range(first, last + 1))
                 for b in owners:
                     self._bucket_params[b] += 1
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(owners)))
+                self._owners.append(owners)
+                self._param_starts.append(off)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
                 off += p.numel()
+            from . import _lib as L
+
+            self._listener = _GradSinkListener(self)
+            L.GRAD_SINK_LISTENERS.append(self._listener)
         self.flat_param = None
         if self.sharded:
             self._flatten_parameters(pad)
@@ -173,16 +221,98 @@ class FlatDDP:
         self._armed = True
         self._issued = [False] * len(self.buckets)
         self._pending = list(self._bucket_params)
+        self._seen = [[0, 0] for _ in self.params]
+        self._done = [False] * len(self.params)
         self.issued_in_backward = 0
 
-    def _make_hook(self, owners):
+    def close(self):
+        """Stop listening (hooks and in-place write reports); the exchange after the backward keeps working."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._listener is not None:
+            self._listener.remove()
+            self._listener = None
+        self.overlap = False
+        self._armed = False
+
+    def _make_hook(self, idx):
         def hook(_param):
-            if not self._armed:
-                return
-            for b in owners:
-                self._pending[b] -= 1
-            self._issue_ready(from_hook=True)
+            self._event(idx, 1)
         return hook
+
+    def _param_of(self, view) -> int:
+        """The parameter whose slice of the flat gradient buffer ``view`` starts in (-1: not in this buffer)."""
+        ptr = view.data_ptr()
+        idx = self._ptr_param.get(ptr)
+        if idx is None:
+            import bisect
+
+            off = ptr - self.flat_grad.data_ptr()
+            idx = -1
+            if 0 <= off < 4 * self.total and view.device == self.flat_grad.device:
+                idx = bisect.bisect_right(self._param_starts, off // 4) - 1
+            self._ptr_param[ptr] = idx
+        return idx
+
+    def _sink_taken(self, view):
+        idx = self._param_of(view)
+        if idx >= 0:
+            self._inplace.add(idx)
+
+    def _written(self, views):
+        if not self._armed:
+            return
+        for v in views:
+            if v is not None:
+                idx = self._param_of(v)
+                if idx >= 0:
+                    self._event(idx, 0)
+
+    def _event(self, idx: int, kind: int):
+        """kind 0: an in-place sum into parameter idx's gradient has been enqueued; kind 1: its post-accumulate hook fired."""
+        if not self._armed:
+            return
+        seen = self._seen[idx]
+        seen[kind] += 1
+        if kind == 1 and idx not in self._inplace:
+            self._finish(idx)            # everything goes through autograd: its sum over the AR steps IS the final gradient
+            return
+        self._inplace.add(idx)
+        prof = self._profile.get(idx)
+        if prof is None:
+            return                       # learning pass for this parameter: its buckets stay back until all_reduce_grads
+        if seen[0] > prof[0] or seen[1] > prof[1]:
+            if any(self._issued[b] for b in self._owners[idx]):
+                self._armed = False
+                raise RuntimeError(
+                    f"FlatDDP(overlap=True): parameter #{idx} received gradient contribution {seen} after its bucket had been issued "
+                    f"on the {prof} contributions learned from an earlier step -- the number of uses of a parameter changed between "
+                    "steps (a longer rollout, a branch taken for the first time).  Construct FlatDDP with overlap=False for such a "
+                    "program, or keep the armed steps alike.")
+            if self._done[idx]:          # not on the wire yet: take the parameter back and learn again from this pass
+                self._done[idx] = False
+                for b in self._owners[idx]:
+                    self._pending[b] += 1
+            del self._profile[idx]
+            return
+        if seen[0] == prof[0] and seen[1] == prof[1] and (prof[0] + prof[1]) > 0:
+            self._finish(idx)
+
+    def _finish(self, idx: int):
+        if self._done[idx]:
+            return
+        self._done[idx] = True
+        for b in self._owners[idx]:
+            self._pending[b] -= 1
+        self._issue_ready(from_hook=True)
+
+    def _learn(self):
+        """End of an armed backward: the counts of this pass become the expectation for the parameters that bypass autograd."""
+        for idx in self._inplace:
+            seen = tuple(self._seen[idx])
+            if self._profile.get(idx) != seen:
+                self._profile[idx] = seen
 
     def _issue_ready(self, from_hook: bool, force: bool = False):
         """Issue, last bucket first, every not yet issued bucket that is complete (or all of them with ``force``); stops at the
@@ -254,6 +384,7 @@ class FlatDDP:
                 self._issued = [False] * len(self.buckets)
             self._regather()
         if self.overlap and self._armed:
+            self._learn()
             # what the hooks have not issued yet (parameters that received no gradient in this pass never fire theirs)
             self._issue_ready(from_hook=False, force=True)
             self._armed = False

@@ -286,6 +286,119 @@ def test_overlap_with_replaced_gradient_tensors_gloo():
         assert n_in >= 1 and msg is not None and "reduce-scattered" in msg
 
 
+def _in_place_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from py4cast_amd import _lib as L
+    from py4cast_amd.ops_rows import grad_view
+    from py4cast_amd.trainer import FlatDDP
+
+    class InPlaceLinear(torch.autograd.Function):
+        """The protocol of ops_gemm's GRADS_IN_PLACE nodes on CPU tensors: the .grad views are taken in the forward (grad_view reports
+        them), the backward ADDS into them, reports the writes and returns None for the parameters -- no AccumulateGrad, no hook."""
+
+        @staticmethod
+        def forward(ctx, x, w, b, gw, gb):
+            ctx.gw, ctx.gb = gw, gb
+            ctx.save_for_backward(x, w.detach())
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            ctx.gw.add_(dy.t() @ x)
+            ctx.gb.add_(dy.sum(0))
+            L.grad_written(ctx.gw, ctx.gb)
+            return dy @ w, None, None, None, None
+
+    def in_place_linear(m, t, attached):
+        """attached: the parameters are inputs of the node (their AccumulateGrad nodes are in the graph and receive undefined
+        gradients); not attached: the node sees detached weights, as with a rollout's stand-ins -- nothing but the reported writes
+        tells anybody that the gradient arrived."""
+        gw, gb = grad_view(m.weight), grad_view(m.bias)
+        assert gw is not None and gw is not False and gb is not None and gb is not False
+        w, b = (m.weight, m.bias) if attached else (m.weight.detach(), m.bias.detach())
+        return InPlaceLinear.apply(t, w, b, gw, gb)
+
+    class Net(torch.nn.Module):
+        def __init__(self, in_place):
+            super().__init__()
+            torch.manual_seed(11)
+            self.a, self.b, self.c = torch.nn.Linear(24, 96), torch.nn.Linear(96, 64), torch.nn.Linear(64, 24)
+            self.in_place = in_place
+
+        def forward(self, x):
+            lin = in_place_linear if self.in_place else (lambda m, t, attached: m(t))
+            h = torch.tanh(lin(self.a, x, True))
+            h = torch.tanh(self.b(h))            # (the middle layer goes through autograd in both flavours: a mixed model)
+            return lin(self.c, h, False)
+
+    torch.manual_seed(70 + rank)
+    x, y = torch.randn(9, 24), torch.randn(9, 4, 24)
+
+    def step(net, ddp, T):
+        ddp.zero_grad()
+        state, loss = x, 0.0
+        for t in range(T):                       # BPTT: every parameter is used T times
+            state = net(state)
+            loss = loss + ((state - y[:, t]) ** 2).mean()
+        ddp.arm()
+        loss.backward()
+        n_in = ddp.issued_in_backward
+        ddp.all_reduce_grads()
+        return n_in, ddp.flat_grad[: ddp.total].clone()
+
+    out = {}
+    ref_net = Net(False)
+    ref = FlatDDP(ref_net, world, bucket_bytes=4096, single_bucket_bytes=1024, overlap=False)
+    net = Net(True)
+    ddp = FlatDDP(net, world, bucket_bytes=4096, single_bucket_bytes=1024, overlap=True)
+    out["nb"] = len(ddp.buckets)
+    out["ref3"] = step(ref_net, ref, 3)[1]
+    out["ref2"] = step(ref_net, ref, 2)[1]
+    out["learn"] = step(net, ddp, 3)             # first armed backward: counts the in-place writes, holds their buckets back
+    out["steady"] = step(net, ddp, 3)            # from now on the buckets leave inside the backward
+    out["profile"] = [ddp._profile[i] for i in range(len(ddp.params))if i in ddp._profile]
+    out["shorter"] = step(net, ddp, 2)           # fewer uses than learned: nothing leaves early, the result is still the mean
+    out["shorter_again"] = step(net, ddp, 2)     # ... and the new counts have been learned
+    try:                                         # more uses than learned: a bucket would have left before its last contribution
+        step(net, ddp, 3)
+        out["longer"] = None
+    except RuntimeError as exc:
+        out["longer"] = str(exc)
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_in_place_gradients_join_the_overlapped_exchange_gloo():
+    """gradients that a kernel adds straight into ``.grad`` (GRADS_IN_PLACE) fire no per-parameter hook.  The ops
+    report their writes (``_lib.grad_written``), FlatDDP learns the number of writes per parameter in the first armed backward and
+    from the second one on issues the buckets INSIDE the backward (>= 1 before it returns), with the same mean as the exchange after
+    the backward; a step with fewer uses falls back to the exchange after the backward, one with more uses than learned raises."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 34500 + (os.getpid() % 1000)
+    mp.spawn(_in_place_worker, args=(world, port, ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    for r in (a, b):
+        assert r["nb"] > 3
+        assert r["learn"][0] == 0                                  # the last layer's gradients are in place: nothing may leave yet
+        assert r["steady"][0] >= r["nb"] - 1                       # all but (at most) the first layer's bucket inside the backward
+        # three writes per in-place parameter (whether the engine also runs the AccumulateGrad node of a parameter whose gradients
+        # all came back undefined -- and with it the hook -- is the engine's business: the count is learned, not assumed)
+        assert len(r["profile"]) == 4 and all(w == 3 and h in (0, 1) for w, h in r["profile"]) and r["profile"][2:] == [(3, 0), (3, 0)]
+        assert r["shorter"][0] == 0 and r["shorter_again"][0] >= r["nb"] - 1
+        assert r["longer"] is not None and "after its bucket had been issued" in r["longer"]
+        torch.testing.assert_close(r["learn"][1], a["ref3"])
+        torch.testing.assert_close(r["steady"][1], a["ref3"])
+        torch.testing.assert_close(r["shorter"][1], a["ref2"])
+        torch.testing.assert_close(r["shorter_again"][1], a["ref2"])
+    torch.testing.assert_close(a["ref3"], b["ref3"])
+
+
 def test_rank_pinning_hands_out_whole_physical_cores_per_numa_node(monkeypatch):
     """pin_rank_to_cores on an SMT host whose CPU ids run socket 0, socket 1, socket-0 siblings, socket-1 siblings: every
     rank gets whole physical cores (both hardware threads), ranks 0..N/2-1 on node 0 and the rest on node 1, no CPU twice; a rank the
