@@ -719,6 +719,15 @@ int p4c_ts_apply_mt(const void* x, int x_dtype, int64_t x_bs, int64_t x_hs, int6
 int p4c_ts_apply_softmax(const void* x, int64_t x_bs, int64_t x_hs, int64_t x_rs, const float* m, int64_t m_gs, void* out, int64_t o_bs,
                          int64_t o_hs, int64_t o_rs, int B, int heads, int64_t N, int d, int e, int epi, const void* s, int64_t s_bs,
                          int64_t s_hs, int64_t s_rs, p4c_stream_t stream);
+/* Sums of the gram partials without the tensor library (round 6; replaces `part.sum(dim=1)` + the strided copies / cast / bias addition
+ * that followed it in py4cast_amd/ops_ts.py): part is (A, S, R, E) fp32 dense; out = sum over s of part[a, s, r, :] (+ bias[column %
+ * bias_len] when bias is given) (+ out when accumulate), the E columns cut into nseg <= 3 consecutive segments of seg_len[i] columns,
+ * segment i stored dense as (A, R, seg_len[i]) at outs[i] (G | nq2 | nk2 of a p4c_ts_gram_norms row).  Lengths multiples of 4. */
+int p4c_ts_reduce_splits(const float* part, int A, int S, int R, int E, int nseg, const int* seg_len, float* const* outs, const float* bias,
+                         int bias_len, int accumulate, p4c_stream_t stream);
+/* out (E x R, dense) (+)= sum over s of part[s] (R x E)^T, E <= 64 and a multiple of 4: the weight gradient of EPA's token-axis Linear (mfai's `E` / `F`,
+ * weight (p, N)) from the per-(k | v_sa, sample) token-major products of p4c_ts_apply. */
+int p4c_ts_reduce_transpose(const float* part, int S, int64_t R, int E, float* out, int accumulate, p4c_stream_t stream);
 /* The small matrices of one EPA block in one launch each way (all fp32, contiguous): G = q^T k, Gq = q^T q, Gk = k^T k (B, heads, d, d)
  * from p4c_ts_gram, KP (B, heads, d, p), temperatures t1 / t2 (heads):
  *   nq_i = max(sqrt(max(Gq_ii, 0)), 1e-12), nk_j likewise;  A = softmax_j(t1 G_ij / (nq_i nk_j));  Mq_ic = t2 KP_ic / nq_i.

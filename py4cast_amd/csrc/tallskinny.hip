@@ -428,30 +428,58 @@ __global__ void __launch_bounds__(128) gram_mfma_kernel(Mat X, Mat Y, float* __r
     const int64_t tps = (ntiles + nsplit - 1) / nsplit;
     const int64_t tend = ((int64_t)(sp + 1) * tps) < ntiles ? ((int64_t)(sp + 1) * tps) : ntiles;
     const int i16 = lane & 15, tg = (lane >> 4) & 1, hh = lane >> 5;
-    for (int64_t t = (int64_t)sp * tps + wv; t < tend; t += 2) {
+    // a lane stages the same (row, 16-byte column) slots of every tile: up to four of X and four of Y (32 rows x <= 8 vectors / 64 lanes).
+    // Round 6: the loads of the wave's NEXT tile are issued before the matrix phase of the current one (they used to start after it:
+    // with two waves per workgroup and a few workgroups per CU nothing else covered their latency).
+    int64_t gx[4], gy[4];
+    int lx[4], ly[4], rx[4], ry[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = lane + 64 * i;
+        const bool vx = v < GROWS * dv, vy = v < GROWS * ev;
+        const int rrx = vx ? v / dv : 0, cx = vx ? v - rrx * dv : 0;
+        const int rry = vy ? v / ev : 0, cy = vy ? v - rry * ev : 0;
+        rx[i] = vx ? rrx : -1;
+        ry[i] = vy ? rry : -1;
+        gx[i] = (int64_t)rrx * X.rs + 8 * cx;
+        gy[i] = (int64_t)rry * Y.rs + 8 * cy;
+        lx[i] = rrx * GROWB + cx * 16;
+        ly[i] = rry * GROWB + cy * 16;
+    }
+    ts_u32x4 qx[4], qy[4];
+    auto load_tile = [&](int64_t t) {
         const int64_t row0 = t * GROWS;
-        for (int v = lane; v < GROWS * dv; v += 64) {
-            const int rr = v / dv, c = v - rr * dv;
-            ts_u32x4 q = {0u, 0u, 0u, 0u};
-            if (row0 + rr < N) q = *reinterpret_cast<const ts_u32x4*>(xb + (row0 + rr) * X.rs + 8 * c);
-            *reinterpret_cast<ts_u32x4*>(imgX + rr * GROWB + c * 16) = q;
-            if (NORMS) {
-                const ts_bf16x8 f = __builtin_bit_cast(ts_bf16x8, q);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) nx[j] = __builtin_fmaf((float)f[j], (float)f[j], nx[j]);
+        for (int i = 0; i < 4; ++i) {
+            qx[i] = ts_u32x4{0u, 0u, 0u, 0u};
+            qy[i] = ts_u32x4{0u, 0u, 0u, 0u};
+            if (rx[i] >= 0 && row0 + rx[i] < N) qx[i] = *reinterpret_cast<const ts_u32x4*>(xb + row0 * X.rs + gx[i]);
+            if (ry[i] >= 0 && row0 + ry[i] < N) qy[i] = *reinterpret_cast<const ts_u32x4*>(yb + row0 * Y.rs + gy[i]);
+        }
+    };
+    int64_t t = (int64_t)sp * tps + wv;
+    if (t < tend) load_tile(t);
+    for (; t < tend; t += 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (rx[i] >= 0) {
+                *reinterpret_cast<ts_u32x4*>(imgX + lx[i]) = qx[i];
+                if (NORMS) {
+                    const ts_bf16x8 f = __builtin_bit_cast(ts_bf16x8, qx[i]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) nx[j] = __builtin_fmaf((float)f[j], (float)f[j], nx[j]);
+                }
+            }
+            if (ry[i] >= 0) {
+                *reinterpret_cast<ts_u32x4*>(imgY + ly[i]) = qy[i];
+                if (NORMS) {
+                    const ts_bf16x8 f = __builtin_bit_cast(ts_bf16x8, qy[i]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ny[j] = __builtin_fmaf((float)f[j], (float)f[j], ny[j]);
+                }
             }
         }
-        for (int v = lane; v < GROWS * ev; v += 64) {
-            const int rr = v / ev, c = v - rr * ev;
-            ts_u32x4 q = {0u, 0u, 0u, 0u};
-            if (row0 + rr < N) q = *reinterpret_cast<const ts_u32x4*>(yb + (row0 + rr) * Y.rs + 8 * c);
-            *reinterpret_cast<ts_u32x4*>(imgY + rr * GROWB + c * 16) = q;
-            if (NORMS) {
-                const ts_bf16x8 f = __builtin_bit_cast(ts_bf16x8, q);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ny[j] = __builtin_fmaf((float)f[j], (float)f[j], ny[j]);
-            }
-        }
+        if (t + 2 < tend) load_tile(t + 2);
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -940,5 +968,142 @@ extern "C" int p4c_epa_small_bwd(const float* G, const float* Gq, const float* G
     hipLaunchKernelGGL(ts::epa_small_bwd_kernel, dim3(B * heads), dim3(256), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, nq, nk, dAt, dMq, dG, dGq,
                        dGk, dKP, dt1_part, dt2_part, heads, d, p, diag_only ? 1 : d);
     P4C_CHECK_LAUNCH("p4c_epa_small_bwd");
+    return P4C_OK;
+}
+
+// ---- sums of partials (round 6) ---------------------------------------------------------------------------------------------
+// The gram kernels leave one partial per token split; the caller used to sum them with the tensor library (a reduction launch, then
+// one strided copy per piece of a gram_norms row, a cast and a bias addition for the token-axis projection).  reduce_splits_kernel
+// does all of that in ONE pass: part is (A, S, R, E) fp32; the S partials of 4 consecutive columns of one (a, r) row are added in a
+// fixed order (bit-identical reruns), bias[column % bias_len] is added and the quad stored into the segment the columns belong to --
+// up to three dense outputs (G | nq2 | nk2 of a gram_norms row).
+namespace p4c {
+namespace ts {
+struct RedSegs {
+    float* out[3];
+    int end[3];      // exclusive column ends of the segments (multiples of 4); segment i = [end[i-1], end[i])
+    int nseg;
+};
+
+// A workgroup = 32 column quads x 8 split lanes: lane sl adds the partials sl, sl + 8, ... (loads of different splits in flight
+// together), the eight sums meet in LDS and are added in lane order -- the order is fixed, a rerun reproduces every bit.
+__global__ void __launch_bounds__(256) reduce_splits_kernel(const float* __restrict__ part, int S, int R, int E, RedSegs segs,
+                                                            const float* __restrict__ bias, int bias_len, int accumulate, int64_t total4) {
+    __shared__ p4c_f32x4 red[8][32];
+    const int q = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int64_t idx = (int64_t)blockIdx.x * 32 + q;
+    const bool live = idx < total4;
+    const int e4 = E >> 2;
+    const int64_t row = live ? idx / e4 : 0;            // (a, r)
+    const int j = live ? (int)(idx - row * e4) << 2 : 0;
+    const int64_t a = row / R, r = row - a * R;
+    const float* p = part + ((a * S) * R + r) * (int64_t)E + j;
+    const int64_t sstride = (int64_t)R * E;
+    p4c_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        int s = sl;
+        for (; s + 24 < S; s += 32) {                    // four loads in flight per lane
+            const p4c_f32x4 v0 = *reinterpret_cast<const p4c_f32x4*>(p + (int64_t)s * sstride);
+            const p4c_f32x4 v1 = *reinterpret_cast<const p4c_f32x4*>(p + (int64_t)(s + 8) * sstride);
+            const p4c_f32x4 v2 = *reinterpret_cast<const p4c_f32x4*>(p + (int64_t)(s + 16) * sstride);
+            const p4c_f32x4 v3 = *reinterpret_cast<const p4c_f32x4*>(p + (int64_t)(s + 24) * sstride);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (((acc[i] + v0[i]) + v1[i]) + v2[i]) + v3[i];
+        }
+        for (; s < S; s += 8) {
+            const p4c_f32x4 v = *reinterpret_cast<const p4c_f32x4*>(p + (int64_t)s * sstride);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += v[i];
+        }
+    }
+    red[sl][q] = acc;
+    __syncthreads();
+    if (sl != 0 || !live) return;
+#pragma unroll
+    for (int t = 1; t < 8; ++t) {
+        const p4c_f32x4 v = red[t][q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += v[i];
+    }
+    if (bias) {
+        const int bj = j % bias_len;                     // bias_len % 4 == 0: the four columns stay inside one period
+        acc[0] += bias[bj]; acc[1] += bias[bj + 1]; acc[2] += bias[bj + 2]; acc[3] += bias[bj + 3];
+    }
+    int seg = 0, begin = 0;
+    while (seg + 1 < segs.nseg && j >= segs.end[seg]) begin = segs.end[seg++];
+    const int len = segs.end[seg] - begin;
+    float* o = segs.out[seg] + row * len + (j - begin);
+    if (accumulate) {
+        const p4c_f32x4 old = *reinterpret_cast<const p4c_f32x4*>(o);
+        acc[0] += old[0]; acc[1] += old[1]; acc[2] += old[2]; acc[3] += old[3];
+    }
+    *reinterpret_cast<p4c_f32x4*>(o) = acc;
+}
+
+// out (E x R) (+)= sum over the S groups of part[s] (R x E), E <= 64 (a multiple of 4): the weight gradient of the token-axis
+// projection, whose per-group products come token-major ((N x p) from an apply) while the parameter is (p x N).  A workgroup
+// transposes 32 rows through LDS: 16-byte reads of whole rows (all groups' loads of a quad in flight together), 128-byte runs of one
+// output row on the way out.
+__global__ void __launch_bounds__(256) reduce_transpose_kernel(const float* __restrict__ part, int S, int64_t R, int E, float* __restrict__ out,
+                                                               int accumulate) {
+    __shared__ float tile[32][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int e4 = E >> 2;
+    for (int i = threadIdx.x; i < 32 * e4; i += 256) {
+        const int rr = i / e4, j = (i - rr * e4) << 2;
+        p4c_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + rr < R) {
+            const float* p = part + (r0 + rr) * E + j;
+            for (int s = 0; s < S; ++s) {
+                const p4c_f32x4 u = *reinterpret_cast<const p4c_f32x4*>(p + (int64_t)s * R * E);
+                v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+            }
+        }
+        tile[rr][j] = v[0]; tile[rr][j + 1] = v[1]; tile[rr][j + 2] = v[2]; tile[rr][j + 3] = v[3];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * E; i += 256) {
+        const int j = i >> 5, rr = i & 31;
+        if (r0 + rr < R) {
+            float* o = out + (int64_t)j * R + r0 + rr;
+            *o = (accumulate ? *o : 0.f) + tile[rr][j];
+        }
+    }
+}
+}  // namespace ts
+}  // namespace p4c
+
+extern "C" int p4c_ts_reduce_splits(const float* part, int A, int S, int R, int E, int nseg, const int* seg_len, float* const* outs,
+                                    const float* bias, int bias_len, int accumulate, p4c_stream_t stream) {
+    P4C_CHECK_ARG(part && seg_len && outs, "p4c_ts_reduce_splits: null pointer");
+    P4C_CHECK_ARG(A > 0 && S > 0 && R > 0 && E > 0 && E % 4 == 0, "p4c_ts_reduce_splits: empty problem or a row length that is not a multiple of 4 (%d)", E);
+    P4C_CHECK_ARG(nseg >= 1 && nseg <= 3, "p4c_ts_reduce_splits: 1..3 output segments (got %d)", nseg);
+    P4C_CHECK_ARG(!bias || (bias_len > 0 && bias_len % 4 == 0 && E % bias_len == 0), "p4c_ts_reduce_splits: bias period %d must divide the row length %d (multiples of 4)",
+                  bias_len, E);
+    ts::RedSegs segs{};
+    segs.nseg = nseg;
+    int end = 0;
+    for (int i = 0; i < nseg; ++i) {
+        P4C_CHECK_ARG(seg_len[i] > 0 && seg_len[i] % 4 == 0 && outs[i] && (reinterpret_cast<uintptr_t>(outs[i]) & 15) == 0,
+                      "p4c_ts_reduce_splits: segment %d: length must be a positive multiple of 4, output 16-byte aligned", i);
+        end += seg_len[i];
+        segs.end[i] = end;
+        segs.out[i] = outs[i];
+    }
+    P4C_CHECK_ARG(end == E, "p4c_ts_reduce_splits: the segments cover %d of %d columns", end, E);
+    P4C_CHECK_ARG((reinterpret_cast<uintptr_t>(part) & 15) == 0, "p4c_ts_reduce_splits: partials must be 16-byte aligned");
+    const int64_t total4 = (int64_t)A * R * (E / 4);
+    hipLaunchKernelGGL(ts::reduce_splits_kernel, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, as_stream(stream), part, S, R, E, segs, bias,
+                       bias_len, accumulate, total4);
+    P4C_CHECK_LAUNCH("p4c_ts_reduce_splits");
+    return P4C_OK;
+}
+
+extern "C" int p4c_ts_reduce_transpose(const float* part, int S, int64_t R, int E, float* out, int accumulate, p4c_stream_t stream) {
+    P4C_CHECK_ARG(part && out, "p4c_ts_reduce_transpose: null pointer");
+    P4C_CHECK_ARG(S > 0 && R > 0 && E > 0 && E <= 64 && E % 4 == 0, "p4c_ts_reduce_transpose: 4..64 columns per row, a multiple of 4 (got %d)", E);
+    P4C_CHECK_ARG((reinterpret_cast<uintptr_t>(part) & 15) == 0, "p4c_ts_reduce_transpose: partials must be 16-byte aligned");
+    hipLaunchKernelGGL(ts::reduce_transpose_kernel, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, as_stream(stream), part, S, R, E, out, accumulate);
+    P4C_CHECK_LAUNCH("p4c_ts_reduce_transpose");
     return P4C_OK;
 }

@@ -3,6 +3,8 @@ paired attention of UNETR++ is made of, forward and backward (each is the other'
 VIEWS with unit stride in the last dimension and arbitrary strides elsewhere (slices of the qkvv projection, permuted views of
 (B, N, C) tensors): they are addressed in place, nothing is made contiguous.  No CPU fallback."""
 
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -29,21 +31,57 @@ def _gram_wide(x, y) -> bool:
     return al(x) and al(y)
 
 
-def _gram_call(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+_I3 = ctypes.c_int * 3
+_P3 = ctypes.c_void_p * 3
+
+
+def reduce_splits(part: torch.Tensor, outs, bias=None, accumulate: bool = False):
+    """outs[i] (A, R, len_i) (+)= sum over s of part[a, s, r, segment i] (+ bias, one period of ``bias.numel()`` columns): ``part`` is the
+    dense (A, S, R, E) fp32 output of a gram launch, the segments cut its E columns in order (p4c_ts_reduce_splits: one launch, the
+    partials added in split order -- no tensor-library reduction, no strided copies of the pieces)."""
+    A, S, R = part.shape[:3]
+    E = part[0, 0, 0].numel()
+    lens = [o.numel() // (A * R) for o in outs]
+    for o, n in zip(outs, lens):
+        if o.dtype != torch.float32 or not o.is_contiguous() or o.numel() != A * R * n:
+            raise L.P4CError("ops_ts.reduce_splits: outputs are dense fp32 (A, R, ...) tensors")
+    if not part.is_contiguous() or part.dtype != torch.float32 or sum(lens) != E:
+        raise L.P4CError("ops_ts.reduce_splits: partials are a dense fp32 (A, S, R, E) tensor covered by the output segments")
+    L.call("p4c_ts_reduce_splits", L.ptr(part), A, S, R, E, len(outs), _I3(*lens, *([0] * (3 - len(lens)))),
+           _P3(*[o.data_ptr() for o in outs], *([None] * (3 - len(outs)))), L.ptr(bias), 0 if bias is None else bias.numel(), int(accumulate),
+           L.stream(part.device), alg_bytes=4 * A * R * E * (S + 1))
+    return outs
+
+
+def _gram_call(x: torch.Tensor, y: torch.Tensor, out=None) -> torch.Tensor:
+    """X^T Y (B, H, d, e) fp32 (into ``out`` when given: a dense fp32 tensor of that many elements)"""
     B, H, N, d = x.shape
     e = y.shape[-1]
     ns = L.lib().p4c_ts_gram_splits(N)
-    part = torch.empty(B, ns, H, d, e, dtype=torch.float32, device=x.device)
+    direct = ns == 1 and out is not None and out.is_contiguous()
+    part = out.view(B, 1, H, d, e) if direct else torch.empty(B, ns, H, d, e, dtype=torch.float32, device=x.device)
     xs, ys = _strides(x), _strides(y)
     L.call("p4c_ts_gram", L.ptr(x), L.dtype_code(x.dtype), *xs, L.ptr(y), L.dtype_code(y.dtype), *ys, L.ptr(part), B, H, N, d, e,
            L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * y.element_size()))
-    return part.sum(dim=1) if ns > 1 else part[:, 0]
+    if direct:
+        return out
+    if ns == 1 and out is None:
+        return part[:, 0]
+    if out is None:
+        out = torch.empty(B, H, d, e, dtype=torch.float32, device=x.device)
+    if (d * e) % 4:
+        out.copy_(part.sum(dim=1).view_as(out))
+        return out
+    reduce_splits(part.view(B, ns, H, d * e), [out.view(B, H, d * e)])
+    return out
 
 
-def _gram_raw(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+def _gram_raw(x: torch.Tensor, y: torch.Tensor, out=None) -> torch.Tensor:
     d, e = x.shape[-1], y.shape[-1]
     if (d <= MAXD and e <= MAXD) or _gram_wide(x, y):
-        return _gram_call(x, y)
+        return _gram_call(x, y, out)
+    if out is not None:
+        raise L.P4CError("ops_ts._gram_raw: an output buffer needs operands one gram launch serves")
     return torch.cat([torch.cat([_gram_call(x[..., i0:i1], y[..., j0:j1]) for j0, j1 in _chunks(e)], dim=-1) for i0, i1 in _chunks(d)], dim=-2)
 
 
@@ -161,9 +199,13 @@ class _GramNorms(torch.autograd.Function):
         part = torch.empty(B, ns, H, d * e + d + e, dtype=torch.float32, device=x.device)
         L.call("p4c_ts_gram_norms", L.ptr(x), L.dtype_code(x.dtype), *_strides(x), L.ptr(y), L.dtype_code(y.dtype), *_strides(y), L.ptr(part), B, H,
                N, d, e, L.stream(x.device), alg_bytes=B * H * N * (d * x.element_size() + e * y.element_size()))
-        tot = part.sum(dim=1) if ns > 1 else part[:, 0]
         ctx.save_for_backward(x, y)
-        return tot[..., : d * e].reshape(B, H, d, e), tot[..., d * e : d * e + d], tot[..., d * e + d :]
+        if ns == 1 or d % 4 or e % 4:
+            tot = part.sum(dim=1) if ns > 1 else part[:, 0]
+            return tot[..., : d * e].reshape(B, H, d, e), tot[..., d * e : d * e + d], tot[..., d * e + d :]
+        G, nx2, ny2 = (torch.empty(B, H, n, dtype=torch.float32, device=x.device) for n in (d * e, d, e))
+        reduce_splits(part, [G, nx2, ny2])
+        return G.view(B, H, d, e), nx2, ny2
 
     @staticmethod
     def backward(ctx, dG, dnx2, dny2):
@@ -329,36 +371,33 @@ class _EpaCore(torch.autograd.Function):
         B, N, _, H, d = qkvv.shape
         C, p, dt = H * d, W.shape[0], qkvv.dtype
         q, k, vca, vsa = (qkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))
-        # q^T k with the squared column norms of q and k
+        # q^T k with the squared column norms of q and k: one gram pass, one launch that sums the splits into the three pieces
         ns = L.lib().p4c_ts_gram_splits(N)
         part = torch.empty(B, ns, H, d * d + 2 * d, dtype=torch.float32, device=qkvv.device)
         L.call("p4c_ts_gram_norms", L.ptr(q), L.dtype_code(dt), *_strides(q), L.ptr(k), L.dtype_code(dt), *_strides(k), L.ptr(part), B, H, N, d, d,
                L.stream(qkvv.device), alg_bytes=B * H * N * 2 * d * q.element_size())
-        tot = part.sum(dim=1) if ns > 1 else part[:, 0]
-        G = tot[..., : d * d].reshape(B, H, d, d).contiguous()
-        nq2, nk2 = tot[..., d * d: d * d + d].contiguous(), tot[..., d * d + d:].contiguous()   # (B,H,d): |q columns|^2, |k columns|^2
+        G = torch.empty(B, H, d, d, dtype=torch.float32, device=qkvv.device)
+        nq2, nk2 = (torch.empty(B, H, d, dtype=torch.float32, device=qkvv.device) for _ in range(2))   # |q columns|^2, |k columns|^2
+        reduce_splits(part, [G, nq2, nk2])
         # token-axis projection of k and v_sa (shared weights E = F): KP[b,h] = k[b,h]^T W^T + bias, (d x p) per head
         from .ops_rows import weight_as
 
-        W16 = weight_as(W, dt)                                               # (p, N)
-        if _token_proj_native(qkvv, p):
-            # round 6 (diagnostic route, measured no faster): the projection IS a gram product of the head's token matrix with the
-            # (N x p) matrix W^T shared by all heads (strides 0 over sample and head): k and v_sa are read IN PLACE inside qkvv by the
-            # tall-skinny kernel -- no (2, B, N, C) gather of them (16 MB per block at the first stage)
-            Wt = weight_as(W, dt, transposed=True)                           # (N, p), once per parameter version
-            Wv = Wt.view(1, 1, N, p).expand(B, H, N, p)
-            proj = torch.empty(2, B, H, d, p, dtype=torch.float32, device=qkvv.device)
-            for i, x in enumerate((k, vsa)):
-                part = _gram_partial(x, Wv)                                  # (B, splits, H, d, p)
-                if part.shape[1] > 1:
-                    torch.sum(part, dim=1, out=proj[i])
-                else:
-                    proj[i].copy_(part[:, 0])
-            proj += bias.float()
+        proj = torch.empty(2, B, C, p, dtype=torch.float32, device=qkvv.device)      # KP and VP are its two halves
+        native = _token_proj_native(qkvv, p)
+        if native:
+            # round 6: the projection is a gram product of the token matrices with W^T (N x p), over ALL channels of a sample at once --
+            # group (k | v_sa, sample), k and v_sa read in place inside qkvv as (N x C) matrices with row stride 4 C, the shared
+            # operand with group strides 0; the splits' partials, the cast and the bias are one more launch.  (Rounds 3-5: a strided
+            # gather of k / v_sa into (2, B, N, C), its transposed copy for the library's batched GEMM, the GEMM, a cast and an addition:
+            # five launches and five passes over 16 MB at the first stage.)
+            Wm = weight_as(W, dt, transposed=True)                           # W^T (N, p), once per parameter version
             kv = None
+            part = _gram_partial(_kv_view(qkvv), Wm.view(1, 1, N, p).expand(2, B, N, p))       # (2, splits, B, C, p)
+            reduce_splits(part.view(2, part.shape[1], B, C * p), [proj], bias=bias.detach().float().contiguous())
         else:
+            Wm = weight_as(W, dt)                                                # (p, N)
             kv = qkvv[:, :, 1::2].permute(2, 0, 1, 3, 4).reshape(2, B, N, C)      # k and v_sa token-major, ONE strided copy: (2,B,N,C)
-            proj = (kv.transpose(-1, -2) @ W16.t()).float() + bias.float()       # (2,B,C,p): KP and VP are its two contiguous halves
+            proj = (kv.transpose(-1, -2) @ Wm.t()).float() + bias.float()        # (2,B,C,p)
         KP, VP = proj[0].view(B, H, d, p), proj[1].view(B, H, d, p)
         t1f, t2f = t1.detach().float().reshape(-1).contiguous(), t2.detach().float().reshape(-1).contiguous()
         At = torch.empty(B, H, d, d, dtype=torch.float32, device=qkvv.device)
@@ -369,64 +408,70 @@ class _EpaCore(torch.autograd.Function):
         x_ca = _apply_raw(vca, At, dt)
         S = _apply_softmax(q, Mq, 1)
         x_sa = _apply_raw(S, VP.transpose(-1, -2), dt)
-        ctx.native_proj = kv is None
-        ctx.save_for_backward(qkvv, W16, Wt if kv is None else kv, G, nq2, nk2, KP, VP, t1f, t2f, At, Mq, nrm, S)
+        ctx.native_proj = native
+        from .ops_gemm import _sink
+
+        ctx.wsink = _sink(W, None) if native else None     # (the weight gradient goes straight into E.weight.grad, as ops_gemm's do)
+        ctx.save_for_backward(qkvv, Wm, kv, G, nq2, nk2, KP, VP, t1f, t2f, At, Mq, nrm, S)
         ctx.meta = (W.dtype, bias.dtype, t1.shape, t1.dtype)
         return x_sa, x_ca
 
     @staticmethod
     def backward(ctx, dx_sa, dx_ca):
-        qkvv, W16, kv, G, nq2, nk2, KP, VP, t1f, t2f, At, Mq, nrm, S = ctx.saved_tensors
+        qkvv, Wm, kv, G, nq2, nk2, KP, VP, t1f, t2f, At, Mq, nrm, S = ctx.saved_tensors
         wdt, bdt, tshape, tdt = ctx.meta
         B, N, _, H, d = qkvv.shape
         C, p, dt = H * d, KP.shape[-1], qkvv.dtype
+        dev = qkvv.device
         q, k, vca, vsa = (qkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))
         ok = lambda t: t.stride(3) == 1 and all(v % 8 == 0 for v in _strides(t)) and t.data_ptr() % 16 == 0   # noqa: E731
         dx_sa = dx_sa if ok(dx_sa) else dx_sa.contiguous()
         dx_ca = dx_ca if ok(dx_ca) else dx_ca.contiguous()
         dqkvv = torch.empty_like(qkvv)
         dq, dk, dvca, dvsa = (dqkvv[:, :, i].permute(0, 2, 1, 3) for i in range(4))
+        g = torch.empty(2, B, C, p, dtype=torch.float32, device=dev)         # (dKP, dVP): the gradient of the token-axis projection
+        dKP, dVP = g[0].view(B, H, d, p), g[1].view(B, H, d, p)
         # channel branch x_ca = v_ca At
         _apply_into(dvca, dx_ca, At.transpose(-1, -2), False)
         dAt = _gram_raw(vca, dx_ca)
         # spatial branch x_sa = softmax(q Mq) VP^T
         dL = _apply_softmax(dx_sa, VP, 2, S)                                 # dS = dx VP, softmax adjoint in the epilogue
-        dVP = _gram_raw(dx_sa, S)                                            # d(VP^T) = S^T dx, i.e. dVP = dx^T S (B,H,d,p)
+        _gram_raw(dx_sa, S, out=dVP)                                         # d(VP^T) = S^T dx, i.e. dVP = dx^T S (B,H,d,p)
         _apply_into(dq, dL, Mq.transpose(-1, -2), False)                     # dq, first contribution
         dMq = _gram_raw(q, dL)
         # small matrices
-        dG = torch.empty(B, H, d, d, dtype=torch.float32, device=G.device)
-        dn = torch.empty(2, B, H, d, dtype=torch.float32, device=G.device)
-        dKP = torch.empty_like(KP)
-        dtp = torch.empty(2, B, H, dtype=torch.float32, device=G.device)
+        dG = torch.empty(B, H, d, d, dtype=torch.float32, device=dev)
+        dn = torch.empty(2, B, H, d, dtype=torch.float32, device=dev)
+        dtp = torch.empty(2, B, H, dtype=torch.float32, device=dev)
         L.call("p4c_epa_small_bwd", L.ptr(G), L.ptr(nq2), L.ptr(nk2), L.ptr(KP), L.ptr(t1f), L.ptr(t2f), L.ptr(At), L.ptr(nrm[0]), L.ptr(nrm[1]),
                L.ptr(dAt.float().contiguous()), L.ptr(dMq.float().contiguous()), L.ptr(dG), L.ptr(dn[0]), L.ptr(dn[1]), L.ptr(dKP), L.ptr(dtp[0]),
-               L.ptr(dtp[1]), B, H, d, p, 1, L.stream(G.device))
+               L.ptr(dtp[1]), B, H, d, p, 1, L.stream(dev))
         dts = dtp.sum(dim=1)
-        # token-axis projection: proj = kv^T W16^T + bias
-        g = torch.stack([dKP.reshape(B, C, p), dVP.reshape(B, C, p)], dim=0)         # (2,B,C,p) fp32
+        # token-axis projection: proj = kv^T W^T + bias
         dbias = g.sum(dim=(0, 1, 2)).to(bdt)
+        dW = None
         if ctx.native_proj:
-            # the adjoints as tall-skinny products on the operands in place: dk = W^T dKP^T and dv_sa = W^T dVP^T per head (apply with
-            # the shared (N x p) matrix as the token operand: first contributions, written straight into dqkvv), dW^T = sum over
-            # samples of k[b] (N x C) dKP[b] (C x p) + the same for v_sa (apply over ALL heads' channels at once, accumulated in a
-            # fixed order into one fp32 (N x p) matrix) -- no bf16 copy of g, no (2,B,N,C) gradient tensor, no scatter copy
-            Wt = kv
-            Wv = Wt.view(1, 1, N, p).expand(B, H, N, p)
-            _apply_into(dk, Wv, dKP.transpose(-1, -2), False)
-            _apply_into(dvsa, Wv, dVP.transpose(-1, -2), False)
-            dWt = torch.empty(1, N, 1, p, dtype=torch.float32, device=G.device)
-            dWv = dWt.permute(0, 2, 1, 3)                                            # (1,1,N,p) token-major view
-            first = True
-            for b in range(B):
-                for i, gm in ((1, dKP), (3, dVP)):
-                    xb = qkvv[b:b + 1, :, i].reshape(1, N, 1, C).permute(0, 2, 1, 3)   # (1,1,N,C): all heads' channels of sample b, in place
-                    _apply_into(dWv, xb, gm[b].reshape(1, 1, C, p), not first)
-                    first = False
-            dW = dWt.view(N, p).t().to(wdt)                                          # (p, N)
+            # the adjoints as tall-skinny products on the operands in place, groups = (k | v_sa, sample), all heads' channels at once:
+            # (dk | dv_sa)[g] (N x C) = W^T (N x p) g[g]^T (p x C) written straight into dqkvv (first contributions), and
+            # dW^T (N x p) = sum over the groups of X[g] (N x C) g[g] (C x p): one apply into per-group fp32 products, one launch that adds
+            # the four and transposes them into (p x N) -- into E.weight.grad itself when that buffer exists.  No bf16 copy of g, no
+            # (2, B, N, C) gradient tensor, no scatter copy, no library GEMM.
+            Wv = Wm.view(1, 1, N, p).expand(2, B, N, p)
+            _apply_call(Wv, g.transpose(-1, -2), _kv_view(dqkvv), 2, B, N, p, C, False)
+            prod = torch.empty(2, B, N, p, dtype=torch.float32, device=dev)
+            _apply_call(_kv_view(qkvv), g, prod, 2, B, N, C, p, False)
+            if ctx.wsink is not None:
+                out, acc = ctx.wsink[0], 1
+            else:
+                out, acc = torch.empty(p, N, dtype=torch.float32, device=dev), 0
+            L.call("p4c_ts_reduce_transpose", L.ptr(prod), 2 * B, N, p, L.ptr(out), acc, L.stream(dev), alg_bytes=4 * N * p * (2 * B + 1 + acc))
+            if acc:
+                L.grad_written(out)
+            else:
+                dW = out.to(wdt)
         else:
             g16 = g.to(dt)
-            dkv = (g16 @ W16).transpose(-1, -2)                                          # (2,B,N,C) view of (2,B,C,N)
+            dkv = (g16 @ Wm).transpose(-1, -2)                                           # (2,B,N,C) view of (2,B,C,N)
             dW = torch.bmm(g16.reshape(2 * B, C, p).transpose(1, 2), kv.reshape(2 * B, N, C).transpose(1, 2)).sum(dim=0).to(wdt)   # (p,N)
             dqkvv[:, :, 1::2].copy_(dkv.reshape(2, B, N, H, d).permute(1, 2, 0, 3, 4))    # dk (first contribution) and dv_sa: one copy
         # q^T k and the norms: dq += k dG^T + 2 q diag(dnq2),  dk += q dG + 2 k diag(dnk2)
@@ -436,6 +481,15 @@ class _EpaCore(torch.autograd.Function):
         _apply_into(dk, q, dG, True)
         _apply_into(dk, k, D[1], True)
         return dqkvv, dW, dbias, dts[0].view(tshape).to(tdt), dts[1].view(tshape).to(tdt)
+
+
+def _kv_view(qkvv: torch.Tensor) -> torch.Tensor:
+    """k and v_sa inside a (B, N, 4, heads, d) tensor as (2, B, N, C) token matrices IN PLACE: group strides (2 C, 4 N C), row stride 4 C"""
+    B, N, _, H, d = qkvv.shape
+    C = H * d
+    if not qkvv.is_contiguous():
+        raise L.P4CError("ops_ts._kv_view: the qkvv tensor must be dense")
+    return qkvv.as_strided((2, B, N, C), (2 * C, 4 * N * C, 4 * C, 1), qkvv.storage_offset() + C)
 
 
 def _gram_partial(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
@@ -449,21 +503,16 @@ def _gram_partial(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return part
 
 
-TOKEN_PROJ_MIN_TOKENS = 2048   # from here on the (2, B, N, C) gather of k / v_sa is worth avoiding (below: the library GEMM on a small copy)
-
-
 def _token_proj_native(qkvv: torch.Tensor, p: int) -> bool:
-    """EPA's token-axis projection on the tall-skinny kernels, k / v_sa read in place (see _EpaCore.forward): the stages with many
-    tokens, whose whole token rows (C = heads x d channels) fit the matrix-core apply kernel (C <= 256) for the weight gradient"""
+    """EPA's token-axis projection and its adjoints on the tall-skinny kernels, k / v_sa read in place (see _EpaCore): bf16, all heads'
+    channels of a token as one row (C = heads x d <= 256 for the weight gradient's apply).  ``P4C_EPA_LIB_PROJ=1`` (diagnostic
+    library) keeps the gather + library GEMM route of rounds 3-5 for A/B runs."""
     B, N, _, H, d = qkvv.shape
     C = H * d
-    # Measured in round 6 (profiles/r06_ab_runs.txt 6): the UNETR++ step is NOT faster this way -- 137.8 ms against 136.8 with the
-    # gather + library GEMM (the shared (N x p) operand is re-read by every (sample, head) group, the weight gradient is four
-    # accumulating passes over an fp32 (N x p) matrix) -- so the library route stays the product's; this one is a diagnostic switch.
-    if L.diag_switch("P4C_EPA_NATIVE_PROJ") != "1" or N < TOKEN_PROJ_MIN_TOKENS or C > 256 or C % 8 or p % 8:
+    if L.diag_switch("P4C_EPA_LIB_PROJ") == "1" or C > 256 or C % 8 or p % 8 or p > 64:
         return False
     lib, bf, f32 = L.lib(), L.dtype_code(torch.bfloat16), L.dtype_code(torch.float32)
-    return bool(lib.p4c_ts_gram_wide_ok(bf, bf, d, p) and lib.p4c_ts_apply_wide_ok(bf, bf, p, d) and lib.p4c_ts_apply_wide_ok(bf, f32, C, p))
+    return bool(lib.p4c_ts_gram_wide_ok(bf, bf, C, p) and lib.p4c_ts_apply_wide_ok(bf, bf, p, C) and lib.p4c_ts_apply_wide_ok(bf, f32, C, p))
 
 
 def epa_core_ok(qkvv: torch.Tensor, p: int) -> bool:
