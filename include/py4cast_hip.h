@@ -728,6 +728,14 @@ int p4c_ts_reduce_splits(const float* part, int A, int S, int R, int E, int nseg
 /* out (E x R, dense) (+)= sum over s of part[s] (R x E)^T, E <= 64 and a multiple of 4: the weight gradient of EPA's token-axis Linear (mfai's `E` / `F`,
  * weight (p, N)) from the per-(k | v_sa, sample) token-major products of p4c_ts_apply. */
 int p4c_ts_reduce_transpose(const float* part, int S, int64_t R, int E, float* out, int accumulate, p4c_stream_t stream);
+/* The x_SA merge of the published EPA code, `x_SA.permute(0, 3, 1, 2).reshape(B, N, C)` on a (B, heads, N, d) tensor (mfai v5.0.1
+ * UNetRPP, EPA.forward), for bf16: x = the token-major (B, N, heads, d) memory the apply kernels write, out = (B, d, heads, N) memory
+ * (read as (B, N, C) by the output projection); inverse = 1: the adjoint, out = token-major gradient from a (B, d, heads, N) one.
+ * A tiled transpose through LDS.  N and C = heads * d multiples of 8, buffers dense and 16-byte aligned. */
+int p4c_ts_merge_published(const void* x, void* out, int B, int64_t N, int heads, int d, int inverse, p4c_stream_t stream);
+/* Column sums of njobs <= 4 small dense fp32 matrices (rows[i] x cols[i], cols <= 64) in one launch: out[i][j] = sum over the rows.
+ * The tails of an EPA backward (bias gradient of the token-axis Linear, the two temperature gradients). */
+int p4c_ts_colsums(int njobs, const float* const* in, const int64_t* rows, const int* cols, float* const* out, p4c_stream_t stream);
 /* The small matrices of one EPA block in one launch each way (all fp32, contiguous): G = q^T k, Gq = q^T q, Gk = k^T k (B, heads, d, d)
  * from p4c_ts_gram, KP (B, heads, d, p), temperatures t1 / t2 (heads):
  *   nq_i = max(sqrt(max(Gq_ii, 0)), 1e-12), nk_j likewise;  A = softmax_j(t1 G_ij / (nq_i nk_j));  Mq_ic = t2 KP_ic / nq_i.
@@ -842,10 +850,10 @@ int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t ldq, int R, 
                 float* db, int accumulate, void* workspace, p4c_stream_t stream);
 /* BatchNorm2d (training mode) statistics from column partial sums [nblk][2][C] over `count` values per channel: mean, rstd,
  * scale = gamma rstd, shift = beta - mean scale (C each, fp32); running_mean / running_var (optional) get torch's momentum update
- * with the unbiased variance. */
+ * with the unbiased variance, num_batches_tracked (optional, the module's int64 counter) is incremented by one. */
 int p4c_bnorm_finalize(const float* partial, int nblk, double count, int C, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
-                       p4c_stream_t stream);
+                       int64_t* num_batches_tracked, p4c_stream_t stream);
 
 /* Bilinear up-sampling of a features-last bf16 map (B, H, W, C) by an integer factor (torch interpolate, align_corners = False),
  * + skip (B, H*scale, W*scale, C) when given -- mfai's UnetrUpBlock with `linear_upsampling: true` (config/CLI/model/unetrpp.yaml:29).

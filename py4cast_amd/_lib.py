@@ -89,6 +89,8 @@ OTHER = {
     "p4c_ts_gram_norms": ([P, I, L, L, L, P, I, L, L, L, P, I, I, L, I, I, P], c_int),
     "p4c_ts_reduce_splits": ([P, I, I, I, I, I, P, P, P, I, I, P], c_int),
     "p4c_ts_reduce_transpose": ([P, I, L, I, P, I, P], c_int),
+    "p4c_ts_colsums": ([I, P, P, P, P, P], c_int),
+    "p4c_ts_merge_published": ([P, P, I, L, I, I, I, P], c_int),
     "p4c_prof_enable": ([I, I], c_int),
     "p4c_prof_filter": ([L], c_int),
     "p4c_prof_collect": ([I, L, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)], c_int),

@@ -95,7 +95,7 @@ SIGNATURES = {
     "p4c_gemm_scale_fold_bwd": [P, P, P, P, P, I, I, P, P, P, I, P],
     "p4c_gemm_nt": [P, L, P, I, I, I, I, I, I, I, P, P, L, I, P, P, L, P, L, P, P, P],
     "p4c_gemm_tn": [P, L, P, L, I, I, I, I, I, I, P, P, I, P, P],
-    "p4c_bnorm_finalize": [P, I, ctypes.c_double, I, P, P, F, F, P, P, P, P, P, P, P],
+    "p4c_bnorm_finalize": [P, I, ctypes.c_double, I, P, P, F, F, P, P, P, P, P, P, P, P],
 }
 OTHER = {
     "p4c_conv_wgrad_workspace_bytes": ([I, I], c_size_t),

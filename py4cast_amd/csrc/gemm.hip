@@ -678,7 +678,9 @@ __global__ void __launch_bounds__(256) bnorm_finalize_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                              float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                              float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
-                                                             float* __restrict__ shift) {
+                                                             float* __restrict__ shift, long long* __restrict__ batches_tracked) {
+    // (batches_tracked: torch.nn.BatchNorm2d.num_batches_tracked, incremented here instead of by a launch of its own)
+    if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;
     // a workgroup owns 32 channels; its 8 thread rows take the partial blocks b = row (mod 8), then the rows are added in order
     __shared__ double red[2][8][32];
     const int cl = threadIdx.x & 31, row = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
@@ -915,10 +917,10 @@ extern "C" int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t l
 
 extern "C" int p4c_bnorm_finalize(const float* partial, int nblk, double count, int C, const float* gamma, const float* beta, float eps,
                                   float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
-                                  float* shift, p4c_stream_t stream) {
+                                  float* shift, int64_t* num_batches_tracked, p4c_stream_t stream) {
     P4C_CHECK_ARG(partial && mean && rstd && scale && shift && nblk > 0 && C > 0 && count > 0, "p4c_bnorm_finalize: bad arguments");
     hipLaunchKernelGGL(bnorm_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, as_stream(stream), partial, nblk, count, C, gamma, beta, eps,
-                       momentum, running_mean, running_var, mean, rstd, scale, shift);
+                       momentum, running_mean, running_var, mean, rstd, scale, shift, reinterpret_cast<long long*>(num_batches_tracked));
     P4C_CHECK_LAUNCH("bnorm_finalize");
     return P4C_OK;
 }

@@ -1073,6 +1073,131 @@ __global__ void __launch_bounds__(256) reduce_transpose_kernel(const float* __re
 }  // namespace ts
 }  // namespace p4c
 
+namespace p4c {
+namespace ts {
+// Column sums of up to four small dense fp32 matrices in one launch (job = blockIdx.x): out[j] = sum over the rows of in[row][j],
+// cols <= 64.  The tails of an EPA backward: the bias gradient of the token-axis Linear (2 B C rows of p columns) and the two
+// temperature gradients (B rows of `heads` columns each) -- three tensor-library reductions before.  64 column lanes x 16 row lanes,
+// the row lanes' sums added in lane order.
+struct ColSumJobs {
+    const float* in[4];
+    float* out[4];
+    int64_t rows[4];
+    int cols[4];
+};
+
+__global__ void __launch_bounds__(1024) colsums_kernel(ColSumJobs jobs) {
+    __shared__ float red[16][64];
+    const int job = blockIdx.x, c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int cols = jobs.cols[job];
+    const int64_t rows = jobs.rows[job];
+    const float* in = jobs.in[job];
+    float acc = 0.f;
+    if (c < cols) {
+        int64_t r = rl;
+        for (; r + 48 < rows; r += 64) {
+            const float v0 = in[r * cols + c], v1 = in[(r + 16) * cols + c], v2 = in[(r + 32) * cols + c], v3 = in[(r + 48) * cols + c];
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; r < rows; r += 16) acc += in[r * cols + c];
+    }
+    red[rl][c] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+#pragma unroll
+        for (int t = 1; t < 16; ++t) acc += red[t][c];
+        jobs.out[job][c] = acc;
+    }
+}
+}  // namespace ts
+}  // namespace p4c
+
+namespace p4c {
+namespace ts {
+// The published EPA code merges the spatial branch as `x_SA.permute(0, 3, 1, 2).reshape(B, N, C)` on a (B, heads, N, d) tensor: the
+// memory order becomes (d, heads, N) -- per sample the TRANSPOSE of the token-major (N x C) matrix the kernels produce, with the
+// channels reordered c = hh d + j -> row r = j heads + hh.  The tensor library does that as a strided gather (1 TB/s); here a
+// workgroup moves a 64-token x 64-channel tile through LDS: 16-byte reads of token rows, 16-byte writes of 8 consecutive tokens of
+// one output row.  inverse = 1: the adjoint (the gradient back to token-major).
+constexpr int MP_LD = 72;       // LDS row stride in bf16 elements (144 bytes: 16-byte aligned rows)
+
+__global__ void __launch_bounds__(256) merge_published_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, int64_t N,
+                                                              int heads, int d, int inverse) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * MP_LD];
+    const int C = heads * d;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int64_t base = (int64_t)b * N * C;
+    if (!inverse) {
+        // token-major in: tile[t][c]
+        for (int v = threadIdx.x; v < 64 * 8; v += 256) {
+            const int t = v >> 3, c8 = (v & 7) << 3;
+            ts_u32x4 q = {0u, 0u, 0u, 0u};
+            if (n0 + t < N && c0 + c8 < C) q = *reinterpret_cast<const ts_u32x4*>(in + base + (n0 + t) * C + c0 + c8);
+            *reinterpret_cast<ts_u32x4*>(tile + t * MP_LD + c8) = q;
+        }
+        __syncthreads();
+        for (int v = threadIdx.x; v < 64 * 8; v += 256) {
+            const int cl = v >> 3, t8 = (v & 7) << 3, c = c0 + cl;
+            if (c >= C || n0 + t8 >= N) continue;
+            const int hh = c / d, j = c - hh * d;
+            union { unsigned short s[8]; ts_u32x4 q; } u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) u.s[i] = tile[(t8 + i) * MP_LD + cl];
+            *reinterpret_cast<ts_u32x4*>(out + base + ((int64_t)j * heads + hh) * N + n0 + t8) = u.q;
+        }
+    } else {
+        // transposed in: tile[c][t]
+        for (int v = threadIdx.x; v < 64 * 8; v += 256) {
+            const int cl = v >> 3, t8 = (v & 7) << 3, c = c0 + cl;
+            ts_u32x4 q = {0u, 0u, 0u, 0u};
+            if (c < C && n0 + t8 < N) {
+                const int hh = c / d, j = c - hh * d;
+                q = *reinterpret_cast<const ts_u32x4*>(in + base + ((int64_t)j * heads + hh) * N + n0 + t8);
+            }
+            *reinterpret_cast<ts_u32x4*>(tile + cl * MP_LD + t8) = q;
+        }
+        __syncthreads();
+        for (int v = threadIdx.x; v < 64 * 8; v += 256) {
+            const int t = v >> 3, c8 = (v & 7) << 3;
+            if (n0 + t >= N || c0 + c8 >= C) continue;
+            union { unsigned short s[8]; ts_u32x4 q; } u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) u.s[i] = tile[(c8 + i) * MP_LD + t];
+            *reinterpret_cast<ts_u32x4*>(out + base + (n0 + t) * C + c0 + c8) = u.q;
+        }
+    }
+}
+}  // namespace ts
+}  // namespace p4c
+
+extern "C" int p4c_ts_merge_published(const void* x, void* out, int B, int64_t N, int heads, int d, int inverse, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && out && x != out, "p4c_ts_merge_published: null pointer or in-place call");
+    P4C_CHECK_ARG(B > 0 && N > 0 && heads > 0 && d > 0, "p4c_ts_merge_published: empty problem");
+    const int C = heads * d;
+    P4C_CHECK_ARG(N % 8 == 0 && C % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                  "p4c_ts_merge_published: tokens and channels must be multiples of 8 (got %lld, %d), buffers 16-byte aligned", (long long)N, C);
+    hipLaunchKernelGGL(ts::merge_published_kernel, dim3((unsigned)((N + 63) / 64), (C + 63) / 64, B), dim3(256), 0, as_stream(stream),
+                       static_cast<const unsigned short*>(x), static_cast<unsigned short*>(out), N, heads, d, inverse);
+    P4C_CHECK_LAUNCH("p4c_ts_merge_published");
+    return P4C_OK;
+}
+
+extern "C" int p4c_ts_colsums(int njobs, const float* const* in, const int64_t* rows, const int* cols, float* const* out, p4c_stream_t stream) {
+    P4C_CHECK_ARG(njobs >= 1 && njobs <= 4 && in && rows && cols && out, "p4c_ts_colsums: 1..4 jobs");
+    ts::ColSumJobs jobs{};
+    for (int i = 0; i < njobs; ++i) {
+        P4C_CHECK_ARG(in[i] && out[i] && rows[i] > 0 && cols[i] > 0 && cols[i] <= 64, "p4c_ts_colsums: job %d: null pointer, no rows or more than 64 columns", i);
+        jobs.in[i] = in[i];
+        jobs.out[i] = out[i];
+        jobs.rows[i] = rows[i];
+        jobs.cols[i] = cols[i];
+    }
+    hipLaunchKernelGGL(ts::colsums_kernel, dim3(njobs), dim3(1024), 0, as_stream(stream), jobs);
+    P4C_CHECK_LAUNCH("p4c_ts_colsums");
+    return P4C_OK;
+}
+
 extern "C" int p4c_ts_reduce_splits(const float* part, int A, int S, int R, int E, int nseg, const int* seg_len, float* const* outs,
                                     const float* bias, int bias_len, int accumulate, p4c_stream_t stream) {
     P4C_CHECK_ARG(part && seg_len && outs, "p4c_ts_reduce_splits: null pointer");

@@ -335,6 +335,7 @@ class _Conv(torch.autograd.Function):
         ctx.geom, ctx.has_bias, ctx.has_res = (B, H, W_, Cx, Co, Ci, taps), b is not None, res is not None
         ctx.wdtype, ctx.bdtype, ctx.wshape = w.dtype, (None if b is None else b.dtype), w.shape
         ctx.sink = _sink(w, b)
+        ctx.set_materialize_grads(False)     # (no zero-filled "gradient" of the statistics output: a fill launch per convolution)
         y = y.view(B, H, W_, Co)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -343,6 +344,8 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        if dy is None:
+            return None, None, None, None, None
         xm, dgr = ctx.saved_tensors
         B, H, W_, Cx, Co, Ci, taps = ctx.geom
         dy2 = _rows(dy, Co)
@@ -383,7 +386,7 @@ class _BatchNormAct(torch.autograd.Function):
     partial sums (training) or the running statistics (eval); the streaming kernels of csrc/inorm.hip with the batch as ONE sample."""
 
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, res, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, y, stats, gamma, beta, res, running_mean, running_var, training, momentum, eps, slope, batches_tracked=None):
         yc = y.contiguous()
         C = yc.shape[-1]
         N = yc.numel() // C
@@ -396,7 +399,7 @@ class _BatchNormAct(torch.autograd.Function):
                 stats = torch.empty(nb, 2, C, dtype=torch.float32, device=dev)
                 L.call("p4c_inorm_reduce", L.ptr(yc), None, None, None, None, 1.0, L.ptr(stats), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev))
             L.call("p4c_bnorm_finalize", L.ptr(stats), stats.shape[0], float(N), C, L.ptr(g32), L.ptr(b32), float(eps), float(momentum),
-                   L.ptr(running_mean), L.ptr(running_var), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]), L.stream(dev))
+                   L.ptr(running_mean), L.ptr(running_var), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]), L.ptr(batches_tracked), L.stream(dev))
         else:
             st[0] = running_mean
             st[1] = torch.rsqrt(running_var.float() + eps)
@@ -442,7 +445,7 @@ class _BatchNormAct(torch.autograd.Function):
                alg_bytes=yc.numel() * yc.element_size() * (4 + ctx.has_res))
         dg = None if ctx.gdtype is None else dgb[0].to(ctx.gdtype)
         db = None if ctx.gdtype is None else dgb[1].to(ctx.gdtype)
-        return dy, None, dg, db, dres, None, None, None, None, None, None
+        return dy, None, dg, db, dres, None, None, None, None, None, None, None
 
 
 def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=None):
@@ -457,10 +460,15 @@ def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=N
         # torch: the cumulative moving average, factor 1 / num_batches_tracked -- a per-step value the fused finalize does not take
         raise L.P4CError("ops_gemm.batch_norm_act: BatchNorm2d(momentum=None) (cumulative average) is not served; give a momentum")
     mom = 0.1 if bn.momentum is None else bn.momentum
+    nbt = None
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)      # a device add: captured into a HIP graph like the kernels around it (replays advance it)
+        # incremented by the statistics kernel itself (p4c_bnorm_finalize; round 6 -- a launch of its own before: 42 per model call):
+        # on the device, so captured into a HIP graph like the kernels around it (replays advance it)
+        nbt = bn.num_batches_tracked
+        if nbt.dtype != torch.int64 or nbt.device != y.device:
+            raise L.P4CError("ops_gemm.batch_norm_act: num_batches_tracked must be an int64 tensor on the map's device")
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BatchNormAct.apply(y, stats if training else None, bn.weight, bn.bias, res, rm, rv, training, mom, bn.eps, float(slope))
+    return _BatchNormAct.apply(y, stats if training else None, bn.weight, bn.bias, res, rm, rv, training, mom, bn.eps, float(slope), nbt)
 
 
 class _UpsampleAdd(torch.autograd.Function):

@@ -53,6 +53,23 @@ def reduce_splits(part: torch.Tensor, outs, bias=None, accumulate: bool = False)
     return outs
 
 
+_L4 = ctypes.c_int64 * 4
+_I4 = ctypes.c_int * 4
+_P4 = ctypes.c_void_p * 4
+
+
+def colsums(jobs):
+    """[(x (rows, cols <= 64) fp32 dense, out (cols,) fp32), ...] (<= 4 pairs): out = x.sum(0), all pairs in one launch (p4c_ts_colsums)"""
+    n = len(jobs)
+    for x, o in jobs:
+        if x.dtype != torch.float32 or o.dtype != torch.float32 or x.dim() != 2 or not x.is_contiguous() or not o.is_contiguous() \
+                or o.numel() != x.shape[1] or x.shape[1] > 64:
+            raise L.P4CError("ops_ts.colsums: dense fp32 (rows, cols <= 64) matrices and (cols,) outputs")
+    pad = [None] * (4 - n)
+    L.call("p4c_ts_colsums", n, _P4(*[x.data_ptr() for x, _ in jobs], *pad), _L4(*[x.shape[0] for x, _ in jobs], *([0] * (4 - n))),
+           _I4(*[x.shape[1] for x, _ in jobs], *([0] * (4 - n))), _P4(*[o.data_ptr() for _, o in jobs], *pad), L.stream(jobs[0][0].device))
+
+
 def _gram_call(x: torch.Tensor, y: torch.Tensor, out=None) -> torch.Tensor:
     """X^T Y (B, H, d, e) fp32 (into ``out`` when given: a dense fp32 tensor of that many elements)"""
     B, H, N, d = x.shape
@@ -446,9 +463,12 @@ class _EpaCore(torch.autograd.Function):
         L.call("p4c_epa_small_bwd", L.ptr(G), L.ptr(nq2), L.ptr(nk2), L.ptr(KP), L.ptr(t1f), L.ptr(t2f), L.ptr(At), L.ptr(nrm[0]), L.ptr(nrm[1]),
                L.ptr(dAt.float().contiguous()), L.ptr(dMq.float().contiguous()), L.ptr(dG), L.ptr(dn[0]), L.ptr(dn[1]), L.ptr(dKP), L.ptr(dtp[0]),
                L.ptr(dtp[1]), B, H, d, p, 1, L.stream(dev))
-        dts = dtp.sum(dim=1)
-        # token-axis projection: proj = kv^T W^T + bias
-        dbias = g.sum(dim=(0, 1, 2)).to(bdt)
+        # the temperatures' gradients (sums over the samples) and the bias gradient of the token-axis projection proj = kv^T W^T + bias
+        # (sum over k | v_sa, samples and channels): one launch for the three column sums
+        dts = torch.empty(2, H, dtype=torch.float32, device=dev)
+        dbias = torch.empty(p, dtype=torch.float32, device=dev)
+        colsums([(dtp[0], dts[0]), (dtp[1], dts[1]), (g.view(2 * B * C, p), dbias)])
+        dbias = dbias.to(bdt)
         dW = None
         if ctx.native_proj:
             # the adjoints as tall-skinny products on the operands in place, groups = (k | v_sa, sample), all heads' channels at once:
@@ -526,3 +546,38 @@ def epa_core_ok(qkvv: torch.Tensor, p: int) -> bool:
 def epa_core(qkvv, W, bias, t1, t2):
     """(x_sa, x_ca) of an EPA block from its qkvv projection, the token-axis Linear E (weight (p, N), bias) and the temperatures."""
     return _EpaCore.apply(qkvv, W, bias, t1, t2)
+
+
+class _MergePublished(torch.autograd.Function):
+    """``x_sa.permute(0, 3, 1, 2).reshape(B, N, C)`` of the published EPA code on the token-major (B, heads, N, d) view the apply kernels
+    produce, and its adjoint, as tiled transposes (p4c_ts_merge_published) instead of the tensor library's strided gathers; the gradient
+    comes back token-major, i.e. as the (B, heads, N, d) view with unit stride the backward kernels of the block read in place."""
+
+    @staticmethod
+    def forward(ctx, x_sa):
+        B, H, N, d = x_sa.shape
+        ctx.geom = (B, H, N, d)
+        out = torch.empty(B, N, H * d, dtype=x_sa.dtype, device=x_sa.device)
+        L.call("p4c_ts_merge_published", L.ptr(x_sa), L.ptr(out), B, N, H, d, 0, L.stream(x_sa.device), alg_bytes=2 * out.numel() * out.element_size())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, H, N, d = ctx.geom
+        dout = dout.contiguous()
+        dx = torch.empty(B, N, H, d, dtype=dout.dtype, device=dout.device)
+        L.call("p4c_ts_merge_published", L.ptr(dout), L.ptr(dx), B, N, H, d, 1, L.stream(dout.device), alg_bytes=2 * dx.numel() * dx.element_size())
+        return dx.permute(0, 2, 1, 3)
+
+
+def merge_published_ok(x_sa: torch.Tensor) -> bool:
+    """bf16 (B, heads, N, d) view of dense token-major (B, N, heads, d) memory, N and heads * d multiples of 8"""
+    if not (x_sa.is_cuda and x_sa.dtype == torch.bfloat16 and x_sa.dim() == 4):
+        return False
+    B, H, N, d = x_sa.shape
+    return (N % 8 == 0 and (H * d) % 8 == 0 and x_sa.permute(0, 2, 1, 3).is_contiguous() and x_sa.data_ptr() % 16 == 0)
+
+
+def merge_published(x_sa: torch.Tensor) -> torch.Tensor:
+    """(B, heads, N, d) -> (B, N, C) as the published block merges its spatial branch (see _MergePublished)"""
+    return _MergePublished.apply(x_sa)

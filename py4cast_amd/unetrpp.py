@@ -296,6 +296,8 @@ class EPA(nn.Module):
         """(B, h, N, d) -> (B, N, C): head-major per token (restated block: a view of the kernels' token-major output), or the published
         code's ``permute(0, 3, 1, 2).reshape(B, N, C)`` -- the (B, d, h, N) order read as (N, C): one gather copy"""
         if self.published:
+            if TS.merge_published_ok(x_sa) and L.diag_switch("P4C_EPA_LIB_MERGE") != "1":
+                return TS.merge_published(x_sa)      # (a tiled transpose each way instead of the tensor library's strided gather)
             return x_sa.permute(0, 3, 1, 2).reshape(B, N, C)
         return x_sa.permute(0, 2, 1, 3).reshape(B, N, C)
 

@@ -56,8 +56,8 @@ for ev in prof.events():
     frame = next((f for f in (ev.stack or []) if "py4cast_amd" in f), "")
     frame = frame.split("py4cast_amd/")[-1][:70]
     chain, p = [], ev.cpu_parent
-    while p is not None and len(chain) < 3:
-        chain.append(p.name[:48])
+    while p is not None and len(chain) < 5:
+        chain.append(p.name[:40].replace("autograd::engine::evaluate_function: ", "eval:"))
         p = p.cpu_parent
     for k in ev.kernels:
         total += k.duration
@@ -75,4 +75,4 @@ for ev in prof.events():
         rows[key][1] += 1
 print(f"{model} T={T} {strategy}: device kernel time {total / 1e3:.2f} ms, native {native / total:.3f}")
 for key, (t, n) in sorted(rows.items(), key=lambda kv: -kv[1][0])[:top]:
-    print(f"{t / 1e3:8.3f} ms {n:5d}  {key[0]:40s} | {key[1]:40s} | {key[2][:100]:100s} | {key[3]}")
+    print(f"{t / 1e3:8.3f} ms {n:5d}  {key[0]:40s} | {key[1]:40s} | {key[2][:150]:150s} | {key[3]}")
