@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) reduce_kernel(const T* __restrict__ x, co
     finalize_in_kernel(fin, MODE == 1, partial, (int)gridDim.x, (int)gridDim.y, C, red, red + 1024);
 }
 
-// forward: y = lrelu(x * scale[b,c] + shift[b,c] (+ res));  backward (MODE 1): dx = scale * (dz - m1 - xhat * m2), dres = dz;
+// forward: y = lrelu(x * scale[b,c] + shift[b,c] (+ res));  backward (MODE 1): dx = scale * (dz - m1 - xhat * m2), dres = dz (+ res);
 // MODE 2 (rstd == NULL): dx = scale * dz - m1 - (x - mean) * m2
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const T* __restrict__ dy,
@@ -137,7 +137,14 @@ __global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, con
                 }
             }
             store4f(out + off, o);
-            if (dres) store4f(dres + off, dz);
+            if (dres) {
+                if (res) {      // backward: `res` is a gradient that reached the residual operand by another path -- added here, not by a launch
+                    const p4c_f32x4 rv = ld4(res + off);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dz[k] += rv[k];
+                }
+                store4f(dres + off, dz);
+            }
         }
     }
 }

@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(128) gram_mfma_kernel(Mat X, Mat Y, float* __r
             float sacc = 0.f;
             for (int w = 0; w < 2; ++w)
                 for (int l = c; l < 64; l += nv) sacc += src[(w * 64 + l) * 8 + j];
-            pb[(int64_t)d * e + (isx ? 0 : d) + col] = sacc;
+            pb[(int64_t)d * e + (isx ? i0 : d + j0) + col] = sacc;      // (every result block of a column range writes the same sums)
         }
     }
 }
@@ -637,16 +637,19 @@ extern "C" int p4c_ts_gram_norms(const void* x, int x_dtype, int64_t x_bs, int64
                                  int64_t y_bs, int64_t y_hs, int64_t y_rs, float* partial, int B, int heads, int64_t N, int d, int e,
                                  p4c_stream_t stream) {
     P4C_CHECK_ARG(x && y && partial, "p4c_ts_gram_norms: null pointer");
-    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0 && d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
-                  "p4c_ts_gram_norms: d, e must be multiples of 4 up to %d (got %d, %d)", ts::MAXD, d, e);
+    P4C_CHECK_ARG(B > 0 && heads > 0 && N > 0 && d > 0 && e > 0, "p4c_ts_gram_norms: empty problem");
     P4C_CHECK_ARG(x_dtype == P4C_BF16 && y_dtype == P4C_BF16, "p4c_ts_gram_norms: bf16 token matrices");
-    if (p4c_ts_gram_wide_ok(x_dtype, y_dtype, d, e) && (64 % (d / 8)) == 0 && (64 % (e / 8)) == 0 &&
-        gram_mfma_aligned(x, x_bs, x_hs, x_rs, y, y_bs, y_hs, y_rs)) {
+    // matrix-core form: a lane keeps its 8 columns from tile to tile when the 16-byte vectors of a staged row divide 64 lanes -- widths
+    // 8, 16, 32, 64, or (round 6) whole 64-column result blocks (128-wide decoder heads)
+    const auto lanes_ok = [](int w) { return w % 8 == 0 && (w <= 64 ? 64 % (w / 8) == 0 : w % 64 == 0); };
+    if (p4c_ts_gram_wide_ok(x_dtype, y_dtype, d, e) && lanes_ok(d) && lanes_ok(e) && gram_mfma_aligned(x, x_bs, x_hs, x_rs, y, y_bs, y_hs, y_rs)) {
         const ts::Mat Xm{x, x_bs, x_hs, x_rs}, Ym{y, y_bs, y_hs, y_rs};
         launch_gram_mfma<true>(Xm, Ym, partial, B, heads, N, d, e, p4c_ts_gram_splits(N), as_stream(stream));
         P4C_CHECK_LAUNCH("p4c_ts_gram_norms");
         return P4C_OK;
     }
+    P4C_CHECK_ARG(d <= ts::MAXD && e <= ts::MAXD && d % 4 == 0 && e % 4 == 0,
+                  "p4c_ts_gram_norms: off the matrix-core form d, e must be multiples of 4 up to %d (got %d, %d)", ts::MAXD, d, e);
     P4C_CHECK_ARG(x_bs % 4 == 0 && x_hs % 4 == 0 && x_rs % 4 == 0 && y_bs % 4 == 0 && y_hs % 4 == 0 && y_rs % 4 == 0 &&
                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                   "p4c_ts_gram_norms: strides must be multiples of 4 elements, bases 16-byte aligned");
@@ -807,24 +810,31 @@ constexpr float EPA_EPS = 1e-12f;   // F.normalize's clamp
 // inner loops (and the projection columns c = s (mod 4)); the four slices' partial maxima / sums meet in LDS and are added in slice
 // order (deterministic).  G (d x d, row-major) and KP are staged through LDS with coalesced loads: a thread per row walking its
 // row in global memory touched 64 cache lines per instruction (the first version: one 64-thread wave per (b, h), 20 / 36 us per launch).
-constexpr int EPA_LD = 65;
-
-__device__ __forceinline__ void epa_stage(float* dst, const float* __restrict__ src, int rows, int cols) {
+// Round 6: the head width is a template parameter (DM = 64: 64 rows x 4 slices; DM = 128: 128 rows x 2 slices -- the decoder stage with
+// 128-channel heads ran on separate tensor-library nodes before); the tiles live in dynamic LDS (DM = 128: 101 / 136 KB).
+__device__ __forceinline__ void epa_stage(float* dst, int ld, const float* __restrict__ src, int rows, int cols) {
     for (int e = threadIdx.x; e < rows * cols; e += 256) {
         const int r = e / cols, c = e - r * cols;
-        dst[r * EPA_LD + c] = src[e];
+        dst[r * ld + c] = src[e];
     }
 }
 
+template <int DM>
 __global__ void __launch_bounds__(256) epa_small_fwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
                                                             const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
                                                             float* __restrict__ At, float* __restrict__ Mq, float* __restrict__ nq_out,
                                                             float* __restrict__ nk_out, int heads, int d, int p, int dstride) {
     // dstride = d: Gq / Gk are the full (d x d) q^T q / k^T k, only their diagonals are read;  dstride = 1: they ARE the diagonals (B, h, d)
-    __shared__ float nq[64], nk[64], gl[64 * EPA_LD], kl[64 * EPA_LD], part[4][64];
-    const int g = blockIdx.x, h = g % heads, i = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    epa_stage(gl, G + (int64_t)g * d * d, d, d);
-    epa_stage(kl, KP + (int64_t)g * d * p, d, p);
+    constexpr int LD = DM + 1, NSL = 256 / DM, KLD = 65;
+    extern __shared__ float epa_sm[];
+    float* nq = epa_sm;                 // [DM]
+    float* nk = nq + DM;                // [DM]
+    float* gl = nk + DM;                // [DM][LD]
+    float* kl = gl + DM * LD;           // [DM][KLD]
+    float* part = kl + DM * KLD;        // [NSL][DM]
+    const int g = blockIdx.x, h = g % heads, i = threadIdx.x % DM, sl = threadIdx.x / DM;
+    epa_stage(gl, LD, G + (int64_t)g * d * d, d, d);
+    epa_stage(kl, KLD, KP + (int64_t)g * d * p, d, p);
     if (threadIdx.x < d) {
         const int64_t od = (int64_t)g * d * dstride + i * dstride + (dstride > 1 ? i : 0);
         const float a = fmaxf(sqrtf(fmaxf(Gq[od], 0.f)), EPA_EPS), c = fmaxf(sqrtf(fmaxf(Gk[od], 0.f)), EPA_EPS);
@@ -839,28 +849,34 @@ __global__ void __launch_bounds__(256) epa_small_fwd_kernel(const float* __restr
     const float nqi = row ? nq[i] : 1.f;
     float mx = -INFINITY;
     if (row)
-        for (int j = sl; j < d; j += 4) mx = fmaxf(mx, gl[i * EPA_LD + j] / (nqi * nk[j]) * s1);
-    part[sl][i] = mx;
+        for (int j = sl; j < d; j += NSL) mx = fmaxf(mx, gl[i * LD + j] / (nqi * nk[j]) * s1);
+    part[sl * DM + i] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(part[0][i], part[1][i]), fmaxf(part[2][i], part[3][i]));
+    mx = part[i];
+#pragma unroll
+    for (int t = 1; t < NSL; ++t) mx = fmaxf(mx, part[t * DM + i]);
     __syncthreads();
     float sum = 0.f;
     if (row)
-        for (int j = sl; j < d; j += 4) sum += expf(gl[i * EPA_LD + j] / (nqi * nk[j]) * s1 - mx);
-    part[sl][i] = sum;
+        for (int j = sl; j < d; j += NSL) sum += expf(gl[i * LD + j] / (nqi * nk[j]) * s1 - mx);
+    part[sl * DM + i] = sum;
     __syncthreads();
     if (row) {
-        const float inv = 1.f / (((part[0][i] + part[1][i]) + part[2][i]) + part[3][i]);
-        for (int j = sl; j < d; j += 4) At[(int64_t)g * d * d + j * d + i] = expf(gl[i * EPA_LD + j] / (nqi * nk[j]) * s1 - mx) * inv;
+        float tot = part[i];
+#pragma unroll
+        for (int t = 1; t < NSL; ++t) tot += part[t * DM + i];
+        const float inv = 1.f / tot;
+        for (int j = sl; j < d; j += NSL) At[(int64_t)g * d * d + j * d + i] = expf(gl[i * LD + j] / (nqi * nk[j]) * s1 - mx) * inv;
     }
-    // Mq rows: coalesced over c (thread -> column), rows dealt to the 4 x 64 / p' thread groups
+    // Mq rows: coalesced over c (thread -> column)
     for (int e = threadIdx.x; e < d * p; e += 256) {
         const int r = e / p, c = e - r * p;
-        Mq[(int64_t)g * d * p + e] = kl[r * EPA_LD + c] / nq[r] * s2;
+        Mq[(int64_t)g * d * p + e] = kl[r * KLD + c] / nq[r] * s2;
     }
 }
 
 // backward: dG, dGq, dGk (zero off the diagonal), dKP, and per-(b, h) partials of dt1 / dt2 (the caller sums them over b)
+template <int DM>
 __global__ void __launch_bounds__(256) epa_small_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Gq, const float* __restrict__ Gk,
                                                             const float* __restrict__ KP, const float* __restrict__ t1, const float* __restrict__ t2,
                                                             const float* __restrict__ At, const float* __restrict__ nq_in, const float* __restrict__ nk_in,
@@ -868,11 +884,18 @@ __global__ void __launch_bounds__(256) epa_small_bwd_kernel(const float* __restr
                                                             float* __restrict__ dGq, float* __restrict__ dGk, float* __restrict__ dKP,
                                                             float* __restrict__ dt1_part, float* __restrict__ dt2_part, int heads, int d, int p,
                                                             int dstride) {
-    __shared__ float nq[64], nk[64], gl[64 * EPA_LD], col[64 * EPA_LD];
-    __shared__ float pa[4][64], pb[4][64], pc[4][64];
-    const int g = blockIdx.x, h = g % heads, i = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    constexpr int LD = DM + 1, NSL = 256 / DM;
+    extern __shared__ float epa_sm[];
+    float* nq = epa_sm;                 // [DM]
+    float* nk = nq + DM;                // [DM]
+    float* gl = nk + DM;                // [DM][LD]
+    float* col = gl + DM * LD;          // [DM][LD]
+    float* pa = col + DM * LD;          // [NSL][DM]
+    float* pb = pa + NSL * DM;
+    float* pc = pb + NSL * DM;
+    const int g = blockIdx.x, h = g % heads, i = threadIdx.x % DM, sl = threadIdx.x / DM;
     const int64_t o2 = (int64_t)g * d * d, op = (int64_t)g * d * p;
-    epa_stage(gl, G + o2, d, d);
+    epa_stage(gl, LD, G + o2, d, d);
     if (threadIdx.x < d) {
         nq[i] = nq_in[(int64_t)g * d + i];
         nk[i] = nk_in[(int64_t)g * d + i];
@@ -883,42 +906,46 @@ __global__ void __launch_bounds__(256) epa_small_bwd_kernel(const float* __restr
     const float nqi = row ? nq[i] : 1.f;
     float dot = 0.f;                                        // sum_j dA_ij A_ij
     if (row)
-        for (int j = sl; j < d; j += 4) dot += dAt[o2 + j * d + i] * At[o2 + j * d + i];
-    pa[sl][i] = dot;
+        for (int j = sl; j < d; j += NSL) dot += dAt[o2 + j * d + i] * At[o2 + j * d + i];
+    pa[sl * DM + i] = dot;
     __syncthreads();
-    dot = ((pa[0][i] + pa[1][i]) + pa[2][i]) + pa[3][i];
+    dot = pa[i];
+#pragma unroll
+    for (int t = 1; t < NSL; ++t) dot += pa[t * DM + i];
     __syncthreads();
     float a1 = 0.f, a2 = 0.f, dnq = 0.f;
     if (row) {
-        for (int j = sl; j < d; j += 4) {
+        for (int j = sl; j < d; j += NSL) {
             const float a = At[o2 + j * d + i];
             const float dz = a * (dAt[o2 + j * d + i] - dot);          // softmax backward
-            const float r = gl[i * EPA_LD + j] / (nqi * nk[j]);
+            const float r = gl[i * LD + j] / (nqi * nk[j]);
             a1 += dz * r;                                   // dt1
             const float dr = dz * s1;
-            gl[i * EPA_LD + j] = dr / (nqi * nk[j]);        // dG_ij (the element is this thread's own: read above, stored below)
+            gl[i * LD + j] = dr / (nqi * nk[j]);            // dG_ij (the element is this thread's own: read above, stored below)
             dnq -= dr * r / nqi;
-            col[i * EPA_LD + j] = -dr * r;                  // contribution to dnk_j (/ nk_j below), summed over i
+            col[i * LD + j] = -dr * r;                      // contribution to dnk_j (/ nk_j below), summed over i
         }
-        for (int c = sl; c < p; c += 4) {                   // (d x p: a row per thread, its cache lines shared by the row's four slices)
+        for (int c = sl; c < p; c += NSL) {                 // (d x p: a row per thread, its cache lines shared by the row's slices)
             const float dm = dMq[op + i * p + c], kp = KP[op + i * p + c];
             dKP[op + i * p + c] = dm * s2 / nqi;
             a2 += dm * kp / nqi;                            // dt2
             dnq -= dm * kp * s2 / (nqi * nqi);
         }
     }
-    pa[sl][i] = a1;
-    pb[sl][i] = a2;
-    pc[sl][i] = dnq;
+    pa[sl * DM + i] = a1;
+    pb[sl * DM + i] = a2;
+    pc[sl * DM + i] = dnq;
     __syncthreads();
     for (int e = threadIdx.x; e < d * d; e += 256) {        // coalesced stores of the staged results
         const int r = e / d, c = e - r * d;
-        dG[o2 + e] = gl[r * EPA_LD + c];
+        dG[o2 + e] = gl[r * LD + c];
     }
     if (row && sl == 0) {
-        dnq = ((pc[0][i] + pc[1][i]) + pc[2][i]) + pc[3][i];
+        dnq = pc[i];
+#pragma unroll
+        for (int t = 1; t < NSL; ++t) dnq += pc[t * DM + i];
         float dnk = 0.f;
-        for (int r2 = 0; r2 < d; ++r2) dnk += col[r2 * EPA_LD + i];
+        for (int r2 = 0; r2 < d; ++r2) dnk += col[r2 * LD + i];
         dnk /= nk[i];
         // n = max(sqrt(max(x, 0)), eps): dn/dx = 1 / (2 sqrt(x)) where x > 0 and sqrt(x) > eps, else 0
         const int64_t od = (int64_t)g * d * dstride + i * dstride;
@@ -938,8 +965,11 @@ __global__ void __launch_bounds__(256) epa_small_bwd_kernel(const float* __restr
     if (threadIdx.x == 0) {
         float u = 0.f, v = 0.f;
         for (int r2 = 0; r2 < d; ++r2) {
-            u += ((pa[0][r2] + pa[1][r2]) + pa[2][r2]) + pa[3][r2];
-            v += ((pb[0][r2] + pb[1][r2]) + pb[2][r2]) + pb[3][r2];
+            float ur = pa[r2], vr = pb[r2];
+#pragma unroll
+            for (int t = 1; t < NSL; ++t) { ur += pa[t * DM + r2]; vr += pb[t * DM + r2]; }
+            u += ur;
+            v += vr;
         }
         dt1_part[g] = u;
         dt2_part[g] = v;
@@ -951,9 +981,20 @@ __global__ void __launch_bounds__(256) epa_small_bwd_kernel(const float* __restr
 extern "C" int p4c_epa_small_fwd(const float* G, const float* Gq, const float* Gk, const float* KP, const float* t1, const float* t2, float* At,
                                  float* Mq, float* nq, float* nk, int B, int heads, int d, int p, int diag_only, p4c_stream_t stream) {
     P4C_CHECK_ARG(G && Gq && Gk && KP && t1 && t2 && At && Mq && nq && nk, "p4c_epa_small_fwd: null pointer");
-    P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0 && p <= 64, "p4c_epa_small_fwd: head width / projection size 1..64 (got %d, %d)", d, p);
-    hipLaunchKernelGGL(ts::epa_small_fwd_kernel, dim3(B * heads), dim3(256), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, Mq, nq, nk, heads, d, p,
-                       diag_only ? 1 : d);
+    P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 128 && p > 0 && p <= 64, "p4c_epa_small_fwd: head width 1..128, projection size 1..64 (got %d, %d)", d, p);
+    const int ds = diag_only ? 1 : d;
+    if (d <= 64) {
+        constexpr int DM = 64;
+        const size_t smem = (2 * DM + DM * (DM + 1) + DM * 65 + 256) * sizeof(float);
+        hipLaunchKernelGGL(ts::epa_small_fwd_kernel<DM>, dim3(B * heads), dim3(256), smem, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, Mq, nq, nk, heads,
+                           d, p, ds);
+    } else {
+        constexpr int DM = 128;
+        const size_t smem = (2 * DM + DM * (DM + 1) + DM * 65 + 256) * sizeof(float);
+        P4C_TRY(ensure_dyn_smem((const void*)ts::epa_small_fwd_kernel<DM>, (int)smem));
+        hipLaunchKernelGGL(ts::epa_small_fwd_kernel<DM>, dim3(B * heads), dim3(256), smem, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, Mq, nq, nk, heads,
+                           d, p, ds);
+    }
     P4C_CHECK_LAUNCH("p4c_epa_small_fwd");
     return P4C_OK;
 }
@@ -964,9 +1005,20 @@ extern "C" int p4c_epa_small_bwd(const float* G, const float* Gq, const float* G
                                  p4c_stream_t stream) {
     P4C_CHECK_ARG(G && Gq && Gk && KP && t1 && t2 && At && nq && nk && dAt && dMq && dG && dGq && dGk && dKP && dt1_part && dt2_part,
                   "p4c_epa_small_bwd: null pointer");
-    P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 64 && p > 0, "p4c_epa_small_bwd: head width 1..64 (got %d)", d);
-    hipLaunchKernelGGL(ts::epa_small_bwd_kernel, dim3(B * heads), dim3(256), 0, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, nq, nk, dAt, dMq, dG, dGq,
-                       dGk, dKP, dt1_part, dt2_part, heads, d, p, diag_only ? 1 : d);
+    P4C_CHECK_ARG(B > 0 && heads > 0 && d > 0 && d <= 128 && p > 0, "p4c_epa_small_bwd: head width 1..128 (got %d)", d);
+    const int ds = diag_only ? 1 : d;
+    if (d <= 64) {
+        constexpr int DM = 64;
+        const size_t smem = (2 * DM + 2 * DM * (DM + 1) + 3 * 256) * sizeof(float);
+        hipLaunchKernelGGL(ts::epa_small_bwd_kernel<DM>, dim3(B * heads), dim3(256), smem, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, nq, nk, dAt, dMq,
+                           dG, dGq, dGk, dKP, dt1_part, dt2_part, heads, d, p, ds);
+    } else {
+        constexpr int DM = 128;
+        const size_t smem = (2 * DM + 2 * DM * (DM + 1) + 3 * 256) * sizeof(float);
+        P4C_TRY(ensure_dyn_smem((const void*)ts::epa_small_bwd_kernel<DM>, (int)smem));
+        hipLaunchKernelGGL(ts::epa_small_bwd_kernel<DM>, dim3(B * heads), dim3(256), smem, as_stream(stream), G, Gq, Gk, KP, t1, t2, At, nq, nk, dAt, dMq,
+                           dG, dGq, dGk, dKP, dt1_part, dt2_part, heads, d, p, ds);
+    }
     P4C_CHECK_LAUNCH("p4c_epa_small_bwd");
     return P4C_OK;
 }

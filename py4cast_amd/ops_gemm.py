@@ -320,7 +320,7 @@ class _Conv(torch.autograd.Function):
     sums of y for a batch norm (not differentiable: the norm's backward accounts for them analytically)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, want_stats):
+    def forward(ctx, x, w, b, res, want_stats, passthrough=False):
         Co, Ci, k = w.shape[0], w.shape[1], w.shape[2]
         B, H, W_, Cx = x.shape
         taps = k * k
@@ -339,31 +339,36 @@ class _Conv(torch.autograd.Function):
         y = y.view(B, H, W_, Co)
         if want_stats:
             ctx.mark_non_differentiable(stats)
-            return y, stats
-        return y, None
+        # passthrough: x itself is one more output -- the tensor's OTHER consumers (a residual connection) take it from here, so their
+        # gradient arrives at this node and is added in the data gradient's epilogue instead of by a launch of autograd's
+        return y, (stats if want_stats else None), (x if passthrough else None)
 
     @staticmethod
-    def backward(ctx, dy, _dstats):
+    def backward(ctx, dy, _dstats, dpass):
         if dy is None:
-            return None, None, None, None, None
+            return dpass, None, None, None, None, None
         xm, dgr = ctx.saved_tensors
         B, H, W_, Cx, Co, Ci, taps = ctx.geom
         dy2 = _rows(dy, Co)
         dx = None
         if ctx.needs_input_grad[0]:
+            fold = dpass is not None and Cx == Ci and dpass.dtype == dy.dtype
+            r2 = _rows(dpass, Cx) if fold else None
             if taps == 9:
-                dx = gemm_nt(dy2, dgr, Ci, 9 * Co, conv=(H, W_, Co))[0]
+                dx = gemm_nt(dy2, dgr, Ci, 9 * Co, conv=(H, W_, Co), res=r2)[0]
             else:
-                dx = gemm_nt(dy2, dgr, Ci, Co)[0]
+                dx = gemm_nt(dy2, dgr, Ci, Co, res=r2)[0]
             if Cx > Ci:      # the map was wider than the weight's input channels (zero-padded rows): no gradient there
                 dx = torch.nn.functional.pad(dx, (0, Cx - Ci))
             dx = dx.view(B, H, W_, Cx)
+            if dpass is not None and not fold:
+                dx = dx + dpass
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = gemm_tn(dy2, xm, Co, Ci, conv=(H, W_) if taps == 9 else None, want_bias=ctx.has_bias, sink=ctx.sink)
             dw = None if dw is None else dw.view(ctx.wshape).to(ctx.wdtype)
             db = None if db is None else db.to(ctx.bdtype)
-        return dx, dw, db, (dy if ctx.has_res else None), None
+        return dx, dw, db, (dy if ctx.has_res else None), None, None
 
 
 def conv_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -372,13 +377,18 @@ def conv_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
             and x.shape[-1] >= w.shape[1] and x.shape[-1] % 8 == 0)
 
 
-def conv2d_nhwc(x, w, b=None, res=None, want_stats=False):
-    """3x3 "same" / 1x1 convolution of a features-last map; returns y, or (y, stats) with want_stats"""
+def conv2d_nhwc(x, w, b=None, res=None, want_stats=False, passthrough=False):
+    """3x3 "same" / 1x1 convolution of a features-last map; returns y, or (y, stats) with want_stats.  ``passthrough``: x is appended to
+    the results -- hand THAT tensor to the other consumers of x (a residual connection): their gradient is then added inside the data
+    gradient's epilogue."""
     L.require_cuda(x)
     if not conv_supported(x, w):
         raise L.P4CError(f"ops_gemm.conv2d_nhwc: unsupported operands (x {tuple(x.shape)} {x.dtype}, w {tuple(w.shape)} {w.dtype})")
-    y, stats = _Conv.apply(x, w, b, res, bool(want_stats))
-    return (y, stats) if want_stats else y
+    y, stats, xp = _Conv.apply(x, w, b, res, bool(want_stats), bool(passthrough))
+    out = (y, stats) if want_stats else (y,)
+    if passthrough:
+        out = out + (xp,)
+    return out if len(out) > 1 else y
 
 
 class _BatchNormAct(torch.autograd.Function):
@@ -386,7 +396,8 @@ class _BatchNormAct(torch.autograd.Function):
     partial sums (training) or the running statistics (eval); the streaming kernels of csrc/inorm.hip with the batch as ONE sample."""
 
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, res, running_mean, running_var, training, momentum, eps, slope, batches_tracked=None):
+    def forward(ctx, y, stats, gamma, beta, res, running_mean, running_var, training, momentum, eps, slope, batches_tracked=None,
+                res_passthrough=False):
         yc = y.contiguous()
         C = yc.shape[-1]
         N = yc.numel() // C
@@ -412,10 +423,15 @@ class _BatchNormAct(torch.autograd.Function):
         ctx.save_for_backward(yc, out, st)
         ctx.slope, ctx.has_res, ctx.training = float(slope), res is not None, bool(training)
         ctx.gdtype = None if gamma is None else gamma.dtype
-        return out
+        ctx.set_materialize_grads(False)
+        # res_passthrough: the residual operand is returned as a second output for ITS other consumers (see _Conv): their gradient
+        # arrives here and is added to the residual's gradient inside the backward apply launch
+        return out, (res if (res_passthrough and res is not None) else None)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dpass):
+        if dout is None:
+            return None, None, None, None, dpass, None, None, None, None, None, None, None, None
         yc, out, st = ctx.saved_tensors
         C = yc.shape[-1]
         N = yc.numel() // C
@@ -440,18 +456,23 @@ class _BatchNormAct(torch.autograd.Function):
             co.zero_()          # running statistics are constants: dy = scale * dz
         dy = torch.empty_like(yc)
         dres = torch.empty_like(yc) if ctx.has_res else None
-        L.call("p4c_inorm_apply", L.ptr(yc), None, L.ptr(dout), L.ptr(out), L.ptr(st[2]), None, L.ptr(st[0]), L.ptr(st[1]), L.ptr(co[0]),
+        fold = dpass is not None and ctx.has_res and dpass.dtype == yc.dtype
+        dadd = dpass.contiguous() if fold else None
+        L.call("p4c_inorm_apply", L.ptr(yc), L.ptr(dadd), L.ptr(dout), L.ptr(out), L.ptr(st[2]), None, L.ptr(st[0]), L.ptr(st[1]), L.ptr(co[0]),
                L.ptr(co[1]), ctx.slope, L.ptr(dy), L.ptr(dres), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev),
-               alg_bytes=yc.numel() * yc.element_size() * (4 + ctx.has_res))
+               alg_bytes=yc.numel() * yc.element_size() * (4 + ctx.has_res + fold))
+        if dpass is not None and not fold:
+            dres = dpass if dres is None else dres + dpass
         dg = None if ctx.gdtype is None else dgb[0].to(ctx.gdtype)
         db = None if ctx.gdtype is None else dgb[1].to(ctx.gdtype)
-        return dy, None, dg, db, dres, None, None, None, None, None, None, None
+        return dy, None, dg, db, dres, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=None):
+def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=None, res_passthrough=False):
     """``leaky_relu(bn(y) (+ res), slope)`` for a features-last y (B,H,W,C) and a torch.nn.BatchNorm2d module `bn` (its parameters,
     running statistics, momentum, eps and training flag); `stats`: the producer's column sums (conv2d_nhwc(..., want_stats=True)) or
-    None.  slope = 1: no activation."""
+    None.  slope = 1: no activation.  ``res_passthrough``: returns (out, res) -- hand that second tensor to the other consumers of the
+    residual operand, and their gradient is added inside this node's backward launch."""
     L.require_cuda(y)
     if y.dtype not in (torch.bfloat16, torch.float32) or y.shape[-1] % 4 or y.shape[-1] > 1024:
         raise L.P4CError(f"ops_gemm.batch_norm_act: unsupported map {tuple(y.shape)} {y.dtype}")
@@ -468,7 +489,9 @@ def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=N
         if nbt.dtype != torch.int64 or nbt.device != y.device:
             raise L.P4CError("ops_gemm.batch_norm_act: num_batches_tracked must be an int64 tensor on the map's device")
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BatchNormAct.apply(y, stats if training else None, bn.weight, bn.bias, res, rm, rv, training, mom, bn.eps, float(slope), nbt)
+    out, rp = _BatchNormAct.apply(y, stats if training else None, bn.weight, bn.bias, res, rm, rv, training, mom, bn.eps, float(slope), nbt,
+                                  bool(res_passthrough))
+    return (out, rp) if res_passthrough else out
 
 
 class _UpsampleAdd(torch.autograd.Function):

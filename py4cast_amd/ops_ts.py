@@ -16,6 +16,7 @@ def _strides(t: torch.Tensor):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
+APPLY_MAX_D = 256   # reduction width of one matrix-core apply launch (csrc/tallskinny.hip: p4c_ts_apply_wide_ok)
 MAXD = 64   # columns per kernel call (csrc/tallskinny.hip); wider operands (decoder heads of 128 channels) go in column chunks
 
 
@@ -119,12 +120,18 @@ def _stored_transposed(m: torch.Tensor):
     return None
 
 
-def _apply_call(x, m, ov, B, H, N, d, e, accumulate):
+def _apply_call(x, m, ov, B, H, N, d, e, accumulate, m_gs=None):
     """out (+)= x @ m on the matrix-core kernel; a transposed view of a stored matrix is read as stored (p4c_ts_apply_mt), anything
-    else is made contiguous first"""
+    else is made contiguous first.  m_gs: m is a block of d consecutive ROWS of each group's dense fp32 matrix, the groups m_gs
+    elements apart (a chunk of a wider matrix: read in place)."""
     args_x = (L.ptr(x), L.dtype_code(x.dtype), *_strides(x))
     args_o = (L.ptr(ov), L.dtype_code(ov.dtype), *_strides(ov))
     nbytes = B * H * N * (d * x.element_size() + e * ov.element_size() * (1 + int(accumulate)))
+    if m_gs is not None:
+        if m.dtype != torch.float32 or m.stride(-1) != 1 or m.stride(-2) != e:
+            raise L.P4CError("ops_ts._apply_call: a row block of dense fp32 matrices expected")
+        L.call("p4c_ts_apply", *args_x, L.ptr(m), m_gs, *args_o, B, H, N, d, e, int(accumulate), L.stream(x.device), alg_bytes=nbytes)
+        return
     mt = _stored_transposed(m)
     if mt is not None and L.lib().p4c_ts_apply_mt_ok(*args_x, L.ptr(mt), d * e, *args_o, d, e):
         L.call("p4c_ts_apply_mt", *args_x, L.ptr(mt), d * e, *args_o, B, H, N, d, e, int(accumulate), L.stream(x.device), alg_bytes=nbytes)
@@ -376,7 +383,7 @@ def _two_eye(d: int, device) -> torch.Tensor:
 
 class _EpaCore(torch.autograd.Function):
     """The whole efficient paired attention between the qkvv projection and the two output projections as ONE autograd node
-    (bf16 flavour, d, p <= 64): qkvv (B, N, 4, heads, d) -> (x_sa, x_ca), both (B, heads, N, d) token-major.  The pieces are the
+    (bf16 flavour, d <= 128, p <= 64): qkvv (B, N, 4, heads, d) -> (x_sa, x_ca), both (B, heads, N, d) token-major.  The pieces are the
     kernels of this module (gram with norms, the small-matrix kernel, apply, apply with the softmax epilogues) and the library GEMM of
     the token-axis projection E; what the node adds is the BACKWARD's bookkeeping: dq, dk, dv_ca, dv_sa are written straight into one
     (B, N, 4, heads, d) gradient by accumulating applies -- through separate nodes autograd added q's and k's two contributions each
@@ -479,7 +486,10 @@ class _EpaCore(torch.autograd.Function):
             Wv = Wm.view(1, 1, N, p).expand(2, B, N, p)
             _apply_call(Wv, g.transpose(-1, -2), _kv_view(dqkvv), 2, B, N, p, C, False)
             prod = torch.empty(2, B, N, p, dtype=torch.float32, device=dev)
-            _apply_call(_kv_view(qkvv), g, prod, 2, B, N, C, p, False)
+            Xkv = _kv_view(qkvv)
+            for c0 in range(0, C, APPLY_MAX_D):       # (the apply kernel reduces over <= 256 columns per launch: wider rows in chunks)
+                c1 = min(c0 + APPLY_MAX_D, C)
+                _apply_call(Xkv[..., c0:c1], g[:, :, c0:c1], prod, 2, B, N, c1 - c0, p, c0 > 0, m_gs=C * p)
             if ctx.wsink is not None:
                 out, acc = ctx.wsink[0], 1
             else:
@@ -525,22 +535,24 @@ def _gram_partial(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 def _token_proj_native(qkvv: torch.Tensor, p: int) -> bool:
     """EPA's token-axis projection and its adjoints on the tall-skinny kernels, k / v_sa read in place (see _EpaCore): bf16, all heads'
-    channels of a token as one row (C = heads x d <= 256 for the weight gradient's apply).  ``P4C_EPA_LIB_PROJ=1`` (diagnostic
+    channels of a token as one row (the weight gradient's apply in chunks of 256 channels).  ``P4C_EPA_LIB_PROJ=1`` (diagnostic
     library) keeps the gather + library GEMM route of rounds 3-5 for A/B runs."""
     B, N, _, H, d = qkvv.shape
     C = H * d
-    if L.diag_switch("P4C_EPA_LIB_PROJ") == "1" or C > 256 or C % 8 or p % 8 or p > 64:
+    if L.diag_switch("P4C_EPA_LIB_PROJ") == "1" or C % 8 or p % 8 or p > 64 or (C > APPLY_MAX_D and C % APPLY_MAX_D):
         return False
     lib, bf, f32 = L.lib(), L.dtype_code(torch.bfloat16), L.dtype_code(torch.float32)
-    return bool(lib.p4c_ts_gram_wide_ok(bf, bf, C, p) and lib.p4c_ts_apply_wide_ok(bf, bf, p, C) and lib.p4c_ts_apply_wide_ok(bf, f32, C, p))
+    return bool(lib.p4c_ts_gram_wide_ok(bf, bf, C, p) and lib.p4c_ts_apply_wide_ok(bf, bf, p, C)
+                and lib.p4c_ts_apply_wide_ok(bf, f32, min(C, APPLY_MAX_D), p))
 
 
 def epa_core_ok(qkvv: torch.Tensor, p: int) -> bool:
-    """bf16 qkvv (B, N, 4, heads, d) with d, p multiples of 8 up to 64 and 16-byte aligned head rows."""
+    """bf16 qkvv (B, N, 4, heads, d) with d a multiple of 8 up to 128 (8, 16, 32, 64, 128), p a multiple of 8 up to 64 and 16-byte aligned
+    head rows."""
     if qkvv.dim() != 5 or qkvv.dtype != torch.bfloat16 or not qkvv.is_contiguous():
         return False
     d = qkvv.shape[-1]
-    return d % 8 == 0 and p % 8 == 0 and d <= 64 and p <= 64 and 64 % (d // 8) == 0 and spatial_fused_ok(qkvv[:, :, 0].permute(0, 2, 1, 3), p)
+    return d % 8 == 0 and p % 8 == 0 and d <= 128 and p <= 64 and 64 % (d // 8) == 0 and spatial_fused_ok(qkvv[:, :, 0].permute(0, 2, 1, 3), p)
 
 
 def epa_core(qkvv, W, bias, t1, t2):

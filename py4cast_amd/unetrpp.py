@@ -188,7 +188,16 @@ class ResBlock(nn.Module):
             self.conv3 = nn.Conv2d(cin, cout, 1, bias=False)
             self.norm3 = _norm(norm, cout)
 
-    def forward(self, x):
+    def forward(self, x, pass_input=False):
+        """``pass_input``: returns (out, x') with x' the input as handed on by this block's last consumer of it (features-last) -- a
+        caller that uses x once more (the transformer block's skip) takes x' and its gradient is added inside this block's backward
+        launches; x' is None when the block ran on a route without that (the caller then uses its own tensor)."""
+        out = self._forward(x, pass_input)
+        if pass_input:
+            return out if isinstance(out, tuple) else (out, None)
+        return out
+
+    def _forward(self, x, pass_input=False):
         # (the norms act on the convolutions' OUTPUT channels: encoder1's 69-channel input is no obstacle)
         cout = self.conv1.weight.shape[0]
         if (isinstance(self.norm1, nn.InstanceNorm2d) and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
@@ -203,15 +212,25 @@ class ResBlock(nn.Module):
                 and G.conv_supported(x.permute(0, 2, 3, 1), self.conv1.weight) and cout % 8 == 0 and cout <= 1024):
             # the 128 ... 1024-channel blocks of the transformer stages: implicit-GEMM convolutions whose drain leaves the batch-norm
             # sums, BatchNorm2d + LeakyReLU (+ residual) as one streaming node each way (ops_gemm: csrc/gemm.hip + csrc/inorm.hip)
+            # x has two consumers here (conv1 and the residual path) and, with pass_input, one more in the caller: each consumer hands
+            # the tensor on to the next (`passthrough`), so the gradients meet inside the backward launches of this chain -- the residual's
+            # in the batch-norm backward, the sum in conv1's data gradient -- instead of in element-wise additions of autograd (round 6)
             xl = x.permute(0, 2, 3, 1)
-            y1, st1 = G.conv2d_nhwc(xl, self.conv1.weight, want_stats=True)
+            y1, st1, xp = G.conv2d_nhwc(xl, self.conv1.weight, want_stats=True, passthrough=True)
             a1 = G.batch_norm_act(y1, st1, self.norm1, 0.01)
             y2, st2 = G.conv2d_nhwc(a1, self.conv2.weight, want_stats=True)
-            rl = xl
             if self.down:
-                y3, st3 = G.conv2d_nhwc(xl, self.conv3.weight, want_stats=True)
+                if pass_input:
+                    y3, st3, xp = G.conv2d_nhwc(xp, self.conv3.weight, want_stats=True, passthrough=True)
+                else:
+                    y3, st3 = G.conv2d_nhwc(xp, self.conv3.weight, want_stats=True)
                 rl = G.batch_norm_act(y3, st3, self.norm3, 1.0)
-            return G.batch_norm_act(y2, st2, self.norm2, 0.01, rl).permute(0, 3, 1, 2)
+                out = G.batch_norm_act(y2, st2, self.norm2, 0.01, rl)
+            elif pass_input:
+                out, xp = G.batch_norm_act(y2, st2, self.norm2, 0.01, xp, res_passthrough=True)
+            else:
+                out = G.batch_norm_act(y2, st2, self.norm2, 0.01, xp)
+            return (out.permute(0, 3, 1, 2), xp) if pass_input else out.permute(0, 3, 1, 2)
         r = x
         y = F.leaky_relu(_nrm(self.norm1, _conv(self.conv1, x)), 0.01)
         y = _nrm(self.norm2, _conv(self.conv2, y))
@@ -386,7 +405,12 @@ class TransformerBlock(nn.Module):
             t, ln = R.add_layer_norm(xl.reshape(B, H * W, C), self.pos_embed, self.norm.weight, self.norm.bias, self.norm.eps)
             t = self.epa_block(ln, res=t, gamma=self.gamma)
             skip = t.reshape(B, H, W, C)
-            r = self._conv8_in(self.conv51(skip.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+            if isinstance(self.conv51, ResBlock):
+                r, handed = self.conv51(skip.permute(0, 3, 1, 2), pass_input=True)     # (skip comes back from its consumers inside conv51)
+                skip = skip if handed is None else handed
+            else:
+                r = self.conv51(skip.permute(0, 3, 1, 2))
+            r = self._conv8_in(r).permute(0, 2, 3, 1)
             if G.conv_supported(r, conv8.weight) and r.is_contiguous():
                 return G.conv2d_nhwc(r, conv8.weight, conv8.bias, res=skip).permute(0, 3, 1, 2)
             return (skip + _conv(conv8, r.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)).permute(0, 3, 1, 2)

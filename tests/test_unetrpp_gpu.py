@@ -417,7 +417,8 @@ def test_unetrpp_takes_its_input_straight_from_build_x(gpu_device):
     assert cos > 0.999, cos
 
 
-@pytest.mark.parametrize("N,hidden,heads,proj", [(256, 64, 4, 16), (1024, 128, 16, 64), (4096, 128, 4, 32), (16384, 128, 16, 64), (4096, 256, 16, 64)])
+@pytest.mark.parametrize("N,hidden,heads,proj", [(256, 64, 4, 16), (1024, 128, 16, 64), (4096, 128, 4, 32), (16384, 128, 16, 64), (4096, 256, 16, 64),
+                                                 (1024, 512, 4, 64), (256, 1024, 16, 32)])     # (128-wide heads; 512 / 1024 channels per token)
 def test_epa_core_as_one_node(gpu_device, monkeypatch, diag_library, N, hidden, heads, proj):
     """The attention between the projections as ONE autograd node (ops_ts.epa_core: dq / dk / dv written straight into the gradient of
     the qkvv projection) against the same module composed of separate nodes: identical output (same kernels, same order), gradients
@@ -441,7 +442,9 @@ def test_epa_core_as_one_node(gpu_device, monkeypatch, diag_library, N, hidden, 
         out[flag] = (y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in m.named_parameters()})
     (ya, xa, ga), (yb, xb, gb) = out["1"], out["0"]
     print("epa_core vs composed: output", _rel(ya, yb), "dx", _rel(xa, xb), {n: round(_rel(ga[n], gb[n]), 5) for n in ga})
-    assert _rel(ya, yb) < 2e-3
+    # (128-wide heads: the composed module has no fused small-matrix node there -- its norms, softmax and scalings are separate bf16 /
+    #  fp32 tensor-library ops, i.e. other roundings than the node's fp32 kernel)
+    assert _rel(ya, yb) < (2e-3 if hidden // heads <= 64 else 5e-3)
     assert _rel(xa, xb) < 2e-2
     for n in ga:
         assert _rel(ga[n], gb[n]) < 2e-2, n
