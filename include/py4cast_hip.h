@@ -564,6 +564,9 @@ int p4c_row_add_layernorm_fwd(const void* x, const void* add, int64_t add_rows, 
 size_t p4c_row_add_layernorm_bwd_workspace_bytes(int64_t R, int C);
 int p4c_row_add_layernorm_bwd(const void* dy, const void* t, const void* extra, const float* gamma, float eps, void* dt, float* dgamma,
                               float* dbeta, void* workspace, int64_t R, int C, int dtype, p4c_stream_t stream);
+/* out (n, fp32) (+)= sum over the nb slices of x (nb x n, fp32 or bf16), n a multiple of 4: the gradient of the `add` table of
+ * p4c_row_add_layernorm_fwd (broadcast over the samples), written -- with accumulate -- straight into the parameter's gradient. */
+int p4c_sum_leading(const void* x, int dtype, int nb, int64_t n, float* out, int accumulate, p4c_stream_t stream);
 /* Weight and bias gradient of y = x W^T + b over R >> O rows:  dw_db[0 .. O*K) = dW[o][k] = sum_r dy[r][o] x[r][k],
  * dw_db[O*K .. O*K+O) = db[o] = sum_r dy[r][o]  (fp32, overwritten).  O = 64, K a multiple of 16 up to 128, bf16 rows
  * (bf16 matrix cores, fp32 accumulation, fixed reduction order).  workspace: p4c_row_linear_wgrad_workspace_bytes(R, K). */

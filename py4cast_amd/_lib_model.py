@@ -88,6 +88,7 @@ SIGNATURES = {
     "p4c_window_attn_bwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
     "p4c_row_add_layernorm_fwd": [P, P, L, P, P, F, P, P, L, I, I, P],
     "p4c_row_add_layernorm_bwd": [P, P, P, P, F, P, P, P, P, L, I, I, P],
+    "p4c_sum_leading": [P, I, I, L, P, I, P],
     "p4c_upsample_bilinear_fwd": [P, P, P, I, I, I, I, I, P],
     "p4c_upsample_bilinear_bwd": [P, P, I, I, I, I, I, P],
     "p4c_gemm_prep_weight": [P, I, I, I, P, P, P],

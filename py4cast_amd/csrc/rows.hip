@@ -395,6 +395,55 @@ __global__ void __launch_bounds__(256) row_param_reduce_kernel(const float* __re
     }
 }
 
+// The same sum for n % 4 == 0 with more loads in flight (round 6): with 2 048 slots (the add + LayerNorm backward of 32 768 token rows)
+// a thread of the kernel above walks 256 slots in 64 dependent rounds -- 15 us for 2 MB of L2-resident partials, 126 times per UNETR++
+// step.  Here a block owns 32 outputs as 8 quads x 32 slot lanes, a lane takes the slots s = lane (mod 32) eight 16-byte loads at a
+// time, the 32 lanes' sums are added in lane order through LDS (fixed order: bit-identical reruns).
+__global__ void __launch_bounds__(256) row_param_reduce4_kernel(const float* __restrict__ partial, int slots, int n, float* __restrict__ out) {
+    __shared__ p4c_f32x4 red[32][8];
+    const int q = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int j = blockIdx.x * 32 + 4 * q;
+    p4c_f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (j < n) {
+        const float* p = partial + j;
+        int s = sl;
+        for (; s + 7 * 32 < slots; s += 8 * 32) {
+            p4c_f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const p4c_f32x4*>(p + (int64_t)(s + 32 * u) * n);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a0[k] += v[u][k]; a1[k] += v[u + 1][k]; }
+        }
+        for (; s < slots; s += 32) {
+            const p4c_f32x4 v = *reinterpret_cast<const p4c_f32x4*>(p + (int64_t)s * n);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a0[k] += v[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a0[k] += a1[k];
+    red[sl][q] = a0;
+    __syncthreads();
+    if (sl == 0 && j < n) {
+        p4c_f32x4 t = red[0][q];
+        for (int r = 1; r < 32; ++r) {
+            const p4c_f32x4 v = red[r][q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += v[k];
+        }
+        *reinterpret_cast<p4c_f32x4*>(out + j) = t;
+    }
+}
+
+static void launch_row_param_reduce(const float* partial, int slots, int n, float* out, hipStream_t s) {
+    if (n % 4 == 0 && slots >= 64 && (reinterpret_cast<uintptr_t>(partial) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+        hipLaunchKernelGGL(row_param_reduce4_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, slots, n, out);
+    else
+        hipLaunchKernelGGL(row_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, slots, n, out);
+}
+
 // ---------------------------------------------------------------- tall-skinny weight gradient
 // dW[o][k] = sum_r dY[r][o] X[r][k]  (O = 64, K = 16 * KS16 <= 128), db[o] = sum_r dY[r][o];  bf16 rows.
 // A wave stages tiles of 64 rows of dY ([row][64]) and X ([row][K]) into its own LDS images (16-byte coalesced loads, rows
@@ -576,6 +625,22 @@ int launch_wgrad(const void* dy, const void* x, float* partial, int64_t R, int G
     return P4C_OK;
 }
 
+// out (n fp32) (+)= sum over the nb slices of x (nb x n): the gradient of a table that was broadcast over the samples (UNETR++'s position
+// embedding: t = x + pos), added straight into the parameter's .grad -- the tensor library summed into a fresh tensor that autograd then
+// added to the gradient in a second pass.
+template <typename T>
+__global__ void __launch_bounds__(256) sum_leading_kernel(const T* __restrict__ x, int nb, int64_t n, float* __restrict__ out, int accumulate) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    p4c_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) acc = load4f(out + i);
+    for (int b = 0; b < nb; ++b) {
+        const p4c_f32x4 v = load4f(x + (int64_t)b * n + i);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    store4f(out + i, acc);
+}
+
 }  // namespace
 }  // namespace p4c
 
@@ -646,7 +711,7 @@ extern "C" int p4c_row_layernorm_bwd_masked(const void* dy, const void* x, const
         hipLaunchKernelGGL(row_layernorm_bwd_kernel<bf16>, dim3(G), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, eps,
                            (bf16*)dx, partial, R, C, lpr_log2, mk);
     P4C_CHECK_LAUNCH("row_layernorm_bwd");
-    hipLaunchKernelGGL(row_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, partial, G, 2 * C, dgamma);
+    launch_row_param_reduce(partial, G, 2 * C, dgamma, s);
     P4C_CHECK_LAUNCH("row_param_reduce");
     return P4C_OK;
 }
@@ -705,7 +770,7 @@ extern "C" int p4c_row_add_layernorm_bwd(const void* dy, const void* t, const vo
     else { if (nch == 2) P4C_LAUNCH_ALNB(bf16, 2); else P4C_LAUNCH_ALNB(bf16, 1); }
 #undef P4C_LAUNCH_ALNB
     P4C_CHECK_LAUNCH("row_add_layernorm_bwd");
-    hipLaunchKernelGGL(row_param_reduce_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, partial, G, 2 * C, dgamma);
+    launch_row_param_reduce(partial, G, 2 * C, dgamma, s);
     P4C_CHECK_LAUNCH("row_param_reduce");
     return P4C_OK;
 }
@@ -738,7 +803,18 @@ extern "C" int p4c_row_linear_wgrad(const void* dy, const void* x, float* dw_db,
     }
     if (rc != P4C_OK) return rc;
     const int n = 64 * K + 64;
-    hipLaunchKernelGGL(row_param_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, partial, G, n, dw_db);
+    launch_row_param_reduce(partial, G, n, dw_db, s);
     P4C_CHECK_LAUNCH("row_param_reduce");
+    return P4C_OK;
+}
+
+
+extern "C" int p4c_sum_leading(const void* x, int dtype, int nb, int64_t n, float* out, int accumulate, p4c_stream_t stream) {
+    P4C_CHECK_ARG(x && out && nb > 0 && n > 0 && n % 4 == 0 && (dtype == P4C_F32 || dtype == P4C_BF16), "p4c_sum_leading: bad arguments");
+    P4C_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "p4c_sum_leading: unaligned buffers");
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
+    if (dtype == P4C_F32) hipLaunchKernelGGL(sum_leading_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)x, nb, n, out, accumulate);
+    else hipLaunchKernelGGL(sum_leading_kernel<bf16>, dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16*)x, nb, n, out, accumulate);
+    P4C_CHECK_LAUNCH("p4c_sum_leading");
     return P4C_OK;
 }

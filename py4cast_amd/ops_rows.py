@@ -548,6 +548,16 @@ class _AddLayerNorm(torch.autograd.Function):
         ctx.save_for_backward(t, g)
         ctx.eps, ctx.shape, ctx.arows = float(eps), x.shape, arows
         ctx.dtypes = (gamma.dtype, None if add is None else add.dtype, None if add is None else add.shape)
+        # the table's gradient goes straight into its .grad buffer when that exists (FlatDDP / the trainer allocate them), as ops_gemm's
+        # weight gradients do: one pass over dt instead of the tensor library's sum into a fresh tensor + autograd's accumulation
+        ctx.asink = None
+        if add is not None and add.requires_grad and (R * C) % 4 == 0:
+            from . import ops_gemm as G
+
+            if G.GRADS_IN_PLACE:
+                gv = grad_view(add)
+                if gv is not None and gv is not False and gv.is_contiguous():
+                    ctx.asink = gv
         return t.view(x.shape), ln.view(x.shape)
 
     @staticmethod
@@ -563,7 +573,11 @@ class _AddLayerNorm(torch.autograd.Function):
                R, C, L.dtype_code(t.dtype), L.stream(t.device), alg_bytes=R * C * t.element_size() * (3 + (extra is not None)))
         gdt, adt, ashape = ctx.dtypes
         dadd = None
-        if ctx.arows:
+        if ctx.arows and ctx.asink is not None:
+            L.call("p4c_sum_leading", L.ptr(dt), L.dtype_code(dt.dtype), R // ctx.arows, ctx.arows * C, L.ptr(ctx.asink), 1, L.stream(t.device),
+                   alg_bytes=R * C * dt.element_size() + 8 * ctx.arows * C)
+            L.grad_written(ctx.asink)
+        elif ctx.arows:
             dadd = dt.view(-1, ctx.arows, C).sum(dim=0, dtype=torch.float32).to(adt).view(ashape)
         return dt.view(ctx.shape), dadd, dgb[0].to(gdt), dgb[1].to(gdt), None
 

@@ -77,3 +77,35 @@ def test_published_merge_is_the_permute_reshape_of_the_published_code(gpu_device
     ref.backward(w)
     assert torch.equal(x_sa.grad, ref_in.grad)
     assert x_sa.grad.stride(3) == 1 or x_sa.grad.shape[3] == 1              # handed back token-major: the block's backward reads it in place
+
+
+def test_add_layer_norm_table_gradient_goes_into_its_grad_buffer(gpu_device):
+    """ops_rows.add_layer_norm: with a gradient buffer on the table (position embedding) its gradient -- the sum of dt over the samples --
+    is ADDED into that buffer by one native pass (p4c_sum_leading); without one it comes back through autograd.  Same numbers."""
+    from py4cast_amd import ops_rows as R
+
+    torch.manual_seed(3)
+    B, N, C = 2, 1024, 128
+    x = torch.randn(B, N, C, device=gpu_device).to(torch.bfloat16)
+    pos = torch.nn.Parameter(torch.randn(1, N, C, device=gpu_device) * 0.1)
+    gamma = torch.nn.Parameter(torch.rand(C, device=gpu_device) + 0.5)
+    beta = torch.nn.Parameter(torch.randn(C, device=gpu_device) * 0.1)
+    w1 = torch.randn(B, N, C, device=gpu_device).to(torch.bfloat16)
+    w2 = torch.randn(B, N, C, device=gpu_device).to(torch.bfloat16)
+
+    def run():
+        t, ln = R.add_layer_norm(x, pos, gamma, beta, 1e-5)
+        ((t * w1).float().sum() + (ln * w2).float().sum()).backward()
+
+    run()                                   # no buffers yet: through autograd
+    ref = pos.grad.clone()
+    assert float(ref.abs().max()) > 0
+    run()                                   # buffers exist: added in place
+    torch.testing.assert_close(pos.grad, 2 * ref, rtol=1e-6, atol=1e-6)
+    # and the reference itself against the tensor library on the same bf16 dt
+    xr = x.detach().clone().requires_grad_(True)
+    t = xr + pos.detach().to(torch.bfloat16)
+    ln = torch.nn.functional.layer_norm(t.float(), (C,), gamma.detach(), beta.detach(), 1e-5).to(torch.bfloat16)
+    ((t * w1).float().sum() + (ln * w2).float().sum()).backward()
+    cos = torch.nn.functional.cosine_similarity(ref.flatten(), xr.grad.float().sum(0).flatten(), dim=0)
+    assert float(cos) > 0.999

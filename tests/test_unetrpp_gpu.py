@@ -442,9 +442,9 @@ def test_epa_core_as_one_node(gpu_device, monkeypatch, diag_library, N, hidden, 
         out[flag] = (y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in m.named_parameters()})
     (ya, xa, ga), (yb, xb, gb) = out["1"], out["0"]
     print("epa_core vs composed: output", _rel(ya, yb), "dx", _rel(xa, xb), {n: round(_rel(ga[n], gb[n]), 5) for n in ga})
-    # (128-wide heads: the composed module has no fused small-matrix node there -- its norms, softmax and scalings are separate bf16 /
-    #  fp32 tensor-library ops, i.e. other roundings than the node's fp32 kernel)
-    assert _rel(ya, yb) < (2e-3 if hidden // heads <= 64 else 5e-3)
+    # (round 6: the node's token-axis projection accumulates and adds its bias in fp32 -- the composed module's is the library's bf16
+    #  GEMM result; with 128-wide heads the composed module has no fused small-matrix node either: other roundings, not other kernels)
+    assert _rel(ya, yb) < 5e-3
     assert _rel(xa, xb) < 2e-2
     for n in ga:
         assert _rel(ga[n], gb[n]) < 2e-2, n
@@ -465,7 +465,8 @@ def test_epa_core_as_one_node(gpu_device, monkeypatch, diag_library, N, hidden, 
     gl = {n: p.grad.float().clone() for n, p in m.named_parameters()}
     print("native vs library projection: output", _rel(ya, y.detach().float()), "dx", _rel(xa, x.grad.float()),
           {n: round(_rel(ga[n], gl[n]), 5) for n in ga})
-    assert _rel(ya, y.detach().float()) < 2e-3 and _rel(xa, x.grad.float()) < 2e-2
+    # (the library route rounds KP / VP to bf16 -- the GEMM's output type -- before the small-matrix kernel reads them: 2^-9 per element)
+    assert _rel(ya, y.detach().float()) < 5e-3 and _rel(xa, x.grad.float()) < 2e-2
     for n in ga:
         assert _rel(ga[n], gl[n]) < 2e-2, n
     monkeypatch.delenv("P4C_EPA_LIB_PROJ")
