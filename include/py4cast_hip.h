@@ -784,6 +784,17 @@ int p4c_inorm_reduce(const void* x, const void* dy, const void* y, const float* 
 int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
                     const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres, int dtype,
                     int B, int64_t N, int C, p4c_stream_t stream);
+/* (dy != NULL, res != NULL: res is a gradient that reached the residual operand by another path; dres = dz + res.)
+ * The same two passes with a MULTIPLIER behind the activation (round 6): out = lrelu((x * scale + shift (+ res)) * m), m =
+ * mul[(row / mul_rows)][c] * mul_factor >= 0 (fp32 table, C per row group): the channel dropout in front of UNETR++'s conv8 (mfai's
+ * `nn.Sequential(nn.Dropout2d(0.1), nn.Conv2d(...))`: mul = the Bernoulli draw per (sample, channel), mul_rows = H * W, mul_factor =
+ * 1 / (1 - p)) applied by the batch norm + LeakyReLU pass that produces the convolution's input; backward: dz = dy * lrelu' * m in the
+ * sums (p4c_inorm_reduce_mul, dy != NULL) and in the apply pass.  mul_rows must divide N. */
+int p4c_inorm_reduce_mul(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope, float* partial,
+                         int dtype, int B, int64_t N, int C, const float* mul, int64_t mul_rows, float mul_factor, p4c_stream_t stream);
+int p4c_inorm_apply_mul(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
+                        const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres, int dtype,
+                        int B, int64_t N, int C, const float* mul, int64_t mul_rows, float mul_factor, p4c_stream_t stream);
 
 /* p4c_inorm_reduce with the finalize INSIDE the launch (round 6): the workgroup that draws the last ticket turns the partial sums of all
  * samples into the statistics, exactly as p4c_inorm_finalize_fwd / _bwd would (same summation order: bit-identical) -- one dependent

@@ -72,6 +72,8 @@ OTHER = {
     "p4c_inorm_blocks": ([L, I], c_int),
     "p4c_inorm_reduce": ([P, P, P, P, P, F, P, I, I, L, I, P], c_int),
     "p4c_inorm_apply": ([P, P, P, P, P, P, P, P, P, P, F, P, P, I, I, L, I, P], c_int),
+    "p4c_inorm_apply_mul": ([P, P, P, P, P, P, P, P, P, P, F, P, P, I, I, L, I, P, L, F, P], c_int),
+    "p4c_inorm_reduce_mul": ([P, P, P, P, P, F, P, I, I, L, I, P, L, F, P], c_int),
     "p4c_inorm_finalize_fwd": ([P, I, I, L, I, I, P, P, F, P, P, P, P, P], c_int),
     "p4c_inorm_reduce_finalize_fwd": ([P, P, P, P, P, F, P, P, P, P, I, I, L, I, P], c_int),
     "p4c_inorm_reduce_finalize_bwd": ([P, P, P, P, P, F, P, P, P, P, P, P, I, I, L, I, P], c_int),

@@ -12,6 +12,22 @@ namespace inorm {
 __device__ __forceinline__ p4c_f32x4 ld4(const float* p) { return *reinterpret_cast<const p4c_f32x4*>(p); }
 __device__ __forceinline__ p4c_f32x4 ld4(const bf16* p) { return load4f(p); }
 
+// A multiplier per (row group, channel) behind the activation (round 6): out = lrelu((x * scale + shift + res) * m[p / rows][c] * factor).
+// The channel dropout in front of UNETR++'s conv8 (mfai's `Sequential(Dropout2d(0.1), Conv2d)`: m = the Bernoulli draw per (sample,
+// channel), factor = 1 / (1 - p)) rides in the batch norm + LeakyReLU passes that produce the convolution's input -- a full-size
+// multiplication each way before.  m >= 0, so lrelu(z) m = lrelu(z m) and the saved output still tells the sign of z where m > 0;
+// where m = 0 every gradient through the element is 0.  base == nullptr: no multiplier.
+struct PostMul {
+    const float* base;
+    int64_t rows;         // rows of a (batch-as-one-sample) map that share a multiplier row: H * W of the real samples
+    float factor;
+    __device__ __forceinline__ p4c_f32x4 at(int64_t p, int C, int c) const {
+        if (!base) return p4c_f32x4{1.f, 1.f, 1.f, 1.f};
+        const p4c_f32x4 v = *reinterpret_cast<const p4c_f32x4*>(base + (p / rows) * C + c);
+        return p4c_f32x4{v[0] * factor, v[1] * factor, v[2] * factor, v[3] * factor};
+    }
+};
+
 // Finalize INSIDE the reduce launch (round 6): the workgroup that draws the last ticket turns the partials of all samples into the
 // statistics -- what p4c_inorm_finalize_fwd / _bwd do in a launch of their own (a dependent 5-8 us launch per normalisation each way:
 // ~160 per SwinUNETR training step, the finalize launches of UNETR++'s full-resolution blocks and batch norms).  Instance form only
@@ -38,7 +54,7 @@ __device__ void finalize_in_kernel(const InFin& f, bool bwd, const float* partia
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, float slope,
-                                                     float* __restrict__ partial, int64_t N, int C, InFin fin) {
+                                                     float* __restrict__ partial, int64_t N, int C, InFin fin, PostMul pm) {
     extern __shared__ float red[];              // [rows][2][C]  (>= 2048 floats: the in-kernel finalize reuses it)
     const int b = blockIdx.y, cqn = C >> 2;
     const int rows = 256 / cqn > 0 ? 256 / cqn : 1;
@@ -58,9 +74,10 @@ __global__ void __launch_bounds__(256) reduce_kernel(const T* __restrict__ x, co
                     for (int k = 0; k < 4; ++k) { s1[k] += xv[k]; s2[k] = __builtin_fmaf(xv[k], xv[k], s2[k]); }
                 } else {
                     const p4c_f32x4 g = ld4(dyb + p * C + 4 * q), yv = ld4(yb + p * C + 4 * q);
+                    const p4c_f32x4 pv = pm.at(p, C, 4 * q);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float dz = yv[k] > 0.f ? g[k] : g[k] * slope;
+                        const float dz = (yv[k] > 0.f ? g[k] : g[k] * slope) * pv[k];
                         s1[k] += dz;
                         s2[k] = __builtin_fmaf(dz, (xv[k] - mu[k]) * rs[k], s2[k]);
                     }
@@ -96,7 +113,7 @@ __global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, con
                                                     const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ m1,
                                                     const float* __restrict__ m2, float slope, T* __restrict__ out, T* __restrict__ dres,
-                                                    int64_t N, int C) {
+                                                    int64_t N, int C, PostMul pm) {
     const int b = blockIdx.y, cqn = C >> 2;
     const int64_t total = N * cqn;
     const int64_t base = (int64_t)b * N * C;
@@ -104,6 +121,7 @@ __global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, con
         const int q = (int)(i % cqn);
         const int64_t off = base + (i / cqn) * C + 4 * q;
         const p4c_f32x4 xv = ld4(x + off);
+        const p4c_f32x4 pv = pm.at(i / cqn, C, 4 * q);
         p4c_f32x4 o;
         if (MODE == 0) {
             const p4c_f32x4 sc = ld4(scale + b * C + 4 * q), sh = ld4(shift + b * C + 4 * q);
@@ -115,7 +133,10 @@ __global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, con
                 for (int k = 0; k < 4; ++k) o[k] += rv[k];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : o[k] * slope;
+            for (int k = 0; k < 4; ++k) {
+                o[k] *= pv[k];
+                o[k] = o[k] > 0.f ? o[k] : o[k] * slope;
+            }
             store4f(out + off, o);
         } else {
             const p4c_f32x4 g = ld4(dy + off), yv = ld4(y + off);
@@ -126,13 +147,13 @@ __global__ void __launch_bounds__(256) apply_kernel(const T* __restrict__ x, con
                 const p4c_f32x4 rs = ld4(rstd + b * C + 4 * q);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    dz[k] = yv[k] > 0.f ? g[k] : g[k] * slope;
+                    dz[k] = (yv[k] > 0.f ? g[k] : g[k] * slope) * pv[k];
                     o[k] = sc[k] * (dz[k] - a1[k] - (xv[k] - mu[k]) * rs[k] * a2[k]);
                 }
             } else {   // MODE 2: the caller's coefficients as they are (group norm: statistics shared by the channels of a group)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    dz[k] = yv[k] > 0.f ? g[k] : g[k] * slope;
+                    dz[k] = (yv[k] > 0.f ? g[k] : g[k] * slope) * pv[k];
                     o[k] = sc[k] * dz[k] - a1[k] - (xv[k] - mu[k]) * a2[k];
                 }
             }
@@ -317,7 +338,8 @@ extern "C" int p4c_inorm_blocks(int64_t N, int C) {
 }
 
 static int inorm_reduce_launch(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope, float* partial,
-                               int dtype, int B, int64_t N, int C, const inorm::InFin& fin, p4c_stream_t stream) {
+                               int dtype, int B, int64_t N, int C, const inorm::InFin& fin, p4c_stream_t stream,
+                               const inorm::PostMul& pm = inorm::PostMul{nullptr, 1, 1.f}) {
     P4C_CHECK_ARG(x && partial && B > 0 && N > 0 && C > 0 && C % 4 == 0 && C <= 1024, "p4c_inorm_reduce: C must be a multiple of 4 up to 1024");
     const bool bwd = dy != nullptr;
     P4C_CHECK_ARG(!bwd || (y && mean && rstd), "p4c_inorm_reduce: the backward sums need y, mean and rstd");
@@ -330,7 +352,7 @@ static int inorm_reduce_launch(const void* x, const void* dy, const void* y, con
     do {                                                                                                             \
         P4C_TRY(ensure_dyn_smem((const void*)inorm::reduce_kernel<T, M>, 64 * 1024));                                \
         hipLaunchKernelGGL((inorm::reduce_kernel<T, M>), grid, dim3(256), smem, st, (const T*)x, (const T*)dy, (const T*)y, mean, \
-                           rstd, slope, partial, N, C, fin);                                                         \
+                           rstd, slope, partial, N, C, fin, pm);                                                     \
     } while (0)
     if (dtype == P4C_F32) { if (bwd) P4C_IN_RED(float, 1); else P4C_IN_RED(float, 0); }
     else if (dtype == P4C_BF16) { if (bwd) P4C_IN_RED(bf16, 1); else P4C_IN_RED(bf16, 0); }
@@ -365,9 +387,9 @@ extern "C" int p4c_inorm_reduce_finalize_bwd(const void* x, const void* dy, cons
     return inorm_reduce_launch(x, dy, y, mean, rstd, slope, partial, dtype, B, N, C, fin, stream);
 }
 
-extern "C" int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
-                               const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres,
-                               int dtype, int B, int64_t N, int C, p4c_stream_t stream) {
+static int inorm_apply_launch(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
+                              const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres,
+                              int dtype, int B, int64_t N, int C, p4c_stream_t stream, const inorm::PostMul& pm) {
     P4C_CHECK_ARG(x && out && scale && B > 0 && N > 0 && C > 0 && C % 4 == 0, "p4c_inorm_apply: bad arguments");
     const bool bwd = dy != nullptr;
     P4C_CHECK_ARG(bwd ? (y && mean && m1 && m2) : (shift != nullptr), "p4c_inorm_apply: missing operands");
@@ -378,13 +400,42 @@ extern "C" int p4c_inorm_apply(const void* x, const void* res, const void* dy, c
     hipStream_t st = as_stream(stream);
 #define P4C_IN_APP(T, M)                                                                                                        \
     hipLaunchKernelGGL((inorm::apply_kernel<T, M>), grid, dim3(256), 0, st, (const T*)x, (const T*)res, (const T*)dy, (const T*)y, scale, \
-                       shift, mean, rstd, m1, m2, slope, (T*)out, (T*)dres, N, C)
+                       shift, mean, rstd, m1, m2, slope, (T*)out, (T*)dres, N, C, pm)
     if (dtype == P4C_F32) { if (!bwd) P4C_IN_APP(float, 0); else if (rstd) P4C_IN_APP(float, 1); else P4C_IN_APP(float, 2); }
     else if (dtype == P4C_BF16) { if (!bwd) P4C_IN_APP(bf16, 0); else if (rstd) P4C_IN_APP(bf16, 1); else P4C_IN_APP(bf16, 2); }
     else return fail(P4C_ERR_INVALID, "p4c_inorm_apply: bad dtype");
 #undef P4C_IN_APP
     P4C_CHECK_LAUNCH("p4c_inorm_apply");
     return P4C_OK;
+}
+
+extern "C" int p4c_inorm_apply(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres,
+                               int dtype, int B, int64_t N, int C, p4c_stream_t stream) {
+    return inorm_apply_launch(x, res, dy, y, scale, shift, mean, rstd, m1, m2, slope, out, dres, dtype, B, N, C, stream,
+                              inorm::PostMul{nullptr, 1, 1.f});
+}
+
+static int check_postmul(const char* name, const float* mul, int64_t mul_rows, int64_t N) {
+    P4C_CHECK_ARG(mul && mul_rows > 0 && N % mul_rows == 0 && (reinterpret_cast<uintptr_t>(mul) & 15) == 0,
+                  "%s: the multiplier needs a 16-byte aligned table and a row count that divides the map's rows", name);
+    return P4C_OK;
+}
+
+extern "C" int p4c_inorm_apply_mul(const void* x, const void* res, const void* dy, const void* y, const float* scale, const float* shift,
+                                   const float* mean, const float* rstd, const float* m1, const float* m2, float slope, void* out, void* dres,
+                                   int dtype, int B, int64_t N, int C, const float* mul, int64_t mul_rows, float mul_factor, p4c_stream_t stream) {
+    P4C_TRY(check_postmul("p4c_inorm_apply_mul", mul, mul_rows, N));
+    return inorm_apply_launch(x, res, dy, y, scale, shift, mean, rstd, m1, m2, slope, out, dres, dtype, B, N, C, stream,
+                              inorm::PostMul{mul, mul_rows, mul_factor});
+}
+
+extern "C" int p4c_inorm_reduce_mul(const void* x, const void* dy, const void* y, const float* mean, const float* rstd, float slope,
+                                    float* partial, int dtype, int B, int64_t N, int C, const float* mul, int64_t mul_rows, float mul_factor,
+                                    p4c_stream_t stream) {
+    P4C_TRY(check_postmul("p4c_inorm_reduce_mul", mul, mul_rows, N));
+    P4C_CHECK_ARG(dy != nullptr, "p4c_inorm_reduce_mul: the backward sums only (the forward statistics see no multiplier)");
+    return inorm_reduce_launch(x, dy, y, mean, rstd, slope, partial, dtype, B, N, C, inorm::InFin{}, stream, inorm::PostMul{mul, mul_rows, mul_factor});
 }
 
 extern "C" int p4c_inorm_finalize_fwd(const float* partial, int nblk, int B, int64_t N, int C, int groups, const float* gamma, const float* beta,

@@ -397,7 +397,7 @@ class _BatchNormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, stats, gamma, beta, res, running_mean, running_var, training, momentum, eps, slope, batches_tracked=None,
-                res_passthrough=False):
+                res_passthrough=False, mul=None, mul_factor=1.0):
         yc = y.contiguous()
         C = yc.shape[-1]
         N = yc.numel() // C
@@ -418,9 +418,20 @@ class _BatchNormAct(torch.autograd.Function):
             st[3] = (0.0 if b32 is None else b32) - st[0] * st[2]
         out = torch.empty_like(yc)
         rc = None if res is None else res.contiguous()
-        L.call("p4c_inorm_apply", L.ptr(yc), L.ptr(rc), None, None, L.ptr(st[2]), L.ptr(st[3]), None, None, None, None, float(slope),
-               L.ptr(out), None, L.dtype_code(yc.dtype), 1, N, C, L.stream(dev), alg_bytes=yc.numel() * yc.element_size() * (2 + (rc is not None)))
-        ctx.save_for_backward(yc, out, st)
+        # mul (groups, C) fp32 >= 0, mul_factor: a multiplier per (row group, channel) behind the activation -- a channel dropout's draw
+        # per (sample, channel) and 1 / (1 - p) -- applied by THIS pass and its backward passes (csrc/inorm.hip: PostMul)
+        ctx.mul_rows = 0
+        if mul is not None:
+            if mul.dtype != torch.float32 or mul.dim() != 2 or mul.shape[1] != C or not mul.is_contiguous() or N % mul.shape[0]:
+                raise L.P4CError("ops_gemm.batch_norm_act: the multiplier is a dense fp32 (groups, C) table whose group count divides the rows")
+            ctx.mul_rows, ctx.mul_factor = N // mul.shape[0], float(mul_factor)
+            L.call("p4c_inorm_apply_mul", L.ptr(yc), L.ptr(rc), None, None, L.ptr(st[2]), L.ptr(st[3]), None, None, None, None, float(slope),
+                   L.ptr(out), None, L.dtype_code(yc.dtype), 1, N, C, L.ptr(mul), ctx.mul_rows, ctx.mul_factor, L.stream(dev),
+                   alg_bytes=yc.numel() * yc.element_size() * (2 + (rc is not None)))
+        else:
+            L.call("p4c_inorm_apply", L.ptr(yc), L.ptr(rc), None, None, L.ptr(st[2]), L.ptr(st[3]), None, None, None, None, float(slope),
+                   L.ptr(out), None, L.dtype_code(yc.dtype), 1, N, C, L.stream(dev), alg_bytes=yc.numel() * yc.element_size() * (2 + (rc is not None)))
+        ctx.save_for_backward(yc, out, st, *(() if mul is None else (mul,)))
         ctx.slope, ctx.has_res, ctx.training = float(slope), res is not None, bool(training)
         ctx.gdtype = None if gamma is None else gamma.dtype
         ctx.set_materialize_grads(False)
@@ -431,8 +442,9 @@ class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dpass):
         if dout is None:
-            return None, None, None, None, dpass, None, None, None, None, None, None, None, None
-        yc, out, st = ctx.saved_tensors
+            return (None, None, None, None, dpass) + (None,) * 10
+        yc, out, st, *rest = ctx.saved_tensors
+        mul = rest[0] if rest else None
         C = yc.shape[-1]
         N = yc.numel() // C
         dev = yc.device
@@ -443,7 +455,12 @@ class _BatchNormAct(torch.autograd.Function):
         part = torch.empty(1, nb, 2, C, dtype=torch.float32, device=dev)
         co = torch.empty(2, C, dtype=torch.float32, device=dev)
         dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
-        if ON.FUSED_FINALIZE:    # the coefficients and dgamma / dbeta from the reduce launch's last workgroup (csrc/inorm.hip: InFin)
+        if mul is not None:
+            L.call("p4c_inorm_reduce_mul", L.ptr(yc), L.ptr(dout), L.ptr(out), L.ptr(st[0]), L.ptr(st[1]), ctx.slope, L.ptr(part), L.dtype_code(yc.dtype),
+                   1, N, C, L.ptr(mul), ctx.mul_rows, ctx.mul_factor, L.stream(dev), alg_bytes=3 * yc.numel() * yc.element_size())
+            L.call("p4c_inorm_finalize_bwd", L.ptr(part), nb, 1, N, C, 0, None, None, L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]),
+                   L.stream(dev))
+        elif ON.FUSED_FINALIZE:    # the coefficients and dgamma / dbeta from the reduce launch's last workgroup (csrc/inorm.hip: InFin)
             L.call("p4c_inorm_reduce_finalize_bwd", L.ptr(yc), L.ptr(dout), L.ptr(out), L.ptr(st[0]), L.ptr(st[1]), ctx.slope, L.ptr(part),
                    ON.next_ticket(dev), L.ptr(co[0]), L.ptr(co[1]), L.ptr(dgb[0]), L.ptr(dgb[1]), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev),
                    alg_bytes=3 * yc.numel() * yc.element_size())
@@ -458,21 +475,27 @@ class _BatchNormAct(torch.autograd.Function):
         dres = torch.empty_like(yc) if ctx.has_res else None
         fold = dpass is not None and ctx.has_res and dpass.dtype == yc.dtype
         dadd = dpass.contiguous() if fold else None
-        L.call("p4c_inorm_apply", L.ptr(yc), L.ptr(dadd), L.ptr(dout), L.ptr(out), L.ptr(st[2]), None, L.ptr(st[0]), L.ptr(st[1]), L.ptr(co[0]),
-               L.ptr(co[1]), ctx.slope, L.ptr(dy), L.ptr(dres), L.dtype_code(yc.dtype), 1, N, C, L.stream(dev),
-               alg_bytes=yc.numel() * yc.element_size() * (4 + ctx.has_res + fold))
+        args = (L.ptr(yc), L.ptr(dadd), L.ptr(dout), L.ptr(out), L.ptr(st[2]), None, L.ptr(st[0]), L.ptr(st[1]), L.ptr(co[0]), L.ptr(co[1]), ctx.slope,
+                L.ptr(dy), L.ptr(dres), L.dtype_code(yc.dtype), 1, N, C)
+        nbytes = yc.numel() * yc.element_size() * (4 + ctx.has_res + fold)
+        if mul is not None:
+            L.call("p4c_inorm_apply_mul", *args, L.ptr(mul), ctx.mul_rows, ctx.mul_factor, L.stream(dev), alg_bytes=nbytes)
+        else:
+            L.call("p4c_inorm_apply", *args, L.stream(dev), alg_bytes=nbytes)
         if dpass is not None and not fold:
             dres = dpass if dres is None else dres + dpass
         dg = None if ctx.gdtype is None else dgb[0].to(ctx.gdtype)
         db = None if ctx.gdtype is None else dgb[1].to(ctx.gdtype)
-        return dy, None, dg, db, dres, None, None, None, None, None, None, None, None
+        return (dy, None, dg, db, dres) + (None,) * 10
 
 
-def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=None, res_passthrough=False):
+def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=None, res_passthrough=False, mul=None, mul_factor=1.0):
     """``leaky_relu(bn(y) (+ res), slope)`` for a features-last y (B,H,W,C) and a torch.nn.BatchNorm2d module `bn` (its parameters,
     running statistics, momentum, eps and training flag); `stats`: the producer's column sums (conv2d_nhwc(..., want_stats=True)) or
     None.  slope = 1: no activation.  ``res_passthrough``: returns (out, res) -- hand that second tensor to the other consumers of the
-    residual operand, and their gradient is added inside this node's backward launch."""
+    residual operand, and their gradient is added inside this node's backward launch.  ``mul`` (groups, C) fp32 >= 0 with ``mul_factor``:
+    the result is multiplied by mul[row group, channel] * mul_factor (row groups = equal consecutive runs of the B*H*W rows: the samples) --
+    a channel dropout (Dropout2d) on the block's output, applied by the normalisation passes themselves."""
     L.require_cuda(y)
     if y.dtype not in (torch.bfloat16, torch.float32) or y.shape[-1] % 4 or y.shape[-1] > 1024:
         raise L.P4CError(f"ops_gemm.batch_norm_act: unsupported map {tuple(y.shape)} {y.dtype}")
@@ -490,7 +513,7 @@ def batch_norm_act(y, stats, bn: torch.nn.BatchNorm2d, slope: float = 1.0, res=N
             raise L.P4CError("ops_gemm.batch_norm_act: num_batches_tracked must be an int64 tensor on the map's device")
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     out, rp = _BatchNormAct.apply(y, stats if training else None, bn.weight, bn.bias, res, rm, rv, training, mom, bn.eps, float(slope), nbt,
-                                  bool(res_passthrough))
+                                  bool(res_passthrough), mul, float(mul_factor))
     return (out, rp) if res_passthrough else out
 
 

@@ -188,16 +188,19 @@ class ResBlock(nn.Module):
             self.conv3 = nn.Conv2d(cin, cout, 1, bias=False)
             self.norm3 = _norm(norm, cout)
 
-    def forward(self, x, pass_input=False):
+    def forward(self, x, pass_input=False, post=None):
         """``pass_input``: returns (out, x') with x' the input as handed on by this block's last consumer of it (features-last) -- a
         caller that uses x once more (the transformer block's skip) takes x' and its gradient is added inside this block's backward
-        launches; x' is None when the block ran on a route without that (the caller then uses its own tensor)."""
-        out = self._forward(x, pass_input)
-        if pass_input:
-            return out if isinstance(out, tuple) else (out, None)
-        return out
+        launches; x' is None when the block ran on a route without that (the caller then uses its own tensor).
+        ``post`` = (m (B, C) fp32 >= 0, factor): the output is multiplied by m[b, c] * factor -- a channel dropout's draw -- inside the
+        last normalisation pass where the route has one (ops_gemm.batch_norm_act), by a tensor-library product otherwise."""
+        out, xp, applied = self._forward(x, pass_input, post)
+        if post is not None and not applied:
+            out = out * (post[0] * post[1]).to(out.dtype)[:, :, None, None]
+        return (out, xp) if pass_input else out
 
-    def _forward(self, x, pass_input=False):
+    def _forward(self, x, pass_input=False, post=None):
+        """(out NCHW-shaped, the input handed on or None, whether ``post`` was applied)"""
         # (the norms act on the convolutions' OUTPUT channels: encoder1's 69-channel input is no obstacle)
         cout = self.conv1.weight.shape[0]
         if (isinstance(self.norm1, nn.InstanceNorm2d) and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
@@ -207,7 +210,7 @@ class ResBlock(nn.Module):
                 t.permute(0, 2, 3, 1), m.weight, m.bias, m.eps, slope, None if res is None else res.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
             y = inorm(self.norm1, _conv(self.conv1, x).contiguous(memory_format=torch.channels_last), 0.01)
             r = inorm(self.norm3, _conv(self.conv3, x).contiguous(memory_format=torch.channels_last)) if self.down else x
-            return inorm(self.norm2, _conv(self.conv2, y).contiguous(memory_format=torch.channels_last), 0.01, r)
+            return inorm(self.norm2, _conv(self.conv2, y).contiguous(memory_format=torch.channels_last), 0.01, r), None, False
         if (isinstance(self.norm1, nn.BatchNorm2d) and _native(x) and x.permute(0, 2, 3, 1).is_contiguous()
                 and G.conv_supported(x.permute(0, 2, 3, 1), self.conv1.weight) and cout % 8 == 0 and cout <= 1024):
             # the 128 ... 1024-channel blocks of the transformer stages: implicit-GEMM convolutions whose drain leaves the batch-norm
@@ -225,18 +228,20 @@ class ResBlock(nn.Module):
                 else:
                     y3, st3 = G.conv2d_nhwc(xp, self.conv3.weight, want_stats=True)
                 rl = G.batch_norm_act(y3, st3, self.norm3, 1.0)
-                out = G.batch_norm_act(y2, st2, self.norm2, 0.01, rl)
-            elif pass_input:
-                out, xp = G.batch_norm_act(y2, st2, self.norm2, 0.01, xp, res_passthrough=True)
+                res_pass = False
             else:
-                out = G.batch_norm_act(y2, st2, self.norm2, 0.01, xp)
-            return (out.permute(0, 3, 1, 2), xp) if pass_input else out.permute(0, 3, 1, 2)
+                rl, res_pass = xp, pass_input
+            mul, factor = (None, 1.0) if post is None else post
+            out = G.batch_norm_act(y2, st2, self.norm2, 0.01, rl, res_passthrough=res_pass, mul=mul, mul_factor=factor)
+            if res_pass:
+                out, xp = out
+            return out.permute(0, 3, 1, 2), (xp if pass_input else None), post is not None
         r = x
         y = F.leaky_relu(_nrm(self.norm1, _conv(self.conv1, x)), 0.01)
         y = _nrm(self.norm2, _conv(self.conv2, y))
         if self.down:
             r = _nrm(self.norm3, _conv(self.conv3, r))
-        return F.leaky_relu(y + r, 0.01)
+        return F.leaky_relu(y + r, 0.01), None, False
 
 
 class _SplitQKVV(torch.autograd.Function):
@@ -406,11 +411,18 @@ class TransformerBlock(nn.Module):
             t = self.epa_block(ln, res=t, gamma=self.gamma)
             skip = t.reshape(B, H, W, C)
             if isinstance(self.conv51, ResBlock):
-                r, handed = self.conv51(skip.permute(0, 3, 1, 2), pass_input=True)     # (skip comes back from its consumers inside conv51)
+                # the channel dropout in front of conv8 (published block, training mode): the draw per (sample, channel) as
+                # F.dropout2d makes it, applied by conv51's last normalisation pass (and its backward passes) instead of by a
+                # full-size product each way (round 6)
+                post = None
+                if self.published and self.training and 0 < self.conv8[0].p < 1 and L.diag_switch("P4C_UNETRPP_LIB_DROPOUT") != "1":
+                    keep = 1.0 - self.conv8[0].p
+                    post = (torch.empty(B, C, dtype=torch.float32, device=x.device).bernoulli_(keep), 1.0 / keep)
+                r, handed = self.conv51(skip.permute(0, 3, 1, 2), pass_input=True, post=post)   # (skip comes back from its consumers)
                 skip = skip if handed is None else handed
+                r = (r if post is not None else self._conv8_in(r)).permute(0, 2, 3, 1)
             else:
-                r = self.conv51(skip.permute(0, 3, 1, 2))
-            r = self._conv8_in(r).permute(0, 2, 3, 1)
+                r = self._conv8_in(self.conv51(skip.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
             if G.conv_supported(r, conv8.weight) and r.is_contiguous():
                 return G.conv2d_nhwc(r, conv8.weight, conv8.bias, res=skip).permute(0, 3, 1, 2)
             return (skip + _conv(conv8, r.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)).permute(0, 3, 1, 2)

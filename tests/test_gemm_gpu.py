@@ -243,6 +243,51 @@ def test_batch_norm_node_vs_torch_float64(gpu_device, C, slope, with_res):
     close_bf16(oe, F.leaky_relu(re_, slope) if slope != 1.0 else re_, "eval out")
 
 
+def test_batch_norm_node_with_channel_dropout_and_handed_on_residual(gpu_device):
+    """Round 6: (a) ``mul`` -- a multiplier per (sample, channel) behind the activation (the Dropout2d in front of UNETR++'s conv8) applied
+    by the normalisation passes themselves, forward and backward, against float64 torch with the same mask; (b) ``res_passthrough`` /
+    ``conv2d_nhwc(passthrough=True)`` -- a tensor with several consumers handed from one to the next, its gradients meeting inside the
+    backward launches: same gradients as autograd's additions; (c) num_batches_tracked is advanced by the statistics kernel."""
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    B, H, W, C, slope = 2, 16, 16, 128, 0.01
+    x = rnd((B, H, W, C), dev, 61).bfloat16().requires_grad_()
+    w = torch.nn.Parameter(rnd((C, C, 3, 3), dev, 62) / (C * 9) ** 0.5)
+    bn = torch.nn.BatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * rnd((C,), dev, 63))
+        bn.bias.copy_(0.1 * rnd((C,), dev, 64))
+    ref_bn = torch.nn.BatchNorm2d(C).to(dev).double()
+    ref_bn.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    mask = (torch.rand(B, C, device=dev, generator=torch.Generator(device=dev).manual_seed(65)) < 0.7).float()
+    mask[0, :4] = 0.0                                            # (dropped channels for sure)
+    factor = 1.0 / 0.7
+    dy = rnd((B, H, W, C), dev, 66).bfloat16()
+    dx2 = rnd((B, H, W, C), dev, 67).bfloat16()
+    # x -> conv (hands x on) -> batch norm + residual x (hands it on) + dropout -> out;  x2 = the handed-on x, used once more
+    y, stats, xp = G.conv2d_nhwc(x, w, want_stats=True, passthrough=True)
+    out, x2 = G.batch_norm_act(y, stats, bn, slope, xp, res_passthrough=True, mul=mask, mul_factor=factor)
+    assert int(bn.num_batches_tracked) == 1
+    torch.autograd.backward([out, x2], [dy, dx2])
+    # float64 reference on the same bf16 operands
+    xr = x.detach().double().requires_grad_()
+    wr = w.detach().double().requires_grad_()
+    # (the normalisation's reference starts from the node's own bf16 y, as in the test above: a y computed apart flips the LeakyReLU branch
+    #  of the elements nearest to zero, and every flip moves a gradient sum by a whole term)
+    yr = y.detach().double().permute(0, 3, 1, 2).requires_grad_()
+    o = F.leaky_relu(ref_bn(yr) + xr.permute(0, 3, 1, 2), slope) * (mask.double() * factor)[:, :, None, None]
+    o = o.permute(0, 2, 3, 1)
+    o.backward(dy.double())
+    close_bf16(out, o, "out")
+    assert float(out[0, :, :, :4].abs().max()) == 0.0
+    assert rel(bn.weight.grad, ref_bn.weight.grad) <= 5e-3 and rel(bn.bias.grad, ref_bn.bias.grad) <= 5e-3
+    # gradient of x: through the residual (float64: xr.grad so far) + through the convolution (dy_conv = yr.grad) + the third consumer
+    g_conv = torch.autograd.grad(F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1), xr, yr.grad)[0]
+    want = xr.grad + g_conv + dx2.double()
+    close_bf16(x.grad, want, "dx (three consumers, no addition launch)")
+
+
 def test_weight_images_follow_the_parameter_version(gpu_device):
     from py4cast_amd import ops_gemm as G
 
