@@ -42,7 +42,7 @@ def step(i):
 for i in range(2):
     step(i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step(2)
     torch.cuda.synchronize()
 
@@ -70,7 +70,8 @@ for ev in prof.events():
             if w in short:
                 short = w + (" bf16" if "BFloat16" in k.name else " f32" if "float" in k.name else "")
                 break
-        key = (short[:40], ev.name[:40], " < ".join(chain), frame)
+        shp = str([tuple(x) for x in (ev.input_shapes or []) if x])[:60]
+        key = (short[:40], ev.name[:40], " < ".join(chain), frame or shp)
         rows[key][0] += k.duration
         rows[key][1] += 1
 print(f"{model} T={T} {strategy}: device kernel time {total / 1e3:.2f} ms, native {native / total:.3f}")
