@@ -28,7 +28,11 @@
 //                    the four j-waves).  gemm_tn_reduce_kernel sums the slabs in a fixed order, turns (tap, ci) -> (ci, tap) through
 //                    LDS and writes -- or adds into the parameter's .grad -- the gradient in the torch layout [co][ci][kh][kw].
 // Every reduction has a fixed order: reruns are bit-identical.
+#include <mutex>
+#include <vector>
+
 #include "common.hpp"
+#include "kernels.hpp"
 
 namespace p4c {
 namespace gemm {
@@ -582,10 +586,8 @@ struct TnRedArgs {
     float* db;
     int splits, tiles, tiles_i, Mo, No, Cin, taps, cchunk, accumulate;
 };
-__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
-    __shared__ float turn[9 * 512];
-    __shared__ float part[256];
-    const int i = blockIdx.y, c0 = blockIdx.x * a.cchunk;
+__device__ __forceinline__ void tn_reduce_block(const TnRedArgs& a, const int bx, const int i, float* __restrict__ turn, float* __restrict__ part) {
+    const int c0 = bx * a.cchunk;
     const int cn = a.Cin - c0 < a.cchunk ? a.Cin - c0 : a.cchunk;
     const int ne = a.taps * cn;
     const int64_t sstride = (int64_t)a.tiles * (128 * 128);
@@ -627,7 +629,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
         const float v = turn[tap * cn + c];
         out[e] = a.accumulate ? out[e] + v : v;
     }
-    if (a.db && blockIdx.x == 0 && threadIdx.x < 64) {
+    if (a.db && bx == 0 && threadIdx.x < 64) {
         // the 4 * splits partial column sums: lane l takes the entries k = l (mod 64) in order, then a fixed shuffle tree
         float t = 0.f;
         for (int k = threadIdx.x; k < 4 * a.splits; k += 64)
@@ -635,6 +637,35 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
         t = wave_sum(t);
         if (threadIdx.x == 0) a.db[i] = a.accumulate ? a.db[i] + t : t;
     }
+}
+
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedArgs a) {
+    __shared__ float turn[9 * 512];
+    __shared__ float part[256];
+    tn_reduce_block(a, (int)blockIdx.x, (int)blockIdx.y, turn, part);
+}
+
+// Round 6: the reductions of one backward pass that ADD into gradient buffers, TN_BATCH per launch (the queue below): UNETR++ issued 804
+// of them per optimizer step, 8 us each -- every one a grid of its own for a few hundred KB of slabs.  block -> (job, block of the job's
+// own (channel chunk, output row) grid) through a prefix table in the kernel arguments; a job's arithmetic is tn_reduce_block's, so a
+// batched and a separate reduction give the same bits.
+constexpr int TN_BATCH = 32;
+struct TnBatchArgs {
+    TnRedArgs job[TN_BATCH];
+    int first[TN_BATCH + 1];
+    int n;
+};
+static_assert(sizeof(TnBatchArgs) <= 4000, "the job table travels in the kernel arguments");
+
+__global__ void __launch_bounds__(256) gemm_tn_reduce_batch_kernel(TnBatchArgs b) {
+    __shared__ float turn[9 * 512];
+    __shared__ float part[256];
+    int jb = 0;
+    while (jb + 1 < b.n && (int)blockIdx.x >= b.first[jb + 1]) ++jb;
+    const TnRedArgs& a = b.job[jb];
+    const int local = (int)blockIdx.x - b.first[jb];
+    const int gx = (a.Cin + a.cchunk - 1) / a.cchunk;
+    tn_reduce_block(a, local % gx, local / gx, turn, part);
 }
 
 // ------------------------------------------------------------------------------------------------ weight images
@@ -877,6 +908,62 @@ extern "C" size_t p4c_gemm_tn_workspace_bytes(int R, int Mo, int No) {
     return ((size_t)s * ti * tj * 128 * 128 + (size_t)s * ti * 4 * 128) * sizeof(float);
 }
 
+// ---- the queue of accumulating reductions (kernels.hpp: tn_reduce_*; flushed by p4c_grad_reduce_flush at the end of a backward pass)
+namespace {
+struct TnPending {
+    TnRedArgs job;
+    hipStream_t stream;
+};
+std::mutex g_tn_mu;
+std::vector<TnPending> g_tn_pending;
+
+int tn_launch_batch(const TnBatchArgs& b, hipStream_t st) {
+    hipLaunchKernelGGL(gemm_tn_reduce_batch_kernel, dim3(b.first[b.n]), dim3(256), 0, st, b);
+    P4C_CHECK_LAUNCH("gemm_tn_reduce_batch");
+    return P4C_OK;
+}
+}  // namespace
+
+namespace p4c {
+int tn_reduce_pending() {
+    std::lock_guard<std::mutex> lk(g_tn_mu);
+    return (int)g_tn_pending.size();
+}
+void tn_reduce_drop() {
+    std::lock_guard<std::mutex> lk(g_tn_mu);
+    g_tn_pending.clear();
+}
+// the queued jobs in submission order, TN_BATCH per launch; a job that adds into a buffer a job of the launch being assembled already adds
+// into (the same weight in the next AR step of a rollout) starts a new launch: additions into one element happen in submission order
+int tn_reduce_flush(hipStream_t st) {
+    std::vector<TnPending> jobs;
+    {
+        std::lock_guard<std::mutex> lk(g_tn_mu);
+        jobs.swap(g_tn_pending);
+    }
+    if (jobs.empty()) return P4C_OK;
+    TnBatchArgs b;
+    b.n = 0;
+    b.first[0] = 0;
+    for (const TnPending& pj : jobs) {
+        P4C_CHECK_ARG(pj.stream == st, "p4c_grad_reduce_flush: a queued weight-gradient reduction was produced on another stream");
+        bool clash = false;
+        for (int q = 0; q < b.n && !clash; ++q)
+            clash = pj.job.dw == b.job[q].dw || (pj.job.db && pj.job.db == b.job[q].db);
+        const int blocks = ((pj.job.Cin + pj.job.cchunk - 1) / pj.job.cchunk) * pj.job.Mo;
+        if (b.n == TN_BATCH || clash || (b.n && (int64_t)b.first[b.n] + blocks > (1 << 20))) {
+            P4C_TRY(tn_launch_batch(b, st));
+            b.n = 0;
+        }
+        b.job[b.n] = pj.job;
+        b.first[b.n + 1] = b.first[b.n] + blocks;
+        ++b.n;
+    }
+    if (b.n) P4C_TRY(tn_launch_batch(b, st));
+    return P4C_OK;
+}
+}  // namespace p4c
+
 // dW (Mo, Cin, taps) fp32 = sum over the R rows of dy^T (x) [x or its 3x3 im2col view], db (Mo) = column sums of dy (or NULL)
 extern "C" int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t ldq, int R, int Mo, int H, int W, int Cin, int taps,
                            float* dw, float* db, int accumulate, void* workspace, p4c_stream_t stream) {
@@ -910,6 +997,12 @@ extern "C" int p4c_gemm_tn(const void* dy, int64_t ldp, const void* x, int64_t l
     while (cchunk > 32 && (int64_t)((Cin + cchunk - 1) / cchunk) * Mo < 1024) cchunk >>= 1;
     if (cchunk > Cin) cchunk = Cin;
     TnRedArgs r{a.partial, a.bias_partial, dw, db, a.splits, tiles, a.tiles_i, Mo, a.No, Cin, taps, cchunk, accumulate ? 1 : 0};
+    if (accumulate && grad_reduce_deferring()) {
+        // (the caller keeps the workspace alive until p4c_grad_reduce_flush: py4cast_amd.ops_nodeproj.GradQueue)
+        std::lock_guard<std::mutex> lk(g_tn_mu);
+        g_tn_pending.push_back(TnPending{r, st});
+        return P4C_OK;
+    }
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((Cin + cchunk - 1) / cchunk, Mo), dim3(256), 0, st, r);
     P4C_CHECK_LAUNCH("gemm_tn_reduce");
     return P4C_OK;

@@ -215,6 +215,12 @@ struct GradReduceJob {
     int k_real, o_real;
 };
 int grad_reduce_submit(const GradReduceJob& job, hipStream_t stream);
+bool grad_reduce_deferring();      // p4c_grad_reduce_defer(1) is in force
+// gemm.hip: the same deferral for the accumulating reductions of p4c_gemm_tn (weight gradients added into .grad buffers: the split-K
+// slabs of the calls of one backward pass are reduced TN_BATCH per launch when the pass ends); driven by the entry points above
+int tn_reduce_flush(hipStream_t stream);
+int tn_reduce_pending();
+void tn_reduce_drop();
 
 // tiles of the conv kernels (for sizing the statistics partial buffers)
 constexpr int CONV_TH = 4;

@@ -412,6 +412,11 @@ int flush_range(const std::vector<Pending>& v, hipStream_t st) {
 
 }  // namespace
 
+bool grad_reduce_deferring() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_defer;
+}
+
 int grad_reduce_submit(const GradReduceJob& job, hipStream_t st) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -431,14 +436,17 @@ using namespace p4c;
 extern "C" int p4c_grad_reduce_defer(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     const int was = g_defer ? 1 : 0;
-    if (on < 0) g_pending.clear();      // -1: drop what is queued (a backward pass that died before its flush) and reduce at once again
+    if (on < 0) {                       // -1: drop what is queued (a backward pass that died before its flush) and reduce at once again
+        g_pending.clear();
+        tn_reduce_drop();
+    }
     g_defer = on > 0;
     return was;
 }
 
 extern "C" int p4c_grad_reduce_pending(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    return (int)g_pending.size();
+    return (int)g_pending.size() + tn_reduce_pending();
 }
 
 extern "C" int p4c_grad_reduce_flush(p4c_stream_t stream) {
@@ -447,8 +455,9 @@ extern "C" int p4c_grad_reduce_flush(p4c_stream_t stream) {
         std::lock_guard<std::mutex> lk(g_mu);
         jobs.swap(g_pending);
     }
-    if (jobs.empty()) return P4C_OK;
     hipStream_t st = as_stream(stream);
+    P4C_TRY(tn_reduce_flush(st));
+    if (jobs.empty()) return P4C_OK;
     for (const Pending& pj : jobs)
         P4C_CHECK_ARG(pj.stream == st, "p4c_grad_reduce_flush: a queued job was produced on another stream (flush on the stream of the backward)");
     return flush_range(jobs, st);

@@ -125,10 +125,19 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, Mo: int, Cin: int, conv=None, wan
         dw = torch.empty((Mo, Cin, 3, 3) if conv is not None else (Mo, Cin), dtype=torch.float32, device=dy.device)
         db = torch.empty(Mo, dtype=torch.float32, device=dy.device) if want_bias else None
     ws = torch.empty(max(lib.p4c_gemm_tn_workspace_bytes(R, Mo, taps * Cin) // 4, 1), dtype=torch.float32, device=dy.device)
+    if sink is not None:
+        # round 6: inside a backward pass the split-K slabs of the accumulating calls are summed 32 calls per launch when the pass ends
+        # (csrc/gemm.hip: gemm_tn_reduce_batch_kernel; ops_nodeproj.GradQueue keeps the slabs alive and flushes) -- 804 reduce launches per
+        # UNETR++ step before.  Not when a gradient exchange listens for the sums as they become final (FlatDDP(overlap=True), eager
+        # steps of N > 1 ranks): there every call reduces at once and reports it.
+        from .ops_nodeproj import GradQueue
+
+        if GradQueue.active() or not L.GRAD_SINK_LISTENERS:
+            GradQueue.begin(ws)
     L.call("p4c_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), R, Mo, H, W, Cin, taps, L.ptr(dw), L.ptr(db), int(sink is not None),
            L.ptr(ws), L.stream(dy.device), alg_bytes=2 * R * (Mo + Cin) + 4 * Mo * Cin * taps, alg_flops=2 * R * Mo * Cin * taps)
     if sink is not None:
-        L.grad_written(dw, db)       # (FlatDDP(overlap=True) counts these: the bucket may leave once its last sum is enqueued)
+        GradQueue.wrote([dw, db])    # (FlatDDP(overlap=True) counts these: now, or at the flush when the sums were queued)
         return None, None
     return dw, db
 

@@ -56,6 +56,11 @@ class GradQueue:
         cls._keep.append(keep)
 
     @classmethod
+    def active(cls) -> bool:
+        """the reductions of the backward pass in progress are being queued"""
+        return cls.enabled and cls._task >= 0 and cls._task == torch._C._current_graph_task_id()
+
+    @classmethod
     def wrote(cls, views) -> None:
         """After the launch that produced the partials: ``views`` (regions of parameters' .grad) receive their sums when the queue is
         flushed -- or have just received them when nothing is being deferred."""

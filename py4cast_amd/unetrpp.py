@@ -16,12 +16,16 @@ What runs where (state after round 6; DESIGN.md section 7 has the numbers)
   implicit-GEMM convolution with bias / residual / statistics epilogues, round 5); bilinear up-sampling + skip: csrc/resize.hip.
 * the two full-resolution 64-channel residual blocks (encoder1 / decoder2): the MFMA convolution kernels of csrc/conv_rows.hip /
   conv_bf16.hip + the native instance-norm nodes (csrc/inorm.hip); the 1 x 1 output head: a row GEMM (csrc/rowgemm.hip).
-* still a library call: the token-axis projection E = F (a Linear over N, hipBLASLt).
+* the token-axis projection E = F and its adjoints: the same tall-skinny kernels, k / v_sa read in place over all channels of a sample
+  (round 6; a gather + hipBLASLt before); the sums of the token splits, the bias / temperature gradient tails, the published x_SA merge
+  (a tiled transpose each way) and the channel dropout in front of conv8 (applied by conv51's last batch-norm pass) are native too;
+  a tensor with several consumers (the block's skip, a residual block's input) is handed from consumer to consumer so that its
+  gradients are added inside the backward launches (``passthrough``).  What is still tensor-library code: DESIGN.md section 3.12.
 
 ``UNetRPPSettings.published_block`` (round 6, default True) selects the block AS PUBLISHED (Shaker et al., the code mfai wraps), so
 that state dicts have the published keys and a checkpoint trained there means the same function here:
 * the spatial-attention branch is merged as the published code writes it, ``(attn_SA @ v_SA^T).permute(0, 3, 1, 2).reshape(B, N, C)``
-  -- a fixed permutation of the (N x C) entries that mixes tokens and channels (one gather copy per block here);
+  -- a fixed permutation of the (N x C) entries that mixes tokens and channels (``p4c_ts_merge_published``: one tiled transpose);
 * ``conv8 = Sequential(Dropout2d(0.1), Conv2d)`` (keys ``conv8.1.*``; the channel dropout is drawn in training mode, p =
   ``conv8_dropout``), ``E`` and ``F`` are one Linear registered under both names (keys ``E.*`` and ``F.*``), and the two attention
   dropouts exist as modules (p = ``dropout_rate``, which must be 0 here);

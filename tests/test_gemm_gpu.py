@@ -288,6 +288,49 @@ def test_batch_norm_node_with_channel_dropout_and_handed_on_residual(gpu_device)
     close_bf16(x.grad, want, "dx (three consumers, no addition launch)")
 
 
+def test_accumulating_weight_gradients_are_reduced_in_batches_at_the_end_of_the_backward(gpu_device):
+    """Round 6: inside a backward pass the split-K slabs of the weight-gradient calls that ADD into .grad buffers are queued and summed 32
+    calls per launch when the pass ends (csrc/gemm.hip: gemm_tn_reduce_batch_kernel, driven by ops_nodeproj.GradQueue).  Same bits as
+    one reduction per call -- also for a weight used by several steps of a rollout (its additions stay in submission order) -- and
+    nothing is left in the queue."""
+    from py4cast_amd import _lib as L
+    from py4cast_amd import ops_gemm as G
+    from py4cast_amd.ops_nodeproj import GradQueue
+
+    dev = gpu_device
+    torch.manual_seed(71)
+    lins = [torch.nn.Linear(128, 256).to(dev), torch.nn.Linear(256, 128).to(dev), torch.nn.Linear(128, 128, bias=False).to(dev)]
+    conv = torch.nn.Conv2d(128, 128, 3, padding=1, bias=False).to(dev)
+    params = [p for m in lins + [conv] for p in m.parameters()]
+    x0 = rnd((2, 16, 16, 128), dev, 72).bfloat16()
+
+    def rollout():
+        x, loss = x0, 0.0
+        for _ in range(3):                                   # three "AR steps" on the same weights
+            h = G.linear(x, lins[0].weight, lins[0].bias)
+            h = G.linear(h, lins[1].weight, lins[1].bias)
+            h = G.conv2d_nhwc(h, conv.weight)
+            x = G.linear(h, lins[2].weight, None, res=x)
+            loss = loss + x.float().square().mean()
+        return loss
+
+    out = {}
+    for mode in (False, True, True):
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        GradQueue.enabled = mode
+        try:
+            rollout().backward()
+        finally:
+            GradQueue.enabled = True
+        assert L.lib().p4c_grad_reduce_pending() == 0
+        out.setdefault(mode, []).append([p.grad.clone() for p in params])
+    for a, b in zip(out[False][0], out[True][0]):
+        assert float(a.abs().max()) > 0 and torch.equal(a, b)
+    for a, b in zip(out[True][0], out[True][1]):
+        assert torch.equal(a, b)
+
+
 def test_weight_images_follow_the_parameter_version(gpu_device):
     from py4cast_amd import ops_gemm as G
 
