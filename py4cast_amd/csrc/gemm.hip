@@ -716,11 +716,21 @@ __global__ void __launch_bounds__(256) bnorm_finalize_kernel(const float* __rest
     __shared__ double red[2][8][32];
     const int cl = threadIdx.x & 31, row = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = row; b < nblk; b += 8) {
+    if (c < C) {
+        int b = row;
+        for (; b + 24 < nblk; b += 32) {          // four blocks' loads in flight (256 blocks at the first stage: 8 rounds, not 32)
+            const float a0 = partial[((int64_t)b * 2 + 0) * C + c], q0 = partial[((int64_t)b * 2 + 1) * C + c];
+            const float a1 = partial[((int64_t)(b + 8) * 2 + 0) * C + c], q1 = partial[((int64_t)(b + 8) * 2 + 1) * C + c];
+            const float a2 = partial[((int64_t)(b + 16) * 2 + 0) * C + c], q2 = partial[((int64_t)(b + 16) * 2 + 1) * C + c];
+            const float a3 = partial[((int64_t)(b + 24) * 2 + 0) * C + c], q3 = partial[((int64_t)(b + 24) * 2 + 1) * C + c];
+            s1 = (((s1 + (double)a0) + (double)a1) + (double)a2) + (double)a3;
+            s2 = (((s2 + (double)q0) + (double)q1) + (double)q2) + (double)q3;
+        }
+        for (; b < nblk; b += 8) {
             s1 += (double)partial[((int64_t)b * 2 + 0) * C + c];
             s2 += (double)partial[((int64_t)b * 2 + 1) * C + c];
         }
+    }
     red[0][row][cl] = s1;
     red[1][row][cl] = s2;
     __syncthreads();
