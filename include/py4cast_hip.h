@@ -828,6 +828,11 @@ int p4c_inorm_finalize_bwd(const float* partial, int nblk, int B, int64_t N, int
  * (out, in) or a 1x1 convolution: fwd[co][tap][ci] = w[co][ci][tap] (forward), dgrad[ci][tap'][co] = w[co][ci][taps-1-tap'] (data
  * gradient: the same kernel on the transposed, tap-flipped image).  Either output may be NULL. */
 int p4c_gemm_prep_weight(const float* w, int CO, int CI, int taps, void* fwd, void* dgrad, p4c_stream_t stream);
+/* The images of n weights in ONE launch per 24 (round 6: a model prepares all its stale images at the first miss of a step --
+ * py4cast_amd/ops_gemm.py::_prepare_logged): parallel arrays of the arguments of p4c_gemm_prep_weight_scaled; rowscale / bias / bias_out
+ * (the arrays, or single entries) may be NULL. */
+int p4c_gemm_prep_weight_batch(int n, const float* const* w, const float* const* rowscale, const float* const* bias, float* const* bias_out,
+                               const int* CO, const int* CI, const int* taps, void* const* fwd, void* const* dgrad, p4c_stream_t stream);
 /* The same with a per-output-channel scale folded in: images of rowscale[co] * w[co] (fp32 product, one bf16 rounding) and, with a bias,
  * bias_out[co] = rowscale[co] * bias[co] (fp32).  UNETR++'s transformer block `t + gamma * epa(norm(t))` (layer scale gamma, the class comes
  * through mfai: py4cast/models.py:10-20, config/CLI/model/unetrpp.yaml:19-35): gamma rides in the output projections' weights, so the

@@ -93,6 +93,7 @@ SIGNATURES = {
     "p4c_upsample_bilinear_bwd": [P, P, I, I, I, I, I, P],
     "p4c_gemm_prep_weight": [P, I, I, I, P, P, P],
     "p4c_gemm_prep_weight_scaled": [P, P, P, P, I, I, I, P, P, P],
+    "p4c_gemm_prep_weight_batch": [I, P, P, P, P, P, P, P, P, P, P],
     "p4c_gemm_scale_fold_bwd": [P, P, P, P, P, I, I, P, P, P, I, P],
     "p4c_gemm_nt": [P, L, P, I, I, I, I, I, I, I, P, P, L, I, P, P, L, P, L, P, P, P],
     "p4c_gemm_tn": [P, L, P, L, I, I, I, I, I, I, P, P, I, P, P],

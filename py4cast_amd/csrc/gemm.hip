@@ -673,11 +673,10 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_batch_kernel(TnBatchArgs b
 // layout [CO][CI][taps]; one workgroup per 32 x 32 (co, ci) block, through LDS so that reads and writes are row pieces.
 // rowscale (CO floats or NULL): the images hold rowscale[co] * w[co] (fp32 product, one rounding) -- a per-output-channel scale of the
 // layer (UNETR++'s layer scale gamma) folded into its weight; bias_out[co] = rowscale[co] * bias[co] comes with it (block (0, y)).
-__global__ void __launch_bounds__(256) gemm_prep_kernel(const float* __restrict__ w, int CO, int CI, int taps, bf16* __restrict__ fwd,
-                                                        bf16* __restrict__ dgrad, const float* __restrict__ rowscale,
-                                                        const float* __restrict__ bias, float* __restrict__ bias_out) {
-    extern __shared__ float tilew[];          // [32 co][32 ci * taps + 1]
-    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+__device__ __forceinline__ void prep_block(const float* __restrict__ w, int CO, int CI, int taps, bf16* __restrict__ fwd,
+                                           bf16* __restrict__ dgrad, const float* __restrict__ rowscale, const float* __restrict__ bias,
+                                           float* __restrict__ bias_out, const int bx, const int by, float* __restrict__ tilew) {
+    const int co0 = by * 32, ci0 = bx * 32;
     const int rowlen = 32 * taps, ld = rowlen + 1;
     for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {
         const int c = idx / rowlen, e = idx - c * rowlen;            // e = ci_local * taps + tap
@@ -686,7 +685,7 @@ __global__ void __launch_bounds__(256) gemm_prep_kernel(const float* __restrict_
         if (rowscale && co0 + c < CO) v *= rowscale[co0 + c];
         tilew[c * ld + e] = v;
     }
-    if (bias_out && blockIdx.x == 0 && threadIdx.x < 32 && co0 + threadIdx.x < CO)
+    if (bias_out && bx == 0 && threadIdx.x < 32 && co0 + threadIdx.x < CO)
         bias_out[co0 + threadIdx.x] = (rowscale ? rowscale[co0 + threadIdx.x] : 1.f) * bias[co0 + threadIdx.x];
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {
@@ -701,6 +700,42 @@ __global__ void __launch_bounds__(256) gemm_prep_kernel(const float* __restrict_
                 dgrad[((int64_t)(ci0 + ci) * taps + t) * CO + co0 + c] = __float2bfloat16(tilew[c * ld + ci * taps + (taps - 1 - t)]);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) gemm_prep_kernel(const float* __restrict__ w, int CO, int CI, int taps, bf16* __restrict__ fwd,
+                                                        bf16* __restrict__ dgrad, const float* __restrict__ rowscale,
+                                                        const float* __restrict__ bias, float* __restrict__ bias_out) {
+    extern __shared__ float tilew[];          // [32 co][32 ci * taps + 1]
+    prep_block(w, CO, CI, taps, fwd, dgrad, rowscale, bias, bias_out, (int)blockIdx.x, (int)blockIdx.y, tilew);
+}
+
+// Round 6: the images of PREP_BATCH weights per launch (UNETR++ prepares 154 per optimizer step, SwinUNETR 54 -- a launch of ~12 us each
+// for a few hundred KB): block -> (job, block of the job's own (ci, co) grid) through a prefix table in the kernel arguments.
+constexpr int PREP_BATCH = 24;
+struct WPrepJob {
+    const float* w;
+    const float* rowscale;
+    const float* bias;
+    float* bias_out;
+    bf16* fwd;
+    bf16* dgrad;
+    int CO, CI, taps;
+};
+struct PrepBatchArgs {
+    WPrepJob job[PREP_BATCH];
+    int first[PREP_BATCH + 1];
+    int n;
+};
+static_assert(sizeof(PrepBatchArgs) <= 4000, "the job table travels in the kernel arguments");
+
+__global__ void __launch_bounds__(256) gemm_prep_batch_kernel(PrepBatchArgs b) {
+    extern __shared__ float tilew[];
+    int jb = 0;
+    while (jb + 1 < b.n && (int)blockIdx.x >= b.first[jb + 1]) ++jb;
+    const WPrepJob& J = b.job[jb];
+    const int local = (int)blockIdx.x - b.first[jb];
+    const int gx = (J.CI + 31) / 32;
+    prep_block(J.w, J.CO, J.CI, J.taps, J.fwd, J.dgrad, J.rowscale, J.bias, J.bias_out, local % gx, local / gx, tilew);
 }
 
 // batch-norm statistics from the producers' partial sums [nblk][2][C] (fp64 combine, fixed order): mean, rstd, scale = gamma rstd,
@@ -784,6 +819,41 @@ extern "C" int p4c_gemm_prep_weight_scaled(const float* w, const float* rowscale
 
 extern "C" int p4c_gemm_prep_weight(const float* w, int CO, int CI, int taps, void* fwd, void* dgrad, p4c_stream_t stream) {
     return p4c_gemm_prep_weight_scaled(w, nullptr, nullptr, nullptr, CO, CI, taps, fwd, dgrad, stream);
+}
+
+// n jobs given as parallel arrays (rowscale / bias / bias_out entries may be NULL; or the three arrays themselves): the same images as
+// n calls of p4c_gemm_prep_weight_scaled, PREP_BATCH jobs per launch
+extern "C" int p4c_gemm_prep_weight_batch(int n, const float* const* w, const float* const* rowscale, const float* const* bias,
+                                          float* const* bias_out, const int* CO, const int* CI, const int* taps, void* const* fwd,
+                                          void* const* dgrad, p4c_stream_t stream) {
+    P4C_CHECK_ARG(n > 0 && w && CO && CI && taps && fwd && dgrad, "p4c_gemm_prep_weight_batch: NULL pointer or no job");
+    hipStream_t st = as_stream(stream);
+    PrepBatchArgs b;
+    b.n = 0;
+    b.first[0] = 0;
+    int smem = 0;
+    auto launch = [&]() -> int {
+        hipLaunchKernelGGL(gemm_prep_batch_kernel, dim3(b.first[b.n]), dim3(256), smem, st, b);
+        P4C_CHECK_LAUNCH("gemm_prep_batch");
+        b.n = 0;
+        smem = 0;
+        return P4C_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        P4C_CHECK_ARG(w[i] && (fwd[i] || dgrad[i]) && CO[i] > 0 && CI[i] > 0 && (taps[i] == 1 || taps[i] == 9), "p4c_gemm_prep_weight_batch: job %d: bad arguments", i);
+        const float* rs = rowscale ? rowscale[i] : nullptr;
+        const float* bi = bias ? bias[i] : nullptr;
+        float* bo = bias_out ? bias_out[i] : nullptr;
+        P4C_CHECK_ARG((bi == nullptr) == (bo == nullptr), "p4c_gemm_prep_weight_batch: job %d: bias and bias_out come together", i);
+        if (b.n == PREP_BATCH) P4C_TRY(launch());
+        b.job[b.n] = WPrepJob{w[i], rs, bi, bo, (bf16*)fwd[i], (bf16*)dgrad[i], CO[i], CI[i], taps[i]};
+        b.first[b.n + 1] = b.first[b.n] + ((CI[i] + 31) / 32) * ((CO[i] + 31) / 32);
+        const int need = 32 * (32 * taps[i] + 1) * 4;
+        if (need > smem) smem = need;
+        ++b.n;
+    }
+    if (b.n) P4C_TRY(launch());
+    return P4C_OK;
 }
 
 // Backward of a layer whose weight and bias were scaled per output channel (z = x W^T + b, y = gamma (.) z): from the RAW gradients

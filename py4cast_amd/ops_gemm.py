@@ -26,6 +26,91 @@ ACT_NONE, ACT_GELU_FWD, ACT_GELU_BWD = 0, 1, 2
 _WIMG = {}   # eager mode: (address, shape, strides, taps) -> (parameter version, (fwd image, dgrad image), owners)
 
 
+# Round 6: the images of ALL weights a model used before are prepared at the first miss of a step (eager: after the optimizer moved the
+# parameters; a HIP-graph capture: at the first use inside it), 24 per launch (p4c_gemm_prep_weight_batch) -- one launch per weight before:
+# 154 per UNETR++ step, 54 per SwinUNETR step.  The log holds what was asked for (weak references to the parameters, in first-use order);
+# an entry is prepared again only when its cache entry is stale by the same test a single lookup applies.
+_PREP_LOG = {}        # cache key -> (weakref(w), taps, None | (weakref(scale parameter), first, length), None | weakref(b) | False)
+BATCHED_PREP = True
+
+
+def _whole_parameter(t: torch.Tensor):
+    """the parameter behind t when t IS that parameter (or a rollout's stand-in of it), else None (slices are prepared one by one)"""
+    base = L._base(t)
+    if base.data_ptr() == t.data_ptr() and base.shape == t.shape and base.stride() == t.stride() and base.dtype == t.dtype:
+        return base
+    return None
+
+
+def _plain_key(w, taps):
+    return ("wimg", w.data_ptr(), tuple(w.shape), tuple(w.stride()), taps)
+
+
+def _scaled_key(w, b, g):
+    return ("wimg_scaled", w.data_ptr(), tuple(w.shape), tuple(w.stride()), g.data_ptr(), None if b is None else b.data_ptr())
+
+
+def _fresh(cache, key, ver, owners) -> bool:
+    hit = cache.get(key)
+    return hit is not None and hit[0] == ver and L.owners_alive(hit[2], owners)
+
+
+def _prepare_logged(cache, device) -> None:
+    """prepare the images of every logged weight whose entry in ``cache`` is stale: one launch per 24 jobs"""
+    import ctypes
+
+    jobs, dead = [], []
+    for key, (rw, taps, rg, rb) in _PREP_LOG.items():
+        w = rw()
+        scaled = rg is not None
+        g = b = None
+        gone = w is None
+        if scaled and not gone:
+            gbase = rg[0]()                       # (the scale is a run of a 1-D parameter: base, first element, length)
+            gone = gbase is None
+            if not gone:
+                with torch.no_grad():
+                    g = gbase[rg[1]: rg[1] + rg[2]]          # (a view OF THE PARAMETER: the cache's owner test sees what a caller's slice shows)
+            if rb is not False and not gone:
+                b = rb()
+                gone = b is None
+        if gone:
+            dead.append(key)
+            continue
+        if w.device != device:
+            continue
+        if (key != (_scaled_key(w, b, g) if scaled else _plain_key(w, taps))) or w.dtype != torch.float32 or not w.is_contiguous():
+            dead.append(key)          # the parameter moved (another storage / layout): it is logged again under its new key when used
+            continue
+        if scaled:
+            ver = (L.PARAM_EPOCH[0], w._version, g._version, None if b is None else b._version)
+            owners = (w, g) if b is None else (w, g, b)
+        else:
+            ver, owners = (L.PARAM_EPOCH[0], w._version), (w,)
+        if _fresh(cache, key, ver, owners):
+            continue
+        CO, CI = w.shape[0], w.shape[1]
+        fwd = torch.empty(CO, taps * CI, dtype=torch.bfloat16, device=device)
+        dgr = torch.empty(CI, taps * CO, dtype=torch.bfloat16, device=device)
+        beff = torch.empty(CO, dtype=torch.float32, device=device) if (scaled and b is not None) else None
+        jobs.append((key, ver, owners, w.detach(), None if g is None else g.detach(), None if b is None else b.detach(), beff, CO, CI, taps, fwd, dgr,
+                     scaled))
+    for key in dead:
+        del _PREP_LOG[key]
+    if not jobs:
+        return
+    n = len(jobs)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    ptr = lambda t: None if t is None else t.data_ptr()     # noqa: E731
+    L.call("p4c_gemm_prep_weight_batch", n, PA(*[ptr(j[3]) for j in jobs]), PA(*[ptr(j[4]) for j in jobs]), PA(*[ptr(j[5]) for j in jobs]),
+           PA(*[ptr(j[6]) for j in jobs]), IA(*[j[7] for j in jobs]), IA(*[j[8] for j in jobs]), IA(*[j[9] for j in jobs]),
+           PA(*[ptr(j[10]) for j in jobs]), PA(*[ptr(j[11]) for j in jobs]), L.stream(device))
+    for key, ver, owners, _w, _g, _b, beff, _co, _ci, _taps, fwd, dgr, scaled in jobs:
+        refs = L.owner_refs(owners)
+        assert L.owners_alive(refs, owners)
+        cache[key] = (ver, (fwd, dgr, beff) if scaled else (fwd, dgr), refs)
+
+
 def weight_images(w: torch.Tensor, taps: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """bf16 operand images of an fp32 master weight (CO, CI[, 3, 3]): ([CO][taps][CI], [CI][taps'][CO]); once per parameter version
     in eager mode and once per HIP-graph capture (the AR steps of a rollout share them)."""
@@ -36,13 +121,22 @@ def weight_images(w: torch.Tensor, taps: int) -> Tuple[torch.Tensor, torch.Tenso
     if not wd.is_contiguous():
         wd = wd.contiguous()
     CO, CI = wd.shape[0], wd.shape[1]
-    key = ("wimg", w.data_ptr(), tuple(w.shape), tuple(w.stride()), taps)
+    key = _plain_key(w, taps)
     ver = (L.PARAM_EPOCH[0], w._version)
     cache = _WIMG if not torch.cuda.is_current_stream_capturing() else L.capture_cache()
     if cache is not None:
-        hit = cache.get(key)
-        if hit is not None and hit[0] == ver and L.owners_alive(hit[2], (w,)):
-            return hit[1]
+        if _fresh(cache, key, ver, (w,)):
+            return cache[key][1]
+        if BATCHED_PREP and w.is_contiguous():
+            import weakref
+
+            base = _whole_parameter(w)
+            if base is not None:
+                if key not in _PREP_LOG:
+                    _PREP_LOG[key] = (weakref.ref(base), taps, None, None)
+                _prepare_logged(cache, w.device)
+                if _fresh(cache, key, ver, (w,)):
+                    return cache[key][1]
     fwd = torch.empty(CO, taps * CI, dtype=torch.bfloat16, device=w.device)
     dgr = torch.empty(CI, taps * CO, dtype=torch.bfloat16, device=w.device)
     L.call("p4c_gemm_prep_weight", L.ptr(wd), CO, CI, taps, L.ptr(fwd), L.ptr(dgr), L.stream(w.device))
@@ -60,14 +154,26 @@ def scaled_images(w: torch.Tensor, b: Optional[torch.Tensor], g: torch.Tensor):
     wd, gd = w.detach().contiguous(), g.detach().contiguous()
     bd = None if b is None else b.detach().contiguous()
     CO, CI = wd.shape
-    key = ("wimg_scaled", w.data_ptr(), tuple(w.shape), tuple(w.stride()), g.data_ptr(), None if b is None else b.data_ptr())
+    key = _scaled_key(w, b, g)
     ver = (L.PARAM_EPOCH[0], w._version, g._version, None if b is None else b._version)
     owners = (w, g) if b is None else (w, g, b)
     cache = _WIMG if not torch.cuda.is_current_stream_capturing() else L.capture_cache()
     if cache is not None:
-        hit = cache.get(key)
-        if hit is not None and hit[0] == ver and L.owners_alive(hit[2], owners):
-            return hit[1]
+        if _fresh(cache, key, ver, owners):
+            return cache[key][1]
+        if BATCHED_PREP and w.is_contiguous() and g.is_contiguous() and (b is None or b.is_contiguous()):
+            import weakref
+
+            # (g is a run of the 1-D layer-scale parameter, w and b whole parameters -- or a rollout's stand-ins of them)
+            bw, gb = _whole_parameter(w), L._base(g)
+            bb = None if b is None else _whole_parameter(b)
+            if bw is not None and g.dim() == 1 and gb.dim() == 1 and gb.is_contiguous() and (b is None or bb is not None):
+                if key not in _PREP_LOG:
+                    _PREP_LOG[key] = (weakref.ref(bw), 1, (weakref.ref(gb), g.storage_offset() - gb.storage_offset(), g.numel()),
+                                      False if b is None else weakref.ref(bb))
+                _prepare_logged(cache, w.device)
+                if _fresh(cache, key, ver, owners):
+                    return cache[key][1]
     fwd = torch.empty(CO, CI, dtype=torch.bfloat16, device=w.device)
     dgr = torch.empty(CI, CO, dtype=torch.bfloat16, device=w.device)
     beff = None if b is None else torch.empty(CO, dtype=torch.float32, device=w.device)

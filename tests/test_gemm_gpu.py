@@ -331,6 +331,62 @@ def test_accumulating_weight_gradients_are_reduced_in_batches_at_the_end_of_the_
         assert torch.equal(a, b)
 
 
+def test_all_stale_weight_images_are_prepared_by_the_first_miss_of_a_step(gpu_device):
+    """Round 6: the first lookup that misses prepares the images of every weight used before whose cache entry is stale, 24 per launch
+    (p4c_gemm_prep_weight_batch) -- the same bits as one preparation per weight, for plain and layer-scaled weights, and the later
+    lookups of the step launch nothing."""
+    from py4cast_amd import _lib as L
+    from py4cast_amd import ops_gemm as G
+
+    dev = gpu_device
+    torch.manual_seed(81)
+    ws = [torch.nn.Parameter(rnd(shape, dev, 82 + i)) for i, shape in enumerate([(64, 32, 3, 3), (128, 64), (96, 96, 3, 3), (40, 72), (256, 128)])]
+    taps = [9, 1, 9, 1, 1]
+    gamma = torch.nn.Parameter(1 + 0.1 * rnd((256 + 128,), dev, 90))
+    sw = [torch.nn.Parameter(rnd((256, 64), dev, 91)), torch.nn.Parameter(rnd((128, 64), dev, 92))]
+    sb = [torch.nn.Parameter(rnd((256,), dev, 93)), None]
+    sg = lambda: (gamma[:256], gamma[256:])     # noqa: E731   (fresh slices every time, as the model makes them)
+
+    def lookup_all():
+        out = [G.weight_images(w, t) for w, t in zip(ws, taps)]
+        out += [G.scaled_images(w, b, g) for w, b, g in zip(sw, sb, sg())]
+        return out
+
+    G._WIMG.clear()
+    G._PREP_LOG.clear()
+    lookup_all()                                               # first use: logged (and prepared)
+    assert len(G._PREP_LOG) == len(ws) + len(sw)
+    with torch.no_grad():                                      # "the optimizer moved the parameters"
+        for p in ws + sw + [gamma, sb[0]]:
+            p.mul_(1.01)
+    calls = []
+    real = L.call
+    L.call = lambda name, *a, **k: (calls.append(name), real(name, *a, **k))[1]
+    try:
+        batched = lookup_all()
+    finally:
+        L.call = real
+    assert [c for c in calls if "prep" in c] == ["p4c_gemm_prep_weight_batch"], calls      # ONE launch request for all seven
+    G.BATCHED_PREP = False
+    try:
+        G._WIMG.clear()
+        single = lookup_all()
+    finally:
+        G.BATCHED_PREP = True
+    for a, b in zip(batched, single):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or torch.equal(x, y)
+    del ws[2]                                                  # a weight that is gone leaves the log at the next miss
+    with torch.no_grad():
+        ws[0].mul_(1.01)
+    import gc
+
+    gc.collect()
+    G.weight_images(ws[0], 9)
+    assert len(G._PREP_LOG) == len(ws) + len(sw)
+
+
 def test_weight_images_follow_the_parameter_version(gpu_device):
     from py4cast_amd import ops_gemm as G
 
