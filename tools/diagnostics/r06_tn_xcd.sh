@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the kernel-side experiment is NOT in the tree: tools/diagnostics/patches/r06_tn_xcd.patch; apply it, build, then gemm_build.sh tn_noxcd -DP4C_TN_XCD=0)
 # round 6: gemm_tn, the nine tap tiles of a unit on one XCD (default) against tile = blockIdx.x (lib_gemm_tn_noxcd.so, -DP4C_TN_XCD=0)
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-/root/repo}
